@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE'S OWN CODE.
+
+Build-container only (needs /root/reference).  Run as:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's files unmodified (gat_skip.py, baseline_and_test_models/lcgn.py,
+pipeline_model_{gine,gcn}.py's *_seq classes) on top of `oracle/pyg_shim` (a pure-torch
+restatement of the absent third-party packages, see its README), loads deterministic
+parameters from `graphvqa_amd.synth` (pure functions of integer seeds, so multi-MB weights
+are never stored), runs the reference forward on CPU in fp32 and stores plain arrays:
+inputs that are cheap to store, every output needed for parity, and the seeds/dims.
+
+Nothing from /root/reference (source, bytecode, pickled classes) is written into the repo;
+the .npz files hold arrays and a JSON metadata string only.
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(ROOT, "oracle", "pyg_shim"), REF,
+                os.path.join(REF, "baseline_and_test_models"), ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from graphvqa_amd import synth  # noqa: E402
+from graphvqa_amd.scene_graph import scene_graph_topology, batch_scene_graphs  # noqa: E402
+
+torch.set_num_threads(1)  # fixed reduction order inside BLAS for reproducible fixtures
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def load_params(module, params):
+    sd = {k: t(v) for k, v in params.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return module.eval()
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    arrays = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+              for k, v in arrays.items()}
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  " +
+          " ".join(f"{k}{list(v.shape)}" for k, v in arrays.items()))
+
+
+def stub_dataset_entry():
+    """`pipeline_model_*.py` import `gqa_dataset_entry` for vocab sizes only; the real module needs
+    torchtext/spaCy/GloVe (absent).  A stub with a fake vocabulary is enough to import the
+    files that define gine_seq / gcn_seq."""
+    import types
+
+    class _Vocab:
+        def __init__(self, n):
+            self.itos = [f"w{i}" for i in range(n)]
+            self.stoi = {w: i for i, w in enumerate(self.itos)}
+            self.vectors = torch.zeros(n, 300)
+
+    class _Field:
+        def __init__(self, n):
+            self.vocab = _Vocab(n)
+            self.pad_token, self.init_token, self.eos_token = "w0", "w1", "w2"
+
+    m = types.ModuleType("gqa_dataset_entry")
+
+    class GQATorchDataset:
+        MAX_EXECUTION_STEP = 5
+        TEXT = _Field(50)
+
+    class GQA_gt_sg_feature_lookup:
+        SG_ENCODING_TEXT = _Field(50)
+
+    m.GQATorchDataset = GQATorchDataset
+    m.GQA_gt_sg_feature_lookup = GQA_gt_sg_feature_lookup
+    sys.modules["gqa_dataset_entry"] = m
+    c = types.ModuleType("Constants")
+    sys.modules.setdefault("Constants", c)
+
+
+def small_multigraph(seed, n=10, e=37):
+    """Random multigraph incl. duplicate edges, a self-loop-free node and a node with no in-edge."""
+    src = synth.randint(e, seed, 0, n, stream=7)
+    dst = synth.randint(e, seed, 0, n - 1, stream=8)       # node n-1 never a destination
+    return np.stack([src, dst]).astype(np.int64)
+
+
+def debug_graphs():
+    sgs = json.load(open(os.path.join(REF, "debug_sceneGraphs.json")))
+    return sgs
+
+
+# ----------------------------------------------------------------------------
+def gen_gat():
+    import gat_skip
+
+    # A. single conv, tiny dims, arbitrary multigraph (no batch structure)
+    in_c, C, e_in, H = 24, 8, 20, 4
+    ei = small_multigraph(11)
+    N, E = 10, ei.shape[1]
+    p = synth.gat_seq_params(in_c - 4, C, e_in - 4, 4, 1, H, seed=101)   # convs.0.* with in=24/e_in=20
+    conv = gat_skip.gat(in_channels=in_c, out_channels=C, edge_in_channels=e_in, heads=H,
+                        concat=False, negative_slope=0.2, dropout=0.0, bias=True)
+    load_params(conv, {k[len("convs.0."):]: v for k, v in p.items() if k.startswith("convs.0.")})
+    x = synth.normal((N, in_c), 12)
+    ea = synth.normal((E, e_in), 13)
+    with torch.no_grad():
+        out, (_, alpha) = conv(t(x), t(ei), t(ea), return_attention_weights=True)
+    save("gat_conv_small", dict(case="gat.forward", ref="gat_skip.py:111-177", in_channels=in_c,
+                                out_channels=C, edge_in=e_in, heads=H, param_seed=101,
+                                param_fn="gat_seq_params(20,8,16,4,1,4)"),
+         x=x, edge_index=ei, edge_attr=ea, out=out, alpha=alpha)
+
+    # B. gat_seq small dims, 8 ragged graphs (incl. 1-node graphs)
+    dn, de, di, K = 32, 24, 16, 5
+    gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=202)
+    m = gat_skip.gat_seq(dn, dn, de, di, K, dropout=0.1, gat_heads=H)
+    load_params(m, p)
+    x, ea, ins = synth.normal((N, dn), 22), synth.normal((E, de), 23), synth.normal((K, B, di), 24)
+    hs, alphas = run_gat_seq_with_taps(m, x, gb, ea, ins)
+    save("gat_seq_small", dict(case="gat_seq.forward eval", ref="gat_skip.py:249-279", dn=dn, de=de,
+                               di=di, K=K, heads=H, param_seed=202, graph="make_graph_batch(8,21,1,12,1.5)"),
+         x=x, edge_index=gb.edge_index, batch=gb.batch, edge_attr=ea, instr=ins,
+         out=hs[-1], hs=np.stack(hs), alphas=np.stack(alphas))
+
+    # C. train-mode BatchNorm (batch statistics), dropout p=0 -> deterministic
+    m2 = gat_skip.gat_seq(dn, dn, de, di, K, dropout=0.0, gat_heads=H)
+    load_params(m2, p)
+    m2.train()
+    with torch.no_grad():
+        out_tr = m2(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch))
+    rm = np.stack([m2.bns[j].running_mean.numpy() for j in range(K - 1)])
+    rv = np.stack([m2.bns[j].running_var.numpy() for j in range(K - 1)])
+    save("gat_seq_small_trainbn", dict(case="gat_seq.forward train, dropout=0", ref="gat_skip.py:273-276",
+                                       dn=dn, de=de, di=di, K=K, heads=H, param_seed=202,
+                                       inputs="gat_seq_small.npz"),
+         out=out_tr, running_mean_after=rm, running_var_after=rv)
+
+    # D. real model dims (pipeline_model_gat.py:683-687) on the reference's debug scene graphs
+    sgs = debug_graphs()
+    p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303)
+    m = gat_skip.gat_seq(in_channels=300, out_channels=300, edge_attr_dim=300, ins_dim=512,
+                         num_ins=5, dropout=0.1, gat_heads=4, gat_negative_slope=0.2, gat_bias=True)
+    load_params(m, p)
+    for name, ids in (("gat_seq_debug2_d300", ["2354786", "2375429"]),
+                      ("gat_seq_debug4_d300", list(sgs.keys()))):
+        gb = batch_scene_graphs([sgs[i] for i in ids])
+        N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+        x, ea = synth.normal((N, 300), 31), synth.normal((E, 300), 32)
+        ins = synth.normal((5, B, 512), 33)
+        hs, alphas = run_gat_seq_with_taps(m, x, gb, ea, ins)
+        save(name, dict(case="gat_seq.forward eval, real dims", ref="pipeline_model_gat.py:683-687,791",
+                        dn=300, de=300, di=512, K=5, heads=4, param_seed=303, image_ids=ids,
+                        input_seeds=dict(x=31, edge_attr=32, instr=33)),
+             edge_index=gb.edge_index, batch=gb.batch, out=hs[-1], hs=np.stack(hs),
+             alpha0=alphas[0], alpha4=alphas[4])
+
+    # E. topology of the four debug graphs (pins the JSON->COO builder)
+    arrs, meta = {}, {}
+    for k, sg in sgs.items():
+        n, ei, added = scene_graph_topology(sg)
+        arrs[f"ei_{k}"], arrs[f"added_{k}"] = ei, added
+        meta[k] = [n, int(ei.shape[1])]
+    save("debug_topology", dict(case="convert_one_gqa_scene_graph topology", n_e=meta,
+                                ref="gqa_dataset_entry.py:231-332",
+                                note="(N,E) cross-checked against SURVEY 8c: (21,85),(12,40),(20,107),(6,23)"),
+         **arrs)
+
+
+def run_gat_seq_with_taps(m, x, gb, ea, ins):
+    """Run the reference gat_seq and tap per-hop h (input of the next conv / final) and alpha."""
+    hs, alphas = [], []
+    K = len(m.convs)
+    # re-run each conv with return_attention_weights on the same inputs, and check the loop
+    # reproduces the module's own forward bit-for-bit
+    with torch.no_grad():
+        h = t(x)
+        edge_index, batch = t(gb.edge_index), t(gb.batch)
+        tea, tins = t(ea), t(ins)
+        out_ref = m(h, edge_index, tea, tins, batch)
+        for i in range(K):
+            ins_i = tins[i]
+            edge_cat = torch.cat((tea, ins_i[batch[edge_index[0]]]), dim=-1)
+            x_cat = torch.cat((h, ins_i[batch]), dim=-1)
+            conv_res, (_, alpha) = m.convs[i](x=x_cat, edge_index=edge_index, edge_attr=edge_cat,
+                                              return_attention_weights=True)
+            h = conv_res + h
+            if i != K - 1:
+                h = torch.relu(m.bns[i](h))
+            hs.append(h.numpy().copy())
+            alphas.append(alpha.numpy().copy())
+        assert torch.equal(h, out_ref), "tap loop must reproduce gat_seq.forward bit-for-bit"
+    return hs, alphas
+
+
+def gen_gine_gcn():
+    stub_dataset_entry()
+    import pipeline_model_gine
+    import pipeline_model_gcn
+
+    dn, di, K = 32, 16, 5
+    gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    x, ins = synth.normal((N, dn), 22), synth.normal((K, B, di), 24)
+    ea = synth.normal((E, dn), 25)                      # GINE needs dim(edge_attr)+ins == dim(x)+ins
+    ei, batch = t(gb.edge_index), t(gb.batch)
+
+    for name, mod, pfn, seed in (("gine", pipeline_model_gine.gine_seq, synth.gine_seq_params, 404),
+                                 ("gcn", pipeline_model_gcn.gcn_seq, synth.gcn_seq_params, 505)):
+        m = mod(dn, dn, di, dropout=0.1)
+        p = pfn(dn, dn, di, seed)
+        load_params(m, p)
+        convs = []
+        hk = [c.register_forward_hook(lambda mod_, a, o: convs.append(o.detach().numpy().copy()))
+              for c in m.convs]
+        with torch.no_grad():
+            if name == "gine":
+                out = m(t(x), ei, t(ea), t(ins), batch)
+            else:
+                out = m(t(x), ei, t(ins), batch)
+        for h_ in hk:
+            h_.remove()
+        arrays = dict(x=x, edge_index=gb.edge_index, batch=gb.batch, instr=ins, out=out,
+                      convs=np.stack(convs))
+        if name == "gine":
+            arrays["edge_attr"] = ea
+        save(f"{name}_seq_small",
+             dict(case=f"{name}_seq.forward eval (module output discards conv_res; convs = tapped "
+                       f"per-hop conv outputs)", ref=f"pipeline_model_{name}.py:622-674", dn=dn, di=di,
+                  K=K, param_seed=seed, graph="make_graph_batch(8,21,1,12,1.5)"), **arrays)
+
+    # GCN on an arbitrary multigraph with duplicate self-loops and a node lacking one
+    import torch_geometric
+    ei2 = small_multigraph(11)
+    ei2 = np.concatenate([ei2, np.array([[2, 2, 5], [2, 2, 5]])], axis=1)   # duplicate self loops
+    conv = torch_geometric.nn.GCNConv(24, 8)
+    p = synth.gcn_seq_params(20, 8, 4, 606, num_layers=1)
+    load_params(conv, {"weight": p["convs.0.weight"], "bias": p["convs.0.bias"]})
+    x2 = synth.normal((10, 24), 12)
+    with torch.no_grad():
+        o2 = conv(t(x2), t(ei2))
+    save("gcn_conv_small", dict(case="GCNConv (shim of PyG 1.6/1.7) multigraph + dup self-loops",
+                                in_channels=24, out_channels=8, param_seed=606,
+                                param_fn="gcn_seq_params(20,8,4,606,num_layers=1)"),
+         x=x2, edge_index=ei2, out=o2)
+
+
+def gen_lcgn():
+    import lcgn
+
+    for name, in_c, O, L, graphs in (("lcgn_seq_small", 20, 32, 6, None),
+                                     ("lcgn_seq_debug4_d512", 300, 512, 10, "debug")):
+        if graphs is None:
+            gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
+        else:
+            sgs = debug_graphs()
+            gb = batch_scene_graphs(list(sgs.values()))
+        N, B = gb.num_nodes, gb.num_graphs
+        m = lcgn.lcgn_seq(in_channels=in_c, out_channels=O, edge_attr_dim=in_c, num_ins=5,
+                          gat_cmd_dim=O, question_dim=O, MAX_ITER_NUM=4, dropout=0.1, gat_heads=1)
+        p = synth.lcgn_seq_params(in_c, O, seed=707, cmd_dim=O, question_dim=O)
+        load_params(m, p)
+        x = synth.normal((N, in_c), 41)
+        q = synth.normal((B, O), 42)
+        lstm = synth.normal((L, B, O), 43)
+        torch.manual_seed(1234)
+        x_ctx_init = torch.randn(N, O)                 # the draw lcgn.py:306 will make
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            out = m(t(x), t(gb.edge_index), t(gb.batch), t(q), t(lstm))
+        save(name, dict(case="lcgn_seq.forward eval", ref="lcgn.py:303-323", in_channels=in_c,
+                        out_channels=O, L=L, param_seed=707, torch_seed=1234,
+                        input_seeds=dict(x=41, q=42, lstm=43)),
+             edge_index=gb.edge_index, batch=gb.batch, x_ctx_init=x_ctx_init, out=out)
+
+
+if __name__ == "__main__":
+    gen_gat()
+    gen_gine_gcn()
+    gen_lcgn()
