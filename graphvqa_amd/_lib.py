@@ -1,0 +1,127 @@
+"""ctypes binding of libgvqa_hip.so (C ABI declared in include/gvqa.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, importing
+an operator raises `GvqaLibraryError` with the build command.  (The CPU oracle under oracle/ is
+test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgvqa_hip.so")
+
+GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other")
+NUM_STAGES = len(STAGES)
+
+
+class GvqaLibraryError(RuntimeError):
+    pass
+
+
+class GvqaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gvqa error {code}: {msg}")
+        self.code = code
+
+
+class GvqaUnsupported(GvqaError):
+    pass
+
+
+class Graph(C.Structure):
+    """Mirror of `struct gvqa_graph`."""
+    _fields_ = [("num_nodes", C.c_int64), ("num_edges", C.c_int64), ("num_graphs", C.c_int64),
+                ("rowptr", C.c_void_p), ("csr_src", C.c_void_p), ("csr_eid", C.c_void_p),
+                ("node_graph", C.c_void_p), ("graph_ptr", C.c_void_p), ("stats_dev", C.c_void_p),
+                ("max_graph_nodes", C.c_int32), ("max_graph_edges", C.c_int32),
+                ("max_in_degree", C.c_int32), ("intra_graph", C.c_int32), ("valid", C.c_int32),
+                ("finalized", C.c_int32)]
+
+
+class GatConvParams(C.Structure):
+    """Mirror of `struct gvqa_gat_conv_params` (device pointers)."""
+    _fields_ = [(n, C.c_void_p) for n in
+                ("lin_l_weight", "lin_e_weight", "att_l", "att_r", "att_e", "bias",
+                 "bn_weight", "bn_bias", "bn_mean", "bn_var")]
+
+
+class GatDims(C.Structure):
+    _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
+                ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
+                ("negative_slope", C.c_float), ("bn_eps", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/gvqa.h declares
+PROTOTYPES = {
+    "gvqa_last_error": (C.c_char_p, []),
+    "gvqa_version": (C.c_char_p, []),
+    "gvqa_graph_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "gvqa_graph_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.POINTER(Graph)]),
+    "gvqa_graph_finalize": (C.c_int, [C.POINTER(Graph), C.c_void_p]),
+    "gvqa_gat_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(GatDims)]),
+    "gvqa_gat_conv_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]),
+    "gvqa_gat_seq_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(GatDims)]),
+    "gvqa_gat_seq_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_linear_f32": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_gat_message_passing": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.POINTER(GatConvParams), C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_prof_enable": (C.c_int, [C.c_int]),
+    "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raises GvqaLibraryError if it is missing or not loadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GvqaLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -m graphvqa_amd.build` (needs hipcc; "
+            "cross-compiles for gfx950 without a GPU). There is no CPU fallback for this path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64, wrong arch ...
+        raise GvqaLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GvqaLibraryError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc == GVQA_OK:
+        return
+    msg = load().gvqa_last_error().decode("utf-8", "replace")
+    if rc == E_UNSUPPORTED:
+        raise GvqaUnsupported(rc, msg)
+    raise GvqaError(rc, msg)
+
+
+def prof_enable(on: bool):
+    check(load().gvqa_prof_enable(1 if on else 0))
+
+
+def prof_collect():
+    """Returns {stage: (milliseconds, launches)} accumulated since the last collect."""
+    ms = (C.c_double * NUM_STAGES)()
+    cnt = (C.c_int64 * NUM_STAGES)()
+    check(load().gvqa_prof_collect(ms, cnt))
+    return {STAGES[i]: (ms[i], cnt[i]) for i in range(NUM_STAGES)}

@@ -1,0 +1,68 @@
+// Internal helpers shared by the HIP translation units of libgvqa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gvqa.h"
+
+namespace gvqa {
+
+void set_error(const char* fmt, ...);
+
+#define GVQA_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::gvqa::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                              __FILE__, __LINE__);                                        \
+            return GVQA_E_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define GVQA_REQUIRE(cond, code, ...)          \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::gvqa::set_error(__VA_ARGS__);    \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+// launch-error check without synchronising
+#define GVQA_LAUNCH_CHECK() GVQA_HIP_CHECK(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bump allocator over a caller-provided workspace; 256-byte aligned slices.
+struct Carver {
+    char* base;
+    size_t cap, off;
+    Carver(void* p, size_t n) : base(static_cast<char*>(p)), cap(n), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T), 256);
+        T* r = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+// Stage timing (gvqa_prof_*): RAII bracket recording two events on the stream when enabled.
+struct StageTimer {
+    int stage;
+    hipStream_t stream;
+    void* slot;
+    StageTimer(int stage, hipStream_t s);
+    ~StageTimer();
+};
+
+// GEMM entry used by the orchestration code (defined in gemm.hip).
+// C[M,N] = A[M,K] . B[N,K]^T (+bias) (relu);  batched over blockIdx.z with element strides.
+int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                  int64_t ldb, const float* bias, int relu, float* C, int64_t ldc, int batch,
+                  int64_t strideA, int64_t strideB, int64_t strideC, hipStream_t stream);
+
+}  // namespace gvqa

@@ -1,0 +1,618 @@
+// GAT execution path for gfx950: weight folding, the fused message-passing kernels and the
+// K-hop driver behind gvqa_gat_conv_forward / gvqa_gat_seq_forward.
+//
+// Reference being replaced: gat_skip.py:111-208 (gat.forward + message, aggregated by PyG's
+// MessagePassing.propagate / torch_scatter) and gat_skip.py:249-279 (gat_seq.forward).
+//
+// What is restructured relative to the reference (same math, fp32, re-associated sums):
+//   * a_l/a_r/a_e (gat_skip.py:134-135,150-151) are dot products of a projection with a fixed
+//     attention vector, i.e. x . (W^T att).  The folded vectors V = W^T att are computed once
+//     per forward from the weights (k_fold_*), which turns the E x (De+Di) x H*C edge GEMM
+//     (two thirds of the reference's FLOPs, its result is used for nothing else) into an
+//     E x De x H mat-vec, done for all K hops in ONE pass over edge_attr.
+//   * the [h || ins[batch]] / [edge_attr || ins[batch[src]]] concatenations (gat_skip.py:256-264)
+//     are never materialised: W = [W_h | W_ins] splits the projection into a per-node part and
+//     a per-GRAPH part.  Because softmax weights sum to one per destination and edges never
+//     leave their graph, the per-graph part passes through the aggregation unchanged and
+//     reduces to one [B, C] row (mean over heads) plus one logit offset per (graph, head).
+//   * gather (K4), logits (K5), segment softmax (K6), weighted scatter-add (K8), head mean +
+//     bias (K9), skip + BatchNorm(eval) + ReLU (K11) are ONE kernel per hop; nothing of size
+//     E x H x C ever reaches HBM (the reference writes and re-reads it three times).
+#include "common.h"
+
+namespace gvqa {
+
+constexpr int MAX_HOPS = 8;
+
+// ==============================================================================================
+// Weight folding
+// ==============================================================================================
+struct FoldArgs {
+    const float* W_l[MAX_HOPS];
+    const float* W_e[MAX_HOPS];
+    const float* att_l[MAX_HOPS];
+    const float* att_r[MAX_HOPS];
+    const float* att_e[MAX_HOPS];
+    float* Vn;    // [K][2H][Dn]
+    float* Ve;    // [K*H][De]
+    float* Gw;    // [K][C+H][Di]   (rows C.. : logit offsets)   may be NULL when Di == 0
+    int Dn, De, Di, C, H, K;
+};
+
+// out[h, k] = sum_c W[(h*C + c), koff + k] * att[h*C + c]      (V = W^T att, per head)
+// grid: (ceil(maxK/64), H, K*4): z = hop*4 + which; which 0: V_l -> Vn rows [0,H); 1: V_r -> Vn rows
+// [H,2H); 2: V_e -> Ve; 3: instruction-column part of (V_l + V_r + V_e) -> Gw rows C + h.
+__global__ __launch_bounds__(256) void k_fold_att(FoldArgs a) {
+    __shared__ float red[4][64];
+    const int hop = blockIdx.z >> 2, which = blockIdx.z & 3, h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const int ldl = a.Dn + a.Di, lde = a.De + a.Di;
+    int nk;
+    if (which < 2) nk = a.Dn; else if (which == 2) nk = a.De; else nk = a.Di;
+    if (blockIdx.x * 64 >= nk) return;
+    // the C-range is split over the 4 waves, partial sums combined in a fixed order
+    const int cpw = (a.C + 3) / 4, c_lo = wave * cpw, c_hi = min(a.C, c_lo + cpw);
+    float acc = 0.f;
+    if (k < nk) {
+        if (which < 2) {
+            const float* W = a.W_l[hop];
+            const float* att = which == 0 ? a.att_l[hop] : a.att_r[hop];
+            for (int c = c_lo; c < c_hi; ++c) acc += W[(int64_t)(h * a.C + c) * ldl + k] * att[h * a.C + c];
+        } else if (which == 2) {
+            const float* W = a.W_e[hop];
+            const float* att = a.att_e[hop];
+            for (int c = c_lo; c < c_hi; ++c) acc += W[(int64_t)(h * a.C + c) * lde + k] * att[h * a.C + c];
+        } else {
+            const float* Wl = a.W_l[hop];
+            const float* We = a.W_e[hop];
+            for (int c = c_lo; c < c_hi; ++c) {
+                const int r = h * a.C + c;
+                const float wl = Wl[(int64_t)r * ldl + a.Dn + k];
+                acc += wl * a.att_l[hop][r] + wl * a.att_r[hop][r] + We[(int64_t)r * lde + a.De + k] * a.att_e[hop][r];
+            }
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && k < nk) {
+        float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (which == 0) a.Vn[((int64_t)hop * 2 * a.H + h) * a.Dn + k] = s;
+        else if (which == 1) a.Vn[((int64_t)hop * 2 * a.H + a.H + h) * a.Dn + k] = s;
+        else if (which == 2) a.Ve[((int64_t)hop * a.H + h) * a.De + k] = s;
+        else a.Gw[((int64_t)hop * (a.C + a.H) + a.C + h) * a.Di + k] = s;
+    }
+}
+
+// Gw[hop][c, k] = (1/H) sum_h W_l[h*C + c, Dn + k]     (head-mean of the instruction columns)
+__global__ __launch_bounds__(256) void k_fold_headmean(FoldArgs a) {
+    const int hop = blockIdx.z;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.C * a.Di) return;
+    const int c = (int)(idx / a.Di), k = (int)(idx - (int64_t)c * a.Di);
+    const int ldl = a.Dn + a.Di;
+    const float* W = a.W_l[hop];
+    float s = 0.f;
+    for (int h = 0; h < a.H; ++h) s += W[(int64_t)(h * a.C + c) * ldl + a.Dn + k];
+    a.Gw[((int64_t)hop * (a.C + a.H) + c) * a.Di + k] = s * (1.0f / a.H);
+}
+
+// ==============================================================================================
+// Fused message passing
+// ==============================================================================================
+struct MpArgs {
+    const int32_t* rowptr;
+    const int32_t* csr_src;
+    const int32_t* csr_eid;
+    const int32_t* node_graph;
+    const int32_t* graph_ptr;
+    const float* xp;        // [N, H*C]
+    const float* a_node;    // [N, 2H]
+    const float* a_edge;    // COO-indexed: a_edge[eid * a_edge_stride + h]
+    int64_t a_edge_stride;
+    const float* graph_term;  // NULL or [B, t_ld]: columns [0,C) head-mean instruction term, [C,C+H) logit offset
+    int64_t t_ld;
+    const float* skip;        // NULL or [N, C]
+    const float* bias;        // NULL or [C]
+    const float* bn_w;        // all four NULL = no BN / ReLU
+    const float* bn_b;
+    const float* bn_m;
+    const float* bn_v;
+    float* out;               // [N, C]
+    float* alpha_out;         // NULL or [E, H] COO order
+    float* alpha_csr;         // general kernel only: [E, H] in CSR slot order
+    int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
+    int e_cap;                // LDS capacity in edges (tiled kernel)
+    float slope, bn_eps;
+};
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// bias + skip + BatchNorm(eval) + ReLU on 4 consecutive channels (gat_skip.py:168,270,273-275)
+__device__ __forceinline__ float4 mp_epilogue(const MpArgs& a, float4 r, int node, int c) {
+    if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+        r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
+    }
+    if (a.skip) {
+        const float4 s = *reinterpret_cast<const float4*>(a.skip + (int64_t)node * a.C + c);
+        r.x += s.x; r.y += s.y; r.z += s.z; r.w += s.w;
+    }
+    if (a.bn_w) {
+        const float4 m = *reinterpret_cast<const float4*>(a.bn_m + c);
+        const float4 v = *reinterpret_cast<const float4*>(a.bn_v + c);
+        const float4 w = *reinterpret_cast<const float4*>(a.bn_w + c);
+        const float4 b = *reinterpret_cast<const float4*>(a.bn_b + c);
+        r.x = fmaxf((r.x - m.x) * (1.0f / sqrtf(v.x + a.bn_eps)) * w.x + b.x, 0.f);
+        r.y = fmaxf((r.y - m.y) * (1.0f / sqrtf(v.y + a.bn_eps)) * w.y + b.y, 0.f);
+        r.z = fmaxf((r.z - m.z) * (1.0f / sqrtf(v.z + a.bn_eps)) * w.z + b.z, 0.f);
+        r.w = fmaxf((r.w - m.w) * (1.0f / sqrtf(v.w + a.bn_eps)) * w.w + b.w, 0.f);
+    }
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// LDS-tiled kernel: one block = one graph x one channel chunk.
+//
+// Scene graphs are small and the batch adjacency is block-diagonal, so every neighbour of a
+// node lives in the same graph: the graph's slice xp[n0:n1, :, c0:c0+cw] is streamed from HBM
+// into LDS exactly once (16 B per lane, fully coalesced row segments), and the E_g x H gathers
+// of K4/K8 are LDS reads.  While those loads are in flight the block computes the attention
+// coefficients of the graph's edges (also in LDS).  HBM traffic = compulsory traffic.
+// grid = (B, ceil(C/cw)); dynamic LDS = [alpha: e_cap*H f32][src_local: e_cap i32][xs: n*H*cw f32].
+// ----------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* alpha_s = reinterpret_cast<float*>(smem);                       // [ne][H]
+    int* src_l = reinterpret_cast<int*>(smem + (size_t)a.e_cap * H * 4);   // [ne]
+    float4* xs4 = reinterpret_cast<float4*>(smem + (((size_t)a.e_cap * (H + 1) * 4 + 15) & ~(size_t)15));
+
+    const int g = blockIdx.x;
+    const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
+    const int tn = n1 - n0;
+    if (tn <= 0) return;
+    const int e0 = a.rowptr[n0], ne = a.rowptr[n1] - e0;
+    const int c0 = blockIdx.y * a.cw;
+    const int q4 = min(a.cw, a.C - c0) >> 2;          // float4 columns of this chunk
+    const int tid = threadIdx.x;
+    const int HC = H * a.C;
+
+    // ---- phase A: stream the graph's xp slice into LDS (unit = one float4) ----
+    {
+        const int units = tn * H * q4;
+        const float* base = a.xp + (int64_t)n0 * HC + c0;
+        for (int u0 = 0; u0 < units; u0 += 256 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = u0 + j * 256 + tid;
+                if (u < units) {
+                    const int row = u / q4, col = u - row * q4;
+                    v[j] = *reinterpret_cast<const float4*>(base + (int64_t)row * a.C + col * 4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = u0 + j * 256 + tid;
+                if (u < units) xs4[u] = v[j];
+            }
+        }
+    }
+    // ---- phase B: per-edge logit terms that do not depend on the destination ----
+    for (int s = tid; s < ne; s += 256) {
+        const int src = a.csr_src[e0 + s];
+        const int eid = a.csr_eid[e0 + s];
+        src_l[s] = src - n0;
+        const float* al = a.a_node + (int64_t)src * 2 * H;
+        const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
+#pragma unroll
+        for (int h = 0; h < H; ++h) alpha_s[s * H + h] = al[h] + ae[h];
+    }
+    __syncthreads();
+    // ---- phase C: leaky-relu + softmax over the incoming edges of each (node, head) ----
+    for (int it = tid; it < tn * H; it += 256) {
+        const int i = it / H, h = it - i * H;
+        const int lo = a.rowptr[n0 + i] - e0, hi = a.rowptr[n0 + i + 1] - e0;
+        float ar = a.a_node[(int64_t)(n0 + i) * 2 * H + H + h];
+        if (a.graph_term) ar += a.graph_term[(int64_t)g * a.t_ld + a.C + h];
+        float m = -INFINITY;
+        for (int s = lo; s < hi; ++s) {
+            const float v = leaky(alpha_s[s * H + h] + ar, a.slope);
+            alpha_s[s * H + h] = v;
+            m = fmaxf(m, v);
+        }
+        float sum = 0.f;
+        for (int s = lo; s < hi; ++s) {
+            const float ex = expf(alpha_s[s * H + h] - m);
+            alpha_s[s * H + h] = ex;
+            sum += ex;
+        }
+        const float den = sum + 1e-16f;
+        for (int s = lo; s < hi; ++s) {
+            const float al = alpha_s[s * H + h] / den;
+            alpha_s[s * H + h] = al;
+            if (a.alpha_out && blockIdx.y == 0) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+        }
+    }
+    __syncthreads();
+    // ---- phase D: alpha-weighted aggregation out of LDS + fused epilogue ----
+    const float inv_h = 1.0f / H;
+    for (int it = tid; it < tn * q4; it += 256) {
+        const int i = it / q4, q = it - i * q4;
+        const int lo = a.rowptr[n0 + i] - e0, hi = a.rowptr[n0 + i + 1] - e0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = lo; s < hi; ++s) {
+            const float4* row = xs4 + (size_t)src_l[s] * H * q4 + q;
+            float al[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) al[h] = alpha_s[s * H + h];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float4 v = row[h * q4];
+                acc.x += al[h] * v.x; acc.y += al[h] * v.y; acc.z += al[h] * v.z; acc.w += al[h] * v.w;
+            }
+        }
+        const int c = c0 + q * 4;
+        float4 r = make_float4(acc.x * inv_h, acc.y * inv_h, acc.z * inv_h, acc.w * inv_h);
+        if (a.graph_term && hi > lo) {
+            const float4 t = *reinterpret_cast<const float4*>(a.graph_term + (int64_t)g * a.t_ld + c);
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        r = mp_epilogue(a, r, n0 + i, c);
+        *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.C + c) = r;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// General CSR kernels (any graph: huge graphs, inter-graph edges, C % 4 != 0).
+//   k_gat_alpha_general: one thread per (node, head): three passes over the node's in-edges.
+//   k_gat_aggregate_general: one wave per node, lanes stride the channels, gathers from global.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
+    const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (it >= (int64_t)a.N * H) return;
+    const int i = (int)(it / H), h = (int)(it - (int64_t)i * H);
+    const int lo = a.rowptr[i], hi = a.rowptr[i + 1];
+    float ar = a.a_node[(int64_t)i * 2 * H + H + h];
+    if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[i] * a.t_ld + a.C + h];
+    float m = -INFINITY;
+    for (int s = lo; s < hi; ++s) {
+        const float v = leaky(a.a_node[(int64_t)a.csr_src[s] * 2 * H + h] +
+                              a.a_edge[(int64_t)a.csr_eid[s] * a.a_edge_stride + h] + ar, a.slope);
+        a.alpha_csr[(int64_t)s * H + h] = v;
+        m = fmaxf(m, v);
+    }
+    float sum = 0.f;
+    for (int s = lo; s < hi; ++s) {
+        const float ex = expf(a.alpha_csr[(int64_t)s * H + h] - m);
+        a.alpha_csr[(int64_t)s * H + h] = ex;
+        sum += ex;
+    }
+    const float den = sum + 1e-16f;
+    for (int s = lo; s < hi; ++s) {
+        const float al = a.alpha_csr[(int64_t)s * H + h] / den;
+        a.alpha_csr[(int64_t)s * H + h] = al;
+        if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[s] * H + h] = al;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gat_aggregate_general(MpArgs a, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= a.N) return;
+    const int lo = a.rowptr[i], hi = a.rowptr[i + 1];
+    const int g = a.node_graph[i];
+    const float inv_h = 1.0f / H;
+    const int HC = H * a.C;
+    for (int c = lane; c < a.C; c += 64) {
+        float acc = 0.f;
+        for (int s = lo; s < hi; ++s) {
+            const float* row = a.xp + (int64_t)a.csr_src[s] * HC + c;
+            const float* al = a.alpha_csr + (int64_t)s * H;
+            for (int h = 0; h < H; ++h) acc += al[h] * row[(int64_t)h * a.C];
+        }
+        float r = acc * inv_h;
+        if (a.graph_term && hi > lo) r += a.graph_term[(int64_t)g * a.t_ld + c];
+        if (a.bias) r += a.bias[c];
+        if (a.skip) r += a.skip[(int64_t)i * a.C + c];
+        if (a.bn_w) r = fmaxf((r - a.bn_m[c]) * (1.0f / sqrtf(a.bn_v[c] + a.bn_eps)) * a.bn_w[c] + a.bn_b[c], 0.f);
+        a.out[(int64_t)i * a.C + c] = r;
+    }
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------
+constexpr size_t LDS_TWO_PER_CU = 80 * 1024;    // 160 KiB / 2 resident blocks
+constexpr size_t LDS_MAX = 160 * 1024;
+
+struct TilePlan {
+    bool ok;
+    int cw, nchunks, e_cap;
+    size_t lds_bytes;
+};
+
+static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
+    TilePlan p{false, 0, 0, 0, 0};
+    if (!g->finalized || !g->intra_graph || (C & 3) || !(H == 1 || H == 2 || H == 4 || H == 8)) return p;
+    if (g->num_graphs <= 0 || g->num_graphs > 0x7fffffff) return p;
+    const size_t e_cap = (size_t)(g->max_graph_edges > 0 ? g->max_graph_edges : 1);
+    const size_t fixed = align_up(e_cap * (H + 1) * 4, 16);
+    const size_t n_max = (size_t)(g->max_graph_nodes > 0 ? g->max_graph_nodes : 1);
+    const int max_chunks = C / 4;
+    size_t best = 0;
+    for (int nch = 1; nch <= max_chunks; ++nch) {
+        const int cw = (int)align_up((size_t)cdiv(C, nch), 4);
+        const size_t bytes = fixed + n_max * H * cw * 4;
+        if (bytes > LDS_MAX) continue;
+        if (best == 0 || bytes <= LDS_TWO_PER_CU) {   // widest that fits at all, then widest with 2 blocks/CU
+            best = bytes;
+            p.cw = cw; p.nchunks = (int)cdiv(C, cw); p.e_cap = (int)e_cap; p.lds_bytes = bytes;
+        }
+        if (bytes <= LDS_TWO_PER_CU) break;
+    }
+    if (best) p.ok = true;
+    return p;
+}
+
+template <int H>
+static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gat_mp_tiled<H>), dim3((unsigned)B, (unsigned)p.nchunks), dim3(256), p.lds_bytes, stream, a);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+static int launch_gat_mp(const gvqa_graph* g, int C, int H, float slope, float bn_eps, const float* xp,
+                         const float* a_node, const float* a_edge, int64_t a_edge_stride,
+                         const float* graph_term, int64_t graph_term_ld, const float* skip,
+                         const gvqa_gat_conv_params* p, float* out, float* alpha_out, int force, void* ws,
+                         size_t ws_bytes, hipStream_t stream) {
+    GVQA_REQUIRE(g && xp && a_node && a_edge && p && out, GVQA_E_INVALID, "gat_mp: null argument");
+    GVQA_REQUIRE(C > 0 && H > 0, GVQA_E_INVALID, "gat_mp: bad dims");
+    const bool bn = p->bn_weight || p->bn_bias || p->bn_mean || p->bn_var;
+    GVQA_REQUIRE(!bn || (p->bn_weight && p->bn_bias && p->bn_mean && p->bn_var), GVQA_E_INVALID,
+                 "gat_mp: BatchNorm needs weight, bias, running_mean and running_var");
+    if (g->num_nodes == 0) return GVQA_OK;
+    MpArgs a;
+    a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid;
+    a.node_graph = g->node_graph; a.graph_ptr = g->graph_ptr;
+    a.xp = xp; a.a_node = a_node; a.a_edge = a_edge; a.a_edge_stride = a_edge_stride;
+    GVQA_REQUIRE(!graph_term || (graph_term_ld >= C + H && graph_term_ld % 4 == 0), GVQA_E_INVALID,
+                 "gat_mp: graph_term_ld must be >= C+H and a multiple of 4");
+    a.graph_term = graph_term; a.t_ld = graph_term_ld; a.skip = skip; a.bias = p->bias;
+    a.bn_w = p->bn_weight; a.bn_b = p->bn_bias; a.bn_m = p->bn_mean; a.bn_v = p->bn_var;
+    a.out = out; a.alpha_out = alpha_out; a.alpha_csr = nullptr;
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.slope = slope; a.bn_eps = bn_eps;
+
+    StageTimer timer(GVQA_STAGE_MP, stream);
+    TilePlan plan = plan_tiled(g, C, H);
+    GVQA_REQUIRE(force != 1 || plan.ok, GVQA_E_UNSUPPORTED,
+                 "gat_mp: tiled kernel not applicable (needs finalized intra-graph batch, C %% 4 == 0, "
+                 "H in {1,2,4,8}, largest graph fitting 160 KiB of LDS)");
+    if (plan.ok && force != 2) {
+        a.cw = plan.cw; a.e_cap = plan.e_cap;
+        switch (H) {
+            case 1: return launch_tiled<1>(a, plan, g->num_graphs, stream);
+            case 2: return launch_tiled<2>(a, plan, g->num_graphs, stream);
+            case 4: return launch_tiled<4>(a, plan, g->num_graphs, stream);
+            default: return launch_tiled<8>(a, plan, g->num_graphs, stream);
+        }
+    }
+    GVQA_REQUIRE(graph_term == nullptr || (g->finalized && g->intra_graph), GVQA_E_UNSUPPORTED,
+                 "gat_mp: per-graph terms need an intra-graph batch");
+    const size_t need = (size_t)g->num_edges * H * sizeof(float);
+    GVQA_REQUIRE(need == 0 || (ws && ws_bytes >= need), GVQA_E_WORKSPACE,
+                 "gat_mp: general kernel needs %zu workspace bytes", need);
+    a.alpha_csr = static_cast<float*>(ws);
+    hipLaunchKernelGGL(k_gat_alpha_general, dim3((unsigned)cdiv((int64_t)a.N * H, 256)), dim3(256), 0, stream, a, H);
+    hipLaunchKernelGGL(k_gat_aggregate_general, dim3((unsigned)cdiv(a.N, 4)), dim3(256), 0, stream, a, H);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// ==============================================================================================
+// Drivers
+// ==============================================================================================
+struct SeqLayout {
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, total;
+};
+
+static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d) {
+    SeqLayout L;
+    size_t off = 0;
+    auto take = [&](size_t count) {
+        size_t r = off;
+        off += align_up(count * sizeof(float), 256);
+        return r;
+    };
+    const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
+    L.Vn = take(K * 2 * H * d->node_dim);
+    L.Ve = take(K * H * d->edge_dim);
+    L.Gw = take(K * (C + H) * (size_t)d->ins_dim);
+    L.T = take(K * B * align_up(C + H, 4));
+    L.a_edge = take((size_t)E * K * H);
+    L.a_node = take((size_t)N * 2 * H);
+    L.xp = take((size_t)N * H * C);
+    L.h0 = take((size_t)N * C);
+    L.h1 = take((size_t)N * C);
+    L.alpha_csr = take((size_t)E * H);
+    L.total = off;
+    return L;
+}
+
+static int check_dims(const gvqa_gat_dims* d, bool seq) {
+    GVQA_REQUIRE(d, GVQA_E_INVALID, "gat: null dims");
+    GVQA_REQUIRE(d->node_dim > 0 && d->edge_dim > 0 && d->out_channels > 0 && d->heads > 0 && d->ins_dim >= 0,
+                 GVQA_E_INVALID, "gat: non-positive dimension");
+    GVQA_REQUIRE(d->num_hops >= 1 && d->num_hops <= MAX_HOPS, GVQA_E_INVALID, "gat: num_hops must be in [1,%d]", MAX_HOPS);
+    if (seq) {
+        GVQA_REQUIRE(d->node_dim == d->out_channels, GVQA_E_INVALID,
+                     "gat_seq: skip connection needs in_channels == out_channels (gat_skip.py:270)");
+    } else {
+        GVQA_REQUIRE(d->ins_dim == 0 && d->num_hops == 1, GVQA_E_INVALID, "gat_conv: ins_dim must be 0 and num_hops 1");
+    }
+    return GVQA_OK;
+}
+
+static int run_fold(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, float* Vn, float* Ve, float* Gw,
+                    hipStream_t stream) {
+    FoldArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    for (int i = 0; i < d->num_hops; ++i) {
+        GVQA_REQUIRE(hops[i].lin_l_weight && hops[i].lin_e_weight && hops[i].att_l && hops[i].att_r && hops[i].att_e,
+                     GVQA_E_INVALID, "gat: hop %d has a null weight", i);
+        fa.W_l[i] = hops[i].lin_l_weight; fa.W_e[i] = hops[i].lin_e_weight;
+        fa.att_l[i] = hops[i].att_l; fa.att_r[i] = hops[i].att_r; fa.att_e[i] = hops[i].att_e;
+    }
+    fa.Vn = Vn; fa.Ve = Ve; fa.Gw = Gw;
+    fa.Dn = d->node_dim; fa.De = d->edge_dim; fa.Di = d->ins_dim; fa.C = d->out_channels; fa.H = d->heads;
+    fa.K = d->num_hops;
+    StageTimer timer(GVQA_STAGE_FOLD, stream);
+    int maxk = fa.Dn > fa.De ? fa.Dn : fa.De;
+    if (fa.Di > maxk) maxk = fa.Di;
+    hipLaunchKernelGGL(k_fold_att, dim3((unsigned)cdiv(maxk, 64), (unsigned)fa.H, (unsigned)fa.K * 4), dim3(256), 0,
+                       stream, fa);
+    if (fa.Di > 0)
+        hipLaunchKernelGGL(k_fold_headmean, dim3((unsigned)cdiv((int64_t)fa.C * fa.Di, 256), 1, (unsigned)fa.K),
+                           dim3(256), 0, stream, fa);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+}  // namespace gvqa
+
+extern "C" {
+
+using namespace gvqa;
+
+int gvqa_gat_message_passing(const gvqa_graph* g, int32_t C, int32_t H, float negative_slope, float bn_eps,
+                             const float* xp, const float* a_node, const float* a_edge, int64_t a_edge_stride,
+                             const float* graph_term, int64_t graph_term_ld, const float* skip,
+                             const gvqa_gat_conv_params* p, float* out, float* alpha_out, int force, void* ws,
+                             size_t ws_bytes, void* stream) {
+    return launch_gat_mp(g, C, H, negative_slope, bn_eps, xp, a_node, a_edge, a_edge_stride, graph_term, graph_term_ld,
+                         skip, p, out, alpha_out, force, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t gvqa_gat_seq_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    if (!g || !d) return 0;
+    return seq_layout(g->num_nodes, g->num_edges, g->num_graphs, d).total;
+}
+
+size_t gvqa_gat_conv_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    return gvqa_gat_seq_workspace_bytes(g, d);
+}
+
+int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* p, const float* x,
+                          const float* edge_attr, float* out, float* alpha_out, void* ws, size_t ws_bytes,
+                          void* stream_) {
+    GVQA_REQUIRE(g && p, GVQA_E_INVALID, "gat_conv: null argument");
+    int rc = check_dims(d, false);
+    if (rc) return rc;
+    const int64_t N = g->num_nodes, E = g->num_edges, B = g->num_graphs;
+    SeqLayout L = seq_layout(N, E, B, d);
+    GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "gat_conv: workspace %zu < required %zu", ws_bytes, L.total);
+    GVQA_REQUIRE((N == 0 || (x && out)) && (E == 0 || edge_attr), GVQA_E_INVALID, "gat_conv: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* base = static_cast<char*>(ws);
+    auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    const int H = d->heads, C = d->out_channels;
+
+    rc = run_fold(d, p, P(L.Vn), P(L.Ve), nullptr, stream);
+    if (rc) return rc;
+    {   // a_e = edge_attr . V_e^T                       (gat_skip.py:150-151, folded)
+        StageTimer t(GVQA_STAGE_EDGE_LOGIT, stream);
+        rc = launch_linear(E, H, d->edge_dim, edge_attr, d->edge_dim, P(L.Ve), d->edge_dim, nullptr, 0, P(L.a_edge), H, 1,
+                           0, 0, 0, stream);
+        if (rc) return rc;
+    }
+    {   // xp = x . W_l^T                                (gat_skip.py:133)
+        StageTimer t(GVQA_STAGE_PROJ, stream);
+        rc = launch_linear(N, (int64_t)H * C, d->node_dim, x, d->node_dim, p->lin_l_weight, d->node_dim, nullptr, 0,
+                           P(L.xp), (int64_t)H * C, 1, 0, 0, 0, stream);
+        if (rc) return rc;
+    }
+    {   // (a_l | a_r) = x . [V_l | V_r]                 (gat_skip.py:134-135, folded)
+        StageTimer t(GVQA_STAGE_NODE_LOGIT, stream);
+        rc = launch_linear(N, 2 * H, d->node_dim, x, d->node_dim, P(L.Vn), d->node_dim, nullptr, 0, P(L.a_node), 2 * H, 1,
+                           0, 0, 0, stream);
+        if (rc) return rc;
+    }
+    return launch_gat_mp(g, C, H, d->negative_slope, d->bn_eps, P(L.xp), P(L.a_node), P(L.a_edge), H, nullptr, 0, nullptr, p,
+                         out, alpha_out, 0, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
+}
+
+int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+                         const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
+                         void* ws, size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(g && hops, GVQA_E_INVALID, "gat_seq: null argument");
+    int rc = check_dims(d, true);
+    if (rc) return rc;
+    GVQA_REQUIRE(g->finalized, GVQA_E_INVALID, "gat_seq: call gvqa_graph_finalize first");
+    GVQA_REQUIRE(g->intra_graph, GVQA_E_UNSUPPORTED,
+                 "gat_seq: an edge joins two graphs of the batch; use gvqa_gat_conv_forward on concatenated inputs");
+    const int64_t N = g->num_nodes, E = g->num_edges, B = g->num_graphs;
+    SeqLayout L = seq_layout(N, E, B, d);
+    GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "gat_seq: workspace %zu < required %zu", ws_bytes, L.total);
+    GVQA_REQUIRE((N == 0 || (x && out)) && (E == 0 || edge_attr) && (d->ins_dim == 0 || B == 0 || instr), GVQA_E_INVALID,
+                 "gat_seq: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* base = static_cast<char*>(ws);
+    auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    const int H = d->heads, C = d->out_channels, K = d->num_hops, Dn = d->node_dim, De = d->edge_dim, Di = d->ins_dim;
+    const int64_t Tld = (int64_t)align_up((size_t)(C + H), 4);
+    if (N == 0) return GVQA_OK;
+
+    rc = run_fold(d, hops, P(L.Vn), P(L.Ve), Di > 0 ? P(L.Gw) : nullptr, stream);
+    if (rc) return rc;
+    {   // edge logit terms of ALL hops in one pass over edge_attr: [E, De] x [De, K*H]
+        StageTimer t(GVQA_STAGE_EDGE_LOGIT, stream);
+        rc = launch_linear(E, (int64_t)K * H, De, edge_attr, De, P(L.Ve), De, nullptr, 0, P(L.a_edge), (int64_t)K * H, 1, 0,
+                           0, 0, stream);
+        if (rc) return rc;
+    }
+    if (Di > 0) {   // per-graph instruction terms of all hops: [K] x ([B, Di] x [Di, C+H])
+        StageTimer t(GVQA_STAGE_GRAPH_TERM, stream);
+        rc = launch_linear(B, C + H, Di, instr, Di, P(L.Gw), Di, nullptr, 0, P(L.T), Tld, K, (int64_t)B * Di,
+                           (int64_t)(C + H) * Di, (int64_t)B * Tld, stream);
+        if (rc) return rc;
+    }
+    const float* h = x;
+    for (int i = 0; i < K; ++i) {
+        float* h_next;
+        if (hop_out) h_next = hop_out + (int64_t)i * N * C;
+        else if (i == K - 1) h_next = out;
+        else h_next = (i & 1) ? P(L.h1) : P(L.h0);
+        {   // xp = h . W_l[:, :Dn]^T   (node half of gat_skip.py:133; instruction half is in T)
+            StageTimer t(GVQA_STAGE_PROJ, stream);
+            rc = launch_linear(N, (int64_t)H * C, Dn, h, Dn, hops[i].lin_l_weight, Dn + Di, nullptr, 0, P(L.xp),
+                               (int64_t)H * C, 1, 0, 0, 0, stream);
+            if (rc) return rc;
+        }
+        {
+            StageTimer t(GVQA_STAGE_NODE_LOGIT, stream);
+            rc = launch_linear(N, 2 * H, Dn, h, Dn, P(L.Vn) + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
+                               1, 0, 0, 0, stream);
+            if (rc) return rc;
+        }
+        rc = launch_gat_mp(g, C, H, d->negative_slope, d->bn_eps, P(L.xp), P(L.a_node), P(L.a_edge) + (int64_t)i * H,
+                           (int64_t)K * H, Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr, Tld, h, &hops[i], h_next,
+                           alpha_out ? alpha_out + (int64_t)i * E * H : nullptr, 0, P(L.alpha_csr),
+                           (size_t)E * H * sizeof(float), stream);
+        if (rc) return rc;
+        h = h_next;
+    }
+    if (hop_out) {
+        StageTimer t(GVQA_STAGE_OTHER, stream);
+        GVQA_HIP_CHECK(hipMemcpyAsync(out, hop_out + (int64_t)(K - 1) * N * C, (size_t)N * C * sizeof(float),
+                                      hipMemcpyDeviceToDevice, stream));
+    }
+    return GVQA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""MI355X-native drop-in for the reference's `gat_skip` module (gat_skip.py).
+
+Same class names, constructor arguments, forward signatures and state_dict keys/shapes as the
+reference (`gat`: gat_skip.py:60-63,111-112; `gat_seq`: gat_skip.py:224-225,249), so that
+`from gat_skip import gat_seq` in pipeline_model_gat.py:16 can be pointed here unchanged
+ and checkpoints load through the pipeline's tolerant loader
+(pipeline_model_gat.py:823-836).  The compute runs in hand-written HIP kernels behind the
+C ABI of include/gvqa.h; torch only provides device memory and the current stream.
+
+Scope: inference (eval-mode BatchNorm, dropout inactive).  `.train()` with dropout p > 0 is not
+reproducible against torch's RNG and raises; `.train()` with p == 0 (batch-statistics BN) is a
+"next" row and raises NotImplementedError as well.  There is no CPU path: CPU
+tensors raise, and a missing HIP library raises at construction.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.nn import Parameter, Linear
+
+from . import _lib
+from .graph import SceneGraphBatch, _stream, _ptr
+
+
+def _glorot(t: Tensor):
+    """PyG inits.glorot (call sites gat_skip.py:101-107)."""
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the MI355X execution path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class gat(torch.nn.Module):
+    """Edge- and instruction-conditioned GAT layer (reference class `gat`, gat_skip.py:16-213).
+
+    forward(x, edge_index, edge_attr, size=None, return_attention_weights=None) -> out [N, C]
+    (concat=False) or (out, (edge_index, alpha [E, H])).  No self-loops are added
+    (gat_skip.py:111-177 never uses `add_self_loops`).
+    """
+
+    def __init__(self, in_channels: int, out_channels: int, edge_in_channels: int, heads: int = 1,
+                 concat: bool = True, negative_slope: float = 0.2, dropout: float = 0.0,
+                 add_self_loops: bool = True, bias: bool = True, **kwargs):
+        super().__init__()
+        if not isinstance(in_channels, int):
+            raise NotImplementedError("bipartite (tuple) in_channels is not on the GraphVQA path")
+        _lib.load()   # fail loudly at construction when the HIP library is missing
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.add_self_loops = add_self_loops
+        self.lin_l = Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_r = self.lin_l                      # shared (gat_skip.py:76-77); separate state_dict key
+        self.lin_e = Linear(edge_in_channels, heads * out_channels, bias=False)
+        self.att_e = Parameter(torch.empty(1, heads, out_channels))
+        self.att_l = Parameter(torch.empty(1, heads, out_channels))
+        self.att_r = Parameter(torch.empty(1, heads, out_channels))
+        if bias and concat:
+            self.bias = Parameter(torch.empty(heads * out_channels))
+        elif bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for t in (self.lin_l.weight, self.lin_e.weight, self.att_l, self.att_r, self.att_e):
+            _glorot(t)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+    def _params(self, bn: Optional[torch.nn.BatchNorm1d] = None) -> "_lib.GatConvParams":
+        p = _lib.GatConvParams()
+        p.lin_l_weight = _f32c(self.lin_l.weight, "lin_l.weight").data_ptr()
+        p.lin_e_weight = _f32c(self.lin_e.weight, "lin_e.weight").data_ptr()
+        p.att_l = _f32c(self.att_l, "att_l").data_ptr()
+        p.att_r = _f32c(self.att_r, "att_r").data_ptr()
+        p.att_e = _f32c(self.att_e, "att_e").data_ptr()
+        p.bias = None if self.bias is None else _f32c(self.bias, "bias").data_ptr()
+        if bn is not None:
+            p.bn_weight = _f32c(bn.weight, "bn.weight").data_ptr()
+            p.bn_bias = _f32c(bn.bias, "bn.bias").data_ptr()
+            p.bn_mean = _f32c(bn.running_mean, "bn.running_mean").data_ptr()
+            p.bn_var = _f32c(bn.running_var, "bn.running_var").data_ptr()
+        return p
+
+    def _check_mode(self):
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("training-mode attention dropout is not implemented on the HIP path "
+                                      "(call .eval(); SURVEY 8f-4)")
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor, size=None,
+                return_attention_weights=None, graph: Optional[SceneGraphBatch] = None):
+        assert x.dim() == 2, "Static graphs not supported in `GATConv`."      # gat_skip.py:132
+        if self.concat:
+            raise NotImplementedError("concat=True is not used by GraphVQA (gat_skip.py:232) and not implemented")
+        self._check_mode()
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        edge_attr = _f32c(edge_attr, "edge_attr")
+        N, E = x.shape[0], edge_index.shape[1]
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, None, N, 1)
+        H, Cc = self.heads, self.out_channels
+        d = _lib.GatDims(self.in_channels, edge_attr.shape[1], 0, Cc, H, 1, self.negative_slope, 1e-5)
+        if x.shape[1] != self.in_channels or edge_attr.shape[1] != self.lin_e.weight.shape[1]:
+            raise ValueError("feature width does not match the layer")
+        p = self._params()
+        out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        want_alpha = isinstance(return_attention_weights, bool)
+        alpha = torch.empty((E, H), dtype=torch.float32, device=x.device) if want_alpha else None
+        with torch.cuda.device(x.device):
+            ws = _workspace(lib.gvqa_gat_conv_workspace_bytes(C.byref(graph.c), C.byref(d)), x.device)
+            _lib.check(lib.gvqa_gat_conv_forward(C.byref(graph.c), C.byref(d), C.byref(p), x.data_ptr(),
+                                                 edge_attr.data_ptr(), out.data_ptr(), _ptr(alpha),
+                                                 ws.data_ptr(), ws.numel(), _stream(x.device)))
+        if want_alpha:
+            return out, (edge_index, alpha)
+        return out
+
+    def __repr__(self):
+        return "{}({}, {}, heads={})".format(self.__class__.__name__, self.in_channels, self.out_channels,
+                                             self.heads)
+
+
+class gat_seq(torch.nn.Module):
+    """K hops of instruction-conditioned GAT with skip, BN, ReLU (reference `gat_seq`,
+    gat_skip.py:220-279).  forward(x, edge_index, edge_attr, instr_vectors, batch) -> h [N, out]."""
+
+    def __init__(self, in_channels, out_channels, edge_attr_dim, ins_dim, num_ins, dropout=0.0, gat_heads=4,
+                 gat_negative_slope=0.2, gat_bias=True):
+        super().__init__()
+        self.convs = torch.nn.ModuleList([
+            gat(in_channels=in_channels + ins_dim, out_channels=out_channels,
+                edge_in_channels=edge_attr_dim + ins_dim, heads=gat_heads, concat=False,
+                negative_slope=gat_negative_slope, dropout=dropout, bias=gat_bias) for _ in range(num_ins)])
+        self.bns = torch.nn.ModuleList([torch.nn.BatchNorm1d(out_channels) for _ in range(num_ins - 1)])
+        self.dropout = dropout
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.edge_attr_dim, self.ins_dim, self.heads = edge_attr_dim, ins_dim, gat_heads
+        self.negative_slope = gat_negative_slope
+        self.last_stats = None
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph: Optional[SceneGraphBatch] = None,
+                return_attention_weights: bool = False, return_hops: bool = False):
+        if self.training:
+            raise NotImplementedError(
+                "gat_seq on the HIP path implements inference (eval-mode BatchNorm, dropout inactive); "
+                "call .eval().  Training mode is a 'next' row (SURVEY 8f-4).")
+        lib = _lib.load()
+        assert x.dim() == 2, "Static graphs not supported in `GATConv`."
+        x = _f32c(x, "x")
+        edge_attr = _f32c(edge_attr, "edge_attr")
+        instr = _f32c(instr_vectors, "instr_vectors")
+        K = len(self.convs)
+        N, E = x.shape[0], edge_index.shape[1]
+        if instr.dim() != 3 or instr.shape[0] < K or instr.shape[2] != self.ins_dim:
+            raise ValueError(f"instr_vectors must be [>= {K}, B, {self.ins_dim}]")
+        B = instr.shape[1]
+        if x.shape[1] != self.in_channels or edge_attr.shape[1] != self.edge_attr_dim:
+            raise ValueError("feature width does not match the module")
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, batch, N, B)
+        elif graph.num_nodes != N or graph.num_edges != E or graph.num_graphs != B:
+            raise ValueError("prebuilt graph does not match the inputs")
+        if not graph.intra_graph:
+            return self._forward_unfolded(x, edge_index, edge_attr, instr, batch, graph)
+        H, Cc = self.heads, self.out_channels
+        d = _lib.GatDims(self.in_channels, self.edge_attr_dim, self.ins_dim, Cc, H, K, self.negative_slope,
+                         self.bns[0].eps if len(self.bns) else 1e-5)
+        hops = (_lib.GatConvParams * K)()
+        for i, conv in enumerate(self.convs):
+            hops[i] = conv._params(self.bns[i] if i != K - 1 else None)
+        dev = x.device
+        out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+        alpha = torch.empty((K, E, H), dtype=torch.float32, device=dev) if return_attention_weights else None
+        hop_out = torch.empty((K, N, Cc), dtype=torch.float32, device=dev) if return_hops else None
+        with torch.cuda.device(dev):
+            ws = _workspace(lib.gvqa_gat_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), dev)
+            _lib.check(lib.gvqa_gat_seq_forward(C.byref(graph.c), C.byref(d), hops, x.data_ptr(),
+                                                edge_attr.data_ptr(), instr.data_ptr(), out.data_ptr(),
+                                                _ptr(alpha), _ptr(hop_out), ws.data_ptr(), ws.numel(),
+                                                _stream(dev)))
+        if return_attention_weights or return_hops:
+            return out, alpha, hop_out
+        return out
+
+    def _forward_unfolded(self, x, edge_index, edge_attr, instr, batch, graph):
+        """Batches whose edges cross graphs (never produced by the reference's collate): run the
+        reference's literal per-hop formulation (gat_skip.py:254-276) on the generic conv op."""
+        K = len(self.convs)
+        h = x
+        edge_batch = batch[edge_index[0]]
+        for i in range(K):
+            ins = instr[i]
+            edge_cat = torch.cat((edge_attr, ins[edge_batch]), dim=-1)
+            x_cat = torch.cat((h, ins[batch]), dim=-1)
+            h = self.convs[i](x_cat, edge_index, edge_cat, graph=graph) + h
+            if i != K - 1:
+                h = torch.relu(self.bns[i](h))
+        return h

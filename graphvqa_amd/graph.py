@@ -1,0 +1,86 @@
+"""Device-resident scene-graph batch (destination-sorted CSR) built by the HIP library.
+
+Host-side handle for `struct gvqa_graph`.  Replaces the COO indexing PyG's `MessagePassing`
+performs on every hop for the reference (gat_skip.py:155-156); the input is exactly what the
+reference's collate function emits (gqa_dataset_entry.py:361-369, :654).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class SceneGraphBatch:
+    """CSR-by-destination view of (edge_index [2,E] int64, batch [N] int64, num_graphs)."""
+
+    def __init__(self, edge_index: torch.Tensor, batch: torch.Tensor | None, num_nodes: int,
+                 num_graphs: int | None = None):
+        lib = _lib.load()
+        if not edge_index.is_cuda:
+            raise ValueError("SceneGraphBatch needs CUDA/HIP tensors (edge_index is on %s)" % edge_index.device)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("edge_index must be int64 [2, E]")
+        dev = edge_index.device
+        edge_index = edge_index.contiguous()
+        if batch is not None:
+            if batch.dtype != torch.int64 or batch.dim() != 1 or batch.shape[0] != num_nodes:
+                raise ValueError("batch must be int64 [N]")
+            batch = batch.to(dev).contiguous()
+        if num_graphs is None:
+            # same host sync the reference's pipeline performs (pipeline_model_gat.py:152)
+            num_graphs = int(batch[-1].item()) + 1 if (batch is not None and num_nodes > 0) else 1
+        N, E, B = int(num_nodes), int(edge_index.shape[1]), int(num_graphs)
+        self.device = dev
+        self.num_nodes, self.num_edges, self.num_graphs = N, E, B
+        nbytes = lib.gvqa_graph_workspace_bytes(N, E, B)
+        self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        self._keep = (edge_index, batch)
+        self.c = _lib.Graph()
+        with torch.cuda.device(dev):
+            _lib.check(lib.gvqa_graph_build(N, E, B, _ptr(edge_index), _ptr(batch), self._ws.data_ptr(),
+                                            self._ws.numel(), _stream(dev), C.byref(self.c)))
+            _lib.check(lib.gvqa_graph_finalize(C.byref(self.c), _stream(dev)))
+
+    # statistics ------------------------------------------------------------------------------
+    @property
+    def max_graph_nodes(self): return self.c.max_graph_nodes
+
+    @property
+    def max_graph_edges(self): return self.c.max_graph_edges
+
+    @property
+    def max_in_degree(self): return self.c.max_in_degree
+
+    @property
+    def intra_graph(self): return bool(self.c.intra_graph)
+
+    # device arrays as torch views (tests / debugging) ------------------------------------------
+    def _view(self, ptr, n):
+        off = ptr - self._ws.data_ptr()
+        return self._ws[off:off + 4 * n].view(torch.int32)
+
+    @property
+    def rowptr(self): return self._view(self.c.rowptr, self.num_nodes + 1)
+
+    @property
+    def csr_src(self): return self._view(self.c.csr_src, self.num_edges)
+
+    @property
+    def csr_eid(self): return self._view(self.c.csr_eid, self.num_edges)
+
+    @property
+    def graph_ptr(self): return self._view(self.c.graph_ptr, self.num_graphs + 1)
+
+    @property
+    def node_graph(self): return self._view(self.c.node_graph, self.num_nodes)

@@ -1,0 +1,72 @@
+"""Data-parallel sharding of scene-graph batches over the GPUs of one node.
+
+Graphs are independent units (block-diagonal batch, no edge crosses graphs -- the reference
+uses `batch[edge_index[0]]` as *the* graph of an edge, gat_skip.py:257), and eval-mode BatchNorm is
+a per-channel affine, so the K hops need NO communication: each rank (one process per GPU) runs
+a contiguous range of graphs.  The only exchange is an all-gather of per-graph result rows
+(the north star's "all-gather of per-batch logits"; the reference itself never gathers --
+every rank overwrites the same dump file, mainExplain_gat.py:938-942).  Backend: RCCL on GPUs
+(`nccl` in torch.distributed), gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def partition_graphs(edges_per_graph: np.ndarray, world_size: int) -> np.ndarray:
+    """Contiguous graph ranges balanced by edge count.  Returns bounds[world_size + 1]: rank r owns
+    graphs [bounds[r], bounds[r+1]).  Deterministic; every rank computes the same answer."""
+    B = int(edges_per_graph.shape[0])
+    csum = np.concatenate([[0], np.cumsum(edges_per_graph.astype(np.int64))])
+    total = csum[-1]
+    bounds = np.zeros(world_size + 1, dtype=np.int64)
+    for r in range(1, world_size):
+        target = total * r / world_size
+        bounds[r] = int(np.searchsorted(csum, target, side="left"))
+    bounds[world_size] = B
+    return np.maximum.accumulate(np.minimum(bounds, B))
+
+
+def shard_batch(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int, rank: int, world_size: int):
+    """Local shard of a COO batch for `rank`: (node slice, edge mask, local edge_index, local batch,
+    graph range).  Node ids and graph ids are rebased to the shard."""
+    edge_graph = batch[edge_index[0]]
+    epg = np.bincount(edge_graph, minlength=num_graphs)
+    bounds = partition_graphs(epg, world_size)
+    g0, g1 = int(bounds[rank]), int(bounds[rank + 1])
+    n0, n1 = int(np.searchsorted(batch, g0, side="left")), int(np.searchsorted(batch, g1, side="left"))
+    emask = (edge_graph >= g0) & (edge_graph < g1)
+    ei = edge_index[:, emask] - n0
+    return slice(n0, n1), emask, ei, batch[n0:n1] - g0, (g0, g1)
+
+
+def graph_mean_pool(h: torch.Tensor, batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
+    """Per-graph mean of node rows -> [B, C]; the small per-graph payload that is all-gathered.
+    (Stand-in for the answer logits until the pooling/classifier row, SURVEY 8f-2, is built.)"""
+    out = torch.zeros((num_graphs, h.shape[1]), dtype=h.dtype, device=h.device)
+    out.index_add_(0, batch, h)
+    cnt = torch.bincount(batch, minlength=num_graphs).clamp(min=1).to(h.dtype)
+    return out / cnt[:, None]
+
+
+def all_gather_graph_rows(rows: torch.Tensor, counts=None) -> torch.Tensor:
+    """All-gather per-graph rows [B_r, C] from every rank into [sum B_r, C] (rank order).
+    Ragged shards are padded to the largest B_r (one collective, latency-bound at these sizes)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return rows
+    world = dist.get_world_size()
+    if counts is None:
+        c = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+        cl = [torch.zeros_like(c) for _ in range(world)]
+        dist.all_gather(cl, c)
+        counts = [int(v.item()) for v in cl]
+    mx = max(counts)
+    if rows.shape[0] < mx:
+        rows = torch.cat([rows, rows.new_zeros((mx - rows.shape[0], rows.shape[1]))])
+    out = torch.empty((world * mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, rows.contiguous())
+    if all(c == mx for c in counts):
+        return out
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])

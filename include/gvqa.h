@@ -1,0 +1,194 @@
+/*
+ * gvqa.h -- C ABI of the MI355X-native scene-graph execution library (libgvqa_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of codexxxl/GraphVQA: the scene-graph execution module
+ *     gat_skip.gat / gat_skip.gat_seq            (reference gat_skip.py:16-279)
+ * and its variants
+ *     GINEConv / gine_seq                        (baseline_and_test_models/pipeline_model_gine.py:622-674)
+ *     GCNConv  / gcn_seq                         (baseline_and_test_models/pipeline_model_gcn.py:622-669)
+ *     gat_lcgn / lcgn_seq                        (baseline_and_test_models/lcgn.py:17-323)
+ * The reference has no FFI of its own (it is pure Python on torch_geometric / torch_scatter);
+ * these entry points are what a ctypes binding of that path binds -- see INTEGRATION.md.
+ *
+ * Conventions
+ *  - Plain C: pointers and sizes only, no torch / C++ types.  Every function returns an int
+ *    status: 0 = ok, <0 = GVQA_E_* ; no C++ exception crosses the boundary.
+ *    gvqa_last_error() returns a thread-local human-readable message for the last failure.
+ *  - All tensor pointers are DEVICE pointers (HBM), fp32 row-major contiguous unless a leading
+ *    dimension is given, indices int64 on input (the reference's dtype, gqa_dataset_entry.py:361)
+ *    and int32 inside the library.
+ *  - Ownership: the caller owns every buffer, including workspaces (query *_workspace_bytes,
+ *    allocate with the caller's allocator, e.g. torch's caching allocator).  The library never
+ *    calls hipMalloc/hipFree on the hot path.
+ *  - Threading / streams: re-entrant; work is enqueued on the caller's hipStream_t (passed as
+ *    void*) and the call returns without synchronising, except gvqa_graph_finalize, which waits
+ *    for the graph statistics.
+ *  - Inputs are never modified (the reference never mutates its inputs either).
+ */
+#ifndef GVQA_H
+#define GVQA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVQA_OK 0
+#define GVQA_E_INVALID (-1)    /* bad argument (null pointer, negative size, unsupported shape) */
+#define GVQA_E_WORKSPACE (-2)  /* workspace too small */
+#define GVQA_E_HIP (-3)        /* a HIP runtime call failed; see gvqa_last_error() */
+#define GVQA_E_GRAPH (-4)      /* malformed graph (index out of range, batch not sorted) */
+#define GVQA_E_UNSUPPORTED (-5)
+
+const char* gvqa_last_error(void);
+/* Library / build identification, e.g. "gvqa-hip 0.1 gfx950". */
+const char* gvqa_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph container: destination-sorted CSR of a batched (block-diagonal) scene-graph batch.
+ *
+ * Replaces what PyG's MessagePassing.__collect__ / torch_scatter index on the fly from COO
+ * `edge_index` on every hop (call site gat_skip.py:155-156).  Input contract = the reference's
+ * collate output (gqa_dataset_entry.py:361-369, :654): edge_index[0] = source, edge_index[1] =
+ * destination, batch[n] = graph id of node n, non-decreasing.  Multi-edges and explicit
+ * self-loops are ordinary edges and are preserved.
+ *
+ * Within a row (destination) the CSR slots are ordered by ORIGINAL edge id, so per-node
+ * reductions run in the reference's COO order and results are deterministic run to run.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gvqa_graph {
+    int64_t num_nodes, num_edges, num_graphs;
+    const int32_t* rowptr;      /* [N+1]  CSR row pointer by destination node                  */
+    const int32_t* csr_src;     /* [E]    source node of CSR slot s                            */
+    const int32_t* csr_eid;     /* [E]    original COO edge id of CSR slot s ("eperm")         */
+    const int32_t* node_graph;  /* [N]    graph id of node n (int32 copy of `batch`)           */
+    const int32_t* graph_ptr;   /* [B+1]  first node of graph g; graph g's in-edges are CSR
+                                          slots rowptr[graph_ptr[g]] .. rowptr[graph_ptr[g+1]] */
+    const int32_t* stats_dev;   /* [8]    device copy of the statistics below                  */
+    /* statistics, valid after gvqa_graph_finalize(): */
+    int32_t max_graph_nodes;    /* largest graph, in nodes                                     */
+    int32_t max_graph_edges;    /* largest graph, in in-edges                                  */
+    int32_t max_in_degree;
+    int32_t intra_graph;        /* 1 iff every edge has batch[src] == batch[dst]               */
+    int32_t valid;              /* 1 iff indices in range and batch non-decreasing in [0,B)    */
+    int32_t finalized;
+} gvqa_graph;
+
+size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
+
+/* Enqueue the CSR build.  `ws` (>= gvqa_graph_workspace_bytes, 256-byte aligned) backs every
+ * array `out` points to and must stay alive as long as `out` is used. */
+int gvqa_graph_build(int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                     const int64_t* edge_index /* [2,E] */, const int64_t* batch /* [N] or NULL (one graph) */,
+                     void* ws, size_t ws_bytes, void* stream, gvqa_graph* out);
+
+/* Copy the statistics to the host struct (synchronises `stream`).  Returns GVQA_E_GRAPH if the
+ * input violated the contract. */
+int gvqa_graph_finalize(gvqa_graph* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GAT execution path
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gvqa_gat_conv_params {   /* one `gat` layer; state_dict names in comments */
+    const float* lin_l_weight;  /* [H*C, in]       convs.i.lin_l.weight (== lin_r, gat_skip.py:76-77) */
+    const float* lin_e_weight;  /* [H*C, edge_in]  convs.i.lin_e.weight */
+    const float* att_l;         /* [H*C]           convs.i.att_l  ([1,H,C]) */
+    const float* att_r;         /* [H*C]           convs.i.att_r */
+    const float* att_e;         /* [H*C]           convs.i.att_e */
+    const float* bias;          /* [C] or NULL     convs.i.bias (concat=False) */
+    /* eval-mode BatchNorm1d + ReLU applied after the skip connection (gat_skip.py:273-275);
+       all NULL = no BN/ReLU after this layer (last hop, or plain `gat`). */
+    const float* bn_weight;     /* [C]  bns.i.weight */
+    const float* bn_bias;       /* [C]  bns.i.bias */
+    const float* bn_mean;       /* [C]  bns.i.running_mean */
+    const float* bn_var;        /* [C]  bns.i.running_var */
+} gvqa_gat_conv_params;
+
+typedef struct gvqa_gat_dims {
+    int32_t node_dim;    /* Dn: width of x (== out_channels for gat_seq: skip connection)    */
+    int32_t edge_dim;    /* De: width of edge_attr                                            */
+    int32_t ins_dim;     /* Di: width of one instruction vector (0 for a plain `gat` call)    */
+    int32_t out_channels;/* C                                                                 */
+    int32_t heads;       /* H (1, 2, 4 or 8)                                                  */
+    int32_t num_hops;    /* K                                                                 */
+    float negative_slope;
+    float bn_eps;
+} gvqa_gat_dims;
+
+/* gat.forward(x, edge_index, edge_attr) with concat=False (gat_skip.py:111-177): `x` is the
+ * already-concatenated [N, node_dim] input, `edge_attr` the already-concatenated
+ * [E, edge_dim] (COO order).  out [N, C].  alpha_out: NULL or [E, H] in COO edge order
+ * (return_attention_weights, gat_skip.py:170-175).  dims.ins_dim must be 0, num_hops 1.
+ * Works for any graph (no intra-graph requirement). */
+size_t gvqa_gat_conv_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d);
+int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* p,
+                          const float* x, const float* edge_attr, float* out, float* alpha_out,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* gat_seq.forward(x, edge_index, edge_attr, instr_vectors, batch) in eval mode
+ * (gat_skip.py:249-279): K hops of { [h || ins[batch]], [edge_attr || ins[batch[src]]] -> gat ->
+ * + h -> (BN -> ReLU unless last) }.  x [N,Dn], edge_attr [E,De] (COO order), instr [K,B,Di],
+ * out [N,C] (Dn == C).  alpha_out: NULL or [K,E,H].  hop_out: NULL or [K,N,C] (h after every hop).
+ * Requires g->intra_graph (true for any PyG batch); otherwise GVQA_E_UNSUPPORTED and the caller
+ * falls back to K gvqa_gat_conv_forward calls on concatenated inputs. */
+size_t gvqa_gat_seq_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d);
+int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops /* [K], host */,
+                         const float* x, const float* edge_attr, const float* instr,
+                         float* out, float* alpha_out, float* hop_out,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks exported for tests, benchmarks and the variants' host code
+ * ---------------------------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (optionally ReLU) in exact fp32 on the MFMA f32 path.
+ * lda/ldb/ldc in elements.  This is torch.nn.Linear's math (F.linear) for the dense
+ * projections (gat_skip.py:133,150).  bias may be NULL. */
+int gvqa_linear_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                    const float* B, int64_t ldb, const float* bias, int relu,
+                    float* C, int64_t ldc, void* stream);
+
+/* The fused GAT message-passing kernel on its own (SURVEY 2.1 K4-K9 + K11): attention logits
+ * -> leaky-relu -> softmax over incoming edges -> alpha-weighted sum of projected source
+ * features -> head mean -> (+graph term) + bias + skip -> (BN -> ReLU).
+ *   xp        [N, H*C]   projected node features
+ *   a_node    [N, 2H]    (a_l | a_r) per node
+ *   a_edge    base pointer, logit term of COO edge e, head h at a_edge[e*a_edge_stride + h]
+ *   graph_term NULL or [B, graph_term_ld]: per graph, columns [0,C) = mean-over-heads instruction
+ *             projection, columns [C,C+H) = logit offset; graph_term_ld >= C+H, multiple of 4
+ *   skip      NULL or [N, C]
+ * Chooses the LDS-tiled kernel when the graph statistics allow, else the general CSR kernel
+ * (force: 0 = auto, 1 = tiled, 2 = general). */
+int gvqa_gat_message_passing(const gvqa_graph* g, int32_t C, int32_t H, float negative_slope, float bn_eps,
+                             const float* xp, const float* a_node, const float* a_edge, int64_t a_edge_stride,
+                             const float* graph_term, int64_t graph_term_ld, const float* skip,
+                             const gvqa_gat_conv_params* p,
+                             float* out, float* alpha_out, int force,
+                             void* ws /* >= 4*E*H bytes, general kernel only */, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * In-library stage timing (HIP events recorded on the caller's stream around each stage).
+ * Used by bench.py to obtain the message-passing kernel's launch duration inside the timed
+ * region.  Off by default; costs two hipEventRecord per stage when on.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    GVQA_STAGE_GRAPH = 0,      /* CSR build                                   */
+    GVQA_STAGE_FOLD = 1,       /* weight folding (attention vectors, head mean) */
+    GVQA_STAGE_EDGE_LOGIT = 2, /* a_e for all hops (skinny GEMM over edge_attr) */
+    GVQA_STAGE_GRAPH_TERM = 3, /* per-graph instruction terms                  */
+    GVQA_STAGE_PROJ = 4,       /* dense node projection (MFMA GEMM)            */
+    GVQA_STAGE_NODE_LOGIT = 5, /* a_l / a_r                                    */
+    GVQA_STAGE_MP = 6,         /* fused GAT message passing                    */
+    GVQA_STAGE_OTHER = 7,
+    GVQA_NUM_STAGES = 8
+};
+int gvqa_prof_enable(int on);
+/* Waits for outstanding events, ADDS elapsed milliseconds / launch counts per stage into the
+ * arrays (each GVQA_NUM_STAGES long) and clears the internal list. */
+int gvqa_prof_collect(double* ms_by_stage, int64_t* launches_by_stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVQA_H */

@@ -1,0 +1,284 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the golden vectors.  GPU only.
+
+Tolerance: north_star states <= 1e-4 max-abs in fp32 against the reference forward; the tests
+assert that bound against the golden vectors (recorded from the reference's code) and a tighter
+one against the fp64 oracle where sizes allow.
+"""
+import numpy as np
+import pytest
+import torch
+
+from graphvqa_amd import synth
+from tests.util import load_golden, t, tparams, maxabs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _csr_reference(edge_index, N):
+    src, dst = edge_index
+    order = np.lexsort((np.arange(dst.shape[0]), dst))       # by dst, then original edge id
+    rowptr = np.zeros(N + 1, np.int64)
+    np.add.at(rowptr, dst + 1, 1)
+    return np.cumsum(rowptr), src[order], order
+
+
+@pytest.mark.parametrize("maker", ["small", "config2", "hub", "empty_edges"])
+def test_graph_build_matches_numpy(dev, maker):
+    from graphvqa_amd.graph import SceneGraphBatch
+    if maker == "small":
+        gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
+    elif maker == "config2":
+        gb = synth.config2_batch()
+    elif maker == "hub":   # one graph, node 0 receives 3000 edges (exercises the in-row rank sort)
+        E = 3000
+        src = synth.randint(E, 5, 0, 50)
+        ei = np.stack([src, np.zeros(E, np.int64)])
+        gb = synth.GraphBatch(ei, np.zeros(50, np.int64), 1)
+    else:
+        gb = synth.GraphBatch(np.zeros((2, 0), np.int64), np.array([0, 0, 2, 2, 2], np.int64), 4)
+    g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), gb.num_nodes, gb.num_graphs)
+    rowptr, csr_src, eid = _csr_reference(gb.edge_index, gb.num_nodes)
+    assert np.array_equal(g.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(g.csr_eid.cpu().numpy(), eid)
+    assert np.array_equal(g.csr_src.cpu().numpy(), csr_src)
+    gp = np.searchsorted(gb.batch, np.arange(gb.num_graphs + 1))
+    assert np.array_equal(g.graph_ptr.cpu().numpy(), gp)
+    sizes = np.diff(gp)
+    assert g.max_graph_nodes == (sizes.max() if len(sizes) else 0)
+    assert g.max_in_degree == (np.diff(rowptr).max() if gb.num_nodes else 0)
+    assert g.intra_graph
+
+
+def test_graph_contract_violations(dev):
+    from graphvqa_amd.graph import SceneGraphBatch
+    from graphvqa_amd._lib import GvqaError
+    ei = torch.tensor([[0, 1], [1, 7]], device=dev)
+    with pytest.raises(GvqaError):
+        SceneGraphBatch(ei, torch.zeros(3, dtype=torch.int64, device=dev), 3, 1)
+    ei = torch.tensor([[0, 1], [1, 2]], device=dev)
+    with pytest.raises(GvqaError):   # batch not sorted
+        SceneGraphBatch(ei, torch.tensor([1, 0, 1], device=dev), 3, 2)
+    g = SceneGraphBatch(ei, torch.tensor([0, 0, 1], device=dev), 3, 2)
+    assert not g.intra_graph        # edge 1->2 crosses graphs
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (33, 20, 300), (130, 8, 512), (257, 1200, 300), (1000, 2048, 512),
+                                   (64, 129, 37), (4096, 1208, 812)])
+def test_linear_f32(dev, M, N, K):
+    import ctypes as C
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    A = t(synth.normal((M, K), 1), device=dev)
+    B = t(synth.normal((N, K), 2), device=dev)
+    bias = t(synth.normal((N,), 3), device=dev)
+    out = torch.empty((M, N), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gvqa_linear_f32(M, N, K, A.data_ptr(), K, B.data_ptr(), K, bias.data_ptr(), 1, out.data_ptr(), N, st))
+    ref = torch.relu(A.double() @ B.double().T + bias.double())
+    scale = float(ref.abs().max()) + 1.0
+    assert maxabs(out, ref) < 2e-6 * scale * np.sqrt(K)
+    # strided operands (sub-matrix of a wider weight, as the node half of lin_l)
+    if K >= 8:
+        K2 = K // 2 // 4 * 4 or 4
+        out2 = torch.empty((M, N), device=dev)
+        _lib.check(lib.gvqa_linear_f32(M, N, K2, A.data_ptr(), K, B.data_ptr(), K, None, 0, out2.data_ptr(), N, st))
+        ref2 = A[:, :K2].double() @ B[:, :K2].double().T
+        assert maxabs(out2, ref2) < 2e-6 * (float(ref2.abs().max()) + 1) * np.sqrt(K)
+
+
+def _load_module(m, params, dev):
+    sd = {k: t(v) for k, v in params.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return m.to(dev).eval()
+
+
+def test_gat_conv_small_golden(dev):
+    from graphvqa_amd.gat_skip import gat
+    meta, g = load_golden("gat_conv_small")
+    p = synth.gat_seq_params(20, 8, 16, 4, 1, 4, seed=meta["param_seed"])
+    conv = gat(24, 8, 20, heads=4, concat=False, negative_slope=0.2, dropout=0.0, bias=True)
+    _load_module(conv, {k[len("convs.0."):]: v for k, v in p.items() if k.startswith("convs.0.")}, dev)
+    ei = t(g["edge_index"], device=dev)
+    out, (ei2, alpha) = conv(t(g["x"], device=dev), ei, t(g["edge_attr"], device=dev), return_attention_weights=True)
+    assert ei2 is ei
+    assert maxabs(out, g["out"]) < TOL
+    assert maxabs(alpha, g["alpha"]) < 1e-5
+    out_only = conv(t(g["x"], device=dev), ei, t(g["edge_attr"], device=dev))
+    assert torch.equal(out_only, out)      # deterministic, run to run
+
+
+def _run_gat_seq(dev, dims, params, x, ei, ea, ins, batch, **kw):
+    from graphvqa_amd.gat_skip import gat_seq
+    dn, de, di, K, H = dims
+    m = gat_seq(dn, dn, de, di, K, dropout=0.1, gat_heads=H)
+    _load_module(m, params, dev)
+    return m(t(x, device=dev), t(ei, device=dev), t(ea, device=dev), t(ins, device=dev), t(batch, device=dev), **kw)
+
+
+def test_gat_seq_small_golden_all_hops(dev):
+    meta, g = load_golden("gat_seq_small")
+    dims = (meta["dn"], meta["de"], meta["di"], meta["K"], meta["heads"])
+    p = synth.gat_seq_params(dims[0], dims[0], dims[1], dims[2], dims[3], dims[4], seed=meta["param_seed"])
+    out, alpha, hops = _run_gat_seq(dev, dims, p, g["x"], g["edge_index"], g["edge_attr"], g["instr"], g["batch"],
+                                    return_attention_weights=True, return_hops=True)
+    assert maxabs(out, g["out"]) < TOL
+    assert maxabs(hops, g["hs"]) < TOL
+    assert maxabs(alpha, g["alphas"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["gat_seq_debug2_d300", "gat_seq_debug4_d300"])
+def test_gat_seq_real_dims_golden(dev, name):
+    meta, g = load_golden(name)
+    s = meta["input_seeds"]
+    N, E, B = g["batch"].shape[0], g["edge_index"].shape[1], int(g["batch"].max()) + 1
+    x, ea = synth.normal((N, 300), s["x"]), synth.normal((E, 300), s["edge_attr"])
+    ins = synth.normal((5, B, 512), s["instr"])
+    p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=meta["param_seed"])
+    out, alpha, hops = _run_gat_seq(dev, (300, 300, 512, 5, 4), p, x, g["edge_index"], ea, ins, g["batch"],
+                                    return_attention_weights=True, return_hops=True)
+    assert maxabs(out, g["out"]) < TOL
+    assert maxabs(hops, g["hs"]) < TOL
+    assert maxabs(alpha[0], g["alpha0"]) < 1e-5 and maxabs(alpha[4], g["alpha4"]) < 1e-5
+
+
+@pytest.mark.parametrize("H,C", [(1, 16), (2, 24), (4, 100), (8, 8)])
+def test_gat_seq_vs_fp64_oracle_heads(dev, H, C):
+    """Other head counts / widths against the oracle evaluated in float64."""
+    from oracle import ref_torch as R
+    de, di, K = 12, 20, 3
+    gb = synth.make_graph_batch(13, seed=77, nodes_lo=1, nodes_hi=30, rel_per_node=2.0)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=900 + H)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    out = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
+    ref = R.gat_seq(t(x, torch.float64), t(gb.edge_index), t(ea, torch.float64), t(ins, torch.float64),
+                    t(gb.batch), tparams(p, torch.float64), heads=H)
+    assert maxabs(out, ref) < 2e-5
+
+
+def test_tiled_and_general_kernels_agree(dev):
+    """Same inputs through the LDS-tiled and the general CSR kernel (C ABI `force` switch)."""
+    import ctypes as C_
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch
+    lib = _lib.load()
+    H, C = 4, 64
+    gb = synth.make_graph_batch(50, seed=5, nodes_lo=1, nodes_hi=40, rel_per_node=2.0)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
+    xp = t(synth.normal((N, H * C), 1), device=dev)
+    a_node = t(synth.normal((N, 2 * H), 2), device=dev)
+    a_edge = t(synth.normal((E, H), 3), device=dev)
+    T = t(synth.normal((B, C + H), 4), device=dev)
+    skip = t(synth.normal((N, C), 5), device=dev)
+    vec = [t(synth.uniform((C,), 10 + i, 0.5, 1.5), device=dev) for i in range(5)]
+    p = _lib.GatConvParams()
+    p.bias, p.bn_weight, p.bn_bias, p.bn_mean, p.bn_var = [v.data_ptr() for v in vec]
+    outs, alphas = [], []
+    ws = torch.empty(E * H * 4 + 256, dtype=torch.uint8, device=dev)
+    for force in (1, 2):
+        out = torch.empty((N, C), device=dev)
+        alpha = torch.empty((E, H), device=dev)
+        _lib.check(lib.gvqa_gat_message_passing(C_.byref(g.c), C, H, 0.2, 1e-5, xp.data_ptr(), a_node.data_ptr(),
+                                                a_edge.data_ptr(), H, T.data_ptr(), C + H, skip.data_ptr(),
+                                                C_.byref(p), out.data_ptr(), alpha.data_ptr(), force,
+                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        outs.append(out)
+        alphas.append(alpha)
+    assert maxabs(alphas[0], alphas[1]) < 1e-6
+    assert maxabs(outs[0], outs[1]) < 1e-5
+    # softmax property: alpha sums to one over the incoming edges of every node with in-edges
+    s = torch.zeros(N, H, device=dev).index_add_(0, t(gb.edge_index[1], device=dev), alphas[0])
+    deg = torch.bincount(t(gb.edge_index[1], device=dev), minlength=N)
+    assert maxabs(s[deg > 0], torch.ones_like(s[deg > 0])) < 1e-5
+
+
+def test_inter_graph_edges_fall_back_to_unfolded(dev):
+    """An edge crossing graphs (never produced by the reference's collate) must still follow the
+    reference's literal formula (instruction of batch[src] for the edge, batch[n] for nodes)."""
+    from oracle import ref_torch as R
+    H, C, de, di, K = 4, 16, 8, 12, 3
+    gb = synth.make_graph_batch(4, seed=9, nodes_lo=3, nodes_hi=6, rel_per_node=1.0)
+    ei = np.concatenate([gb.edge_index, np.array([[0], [gb.num_nodes - 1]])], axis=1)   # graph 0 -> graph 3
+    N, E, B = gb.num_nodes, ei.shape[1], gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=42)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    out = _run_gat_seq(dev, (C, de, di, K, H), p, x, ei, ea, ins, gb.batch)
+    ref = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(gb.batch), tparams(p), heads=H)
+    assert maxabs(out, ref) < TOL
+
+
+def test_large_single_graph_uses_general_kernel(dev):
+    """One 5000-node graph does not fit an LDS tile: general CSR kernel, same answer as the oracle."""
+    from oracle import ref_torch as R
+    H, C, de, di, K = 4, 32, 8, 12, 2
+    gb = synth.make_graph_batch(1, seed=3, fixed_nodes=5000, fixed_rel=15000)
+    N, E = gb.num_nodes, gb.num_edges
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=43)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, 1, di), 3)
+    out = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
+    ref = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H)
+    assert maxabs(out, ref) < TOL
+
+
+def test_config2_shape_vs_oracle(dev):
+    """BASELINE config 2 (1k graphs, ~30 nodes / ~60 edges, exact reference dims) against the fp32 oracle."""
+    from oracle import ref_torch as R
+    gb = synth.config2_batch()
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303)
+    x, ea, ins = synth.normal((N, 300), 1), synth.normal((E, 300), 2), synth.normal((5, B, 512), 3)
+    out, alpha, _ = _run_gat_seq(dev, (300, 300, 512, 5, 4), p, x, gb.edge_index, ea, ins, gb.batch,
+                                 return_attention_weights=True)
+    ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), return_all=True)
+    assert maxabs(out, ref) < TOL
+    assert maxabs(alpha[4], alphas[4]) < 2e-5
+
+
+def test_config3_full_size_properties(dev):
+    """BASELINE config 3 (64k nodes / 256k edges, d=512): size-independent properties --
+    (1) attention rows sum to one, (2) the result is invariant to a permutation of the COO edge list
+    (features permuted alike), (3) graphs are independent: a sub-batch gives the same rows."""
+    gb = synth.config3_batch()
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    d = 512
+    p = synth.gat_seq_params(d, d, d, d, 5, 4, seed=777)
+    x, ea, ins = synth.normal((N, d), 1), synth.normal((E, d), 2), synth.normal((5, B, d), 3)
+    out, alpha, _ = _run_gat_seq(dev, (d, d, d, 5, 4), p, x, gb.edge_index, ea, ins, gb.batch,
+                                 return_attention_weights=True)
+    assert torch.isfinite(out).all()
+    dst = t(gb.edge_index[1], device=dev)
+    s = torch.zeros(N, 4, device=dev).index_add_(0, dst, alpha[2])
+    assert maxabs(s, torch.ones_like(s)) < 1e-5
+    perm = np.argsort(synth.uniform01(E, 99))
+    out_p = _run_gat_seq(dev, (d, d, d, 5, 4), p, x, gb.edge_index[:, perm], ea[perm], ins, gb.batch)
+    assert maxabs(out, out_p) < 2e-5
+    nb = 64                                    # first 64 graphs on their own
+    nn, ne = nb * 32, int((gb.edge_index[0] < nb * 32).sum())
+    out_s = _run_gat_seq(dev, (d, d, d, 5, 4), p, x[:nn], gb.edge_index[:, :ne], ea[:ne], ins[:, :nb], gb.batch[:nn])
+    assert maxabs(out[:nn], out_s) < 2e-5
+
+
+def test_errors_are_loud(dev):
+    from graphvqa_amd.gat_skip import gat_seq
+    m = gat_seq(8, 8, 8, 8, 2, gat_heads=4).to(dev)
+    x = torch.zeros(3, 8)
+    with pytest.raises(NotImplementedError):
+        m(x.to(dev), torch.zeros(2, 0, dtype=torch.int64, device=dev), torch.zeros(0, 8, device=dev),
+          torch.zeros(2, 1, 8, device=dev), torch.zeros(3, dtype=torch.int64, device=dev))   # train mode
+    m.eval()
+    with pytest.raises(RuntimeError):   # CPU tensor: no fallback
+        m(x, torch.zeros(2, 0, dtype=torch.int64, device=dev), torch.zeros(0, 8, device=dev),
+          torch.zeros(2, 1, 8, device=dev), torch.zeros(3, dtype=torch.int64, device=dev))
+    out = m(x.to(dev), torch.zeros(2, 0, dtype=torch.int64, device=dev), torch.zeros(0, 8, device=dev),
+            torch.zeros(2, 1, 8, device=dev), torch.zeros(3, dtype=torch.int64, device=dev))     # E = 0 works
+    assert out.shape == (3, 8) and torch.isfinite(out).all()
