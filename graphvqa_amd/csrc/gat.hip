@@ -18,6 +18,8 @@
 //   * gather (K4), logits (K5), segment softmax (K6), weighted scatter-add (K8), head mean +
 //     bias (K9), skip + BatchNorm(eval) + ReLU (K11) are ONE kernel per hop; nothing of size
 //     E x H x C ever reaches HBM (the reference writes and re-reads it three times).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gvqa {
@@ -122,7 +124,7 @@ struct MpArgs {
     float* alpha_out;         // NULL or [E, H] COO order
     float* alpha_csr;         // general kernel only: [E, H] in CSR slot order
     int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
-    int e_cap;                // LDS capacity in edges (tiled kernel)
+    int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
     float slope, bn_eps;
 };
 
@@ -152,54 +154,80 @@ __device__ __forceinline__ float4 mp_epilogue(const MpArgs& a, float4 r, int nod
 }
 
 // ----------------------------------------------------------------------------------------------
-// LDS-tiled kernel: one block = one graph x one channel chunk.
+// LDS-tiled streaming kernel: one block = one graph.
 //
 // Scene graphs are small and the batch adjacency is block-diagonal, so every neighbour of a
-// node lives in the same graph: the graph's slice xp[n0:n1, :, c0:c0+cw] is streamed from HBM
-// into LDS exactly once (16 B per lane, fully coalesced row segments), and the E_g x H gathers
-// of K4/K8 are LDS reads.  While those loads are in flight the block computes the attention
-// coefficients of the graph's edges (also in LDS).  HBM traffic = compulsory traffic.
-// grid = (B, ceil(C/cw)); dynamic LDS = [alpha: e_cap*H f32][src_local: e_cap i32][xs: n*H*cw f32].
+// node lives in the same graph.  The block
+//   1. computes the attention coefficients of the graph's edges ONCE (logits -> leaky-relu ->
+//      softmax over incoming edges), kept in LDS together with the local CSR;
+//   2. walks the graph's slab xp[n0:n1, :, :] in stages of (head h, channel range cr): each stage
+//      is an n x cw tile (row segments of cw*4 contiguous bytes) DMA'd HBM -> LDS with
+//      global_load_lds (no VGPR round trip, 16 B per lane), double buffered: stage t+1 is in
+//      flight while stage t is aggregated out of LDS.  Every byte of xp is read from HBM exactly
+//      once; the E x H gathers of K4/K8 are LDS reads; nothing of size E x H x C exists anywhere.
+//   3. after the H head stages of a channel range, a final stage brings the skip rows h[n, cr]
+//      and the epilogue (head mean, per-graph instruction term, bias, skip, BN, ReLU) writes
+//      out[n0:n1, cr] with 16-byte stores.
+// Inside the stage loop there are no ordinary global loads (they would make the compiler drain
+// the DMA queue early): CSR, alpha and the per-channel epilogue constants all live in LDS.
+// grid = B.  dynamic LDS = [alpha e_cap*H][src e_cap][rowptr n_cap+1][consts 4*C][2 stage buffers].
 // ----------------------------------------------------------------------------------------------
+constexpr int MP_ITEMS = 8;     // float4 accumulators per thread (n_cap * cw/4 <= 256 * MP_ITEMS)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
 template <int H>
 __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* alpha_s = reinterpret_cast<float*>(smem);                       // [ne][H]
-    int* src_l = reinterpret_cast<int*>(smem + (size_t)a.e_cap * H * 4);   // [ne]
-    float4* xs4 = reinterpret_cast<float4*>(smem + (((size_t)a.e_cap * (H + 1) * 4 + 15) & ~(size_t)15));
+    const size_t off_src = (size_t)a.e_cap * H * 4;
+    const size_t off_row = (off_src + (size_t)a.e_cap * 4 + 15) & ~(size_t)15;
+    const size_t off_cst = (off_row + (size_t)(a.n_cap + 1) * 4 + 15) & ~(size_t)15;
+    const size_t off_buf = off_cst + (size_t)4 * a.C * 4;
+    float* alpha_s = reinterpret_cast<float*>(smem);
+    int* src_l = reinterpret_cast<int*>(smem + off_src);
+    int* rowp_l = reinterpret_cast<int*>(smem + off_row);
+    float* cst = reinterpret_cast<float*>(smem + off_cst);      // [pbar | bias | scale | shift][C]
+    const size_t buf_bytes = (size_t)a.n_cap * (a.cw >> 2) * 16;
 
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int tn = n1 - n0;
     if (tn <= 0) return;
     const int e0 = a.rowptr[n0], ne = a.rowptr[n1] - e0;
-    const int c0 = blockIdx.y * a.cw;
-    const int q4 = min(a.cw, a.C - c0) >> 2;          // float4 columns of this chunk
     const int tid = threadIdx.x;
-    const int HC = H * a.C;
+    const int wave_unit0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int C = a.C;
+    const int nch = (C + a.cw - 1) / a.cw;
+    const int spc = H + (a.skip ? 1 : 0);            // stages per channel range
+    const int T = nch * spc;
 
-    // ---- phase A: stream the graph's xp slice into LDS (unit = one float4) ----
-    {
-        const int units = tn * H * q4;
-        const float* base = a.xp + (int64_t)n0 * HC + c0;
-        for (int u0 = 0; u0 < units; u0 += 256 * 4) {
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int u = u0 + j * 256 + tid;
-                if (u < units) {
-                    const int row = u / q4, col = u - row * q4;
-                    v[j] = *reinterpret_cast<const float4*>(base + (int64_t)row * a.C + col * 4);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int u = u0 + j * 256 + tid;
-                if (u < units) xs4[u] = v[j];
+    // stage t -> DMA of an [tn x q4c] float4 tile into stage buffer (t & 1)
+    auto prefetch = [&](int t) {
+        const int cr = t / spc, j = t - cr * spc;
+        const int c0 = cr * a.cw;
+        const int q4c = min(a.cw, C - c0) >> 2;
+        const int units = tn * q4c;
+        const float* base;
+        int64_t row_stride;
+        if (j < H) { base = a.xp + ((int64_t)n0 * H + j) * C + c0; row_stride = (int64_t)H * C; }
+        else       { base = a.skip + (int64_t)n0 * C + c0;          row_stride = C; }
+        char* buf = smem + off_buf + (size_t)(t & 1) * buf_bytes;
+        for (int u0 = 0; u0 < units; u0 += 256) {
+            const int u = u0 + tid;
+            if (u < units) {
+                const int row = u / q4c, col = u - row * q4c;
+                const float* gp = base + row * row_stride + col * 4;
+                // LDS destination: wave-uniform base + lane * 16
+                char* lp = buf + (size_t)(u0 + wave_unit0) * 16;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)gp, (lds_ptr_t)lp, 16, 0, 0);
             }
         }
-    }
-    // ---- phase B: per-edge logit terms that do not depend on the destination ----
+    };
+
+    prefetch(0);
+
+    // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
     for (int s = tid; s < ne; s += 256) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
@@ -209,13 +237,26 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
 #pragma unroll
         for (int h = 0; h < H; ++h) alpha_s[s * H + h] = al[h] + ae[h];
     }
+    for (int i = tid; i <= tn; i += 256) rowp_l[i] = a.rowptr[n0 + i] - e0;
+    for (int c = tid; c < C; c += 256) {
+        cst[c] = a.graph_term ? a.graph_term[(int64_t)g * a.t_ld + c] : 0.f;
+        cst[C + c] = a.bias ? a.bias[c] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (a.bn_w) {   // torch's eval BatchNorm: y = x * (w * invstd) + (b - mean * w * invstd)
+            const float invstd = 1.0f / sqrtf(a.bn_v[c] + a.bn_eps);
+            sc = a.bn_w[c] * invstd;
+            sh = a.bn_b[c] - a.bn_m[c] * sc;
+        }
+        cst[2 * C + c] = sc;
+        cst[3 * C + c] = sh;
+    }
     __syncthreads();
-    // ---- phase C: leaky-relu + softmax over the incoming edges of each (node, head) ----
+    // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
     for (int it = tid; it < tn * H; it += 256) {
         const int i = it / H, h = it - i * H;
-        const int lo = a.rowptr[n0 + i] - e0, hi = a.rowptr[n0 + i + 1] - e0;
+        const int lo = rowp_l[i], hi = rowp_l[i + 1];
         float ar = a.a_node[(int64_t)(n0 + i) * 2 * H + H + h];
-        if (a.graph_term) ar += a.graph_term[(int64_t)g * a.t_ld + a.C + h];
+        if (a.graph_term) ar += a.graph_term[(int64_t)g * a.t_ld + C + h];
         float m = -INFINITY;
         for (int s = lo; s < hi; ++s) {
             const float v = leaky(alpha_s[s * H + h] + ar, a.slope);
@@ -232,35 +273,76 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
         for (int s = lo; s < hi; ++s) {
             const float al = alpha_s[s * H + h] / den;
             alpha_s[s * H + h] = al;
-            if (a.alpha_out && blockIdx.y == 0) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+            if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
         }
     }
-    __syncthreads();
-    // ---- phase D: alpha-weighted aggregation out of LDS + fused epilogue ----
+
+    // ---- stage loop ----
+    float4 acc[MP_ITEMS];
+#pragma unroll
+    for (int k = 0; k < MP_ITEMS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_h = 1.0f / H;
-    for (int it = tid; it < tn * q4; it += 256) {
-        const int i = it / q4, q = it - i * q4;
-        const int lo = a.rowptr[n0 + i] - e0, hi = a.rowptr[n0 + i + 1] - e0;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = lo; s < hi; ++s) {
-            const float4* row = xs4 + (size_t)src_l[s] * H * q4 + q;
-            float al[H];
+    const bool relu = a.bn_w != nullptr;
+
+    for (int t = 0; t < T; ++t) {
+        // stage t has landed (own DMA drained, then barrier); everybody is done with stage t-1,
+        // so its buffer may be overwritten by the prefetch of stage t+1.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < T) prefetch(t + 1);
+
+        const int cr = t / spc, j = t - cr * spc;
+        const int c0 = cr * a.cw;
+        const int q4c = min(a.cw, C - c0) >> 2;
+        const int total = tn * q4c;
+        const float4* buf4 = reinterpret_cast<const float4*>(smem + off_buf + (size_t)(t & 1) * buf_bytes);
+        if (j < H) {
 #pragma unroll
-            for (int h = 0; h < H; ++h) al[h] = alpha_s[s * H + h];
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const float4 v = row[h * q4];
-                acc.x += al[h] * v.x; acc.y += al[h] * v.y; acc.z += al[h] * v.z; acc.w += al[h] * v.w;
+            for (int k = 0; k < MP_ITEMS; ++k) {
+                const int it = tid + k * 256;
+                if (it < total) {
+                    const int i = it / q4c, q = it - i * q4c;
+                    const int lo = rowp_l[i], hi = rowp_l[i + 1];
+                    float4 s4 = acc[k];
+                    for (int s = lo; s < hi; ++s) {
+                        const float al = alpha_s[s * H + j];
+                        const float4 v = buf4[src_l[s] * q4c + q];
+                        s4.x += al * v.x; s4.y += al * v.y; s4.z += al * v.z; s4.w += al * v.w;
+                    }
+                    acc[k] = s4;
+                }
             }
         }
-        const int c = c0 + q * 4;
-        float4 r = make_float4(acc.x * inv_h, acc.y * inv_h, acc.z * inv_h, acc.w * inv_h);
-        if (a.graph_term && hi > lo) {
-            const float4 t = *reinterpret_cast<const float4*>(a.graph_term + (int64_t)g * a.t_ld + c);
-            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        if (j == spc - 1) {      // last stage of this channel range: epilogue + store
+#pragma unroll
+            for (int k = 0; k < MP_ITEMS; ++k) {
+                const int it = tid + k * 256;
+                if (it < total) {
+                    const int i = it / q4c, q = it - i * q4c;
+                    const int c = c0 + q * 4;
+                    const bool has_edges = rowp_l[i + 1] > rowp_l[i];
+                    float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
+                    if (has_edges) {
+                        const float4 pb = *reinterpret_cast<const float4*>(cst + c);
+                        r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w;
+                    }
+                    const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
+                    r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
+                    if (a.skip) {
+                        const float4 sk = buf4[i * q4c + q];
+                        r.x += sk.x; r.y += sk.y; r.z += sk.z; r.w += sk.w;
+                    }
+                    if (relu) {
+                        const float4 sc = *reinterpret_cast<const float4*>(cst + 2 * C + c);
+                        const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
+                        r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
+                        r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * C + c) = r;
+                    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
         }
-        r = mp_epilogue(a, r, n0 + i, c);
-        *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.C + c) = r;
     }
 }
 
@@ -322,35 +404,56 @@ __global__ __launch_bounds__(256) void k_gat_aggregate_general(MpArgs a, int H) 
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------
-constexpr size_t LDS_TWO_PER_CU = 80 * 1024;    // 160 KiB / 2 resident blocks
 constexpr size_t LDS_MAX = 160 * 1024;
 
 struct TilePlan {
     bool ok;
-    int cw, nchunks, e_cap;
+    int cw, e_cap, n_cap;
     size_t lds_bytes;
 };
 
+static size_t env_size(const char* name, size_t dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? (size_t)strtoull(v, nullptr, 10) : dflt;
+}
+
+static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw) {
+    size_t off = e_cap * H * 4;
+    off = align_up(off + e_cap * 4, 16);
+    off = align_up(off + (n_cap + 1) * 4, 16);
+    off += (size_t)4 * C * 4;
+    return off + 2 * n_cap * (size_t)(cw / 4) * 16;
+}
+
+// Channel-range width cw (multiple of 4): as wide as possible (longer contiguous row segments
+// per DMA) while the block's LDS stays under the residency target -- first 3 blocks per CU
+// (~53 KiB each: three graphs streaming per CU keeps >= 32 KiB of HBM loads in flight), then 2,
+// then 1 -- and the per-thread accumulator budget holds.  Tunables for experiments:
+// GVQA_MP_CW (force cw), GVQA_MP_LDS (force the per-block LDS target in bytes).
 static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
     TilePlan p{false, 0, 0, 0, 0};
     if (!g->finalized || !g->intra_graph || (C & 3) || !(H == 1 || H == 2 || H == 4 || H == 8)) return p;
     if (g->num_graphs <= 0 || g->num_graphs > 0x7fffffff) return p;
     const size_t e_cap = (size_t)(g->max_graph_edges > 0 ? g->max_graph_edges : 1);
-    const size_t fixed = align_up(e_cap * (H + 1) * 4, 16);
-    const size_t n_max = (size_t)(g->max_graph_nodes > 0 ? g->max_graph_nodes : 1);
-    const int max_chunks = C / 4;
-    size_t best = 0;
-    for (int nch = 1; nch <= max_chunks; ++nch) {
-        const int cw = (int)align_up((size_t)cdiv(C, nch), 4);
-        const size_t bytes = fixed + n_max * H * cw * 4;
-        if (bytes > LDS_MAX) continue;
-        if (best == 0 || bytes <= LDS_TWO_PER_CU) {   // widest that fits at all, then widest with 2 blocks/CU
-            best = bytes;
-            p.cw = cw; p.nchunks = (int)cdiv(C, cw); p.e_cap = (int)e_cap; p.lds_bytes = bytes;
+    const size_t n_cap = (size_t)(g->max_graph_nodes > 0 ? g->max_graph_nodes : 1);
+    const size_t forced_cw = env_size("GVQA_MP_CW", 0);
+    const size_t forced_lds = env_size("GVQA_MP_LDS", 0);
+    const size_t targets[3] = {LDS_MAX / 3, LDS_MAX / 2, LDS_MAX};
+    for (int ti = 0; ti < 3 && !p.ok; ++ti) {
+        const size_t target = forced_lds ? forced_lds : targets[ti];
+        for (int nch = 1; nch <= C / 4; ++nch) {
+            int cw = (int)align_up((size_t)cdiv(C, nch), 4);
+            if (forced_cw) cw = (int)forced_cw;
+            if (n_cap * (size_t)(cw / 4) > 256 * (size_t)MP_ITEMS) continue;
+            const size_t bytes = tiled_lds_bytes(e_cap, n_cap, C, H, cw);
+            if (bytes > target || bytes > LDS_MAX) { if (forced_cw) break; continue; }
+            // below 128 contiguous bytes per row segment the DMA is inefficient: try a larger target
+            if (cw < 32 && cw < C && ti < 2 && !forced_lds && !forced_cw) break;
+            p.ok = true; p.cw = cw; p.e_cap = (int)e_cap; p.n_cap = (int)n_cap; p.lds_bytes = bytes;
+            break;
         }
-        if (bytes <= LDS_TWO_PER_CU) break;
+        if (forced_lds) break;
     }
-    if (best) p.ok = true;
     return p;
 }
 
@@ -362,7 +465,7 @@ static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gat_mp_tiled<H>), dim3((unsigned)B, (unsigned)p.nchunks), dim3(256), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_gat_mp_tiled<H>), dim3((unsigned)B), dim3(256), p.lds_bytes, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -387,7 +490,7 @@ static int launch_gat_mp(const gvqa_graph* g, int C, int H, float slope, float b
     a.graph_term = graph_term; a.t_ld = graph_term_ld; a.skip = skip; a.bias = p->bias;
     a.bn_w = p->bn_weight; a.bn_b = p->bn_bias; a.bn_m = p->bn_mean; a.bn_v = p->bn_var;
     a.out = out; a.alpha_out = alpha_out; a.alpha_csr = nullptr;
-    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.slope = slope; a.bn_eps = bn_eps;
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.slope = slope; a.bn_eps = bn_eps;
 
     StageTimer timer(GVQA_STAGE_MP, stream);
     TilePlan plan = plan_tiled(g, C, H);
@@ -395,7 +498,7 @@ static int launch_gat_mp(const gvqa_graph* g, int C, int H, float slope, float b
                  "gat_mp: tiled kernel not applicable (needs finalized intra-graph batch, C %% 4 == 0, "
                  "H in {1,2,4,8}, largest graph fitting 160 KiB of LDS)");
     if (plan.ok && force != 2) {
-        a.cw = plan.cw; a.e_cap = plan.e_cap;
+        a.cw = plan.cw; a.e_cap = plan.e_cap; a.n_cap = plan.n_cap;
         switch (H) {
             case 1: return launch_tiled<1>(a, plan, g->num_graphs, stream);
             case 2: return launch_tiled<2>(a, plan, g->num_graphs, stream);

@@ -22,12 +22,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // padded leading dimension (floats)
 
-template <int BM, int BN, int WR, int WC>
+template <int BM, int BN, int WR, int WC, bool VEC>
 __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const float* __restrict__ A,
                                                     int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                     const float* __restrict__ bias, int relu,
                                                     float* __restrict__ C, int64_t ldc, int64_t strideA,
-                                                    int64_t strideB, int64_t strideC, int vec_ok) {
+                                                    int64_t strideB, int64_t strideC) {
     static_assert(WR * WC == 4, "4 waves per block");
     constexpr int WM = BM / WR, WN = BN / WC;     // wave tile
     constexpr int MT = WM / 32, NT = WN / 32;     // 32x32 MFMA tiles per wave
@@ -56,69 +56,63 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
 
     float4 ra[A_V4], rb[B_V4];
 
+    // Branch-free tile loads: out-of-range rows / k are CLAMPED to a valid address; the zero-fill of
+    // the K tail is a select applied only when the registers are written to LDS (store_tile), so
+    // that nothing consumes the loaded values -- and forces a vmcnt wait -- before the MFMAs of
+    // the current tile have been issued.  (A branch around a load, or an early select, makes the
+    // prefetch synchronous.)
+    auto load_one = [&](const float* __restrict__ P, int64_t ld, int rows, int gr, int gk) -> float4 {
+        const float* p = P + (int64_t)min(gr, rows - 1) * ld;
+        if (VEC) return *reinterpret_cast<const float4*>(p + min(gk, K - 4));
+        return make_float4(p[min(gk + 0, K - 1)], p[min(gk + 1, K - 1)], p[min(gk + 2, K - 1)],
+                           p[min(gk + 3, K - 1)]);
+    };
+    auto mask_k = [&](float4 v, int gk) -> float4 {
+        if (gk + 0 >= K) v.x = 0.f;
+        if (gk + 1 >= K) v.y = 0.f;
+        if (gk + 2 >= K) v.z = 0.f;
+        if (gk + 3 >= K) v.w = 0.f;
+        return v;
+    };
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            int idx = tid + i * 256;
-            int r = idx >> 3, c4 = (idx & 7) * 4;
-            int gr = m0 + r, gk = k0 + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr < M) {
-                const float* p = A + (int64_t)gr * lda + gk;
-                if (vec_ok && gk + 3 < K) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (gk + 0 < K) v.x = p[0];
-                    if (gk + 1 < K) v.y = p[1];
-                    if (gk + 2 < K) v.z = p[2];
-                    if (gk + 3 < K) v.w = p[3];
-                }
-            }
-            ra[i] = v;
+            const int idx = tid + i * 256;
+            ra[i] = load_one(A, lda, M, m0 + (idx >> 3), k0 + (idx & 7) * 4);
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
-            int idx = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BN * BK / 4) {
-                int r = idx >> 3, c4 = (idx & 7) * 4;
-                int gr = n0 + r, gk = k0 + c4;
-                if (gr < N) {
-                    const float* p = B + (int64_t)gr * ldb + gk;
-                    if (vec_ok && gk + 3 < K) {
-                        v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (gk + 0 < K) v.x = p[0];
-                        if (gk + 1 < K) v.y = p[1];
-                        if (gk + 2 < K) v.z = p[2];
-                        if (gk + 3 < K) v.w = p[3];
-                    }
-                }
-            }
-            rb[i] = v;
+            const int idx = min(tid + i * 256, BN * BK / 4 - 1);
+            rb[i] = load_one(B, ldb, N, n0 + (idx >> 3), k0 + (idx & 7) * 4);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int kt) {
+        const int k0 = kt * BK;
+        const bool tail = k0 + BK > K;      // block-uniform: only the last K tile needs masking
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            int idx = tid + i * 256;
-            int r = idx >> 3, c4 = (idx & 7) * 4;
-            *reinterpret_cast<float4*>(&As[buf][r * LDS_LD + c4]) = ra[i];
+            const int idx = tid + i * 256;
+            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            float4 v = ra[i];
+            if (tail) v = mask_k(v, k0 + c4);
+            *reinterpret_cast<float4*>(&As[buf][r * LDS_LD + c4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
-            int idx = tid + i * 256;
+            const int idx = tid + i * 256;
             if (idx < BN * BK / 4) {
-                int r = idx >> 3, c4 = (idx & 7) * 4;
-                *reinterpret_cast<float4*>(&Bs[buf][r * LDS_LD + c4]) = rb[i];
+                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                float4 v = rb[i];
+                if (tail) v = mask_k(v, k0 + c4);
+                *reinterpret_cast<float4*>(&Bs[buf][r * LDS_LD + c4]) = v;
             }
         }
     };
 
     const int nkt = (K + BK - 1) / BK;
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
@@ -146,7 +140,7 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        if (kt + 1 < nkt) store_tile(cur ^ 1, kt + 1);
         __syncthreads();
     }
 
@@ -179,25 +173,30 @@ int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
     GVQA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1, GVQA_E_INVALID, "linear: negative size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), GVQA_E_INVALID, "linear: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
+    GVQA_REQUIRE(K > 0, GVQA_E_INVALID, "linear: K must be positive");
     GVQA_REQUIRE(cdiv(M, 128) <= 65535, GVQA_E_INVALID, "linear: M too large for one launch");
     GVQA_REQUIRE(A && B && C, GVQA_E_INVALID, "linear: null operand");
     GVQA_REQUIRE(lda >= K && ldb >= K && ldc >= N, GVQA_E_INVALID, "linear: leading dimension too small");
     // 16-byte vector loads need 16-byte aligned rows
-    int vec_ok = (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) &&
-                 ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-    if (N <= 32) {
-        dim3 grid((unsigned)cdiv(N, 32), (unsigned)cdiv(M, 128), (unsigned)batch);
-        hipLaunchKernelGGL((k_linear_f32<128, 32, 4, 1>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A,
-                           lda, B, ldb, bias, relu, C, ldc, strideA, strideB, strideC, vec_ok);
-    } else if (N <= 64) {
-        dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 128), (unsigned)batch);
-        hipLaunchKernelGGL((k_linear_f32<128, 64, 2, 2>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A,
-                           lda, B, ldb, bias, relu, C, ldc, strideA, strideB, strideC, vec_ok);
-    } else {
-        dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch);
-        hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A,
-                           lda, B, ldb, bias, relu, C, ldc, strideA, strideB, strideC, vec_ok);
-    }
+    const bool vec = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
+                     (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+#define GVQA_LAUNCH_LINEAR(BM_, BN_, WR_, WC_)                                                          \
+    do {                                                                                               \
+        dim3 grid((unsigned)cdiv(N, BN_), (unsigned)cdiv(M, BM_), (unsigned)batch);                    \
+        if (vec)                                                                                       \
+            hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, true>), grid, dim3(256), 0, stream,   \
+                               (int)M, (int)N, (int)K, A, lda, B, ldb, bias, relu, C, ldc, strideA,    \
+                               strideB, strideC);                                                      \
+        else                                                                                           \
+            hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, false>), grid, dim3(256), 0, stream,  \
+                               (int)M, (int)N, (int)K, A, lda, B, ldb, bias, relu, C, ldc, strideA,    \
+                               strideB, strideC);                                                      \
+    } while (0)
+    if (N <= 32) GVQA_LAUNCH_LINEAR(128, 32, 4, 1);
+    else if (N <= 64) GVQA_LAUNCH_LINEAR(128, 64, 2, 2);
+    else GVQA_LAUNCH_LINEAR(128, 128, 2, 2);
+#undef GVQA_LAUNCH_LINEAR
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
