@@ -125,6 +125,8 @@ struct MpArgs {
     float* alpha_csr;         // general kernel only: [E, H] in CSR slot order
     int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
     int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
+    int nbuf;                 // stage buffers in LDS (prefetch depth = nbuf - 1)
+    int lpn_log;              // log2(lanes per node) in the aggregation mapping
     float slope, bn_eps;
 };
 
@@ -172,13 +174,27 @@ __device__ __forceinline__ float4 mp_epilogue(const MpArgs& a, float4 r, int nod
 // the DMA queue early): CSR, alpha and the per-channel epilogue constants all live in LDS.
 // grid = B.  dynamic LDS = [alpha e_cap*H][src e_cap][rowptr n_cap+1][consts 4*C][2 stage buffers].
 // ----------------------------------------------------------------------------------------------
-constexpr int MP_ITEMS = 8;     // float4 accumulators per thread (n_cap * cw/4 <= 256 * MP_ITEMS)
+constexpr int MP_THREADS = 512;  // 8 waves: more LDS-latency hiding per resident graph
+constexpr int MP_ITEMS = 4;      // float4 accumulators per thread
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __attribute__((address_space(3))) char* lds_ptr_t;
+
+// LDS-DMA: 16 bytes per lane from `gsrc` (per lane) to LDS byte address `lds_dst` + lane * 16
+// (`lds_dst` wave-uniform, goes through M0).  Inline asm on purpose: a DMA issued through the
+// builtin is tracked by hipcc as a pending LDS write and it then waits vmcnt(0) before every
+// ds_read of the stage buffers, which serialises the pipeline; issued here it is invisible to the
+// compiler and ordered by the counted s_waitcnt + barrier of the stage loop instead.
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
 
 template <int H>
-__global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
+__global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t off_src = (size_t)a.e_cap * H * 4;
     const size_t off_row = (off_src + (size_t)a.e_cap * 4 + 15) & ~(size_t)15;
@@ -188,7 +204,9 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
     int* src_l = reinterpret_cast<int*>(smem + off_src);
     int* rowp_l = reinterpret_cast<int*>(smem + off_row);
     float* cst = reinterpret_cast<float*>(smem + off_cst);      // [pbar | bias | scale | shift][C]
-    const size_t buf_bytes = (size_t)a.n_cap * (a.cw >> 2) * 16;
+    // stage buffers hold whole DMA rounds of MP_THREADS units
+    const size_t buf_bytes = (((size_t)a.n_cap * (a.cw >> 2) + MP_THREADS - 1) / MP_THREADS) * MP_THREADS * 16;
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
 
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
@@ -201,8 +219,13 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
     const int nch = (C + a.cw - 1) / a.cw;
     const int spc = H + (a.skip ? 1 : 0);            // stages per channel range
     const int T = nch * spc;
+    const int q4cap = a.cw >> 2;
+    const int dma_round_rows = MP_THREADS / q4cap, dma_round_cols = MP_THREADS - dma_round_rows * q4cap;
+    const int dma_row0 = tid / q4cap, dma_col0 = tid - dma_row0 * q4cap;   // unit `tid` of a full-width range
 
-    // stage t -> DMA of an [tn x q4c] float4 tile into stage buffer (t & 1)
+    // stage t -> DMA of a [tn x q4c] float4 tile (row segments of q4c*16 contiguous bytes) into
+    // stage buffer t % nbuf.  Every wave issues the same number of DMAs per stage (lanes past the
+    // end re-load the last unit into the buffer's padding), so the counted vmcnt below is exact.
     auto prefetch = [&](int t) {
         const int cr = t / spc, j = t - cr * spc;
         const int c0 = cr * a.cw;
@@ -212,23 +235,26 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
         int64_t row_stride;
         if (j < H) { base = a.xp + ((int64_t)n0 * H + j) * C + c0; row_stride = (int64_t)H * C; }
         else       { base = a.skip + (int64_t)n0 * C + c0;          row_stride = C; }
-        char* buf = smem + off_buf + (size_t)(t & 1) * buf_bytes;
-        for (int u0 = 0; u0 < units; u0 += 256) {
-            const int u = u0 + tid;
-            if (u < units) {
-                const int row = u / q4c, col = u - row * q4c;
-                const float* gp = base + row * row_stride + col * 4;
-                // LDS destination: wave-uniform base + lane * 16
-                char* lp = buf + (size_t)(u0 + wave_unit0) * 16;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)gp, (lds_ptr_t)lp, 16, 0, 0);
-            }
+        unsigned dst = lds_base + (unsigned)(off_buf + (size_t)(t % a.nbuf) * buf_bytes) + (unsigned)wave_unit0 * 16u;
+        int row, col, rstep, cstep;
+        if (q4c == q4cap) { row = dma_row0; col = dma_col0; rstep = dma_round_rows; cstep = dma_round_cols; }
+        else { row = tid / q4c; col = tid - row * q4c; rstep = MP_THREADS / q4c; cstep = MP_THREADS - rstep * q4c; }
+        const int last_row = tn - 1, last_col = q4c - 1;
+        for (int u0 = 0; u0 < units; u0 += MP_THREADS) {
+            const bool in = row < tn;
+            const int r = in ? row : last_row, c = in ? col : last_col;
+            lds_dma16(base + r * row_stride + c * 4, __builtin_amdgcn_readfirstlane(dst));
+            dst += MP_THREADS * 16;
+            row += rstep; col += cstep;
+            if (col >= q4c) { col -= q4c; ++row; }
         }
     };
 
-    prefetch(0);
+    const int depth = a.nbuf - 1;
+    for (int t = 0; t < depth && t < T; ++t) prefetch(t);
 
     // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
-    for (int s = tid; s < ne; s += 256) {
+    for (int s = tid; s < ne; s += MP_THREADS) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
         src_l[s] = src - n0;
@@ -237,8 +263,8 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
 #pragma unroll
         for (int h = 0; h < H; ++h) alpha_s[s * H + h] = al[h] + ae[h];
     }
-    for (int i = tid; i <= tn; i += 256) rowp_l[i] = a.rowptr[n0 + i] - e0;
-    for (int c = tid; c < C; c += 256) {
+    for (int i = tid; i <= tn; i += MP_THREADS) rowp_l[i] = a.rowptr[n0 + i] - e0;
+    for (int c = tid; c < C; c += MP_THREADS) {
         cst[c] = a.graph_term ? a.graph_term[(int64_t)g * a.t_ld + c] : 0.f;
         cst[C + c] = a.bias ? a.bias[c] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
     }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
-    for (int it = tid; it < tn * H; it += 256) {
+    for (int it = tid; it < tn * H; it += MP_THREADS) {
         const int i = it / H, h = it - i * H;
         const int lo = rowp_l[i], hi = rowp_l[i + 1];
         float ar = a.a_node[(int64_t)(n0 + i) * 2 * H + H + h];
@@ -278,68 +304,110 @@ __global__ __launch_bounds__(256) void k_gat_mp_tiled(MpArgs a) {
     }
 
     // ---- stage loop ----
+    // Work item = (node i, float4 column q).  A node's columns sit on `lpn` consecutive lanes
+    // (power of two >= cw/4, so the (i, q) split is shifts only); a thread walks nodes
+    // i = tid / lpn + k * (MP_THREADS / lpn).
+    const int lpn_log = a.lpn_log, lpn = 1 << lpn_log;
+    const int q = tid & (lpn - 1), i_base = tid >> lpn_log, i_step = MP_THREADS >> lpn_log;
     float4 acc[MP_ITEMS];
 #pragma unroll
     for (int k = 0; k < MP_ITEMS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_h = 1.0f / H;
     const bool relu = a.bn_w != nullptr;
 
+    auto dma_count = [&](int t) -> int {     // DMA instructions per wave for stage t
+        if (t >= T) return 0;
+        const int cr = t / spc;
+        return (tn * (min(a.cw, C - cr * a.cw) >> 2) + MP_THREADS - 1) / MP_THREADS;
+    };
+
     for (int t = 0; t < T; ++t) {
-        // stage t has landed (own DMA drained, then barrier); everybody is done with stage t-1,
-        // so its buffer may be overwritten by the prefetch of stage t+1.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < T) prefetch(t + 1);
+        // Wait until stage t has landed: this wave's DMAs of stage t are older than those of stages
+        // t+1 .. t+depth-1, loads retire in order, so "at most N outstanding" with N = the younger
+        // stages' DMA count covers it (output stores, if any, only make the wait stricter).  Then a
+        // raw barrier (no compiler fence, which would drain the whole DMA queue): every wave's
+        // part of stage t is in LDS, and everybody is done computing stage t-1, whose buffer the
+        // prefetch of stage t+depth overwrites.
+        int allow = 0;
+        for (int k = 1; k < depth; ++k) allow += dma_count(t + k);
+        switch (allow) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + depth < T) prefetch(t + depth);
 
         const int cr = t / spc, j = t - cr * spc;
         const int c0 = cr * a.cw;
         const int q4c = min(a.cw, C - c0) >> 2;
-        const int total = tn * q4c;
-        const float4* buf4 = reinterpret_cast<const float4*>(smem + off_buf + (size_t)(t & 1) * buf_bytes);
-        if (j < H) {
+        const float4* buf4 = reinterpret_cast<const float4*>(smem + off_buf + (size_t)(t % a.nbuf) * buf_bytes);
+        if (q < q4c) {
+            if (j < H) {
 #pragma unroll
-            for (int k = 0; k < MP_ITEMS; ++k) {
-                const int it = tid + k * 256;
-                if (it < total) {
-                    const int i = it / q4c, q = it - i * q4c;
-                    const int lo = rowp_l[i], hi = rowp_l[i + 1];
-                    float4 s4 = acc[k];
-                    for (int s = lo; s < hi; ++s) {
-                        const float al = alpha_s[s * H + j];
-                        const float4 v = buf4[src_l[s] * q4c + q];
-                        s4.x += al * v.x; s4.y += al * v.y; s4.z += al * v.z; s4.w += al * v.w;
+                for (int k = 0; k < MP_ITEMS; ++k) {
+                    const int i = i_base + k * i_step;
+                    if (i < tn) {
+                        const int lo = rowp_l[i], hi = rowp_l[i + 1];
+                        float4 s4 = acc[k];
+                        // four edges per trip, branch-free (clamped index, zero weight for padding):
+                        // the 8 scalar and 4 vector LDS reads issue back to back instead of
+                        // forming one dependent chain per edge
+                        for (int s = lo; s < hi; s += 4) {
+                            int sl[4];
+                            float al[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int idx = min(s + e, hi - 1);
+                                sl[e] = src_l[idx];
+                                al[e] = (s + e < hi) ? alpha_s[idx * H + j] : 0.f;
+                            }
+                            float4 v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = buf4[sl[e] * q4c + q];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                s4.x += al[e] * v[e].x; s4.y += al[e] * v[e].y;
+                                s4.z += al[e] * v[e].z; s4.w += al[e] * v[e].w;
+                            }
+                        }
+                        acc[k] = s4;
                     }
-                    acc[k] = s4;
                 }
             }
-        }
-        if (j == spc - 1) {      // last stage of this channel range: epilogue + store
+            if (j == spc - 1) {      // last stage of this channel range: epilogue + store
+                const int c = c0 + q * 4;
+                const float4 pb = *reinterpret_cast<const float4*>(cst + c);
+                const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
+                const float4 sc = *reinterpret_cast<const float4*>(cst + 2 * C + c);
+                const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
 #pragma unroll
-            for (int k = 0; k < MP_ITEMS; ++k) {
-                const int it = tid + k * 256;
-                if (it < total) {
-                    const int i = it / q4c, q = it - i * q4c;
-                    const int c = c0 + q * 4;
-                    const bool has_edges = rowp_l[i + 1] > rowp_l[i];
-                    float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
-                    if (has_edges) {
-                        const float4 pb = *reinterpret_cast<const float4*>(cst + c);
-                        r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w;
+                for (int k = 0; k < MP_ITEMS; ++k) {
+                    const int i = i_base + k * i_step;
+                    if (i < tn) {
+                        const bool has_edges = rowp_l[i + 1] > rowp_l[i];
+                        float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
+                        if (has_edges) { r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w; }
+                        r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
+                        if (a.skip) {
+                            const float4 sk = buf4[i * q4c + q];
+                            r.x += sk.x; r.y += sk.y; r.z += sk.z; r.w += sk.w;
+                        }
+                        if (relu) {
+                            r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
+                            r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
+                        }
+                        *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * C + c) = r;
+                        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
-                    r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
-                    if (a.skip) {
-                        const float4 sk = buf4[i * q4c + q];
-                        r.x += sk.x; r.y += sk.y; r.z += sk.z; r.w += sk.w;
-                    }
-                    if (relu) {
-                        const float4 sc = *reinterpret_cast<const float4*>(cst + 2 * C + c);
-                        const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
-                        r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
-                        r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
-                    }
-                    *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * C + c) = r;
-                    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -408,7 +476,7 @@ constexpr size_t LDS_MAX = 160 * 1024;
 
 struct TilePlan {
     bool ok;
-    int cw, e_cap, n_cap;
+    int cw, e_cap, n_cap, nbuf, lpn_log;
     size_t lds_bytes;
 };
 
@@ -417,40 +485,54 @@ static size_t env_size(const char* name, size_t dflt) {
     return (v && *v) ? (size_t)strtoull(v, nullptr, 10) : dflt;
 }
 
-static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw) {
+static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, int nbuf) {
     size_t off = e_cap * H * 4;
     off = align_up(off + e_cap * 4, 16);
     off = align_up(off + (n_cap + 1) * 4, 16);
     off += (size_t)4 * C * 4;
-    return off + 2 * n_cap * (size_t)(cw / 4) * 16;
+    return off + (size_t)nbuf * align_up(n_cap * (size_t)(cw / 4), MP_THREADS) * 16;
 }
 
-// Channel-range width cw (multiple of 4): as wide as possible (longer contiguous row segments
-// per DMA) while the block's LDS stays under the residency target -- first 3 blocks per CU
-// (~53 KiB each: three graphs streaming per CU keeps >= 32 KiB of HBM loads in flight), then 2,
-// then 1 -- and the per-thread accumulator budget holds.  Tunables for experiments:
-// GVQA_MP_CW (force cw), GVQA_MP_LDS (force the per-block LDS target in bytes).
+// Stage geometry.  HBM streaming is latency-bound per CU (Little: ~25 GB/s/CU x ~3 us loaded latency
+// ~ 80 KB in flight), so the plan maximises bytes in flight per CU = blocks/CU x (nbuf-1) x stage
+// bytes: per-block LDS target 160 KiB / 3, up to 4 stage buffers, channel range cw as wide as
+// fits (row segments of >= 256 B preferred, >= 128 B required unless C is smaller), subject to the
+// per-thread accumulator budget.  If nothing fits the 3-per-CU target, 2 then 1 per CU.
+// Tunables for experiments: GVQA_MP_CW, GVQA_MP_NBUF, GVQA_MP_LDS (bytes per block).
 static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
-    TilePlan p{false, 0, 0, 0, 0};
+    TilePlan p{false, 0, 0, 0, 0, 0, 0};
     if (!g->finalized || !g->intra_graph || (C & 3) || !(H == 1 || H == 2 || H == 4 || H == 8)) return p;
     if (g->num_graphs <= 0 || g->num_graphs > 0x7fffffff) return p;
     const size_t e_cap = (size_t)(g->max_graph_edges > 0 ? g->max_graph_edges : 1);
     const size_t n_cap = (size_t)(g->max_graph_nodes > 0 ? g->max_graph_nodes : 1);
     const size_t forced_cw = env_size("GVQA_MP_CW", 0);
+    const size_t forced_nbuf = env_size("GVQA_MP_NBUF", 2);   // measured: deeper prefetch does not pay
     const size_t forced_lds = env_size("GVQA_MP_LDS", 0);
     const size_t targets[3] = {LDS_MAX / 3, LDS_MAX / 2, LDS_MAX};
     for (int ti = 0; ti < 3 && !p.ok; ++ti) {
-        const size_t target = forced_lds ? forced_lds : targets[ti];
-        for (int nch = 1; nch <= C / 4; ++nch) {
-            int cw = (int)align_up((size_t)cdiv(C, nch), 4);
-            if (forced_cw) cw = (int)forced_cw;
-            if (n_cap * (size_t)(cw / 4) > 256 * (size_t)MP_ITEMS) continue;
-            const size_t bytes = tiled_lds_bytes(e_cap, n_cap, C, H, cw);
-            if (bytes > target || bytes > LDS_MAX) { if (forced_cw) break; continue; }
-            // below 128 contiguous bytes per row segment the DMA is inefficient: try a larger target
-            if (cw < 32 && cw < C && ti < 2 && !forced_lds && !forced_cw) break;
-            p.ok = true; p.cw = cw; p.e_cap = (int)e_cap; p.n_cap = (int)n_cap; p.lds_bytes = bytes;
-            break;
+        const size_t target = forced_lds ? (forced_lds < LDS_MAX ? forced_lds : LDS_MAX) : targets[ti];
+        size_t best_score = 0;
+        for (int nbuf = 2; nbuf <= 4; ++nbuf) {
+            if (forced_nbuf && (size_t)nbuf != forced_nbuf) continue;
+            for (int nch = 1; nch <= C / 4; ++nch) {
+                int cw = (int)align_up((size_t)cdiv(C, nch), 4);
+                if (forced_cw) cw = (int)forced_cw;
+                int lpn_log = 0;
+                while ((1 << lpn_log) < cw / 4) ++lpn_log;
+                if (cw > C || (1 << lpn_log) > MP_THREADS ||
+                    n_cap > (size_t)MP_ITEMS * (MP_THREADS >> lpn_log)) { if (forced_cw) break; continue; }
+                const size_t bytes = tiled_lds_bytes(e_cap, n_cap, C, H, cw, nbuf);
+                if (bytes > target) { if (forced_cw) break; continue; }
+                if (cw < 32 && cw < C && ti < 2 && !forced_cw) break;        // segments < 128 B: next target
+                size_t score = (size_t)(nbuf - 1) * n_cap * cw * 4;           // bytes in flight per block
+                if (cw < 64 && cw < C) score /= 2;                            // < 256 B segments: penalise
+                if (score > best_score) {
+                    best_score = score;
+                    p.ok = true; p.cw = cw; p.e_cap = (int)e_cap; p.n_cap = (int)n_cap; p.nbuf = nbuf; p.lpn_log = lpn_log;
+                    p.lds_bytes = bytes;
+                }
+                break;      // widest cw for this nbuf found
+            }
         }
         if (forced_lds) break;
     }
@@ -465,7 +547,7 @@ static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gat_mp_tiled<H>), dim3((unsigned)B), dim3(256), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_gat_mp_tiled<H>), dim3((unsigned)B), dim3(MP_THREADS), p.lds_bytes, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -490,7 +572,7 @@ static int launch_gat_mp(const gvqa_graph* g, int C, int H, float slope, float b
     a.graph_term = graph_term; a.t_ld = graph_term_ld; a.skip = skip; a.bias = p->bias;
     a.bn_w = p->bn_weight; a.bn_b = p->bn_bias; a.bn_m = p->bn_mean; a.bn_v = p->bn_var;
     a.out = out; a.alpha_out = alpha_out; a.alpha_csr = nullptr;
-    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.slope = slope; a.bn_eps = bn_eps;
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0; a.slope = slope; a.bn_eps = bn_eps;
 
     StageTimer timer(GVQA_STAGE_MP, stream);
     TilePlan plan = plan_tiled(g, C, H);
@@ -498,7 +580,7 @@ static int launch_gat_mp(const gvqa_graph* g, int C, int H, float slope, float b
                  "gat_mp: tiled kernel not applicable (needs finalized intra-graph batch, C %% 4 == 0, "
                  "H in {1,2,4,8}, largest graph fitting 160 KiB of LDS)");
     if (plan.ok && force != 2) {
-        a.cw = plan.cw; a.e_cap = plan.e_cap; a.n_cap = plan.n_cap;
+        a.cw = plan.cw; a.e_cap = plan.e_cap; a.n_cap = plan.n_cap; a.nbuf = plan.nbuf; a.lpn_log = plan.lpn_log;
         switch (H) {
             case 1: return launch_tiled<1>(a, plan, g->num_graphs, stream);
             case 2: return launch_tiled<2>(a, plan, g->num_graphs, stream);
