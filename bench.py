@@ -39,27 +39,45 @@ def mp_algorithmic_bytes(N, E, C, Hh):
 
 def cpu_baseline(params):
     """The oracle (a torch-CPU restatement of the reference's op sequence) timed on the host cores on
-    a bounded sample of the same workload: the first 128 graphs (4096 nodes / 16384 edges)."""
+    a bounded sample of the same workload.  torch's CPU scatter/gather ops oversubscribe badly at
+    the box's full thread count (256 threads: 100x slower than 16), so the thread count is chosen by
+    a quick sweep on a 32-graph sample and reported as `cores`."""
     from oracle import ref_torch as R   # baseline leg only
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    nb = 128
-    gb = synth.config3_batch(nb)
-    N, E = gb.num_nodes, gb.num_edges
-    x, ea, ins = synth.normal((N, D), 11), synth.normal((E, D), 12), synth.normal((K, nb, D), 13)
     p = {k: tt(v) for k, v in params.items()}
-    args = (tt(x), tt(gb.edge_index), tt(ea), tt(ins), tt(gb.batch), p)
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and time.perf_counter() - t_all < 25.0:
+
+    def make(nb):
+        gb = synth.config3_batch(nb)
+        N, E = gb.num_nodes, gb.num_edges
+        return E, N, (tt(synth.normal((N, D), 11)), tt(gb.edge_index), tt(synth.normal((E, D), 12)),
+                      tt(synth.normal((K, nb, D), 13)), tt(gb.batch), p)
+
+    def run(args):
         t0 = time.perf_counter()
         with torch.no_grad():
             R.gat_seq(*args, heads=H)
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    _, _, small = make(32)
+    best_t, best_th = None, 1
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        run(small)
+        dt = run(small)
+        if best_t is None or dt < best_t:
+            best_t, best_th = dt, th
+    torch.set_num_threads(best_th)
+    nb = 1024                                   # half the GPU workload: ~7-10 s per forward
+    E, N, args = make(nb)
+    times = [run(args)]
+    if times[0] < 12.0:
+        times.append(run(args))
     best = min(times)
-    return {"value": E / best, "unit": "edges/s", "cores": cores, "kind": "port",
+    return {"value": E / best, "unit": "edges/s", "cores": best_th, "kind": "port",
+            "host_cpus": ncpu,
             "sample": f"oracle/ref_torch.gat_seq on {nb} graphs ({N} nodes / {E} edges), d={D}, K={K}, "
-                      f"fp32, best of {len(times)} forwards ({best:.2f} s)"}
+                      f"fp32, best of {len(times)} forwards ({best:.2f} s), {best_th} torch threads "
+                      f"(best of 8/16/32/64 on a 32-graph sample)"}
 
 
 def main():

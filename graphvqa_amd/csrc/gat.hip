@@ -60,14 +60,17 @@ __global__ __launch_bounds__(256) void k_fold_att(FoldArgs a) {
         if (which < 2) {
             const float* W = a.W_l[hop];
             const float* att = which == 0 ? a.att_l[hop] : a.att_r[hop];
+#pragma unroll 8
             for (int c = c_lo; c < c_hi; ++c) acc += W[(int64_t)(h * a.C + c) * ldl + k] * att[h * a.C + c];
         } else if (which == 2) {
             const float* W = a.W_e[hop];
             const float* att = a.att_e[hop];
+#pragma unroll 8
             for (int c = c_lo; c < c_hi; ++c) acc += W[(int64_t)(h * a.C + c) * lde + k] * att[h * a.C + c];
         } else {
             const float* Wl = a.W_l[hop];
             const float* We = a.W_e[hop];
+#pragma unroll 4
             for (int c = c_lo; c < c_hi; ++c) {
                 const int r = h * a.C + c;
                 const float wl = Wl[(int64_t)r * ldl + a.Dn + k];

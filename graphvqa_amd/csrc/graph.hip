@@ -147,14 +147,28 @@ __global__ __launch_bounds__(256) void k_rank_rows(int64_t N, int64_t E, const i
     csr_src[pos] = (int32_t)edge_index[e];
 }
 
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// One atomic per wave and statistic (a per-thread atomicMax on three words serialises the chip).
 __global__ __launch_bounds__(256) void k_stats(int64_t N, int64_t B, const int32_t* __restrict__ rowptr,
                                                const int32_t* __restrict__ graph_ptr, int32_t* stats) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) atomicMax(&stats[ST_MAX_DEG], rowptr[i + 1] - rowptr[i]);
+    int deg = 0, gn = 0, ge = 0;
+    if (i < N) deg = rowptr[i + 1] - rowptr[i];
     if (i < B) {
         int n0 = graph_ptr[i], n1 = graph_ptr[i + 1];
-        atomicMax(&stats[ST_MAX_GNODES], n1 - n0);
-        atomicMax(&stats[ST_MAX_GEDGES], rowptr[n1] - rowptr[n0]);
+        gn = n1 - n0;
+        ge = rowptr[n1] - rowptr[n0];
+    }
+    deg = wave_max(deg); gn = wave_max(gn); ge = wave_max(ge);
+    if ((threadIdx.x & 63) == 0) {
+        if (deg > 0) atomicMax(&stats[ST_MAX_DEG], deg);
+        if (gn > 0) atomicMax(&stats[ST_MAX_GNODES], gn);
+        if (ge > 0) atomicMax(&stats[ST_MAX_GEDGES], ge);
     }
 }
 
