@@ -32,9 +32,22 @@ def tt(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def mp_algorithmic_bytes(N, E, C, Hh):
-    """compulsory traffic of the fused message-passing kernel per launch (hop)."""
-    return 4 * (N * Hh * C + 2 * N * Hh + E * Hh + E + (N + 1) + N * C)
+def mp_algorithmic_bytes(N, E, C, Hh, fused_skip=True):
+    """compulsory traffic of the fused message-passing kernel per launch (hop):
+    xp once + a_l/a_r + a_e + CSR + out, plus 4*N*C for reading h when the skip/BN/ReLU epilogue is
+    fused into the kernel (it is), exactly as 8(d) prescribes."""
+    b = 4 * (N * Hh * C + 2 * N * Hh + E * Hh + E + (N + 1) + N * C)
+    return b + (4 * N * C if fused_skip else 0)
+
+
+def measured_traffic():
+    """HBM bytes per launch of the message-passing kernel from the committed PMC passes
+    (profiles/r01_pmc_hbm_cfg3.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_cfg3.json")) as f:
+            return json.load(f)["k_gat_mp_tiled<4>"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(params):
@@ -149,6 +162,7 @@ def main():
         mp_ms, mp_n = prof["mp"]
         mp_avg_s = mp_ms / max(mp_n, 1) * 1e-3
         alg = mp_algorithmic_bytes(N, E, D, H)
+        alg_base = mp_algorithmic_bytes(N, E, D, H, fused_skip=False)
         achieved = alg / mp_avg_s / 1e9 if mp_n else None
         res = {
             "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
@@ -164,7 +178,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_gat_mp_tiled<4>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "traffic": measured_traffic(), "algorithmic_bytes_per_launch": alg,
+                         "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
                          "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
             "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
         }
