@@ -48,6 +48,30 @@ class GatConvParams(C.Structure):
                  "bn_weight", "bn_bias", "bn_mean", "bn_var")]
 
 
+class GatMpDesc(C.Structure):
+    """Mirror of `struct gvqa_gat_mp_desc`."""
+    _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("negative_slope", C.c_float), ("bn_eps", C.c_float),
+                ("xp", C.c_void_p), ("xp_ld", C.c_int64), ("a_node", C.c_void_p), ("a_edge", C.c_void_p),
+                ("a_edge_stride", C.c_int64), ("graph_term", C.c_void_p), ("graph_term_ld", C.c_int64),
+                ("graph_scale", C.c_void_p), ("graph_scale_ld", C.c_int64), ("skip", C.c_void_p),
+                ("skip_ld", C.c_int64), ("bias", C.c_void_p), ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p),
+                ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int64),
+                ("alpha_out", C.c_void_p), ("force", C.c_int32)]
+
+
+class BnParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("weight", "bias", "mean", "var")]
+
+
+class GineParams(C.Structure):
+    _fields_ = [("nn0_weight", C.c_void_p), ("nn0_bias", C.c_void_p), ("nn2_weight", C.c_void_p),
+                ("nn2_bias", C.c_void_p), ("eps", C.c_float)]
+
+
+class GcnParams(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
 class GatDims(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
                 ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
@@ -72,10 +96,20 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_linear_f32": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
-    "gvqa_gat_message_passing": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                           C.c_int64, C.c_void_p, C.POINTER(GatConvParams), C.c_void_p,
-                                           C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_linear_f32_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_gat_message_passing": (C.c_int, [C.POINTER(Graph), C.POINTER(GatMpDesc), C.c_void_p, C.c_size_t,
+                                           C.c_void_p]),
+    "gvqa_bn_relu_chain": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(BnParams), C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "gvqa_gine_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32]),
+    "gvqa_gine_conv_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.POINTER(GineParams),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "gvqa_gcn_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32]),
+    "gvqa_gcn_conv_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.POINTER(GcnParams),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -1,0 +1,207 @@
+"""MI355X-native drop-ins for the GINE / GCN execution modules of the reference's baselines.
+
+Mirrors `gine_seq` (baseline_and_test_models/pipeline_model_gine.py:622-674) and `gcn_seq`
+(pipeline_model_gcn.py:622-669): same constructor arguments, forward signatures and state_dict
+keys (`convs.i.nn.{0,2}.{weight,bias}`, `convs.i.eps`, `convs.i.weight` [in, out], `convs.i.bias`,
+`bns.j.*`).
+
+Faithful to the reference AS WRITTEN: both forwards compute `conv_res` and never use it, so the
+module output is `x` pushed through 4 x (eval BatchNorm, ReLU) -- one HIP kernel here.  The conv
+layers themselves (the kernel-level target) are exposed through
+`forward(..., return_convs=True)` and as `GINEConv` / `GCNConv` modules.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import Tensor
+from torch.nn import Linear, Parameter, ReLU, Sequential
+
+from . import _lib
+from .gat_skip import _f32c, _workspace, _glorot
+from .graph import SceneGraphBatch, _stream
+
+
+class GINEConv(torch.nn.Module):
+    """PyG `GINEConv(nn, eps=0, train_eps=False)` with nn = Seq(Lin, ReLU, Lin) on the HIP path."""
+
+    def __init__(self, nn: Sequential, eps: float = 0.0, train_eps: bool = False):
+        super().__init__()
+        _lib.load()
+        if not (len(nn) == 3 and isinstance(nn[0], Linear) and isinstance(nn[1], ReLU) and isinstance(nn[2], Linear)):
+            raise NotImplementedError("GINEConv on the HIP path supports nn = Sequential(Linear, ReLU, Linear) "
+                                      "(pipeline_model_gine.py:628)")
+        self.nn = nn
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = Parameter(torch.tensor([eps]))
+        else:
+            self.register_buffer("eps", torch.tensor([eps]))
+
+    def _params(self):
+        p = _lib.GineParams()
+        p.nn0_weight = _f32c(self.nn[0].weight, "nn.0.weight").data_ptr()
+        p.nn0_bias = _f32c(self.nn[0].bias, "nn.0.bias").data_ptr()
+        p.nn2_weight = _f32c(self.nn[2].weight, "nn.2.weight").data_ptr()
+        p.nn2_bias = _f32c(self.nn[2].bias, "nn.2.bias").data_ptr()
+        p.eps = float(self.eps.item()) if isinstance(self.eps, Parameter) else self.initial_eps
+        return p
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor, size=None, graph=None,
+                ins: Tensor | None = None):
+        """x [N, D], edge_attr [E, D] (PyG requires equal widths).  With `ins` [B, Di] (and an
+        intra-graph `graph`), x / edge_attr are the node / edge halves and the instruction halves
+        are handled per graph without concatenation."""
+        lib = _lib.load()
+        x, edge_attr = _f32c(x, "x"), _f32c(edge_attr, "edge_attr")
+        if x.shape[1] != edge_attr.shape[1]:
+            raise AssertionError("GINEConv: node and edge feature widths must match")
+        N = x.shape[0]
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, None, N, 1)
+        Dn, Di = x.shape[1], 0 if ins is None else ins.shape[1]
+        Cc = self.nn[2].weight.shape[0]
+        if self.nn[0].weight.shape[1] != Dn + Di:
+            raise ValueError("feature width does not match the layer")
+        p = self._params()
+        out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = _workspace(lib.gvqa_gine_conv_workspace_bytes(C.byref(graph.c), Dn, Di, Cc), x.device)
+            _lib.check(lib.gvqa_gine_conv_forward(C.byref(graph.c), Dn, Di, Cc, C.byref(p), x.data_ptr(),
+                                                  edge_attr.data_ptr(), None if ins is None else _f32c(ins, "ins").data_ptr(),
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
+        return out
+
+
+class GCNConv(torch.nn.Module):
+    """PyG 1.6/1.7 `GCNConv(in, out)` (weight [in, out], add_remaining_self_loops, symmetric norm)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__()
+        _lib.load()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _glorot(self.weight)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight=None, graph=None, ins: Tensor | None = None):
+        if edge_weight is not None:
+            raise NotImplementedError("edge weights are not used by GraphVQA (pipeline_model_gcn.py:660)")
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        N = x.shape[0]
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, None, N, 1)
+        Dn, Di = x.shape[1], 0 if ins is None else ins.shape[1]
+        if Dn + Di != self.in_channels:
+            raise ValueError("feature width does not match the layer")
+        p = _lib.GcnParams(_f32c(self.weight, "weight").data_ptr(),
+                           None if self.bias is None else _f32c(self.bias, "bias").data_ptr())
+        out = torch.empty((N, self.out_channels), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = _workspace(lib.gvqa_gcn_conv_workspace_bytes(C.byref(graph.c), Dn, Di, self.out_channels), x.device)
+            _lib.check(lib.gvqa_gcn_conv_forward(C.byref(graph.c), Dn, Di, self.out_channels, C.byref(p), x.data_ptr(),
+                                                 None if ins is None else _f32c(ins, "ins").data_ptr(), out.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _stream(x.device)))
+        return out
+
+
+def _bn_relu_chain(x: Tensor, bns) -> Tensor:
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    S = len(bns)
+    arr = (_lib.BnParams * max(S, 1))()
+    for j, bn in enumerate(bns):
+        arr[j] = _lib.BnParams(_f32c(bn.weight, "bn.weight").data_ptr(), _f32c(bn.bias, "bn.bias").data_ptr(),
+                               _f32c(bn.running_mean, "bn.running_mean").data_ptr(),
+                               _f32c(bn.running_var, "bn.running_var").data_ptr())
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gvqa_bn_relu_chain(x.shape[0], x.shape[1], S, arr, bns[0].eps if S else 1e-5, x.data_ptr(),
+                                          out.data_ptr(), _stream(x.device)))
+    return out
+
+
+class _SeqBase(torch.nn.Module):
+    def _check(self):
+        if self.training:
+            raise NotImplementedError("the HIP path implements inference; call .eval() (SURVEY 8f-4)")
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            if hasattr(conv, "reset_parameters"):
+                conv.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+
+class gine_seq(_SeqBase):
+    """Reference `gine_seq(in_channels, out_channels, ins_dim, dropout)`; forward(x, edge_index, edge_attr,
+    instr_vectors, batch) -> [N, out] (pipeline_model_gine.py:641-674)."""
+
+    def __init__(self, in_channels, out_channels, ins_dim, dropout=0.0):
+        super().__init__()
+        self.convs = torch.nn.ModuleList([
+            GINEConv(Sequential(Linear(in_channels + ins_dim, out_channels), ReLU(), Linear(out_channels, out_channels)))
+            for _ in range(5)])
+        self.bns = torch.nn.ModuleList([torch.nn.BatchNorm1d(out_channels) for _ in range(5 - 1)])
+        self.dropout = dropout
+
+    def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph=None, return_convs=False):
+        self._check()
+        out = _bn_relu_chain(x, list(self.bns))           # conv_res is discarded by the reference
+        if not return_convs:
+            return out
+        # kernel-level target: the five conv results the reference computes (and drops); hop i sees
+        # h = x after i BN/ReLU stages and instruction vector i
+        N, B = x.shape[0], instr_vectors.shape[1]
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, batch, N, B)
+        convs, h = [], _f32c(x, "x")
+        for i, conv in enumerate(self.convs):
+            ins = _f32c(instr_vectors[i], "instr_vectors")
+            if graph.intra_graph:
+                convs.append(conv(h, edge_index, edge_attr, graph=graph, ins=ins))
+            else:   # literal formulation on concatenated inputs
+                convs.append(conv(torch.cat((h, ins[batch]), -1), edge_index,
+                                  torch.cat((edge_attr, ins[batch[edge_index[0]]]), -1), graph=graph))
+            if i != len(self.convs) - 1:
+                h = _bn_relu_chain(h, [self.bns[i]])
+        return out, convs
+
+
+class gcn_seq(_SeqBase):
+    """Reference `gcn_seq(in_channels, out_channels, ins_dim, dropout)`; forward(x, edge_index, instr_vectors,
+    batch) -> [N, out] (pipeline_model_gcn.py:641-669)."""
+
+    def __init__(self, in_channels, out_channels, ins_dim, dropout=0.0):
+        super().__init__()
+        self.convs = torch.nn.ModuleList([GCNConv(in_channels + ins_dim, out_channels) for _ in range(5)])
+        self.bns = torch.nn.ModuleList([torch.nn.BatchNorm1d(out_channels) for _ in range(5 - 1)])
+        self.dropout = dropout
+
+    def forward(self, x, edge_index, instr_vectors, batch, graph=None, return_convs=False):
+        self._check()
+        out = _bn_relu_chain(x, list(self.bns))
+        if not return_convs:
+            return out
+        N, B = x.shape[0], instr_vectors.shape[1]
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, batch, N, B)
+        convs, h = [], _f32c(x, "x")
+        for i, conv in enumerate(self.convs):
+            convs.append(conv(h, edge_index, graph=graph, ins=_f32c(instr_vectors[i], "instr_vectors")))
+            if i != len(self.convs) - 1:
+                h = _bn_relu_chain(h, [self.bns[i]])
+        return out, convs

@@ -59,10 +59,23 @@ struct StageTimer {
     ~StageTimer();
 };
 
+// Epilogue of the dense projection: v = acc + bias[n]; v += addend[m,n]; v *= mul[m,n]; relu.
+struct LinearEpilogue {
+    const float* bias;      // [N] or NULL
+    const float* addend;    // [M, ld_add] or NULL (may alias C: accumulate in place)
+    int64_t ld_add;
+    const float* mul;       // [M, ld_mul] or NULL
+    int64_t ld_mul;
+    int relu;
+};
+
 // GEMM entry used by the orchestration code (defined in gemm.hip).
 // C[M,N] = A[M,K] . B[N,K]^T (+bias) (relu);  batched over blockIdx.z with element strides.
 int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                   int64_t ldb, const float* bias, int relu, float* C, int64_t ldc, int batch,
                   int64_t strideA, int64_t strideB, int64_t strideC, hipStream_t stream);
+int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                     int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
+                     int64_t strideB, int64_t strideC, hipStream_t stream);
 
 }  // namespace gvqa

@@ -111,19 +111,24 @@ struct MpArgs {
     const int32_t* csr_eid;
     const int32_t* node_graph;
     const int32_t* graph_ptr;
-    const float* xp;        // [N, H*C]
-    const float* a_node;    // [N, 2H]
+    const float* xp;        // [N, xp_ld]: head h of node n at xp[n*xp_ld + h*C .. + C)
+    int64_t xp_ld;
+    const float* a_node;    // [N, 2H] or NULL (zeros)
     const float* a_edge;    // COO-indexed: a_edge[eid * a_edge_stride + h]
     int64_t a_edge_stride;
     const float* graph_term;  // NULL or [B, t_ld]: columns [0,C) head-mean instruction term, [C,C+H) logit offset
     int64_t t_ld;
-    const float* skip;        // NULL or [N, C]
+    const float* graph_scale; // NULL or [B, gs_ld]: per-graph channel scale of the head mean (LCGN cal_cmd)
+    int64_t gs_ld;
+    const float* skip;        // NULL or [N, skip_ld]
+    int64_t skip_ld;
     const float* bias;        // NULL or [C]
     const float* bn_w;        // all four NULL = no BN / ReLU
     const float* bn_b;
     const float* bn_m;
     const float* bn_v;
-    float* out;               // [N, C]
+    float* out;               // [N, out_ld]
+    int64_t out_ld;
     float* alpha_out;         // NULL or [E, H] COO order
     float* alpha_csr;         // general kernel only: [E, H] in CSR slot order
     int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
@@ -202,11 +207,11 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const size_t off_src = (size_t)a.e_cap * H * 4;
     const size_t off_row = (off_src + (size_t)a.e_cap * 4 + 15) & ~(size_t)15;
     const size_t off_cst = (off_row + (size_t)(a.n_cap + 1) * 4 + 15) & ~(size_t)15;
-    const size_t off_buf = off_cst + (size_t)4 * a.C * 4;
+    const size_t off_buf = off_cst + (size_t)5 * a.C * 4;
     float* alpha_s = reinterpret_cast<float*>(smem);
     int* src_l = reinterpret_cast<int*>(smem + off_src);
     int* rowp_l = reinterpret_cast<int*>(smem + off_row);
-    float* cst = reinterpret_cast<float*>(smem + off_cst);      // [pbar | bias | scale | shift][C]
+    float* cst = reinterpret_cast<float*>(smem + off_cst);      // [pbar | bias | scale | shift | gscale][C]
     // stage buffers hold whole DMA rounds of MP_THREADS units
     const size_t buf_bytes = (((size_t)a.n_cap * (a.cw >> 2) + MP_THREADS - 1) / MP_THREADS) * MP_THREADS * 16;
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         const int units = tn * q4c;
         const float* base;
         int64_t row_stride;
-        if (j < H) { base = a.xp + ((int64_t)n0 * H + j) * C + c0; row_stride = (int64_t)H * C; }
-        else       { base = a.skip + (int64_t)n0 * C + c0;          row_stride = C; }
+        if (j < H) { base = a.xp + (int64_t)n0 * a.xp_ld + (int64_t)j * C + c0; row_stride = a.xp_ld; }
+        else       { base = a.skip + (int64_t)n0 * a.skip_ld + c0;             row_stride = a.skip_ld; }
         unsigned dst = lds_base + (unsigned)(off_buf + (size_t)(t % a.nbuf) * buf_bytes) + (unsigned)wave_unit0 * 16u;
         int row, col, rstep, cstep;
         if (q4c == q4cap) { row = dma_row0; col = dma_col0; rstep = dma_round_rows; cstep = dma_round_cols; }
@@ -261,10 +266,9 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
         src_l[s] = src - n0;
-        const float* al = a.a_node + (int64_t)src * 2 * H;
         const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
 #pragma unroll
-        for (int h = 0; h < H; ++h) alpha_s[s * H + h] = al[h] + ae[h];
+        for (int h = 0; h < H; ++h) alpha_s[s * H + h] = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + ae[h];
     }
     for (int i = tid; i <= tn; i += MP_THREADS) rowp_l[i] = a.rowptr[n0 + i] - e0;
     for (int c = tid; c < C; c += MP_THREADS) {
@@ -278,13 +282,14 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         }
         cst[2 * C + c] = sc;
         cst[3 * C + c] = sh;
+        cst[4 * C + c] = a.graph_scale ? a.graph_scale[(int64_t)g * a.gs_ld + c] : 1.f;
     }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
     for (int it = tid; it < tn * H; it += MP_THREADS) {
         const int i = it / H, h = it - i * H;
         const int lo = rowp_l[i], hi = rowp_l[i + 1];
-        float ar = a.a_node[(int64_t)(n0 + i) * 2 * H + H + h];
+        float ar = a.a_node ? a.a_node[(int64_t)(n0 + i) * 2 * H + H + h] : 0.f;
         if (a.graph_term) ar += a.graph_term[(int64_t)g * a.t_ld + C + h];
         float m = -INFINITY;
         for (int s = lo; s < hi; ++s) {
@@ -392,12 +397,14 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                 const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
                 const float4 sc = *reinterpret_cast<const float4*>(cst + 2 * C + c);
                 const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
+                const float4 gs = *reinterpret_cast<const float4*>(cst + 4 * C + c);
 #pragma unroll
                 for (int k = 0; k < MP_ITEMS; ++k) {
                     const int i = i_base + k * i_step;
                     if (i < tn) {
                         const bool has_edges = rowp_l[i + 1] > rowp_l[i];
                         float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
+                        if (a.graph_scale) { r.x *= gs.x; r.y *= gs.y; r.z *= gs.z; r.w *= gs.w; }
                         if (has_edges) { r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w; }
                         r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
                         if (a.skip) {
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                             r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
                             r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
                         }
-                        *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * C + c) = r;
+                        *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
                         acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
@@ -427,11 +434,11 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     if (it >= (int64_t)a.N * H) return;
     const int i = (int)(it / H), h = (int)(it - (int64_t)i * H);
     const int lo = a.rowptr[i], hi = a.rowptr[i + 1];
-    float ar = a.a_node[(int64_t)i * 2 * H + H + h];
+    float ar = a.a_node ? a.a_node[(int64_t)i * 2 * H + H + h] : 0.f;
     if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[i] * a.t_ld + a.C + h];
     float m = -INFINITY;
     for (int s = lo; s < hi; ++s) {
-        const float v = leaky(a.a_node[(int64_t)a.csr_src[s] * 2 * H + h] +
+        const float v = leaky((a.a_node ? a.a_node[(int64_t)a.csr_src[s] * 2 * H + h] : 0.f) +
                               a.a_edge[(int64_t)a.csr_eid[s] * a.a_edge_stride + h] + ar, a.slope);
         a.alpha_csr[(int64_t)s * H + h] = v;
         m = fmaxf(m, v);
@@ -457,20 +464,20 @@ __global__ __launch_bounds__(256) void k_gat_aggregate_general(MpArgs a, int H) 
     const int lo = a.rowptr[i], hi = a.rowptr[i + 1];
     const int g = a.node_graph[i];
     const float inv_h = 1.0f / H;
-    const int HC = H * a.C;
     for (int c = lane; c < a.C; c += 64) {
         float acc = 0.f;
         for (int s = lo; s < hi; ++s) {
-            const float* row = a.xp + (int64_t)a.csr_src[s] * HC + c;
+            const float* row = a.xp + (int64_t)a.csr_src[s] * a.xp_ld + c;
             const float* al = a.alpha_csr + (int64_t)s * H;
             for (int h = 0; h < H; ++h) acc += al[h] * row[(int64_t)h * a.C];
         }
         float r = acc * inv_h;
+        if (a.graph_scale) r *= a.graph_scale[(int64_t)g * a.gs_ld + c];
         if (a.graph_term && hi > lo) r += a.graph_term[(int64_t)g * a.t_ld + c];
         if (a.bias) r += a.bias[c];
-        if (a.skip) r += a.skip[(int64_t)i * a.C + c];
+        if (a.skip) r += a.skip[(int64_t)i * a.skip_ld + c];
         if (a.bn_w) r = fmaxf((r - a.bn_m[c]) * (1.0f / sqrtf(a.bn_v[c] + a.bn_eps)) * a.bn_w[c] + a.bn_b[c], 0.f);
-        a.out[(int64_t)i * a.C + c] = r;
+        a.out[(int64_t)i * a.out_ld + c] = r;
     }
 }
 
@@ -492,7 +499,7 @@ static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, 
     size_t off = e_cap * H * 4;
     off = align_up(off + e_cap * 4, 16);
     off = align_up(off + (n_cap + 1) * 4, 16);
-    off += (size_t)4 * C * 4;
+    off += (size_t)5 * C * 4;
     return off + (size_t)nbuf * align_up(n_cap * (size_t)(cw / 4), MP_THREADS) * 16;
 }
 
@@ -555,30 +562,39 @@ static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream
     return GVQA_OK;
 }
 
-static int launch_gat_mp(const gvqa_graph* g, int C, int H, float slope, float bn_eps, const float* xp,
-                         const float* a_node, const float* a_edge, int64_t a_edge_stride,
-                         const float* graph_term, int64_t graph_term_ld, const float* skip,
-                         const gvqa_gat_conv_params* p, float* out, float* alpha_out, int force, void* ws,
-                         size_t ws_bytes, hipStream_t stream) {
-    GVQA_REQUIRE(g && xp && a_node && a_edge && p && out, GVQA_E_INVALID, "gat_mp: null argument");
+static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
+    GVQA_REQUIRE(g && d, GVQA_E_INVALID, "gat_mp: null argument");
+    const int C = d->C, H = d->H;
+    GVQA_REQUIRE(d->xp && d->a_edge && d->out, GVQA_E_INVALID, "gat_mp: null tensor");
     GVQA_REQUIRE(C > 0 && H > 0, GVQA_E_INVALID, "gat_mp: bad dims");
-    const bool bn = p->bn_weight || p->bn_bias || p->bn_mean || p->bn_var;
-    GVQA_REQUIRE(!bn || (p->bn_weight && p->bn_bias && p->bn_mean && p->bn_var), GVQA_E_INVALID,
+    const bool bn = d->bn_weight || d->bn_bias || d->bn_mean || d->bn_var;
+    GVQA_REQUIRE(!bn || (d->bn_weight && d->bn_bias && d->bn_mean && d->bn_var), GVQA_E_INVALID,
                  "gat_mp: BatchNorm needs weight, bias, running_mean and running_var");
     if (g->num_nodes == 0) return GVQA_OK;
     MpArgs a;
     a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid;
     a.node_graph = g->node_graph; a.graph_ptr = g->graph_ptr;
-    a.xp = xp; a.a_node = a_node; a.a_edge = a_edge; a.a_edge_stride = a_edge_stride;
-    GVQA_REQUIRE(!graph_term || (graph_term_ld >= C + H && graph_term_ld % 4 == 0), GVQA_E_INVALID,
+    a.xp = d->xp; a.xp_ld = d->xp_ld ? d->xp_ld : (int64_t)H * C;
+    a.a_node = d->a_node; a.a_edge = d->a_edge; a.a_edge_stride = d->a_edge_stride ? d->a_edge_stride : H;
+    GVQA_REQUIRE(!d->graph_term || (d->graph_term_ld >= C + H && d->graph_term_ld % 4 == 0), GVQA_E_INVALID,
                  "gat_mp: graph_term_ld must be >= C+H and a multiple of 4");
-    a.graph_term = graph_term; a.t_ld = graph_term_ld; a.skip = skip; a.bias = p->bias;
-    a.bn_w = p->bn_weight; a.bn_b = p->bn_bias; a.bn_m = p->bn_mean; a.bn_v = p->bn_var;
-    a.out = out; a.alpha_out = alpha_out; a.alpha_csr = nullptr;
-    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0; a.slope = slope; a.bn_eps = bn_eps;
+    a.graph_term = d->graph_term; a.t_ld = d->graph_term_ld;
+    a.graph_scale = d->graph_scale; a.gs_ld = d->graph_scale_ld ? d->graph_scale_ld : C;
+    a.skip = d->skip; a.skip_ld = d->skip_ld ? d->skip_ld : C;
+    a.bias = d->bias;
+    a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
+    a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_csr = nullptr;
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0;
+    a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
+    const int force = d->force;
+    const float* graph_term = d->graph_term;
+    const bool ld_vec_ok = (a.xp_ld % 4 == 0) && (a.skip_ld % 4 == 0) && (a.out_ld % 4 == 0) &&
+                           ((reinterpret_cast<uintptr_t>(a.xp) | reinterpret_cast<uintptr_t>(a.out) |
+                             reinterpret_cast<uintptr_t>(a.skip)) & 15) == 0;
 
     StageTimer timer(GVQA_STAGE_MP, stream);
     TilePlan plan = plan_tiled(g, C, H);
+    if (!ld_vec_ok) plan.ok = false;
     GVQA_REQUIRE(force != 1 || plan.ok, GVQA_E_UNSUPPORTED,
                  "gat_mp: tiled kernel not applicable (needs finalized intra-graph batch, C %% 4 == 0, "
                  "H in {1,2,4,8}, largest graph fitting 160 KiB of LDS)");
@@ -633,6 +649,14 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     return L;
 }
 
+static gvqa_gat_mp_desc mp_desc_from(const gvqa_gat_dims* d, const gvqa_gat_conv_params* p) {
+    gvqa_gat_mp_desc m;
+    memset(&m, 0, sizeof(m));
+    m.C = d->out_channels; m.H = d->heads; m.negative_slope = d->negative_slope; m.bn_eps = d->bn_eps;
+    m.bias = p->bias; m.bn_weight = p->bn_weight; m.bn_bias = p->bn_bias; m.bn_mean = p->bn_mean; m.bn_var = p->bn_var;
+    return m;
+}
+
 static int check_dims(const gvqa_gat_dims* d, bool seq) {
     GVQA_REQUIRE(d, GVQA_E_INVALID, "gat: null dims");
     GVQA_REQUIRE(d->node_dim > 0 && d->edge_dim > 0 && d->out_channels > 0 && d->heads > 0 && d->ins_dim >= 0,
@@ -678,13 +702,8 @@ extern "C" {
 
 using namespace gvqa;
 
-int gvqa_gat_message_passing(const gvqa_graph* g, int32_t C, int32_t H, float negative_slope, float bn_eps,
-                             const float* xp, const float* a_node, const float* a_edge, int64_t a_edge_stride,
-                             const float* graph_term, int64_t graph_term_ld, const float* skip,
-                             const gvqa_gat_conv_params* p, float* out, float* alpha_out, int force, void* ws,
-                             size_t ws_bytes, void* stream) {
-    return launch_gat_mp(g, C, H, negative_slope, bn_eps, xp, a_node, a_edge, a_edge_stride, graph_term, graph_term_ld,
-                         skip, p, out, alpha_out, force, ws, ws_bytes, static_cast<hipStream_t>(stream));
+int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream) {
+    return launch_gat_mp(g, d, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 size_t gvqa_gat_seq_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d) {
@@ -731,8 +750,10 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
                            0, 0, 0, stream);
         if (rc) return rc;
     }
-    return launch_gat_mp(g, C, H, d->negative_slope, d->bn_eps, P(L.xp), P(L.a_node), P(L.a_edge), H, nullptr, 0, nullptr, p,
-                         out, alpha_out, 0, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
+    gvqa_gat_mp_desc m = mp_desc_from(d, p);
+    m.xp = P(L.xp); m.a_node = P(L.a_node); m.a_edge = P(L.a_edge); m.a_edge_stride = H;
+    m.out = out; m.alpha_out = alpha_out;
+    return launch_gat_mp(g, &m, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
 }
 
 int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
@@ -788,10 +809,13 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
                                1, 0, 0, 0, stream);
             if (rc) return rc;
         }
-        rc = launch_gat_mp(g, C, H, d->negative_slope, d->bn_eps, P(L.xp), P(L.a_node), P(L.a_edge) + (int64_t)i * H,
-                           (int64_t)K * H, Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr, Tld, h, &hops[i], h_next,
-                           alpha_out ? alpha_out + (int64_t)i * E * H : nullptr, 0, P(L.alpha_csr),
-                           (size_t)E * H * sizeof(float), stream);
+        gvqa_gat_mp_desc m = mp_desc_from(d, &hops[i]);
+        m.xp = P(L.xp); m.a_node = P(L.a_node);
+        m.a_edge = P(L.a_edge) + (int64_t)i * H; m.a_edge_stride = (int64_t)K * H;
+        m.graph_term = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr; m.graph_term_ld = Tld;
+        m.skip = h; m.out = h_next;
+        m.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
+        rc = launch_gat_mp(g, &m, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
         if (rc) return rc;
         h = h_next;
     }

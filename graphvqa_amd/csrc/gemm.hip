@@ -25,9 +25,8 @@ constexpr int LDS_LD = BK + 4;   // padded leading dimension (floats)
 template <int BM, int BN, int WR, int WC, bool VEC>
 __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const float* __restrict__ A,
                                                     int64_t lda, const float* __restrict__ B, int64_t ldb,
-                                                    const float* __restrict__ bias, int relu,
-                                                    float* __restrict__ C, int64_t ldc, int64_t strideA,
-                                                    int64_t strideB, int64_t strideC) {
+                                                    LinearEpilogue ep, float* C, int64_t ldc,
+                                                    int64_t strideA, int64_t strideB, int64_t strideC) {
     static_assert(WR * WC == 4, "4 waves per block");
     constexpr int WM = BM / WR, WN = BN / WC;     // wave tile
     constexpr int MT = WM / 32, NT = WN / 32;     // 32x32 MFMA tiles per wave
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
     for (int j = 0; j < NT; ++j) {
         const int gc = n0 + wc * WN + j * 32 + ccol;
         if (gc >= N) continue;
-        const float bv = bias ? bias[gc] : 0.f;
+        const float bv = ep.bias ? ep.bias[gc] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int gr0 = m0 + wr * WM + i * 32 + crow0;
@@ -159,7 +158,9 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
                 const int gr = gr0 + (r & 3) + 8 * (r >> 2);
                 if (gr < M) {
                     float v = acc[i][j][r] + bv;
-                    if (relu) v = fmaxf(v, 0.f);
+                    if (ep.addend) v += ep.addend[(int64_t)gr * ep.ld_add + gc];
+                    if (ep.mul) v *= ep.mul[(int64_t)gr * ep.ld_mul + gc];
+                    if (ep.relu) v = fmaxf(v, 0.f);
                     C[(int64_t)gr * ldc + gc] = v;
                 }
             }
@@ -170,6 +171,13 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
 int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                   int64_t ldb, const float* bias, int relu, float* C, int64_t ldc, int batch,
                   int64_t strideA, int64_t strideB, int64_t strideC, hipStream_t stream) {
+    LinearEpilogue ep{bias, nullptr, 0, nullptr, 0, relu};
+    return launch_linear_ex(M, N, K, A, lda, B, ldb, ep, C, ldc, batch, strideA, strideB, strideC, stream);
+}
+
+int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                     int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
+                     int64_t strideB, int64_t strideC, hipStream_t stream) {
     GVQA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1, GVQA_E_INVALID, "linear: negative size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), GVQA_E_INVALID, "linear: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
@@ -177,6 +185,9 @@ int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
     GVQA_REQUIRE(cdiv(M, 128) <= 65535, GVQA_E_INVALID, "linear: M too large for one launch");
     GVQA_REQUIRE(A && B && C, GVQA_E_INVALID, "linear: null operand");
     GVQA_REQUIRE(lda >= K && ldb >= K && ldc >= N, GVQA_E_INVALID, "linear: leading dimension too small");
+    GVQA_REQUIRE((!ep.addend || ep.ld_add >= N) && (!ep.mul || ep.ld_mul >= N), GVQA_E_INVALID,
+                 "linear: epilogue leading dimension too small");
+    GVQA_REQUIRE((!ep.addend && !ep.mul) || batch == 1, GVQA_E_INVALID, "linear: addend/mul epilogue is not batched");
     // 16-byte vector loads need 16-byte aligned rows
     const bool vec = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
                      (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
@@ -186,11 +197,11 @@ int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
         dim3 grid((unsigned)cdiv(N, BN_), (unsigned)cdiv(M, BM_), (unsigned)batch);                    \
         if (vec)                                                                                       \
             hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, true>), grid, dim3(256), 0, stream,   \
-                               (int)M, (int)N, (int)K, A, lda, B, ldb, bias, relu, C, ldc, strideA,    \
+                               (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA,            \
                                strideB, strideC);                                                      \
         else                                                                                           \
             hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, false>), grid, dim3(256), 0, stream,  \
-                               (int)M, (int)N, (int)K, A, lda, B, ldb, bias, relu, C, ldc, strideA,    \
+                               (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA,            \
                                strideB, strideC);                                                      \
     } while (0)
     if (N <= 32) GVQA_LAUNCH_LINEAR(128, 32, 4, 1);
@@ -202,6 +213,13 @@ int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
 }
 
 }  // namespace gvqa
+
+extern "C" int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                                  int64_t ldb, const float* bias, const float* addend, int64_t ld_add,
+                                  const float* mul, int64_t ld_mul, int relu, float* C, int64_t ldc, void* stream) {
+    gvqa::LinearEpilogue ep{bias, addend, ld_add, mul, ld_mul, relu};
+    return gvqa::launch_linear_ex(M, N, K, A, lda, B, ldb, ep, C, ldc, 1, 0, 0, 0, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int gvqa_linear_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                                int64_t ldb, const float* bias, int relu, float* C, int64_t ldc, void* stream) {

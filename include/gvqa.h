@@ -148,24 +148,91 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
 int gvqa_linear_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                     const float* B, int64_t ldb, const float* bias, int relu,
                     float* C, int64_t ldc, void* stream);
+/* Same with the full epilogue: v = acc + bias[n]; v += addend[m*ld_add + n]; v *= mul[m*ld_mul + n];
+ * relu.  addend may alias C (accumulate a second product in place: split-source concatenations,
+ * lcgn.py:316-319).  bias / addend / mul may be NULL. */
+int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                       const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_add,
+                       const float* mul, int64_t ld_mul, int relu, float* C, int64_t ldc, void* stream);
 
 /* The fused GAT message-passing kernel on its own (SURVEY 2.1 K4-K9 + K11): attention logits
  * -> leaky-relu -> softmax over incoming edges -> alpha-weighted sum of projected source
- * features -> head mean -> (+graph term) + bias + skip -> (BN -> ReLU).
- *   xp        [N, H*C]   projected node features
- *   a_node    [N, 2H]    (a_l | a_r) per node
- *   a_edge    base pointer, logit term of COO edge e, head h at a_edge[e*a_edge_stride + h]
- *   graph_term NULL or [B, graph_term_ld]: per graph, columns [0,C) = mean-over-heads instruction
- *             projection, columns [C,C+H) = logit offset; graph_term_ld >= C+H, multiple of 4
- *   skip      NULL or [N, C]
- * Chooses the LDS-tiled kernel when the graph statistics allow, else the general CSR kernel
- * (force: 0 = auto, 1 = tiled, 2 = general). */
-int gvqa_gat_message_passing(const gvqa_graph* g, int32_t C, int32_t H, float negative_slope, float bn_eps,
-                             const float* xp, const float* a_node, const float* a_edge, int64_t a_edge_stride,
-                             const float* graph_term, int64_t graph_term_ld, const float* skip,
-                             const gvqa_gat_conv_params* p,
-                             float* out, float* alpha_out, int force,
-                             void* ws /* >= 4*E*H bytes, general kernel only */, size_t ws_bytes, void* stream);
+ * features -> head mean -> (x graph scale) (+graph term) + bias + skip -> (BN -> ReLU).
+ * Zero-initialise the descriptor; leading dimensions of 0 mean "dense". */
+typedef struct gvqa_gat_mp_desc {
+    int32_t C, H;               /* out channels, heads                                               */
+    float negative_slope, bn_eps;
+    const float* xp;            /* [N, xp_ld] projected node features, head h at columns [h*C,(h+1)*C) */
+    int64_t xp_ld;              /* 0 -> H*C                                                          */
+    const float* a_node;        /* [N, 2H] (a_l | a_r) per node, or NULL (zeros)                     */
+    const float* a_edge;        /* logit term of COO edge e, head h at a_edge[e*a_edge_stride + h]   */
+    int64_t a_edge_stride;      /* 0 -> H                                                            */
+    const float* graph_term;    /* NULL or [B, graph_term_ld]: columns [0,C) head-mean instruction
+                                   projection, [C,C+H) logit offset; ld >= C+H, multiple of 4        */
+    int64_t graph_term_ld;
+    const float* graph_scale;   /* NULL or [B, graph_scale_ld]: per-graph channel scale of the head
+                                   mean, applied before graph term / bias (LCGN cal_cmd, lcgn.py:231) */
+    int64_t graph_scale_ld;     /* 0 -> C                                                            */
+    const float* skip;          /* NULL or [N, skip_ld]                                              */
+    int64_t skip_ld;            /* 0 -> C                                                            */
+    const float* bias;          /* NULL or [C]                                                       */
+    const float* bn_weight;     /* eval BatchNorm + ReLU after the skip; all four NULL = none        */
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+    float* out;                 /* [N, out_ld]                                                       */
+    int64_t out_ld;             /* 0 -> C                                                            */
+    float* alpha_out;           /* NULL or [E, H] in COO edge order                                  */
+    int32_t force;              /* 0 = auto, 1 = LDS-tiled kernel, 2 = general CSR kernel            */
+} gvqa_gat_mp_desc;
+/* ws: >= 4*E*H bytes, used by the general kernel only. */
+int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GINE / GCN variants (baseline_and_test_models/pipeline_model_{gine,gcn}.py:622-674)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gvqa_bn_params {     /* one eval-mode BatchNorm1d: bns.j.{weight,bias,running_mean,running_var} */
+    const float* weight;
+    const float* bias;
+    const float* mean;
+    const float* var;
+} gvqa_bn_params;
+
+/* out = relu(bn_{S-1}(... relu(bn_0(x)) ...)): what gine_seq.forward / gcn_seq.forward return as
+ * written -- they compute conv_res and discard it (pipeline_model_gine.py:665-671,
+ * pipeline_model_gcn.py:660-666).  x, out [N, C]; `stages` is a host array. */
+int gvqa_bn_relu_chain(int64_t N, int32_t C, int32_t num_stages, const gvqa_bn_params* stages, float bn_eps,
+                       const float* x, float* out, void* stream);
+
+typedef struct gvqa_gine_params {   /* GINEConv(Seq(Lin, ReLU, Lin)): convs.i.nn.{0,2}.{weight,bias}, convs.i.eps */
+    const float* nn0_weight;        /* [C, node_dim + ins_dim] */
+    const float* nn0_bias;          /* [C] */
+    const float* nn2_weight;        /* [C, C] */
+    const float* nn2_bias;          /* [C] */
+    float eps;
+} gvqa_gine_params;
+
+/* PyG GINEConv on x = [h || ins[batch]], e = [edge_attr || ins[batch[src]]] (both node_dim+ins_dim
+ * wide, pipeline_model_gine.py:651-665): out = nn((1+eps) x_i + sum_{j->i} relu(x_j + e_ji)).
+ * h [N, node_dim], edge_attr [E, node_dim] (COO order), ins [B, ins_dim] (NULL when ins_dim == 0:
+ * h / edge_attr are then the full inputs), out [N, C].  ins_dim > 0 needs an intra-graph batch. */
+size_t gvqa_gine_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
+int gvqa_gine_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
+                           const gvqa_gine_params* p, const float* h, const float* edge_attr, const float* ins,
+                           float* out, void* ws, size_t ws_bytes, void* stream);
+
+typedef struct gvqa_gcn_params {    /* PyG 1.6/1.7 GCNConv: convs.i.weight [in, out], convs.i.bias [out] */
+    const float* weight;            /* [node_dim + ins_dim, C] */
+    const float* bias;              /* [C] or NULL */
+} gvqa_gcn_params;
+
+/* PyG GCNConv on x = [h || ins[batch]] (pipeline_model_gcn.py:651-660): unit edge weights,
+ * add_remaining_self_loops (existing self loops collapse into one per node), symmetric
+ * normalisation.  h [N, node_dim], ins [B, ins_dim] or NULL, out [N, C].  Any graph. */
+size_t gvqa_gcn_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
+int gvqa_gcn_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
+                          const gvqa_gcn_params* p, const float* h, const float* ins, float* out,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * In-library stage timing (HIP events recorded on the caller's stream around each stage).
