@@ -72,6 +72,24 @@ class GcnParams(C.Structure):
     _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
 
 
+class LcgnDims(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("question_dim", C.c_int32),
+                ("num_iters", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32),
+                ("negative_slope", C.c_float)]
+
+
+class LcgnParams(C.Structure):
+    _fields_ = [("init_weight", C.c_void_p), ("init_bias", C.c_void_p), ("qinput1_weight", C.c_void_p),
+                ("qinput1_bias", C.c_void_p), ("qinput2_weight", C.c_void_p * 8), ("qinput2_bias", C.c_void_p * 8),
+                ("cmd_logit_weight", C.c_void_p), ("cmd_logit_bias", C.c_void_p),
+                ("proj_x_loc_weight", C.c_void_p), ("proj_x_loc_bias", C.c_void_p),
+                ("proj_x_ctx_weight", C.c_void_p), ("proj_x_ctx_bias", C.c_void_p),
+                ("output_weight", C.c_void_p), ("output_bias", C.c_void_p), ("fin_weight", C.c_void_p),
+                ("fin_bias", C.c_void_p), ("lin_l_weight", C.c_void_p), ("lin_r_weight", C.c_void_p),
+                ("cal_x_weight", C.c_void_p), ("proj_cmd_weight", C.c_void_p), ("cal_cmd_weight", C.c_void_p),
+                ("bias", C.c_void_p)]
+
+
 class GatDims(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
                 ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
@@ -110,6 +128,10 @@ PROTOTYPES = {
     "gvqa_gcn_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32]),
     "gvqa_gcn_conv_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.POINTER(GcnParams),
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_lcgn_seq_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(LcgnDims)]),
+    "gvqa_lcgn_seq_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(LcgnDims), C.POINTER(LcgnParams), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

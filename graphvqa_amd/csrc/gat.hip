@@ -619,6 +619,10 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     return GVQA_OK;
 }
 
+int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return launch_gat_mp(g, d, ws, ws_bytes, stream);
+}
+
 // ==============================================================================================
 // Drivers
 // ==============================================================================================

@@ -1,0 +1,193 @@
+// LCGN variant of the execution module (gfx950): `lcgn_seq.forward` with its `gat_lcgn` layer.
+//
+// Reference being replaced: baseline_and_test_models/lcgn.py:303-323 (lcgn_seq.forward),
+// :292-300 (extract_textual_command), :120-199 + :202-238 (gat_lcgn.forward / message).
+//
+// Restructuring (same math, fp32, re-associated sums):
+//   * x_joint = [x_loc || x_ctx || proj_x_ctx * proj_x_loc] (lcgn.py:313) is never materialised:
+//     the three projections lin_l / lin_r / cal_x are ONE stacked weight [3O, 3O] and the product
+//     x_joint . W^T is computed as three K-segments accumulated in place; the x_loc segment does
+//     not change across iterations and is computed once.
+//   * cal_x is applied per NODE (N x 3O x O) instead of per edge on x_j (E x 3O x O, lcgn.py:230):
+//     the same row-wise linear map, gathered afterwards.
+//   * F.one_hot(batch).matmul(.) ([N, B] dense matmuls, lcgn.py:150-153) is a gather by graph id.
+//   * messages cal_x(x_j) * cal_cmd_j * alpha summed over in-edges (lcgn.py:231-238): cal_cmd_j is the
+//     source's graph = the destination's graph, so it factors out of the sum as a per-graph channel
+//     scale; the aggregation itself is the GAT message-passing kernel with H heads = 1, fed
+//     with the dot-product logits as its per-edge logit term (leaky-relu + softmax happen inside).
+#include "common.h"
+
+namespace gvqa {
+
+int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream);
+
+// cmd[b, :] = sum_l softmax_l( (q_cmd[b] * lstm[l, b]) . w + bias ) * lstm[l, b, :]     (lcgn.py:292-300)
+// One block per graph b; dynamic LDS: L floats.
+__global__ __launch_bounds__(256) void k_lcgn_command(int L, int B, int O, const float* __restrict__ q_cmd,
+                                                      const float* __restrict__ lstm, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ cmd) {
+    extern __shared__ float att[];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int l = wave; l < L; l += 4) {
+        const float* row = lstm + ((int64_t)l * B + b) * O;
+        float s = 0.f;
+        for (int d = lane; d < O; d += 64) s += (q_cmd[(int64_t)b * O + d] * row[d]) * w[d];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) att[l] = s + bias[0];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, att[l]);
+    float den = 0.f;
+    for (int l = 0; l < L; ++l) den += expf(att[l] - m);
+    for (int d = threadIdx.x; d < O; d += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += (expf(att[l] - m) / den) * lstm[((int64_t)l * B + b) * O + d];
+        cmd[(int64_t)b * O + d] = acc;
+    }
+}
+
+// logit[eid] = sum_c x_l[src, c] * (proj_cmd[g(dst), c] * x_r[dst, c])      (lcgn.py:154,207), H = 1.
+// One wave per destination node; its y = proj_cmd * x_r row stays in registers.
+constexpr int LCGN_MAXC_PER_LANE = 16;      // C <= 1024
+__global__ __launch_bounds__(256) void k_lcgn_edge_logit(int N, int C, const float* __restrict__ xl, int64_t xl_ld,
+                                                         const float* __restrict__ xr, int64_t xr_ld,
+                                                         const float* __restrict__ proj_cmd, int64_t pc_ld,
+                                                         const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ csr_src,
+                                                         const int32_t* __restrict__ csr_eid,
+                                                         const int32_t* __restrict__ node_graph, float* __restrict__ logit) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int g = node_graph[i];
+    float y[LCGN_MAXC_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < LCGN_MAXC_PER_LANE; ++k) {
+        const int c = lane + k * 64;
+        y[k] = c < C ? proj_cmd[(int64_t)g * pc_ld + c] * xr[(int64_t)i * xr_ld + c] : 0.f;
+    }
+    for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) {
+        const float* row = xl + (int64_t)csr_src[s] * xl_ld;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LCGN_MAXC_PER_LANE; ++k) {
+            const int c = lane + k * 64;
+            if (c < C) acc += row[c] * y[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) logit[csr_eid[s]] = acc;
+    }
+}
+
+struct LcgnLayout {
+    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, x_ctx0, x_ctx1, prod, XL, J, logit, msg, Wcat, Wpc, alpha, total;
+};
+static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_dims* d) {
+    LcgnLayout L; size_t off = 0;
+    auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
+    const size_t O = d->out_channels;
+    L.x_loc = take(N * O); L.proj_x_loc = take(N * O); L.q_emb = take(B * O); L.q_cmd = take(B * O);
+    L.cmd = take(B * O); L.pc = take(B * 2 * O); L.x_ctx0 = take(N * O); L.x_ctx1 = take(N * O);
+    L.prod = take(N * O); L.XL = take(N * 3 * O); L.J = take(N * 3 * O); L.logit = take(E); L.msg = take(N * O);
+    L.Wcat = take(3 * O * 3 * O); L.Wpc = take(2 * O * O); L.alpha = take(E);
+    L.total = off;
+    return L;
+}
+
+}  // namespace gvqa
+
+extern "C" {
+using namespace gvqa;
+
+size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* d) {
+    if (!g || !d) return 0;
+    return lcgn_layout(g->num_nodes, g->num_edges, g->num_graphs, d).total;
+}
+
+int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, const float* x,
+                          const float* q_encoding, const float* lstm_outputs, const float* x_ctx_init, float* out,
+                          void* ws, size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(g && d && p, GVQA_E_INVALID, "lcgn_seq: null argument");
+    const int O = d->out_channels, Cin = d->in_channels, Q = d->question_dim, T = d->num_iters, Lq = d->seq_len;
+    GVQA_REQUIRE(O > 0 && Cin > 0 && Q > 0 && Lq > 0 && T >= 1 && T <= 8, GVQA_E_INVALID, "lcgn_seq: bad dims");
+    GVQA_REQUIRE(d->heads == 1, GVQA_E_UNSUPPORTED, "lcgn_seq: gat_heads != 1 is not implemented (reference default 1)");
+    GVQA_REQUIRE(O <= 64 * LCGN_MAXC_PER_LANE, GVQA_E_UNSUPPORTED, "lcgn_seq: out_channels > %d", 64 * LCGN_MAXC_PER_LANE);
+    GVQA_REQUIRE(g->finalized && g->intra_graph, GVQA_E_UNSUPPORTED, "lcgn_seq: needs a finalized intra-graph batch");
+    const int64_t N = g->num_nodes, E = g->num_edges, B = g->num_graphs;
+    LcgnLayout L = lcgn_layout(N, E, B, d);
+    GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "lcgn_seq: workspace %zu < required %zu", ws_bytes, L.total);
+    if (N == 0) return GVQA_OK;
+    GVQA_REQUIRE(x && q_encoding && lstm_outputs && x_ctx_init && out, GVQA_E_INVALID, "lcgn_seq: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* base = static_cast<char*>(ws);
+    auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    int rc;
+#define LIN(M_, N_, K_, A_, lda_, W_, ldw_, bias_, relu_, C_, ldc_)                                                  \
+    do { rc = launch_linear(M_, N_, K_, A_, lda_, W_, ldw_, bias_, relu_, C_, ldc_, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
+#define LINX(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_)                                                          \
+    do { rc = launch_linear_ex(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
+
+    StageTimer timer(GVQA_STAGE_OTHER, stream);
+    // stacked weights: Wcat = [lin_l; lin_r; cal_x] ([3O, 3O]),  Wpc = [proj_cmd; cal_cmd] ([2O, O])
+    const size_t wb = (size_t)O * 3 * O * sizeof(float);
+    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wcat), p->lin_l_weight, wb, hipMemcpyDeviceToDevice, stream));
+    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wcat) + (size_t)O * 3 * O, p->lin_r_weight, wb, hipMemcpyDeviceToDevice, stream));
+    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wcat) + (size_t)2 * O * 3 * O, p->cal_x_weight, wb, hipMemcpyDeviceToDevice, stream));
+    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc), p->proj_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc) + (size_t)O * O, p->cal_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+
+    LIN(N, O, Cin, x, Cin, p->init_weight, Cin, p->init_bias, 0, P(L.x_loc), O);                   // lcgn.py:305
+    LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
+    LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, p->proj_x_loc_bias, 0, P(L.proj_x_loc), O); // :308
+    LIN(N, 3 * O, O, P(L.x_loc), O, P(L.Wcat), 3 * O, nullptr, 0, P(L.XL), 3 * O);                  // x_loc segment of :144-145,230
+    const float* x_ctx = x_ctx_init;
+    for (int t = 0; t < T; ++t) {
+        float* x_ctx_next = (t & 1) ? P(L.x_ctx1) : P(L.x_ctx0);
+        // textual command (:292-300)
+        LIN(B, O, O, P(L.q_emb), O, p->qinput2_weight[t], O, p->qinput2_bias[t], 0, P(L.q_cmd), O);
+        hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B, O,
+                           P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
+        GVQA_LAUNCH_CHECK();
+        LIN(B, 2 * O, O, P(L.cmd), O, P(L.Wpc), O, nullptr, 0, P(L.pc), 2 * O);                     // :148-149
+        // prod = proj_x_ctx(x_ctx) * proj_x_loc                                                     // :312-313
+        LinearEpilogue ep_mul{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0};
+        LINX(N, O, O, x_ctx, O, p->proj_x_ctx_weight, O, ep_mul, P(L.prod), O);
+        // J = x_joint . Wcat^T = XL + x_ctx . Wcat[:, O:2O]^T + prod . Wcat[:, 2O:3O]^T            // :144-145,230
+        LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
+        LINX(N, 3 * O, O, x_ctx, O, P(L.Wcat) + O, 3 * O, ep_add, P(L.J), 3 * O);
+        LinearEpilogue ep_acc{nullptr, P(L.J), 3 * O, nullptr, 0, 0};
+        LINX(N, 3 * O, O, P(L.prod), O, P(L.Wcat) + 2 * O, 3 * O, ep_acc, P(L.J), 3 * O);
+        // dot-product attention logits per edge                                                     // :154,207
+        hipLaunchKernelGGL(k_lcgn_edge_logit, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J), (int64_t)3 * O,
+                           P(L.J) + O, (int64_t)3 * O, P(L.pc), (int64_t)2 * O, g->rowptr, g->csr_src, g->csr_eid,
+                           g->node_graph, P(L.logit));
+        GVQA_LAUNCH_CHECK();
+        // leaky-relu, softmax over in-edges, alpha-weighted sum of cal_x(x_joint)[src], x cal_cmd[g], + bias  // :209-238,166-168
+        gvqa_gat_mp_desc m;
+        memset(&m, 0, sizeof(m));
+        m.C = O; m.H = 1; m.negative_slope = d->negative_slope; m.bn_eps = 1e-5f;
+        m.xp = P(L.J) + 2 * O; m.xp_ld = 3 * O;
+        m.a_edge = P(L.logit); m.a_edge_stride = 1;
+        m.graph_scale = P(L.pc) + O; m.graph_scale_ld = 2 * O;
+        m.bias = p->bias; m.out = P(L.msg);
+        rc = launch_gat_mp_public(g, &m, P(L.alpha), (size_t)E * sizeof(float), stream);
+        if (rc) return rc;
+        // x_ctx = output_layer([x_ctx || msg])                                                       // :316-319
+        LIN(N, O, O, x_ctx, O, p->output_weight, 2 * O, p->output_bias, 0, x_ctx_next, O);
+        LinearEpilogue ep_acc2{nullptr, x_ctx_next, O, nullptr, 0, 0};
+        LINX(N, O, O, P(L.msg), O, p->output_weight + O, 2 * O, ep_acc2, x_ctx_next, O);
+        x_ctx = x_ctx_next;
+    }
+    // out = fin_layer([x_loc || x_ctx])                                                              // :321-322
+    LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, p->fin_bias, 0, out, O);
+    LinearEpilogue ep_fin{nullptr, out, O, nullptr, 0, 0};
+    LINX(N, O, O, x_ctx, O, p->fin_weight + O, 2 * O, ep_fin, out, O);
+#undef LIN
+#undef LINX
+    return GVQA_OK;
+}
+
+}  // extern "C"

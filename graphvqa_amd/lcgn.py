@@ -1,0 +1,127 @@
+"""MI355X-native drop-in for the reference's `lcgn` module (baseline_and_test_models/lcgn.py).
+
+`lcgn_seq` keeps the reference's constructor arguments (lcgn.py:255-256), forward signature
+(:303) and state_dict keys (incl. the dead `bns.*` entries); the whole forward runs in one C-ABI
+call (`gvqa_lcgn_seq_forward`).  `x_ctx` is initialised exactly like the reference:
+`torch.randn(x_loc.size())` drawn on the CPU generator, then moved (lcgn.py:306), so the same
+`torch.manual_seed` gives the same result.  Inference only (dropout layers inactive).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+from torch.nn import Linear, Parameter
+
+from . import _lib
+from .gat_skip import _f32c, _workspace, _glorot
+from .graph import SceneGraphBatch, _stream
+
+
+class gat_lcgn(nn.Module):
+    """Parameter container of the reference's `gat_lcgn` layer (lcgn.py:63-118).  Its compute is fused
+    into `lcgn_seq.forward`; calling it on its own is not part of the GraphVQA path."""
+
+    def __init__(self, in_channels, out_channels, edge_in_channels, heads=1, concat=True, negative_slope=0.2,
+                 dropout=0.0, cmd_dim=512, add_self_loops=True, bias=True, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
+        self.lin_l = Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_r = Linear(in_channels, heads * out_channels, bias=False)
+        self.cal_x = Linear(in_channels, heads * out_channels, bias=False)
+        self.proj_cmd = Linear(cmd_dim, heads * out_channels, False)
+        self.cal_cmd = Linear(cmd_dim, heads * out_channels, False)
+        if bias and concat:
+            self.bias = Parameter(torch.empty(heads * out_channels))
+        elif bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in (self.lin_l, self.lin_r, self.proj_cmd, self.cal_cmd, self.cal_x):
+            _glorot(lin.weight)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("gat_lcgn is executed inside lcgn_seq.forward on the HIP path")
+
+
+class lcgn_seq(nn.Module):
+    def __init__(self, in_channels, out_channels, edge_attr_dim, num_ins, gat_cmd_dim=512, question_dim=512,
+                 MAX_ITER_NUM=4, dropout=0.0, gat_heads=1, gat_negative_slope=0.2, gat_bias=True):
+        super().__init__()
+        _lib.load()
+        self.init_sg_emb_input = nn.Sequential(Linear(in_channels, out_channels), nn.Dropout(dropout))
+        self.MAX_ITER_NUM = MAX_ITER_NUM
+        self.qInput1 = Linear(question_dim, out_channels)
+        for t in range(MAX_ITER_NUM):
+            setattr(self, "qInput2_%d" % t, Linear(out_channels, out_channels))
+        self.cmd_inter2logits = Linear(out_channels, 1)
+        self.dropout = dropout
+        self.proj_x_loc = nn.Sequential(nn.Dropout(dropout), Linear(out_channels, out_channels))
+        self.proj_x_ctx = nn.Sequential(nn.Dropout(dropout), Linear(out_channels, out_channels))
+        self.output_layer = Linear(2 * out_channels, out_channels)
+        self.fin_layer = Linear(2 * out_channels, out_channels)
+        self.lcgn = gat_lcgn(in_channels=3 * out_channels, out_channels=out_channels, edge_in_channels=1,
+                             heads=gat_heads, concat=False, negative_slope=gat_negative_slope, dropout=dropout,
+                             bias=gat_bias, cmd_dim=gat_cmd_dim)
+        self.bns = nn.ModuleList([nn.BatchNorm1d(out_channels) for _ in range(num_ins - 1)])   # dead in the reference too
+        self.in_channels, self.out_channels, self.question_dim = in_channels, out_channels, question_dim
+        self.gat_cmd_dim, self.gat_heads, self.negative_slope = gat_cmd_dim, gat_heads, gat_negative_slope
+
+    def forward(self, x, edge_index, batch, q_encoding, lstm_outputs, edge_attr=None, instr_vectors=None,
+                graph: SceneGraphBatch | None = None, x_ctx_init: torch.Tensor | None = None):
+        if self.training:
+            raise NotImplementedError("lcgn_seq on the HIP path implements inference; call .eval() (SURVEY 8f-4)")
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        q = _f32c(q_encoding, "q_encoding")
+        lstm = _f32c(lstm_outputs, "lstm_outputs")
+        N, O = x.shape[0], self.out_channels
+        B, L = q.shape[0], lstm.shape[0]
+        if self.gat_cmd_dim != O or lstm.shape[2] != O:
+            raise ValueError("command width must equal out_channels (cmd is a weighted sum of lstm_outputs)")
+        if lstm.shape[1] != B or x.shape[1] != self.in_channels or q.shape[1] != self.question_dim:
+            raise ValueError("input shapes do not match the module")
+        if x_ctx_init is None:
+            x_ctx_init = torch.randn((N, O)).to(x.device)          # lcgn.py:306: CPU generator, then moved
+        x_ctx_init = _f32c(x_ctx_init, "x_ctx_init")
+        if graph is None:
+            graph = SceneGraphBatch(edge_index, batch, N, B)
+        d = _lib.LcgnDims(self.in_channels, O, self.question_dim, self.MAX_ITER_NUM, L, self.gat_heads,
+                          self.negative_slope)
+        p = _lib.LcgnParams()
+        keep = []
+
+        def ptr(t, name):
+            t = _f32c(t, name)
+            keep.append(t)
+            return t.data_ptr()
+
+        p.init_weight, p.init_bias = ptr(self.init_sg_emb_input[0].weight, "w"), ptr(self.init_sg_emb_input[0].bias, "b")
+        p.qinput1_weight, p.qinput1_bias = ptr(self.qInput1.weight, "w"), ptr(self.qInput1.bias, "b")
+        for t in range(self.MAX_ITER_NUM):
+            lin = getattr(self, "qInput2_%d" % t)
+            p.qinput2_weight[t], p.qinput2_bias[t] = ptr(lin.weight, "w"), ptr(lin.bias, "b")
+        p.cmd_logit_weight, p.cmd_logit_bias = ptr(self.cmd_inter2logits.weight, "w"), ptr(self.cmd_inter2logits.bias, "b")
+        p.proj_x_loc_weight, p.proj_x_loc_bias = ptr(self.proj_x_loc[1].weight, "w"), ptr(self.proj_x_loc[1].bias, "b")
+        p.proj_x_ctx_weight, p.proj_x_ctx_bias = ptr(self.proj_x_ctx[1].weight, "w"), ptr(self.proj_x_ctx[1].bias, "b")
+        p.output_weight, p.output_bias = ptr(self.output_layer.weight, "w"), ptr(self.output_layer.bias, "b")
+        p.fin_weight, p.fin_bias = ptr(self.fin_layer.weight, "w"), ptr(self.fin_layer.bias, "b")
+        p.lin_l_weight, p.lin_r_weight = ptr(self.lcgn.lin_l.weight, "w"), ptr(self.lcgn.lin_r.weight, "w")
+        p.cal_x_weight = ptr(self.lcgn.cal_x.weight, "w")
+        p.proj_cmd_weight, p.cal_cmd_weight = ptr(self.lcgn.proj_cmd.weight, "w"), ptr(self.lcgn.cal_cmd.weight, "w")
+        p.bias = None if self.lcgn.bias is None else ptr(self.lcgn.bias, "b")
+        out = torch.empty((N, O), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            ws = _workspace(lib.gvqa_lcgn_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), x.device)
+            _lib.check(lib.gvqa_lcgn_seq_forward(C.byref(graph.c), C.byref(d), C.byref(p), x.data_ptr(), q.data_ptr(),
+                                                 lstm.data_ptr(), x_ctx_init.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), _stream(x.device)))
+        return out

@@ -235,6 +235,53 @@ int gvqa_gcn_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim
                           void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LCGN variant (baseline_and_test_models/lcgn.py)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gvqa_lcgn_dims {
+    int32_t in_channels;    /* width of x (300)                                                   */
+    int32_t out_channels;   /* O (512): node state width = command width = lstm output width      */
+    int32_t question_dim;   /* width of q_encoding (512)                                          */
+    int32_t num_iters;      /* MAX_ITER_NUM (4), <= 8                                             */
+    int32_t seq_len;        /* L: number of lstm_outputs steps                                    */
+    int32_t heads;          /* gat_heads (1)                                                      */
+    float negative_slope;
+} gvqa_lcgn_dims;
+
+typedef struct gvqa_lcgn_params {   /* lcgn_seq state_dict (lcgn.py:255-282), device pointers */
+    const float* init_weight;          /* init_sg_emb_input.0.weight [O, in]  */
+    const float* init_bias;            /* init_sg_emb_input.0.bias   [O]      */
+    const float* qinput1_weight;       /* qInput1.weight [O, Q]               */
+    const float* qinput1_bias;
+    const float* qinput2_weight[8];    /* qInput2_t.weight [O, O]             */
+    const float* qinput2_bias[8];
+    const float* cmd_logit_weight;     /* cmd_inter2logits.weight [1, O]      */
+    const float* cmd_logit_bias;       /* cmd_inter2logits.bias [1]           */
+    const float* proj_x_loc_weight;    /* proj_x_loc.1.weight [O, O]          */
+    const float* proj_x_loc_bias;
+    const float* proj_x_ctx_weight;    /* proj_x_ctx.1.weight [O, O]          */
+    const float* proj_x_ctx_bias;
+    const float* output_weight;        /* output_layer.weight [O, 2O]         */
+    const float* output_bias;
+    const float* fin_weight;           /* fin_layer.weight [O, 2O]            */
+    const float* fin_bias;
+    const float* lin_l_weight;         /* lcgn.lin_l.weight  [O, 3O]          */
+    const float* lin_r_weight;         /* lcgn.lin_r.weight  [O, 3O]          */
+    const float* cal_x_weight;         /* lcgn.cal_x.weight  [O, 3O]          */
+    const float* proj_cmd_weight;      /* lcgn.proj_cmd.weight [O, O]         */
+    const float* cal_cmd_weight;       /* lcgn.cal_cmd.weight  [O, O]         */
+    const float* bias;                 /* lcgn.bias [O] or NULL               */
+} gvqa_lcgn_params;
+
+/* lcgn_seq.forward(x, edge_index, batch, q_encoding, lstm_outputs) in eval mode (lcgn.py:303-323).
+ * x [N, in], q_encoding [B, Q], lstm_outputs [L, B, O], x_ctx_init [N, O] = the noise the reference
+ * draws with torch.randn on the CPU generator (lcgn.py:306; the caller draws it the same way),
+ * out [N, O].  Needs a finalized intra-graph batch. */
+size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* d);
+int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p,
+                          const float* x, const float* q_encoding, const float* lstm_outputs,
+                          const float* x_ctx_init, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * In-library stage timing (HIP events recorded on the caller's stream around each stage).
  * Used by bench.py to obtain the message-passing kernel's launch duration inside the timed
  * region.  Off by default; costs two hipEventRecord per stage when on.

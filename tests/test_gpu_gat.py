@@ -360,3 +360,43 @@ def test_gine_unaligned_width_and_cross_graph_edges(dev):
                    t(gb.batch, device=dev), return_convs=True)
     _, ref_convs = R.gine_seq(t(x), t(ei), t(ea), t(ins), t(gb.batch), tparams(p), return_convs=True)
     assert maxabs(torch.stack(convs), torch.stack(ref_convs)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# LCGN variant
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lcgn_seq_small", "lcgn_seq_debug4_d512"])
+def test_lcgn_seq_golden(dev, name):
+    from graphvqa_amd.lcgn import lcgn_seq
+    meta, g = load_golden(name)
+    s = meta["input_seeds"]
+    O, in_c, L = meta["out_channels"], meta["in_channels"], meta["L"]
+    N, B = g["batch"].shape[0], int(g["batch"].max()) + 1
+    p = synth.lcgn_seq_params(in_c, O, seed=meta["param_seed"], cmd_dim=O, question_dim=O)
+    m = lcgn_seq(in_channels=in_c, out_channels=O, edge_attr_dim=in_c, num_ins=5, gat_cmd_dim=O, question_dim=O,
+                 MAX_ITER_NUM=4, dropout=0.1, gat_heads=1)
+    _load_module(m, p, dev)
+    x, q, lstm = synth.normal((N, in_c), s["x"]), synth.normal((B, O), s["q"]), synth.normal((L, B, O), s["lstm"])
+    torch.manual_seed(meta["torch_seed"])        # the module draws x_ctx like the reference (lcgn.py:306)
+    out = m(t(x, device=dev), t(g["edge_index"], device=dev), t(g["batch"], device=dev), t(q, device=dev),
+            t(lstm, device=dev))
+    assert maxabs(out, g["out"]) < TOL
+    out2 = m(t(x, device=dev), t(g["edge_index"], device=dev), t(g["batch"], device=dev), t(q, device=dev),
+             t(lstm, device=dev), x_ctx_init=t(g["x_ctx_init"], device=dev))
+    assert torch.equal(out, out2)
+
+
+def test_lcgn_config2_shape_vs_oracle(dev):
+    """BASELINE config 5 shape (fp32): config-2 batch, lcgn_seq(in=300, out=512, cmd=512, H=1, 4 iterations), L=10."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.lcgn import lcgn_seq
+    gb = synth.make_graph_batch(200, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=1.0)
+    N, B, O, L = gb.num_nodes, gb.num_graphs, 512, 10
+    p = synth.lcgn_seq_params(300, O, seed=808)
+    m = _load_module(lcgn_seq(300, O, 300, 5), p, dev)
+    x, q, lstm = synth.normal((N, 300), 1), synth.normal((B, O), 2), synth.normal((L, B, O), 3)
+    x_ctx = synth.normal((N, O), 4)
+    out = m(t(x, device=dev), t(gb.edge_index, device=dev), t(gb.batch, device=dev), t(q, device=dev),
+            t(lstm, device=dev), x_ctx_init=t(x_ctx, device=dev))
+    ref = R.lcgn_seq(t(x), t(gb.edge_index), t(gb.batch), t(q), t(lstm), tparams(p), t(x_ctx))
+    assert maxabs(out, ref) < TOL
