@@ -201,7 +201,7 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-template <int H>
+template <int H, int ITEMS>
 __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t off_src = (size_t)a.e_cap * H * 4;
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     // i = tid / lpn + k * (MP_THREADS / lpn).
     const int lpn_log = a.lpn_log, lpn = 1 << lpn_log;
     const int q = tid & (lpn - 1), i_base = tid >> lpn_log, i_step = MP_THREADS >> lpn_log;
-    float4 acc[MP_ITEMS];
+    float4 acc[ITEMS];
 #pragma unroll
-    for (int k = 0; k < MP_ITEMS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ITEMS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_h = 1.0f / H;
     const bool relu = a.bn_w != nullptr;
 
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         if (q < q4c) {
             if (j < H) {
 #pragma unroll
-                for (int k = 0; k < MP_ITEMS; ++k) {
+                for (int k = 0; k < ITEMS; ++k) {
                     const int i = i_base + k * i_step;
                     if (i < tn) {
                         const int lo = rowp_l[i], hi = rowp_l[i + 1];
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                 }
             }
             if (j == spc - 1) {      // last stage of this channel range: epilogue + store
+                // per-channel epilogue constants live in LDS: no ordinary global load inside the stage loop
                 const int c = c0 + q * 4;
                 const float4 pb = *reinterpret_cast<const float4*>(cst + c);
                 const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                 const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
                 const float4 gs = *reinterpret_cast<const float4*>(cst + 4 * C + c);
 #pragma unroll
-                for (int k = 0; k < MP_ITEMS; ++k) {
+                for (int k = 0; k < ITEMS; ++k) {
                     const int i = i_base + k * i_step;
                     if (i < tn) {
                         const bool has_edges = rowp_l[i + 1] > rowp_l[i];
@@ -518,6 +519,8 @@ static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
     const size_t forced_cw = env_size("GVQA_MP_CW", 0);
     const size_t forced_nbuf = env_size("GVQA_MP_NBUF", 2);   // measured: deeper prefetch does not pay
     const size_t forced_lds = env_size("GVQA_MP_LDS", 0);
+    // 3 graphs per CU, else 2, else 1 (measured at config 3: 4 per CU with narrower channel ranges is
+    // slower -- 228 us vs 166 us -- the per-stage overhead outweighs the removed block-wave tail)
     const size_t targets[3] = {LDS_MAX / 3, LDS_MAX / 2, LDS_MAX};
     for (int ti = 0; ti < 3 && !p.ok; ++ti) {
         const size_t target = forced_lds ? (forced_lds < LDS_MAX ? forced_lds : LDS_MAX) : targets[ti];
@@ -549,17 +552,24 @@ static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
     return p;
 }
 
-template <int H>
-static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
+template <int H, int ITEMS>
+static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H>),
+        GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H, ITEMS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gat_mp_tiled<H>), dim3((unsigned)B), dim3(MP_THREADS), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_gat_mp_tiled<H, ITEMS>), dim3((unsigned)B), dim3(MP_THREADS), p.lds_bytes, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
+}
+
+template <int H>
+static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
+    // fewer accumulators (registers) when the largest graph needs only two node passes per thread
+    if ((size_t)p.n_cap <= (size_t)2 * (MP_THREADS >> p.lpn_log)) return launch_tiled_i<H, 2>(a, p, B, stream);
+    return launch_tiled_i<H, MP_ITEMS>(a, p, B, stream);
 }
 
 static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {

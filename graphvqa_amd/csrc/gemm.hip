@@ -13,6 +13,8 @@
 // The K index inside a 32x32x2 step is free to permute (both operands use the same map), so
 // lane-half kk = lane>>5 takes the 4 consecutive k's [8t+4kk, 8t+4kk+4) from ONE b128 read and
 // feeds 4 MFMA steps from it.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gvqa {
@@ -23,16 +25,16 @@ constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;   // padded leading dimension (floats)
 
 template <int BM, int BN, int WR, int WC, bool VEC>
-__global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const float* __restrict__ A,
+__global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K, const float* __restrict__ A,
                                                     int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                     LinearEpilogue ep, float* C, int64_t ldc,
                                                     int64_t strideA, int64_t strideB, int64_t strideC) {
-    static_assert(WR * WC == 4, "4 waves per block");
+    constexpr int NTH = 64 * WR * WC;             // threads per block
     constexpr int WM = BM / WR, WN = BN / WC;     // wave tile
     constexpr int MT = WM / 32, NT = WN / 32;     // 32x32 MFMA tiles per wave
-    constexpr int A_V4 = BM * BK / 4 / 256;       // float4 staged per thread
-    constexpr int B_V4 = (BN * BK / 4 + 255) / 256;
-    static_assert(BM * BK / 4 % 256 == 0, "A tile must divide evenly");
+    constexpr int A_V4 = BM * BK / 4 / NTH;       // float4 staged per thread
+    constexpr int B_V4 = (BN * BK / 4 + NTH - 1) / NTH;
+    static_assert(BM * BK / 4 % NTH == 0, "A tile must divide evenly");
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
@@ -77,12 +79,12 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
         const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTH;
             ra[i] = load_one(A, lda, M, m0 + (idx >> 3), k0 + (idx & 7) * 4);
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
-            const int idx = min(tid + i * 256, BN * BK / 4 - 1);
+            const int idx = min(tid + i * NTH, BN * BK / 4 - 1);
             rb[i] = load_one(B, ldb, N, n0 + (idx >> 3), k0 + (idx & 7) * 4);
         }
     };
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
         const bool tail = k0 + BK > K;      // block-uniform: only the last K tile needs masking
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTH;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
             float4 v = ra[i];
             if (tail) v = mask_k(v, k0 + c4);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void k_linear_f32(int M, int N, int K, const f
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTH;
             if (idx < BN * BK / 4) {
                 const int r = idx >> 3, c4 = (idx & 7) * 4;
                 float4 v = rb[i];
@@ -196,16 +198,20 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     do {                                                                                               \
         dim3 grid((unsigned)cdiv(N, BN_), (unsigned)cdiv(M, BM_), (unsigned)batch);                    \
         if (vec)                                                                                       \
-            hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, true>), grid, dim3(256), 0, stream,   \
+            hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, true>), grid, dim3(64 * WR_ * WC_), 0, stream, \
                                (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA,            \
                                strideB, strideC);                                                      \
         else                                                                                           \
-            hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, false>), grid, dim3(256), 0, stream,  \
+            hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, false>), grid, dim3(64 * WR_ * WC_), 0, stream, \
                                (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA,            \
                                strideB, strideC);                                                      \
     } while (0)
+    static const int tile_sel = []() { const char* v = getenv("GVQA_GEMM_TILE"); return v ? atoi(v) : 0; }();
     if (N <= 32) GVQA_LAUNCH_LINEAR(128, 32, 4, 1);
     else if (N <= 64) GVQA_LAUNCH_LINEAR(128, 64, 2, 2);
+    else if (tile_sel == 1 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 4, 2);
+    else if (tile_sel == 2 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 2, 2);
+    else if (tile_sel == 3) GVQA_LAUNCH_LINEAR(128, 128, 4, 2);
     else GVQA_LAUNCH_LINEAR(128, 128, 2, 2);
 #undef GVQA_LAUNCH_LINEAR
     GVQA_LAUNCH_CHECK();

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE configs that are not the headline bench line:
+config 2 (GAT, d=300, 1k graphs), config 4 (GINEConv x5 on the config-2 batch), config 5 shape (LCGN, fp32).
+Prints one JSON object; run on the GPU box:  python scripts/bench_configs.py > gpurun_out/configs.json"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from graphvqa_amd import synth, _lib
+from graphvqa_amd.graph import SceneGraphBatch
+
+tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+dev = torch.device("cuda:0")
+
+
+def timed(fn, warmup=3, steps=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    _lib.prof_enable(True); _lib.prof_collect()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = _lib.prof_collect(); _lib.prof_enable(False)
+    return dt, {k: (v[0] / steps, v[1] // steps) for k, v in prof.items() if v[1]}
+
+
+def load(m, p):
+    m.load_state_dict({k: tt(v) for k, v in p.items()})
+    return m.to(dev).eval()
+
+
+res = {}
+gb = synth.config2_batch()
+N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+ei, batch = tt(gb.edge_index).to(dev), tt(gb.batch).to(dev)
+x, ea = tt(synth.normal((N, 300), 1)).to(dev), tt(synth.normal((E, 300), 2)).to(dev)
+ins = tt(synth.normal((5, B, 512), 3)).to(dev)
+
+from graphvqa_amd.gat_skip import gat_seq
+m = load(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303))
+dt, prof = timed(lambda: m(x, ei, ea, ins, batch))
+mp_ms, mp_n = prof["mp"]
+alg = 4 * (N * 4 * 300 + 2 * N * 4 + E * 4 + E + (N + 1) + N * 300) + 4 * N * 300
+res["config2_gat_d300"] = {"N": N, "E": E, "B": B, "ms_per_forward": dt * 1e3, "edges_per_s": E / dt,
+                           "mp_us_per_hop": mp_ms / mp_n * 1e3, "mp_alg_bytes": alg,
+                           "mp_GBps": alg / (mp_ms / mp_n * 1e-3) / 1e9, "stage_ms": {k: v[0] for k, v in prof.items()}}
+
+from graphvqa_amd.baseline_models import gine_seq, gcn_seq
+m = load(gine_seq(300, 300, 512), synth.gine_seq_params(300, 300, 512, 404))
+g = SceneGraphBatch(ei, batch, N, B)
+dt, prof = timed(lambda: m(x, ei, ea, ins, batch, graph=g, return_convs=True))
+agg_ms, agg_n = prof["mp"]
+alg = 4 * (N * 300 + E * 300 + E + (N + 1) + N * 300)
+res["config4_gine_convs"] = {"ms_per_5_convs_plus_module": dt * 1e3, "edges_per_s": E / dt,
+                             "aggregate_us_per_layer": agg_ms / agg_n * 1e3, "aggregate_alg_bytes": alg,
+                             "aggregate_GBps": alg / (agg_ms / agg_n * 1e-3) / 1e9,
+                             "stage_ms": {k: v[0] for k, v in prof.items()}}
+dt, _ = timed(lambda: m(x, ei, ea, ins, batch))
+res["config4_gine_module_as_written"] = {"ms": dt * 1e3}
+m = load(gcn_seq(300, 300, 512), synth.gcn_seq_params(300, 300, 512, 505))
+dt, prof = timed(lambda: m(x, ei, ins, batch, graph=g, return_convs=True))
+res["gcn_convs"] = {"ms_per_5_convs_plus_module": dt * 1e3, "stage_ms": {k: v[0] for k, v in prof.items()}}
+
+from graphvqa_amd.lcgn import lcgn_seq
+m = load(lcgn_seq(300, 512, 300, 5), synth.lcgn_seq_params(300, 512, seed=808))
+q, lstm = tt(synth.normal((B, 512), 5)).to(dev), tt(synth.normal((10, B, 512), 6)).to(dev)
+xc = tt(synth.normal((N, 512), 7)).to(dev)
+dt, prof = timed(lambda: m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc))
+res["config5_lcgn_fp32"] = {"ms_per_forward": dt * 1e3, "edges_per_s": E / dt, "stage_ms": {k: v[0] for k, v in prof.items()}}
+print(json.dumps(res))
