@@ -135,6 +135,7 @@ struct MpArgs {
     int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
     int nbuf;                 // stage buffers in LDS (prefetch depth = nbuf - 1)
     int lpn_log;              // log2(lanes per node) in the aggregation mapping
+    int dbg;                  // profiling experiments only (GVQA_MP_DBG): 1 no DMA, 2 no aggregation, 4 no alpha prologue, 8 no stores, 16 no consts
     float slope, bn_eps;
 };
 
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int tn = n1 - n0;
-    if (tn <= 0) return;
+    if (tn <= 0 || (a.dbg & 32)) return;
     const int e0 = a.rowptr[n0], ne = a.rowptr[n1] - e0;
     const int tid = threadIdx.x;
     const int wave_unit0 = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -231,19 +232,21 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const int dma_round_rows = MP_THREADS / q4cap, dma_round_cols = MP_THREADS - dma_round_rows * q4cap;
     const int dma_row0 = tid / q4cap, dma_col0 = tid - dma_row0 * q4cap;   // unit `tid` of a full-width range
 
-    // stage t -> DMA of a [tn x q4c] float4 tile (row segments of q4c*16 contiguous bytes) into
-    // stage buffer t % nbuf.  Every wave issues the same number of DMAs per stage (lanes past the
-    // end re-load the last unit into the buffer's padding), so the counted vmcnt below is exact.
-    auto prefetch = [&](int t) {
-        const int cr = t / spc, j = t - cr * spc;
-        const int c0 = cr * a.cw;
+    // DMA of one stage -- head j (or the skip rows when j == H) of the channel range starting at
+    // c0 -- as a [tn x q4c] float4 tile (row segments of q4c*16 contiguous bytes) into stage buffer
+    // `bufi`.  Every wave issues the same number of DMAs per stage (lanes past the end re-load the
+    // last unit into the buffer's padding), so the counted vmcnt below is exact.
+    // All stage bookkeeping is incremental (adds and compares): the scalar unit is shared by every
+    // wave of the CU and runtime integer divisions here made it the kernel's bottleneck.
+    auto prefetch = [&](int j, int c0, int bufi) {
+        if (a.dbg & 1) return;
         const int q4c = min(a.cw, C - c0) >> 2;
         const int units = tn * q4c;
         const float* base;
         int64_t row_stride;
         if (j < H) { base = a.xp + (int64_t)n0 * a.xp_ld + (int64_t)j * C + c0; row_stride = a.xp_ld; }
         else       { base = a.skip + (int64_t)n0 * a.skip_ld + c0;             row_stride = a.skip_ld; }
-        unsigned dst = lds_base + (unsigned)(off_buf + (size_t)(t % a.nbuf) * buf_bytes) + (unsigned)wave_unit0 * 16u;
+        unsigned dst = lds_base + (unsigned)off_buf + (unsigned)bufi * (unsigned)buf_bytes + (unsigned)wave_unit0 * 16u;
         int row, col, rstep, cstep;
         if (q4c == q4cap) { row = dma_row0; col = dma_col0; rstep = dma_round_rows; cstep = dma_round_cols; }
         else { row = tid / q4c; col = tid - row * q4c; rstep = MP_THREADS / q4c; cstep = MP_THREADS - rstep * q4c; }
@@ -257,12 +260,18 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
             if (col >= q4c) { col -= q4c; ++row; }
         }
     };
+    // advance a (j, c0, buffer) stage cursor by one stage
+    auto advance = [&](int& j, int& c0, int& bufi) {
+        if (++j == spc) { j = 0; c0 += a.cw; }
+        if (++bufi == a.nbuf) bufi = 0;
+    };
 
     const int depth = a.nbuf - 1;
-    for (int t = 0; t < depth && t < T; ++t) prefetch(t);
+    int pf_j = 0, pf_c0 = 0, pf_buf = 0, pf_t = 0;      // cursor of the next stage to prefetch
+    for (; pf_t < depth && pf_t < T; ++pf_t) { prefetch(pf_j, pf_c0, pf_buf); advance(pf_j, pf_c0, pf_buf); }
 
     // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
-    for (int s = tid; s < ne; s += MP_THREADS) {
+    for (int s = tid; s < ne && !(a.dbg & 4); s += MP_THREADS) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
         src_l[s] = src - n0;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         for (int h = 0; h < H; ++h) alpha_s[s * H + h] = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + ae[h];
     }
     for (int i = tid; i <= tn; i += MP_THREADS) rowp_l[i] = a.rowptr[n0 + i] - e0;
-    for (int c = tid; c < C; c += MP_THREADS) {
+    for (int c = tid; c < C && !(a.dbg & 16); c += MP_THREADS) {
         cst[c] = a.graph_term ? a.graph_term[(int64_t)g * a.t_ld + c] : 0.f;
         cst[C + c] = a.bias ? a.bias[c] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
-    for (int it = tid; it < tn * H; it += MP_THREADS) {
+    for (int it = tid; it < tn * H && !(a.dbg & 4); it += MP_THREADS) {
         const int i = it / H, h = it - i * H;
         const int lo = rowp_l[i], hi = rowp_l[i + 1];
         float ar = a.a_node ? a.a_node[(int64_t)(n0 + i) * 2 * H + H + h] : 0.f;
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         }
     }
 
+    if (a.dbg & 64) return;
     // ---- stage loop ----
     // Work item = (node i, float4 column q).  A node's columns sit on `lpn` consecutive lanes
     // (power of two >= cw/4, so the (i, q) split is shifts only); a thread walks nodes
@@ -323,12 +333,31 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const float inv_h = 1.0f / H;
     const bool relu = a.bn_w != nullptr;
 
-    auto dma_count = [&](int t) -> int {     // DMA instructions per wave for stage t
-        if (t >= T) return 0;
-        const int cr = t / spc;
-        return (tn * (min(a.cw, C - cr * a.cw) >> 2) + MP_THREADS - 1) / MP_THREADS;
-    };
+    // DMA instructions per wave for a stage of a full-width / of the last (narrower) channel range
+    const int dma_full = (tn * q4cap + MP_THREADS - 1) / MP_THREADS;
+    const int dma_last = (tn * ((C - (nch - 1) * a.cw) >> 2) + MP_THREADS - 1) / MP_THREADS;
+    const int last_c0 = (nch - 1) * a.cw;
 
+    // Per-item row extents and the wave-uniform trip count of the 4-wide edge loop are the same in
+    // every stage: computed once per graph.  (Wave-uniform trips + branch-free body: a divergent
+    // loop costs ~8 scalar instructions of exec-mask handling per trip.)
+    int it_lo[ITEMS], it_hi[ITEMS], it_trips[ITEMS];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // rowp_l / alpha_s complete before they are read below
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int i = i_base + k * i_step;
+        const bool valid = q < q4cap && i < tn;
+        const int ii = min(i, tn - 1);
+        it_lo[k] = valid ? rowp_l[ii] : 0;
+        it_hi[k] = valid ? rowp_l[ii + 1] : 0;
+        int trips = (it_hi[k] - it_lo[k] + 3) >> 2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
+        it_trips[k] = __builtin_amdgcn_readfirstlane(trips);
+    }
+
+    int cur_j = 0, cur_c0 = 0, cur_buf = 0;               // cursor of the stage being consumed
     for (int t = 0; t < T; ++t) {
         // Wait until stage t has landed: this wave's DMAs of stage t are older than those of stages
         // t+1 .. t+depth-1, loads retire in order, so "at most N outstanding" with N = the younger
@@ -336,92 +365,97 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         // raw barrier (no compiler fence, which would drain the whole DMA queue): every wave's
         // part of stage t is in LDS, and everybody is done computing stage t-1, whose buffer the
         // prefetch of stage t+depth overwrites.
-        int allow = 0;
-        for (int k = 1; k < depth; ++k) allow += dma_count(t + k);
-        switch (allow) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        if (depth <= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            int allow = 0, jj = cur_j, cc = cur_c0, bb = cur_buf;
+            for (int k = 1; k < depth && t + k < T; ++k) {
+                advance(jj, cc, bb);
+                allow += (cc == last_c0) ? dma_last : dma_full;
+            }
+            switch (allow) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + depth < T) prefetch(t + depth);
+        if (pf_t < T) { prefetch(pf_j, pf_c0, pf_buf); advance(pf_j, pf_c0, pf_buf); ++pf_t; }
 
-        const int cr = t / spc, j = t - cr * spc;
-        const int c0 = cr * a.cw;
+        const int j = cur_j, c0 = cur_c0;
         const int q4c = min(a.cw, C - c0) >> 2;
-        const float4* buf4 = reinterpret_cast<const float4*>(smem + off_buf + (size_t)(t % a.nbuf) * buf_bytes);
-        if (q < q4c) {
-            if (j < H) {
+        const float4* buf4 = reinterpret_cast<const float4*>(smem + off_buf + (size_t)cur_buf * buf_bytes);
+        const bool lane_on = q < q4c;
+        const int qq = lane_on ? q : 0;
+        if (j < H && !(a.dbg & 2)) {
 #pragma unroll
-                for (int k = 0; k < ITEMS; ++k) {
-                    const int i = i_base + k * i_step;
-                    if (i < tn) {
-                        const int lo = rowp_l[i], hi = rowp_l[i + 1];
-                        float4 s4 = acc[k];
-                        // four edges per trip, branch-free (clamped index, zero weight for padding):
-                        // the 8 scalar and 4 vector LDS reads issue back to back instead of
-                        // forming one dependent chain per edge
-                        for (int s = lo; s < hi; s += 4) {
-                            int sl[4];
-                            float al[4];
+            for (int k = 0; k < ITEMS; ++k) {
+                const int lo = it_lo[k], hi = it_hi[k], trips = it_trips[k];
+                float4 s4 = acc[k];
+                for (int tr = 0; tr < trips; ++tr) {
+                    const int s = lo + tr * 4;
+                    int sl[4];
+                    float al[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int idx = min(s + e, hi - 1);
-                                sl[e] = src_l[idx];
-                                al[e] = (s + e < hi) ? alpha_s[idx * H + j] : 0.f;
-                            }
-                            float4 v[4];
+                    for (int e = 0; e < 4; ++e) {      // clamped index, zero weight past the end of the row
+                        const int idx = max(min(s + e, hi - 1), 0);
+                        sl[e] = src_l[idx];
+                        al[e] = (s + e < hi) ? alpha_s[idx * H + j] : 0.f;
+                    }
+                    float4 v[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = buf4[sl[e] * q4c + q];
+                    for (int e = 0; e < 4; ++e) v[e] = buf4[sl[e] * q4c + qq];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                s4.x += al[e] * v[e].x; s4.y += al[e] * v[e].y;
-                                s4.z += al[e] * v[e].z; s4.w += al[e] * v[e].w;
-                            }
-                        }
-                        acc[k] = s4;
+                    for (int e = 0; e < 4; ++e) {
+                        s4.x += al[e] * v[e].x; s4.y += al[e] * v[e].y;
+                        s4.z += al[e] * v[e].z; s4.w += al[e] * v[e].w;
                     }
                 }
+                acc[k] = s4;
             }
-            if (j == spc - 1) {      // last stage of this channel range: epilogue + store
-                // per-channel epilogue constants live in LDS: no ordinary global load inside the stage loop
-                const int c = c0 + q * 4;
-                const float4 pb = *reinterpret_cast<const float4*>(cst + c);
-                const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
-                const float4 sc = *reinterpret_cast<const float4*>(cst + 2 * C + c);
-                const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
-                const float4 gs = *reinterpret_cast<const float4*>(cst + 4 * C + c);
+        }
+        if (j == spc - 1 && lane_on) {      // last stage of this channel range: epilogue + store
+            // per-channel epilogue constants live in LDS: no ordinary global load inside the stage loop
+            const int c = c0 + q * 4;
+            const float4 pb = *reinterpret_cast<const float4*>(cst + c);
+            const float4 bi = *reinterpret_cast<const float4*>(cst + C + c);
+            const float4 sc = *reinterpret_cast<const float4*>(cst + 2 * C + c);
+            const float4 sh = *reinterpret_cast<const float4*>(cst + 3 * C + c);
+            const float4 gs = *reinterpret_cast<const float4*>(cst + 4 * C + c);
 #pragma unroll
-                for (int k = 0; k < ITEMS; ++k) {
-                    const int i = i_base + k * i_step;
-                    if (i < tn) {
-                        const bool has_edges = rowp_l[i + 1] > rowp_l[i];
-                        float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
-                        if (a.graph_scale) { r.x *= gs.x; r.y *= gs.y; r.z *= gs.z; r.w *= gs.w; }
-                        if (has_edges) { r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w; }
-                        r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
-                        if (a.skip) {
-                            const float4 sk = buf4[i * q4c + q];
-                            r.x += sk.x; r.y += sk.y; r.z += sk.z; r.w += sk.w;
-                        }
-                        if (relu) {
-                            r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
-                            r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
-                        }
-                        *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
-                        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < ITEMS; ++k) {
+                const int i = i_base + k * i_step;
+                if (i < tn) {
+                    const bool has_edges = rowp_l[i + 1] > rowp_l[i];
+                    float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
+                    if (a.graph_scale) { r.x *= gs.x; r.y *= gs.y; r.z *= gs.z; r.w *= gs.w; }
+                    if (has_edges) { r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w; }
+                    r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
+                    if (a.skip) {
+                        const float4 sk = buf4[i * q4c + q];
+                        r.x += sk.x; r.y += sk.y; r.z += sk.z; r.w += sk.w;
                     }
+                    if (relu) {
+                        r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
+                        r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
+                    }
+                    if (!(a.dbg & 8)) *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
                 }
             }
         }
+        if (j == spc - 1) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        advance(cur_j, cur_c0, cur_buf);
     }
 }
 
@@ -594,7 +628,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.bias = d->bias;
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
     a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_csr = nullptr;
-    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0;
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0; a.dbg = (int)env_size("GVQA_MP_DBG", 0);
     a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
     const int force = d->force;
     const float* graph_term = d->graph_term;
