@@ -182,6 +182,7 @@ def main():
                          "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
                          "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
             "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
+            "gemm_backend": _lib.load().gvqa_gemm_backend().decode(),
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(params)

@@ -78,4 +78,6 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
                      int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, hipStream_t stream);
 
+const char* gemm_backend_name();
+
 }  // namespace gvqa

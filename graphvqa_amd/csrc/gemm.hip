@@ -13,7 +13,10 @@
 // The K index inside a 32x32x2 step is free to permute (both operands use the same map), so
 // lane-half kk = lane>>5 takes the 4 consecutive k's [8t+4kk, 8t+4kk+4) from ONE b128 read and
 // feeds 4 MFMA steps from it.
+#include <dlfcn.h>
 #include <stdlib.h>
+
+#include <mutex>
 
 #include "common.h"
 
@@ -170,6 +173,67 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
     }
 }
 
+// ---- vendor backend for PLAIN large projections ---------------------------------------------------
+// Epilogue-free fp32 GEMMs above a size threshold go to rocBLAS (Tensile f32-MFMA kernels: 126-140 TF
+// on the config-3 projection vs ~100-112 TF for k_linear_f32 above); everything with a fused epilogue,
+// the tall-skinny logit products and all small shapes stay on the hand-written kernel.  rocBLAS is
+// resolved with dlopen at first use, so the library has no link-time dependency on it and loads on
+// machines without it (the hand-written kernel is then used everywhere).
+// GVQA_GEMM_BACKEND = auto (default) | hip (hand-written only) | rocblas (vendor wherever eligible).
+namespace {
+typedef void* rb_handle;
+typedef int (*rb_create_t)(rb_handle*);
+typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
+typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
+                          const float*, float*, int);
+struct Vendor {
+    bool tried = false, ok = false;
+    rb_handle handle = nullptr;
+    rb_set_stream_t set_stream = nullptr;
+    rb_sgemm_t sgemm = nullptr;
+    int mode = 0;   // 0 auto, 1 hip only, 2 vendor wherever eligible
+};
+Vendor g_vendor;
+std::mutex g_vendor_mu;
+
+Vendor& vendor() {
+    std::lock_guard<std::mutex> lk(g_vendor_mu);
+    if (g_vendor.tried) return g_vendor;
+    g_vendor.tried = true;
+    const char* be = getenv("GVQA_GEMM_BACKEND");
+    if (be && !strcmp(be, "hip")) { g_vendor.mode = 1; return g_vendor; }
+    if (be && !strcmp(be, "rocblas")) g_vendor.mode = 2;
+    void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return g_vendor;
+    rb_create_t create = reinterpret_cast<rb_create_t>(dlsym(lib, "rocblas_create_handle"));
+    g_vendor.set_stream = reinterpret_cast<rb_set_stream_t>(dlsym(lib, "rocblas_set_stream"));
+    g_vendor.sgemm = reinterpret_cast<rb_sgemm_t>(dlsym(lib, "rocblas_sgemm"));
+    if (!create || !g_vendor.set_stream || !g_vendor.sgemm) return g_vendor;
+    if (create(&g_vendor.handle) != 0) return g_vendor;
+    g_vendor.ok = true;
+    return g_vendor;
+}
+
+// C_rm[M,N] = A_rm[M,K] . B_rm[N,K]^T  ==  column-major  C^T[N,M] = (B^T)^T . A^T
+bool vendor_sgemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                  int64_t ldc, hipStream_t stream) {
+    Vendor& v = vendor();
+    if (!v.ok) return false;
+    const float one = 1.f, zero = 0.f;
+    std::lock_guard<std::mutex> lk(g_vendor_mu);
+    if (v.set_stream(v.handle, stream) != 0) return false;
+    return v.sgemm(v.handle, /*transpose*/ 112, /*none*/ 111, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &zero,
+                   C, (int)ldc) == 0;
+}
+}  // namespace
+
+const char* gemm_backend_name() {
+    Vendor& v = vendor();
+    if (v.mode == 1) return "hip (k_linear_f32, forced)";
+    return v.ok ? "rocblas for plain projections >= 2 GFLOP, k_linear_f32 otherwise" : "hip (k_linear_f32; rocblas unavailable)";
+}
+
 int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                   int64_t ldb, const float* bias, int relu, float* C, int64_t ldc, int batch,
                   int64_t strideA, int64_t strideB, int64_t strideC, hipStream_t stream) {
@@ -191,6 +255,10 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
                  "linear: epilogue leading dimension too small");
     GVQA_REQUIRE((!ep.addend && !ep.mul) || batch == 1, GVQA_E_INVALID, "linear: addend/mul epilogue is not batched");
     // 16-byte vector loads need 16-byte aligned rows
+    if (!ep.bias && !ep.addend && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
+        (2.0 * M * N * K >= 2e9 || vendor().mode == 2) && vendor().mode != 1) {
+        if (vendor_sgemm(M, N, K, A, lda, B, ldb, C, ldc, stream)) return GVQA_OK;
+    }
     const bool vec = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
                      (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -219,6 +287,8 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
 }
 
 }  // namespace gvqa
+
+extern "C" const char* gvqa_gemm_backend(void) { return gvqa::gemm_backend_name(); }
 
 extern "C" int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                                   int64_t ldb, const float* bias, const float* addend, int64_t ld_add,

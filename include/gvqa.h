@@ -155,6 +155,10 @@ int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t 
                        const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_add,
                        const float* mul, int64_t ld_mul, int relu, float* C, int64_t ldc, void* stream);
 
+/* Which GEMM backend serves the plain dense projections in this process (hand-written k_linear_f32,
+ * or rocBLAS for large epilogue-free products; GVQA_GEMM_BACKEND=auto|hip|rocblas). */
+const char* gvqa_gemm_backend(void);
+
 /* The fused GAT message-passing kernel on its own (SURVEY 2.1 K4-K9 + K11): attention logits
  * -> leaky-relu -> softmax over incoming edges -> alpha-weighted sum of projected source
  * features -> head mean -> (x graph scale) (+graph term) + bias + skip -> (BN -> ReLU).
