@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-head", action="store_true",
+                    help="also run global attention pooling + answer classifier each step and all-gather the true logits")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,8 +130,21 @@ def main():
     ins = tt(synth.normal((K, B, D), 3 + 10 * rank)).to(dev)
     ei, batch = tt(gb.edge_index).to(dev), tt(gb.batch).to(dev)
 
+    head = None
+    if a.with_head:
+        from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+        pool = MyConditionalGlobalAttention(D, D)
+        pool.load_state_dict({k: tt(v) for k, v in synth.attention_pool_params(D, D, seed=811).items()})
+        clf = ShortAnswerClassifier(D, 512, 1842)
+        clf.load_state_dict({k: tt(v) for k, v in synth.classifier_params(D, 512, 1842, seed=822).items()})
+        head = (pool.to(dev).eval(), clf.to(dev).eval())
+        q_feat = tt(synth.normal((B, D), 4 + 10 * rank)).to(dev)
+
     def step():
         h = m(x, ei, ea, ins, batch)
+        if head is not None:
+            logits = head[1](head[0](h, q_feat, batch), q_feat)
+            return all_gather_graph_rows(logits, counts=[B] * world) if world > 1 else logits
         if world > 1:
             return all_gather_graph_rows(graph_mean_pool(h, batch, B), counts=[B] * world)
         return h

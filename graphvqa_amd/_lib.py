@@ -90,6 +90,16 @@ class LcgnParams(C.Structure):
                 ("bias", C.c_void_p)]
 
 
+class PoolParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("node0_weight", "node0_bias", "node2_weight", "node2_bias", "ques0_weight",
+                                          "ques0_bias", "ques2_weight", "ques2_bias", "gate0_weight", "gate0_bias",
+                                          "gate2_weight", "gate2_bias")]
+
+
+class ClassifierParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias")]
+
+
 class GatDims(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
                 ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
@@ -133,6 +143,12 @@ PROTOTYPES = {
     "gvqa_lcgn_seq_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(LcgnDims), C.POINTER(LcgnParams), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
+    "gvqa_attention_pool_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32, C.c_int32]),
+    "gvqa_attention_pool_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.POINTER(PoolParams), C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_answer_logits_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gvqa_answer_logits_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ClassifierParams),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -66,7 +66,7 @@ struct LinearEpilogue {
     int64_t ld_add;
     const float* mul;       // [M, ld_mul] or NULL
     int64_t ld_mul;
-    int relu;
+    int relu;               // activation: 0 none, 1 ReLU, 2 ELU(alpha = 1)
 };
 
 // GEMM entry used by the orchestration code (defined in gemm.hip).

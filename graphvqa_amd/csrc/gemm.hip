@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
                     float v = acc[i][j][r] + bv;
                     if (ep.addend) v += ep.addend[(int64_t)gr * ep.ld_add + gc];
                     if (ep.mul) v *= ep.mul[(int64_t)gr * ep.ld_mul + gc];
-                    if (ep.relu) v = fmaxf(v, 0.f);
+                    if (ep.relu == 1) v = fmaxf(v, 0.f);
+                    else if (ep.relu == 2) v = v > 0.f ? v : expf(v) - 1.f;   // ELU(alpha = 1), torch's exp(x) - 1 form
                     C[(int64_t)gr * ldc + gc] = v;
                 }
             }

@@ -1,0 +1,134 @@
+// Step right after the execution path ("next" row): language-conditioned global
+// attention pooling and the short-answer classifier.
+//
+// Reference being replaced: MyConditionalGlobalAttention.forward (pipeline_model_gat.py:149-181;
+// PyG softmax over `batch` + torch_scatter.scatter_add, K13 in SURVEY 2.1) and logit_fc fed with
+// [g || q || g*q] (pipeline_model_gat.py:722-728, 814-816).  Per-graph segment softmax reuses the
+// batch structure (graph_ptr) of the graph container; the dense layers run on k_linear_f32.
+#include "common.h"
+
+namespace gvqa {
+
+// prod[n, c] = qn[g(n), c] * xn[n, c]                       (ques_nn(u)[batch] * x, :165)
+__global__ __launch_bounds__(256) void k_scale_rows_by_graph(int64_t N, int C, const int32_t* __restrict__ node_graph,
+                                                             const float* __restrict__ qn, const float* __restrict__ xn,
+                                                             float* __restrict__ prod) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = (int)(i / C), c = (int)(i - (int64_t)n * C);
+    prod[i] = qn[(int64_t)node_graph[n] * C + c] * xn[i];
+}
+
+// One block per graph: softmax of the node gates (PyG: exp(g - max) / (sum + 1e-16)), then
+// out[g, :] = sum_n p_n xn[n, :] with nodes added in order (scatter_add order).
+__global__ __launch_bounds__(256) void k_graph_attention_pool(int C, const int32_t* __restrict__ graph_ptr,
+                                                              const float* __restrict__ gate, const float* __restrict__ xn,
+                                                              float* __restrict__ out) {
+    const int g = blockIdx.x;
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    float m = -INFINITY;
+    for (int n = n0; n < n1; ++n) m = fmaxf(m, gate[n]);
+    float den = 0.f;
+    for (int n = n0; n < n1; ++n) den += expf(gate[n] - m);
+    den += 1e-16f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int n = n0; n < n1; ++n) acc += (expf(gate[n] - m) / den) * xn[(int64_t)n * C + c];
+        out[(int64_t)g * C + c] = acc;
+    }
+}
+
+// feat[b] = [g || q || g * q]                                                            (:814)
+__global__ __launch_bounds__(256) void k_head_features(int64_t B, int Q, const float* __restrict__ g, const float* __restrict__ q,
+                                                       float* __restrict__ feat) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Q) return;
+    const int64_t b = i / Q;
+    const int c = (int)(i - b * Q);
+    const float gv = g[i], qv = q[i];
+    feat[b * 3 * Q + c] = gv;
+    feat[b * 3 * Q + Q + c] = qv;
+    feat[b * 3 * Q + 2 * Q + c] = gv * qv;
+}
+
+struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, total; };
+static PoolLayout pool_layout(int64_t N, int64_t B, int Ch) {
+    PoolLayout L; size_t off = 0;
+    auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
+    L.h1 = take((size_t)N * Ch); L.xn = take((size_t)N * Ch); L.qh = take((size_t)B * Ch); L.qn = take((size_t)B * Ch);
+    L.prod = take((size_t)N * Ch); L.z = take((size_t)N * Ch); L.gate = take((size_t)N);
+    L.total = off;
+    return L;
+}
+
+}  // namespace gvqa
+
+extern "C" {
+using namespace gvqa;
+
+size_t gvqa_attention_pool_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t channels) {
+    (void)node_dim;
+    if (!g) return 0;
+    return pool_layout(g->num_nodes, g->num_graphs, channels).total;
+}
+
+int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, const gvqa_pool_params* p, const float* x,
+                                const float* u, float* out, void* ws, size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(g && p, GVQA_E_INVALID, "attention_pool: null argument");
+    GVQA_REQUIRE(Dn > 0 && Ch > 0, GVQA_E_INVALID, "attention_pool: bad dims");
+    GVQA_REQUIRE(p->node0_weight && p->node0_bias && p->node2_weight && p->node2_bias && p->ques0_weight && p->ques0_bias &&
+                 p->ques2_weight && p->ques2_bias && p->gate0_weight && p->gate0_bias && p->gate2_weight && p->gate2_bias,
+                 GVQA_E_INVALID, "attention_pool: null weight");
+    const int64_t N = g->num_nodes, B = g->num_graphs;
+    PoolLayout L = pool_layout(N, B, Ch);
+    GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "attention_pool: workspace %zu < required %zu", ws_bytes, L.total);
+    if (B == 0) return GVQA_OK;
+    GVQA_REQUIRE(u && out && (N == 0 || x), GVQA_E_INVALID, "attention_pool: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* base = static_cast<char*>(ws);
+    auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    StageTimer timer(GVQA_STAGE_OTHER, stream);
+    int rc;
+#define LIN(M_, N_, K_, A_, W_, b_, act_, C_)                                                                  \
+    do { rc = launch_linear(M_, N_, K_, A_, K_, W_, K_, b_, act_, C_, N_, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
+    LIN(N, Ch, Dn, x, p->node0_weight, p->node0_bias, 1, P(L.h1));                 // node_nn (:160)
+    LIN(N, Ch, Ch, P(L.h1), p->node2_weight, p->node2_bias, 0, P(L.xn));
+    LIN(B, Ch, Ch, u, p->ques0_weight, p->ques0_bias, 1, P(L.qh));                 // ques_nn (:165)
+    LIN(B, Ch, Ch, P(L.qh), p->ques2_weight, p->ques2_bias, 0, P(L.qn));
+    if (N > 0) {
+        hipLaunchKernelGGL(k_scale_rows_by_graph, dim3((unsigned)cdiv(N * Ch, 256)), dim3(256), 0, stream, N, Ch, g->node_graph,
+                           P(L.qn), P(L.xn), P(L.prod));
+        GVQA_LAUNCH_CHECK();
+    }
+    LIN(N, Ch, Ch, P(L.prod), p->gate0_weight, p->gate0_bias, 1, P(L.z));          // gate_nn (:165)
+    LIN(N, 1, Ch, P(L.z), p->gate2_weight, p->gate2_bias, 0, P(L.gate));
+#undef LIN
+    hipLaunchKernelGGL(k_graph_attention_pool, dim3((unsigned)B), dim3(256), 0, stream, Ch, g->graph_ptr, P(L.gate), P(L.xn), out);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+size_t gvqa_answer_logits_workspace_bytes(int64_t B, int32_t Q, int32_t hidden) {
+    if (B < 0 || Q <= 0 || hidden <= 0) return 0;
+    return align_up((size_t)B * 3 * Q * 4, 256) + align_up((size_t)B * hidden * 4, 256);
+}
+
+int gvqa_answer_logits_forward(int64_t B, int32_t Q, int32_t hidden, int32_t A, const gvqa_classifier_params* p,
+                               const float* g_feat, const float* q, float* logits, void* ws, size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(p && B >= 0 && Q > 0 && hidden > 0 && A > 0, GVQA_E_INVALID, "answer_logits: bad argument");
+    GVQA_REQUIRE(p->fc1_weight && p->fc1_bias && p->fc2_weight && p->fc2_bias, GVQA_E_INVALID, "answer_logits: null weight");
+    GVQA_REQUIRE(ws && ws_bytes >= gvqa_answer_logits_workspace_bytes(B, Q, hidden), GVQA_E_WORKSPACE, "answer_logits: workspace too small");
+    if (B == 0) return GVQA_OK;
+    GVQA_REQUIRE(g_feat && q && logits, GVQA_E_INVALID, "answer_logits: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* feat = static_cast<float*>(ws);
+    float* hid = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)B * 3 * Q * 4, 256));
+    StageTimer timer(GVQA_STAGE_OTHER, stream);
+    hipLaunchKernelGGL(k_head_features, dim3((unsigned)cdiv(B * Q, 256)), dim3(256), 0, stream, B, Q, g_feat, q, feat);
+    GVQA_LAUNCH_CHECK();
+    int rc = launch_linear(B, hidden, 3 * Q, feat, 3 * Q, p->fc1_weight, 3 * Q, p->fc1_bias, 2 /* ELU */, hid, hidden, 1, 0, 0, 0, stream);
+    if (rc) return rc;
+    return launch_linear(B, A, hidden, hid, hidden, p->fc2_weight, hidden, p->fc2_bias, 0, logits, A, 1, 0, 0, 0, stream);
+}
+
+}  // extern "C"

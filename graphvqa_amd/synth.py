@@ -260,3 +260,23 @@ def lcgn_seq_params(in_channels: int, out_channels: int, seed: int, cmd_dim: int
         p[f"bns.{j}.running_mean"], p[f"bns.{j}.running_var"] = rm, rv
         p[f"bns.{j}.num_batches_tracked"] = np.zeros((), np.int64)
     return p
+
+
+def attention_pool_params(num_node_features: int, channels: int, seed: int) -> dict:
+    """`MyConditionalGlobalAttention(num_node_features, num_out_features)` (pipeline_model_gat.py:134-147)."""
+    p = {}
+    p.update(_linear(channels, channels, seed + 1, prefix="gate_nn.0."))
+    p.update(_linear(1, channels, seed + 2, prefix="gate_nn.2."))
+    p.update(_linear(channels, num_node_features, seed + 3, prefix="node_nn.0."))
+    p.update(_linear(channels, channels, seed + 4, prefix="node_nn.2."))
+    p.update(_linear(channels, channels, seed + 5, prefix="ques_nn.0."))
+    p.update(_linear(channels, channels, seed + 6, prefix="ques_nn.2."))
+    return p
+
+
+def classifier_params(question_dim: int, hidden: int, num_answers: int, seed: int, prefix: str = "logit_fc.") -> dict:
+    """`logit_fc` = Seq(Dropout, Lin(3Q, hidden), ELU, Dropout, Lin(hidden, A)) (pipeline_model_gat.py:718-728)."""
+    p = {}
+    p.update(_linear(hidden, 3 * question_dim, seed + 1, prefix=prefix + "1."))
+    p.update(_linear(num_answers, hidden, seed + 2, prefix=prefix + "4."))
+    return p

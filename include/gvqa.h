@@ -149,7 +149,7 @@ int gvqa_linear_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
                     const float* B, int64_t ldb, const float* bias, int relu,
                     float* C, int64_t ldc, void* stream);
 /* Same with the full epilogue: v = acc + bias[n]; v += addend[m*ld_add + n]; v *= mul[m*ld_mul + n];
- * relu.  addend may alias C (accumulate a second product in place: split-source concatenations,
+ * activation (`relu`: 0 none, 1 ReLU, 2 ELU).  addend may alias C (accumulate a second product in place: split-source concatenations,
  * lcgn.py:316-319).  bias / addend / mul may be NULL. */
 int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_add,
@@ -284,6 +284,43 @@ size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* 
 int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p,
                           const float* x, const float* q_encoding, const float* lstm_outputs,
                           const float* x_ctx_init, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step after the path ("next" row): language-conditioned global attention pooling and
+ * the short-answer classifier (pipeline_model_gat.py:108-185, :722-728, :800-816)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gvqa_pool_params {     /* MyConditionalGlobalAttention: {node,ques,gate}_nn.{0,2}.{weight,bias} */
+    const float* node0_weight;  /* [Ch, node_dim] */
+    const float* node0_bias;
+    const float* node2_weight;  /* [Ch, Ch] */
+    const float* node2_bias;
+    const float* ques0_weight;  /* [Ch, Ch] */
+    const float* ques0_bias;
+    const float* ques2_weight;  /* [Ch, Ch] */
+    const float* ques2_bias;
+    const float* gate0_weight;  /* [Ch, Ch] */
+    const float* gate0_bias;
+    const float* gate2_weight;  /* [1, Ch] */
+    const float* gate2_bias;    /* [1] */
+} gvqa_pool_params;
+
+/* x' = node_nn(x); gate = gate_nn(ques_nn(u)[batch] * x'); softmax over the nodes of each graph;
+ * out[g] = sum_n gate[n] x'[n].  x [N, node_dim], u [B, Ch], out [B, Ch]. */
+size_t gvqa_attention_pool_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t channels);
+int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t node_dim, int32_t channels, const gvqa_pool_params* p,
+                                const float* x, const float* u, float* out, void* ws, size_t ws_bytes, void* stream);
+
+typedef struct gvqa_classifier_params {   /* logit_fc.{1,4}.{weight,bias} */
+    const float* fc1_weight;    /* [hidden, 3Q] */
+    const float* fc1_bias;
+    const float* fc2_weight;    /* [A, hidden] */
+    const float* fc2_bias;
+} gvqa_classifier_params;
+
+/* logits = fc2(ELU(fc1([g || q || g*q])))  (eval: dropouts inactive).  g_feat, q [B, Q]; logits [B, A]. */
+size_t gvqa_answer_logits_workspace_bytes(int64_t B, int32_t Q, int32_t hidden);
+int gvqa_answer_logits_forward(int64_t B, int32_t Q, int32_t hidden, int32_t A, const gvqa_classifier_params* p,
+                               const float* g_feat, const float* q, float* logits, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * In-library stage timing (HIP events recorded on the caller's stream around each stage).

@@ -266,3 +266,30 @@ def lcgn_seq(x, edge_index, batch, q_encoding, lstm_outputs, p, x_ctx_init, max_
         ctxs.append(x_ctx)
     out = F.linear(torch.cat([x_loc, x_ctx], dim=-1), p["fin_layer.weight"], p["fin_layer.bias"])
     return (out, ctxs) if return_all else out
+
+
+# ----------------------------------------------------------------------------
+# Step after the path: language-conditioned global attention pooling + classifier
+# ----------------------------------------------------------------------------
+def _mlp2(x, p, prefix):
+    """Seq(Lin, ReLU, Lin) with state_dict keys prefix.0.* / prefix.2.*"""
+    h = F.relu(F.linear(x, p[prefix + "0.weight"], p[prefix + "0.bias"]))
+    return F.linear(h, p[prefix + "2.weight"], p[prefix + "2.bias"])
+
+
+def global_attention_pool(x, u, batch, p, num_graphs):
+    """`MyConditionalGlobalAttention.forward` (pipeline_model_gat.py:149-181):
+    x' = node_nn(x); gate = gate_nn(ques_nn(u)[batch] * x'); softmax over the nodes of each graph;
+    out[g] = sum_n gate[n] x'[n]."""
+    xn = _mlp2(x, p, "node_nn.")
+    gate = _mlp2(_mlp2(u, p, "ques_nn.").index_select(0, batch) * xn, p, "gate_nn.")
+    gate = segment_softmax(gate, batch, num_graphs)
+    return scatter_add_rows(gate * xn, batch, num_graphs)
+
+
+def short_answer_logits(g_feat, q, p, prefix="logit_fc."):
+    """pipeline_model_gat.py:814-816 with logit_fc = Seq(Dropout, Lin(3Q,512), ELU, Dropout, Lin(512,A))
+    (:722-728), eval mode."""
+    feat = torch.cat((g_feat, q, g_feat * q), dim=-1)
+    h = F.elu(F.linear(feat, p[prefix + "1.weight"], p[prefix + "1.bias"]))
+    return F.linear(h, p[prefix + "4.weight"], p[prefix + "4.bias"])

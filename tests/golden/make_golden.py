@@ -287,7 +287,39 @@ def gen_lcgn():
              edge_index=gb.edge_index, batch=gb.batch, x_ctx_init=x_ctx_init, out=out)
 
 
+def gen_head():
+    """Pooling + classifier (the step right after the path): the reference's own
+    MyConditionalGlobalAttention (pipeline_model_gat.py:108-185) and a Sequential laid out like
+    `logit_fc` (:722-728) fed as at :814-816."""
+    stub_dataset_entry()
+    import pipeline_model_gat as PM
+
+    for name, in_c, ch, nans, graphs in (("pool_head_small", 20, 32, 50, None), ("pool_head_debug4", 300, 512, 1842, "debug")):
+        if graphs is None:
+            gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
+        else:
+            gb = batch_scene_graphs(list(debug_graphs().values()))
+        N, B = gb.num_nodes, gb.num_graphs
+        pool = PM.MyConditionalGlobalAttention(num_node_features=in_c, num_out_features=ch)
+        pp = synth.attention_pool_params(in_c, ch, seed=811)
+        load_params(pool, pp)
+        fc = torch.nn.Sequential(torch.nn.Dropout(p=0.2), torch.nn.Linear(3 * ch, ch), torch.nn.ELU(),
+                                 torch.nn.Dropout(p=0.2), torch.nn.Linear(ch, nans))
+        cp = synth.classifier_params(ch, ch, nans, seed=822, prefix="")
+        load_params(fc, cp)
+        x, u = synth.normal((N, in_c), 51), synth.normal((B, ch), 52)
+        with torch.no_grad():
+            g_feat = pool(t(x), t(u), t(gb.batch))
+            logits = fc(torch.cat((g_feat, t(u), g_feat * t(u)), dim=-1))
+        save(name, dict(case="MyConditionalGlobalAttention + logit_fc eval", ref="pipeline_model_gat.py:149-181,814-816",
+                        in_channels=in_c, channels=ch, num_answers=nans, pool_seed=811, fc_seed=822,
+                        input_seeds=dict(x=51, u=52)),
+             batch=gb.batch, pooled=g_feat, logits=logits)
+
+
 if __name__ == "__main__":
+    gen_head()
+    sys.exit(0) if "--head-only" in sys.argv else None
     gen_gat()
     gen_gine_gcn()
     gen_lcgn()

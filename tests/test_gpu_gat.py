@@ -400,3 +400,21 @@ def test_lcgn_config2_shape_vs_oracle(dev):
             t(lstm, device=dev), x_ctx_init=t(x_ctx, device=dev))
     ref = R.lcgn_seq(t(x), t(gb.edge_index), t(gb.batch), t(q), t(lstm), tparams(p), t(x_ctx))
     assert maxabs(out, ref) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row 8f-2: global attention pooling + short-answer classifier
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["pool_head_small", "pool_head_debug4"])
+def test_pool_and_classifier_golden(dev, name):
+    from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+    meta, g = load_golden(name)
+    in_c, ch, nans = meta["in_channels"], meta["channels"], meta["num_answers"]
+    N, B = g["batch"].shape[0], int(g["batch"].max()) + 1
+    pool = _load_module(MyConditionalGlobalAttention(in_c, ch), synth.attention_pool_params(in_c, ch, seed=meta["pool_seed"]), dev)
+    head = _load_module(ShortAnswerClassifier(ch, ch, nans), synth.classifier_params(ch, ch, nans, seed=meta["fc_seed"]), dev)
+    x, u = synth.normal((N, in_c), meta["input_seeds"]["x"]), synth.normal((B, ch), meta["input_seeds"]["u"])
+    pooled = pool(t(x, device=dev), t(u, device=dev), t(g["batch"], device=dev))
+    assert maxabs(pooled, g["pooled"]) < 2e-5
+    logits = head(pooled, t(u, device=dev))
+    assert maxabs(logits, g["logits"]) < TOL

@@ -111,3 +111,17 @@ def test_lcgn_seq(name):
     # the stored noise is what torch.randn draws under the recorded seed (lcgn.py:306)
     torch.manual_seed(meta["torch_seed"])
     assert torch.equal(torch.randn(N, O), t(g["x_ctx_init"]))
+
+
+@pytest.mark.parametrize("name", ["pool_head_small", "pool_head_debug4"])
+def test_pool_and_classifier(name):
+    meta, g = load_golden(name)
+    in_c, ch, nans = meta["in_channels"], meta["channels"], meta["num_answers"]
+    N, B = g["batch"].shape[0], int(g["batch"].max()) + 1
+    pp = tparams(synth.attention_pool_params(in_c, ch, seed=meta["pool_seed"]))
+    cp = tparams(synth.classifier_params(ch, ch, nans, seed=meta["fc_seed"]))
+    x, u = synth.normal((N, in_c), meta["input_seeds"]["x"]), synth.normal((B, ch), meta["input_seeds"]["u"])
+    pooled = R.global_attention_pool(t(x), t(u), t(g["batch"]), pp, B)
+    assert maxabs(pooled, g["pooled"]) < TOL
+    logits = R.short_answer_logits(pooled, t(u), cp)
+    assert maxabs(logits, g["logits"]) < 5e-5
