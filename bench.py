@@ -111,8 +111,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("GVQA_BENCH_FORCE_DIST"))      # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -144,9 +149,9 @@ def main():
         h = m(x, ei, ea, ins, batch)
         if head is not None:
             logits = head[1](head[0](h, q_feat, batch), q_feat)
-            return all_gather_graph_rows(logits, counts=[B] * world) if world > 1 else logits
-        if world > 1:
-            return all_gather_graph_rows(graph_mean_pool(h, batch, B), counts=[B] * world)
+            return all_gather_graph_rows(logits, counts=[B] * world, force=force_dist) if dist is not None else logits
+        if dist is not None:
+            return all_gather_graph_rows(graph_mean_pool(h, batch, B), counts=[B] * world, force=force_dist)
         return h
 
     def fence():
@@ -201,10 +206,23 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(params)
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would
+        # otherwise be flushed at exit, AFTER our line: flush the C streams first so that the JSON
+        # line is the last thing on stdout.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

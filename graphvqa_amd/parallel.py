@@ -50,11 +50,11 @@ def graph_mean_pool(h: torch.Tensor, batch: torch.Tensor, num_graphs: int) -> to
     return out / cnt[:, None]
 
 
-def all_gather_graph_rows(rows: torch.Tensor, counts=None) -> torch.Tensor:
+def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False) -> torch.Tensor:
     """All-gather per-graph rows [B_r, C] from every rank into [sum B_r, C] (rank order).
     Ragged shards are padded to the largest B_r (one collective, latency-bound at these sizes)."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return rows
     world = dist.get_world_size()
     if counts is None:
