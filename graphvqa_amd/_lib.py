@@ -123,6 +123,9 @@ PROTOTYPES = {
     "gvqa_gat_seq_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_gat_seq_forward_trainbn": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_linear_f32": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_linear_f32_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

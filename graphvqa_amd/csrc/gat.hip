@@ -663,6 +663,62 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     return GVQA_OK;
 }
 
+// ---- train-mode BatchNorm1d forward (batch statistics over all N rows, gat_skip.py:274) ----------
+// Deterministic two-level column reductions (no atomics): partial[b, c] over row blocks, then a
+// fixed-order finish.  Two passes (mean, then sum of squared deviations) like torch's CPU kernel.
+constexpr int BN_ROWS_PER_BLOCK = 256;
+
+__global__ __launch_bounds__(256) void k_col_partial(int64_t N, int C, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS_PER_BLOCK, r1 = min(N, r0 + BN_ROWS_PER_BLOCK);
+    const float m = mean ? mean[c] : 0.f;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float v = x[r * C + c] - m;
+        acc += mean ? v * v : v;
+    }
+    partial[(int64_t)blockIdx.y * C + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_col_finish(int nblocks, int C, const float* __restrict__ partial, float inv_n,
+                                                    float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * C + c];
+    out[c] = acc * inv_n;
+}
+
+// h = relu((h - mean) * invstd * w + b), in place
+__global__ __launch_bounds__(256) void k_bn_apply_relu(int64_t total, int C, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float eps, float* __restrict__ h) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float invstd = 1.0f / sqrtf(var[c] + eps);
+        h[i] = fmaxf((h[i] - mean[c]) * invstd * w[c] + b[c], 0.f);
+    }
+}
+
+static int bn_train_forward(int64_t N, int C, float* h, const gvqa_gat_conv_params* p, float eps, float* stats /* [2,C] */,
+                            float* partial, hipStream_t stream) {
+    StageTimer t(GVQA_STAGE_OTHER, stream);
+    const int nb = (int)cdiv(N, BN_ROWS_PER_BLOCK);
+    dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb);
+    hipLaunchKernelGGL(k_col_partial, grid, dim3(256), 0, stream, N, C, h, nullptr, partial);
+    hipLaunchKernelGGL(k_col_finish, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, nb, C, partial, 1.0f / (float)N, stats);
+    hipLaunchKernelGGL(k_col_partial, grid, dim3(256), 0, stream, N, C, h, stats, partial);
+    hipLaunchKernelGGL(k_col_finish, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, nb, C, partial, 1.0f / (float)N, stats + C);
+    int64_t blocks = cdiv(N * C, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_bn_apply_relu, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, C, stats, stats + C, p->bn_weight,
+                       p->bn_bias, eps, h);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
 int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
     return launch_gat_mp(g, d, ws, ws_bytes, stream);
 }
@@ -671,7 +727,7 @@ int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
 // Drivers
 // ==============================================================================================
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, total;
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, total;
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d) {
@@ -693,6 +749,8 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.h0 = take((size_t)N * C);
     L.h1 = take((size_t)N * C);
     L.alpha_csr = take((size_t)E * H);
+    L.bn_partial = take((size_t)cdiv(N > 0 ? N : 1, BN_ROWS_PER_BLOCK) * C);
+    L.bn_stats = take(2 * C);
     L.total = off;
     return L;
 }
@@ -804,9 +862,9 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
     return launch_gat_mp(g, &m, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
 }
 
-int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
-                         const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
-                         void* ws, size_t ws_bytes, void* stream_) {
+static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+                                const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
+                                float* bn_stats_out, void* ws, size_t ws_bytes, void* stream_) {
     GVQA_REQUIRE(g && hops, GVQA_E_INVALID, "gat_seq: null argument");
     int rc = check_dims(d, true);
     if (rc) return rc;
@@ -858,6 +916,8 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
             if (rc) return rc;
         }
         gvqa_gat_mp_desc m = mp_desc_from(d, &hops[i]);
+        const bool train_bn = bn_stats_out && hops[i].bn_weight;
+        if (train_bn) { m.bn_weight = m.bn_bias = m.bn_mean = m.bn_var = nullptr; }   // BN applied after the batch statistics
         m.xp = P(L.xp); m.a_node = P(L.a_node);
         m.a_edge = P(L.a_edge) + (int64_t)i * H; m.a_edge_stride = (int64_t)K * H;
         m.graph_term = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr; m.graph_term_ld = Tld;
@@ -865,6 +925,12 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
         m.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
         rc = launch_gat_mp(g, &m, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
         if (rc) return rc;
+        if (train_bn) {
+            GVQA_REQUIRE(hops[i].bn_bias, GVQA_E_INVALID, "gat_seq: BatchNorm needs weight and bias");
+            float* st = bn_stats_out + (int64_t)i * 2 * C;
+            rc = bn_train_forward(N, C, h_next, &hops[i], d->bn_eps, st, P(L.bn_partial), stream);
+            if (rc) return rc;
+        }
         h = h_next;
     }
     if (hop_out) {
@@ -873,6 +939,19 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
                                       hipMemcpyDeviceToDevice, stream));
     }
     return GVQA_OK;
+}
+
+int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+                         const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
+                         void* ws, size_t ws_bytes, void* stream) {
+    return gat_seq_forward_impl(g, d, hops, x, edge_attr, instr, out, alpha_out, hop_out, nullptr, ws, ws_bytes, stream);
+}
+
+int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+                                 const float* edge_attr, const float* instr, float* out, float* bn_stats_out, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    GVQA_REQUIRE(bn_stats_out, GVQA_E_INVALID, "gat_seq_trainbn: null statistics buffer");
+    return gat_seq_forward_impl(g, d, hops, x, edge_attr, instr, out, nullptr, nullptr, bn_stats_out, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -7,9 +7,10 @@ reference (`gat`: gat_skip.py:60-63,111-112; `gat_seq`: gat_skip.py:224-225,249)
 (pipeline_model_gat.py:823-836).  The compute runs in hand-written HIP kernels behind the
 C ABI of include/gvqa.h; torch only provides device memory and the current stream.
 
-Scope: inference (eval-mode BatchNorm, dropout inactive).  `.train()` with dropout p > 0 is not
-reproducible against torch's RNG and raises; `.train()` with p == 0 (batch-statistics BN) is a
-"next" row and raises NotImplementedError as well.  There is no CPU path: CPU
+Scope: forward.  `.eval()` (running-statistics BatchNorm, dropout inactive) is the measured path;
+`.train()` with dropout p == 0 runs the batch-statistics BatchNorm forward and updates the running
+statistics like torch; `.train()` with p > 0 is not reproducible against torch's RNG and raises.
+Backward is a "next" row.  There is no CPU path: CPU
 tensors raise, and a missing HIP library raises at construction.
 """
 from __future__ import annotations
@@ -164,10 +165,11 @@ class gat_seq(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph: Optional[SceneGraphBatch] = None,
                 return_attention_weights: bool = False, return_hops: bool = False):
-        if self.training:
+        if self.training and self.dropout > 0:
             raise NotImplementedError(
-                "gat_seq on the HIP path implements inference (eval-mode BatchNorm, dropout inactive); "
-                "call .eval().  Training mode is a 'next' row (SURVEY 8f-4).")
+                "gat_seq.train() with dropout p > 0 is not implemented on the HIP path (the masks are not "
+                "reproducible against torch's RNG); use .eval(), or dropout=0 for the train-mode BatchNorm "
+                "forward.  Backward is a 'next' row (SURVEY 8f-4).")
         lib = _lib.load()
         assert x.dim() == 2, "Static graphs not supported in `GATConv`."
         x = _f32c(x, "x")
@@ -196,6 +198,8 @@ class gat_seq(torch.nn.Module):
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
         alpha = torch.empty((K, E, H), dtype=torch.float32, device=dev) if return_attention_weights else None
         hop_out = torch.empty((K, N, Cc), dtype=torch.float32, device=dev) if return_hops else None
+        if self.training:
+            return self._forward_train_bn(lib, graph, d, hops, x, edge_attr, instr, out)
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_gat_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), dev)
             _lib.check(lib.gvqa_gat_seq_forward(C.byref(graph.c), C.byref(d), hops, x.data_ptr(),
@@ -206,9 +210,33 @@ class gat_seq(torch.nn.Module):
             return out, alpha, hop_out
         return out
 
+    def _forward_train_bn(self, lib, graph, d, hops, x, edge_attr, instr, out):
+        """model.train() with dropout p = 0: BatchNorm uses batch statistics over all N rows
+        (gat_skip.py:274) and its running statistics are updated like torch does (momentum, unbiased
+        variance, num_batches_tracked)."""
+        K, N, Cc, dev = len(self.convs), x.shape[0], self.out_channels, x.device
+        stats = torch.empty((max(K - 1, 1), 2, Cc), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = _workspace(lib.gvqa_gat_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), dev)
+            _lib.check(lib.gvqa_gat_seq_forward_trainbn(C.byref(graph.c), C.byref(d), hops, x.data_ptr(),
+                                                        edge_attr.data_ptr(), instr.data_ptr(), out.data_ptr(),
+                                                        stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+        with torch.no_grad():
+            for j, bn in enumerate(self.bns):
+                if not bn.track_running_stats:
+                    continue
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                unbiased = stats[j, 1] * (N / max(N - 1, 1))
+                bn.running_mean.mul_(1 - mom).add_(stats[j, 0], alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(unbiased, alpha=mom)
+        return out
+
     def _forward_unfolded(self, x, edge_index, edge_attr, instr, batch, graph):
         """Batches whose edges cross graphs (never produced by the reference's collate): run the
         reference's literal per-hop formulation (gat_skip.py:254-276) on the generic conv op."""
+        if self.training:
+            raise NotImplementedError("train-mode forward needs an intra-graph batch")
         K = len(self.convs)
         h = x
         edge_batch = batch[edge_index[0]]

@@ -139,6 +139,16 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
                          float* out, float* alpha_out, float* hop_out,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Same forward with TRAIN-mode BatchNorm (model.train(), gat_skip.py:273-276): after every hop but the
+ * last, BN uses the batch statistics over all N node rows (biased variance, eps), then ReLU.  The
+ * attention / feature dropouts are NOT applied (the caller must have p = 0; they are not
+ * reproducible against torch's RNG).  bn_stats_out [K-1, 2, C] receives per hop the batch mean and
+ * the biased batch variance, from which the caller updates running_mean / running_var
+ * (momentum, unbiased variance) exactly as torch does.  bn_mean / bn_var of `hops` are ignored. */
+int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops,
+                                 const float* x, const float* edge_attr, const float* instr, float* out,
+                                 float* bn_stats_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Building blocks exported for tests, benchmarks and the variants' host code
  * ---------------------------------------------------------------------------------------- */

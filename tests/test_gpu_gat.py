@@ -270,9 +270,27 @@ def test_config3_full_size_properties(dev):
     assert maxabs(out[:nn], out_s) < 2e-5
 
 
+def test_gat_seq_train_mode_batchnorm_golden(dev):
+    """model.train(), dropout p=0: batch-statistics BN forward and running-stat update (gat_skip.py:273-276)."""
+    from graphvqa_amd.gat_skip import gat_seq
+    meta, g0 = load_golden("gat_seq_small")
+    _, g = load_golden("gat_seq_small_trainbn")
+    dn, de, di, K, H = meta["dn"], meta["de"], meta["di"], meta["K"], meta["heads"]
+    p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=meta["param_seed"])
+    m = gat_seq(dn, dn, de, di, K, dropout=0.0, gat_heads=H)
+    _load_module(m, p, dev)
+    m.train()
+    out = m(*[t(g0[k], device=dev) for k in ("x", "edge_index", "edge_attr", "instr", "batch")])
+    assert maxabs(out, g["out"]) < TOL
+    rm = torch.stack([bn.running_mean for bn in m.bns])
+    rv = torch.stack([bn.running_var for bn in m.bns])
+    assert maxabs(rm, g["running_mean_after"]) < 1e-5 and maxabs(rv, g["running_var_after"]) < 1e-5
+    assert int(m.bns[0].num_batches_tracked) == 1
+
+
 def test_errors_are_loud(dev):
     from graphvqa_amd.gat_skip import gat_seq
-    m = gat_seq(8, 8, 8, 8, 2, gat_heads=4).to(dev)
+    m = gat_seq(8, 8, 8, 8, 2, dropout=0.1, gat_heads=4).to(dev)
     x = torch.zeros(3, 8)
     with pytest.raises(NotImplementedError):
         m(x.to(dev), torch.zeros(2, 0, dtype=torch.int64, device=dev), torch.zeros(0, 8, device=dev),
