@@ -42,10 +42,10 @@ def mp_algorithmic_bytes(N, E, C, Hh, fused_skip=True):
 
 def measured_traffic():
     """HBM bytes per launch of the message-passing kernel from the committed PMC passes
-    (profiles/r01_pmc_hbm_cfg3.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    (profiles/r01b_pmc_hbm_cfg3.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_cfg3.json")) as f:
-            return json.load(f)["k_gat_mp_tiled<4>"]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_cfg3.json")) as f:
+            return json.load(f)["mp_kernel"]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -195,7 +195,7 @@ def main():
                                    "CSR build from COO inside the step",
                        "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
                        "parallelism": f"graphs sharded over {world} GPU(s), all-gather of per-graph rows"},
-            "roofline": {"bound": "hbm", "kernel": "k_gat_mp_tiled<4>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_gat_mp_tiled<4,2>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": measured_traffic(), "algorithmic_bytes_per_launch": alg,
