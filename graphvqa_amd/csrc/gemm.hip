@@ -16,7 +16,11 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+#include <hipblaslt/hipblaslt.h>
+
+#include <map>
 #include <mutex>
+#include <tuple>
 
 #include "common.h"
 
@@ -286,65 +290,157 @@ __global__ __launch_bounds__(256, 5) void k_linear_f32_s16(int M, int N, int K, 
     }
 }
 
-// ---- vendor backend for PLAIN large projections ---------------------------------------------------
-// Epilogue-free fp32 GEMMs above a size threshold go to rocBLAS (Tensile f32-MFMA kernels: 126-140 TF
-// on the config-3 projection vs ~100-112 TF for k_linear_f32 above); everything with a fused epilogue,
-// the tall-skinny logit products and all small shapes stay on the hand-written kernel.  rocBLAS is
-// resolved with dlopen at first use, so the library has no link-time dependency on it and loads on
-// machines without it (the hand-written kernel is then used everywhere).
-// GVQA_GEMM_BACKEND = auto (default) | hip (hand-written only) | rocblas (vendor wherever eligible).
+// ---- vendor backends for PLAIN large projections ------------------------------------------------
+// Epilogue-free fp32 GEMMs above a size threshold go to the vendor library (f32-MFMA assembly
+// kernels: 126-150 TF on the projection shapes vs ~100-112 TF for k_linear_f32 above); everything
+// with a fused epilogue, the tall-skinny logit products and all small shapes stay on the
+// hand-written kernel.  hipBLASLt is tried first, then rocBLAS; both are resolved with dlopen at
+// first use, so the library has no link-time dependency on them and loads on machines without
+// them (the hand-written kernel is then used everywhere).
+// GVQA_GEMM_BACKEND = auto (default) | hip (hand-written only) | hipblaslt | rocblas.
 namespace {
 typedef void* rb_handle;
 typedef int (*rb_create_t)(rb_handle*);
 typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
 typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
                           const float*, float*, int);
+struct LtPlan {
+    hipblasLtMatmulDesc_t desc;
+    hipblasLtMatrixLayout_t la, lb, lc;
+    hipblasLtMatmulAlgo_t algo;
+    bool ok;
+};
 struct Vendor {
-    bool tried = false, ok = false;
-    rb_handle handle = nullptr;
-    rb_set_stream_t set_stream = nullptr;
-    rb_sgemm_t sgemm = nullptr;
-    int mode = 0;   // 0 auto, 1 hip only, 2 vendor wherever eligible
+    bool tried = false;
+    int mode = 0;                 // 0 auto, 1 hip only, 2 hipblaslt only, 3 rocblas only
+    // rocBLAS
+    bool rb_ok = false;
+    rb_handle rb = nullptr;
+    rb_set_stream_t rb_set_stream = nullptr;
+    rb_sgemm_t rb_sgemm = nullptr;
+    // hipBLASLt
+    bool lt_ok = false;
+    hipblasLtHandle_t lt = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) lt_desc_create = nullptr;
+    decltype(&hipblasLtMatmulDescSetAttribute) lt_desc_set = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) lt_layout_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) lt_pref_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceDestroy) lt_pref_destroy = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) lt_heuristic = nullptr;
+    decltype(&hipblasLtMatmul) lt_matmul = nullptr;
+    std::map<std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t>, LtPlan> plans;
 };
 Vendor g_vendor;
 std::mutex g_vendor_mu;
 
-Vendor& vendor() {
-    std::lock_guard<std::mutex> lk(g_vendor_mu);
-    if (g_vendor.tried) return g_vendor;
-    g_vendor.tried = true;
+void vendor_init_locked() {
+    Vendor& v = g_vendor;
+    if (v.tried) return;
+    v.tried = true;
     const char* be = getenv("GVQA_GEMM_BACKEND");
-    if (be && !strcmp(be, "hip")) { g_vendor.mode = 1; return g_vendor; }
-    if (be && !strcmp(be, "rocblas")) g_vendor.mode = 2;
-    void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) return g_vendor;
-    rb_create_t create = reinterpret_cast<rb_create_t>(dlsym(lib, "rocblas_create_handle"));
-    g_vendor.set_stream = reinterpret_cast<rb_set_stream_t>(dlsym(lib, "rocblas_set_stream"));
-    g_vendor.sgemm = reinterpret_cast<rb_sgemm_t>(dlsym(lib, "rocblas_sgemm"));
-    if (!create || !g_vendor.set_stream || !g_vendor.sgemm) return g_vendor;
-    if (create(&g_vendor.handle) != 0) return g_vendor;
-    g_vendor.ok = true;
-    return g_vendor;
+    if (be && !strcmp(be, "hip")) { v.mode = 1; return; }
+    if (be && !strcmp(be, "hipblaslt")) v.mode = 2;
+    if (be && !strcmp(be, "rocblas")) v.mode = 3;
+    if (v.mode != 3) {
+        void* lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
+        if (lib) {
+            auto create = reinterpret_cast<decltype(&hipblasLtCreate)>(dlsym(lib, "hipblasLtCreate"));
+            v.lt_desc_create = reinterpret_cast<decltype(v.lt_desc_create)>(dlsym(lib, "hipblasLtMatmulDescCreate"));
+            v.lt_desc_set = reinterpret_cast<decltype(v.lt_desc_set)>(dlsym(lib, "hipblasLtMatmulDescSetAttribute"));
+            v.lt_layout_create = reinterpret_cast<decltype(v.lt_layout_create)>(dlsym(lib, "hipblasLtMatrixLayoutCreate"));
+            v.lt_pref_create = reinterpret_cast<decltype(v.lt_pref_create)>(dlsym(lib, "hipblasLtMatmulPreferenceCreate"));
+            v.lt_pref_destroy = reinterpret_cast<decltype(v.lt_pref_destroy)>(dlsym(lib, "hipblasLtMatmulPreferenceDestroy"));
+            v.lt_heuristic = reinterpret_cast<decltype(v.lt_heuristic)>(dlsym(lib, "hipblasLtMatmulAlgoGetHeuristic"));
+            v.lt_matmul = reinterpret_cast<decltype(v.lt_matmul)>(dlsym(lib, "hipblasLtMatmul"));
+            if (create && v.lt_desc_create && v.lt_desc_set && v.lt_layout_create && v.lt_pref_create && v.lt_pref_destroy &&
+                v.lt_heuristic && v.lt_matmul && create(&v.lt) == HIPBLAS_STATUS_SUCCESS)
+                v.lt_ok = true;
+        }
+    }
+    if (v.mode != 2) {
+        void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (lib) {
+            rb_create_t create = reinterpret_cast<rb_create_t>(dlsym(lib, "rocblas_create_handle"));
+            v.rb_set_stream = reinterpret_cast<rb_set_stream_t>(dlsym(lib, "rocblas_set_stream"));
+            v.rb_sgemm = reinterpret_cast<rb_sgemm_t>(dlsym(lib, "rocblas_sgemm"));
+            if (create && v.rb_set_stream && v.rb_sgemm && create(&v.rb) == 0) v.rb_ok = true;
+        }
+    }
 }
 
-// C_rm[M,N] = A_rm[M,K] . B_rm[N,K]^T  ==  column-major  C^T[N,M] = (B^T)^T . A^T
+// C_rm[M,N] = A_rm[M,K] . B_rm[N,K]^T  ==  column-major  D[N,M] = op_T(B as [K,N]) . (A as [K,M])
+bool lt_sgemm_locked(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                     int64_t ldc, hipStream_t stream) {
+    Vendor& v = g_vendor;
+    auto key = std::make_tuple(M, N, K, lda, ldb, ldc);
+    auto it = v.plans.find(key);
+    if (it == v.plans.end()) {
+        LtPlan p{};
+        p.ok = false;
+        hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+        hipblasLtMatmulPreference_t pref = nullptr;
+        bool good = v.lt_desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS &&
+                    v.lt_desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS &&
+                    v.lt_desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS &&
+                    v.lt_layout_create(&p.la, HIP_R_32F, (uint64_t)K, (uint64_t)N, ldb) == HIPBLAS_STATUS_SUCCESS &&
+                    v.lt_layout_create(&p.lb, HIP_R_32F, (uint64_t)K, (uint64_t)M, lda) == HIPBLAS_STATUS_SUCCESS &&
+                    v.lt_layout_create(&p.lc, HIP_R_32F, (uint64_t)N, (uint64_t)M, ldc) == HIPBLAS_STATUS_SUCCESS &&
+                    v.lt_pref_create(&pref) == HIPBLAS_STATUS_SUCCESS;
+        if (good) {
+            hipblasLtMatmulHeuristicResult_t res[1];
+            int n = 0;
+            if (v.lt_heuristic(v.lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, res, &n) == HIPBLAS_STATUS_SUCCESS && n > 0 &&
+                res[0].workspaceSize == 0) {      // preference default: no workspace allowed
+                p.algo = res[0].algo;
+                p.ok = true;
+            }
+            v.lt_pref_destroy(pref);
+        }
+        it = v.plans.emplace(key, p).first;
+    }
+    const LtPlan& p = it->second;
+    if (!p.ok) return false;
+    const float one = 1.f, zero = 0.f;
+    return v.lt_matmul(v.lt, p.desc, &one, B, p.la, A, p.lb, &zero, C, p.lc, C, p.lc, &p.algo, nullptr, 0, stream) ==
+           HIPBLAS_STATUS_SUCCESS;
+}
+
 bool vendor_sgemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                   int64_t ldc, hipStream_t stream) {
-    Vendor& v = vendor();
-    if (!v.ok) return false;
-    const float one = 1.f, zero = 0.f;
     std::lock_guard<std::mutex> lk(g_vendor_mu);
-    if (v.set_stream(v.handle, stream) != 0) return false;
-    return v.sgemm(v.handle, /*transpose*/ 112, /*none*/ 111, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &zero,
-                   C, (int)ldc) == 0;
+    vendor_init_locked();
+    Vendor& v = g_vendor;
+    // measured on the config-3 projection (in situ): rocBLAS 0.955 ms, hipBLASLt (first heuristic, no
+    // workspace) 0.977 ms -> rocBLAS first unless hipBLASLt is requested explicitly
+    if (v.mode == 2 && v.lt_ok && lt_sgemm_locked(M, N, K, A, lda, B, ldb, C, ldc, stream)) return true;
+    if (v.rb_ok) {
+        const float one = 1.f, zero = 0.f;
+        if (v.rb_set_stream(v.rb, stream) != 0) return false;
+        if (v.rb_sgemm(v.rb, /*transpose*/ 112, /*none*/ 111, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &zero,
+                       C, (int)ldc) == 0)
+            return true;
+    }
+    return v.lt_ok && lt_sgemm_locked(M, N, K, A, lda, B, ldb, C, ldc, stream);
+}
+
+int vendor_mode() {
+    std::lock_guard<std::mutex> lk(g_vendor_mu);
+    vendor_init_locked();
+    return g_vendor.mode;
 }
 }  // namespace
 
 const char* gemm_backend_name() {
-    Vendor& v = vendor();
+    std::lock_guard<std::mutex> lk(g_vendor_mu);
+    vendor_init_locked();
+    const Vendor& v = g_vendor;
     if (v.mode == 1) return "hip (k_linear_f32, forced)";
-    return v.ok ? "rocblas for plain projections >= 2 GFLOP, k_linear_f32 otherwise" : "hip (k_linear_f32; rocblas unavailable)";
+    if (v.mode == 2 && v.lt_ok) return "hipblaslt for plain projections >= 2 GFLOP, k_linear_f32 otherwise";
+    if (v.rb_ok) return "rocblas for plain projections >= 2 GFLOP, k_linear_f32 otherwise";
+    if (v.lt_ok) return "hipblaslt for plain projections >= 2 GFLOP, k_linear_f32 otherwise";
+    return "hip (k_linear_f32; no vendor BLAS available)";
 }
 
 int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
@@ -369,7 +465,7 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     GVQA_REQUIRE((!ep.addend && !ep.mul) || batch == 1, GVQA_E_INVALID, "linear: addend/mul epilogue is not batched");
     // 16-byte vector loads need 16-byte aligned rows
     if (!ep.bias && !ep.addend && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
-        (2.0 * M * N * K >= 2e9 || vendor().mode == 2) && vendor().mode != 1) {
+        (2.0 * M * N * K >= 2e9 || vendor_mode() >= 2) && vendor_mode() != 1) {
         if (vendor_sgemm(M, N, K, A, lda, B, ldb, C, ldc, stream)) return GVQA_OK;
     }
     const bool vec = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
