@@ -100,6 +100,13 @@ class ClassifierParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias")]
 
 
+class EncoderParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("embedding", "edge0_weight", "edge0_bias", "edge2_weight", "edge2_bias",
+                                          "node1_0_weight", "node1_0_bias", "node1_2_weight", "node1_2_bias",
+                                          "node2_0_weight", "node2_0_bias", "node2_2_weight", "node2_2_bias",
+                                          "ln_weight", "ln_bias")]
+
+
 class GatDims(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
                 ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
@@ -152,6 +159,11 @@ PROTOTYPES = {
     "gvqa_answer_logits_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "gvqa_answer_logits_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ClassifierParams),
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_sg_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32]),
+    "gvqa_sg_encoder_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(EncoderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -1,0 +1,199 @@
+// Step right before the execution path ("next" row): ground-truth scene-graph encoder.
+//
+// Reference being replaced: GroundTruth_SceneGraph_Encoder.forward (pipeline_model_gat.py:575-610):
+// token-embedding sums (12 tokens per node, 1 per edge; embeddings of edges listed in
+// `added_sym_edge` negated, :590), PyG MetaLayer with EdgeModel (:65-76) and NodeModel (:78-98,
+// torch_scatter.scatter_mean :96), graph LayerNorm (graph_utils/my_graph_layernorm.py:52-78).
+//
+// Restructuring: the concatenations [x_src || x_dst || e] / [x_src || e'] / [x || agg] are never
+// built -- the first Linear of every MLP is split by column block; node-side blocks are projected
+// per NODE (N x D x D) and gathered, only the edge-side blocks cost E x D x D.
+#include "common.h"
+
+namespace gvqa {
+
+// out[r, :] = sign(r) * sum_t emb[tok[r, t], :]
+__global__ __launch_bounds__(256) void k_embed_sum(int64_t rows, int T, int V, int D, const int64_t* __restrict__ tok,
+                                                   const float* __restrict__ emb, const uint8_t* __restrict__ neg,
+                                                   float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int c = (int)(i - r * D);
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        int64_t id = tok[r * T + t];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const float v = emb[id * D + c];
+        acc += (neg && neg[r]) ? -v : v;
+    }
+    out[i] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_mark(int64_t n, int64_t limit, const int64_t* __restrict__ idx, uint8_t* flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && idx[i] >= 0 && idx[i] < limit) flags[idx[i]] = 1;
+}
+
+// y[e, :] = relu(a[ia[e], :] + b[ib[e], :] + y[e, :] + bias)       (first Linear of an edge-level MLP,
+// node-side column blocks pre-projected per node; either gather may be absent)
+__global__ __launch_bounds__(256) void k_gather_add_relu(int64_t E, int D, const float* __restrict__ a,
+                                                         const int64_t* __restrict__ ia, const float* __restrict__ b,
+                                                         const int64_t* __restrict__ ib, const float* __restrict__ bias,
+                                                         float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E * D) return;
+    const int64_t e = i / D;
+    const int c = (int)(i - e * D);
+    float v = 0.f;
+    if (a) v += a[ia[e] * D + c];
+    if (b) v += b[ib[e] * D + c];
+    v += y[i];
+    y[i] = fmaxf(v + bias[c], 0.f);
+}
+
+// agg[i, :] = mean over in-edges of m[eid, :] (torch_scatter.scatter_mean: count clamped to >= 1),
+// rows summed in COO order.  One wave per destination node.
+__global__ __launch_bounds__(256) void k_segment_mean(int N, int D, const float* __restrict__ m,
+                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_eid,
+                                                      float* __restrict__ agg) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    const float cnt = (float)max(hi - lo, 1);
+    for (int c = lane; c < D; c += 64) {
+        float acc = 0.f;
+        for (int s = lo; s < hi; ++s) acc += m[(int64_t)csr_eid[s] * D + c];
+        agg[(int64_t)i * D + c] = acc / cnt;
+    }
+}
+
+// Per-graph LayerNorm over nodes x channels (my_graph_layernorm.py:57-78): mean, then the variance
+// of the centred values, out = xc / (sqrt(var) + eps) * w[0] + b[0].  One block per graph.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_graph_layernorm(int D, const int32_t* __restrict__ graph_ptr,
+                                                         const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float eps, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int g = blockIdx.x;
+    const int64_t i0 = (int64_t)graph_ptr[g] * D, i1 = (int64_t)graph_ptr[g + 1] * D;
+    if (i1 <= i0) return;
+    const float norm = (float)(i1 - i0);
+    float s = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) s += x[i];
+    const float mean = block_sum(s, red) / norm;
+    float q = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) { const float d = x[i] - mean; q += d * d; }
+    const float sd = sqrtf(block_sum(q, red) / norm) + eps;
+    const float ww = w ? w[0] : 1.f, bb = b ? b[0] : 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) out[i] = (x[i] - mean) / sd * ww + bb;
+}
+
+struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, total; };
+static EncLayout enc_layout(int64_t N, int64_t E, int D) {
+    EncLayout L; size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
+    const size_t nd = (size_t)N * D * 4, ed = (size_t)E * D * 4;
+    L.x0 = take(nd); L.e0 = take(ed); L.S = take(nd); L.Dd = take(nd); L.P = take(nd); L.Y = take(ed); L.m = take(ed);
+    L.agg = take(nd); L.t = take(nd); L.x2 = take(nd); L.flags = take((size_t)E + 1);
+    L.total = off;
+    return L;
+}
+
+}  // namespace gvqa
+
+extern "C" {
+using namespace gvqa;
+
+size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D) {
+    if (!g || D <= 0) return 0;
+    return enc_layout(g->num_nodes, g->num_edges, D).total;
+}
+
+int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t node_tokens, int32_t edge_tokens_per_edge,
+                            const gvqa_encoder_params* p, const int64_t* x_tokens, const int64_t* edge_tokens,
+                            const int64_t* added_sym_edge, int64_t num_added, const int64_t* edge_index, float ln_eps,
+                            float* x_encoded, float* edge_attr_encoded, void* ws, size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(g && p, GVQA_E_INVALID, "sg_encoder: null argument");
+    GVQA_REQUIRE(V > 0 && D > 0 && node_tokens > 0 && edge_tokens_per_edge > 0 && num_added >= 0, GVQA_E_INVALID,
+                 "sg_encoder: bad dims");
+    GVQA_REQUIRE(p->embedding && p->edge0_weight && p->edge0_bias && p->edge2_weight && p->edge2_bias && p->node1_0_weight &&
+                 p->node1_0_bias && p->node1_2_weight && p->node1_2_bias && p->node2_0_weight && p->node2_0_bias &&
+                 p->node2_2_weight && p->node2_2_bias, GVQA_E_INVALID, "sg_encoder: null weight");
+    const int64_t N = g->num_nodes, E = g->num_edges, B = g->num_graphs;
+    EncLayout L = enc_layout(N, E, D);
+    GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "sg_encoder: workspace %zu < required %zu", ws_bytes, L.total);
+    if (N == 0) return GVQA_OK;
+    GVQA_REQUIRE(x_tokens && x_encoded && (E == 0 || (edge_tokens && edge_index && edge_attr_encoded)) &&
+                 (num_added == 0 || added_sym_edge), GVQA_E_INVALID, "sg_encoder: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* base = static_cast<char*>(ws);
+    auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    uint8_t* flags = reinterpret_cast<uint8_t*>(base + L.flags);
+    StageTimer timer(GVQA_STAGE_OTHER, stream);
+    int rc;
+    const int64_t* src = edge_index;
+    const int64_t* dst = edge_index + E;
+#define LINW(M_, K_, A_, W_, ldw_, b_, act_, C_)                                                                \
+    do { rc = launch_linear(M_, D, K_, A_, K_, W_, ldw_, b_, act_, C_, D, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
+
+    // token-embedding sums (:583-593); reverse edges added for symmetry carry the negated embedding (:590)
+    hipLaunchKernelGGL(k_embed_sum, dim3((unsigned)cdiv(N * D, 256)), dim3(256), 0, stream, N, node_tokens, V, D, x_tokens,
+                       p->embedding, nullptr, P(L.x0));
+    if (E > 0) {
+        GVQA_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)E, stream));
+        if (num_added > 0)
+            hipLaunchKernelGGL(k_mark, dim3((unsigned)cdiv(num_added, 256)), dim3(256), 0, stream, num_added, E, added_sym_edge, flags);
+        hipLaunchKernelGGL(k_embed_sum, dim3((unsigned)cdiv(E * D, 256)), dim3(256), 0, stream, E, edge_tokens_per_edge, V, D,
+                           edge_tokens, p->embedding, flags, P(L.e0));
+    }
+    GVQA_LAUNCH_CHECK();
+    // EdgeModel: e' = Lin2(relu(Lin1([x_src || x_dst || e])))                       (:65-76)
+    if (E > 0) {
+        LINW(N, D, P(L.x0), p->edge0_weight, 3 * D, nullptr, 0, P(L.S));
+        LINW(N, D, P(L.x0), p->edge0_weight + D, 3 * D, nullptr, 0, P(L.Dd));
+        LINW(E, D, P(L.e0), p->edge0_weight + 2 * D, 3 * D, nullptr, 0, P(L.Y));
+        hipLaunchKernelGGL(k_gather_add_relu, dim3((unsigned)cdiv(E * D, 256)), dim3(256), 0, stream, E, D, P(L.S), src, P(L.Dd),
+                           dst, p->edge0_bias, P(L.Y));
+        GVQA_LAUNCH_CHECK();
+        LINW(E, D, P(L.Y), p->edge2_weight, D, p->edge2_bias, 0, edge_attr_encoded);
+        // NodeModel part 1: m = Lin2(relu(Lin1([x_src || e'])))                     (:92-95)
+        LINW(N, D, P(L.x0), p->node1_0_weight, 2 * D, nullptr, 0, P(L.P));
+        LINW(E, D, edge_attr_encoded, p->node1_0_weight + D, 2 * D, nullptr, 0, P(L.Y));
+        hipLaunchKernelGGL(k_gather_add_relu, dim3((unsigned)cdiv(E * D, 256)), dim3(256), 0, stream, E, D, P(L.P), src,
+                           (const float*)nullptr, (const int64_t*)nullptr, p->node1_0_bias, P(L.Y));
+        GVQA_LAUNCH_CHECK();
+        LINW(E, D, P(L.Y), p->node1_2_weight, D, p->node1_2_bias, 0, P(L.m));
+    }
+    // scatter_mean by destination                                                   (:96)
+    hipLaunchKernelGGL(k_segment_mean, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, D, P(L.m), g->rowptr, g->csr_eid,
+                       P(L.agg));
+    GVQA_LAUNCH_CHECK();
+    // NodeModel part 2: x' = Lin2(relu(Lin1([x || agg])))                           (:97-98)
+    LINW(N, D, P(L.x0), p->node2_0_weight, 2 * D, p->node2_0_bias, 0, P(L.t));
+    {
+        LinearEpilogue ep{nullptr, P(L.t), D, nullptr, 0, 1};
+        rc = launch_linear_ex(N, D, D, P(L.agg), D, p->node2_0_weight + D, 2 * D, ep, P(L.t), D, 1, 0, 0, 0, stream);
+        if (rc) return rc;
+    }
+    LINW(N, D, P(L.t), p->node2_2_weight, D, p->node2_2_bias, 0, P(L.x2));
+#undef LINW
+    // graph LayerNorm                                                               (:608)
+    if (B > 0) {
+        hipLaunchKernelGGL(k_graph_layernorm, dim3((unsigned)B), dim3(256), 0, stream, D, g->graph_ptr, P(L.x2), p->ln_weight,
+                           p->ln_bias, ln_eps, x_encoded);
+        GVQA_LAUNCH_CHECK();
+    }
+    return GVQA_OK;
+}
+
+}  // extern "C"

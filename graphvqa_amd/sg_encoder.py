@@ -1,0 +1,99 @@
+"""MI355X-native counterpart of the step right before the execution path:
+`GroundTruth_SceneGraph_Encoder` (pipeline_model_gat.py:553-610).
+
+Same forward signature (`forward(gt_scene_graphs) -> (x_encoded, edge_attr_encoded, None)`, reading
+`.x`, `.edge_attr`, `.edge_index`, `.batch`, `.added_sym_edge`) and state_dict keys as the reference;
+the constructor takes the vocabulary size / padding index explicitly instead of importing them from
+`gqa_dataset_entry` (the reference reads `len(SG_ENCODING_TEXT.vocab)`, pipeline_model_gat.py:556-562).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.nn import Sequential as Seq, Linear as Lin, ReLU, Parameter
+
+from . import _lib
+from .gat_skip import _f32c, _workspace
+from .graph import SceneGraphBatch, _stream
+
+
+class _EdgeModel(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.edge_mlp = Seq(Lin(3 * d, d), ReLU(), Lin(d, d))
+
+
+class _NodeModel(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.node_mlp_1 = Seq(Lin(2 * d, d), ReLU(), Lin(d, d))
+        self.node_mlp_2 = Seq(Lin(2 * d, d), ReLU(), Lin(d, d))
+
+
+class _MetaLayer(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.edge_model = _EdgeModel(d)
+        self.node_model = _NodeModel(d)
+        self.global_model = None
+
+
+class _GraphLayerNorm(torch.nn.Module):
+    """graph_utils/my_graph_layernorm.LayerNorm: weight / bias are 1-element tensors (:38-39)."""
+
+    def __init__(self, in_channels, eps=1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = Parameter(torch.ones(1))
+        self.bias = Parameter(torch.zeros(1))
+
+
+class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
+    def __init__(self, vocab_size: int, pad_idx: int = 0, sg_emb_dim: int = 300):
+        super().__init__()
+        _lib.load()
+        self.sg_emb_dim = sg_emb_dim
+        self.sg_vocab_embedding = torch.nn.Embedding(vocab_size, sg_emb_dim, padding_idx=pad_idx)
+        self.scene_graph_encoding_layer = _MetaLayer(sg_emb_dim)
+        self.graph_layer_norm = _GraphLayerNorm(sg_emb_dim)
+
+    def forward(self, gt_scene_graphs, graph: SceneGraphBatch | None = None):
+        lib = _lib.load()
+        d = gt_scene_graphs
+        x_tok, e_tok, ei, batch = d.x, d.edge_attr, d.edge_index, d.batch
+        added = getattr(d, "added_sym_edge", None)
+        dev = x_tok.device
+        if not x_tok.is_cuda:
+            raise RuntimeError("scene-graph tensors are on %s: the MI355X path has no CPU fallback" % dev)
+        x_tok, e_tok, ei = x_tok.contiguous(), e_tok.contiguous(), ei.contiguous()
+        N, E = x_tok.shape[0], ei.shape[1]
+        if graph is None:
+            graph = SceneGraphBatch(ei, batch, N)
+        D, V = self.sg_emb_dim, self.sg_vocab_embedding.num_embeddings
+        m = self.scene_graph_encoding_layer
+        p = _lib.EncoderParams()
+        keep = []
+        for name, t in (("embedding", self.sg_vocab_embedding.weight),
+                        ("edge0_weight", m.edge_model.edge_mlp[0].weight), ("edge0_bias", m.edge_model.edge_mlp[0].bias),
+                        ("edge2_weight", m.edge_model.edge_mlp[2].weight), ("edge2_bias", m.edge_model.edge_mlp[2].bias),
+                        ("node1_0_weight", m.node_model.node_mlp_1[0].weight), ("node1_0_bias", m.node_model.node_mlp_1[0].bias),
+                        ("node1_2_weight", m.node_model.node_mlp_1[2].weight), ("node1_2_bias", m.node_model.node_mlp_1[2].bias),
+                        ("node2_0_weight", m.node_model.node_mlp_2[0].weight), ("node2_0_bias", m.node_model.node_mlp_2[0].bias),
+                        ("node2_2_weight", m.node_model.node_mlp_2[2].weight), ("node2_2_bias", m.node_model.node_mlp_2[2].bias),
+                        ("ln_weight", self.graph_layer_norm.weight), ("ln_bias", self.graph_layer_norm.bias)):
+            tc = _f32c(t, name)
+            keep.append(tc)
+            setattr(p, name, tc.data_ptr())
+        xe = torch.empty((N, D), dtype=torch.float32, device=dev)
+        ee = torch.empty((E, D), dtype=torch.float32, device=dev)
+        na = 0 if added is None else int(added.numel())
+        added_c = None if na == 0 else added.to(dev).contiguous()
+        with torch.cuda.device(dev):
+            ws = _workspace(lib.gvqa_sg_encoder_workspace_bytes(C.byref(graph.c), D), dev)
+            _lib.check(lib.gvqa_sg_encoder_forward(C.byref(graph.c), V, D, x_tok.shape[1], e_tok.shape[1], C.byref(p),
+                                                   x_tok.data_ptr(), e_tok.data_ptr(),
+                                                   None if added_c is None else added_c.data_ptr(), na, ei.data_ptr(),
+                                                   self.graph_layer_norm.eps, xe.data_ptr(), ee.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), _stream(dev)))
+        return xe, ee, None

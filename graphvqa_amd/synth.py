@@ -280,3 +280,23 @@ def classifier_params(question_dim: int, hidden: int, num_answers: int, seed: in
     p.update(_linear(hidden, 3 * question_dim, seed + 1, prefix=prefix + "1."))
     p.update(_linear(num_answers, hidden, seed + 2, prefix=prefix + "4."))
     return p
+
+
+def encoder_params(vocab_size: int, dim: int, seed: int, pad_idx: int = 0) -> dict:
+    """`GroundTruth_SceneGraph_Encoder` (pipeline_model_gat.py:553-573): embedding [V, D] (padding row
+    zero), MetaLayer MLPs (EdgeModel 3D->D->D, NodeModel 2D->D->D twice), graph LayerNorm with
+    1-element weight / bias (my_graph_layernorm.py:38-39)."""
+    p = {}
+    emb = normal((vocab_size, dim), seed + 1)
+    emb[pad_idx] = 0.0
+    p["sg_vocab_embedding.weight"] = emb
+    pre = "scene_graph_encoding_layer."
+    p.update(_linear(dim, 3 * dim, seed + 2, prefix=pre + "edge_model.edge_mlp.0."))
+    p.update(_linear(dim, dim, seed + 3, prefix=pre + "edge_model.edge_mlp.2."))
+    p.update(_linear(dim, 2 * dim, seed + 4, prefix=pre + "node_model.node_mlp_1.0."))
+    p.update(_linear(dim, dim, seed + 5, prefix=pre + "node_model.node_mlp_1.2."))
+    p.update(_linear(dim, 2 * dim, seed + 6, prefix=pre + "node_model.node_mlp_2.0."))
+    p.update(_linear(dim, dim, seed + 7, prefix=pre + "node_model.node_mlp_2.2."))
+    p["graph_layer_norm.weight"] = uniform((1,), seed + 8, 0.5, 1.5)
+    p["graph_layer_norm.bias"] = uniform((1,), seed + 9, -0.5, 0.5)
+    return p

@@ -333,6 +333,38 @@ int gvqa_answer_logits_forward(int64_t B, int32_t Q, int32_t hidden, int32_t A, 
                                const float* g_feat, const float* q, float* logits, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Step before the path ("next" row): ground-truth scene-graph encoder
+ * (pipeline_model_gat.py:63-101, 553-610; graph_utils/my_graph_layernorm.py:52-78)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gvqa_encoder_params {
+    const float* embedding;        /* sg_vocab_embedding.weight [V, D]                                         */
+    const float* edge0_weight;     /* scene_graph_encoding_layer.edge_model.edge_mlp.0.weight [D, 3D]          */
+    const float* edge0_bias;
+    const float* edge2_weight;     /* ...edge_mlp.2.weight [D, D]                                              */
+    const float* edge2_bias;
+    const float* node1_0_weight;   /* ...node_model.node_mlp_1.0.weight [D, 2D]                                */
+    const float* node1_0_bias;
+    const float* node1_2_weight;   /* ...node_mlp_1.2.weight [D, D]                                            */
+    const float* node1_2_bias;
+    const float* node2_0_weight;   /* ...node_model.node_mlp_2.0.weight [D, 2D]                                */
+    const float* node2_0_bias;
+    const float* node2_2_weight;   /* ...node_mlp_2.2.weight [D, D]                                            */
+    const float* node2_2_bias;
+    const float* ln_weight;        /* graph_layer_norm.weight [1] or NULL                                      */
+    const float* ln_bias;          /* graph_layer_norm.bias   [1] or NULL                                      */
+} gvqa_encoder_params;
+
+/* x_tokens int64 [N, node_tokens], edge_tokens int64 [E, edge_tokens_per_edge] (COO order),
+ * added_sym_edge int64 [num_added] (indices of edges whose embedding is negated), edge_index int64
+ * [2, E] (the same COO the graph was built from).  Outputs x_encoded [N, D], edge_attr_encoded [E, D]
+ * -- exactly the (x, edge_attr) the execution path consumes (pipeline_model_gat.py:751, 791). */
+size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D);
+int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t node_tokens, int32_t edge_tokens_per_edge,
+                            const gvqa_encoder_params* p, const int64_t* x_tokens, const int64_t* edge_tokens,
+                            const int64_t* added_sym_edge, int64_t num_added, const int64_t* edge_index, float ln_eps,
+                            float* x_encoded, float* edge_attr_encoded, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * In-library stage timing (HIP events recorded on the caller's stream around each stage).
  * Used by bench.py to obtain the message-passing kernel's launch duration inside the timed
  * region.  Off by default; costs two hipEventRecord per stage when on.

@@ -293,3 +293,41 @@ def short_answer_logits(g_feat, q, p, prefix="logit_fc."):
     feat = torch.cat((g_feat, q, g_feat * q), dim=-1)
     h = F.elu(F.linear(feat, p[prefix + "1.weight"], p[prefix + "1.bias"]))
     return F.linear(h, p[prefix + "4.weight"], p[prefix + "4.bias"])
+
+
+# ----------------------------------------------------------------------------
+# Step before the path: ground-truth scene-graph encoder
+# ----------------------------------------------------------------------------
+def graph_layernorm(x, batch, num_graphs, weight, bias, eps=1e-5):
+    """graph_utils/my_graph_layernorm.py:52-78: per-graph mean / variance over nodes x channels;
+    out = x / (sqrt(var) + eps) (eps OUTSIDE the sqrt), then * weight + bias (1-element tensors)."""
+    C = x.shape[-1]
+    cnt = torch.zeros(num_graphs, dtype=x.dtype).scatter_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
+    norm = cnt.clamp(min=1).mul(C).view(-1, 1)
+    mean = scatter_add_rows(x, batch, num_graphs).sum(dim=-1, keepdim=True) / norm
+    x = x - mean.index_select(0, batch)
+    var = scatter_add_rows(x * x, batch, num_graphs).sum(dim=-1, keepdim=True) / norm
+    out = x / (var.sqrt().index_select(0, batch) + eps)
+    return out * weight + bias
+
+
+def scene_graph_encoder(x_tokens, edge_index, edge_tokens, added_sym_edge, batch, num_graphs, p):
+    """`GroundTruth_SceneGraph_Encoder.forward` (pipeline_model_gat.py:575-610) with its MetaLayer
+    (EdgeModel :65-76, NodeModel :78-98, torch_scatter.scatter_mean :96).  Returns
+    (x_encoded [N, D], edge_attr_encoded [E, D])."""
+    emb = p["sg_vocab_embedding.weight"]
+    x = emb.index_select(0, x_tokens.reshape(-1)).view(x_tokens.shape[0], x_tokens.shape[1], -1).sum(dim=-2)
+    e = emb.index_select(0, edge_tokens.reshape(-1)).view(edge_tokens.shape[0], edge_tokens.shape[1], -1).clone()
+    e[added_sym_edge] = e[added_sym_edge] * -1                                   # :590
+    e = e.sum(dim=-2)
+    src, dst = edge_index[0], edge_index[1]
+    pre = "scene_graph_encoding_layer."
+    e2 = _mlp2(torch.cat([x.index_select(0, src), x.index_select(0, dst), e], 1), p, pre + "edge_model.edge_mlp.")
+    m = _mlp2(torch.cat([x.index_select(0, src), e2], 1), p, pre + "node_model.node_mlp_1.")
+    N = x.shape[0]
+    s = scatter_add_rows(m, dst, N)
+    cnt = torch.zeros(N, dtype=x.dtype).scatter_add_(0, dst, torch.ones(dst.shape[0], dtype=x.dtype))
+    agg = s / cnt.clamp(min=1).view(-1, 1)                                       # scatter_mean
+    x2 = _mlp2(torch.cat([x, agg], 1), p, pre + "node_model.node_mlp_2.")
+    x2 = graph_layernorm(x2, batch, num_graphs, p["graph_layer_norm.weight"], p["graph_layer_norm.bias"])
+    return x2, e2

@@ -68,6 +68,9 @@ def stub_dataset_entry():
             self.stoi = {w: i for i, w in enumerate(self.itos)}
             self.vectors = torch.zeros(n, 300)
 
+        def __len__(self):
+            return len(self.itos)
+
     class _Field:
         def __init__(self, n):
             self.vocab = _Vocab(n)
@@ -317,7 +320,45 @@ def gen_head():
              batch=gb.batch, pooled=g_feat, logits=logits)
 
 
+def gen_encoder():
+    """Scene-graph encoder (the step right before the path): the reference's own
+    GroundTruth_SceneGraph_Encoder (pipeline_model_gat.py:553-610) built on the stub vocabulary (50
+    words; the real vocabulary needs torchtext/spaCy/GloVe), run on the four debug graphs' topology
+    with seeded token ids."""
+    stub_dataset_entry()
+    import types
+    import pipeline_model_gat as PM
+    enc = PM.GroundTruth_SceneGraph_Encoder()
+    V, D = enc.sg_vocab_embedding.weight.shape
+    p = synth.encoder_params(V, D, seed=833, pad_idx=enc.sg_vocab_embedding.padding_idx)
+    load_params(enc, p)
+    sgs = debug_graphs()
+    gb = batch_scene_graphs(list(sgs.values()))
+    N, E = gb.num_nodes, gb.num_edges
+    added, off = [], 0
+    for sg in sgs.values():
+        n, ei, a = scene_graph_topology(sg)
+        added.append(a + off)
+        off += ei.shape[1]
+    added = np.concatenate(added)
+    x_tok = synth.randint(N * 12, 61, 0, V, stream=9).reshape(N, 12)
+    x_tok[:, 4:] = enc.sg_vocab_embedding.padding_idx            # objects have 1 name + up to 3 attributes
+    e_tok = synth.randint(E, 62, 1, V, stream=9).reshape(E, 1)
+    data = types.SimpleNamespace(x=t(x_tok), edge_attr=t(e_tok), edge_index=t(gb.edge_index), batch=t(gb.batch),
+                                 added_sym_edge=t(added))
+    with torch.no_grad():
+        xe, ee, _ = enc(data)
+    save("sg_encoder_debug4", dict(case="GroundTruth_SceneGraph_Encoder.forward eval", ref="pipeline_model_gat.py:575-610",
+                                   vocab=int(V), dim=int(D), pad_idx=int(enc.sg_vocab_embedding.padding_idx), param_seed=833),
+         x_tokens=x_tok, edge_tokens=e_tok, added_sym_edge=added, edge_index=gb.edge_index, batch=gb.batch,
+         x_encoded=xe, edge_attr_encoded=ee)
+
+
 if __name__ == "__main__":
+    if "--encoder-only" in sys.argv:
+        gen_encoder()
+        sys.exit(0)
+    gen_encoder()
     gen_head()
     sys.exit(0) if "--head-only" in sys.argv else None
     gen_gat()

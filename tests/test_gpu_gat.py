@@ -436,3 +436,56 @@ def test_pool_and_classifier_golden(dev, name):
     assert maxabs(pooled, g["pooled"]) < 2e-5
     logits = head(pooled, t(u, device=dev))
     assert maxabs(logits, g["logits"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row 8f-1: scene-graph encoder; and config 1: encoder -> gat_seq -> pooling -> logits
+# ------------------------------------------------------------------------------------------------
+def test_scene_graph_encoder_golden(dev):
+    import types
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    meta, g = load_golden("sg_encoder_debug4")
+    enc = GroundTruth_SceneGraph_Encoder(meta["vocab"], meta["pad_idx"], meta["dim"])
+    _load_module(enc, synth.encoder_params(meta["vocab"], meta["dim"], seed=meta["param_seed"], pad_idx=meta["pad_idx"]), dev)
+    data = types.SimpleNamespace(x=t(g["x_tokens"], device=dev), edge_attr=t(g["edge_tokens"], device=dev),
+                                 edge_index=t(g["edge_index"], device=dev), batch=t(g["batch"], device=dev),
+                                 added_sym_edge=t(g["added_sym_edge"], device=dev))
+    xe, ee, _ = enc(data)
+    assert maxabs(ee, g["edge_attr_encoded"]) < 5e-5
+    assert maxabs(xe, g["x_encoded"]) < TOL
+
+
+def test_config1_debug_pipeline_chain(dev):
+    """BASELINE config 1 shape: the reference's two debug scene graphs (batch = 2) through
+    encoder -> gat_seq (K = 5) -> global attention pooling -> answer logits on the HIP path, against the
+    same chain on the CPU oracle (transformer question encoder / program decoder are out of scope:
+    instruction vectors and the question feature are seeded inputs)."""
+    import json, types
+    from oracle import ref_torch as R
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+    meta, gg = load_golden("gat_seq_debug2_d300")
+    ei, batch = gg["edge_index"], gg["batch"]
+    N, E, B, V = batch.shape[0], ei.shape[1], 2, 50
+    assert (N, E) == (33, 125)
+    x_tok = synth.randint(N * 12, 71, 0, V, stream=9).reshape(N, 12)
+    e_tok = synth.randint(E, 72, 1, V, stream=9).reshape(E, 1)
+    added = np.array([3, 17, 60], dtype=np.int64)
+    ins, q = synth.normal((5, B, 512), 73), synth.normal((B, 512), 74)
+    pe, pg = synth.encoder_params(V, 300, seed=1), synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=2)
+    pp, pc = synth.attention_pool_params(300, 512, seed=3), synth.classifier_params(512, 512, 1842, seed=4)
+    enc = _load_module(GroundTruth_SceneGraph_Encoder(V, 0, 300), pe, dev)
+    gs = _load_module(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), pg, dev)
+    pool = _load_module(MyConditionalGlobalAttention(300, 512), pp, dev)
+    clf = _load_module(ShortAnswerClassifier(512, 512, 1842), pc, dev)
+    data = types.SimpleNamespace(x=t(x_tok, device=dev), edge_attr=t(e_tok, device=dev), edge_index=t(ei, device=dev),
+                                 batch=t(batch, device=dev), added_sym_edge=t(added, device=dev))
+    xe, ee, _ = enc(data)
+    h = gs(xe, data.edge_index, ee, t(ins, device=dev), data.batch)
+    logits = clf(pool(h, t(q, device=dev), data.batch), t(q, device=dev))
+    rxe, ree = R.scene_graph_encoder(t(x_tok), t(ei), t(e_tok), t(added), t(batch), B, tparams(pe))
+    rh = R.gat_seq(rxe, t(ei), ree, t(ins), t(batch), tparams(pg))
+    rlogits = R.short_answer_logits(R.global_attention_pool(rh, t(q), t(batch), tparams(pp), B), t(q), tparams(pc))
+    assert logits.shape == (2, 1842)
+    assert maxabs(h, rh) < TOL and maxabs(logits, rlogits) < TOL

@@ -125,3 +125,13 @@ def test_pool_and_classifier(name):
     assert maxabs(pooled, g["pooled"]) < TOL
     logits = R.short_answer_logits(pooled, t(u), cp)
     assert maxabs(logits, g["logits"]) < 5e-5
+
+
+def test_scene_graph_encoder():
+    meta, g = load_golden("sg_encoder_debug4")
+    p = tparams(synth.encoder_params(meta["vocab"], meta["dim"], seed=meta["param_seed"], pad_idx=meta["pad_idx"]))
+    B = int(g["batch"].max()) + 1
+    xe, ee = R.scene_graph_encoder(t(g["x_tokens"]), t(g["edge_index"]), t(g["edge_tokens"]), t(g["added_sym_edge"]),
+                                   t(g["batch"]), B, p)
+    assert maxabs(ee, g["edge_attr_encoded"]) < 2e-5
+    assert maxabs(xe, g["x_encoded"]) < 5e-5
