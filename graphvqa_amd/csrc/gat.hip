@@ -135,7 +135,6 @@ struct MpArgs {
     int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
     int nbuf;                 // stage buffers in LDS (prefetch depth = nbuf - 1)
     int lpn_log;              // log2(lanes per node) in the aggregation mapping
-    int dbg;                  // profiling experiments only (GVQA_MP_DBG): 1 no DMA, 2 no aggregation, 4 no alpha prologue, 8 no stores, 16 no consts
     float slope, bn_eps;
 };
 
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const int g = blockIdx.x;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int tn = n1 - n0;
-    if (tn <= 0 || (a.dbg & 32)) return;
+    if (tn <= 0) return;
     const int e0 = a.rowptr[n0], ne = a.rowptr[n1] - e0;
     const int tid = threadIdx.x;
     const int wave_unit0 = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -239,7 +238,6 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     // All stage bookkeeping is incremental (adds and compares): the scalar unit is shared by every
     // wave of the CU and runtime integer divisions here made it the kernel's bottleneck.
     auto prefetch = [&](int j, int c0, int bufi) {
-        if (a.dbg & 1) return;
         const int q4c = min(a.cw, C - c0) >> 2;
         const int units = tn * q4c;
         const float* base;
@@ -271,7 +269,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     for (; pf_t < depth && pf_t < T; ++pf_t) { prefetch(pf_j, pf_c0, pf_buf); advance(pf_j, pf_c0, pf_buf); }
 
     // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
-    for (int s = tid; s < ne && !(a.dbg & 4); s += MP_THREADS) {
+    for (int s = tid; s < ne; s += MP_THREADS) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
         src_l[s] = src - n0;
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         for (int h = 0; h < H; ++h) alpha_s[s * H + h] = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + ae[h];
     }
     for (int i = tid; i <= tn; i += MP_THREADS) rowp_l[i] = a.rowptr[n0 + i] - e0;
-    for (int c = tid; c < C && !(a.dbg & 16); c += MP_THREADS) {
+    for (int c = tid; c < C; c += MP_THREADS) {
         cst[c] = a.graph_term ? a.graph_term[(int64_t)g * a.t_ld + c] : 0.f;
         cst[C + c] = a.bias ? a.bias[c] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
-    for (int it = tid; it < tn * H && !(a.dbg & 4); it += MP_THREADS) {
+    for (int it = tid; it < tn * H; it += MP_THREADS) {
         const int i = it / H, h = it - i * H;
         const int lo = rowp_l[i], hi = rowp_l[i + 1];
         float ar = a.a_node ? a.a_node[(int64_t)(n0 + i) * 2 * H + H + h] : 0.f;
@@ -320,7 +318,6 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         }
     }
 
-    if (a.dbg & 64) return;
     // ---- stage loop ----
     // Work item = (node i, float4 column q).  A node's columns sit on `lpn` consecutive lanes
     // (power of two >= cw/4, so the (i, q) split is shifts only); a thread walks nodes
@@ -395,7 +392,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         const float4* buf4 = reinterpret_cast<const float4*>(smem + off_buf + (size_t)cur_buf * buf_bytes);
         const bool lane_on = q < q4c;
         const int qq = lane_on ? q : 0;
-        if (j < H && !(a.dbg & 2)) {
+        if (j < H) {
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 const int lo = it_lo[k], hi = it_hi[k], trips = it_trips[k];
@@ -447,7 +444,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                         r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
                         r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
                     }
-                    if (!(a.dbg & 8)) *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
+                    *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
                 }
             }
         }
@@ -628,7 +625,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.bias = d->bias;
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
     a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_csr = nullptr;
-    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0; a.dbg = (int)env_size("GVQA_MP_DBG", 0);
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0;
     a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
     const int force = d->force;
     const float* graph_term = d->graph_term;
