@@ -752,6 +752,44 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     return L;
 }
 
+// Side stream for work that is independent of the projection GEMM of the same hop (HBM-bound
+// logit / fold kernels under the MFMA-bound projection).  One non-blocking stream and a pair of
+// events per host thread; fork = side waits for everything already enqueued on the caller's
+// stream, join = caller's stream waits for the side stream.  OFF by default (GVQA_OVERLAP=1 turns it
+// on): measured at config 3 the projection's blocks fill every CU, the side-stream kernels mostly
+// wait for it anyway and the step gains only 1.2 % (6.23 vs 6.30 ms) while per-stage timings
+// stop being additive.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int device = -1;
+    bool ok = false;
+};
+static SideStream* side_stream() {
+    static const bool enabled = []() { const char* v = getenv("GVQA_OVERLAP"); return v && v[0] == '1'; }();
+    if (!enabled) return nullptr;
+    static thread_local SideStream ss;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (!ss.ok || ss.device != dev) {
+        ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.fork_ev, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.join_ev, hipEventDisableTiming) == hipSuccess;
+        ss.device = dev;
+    }
+    return ss.ok ? &ss : nullptr;
+}
+static int side_fork(SideStream* ss, hipStream_t main) {
+    GVQA_HIP_CHECK(hipEventRecord(ss->fork_ev, main));
+    GVQA_HIP_CHECK(hipStreamWaitEvent(ss->stream, ss->fork_ev, 0));
+    return GVQA_OK;
+}
+static int side_join(SideStream* ss, hipStream_t main) {
+    GVQA_HIP_CHECK(hipEventRecord(ss->join_ev, ss->stream));
+    GVQA_HIP_CHECK(hipStreamWaitEvent(main, ss->join_ev, 0));
+    return GVQA_OK;
+}
+
 static gvqa_gat_mp_desc mp_desc_from(const gvqa_gat_dims* d, const gvqa_gat_conv_params* p) {
     gvqa_gat_mp_desc m;
     memset(&m, 0, sizeof(m));
@@ -880,18 +918,24 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const int64_t Tld = (int64_t)align_up((size_t)(C + H), 4);
     if (N == 0) return GVQA_OK;
 
-    rc = run_fold(d, hops, P(L.Vn), P(L.Ve), Di > 0 ? P(L.Gw) : nullptr, stream);
+    // Everything that does not depend on the current hop's projection runs on a side stream, under
+    // the MFMA-bound projection GEMM on the caller's stream: weight folding, the all-hops edge-logit
+    // pass and the graph terms (hop 0), and each hop's node-logit product.
+    SideStream* ss = side_stream();
+    hipStream_t aux = ss ? ss->stream : stream;
+    if (ss) { rc = side_fork(ss, stream); if (rc) return rc; }
+    rc = run_fold(d, hops, P(L.Vn), P(L.Ve), Di > 0 ? P(L.Gw) : nullptr, aux);
     if (rc) return rc;
     {   // edge logit terms of ALL hops in one pass over edge_attr: [E, De] x [De, K*H]
-        StageTimer t(GVQA_STAGE_EDGE_LOGIT, stream);
+        StageTimer t(GVQA_STAGE_EDGE_LOGIT, aux);
         rc = launch_linear(E, (int64_t)K * H, De, edge_attr, De, P(L.Ve), De, nullptr, 0, P(L.a_edge), (int64_t)K * H, 1, 0,
-                           0, 0, stream);
+                           0, 0, aux);
         if (rc) return rc;
     }
     if (Di > 0) {   // per-graph instruction terms of all hops: [K] x ([B, Di] x [Di, C+H])
-        StageTimer t(GVQA_STAGE_GRAPH_TERM, stream);
+        StageTimer t(GVQA_STAGE_GRAPH_TERM, aux);
         rc = launch_linear(B, C + H, Di, instr, Di, P(L.Gw), Di, nullptr, 0, P(L.T), Tld, K, (int64_t)B * Di,
-                           (int64_t)(C + H) * Di, (int64_t)B * Tld, stream);
+                           (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
         if (rc) return rc;
     }
     const float* h = x;
@@ -900,18 +944,20 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         if (hop_out) h_next = hop_out + (int64_t)i * N * C;
         else if (i == K - 1) h_next = out;
         else h_next = (i & 1) ? P(L.h1) : P(L.h0);
+        if (ss && i > 0) { rc = side_fork(ss, stream); if (rc) return rc; }     // h of this hop is ready on `stream`
+        {   // (a_l | a_r) node halves = h . [V_l | V_r]     (side stream)
+            StageTimer t(GVQA_STAGE_NODE_LOGIT, aux);
+            rc = launch_linear(N, 2 * H, Dn, h, Dn, P(L.Vn) + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
+                               1, 0, 0, 0, aux);
+            if (rc) return rc;
+        }
         {   // xp = h . W_l[:, :Dn]^T   (node half of gat_skip.py:133; instruction half is in T)
             StageTimer t(GVQA_STAGE_PROJ, stream);
             rc = launch_linear(N, (int64_t)H * C, Dn, h, Dn, hops[i].lin_l_weight, Dn + Di, nullptr, 0, P(L.xp),
                                (int64_t)H * C, 1, 0, 0, 0, stream);
             if (rc) return rc;
         }
-        {
-            StageTimer t(GVQA_STAGE_NODE_LOGIT, stream);
-            rc = launch_linear(N, 2 * H, Dn, h, Dn, P(L.Vn) + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
-                               1, 0, 0, 0, stream);
-            if (rc) return rc;
-        }
+        if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
         gvqa_gat_mp_desc m = mp_desc_from(d, &hops[i]);
         const bool train_bn = bn_stats_out && hops[i].bn_weight;
         if (train_bn) { m.bn_weight = m.bn_bias = m.bn_mean = m.bn_var = nullptr; }   // BN applied after the batch statistics
