@@ -79,5 +79,7 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
                      int64_t strideB, int64_t strideC, hipStream_t stream);
 
 const char* gemm_backend_name();
+int launch_split_bf16x3(int64_t rows, int K, const float* x, int64_t ld, int which, void* out, hipStream_t stream);
+bool vendor_bf16_gemm(int64_t M, int64_t N, int64_t K6, const void* A, const void* B, float* C, int64_t ldc, hipStream_t stream);
 
 }  // namespace gvqa

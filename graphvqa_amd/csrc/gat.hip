@@ -723,8 +723,14 @@ int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
 // ==============================================================================================
 // Drivers
 // ==============================================================================================
+// GVQA_PROJ=bf16x3 selects the split-bf16 projection (opt-in; default exact fp32).
+static bool proj_bf16x3_enabled() {
+    static const bool on = []() { const char* v = getenv("GVQA_PROJ"); return v && !strcmp(v, "bf16x3"); }();
+    return on;
+}
+
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, total;
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, total;
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d) {
@@ -748,6 +754,12 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.alpha_csr = take((size_t)E * H);
     L.bn_partial = take((size_t)cdiv(N > 0 ? N : 1, BN_ROWS_PER_BLOCK) * C);
     L.bn_stats = take(2 * C);
+    if (proj_bf16x3_enabled()) {     // bf16 pieces: 6*K uint16 per row = 3*K floats
+        L.a6 = take((size_t)N * 3 * d->node_dim);
+        L.w6 = take(K * H * C * 3 * d->node_dim);
+    } else {
+        L.a6 = L.w6 = off;
+    }
     L.total = off;
     return L;
 }
@@ -938,6 +950,16 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                            (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
         if (rc) return rc;
     }
+    const bool split = proj_bf16x3_enabled();
+    uint16_t* a6 = reinterpret_cast<uint16_t*>(base + L.a6);
+    uint16_t* w6 = reinterpret_cast<uint16_t*>(base + L.w6);
+    if (split) {     // weights of all hops -> B' pieces, once per forward
+        StageTimer t(GVQA_STAGE_FOLD, stream);
+        for (int i = 0; i < K; ++i) {
+            rc = launch_split_bf16x3((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, 1, w6 + (int64_t)i * H * C * 6 * Dn, stream);
+            if (rc) return rc;
+        }
+    }
     const float* h = x;
     for (int i = 0; i < K; ++i) {
         float* h_next;
@@ -953,9 +975,18 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         }
         {   // xp = h . W_l[:, :Dn]^T   (node half of gat_skip.py:133; instruction half is in T)
             StageTimer t(GVQA_STAGE_PROJ, stream);
-            rc = launch_linear(N, (int64_t)H * C, Dn, h, Dn, hops[i].lin_l_weight, Dn + Di, nullptr, 0, P(L.xp),
-                               (int64_t)H * C, 1, 0, 0, 0, stream);
-            if (rc) return rc;
+            bool done = false;
+            if (split) {
+                rc = launch_split_bf16x3(N, Dn, h, Dn, 0, a6, stream);
+                if (rc) return rc;
+                done = vendor_bf16_gemm(N, (int64_t)H * C, (int64_t)6 * Dn, a6, w6 + (int64_t)i * H * C * 6 * Dn, P(L.xp),
+                                        (int64_t)H * C, stream);
+            }
+            if (!done) {
+                rc = launch_linear(N, (int64_t)H * C, Dn, h, Dn, hops[i].lin_l_weight, Dn + Di, nullptr, 0, P(L.xp),
+                                   (int64_t)H * C, 1, 0, 0, 0, stream);
+                if (rc) return rc;
+            }
         }
         if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
         gvqa_gat_mp_desc m = mp_desc_from(d, &hops[i]);

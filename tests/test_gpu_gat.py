@@ -489,3 +489,35 @@ def test_config1_debug_pipeline_chain(dev):
     rlogits = R.short_answer_logits(R.global_attention_pool(rh, t(q), t(batch), tparams(pp), B), t(q), tparams(pc))
     assert logits.shape == (2, 1842)
     assert maxabs(h, rh) < TOL and maxabs(logits, rlogits) < TOL
+
+
+def test_bf16x3_projection_opt_in_is_fp32_accurate(dev):
+    """GVQA_PROJ=bf16x3 (read once per process -> subprocess): the split-bf16 projection must be as close to the
+    fp64 oracle as the exact-fp32 default on the real-dims golden case."""
+    import os, subprocess, sys, json
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from graphvqa_amd import synth, _lib
+from graphvqa_amd.gat_skip import gat_seq
+from oracle import ref_torch as R
+from tests.util import load_golden, t, tparams
+meta, g = load_golden("gat_seq_debug4_d300")
+s = meta["input_seeds"]; N, E, B = g["batch"].shape[0], g["edge_index"].shape[1], int(g["batch"].max()) + 1
+x, ea, ins = synth.normal((N, 300), s["x"]), synth.normal((E, 300), s["edge_attr"]), synth.normal((5, B, 512), s["instr"])
+p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=meta["param_seed"])
+m = gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4); m.load_state_dict({k: t(v) for k, v in p.items()}); m = m.cuda().eval()
+out = m(t(x).cuda(), t(g["edge_index"]).cuda(), t(ea).cuda(), t(ins).cuda(), t(g["batch"]).cuda()).cpu().double()
+ref = R.gat_seq(t(x, torch.float64), t(g["edge_index"]), t(ea, torch.float64), t(ins, torch.float64), t(g["batch"]), tparams(p, torch.float64))
+print(json.dumps({"err64": float((out - ref).abs().max()), "err_golden": float((out - torch.from_numpy(g["out"]).double()).abs().max()),
+                  "backend": _lib.load().gvqa_gemm_backend().decode()}))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for mode in ("bf16x3", "f32"):
+        env = dict(os.environ, GVQA_PROJ=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "bf16x3" in res["bf16x3"]["backend"] and "bf16x3" not in res["f32"]["backend"]
+    assert res["bf16x3"]["err_golden"] < TOL
+    assert res["bf16x3"]["err64"] < max(2e-5, 3 * res["f32"]["err64"])
