@@ -521,3 +521,24 @@ print(json.dumps({"err64": float((out - ref).abs().max()), "err_golden": float((
     assert "bf16x3" in res["bf16x3"]["backend"] and "bf16x3" not in res["f32"]["backend"]
     assert res["bf16x3"]["err_golden"] < TOL
     assert res["bf16x3"]["err64"] < max(2e-5, 3 * res["f32"]["err64"])
+
+
+def test_empty_batch_and_empty_graphs_in_the_middle(dev):
+    """N = 0 returns an empty tensor; graph ids that own no node (batch skips them), nodes without
+    in-edges and single-node graphs follow the reference (softmax over nothing = 0, no instruction term)."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.gat_skip import gat_seq
+    H, C, de, di, K = 4, 16, 8, 12, 3
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=77)
+    m = _load_module(gat_seq(C, C, de, di, K, gat_heads=H), p, dev)
+    z = m(torch.zeros(0, C, device=dev), torch.zeros(2, 0, dtype=torch.int64, device=dev), torch.zeros(0, de, device=dev),
+          torch.zeros(K, 3, di, device=dev), torch.zeros(0, dtype=torch.int64, device=dev))
+    assert z.shape == (0, C)
+    # 5 graph ids, graphs 1 and 3 own no node; node 4 has no in-edge; graph 4 is a single node with a self loop
+    batch = np.array([0, 0, 0, 2, 2, 4], dtype=np.int64)
+    ei = np.array([[0, 1, 2, 0, 3, 5, 1], [0, 1, 2, 1, 3, 5, 2]], dtype=np.int64)
+    N, E, B = 6, ei.shape[1], 5
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    out = m(t(x, device=dev), t(ei, device=dev), t(ea, device=dev), t(ins, device=dev), t(batch, device=dev))
+    ref = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(batch), tparams(p), heads=H)
+    assert maxabs(out, ref) < 2e-5
