@@ -50,6 +50,22 @@ def measured_traffic():
         return None
 
 
+def measured_copy_bandwidth(dev):
+    """Device-to-device copy of 1 GiB (read + write counted) -- the achievable-HBM yardstick of SURVEY 8(d)."""
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * n * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(params):
     """The oracle (a torch-CPU restatement of the reference's op sequence) timed on the host cores on
     a bounded sample of the same workload.  torch's CPU scatter/gather ops oversubscribe badly at
@@ -160,6 +176,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    copy_gbs = measured_copy_bandwidth(dev) if rank == 0 else None
     for _ in range(a.warmup):
         step()
     fence()
@@ -199,6 +216,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": measured_traffic(), "algorithmic_bytes_per_launch": alg,
+                         "measured_copy_GBps": copy_gbs,
+                         "frac_of_measured_copy": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
                          "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
                          "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
             "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},

@@ -85,19 +85,25 @@ class gat(torch.nn.Module):
             with torch.no_grad():
                 self.bias.zero_()
 
-    def _params(self, bn: Optional[torch.nn.BatchNorm1d] = None) -> "_lib.GatConvParams":
+    def _params(self, bn: Optional[torch.nn.BatchNorm1d] = None, keep: Optional[list] = None) -> "_lib.GatConvParams":
+        """Device pointers of this layer's parameters.  `keep` collects the (possibly re-laid-out)
+        tensors so that they outlive the C call."""
+        keep = [] if keep is None else keep
+
+        def ptr(t, name):
+            t = _f32c(t, name)
+            keep.append(t)
+            return t.data_ptr()
+
         p = _lib.GatConvParams()
-        p.lin_l_weight = _f32c(self.lin_l.weight, "lin_l.weight").data_ptr()
-        p.lin_e_weight = _f32c(self.lin_e.weight, "lin_e.weight").data_ptr()
-        p.att_l = _f32c(self.att_l, "att_l").data_ptr()
-        p.att_r = _f32c(self.att_r, "att_r").data_ptr()
-        p.att_e = _f32c(self.att_e, "att_e").data_ptr()
-        p.bias = None if self.bias is None else _f32c(self.bias, "bias").data_ptr()
+        p._keep = keep
+        p.lin_l_weight = ptr(self.lin_l.weight, "lin_l.weight")
+        p.lin_e_weight = ptr(self.lin_e.weight, "lin_e.weight")
+        p.att_l, p.att_r, p.att_e = ptr(self.att_l, "att_l"), ptr(self.att_r, "att_r"), ptr(self.att_e, "att_e")
+        p.bias = None if self.bias is None else ptr(self.bias, "bias")
         if bn is not None:
-            p.bn_weight = _f32c(bn.weight, "bn.weight").data_ptr()
-            p.bn_bias = _f32c(bn.bias, "bn.bias").data_ptr()
-            p.bn_mean = _f32c(bn.running_mean, "bn.running_mean").data_ptr()
-            p.bn_var = _f32c(bn.running_var, "bn.running_var").data_ptr()
+            p.bn_weight, p.bn_bias = ptr(bn.weight, "bn.weight"), ptr(bn.bias, "bn.bias")
+            p.bn_mean, p.bn_var = ptr(bn.running_mean, "bn.running_mean"), ptr(bn.running_var, "bn.running_var")
         return p
 
     def _check_mode(self):
@@ -192,8 +198,9 @@ class gat_seq(torch.nn.Module):
         d = _lib.GatDims(self.in_channels, self.edge_attr_dim, self.ins_dim, Cc, H, K, self.negative_slope,
                          self.bns[0].eps if len(self.bns) else 1e-5)
         hops = (_lib.GatConvParams * K)()
+        keep = []       # parameter tensors referenced by raw pointer stay alive until the call has been enqueued
         for i, conv in enumerate(self.convs):
-            hops[i] = conv._params(self.bns[i] if i != K - 1 else None)
+            hops[i] = conv._params(self.bns[i] if i != K - 1 else None, keep)
         dev = x.device
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
         alpha = torch.empty((K, E, H), dtype=torch.float32, device=dev) if return_attention_weights else None
