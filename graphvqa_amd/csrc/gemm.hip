@@ -28,14 +28,13 @@ namespace gvqa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;   // padded leading dimension (floats)
-
-template <int BM, int BN, int WR, int WC, bool VEC>
+template <int BM, int BN, int WR, int WC, bool VEC, int BK = 32>
 __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K, const float* __restrict__ A,
                                                     int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                     LinearEpilogue ep, float* C, int64_t ldc,
                                                     int64_t strideA, int64_t strideB, int64_t strideC) {
+    constexpr int LDS_LD = BK + 4;                // padded leading dimension (floats)
+    constexpr int RQ = BK / 4;                    // float4 per tile row
     constexpr int NTH = 64 * WR * WC;             // threads per block
     constexpr int WM = BM / WR, WN = BN / WC;     // wave tile
     constexpr int MT = WM / 32, NT = WN / 32;     // 32x32 MFMA tiles per wave
@@ -87,12 +86,12 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int idx = tid + i * NTH;
-            ra[i] = load_one(A, lda, M, m0 + (idx >> 3), k0 + (idx & 7) * 4);
+            ra[i] = load_one(A, lda, M, m0 + (idx / RQ), k0 + (idx % RQ) * 4);
         }
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) {
             const int idx = min(tid + i * NTH, BN * BK / 4 - 1);
-            rb[i] = load_one(B, ldb, N, n0 + (idx >> 3), k0 + (idx & 7) * 4);
+            rb[i] = load_one(B, ldb, N, n0 + (idx / RQ), k0 + (idx % RQ) * 4);
         }
     };
     auto store_tile = [&](int buf, int kt) {
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
 #pragma unroll
         for (int i = 0; i < A_V4; ++i) {
             const int idx = tid + i * NTH;
-            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int r = idx / RQ, c4 = (idx % RQ) * 4;
             float4 v = ra[i];
             if (tail) v = mask_k(v, k0 + c4);
             *reinterpret_cast<float4*>(&As[buf][r * LDS_LD + c4]) = v;
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
         for (int i = 0; i < B_V4; ++i) {
             const int idx = tid + i * NTH;
             if (idx < BN * BK / 4) {
-                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                const int r = idx / RQ, c4 = (idx % RQ) * 4;
                 float4 v = rb[i];
                 if (tail) v = mask_k(v, k0 + c4);
                 *reinterpret_cast<float4*>(&Bs[buf][r * LDS_LD + c4]) = v;
@@ -538,12 +537,17 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     else if (tile_sel == 1 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 4, 2);
     else if (tile_sel == 2 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 2, 2);
     else if (tile_sel == 3) GVQA_LAUNCH_LINEAR(128, 128, 4, 2);
+    else if (tile_sel == 5 || (tile_sel == 0 && K <= 1024)) {   // short K: K step 16, 3 blocks/CU (+4.5 % at K = 512)
+        dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch);
+        if (vec) hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2, true, 16>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);
+        else hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2, false, 16>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);
+    }
     else if (tile_sel == 4 && batch == 1 && cdiv(M, 64) <= 65535) {
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 64));
         if (vec) hipLaunchKernelGGL((k_linear_f32_s16<true>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc);
         else hipLaunchKernelGGL((k_linear_f32_s16<false>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc);
     }
-    else GVQA_LAUNCH_LINEAR(128, 128, 2, 2);
+    else GVQA_LAUNCH_LINEAR(128, 128, 2, 2);    // also tile_sel == 6: force K step 32
 #undef GVQA_LAUNCH_LINEAR
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
