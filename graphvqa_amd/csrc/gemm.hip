@@ -63,16 +63,36 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
 
     float4 ra[A_V4], rb[B_V4];
 
-    // Branch-free tile loads: out-of-range rows / k are CLAMPED to a valid address; the zero-fill of
-    // the K tail is a select applied only when the registers are written to LDS (store_tile), so
-    // that nothing consumes the loaded values -- and forces a vmcnt wait -- before the MFMAs of
-    // the current tile have been issued.  (A branch around a load, or an early select, makes the
-    // prefetch synchronous.)
-    auto load_one = [&](const float* __restrict__ P, int64_t ld, int rows, int gr, int gk) -> float4 {
-        const float* p = P + (int64_t)min(gr, rows - 1) * ld;
-        if (VEC) return *reinterpret_cast<const float4*>(p + min(gk, K - 4));
-        return make_float4(p[min(gk + 0, K - 1)], p[min(gk + 1, K - 1)], p[min(gk + 2, K - 1)],
-                           p[min(gk + 3, K - 1)]);
+    // Branch-free tile loads: out-of-range rows are CLAMPED to a valid row (their products are never
+    // stored) and the zero-fill of the K tail is a select applied only when the registers are
+    // written to LDS (store_tile), so that nothing consumes the loaded values -- and forces a vmcnt
+    // wait -- before the MFMAs of the current tile have been issued.  (A branch around a load, or an
+    // early select, makes the prefetch synchronous.)  The per-thread row pointers are formed ONCE;
+    // inside the K loop a load is pointer + uniform offset (the address/clamp arithmetic per tile
+    // used to cost ~2.6 VALU instructions per MFMA).
+    const float* pa[A_V4];
+    const float* pb[B_V4];
+    int ca[A_V4], cb[B_V4];           // k offset of this thread's float4 within a tile
+#pragma unroll
+    for (int i = 0; i < A_V4; ++i) {
+        const int idx = tid + i * NTH;
+        ca[i] = (idx % RQ) * 4;
+        pa[i] = A + (int64_t)min(m0 + idx / RQ, M - 1) * lda + ca[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_V4; ++i) {
+        const int idx = min(tid + i * NTH, BN * BK / 4 - 1);
+        cb[i] = (idx % RQ) * 4;
+        pb[i] = B + (int64_t)min(n0 + idx / RQ, N - 1) * ldb + cb[i];
+    }
+    auto load_vec = [&](const float* __restrict__ p, int k0, int c, bool tail) -> float4 {
+        if (VEC) {
+            if (!tail) return *reinterpret_cast<const float4*>(p + k0);
+            return *reinterpret_cast<const float4*>(p + (min(k0 + c, K - 4) - c));
+        }
+        const float* q = p - c;          // row start
+        return make_float4(q[min(k0 + c + 0, K - 1)], q[min(k0 + c + 1, K - 1)], q[min(k0 + c + 2, K - 1)],
+                           q[min(k0 + c + 3, K - 1)]);
     };
     auto mask_k = [&](float4 v, int gk) -> float4 {
         if (gk + 0 >= K) v.x = 0.f;
@@ -83,16 +103,11 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
     };
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
+        const bool tail = k0 + BK > K;       // block-uniform
 #pragma unroll
-        for (int i = 0; i < A_V4; ++i) {
-            const int idx = tid + i * NTH;
-            ra[i] = load_one(A, lda, M, m0 + (idx / RQ), k0 + (idx % RQ) * 4);
-        }
+        for (int i = 0; i < A_V4; ++i) ra[i] = load_vec(pa[i], k0, ca[i], tail);
 #pragma unroll
-        for (int i = 0; i < B_V4; ++i) {
-            const int idx = min(tid + i * NTH, BN * BK / 4 - 1);
-            rb[i] = load_one(B, ldb, N, n0 + (idx / RQ), k0 + (idx % RQ) * 4);
-        }
+        for (int i = 0; i < B_V4; ++i) rb[i] = load_vec(pb[i], k0, cb[i], tail);
     };
     auto store_tile = [&](int buf, int kt) {
         const int k0 = kt * BK;
