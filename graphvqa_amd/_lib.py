@@ -75,7 +75,7 @@ class GcnParams(C.Structure):
 class LcgnDims(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("question_dim", C.c_int32),
                 ("num_iters", C.c_int32), ("seq_len", C.c_int32), ("heads", C.c_int32),
-                ("negative_slope", C.c_float)]
+                ("negative_slope", C.c_float), ("node_bf16", C.c_int32)]
 
 
 class LcgnParams(C.Structure):

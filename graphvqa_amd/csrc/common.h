@@ -59,12 +59,25 @@ struct StageTimer {
     ~StageTimer();
 };
 
+// bf16 storage helpers (node tensors of the LCGN bf16-node-feature mode): fp32 compute, bf16 in HBM
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {      // round to nearest even
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <bool H16>
+__device__ __forceinline__ float load_elem(const void* p, int64_t i) {
+    if (H16) return bf16_to_f32(static_cast<const uint16_t*>(p)[i]);
+    return static_cast<const float*>(p)[i];
+}
+
 // Epilogue of the dense projection: v = acc + bias[n]; v += addend[m,n]; v *= mul[m,n]; relu.
 struct LinearEpilogue {
     const float* bias;      // [N] or NULL
-    const float* addend;    // [M, ld_add] or NULL (may alias C: accumulate in place)
+    const float* addend;    // [M, ld_add] or NULL (may alias C: accumulate in place); bf16 when C is bf16
     int64_t ld_add;
-    const float* mul;       // [M, ld_mul] or NULL
+    const float* mul;       // [M, ld_mul] or NULL; bf16 when C is bf16
     int64_t ld_mul;
     int relu;               // activation: 0 none, 1 ReLU, 2 ELU(alpha = 1)
 };
@@ -78,6 +91,9 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
                      int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, hipStream_t stream);
 
+int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                    int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
+                    int64_t strideB, int64_t strideC, int dtype_flags, hipStream_t stream);
 const char* gemm_backend_name();
 int launch_split_bf16x3(int64_t rows, int K, const float* x, int64_t ld, int which, void* out, hipStream_t stream);
 bool vendor_bf16_gemm(int64_t M, int64_t N, int64_t K6, const void* A, const void* B, float* C, int64_t ldc, hipStream_t stream);

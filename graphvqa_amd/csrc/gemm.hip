@@ -21,6 +21,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 #include "common.h"
 
@@ -28,11 +29,17 @@ namespace gvqa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WR, int WC, bool VEC, int BK = 32>
-__global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K, const float* __restrict__ A,
+// A16: A is stored as bf16; C16: C, and the addend / mul operands of the epilogue, are stored as bf16
+// (leading dimensions are in elements of the respective type).  B (weights) and bias are fp32.
+template <int BM, int BN, int WR, int WC, bool VEC, int BK = 32, bool A16 = false, bool C16 = false>
+__global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K, const float* __restrict__ A_,
                                                     int64_t lda, const float* __restrict__ B, int64_t ldb,
-                                                    LinearEpilogue ep, float* C, int64_t ldc,
+                                                    LinearEpilogue ep, float* C_, int64_t ldc,
                                                     int64_t strideA, int64_t strideB, int64_t strideC) {
+    typedef typename std::conditional<A16, uint16_t, float>::type TA;
+    typedef typename std::conditional<C16, uint16_t, float>::type TC;
+    const TA* A = reinterpret_cast<const TA*>(A_);
+    TC* C = reinterpret_cast<TC*>(C_);
     constexpr int LDS_LD = BK + 4;                // padded leading dimension (floats)
     constexpr int RQ = BK / 4;                    // float4 per tile row
     constexpr int NTH = 64 * WR * WC;             // threads per block
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
     // early select, makes the prefetch synchronous.)  The per-thread row pointers are formed ONCE;
     // inside the K loop a load is pointer + uniform offset (the address/clamp arithmetic per tile
     // used to cost ~2.6 VALU instructions per MFMA).
-    const float* pa[A_V4];
+    const TA* pa[A_V4];
     const float* pb[B_V4];
     int ca[A_V4], cb[B_V4];           // k offset of this thread's float4 within a tile
 #pragma unroll
@@ -94,6 +101,20 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
         return make_float4(q[min(k0 + c + 0, K - 1)], q[min(k0 + c + 1, K - 1)], q[min(k0 + c + 2, K - 1)],
                            q[min(k0 + c + 3, K - 1)]);
     };
+    auto load_vec_a = [&](const TA* __restrict__ p, int k0, int c, bool tail) -> float4 {
+        if constexpr (!A16) {
+            return load_vec(reinterpret_cast<const float*>(p), k0, c, tail);
+        } else {
+            if (VEC) {      // 4 bf16 = 8 bytes
+                const uint2 raw = *reinterpret_cast<const uint2*>(p + (tail ? (min(k0 + c, K - 4) - c) : k0));
+                return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xFFFF0000u),
+                                   __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xFFFF0000u));
+            }
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(p) - c;
+            return make_float4(bf16_to_f32(q[min(k0 + c + 0, K - 1)]), bf16_to_f32(q[min(k0 + c + 1, K - 1)]),
+                               bf16_to_f32(q[min(k0 + c + 2, K - 1)]), bf16_to_f32(q[min(k0 + c + 3, K - 1)]));
+        }
+    };
     auto mask_k = [&](float4 v, int gk) -> float4 {
         if (gk + 0 >= K) v.x = 0.f;
         if (gk + 1 >= K) v.y = 0.f;
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
         const int k0 = kt * BK;
         const bool tail = k0 + BK > K;       // block-uniform
 #pragma unroll
-        for (int i = 0; i < A_V4; ++i) ra[i] = load_vec(pa[i], k0, ca[i], tail);
+        for (int i = 0; i < A_V4; ++i) ra[i] = load_vec_a(pa[i], k0, ca[i], tail);
 #pragma unroll
         for (int i = 0; i < B_V4; ++i) rb[i] = load_vec(pb[i], k0, cb[i], tail);
     };
@@ -181,11 +202,12 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
                 const int gr = gr0 + (r & 3) + 8 * (r >> 2);
                 if (gr < M) {
                     float v = acc[i][j][r] + bv;
-                    if (ep.addend) v += ep.addend[(int64_t)gr * ep.ld_add + gc];
-                    if (ep.mul) v *= ep.mul[(int64_t)gr * ep.ld_mul + gc];
+                    if (ep.addend) v += load_elem<C16>(ep.addend, (int64_t)gr * ep.ld_add + gc);
+                    if (ep.mul) v *= load_elem<C16>(ep.mul, (int64_t)gr * ep.ld_mul + gc);
                     if (ep.relu == 1) v = fmaxf(v, 0.f);
                     else if (ep.relu == 2) v = v > 0.f ? v : expf(v) - 1.f;   // ELU(alpha = 1), torch's exp(x) - 1 form
-                    C[(int64_t)gr * ldc + gc] = v;
+                    if constexpr (C16) C[(int64_t)gr * ldc + gc] = f32_to_bf16(v);
+                    else C[(int64_t)gr * ldc + gc] = v;
                 }
             }
         }
@@ -516,6 +538,14 @@ int launch_linear(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, 
 int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
                      int64_t strideB, int64_t strideC, hipStream_t stream) {
+    return launch_linear_t(M, N, K, A, lda, B, ldb, ep, C, ldc, batch, strideA, strideB, strideC, 0, stream);
+}
+
+// dtype_flags: bit 0 = A stored as bf16, bit 1 = C / addend / mul stored as bf16 (pointers are then
+// uint16_t* passed through the float* parameters; leading dimensions in elements).
+int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                    int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
+                    int64_t strideB, int64_t strideC, int dtype_flags, hipStream_t stream) {
     GVQA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1, GVQA_E_INVALID, "linear: negative size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), GVQA_E_INVALID, "linear: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
@@ -527,13 +557,37 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
                  "linear: epilogue leading dimension too small");
     GVQA_REQUIRE((!ep.addend && !ep.mul) || batch == 1, GVQA_E_INVALID, "linear: addend/mul epilogue is not batched");
     // 16-byte vector loads need 16-byte aligned rows
-    if (!ep.bias && !ep.addend && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
+    if (dtype_flags == 0 && !ep.bias && !ep.addend && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
         (2.0 * M * N * K >= 2e9 || vendor_mode() >= 2) && vendor_mode() != 1) {
         if (vendor_sgemm(M, N, K, A, lda, B, ldb, C, ldc, stream)) return GVQA_OK;
     }
+    const bool a16 = dtype_flags & 1;
     const bool vec = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
-                     (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                     (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & (a16 ? 7 : 15)) == 0) &&
                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    if (dtype_flags) {      // bf16-storage variants: default tile shapes only
+#define GVQA_LAUNCH_T(BM_, BN_, WR_, WC_, BK_, A16_, C16_)                                                              \
+        do {                                                                                                        \
+            dim3 grid((unsigned)cdiv(N, BN_), (unsigned)cdiv(M, BM_), (unsigned)batch);                             \
+            if (vec) hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, true, BK_, A16_, C16_>), grid, dim3(256), 0, stream, \
+                                        (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);  \
+            else hipLaunchKernelGGL((k_linear_f32<BM_, BN_, WR_, WC_, false, BK_, A16_, C16_>), grid, dim3(256), 0, stream, \
+                                    (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);     \
+        } while (0)
+#define GVQA_LAUNCH_T_SHAPE(A16_, C16_)                                                  \
+        do {                                                                             \
+            if (N <= 32) GVQA_LAUNCH_T(128, 32, 4, 1, 32, A16_, C16_);                   \
+            else if (N <= 64) GVQA_LAUNCH_T(128, 64, 2, 2, 32, A16_, C16_);              \
+            else GVQA_LAUNCH_T(128, 128, 2, 2, 16, A16_, C16_);                          \
+        } while (0)
+        if (dtype_flags == 1) GVQA_LAUNCH_T_SHAPE(true, false);
+        else if (dtype_flags == 2) GVQA_LAUNCH_T_SHAPE(false, true);
+        else GVQA_LAUNCH_T_SHAPE(true, true);
+#undef GVQA_LAUNCH_T_SHAPE
+#undef GVQA_LAUNCH_T
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
 #define GVQA_LAUNCH_LINEAR(BM_, BN_, WR_, WC_)                                                          \
     do {                                                                                               \
         dim3 grid((unsigned)cdiv(N, BN_), (unsigned)cdiv(M, BM_), (unsigned)batch);                    \

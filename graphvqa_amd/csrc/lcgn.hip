@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void k_lcgn_command(int L, int B, int O, const
 // logit[eid] = sum_c x_l[src, c] * (proj_cmd[g(dst), c] * x_r[dst, c])      (lcgn.py:154,207), H = 1.
 // One wave per destination node; its y = proj_cmd * x_r row stays in registers.
 constexpr int LCGN_MAXC_PER_LANE = 16;      // C <= 1024
-__global__ __launch_bounds__(256) void k_lcgn_edge_logit(int N, int C, const float* __restrict__ xl, int64_t xl_ld,
-                                                         const float* __restrict__ xr, int64_t xr_ld,
+template <bool T16>      // T16: x_l / x_r rows stored as bf16
+__global__ __launch_bounds__(256) void k_lcgn_edge_logit(int N, int C, const void* __restrict__ xl, int64_t xl_ld,
+                                                         const void* __restrict__ xr, int64_t xr_ld,
                                                          const float* __restrict__ proj_cmd, int64_t pc_ld,
                                                          const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ csr_src,
@@ -66,19 +67,56 @@ __global__ __launch_bounds__(256) void k_lcgn_edge_logit(int N, int C, const flo
 #pragma unroll
     for (int k = 0; k < LCGN_MAXC_PER_LANE; ++k) {
         const int c = lane + k * 64;
-        y[k] = c < C ? proj_cmd[(int64_t)g * pc_ld + c] * xr[(int64_t)i * xr_ld + c] : 0.f;
+        y[k] = c < C ? proj_cmd[(int64_t)g * pc_ld + c] * load_elem<T16>(xr, (int64_t)i * xr_ld + c) : 0.f;
     }
     for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) {
-        const float* row = xl + (int64_t)csr_src[s] * xl_ld;
+        const int64_t row = (int64_t)csr_src[s] * xl_ld;
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < LCGN_MAXC_PER_LANE; ++k) {
             const int c = lane + k * 64;
-            if (c < C) acc += row[c] * y[k];
+            if (c < C) acc += load_elem<T16>(xl, row + c) * y[k];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (lane == 0) logit[csr_eid[s]] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_f32_to_bf16(int64_t n, const float* __restrict__ in, uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16(in[i]);
+}
+
+// bf16-node-feature mode: msg[i] = (sum_{e -> i} alpha_e * x_val[src(e)]) * cal_cmd[g(i)] + bias with
+// alpha = softmax over the in-edges of leaky_relu(logit) (lcgn.py:209-238, H = 1), x_val rows and msg
+// stored as bf16, everything accumulated in fp32.  One wave per destination node; the (short) edge
+// list is scanned three times by every lane (max, sum, weighted gather).
+__global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16(int N, int C, const uint16_t* __restrict__ xval, int64_t xv_ld,
+                                                             const float* __restrict__ logit, const float* __restrict__ cal_cmd,
+                                                             int64_t cc_ld, const float* __restrict__ bias, float slope,
+                                                             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
+                                                             const int32_t* __restrict__ csr_eid,
+                                                             const int32_t* __restrict__ node_graph, uint16_t* __restrict__ msg) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1], g = node_graph[i];
+    float m = -INFINITY;
+    for (int s = lo; s < hi; ++s) { float v = logit[csr_eid[s]]; v = v > 0.f ? v : v * slope; m = fmaxf(m, v); }
+    float den = 0.f;
+    for (int s = lo; s < hi; ++s) { float v = logit[csr_eid[s]]; v = v > 0.f ? v : v * slope; den += expf(v - m); }
+    den += 1e-16f;
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.f;
+        for (int s = lo; s < hi; ++s) {
+            float v = logit[csr_eid[s]];
+            v = v > 0.f ? v : v * slope;
+            acc += (expf(v - m) / den) * bf16_to_f32(xval[(int64_t)csr_src[s] * xv_ld + c]);
+        }
+        float r = acc * cal_cmd[(int64_t)g * cc_ld + c];
+        if (bias) r += bias[c];
+        msg[(int64_t)i * C + c] = f32_to_bf16(r);
     }
 }
 
@@ -125,10 +163,18 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     char* base = static_cast<char*>(ws);
     auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     int rc;
+    // node tensors (x_loc, proj_x_loc, x_ctx, prod, XL, J, msg) are fp32, or bf16 in the bf16-node-feature
+    // mode (BASELINE config 5): same buffers, half the bytes, fp32 arithmetic everywhere.
+    const bool nb = d->node_bf16 != 0;
+    const int FA = nb ? 1 : 0, FC = nb ? 2 : 0;      // dtype flags: A is a node tensor / C is a node tensor
+#define LINT(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, fl_)                                                     \
+    do { rc = launch_linear_t(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, fl_, stream); if (rc) return rc; } while (0)
 #define LIN(M_, N_, K_, A_, lda_, W_, ldw_, bias_, relu_, C_, ldc_)                                                  \
-    do { rc = launch_linear(M_, N_, K_, A_, lda_, W_, ldw_, bias_, relu_, C_, ldc_, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
-#define LINX(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_)                                                          \
-    do { rc = launch_linear_ex(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
+    do { LinearEpilogue e_{bias_, nullptr, 0, nullptr, 0, relu_}; LINT(M_, N_, K_, A_, lda_, W_, ldw_, e_, C_, ldc_, 0); } while (0)
+    // element offset into a node tensor (bf16 pointers travel as float*: offsets are halved)
+    auto NP = [&](float* base_, int64_t elems) -> float* {
+        return nb ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base_) + elems) : base_ + elems;
+    };
 
     StageTimer timer(GVQA_STAGE_OTHER, stream);
     // stacked weights: Wcat = [lin_l; lin_r; cal_x] ([3O, 3O]),  Wpc = [proj_cmd; cal_cmd] ([2O, O])
@@ -139,14 +185,29 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc), p->proj_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
     GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc) + (size_t)O * O, p->cal_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
 
-    LIN(N, O, Cin, x, Cin, p->init_weight, Cin, p->init_bias, 0, P(L.x_loc), O);                   // lcgn.py:305
+    {   // x_loc = init(x)                                                                       lcgn.py:305
+        LinearEpilogue e{p->init_bias, nullptr, 0, nullptr, 0, 0};
+        LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);
+    }
     LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
-    LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, p->proj_x_loc_bias, 0, P(L.proj_x_loc), O); // :308
-    LIN(N, 3 * O, O, P(L.x_loc), O, P(L.Wcat), 3 * O, nullptr, 0, P(L.XL), 3 * O);                  // x_loc segment of :144-145,230
+    {   // proj_x_loc                                                                            :308
+        LinearEpilogue e{p->proj_x_loc_bias, nullptr, 0, nullptr, 0, 0};
+        LINT(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, e, P(L.proj_x_loc), O, FA | FC);
+    }
+    {   // x_loc segment of lin_l / lin_r / cal_x                                                :144-145,230
+        LinearEpilogue e{nullptr, nullptr, 0, nullptr, 0, 0};
+        LINT(N, 3 * O, O, P(L.x_loc), O, P(L.Wcat), 3 * O, e, P(L.XL), 3 * O, FA | FC);
+    }
     const float* x_ctx = x_ctx_init;
+    if (nb) {
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N * O, x_ctx_init,
+                           reinterpret_cast<uint16_t*>(P(L.x_ctx1)));
+        GVQA_LAUNCH_CHECK();
+        x_ctx = P(L.x_ctx1);
+    }
     for (int t = 0; t < T; ++t) {
         float* x_ctx_next = (t & 1) ? P(L.x_ctx1) : P(L.x_ctx0);
-        // textual command (:292-300)
+        // textual command (:292-300), per-graph, fp32
         LIN(B, O, O, P(L.q_emb), O, p->qinput2_weight[t], O, p->qinput2_bias[t], 0, P(L.q_cmd), O);
         hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B, O,
                            P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
@@ -154,39 +215,55 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         LIN(B, 2 * O, O, P(L.cmd), O, P(L.Wpc), O, nullptr, 0, P(L.pc), 2 * O);                     // :148-149
         // prod = proj_x_ctx(x_ctx) * proj_x_loc                                                     // :312-313
         LinearEpilogue ep_mul{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0};
-        LINX(N, O, O, x_ctx, O, p->proj_x_ctx_weight, O, ep_mul, P(L.prod), O);
+        ep_mul.addend = nullptr; ep_mul.mul = P(L.proj_x_loc); ep_mul.ld_mul = O;
+        LINT(N, O, O, x_ctx, O, p->proj_x_ctx_weight, O, ep_mul, P(L.prod), O, FA | FC);
         // J = x_joint . Wcat^T = XL + x_ctx . Wcat[:, O:2O]^T + prod . Wcat[:, 2O:3O]^T            // :144-145,230
         LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
-        LINX(N, 3 * O, O, x_ctx, O, P(L.Wcat) + O, 3 * O, ep_add, P(L.J), 3 * O);
+        LINT(N, 3 * O, O, x_ctx, O, P(L.Wcat) + O, 3 * O, ep_add, P(L.J), 3 * O, FA | FC);
         LinearEpilogue ep_acc{nullptr, P(L.J), 3 * O, nullptr, 0, 0};
-        LINX(N, 3 * O, O, P(L.prod), O, P(L.Wcat) + 2 * O, 3 * O, ep_acc, P(L.J), 3 * O);
+        LINT(N, 3 * O, O, P(L.prod), O, P(L.Wcat) + 2 * O, 3 * O, ep_acc, P(L.J), 3 * O, FA | FC);
         // dot-product attention logits per edge                                                     // :154,207
-        hipLaunchKernelGGL(k_lcgn_edge_logit, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J), (int64_t)3 * O,
-                           P(L.J) + O, (int64_t)3 * O, P(L.pc), (int64_t)2 * O, g->rowptr, g->csr_src, g->csr_eid,
-                           g->node_graph, P(L.logit));
+        if (nb)
+            hipLaunchKernelGGL(k_lcgn_edge_logit<true>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
+                               (int64_t)3 * O, NP(P(L.J), O), (int64_t)3 * O, P(L.pc), (int64_t)2 * O, g->rowptr, g->csr_src,
+                               g->csr_eid, g->node_graph, P(L.logit));
+        else
+            hipLaunchKernelGGL(k_lcgn_edge_logit<false>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
+                               (int64_t)3 * O, P(L.J) + O, (int64_t)3 * O, P(L.pc), (int64_t)2 * O, g->rowptr, g->csr_src,
+                               g->csr_eid, g->node_graph, P(L.logit));
         GVQA_LAUNCH_CHECK();
         // leaky-relu, softmax over in-edges, alpha-weighted sum of cal_x(x_joint)[src], x cal_cmd[g], + bias  // :209-238,166-168
-        gvqa_gat_mp_desc m;
-        memset(&m, 0, sizeof(m));
-        m.C = O; m.H = 1; m.negative_slope = d->negative_slope; m.bn_eps = 1e-5f;
-        m.xp = P(L.J) + 2 * O; m.xp_ld = 3 * O;
-        m.a_edge = P(L.logit); m.a_edge_stride = 1;
-        m.graph_scale = P(L.pc) + O; m.graph_scale_ld = 2 * O;
-        m.bias = p->bias; m.out = P(L.msg);
-        rc = launch_gat_mp_public(g, &m, P(L.alpha), (size_t)E * sizeof(float), stream);
-        if (rc) return rc;
+        if (nb) {
+            hipLaunchKernelGGL(k_lcgn_aggregate_bf16, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O,
+                               reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), P(L.pc) + O,
+                               (int64_t)2 * O, p->bias, d->negative_slope, g->rowptr, g->csr_src, g->csr_eid, g->node_graph,
+                               reinterpret_cast<uint16_t*>(P(L.msg)));
+            GVQA_LAUNCH_CHECK();
+        } else {
+            gvqa_gat_mp_desc m;
+            memset(&m, 0, sizeof(m));
+            m.C = O; m.H = 1; m.negative_slope = d->negative_slope; m.bn_eps = 1e-5f;
+            m.xp = P(L.J) + 2 * O; m.xp_ld = 3 * O;
+            m.a_edge = P(L.logit); m.a_edge_stride = 1;
+            m.graph_scale = P(L.pc) + O; m.graph_scale_ld = 2 * O;
+            m.bias = p->bias; m.out = P(L.msg);
+            rc = launch_gat_mp_public(g, &m, P(L.alpha), (size_t)E * sizeof(float), stream);
+            if (rc) return rc;
+        }
         // x_ctx = output_layer([x_ctx || msg])                                                       // :316-319
-        LIN(N, O, O, x_ctx, O, p->output_weight, 2 * O, p->output_bias, 0, x_ctx_next, O);
+        LinearEpilogue ep_o1{p->output_bias, nullptr, 0, nullptr, 0, 0};
+        LINT(N, O, O, x_ctx, O, p->output_weight, 2 * O, ep_o1, x_ctx_next, O, FA | FC);
         LinearEpilogue ep_acc2{nullptr, x_ctx_next, O, nullptr, 0, 0};
-        LINX(N, O, O, P(L.msg), O, p->output_weight + O, 2 * O, ep_acc2, x_ctx_next, O);
+        LINT(N, O, O, P(L.msg), O, p->output_weight + O, 2 * O, ep_acc2, x_ctx_next, O, FA | FC);
         x_ctx = x_ctx_next;
     }
-    // out = fin_layer([x_loc || x_ctx])                                                              // :321-322
-    LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, p->fin_bias, 0, out, O);
+    // out = fin_layer([x_loc || x_ctx]) (fp32 result)                                                // :321-322
+    LinearEpilogue ep_f1{p->fin_bias, nullptr, 0, nullptr, 0, 0};
+    LINT(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, ep_f1, out, O, FA);
     LinearEpilogue ep_fin{nullptr, out, O, nullptr, 0, 0};
-    LINX(N, O, O, x_ctx, O, p->fin_weight + O, 2 * O, ep_fin, out, O);
+    LINT(N, O, O, x_ctx, O, p->fin_weight + O, 2 * O, ep_fin, out, O, FA);
 #undef LIN
-#undef LINX
+#undef LINT
     return GVQA_OK;
 }
 

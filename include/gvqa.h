@@ -259,6 +259,8 @@ typedef struct gvqa_lcgn_dims {
     int32_t seq_len;        /* L: number of lstm_outputs steps                                    */
     int32_t heads;          /* gat_heads (1)                                                      */
     float negative_slope;
+    int32_t node_bf16;      /* 1: per-node tensors (x_loc, x_ctx, their projections, messages) are STORED
+                               as bf16 in HBM, arithmetic stays fp32 (BASELINE config 5); 0: fp32           */
 } gvqa_lcgn_dims;
 
 typedef struct gvqa_lcgn_params {   /* lcgn_seq state_dict (lcgn.py:255-282), device pointers */

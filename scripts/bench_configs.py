@@ -75,4 +75,9 @@ q, lstm = tt(synth.normal((B, 512), 5)).to(dev), tt(synth.normal((10, B, 512), 6
 xc = tt(synth.normal((N, 512), 7)).to(dev)
 dt, prof = timed(lambda: m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc))
 res["config5_lcgn_fp32"] = {"ms_per_forward": dt * 1e3, "edges_per_s": E / dt, "stage_ms": {k: v[0] for k, v in prof.items()}}
+m16 = load(lcgn_seq(300, 512, 300, 5, node_feature_dtype=torch.bfloat16), synth.lcgn_seq_params(300, 512, seed=808))
+dt, prof = timed(lambda: m16(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc))
+res["config5_lcgn_bf16_node_features"] = {"ms_per_forward": dt * 1e3, "edges_per_s": E / dt,
+                                          "max_abs_vs_fp32_mode": float((m16(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc) -
+                                                                         m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc)).abs().max())}
 print(json.dumps(res))

@@ -33,6 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Graph) == 3 * 8 + 6 * 8 + 6 * 4
     assert C.sizeof(_lib.GatConvParams) == 10 * 8
     assert C.sizeof(_lib.GatDims) == 8 * 4
+    assert C.sizeof(_lib.LcgnDims) == 8 * 4
 
 
 def test_argument_validation_without_gpu():
