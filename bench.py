@@ -87,6 +87,15 @@ def cpu_baseline(params):
         return time.perf_counter() - t0
 
     ncpu = os.cpu_count() or 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     _, _, small = make(32)
     best_t, best_th = None, 1
     for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
@@ -103,7 +112,7 @@ def cpu_baseline(params):
         times.append(run(args))
     best = min(times)
     return {"value": E / best, "unit": "edges/s", "cores": best_th, "kind": "port",
-            "host_cpus": ncpu,
+            "host_cpus": ncpu, "cpu_model": cpu_model,
             "sample": f"oracle/ref_torch.gat_seq on {nb} graphs ({N} nodes / {E} edges), d={D}, K={K}, "
                       f"fp32, best of {len(times)} forwards ({best:.2f} s), {best_th} torch threads "
                       f"(best of 8/16/32/64 on a 32-graph sample)"}
@@ -220,6 +229,10 @@ def main():
                          "frac_of_measured_copy": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
                          "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
                          "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
+            "projection": (lambda ms, n: {"flops_per_launch": 2 * N * D * H * D, "avg_launch_us": ms / max(n, 1) * 1e3,
+                                          "tflops": 2 * N * D * H * D / (ms / max(n, 1) * 1e-3) / 1e12 if n else None,
+                                          "peak_tflops_f32_mfma": 157.3,
+                                          "frac": 2 * N * D * H * D / (ms / max(n, 1) * 1e-3) / 1e12 / 157.3 if n else None})(*prof["proj"]),
             "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
             "gemm_backend": _lib.load().gvqa_gemm_backend().decode(),
         }

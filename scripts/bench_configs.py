@@ -53,6 +53,15 @@ res["config2_gat_d300"] = {"N": N, "E": E, "B": B, "ms_per_forward": dt * 1e3, "
                            "mp_us_per_hop": mp_ms / mp_n * 1e3, "mp_alg_bytes": alg,
                            "mp_GBps": alg / (mp_ms / mp_n * 1e-3) / 1e9, "stage_ms": {k: v[0] for k, v in prof.items()}}
 
+# "GQA-shaped" alternative of SURVEY 8(d): E/N ~ 4 (one self loop + ~3 relations per node), same dims
+gb4 = synth.make_graph_batch(1000, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=3.0)
+N4, E4 = gb4.num_nodes, gb4.num_edges
+ei4, batch4 = tt(gb4.edge_index).to(dev), tt(gb4.batch).to(dev)
+x4, ea4 = tt(synth.normal((N4, 300), 1)).to(dev), tt(synth.normal((E4, 300), 2)).to(dev)
+dt, prof = timed(lambda: m(x4, ei4, ea4, ins, batch4))
+res["config2_gat_d300_EoverN4"] = {"N": N4, "E": E4, "ms_per_forward": dt * 1e3, "edges_per_s": E4 / dt,
+                                   "mp_us_per_hop": prof["mp"][0] / prof["mp"][1] * 1e3}
+
 from graphvqa_amd.baseline_models import gine_seq, gcn_seq
 m = load(gine_seq(300, 300, 512), synth.gine_seq_params(300, 300, 512, 404))
 g = SceneGraphBatch(ei, batch, N, B)
