@@ -107,6 +107,12 @@ class EncoderParams(C.Structure):
                                           "ln_weight", "ln_bias")]
 
 
+class MpPlan(C.Structure):
+    _fields_ = [("tiled", C.c_int32), ("channel_range", C.c_int32), ("stage_buffers", C.c_int32),
+                ("blocks_per_cu", C.c_int32), ("stages_per_graph", C.c_int32), ("accumulators", C.c_int32),
+                ("lds_bytes", C.c_int64)]
+
+
 class GatDims(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
                 ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
@@ -164,6 +170,7 @@ PROTOTYPES = {
                                           C.POINTER(EncoderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]),
+    "gvqa_gat_mp_plan": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.POINTER(MpPlan)]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -855,6 +855,22 @@ extern "C" {
 
 using namespace gvqa;
 
+int gvqa_gat_mp_plan(const gvqa_graph* g, int32_t C, int32_t H, gvqa_mp_plan* out) {
+    GVQA_REQUIRE(g && out && C > 0 && H > 0, GVQA_E_INVALID, "gat_mp_plan: bad argument");
+    TilePlan p = plan_tiled(g, C, H);
+    memset(out, 0, sizeof(*out));
+    out->tiled = p.ok ? 1 : 0;
+    if (p.ok) {
+        out->channel_range = p.cw;
+        out->stage_buffers = p.nbuf;
+        out->lds_bytes = (int64_t)p.lds_bytes;
+        out->blocks_per_cu = (int32_t)(LDS_MAX / p.lds_bytes);
+        out->stages_per_graph = (int32_t)(cdiv(C, p.cw) * (H + 1));
+        out->accumulators = ((size_t)p.n_cap <= (size_t)2 * (MP_THREADS >> p.lpn_log)) ? 2 : MP_ITEMS;
+    }
+    return GVQA_OK;
+}
+
 int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream) {
     return launch_gat_mp(g, d, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }

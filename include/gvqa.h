@@ -202,6 +202,19 @@ typedef struct gvqa_gat_mp_desc {
 /* ws: >= 4*E*H bytes, used by the general kernel only. */
 int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream);
 
+/* Host-only introspection: the geometry gvqa_gat_message_passing would use for this (finalized)
+ * graph -- LDS-tiled streaming kernel or general CSR kernels -- without launching anything. */
+typedef struct gvqa_mp_plan {
+    int32_t tiled;             /* 1 = k_gat_mp_tiled, 0 = general CSR kernels                              */
+    int32_t channel_range;     /* cw: channels per stage (row segments of 4*cw contiguous bytes)             */
+    int32_t stage_buffers;     /* LDS stage buffers (prefetch depth + 1)                                     */
+    int32_t blocks_per_cu;     /* graphs resident per CU by LDS                                              */
+    int32_t stages_per_graph;  /* DMA stages per graph incl. the skip-row stage of every channel range       */
+    int32_t accumulators;      /* float4 accumulators per thread                                             */
+    int64_t lds_bytes;         /* dynamic LDS per block                                                      */
+} gvqa_mp_plan;
+int gvqa_gat_mp_plan(const gvqa_graph* g, int32_t C, int32_t H, gvqa_mp_plan* out);
+
 /* ------------------------------------------------------------------------------------------
  * GINE / GCN variants (baseline_and_test_models/pipeline_model_{gine,gcn}.py:622-674)
  * ---------------------------------------------------------------------------------------- */

@@ -105,3 +105,41 @@ def test_scene_graph_builder_matches_pinned_topology():
     assert n0 == 2 and ei0.shape[1] == 4
     gb = batch_scene_graphs([sg, sg])
     assert gb.num_nodes == 6 and gb.edge_index[:, 8:].min() == 3
+
+
+def _fake_graph(nodes, edges, graphs, max_nodes, max_edges, intra=1):
+    """A finalized gvqa_graph with hand-filled statistics (no device memory): enough for host-side planning."""
+    from graphvqa_amd import _lib
+    g = _lib.Graph()
+    g.num_nodes, g.num_edges, g.num_graphs = nodes, edges, graphs
+    g.max_graph_nodes, g.max_graph_edges, g.max_in_degree = max_nodes, max_edges, 8
+    g.intra_graph, g.valid, g.finalized = intra, 1, 1
+    return g
+
+
+def test_mp_tiling_plan_host_logic():
+    """The LDS-tiling decision of the message-passing kernel is pure host code: check it without a GPU."""
+    import ctypes as C
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+
+    def plan(g, Cc, H):
+        p = _lib.MpPlan()
+        assert lib.gvqa_gat_mp_plan(C.byref(g), Cc, H, C.byref(p)) == 0
+        return p
+
+    p = plan(_fake_graph(65536, 262144, 2048, 32, 128), 512, 4)          # BASELINE config 3
+    assert p.tiled == 1 and p.channel_range == 128 and p.stage_buffers == 2 and p.blocks_per_cu == 3
+    assert p.stages_per_graph == 4 * 5 and p.accumulators == 2 and p.lds_bytes <= 160 * 1024 // 3
+    p = plan(_fake_graph(29785, 59570, 1000, 40, 80), 300, 4)            # BASELINE config 2
+    assert p.tiled == 1 and p.channel_range == 100 and p.blocks_per_cu >= 3 and p.channel_range % 4 == 0
+    p = plan(_fake_graph(5000, 20000, 1, 5000, 20000), 32, 4)            # one huge graph: no LDS tile
+    assert p.tiled == 0
+    assert plan(_fake_graph(100, 400, 4, 30, 120), 30, 4).tiled == 0     # C % 4 != 0 -> scalar general kernels
+    assert plan(_fake_graph(100, 400, 4, 30, 120, intra=0), 32, 4).tiled == 0   # cross-graph edges
+    assert plan(_fake_graph(100, 400, 4, 30, 120), 32, 3).tiled == 0     # H not in {1,2,4,8}
+    g = _fake_graph(100, 400, 4, 30, 120)
+    g.finalized = 0
+    assert plan(g, 32, 4).tiled == 0                                      # statistics not available yet
+    big = plan(_fake_graph(4000, 16000, 10, 400, 1600), 512, 4)          # 400-node graphs: narrower ranges, fewer per CU
+    assert big.tiled == 1 and big.lds_bytes <= 160 * 1024 and big.channel_range < 128
