@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgvqa_hip.so")
+LIB_PATH = os.environ.get("GVQA_LIB", os.path.join(HERE, "lib", "libgvqa_hip.so"))   # GVQA_LIB: A/B a second build
 
 GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other")
