@@ -143,3 +143,56 @@ def test_mp_tiling_plan_host_logic():
     assert plan(g, 32, 4).tiled == 0                                      # statistics not available yet
     big = plan(_fake_graph(4000, 16000, 10, 400, 1600), 512, 4)          # 400-node graphs: narrower ranges, fewer per CU
     assert big.tiled == 1 and big.lds_bytes <= 160 * 1024 and big.channel_range < 128
+
+
+def test_every_entry_point_rejects_bad_arguments_without_gpu():
+    """Status codes + messages, never a crash: null structs, non-positive dims, missing weights,
+    undersized workspaces (all checked before any device work is enqueued)."""
+    import ctypes as C
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    g = _fake_graph(100, 400, 4, 30, 120)
+    E_INV, E_WS, E_UNS = _lib.E_INVALID, _lib.E_WORKSPACE, _lib.E_UNSUPPORTED
+    err = lambda: lib.gvqa_last_error().decode()
+
+    # linear
+    assert lib.gvqa_linear_f32(4, 4, 4, None, 4, None, 4, None, 0, None, 4, None) == E_INV and "null" in err()
+    assert lib.gvqa_linear_f32(-1, 4, 4, None, 4, None, 4, None, 0, None, 4, None) == E_INV
+    assert lib.gvqa_linear_f32(0, 4, 4, None, 4, None, 4, None, 0, None, 4, None) == 0          # empty product is fine
+    # gat conv / seq
+    d = _lib.GatDims(8, 8, 0, 8, 4, 1, 0.2, 1e-5)
+    p = _lib.GatConvParams()
+    assert lib.gvqa_gat_conv_forward(C.byref(g), C.byref(d), C.byref(p), None, None, None, None, None, 0, None) == E_WS
+    assert lib.gvqa_gat_conv_forward(None, C.byref(d), C.byref(p), None, None, None, None, None, 0, None) == E_INV
+    d9 = _lib.GatDims(8, 8, 4, 8, 4, 9, 0.2, 1e-5)
+    assert lib.gvqa_gat_seq_forward(C.byref(g), C.byref(d9), (_lib.GatConvParams * 9)(), None, None, None, None, None,
+                                    None, None, 0, None) == E_INV and "num_hops" in err()
+    gx = _fake_graph(100, 400, 4, 30, 120, intra=0)
+    d2 = _lib.GatDims(8, 8, 4, 8, 4, 2, 0.2, 1e-5)
+    assert lib.gvqa_gat_seq_forward(C.byref(gx), C.byref(d2), (_lib.GatConvParams * 2)(), None, None, None, None, None,
+                                    None, None, 0, None) == E_UNS and "joins two graphs" in err()
+    assert lib.gvqa_gat_seq_workspace_bytes(C.byref(g), C.byref(d2)) > 0
+    assert lib.gvqa_gat_seq_forward_trainbn(C.byref(g), C.byref(d2), (_lib.GatConvParams * 2)(), None, None, None, None,
+                                            None, None, 0, None) == E_INV
+    # message passing descriptor
+    m = _lib.GatMpDesc()
+    assert lib.gvqa_gat_message_passing(C.byref(g), C.byref(m), None, 0, None) == E_INV
+    # variants
+    assert lib.gvqa_bn_relu_chain(10, 8, 9, None, 1e-5, None, None, None) == E_INV and "stages" in err()
+    gp = _lib.GineParams()
+    assert lib.gvqa_gine_conv_forward(C.byref(g), 8, 0, 8, C.byref(gp), None, None, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_gine_conv_forward(C.byref(gx), 8, 4, 8, C.byref(gp), None, None, None, None, None, 0, None) == E_INV
+    cp = _lib.GcnParams()
+    assert lib.gvqa_gcn_conv_forward(C.byref(g), 8, 0, 8, C.byref(cp), None, None, None, None, 0, None) == E_INV
+    ld = _lib.LcgnDims(8, 8, 8, 4, 5, 2, 0.2, 0)                                   # heads != 1
+    assert lib.gvqa_lcgn_seq_forward(C.byref(g), C.byref(ld), C.byref(_lib.LcgnParams()), None, None, None, None, None,
+                                     None, 0, None) == E_UNS
+    ld1 = _lib.LcgnDims(8, 8, 8, 4, 5, 1, 0.2, 0)
+    assert lib.gvqa_lcgn_seq_forward(C.byref(g), C.byref(ld1), C.byref(_lib.LcgnParams()), None, None, None, None, None,
+                                     None, 0, None) == E_WS
+    assert lib.gvqa_attention_pool_forward(C.byref(g), 8, 8, C.byref(_lib.PoolParams()), None, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_answer_logits_forward(4, 8, 8, 10, C.byref(_lib.ClassifierParams()), None, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_sg_encoder_forward(C.byref(g), 50, 8, 12, 1, C.byref(_lib.EncoderParams()), None, None, None, 0, None,
+                                       1e-5, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_graph_finalize(C.byref(_lib.Graph()), None) == E_INV
+    assert lib.gvqa_prof_collect(None, None) == E_INV
