@@ -327,10 +327,11 @@ __global__ __launch_bounds__(256, 5) void k_linear_f32_s16(int M, int N, int K, 
 }
 
 // ---- vendor backends for PLAIN large projections ------------------------------------------------
-// Epilogue-free fp32 GEMMs above a size threshold go to the vendor library (f32-MFMA assembly
-// kernels: 126-150 TF on the projection shapes vs ~100-112 TF for k_linear_f32 above); everything
-// with a fused epilogue, the tall-skinny logit products and all small shapes stay on the
-// hand-written kernel.  hipBLASLt is tried first, then rocBLAS; both are resolved with dlopen at
+// fp32 GEMMs above a size threshold whose epilogue is nothing or a plain accumulate (C = A.B^T [+ addend],
+// BLAS beta = 1) go to the vendor library (f32-MFMA assembly kernels: 126-150 TF on the projection
+// shapes vs ~100-112 TF for k_linear_f32 above); everything with bias / multiply / activation fused,
+// the tall-skinny logit products and all small shapes stay on the hand-written kernel.  rocBLAS is
+// tried first (measured faster), then hipBLASLt; both are resolved with dlopen at
 // first use, so the library has no link-time dependency on them and loads on machines without
 // them (the hand-written kernel is then used everywhere).
 // GVQA_GEMM_BACKEND = auto (default) | hip (hand-written only) | hipblaslt | rocblas.
@@ -340,6 +341,9 @@ typedef int (*rb_create_t)(rb_handle*);
 typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
 typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
                           const float*, float*, int);
+// rocblas_gemm_ex: D = alpha op(A) op(B) + beta C with separate C and D (rocblas_datatype_f32_r = 151)
+typedef int (*rb_gemm_ex_t)(rb_handle, int, int, int, int, int, const void*, const void*, int, int, const void*, int, int,
+                            const void*, const void*, int, int, void*, int, int, int, int, int32_t, uint32_t);
 struct LtPlan {
     hipblasLtMatmulDesc_t desc;
     hipblasLtMatrixLayout_t la, lb, lc;
@@ -354,6 +358,7 @@ struct Vendor {
     rb_handle rb = nullptr;
     rb_set_stream_t rb_set_stream = nullptr;
     rb_sgemm_t rb_sgemm = nullptr;
+    rb_gemm_ex_t rb_gemm_ex = nullptr;
     // hipBLASLt
     bool lt_ok = false;
     hipblasLtHandle_t lt = nullptr;
@@ -402,6 +407,7 @@ void vendor_init_locked() {
             rb_create_t create = reinterpret_cast<rb_create_t>(dlsym(lib, "rocblas_create_handle"));
             v.rb_set_stream = reinterpret_cast<rb_set_stream_t>(dlsym(lib, "rocblas_set_stream"));
             v.rb_sgemm = reinterpret_cast<rb_sgemm_t>(dlsym(lib, "rocblas_sgemm"));
+            v.rb_gemm_ex = reinterpret_cast<rb_gemm_ex_t>(dlsym(lib, "rocblas_gemm_ex"));
             if (create && v.rb_set_stream && v.rb_sgemm && create(&v.rb) == 0) v.rb_ok = true;
         }
     }
@@ -446,11 +452,23 @@ bool lt_gemm_locked(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
            HIPBLAS_STATUS_SUCCESS;
 }
 
+// addend (optional): C = A.B^T + addend; in place (addend == C, same ld) through beta = 1, otherwise
+// through rocblas_gemm_ex's separate C / D operands.  rocBLAS only.
 bool vendor_sgemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-                  int64_t ldc, hipStream_t stream) {
+                  int64_t ldc, const float* addend, int64_t ld_add, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_vendor_mu);
     vendor_init_locked();
     Vendor& v = g_vendor;
+    if (addend) {
+        if (!v.rb_ok || v.mode == 2) return false;
+        const float one = 1.f;
+        if (v.rb_set_stream(v.rb, stream) != 0) return false;
+        if (addend == C && ld_add == ldc)
+            return v.rb_sgemm(v.rb, 112, 111, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &one, C, (int)ldc) == 0;
+        if (!v.rb_gemm_ex) return false;
+        return v.rb_gemm_ex(v.rb, 112, 111, (int)N, (int)M, (int)K, &one, B, 151, (int)ldb, A, 151, (int)lda, &one, addend, 151,
+                            (int)ld_add, C, 151, (int)ldc, 151, /*algo standard*/ 0, 0, 0) == 0;
+    }
     // measured on the config-3 projection (in situ): rocBLAS 0.955 ms, hipBLASLt (first heuristic, no
     // workspace) 0.977 ms -> rocBLAS first unless hipBLASLt is requested explicitly
     if (v.mode == 2 && v.lt_ok && lt_gemm_locked(M, N, K, A, lda, B, ldb, C, ldc, false, stream)) return true;
@@ -557,9 +575,9 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
                  "linear: epilogue leading dimension too small");
     GVQA_REQUIRE((!ep.addend && !ep.mul) || batch == 1, GVQA_E_INVALID, "linear: addend/mul epilogue is not batched");
     // 16-byte vector loads need 16-byte aligned rows
-    if (dtype_flags == 0 && !ep.bias && !ep.addend && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
+    if (dtype_flags == 0 && !ep.bias && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
         (2.0 * M * N * K >= 2e9 || vendor_mode() >= 2) && vendor_mode() != 1) {
-        if (vendor_sgemm(M, N, K, A, lda, B, ldb, C, ldc, stream)) return GVQA_OK;
+        if (vendor_sgemm(M, N, K, A, lda, B, ldb, C, ldc, ep.addend, ep.ld_add, stream)) return GVQA_OK;
     }
     const bool a16 = dtype_flags & 1;
     const bool vec = (K % 4 == 0) && (K >= 4) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&

@@ -83,9 +83,16 @@ __global__ __launch_bounds__(256) void k_lcgn_edge_logit(int N, int C, const voi
     }
 }
 
-__global__ __launch_bounds__(256) void k_f32_to_bf16(int64_t n, const float* __restrict__ in, uint16_t* __restrict__ out) {
+// out[r, c] = in[r, c] for a [rows, cols] fp32 block into a wider row (fp32 or bf16 storage)
+template <bool OUT16>
+__global__ __launch_bounds__(256) void k_place_rows(int64_t rows, int cols, const float* __restrict__ in, void* __restrict__ out,
+                                                    int64_t out_ld) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = f32_to_bf16(in[i]);
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    if (OUT16) static_cast<uint16_t*>(out)[r * out_ld + c] = f32_to_bf16(in[i]);
+    else static_cast<float*>(out)[r * out_ld + c] = in[i];
 }
 
 // bf16-node-feature mode: msg[i] = (sum_{e -> i} alpha_e * x_val[src(e)]) * cal_cmd[g(i)] + bias with
@@ -97,7 +104,8 @@ __global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16(int N, int C, const
                                                              int64_t cc_ld, const float* __restrict__ bias, float slope,
                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
                                                              const int32_t* __restrict__ csr_eid,
-                                                             const int32_t* __restrict__ node_graph, uint16_t* __restrict__ msg) {
+                                                             const int32_t* __restrict__ node_graph, uint16_t* __restrict__ msg,
+                                                             int64_t msg_ld) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;
@@ -116,21 +124,24 @@ __global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16(int N, int C, const
         }
         float r = acc * cal_cmd[(int64_t)g * cc_ld + c];
         if (bias) r += bias[c];
-        msg[(int64_t)i * C + c] = f32_to_bf16(r);
+        msg[(int64_t)i * msg_ld + c] = f32_to_bf16(r);
     }
 }
 
 struct LcgnLayout {
-    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, x_ctx0, x_ctx1, prod, XL, J, logit, msg, Wcat, Wpc, alpha, total;
+    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, Wx, Wj, Wpc, alpha, total;
 };
 static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_dims* d) {
     LcgnLayout L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
     const size_t O = d->out_channels;
     L.x_loc = take(N * O); L.proj_x_loc = take(N * O); L.q_emb = take(B * O); L.q_cmd = take(B * O);
-    L.cmd = take(B * O); L.pc = take(B * 2 * O); L.x_ctx0 = take(N * O); L.x_ctx1 = take(N * O);
-    L.prod = take(N * O); L.XL = take(N * 3 * O); L.J = take(N * 3 * O); L.logit = take(E); L.msg = take(N * O);
-    L.Wcat = take(3 * O * 3 * O); L.Wpc = take(2 * O * O); L.alpha = take(E);
+    L.cmd = take(B * O); L.pc = take(B * 2 * O);
+    // per-node iteration state, two copies (the output layer reads one and writes the other):
+    // row = [ prod | x_ctx | msg ], so that [prod | x_ctx] and [x_ctx | msg] are contiguous K = 2O operands
+    L.XC0 = take(N * 3 * O); L.XC1 = take(N * 3 * O);
+    L.XL = take(N * 3 * O); L.J = take(N * 3 * O); L.logit = take(E);
+    L.Wx = take(3 * O * O); L.Wj = take(3 * O * 2 * O); L.Wpc = take(2 * O * O); L.alpha = take(E);
     L.total = off;
     return L;
 }
@@ -177,11 +188,18 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     };
 
     StageTimer timer(GVQA_STAGE_OTHER, stream);
-    // stacked weights: Wcat = [lin_l; lin_r; cal_x] ([3O, 3O]),  Wpc = [proj_cmd; cal_cmd] ([2O, O])
-    const size_t wb = (size_t)O * 3 * O * sizeof(float);
-    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wcat), p->lin_l_weight, wb, hipMemcpyDeviceToDevice, stream));
-    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wcat) + (size_t)O * 3 * O, p->lin_r_weight, wb, hipMemcpyDeviceToDevice, stream));
-    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wcat) + (size_t)2 * O * 3 * O, p->cal_x_weight, wb, hipMemcpyDeviceToDevice, stream));
+    // stacked weights over the rows [lin_l; lin_r; cal_x] (each [O, 3O], input = [x_loc | x_ctx | prod]):
+    //   Wx = columns of x_loc ([3O, O]);  Wj = columns of [prod | x_ctx] in the order of the XC rows ([3O, 2O]);
+    //   Wpc = [proj_cmd; cal_cmd] ([2O, O])
+    const float* wsrc[3] = {p->lin_l_weight, p->lin_r_weight, p->cal_x_weight};
+    const size_t fo = (size_t)O * sizeof(float);
+    for (int m = 0; m < 3; ++m) {
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(P(L.Wx) + (size_t)m * O * O, fo, wsrc[m], 3 * fo, fo, O, hipMemcpyDeviceToDevice, stream));
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(P(L.Wj) + (size_t)m * O * 2 * O, 2 * fo, wsrc[m] + 2 * O, 3 * fo, fo, O,
+                                        hipMemcpyDeviceToDevice, stream));
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(P(L.Wj) + (size_t)m * O * 2 * O + O, 2 * fo, wsrc[m] + O, 3 * fo, fo, O,
+                                        hipMemcpyDeviceToDevice, stream));
+    }
     GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc), p->proj_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
     GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc) + (size_t)O * O, p->cal_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
 
@@ -196,17 +214,19 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     }
     {   // x_loc segment of lin_l / lin_r / cal_x                                                :144-145,230
         LinearEpilogue e{nullptr, nullptr, 0, nullptr, 0, 0};
-        LINT(N, 3 * O, O, P(L.x_loc), O, P(L.Wcat), 3 * O, e, P(L.XL), 3 * O, FA | FC);
+        LINT(N, 3 * O, O, P(L.x_loc), O, P(L.Wx), O, e, P(L.XL), 3 * O, FA | FC);
     }
-    const float* x_ctx = x_ctx_init;
-    if (nb) {
-        hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N * O, x_ctx_init,
-                           reinterpret_cast<uint16_t*>(P(L.x_ctx1)));
-        GVQA_LAUNCH_CHECK();
-        x_ctx = P(L.x_ctx1);
-    }
+    // x_ctx (:306) into the x_ctx columns of XC0
+    if (nb) hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, x_ctx_init,
+                               static_cast<void*>(NP(P(L.XC0), O)), (int64_t)3 * O);
+    else hipLaunchKernelGGL(k_place_rows<false>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, x_ctx_init,
+                            static_cast<void*>(P(L.XC0) + O), (int64_t)3 * O);
+    GVQA_LAUNCH_CHECK();
+    const int64_t ldx = 3 * O;
     for (int t = 0; t < T; ++t) {
-        float* x_ctx_next = (t & 1) ? P(L.x_ctx1) : P(L.x_ctx0);
+        float* XC = (t & 1) ? P(L.XC1) : P(L.XC0);
+        float* XCn = (t & 1) ? P(L.XC0) : P(L.XC1);
+        float *prod = XC, *x_ctx = NP(XC, O), *msg = NP(XC, 2 * O), *x_ctx_next = NP(XCn, O);
         // textual command (:292-300), per-graph, fp32
         LIN(B, O, O, P(L.q_emb), O, p->qinput2_weight[t], O, p->qinput2_bias[t], 0, P(L.q_cmd), O);
         hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B, O,
@@ -215,13 +235,10 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         LIN(B, 2 * O, O, P(L.cmd), O, P(L.Wpc), O, nullptr, 0, P(L.pc), 2 * O);                     // :148-149
         // prod = proj_x_ctx(x_ctx) * proj_x_loc                                                     // :312-313
         LinearEpilogue ep_mul{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0};
-        ep_mul.addend = nullptr; ep_mul.mul = P(L.proj_x_loc); ep_mul.ld_mul = O;
-        LINT(N, O, O, x_ctx, O, p->proj_x_ctx_weight, O, ep_mul, P(L.prod), O, FA | FC);
-        // J = x_joint . Wcat^T = XL + x_ctx . Wcat[:, O:2O]^T + prod . Wcat[:, 2O:3O]^T            // :144-145,230
+        LINT(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, ep_mul, prod, ldx, FA | FC);
+        // J = x_joint . [lin_l; lin_r; cal_x]^T = XL + [prod | x_ctx] . Wj^T   (one K = 2O product)  // :144-145,230
         LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
-        LINT(N, 3 * O, O, x_ctx, O, P(L.Wcat) + O, 3 * O, ep_add, P(L.J), 3 * O, FA | FC);
-        LinearEpilogue ep_acc{nullptr, P(L.J), 3 * O, nullptr, 0, 0};
-        LINT(N, 3 * O, O, P(L.prod), O, P(L.Wcat) + 2 * O, 3 * O, ep_acc, P(L.J), 3 * O, FA | FC);
+        LINT(N, 3 * O, 2 * O, prod, ldx, P(L.Wj), 2 * O, ep_add, P(L.J), 3 * O, FA | FC);
         // dot-product attention logits per edge                                                     // :154,207
         if (nb)
             hipLaunchKernelGGL(k_lcgn_edge_logit<true>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
@@ -237,7 +254,7 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             hipLaunchKernelGGL(k_lcgn_aggregate_bf16, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O,
                                reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), P(L.pc) + O,
                                (int64_t)2 * O, p->bias, d->negative_slope, g->rowptr, g->csr_src, g->csr_eid, g->node_graph,
-                               reinterpret_cast<uint16_t*>(P(L.msg)));
+                               reinterpret_cast<uint16_t*>(msg), ldx);
             GVQA_LAUNCH_CHECK();
         } else {
             gvqa_gat_mp_desc m;
@@ -246,22 +263,20 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             m.xp = P(L.J) + 2 * O; m.xp_ld = 3 * O;
             m.a_edge = P(L.logit); m.a_edge_stride = 1;
             m.graph_scale = P(L.pc) + O; m.graph_scale_ld = 2 * O;
-            m.bias = p->bias; m.out = P(L.msg);
+            m.bias = p->bias; m.out = msg; m.out_ld = ldx;
             rc = launch_gat_mp_public(g, &m, P(L.alpha), (size_t)E * sizeof(float), stream);
             if (rc) return rc;
         }
-        // x_ctx = output_layer([x_ctx || msg])                                                       // :316-319
-        LinearEpilogue ep_o1{p->output_bias, nullptr, 0, nullptr, 0, 0};
-        LINT(N, O, O, x_ctx, O, p->output_weight, 2 * O, ep_o1, x_ctx_next, O, FA | FC);
-        LinearEpilogue ep_acc2{nullptr, x_ctx_next, O, nullptr, 0, 0};
-        LINT(N, O, O, P(L.msg), O, p->output_weight + O, 2 * O, ep_acc2, x_ctx_next, O, FA | FC);
-        x_ctx = x_ctx_next;
+        // x_ctx = output_layer([x_ctx || msg])   (one K = 2O product)                                 // :316-319
+        LinearEpilogue ep_o{p->output_bias, nullptr, 0, nullptr, 0, 0};
+        LINT(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, ep_o, x_ctx_next, ldx, FA | FC);
     }
+    float* x_ctx_fin = NP((T & 1) ? P(L.XC1) : P(L.XC0), O);
     // out = fin_layer([x_loc || x_ctx]) (fp32 result)                                                // :321-322
     LinearEpilogue ep_f1{p->fin_bias, nullptr, 0, nullptr, 0, 0};
     LINT(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, ep_f1, out, O, FA);
     LinearEpilogue ep_fin{nullptr, out, O, nullptr, 0, 0};
-    LINT(N, O, O, x_ctx, O, p->fin_weight + O, 2 * O, ep_fin, out, O, FA);
+    LINT(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, ep_fin, out, O, FA);
 #undef LIN
 #undef LINT
     return GVQA_OK;

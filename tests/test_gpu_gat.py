@@ -607,14 +607,12 @@ def _lcgn_bf16_storage_emulation(x, edge_index, batch, q, lstm, p, x_ctx_init, T
         cmd = R.lcgn_extract_command(q_emb, lstm, t_, p)
         pc = torch.cat([F.linear(cmd, p["lcgn.proj_cmd.weight"]), F.linear(cmd, p["lcgn.cal_cmd.weight"])], 1)
         prod = rb(F.linear(x_ctx, p["proj_x_ctx.1.weight"], p["proj_x_ctx.1.bias"]) * proj_x_loc)
-        J = rb(x_ctx @ Wcat[:, O:2 * O].T + XL)
-        J = rb(prod @ Wcat[:, 2 * O:].T + J)
+        J = rb(x_ctx @ Wcat[:, O:2 * O].T + prod @ Wcat[:, 2 * O:].T + XL)
         x_l, x_r, x_val = J[:, :O], J[:, O:2 * O], J[:, 2 * O:]
         logit = (x_l[src] * (pc[batch[dst], :O] * x_r[dst])).sum(-1, keepdim=True)
         alpha = R.segment_softmax(F.leaky_relu(logit, slope), dst, N)
         msg = rb(R.scatter_add_rows(alpha * x_val[src], dst, N) * pc[batch, O:] + p["lcgn.bias"])
-        xa = rb(F.linear(x_ctx, p["output_layer.weight"][:, :O], p["output_layer.bias"]))
-        x_ctx = rb(msg @ p["output_layer.weight"][:, O:].T + xa)
+        x_ctx = rb(F.linear(torch.cat([x_ctx, msg], 1), p["output_layer.weight"], p["output_layer.bias"]))
     out = F.linear(x_loc, p["fin_layer.weight"][:, :O], p["fin_layer.bias"])
     return x_ctx @ p["fin_layer.weight"][:, O:].T + out
 

@@ -64,7 +64,7 @@ def test_module_state_dict_contract():
     # reference init rule: glorot bound, zero bias
     a = np.sqrt(6.0 / (1200 + 812))
     w = sd["convs.3.lin_l.weight"]
-    assert float(w.abs().max()) <= a and float(w.abs().max()) > 0.99 * a
+    assert float(w.abs().max()) <= a * (1 + 1e-6) and float(w.abs().max()) > 0.99 * a   # fp32 rounding of the bound
     assert float(sd["convs.0.bias"].abs().max()) == 0.0
 
 
