@@ -141,6 +141,10 @@ PROTOTYPES = {
                                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_linear_f32": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_pack_weight_bf16": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gvqa_linear_bf16": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                   C.c_void_p]),
     "gvqa_linear_f32_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

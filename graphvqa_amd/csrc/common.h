@@ -94,6 +94,11 @@ int launch_linear_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
 int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                     int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
                     int64_t strideB, int64_t strideC, int dtype_flags, hipStream_t stream);
+// bf16 matrix-core projection of a bf16 node tensor against weights packed into P bf16 pieces (gemm_bf16.hip)
+int launch_pack_weight_bf16(int64_t rows, int K, int P, const float* W, int64_t ldw, void* out, hipStream_t stream);
+bool linear_bf16_supported(int64_t K, int64_t lda, const void* A, const void* Wpk);
+int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, int64_t lda, const void* Wpk, LinearEpilogue ep,
+                       void* C, int64_t ldc, bool c16, hipStream_t stream);
 const char* gemm_backend_name();
 int launch_split_bf16x3(int64_t rows, int K, const float* x, int64_t ld, int which, void* out, hipStream_t stream);
 bool vendor_bf16_gemm(int64_t M, int64_t N, int64_t K6, const void* A, const void* B, float* C, int64_t ldc, hipStream_t stream);

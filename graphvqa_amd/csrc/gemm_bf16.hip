@@ -1,0 +1,212 @@
+// Dense projections of bf16 node tensors on the CDNA4 bf16 matrix cores (LCGN bf16-node-feature mode,
+// BASELINE config 5):   C[M,N] = sum_{p < P} A[M,K] . W_p[N,K]^T  (+bias) (+addend) (*mul) (act)
+//
+// A is a node tensor stored as bf16.  The fp32 weights are packed once per forward into P bf16
+// pieces side by side, Wpk[N, P*K]:  P = 2 keeps W = W_hi + W_lo to 16 significant bits (the product
+// with a bf16 operand is then as accurate as the bf16 storage of the node tensors allows -- the
+// products a*w_hi and a*w_lo are exact in fp32 and the accumulation is fp32), P = 1 is the plain
+// "bf16 weights" arithmetic.  `v_mfma_f32_32x32x16_bf16` runs at 16x the f32-input MFMA rate, so even
+// the two-piece product is 8x cheaper in matrix-core time than the fp32 MFMA it replaces.
+//
+// Tiling (64-wide wavefronts): block = 4 waves (2 x 2), block tile 128 x 128, K step 64 (128 bytes
+// per row), both operands K-contiguous, staged global -> registers -> LDS with 16-byte accesses,
+// register double-buffered (next tile's loads fly under this tile's MFMAs, one barrier per K step).
+// LDS rows are padded to 144 bytes = 36 dwords: the same bank geometry as the fp32 kernel, a wave's
+// ds_read_b128 fragment read (32 rows x 2 k-halves) is conflict-free.  Fragment: lane (r = lane & 31,
+// h = lane >> 5) feeds the 8 consecutive k's [16 kg + 8 h, +8) of row r to one MFMA from ONE b128 read.
+#include <type_traits>
+
+#include "common.h"
+
+namespace gvqa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WR, int WC, bool C16>
+__global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int K, int P, const uint16_t* __restrict__ A,
+                                                              int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
+                                                              LinearEpilogue ep, void* C_, int64_t ldc) {
+    constexpr int BK = 64;                        // bf16 per K step
+    constexpr int LDS_LD = BK + 8;                // 144-byte rows
+    constexpr int RQ = BK / 8;                    // 16-byte chunks per tile row
+    constexpr int NTH = 64 * WR * WC;
+    constexpr int WM = BM / WR, WN = BN / WC;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_V = BM * RQ / NTH, B_V = BN * RQ / NTH;
+    static_assert(BM * RQ % NTH == 0 && BN * RQ % NTH == 0, "tiles must divide evenly");
+    typedef typename std::conditional<C16, uint16_t, float>::type TC;
+    TC* C = static_cast<TC*>(C_);
+
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * LDS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // branch-free clamped loads (rows past the edge re-read a valid row and are never stored; the K
+    // tail is zeroed when the registers are written to LDS), row pointers formed once
+    const uint16_t* pa[A_V];
+    const uint16_t* pb[B_V];
+    const int c8 = (tid % RQ) * 8;                // k offset of this thread's chunk (same for all its rows: NTH % RQ == 0)
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) pa[i] = A + (int64_t)min(m0 + (tid + i * NTH) / RQ, M - 1) * lda + c8;
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) pb[i] = B + (int64_t)min(n0 + (tid + i * NTH) / RQ, N - 1) * ldb + c8;
+
+    uint4 ra[A_V], rb[B_V];
+    const int nk = (K + BK - 1) / BK, nt = nk * P;
+    auto load_tile = [&](int kk, int p) {
+        int k = kk * BK;
+        if (k + c8 + 8 > K) k = K - 8 - c8;       // K % 8 == 0: the last whole chunk (masked at the LDS store)
+#pragma unroll
+        for (int i = 0; i < A_V; ++i) ra[i] = *reinterpret_cast<const uint4*>(pa[i] + k);
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) rb[i] = *reinterpret_cast<const uint4*>(pb[i] + (int64_t)p * K + k);
+    };
+    auto store_tile = [&](int buf, int kk) {
+        const unsigned keep = kk * BK + c8 >= K ? 0u : ~0u;   // chunk entirely past K (only in the last K tile): zeros
+#pragma unroll
+        for (int i = 0; i < A_V; ++i)
+            *reinterpret_cast<uint4*>(&As[buf][((tid + i * NTH) / RQ) * LDS_LD + c8]) =
+                make_uint4(ra[i].x & keep, ra[i].y & keep, ra[i].z & keep, ra[i].w & keep);
+#pragma unroll
+        for (int i = 0; i < B_V; ++i)
+            *reinterpret_cast<uint4*>(&Bs[buf][((tid + i * NTH) / RQ) * LDS_LD + c8]) =
+                make_uint4(rb[i].x & keep, rb[i].y & keep, rb[i].z & keep, rb[i].w & keep);
+    };
+
+    load_tile(0, 0);
+    store_tile(0, 0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    int kk = 0, p = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        int kk_n = kk + 1, p_n = p;
+        if (kk_n == nk) { kk_n = 0; ++p_n; }
+        if (t + 1 < nt) load_tile(kk_n, p_n);
+        const uint16_t* as = &As[cur][(wr * WM + frow) * LDS_LD + fk];
+        const uint16_t* bs = &Bs[cur][(wc * WN + frow) * LDS_LD + fk];
+#pragma unroll
+        for (int kg = 0; kg < BK / 16; ++kg) {
+            bf16x8 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(as + i * 32 * LDS_LD + kg * 16));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bs + j * 32 * LDS_LD + kg * 16));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tile(cur ^ 1, kk_n);
+        __syncthreads();
+        kk = kk_n; p = p_n;
+    }
+
+    // Epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gc = n0 + wc * WN + j * 32 + ccol;
+        if (gc >= N) continue;
+        const float bv = ep.bias ? ep.bias[gc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int gr0 = m0 + wr * WM + i * 32 + crow0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = gr0 + (r & 3) + 8 * (r >> 2);
+                if (gr < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (ep.addend) v += load_elem<C16>(ep.addend, (int64_t)gr * ep.ld_add + gc);
+                    if (ep.mul) v *= load_elem<C16>(ep.mul, (int64_t)gr * ep.ld_mul + gc);
+                    if (ep.relu == 1) v = fmaxf(v, 0.f);
+                    else if (ep.relu == 2) v = v > 0.f ? v : expf(v) - 1.f;
+                    if constexpr (C16) C[(int64_t)gr * ldc + gc] = f32_to_bf16(v);
+                    else C[(int64_t)gr * ldc + gc] = v;
+                }
+            }
+        }
+    }
+}
+
+// Wpk[n, p*K + k] = p-th bf16 piece of W[n, k]  (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the remainder)
+__global__ __launch_bounds__(256) void k_pack_weight_bf16(int64_t rows, int K, int P, const float* __restrict__ W, int64_t ldw,
+                                                          uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * K) return;
+    const int64_t r = i / K;
+    const int k = (int)(i - r * K);
+    const float w = W[r * ldw + k];
+    const uint16_t hi = f32_to_bf16(w);
+    uint16_t* o = out + r * (int64_t)P * K + k;
+    o[0] = hi;
+    if (P > 1) o[K] = f32_to_bf16(w - bf16_to_f32(hi));
+}
+
+int launch_pack_weight_bf16(int64_t rows, int K, int P, const float* W, int64_t ldw, void* out, hipStream_t stream) {
+    GVQA_REQUIRE(P == 1 || P == 2, GVQA_E_INVALID, "pack_weight_bf16: pieces must be 1 or 2");
+    if (rows == 0 || K == 0) return GVQA_OK;
+    hipLaunchKernelGGL(k_pack_weight_bf16, dim3((unsigned)cdiv(rows * K, 256)), dim3(256), 0, stream, rows, K, P, W, ldw,
+                       static_cast<uint16_t*>(out));
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+bool linear_bf16_supported(int64_t K, int64_t lda, const void* A, const void* Wpk) {
+    return K >= 8 && K % 8 == 0 && lda % 8 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(Wpk) & 15) == 0;
+}
+
+// A: bf16 [M, lda]; Wpk: packed bf16 [N, P*K]; C and the addend / mul operands are bf16 when c16, fp32 otherwise.
+int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, int64_t lda, const void* Wpk, LinearEpilogue ep,
+                       void* C, int64_t ldc, bool c16, hipStream_t stream) {
+    GVQA_REQUIRE(M >= 0 && N >= 0 && K > 0 && (P == 1 || P == 2), GVQA_E_INVALID, "linear_bf16: bad size");
+    GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 30), GVQA_E_INVALID, "linear_bf16: size overflow");
+    if (M == 0 || N == 0) return GVQA_OK;
+    GVQA_REQUIRE(A && Wpk && C, GVQA_E_INVALID, "linear_bf16: null operand");
+    GVQA_REQUIRE(linear_bf16_supported(K, lda, A, Wpk), GVQA_E_INVALID, "linear_bf16: K / lda must be multiples of 8, operands 16-byte aligned");
+    GVQA_REQUIRE(lda >= K && ldc >= N && cdiv(M, 128) <= 65535, GVQA_E_INVALID, "linear_bf16: bad leading dimension / M too large");
+    dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128));
+    const uint16_t* a = static_cast<const uint16_t*>(A);
+    const uint16_t* b = static_cast<const uint16_t*>(Wpk);
+    if (c16) hipLaunchKernelGGL((k_linear_bf16<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda,
+                                b, (int64_t)P * K, ep, C, ldc);
+    else hipLaunchKernelGGL((k_linear_bf16<128, 128, 2, 2, false>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda,
+                            b, (int64_t)P * K, ep, C, ldc);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+}  // namespace gvqa
+
+extern "C" int gvqa_pack_weight_bf16(int64_t rows, int64_t K, int pieces, const float* W, int64_t ldw, void* Wpk, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ldw >= K, GVQA_E_INVALID, "pack_weight_bf16: bad size");
+    GVQA_REQUIRE((W && Wpk) || rows * K == 0, GVQA_E_INVALID, "pack_weight_bf16: null operand");
+    return launch_pack_weight_bf16(rows, (int)K, pieces, W, ldw, Wpk, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A, int64_t lda, const void* Wpk,
+                                const float* bias, const void* addend, int64_t ld_add, const void* mul, int64_t ld_mul, int relu,
+                                void* C, int64_t ldc, int c_bf16, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE((!addend || ld_add >= N) && (!mul || ld_mul >= N), GVQA_E_INVALID, "linear_bf16: epilogue leading dimension too small");
+    LinearEpilogue ep{bias, static_cast<const float*>(addend), ld_add, static_cast<const float*>(mul), ld_mul, relu};
+    return launch_linear_bf16(M, N, K, pieces, A, lda, Wpk, ep, C, ldc, c_bf16 != 0, static_cast<hipStream_t>(stream));
+}

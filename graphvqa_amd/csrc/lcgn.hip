@@ -21,13 +21,17 @@ namespace gvqa {
 
 int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream);
 
-// cmd[b, :] = sum_l softmax_l( (q_cmd[b] * lstm[l, b]) . w + bias ) * lstm[l, b, :]     (lcgn.py:292-300)
-// One block per graph b; dynamic LDS: L floats.
+// cmd[t, b, :] = sum_l softmax_l( (q_cmd[b, t] * lstm[l, b]) . w + bias ) * lstm[l, b, :]     (lcgn.py:292-300)
+// for every iteration t at once (the commands do not depend on the node state).  q_cmd is [B, T*O]
+// (iteration t at columns [t*O, (t+1)*O)), cmd is [T*B, O].  One block per (graph b, iteration t);
+// dynamic LDS: L floats.
 __global__ __launch_bounds__(256) void k_lcgn_command(int L, int B, int O, const float* __restrict__ q_cmd,
                                                       const float* __restrict__ lstm, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ cmd) {
     extern __shared__ float att[];
-    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x, t = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    q_cmd += ((int64_t)b * gridDim.y + t) * O - (int64_t)b * O;
+    cmd += (int64_t)t * B * O;
     for (int l = wave; l < L; l += 4) {
         const float* row = lstm + ((int64_t)l * B + b) * O;
         float s = 0.f;
@@ -129,19 +133,22 @@ __global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16(int N, int C, const
 }
 
 struct LcgnLayout {
-    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, Wx, Wj, Wpc, alpha, total;
+    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, Wx, Wj, Wpc, Wq, bq, Wpk, alpha, total;
 };
 static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_dims* d) {
     LcgnLayout L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
     const size_t O = d->out_channels;
-    L.x_loc = take(N * O); L.proj_x_loc = take(N * O); L.q_emb = take(B * O); L.q_cmd = take(B * O);
-    L.cmd = take(B * O); L.pc = take(B * 2 * O);
+    const size_t T = d->num_iters;
+    L.x_loc = take(N * O); L.proj_x_loc = take(N * O); L.q_emb = take(B * O); L.q_cmd = take(B * T * O);
+    L.cmd = take(T * B * O); L.pc = take(T * B * 2 * O);
     // per-node iteration state, two copies (the output layer reads one and writes the other):
     // row = [ prod | x_ctx | msg ], so that [prod | x_ctx] and [x_ctx | msg] are contiguous K = 2O operands
     L.XC0 = take(N * 3 * O); L.XC1 = take(N * 3 * O);
     L.XL = take(N * 3 * O); L.J = take(N * 3 * O); L.logit = take(E);
-    L.Wx = take(3 * O * O); L.Wj = take(3 * O * 2 * O); L.Wpc = take(2 * O * O); L.alpha = take(E);
+    L.Wx = take(3 * O * O); L.Wj = take(3 * O * 2 * O); L.Wpc = take(2 * O * O); L.Wq = take(T * O * O); L.bq = take(T * O);
+    L.Wpk = take(d->node_bf16 ? 15 * O * O : 0);     // node-GEMM weights as bf16 pieces: 15 O^2 elements x <= 2 pieces x 2 bytes
+    L.alpha = take(E);
     L.total = off;
     return L;
 }
@@ -152,7 +159,7 @@ extern "C" {
 using namespace gvqa;
 
 size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* d) {
-    if (!g || !d) return 0;
+    if (!g || !d || d->num_iters < 1 || d->num_iters > 8 || d->out_channels < 1) return 0;
     return lcgn_layout(g->num_nodes, g->num_edges, g->num_graphs, d).total;
 }
 
@@ -175,9 +182,28 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     int rc;
     // node tensors (x_loc, proj_x_loc, x_ctx, prod, XL, J, msg) are fp32, or bf16 in the bf16-node-feature
-    // mode (BASELINE config 5): same buffers, half the bytes, fp32 arithmetic everywhere.
+    // mode (BASELINE config 5): same buffers, half the bytes.  In that mode the node GEMMs run on the bf16
+    // matrix cores against the weights split into two bf16 pieces (node_bf16 = 1: weights keep 16
+    // significant bits) or rounded to one (node_bf16 = 2), fp32 accumulation (gemm_bf16.hip); everything
+    // else (logits, softmax, aggregation, per-graph command path) is fp32 arithmetic.  Channel counts that
+    // are not multiples of 8 fall back to the f32-MFMA kernel reading the bf16 storage.
     const bool nb = d->node_bf16 != 0;
+    GVQA_REQUIRE(d->node_bf16 >= 0 && d->node_bf16 <= 2, GVQA_E_INVALID, "lcgn_seq: node_bf16 must be 0, 1 or 2");
     const int FA = nb ? 1 : 0, FC = nb ? 2 : 0;      // dtype flags: A is a node tensor / C is a node tensor
+    const int PW = d->node_bf16 == 2 ? 1 : 2;        // bf16 pieces per weight
+    const bool mf16 = nb && O % 8 == 0;
+    uint16_t* const pk = reinterpret_cast<uint16_t*>(base + L.Wpk);
+    const size_t OO = (size_t)O * O * PW;            // packed elements of one [O, O] weight
+    uint16_t *pk_pxl = pk, *pk_Wx = pk + OO, *pk_Wj = pk + 4 * OO, *pk_pxc = pk + 10 * OO, *pk_out = pk + 11 * OO,
+             *pk_f1 = pk + 13 * OO, *pk_f2 = pk + 14 * OO;
+    // node GEMM: A is a node tensor (bf16 in nb mode); c_node: C (and addend / mul) are node tensors too
+    auto NODE = [&](int64_t M_, int64_t N_, int64_t K_, const float* A_, int64_t lda_, const float* W_, int64_t ldw_,
+                    const uint16_t* Wpk_, LinearEpilogue ep_, float* C_, int64_t ldc_, bool c_node) -> int {
+        if (mf16 && linear_bf16_supported(K_, lda_, A_, Wpk_))
+            return launch_linear_bf16(M_, N_, K_, PW, A_, lda_, Wpk_, ep_, C_, ldc_, c_node, stream);
+        return launch_linear_t(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, FA | (c_node ? FC : 0), stream);
+    };
+#define NODE_LIN(...) do { rc = NODE(__VA_ARGS__); if (rc) return rc; } while (0)
 #define LINT(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, fl_)                                                     \
     do { rc = launch_linear_t(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, fl_, stream); if (rc) return rc; } while (0)
 #define LIN(M_, N_, K_, A_, lda_, W_, ldw_, bias_, relu_, C_, ldc_)                                                  \
@@ -202,19 +228,38 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     }
     GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc), p->proj_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
     GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc) + (size_t)O * O, p->cal_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+    for (int t = 0; t < T; ++t) {       // Wq = [qInput2[0]; ...; qInput2[T-1]] ([T*O, O]), bq likewise
+        GVQA_REQUIRE(p->qinput2_weight[t] && p->qinput2_bias[t], GVQA_E_INVALID, "lcgn_seq: qinput2[%d] is null", t);
+        GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wq) + (size_t)t * O * O, p->qinput2_weight[t], (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+        GVQA_HIP_CHECK(hipMemcpyAsync(P(L.bq) + (size_t)t * O, p->qinput2_bias[t], fo, hipMemcpyDeviceToDevice, stream));
+    }
 
+    if (mf16) {
+        struct { const float* w; int64_t ldw; int rows, K; uint16_t* out; } pw[7] = {
+            {p->proj_x_loc_weight, O, O, O, pk_pxl}, {P(L.Wx), O, 3 * O, O, pk_Wx}, {P(L.Wj), 2 * O, 3 * O, 2 * O, pk_Wj},
+            {p->proj_x_ctx_weight, O, O, O, pk_pxc}, {p->output_weight, 2 * O, O, 2 * O, pk_out},
+            {p->fin_weight, 2 * O, O, O, pk_f1}, {p->fin_weight + O, 2 * O, O, O, pk_f2}};
+        for (auto& e : pw) { rc = launch_pack_weight_bf16(e.rows, e.K, PW, e.w, e.ldw, e.out, stream); if (rc) return rc; }
+    }
     {   // x_loc = init(x)                                                                       lcgn.py:305
         LinearEpilogue e{p->init_bias, nullptr, 0, nullptr, 0, 0};
         LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);
     }
     LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
+    // textual commands (:292-300) and their projections (:148-149) for all T iterations: per-graph, fp32,
+    // independent of the node state -> three launches instead of 3T
+    LIN(B, T * O, O, P(L.q_emb), O, P(L.Wq), O, P(L.bq), 0, P(L.q_cmd), (int64_t)T * O);
+    hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B, (unsigned)T), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B,
+                       O, P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
+    GVQA_LAUNCH_CHECK();
+    LIN((int64_t)T * B, 2 * O, O, P(L.cmd), O, P(L.Wpc), O, nullptr, 0, P(L.pc), 2 * O);
     {   // proj_x_loc                                                                            :308
         LinearEpilogue e{p->proj_x_loc_bias, nullptr, 0, nullptr, 0, 0};
-        LINT(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, e, P(L.proj_x_loc), O, FA | FC);
+        NODE_LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, pk_pxl, e, P(L.proj_x_loc), O, true);
     }
     {   // x_loc segment of lin_l / lin_r / cal_x                                                :144-145,230
         LinearEpilogue e{nullptr, nullptr, 0, nullptr, 0, 0};
-        LINT(N, 3 * O, O, P(L.x_loc), O, P(L.Wx), O, e, P(L.XL), 3 * O, FA | FC);
+        NODE_LIN(N, 3 * O, O, P(L.x_loc), O, P(L.Wx), O, pk_Wx, e, P(L.XL), 3 * O, true);
     }
     // x_ctx (:306) into the x_ctx columns of XC0
     if (nb) hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, x_ctx_init,
@@ -227,32 +272,27 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         float* XC = (t & 1) ? P(L.XC1) : P(L.XC0);
         float* XCn = (t & 1) ? P(L.XC0) : P(L.XC1);
         float *prod = XC, *x_ctx = NP(XC, O), *msg = NP(XC, 2 * O), *x_ctx_next = NP(XCn, O);
-        // textual command (:292-300), per-graph, fp32
-        LIN(B, O, O, P(L.q_emb), O, p->qinput2_weight[t], O, p->qinput2_bias[t], 0, P(L.q_cmd), O);
-        hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B, O,
-                           P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
-        GVQA_LAUNCH_CHECK();
-        LIN(B, 2 * O, O, P(L.cmd), O, P(L.Wpc), O, nullptr, 0, P(L.pc), 2 * O);                     // :148-149
+        const float* pc = P(L.pc) + (size_t)t * B * 2 * O;      // [proj_cmd(cmd_t) | cal_cmd(cmd_t)] per graph
         // prod = proj_x_ctx(x_ctx) * proj_x_loc                                                     // :312-313
         LinearEpilogue ep_mul{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0};
-        LINT(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, ep_mul, prod, ldx, FA | FC);
+        NODE_LIN(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, pk_pxc, ep_mul, prod, ldx, true);
         // J = x_joint . [lin_l; lin_r; cal_x]^T = XL + [prod | x_ctx] . Wj^T   (one K = 2O product)  // :144-145,230
         LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
-        LINT(N, 3 * O, 2 * O, prod, ldx, P(L.Wj), 2 * O, ep_add, P(L.J), 3 * O, FA | FC);
+        NODE_LIN(N, 3 * O, 2 * O, prod, ldx, P(L.Wj), 2 * O, pk_Wj, ep_add, P(L.J), 3 * O, true);
         // dot-product attention logits per edge                                                     // :154,207
         if (nb)
             hipLaunchKernelGGL(k_lcgn_edge_logit<true>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
-                               (int64_t)3 * O, NP(P(L.J), O), (int64_t)3 * O, P(L.pc), (int64_t)2 * O, g->rowptr, g->csr_src,
+                               (int64_t)3 * O, NP(P(L.J), O), (int64_t)3 * O, pc, (int64_t)2 * O, g->rowptr, g->csr_src,
                                g->csr_eid, g->node_graph, P(L.logit));
         else
             hipLaunchKernelGGL(k_lcgn_edge_logit<false>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
-                               (int64_t)3 * O, P(L.J) + O, (int64_t)3 * O, P(L.pc), (int64_t)2 * O, g->rowptr, g->csr_src,
+                               (int64_t)3 * O, P(L.J) + O, (int64_t)3 * O, pc, (int64_t)2 * O, g->rowptr, g->csr_src,
                                g->csr_eid, g->node_graph, P(L.logit));
         GVQA_LAUNCH_CHECK();
         // leaky-relu, softmax over in-edges, alpha-weighted sum of cal_x(x_joint)[src], x cal_cmd[g], + bias  // :209-238,166-168
         if (nb) {
             hipLaunchKernelGGL(k_lcgn_aggregate_bf16, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O,
-                               reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), P(L.pc) + O,
+                               reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), pc + O,
                                (int64_t)2 * O, p->bias, d->negative_slope, g->rowptr, g->csr_src, g->csr_eid, g->node_graph,
                                reinterpret_cast<uint16_t*>(msg), ldx);
             GVQA_LAUNCH_CHECK();
@@ -262,22 +302,23 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             m.C = O; m.H = 1; m.negative_slope = d->negative_slope; m.bn_eps = 1e-5f;
             m.xp = P(L.J) + 2 * O; m.xp_ld = 3 * O;
             m.a_edge = P(L.logit); m.a_edge_stride = 1;
-            m.graph_scale = P(L.pc) + O; m.graph_scale_ld = 2 * O;
+            m.graph_scale = pc + O; m.graph_scale_ld = 2 * O;
             m.bias = p->bias; m.out = msg; m.out_ld = ldx;
             rc = launch_gat_mp_public(g, &m, P(L.alpha), (size_t)E * sizeof(float), stream);
             if (rc) return rc;
         }
         // x_ctx = output_layer([x_ctx || msg])   (one K = 2O product)                                 // :316-319
         LinearEpilogue ep_o{p->output_bias, nullptr, 0, nullptr, 0, 0};
-        LINT(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, ep_o, x_ctx_next, ldx, FA | FC);
+        NODE_LIN(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, pk_out, ep_o, x_ctx_next, ldx, true);
     }
     float* x_ctx_fin = NP((T & 1) ? P(L.XC1) : P(L.XC0), O);
     // out = fin_layer([x_loc || x_ctx]) (fp32 result)                                                // :321-322
     LinearEpilogue ep_f1{p->fin_bias, nullptr, 0, nullptr, 0, 0};
-    LINT(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, ep_f1, out, O, FA);
+    NODE_LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, pk_f1, ep_f1, out, O, false);
     LinearEpilogue ep_fin{nullptr, out, O, nullptr, 0, 0};
-    LINT(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, ep_fin, out, O, FA);
+    NODE_LIN(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, pk_f2, ep_fin, out, O, false);
 #undef LIN
+#undef NODE_LIN
 #undef LINT
     return GVQA_OK;
 }

@@ -55,13 +55,18 @@ class gat_lcgn(nn.Module):
 class lcgn_seq(nn.Module):
     def __init__(self, in_channels, out_channels, edge_attr_dim, num_ins, gat_cmd_dim=512, question_dim=512,
                  MAX_ITER_NUM=4, dropout=0.0, gat_heads=1, gat_negative_slope=0.2, gat_bias=True,
-                 node_feature_dtype: torch.dtype = torch.float32):
+                 node_feature_dtype: torch.dtype = torch.float32, bf16_weight_pieces: int = 2):
         super().__init__()
         _lib.load()
         if node_feature_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("node_feature_dtype must be torch.float32 or torch.bfloat16")
-        # build-side choice (BASELINE config 5): per-node tensors stored as bf16 in HBM, fp32 arithmetic
+        # build-side choice (BASELINE config 5): per-node tensors stored as bf16 in HBM, node GEMMs on the
+        # bf16 matrix cores (fp32 accumulation) against the fp32 weights split into `bf16_weight_pieces`
+        # bf16 pieces (2: the weights keep 16 significant bits; 1: weights rounded to bf16)
+        if bf16_weight_pieces not in (1, 2):
+            raise ValueError("bf16_weight_pieces must be 1 or 2")
         self.node_feature_dtype = node_feature_dtype
+        self.bf16_weight_pieces = bf16_weight_pieces
         self.init_sg_emb_input = nn.Sequential(Linear(in_channels, out_channels), nn.Dropout(dropout))
         self.MAX_ITER_NUM = MAX_ITER_NUM
         self.qInput1 = Linear(question_dim, out_channels)
@@ -100,7 +105,8 @@ class lcgn_seq(nn.Module):
         if graph is None:
             graph = SceneGraphBatch(edge_index, batch, N, B)
         d = _lib.LcgnDims(self.in_channels, O, self.question_dim, self.MAX_ITER_NUM, L, self.gat_heads,
-                          self.negative_slope, 1 if self.node_feature_dtype == torch.bfloat16 else 0)
+                          self.negative_slope,
+                          (3 - self.bf16_weight_pieces) if self.node_feature_dtype == torch.bfloat16 else 0)
         p = _lib.LcgnParams()
         keep = []
 

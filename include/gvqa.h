@@ -165,6 +165,16 @@ int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t 
                        const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_add,
                        const float* mul, int64_t ld_mul, int relu, float* C, int64_t ldc, void* stream);
 
+/* bf16 matrix-core projection of a bf16 tensor (the LCGN bf16-node-feature mode's GEMM, exported for tests):
+ * gvqa_pack_weight_bf16 writes Wpk[rows, pieces*K] (bf16): piece 0 = bf16(W), piece 1 = bf16(W - piece 0);
+ * gvqa_linear_bf16 computes C[M,N] = sum_p A[M,K] . Wpk_p[N,K]^T with fp32 accumulation and the epilogue of
+ * gvqa_linear_f32_ex.  A is bf16 [M, lda]; C, addend and mul are bf16 when c_bf16 != 0, fp32 otherwise; bias
+ * is fp32.  K and lda must be multiples of 8, A and Wpk 16-byte aligned. */
+int gvqa_pack_weight_bf16(int64_t rows, int64_t K, int pieces, const float* W, int64_t ldw, void* Wpk, void* stream);
+int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A, int64_t lda, const void* Wpk,
+                     const float* bias, const void* addend, int64_t ld_add, const void* mul, int64_t ld_mul, int relu,
+                     void* C, int64_t ldc, int c_bf16, void* stream);
+
 /* Which GEMM backend serves the plain dense projections in this process (hand-written k_linear_f32,
  * or rocBLAS for large epilogue-free products; GVQA_GEMM_BACKEND=auto|hip|rocblas). */
 const char* gvqa_gemm_backend(void);
@@ -272,8 +282,11 @@ typedef struct gvqa_lcgn_dims {
     int32_t seq_len;        /* L: number of lstm_outputs steps                                    */
     int32_t heads;          /* gat_heads (1)                                                      */
     float negative_slope;
-    int32_t node_bf16;      /* 1: per-node tensors (x_loc, x_ctx, their projections, messages) are STORED
-                               as bf16 in HBM, arithmetic stays fp32 (BASELINE config 5); 0: fp32           */
+    int32_t node_bf16;      /* 0: fp32.  1 / 2: per-node tensors (x_loc, x_ctx, their projections, messages) are
+                               STORED as bf16 in HBM (BASELINE config 5) and the node GEMMs run on the bf16
+                               matrix cores with fp32 accumulation, against the fp32 weights split into two
+                               bf16 pieces (1: weights keep 16 significant bits) or rounded to one (2);
+                               logits, softmax, aggregation and the per-graph command path stay fp32        */
 } gvqa_lcgn_dims;
 
 typedef struct gvqa_lcgn_params {   /* lcgn_seq state_dict (lcgn.py:255-282), device pointers */
