@@ -26,7 +26,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int BM, int BN, int WR, int WC, bool C16>
 __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int K, int P, const uint16_t* __restrict__ A,
                                                               int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
-                                                              LinearEpilogue ep, void* C_, int64_t ldc) {
+                                                              LinearEpilogue ep, void* C_, int64_t ldc, int vec_ep) {
     constexpr int BK = 64;                        // bf16 per K step
     constexpr int LDS_LD = BK + 8;                // 144-byte rows
     constexpr int RQ = BK / 8;                    // 16-byte chunks per tile row
@@ -38,8 +38,11 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int 
     typedef typename std::conditional<C16, uint16_t, float>::type TC;
     TC* C = static_cast<TC*>(C_);
 
-    __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * LDS_LD];
+    constexpr int ST_LD = BN + 4;                 // fp32 row stride of the epilogue staging tile
+    constexpr int OPER_BYTES = 2 * (BM + BN) * LDS_LD * 2, STAGE_BYTES = BM * ST_LD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES];
+    uint16_t (*As)[BM * LDS_LD] = reinterpret_cast<uint16_t (*)[BM * LDS_LD]>(smem);
+    uint16_t (*Bs)[BN * LDS_LD] = reinterpret_cast<uint16_t (*)[BN * LDS_LD]>(smem + 2 * BM * LDS_LD * 2);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -118,8 +121,77 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int 
         kk = kk_n; p = p_n;
     }
 
-    // Epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+    // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+    if (vec_ep) {
+        // through LDS (the operand buffers are free after the last barrier): every thread then owns 8
+        // consecutive columns of a row, so C, addend and mul move as 16-byte (bf16) / 2 x 16-byte (fp32)
+        // accesses, 16 threads per 128-column row segment, instead of one element per lane
+        float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(wr * WM + i * 32 + crow0 + (r & 3) + 8 * (r >> 2)) * ST_LD + wc * WN + j * 32 + ccol] = acc[i][j][r];
+        __syncthreads();
+        constexpr int CQ = BN / 8;                // 8-column chunks per tile row
+#pragma unroll 2
+        for (int idx = tid; idx < BM * CQ; idx += NTH) {
+            const int row = idx / CQ, col = (idx % CQ) * 8;
+            const int gr = m0 + row, gc = n0 + col;
+            if (gr >= M || gc >= N) continue;     // N % 8 == 0: a chunk is entirely inside or outside
+            float v[8];
+            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stage[row * ST_LD + col]);
+            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stage[row * ST_LD + col + 4]);
+            if (ep.bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += ep.bias[gc + q];
+            }
+            auto load8c = [&](const float* base, int64_t elem, float (&o)[8]) {
+                if constexpr (C16) {
+                    const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+                    o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xFFFF0000u);
+                    o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xFFFF0000u);
+                    o[4] = __uint_as_float(raw.z << 16); o[5] = __uint_as_float(raw.z & 0xFFFF0000u);
+                    o[6] = __uint_as_float(raw.w << 16); o[7] = __uint_as_float(raw.w & 0xFFFF0000u);
+                } else {
+                    *reinterpret_cast<float4*>(&o[0]) = *reinterpret_cast<const float4*>(base + elem);
+                    *reinterpret_cast<float4*>(&o[4]) = *reinterpret_cast<const float4*>(base + elem + 4);
+                }
+            };
+            if (ep.addend) {
+                float a[8];
+                load8c(ep.addend, (int64_t)gr * ep.ld_add + gc, a);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += a[q];
+            }
+            if (ep.mul) {
+                float a[8];
+                load8c(ep.mul, (int64_t)gr * ep.ld_mul + gc, a);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= a[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (ep.relu == 1) v[q] = fmaxf(v[q], 0.f);
+                else if (ep.relu == 2) v[q] = v[q] > 0.f ? v[q] : expf(v[q]) - 1.f;
+            }
+            if constexpr (C16) {
+                uint4 o;
+                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4*>(C + (int64_t)gr * ldc + gc) = o;
+            } else {
+                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = *reinterpret_cast<const float4*>(&v[0]);
+                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc + 4) = *reinterpret_cast<const float4*>(&v[4]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int gc = n0 + wc * WN + j * 32 + ccol;
@@ -183,12 +255,17 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     GVQA_REQUIRE(linear_bf16_supported(K, lda, A, Wpk), GVQA_E_INVALID, "linear_bf16: K / lda must be multiples of 8, operands 16-byte aligned");
     GVQA_REQUIRE(lda >= K && ldc >= N && cdiv(M, 128) <= 65535, GVQA_E_INVALID, "linear_bf16: bad leading dimension / M too large");
     dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128));
+    // vectorised epilogue: whole 8-column chunks, 16-byte aligned rows of C / addend / mul
+    const int esz = c16 ? 2 : 4;
+    auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld * esz) % 16 == 0); };
+    const int vec_ep = N % 8 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul) &&
+                       (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 3) == 0);
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(Wpk);
     if (c16) hipLaunchKernelGGL((k_linear_bf16<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda,
-                                b, (int64_t)P * K, ep, C, ldc);
+                                b, (int64_t)P * K, ep, C, ldc, vec_ep);
     else hipLaunchKernelGGL((k_linear_bf16<128, 128, 2, 2, false>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda,
-                            b, (int64_t)P * K, ep, C, ldc);
+                            b, (int64_t)P * K, ep, C, ldc, vec_ep);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -87,6 +87,151 @@ __global__ __launch_bounds__(256) void k_lcgn_edge_logit(int N, int C, const voi
     }
 }
 
+// ---- vectorised variants (C % 8 == 0, 16-byte aligned rows): a lane owns 8 consecutive channels ------
+template <bool H16>
+__device__ __forceinline__ void load8(const void* base, int64_t elem, float (&v)[8]) {
+    if (H16) {
+        const uint4 r = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(base) + elem);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+        v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u);
+        v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
+        const float4 b = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// k_lcgn_edge_logit with 16/32-byte row segments per lane and two edges in flight.  KC = ceil(C / 512).
+template <bool T16, int KC>
+__global__ __launch_bounds__(256) void k_lcgn_edge_logit_v(int N, int C, const void* __restrict__ xl, int64_t xl_ld,
+                                                           const void* __restrict__ xr, int64_t xr_ld,
+                                                           const float* __restrict__ proj_cmd, int64_t pc_ld,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ csr_src,
+                                                           const int32_t* __restrict__ csr_eid,
+                                                           const int32_t* __restrict__ node_graph, float* __restrict__ logit) {
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (i >= N) return;
+    const int g = node_graph[i];
+    float y[KC][8];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int c = (lane + k * 64) * 8;
+        if (c < C) {
+            float a[8], b[8];
+            load8<false>(proj_cmd, (int64_t)g * pc_ld + c, a);
+            load8<T16>(xr, (int64_t)i * xr_ld + c, b);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[k][q] = a[q] * b[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[k][q] = 0.f;
+        }
+    }
+    auto dot_row = [&](int src) -> float {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = (lane + k * 64) * 8;
+            if (c < C) {
+                float v[8];
+                load8<T16>(xl, (int64_t)src * xl_ld + c, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q] * y[k][q];
+            }
+        }
+        return acc;
+    };
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    int s = lo;
+    for (; s + 1 < hi; s += 2) {
+        float a0 = dot_row(csr_src[s]), a1 = dot_row(csr_src[s + 1]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+        if (lane == 0) { logit[csr_eid[s]] = a0; logit[csr_eid[s + 1]] = a1; }
+    }
+    if (s < hi) {
+        const float a0 = wave_sum(dot_row(csr_src[s]));
+        if (lane == 0) logit[csr_eid[s]] = a0;
+    }
+}
+
+// k_lcgn_aggregate_bf16 with the softmax weights computed once per edge (lanes over edges) and 16-byte
+// row segments per lane in the weighted gather.
+template <int KC>
+__global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16_v(int N, int C, const uint16_t* __restrict__ xval, int64_t xv_ld,
+                                                               const float* __restrict__ logit, const float* __restrict__ cal_cmd,
+                                                               int64_t cc_ld, const float* __restrict__ bias, float slope,
+                                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
+                                                               const int32_t* __restrict__ csr_eid,
+                                                               const int32_t* __restrict__ node_graph, uint16_t* __restrict__ msg,
+                                                               int64_t msg_ld) {
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1], g = node_graph[i];
+    auto edge_logit = [&](int s) { float v = logit[csr_eid[s]]; return v > 0.f ? v : v * slope; };
+    float m = -INFINITY;
+    for (int s = lo + lane; s < hi; s += 64) m = fmaxf(m, edge_logit(s));
+    m = wave_max(m);
+    float den = 0.f;
+    for (int s = lo + lane; s < hi; s += 64) den += expf(edge_logit(s) - m);
+    den = wave_sum(den) + 1e-16f;
+    float acc[KC][8];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[k][q] = 0.f;
+    for (int base = lo; base < hi; base += 64) {
+        const int s = base + lane, cnt = min(64, hi - base);
+        const float alpha = s < hi ? expf(edge_logit(s) - m) / den : 0.f;
+        const int src = s < hi ? csr_src[s] : 0;
+        for (int j = 0; j < cnt; ++j) {
+            const float a = __shfl(alpha, j, 64);
+            const int sj = __shfl(src, j, 64);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int c = (lane + k * 64) * 8;
+                if (c < C) {
+                    float v[8];
+                    load8<true>(xval, (int64_t)sj * xv_ld + c, v);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[k][q] += a * v[q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int c = (lane + k * 64) * 8;
+        if (c < C) {
+            float cc[8];
+            load8<false>(cal_cmd, (int64_t)g * cc_ld + c, cc);
+            unsigned w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float r0 = acc[k][2 * q] * cc[2 * q], r1 = acc[k][2 * q + 1] * cc[2 * q + 1];
+                if (bias) { r0 += bias[c + 2 * q]; r1 += bias[c + 2 * q + 1]; }
+                w[q] = (unsigned)f32_to_bf16(r0) | ((unsigned)f32_to_bf16(r1) << 16);
+            }
+            *reinterpret_cast<uint4*>(msg + (int64_t)i * msg_ld + c) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 // out[r, c] = in[r, c] for a [rows, cols] fp32 block into a wider row (fp32 or bf16 storage)
 template <bool OUT16>
 __global__ __launch_bounds__(256) void k_place_rows(int64_t rows, int cols, const float* __restrict__ in, void* __restrict__ out,
@@ -268,6 +413,7 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
                             static_cast<void*>(P(L.XC0) + O), (int64_t)3 * O);
     GVQA_LAUNCH_CHECK();
     const int64_t ldx = 3 * O;
+    const bool vec8 = O % 8 == 0;      // 16-byte row segments (all node tensors / per-graph rows have O-multiple offsets)
     for (int t = 0; t < T; ++t) {
         float* XC = (t & 1) ? P(L.XC1) : P(L.XC0);
         float* XCn = (t & 1) ? P(L.XC0) : P(L.XC1);
@@ -280,21 +426,32 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
         NODE_LIN(N, 3 * O, 2 * O, prod, ldx, P(L.Wj), 2 * O, pk_Wj, ep_add, P(L.J), 3 * O, true);
         // dot-product attention logits per edge                                                     // :154,207
-        if (nb)
-            hipLaunchKernelGGL(k_lcgn_edge_logit<true>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
-                               (int64_t)3 * O, NP(P(L.J), O), (int64_t)3 * O, pc, (int64_t)2 * O, g->rowptr, g->csr_src,
-                               g->csr_eid, g->node_graph, P(L.logit));
-        else
-            hipLaunchKernelGGL(k_lcgn_edge_logit<false>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O, P(L.J),
-                               (int64_t)3 * O, P(L.J) + O, (int64_t)3 * O, pc, (int64_t)2 * O, g->rowptr, g->csr_src,
-                               g->csr_eid, g->node_graph, P(L.logit));
+        const dim3 ngrid((unsigned)cdiv(N, 4));
+#define EDGE_LOGIT(KERNEL_, XL_, XR_)                                                                                    \
+        hipLaunchKernelGGL(KERNEL_, ngrid, dim3(256), 0, stream, (int)N, O, XL_, (int64_t)3 * O, XR_, (int64_t)3 * O, pc,  \
+                           (int64_t)2 * O, g->rowptr, g->csr_src, g->csr_eid, g->node_graph, P(L.logit))
+        if (nb) {
+            if (vec8 && O <= 512) EDGE_LOGIT((k_lcgn_edge_logit_v<true, 1>), P(L.J), NP(P(L.J), O));
+            else if (vec8) EDGE_LOGIT((k_lcgn_edge_logit_v<true, 2>), P(L.J), NP(P(L.J), O));
+            else EDGE_LOGIT(k_lcgn_edge_logit<true>, P(L.J), NP(P(L.J), O));
+        } else {
+            if (vec8 && O <= 512) EDGE_LOGIT((k_lcgn_edge_logit_v<false, 1>), P(L.J), P(L.J) + O);
+            else if (vec8) EDGE_LOGIT((k_lcgn_edge_logit_v<false, 2>), P(L.J), P(L.J) + O);
+            else EDGE_LOGIT(k_lcgn_edge_logit<false>, P(L.J), P(L.J) + O);
+        }
+#undef EDGE_LOGIT
         GVQA_LAUNCH_CHECK();
         // leaky-relu, softmax over in-edges, alpha-weighted sum of cal_x(x_joint)[src], x cal_cmd[g], + bias  // :209-238,166-168
         if (nb) {
-            hipLaunchKernelGGL(k_lcgn_aggregate_bf16, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, O,
-                               reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), pc + O,
-                               (int64_t)2 * O, p->bias, d->negative_slope, g->rowptr, g->csr_src, g->csr_eid, g->node_graph,
-                               reinterpret_cast<uint16_t*>(msg), ldx);
+#define AGGREGATE(KERNEL_)                                                                                              \
+            hipLaunchKernelGGL(KERNEL_, ngrid, dim3(256), 0, stream, (int)N, O,                                          \
+                               reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), pc + O,  \
+                               (int64_t)2 * O, p->bias, d->negative_slope, g->rowptr, g->csr_src, g->csr_eid, g->node_graph, \
+                               reinterpret_cast<uint16_t*>(msg), ldx)
+            if (vec8 && O <= 512) AGGREGATE(k_lcgn_aggregate_bf16_v<1>);
+            else if (vec8) AGGREGATE(k_lcgn_aggregate_bf16_v<2>);
+            else AGGREGATE(k_lcgn_aggregate_bf16);
+#undef AGGREGATE
             GVQA_LAUNCH_CHECK();
         } else {
             gvqa_gat_mp_desc m;
