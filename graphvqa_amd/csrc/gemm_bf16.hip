@@ -14,6 +14,8 @@
 // LDS rows are padded to 144 bytes = 36 dwords: the same bank geometry as the fp32 kernel, a wave's
 // ds_read_b128 fragment read (32 rows x 2 k-halves) is conflict-free.  Fragment: lane (r = lane & 31,
 // h = lane >> 5) feeds the 8 consecutive k's [16 kg + 8 h, +8) of row r to one MFMA from ONE b128 read.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -22,6 +24,110 @@ namespace gvqa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Epilogue of one BM x BN block tile held in MFMA accumulators (shared by the two kernels below).
+// `smem` must be free (all operand reads retired by a barrier) and hold BM x (BN + 4) floats.
+template <int BM, int BN, int WR, int WC, bool C16, typename TC, typename ACC>
+__device__ __forceinline__ void tile_epilogue(ACC& acc, unsigned char* smem, int M, int N, int m0, int n0,
+                                              const LinearEpilogue& ep, TC* C, int64_t ldc, int vec_ep) {
+    constexpr int NTH = 64 * WR * WC, WM = BM / WR, WN = BN / WC, MT = WM / 32, NT = WN / 32, ST_LD = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+    if (vec_ep) {
+        // through LDS (the operand buffers are free after the last barrier): every thread then owns 8
+        // consecutive columns of a row, so C, addend and mul move as 16-byte (bf16) / 2 x 16-byte (fp32)
+        // accesses, 16 threads per 128-column row segment, instead of one element per lane
+        float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(wr * WM + i * 32 + crow0 + (r & 3) + 8 * (r >> 2)) * ST_LD + wc * WN + j * 32 + ccol] = acc[i][j][r];
+        __syncthreads();
+        constexpr int CQ = BN / 8;                // 8-column chunks per tile row
+#pragma unroll 2
+        for (int idx = tid; idx < BM * CQ; idx += NTH) {
+            const int row = idx / CQ, col = (idx % CQ) * 8;
+            const int gr = m0 + row, gc = n0 + col;
+            if (gr >= M || gc >= N) continue;     // N % 8 == 0: a chunk is entirely inside or outside
+            float v[8];
+            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stage[row * ST_LD + col]);
+            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stage[row * ST_LD + col + 4]);
+            if (ep.bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += ep.bias[gc + q];
+            }
+            auto load8c = [&](const float* base, int64_t elem, float (&o)[8]) {
+                if constexpr (C16) {
+                    const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+                    o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xFFFF0000u);
+                    o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xFFFF0000u);
+                    o[4] = __uint_as_float(raw.z << 16); o[5] = __uint_as_float(raw.z & 0xFFFF0000u);
+                    o[6] = __uint_as_float(raw.w << 16); o[7] = __uint_as_float(raw.w & 0xFFFF0000u);
+                } else {
+                    *reinterpret_cast<float4*>(&o[0]) = *reinterpret_cast<const float4*>(base + elem);
+                    *reinterpret_cast<float4*>(&o[4]) = *reinterpret_cast<const float4*>(base + elem + 4);
+                }
+            };
+            if (ep.addend) {
+                float a[8];
+                load8c(ep.addend, (int64_t)gr * ep.ld_add + gc, a);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += a[q];
+            }
+            if (ep.mul) {
+                float a[8];
+                load8c(ep.mul, (int64_t)gr * ep.ld_mul + gc, a);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= a[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (ep.relu == 1) v[q] = fmaxf(v[q], 0.f);
+                else if (ep.relu == 2) v[q] = v[q] > 0.f ? v[q] : expf(v[q]) - 1.f;
+            }
+            if constexpr (C16) {
+                uint4 o;
+                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                *reinterpret_cast<uint4*>(C + (int64_t)gr * ldc + gc) = o;
+            } else {
+                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = *reinterpret_cast<const float4*>(&v[0]);
+                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc + 4) = *reinterpret_cast<const float4*>(&v[4]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gc = n0 + wc * WN + j * 32 + ccol;
+        if (gc >= N) continue;
+        const float bv = ep.bias ? ep.bias[gc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int gr0 = m0 + wr * WM + i * 32 + crow0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = gr0 + (r & 3) + 8 * (r >> 2);
+                if (gr < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (ep.addend) v += load_elem<C16>(ep.addend, (int64_t)gr * ep.ld_add + gc);
+                    if (ep.mul) v *= load_elem<C16>(ep.mul, (int64_t)gr * ep.ld_mul + gc);
+                    if (ep.relu == 1) v = fmaxf(v, 0.f);
+                    else if (ep.relu == 2) v = v > 0.f ? v : expf(v) - 1.f;
+                    if constexpr (C16) C[(int64_t)gr * ldc + gc] = f32_to_bf16(v);
+                    else C[(int64_t)gr * ldc + gc] = v;
+                }
+            }
+        }
+    }
+}
 
 template <int BM, int BN, int WR, int WC, bool C16>
 __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int K, int P, const uint16_t* __restrict__ A,
@@ -121,100 +227,115 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int 
         kk = kk_n; p = p_n;
     }
 
-    // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
-    if (vec_ep) {
-        // through LDS (the operand buffers are free after the last barrier): every thread then owns 8
-        // consecutive columns of a row, so C, addend and mul move as 16-byte (bf16) / 2 x 16-byte (fp32)
-        // accesses, 16 threads per 128-column row segment, instead of one element per lane
-        float* stage = reinterpret_cast<float*>(smem);
+    tile_epilogue<BM, BN, WR, WC, C16>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
+}
+
+// ---- LDS-DMA variant (K % 64 == 0) ------------------------------------------------------------
+// Same tile and MFMA schedule, but the operand tiles go HBM/L2 -> LDS with `global_load_lds_dwordx4`
+// (no VGPR staging, no ds_write): a wave instruction deposits its 64 lanes' 16-byte chunks at 64
+// consecutive LDS slots, i.e. 8 unpadded 128-byte tile rows.  Unpadded rows would put the 32 rows of a
+// fragment read on two 16-byte columns of the 256-byte bank row, so the tile is XOR-swizzled: slot
+// (row r, position q) holds k-chunk q ^ ((r >> 1) & 7) -- the lane picks its GLOBAL chunk accordingly
+// (still the same 128-byte line per 8 lanes) and the fragment read applies the same XOR.  The DMA is
+// issued from inline asm (invisible to the compiler's LDS dependence tracking) and ordered by counted
+// `s_waitcnt vmcnt` + barriers: tile t+1 is in flight while tile t is multiplied.
+typedef __attribute__((address_space(3))) unsigned char* lds_bytes_t;
+__device__ __forceinline__ void lds_dma16_b(const uint16_t* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <bool C16>
+__global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, int P, const uint16_t* __restrict__ A, int64_t lda,
+                                                         const uint16_t* __restrict__ B, int64_t ldb, LinearEpilogue ep,
+                                                         void* C_, int64_t ldc, int vec_ep) {
+    constexpr int BM = 128, BN = 128, WR = 2, WC = 2, BK = 64;
+    constexpr int TILE_BYTES = 128 * BK * 2;                  // one operand tile: 16 KiB
+    constexpr int STAGE_BYTES = BM * (BN + 4) * 4;
+    constexpr int OPER_BYTES = 4 * TILE_BYTES;                // {A, B} x 2 buffers
+    typedef typename std::conditional<C16, uint16_t, float>::type TC;
+    TC* C = static_cast<TC*>(C_);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[(wr * WM + i * 32 + crow0 + (r & 3) + 8 * (r >> 2)) * ST_LD + wc * WN + j * 32 + ccol] = acc[i][j][r];
-        __syncthreads();
-        constexpr int CQ = BN / 8;                // 8-column chunks per tile row
-#pragma unroll 2
-        for (int idx = tid; idx < BM * CQ; idx += NTH) {
-            const int row = idx / CQ, col = (idx % CQ) * 8;
-            const int gr = m0 + row, gc = n0 + col;
-            if (gr >= M || gc >= N) continue;     // N % 8 == 0: a chunk is entirely inside or outside
-            float v[8];
-            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stage[row * ST_LD + col]);
-            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stage[row * ST_LD + col + 4]);
-            if (ep.bias) {
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA j of wave w fills tile rows [(4 j + w) 8, +8): lane -> (row, slot position q), global chunk q ^ swizzle(row)
+    const uint16_t* pa[4];
+    const uint16_t* pb[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += ep.bias[gc + q];
-            }
-            auto load8c = [&](const float* base, int64_t elem, float (&o)[8]) {
-                if constexpr (C16) {
-                    const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
-                    o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xFFFF0000u);
-                    o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xFFFF0000u);
-                    o[4] = __uint_as_float(raw.z << 16); o[5] = __uint_as_float(raw.z & 0xFFFF0000u);
-                    o[6] = __uint_as_float(raw.w << 16); o[7] = __uint_as_float(raw.w & 0xFFFF0000u);
-                } else {
-                    *reinterpret_cast<float4*>(&o[0]) = *reinterpret_cast<const float4*>(base + elem);
-                    *reinterpret_cast<float4*>(&o[4]) = *reinterpret_cast<const float4*>(base + elem + 4);
-                }
-            };
-            if (ep.addend) {
-                float a[8];
-                load8c(ep.addend, (int64_t)gr * ep.ld_add + gc, a);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += a[q];
-            }
-            if (ep.mul) {
-                float a[8];
-                load8c(ep.mul, (int64_t)gr * ep.ld_mul + gc, a);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] *= a[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (ep.relu == 1) v[q] = fmaxf(v[q], 0.f);
-                else if (ep.relu == 2) v[q] = v[q] > 0.f ? v[q] : expf(v[q]) - 1.f;
-            }
-            if constexpr (C16) {
-                uint4 o;
-                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-                o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-                *reinterpret_cast<uint4*>(C + (int64_t)gr * ldc + gc) = o;
-            } else {
-                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = *reinterpret_cast<const float4*>(&v[0]);
-                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc + 4) = *reinterpret_cast<const float4*>(&v[4]);
-            }
-        }
-        return;
+    for (int j = 0; j < 4; ++j) {
+        const int row = (j * 4 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        pa[j] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        pb[j] = B + (int64_t)min(n0 + row, N - 1) * ldb + chunk * 8;
     }
+    const int nk = K / BK, nt = nk * P;
+    int a_wrap = nk;                                           // tiles until the A k-offset wraps back to 0 (next weight piece)
+    auto issue = [&](int buf) {
+        const unsigned dst = lds_base + buf * 2 * TILE_BYTES + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int gc = n0 + wc * WN + j * 32 + ccol;
-        if (gc >= N) continue;
-        const float bv = ep.bias ? ep.bias[gc] : 0.f;
+        for (int j = 0; j < 4; ++j) lds_dma16_b(pa[j], __builtin_amdgcn_readfirstlane(dst + j * 4096));
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int gr0 = m0 + wr * WM + i * 32 + crow0;
+        for (int j = 0; j < 4; ++j) lds_dma16_b(pb[j], __builtin_amdgcn_readfirstlane(dst + TILE_BYTES + j * 4096));
+        const int adv = (--a_wrap == 0) ? BK - K : BK;         // B runs on through the pieces, A starts over
+        if (a_wrap == 0) a_wrap = nk;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gr = gr0 + (r & 3) + 8 * (r >> 2);
-                if (gr < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (ep.addend) v += load_elem<C16>(ep.addend, (int64_t)gr * ep.ld_add + gc);
-                    if (ep.mul) v *= load_elem<C16>(ep.mul, (int64_t)gr * ep.ld_mul + gc);
-                    if (ep.relu == 1) v = fmaxf(v, 0.f);
-                    else if (ep.relu == 2) v = v > 0.f ? v : expf(v) - 1.f;
-                    if constexpr (C16) C[(int64_t)gr * ldc + gc] = f32_to_bf16(v);
-                    else C[(int64_t)gr * ldc + gc] = v;
-                }
-            }
+        for (int j = 0; j < 4; ++j) { pa[j] += adv; pb[j] += BK; }
+    };
+
+    // fragment read offsets: row R = w-tile base + i*32 + (lane & 31); swizzle((R >> 1) & 7) only depends on the lane
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    unsigned xo[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
+    const unsigned a_row = (unsigned)((wr * 64 + frow) * 128), b_row = (unsigned)((wc * 64 + frow) * 128);
+
+    issue(0);
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            issue(cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile t have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();                          // ... and every other wave's
+        const unsigned char* at = smem + cur * 2 * TILE_BYTES;
+        const unsigned char* bt = at + TILE_BYTES;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(at + a_row + i * 32 * 128 + xo[kg]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bt + b_row + j * 32 * 128 + xo[kg]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // all fragment reads of `cur` retired before it is refilled
     }
+    tile_epilogue<BM, BN, WR, WC, C16>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
 }
 
 // Wpk[n, p*K + k] = p-th bf16 piece of W[n, k]  (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the remainder)
@@ -262,6 +383,15 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
                        (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 3) == 0);
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(Wpk);
+    static const bool no_dma = []() { const char* v = getenv("GVQA_BF16_GEMM"); return v && !strcmp(v, "regs"); }();
+    if (K % 64 == 0 && !no_dma) {        // LDS-DMA staging (whole K steps only)
+        if (c16) hipLaunchKernelGGL(k_linear_bf16_dma<true>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda, b,
+                                    (int64_t)P * K, ep, C, ldc, vec_ep);
+        else hipLaunchKernelGGL(k_linear_bf16_dma<false>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda, b,
+                                (int64_t)P * K, ep, C, ldc, vec_ep);
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
     if (c16) hipLaunchKernelGGL((k_linear_bf16<128, 128, 2, 2, true>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda,
                                 b, (int64_t)P * K, ep, C, ldc, vec_ep);
     else hipLaunchKernelGGL((k_linear_bf16<128, 128, 2, 2, false>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda,
