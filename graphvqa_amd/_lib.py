@@ -87,7 +87,7 @@ class LcgnParams(C.Structure):
                 ("output_weight", C.c_void_p), ("output_bias", C.c_void_p), ("fin_weight", C.c_void_p),
                 ("fin_bias", C.c_void_p), ("lin_l_weight", C.c_void_p), ("lin_r_weight", C.c_void_p),
                 ("cal_x_weight", C.c_void_p), ("proj_cmd_weight", C.c_void_p), ("cal_cmd_weight", C.c_void_p),
-                ("bias", C.c_void_p)]
+                ("bias", C.c_void_p), ("packed", C.c_void_p), ("packed_bytes", C.c_size_t)]
 
 
 class PoolParams(C.Structure):
@@ -159,6 +159,8 @@ PROTOTYPES = {
     "gvqa_gcn_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32]),
     "gvqa_gcn_conv_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.POINTER(GcnParams),
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_lcgn_pack_bytes": (C.c_size_t, [C.POINTER(LcgnDims)]),
+    "gvqa_lcgn_pack_weights": (C.c_int, [C.POINTER(LcgnDims), C.POINTER(LcgnParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_lcgn_seq_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(LcgnDims)]),
     "gvqa_lcgn_seq_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(LcgnDims), C.POINTER(LcgnParams), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -95,7 +95,7 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
                     int64_t ldb, LinearEpilogue ep, float* C, int64_t ldc, int batch, int64_t strideA,
                     int64_t strideB, int64_t strideC, int dtype_flags, hipStream_t stream);
 // bf16 matrix-core projection of a bf16 node tensor against weights packed into P bf16 pieces (gemm_bf16.hip)
-int launch_pack_weight_bf16(int64_t rows, int K, int P, const float* W, int64_t ldw, void* out, hipStream_t stream);
+int launch_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* W, int64_t ldw, void* out, hipStream_t stream);
 bool linear_bf16_supported(int64_t K, int64_t lda, const void* A, const void* Wpk);
 int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, int64_t lda, const void* Wpk, LinearEpilogue ep,
                        void* C, int64_t ldc, bool c16, hipStream_t stream);

@@ -648,7 +648,9 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     else if (tile_sel == 1 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 4, 2);
     else if (tile_sel == 2 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 2, 2);
     else if (tile_sel == 3) GVQA_LAUNCH_LINEAR(128, 128, 4, 2);
-    else if (tile_sel == 5 || (tile_sel == 0 && K <= 1024)) {   // short K: K step 16, 3 blocks/CU (+4.5 % at K = 512)
+    // short K: K step 16, 3 blocks/CU (+4.5 % at K = 512) -- unless the grid cannot fill the chip anyway: a lone
+    // block per CU is bound by the latency of its serial K steps, and K step 32 halves their number
+    else if (tile_sel == 5 || (tile_sel == 0 && K <= 1024 && cdiv(M, 128) * cdiv(N, 128) * batch >= 256)) {
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch);
         if (vec) hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2, true, 16>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);
         else hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2, false, 16>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);

@@ -338,24 +338,26 @@ __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, in
     tile_epilogue<BM, BN, WR, WC, C16>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
 }
 
-// Wpk[n, p*K + k] = p-th bf16 piece of W[n, k]  (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the remainder)
-__global__ __launch_bounds__(256) void k_pack_weight_bf16(int64_t rows, int K, int P, const float* __restrict__ W, int64_t ldw,
-                                                          uint16_t* __restrict__ out) {
+// Wpk[n, p*Kp + k] = p-th bf16 piece of W[n, k] (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the
+// remainder), zero for K <= k < Kp (K padded up to the GEMM's multiple of 8)
+__global__ __launch_bounds__(256) void k_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* __restrict__ W,
+                                                          int64_t ldw, uint16_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * K) return;
-    const int64_t r = i / K;
-    const int k = (int)(i - r * K);
-    const float w = W[r * ldw + k];
+    if (i >= rows * Kp) return;
+    const int64_t r = i / Kp;
+    const int k = (int)(i - r * Kp);
+    const float w = k < K ? W[r * ldw + k] : 0.f;
     const uint16_t hi = f32_to_bf16(w);
-    uint16_t* o = out + r * (int64_t)P * K + k;
+    uint16_t* o = out + r * (int64_t)P * Kp + k;
     o[0] = hi;
-    if (P > 1) o[K] = f32_to_bf16(w - bf16_to_f32(hi));
+    if (P > 1) o[Kp] = f32_to_bf16(w - bf16_to_f32(hi));
 }
 
-int launch_pack_weight_bf16(int64_t rows, int K, int P, const float* W, int64_t ldw, void* out, hipStream_t stream) {
+int launch_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* W, int64_t ldw, void* out, hipStream_t stream) {
     GVQA_REQUIRE(P == 1 || P == 2, GVQA_E_INVALID, "pack_weight_bf16: pieces must be 1 or 2");
-    if (rows == 0 || K == 0) return GVQA_OK;
-    hipLaunchKernelGGL(k_pack_weight_bf16, dim3((unsigned)cdiv(rows * K, 256)), dim3(256), 0, stream, rows, K, P, W, ldw,
+    GVQA_REQUIRE(Kp >= K, GVQA_E_INVALID, "pack_weight_bf16: padded K smaller than K");
+    if (rows == 0 || Kp == 0) return GVQA_OK;
+    hipLaunchKernelGGL(k_pack_weight_bf16, dim3((unsigned)cdiv(rows * Kp, 256)), dim3(256), 0, stream, rows, K, Kp, P, W, ldw,
                        static_cast<uint16_t*>(out));
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
@@ -406,7 +408,7 @@ extern "C" int gvqa_pack_weight_bf16(int64_t rows, int64_t K, int pieces, const 
     using namespace gvqa;
     GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ldw >= K, GVQA_E_INVALID, "pack_weight_bf16: bad size");
     GVQA_REQUIRE((W && Wpk) || rows * K == 0, GVQA_E_INVALID, "pack_weight_bf16: null operand");
-    return launch_pack_weight_bf16(rows, (int)K, pieces, W, ldw, Wpk, static_cast<hipStream_t>(stream));
+    return launch_pack_weight_bf16(rows, (int)K, (int)K, pieces, W, ldw, Wpk, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A, int64_t lda, const void* Wpk,

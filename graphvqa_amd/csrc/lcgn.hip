@@ -232,16 +232,18 @@ __global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16_v(int N, int C, con
     }
 }
 
-// out[r, c] = in[r, c] for a [rows, cols] fp32 block into a wider row (fp32 or bf16 storage)
+// out[r, c] = in[r, c] (c < cols), 0 (cols <= c < cols_out): a [rows, cols] fp32 block into a wider row
+// (fp32 or bf16 storage), optionally zero-padded
 template <bool OUT16>
-__global__ __launch_bounds__(256) void k_place_rows(int64_t rows, int cols, const float* __restrict__ in, void* __restrict__ out,
-                                                    int64_t out_ld) {
+__global__ __launch_bounds__(256) void k_place_rows(int64_t rows, int cols, int cols_out, const float* __restrict__ in,
+                                                    void* __restrict__ out, int64_t out_ld) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int64_t r = i / cols;
-    const int c = (int)(i - r * cols);
-    if (OUT16) static_cast<uint16_t*>(out)[r * out_ld + c] = f32_to_bf16(in[i]);
-    else static_cast<float*>(out)[r * out_ld + c] = in[i];
+    if (i >= rows * cols_out) return;
+    const int64_t r = i / cols_out;
+    const int c = (int)(i - r * cols_out);
+    const float v = c < cols ? in[r * cols + c] : 0.f;
+    if (OUT16) static_cast<uint16_t*>(out)[r * out_ld + c] = f32_to_bf16(v);
+    else static_cast<float*>(out)[r * out_ld + c] = v;
 }
 
 // bf16-node-feature mode: msg[i] = (sum_{e -> i} alpha_e * x_val[src(e)]) * cal_cmd[g(i)] + bias with
@@ -277,8 +279,73 @@ __global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16(int N, int C, const
     }
 }
 
+// Call-invariant weight forms (stacked fp32 matrices + the bf16 pieces of the node-GEMM weights): built by
+// lcgn_pack into a caller-held blob (gvqa_lcgn_pack_weights) or, per call, into the workspace.
+struct LcgnPack {
+    size_t Wx, Wj, Wpc, Wq, bq, Wpk, total;
+};
+static LcgnPack lcgn_pack_layout(const gvqa_lcgn_dims* d) {
+    LcgnPack L; size_t off = 0;
+    auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
+    const size_t O = d->out_channels, T = d->num_iters, K8 = align_up(d->in_channels, 8);
+    L.Wx = take(3 * O * O); L.Wj = take(3 * O * 2 * O); L.Wpc = take(2 * O * O); L.Wq = take(T * O * O); L.bq = take(T * O);
+    // node-GEMM weights as bf16 pieces: (15 O^2 + O K8) elements x <= 2 pieces x 2 bytes
+    L.Wpk = take(d->node_bf16 ? 15 * O * O + O * K8 : 0);
+    L.total = off;
+    return L;
+}
+struct PackedWeights {      // bf16 piece matrices, [rows, PW * K] each
+    uint16_t *pxl, *Wx, *Wj, *pxc, *out, *f1, *f2, *init;
+};
+static PackedWeights packed_weights(char* blob, const LcgnPack& L, const gvqa_lcgn_dims* d) {
+    uint16_t* pk = reinterpret_cast<uint16_t*>(blob + L.Wpk);
+    const size_t OO = (size_t)d->out_channels * d->out_channels * (d->node_bf16 == 2 ? 1 : 2);
+    return {pk, pk + OO, pk + 4 * OO, pk + 10 * OO, pk + 11 * OO, pk + 13 * OO, pk + 14 * OO, pk + 15 * OO};
+}
+static int lcgn_pack(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, char* blob, hipStream_t stream) {
+    const int O = d->out_channels, T = d->num_iters, Cin = d->in_channels;
+    const LcgnPack PL = lcgn_pack_layout(d);
+    auto PB = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
+    GVQA_REQUIRE(p->lin_l_weight && p->lin_r_weight && p->cal_x_weight && p->proj_cmd_weight && p->cal_cmd_weight &&
+                 p->proj_x_loc_weight && p->proj_x_ctx_weight && p->output_weight && p->fin_weight && p->init_weight,
+                 GVQA_E_INVALID, "lcgn_seq: null weight");
+    // stacked weights over the rows [lin_l; lin_r; cal_x] (each [O, 3O], input = [x_loc | x_ctx | prod]):
+    //   Wx = columns of x_loc ([3O, O]);  Wj = columns of [prod | x_ctx] in the order of the XC rows ([3O, 2O]);
+    //   Wpc = [proj_cmd; cal_cmd] ([2O, O]);  Wq = [qInput2[0]; ...; qInput2[T-1]] ([T*O, O]), bq likewise
+    const float* wsrc[3] = {p->lin_l_weight, p->lin_r_weight, p->cal_x_weight};
+    const size_t fo = (size_t)O * sizeof(float);
+    for (int m = 0; m < 3; ++m) {
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(PB(PL.Wx) + (size_t)m * O * O, fo, wsrc[m], 3 * fo, fo, O, hipMemcpyDeviceToDevice, stream));
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(PB(PL.Wj) + (size_t)m * O * 2 * O, 2 * fo, wsrc[m] + 2 * O, 3 * fo, fo, O,
+                                        hipMemcpyDeviceToDevice, stream));
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(PB(PL.Wj) + (size_t)m * O * 2 * O + O, 2 * fo, wsrc[m] + O, 3 * fo, fo, O,
+                                        hipMemcpyDeviceToDevice, stream));
+    }
+    GVQA_HIP_CHECK(hipMemcpyAsync(PB(PL.Wpc), p->proj_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+    GVQA_HIP_CHECK(hipMemcpyAsync(PB(PL.Wpc) + (size_t)O * O, p->cal_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+    for (int t = 0; t < T; ++t) {
+        GVQA_REQUIRE(p->qinput2_weight[t] && p->qinput2_bias[t], GVQA_E_INVALID, "lcgn_seq: qinput2[%d] is null", t);
+        GVQA_HIP_CHECK(hipMemcpyAsync(PB(PL.Wq) + (size_t)t * O * O, p->qinput2_weight[t], (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
+        GVQA_HIP_CHECK(hipMemcpyAsync(PB(PL.bq) + (size_t)t * O, p->qinput2_bias[t], fo, hipMemcpyDeviceToDevice, stream));
+    }
+    if (d->node_bf16 && O % 8 == 0) {
+        const int PW = d->node_bf16 == 2 ? 1 : 2, K8 = (int)align_up(Cin, 8);
+        const PackedWeights w = packed_weights(blob, PL, d);
+        struct { const float* src; int64_t ldw; int rows, K, Kp; uint16_t* out; } pw[8] = {
+            {p->proj_x_loc_weight, O, O, O, O, w.pxl}, {PB(PL.Wx), O, 3 * O, O, O, w.Wx}, {PB(PL.Wj), 2 * O, 3 * O, 2 * O, 2 * O, w.Wj},
+            {p->proj_x_ctx_weight, O, O, O, O, w.pxc}, {p->output_weight, 2 * O, O, 2 * O, 2 * O, w.out},
+            {p->fin_weight, 2 * O, O, O, O, w.f1}, {p->fin_weight + O, 2 * O, O, O, O, w.f2},
+            {p->init_weight, Cin, O, Cin, K8, w.init}};       // K zero-padded to a multiple of 8
+        for (auto& e : pw) {
+            int rc = launch_pack_weight_bf16(e.rows, e.K, e.Kp, PW, e.src, e.ldw, e.out, stream);
+            if (rc) return rc;
+        }
+    }
+    return GVQA_OK;
+}
+
 struct LcgnLayout {
-    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, Wx, Wj, Wpc, Wq, bq, Wpk, alpha, total;
+    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, x16, pack, alpha, total;
 };
 static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_dims* d) {
     LcgnLayout L; size_t off = 0;
@@ -291,8 +358,8 @@ static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_d
     // row = [ prod | x_ctx | msg ], so that [prod | x_ctx] and [x_ctx | msg] are contiguous K = 2O operands
     L.XC0 = take(N * 3 * O); L.XC1 = take(N * 3 * O);
     L.XL = take(N * 3 * O); L.J = take(N * 3 * O); L.logit = take(E);
-    L.Wx = take(3 * O * O); L.Wj = take(3 * O * 2 * O); L.Wpc = take(2 * O * O); L.Wq = take(T * O * O); L.bq = take(T * O);
-    L.Wpk = take(d->node_bf16 ? 15 * O * O : 0);     // node-GEMM weights as bf16 pieces: 15 O^2 elements x <= 2 pieces x 2 bytes
+    L.x16 = take(d->node_bf16 ? (N * align_up(d->in_channels, 8) + 1) / 2 : 0);     // x as bf16, K padded to 8
+    L.pack = take(lcgn_pack_layout(d).total / sizeof(float));                        // used when params->packed is NULL
     L.alpha = take(E);
     L.total = off;
     return L;
@@ -303,8 +370,22 @@ static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_d
 extern "C" {
 using namespace gvqa;
 
+size_t gvqa_lcgn_pack_bytes(const gvqa_lcgn_dims* d) {
+    if (!d || d->num_iters < 1 || d->num_iters > 8 || d->out_channels < 1 || d->in_channels < 1) return 0;
+    return lcgn_pack_layout(d).total;
+}
+
+int gvqa_lcgn_pack_weights(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, void* packed, size_t packed_bytes, void* stream) {
+    GVQA_REQUIRE(d && p && packed, GVQA_E_INVALID, "lcgn_pack_weights: null argument");
+    GVQA_REQUIRE(d->out_channels > 0 && d->in_channels > 0 && d->num_iters >= 1 && d->num_iters <= 8 && d->node_bf16 >= 0 &&
+                 d->node_bf16 <= 2, GVQA_E_INVALID, "lcgn_pack_weights: bad dims");
+    GVQA_REQUIRE(packed_bytes >= lcgn_pack_layout(d).total, GVQA_E_WORKSPACE, "lcgn_pack_weights: buffer %zu < required %zu",
+                 packed_bytes, lcgn_pack_layout(d).total);
+    return lcgn_pack(d, p, static_cast<char*>(packed), static_cast<hipStream_t>(stream));
+}
+
 size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* d) {
-    if (!g || !d || d->num_iters < 1 || d->num_iters > 8 || d->out_channels < 1) return 0;
+    if (!g || !d || d->num_iters < 1 || d->num_iters > 8 || d->out_channels < 1 || d->in_channels < 1) return 0;
     return lcgn_layout(g->num_nodes, g->num_edges, g->num_graphs, d).total;
 }
 
@@ -337,10 +418,12 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     const int FA = nb ? 1 : 0, FC = nb ? 2 : 0;      // dtype flags: A is a node tensor / C is a node tensor
     const int PW = d->node_bf16 == 2 ? 1 : 2;        // bf16 pieces per weight
     const bool mf16 = nb && O % 8 == 0;
-    uint16_t* const pk = reinterpret_cast<uint16_t*>(base + L.Wpk);
-    const size_t OO = (size_t)O * O * PW;            // packed elements of one [O, O] weight
-    uint16_t *pk_pxl = pk, *pk_Wx = pk + OO, *pk_Wj = pk + 4 * OO, *pk_pxc = pk + 10 * OO, *pk_out = pk + 11 * OO,
-             *pk_f1 = pk + 13 * OO, *pk_f2 = pk + 14 * OO;
+    const LcgnPack PL = lcgn_pack_layout(d);
+    GVQA_REQUIRE(!p->packed || p->packed_bytes >= PL.total, GVQA_E_INVALID, "lcgn_seq: packed weights %zu < required %zu bytes",
+                 (size_t)p->packed_bytes, PL.total);
+    char* const blob = p->packed ? static_cast<char*>(const_cast<void*>(p->packed)) : base + L.pack;
+    const PackedWeights pkw = packed_weights(blob, PL, d);
+    auto PB = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
     // node GEMM: A is a node tensor (bf16 in nb mode); c_node: C (and addend / mul) are node tensors too
     auto NODE = [&](int64_t M_, int64_t N_, int64_t K_, const float* A_, int64_t lda_, const float* W_, int64_t ldw_,
                     const uint16_t* Wpk_, LinearEpilogue ep_, float* C_, int64_t ldc_, bool c_node) -> int {
@@ -359,57 +442,40 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     };
 
     StageTimer timer(GVQA_STAGE_OTHER, stream);
-    // stacked weights over the rows [lin_l; lin_r; cal_x] (each [O, 3O], input = [x_loc | x_ctx | prod]):
-    //   Wx = columns of x_loc ([3O, O]);  Wj = columns of [prod | x_ctx] in the order of the XC rows ([3O, 2O]);
-    //   Wpc = [proj_cmd; cal_cmd] ([2O, O])
-    const float* wsrc[3] = {p->lin_l_weight, p->lin_r_weight, p->cal_x_weight};
-    const size_t fo = (size_t)O * sizeof(float);
-    for (int m = 0; m < 3; ++m) {
-        GVQA_HIP_CHECK(hipMemcpy2DAsync(P(L.Wx) + (size_t)m * O * O, fo, wsrc[m], 3 * fo, fo, O, hipMemcpyDeviceToDevice, stream));
-        GVQA_HIP_CHECK(hipMemcpy2DAsync(P(L.Wj) + (size_t)m * O * 2 * O, 2 * fo, wsrc[m] + 2 * O, 3 * fo, fo, O,
-                                        hipMemcpyDeviceToDevice, stream));
-        GVQA_HIP_CHECK(hipMemcpy2DAsync(P(L.Wj) + (size_t)m * O * 2 * O + O, 2 * fo, wsrc[m] + O, 3 * fo, fo, O,
-                                        hipMemcpyDeviceToDevice, stream));
-    }
-    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc), p->proj_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
-    GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wpc) + (size_t)O * O, p->cal_cmd_weight, (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
-    for (int t = 0; t < T; ++t) {       // Wq = [qInput2[0]; ...; qInput2[T-1]] ([T*O, O]), bq likewise
-        GVQA_REQUIRE(p->qinput2_weight[t] && p->qinput2_bias[t], GVQA_E_INVALID, "lcgn_seq: qinput2[%d] is null", t);
-        GVQA_HIP_CHECK(hipMemcpyAsync(P(L.Wq) + (size_t)t * O * O, p->qinput2_weight[t], (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
-        GVQA_HIP_CHECK(hipMemcpyAsync(P(L.bq) + (size_t)t * O, p->qinput2_bias[t], fo, hipMemcpyDeviceToDevice, stream));
-    }
-
-    if (mf16) {
-        struct { const float* w; int64_t ldw; int rows, K; uint16_t* out; } pw[7] = {
-            {p->proj_x_loc_weight, O, O, O, pk_pxl}, {P(L.Wx), O, 3 * O, O, pk_Wx}, {P(L.Wj), 2 * O, 3 * O, 2 * O, pk_Wj},
-            {p->proj_x_ctx_weight, O, O, O, pk_pxc}, {p->output_weight, 2 * O, O, 2 * O, pk_out},
-            {p->fin_weight, 2 * O, O, O, pk_f1}, {p->fin_weight + O, 2 * O, O, O, pk_f2}};
-        for (auto& e : pw) { rc = launch_pack_weight_bf16(e.rows, e.K, PW, e.w, e.ldw, e.out, stream); if (rc) return rc; }
-    }
+    if (!p->packed) { rc = lcgn_pack(d, p, blob, stream); if (rc) return rc; }
     {   // x_loc = init(x)                                                                       lcgn.py:305
         LinearEpilogue e{p->init_bias, nullptr, 0, nullptr, 0, 0};
-        LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);
+        if (mf16) {     // x is a node tensor too: bf16 copy with K zero-padded to a multiple of 8
+            const int K8 = (int)align_up(Cin, 8);
+            hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * K8, 256)), dim3(256), 0, stream, N, Cin, K8, x,
+                               static_cast<void*>(base + L.x16), (int64_t)K8);
+            GVQA_LAUNCH_CHECK();
+            rc = launch_linear_bf16(N, O, K8, PW, base + L.x16, K8, pkw.init, e, P(L.x_loc), O, true, stream);
+            if (rc) return rc;
+        } else {
+            LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);
+        }
     }
     LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
     // textual commands (:292-300) and their projections (:148-149) for all T iterations: per-graph, fp32,
     // independent of the node state -> three launches instead of 3T
-    LIN(B, T * O, O, P(L.q_emb), O, P(L.Wq), O, P(L.bq), 0, P(L.q_cmd), (int64_t)T * O);
+    LIN(B, T * O, O, P(L.q_emb), O, PB(PL.Wq), O, PB(PL.bq), 0, P(L.q_cmd), (int64_t)T * O);
     hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B, (unsigned)T), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B,
                        O, P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
     GVQA_LAUNCH_CHECK();
-    LIN((int64_t)T * B, 2 * O, O, P(L.cmd), O, P(L.Wpc), O, nullptr, 0, P(L.pc), 2 * O);
+    LIN((int64_t)T * B, 2 * O, O, P(L.cmd), O, PB(PL.Wpc), O, nullptr, 0, P(L.pc), 2 * O);
     {   // proj_x_loc                                                                            :308
         LinearEpilogue e{p->proj_x_loc_bias, nullptr, 0, nullptr, 0, 0};
-        NODE_LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, pk_pxl, e, P(L.proj_x_loc), O, true);
+        NODE_LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, pkw.pxl, e, P(L.proj_x_loc), O, true);
     }
     {   // x_loc segment of lin_l / lin_r / cal_x                                                :144-145,230
         LinearEpilogue e{nullptr, nullptr, 0, nullptr, 0, 0};
-        NODE_LIN(N, 3 * O, O, P(L.x_loc), O, P(L.Wx), O, pk_Wx, e, P(L.XL), 3 * O, true);
+        NODE_LIN(N, 3 * O, O, P(L.x_loc), O, PB(PL.Wx), O, pkw.Wx, e, P(L.XL), 3 * O, true);
     }
     // x_ctx (:306) into the x_ctx columns of XC0
-    if (nb) hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, x_ctx_init,
+    if (nb) hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, O, x_ctx_init,
                                static_cast<void*>(NP(P(L.XC0), O)), (int64_t)3 * O);
-    else hipLaunchKernelGGL(k_place_rows<false>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, x_ctx_init,
+    else hipLaunchKernelGGL(k_place_rows<false>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, O, x_ctx_init,
                             static_cast<void*>(P(L.XC0) + O), (int64_t)3 * O);
     GVQA_LAUNCH_CHECK();
     const int64_t ldx = 3 * O;
@@ -421,10 +487,10 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         const float* pc = P(L.pc) + (size_t)t * B * 2 * O;      // [proj_cmd(cmd_t) | cal_cmd(cmd_t)] per graph
         // prod = proj_x_ctx(x_ctx) * proj_x_loc                                                     // :312-313
         LinearEpilogue ep_mul{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0};
-        NODE_LIN(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, pk_pxc, ep_mul, prod, ldx, true);
+        NODE_LIN(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, pkw.pxc, ep_mul, prod, ldx, true);
         // J = x_joint . [lin_l; lin_r; cal_x]^T = XL + [prod | x_ctx] . Wj^T   (one K = 2O product)  // :144-145,230
         LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
-        NODE_LIN(N, 3 * O, 2 * O, prod, ldx, P(L.Wj), 2 * O, pk_Wj, ep_add, P(L.J), 3 * O, true);
+        NODE_LIN(N, 3 * O, 2 * O, prod, ldx, PB(PL.Wj), 2 * O, pkw.Wj, ep_add, P(L.J), 3 * O, true);
         // dot-product attention logits per edge                                                     // :154,207
         const dim3 ngrid((unsigned)cdiv(N, 4));
 #define EDGE_LOGIT(KERNEL_, XL_, XR_)                                                                                    \
@@ -466,14 +532,14 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         }
         // x_ctx = output_layer([x_ctx || msg])   (one K = 2O product)                                 // :316-319
         LinearEpilogue ep_o{p->output_bias, nullptr, 0, nullptr, 0, 0};
-        NODE_LIN(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, pk_out, ep_o, x_ctx_next, ldx, true);
+        NODE_LIN(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, pkw.out, ep_o, x_ctx_next, ldx, true);
     }
     float* x_ctx_fin = NP((T & 1) ? P(L.XC1) : P(L.XC0), O);
     // out = fin_layer([x_loc || x_ctx]) (fp32 result)                                                // :321-322
     LinearEpilogue ep_f1{p->fin_bias, nullptr, 0, nullptr, 0, 0};
-    NODE_LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, pk_f1, ep_f1, out, O, false);
+    NODE_LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, pkw.f1, ep_f1, out, O, false);
     LinearEpilogue ep_fin{nullptr, out, O, nullptr, 0, 0};
-    NODE_LIN(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, pk_f2, ep_fin, out, O, false);
+    NODE_LIN(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, pkw.f2, ep_fin, out, O, false);
 #undef LIN
 #undef NODE_LIN
 #undef LINT

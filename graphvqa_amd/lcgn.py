@@ -67,6 +67,7 @@ class lcgn_seq(nn.Module):
             raise ValueError("bf16_weight_pieces must be 1 or 2")
         self.node_feature_dtype = node_feature_dtype
         self.bf16_weight_pieces = bf16_weight_pieces
+        self._packed, self._packed_key = None, None
         self.init_sg_emb_input = nn.Sequential(Linear(in_channels, out_channels), nn.Dropout(dropout))
         self.MAX_ITER_NUM = MAX_ITER_NUM
         self.qInput1 = Linear(question_dim, out_channels)
@@ -131,6 +132,15 @@ class lcgn_seq(nn.Module):
         p.bias = None if self.lcgn.bias is None else ptr(self.lcgn.bias, "b")
         out = torch.empty((N, O), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
+            # call-invariant weight forms (stacked blocks, bf16 pieces): rebuilt only when a weight tensor was
+            # replaced or modified in place (data_ptr / autograd version counter) or the mode changed
+            key = (d.node_bf16, str(x.device)) + tuple((t.data_ptr(), t._version) for t in keep)
+            if self._packed is None or self._packed_key != key:
+                nbytes = lib.gvqa_lcgn_pack_bytes(C.byref(d))
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+                _lib.check(lib.gvqa_lcgn_pack_weights(C.byref(d), C.byref(p), packed.data_ptr(), nbytes, _stream(x.device)))
+                self._packed, self._packed_key = packed, key
+            p.packed, p.packed_bytes = self._packed.data_ptr(), self._packed.numel()
             ws = _workspace(lib.gvqa_lcgn_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), x.device)
             _lib.check(lib.gvqa_lcgn_seq_forward(C.byref(graph.c), C.byref(d), C.byref(p), x.data_ptr(), q.data_ptr(),
                                                  lstm.data_ptr(), x_ctx_init.data_ptr(), out.data_ptr(), ws.data_ptr(),

@@ -312,7 +312,18 @@ typedef struct gvqa_lcgn_params {   /* lcgn_seq state_dict (lcgn.py:255-282), de
     const float* proj_cmd_weight;      /* lcgn.proj_cmd.weight [O, O]         */
     const float* cal_cmd_weight;       /* lcgn.cal_cmd.weight  [O, O]         */
     const float* bias;                 /* lcgn.bias [O] or NULL               */
+    const void* packed;                /* NULL, or the output of gvqa_lcgn_pack_weights for these weights
+                                          and dims (skips the per-call repacking of the weights)        */
+    size_t packed_bytes;
 } gvqa_lcgn_params;
+
+/* Call-invariant weight forms of lcgn_seq (stacked [lin_l; lin_r; cal_x] blocks, stacked qInput2 /
+ * proj_cmd / cal_cmd, and in the bf16 modes the bf16 pieces of the node-GEMM weights).  A caller whose
+ * weights do not change between forwards builds them once and passes them in params->packed; they must be
+ * rebuilt when any weight, or dims->{in,out}_channels / num_iters / node_bf16, changes. */
+size_t gvqa_lcgn_pack_bytes(const gvqa_lcgn_dims* d);
+int gvqa_lcgn_pack_weights(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, void* packed, size_t packed_bytes,
+                           void* stream);
 
 /* lcgn_seq.forward(x, edge_index, batch, q_encoding, lstm_outputs) in eval mode (lcgn.py:303-323).
  * x [N, in], q_encoding [B, Q], lstm_outputs [L, B, O], x_ctx_init [N, O] = the noise the reference

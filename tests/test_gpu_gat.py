@@ -672,7 +672,8 @@ def _lcgn_bf16_storage_emulation(x, edge_index, batch, q, lstm, p, x_ctx_init, T
     from oracle import ref_torch as R
     rb = lambda v: v.bfloat16().float()
     p = dict(p)
-    for k in ("proj_x_loc.1.weight", "lcgn.lin_l.weight", "lcgn.lin_r.weight", "lcgn.cal_x.weight", "proj_x_ctx.1.weight",
+    x = rb(x)                                              # the input features are node tensors too
+    for k in ("init_sg_emb_input.0.weight", "proj_x_loc.1.weight", "lcgn.lin_l.weight", "lcgn.lin_r.weight", "lcgn.cal_x.weight", "proj_x_ctx.1.weight",
               "output_layer.weight", "fin_layer.weight"):
         p[k] = _bf16_pieces(p[k], pieces)
     O = p["fin_layer.weight"].shape[0]

@@ -190,6 +190,12 @@ def test_every_entry_point_rejects_bad_arguments_without_gpu():
     ld1 = _lib.LcgnDims(8, 8, 8, 4, 5, 1, 0.2, 0)
     assert lib.gvqa_lcgn_seq_forward(C.byref(g), C.byref(ld1), C.byref(_lib.LcgnParams()), None, None, None, None, None,
                                      None, 0, None) == E_WS
+    assert lib.gvqa_lcgn_pack_bytes(C.byref(ld1)) > 15 * 64 * 4 and lib.gvqa_lcgn_pack_bytes(None) == 0
+    ld16 = _lib.LcgnDims(8, 8, 8, 4, 5, 1, 0.2, 1)
+    assert lib.gvqa_lcgn_pack_bytes(C.byref(ld16)) > lib.gvqa_lcgn_pack_bytes(C.byref(ld1))     # + bf16 weight pieces
+    assert lib.gvqa_lcgn_pack_weights(C.byref(ld1), C.byref(_lib.LcgnParams()), None, 0, None) == E_INV
+    assert lib.gvqa_linear_bf16(4, 4, 12, 2, None, 12, None, None, None, 0, None, 0, 0, None, 4, 0, None) == E_INV
+    assert lib.gvqa_pack_weight_bf16(4, 4, 3, None, 4, None, None) == E_INV
     assert lib.gvqa_attention_pool_forward(C.byref(g), 8, 8, C.byref(_lib.PoolParams()), None, None, None, None, 0, None) == E_INV
     assert lib.gvqa_answer_logits_forward(4, 8, 8, 10, C.byref(_lib.ClassifierParams()), None, None, None, None, 0, None) == E_INV
     assert lib.gvqa_sg_encoder_forward(C.byref(g), 50, 8, 12, 1, C.byref(_lib.EncoderParams()), None, None, None, 0, None,
