@@ -30,7 +30,8 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "gvqa.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"),
+               os.path.join(os.path.dirname(HERE), "include", "gvqa.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -24,10 +24,10 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 namespace gvqa {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A16: A is stored as bf16; C16: C, and the addend / mul operands of the epilogue, are stored as bf16
 // (leading dimensions are in elements of the respective type).  B (weights) and bias are fp32.
@@ -212,6 +212,120 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
             }
         }
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 128 x 128 tile (K % 32 == 0, 16-byte aligned rows).  The operand tiles go
+// HBM/L2 -> LDS with `global_load_lds_dwordx4`: no VGPR staging, no ds_write, nothing for the waves to
+// do between MFMAs but the fragment reads.  A K step is 32 floats = 128-byte tile rows, a wave
+// instruction fills 8 of them (64 lanes x 16 B, lane-linear), and the tile is XOR-swizzled -- slot
+// (row r, position q) holds k-chunk q ^ ((r >> 1) & 7), chosen by the lane through its GLOBAL address --
+// so the 32 rows of a ds_read_b128 fragment read spread over all 16-byte columns of the bank row.
+// The DMA is issued from inline asm and ordered by counted s_waitcnt vmcnt + barriers; tile t+1 lands
+// while tile t is multiplied (a K step is 64 MFMAs = 4096 issue cycles per wave, far longer than the
+// DMA latency).
+template <int NBUF>
+__global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb, LinearEpilogue ep,
+                                                        float* C, int64_t ldc, int vec_ep) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int TILE_BYTES = 128 * BK * 4;                  // one operand tile: 16 KiB
+    constexpr int STAGE_BYTES = BM * (BN + 4) * 4;
+    constexpr int OPER_BYTES = 2 * NBUF * TILE_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* pa[4];
+    const float* pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (j * 4 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        pa[j] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 4;
+        pb[j] = B + (int64_t)min(n0 + row, N - 1) * ldb + chunk * 4;
+    }
+    const int nt = K / BK;
+    auto issue = [&](int buf) {
+        const unsigned dst = lds_base + buf * 2 * TILE_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16_b(pa[j], __builtin_amdgcn_readfirstlane(dst + j * 4096));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16_b(pb[j], __builtin_amdgcn_readfirstlane(dst + TILE_BYTES + j * 4096));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] += BK; pb[j] += BK; }
+    };
+
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    unsigned xo[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
+    const unsigned a_row = (unsigned)((wr * 64 + frow) * 128), b_row = (unsigned)((wc * 64 + frow) * 128);
+
+    auto multiply = [&](int buf) {
+        const unsigned char* at = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* bt = at + TILE_BYTES;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(at + a_row + i * 32 * 128 + xo[kg]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const float4*>(bt + b_row + j * 32 * 128 + xo[kg]);
+            // k-major order: consecutive MFMAs hit different accumulators (a dependent MFMA is 4 issues away)
+#define GVQA_MFMA_K(c_)                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].c_, bf[j].c_, acc[i][j], 0, 0, 0);
+            GVQA_MFMA_K(x) GVQA_MFMA_K(y) GVQA_MFMA_K(z) GVQA_MFMA_K(w)
+#undef GVQA_MFMA_K
+        }
+    };
+    if (NBUF == 2) {
+        // issue t+1 -> wait t -> barrier -> multiply t -> barrier (buffer of t is refilled by the next issue)
+        issue(0);
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt) {
+                issue(cur ^ 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            multiply(cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // three buffers, ONE barrier per K step: wait t -> barrier -> issue t+2 (into the buffer every wave
+        // finished reading before it reached this barrier) -> multiply t
+        issue(0);
+        if (nt > 1) issue(1);
+        int cur = 0, nxt = 2;
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nt) issue(nxt);
+            multiply(cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (++cur == 3) cur = 0;
+            if (++nxt == 3) nxt = 0;
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    tile_epilogue<BM, BN, 2, 2, false>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -651,6 +765,16 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     else if (tile_sel == 1 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 4, 2);
     else if (tile_sel == 2 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 2, 2);
     else if (tile_sel == 3) GVQA_LAUNCH_LINEAR(128, 128, 4, 2);
+    // LDS-DMA staging (2 / 3 buffers): the default for chip-filling products with whole K steps (+10 % over the
+    // register-staged kernel at the config-3 projection); GVQA_GEMM_TILE=5/6 force the register-staged kernels
+    else if ((tile_sel == 7 || tile_sel == 8 || (tile_sel == 0 && cdiv(M, 128) * cdiv(N, 128) >= 256)) && batch == 1 &&
+             K % 32 == 0 && vec) {
+        dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128));
+        auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
+        const int vec_ep = N % 8 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul);
+        if (tile_sel != 8) hipLaunchKernelGGL(k_linear_f32_dma<2>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, vec_ep);
+        else hipLaunchKernelGGL(k_linear_f32_dma<3>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, vec_ep);
+    }
     // short K: K step 16, 3 blocks/CU (+4.5 % at K = 512) -- unless the grid cannot fill the chip anyway: a lone
     // block per CU is bound by the latency of its serial K steps, and K step 32 halves their number
     else if (tile_sel == 5 || (tile_sel == 0 && K <= 1024 && cdiv(M, 128) * cdiv(N, 128) * batch >= 256)) {
