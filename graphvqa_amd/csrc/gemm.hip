@@ -273,7 +273,15 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
     for (int kg = 0; kg < 4; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
     const unsigned a_row = (unsigned)((wr * 64 + frow) * 128), b_row = (unsigned)((wc * 64 + frow) * 128);
 
-    auto multiply = [&](int buf) {
+    auto issue2 = [&](int buf, int q) {          // quarter q of a tile's DMAs: A rows and B rows of one 32-row group
+        const unsigned dst = lds_base + buf * 2 * TILE_BYTES + wave * 1024 + q * 4096;
+        lds_dma16_b(pa[q], __builtin_amdgcn_readfirstlane(dst));
+        lds_dma16_b(pb[q], __builtin_amdgcn_readfirstlane(dst + TILE_BYTES));
+        pa[q] += BK; pb[q] += BK;
+    };
+    // multiply tile `buf`; pf >= 0: also DMA the next tile into buffer pf, a quarter per k group, issued
+    // between MFMA groups so that the M0 set-up / address traffic hides under matrix-core time
+    auto multiply = [&](int buf, int pf) {
         const unsigned char* at = smem + buf * 2 * TILE_BYTES;
         const unsigned char* bt = at + TILE_BYTES;
 #pragma unroll
@@ -287,26 +295,25 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
 #define GVQA_MFMA_K(c_)                                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].c_, bf[j].c_, acc[i][j], 0, 0, 0);
-            GVQA_MFMA_K(x) GVQA_MFMA_K(y) GVQA_MFMA_K(z) GVQA_MFMA_K(w)
+            GVQA_MFMA_K(x)
+            if (pf >= 0) issue2(pf, kg);
+            GVQA_MFMA_K(y) GVQA_MFMA_K(z) GVQA_MFMA_K(w)
 #undef GVQA_MFMA_K
         }
     };
     if (NBUF == 2) {
-        // issue t+1 -> wait t -> barrier -> multiply t -> barrier (buffer of t is refilled by the next issue)
+        // ONE barrier per K step: wait t (issued a whole step ago) -> barrier -> multiply t while DMAing t+1
+        // into the other buffer.  The barrier serves both orders: tile t has landed for every wave, and
+        // every wave has finished reading the buffer of step t-1 before anyone refills it.
         issue(0);
         for (int t = 0; t < nt; ++t) {
             const int cur = t & 1;
-            if (t + 1 < nt) {
-                issue(cur ^ 1);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            multiply(cur);
+            multiply(cur, t + 1 < nt ? (cur ^ 1) : -1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
         }
+        __builtin_amdgcn_s_barrier();
     } else {
         // three buffers, ONE barrier per K step: wait t -> barrier -> issue t+2 (into the buffer every wave
         // finished reading before it reached this barrier) -> multiply t
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (t + 2 < nt) issue(nxt);
-            multiply(cur);
+            multiply(cur, -1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (++cur == 3) cur = 0;
             if (++nxt == 3) nxt = 0;

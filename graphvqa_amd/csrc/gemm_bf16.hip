@@ -191,16 +191,27 @@ __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, in
     for (int kg = 0; kg < 4; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
     const unsigned a_row = (unsigned)((wr * 64 + frow) * 128), b_row = (unsigned)((wc * 64 + frow) * 128);
 
+    int a_adv = BK;
+    auto issue2 = [&](int buf, int q) {          // quarter q of a tile's DMAs (A rows and B rows of one 32-row group)
+        const unsigned dst = lds_base + buf * 2 * TILE_BYTES + wave * 1024 + q * 4096;
+        lds_dma16_b(pa[q], __builtin_amdgcn_readfirstlane(dst));
+        lds_dma16_b(pb[q], __builtin_amdgcn_readfirstlane(dst + TILE_BYTES));
+        pb[q] += BK;
+        pa[q] += a_adv;
+    };
+    // ONE barrier per K step: wait t (issued a whole step ago) -> barrier -> multiply t while DMAing t+1 into
+    // the other buffer, a quarter per k group between the MFMAs.  The barrier orders both hazards: tile t has
+    // landed for every wave, and every wave is done reading the buffer of step t-1 before anyone refills it.
     issue(0);
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
-            issue(cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's 8 DMAs of tile t have landed
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool more = t + 1 < nt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (more) {                                            // A k-offset of the tile after next: wraps at a piece boundary
+            a_adv = (--a_wrap == 0) ? BK - K : BK;
+            if (a_wrap == 0) a_wrap = nk;
         }
-        __builtin_amdgcn_s_barrier();                          // ... and every other wave's
         const unsigned char* at = smem + cur * 2 * TILE_BYTES;
         const unsigned char* bt = at + TILE_BYTES;
 #pragma unroll
@@ -212,15 +223,15 @@ __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, in
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bt + b_row + j * 32 * 128 + xo[kg]));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[0][1], 0, 0, 0);
+            if (more) issue2(cur ^ 1, kg);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[1][1], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // all fragment reads of `cur` retired before it is refilled
     }
+    __builtin_amdgcn_s_barrier();
     tile_epilogue<BM, BN, WR, WC, C16>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
 }
 

@@ -4,7 +4,9 @@
 //   mode 0: MFMAs only (operands constant registers)            -> pure matrix-core issue rate
 //   mode 1: + ds_read_b128 fragment reads from a static LDS tile -> LDS feed
 //   mode 2: + one barrier per K step
-//   mode 3: + LDS-DMA of the next tile (global_load_lds) and counted vmcnt (the k_linear_f32_dma loop)
+//   mode 3: + LDS-DMA of the next tile (global_load_lds) issued at the top of the step, counted vmcnt, 2 barriers
+//   mode 4: mode 3 + the direct global store of the tile
+//   mode 5: ONE barrier per step, the next tile's DMA interleaved into this tile's MFMA stream
 // Every wave records shader-clock cycles (s_memtime) and the 100 MHz wall clock (s_memrealtime) around the
 // loop: cycles per MFMA and the implied core clock come out directly.
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_f32_probe mfma_f32_probe.hip ; run: ./mfma_f32_probe [blocks_per_cu]
@@ -53,10 +55,17 @@ __global__ __launch_bounds__(256) void k_probe(const float* __restrict__ A, int6
     float4 ca = make_float4(1.f + lane, 2.f, 3.f, 4.f), cb = make_float4(0.5f, 0.25f, 0.125f, 1.f);
 
     if (MODE >= 3) issue(0);
+    auto issue2 = [&](int buf, int j0) {     // two of the eight DMAs of a tile
+        const unsigned dst = lds_base + buf * 2 * TILE + wave * 1024;
+#pragma unroll
+        for (int j = j0; j < j0 + 2; ++j) { lds_dma16(pa[j], __builtin_amdgcn_readfirstlane(dst + j * 4096)); pa[j] += 32; }
+    };
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int t = 0; t < ksteps; ++t) {
         const int cur = t & 1;
-        if (MODE >= 3) {
+        if (MODE == 5) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (MODE >= 3) {
             if (t + 1 < ksteps) { issue(cur ^ 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -79,10 +88,12 @@ __global__ __launch_bounds__(256) void k_probe(const float* __restrict__ A, int6
 #define MFMA_K(c_)                                                                                      \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].c_, bf[j].c_, acc[i][j], 0, 0, 0);
-            MFMA_K(x) MFMA_K(y) MFMA_K(z) MFMA_K(w)
+            MFMA_K(x)
+            if (MODE == 5 && t + 1 < ksteps) issue2(cur ^ 1, kg * 2);
+            MFMA_K(y) MFMA_K(z) MFMA_K(w)
 #undef MFMA_K
         }
-        if (MODE >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (MODE >= 3) __builtin_amdgcn_s_barrier(); }
+        if (MODE >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (MODE >= 3 && MODE != 5) __builtin_amdgcn_s_barrier(); }
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     if (MODE == 4) {      // the GEMM's direct epilogue: 64 stores of 128-byte row segments per lane pair
@@ -139,5 +150,6 @@ int main(int argc, char** argv) {
     run<2>(blocks, ksteps, A, lda, sink, stamps, Cout);
     run<3>(blocks, ksteps, A, lda, sink, stamps, Cout);
     run<4>(blocks, ksteps, A, lda, sink, stamps, Cout);
+    run<5>(blocks, ksteps, A, lda, sink, stamps, Cout);
     return 0;
 }
