@@ -119,6 +119,7 @@ def cpu_baseline(params):
 
 
 def main():
+    torch.set_grad_enabled(False)       # inference benchmark: the fused path (gradients route gat_seq to the differentiable one)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

@@ -56,7 +56,15 @@ class GatMpDesc(C.Structure):
                 ("graph_scale", C.c_void_p), ("graph_scale_ld", C.c_int64), ("skip", C.c_void_p),
                 ("skip_ld", C.c_int64), ("bias", C.c_void_p), ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p),
                 ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int64),
-                ("alpha_out", C.c_void_p), ("force", C.c_int32)]
+                ("alpha_out", C.c_void_p), ("alpha_mask", C.c_void_p), ("force", C.c_int32)]
+
+
+class GatMpBwdDesc(C.Structure):
+    """Mirror of `struct gvqa_gat_mp_bwd_desc`."""
+    _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("negative_slope", C.c_float), ("xp", C.c_void_p), ("xp_ld", C.c_int64),
+                ("a_node", C.c_void_p), ("a_edge", C.c_void_p), ("a_edge_stride", C.c_int64), ("alpha", C.c_void_p),
+                ("alpha_mask", C.c_void_p), ("dout", C.c_void_p), ("dout_ld", C.c_int64), ("dxp", C.c_void_p),
+                ("dxp_ld", C.c_int64), ("da_node", C.c_void_p), ("da_edge", C.c_void_p)]
 
 
 class BnParams(C.Structure):
@@ -176,6 +184,10 @@ PROTOTYPES = {
                                           C.POINTER(EncoderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]),
+    "gvqa_graph_rows_to_nodes": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                           C.c_void_p]),
+    "gvqa_graph_segment_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_gat_mp_backward": (C.c_int, [C.POINTER(Graph), C.POINTER(Graph), C.POINTER(GatMpBwdDesc), C.c_void_p]),
     "gvqa_gat_mp_plan": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.POINTER(MpPlan)]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -129,7 +129,8 @@ struct MpArgs {
     const float* bn_v;
     float* out;               // [N, out_ld]
     int64_t out_ld;
-    float* alpha_out;         // NULL or [E, H] COO order
+    float* alpha_out;         // NULL or [E, H] COO order (the softmax output, before the mask)
+    const float* alpha_mask;  // NULL or [E, H] COO order: multiplies alpha after the softmax (attention dropout)
     float* alpha_csr;         // general kernel only: [E, H] in CSR slot order
     int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
     int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
@@ -312,9 +313,10 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         }
         const float den = sum + 1e-16f;
         for (int s = lo; s < hi; ++s) {
-            const float al = alpha_s[s * H + h] / den;
-            alpha_s[s * H + h] = al;
+            float al = alpha_s[s * H + h] / den;
             if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+            if (a.alpha_mask) al *= a.alpha_mask[(int64_t)a.csr_eid[e0 + s] * H + h];
+            alpha_s[s * H + h] = al;
         }
     }
 
@@ -483,9 +485,10 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     }
     const float den = sum + 1e-16f;
     for (int s = lo; s < hi; ++s) {
-        const float al = a.alpha_csr[(int64_t)s * H + h] / den;
-        a.alpha_csr[(int64_t)s * H + h] = al;
+        float al = a.alpha_csr[(int64_t)s * H + h] / den;
         if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[s] * H + h] = al;
+        if (a.alpha_mask) al *= a.alpha_mask[(int64_t)a.csr_eid[s] * H + h];
+        a.alpha_csr[(int64_t)s * H + h] = al;
     }
 }
 
@@ -624,7 +627,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.skip = d->skip; a.skip_ld = d->skip_ld ? d->skip_ld : C;
     a.bias = d->bias;
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
-    a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_csr = nullptr;
+    a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_mask = d->alpha_mask; a.alpha_csr = nullptr;
     a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0;
     a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
     const int force = d->force;

@@ -5,6 +5,8 @@
 // Integer work, HBM-bound and tiny (E ~ 1e5..1e6): a counting sort by destination with an
 // in-row rank pass that orders every row by original edge id, so that per-node reductions run
 // in the reference's COO order (deterministic, run-to-run bit-identical).
+#include <algorithm>
+
 #include "common.h"
 
 namespace gvqa {
@@ -282,6 +284,60 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream_) {
     GVQA_REQUIRE(g->valid, GVQA_E_GRAPH,
                  "graph violates the input contract (edge index out of [0,N), or batch not "
                  "non-decreasing in [0,B))");
+    return GVQA_OK;
+}
+
+// ---- per-graph rows <-> node rows (training glue: the instruction halves of the concatenations) -----------
+// out[i, :] = rows[node_graph[i], :]  and its adjoint  out[b, :] = sum_{i in graph b} x[i, :]  (nodes of a graph
+// are contiguous: graph_ptr).  Deterministic; one thread per column, rows in order.
+namespace gvqa {
+__global__ __launch_bounds__(256) void k_graph_rows_to_nodes(int64_t N, int F, const int32_t* __restrict__ node_graph,
+                                                             const float* __restrict__ rows, int64_t ldr, float* __restrict__ out,
+                                                             int64_t ldo, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= F) return;
+    for (int64_t i = blockIdx.y; i < N; i += gridDim.y) {
+        const float v = rows[(int64_t)node_graph[i] * ldr + c];
+        float* o = out + i * ldo + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+__global__ __launch_bounds__(256) void k_graph_segment_sum(int F, const int32_t* __restrict__ graph_ptr, const float* __restrict__ x,
+                                                           int64_t ldx, float* __restrict__ out, int64_t ldo) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= F) return;
+    float acc = 0.f;
+    for (int i = graph_ptr[b]; i < graph_ptr[b + 1]; ++i) acc += x[(int64_t)i * ldx + c];
+    out[(int64_t)b * ldo + c] = acc;
+}
+}  // namespace gvqa
+
+int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
+                             int accumulate, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_rows_to_nodes: graph not built");
+    GVQA_REQUIRE(F >= 0 && F < (1ll << 31) && ld_rows >= F && ld_out >= F, GVQA_E_INVALID, "graph_rows_to_nodes: bad sizes");
+    if (g->num_nodes == 0 || F == 0) return GVQA_OK;
+    GVQA_REQUIRE(rows && out, GVQA_E_INVALID, "graph_rows_to_nodes: null tensor");
+    const dim3 grid((unsigned)cdiv(F, 256), (unsigned)std::min<int64_t>(g->num_nodes, 8192));
+    hipLaunchKernelGGL(k_graph_rows_to_nodes, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g->num_nodes, (int)F,
+                       g->node_graph, rows, ld_rows, out, ld_out, accumulate);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_segment_sum: graph not built");
+    GVQA_REQUIRE(F >= 0 && F < (1ll << 31) && ld_x >= F && ld_out >= F && g->num_graphs <= 65535 * 16, GVQA_E_INVALID,
+                 "graph_segment_sum: bad sizes");
+    if (g->num_graphs == 0 || F == 0) return GVQA_OK;
+    GVQA_REQUIRE((x || g->num_nodes == 0) && out, GVQA_E_INVALID, "graph_segment_sum: null tensor");
+    GVQA_REQUIRE(g->num_graphs <= 65535, GVQA_E_UNSUPPORTED, "graph_segment_sum: more than 65535 graphs");
+    const dim3 grid((unsigned)cdiv(F, 256), (unsigned)g->num_graphs);
+    hipLaunchKernelGGL(k_graph_segment_sum, grid, dim3(256), 0, static_cast<hipStream_t>(stream), (int)F, g->graph_ptr, x, ld_x, out,
+                       ld_out);
+    GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
 

@@ -7,11 +7,14 @@ reference (`gat`: gat_skip.py:60-63,111-112; `gat_seq`: gat_skip.py:224-225,249)
 (pipeline_model_gat.py:823-836).  The compute runs in hand-written HIP kernels behind the
 C ABI of include/gvqa.h; torch only provides device memory and the current stream.
 
-Scope: forward.  `.eval()` (running-statistics BatchNorm, dropout inactive) is the measured path;
-`.train()` with dropout p == 0 runs the batch-statistics BatchNorm forward and updates the running
-statistics like torch; `.train()` with p > 0 is not reproducible against torch's RNG and raises.
-Backward is a "next" row.  There is no CPU path: CPU
-tensors raise, and a missing HIP library raises at construction.
+Scope: `.eval()` under `torch.no_grad()` (running-statistics BatchNorm, dropout inactive) is the measured,
+fully fused path.  When gradients are needed (or in `.train()` with dropout p > 0) `gat_seq.forward` runs
+the differentiable formulation: the message passing -- gather, segment softmax, weighted scatter-add, head
+mean -- and its backward are the HIP kernels (`gvqa_gat_message_passing` / `gvqa_gat_mp_backward` behind
+`gat_message_passing`, a `torch.autograd.Function`), the dense projections, BatchNorm and dropout are torch
+ops on the device, so autograd produces the gradients of every parameter and input.
+`.train()` with p == 0 and no gradient needed keeps the fused batch-statistics forward.  There is no CPU
+path: CPU tensors raise, and a missing HIP library raises at construction.
 """
 from __future__ import annotations
 
@@ -44,6 +47,97 @@ def _f32c(t: Tensor, name: str) -> Tensor:
 
 def _workspace(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class _GatMessagePassing(torch.autograd.Function):
+    """out[i] = (1/H) sum_h sum_{e -> i} alpha[e,h] mask[e,h] xp[src_e, h, :],  alpha = softmax over the in-edges
+    of leaky_relu(a_node[src,h] + a_node[dst,H+h] + a_edge[e,h])   (gat_skip.py:155,183-208,162-165).
+    Forward and backward are HIP kernels; returns (out [N, C], alpha [E, H])."""
+
+    @staticmethod
+    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope):
+        lib = _lib.load()
+        xp, a_node, a_edge = _f32c(xp, "xp"), _f32c(a_node, "a_node"), _f32c(a_edge, "a_edge")
+        if mask is not None:
+            mask = _f32c(mask, "alpha_mask")
+        N, E, dev = graph.num_nodes, graph.num_edges, xp.device
+        if xp.shape != (N, heads * channels) or a_node.shape != (N, 2 * heads) or a_edge.shape != (E, heads):
+            raise ValueError("gat_message_passing: operand shapes do not match the graph")
+        out = torch.empty((N, channels), dtype=torch.float32, device=dev)
+        alpha = torch.empty((E, heads), dtype=torch.float32, device=dev)
+        m = _lib.GatMpDesc()
+        m.C, m.H, m.negative_slope, m.bn_eps = channels, heads, slope, 1e-5
+        m.xp, m.a_node, m.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
+        m.out, m.alpha_out, m.alpha_mask = out.data_ptr(), alpha.data_ptr(), _ptr(mask)
+        with torch.cuda.device(dev):
+            ws = _workspace(4 * E * heads, dev)
+            _lib.check(lib.gvqa_gat_message_passing(C.byref(graph.c), C.byref(m), ws.data_ptr(), ws.numel(), _stream(dev)))
+        ctx.save_for_backward(xp, a_node, a_edge, alpha, mask)
+        ctx.graph, ctx.dims = graph, (heads, channels, slope)
+        ctx.mark_non_differentiable(alpha)
+        return out, alpha
+
+    @staticmethod
+    def backward(ctx, dout, _dalpha):
+        lib = _lib.load()
+        xp, a_node, a_edge, alpha, mask = ctx.saved_tensors
+        heads, channels, slope = ctx.dims
+        graph, dev = ctx.graph, xp.device
+        dout = dout.contiguous()
+        dxp, da_node, da_edge = torch.empty_like(xp), torch.empty_like(a_node), torch.empty_like(a_edge)
+        d = _lib.GatMpBwdDesc()
+        d.C, d.H, d.negative_slope = channels, heads, slope
+        d.xp, d.a_node, d.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
+        d.alpha, d.alpha_mask, d.dout = alpha.data_ptr(), _ptr(mask), dout.data_ptr()
+        d.dxp, d.da_node, d.da_edge = dxp.data_ptr(), da_node.data_ptr(), da_edge.data_ptr()
+        with torch.cuda.device(dev):
+            gt = graph.transposed()
+            _lib.check(lib.gvqa_gat_mp_backward(C.byref(graph.c), C.byref(gt.c), C.byref(d), _stream(dev)))
+        return dxp, da_node, da_edge, None, None, None, None, None
+
+
+class _AddGraphRows(torch.autograd.Function):
+    """x[i, :] += rows[graph(i), :] in place (x must be a fresh intermediate).  Backward: dx = dout,
+    drows[b] = sum of dout over the nodes of graph b -- both HIP kernels, deterministic (the gather's native
+    backward is a sort-based index_put)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, graph):
+        lib = _lib.load()
+        rows = _f32c(rows, "rows")
+        if not x.is_contiguous() or x.dtype != torch.float32 or x.shape[0] != graph.num_nodes or \
+                rows.shape != (graph.num_graphs, x.shape[1]):
+            raise ValueError("add_graph_rows: x must be contiguous fp32 [N, F], rows [B, F]")
+        with torch.cuda.device(x.device):
+            _lib.check(lib.gvqa_graph_rows_to_nodes(C.byref(graph.c), x.shape[1], rows.data_ptr(), rows.shape[1], x.data_ptr(),
+                                                    x.shape[1], 1, _stream(x.device)))
+        ctx.mark_dirty(x)
+        ctx.graph = graph
+        return x
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        graph = ctx.graph
+        dout = dout.contiguous()
+        drows = torch.empty((graph.num_graphs, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            _lib.check(lib.gvqa_graph_segment_sum(C.byref(graph.c), dout.shape[1], dout.data_ptr(), dout.shape[1],
+                                                  drows.data_ptr(), drows.shape[1], _stream(dout.device)))
+        return dout, drows, None
+
+
+def add_graph_rows(x: Tensor, rows: Tensor, graph: SceneGraphBatch) -> Tensor:
+    """x [N, F] (a fresh intermediate, updated in place) + rows[graph of node] ([B, F]); differentiable in both."""
+    return _AddGraphRows.apply(x, rows, graph)
+
+
+def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: SceneGraphBatch, heads: int, channels: int,
+                        negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None):
+    """Differentiable GAT message passing on the HIP kernels: (out [N, C], alpha [E, H]).
+    xp [N, H*C] projected features, a_node [N, 2H] = (a_l | a_r), a_edge [E, H]; alpha_mask [E, H] multiplies alpha
+    after the softmax (attention dropout: mask / (1 - p))."""
+    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope)
 
 
 class gat(torch.nn.Module):
@@ -171,11 +265,6 @@ class gat_seq(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph: Optional[SceneGraphBatch] = None,
                 return_attention_weights: bool = False, return_hops: bool = False):
-        if self.training and self.dropout > 0:
-            raise NotImplementedError(
-                "gat_seq.train() with dropout p > 0 is not implemented on the HIP path (the masks are not "
-                "reproducible against torch's RNG); use .eval(), or dropout=0 for the train-mode BatchNorm "
-                "forward.  Backward is a 'next' row (SURVEY 8f-4).")
         lib = _lib.load()
         assert x.dim() == 2, "Static graphs not supported in `GATConv`."
         x = _f32c(x, "x")
@@ -192,6 +281,11 @@ class gat_seq(torch.nn.Module):
             graph = SceneGraphBatch(edge_index, batch, N, B)
         elif graph.num_nodes != N or graph.num_edges != E or graph.num_graphs != B:
             raise ValueError("prebuilt graph does not match the inputs")
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or instr.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if needs_grad or (self.training and self.dropout > 0):
+            return self._forward_autograd(x, edge_index, edge_attr, instr, batch, graph, return_attention_weights,
+                                          return_hops)
         if not graph.intra_graph:
             return self._forward_unfolded(x, edge_index, edge_attr, instr, batch, graph)
         H, Cc = self.heads, self.out_channels
@@ -238,6 +332,63 @@ class gat_seq(torch.nn.Module):
                 bn.running_mean.mul_(1 - mom).add_(stats[j, 0], alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(unbiased, alpha=mom)
         return out
+
+    def _forward_autograd(self, x, edge_index, edge_attr, instr, batch, graph, return_attention_weights=False,
+                          return_hops=False, alpha_masks=None, feature_masks=None):
+        """Differentiable forward (training): per hop, gat_skip.py:254-276 with the instruction halves of the two
+        concatenations applied per graph instead of per row --
+            xp      = h W_h^T + (ins W_i^T)[batch]                  (lin_l on [h | ins[batch]], :133,263-264)
+            a_l|a_r = h V_n + (ins U_n)[batch],   a_e = edge_attr V_e   (att_* folded into lin_l / lin_e, :134-135,150-151;
+                      the edge's own instruction term ins[batch[src]] U_e, :257-260, is carried by a_l)
+        -- the per-graph rows are added and back-propagated by HIP kernels (gvqa_graph_rows_to_nodes / _segment_sum) --
+        then the HIP message passing (and its HIP backward), + bias, skip, BatchNorm, ReLU, dropout as torch
+        ops.  Attention dropout (:205) is a mask on alpha drawn with torch's generator (not the reference's
+        stream: dropout masks are not reproducible across implementations); `alpha_masks` / `feature_masks`
+        (lists, one per hop) override the drawn masks (tests)."""
+        import torch.nn.functional as F
+        K, H, Cc = len(self.convs), self.heads, self.out_channels
+        N, E = x.shape[0], edge_index.shape[1]
+        Dn, De = self.in_channels, self.edge_attr_dim
+        p = self.dropout if self.training else 0.0
+        h = x
+        alphas, hops = [], []
+        for i, conv in enumerate(self.convs):
+            ins = instr[i]
+            W, We = conv.lin_l.weight, conv.lin_e.weight
+            Di = W.shape[1] - Dn
+            W_h3, W_i3 = W[:, :Dn].reshape(H, Cc, Dn), W[:, Dn:].reshape(H, Cc, Di)
+            att_l, att_r, att_e = conv.att_l.view(H, Cc), conv.att_r.view(H, Cc), conv.att_e.view(H, Cc)
+            # projected features: node half per row, instruction half per graph
+            xp = add_graph_rows(F.linear(h, W[:, :Dn]), F.linear(ins, W[:, Dn:]), graph)
+            # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
+            # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
+            V_n = torch.cat((torch.einsum("hck,hc->kh", W_h3, att_l), torch.einsum("hck,hc->kh", W_h3, att_r)), dim=1)
+            V_e = torch.einsum("hck,hc->kh", We[:, :De].reshape(H, Cc, De), att_e)
+            U_e = torch.einsum("hck,hc->kh", We[:, De:].reshape(H, Cc, We.shape[1] - De), att_e)
+            U_n = torch.cat((torch.einsum("hck,hc->kh", W_i3, att_l) + U_e, torch.einsum("hck,hc->kh", W_i3, att_r)), dim=1)
+            a_node = add_graph_rows(h @ V_n, ins @ U_n, graph)
+            a_edge = edge_attr @ V_e
+            mask = None
+            if alpha_masks is not None:
+                mask = alpha_masks[i]
+            elif p > 0:
+                mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p)
+            out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask)
+            if conv.bias is not None:
+                out = out + conv.bias
+            h = out + h
+            if i != K - 1:
+                h = torch.relu(self.bns[i](h))
+                if feature_masks is not None:
+                    h = h * feature_masks[i]
+                else:
+                    h = F.dropout(h, p=p, training=p > 0)
+            alphas.append(alpha)
+            hops.append(h)
+        if return_attention_weights or return_hops:
+            return (h, torch.stack(alphas) if return_attention_weights else None,
+                    torch.stack(hops) if return_hops else None)
+        return h
 
     def _forward_unfolded(self, x, edge_index, edge_attr, instr, batch, graph):
         """Batches whose edges cross graphs (never produced by the reference's collate): run the

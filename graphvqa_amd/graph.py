@@ -52,6 +52,14 @@ class SceneGraphBatch:
                                             self._ws.numel(), _stream(dev), C.byref(self.c)))
             _lib.check(lib.gvqa_graph_finalize(C.byref(self.c), _stream(dev)))
 
+    def transposed(self) -> "SceneGraphBatch":
+        """CSR by SOURCE of the same batch (flipped edge_index; same COO edge ids): what the backward of the
+        message passing walks to scatter gradients to source nodes without atomics.  Built once, cached."""
+        if getattr(self, "_transposed", None) is None:
+            edge_index, batch = self._keep
+            self._transposed = SceneGraphBatch(edge_index.flip(0), batch, self.num_nodes, self.num_graphs)
+        return self._transposed
+
     # statistics ------------------------------------------------------------------------------
     @property
     def max_graph_nodes(self): return self.c.max_graph_nodes

@@ -149,6 +149,13 @@ int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, co
                                  const float* x, const float* edge_attr, const float* instr, float* out,
                                  float* bn_stats_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Per-graph rows <-> node rows (glue of the differentiable path: the per-graph instruction terms).
+ * rows_to_nodes: out[i, :F] (= or +=) rows[graph(i), :F];  segment_sum (its adjoint): out[b, :F] = sum of x[i, :F]
+ * over the nodes of graph b.  Deterministic. */
+int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
+                             int accumulate, void* stream);
+int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Building blocks exported for tests, benchmarks and the variants' host code
  * ---------------------------------------------------------------------------------------- */
@@ -206,11 +213,37 @@ typedef struct gvqa_gat_mp_desc {
     const float* bn_var;
     float* out;                 /* [N, out_ld]                                                       */
     int64_t out_ld;             /* 0 -> C                                                            */
-    float* alpha_out;           /* NULL or [E, H] in COO edge order                                  */
+    float* alpha_out;           /* NULL or [E, H] in COO edge order (softmax output, before alpha_mask) */
+    const float* alpha_mask;    /* NULL or [E, H] in COO edge order: multiplies alpha after the softmax
+                                   (attention dropout, gat_skip.py:205: mask / (1 - p))              */
     int32_t force;              /* 0 = auto, 1 = LDS-tiled kernel, 2 = general CSR kernel            */
 } gvqa_gat_mp_desc;
 /* ws: >= 4*E*H bytes, used by the general kernel only. */
 int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of gvqa_gat_message_passing in its bare form (no graph terms / scale / bias / skip / BN:
+ * out[i] = (1/H) sum_h sum_{e->i} alpha[e,h] mask[e,h] xp[src_e,h,:]) -- what autograd does through PyG's
+ * gather / utils.softmax / scatter_add (gat_skip.py:155,183-208) and the head mean (:162-165); the "next"
+ * row SURVEY 8f-4.  `g` is the forward graph, `gt` the TRANSPOSED one: gvqa_graph_build + finalize on the
+ * flipped edge_index (row 0 <-> row 1) of the same batch.  Deterministic (no atomics). */
+typedef struct gvqa_gat_mp_bwd_desc {
+    int32_t C, H;
+    float negative_slope;
+    const float* xp;            /* [N, xp_ld] as given to the forward                                   */
+    int64_t xp_ld;              /* 0 -> H*C                                                              */
+    const float* a_node;        /* [N, 2H] or NULL, as given to the forward                              */
+    const float* a_edge;        /* as given to the forward                                               */
+    int64_t a_edge_stride;      /* 0 -> H                                                                */
+    const float* alpha;         /* [E, H] COO: alpha_out of the forward                                  */
+    const float* alpha_mask;    /* NULL or [E, H] COO, as given to the forward                           */
+    const float* dout;          /* [N, dout_ld]: gradient of the loss w.r.t. out                         */
+    int64_t dout_ld;            /* 0 -> C                                                                */
+    float* dxp;                 /* [N, dxp_ld]  (written, not accumulated)                               */
+    int64_t dxp_ld;             /* 0 -> H*C                                                              */
+    float* da_node;             /* [N, 2H]                                                               */
+    float* da_edge;             /* [E, H] COO                                                            */
+} gvqa_gat_mp_bwd_desc;
+int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_gat_mp_bwd_desc* d, void* stream);
 
 /* Host-only introspection: the geometry gvqa_gat_message_passing would use for this (finalized)
  * graph -- LDS-tiled streaming kernel or general CSR kernels -- without launching anything. */

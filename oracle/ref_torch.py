@@ -57,7 +57,7 @@ def scatter_add_rows(msg: torch.Tensor, index: torch.Tensor, num_rows: int) -> t
 # gat  (gat_skip.py:16-213)
 # ----------------------------------------------------------------------------
 def gat_conv(x, edge_index, edge_attr, p, prefix="", heads=4, negative_slope=0.2,
-             concat=False, return_attention_weights=False):
+             concat=False, return_attention_weights=False, alpha_mask=None):
     """One `gat` hop, eval mode (attention dropout inactive; gat_skip.py:190).
 
     x [N, in], edge_attr [E, edge_in]; lin_l is shared with lin_r for int
@@ -82,7 +82,8 @@ def gat_conv(x, edge_index, edge_attr, p, prefix="", heads=4, negative_slope=0.2
     alpha = alpha + a_e                                        # :185
     alpha = F.leaky_relu(alpha, negative_slope)                # :187
     alpha = segment_softmax(alpha, dst, N)                     # :188
-    msg = xp.index_select(0, src) * alpha.unsqueeze(-1)        # :208
+    alpha_d = alpha if alpha_mask is None else alpha * alpha_mask   # :205 F.dropout(alpha) with a given mask / (1 - p)
+    msg = xp.index_select(0, src) * alpha_d.unsqueeze(-1)      # :208
     out = scatter_add_rows(msg, dst, N)                        # aggregate (aggr='add')
     out = out.view(-1, H * C) if concat else out.mean(dim=1)   # :162-165
     if bias is not None:
@@ -104,7 +105,7 @@ def batchnorm_train(h, p, prefix, eps=1e-5):
 
 
 def gat_seq(x, edge_index, edge_attr, instr_vectors, batch, p, heads=4, negative_slope=0.2,
-            training_bn=False, return_all=False):
+            training_bn=False, return_all=False, alpha_masks=None, feature_masks=None):
     """`gat_seq.forward` (gat_skip.py:249-279): K hops of instruction-conditioned GAT with
     skip connection, then BN -> ReLU (-> dropout, inactive) on all but the last hop."""
     K = instr_vectors.shape[0]
@@ -116,11 +117,13 @@ def gat_seq(x, edge_index, edge_attr, instr_vectors, batch, p, heads=4, negative
         edge_cat = torch.cat((edge_attr, ins.index_select(0, edge_batch)), -1)  # :259-260
         x_cat = torch.cat((h, ins.index_select(0, batch)), -1)                  # :263-264
         conv, alpha = gat_conv(x_cat, edge_index, edge_cat, p, f"convs.{i}.", heads,
-                               negative_slope, False, True)
+                               negative_slope, False, True, None if alpha_masks is None else alpha_masks[i])
         h = conv + h                                                            # :270
         if i != K - 1:                                                          # :273-276
             h = (batchnorm_train if training_bn else batchnorm_eval)(h, p, f"bns.{i}.")
             h = F.relu(h)
+            if feature_masks is not None:                                       # :276 F.dropout with a given mask
+                h = h * feature_masks[i]
         hs.append(h)
         alphas.append(alpha)
     if return_all:

@@ -3,6 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+torch.set_grad_enabled(False)      # inference measurements: fused path
 from graphvqa_amd import synth, _lib
 from graphvqa_amd.gat_skip import gat_seq
 dev = torch.device("cuda:0"); tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)

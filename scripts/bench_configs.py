@@ -10,6 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+torch.set_grad_enabled(False)      # inference measurements: fused path
 
 from graphvqa_amd import synth, _lib
 from graphvqa_amd.graph import SceneGraphBatch

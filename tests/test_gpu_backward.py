@@ -1,0 +1,172 @@
+"""GPU tests of the differentiable path: HIP message-passing backward against torch autograd through
+the oracle's restatement of PyG's gather / segment softmax / scatter-add, and gat_seq parameter / input gradients
+against autograd through the oracle's gat_seq.  Tolerances are relative to the gradient's scale."""
+import numpy as np
+import pytest
+import torch
+
+from graphvqa_amd import synth
+from tests.util import t, tparams, maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b, floor=0.0):
+    """max-abs error relative to the reference gradient's scale (`floor`: scale below which a gradient counts as zero
+    -- e.g. a bias added right before a batch-statistics BatchNorm has an exactly zero gradient)."""
+    b = b.detach().cpu().double()
+    return maxabs(a, b) / max(float(b.abs().max()), floor, 1e-12)
+
+
+def _mp_reference(xp, a_node, a_edge, mask, edge_index, N, H, C, slope):
+    """out, alpha of the bare message passing, fp64 torch on the CPU (autograd-capable)."""
+    import torch.nn.functional as F
+    from oracle import ref_torch as R
+    src, dst = edge_index[0], edge_index[1]
+    z = a_node[:, :H].index_select(0, src) + a_node[:, H:].index_select(0, dst) + a_edge
+    alpha = R.segment_softmax(F.leaky_relu(z, slope), dst, N)
+    am = alpha if mask is None else alpha * mask
+    msg = xp.view(N, H, C).index_select(0, src) * am.unsqueeze(-1)
+    return R.scatter_add_rows(msg, dst, N).mean(dim=1), alpha
+
+
+@pytest.mark.parametrize("C,H,with_mask", [(32, 4, False), (12, 4, True), (30, 1, False), (300, 4, True), (512, 8, False),
+                                           (516, 2, False)])
+def test_message_passing_backward_vs_autograd(dev, C, H, with_mask):
+    from graphvqa_amd.gat_skip import gat_message_passing
+    from graphvqa_amd.graph import SceneGraphBatch
+    gb = synth.make_graph_batch(6, seed=0xB00 + C, nodes_lo=5, nodes_hi=40, rel_per_node=2.0)
+    ei = gb.edge_index.copy()
+    # a hub: > 64 in-edges into node 0 of the first graph (recompute path of the by-destination kernel) and a
+    # node without in-edges is impossible here (self loops), so also drop nothing
+    n0 = int((gb.batch == 0).sum())
+    extra = np.stack([np.arange(70) % n0, np.zeros(70, np.int64)])
+    ei = np.concatenate([ei, extra], axis=1)
+    N, E = gb.num_nodes, ei.shape[1]
+    rng = np.random.default_rng(C * 7 + H)
+    xp = rng.standard_normal((N, H * C)).astype(np.float32)
+    a_node = rng.standard_normal((N, 2 * H)).astype(np.float32)
+    a_edge = rng.standard_normal((E, H)).astype(np.float32)
+    mask = ((rng.random((E, H)) > 0.3) / 0.7).astype(np.float32) if with_mask else None
+    w = rng.standard_normal((N, C)).astype(np.float32)
+
+    g = SceneGraphBatch(t(ei, device=dev), t(gb.batch, device=dev), N, gb.num_graphs)
+    xs = [t(a, device=dev).requires_grad_(True) for a in (xp, a_node, a_edge)]
+    out, alpha = gat_message_passing(xs[0], xs[1], xs[2], g, H, C, 0.2, None if mask is None else t(mask, device=dev))
+    (out * t(w, device=dev)).sum().backward()
+
+    rs = [t(a).double().requires_grad_(True) for a in (xp, a_node, a_edge)]
+    ref_out, ref_alpha = _mp_reference(rs[0], rs[1], rs[2], None if mask is None else t(mask).double(), t(ei), N, H, C, 0.2)
+    (ref_out * t(w).double()).sum().backward()
+    assert maxabs(out, ref_out) < 1e-5 and maxabs(alpha, ref_alpha) < 1e-6
+    for got, ref, name in zip(xs, rs, ("dxp", "da_node", "da_edge")):
+        assert _rel(got.grad, ref.grad) < 2e-5, name
+
+
+def _grads_vs_oracle(dev, train, alpha_masks=None, feature_masks=None, dims=(32, 32, 48, 3, 4), seed=5):
+    from oracle import ref_torch as R
+    from graphvqa_amd.gat_skip import gat_seq
+    dn, de, di, K, H = dims
+    gb = synth.make_graph_batch(5, seed=0xA11CE + seed, nodes_lo=6, nodes_hi=20, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=seed)
+    rng = np.random.default_rng(seed)
+    for k in list(p):                                   # non-trivial BN affine / bias so that their gradients matter
+        if k.endswith("bias") or k.endswith("bns.weight"):
+            p[k] = (p[k] + 0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    x, ea, ins = synth.normal((N, dn), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    w = synth.normal((N, dn), 4)
+
+    m = gat_seq(dn, dn, de, di, K, dropout=0.0, gat_heads=H)
+    m.load_state_dict({k: t(v) for k, v in p.items()})
+    m = m.to(dev)
+    m.train(train)
+    xs = [t(a, device=dev).requires_grad_(True) for a in (x, ea, ins)]
+    kw = {}
+    if alpha_masks is not None:
+        out = m._forward_autograd(xs[0], t(gb.edge_index, device=dev), xs[1], xs[2], t(gb.batch, device=dev),
+                                  __import__("graphvqa_amd.graph", fromlist=["SceneGraphBatch"]).SceneGraphBatch(
+                                      t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B),
+                                  alpha_masks=[t(a, device=dev) for a in alpha_masks],
+                                  feature_masks=[t(a, device=dev) for a in feature_masks])
+    else:
+        out = m(xs[0], t(gb.edge_index, device=dev), xs[1], xs[2], t(gb.batch, device=dev), **kw)
+    (out * t(w, device=dev)).sum().backward()
+
+    rp = {k: v.double().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+          for k, v in tparams(p).items()}
+    rs = [t(a).double().requires_grad_(True) for a in (x, ea, ins)]
+    ref = R.gat_seq(rs[0], t(gb.edge_index), rs[1], rs[2], t(gb.batch), rp, heads=H, training_bn=train,
+                    alpha_masks=None if alpha_masks is None else [t(a).double() for a in alpha_masks],
+                    feature_masks=None if feature_masks is None else [t(a).double() for a in feature_masks])
+    (ref * t(w).double()).sum().backward()
+    assert maxabs(out, ref) < 1e-4
+    worst = {}
+    floor = 1e-3 * max(float(r.grad.abs().max()) for r in list(rs) + [v for v in rp.values() if v.grad is not None])
+    for got, r, name in zip(xs, rs, ("x", "edge_attr", "instr_vectors")):
+        worst[name] = _rel(got.grad, r.grad, floor)
+    sd = dict(m.named_parameters())
+    for k, r in rp.items():
+        if not r.requires_grad or k.endswith("lin_r.weight"):
+            continue
+        rg = r.grad
+        if k.endswith("lin_l.weight"):                  # lin_r is lin_l (gat_skip.py:76-77): one parameter, summed gradient
+            rr = rp[k.replace("lin_l", "lin_r")].grad
+            rg = rg if rr is None else rg + rr
+        worst[k] = _rel(sd[k].grad, rg, floor)
+    bad = {k: v for k, v in worst.items() if not v < 2e-4}
+    assert not bad, bad
+    return N, E, K, H
+
+
+def test_gat_seq_gradients_eval_bn(dev):
+    _grads_vs_oracle(dev, train=False)
+
+
+def test_gat_seq_gradients_train_bn(dev):
+    _grads_vs_oracle(dev, train=True)
+
+
+def test_gat_seq_gradients_with_dropout_masks(dev):
+    """Attention dropout (gat_skip.py:205) and feature dropout (:276) with GIVEN masks: forward and every gradient
+    match the oracle applying the same masks (the drawn masks themselves are implementation-specific)."""
+    dims = (32, 32, 48, 3, 4)
+    gb = synth.make_graph_batch(5, seed=0xA11CE + 9, nodes_lo=6, nodes_hi=20, rel_per_node=1.5)
+    rng = np.random.default_rng(99)
+    am = [((rng.random((gb.num_edges, 4)) > 0.1) / 0.9).astype(np.float32) for _ in range(3)]
+    fm = [((rng.random((gb.num_nodes, 32)) > 0.1) / 0.9).astype(np.float32) for _ in range(2)]
+    _grads_vs_oracle(dev, train=True, alpha_masks=am, feature_masks=fm, dims=dims, seed=9)
+
+
+def test_gat_seq_train_step_with_dropout_runs_and_learns(dev):
+    """.train() with p > 0 draws its own masks; a few SGD steps on a fixed batch reduce the loss, running statistics
+    move, and .eval() afterwards reproduces the fused inference path on the updated weights."""
+    from graphvqa_amd.gat_skip import gat_seq
+    gb = synth.make_graph_batch(16, seed=0xD0, nodes_lo=10, nodes_hi=30, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    torch.manual_seed(0)
+    m = gat_seq(64, 64, 64, 96, 3, dropout=0.1, gat_heads=4).to(dev).train()
+    x, ea, ins = [t(a, device=dev) for a in (synth.normal((N, 64), 1), synth.normal((E, 64), 2), synth.normal((3, B, 96), 3))]
+    ei, b = t(gb.edge_index, device=dev), t(gb.batch, device=dev)
+    target = t(synth.normal((N, 64), 4), device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-3)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = ((m(x, ei, ea, ins, b) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+    assert float(m.bns[0].running_mean.abs().max()) > 0 and int(m.bns[0].num_batches_tracked) == 60
+    m.eval()
+    with torch.no_grad():
+        fused = m(x, ei, ea, ins, b)                                   # fused inference kernels
+    diff = m._forward_autograd(x, ei, ea, ins, b, __import__("graphvqa_amd.graph", fromlist=["x"]).SceneGraphBatch(ei, b, N, B))
+    assert maxabs(fused, diff) < 1e-4 * (1.0 + float(fused.abs().max()))
