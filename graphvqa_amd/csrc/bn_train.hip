@@ -1,0 +1,138 @@
+// BatchNorm1d with batch statistics + ReLU, forward and backward (gat_skip.py:273-275 under model.train(); the
+// post-ops of the differentiable path).  x, y, dy, dx are fp32 [N, C] contiguous.  All HBM-bound
+// column reductions: a block owns 256 columns x BN_ROWS rows (coalesced 1 KiB row segments), partial sums go
+// through a [row blocks, C] workspace, so the result is deterministic.
+//   forward : mean, then the variance of the centred values (biased, like torch), y = relu(xhat * w + b)
+//   backward: g = dy * [xhat * w + b > 0];  db = sum g;  dw = sum g * xhat;
+//             dx = w * invstd * (g - db / N - xhat * dw / N)
+#include <algorithm>
+
+#include "common.h"
+
+namespace gvqa {
+namespace {
+
+constexpr int BN_ROWS = 256;
+
+// mode 0: sum x;  mode 1: sum (x - mean)^2
+__global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const float* __restrict__ x, const float* __restrict__ mean,
+                                                      float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
+    const float m = mean ? mean[c] : 0.f;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float v = x[r * C + c] - m;
+        acc += mean ? v * v : v;
+    }
+    partial[(int64_t)blockIdx.y * C + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_bn_col_finish(int nblocks, int C, const float* __restrict__ partial, int64_t blk_stride,
+                                                       float scale, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * blk_stride + c];
+    out[c] = acc * scale;
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_apply(int64_t total, int C, const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float eps, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float invstd = 1.0f / sqrtf(var[c] + eps);
+        y[i] = fmaxf((x[i] - mean[c]) * invstd * w[c] + b[c], 0.f);
+    }
+}
+
+// partial[blk, 0, c] = sum g, partial[blk, 1, c] = sum g * xhat over the block's rows
+__global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce(int64_t N, int C, const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                            float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
+    const float m = mean[c], invstd = 1.0f / sqrtf(var[c] + eps), wc = w[c], bc = b[c];
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float xh = (x[r * C + c] - m) * invstd;
+        const float g = xh * wc + bc > 0.f ? dy[r * C + c] : 0.f;
+        s0 += g;
+        s1 += g * xh;
+    }
+    partial[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0;
+    partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_bwd_apply(int64_t total, int C, float inv_n, const float* __restrict__ x,
+                                                           const float* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float eps, const float* __restrict__ dbias,
+                                                           const float* __restrict__ dweight, float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float invstd = 1.0f / sqrtf(var[c] + eps);
+        const float xh = (x[i] - mean[c]) * invstd;
+        const float g = xh * w[c] + b[c] > 0.f ? dy[i] : 0.f;
+        dx[i] = w[c] * invstd * (g - dbias[c] * inv_n - xh * dweight[c] * inv_n);
+    }
+}
+
+}  // namespace
+}  // namespace gvqa
+
+extern "C" size_t gvqa_bn_train_workspace_bytes(int64_t N, int32_t C) {
+    if (N < 0 || C <= 0) return 0;
+    return (size_t)gvqa::cdiv(N, gvqa::BN_ROWS) * 2 * C * sizeof(float) + 256;
+}
+
+extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                          float* y, float* save_mean, float* save_var, void* ws, size_t ws_bytes, void* stream_) {
+    using namespace gvqa;
+    GVQA_REQUIRE(N >= 0 && C > 0, GVQA_E_INVALID, "bn_relu_train_forward: bad sizes");
+    if (N == 0) return GVQA_OK;
+    GVQA_REQUIRE(x && weight && bias && y && save_mean && save_var, GVQA_E_INVALID, "bn_relu_train_forward: null tensor");
+    GVQA_REQUIRE(ws && ws_bytes >= gvqa_bn_train_workspace_bytes(N, C), GVQA_E_WORKSPACE, "bn_relu_train_forward: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* partial = static_cast<float*>(ws);
+    const int nb = (int)cdiv(N, BN_ROWS);
+    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 256));
+    GVQA_REQUIRE(nb <= 65535, GVQA_E_UNSUPPORTED, "bn_relu_train_forward: N too large");
+    hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, nullptr, partial);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_mean);
+    hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, save_mean, partial);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_var);
+    const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, x, save_mean, save_var, weight, bias,
+                       eps, y);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+                                           const float* save_mean, const float* save_var, float eps, const float* dy, float* dx,
+                                           float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream_) {
+    using namespace gvqa;
+    GVQA_REQUIRE(N >= 0 && C > 0, GVQA_E_INVALID, "bn_relu_train_backward: bad sizes");
+    if (N == 0) return GVQA_OK;
+    GVQA_REQUIRE(x && weight && bias && save_mean && save_var && dy && dx && dweight && dbias, GVQA_E_INVALID,
+                 "bn_relu_train_backward: null tensor");
+    GVQA_REQUIRE(ws && ws_bytes >= gvqa_bn_train_workspace_bytes(N, C), GVQA_E_WORKSPACE, "bn_relu_train_backward: workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* partial = static_cast<float*>(ws);
+    const int nb = (int)cdiv(N, BN_ROWS);
+    GVQA_REQUIRE(nb <= 65535, GVQA_E_UNSUPPORTED, "bn_relu_train_backward: N too large");
+    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 256));
+    hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
+    const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
+    hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, 1.0f / (float)N, x, dy, save_mean,
+                       save_var, weight, bias, eps, dbias, dweight, dx);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}

@@ -96,6 +96,56 @@ class _GatMessagePassing(torch.autograd.Function):
         return dxp, da_node, da_edge, None, None, None, None, None
 
 
+class _BatchNormReluTrain(torch.autograd.Function):
+    """relu(BatchNorm1d(x)) with batch statistics (gat_skip.py:273-275 under model.train()), HIP forward and backward.
+    Returns (y, batch mean, biased batch variance); the module updates the running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        x, weight, bias = _f32c(x, "x"), _f32c(weight, "bn.weight"), _f32c(bias, "bn.bias")
+        N, Cc = x.shape
+        y, mean, var = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
+        with torch.cuda.device(x.device):
+            ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
+            _lib.check(lib.gvqa_bn_relu_train_forward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps, y.data_ptr(),
+                                                      mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
+        ctx.save_for_backward(x, weight, bias, mean, var)
+        ctx.eps = eps
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        lib = _lib.load()
+        x, weight, bias, mean, var = ctx.saved_tensors
+        N, Cc = x.shape
+        dy = dy.contiguous()
+        dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(bias)
+        with torch.cuda.device(x.device):
+            ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
+            _lib.check(lib.gvqa_bn_relu_train_backward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
+                                                       var.data_ptr(), ctx.eps, dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                       db.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
+        return dx, dw, db, None
+
+
+def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor) -> Tensor:
+    """relu(bn(x)) in training mode on the HIP kernels, with torch's running-statistics update (momentum, unbiased
+    variance, num_batches_tracked)."""
+    if bn.weight is None or bn.bias is None or x.shape[0] < 2:
+        return torch.relu(bn(x))
+    y, mean, var = _BatchNormReluTrain.apply(x, bn.weight, bn.bias, bn.eps)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            n = x.shape[0]
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1)), alpha=mom)
+    return y
+
+
 class _AddGraphRows(torch.autograd.Function):
     """x[i, :] += rows[graph(i), :] in place (x must be a fresh intermediate).  Backward: dx = dout,
     drows[b] = sum of dout over the nodes of graph b -- both HIP kernels, deterministic (the gather's native
@@ -378,7 +428,7 @@ class gat_seq(torch.nn.Module):
                 out = out + conv.bias
             h = out + h
             if i != K - 1:
-                h = torch.relu(self.bns[i](h))
+                h = _bn_relu_train(self.bns[i], h) if self.training else torch.relu(self.bns[i](h))
                 if feature_masks is not None:
                     h = h * feature_masks[i]
                 else:

@@ -149,6 +149,17 @@ int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, co
                                  const float* x, const float* edge_attr, const float* instr, float* out,
                                  float* bn_stats_out, void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm1d with BATCH statistics + ReLU, forward and backward (gat_skip.py:273-275 under model.train(); post-ops of
+ * the differentiable path).  x, y, dy, dx: fp32 [N, C] contiguous.  save_mean / save_var [C]: batch mean and BIASED
+ * variance (the caller updates running statistics).  dx = w invstd (g - sum(g)/N - xhat sum(g xhat)/N),
+ * g = dy [y > 0].  ws: gvqa_bn_train_workspace_bytes(N, C).  Deterministic. */
+size_t gvqa_bn_train_workspace_bytes(int64_t N, int32_t C);
+int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                               float* y, float* save_mean, float* save_var, void* ws, size_t ws_bytes, void* stream);
+int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+                                const float* save_mean, const float* save_var, float eps, const float* dy, float* dx,
+                                float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 /* Per-graph rows <-> node rows (glue of the differentiable path: the per-graph instruction terms).
  * rows_to_nodes: out[i, :F] (= or +=) rows[graph(i), :F];  segment_sum (its adjoint): out[b, :F] = sum of x[i, :F]
  * over the nodes of graph b.  Deterministic. */
