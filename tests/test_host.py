@@ -200,5 +200,17 @@ def test_every_entry_point_rejects_bad_arguments_without_gpu():
     assert lib.gvqa_answer_logits_forward(4, 8, 8, 10, C.byref(_lib.ClassifierParams()), None, None, None, None, 0, None) == E_INV
     assert lib.gvqa_sg_encoder_forward(C.byref(g), 50, 8, 12, 1, C.byref(_lib.EncoderParams()), None, None, None, 0, None,
                                        1e-5, None, None, None, 0, None) == E_INV
+    # differentiable path
+    assert lib.gvqa_gat_mp_backward(C.byref(g), None, C.byref(_lib.GatMpBwdDesc()), None) == E_INV
+    bd = _lib.GatMpBwdDesc(); bd.C, bd.H = 8, 9
+    assert lib.gvqa_gat_mp_backward(C.byref(g), C.byref(g), C.byref(bd), None) == E_UNS and "H <=" in err()
+    bd.H = 4
+    assert lib.gvqa_gat_mp_backward(C.byref(g), C.byref(g), C.byref(bd), None) == E_INV and "null tensor" in err()
+    assert lib.gvqa_bn_train_workspace_bytes(1000, 32) >= 4 * 2 * 32 * 4 and lib.gvqa_bn_train_workspace_bytes(10, 0) == 0
+    assert lib.gvqa_bn_relu_train_forward(10, 0, None, None, None, 1e-5, None, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_bn_relu_train_forward(10, 8, None, None, None, 1e-5, None, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_bn_relu_train_backward(10, 8, None, None, None, None, None, 1e-5, None, None, None, None, None, 0, None) == E_INV
+    assert lib.gvqa_graph_rows_to_nodes(C.byref(g), 8, None, 4, None, 8, 0, None) == E_INV       # ld_rows < F
+    assert lib.gvqa_graph_segment_sum(C.byref(g), 8, None, 8, None, 8, None) == E_INV
     assert lib.gvqa_graph_finalize(C.byref(_lib.Graph()), None) == E_INV
     assert lib.gvqa_prof_collect(None, None) == E_INV
