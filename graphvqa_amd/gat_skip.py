@@ -250,17 +250,29 @@ class gat(torch.nn.Module):
             p.bn_mean, p.bn_var = ptr(bn.running_mean, "bn.running_mean"), ptr(bn.running_var, "bn.running_var")
         return p
 
-    def _check_mode(self):
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("training-mode attention dropout is not implemented on the HIP path "
-                                      "(call .eval(); SURVEY 8f-4)")
+    def _forward_autograd(self, x, edge_index, edge_attr, graph, want_alpha):
+        """Differentiable single layer (gat_skip.py:125-177): projections and logits as torch ops, message passing and
+        its backward on the HIP kernels; attention dropout (:205) as a drawn mask in training."""
+        import torch.nn.functional as F
+        H, Cc, N, E = self.heads, self.out_channels, x.shape[0], edge_index.shape[1]
+        xp = F.linear(x, self.lin_l.weight)
+        W3, We3 = self.lin_l.weight.view(H, Cc, -1), self.lin_e.weight.view(H, Cc, -1)
+        V_n = torch.cat((torch.einsum("hck,hc->kh", W3, self.att_l.view(H, Cc)),
+                         torch.einsum("hck,hc->kh", W3, self.att_r.view(H, Cc))), dim=1)
+        a_node = x @ V_n
+        a_edge = edge_attr @ torch.einsum("hck,hc->kh", We3, self.att_e.view(H, Cc))
+        p = self.dropout if self.training else 0.0
+        mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p) if p > 0 else None
+        out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask)
+        if self.bias is not None:
+            out = out + self.bias
+        return (out, (edge_index, alpha)) if want_alpha else out
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor, size=None,
                 return_attention_weights=None, graph: Optional[SceneGraphBatch] = None):
         assert x.dim() == 2, "Static graphs not supported in `GATConv`."      # gat_skip.py:132
         if self.concat:
             raise NotImplementedError("concat=True is not used by GraphVQA (gat_skip.py:232) and not implemented")
-        self._check_mode()
         lib = _lib.load()
         x = _f32c(x, "x")
         edge_attr = _f32c(edge_attr, "edge_attr")
@@ -271,6 +283,10 @@ class gat(torch.nn.Module):
         d = _lib.GatDims(self.in_channels, edge_attr.shape[1], 0, Cc, H, 1, self.negative_slope, 1e-5)
         if x.shape[1] != self.in_channels or edge_attr.shape[1] != self.lin_e.weight.shape[1]:
             raise ValueError("feature width does not match the layer")
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or
+                                                  any(q.requires_grad for q in self.parameters()))
+        if needs_grad or (self.training and self.dropout > 0):
+            return self._forward_autograd(x, edge_index, edge_attr, graph, isinstance(return_attention_weights, bool))
         p = self._params()
         out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
         want_alpha = isinstance(return_attention_weights, bool)

@@ -194,3 +194,25 @@ def test_bn_relu_train_forward_backward_vs_torch(dev, N, C):
     assert _rel(xg.grad, xr.grad) < 1e-5 and _rel(bn.weight.grad, ref.weight.grad) < 1e-5 and _rel(bn.bias.grad, ref.bias.grad) < 1e-5
     assert maxabs(bn.running_mean, ref.running_mean) < 1e-6 and maxabs(bn.running_var, ref.running_var) < 1e-5
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_gat_layer_gradients_vs_oracle(dev):
+    """The single `gat` layer (gat_skip.py:111-177) is differentiable too."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.gat_skip import gat
+    gb = synth.make_graph_batch(4, seed=0x6A7, nodes_lo=6, nodes_hi=20, rel_per_node=1.5)
+    N, E = gb.num_nodes, gb.num_edges
+    conv = gat(24, 8, 20, heads=4, concat=False, negative_slope=0.2, dropout=0.0, bias=True).to(dev)
+    x, ea, w = synth.normal((N, 24), 1), synth.normal((E, 20), 2), synth.normal((N, 8), 3)
+    xs = [t(a, device=dev).requires_grad_(True) for a in (x, ea)]
+    out = conv(xs[0], t(gb.edge_index, device=dev), xs[1])
+    (out * t(w, device=dev)).sum().backward()
+    rp = {k: v.detach().cpu().double().requires_grad_(True) for k, v in conv.state_dict().items() if k != "lin_r.weight"}
+    rp["lin_r.weight"] = rp["lin_l.weight"]
+    rs = [t(a).double().requires_grad_(True) for a in (x, ea)]
+    ref = R.gat_conv(rs[0], t(gb.edge_index), rs[1], rp, heads=4)
+    (ref * t(w).double()).sum().backward()
+    assert maxabs(out, ref) < 1e-5
+    assert _rel(xs[0].grad, rs[0].grad) < 1e-4 and _rel(xs[1].grad, rs[1].grad) < 1e-4
+    for k, v in conv.named_parameters():
+        assert _rel(v.grad, rp[k].grad) < 1e-4, k
