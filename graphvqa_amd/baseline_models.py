@@ -20,7 +20,7 @@ from torch import Tensor
 from torch.nn import Linear, Parameter, ReLU, Sequential
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _glorot
+from .gat_skip import _f32c, _workspace, _glorot, _inference_only
 from .graph import SceneGraphBatch, _stream
 
 
@@ -54,6 +54,7 @@ class GINEConv(torch.nn.Module):
         """x [N, D], edge_attr [E, D] (PyG requires equal widths).  With `ins` [B, Di] (and an
         intra-graph `graph`), x / edge_attr are the node / edge halves and the instruction halves
         are handled per graph without concatenation."""
+        _inference_only(self, x, edge_attr)
         lib = _lib.load()
         x, edge_attr = _f32c(x, "x"), _f32c(edge_attr, "edge_attr")
         if x.shape[1] != edge_attr.shape[1]:
@@ -96,6 +97,7 @@ class GCNConv(torch.nn.Module):
                 self.bias.zero_()
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight=None, graph=None, ins: Tensor | None = None):
+        _inference_only(self, x)
         if edge_weight is not None:
             raise NotImplementedError("edge weights are not used by GraphVQA (pipeline_model_gcn.py:660)")
         lib = _lib.load()
@@ -159,6 +161,7 @@ class gine_seq(_SeqBase):
         self.dropout = dropout
 
     def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph=None, return_convs=False):
+        _inference_only(self, x, edge_attr, instr_vectors)
         self._check()
         out = _bn_relu_chain(x, list(self.bns))           # conv_res is discarded by the reference
         if not return_convs:
@@ -192,6 +195,7 @@ class gcn_seq(_SeqBase):
         self.dropout = dropout
 
     def forward(self, x, edge_index, instr_vectors, batch, graph=None, return_convs=False):
+        _inference_only(self, x, instr_vectors)
         self._check()
         out = _bn_relu_chain(x, list(self.bns))
         if not return_convs:

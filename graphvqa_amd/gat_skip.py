@@ -45,6 +45,16 @@ def _f32c(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
+def _inference_only(module: torch.nn.Module, *tensors) -> None:
+    """Modules whose backward is not built: refuse to run where autograd would expect a differentiable result
+    (a silently detached output would train nothing)."""
+    if torch.is_grad_enabled() and (any(isinstance(t, Tensor) and t.requires_grad for t in tensors) or
+                                    any(p.requires_grad for p in module.parameters())):
+        raise NotImplementedError(
+            f"{type(module).__name__} on the HIP path is inference-only (backward not built, SURVEY 8f-4): call it under "
+            "torch.no_grad() / with requires_grad_(False) parameters")
+
+
 def _workspace(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 

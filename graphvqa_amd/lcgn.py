@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.nn import Linear, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _glorot
+from .gat_skip import _f32c, _workspace, _glorot, _inference_only
 from .graph import SceneGraphBatch, _stream
 
 
@@ -88,6 +88,7 @@ class lcgn_seq(nn.Module):
 
     def forward(self, x, edge_index, batch, q_encoding, lstm_outputs, edge_attr=None, instr_vectors=None,
                 graph: SceneGraphBatch | None = None, x_ctx_init: torch.Tensor | None = None):
+        _inference_only(self, x, q_encoding, lstm_outputs)
         if self.training:
             raise NotImplementedError("lcgn_seq on the HIP path implements inference; call .eval() (SURVEY 8f-4)")
         lib = _lib.load()

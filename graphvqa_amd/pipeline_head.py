@@ -15,7 +15,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU
 
 from . import _lib
-from .gat_skip import _f32c, _workspace
+from .gat_skip import _f32c, _workspace, _inference_only
 from .graph import SceneGraphBatch, _stream
 
 
@@ -30,6 +30,7 @@ class MyConditionalGlobalAttention(torch.nn.Module):
         self.num_node_features, self.channels = num_node_features, channels
 
     def forward(self, x, u, batch, size=None, graph: SceneGraphBatch | None = None):
+        _inference_only(self, x, u)
         lib = _lib.load()
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         x, u = _f32c(x, "x"), _f32c(u, "u")
@@ -70,6 +71,7 @@ class ShortAnswerClassifier(torch.nn.Module):
         self.Q, self.hidden, self.A = question_hidden_dim, out_classifier_dim, num_short_answer_choices
 
     def forward(self, graph_final_feature, question_feature):
+        _inference_only(self, graph_final_feature, question_feature)
         if self.training:
             raise NotImplementedError("inference path: call .eval()")
         lib = _lib.load()

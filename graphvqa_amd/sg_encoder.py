@@ -14,7 +14,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace
+from .gat_skip import _f32c, _workspace, _inference_only
 from .graph import SceneGraphBatch, _stream
 
 
@@ -59,6 +59,7 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         self.graph_layer_norm = _GraphLayerNorm(sg_emb_dim)
 
     def forward(self, gt_scene_graphs, graph: SceneGraphBatch | None = None):
+        _inference_only(self)
         lib = _lib.load()
         d = gt_scene_graphs
         x_tok, e_tok, ei, batch = d.x, d.edge_attr, d.edge_index, d.batch

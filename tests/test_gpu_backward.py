@@ -216,3 +216,18 @@ def test_gat_layer_gradients_vs_oracle(dev):
     assert _rel(xs[0].grad, rs[0].grad) < 1e-4 and _rel(xs[1].grad, rs[1].grad) < 1e-4
     for k, v in conv.named_parameters():
         assert _rel(v.grad, rp[k].grad) < 1e-4, k
+
+
+def test_inference_only_modules_refuse_autograd(dev):
+    """Modules without a backward must not hand autograd a silently detached result."""
+    from graphvqa_amd.baseline_models import gine_seq
+    from graphvqa_amd.pipeline_head import ShortAnswerClassifier
+    m = gine_seq(8, 8, 8).to(dev).eval()
+    gb = synth.make_graph_batch(2, seed=1, nodes_lo=4, nodes_hi=6, rel_per_node=1.0)
+    args = (t(synth.normal((gb.num_nodes, 8), 1), device=dev), t(gb.edge_index, device=dev),
+            t(synth.normal((gb.num_edges, 8), 2), device=dev), t(synth.normal((5, gb.num_graphs, 8), 3), device=dev),
+            t(gb.batch, device=dev))
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        m(*args)
+    with torch.no_grad():
+        assert m(*args).shape == (gb.num_nodes, 8)
