@@ -36,8 +36,8 @@ def _mp_reference(xp, a_node, a_edge, mask, edge_index, N, H, C, slope):
     return R.scatter_add_rows(msg, dst, N).mean(dim=1), alpha
 
 
-@pytest.mark.parametrize("C,H,with_mask", [(32, 4, False), (12, 4, True), (30, 1, False), (300, 4, True), (512, 8, False),
-                                           (516, 2, False)])
+@pytest.mark.parametrize("C,H,with_mask", [(32, 4, False), (12, 4, True), (30, 1, False), (30, 2, True), (300, 4, True),
+                                           (512, 8, False), (516, 2, False), (32, 3, True)])
 def test_message_passing_backward_vs_autograd(dev, C, H, with_mask):
     from graphvqa_amd.gat_skip import gat_message_passing
     from graphvqa_amd.graph import SceneGraphBatch

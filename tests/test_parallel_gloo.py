@@ -89,3 +89,51 @@ def test_two_rank_gloo_matches_single_process():
         assert pr.exitcode == 0
     assert got.shape == want.shape
     assert np.abs(got - want).max() < 1e-5
+
+
+def _grad_worker(rank, world, port, q):
+    """Data-parallel gradient exchange: each rank back-propagates its shard's loss (sum over its graphs) through the
+    oracle (stand-in for the HIP path on this tier), then allreduce_gradients; the summed gradient must equal the
+    single-process gradient of the whole batch's loss (eval BatchNorm: graphs are independent)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_torch as R
+        from graphvqa_amd.parallel import allreduce_gradients
+        torch.set_num_threads(1)
+        gb, p, x, ea, ins, H = _case()
+        nsl, emask, ei, b, (g0, g1) = shard_batch(gb.edge_index, gb.batch, gb.num_graphs, rank, world)
+        params = {k: torch.nn.Parameter(v.double()) for k, v in tparams(p).items() if v.is_floating_point() and "running" not in k}
+        full = dict(tparams(p, torch.float64))
+        full.update(params)
+        h = R.gat_seq(t(x[nsl]).double(), t(ei), t(ea[emask]).double(), t(ins[:, g0:g1]).double(), t(b), full, heads=H)
+        h.square().sum().backward()
+        # tiny buckets: several collectives, identical on every rank (lin_r aliases lin_l in the module; here it has its own grad)
+        n = allreduce_gradients(params.values(), bucket_bytes=4096, average=False)
+        if rank == 0:
+            q.put((n, {k: v.grad.numpy() for k, v in params.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_matches_single_process():
+    from oracle import ref_torch as R
+    gb, p, x, ea, ins, H = _case()
+    params = {k: torch.nn.Parameter(v.double()) for k, v in tparams(p).items() if v.is_floating_point() and "running" not in k}
+    full = dict(tparams(p, torch.float64))
+    full.update(params)
+    R.gat_seq(t(x).double(), t(gb.edge_index), t(ea).double(), t(ins).double(), t(gb.batch), full, heads=H).square().sum().backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    ncalls, got = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert ncalls > 1
+    for k, v in params.items():
+        ref = np.zeros_like(got[k]) if v.grad is None else v.grad.numpy()
+        assert np.abs(got[k] - ref).max() < 1e-9 * (1.0 + np.abs(ref).max()), k
