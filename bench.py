@@ -41,10 +41,11 @@ def mp_algorithmic_bytes(N, E, C, Hh, fused_skip=True):
 
 
 def measured_traffic():
-    """HBM bytes per launch of the message-passing kernel from the committed PMC passes
-    (profiles/r01b_pmc_hbm_cfg3.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    """HBM bytes per launch of the message-passing kernel from the newest committed PMC passes
+    (profiles/*_pmc_hbm_cfg3.json, scripts/collect_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_cfg3.json")) as f:
+        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_cfg3.json")))[-1]) as f:
             return json.load(f)["mp_kernel"]["hbm_bytes_per_launch"]
     except Exception:
         return None
