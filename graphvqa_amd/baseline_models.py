@@ -140,6 +140,16 @@ class _SeqBase(torch.nn.Module):
         if self.training:
             raise NotImplementedError("the HIP path implements inference; call .eval() (SURVEY 8f-4)")
 
+    def _as_written_autograd(self, x):
+        """What the reference module returns, differentiably: the conv results are discarded
+        (pipeline_model_gine.py:665-671 / pipeline_model_gcn.py:660-666), so the output -- in training too -- is x pushed
+        through (BatchNorm, ReLU, dropout) of every layer but the last; no graph work is involved."""
+        import torch.nn.functional as F
+        h = x
+        for bn in self.bns:
+            h = F.dropout(torch.relu(bn(h)), p=self.dropout, training=self.training)
+        return h
+
     def reset_parameters(self):
         for conv in self.convs:
             if hasattr(conv, "reset_parameters"):
@@ -161,6 +171,9 @@ class gine_seq(_SeqBase):
         self.dropout = dropout
 
     def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph=None, return_convs=False):
+        if not return_convs and (self.training or (torch.is_grad_enabled() and (
+                x.requires_grad or any(q.requires_grad for q in self.bns.parameters())))):
+            return self._as_written_autograd(_f32c(x, "x"))
         _inference_only(self, x, edge_attr, instr_vectors)
         self._check()
         out = _bn_relu_chain(x, list(self.bns))           # conv_res is discarded by the reference
@@ -195,6 +208,9 @@ class gcn_seq(_SeqBase):
         self.dropout = dropout
 
     def forward(self, x, edge_index, instr_vectors, batch, graph=None, return_convs=False):
+        if not return_convs and (self.training or (torch.is_grad_enabled() and (
+                x.requires_grad or any(q.requires_grad for q in self.bns.parameters())))):
+            return self._as_written_autograd(_f32c(x, "x"))
         _inference_only(self, x, instr_vectors)
         self._check()
         out = _bn_relu_chain(x, list(self.bns))

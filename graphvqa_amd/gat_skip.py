@@ -192,6 +192,80 @@ def add_graph_rows(x: Tensor, rows: Tensor, graph: SceneGraphBatch) -> Tensor:
     return _AddGraphRows.apply(x, rows, graph)
 
 
+class _GraphRows(torch.autograd.Function):
+    """rows[graph(i), :] for every node i -> [N, F] (HIP broadcast); backward: per-graph sum of dout."""
+
+    @staticmethod
+    def forward(ctx, rows, graph):
+        lib = _lib.load()
+        rows = _f32c(rows, "rows")
+        if rows.dim() != 2 or rows.shape[0] != graph.num_graphs:
+            raise ValueError("graph_rows: rows must be [B, F]")
+        out = torch.empty((graph.num_nodes, rows.shape[1]), dtype=torch.float32, device=rows.device)
+        with torch.cuda.device(rows.device):
+            _lib.check(lib.gvqa_graph_rows_to_nodes(C.byref(graph.c), rows.shape[1], rows.data_ptr(), rows.shape[1], out.data_ptr(),
+                                                    rows.shape[1], 0, _stream(rows.device)))
+        ctx.graph = graph
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return _segment_sum_raw(dout.contiguous(), ctx.graph), None
+
+
+class _GraphSegmentSum(torch.autograd.Function):
+    """out[b, :] = sum of x[i, :] over the nodes of graph b (HIP, deterministic); backward: broadcast of dout."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        x = _f32c(x, "x")
+        if x.dim() != 2 or x.shape[0] != graph.num_nodes:
+            raise ValueError("graph_segment_sum: x must be [N, F]")
+        ctx.graph = graph
+        return _segment_sum_raw(x, graph)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        graph, dout = ctx.graph, dout.contiguous()
+        dx = torch.empty((graph.num_nodes, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            _lib.check(lib.gvqa_graph_rows_to_nodes(C.byref(graph.c), dout.shape[1], dout.data_ptr(), dout.shape[1], dx.data_ptr(),
+                                                    dout.shape[1], 0, _stream(dout.device)))
+        return dx, None
+
+
+def _segment_sum_raw(x: Tensor, graph: SceneGraphBatch) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((graph.num_graphs, x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gvqa_graph_segment_sum(C.byref(graph.c), x.shape[1], x.data_ptr(), x.shape[1], out.data_ptr(), x.shape[1],
+                                              _stream(x.device)))
+    return out
+
+
+def graph_rows(rows: Tensor, graph: SceneGraphBatch) -> Tensor:
+    """Differentiable rows[batch] ([B, F] -> [N, F]) on the HIP kernels."""
+    return _GraphRows.apply(rows, graph)
+
+
+def graph_segment_sum(x: Tensor, graph: SceneGraphBatch) -> Tensor:
+    """Differentiable per-graph sum of node rows ([N, F] -> [B, F]) on the HIP kernels."""
+    return _GraphSegmentSum.apply(x, graph)
+
+
+def graph_softmax(score: Tensor, graph: SceneGraphBatch) -> Tensor:
+    """Softmax of score [N, F] over the nodes of each graph (torch_geometric.utils.softmax semantics: max-shifted,
+    denominator + 1e-16), differentiable; the per-graph reductions / broadcasts are the HIP ops above."""
+    B = graph.num_graphs
+    idx = graph.node_graph.long().unsqueeze(1).expand_as(score)
+    gmax = torch.full((B, score.shape[1]), float("-inf"), device=score.device).scatter_reduce(
+        0, idx, score.detach(), reduce="amax", include_self=True)
+    gmax = torch.where(torch.isinf(gmax), torch.zeros_like(gmax), gmax)
+    ex = (score - graph_rows(gmax, graph)).exp()
+    return ex / (graph_rows(graph_segment_sum(ex, graph), graph) + 1e-16)
+
+
 def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: SceneGraphBatch, heads: int, channels: int,
                         negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None):
     """Differentiable GAT message passing on the HIP kernels: (out [N, C], alpha [E, H]).

@@ -15,7 +15,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _inference_only
+from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, graph_softmax
 from .graph import SceneGraphBatch, _stream
 
 
@@ -30,7 +30,6 @@ class MyConditionalGlobalAttention(torch.nn.Module):
         self.num_node_features, self.channels = num_node_features, channels
 
     def forward(self, x, u, batch, size=None, graph: SceneGraphBatch | None = None):
-        _inference_only(self, x, u)
         lib = _lib.load()
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         x, u = _f32c(x, "x"), _f32c(u, "u")
@@ -38,6 +37,12 @@ class MyConditionalGlobalAttention(torch.nn.Module):
         N = x.shape[0]
         if graph is None:
             graph = SceneGraphBatch(torch.zeros((2, 0), dtype=torch.int64, device=x.device), batch, N, B)
+        if torch.is_grad_enabled() and (x.requires_grad or u.requires_grad or any(q.requires_grad for q in self.parameters())):
+            # differentiable formulation (pipeline_model_gat.py:149-181): the MLPs are torch ops, the per-graph
+            # broadcast / softmax / sum run on the HIP per-graph kernels and their adjoints
+            xn = self.node_nn(x)
+            gate = graph_softmax(self.gate_nn(graph_rows(self.ques_nn(u), graph) * xn), graph)
+            return graph_segment_sum(gate * xn, graph)
         p = _lib.PoolParams()
         keep = []
         for name, lin in (("node0", self.node_nn[0]), ("node2", self.node_nn[2]), ("ques0", self.ques_nn[0]),
@@ -71,11 +76,12 @@ class ShortAnswerClassifier(torch.nn.Module):
         self.Q, self.hidden, self.A = question_hidden_dim, out_classifier_dim, num_short_answer_choices
 
     def forward(self, graph_final_feature, question_feature):
-        _inference_only(self, graph_final_feature, question_feature)
-        if self.training:
-            raise NotImplementedError("inference path: call .eval()")
         lib = _lib.load()
         g, q = _f32c(graph_final_feature, "graph_final_feature"), _f32c(question_feature, "question_feature")
+        if self.training or (torch.is_grad_enabled() and (g.requires_grad or q.requires_grad or
+                                                          any(w.requires_grad for w in self.parameters()))):
+            # training / differentiable: two dense layers on [B, 3Q] rows -- torch ops (with the Sequential's dropouts)
+            return self.logit_fc(torch.cat((g, q, g * q), dim=-1))
         B = g.shape[0]
         p = _lib.ClassifierParams(_f32c(self.logit_fc[1].weight, "w").data_ptr(), _f32c(self.logit_fc[1].bias, "b").data_ptr(),
                                   _f32c(self.logit_fc[4].weight, "w").data_ptr(), _f32c(self.logit_fc[4].bias, "b").data_ptr())
