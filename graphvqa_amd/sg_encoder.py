@@ -14,7 +14,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _inference_only
+from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum
 from .graph import SceneGraphBatch, _stream
 
 
@@ -58,8 +58,34 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         self.scene_graph_encoding_layer = _MetaLayer(sg_emb_dim)
         self.graph_layer_norm = _GraphLayerNorm(sg_emb_dim)
 
+    def _forward_autograd(self, x_tok, e_tok, ei, added, graph):
+        """Differentiable formulation of pipeline_model_gat.py:575-610 (training): embeddings and MLPs are torch ops,
+        the scatter_mean is an index_add, the graph LayerNorm's per-graph reductions / broadcasts run on the HIP
+        per-graph ops with their adjoints (my_graph_layernorm.py:57-78: eps OUTSIDE the square root)."""
+        emb, m, D = self.sg_vocab_embedding, self.scene_graph_encoding_layer, self.sg_emb_dim
+        N = x_tok.shape[0]
+        x = emb(x_tok).sum(dim=-2)
+        e = emb(e_tok)
+        if added is not None and added.numel():
+            sign = torch.ones(e.shape[0], device=e.device)
+            sign[added.to(e.device)] = -1.0                                              # :590
+            e = e * sign.view(-1, 1, 1)
+        e = e.sum(dim=-2)
+        src, dst = ei[0], ei[1]
+        e2 = m.edge_model.edge_mlp(torch.cat([x[src], x[dst], e], dim=1))                # EdgeModel :65-76
+        mm = m.node_model.node_mlp_1(torch.cat([x[src], e2], dim=1))                     # NodeModel :78-98
+        cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(mm.dtype)
+        agg = torch.zeros((N, D), device=mm.device).index_add(0, dst, mm) / cnt.view(-1, 1)   # scatter_mean :96
+        x2 = m.node_model.node_mlp_2(torch.cat([x, agg], dim=1))
+        gp = graph.graph_ptr.long()
+        norm = ((gp[1:] - gp[:-1]).clamp(min=1) * D).to(x2.dtype).view(-1, 1)
+        mean = graph_segment_sum(x2, graph).sum(dim=-1, keepdim=True) / norm
+        xc = x2 - graph_rows(mean, graph)
+        var = graph_segment_sum(xc * xc, graph).sum(dim=-1, keepdim=True) / norm
+        out = xc / (graph_rows(var.sqrt(), graph) + self.graph_layer_norm.eps)
+        return out * self.graph_layer_norm.weight + self.graph_layer_norm.bias, e2, None
+
     def forward(self, gt_scene_graphs, graph: SceneGraphBatch | None = None):
-        _inference_only(self)
         lib = _lib.load()
         d = gt_scene_graphs
         x_tok, e_tok, ei, batch = d.x, d.edge_attr, d.edge_index, d.batch
@@ -71,6 +97,8 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         N, E = x_tok.shape[0], ei.shape[1]
         if graph is None:
             graph = SceneGraphBatch(ei, batch, N)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            return self._forward_autograd(x_tok, e_tok, ei, added, graph)
         D, V = self.sg_emb_dim, self.sg_vocab_embedding.num_embeddings
         m = self.scene_graph_encoding_layer
         p = _lib.EncoderParams()

@@ -282,3 +282,63 @@ def test_gine_gcn_as_written_modules_train(dev):
             assert maxabs(m(*args), out) < 1e-5
         m.train()
         assert m(*args).shape == (N, 8) and int(m.bns[0].num_batches_tracked) == 1
+
+
+def test_config1_pipeline_end_to_end_gradients(dev):
+    """BASELINE config 1 shape, trainable end to end: encoder -> gat_seq -> pooling -> classifier on the differentiable
+    paths (eval-mode statistics so that the oracle chain is the exact reference); the loss gradient reaches every
+    parameter, the embedding table included, and matches autograd through the same chain on the oracle."""
+    import types
+    from oracle import ref_torch as R
+    from tests.util import load_golden
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+    meta, gg = load_golden("gat_seq_debug2_d300")
+    ei, batch = gg["edge_index"], gg["batch"]
+    N, E, B, V, D, Q, A = batch.shape[0], ei.shape[1], 2, 50, 64, 96, 40
+    x_tok = synth.randint(N * 12, 71, 0, V, stream=9).reshape(N, 12)
+    e_tok = synth.randint(E, 72, 1, V, stream=9).reshape(E, 1)
+    added = np.array([3, 17, 60], dtype=np.int64)
+    ins, q, w = synth.normal((3, B, Q), 73), synth.normal((B, Q), 74), synth.normal((B, A), 75)
+    pe, pg = synth.encoder_params(V, D, seed=1), synth.gat_seq_params(D, D, D, Q, 3, 4, seed=2)
+    pp, pc = synth.attention_pool_params(D, Q, seed=3), synth.classifier_params(Q, 48, A, seed=4)
+    mods = [GroundTruth_SceneGraph_Encoder(V, 0, D), gat_seq(D, D, D, Q, 3, dropout=0.0, gat_heads=4),
+            MyConditionalGlobalAttention(D, Q), ShortAnswerClassifier(Q, 48, A)]
+    for m, p in zip(mods, (pe, pg, pp, pc)):
+        m.load_state_dict({k: t(v) for k, v in p.items()})
+        m.to(dev).eval()
+    enc, gs, pool, clf = mods
+    data = types.SimpleNamespace(x=t(x_tok, device=dev), edge_attr=t(e_tok, device=dev), edge_index=t(ei, device=dev),
+                                 batch=t(batch, device=dev), added_sym_edge=t(added, device=dev))
+    xe, ee, _ = enc(data)
+    h = gs(xe, data.edge_index, ee, t(ins, device=dev), data.batch)
+    logits = clf(pool(h, t(q, device=dev), data.batch), t(q, device=dev))
+    (logits * t(w, device=dev)).sum().backward()
+
+    rp = [{k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v)
+           for k, v in tparams(p).items()} for p in (pe, pg, pp, pc)]
+    rxe, ree = R.scene_graph_encoder(t(x_tok), t(ei), t(e_tok), t(added), t(batch), B, rp[0])
+    rh = R.gat_seq(rxe, t(ei), ree, t(ins).double(), t(batch), rp[1], heads=4)
+    ref = R.short_answer_logits(R.global_attention_pool(rh, t(q).double(), t(batch), rp[2], B), t(q).double(), rp[3])
+    (ref * t(w).double()).sum().backward()
+    assert maxabs(logits, ref) < 1e-4
+    grads = [v.grad for d in rp for v in d.values() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None]
+    floor = 1e-3 * max(float(g.abs().max()) for g in grads)
+    bad = {}
+    for m, d in zip(mods, rp):
+        for k, v in m.named_parameters():
+            rg = d[k].grad
+            if k.endswith("lin_l.weight"):
+                rr = d[k.replace("lin_l", "lin_r")].grad
+                rg = rg if rr is None else rg + rr
+            if rg is None:
+                rg = torch.zeros_like(d[k])
+            if k == "sg_vocab_embedding.weight":      # nn.Embedding(padding_idx=0): the pad row receives no gradient
+                rg = rg.clone()
+                rg[0] = 0
+            assert v.grad is not None, k
+            e = _rel(v.grad, rg, floor)
+            if not e < 5e-4:
+                bad[type(m).__name__ + "." + k] = e
+    assert not bad, bad
