@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.nn import Linear, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _glorot, _inference_only
+from .gat_skip import _f32c, _workspace, _glorot, gat_message_passing, graph_rows
 from .graph import SceneGraphBatch, _stream
 
 
@@ -86,11 +86,44 @@ class lcgn_seq(nn.Module):
         self.in_channels, self.out_channels, self.question_dim = in_channels, out_channels, question_dim
         self.gat_cmd_dim, self.gat_heads, self.negative_slope = gat_cmd_dim, gat_heads, gat_negative_slope
 
+    def _forward_autograd(self, x, edge_index, q, lstm, graph, x_ctx_init):
+        """Differentiable / training formulation of lcgn.py:303-323: dense layers (with the module's dropouts) are torch
+        ops; the per-graph command broadcasts, the softmax-weighted neighbour sum and their backward run on the HIP
+        per-graph / message-passing kernels (the dot-product logit x_l[src] . (proj_cmd * x_r)[dst], lcgn.py:154,207,
+        enters the message passing as its per-edge term).  fp32 node tensors only."""
+        if self.node_feature_dtype != torch.float32:
+            raise NotImplementedError("lcgn_seq: the differentiable path keeps fp32 node tensors "
+                                      "(node_feature_dtype=torch.bfloat16 is an inference storage mode)")
+        if self.gat_heads != 1:
+            raise NotImplementedError("lcgn_seq: gat_heads != 1 is not implemented (reference default 1)")
+        O, N, E = self.out_channels, x.shape[0], edge_index.shape[1]
+        L = self.lcgn
+        src, dst = edge_index[0], edge_index[1]
+        x_loc = self.init_sg_emb_input(x)                                             # :305
+        x_ctx = x_ctx_init                                                            # :306
+        q_emb = torch.relu(self.qInput1(q))                                           # :307
+        proj_x_loc = self.proj_x_loc(x_loc)                                           # :308
+        lo = lstm.transpose(1, 0)                                                     # [B, L, O]
+        zeros2 = torch.zeros((N, 2), device=x.device)
+        p_att = L.dropout if self.training else 0.0
+        for t in range(self.MAX_ITER_NUM):
+            q_cmd = getattr(self, "qInput2_%d" % t)(q_emb)                            # :292-300
+            att = torch.softmax(self.cmd_inter2logits(q_cmd[:, None, :] * lo).squeeze(-1), dim=-1)
+            cmd = torch.bmm(att[:, None, :], lo).squeeze(1)
+            x_joint = torch.cat([x_loc, x_ctx, self.proj_x_ctx(x_ctx) * proj_x_loc], dim=-1)    # :312-313
+            x_l, x_r, x_val = L.lin_l(x_joint), L.lin_r(x_joint), L.cal_x(x_joint)    # :144-145,230
+            y = graph_rows(L.proj_cmd(cmd), graph) * x_r                              # :148-154
+            a_edge = (x_l[src] * y[dst]).sum(dim=-1, keepdim=True)                    # :207
+            mask = torch.bernoulli(torch.full((E, 1), 1.0 - p_att, device=x.device)) / (1.0 - p_att) if p_att > 0 else None
+            agg, _ = gat_message_passing(x_val, zeros2, a_edge, graph, 1, O, self.negative_slope, mask)   # :209-238
+            msg = agg * graph_rows(L.cal_cmd(cmd), graph)                             # :231 (edges are intra-graph)
+            if L.bias is not None:
+                msg = msg + L.bias
+            x_ctx = self.output_layer(torch.cat([x_ctx, msg], dim=-1))                # :316-319
+        return self.fin_layer(torch.cat([x_loc, x_ctx], dim=-1))                      # :321-322
+
     def forward(self, x, edge_index, batch, q_encoding, lstm_outputs, edge_attr=None, instr_vectors=None,
                 graph: SceneGraphBatch | None = None, x_ctx_init: torch.Tensor | None = None):
-        _inference_only(self, x, q_encoding, lstm_outputs)
-        if self.training:
-            raise NotImplementedError("lcgn_seq on the HIP path implements inference; call .eval() (SURVEY 8f-4)")
         lib = _lib.load()
         x = _f32c(x, "x")
         q = _f32c(q_encoding, "q_encoding")
@@ -106,6 +139,9 @@ class lcgn_seq(nn.Module):
         x_ctx_init = _f32c(x_ctx_init, "x_ctx_init")
         if graph is None:
             graph = SceneGraphBatch(edge_index, batch, N, B)
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or q.requires_grad or lstm.requires_grad or
+                                                          any(w.requires_grad for w in self.parameters()))):
+            return self._forward_autograd(x, edge_index, q, lstm, graph, x_ctx_init)
         d = _lib.LcgnDims(self.in_channels, O, self.question_dim, self.MAX_ITER_NUM, L, self.gat_heads,
                           self.negative_slope,
                           (3 - self.bf16_weight_pieces) if self.node_feature_dtype == torch.bfloat16 else 0)

@@ -218,16 +218,65 @@ def test_gat_layer_gradients_vs_oracle(dev):
         assert _rel(v.grad, rp[k].grad) < 1e-4, k
 
 
-def test_inference_only_modules_refuse_autograd(dev):
-    """Modules without a backward must not hand autograd a silently detached result."""
+def test_inference_only_paths_refuse_autograd(dev):
+    """Paths without a backward must not hand autograd a silently detached result: the bf16 node-feature storage mode
+    of LCGN and the tapped GINE conv results."""
     from graphvqa_amd.lcgn import lcgn_seq
-    m = lcgn_seq(8, 16, 8, 5).to(dev).eval()
+    from graphvqa_amd.baseline_models import gine_seq
     gb = synth.make_graph_batch(2, seed=1, nodes_lo=4, nodes_hi=6, rel_per_node=1.0)
     N, B = gb.num_nodes, gb.num_graphs
+    m = lcgn_seq(8, 16, 8, 5, gat_cmd_dim=16, question_dim=16, node_feature_dtype=torch.bfloat16).to(dev).eval()
     args = (t(synth.normal((N, 8), 1), device=dev), t(gb.edge_index, device=dev), t(gb.batch, device=dev),
-            t(synth.normal((B, 512), 2), device=dev), t(synth.normal((10, B, 16), 3), device=dev))
-    with pytest.raises(NotImplementedError, match="inference-only"):
+            t(synth.normal((B, 16), 2), device=dev), t(synth.normal((10, B, 16), 3), device=dev))
+    with pytest.raises(NotImplementedError, match="fp32 node tensors"):
         m(*args)
+    g = gine_seq(8, 8, 8).to(dev).eval()
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        g(args[0], args[1], t(synth.normal((gb.num_edges, 8), 4), device=dev), t(synth.normal((5, B, 8), 5), device=dev), args[2],
+          return_convs=True)
+
+
+def test_lcgn_seq_gradients_vs_oracle(dev):
+    """lcgn_seq (lcgn.py:303-323) is differentiable: gradients of every parameter and input against autograd through
+    the oracle's lcgn_seq; the same weights under no_grad run the fused inference path and agree."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.lcgn import lcgn_seq
+    gb = synth.make_graph_batch(5, seed=0x1C6, nodes_lo=4, nodes_hi=14, rel_per_node=1.5)
+    N, B, O, L = gb.num_nodes, gb.num_graphs, 32, 6
+    p = synth.lcgn_seq_params(20, O, seed=11, cmd_dim=O, question_dim=O)
+    rng = np.random.default_rng(3)
+    for k in list(p):
+        if k.endswith("bias"):
+            p[k] = (p[k] + 0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    m = lcgn_seq(20, O, 20, 5, gat_cmd_dim=O, question_dim=O)
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in p.items()}, strict=False)
+    assert not unexpected and all(k.startswith("bns.") for k in missing), (missing, unexpected)
+    m = m.to(dev).eval()
+    x, q, lstm, xc, w = (synth.normal((N, 20), 1), synth.normal((B, O), 2), synth.normal((L, B, O), 3),
+                         synth.normal((N, O), 4), synth.normal((N, O), 5))
+    xs = [t(a, device=dev).requires_grad_(True) for a in (x, q, lstm)]
+    ei, b = t(gb.edge_index, device=dev), t(gb.batch, device=dev)
+    out = m(xs[0], ei, b, xs[1], xs[2], x_ctx_init=t(xc, device=dev))
+    (out * t(w, device=dev)).sum().backward()
+    rp = {k: v.double().requires_grad_(True) for k, v in tparams(p).items() if v.is_floating_point()}
+    rs = [t(a).double().requires_grad_(True) for a in (x, q, lstm)]
+    ref = R.lcgn_seq(rs[0], t(gb.edge_index), t(gb.batch), rs[1], rs[2], rp, t(xc).double())
+    (ref * t(w).double()).sum().backward()
+    assert maxabs(out, ref) < 1e-4
+    floor = 1e-3 * max(float(v.grad.abs().max()) for v in list(rp.values()) + rs if v.grad is not None)
+    bad = {}
+    for got, r, name in zip(xs, rs, ("x", "q_encoding", "lstm_outputs")):
+        bad[name] = _rel(got.grad, r.grad, floor)
+    for k, v in m.named_parameters():
+        if k.startswith("bns."):
+            continue
+        rg = rp[k].grad if rp[k].grad is not None else torch.zeros_like(rp[k])
+        bad[k] = _rel(v.grad if v.grad is not None else torch.zeros_like(v), rg, floor)
+    bad = {k: e for k, e in bad.items() if not e < 5e-4}
+    assert not bad, bad
+    with torch.no_grad():
+        fused = m(xs[0], ei, b, xs[1], xs[2], x_ctx_init=t(xc, device=dev))
+    assert maxabs(fused, out) < 1e-4
 
 
 def test_pooling_and_classifier_gradients_vs_oracle(dev):
