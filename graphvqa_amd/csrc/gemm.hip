@@ -224,14 +224,13 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
 // The DMA is issued from inline asm and ordered by counted s_waitcnt vmcnt + barriers; tile t+1 lands
 // while tile t is multiplied (a K step is 64 MFMAs = 4096 issue cycles per wave, far longer than the
 // DMA latency).
-template <int NBUF>
 __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb, LinearEpilogue ep,
                                                         float* C, int64_t ldc, int vec_ep) {
     constexpr int BM = 128, BN = 128, BK = 32;
     constexpr int TILE_BYTES = 128 * BK * 4;                  // one operand tile: 16 KiB
     constexpr int STAGE_BYTES = BM * (BN + 4) * 4;
-    constexpr int OPER_BYTES = 2 * NBUF * TILE_BYTES;
+    constexpr int OPER_BYTES = 4 * TILE_BYTES;                // {A, B} x 2 buffers
     __shared__ __attribute__((aligned(1024))) unsigned char smem[OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
 #undef GVQA_MFMA_K
         }
     };
-    if (NBUF == 2) {
+    {
         // ONE barrier per K step: wait t (issued a whole step ago) -> barrier -> multiply t while DMAing t+1
         // into the other buffer.  The barrier serves both orders: tile t has landed for every wave, and
         // every wave has finished reading the buffer of step t-1 before anyone refills it.
@@ -314,137 +313,8 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-    } else {
-        // three buffers, ONE barrier per K step: wait t -> barrier -> issue t+2 (into the buffer every wave
-        // finished reading before it reached this barrier) -> multiply t
-        issue(0);
-        if (nt > 1) issue(1);
-        int cur = 0, nxt = 2;
-        for (int t = 0; t < nt; ++t) {
-            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < nt) issue(nxt);
-            multiply(cur, -1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (++cur == 3) cur = 0;
-            if (++nxt == 3) nxt = 0;
-        }
-        __builtin_amdgcn_s_barrier();
     }
     tile_epilogue<BM, BN, 2, 2, false>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
-}
-
-// ----------------------------------------------------------------------------------------------
-// Small-tile variant: macro tile 64 x 128, K step 16, v_mfma_f32_16x16x4_f32 (32-cycle issue).
-// ~15 KiB of LDS per stage and ~32 accumulator registers per lane let 5 blocks (20 waves) share a
-// CU, so MFMA issue is covered by inter-block parallelism instead of deep intra-block pipelining
-// -- the geometry the vendor library picks for K = 512 (short K loops, many tiles).
-// Fragment trick as above: lane (i = lane & 15, kk = lane >> 4) reads the 4 consecutive k's
-// [4 kk, 4 kk + 4) of row i with one b128 and feeds 4 MFMA steps from it (A and B use the same k map).
-// C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.
-// ----------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SBK = 16;
-constexpr int SLD = SBK + 4;      // 80-byte rows: conflict-free ds_read_b128 across 16 rows
-
-template <bool VEC>
-__global__ __launch_bounds__(256, 5) void k_linear_f32_s16(int M, int N, int K, const float* __restrict__ A, int64_t lda,
-                                                           const float* __restrict__ B, int64_t ldb, LinearEpilogue ep,
-                                                           float* C, int64_t ldc) {
-    constexpr int BM = 64, BN = 128;
-    constexpr int MT = 2, NT = 4;                    // wave tile 32 x 64 = 2 x 4 MFMA tiles, waves 2 x 2
-    __shared__ __attribute__((aligned(16))) float As[2][BM * SLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * SLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // staging: A tile 64 x 16 = 256 float4 (one per thread), B tile 128 x 16 = 512 float4 (two per thread)
-    const int sr = tid >> 2, sc = (tid & 3) * 4;
-    float4 ra, rb0, rb1;
-    auto load_one = [&](const float* __restrict__ P, int64_t ld, int rows, int gr, int gk) -> float4 {
-        const float* p = P + (int64_t)min(gr, rows - 1) * ld;
-        if (VEC) return *reinterpret_cast<const float4*>(p + min(gk, K - 4));
-        return make_float4(p[min(gk + 0, K - 1)], p[min(gk + 1, K - 1)], p[min(gk + 2, K - 1)], p[min(gk + 3, K - 1)]);
-    };
-    auto mask_k = [&](float4 v, int gk) -> float4 {
-        if (gk + 0 >= K) v.x = 0.f;
-        if (gk + 1 >= K) v.y = 0.f;
-        if (gk + 2 >= K) v.z = 0.f;
-        if (gk + 3 >= K) v.w = 0.f;
-        return v;
-    };
-    auto load_tile = [&](int kt) {
-        const int gk = kt * SBK + sc;
-        ra = load_one(A, lda, M, m0 + sr, gk);
-        rb0 = load_one(B, ldb, N, n0 + sr, gk);
-        rb1 = load_one(B, ldb, N, n0 + 64 + sr, gk);
-    };
-    auto store_tile = [&](int buf, int kt) {
-        const int gk = kt * SBK + sc;
-        float4 a = ra, b0 = rb0, b1 = rb1;
-        if (kt * SBK + SBK > K) { a = mask_k(a, gk); b0 = mask_k(b0, gk); b1 = mask_k(b1, gk); }
-        *reinterpret_cast<float4*>(&As[buf][sr * SLD + sc]) = a;
-        *reinterpret_cast<float4*>(&Bs[buf][sr * SLD + sc]) = b0;
-        *reinterpret_cast<float4*>(&Bs[buf][(64 + sr) * SLD + sc]) = b1;
-    };
-
-    const int nkt = (K + SBK - 1) / SBK;
-    load_tile(0);
-    store_tile(0, 0);
-    __syncthreads();
-    const int frow = lane & 15, fk = (lane >> 4) * 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const float* as = &As[cur][(wr * 32 + frow) * SLD + fk];
-        const float* bs = &Bs[cur][(wc * 64 + frow) * SLD + fk];
-        float4 af[MT], bf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 16 * SLD);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 16 * SLD);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-            }
-        if (kt + 1 < nkt) store_tile(cur ^ 1, kt + 1);
-        __syncthreads();
-    }
-    const int ccol = lane & 15, crow0 = 4 * (lane >> 4);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int gc = n0 + wc * 64 + j * 16 + ccol;
-        if (gc >= N) continue;
-        const float bv = ep.bias ? ep.bias[gc] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gr = m0 + wr * 32 + i * 16 + crow0 + r;
-                if (gr < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (ep.addend) v += ep.addend[(int64_t)gr * ep.ld_add + gc];
-                    if (ep.mul) v *= ep.mul[(int64_t)gr * ep.ld_mul + gc];
-                    if (ep.relu == 1) v = fmaxf(v, 0.f);
-                    else if (ep.relu == 2) v = v > 0.f ? v : expf(v) - 1.f;
-                    C[(int64_t)gr * ldc + gc] = v;
-                }
-            }
-        }
-    }
 }
 
 // ---- vendor backends for PLAIN large projections ------------------------------------------------
@@ -772,15 +642,14 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     else if (tile_sel == 1 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 4, 2);
     else if (tile_sel == 2 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 2, 2);
     else if (tile_sel == 3) GVQA_LAUNCH_LINEAR(128, 128, 4, 2);
-    // LDS-DMA staging (2 / 3 buffers): the default for chip-filling products with whole K steps (+10 % over the
-    // register-staged kernel at the config-3 projection); GVQA_GEMM_TILE=5/6 force the register-staged kernels
-    else if ((tile_sel == 7 || tile_sel == 8 || (tile_sel == 0 && cdiv(M, 128) * cdiv(N, 128) >= 256)) && batch == 1 &&
+    // LDS-DMA staging: the default for chip-filling products with whole K steps (+10 % over the register-staged
+    // kernel at the config-3 projection); GVQA_GEMM_TILE=5/6 force the register-staged kernels
+    else if ((tile_sel == 7 || (tile_sel == 0 && cdiv(M, 128) * cdiv(N, 128) >= 256)) && batch == 1 &&
              K % 32 == 0 && vec) {
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128));
         auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
         const int vec_ep = N % 8 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul);
-        if (tile_sel != 8) hipLaunchKernelGGL(k_linear_f32_dma<2>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, vec_ep);
-        else hipLaunchKernelGGL(k_linear_f32_dma<3>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, vec_ep);
+        hipLaunchKernelGGL(k_linear_f32_dma, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, vec_ep);
     }
     // short K: K step 16, 3 blocks/CU (+4.5 % at K = 512) -- unless the grid cannot fill the chip anyway: a lone
     // block per CU is bound by the latency of its serial K steps, and K step 32 halves their number
@@ -788,11 +657,6 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128), (unsigned)batch);
         if (vec) hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2, true, 16>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);
         else hipLaunchKernelGGL((k_linear_f32<128, 128, 2, 2, false, 16>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, strideA, strideB, strideC);
-    }
-    else if (tile_sel == 4 && batch == 1 && cdiv(M, 64) <= 65535) {
-        dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 64));
-        if (vec) hipLaunchKernelGGL((k_linear_f32_s16<true>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc);
-        else hipLaunchKernelGGL((k_linear_f32_s16<false>), grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc);
     }
     else GVQA_LAUNCH_LINEAR(128, 128, 2, 2);    // also tile_sel == 6: force K step 32
 #undef GVQA_LAUNCH_LINEAR
