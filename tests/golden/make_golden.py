@@ -152,6 +152,8 @@ def gen_gat():
                                        inputs="gat_seq_small.npz"),
          out=out_tr, running_mean_after=rm, running_var_after=rv)
 
+    gen_gat_grads(gb, p, x, ea, ins, dn, de, di, K, H)
+
     # D. real model dims (pipeline_model_gat.py:683-687) on the reference's debug scene graphs
     sgs = debug_graphs()
     p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303)
@@ -181,6 +183,31 @@ def gen_gat():
                                 ref="gqa_dataset_entry.py:231-332",
                                 note="(N,E) cross-checked against SURVEY 8c: (21,85),(12,40),(20,107),(6,23)"),
          **arrs)
+
+
+def gen_gat_grads(gb, p, x, ea, ins, dn, de, di, K, H):
+    """C'. the reference's own backward (autograd through gat_skip.gat_seq on the shim): loss = sum(out * w), train mode
+    with dropout 0 (batch-statistics BatchNorm, deterministic) and eval mode; gradients of every input and parameter.
+    `lin_r.weight` is the same Parameter object as `lin_l.weight` in the reference (gat_skip.py:76-77): one gradient."""
+    import gat_skip
+    w = synth.normal((gb.num_nodes, dn), 25)
+    arrays = {"w": w}
+    for mode in ("train", "eval"):
+        m = gat_skip.gat_seq(dn, dn, de, di, K, dropout=0.0, gat_heads=H)
+        load_params(m, p)
+        m.train(mode == "train")
+        xs = [t(a).clone().requires_grad_(True) for a in (x, ea, ins)]
+        out = m(xs[0], t(gb.edge_index), xs[1], xs[2], t(gb.batch))
+        (out * t(w)).sum().backward()
+        arrays[f"{mode}.out"] = out
+        for name, v in zip(("x", "edge_attr", "instr"), xs):
+            arrays[f"{mode}.d_{name}"] = v.grad
+        for k, v in m.named_parameters():
+            arrays[f"{mode}.d_{k}"] = v.grad
+    save("gat_seq_small_grads", dict(case="gat_seq forward+backward (autograd through the reference), dropout=0",
+                                     ref="gat_skip.py:249-279; mainExplain_gat.py:259-263", dn=dn, de=de, di=di, K=K, heads=H,
+                                     param_seed=202, inputs="gat_seq_small.npz", loss="sum(out * w), w = synth.normal((N, dn), 25)"),
+         **arrays)
 
 
 def run_gat_seq_with_taps(m, x, gb, ea, ins):
@@ -357,6 +384,14 @@ def gen_encoder():
 if __name__ == "__main__":
     if "--encoder-only" in sys.argv:
         gen_encoder()
+        sys.exit(0)
+    if "--grads-only" in sys.argv:
+        dn, de, di, K, H = 32, 24, 16, 5, 4
+        gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
+        N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+        stub_dataset_entry()
+        gen_gat_grads(gb, synth.gat_seq_params(dn, dn, de, di, K, H, seed=202), synth.normal((N, dn), 22),
+                      synth.normal((E, de), 23), synth.normal((K, B, di), 24), dn, de, di, K, H)
         sys.exit(0)
     gen_encoder()
     gen_head()

@@ -391,3 +391,30 @@ def test_config1_pipeline_end_to_end_gradients(dev):
             if not e < 5e-4:
                 bad[type(m).__name__ + "." + k] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_gat_seq_gradients_vs_reference_golden(dev, mode):
+    """Forward + backward of gat_seq on the HIP differentiable path against gradients recorded from the REFERENCE's own
+    gat_seq under autograd (tests/golden/gat_seq_small_grads.npz; ragged graphs incl. single-node ones)."""
+    from tests.util import load_golden
+    from graphvqa_amd.gat_skip import gat_seq
+    meta, g0 = load_golden("gat_seq_small")
+    _, g = load_golden("gat_seq_small_grads")
+    dn, de, di, K, H = meta["dn"], meta["de"], meta["di"], meta["K"], meta["heads"]
+    p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=meta["param_seed"])
+    m = gat_seq(dn, dn, de, di, K, dropout=0.0, gat_heads=H)
+    m.load_state_dict({k: t(v) for k, v in p.items()})
+    m = m.to(dev).train(mode == "train")
+    xs = [t(g0[k], device=dev).requires_grad_(True) for k in ("x", "edge_attr", "instr")]
+    out = m(xs[0], t(g0["edge_index"], device=dev), xs[1], xs[2], t(g0["batch"], device=dev))
+    (out * t(g["w"], device=dev)).sum().backward()
+    assert maxabs(out, g[f"{mode}.out"]) < 1e-4
+    scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith(mode + ".d_"))
+    bad = {}
+    for name, v in list(zip(("x", "edge_attr", "instr"), xs)) + list(m.named_parameters()):
+        ref = g[f"{mode}.d_{name}"]
+        err = maxabs(v.grad, ref) / max(float(np.abs(ref).max()), 1e-2 * scale)
+        if not err < 3e-4:
+            bad[name] = err
+    assert not bad, bad

@@ -135,3 +135,30 @@ def test_scene_graph_encoder():
                                    t(g["batch"]), B, p)
     assert maxabs(ee, g["edge_attr_encoded"]) < 2e-5
     assert maxabs(xe, g["x_encoded"]) < 5e-5
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_gat_seq_backward_matches_reference_autograd(mode):
+    """The oracle's autograd against gradients recorded from the REFERENCE's own gat_seq under autograd
+    (tests/golden/gat_seq_small_grads.npz): pins the checker used by the GPU backward tests."""
+    meta, g0 = load_golden("gat_seq_small")
+    _, g = load_golden("gat_seq_small_grads")
+    dn, de, di, K, H = meta["dn"], meta["de"], meta["di"], meta["K"], meta["heads"]
+    p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=meta["param_seed"])
+    rp = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in tparams(p).items()}
+    xs = [t(g0[k]).double().requires_grad_(True) for k in ("x", "edge_attr", "instr")]
+    out = R.gat_seq(xs[0], t(g0["edge_index"]), xs[1], xs[2], t(g0["batch"]), rp, heads=H, training_bn=(mode == "train"))
+    (out * t(g["w"]).double()).sum().backward()
+    assert maxabs(out, g[f"{mode}.out"]) < 1e-4
+    scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith(mode + ".d_"))
+    for name, v in zip(("x", "edge_attr", "instr"), xs):
+        assert maxabs(v.grad, g[f"{mode}.d_{name}"]) < 2e-4 * max(float(np.abs(g[f"{mode}.d_{name}"]).max()), 1e-3 * scale), name
+    for k, v in rp.items():
+        key = f"{mode}.d_{k}"
+        if key not in g:
+            continue
+        rg = v.grad if v.grad is not None else torch.zeros_like(v)
+        if k.endswith("lin_l.weight"):          # the reference's lin_r IS lin_l: its recorded gradient is the sum
+            rr = rp[k.replace("lin_l", "lin_r")].grad
+            rg = rg if rr is None else rg + rr
+        assert maxabs(rg, g[key]) < 2e-4 * max(float(np.abs(g[key]).max()), 1e-3 * scale), k
