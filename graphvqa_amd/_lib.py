@@ -118,7 +118,7 @@ class EncoderParams(C.Structure):
 class MpPlan(C.Structure):
     _fields_ = [("tiled", C.c_int32), ("channel_range", C.c_int32), ("stage_buffers", C.c_int32),
                 ("blocks_per_cu", C.c_int32), ("stages_per_graph", C.c_int32), ("accumulators", C.c_int32),
-                ("lds_bytes", C.c_int64)]
+                ("lds_bytes", C.c_int64), ("blocks_per_graph", C.c_int32)]
 
 
 class GatDims(C.Structure):

@@ -20,6 +20,8 @@
 //     E x H x C ever reaches HBM (the reference writes and re-reads it three times).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace gvqa {
@@ -135,6 +137,7 @@ struct MpArgs {
     int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
     int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
     int nbuf;                 // stage buffers in LDS (prefetch depth = nbuf - 1)
+    int nparts;               // blocks per graph: block (g, part) owns the channel ranges [part, part+1) * nch / nparts
     int lpn_log;              // log2(lanes per node) in the aggregation mapping
     float slope, bn_eps;
 };
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const size_t buf_bytes = (((size_t)a.n_cap * (a.cw >> 2) + MP_THREADS - 1) / MP_THREADS) * MP_THREADS * 16;
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
 
-    const int g = blockIdx.x;
+    const int g = blockIdx.x, part = blockIdx.y;
     const int n0 = a.graph_ptr[g], n1 = a.graph_ptr[g + 1];
     const int tn = n1 - n0;
     if (tn <= 0) return;
@@ -225,7 +228,12 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const int tid = threadIdx.x;
     const int wave_unit0 = __builtin_amdgcn_readfirstlane(tid & ~63);
     const int C = a.C;
-    const int nch = (C + a.cw - 1) / a.cw;
+    const int nch_all = (C + a.cw - 1) / a.cw;
+    // this block's share of the channel ranges (small batches: several blocks per graph, each repeating the cheap
+    // alpha prologue, so that the chip is filled and the last block wave is fine-grained)
+    const int r_lo = part * nch_all / a.nparts, r_hi = (part + 1) * nch_all / a.nparts;
+    const int nch = r_hi - r_lo;
+    if (nch <= 0) return;
     const int spc = H + (a.skip ? 1 : 0);            // stages per channel range
     const int T = nch * spc;
     const int q4cap = a.cw >> 2;
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     };
 
     const int depth = a.nbuf - 1;
-    int pf_j = 0, pf_c0 = 0, pf_buf = 0, pf_t = 0;      // cursor of the next stage to prefetch
+    int pf_j = 0, pf_c0 = r_lo * a.cw, pf_buf = 0, pf_t = 0;      // cursor of the next stage to prefetch
     for (; pf_t < depth && pf_t < T; ++pf_t) { prefetch(pf_j, pf_c0, pf_buf); advance(pf_j, pf_c0, pf_buf); }
 
     // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         const float den = sum + 1e-16f;
         for (int s = lo; s < hi; ++s) {
             float al = alpha_s[s * H + h] / den;
-            if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+            if (a.alpha_out && part == 0) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
             if (a.alpha_mask) al *= a.alpha_mask[(int64_t)a.csr_eid[e0 + s] * H + h];
             alpha_s[s * H + h] = al;
         }
@@ -334,8 +342,8 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
 
     // DMA instructions per wave for a stage of a full-width / of the last (narrower) channel range
     const int dma_full = (tn * q4cap + MP_THREADS - 1) / MP_THREADS;
-    const int dma_last = (tn * ((C - (nch - 1) * a.cw) >> 2) + MP_THREADS - 1) / MP_THREADS;
-    const int last_c0 = (nch - 1) * a.cw;
+    const int dma_last = (tn * ((C - (nch_all - 1) * a.cw) >> 2) + MP_THREADS - 1) / MP_THREADS;
+    const int last_c0 = (nch_all - 1) * a.cw;
 
     // Per-item row extents and the wave-uniform trip count of the 4-wide edge loop are the same in
     // every stage: computed once per graph.  (Wave-uniform trips + branch-free body: a divergent
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         it_trips[k] = __builtin_amdgcn_readfirstlane(trips);
     }
 
-    int cur_j = 0, cur_c0 = 0, cur_buf = 0;               // cursor of the stage being consumed
+    int cur_j = 0, cur_c0 = r_lo * a.cw, cur_buf = 0;     // cursor of the stage being consumed
     for (int t = 0; t < T; ++t) {
         // Wait until stage t has landed: this wave's DMAs of stage t are older than those of stages
         // t+1 .. t+depth-1, loads retire in order, so "at most N outstanding" with N = the younger
@@ -586,6 +594,17 @@ static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
     return p;
 }
 
+// Blocks per graph.  Splitting a graph's channel ranges over n blocks repeats its alpha prologue n times, so it only
+// pays while the batch cannot fill the chip by itself (measured at d = 512, 32-node graphs: B = 64: 39.9 us with one
+// block per graph, 18.9 us with four; B = 256: 41.5 -> 32.4 us with two; B >= 1000: one block per graph is best, the
+// block-wave tail costs less than the repeated prologues).  Target two blocks per CU.  GVQA_MP_PARTS overrides.
+static int plan_parts(int64_t B, int C, const TilePlan& p) {
+    const int64_t nch = cdiv(C, p.cw);
+    const size_t forced = env_size("GVQA_MP_PARTS", 0);
+    if (forced) return (int)std::min<int64_t>((int64_t)forced, nch);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(nch, cdiv(2 * 256, std::max<int64_t>(B, 1))));
+}
+
 template <int H, int ITEMS>
 static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
     static bool attr_set = false;
@@ -594,7 +613,7 @@ static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStre
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gat_mp_tiled<H, ITEMS>), dim3((unsigned)B), dim3(MP_THREADS), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_gat_mp_tiled<H, ITEMS>), dim3((unsigned)B, (unsigned)a.nparts), dim3(MP_THREADS), p.lds_bytes, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -628,7 +647,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.bias = d->bias;
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
     a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_mask = d->alpha_mask; a.alpha_csr = nullptr;
-    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.lpn_log = 0;
+    a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.nparts = 1; a.lpn_log = 0;
     a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
     const int force = d->force;
     const float* graph_term = d->graph_term;
@@ -644,6 +663,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
                  "H in {1,2,4,8}, largest graph fitting 160 KiB of LDS)");
     if (plan.ok && force != 2) {
         a.cw = plan.cw; a.e_cap = plan.e_cap; a.n_cap = plan.n_cap; a.nbuf = plan.nbuf; a.lpn_log = plan.lpn_log;
+        a.nparts = plan_parts(g->num_graphs, C, plan);
         switch (H) {
             case 1: return launch_tiled<1>(a, plan, g->num_graphs, stream);
             case 2: return launch_tiled<2>(a, plan, g->num_graphs, stream);
@@ -867,6 +887,7 @@ int gvqa_gat_mp_plan(const gvqa_graph* g, int32_t C, int32_t H, gvqa_mp_plan* ou
         out->channel_range = p.cw;
         out->stage_buffers = p.nbuf;
         out->lds_bytes = (int64_t)p.lds_bytes;
+        out->blocks_per_graph = plan_parts(g->num_graphs, C, p);
         out->blocks_per_cu = (int32_t)(LDS_MAX / p.lds_bytes);
         out->stages_per_graph = (int32_t)(cdiv(C, p.cw) * (H + 1));
         out->accumulators = ((size_t)p.n_cap <= (size_t)2 * (MP_THREADS >> p.lpn_log)) ? 2 : MP_ITEMS;

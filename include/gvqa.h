@@ -266,6 +266,7 @@ typedef struct gvqa_mp_plan {
     int32_t stages_per_graph;  /* DMA stages per graph incl. the skip-row stage of every channel range       */
     int32_t accumulators;      /* float4 accumulators per thread                                             */
     int64_t lds_bytes;         /* dynamic LDS per block                                                      */
+    int32_t blocks_per_graph;  /* > 1 for small batches: the channel ranges of a graph are split over several blocks */
 } gvqa_mp_plan;
 int gvqa_gat_mp_plan(const gvqa_graph* g, int32_t C, int32_t H, gvqa_mp_plan* out);
 

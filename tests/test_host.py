@@ -131,6 +131,10 @@ def test_mp_tiling_plan_host_logic():
     p = plan(_fake_graph(65536, 262144, 2048, 32, 128), 512, 4)          # BASELINE config 3
     assert p.tiled == 1 and p.channel_range == 128 and p.stage_buffers == 2 and p.blocks_per_cu == 3
     assert p.stages_per_graph == 4 * 5 and p.accumulators == 2 and p.lds_bytes <= 160 * 1024 // 3
+    assert p.blocks_per_graph == 1                                          # a full batch: one block per graph
+    small = plan(_fake_graph(2048, 8192, 64, 32, 128), 512, 4)              # 64 graphs cannot fill 256 CUs
+    assert small.tiled == 1 and small.blocks_per_graph == 4 and small.channel_range == 128
+    assert plan(_fake_graph(8192, 32768, 256, 32, 128), 512, 4).blocks_per_graph == 2
     p = plan(_fake_graph(29785, 59570, 1000, 40, 80), 300, 4)            # BASELINE config 2
     assert p.tiled == 1 and p.channel_range == 100 and p.blocks_per_cu >= 3 and p.channel_range % 4 == 0
     p = plan(_fake_graph(5000, 20000, 1, 5000, 20000), 32, 4)            # one huge graph: no LDS tile
