@@ -733,3 +733,29 @@ def test_lcgn_bf16_node_features(dev, pieces):
     out32 = m32(*args, x_ctx_init=t(x_ctx, device=dev))
     assert maxabs(out32, ref) < TOL
     assert maxabs(out32, out) > 1e-5          # the two modes really differ (bf16 rounding is visible)
+
+
+def test_forward_is_hip_graph_capturable(dev):
+    """The library only enqueues work on the caller's stream (no hidden synchronisation or allocation): with a prebuilt
+    batch handle the whole gat_seq forward can be captured in a HIP graph (torch.cuda.CUDAGraph) and replayed on new
+    input values, bit-identically to the eager launches."""
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch
+    gb = synth.make_graph_batch(16, seed=0xCA9, nodes_lo=8, nodes_hi=30, rel_per_node=1.5)
+    N, E, B, D = gb.num_nodes, gb.num_edges, gb.num_graphs, 64
+    m = _load_module(gat_seq(D, D, D, 96, 3, dropout=0.1, gat_heads=4), synth.gat_seq_params(D, D, D, 96, 3, 4, seed=3), dev)
+    x, ea, ins = [t(a, device=dev) for a in (synth.normal((N, D), 1), synth.normal((E, D), 2), synth.normal((3, B, 96), 3))]
+    ei, b = t(gb.edge_index, device=dev), t(gb.batch, device=dev)
+    g = SceneGraphBatch(ei, b, N, B)                     # reads statistics back: outside the capture
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            m(x, ei, ea, ins, b, graph=g)
+    torch.cuda.synchronize()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg, stream=s):
+        out = m(x, ei, ea, ins, b, graph=g)
+    x.copy_(t(synth.normal((N, D), 11), device=dev))     # new values in the captured input buffer
+    cg.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, m(x, ei, ea, ins, b, graph=g))
