@@ -226,12 +226,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
 // DMA latency).
 __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb, LinearEpilogue ep,
-                                                        float* C, int64_t ldc, int vec_ep) {
+                                                        float* C, int64_t ldc) {
     constexpr int BM = 128, BN = 128, BK = 32;
     constexpr int TILE_BYTES = 128 * BK * 4;                  // one operand tile: 16 KiB
-    constexpr int STAGE_BYTES = BM * (BN + 4) * 4;
-    constexpr int OPER_BYTES = 4 * TILE_BYTES;                // {A, B} x 2 buffers
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];      // {A, B} x 2 buffers
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -290,10 +288,13 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
             for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(at + a_row + i * 32 * 128 + xo[kg]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const float4*>(bt + b_row + j * 32 * 128 + xo[kg]);
-            // k-major order: consecutive MFMAs hit different accumulators (a dependent MFMA is 4 issues away)
+            // k-major order: consecutive MFMAs hit different accumulators (a dependent MFMA is 4 issues away).
+            // Operands swapped (B fragment first): the accumulators hold the TRANSPOSED 32 x 32 tile, i.e. a lane owns
+            // 4 CONSECUTIVE COLUMNS of one C row per register quad -- the epilogue stores them as float4 straight from
+            // the registers
 #define GVQA_MFMA_K(c_)                                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].c_, bf[j].c_, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].c_, af[i].c_, acc[i][j], 0, 0, 0);
             GVQA_MFMA_K(x)
             if (pf >= 0) issue2(pf, kg);
             GVQA_MFMA_K(y) GVQA_MFMA_K(z) GVQA_MFMA_K(w)
@@ -314,7 +315,40 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
         }
         __builtin_amdgcn_s_barrier();
     }
-    tile_epilogue<BM, BN, 2, 2, false>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
+    // Epilogue from the transposed accumulators: D'[n, m] with "column" = lane & 31 -> m, "row" = (r & 3) + 8 (r >> 2) +
+    // 4 (lane >> 5) -> n.  16 float4 stores per lane, no LDS round trip, no barrier.
+    const int mrow = lane & 31, ncol0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gr = m0 + wr * 64 + i * 32 + mrow;
+        if (gr >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gc = n0 + wc * 64 + j * 32 + 8 * q + ncol0;
+                if (gc >= N) continue;                 // N % 4 == 0: a quad is entirely inside or outside
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (ep.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(ep.bias + gc);
+                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                }
+                if (ep.addend) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
+                    v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                }
+                if (ep.mul) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc);
+                    v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
+                }
+                if (ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (ep.relu == 2) {
+                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : expf(v.y) - 1.f;
+                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : expf(v.w) - 1.f;
+                }
+                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
+            }
+    }
 }
 
 // ---- vendor backends for PLAIN large projections ------------------------------------------------
@@ -634,6 +668,9 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
                                strideB, strideC);                                                      \
     } while (0)
     static const int tile_sel = []() { const char* v = getenv("GVQA_GEMM_TILE"); return v ? atoi(v) : 0; }();
+    // the LDS-DMA kernel stores C (and reads bias / addend / mul) as float4: whole 4-column quads, 16-byte aligned rows
+    auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
+    const bool ep4_ok = N % 4 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul) && al16(ep.bias, 4);
     if (N <= 32) GVQA_LAUNCH_LINEAR(128, 32, 4, 1);
     else if (N <= 64) GVQA_LAUNCH_LINEAR(128, 64, 2, 2);
     // per-graph products (M = graphs): a 128 x 128 tile is >= 27 us of MFMA issue for its 4 waves however few
@@ -645,11 +682,9 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     // LDS-DMA staging: the default for chip-filling products with whole K steps (+10 % over the register-staged
     // kernel at the config-3 projection); GVQA_GEMM_TILE=5/6 force the register-staged kernels
     else if ((tile_sel == 7 || (tile_sel == 0 && cdiv(M, 128) * cdiv(N, 128) >= 256)) && batch == 1 &&
-             K % 32 == 0 && vec) {
+             K % 32 == 0 && vec && ep4_ok) {
         dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128));
-        auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
-        const int vec_ep = N % 8 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul);
-        hipLaunchKernelGGL(k_linear_f32_dma, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc, vec_ep);
+        hipLaunchKernelGGL(k_linear_f32_dma, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, ep, C, ldc);
     }
     // short K: K step 16, 3 blocks/CU (+4.5 % at K = 512) -- unless the grid cannot fill the chip anyway: a lone
     // block per CU is bound by the latency of its serial K steps, and K step 32 halves their number
