@@ -14,6 +14,8 @@
 // lane-half kk = lane>>5 takes the 4 consecutive k's [8t+4kk, 8t+4kk+4) from ONE b128 read and
 // feeds 4 MFMA steps from it.
 #include <dlfcn.h>
+
+#include <algorithm>
 #include <stdlib.h>
 
 #include <hipblaslt/hipblaslt.h>
@@ -214,6 +216,45 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_f32(int M, int N, int K
     }
 }
 
+// Epilogue from TRANSPOSED accumulators (MFMA operands swapped): D'[n, m] with "column" = lane & 31 -> m,
+// "row" = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n, so a lane owns 4 consecutive columns of one C row per register
+// quad.  16 float4 stores per lane, no LDS round trip, no barrier.
+__device__ __forceinline__ void store_tile_transposed(f32x16 (&acc)[2][2], int M, int N, int m0, int n0, int wr, int wc, int lane,
+                                                      const LinearEpilogue& ep, float* C, int64_t ldc) {
+    const int mrow = lane & 31, ncol0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gr = m0 + wr * 64 + i * 32 + mrow;
+        if (gr >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gc = n0 + wc * 64 + j * 32 + 8 * q + ncol0;
+                if (gc >= N) continue;                 // N % 4 == 0: a quad is entirely inside or outside
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (ep.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(ep.bias + gc);
+                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                }
+                if (ep.addend) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
+                    v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                }
+                if (ep.mul) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc);
+                    v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
+                }
+                if (ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (ep.relu == 2) {
+                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : expf(v.y) - 1.f;
+                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : expf(v.w) - 1.f;
+                }
+                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
+            }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // LDS-DMA variant of the 128 x 128 tile (K % 32 == 0, 16-byte aligned rows).  The operand tiles go
 // HBM/L2 -> LDS with `global_load_lds_dwordx4`: no VGPR staging, no ds_write, nothing for the waves to
@@ -315,40 +356,7 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
         }
         __builtin_amdgcn_s_barrier();
     }
-    // Epilogue from the transposed accumulators: D'[n, m] with "column" = lane & 31 -> m, "row" = (r & 3) + 8 (r >> 2) +
-    // 4 (lane >> 5) -> n.  16 float4 stores per lane, no LDS round trip, no barrier.
-    const int mrow = lane & 31, ncol0 = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gr = m0 + wr * 64 + i * 32 + mrow;
-        if (gr >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gc = n0 + wc * 64 + j * 32 + 8 * q + ncol0;
-                if (gc >= N) continue;                 // N % 4 == 0: a quad is entirely inside or outside
-                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                if (ep.bias) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(ep.bias + gc);
-                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-                }
-                if (ep.addend) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
-                    v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
-                }
-                if (ep.mul) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc);
-                    v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
-                }
-                if (ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                else if (ep.relu == 2) {
-                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : expf(v.y) - 1.f;
-                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : expf(v.w) - 1.f;
-                }
-                *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
-            }
-    }
+    store_tile_transposed(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
 }
 
 // ---- vendor backends for PLAIN large projections ------------------------------------------------
