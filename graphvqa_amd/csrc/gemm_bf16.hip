@@ -135,17 +135,76 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int 
 // (still the same 128-byte line per 8 lanes) and the fragment read applies the same XOR.  The DMA is
 // issued from inline asm (invisible to the compiler's LDS dependence tracking) and ordered by counted
 // `s_waitcnt vmcnt` + barriers: tile t+1 is in flight while tile t is multiplied.
+// Epilogue from TRANSPOSED accumulators (MFMA operands swapped: a lane owns 4 consecutive columns of one C row per
+// register quad): 16 stores per lane of 8 bytes (bf16 C) / 16 bytes (fp32 C), addend / mul read the same way; no LDS
+// round trip, no barrier.  Needs N % 4 == 0 and 8- / 16-byte aligned rows.
+template <bool C16, typename TC>
+__device__ __forceinline__ void store_tile_transposed_b(f32x16 (&acc)[2][2], int M, int N, int m0, int n0, int wr, int wc, int lane,
+                                                        const LinearEpilogue& ep, TC* C, int64_t ldc) {
+    const int mrow = lane & 31, ncol0 = 4 * (lane >> 5);
+    auto load4 = [&](const float* base, int64_t elem, float (&o)[4]) {
+        if constexpr (C16) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+            o[0] = __uint_as_float(raw.x << 16); o[1] = __uint_as_float(raw.x & 0xFFFF0000u);
+            o[2] = __uint_as_float(raw.y << 16); o[3] = __uint_as_float(raw.y & 0xFFFF0000u);
+        } else {
+            const float4 t = *reinterpret_cast<const float4*>(base + elem);
+            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gr = m0 + wr * 64 + i * 32 + mrow;
+        if (gr >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gc = n0 + wc * 64 + j * 32 + 8 * q + ncol0;
+                if (gc >= N) continue;                 // N % 4 == 0: a quad is entirely inside or outside
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (ep.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(ep.bias + gc);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (ep.addend) {
+                    float a4[4];
+                    load4(ep.addend, (int64_t)gr * ep.ld_add + gc, a4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += a4[e];
+                }
+                if (ep.mul) {
+                    float m4[4];
+                    load4(ep.mul, (int64_t)gr * ep.ld_mul + gc, m4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ep.relu == 1) v[e] = fmaxf(v[e], 0.f);
+                    else if (ep.relu == 2) v[e] = v[e] > 0.f ? v[e] : expf(v[e]) - 1.f;
+                }
+                if constexpr (C16) {
+                    uint2 o;
+                    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(C + (int64_t)gr * ldc + gc) = o;
+                } else {
+                    *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    }
+}
+
 template <bool C16>
 __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, int P, const uint16_t* __restrict__ A, int64_t lda,
                                                          const uint16_t* __restrict__ B, int64_t ldb, LinearEpilogue ep,
-                                                         void* C_, int64_t ldc, int vec_ep) {
+                                                         void* C_, int64_t ldc) {
     constexpr int BM = 128, BN = 128, WR = 2, WC = 2, BK = 64;
     constexpr int TILE_BYTES = 128 * BK * 2;                  // one operand tile: 16 KiB
-    constexpr int STAGE_BYTES = BM * (BN + 4) * 4;
-    constexpr int OPER_BYTES = 4 * TILE_BYTES;                // {A, B} x 2 buffers
     typedef typename std::conditional<C16, uint16_t, float>::type TC;
     TC* C = static_cast<TC*>(C_);
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];      // {A, B} x 2 buffers
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -223,16 +282,17 @@ __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, in
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bt + b_row + j * 32 * 128 + xo[kg]));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[0][1], 0, 0, 0);
+            // operands swapped (B fragment first): transposed accumulators, see store_tile_transposed_b
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[0], acc[0][1], 0, 0, 0);
             if (more) issue2(cur ^ 1, kg);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[1][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[1], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[1], acc[1][1], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    tile_epilogue<BM, BN, WR, WC, C16>(acc, smem, M, N, m0, n0, ep, C, ldc, vec_ep);
+    store_tile_transposed_b<C16>(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
 }
 
 // Wpk[n, p*Kp + k] = p-th bf16 piece of W[n, k] (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the
@@ -280,14 +340,20 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld * esz) % 16 == 0); };
     const int vec_ep = N % 8 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul) &&
                        (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 3) == 0);
+    const uintptr_t qa = c16 ? 7 : 15;        // quad = 8 bytes of bf16 / 16 bytes of fp32
+    auto alq = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & qa) == 0 && ld % 4 == 0); };
+    const bool vec_ep_quads = alq(C, ldc) && alq(ep.addend, ep.ld_add) && alq(ep.mul, ep.ld_mul) &&
+                              (!ep.bias || (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0);
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* b = static_cast<const uint16_t*>(Wpk);
     static const bool no_dma = []() { const char* v = getenv("GVQA_BF16_GEMM"); return v && !strcmp(v, "regs"); }();
-    if (K % 64 == 0 && !no_dma) {        // LDS-DMA staging (whole K steps only)
+    // LDS-DMA staging: whole K steps, and the register epilogue's 4-column quads need aligned rows
+    const bool quad_ok = N % 4 == 0 && vec_ep_quads;
+    if (K % 64 == 0 && !no_dma && quad_ok) {
         if (c16) hipLaunchKernelGGL(k_linear_bf16_dma<true>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda, b,
-                                    (int64_t)P * K, ep, C, ldc, vec_ep);
+                                    (int64_t)P * K, ep, C, ldc);
         else hipLaunchKernelGGL(k_linear_bf16_dma<false>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda, b,
-                                (int64_t)P * K, ep, C, ldc, vec_ep);
+                                (int64_t)P * K, ep, C, ldc);
         GVQA_LAUNCH_CHECK();
         return GVQA_OK;
     }

@@ -2,6 +2,7 @@
 Run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import json, sys, time
 import numpy as np, torch
+torch.set_grad_enabled(False)      # inference measurements: fused path
 sys.path.insert(0, ".")
 from graphvqa_amd import synth
 from graphvqa_amd.graph import SceneGraphBatch
