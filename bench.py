@@ -172,13 +172,16 @@ def main():
         head = (pool.to(dev).eval(), clf.to(dev).eval())
         q_feat = tt(synth.normal((B, D), 4 + 10 * rank)).to(dev)
 
+    from graphvqa_amd.graph import SceneGraphBatch
+
     def step():
-        h = m(x, ei, ea, ins, batch)
+        g = SceneGraphBatch(ei, batch, N, B)            # CSR build from COO: part of every step
+        h = m(x, ei, ea, ins, batch, graph=g)
         if head is not None:
-            logits = head[1](head[0](h, q_feat, batch), q_feat)
+            logits = head[1](head[0](h, q_feat, batch, graph=g), q_feat)
             return all_gather_graph_rows(logits, counts=[B] * world, force=force_dist) if dist is not None else logits
         if dist is not None:
-            return all_gather_graph_rows(graph_mean_pool(h, batch, B), counts=[B] * world, force=force_dist)
+            return all_gather_graph_rows(graph_mean_pool(h, batch, B, graph=g), counts=[B] * world, force=force_dist)
         return h
 
     def fence():

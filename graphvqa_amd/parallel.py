@@ -41,9 +41,15 @@ def shard_batch(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int, rank
     return slice(n0, n1), emask, ei, batch[n0:n1] - g0, (g0, g1)
 
 
-def graph_mean_pool(h: torch.Tensor, batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
-    """Per-graph mean of node rows -> [B, C]; the small per-graph payload that is all-gathered.
-    (Stand-in for the answer logits until the pooling/classifier row, SURVEY 8f-2, is built.)"""
+def graph_mean_pool(h: torch.Tensor, batch: torch.Tensor, num_graphs: int, graph=None) -> torch.Tensor:
+    """Per-graph mean of node rows -> [B, C]; the small per-graph payload that is all-gathered when the answer head is
+    not run.  With the batch handle (`graph`, a SceneGraphBatch) on a GPU this is one pass of the HIP segment-sum kernel
+    over h (deterministic); the torch formulation (index_add_) serves the CPU tests."""
+    if graph is not None and h.is_cuda:
+        from .gat_skip import _segment_sum_raw
+        gp = graph.graph_ptr
+        cnt = (gp[1:] - gp[:-1]).clamp(min=1).to(h.dtype)
+        return _segment_sum_raw(h.contiguous(), graph) / cnt[:, None]
     out = torch.zeros((num_graphs, h.shape[1]), dtype=h.dtype, device=h.device)
     out.index_add_(0, batch, h)
     cnt = torch.bincount(batch, minlength=num_graphs).clamp(min=1).to(h.dtype)
