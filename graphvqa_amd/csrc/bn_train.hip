@@ -12,7 +12,7 @@
 namespace gvqa {
 namespace {
 
-constexpr int BN_ROWS = 256;
+constexpr int BN_ROWS = 64;           // rows per block of the column reductions (N / 64 row blocks x C / 256 column blocks)
 
 // mode 0: sum x;  mode 1: sum (x - mean)^2
 __global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const float* __restrict__ x, const float* __restrict__ mean,
@@ -21,21 +21,37 @@ __global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const fl
     if (c >= C) return;
     const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
     const float m = mean ? mean[c] : 0.f;
-    float acc = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        const float v = x[r * C + c] - m;
-        acc += mean ? v * v : v;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four independent chains: loads in flight, fixed summation order
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const float v0 = x[r * C + c] - m, v1 = x[(r + 1) * C + c] - m, v2 = x[(r + 2) * C + c] - m, v3 = x[(r + 3) * C + c] - m;
+        a0 += mean ? v0 * v0 : v0; a1 += mean ? v1 * v1 : v1; a2 += mean ? v2 * v2 : v2; a3 += mean ? v3 * v3 : v3;
     }
-    partial[(int64_t)blockIdx.y * C + c] = acc;
+    for (; r < r1; ++r) {
+        const float v = x[r * C + c] - m;
+        a0 += mean ? v * v : v;
+    }
+    partial[(int64_t)blockIdx.y * C + c] = (a0 + a1) + (a2 + a3);
 }
 
+// out[c] = scale * sum_b partial[b * blk_stride + c]: a block owns 16 columns, its 16 thread rows sum interleaved
+// row blocks, then an LDS tree -- 32 blocks and 16-deep load chains instead of 2 blocks and nblocks-deep ones.
 __global__ __launch_bounds__(256) void k_bn_col_finish(int nblocks, int C, const float* __restrict__ partial, int64_t blk_stride,
                                                        float scale, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * blk_stride + c];
-    out[c] = acc * scale;
+    if (c < C)
+        for (int b = ry; b < nblocks; b += 16) acc += partial[(int64_t)b * blk_stride + c];
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        out[c] = t * scale;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bn_relu_apply(int64_t total, int C, const float* __restrict__ x, const float* __restrict__ mean,
@@ -100,7 +116,7 @@ extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(ws);
     const int nb = (int)cdiv(N, BN_ROWS);
-    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 256));
+    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 16));
     GVQA_REQUIRE(nb <= 65535, GVQA_E_UNSUPPORTED, "bn_relu_train_forward: N too large");
     hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, nullptr, partial);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_mean);
@@ -126,7 +142,7 @@ extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x,
     float* partial = static_cast<float*>(ws);
     const int nb = (int)cdiv(N, BN_ROWS);
     GVQA_REQUIRE(nb <= 65535, GVQA_E_UNSUPPORTED, "bn_relu_train_backward: N too large");
-    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 256));
+    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 16));
     hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
