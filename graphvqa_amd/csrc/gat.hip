@@ -683,60 +683,12 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     return GVQA_OK;
 }
 
-// ---- train-mode BatchNorm1d forward (batch statistics over all N rows, gat_skip.py:274) ----------
-// Deterministic two-level column reductions (no atomics): partial[b, c] over row blocks, then a
-// fixed-order finish.  Two passes (mean, then sum of squared deviations) like torch's CPU kernel.
-constexpr int BN_ROWS_PER_BLOCK = 256;
-
-__global__ __launch_bounds__(256) void k_col_partial(int64_t N, int C, const float* __restrict__ x,
-                                                     const float* __restrict__ mean, float* __restrict__ partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS_PER_BLOCK, r1 = min(N, r0 + BN_ROWS_PER_BLOCK);
-    const float m = mean ? mean[c] : 0.f;
-    float acc = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        const float v = x[r * C + c] - m;
-        acc += mean ? v * v : v;
-    }
-    partial[(int64_t)blockIdx.y * C + c] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_col_finish(int nblocks, int C, const float* __restrict__ partial, float inv_n,
-                                                    float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * C + c];
-    out[c] = acc * inv_n;
-}
-
-// h = relu((h - mean) * invstd * w + b), in place
-__global__ __launch_bounds__(256) void k_bn_apply_relu(int64_t total, int C, const float* __restrict__ mean,
-                                                       const float* __restrict__ var, const float* __restrict__ w,
-                                                       const float* __restrict__ b, float eps, float* __restrict__ h) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const float invstd = 1.0f / sqrtf(var[c] + eps);
-        h[i] = fmaxf((h[i] - mean[c]) * invstd * w[c] + b[c], 0.f);
-    }
-}
-
+// Train-mode BatchNorm1d (batch statistics over all N rows, biased variance) + ReLU after the skip, in place:
+// the column-reduction kernels of bn_train.hip (gvqa_bn_relu_train_forward), y == x.
 static int bn_train_forward(int64_t N, int C, float* h, const gvqa_gat_conv_params* p, float eps, float* stats /* [2,C] */,
-                            float* partial, hipStream_t stream) {
+                            float* partial, size_t partial_bytes, hipStream_t stream) {
     StageTimer t(GVQA_STAGE_OTHER, stream);
-    const int nb = (int)cdiv(N, BN_ROWS_PER_BLOCK);
-    dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb);
-    hipLaunchKernelGGL(k_col_partial, grid, dim3(256), 0, stream, N, C, h, nullptr, partial);
-    hipLaunchKernelGGL(k_col_finish, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, nb, C, partial, 1.0f / (float)N, stats);
-    hipLaunchKernelGGL(k_col_partial, grid, dim3(256), 0, stream, N, C, h, stats, partial);
-    hipLaunchKernelGGL(k_col_finish, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, nb, C, partial, 1.0f / (float)N, stats + C);
-    int64_t blocks = cdiv(N * C, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_bn_apply_relu, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, C, stats, stats + C, p->bn_weight,
-                       p->bn_bias, eps, h);
-    GVQA_LAUNCH_CHECK();
-    return GVQA_OK;
+    return gvqa_bn_relu_train_forward(N, C, h, p->bn_weight, p->bn_bias, eps, h, stats, stats + C, partial, partial_bytes, stream);
 }
 
 int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -775,7 +727,7 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.h0 = take((size_t)N * C);
     L.h1 = take((size_t)N * C);
     L.alpha_csr = take((size_t)E * H);
-    L.bn_partial = take((size_t)cdiv(N > 0 ? N : 1, BN_ROWS_PER_BLOCK) * C);
+    L.bn_partial = take(gvqa_bn_train_workspace_bytes(N > 0 ? N : 1, C) / sizeof(float) + 1);
     L.bn_stats = take(2 * C);
     if (proj_bf16x3_enabled()) {     // bf16 pieces: 6*K uint16 per row = 3*K floats
         L.a6 = take((size_t)N * 3 * d->node_dim);
@@ -1042,7 +994,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         if (train_bn) {
             GVQA_REQUIRE(hops[i].bn_bias, GVQA_E_INVALID, "gat_seq: BatchNorm needs weight and bias");
             float* st = bn_stats_out + (int64_t)i * 2 * C;
-            rc = bn_train_forward(N, C, h_next, &hops[i], d->bn_eps, st, P(L.bn_partial), stream);
+            rc = bn_train_forward(N, C, h_next, &hops[i], d->bn_eps, st, P(L.bn_partial),
+                                  gvqa_bn_train_workspace_bytes(N, C), stream);
             if (rc) return rc;
         }
         h = h_next;
