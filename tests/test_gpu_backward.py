@@ -440,3 +440,56 @@ def test_differentiable_path_matches_fused_path_at_config3_size(dev):
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
     assert float(m.convs[0].lin_l.weight.grad.abs().max()) > 0
+
+
+def test_randomized_forward_and_input_gradient_vs_oracle(dev):
+    """40 random batches -- empty graphs in the batch, nodes without in-edges (no self loops guaranteed), hubs taking
+    half of a graph's edges, C in {8, 12, 32, 100}, H in {1, 2, 4}, K in 1..3 -- forward (fused kernels) and dL/dx
+    (differentiable path) against the oracle in fp64."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.gat_skip import gat_seq
+    rng = np.random.default_rng(2024)
+    worst_f = worst_g = 0.0
+    for case in range(40):
+        B, K, H = int(rng.integers(1, 12)), int(rng.integers(1, 4)), int(rng.choice([1, 2, 4]))
+        C, De, Di = int(rng.choice([8, 12, 32, 100])), int(rng.choice([4, 8, 20])), int(rng.choice([4, 16]))
+        sizes = rng.integers(0, 50, size=B)
+        if sizes.sum() == 0:
+            sizes[0] = 3
+        batch = np.repeat(np.arange(B), sizes).astype(np.int64)
+        N, offs = int(sizes.sum()), np.concatenate([[0], np.cumsum(sizes)])
+        src, dst = [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
+        for g in range(B):
+            n = int(sizes[g])
+            if n == 0:
+                continue
+            e = int(rng.integers(0, 4 * n + 1))
+            s_, d_ = rng.integers(0, n, size=e) + offs[g], rng.integers(0, n, size=e) + offs[g]
+            if rng.random() < 0.3 and n > 2:
+                d_[: e // 2] = offs[g]
+            src.append(s_); dst.append(d_)
+        ei = np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64)
+        E = ei.shape[1]
+        p = synth.gat_seq_params(C, C, De, Di, K, H, seed=case)
+        for k in list(p):
+            if "running_var" in k:
+                p[k] = (0.5 + rng.random(p[k].shape)).astype(np.float32)
+            elif "running_mean" in k or k.endswith("bias"):
+                p[k] = (0.2 * rng.standard_normal(p[k].shape)).astype(np.float32)
+        x, ea = rng.standard_normal((N, C)).astype(np.float32), rng.standard_normal((E, De)).astype(np.float32)
+        ins, w = rng.standard_normal((K, B, Di)).astype(np.float32), rng.standard_normal((N, C)).astype(np.float32)
+        m = gat_seq(C, C, De, Di, K, dropout=0.0, gat_heads=H)
+        m.load_state_dict({k: t(v) for k, v in p.items()})
+        m = m.to(dev).eval()
+        args = [t(a, device=dev) for a in (x, ei, ea, ins, batch)]
+        with torch.no_grad():
+            out = m(*args)
+        rp = {k: (v.double() if v.is_floating_point() else v) for k, v in tparams(p).items()}
+        rx = t(x).double().requires_grad_(True)
+        ref = R.gat_seq(rx, t(ei), t(ea).double(), t(ins).double(), t(batch), rp, heads=H)
+        xg = args[0].clone().requires_grad_(True)
+        (m(xg, *args[1:]) * t(w, device=dev)).sum().backward()
+        (ref * t(w).double()).sum().backward()
+        worst_f = max(worst_f, maxabs(out, ref))
+        worst_g = max(worst_g, maxabs(xg.grad, rx.grad) / (float(rx.grad.abs().max()) + 1e-9))
+    assert worst_f < 1e-4 and worst_g < 1e-4, (worst_f, worst_g)
