@@ -192,6 +192,7 @@ PROTOTYPES = {
                                               C.c_void_p]),
     "gvqa_graph_rows_to_nodes": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                            C.c_void_p]),
+    "gvqa_graph_edge_rows_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_graph_segment_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_gat_mp_backward": (C.c_int, [C.POINTER(Graph), C.POINTER(Graph), C.POINTER(GatMpBwdDesc), C.c_void_p]),
     "gvqa_gat_mp_plan": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.POINTER(MpPlan)]),

@@ -312,6 +312,36 @@ __global__ __launch_bounds__(256) void k_graph_segment_sum(int F, const int32_t*
 }
 }  // namespace gvqa
 
+// out[i, :F] = sum over the CSR row of node i of x[csr_eid[s], :F]  (rows of a per-edge tensor summed per destination
+// node -- or per SOURCE node on the transposed graph): the adjoint of the per-edge row gathers x[dst] / x[src], and
+// torch_scatter's scatter_add by destination.  One wave per node, rows added in slot order (deterministic).
+namespace gvqa {
+__global__ __launch_bounds__(256) void k_csr_row_sum(int N, int F, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_eid,
+                                                     const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    for (int c = lane; c < F; c += 64) {
+        float acc = 0.f;
+        for (int s = lo; s < hi; ++s) acc += x[(int64_t)csr_eid[s] * ldx + c];
+        out[(int64_t)i * ldo + c] = acc;
+    }
+}
+}  // namespace gvqa
+
+int gvqa_graph_edge_rows_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_edge_rows_sum: graph not built");
+    GVQA_REQUIRE(F >= 0 && F < (1ll << 31) && ld_x >= F && ld_out >= F, GVQA_E_INVALID, "graph_edge_rows_sum: bad sizes");
+    if (g->num_nodes == 0 || F == 0) return GVQA_OK;
+    GVQA_REQUIRE((x || g->num_edges == 0) && out, GVQA_E_INVALID, "graph_edge_rows_sum: null tensor");
+    hipLaunchKernelGGL(k_csr_row_sum, dim3((unsigned)cdiv(g->num_nodes, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (int)g->num_nodes, (int)F, g->rowptr, g->csr_eid, x, ld_x, out, ld_out);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
 int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
                              int accumulate, void* stream) {
     using namespace gvqa;

@@ -254,6 +254,55 @@ def graph_segment_sum(x: Tensor, graph: SceneGraphBatch) -> Tensor:
     return _GraphSegmentSum.apply(x, graph)
 
 
+def _edge_rows_sum_raw(x: Tensor, g: SceneGraphBatch) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty((g.num_nodes, x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.gvqa_graph_edge_rows_sum(C.byref(g.c), x.shape[1], x.data_ptr(), x.shape[1], out.data_ptr(), x.shape[1],
+                                                _stream(x.device)))
+    return out
+
+
+class _EdgeGather(torch.autograd.Function):
+    """x[src] or x[dst] per COO edge ([N, F] -> [E, F]); backward: HIP CSR row sums over the forward graph (dst) or the
+    transposed one (src) instead of torch's sort-based index_put."""
+
+    @staticmethod
+    def forward(ctx, x, graph, side):
+        edge_index = graph._keep[0]
+        ctx.graph, ctx.side = graph, side
+        return x.index_select(0, edge_index[side])
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.graph if ctx.side == 1 else ctx.graph.transposed()
+        return _edge_rows_sum_raw(_f32c(dout, "dout"), g), None, None
+
+
+class _EdgeScatterAdd(torch.autograd.Function):
+    """out[i] = sum of m[e] over the in-edges e of node i (torch_scatter.scatter_add by destination, HIP, deterministic);
+    backward: dm[e] = dout[dst_e]."""
+
+    @staticmethod
+    def forward(ctx, m, graph):
+        ctx.graph = graph
+        return _edge_rows_sum_raw(_f32c(m, "m"), graph)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout.index_select(0, ctx.graph._keep[0][1]), None
+
+
+def edge_gather(x: Tensor, graph: SceneGraphBatch, side: str) -> Tensor:
+    """Differentiable x[src] (side='src') / x[dst] (side='dst') per edge with a HIP adjoint."""
+    return _EdgeGather.apply(x, graph, 0 if side == "src" else 1)
+
+
+def edge_scatter_add(m: Tensor, graph: SceneGraphBatch) -> Tensor:
+    """Differentiable per-destination sum of per-edge rows ([E, F] -> [N, F]) on the HIP kernel."""
+    return _EdgeScatterAdd.apply(m, graph)
+
+
 def graph_softmax(score: Tensor, graph: SceneGraphBatch) -> Tensor:
     """Softmax of score [N, F] over the nodes of each graph (torch_geometric.utils.softmax semantics: max-shifted,
     denominator + 1e-16), differentiable; the per-graph reductions / broadcasts are the HIP ops above."""

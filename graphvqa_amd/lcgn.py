@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.nn import Linear, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _glorot, gat_message_passing, graph_rows
+from .gat_skip import _f32c, _workspace, _glorot, gat_message_passing, graph_rows, edge_gather
 from .graph import SceneGraphBatch, _stream
 
 
@@ -113,7 +113,7 @@ class lcgn_seq(nn.Module):
             x_joint = torch.cat([x_loc, x_ctx, self.proj_x_ctx(x_ctx) * proj_x_loc], dim=-1)    # :312-313
             x_l, x_r, x_val = L.lin_l(x_joint), L.lin_r(x_joint), L.cal_x(x_joint)    # :144-145,230
             y = graph_rows(L.proj_cmd(cmd), graph) * x_r                              # :148-154
-            a_edge = (x_l[src] * y[dst]).sum(dim=-1, keepdim=True)                    # :207
+            a_edge = (edge_gather(x_l, graph, "src") * edge_gather(y, graph, "dst")).sum(dim=-1, keepdim=True)   # :207
             mask = torch.bernoulli(torch.full((E, 1), 1.0 - p_att, device=x.device)) / (1.0 - p_att) if p_att > 0 else None
             agg, _ = gat_message_passing(x_val, zeros2, a_edge, graph, 1, O, self.negative_slope, mask)   # :209-238
             msg = agg * graph_rows(L.cal_cmd(cmd), graph)                             # :231 (edges are intra-graph)

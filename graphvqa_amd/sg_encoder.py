@@ -14,7 +14,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum
+from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, edge_gather, edge_scatter_add
 from .graph import SceneGraphBatch, _stream
 
 
@@ -60,7 +60,7 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
 
     def _forward_autograd(self, x_tok, e_tok, ei, added, graph):
         """Differentiable formulation of pipeline_model_gat.py:575-610 (training): embeddings and MLPs are torch ops,
-        the scatter_mean is an index_add, the graph LayerNorm's per-graph reductions / broadcasts run on the HIP
+        the per-edge gathers and the scatter_mean use the HIP CSR row-sum kernel (as adjoint / forward), the graph LayerNorm's per-graph reductions / broadcasts run on the HIP
         per-graph ops with their adjoints (my_graph_layernorm.py:57-78: eps OUTSIDE the square root)."""
         emb, m, D = self.sg_vocab_embedding, self.scene_graph_encoding_layer, self.sg_emb_dim
         N = x_tok.shape[0]
@@ -71,11 +71,12 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
             sign[added.to(e.device)] = -1.0                                              # :590
             e = e * sign.view(-1, 1, 1)
         e = e.sum(dim=-2)
-        src, dst = ei[0], ei[1]
-        e2 = m.edge_model.edge_mlp(torch.cat([x[src], x[dst], e], dim=1))                # EdgeModel :65-76
-        mm = m.node_model.node_mlp_1(torch.cat([x[src], e2], dim=1))                     # NodeModel :78-98
+        dst = ei[1]
+        x_src = edge_gather(x, graph, "src")                                             # HIP adjoints (CSR row sums)
+        e2 = m.edge_model.edge_mlp(torch.cat([x_src, edge_gather(x, graph, "dst"), e], dim=1))   # EdgeModel :65-76
+        mm = m.node_model.node_mlp_1(torch.cat([x_src, e2], dim=1))                      # NodeModel :78-98
         cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(mm.dtype)
-        agg = torch.zeros((N, D), device=mm.device).index_add(0, dst, mm) / cnt.view(-1, 1)   # scatter_mean :96
+        agg = edge_scatter_add(mm, graph) / cnt.view(-1, 1)                              # scatter_mean :96
         x2 = m.node_model.node_mlp_2(torch.cat([x, agg], dim=1))
         gp = graph.graph_ptr.long()
         norm = ((gp[1:] - gp[:-1]).clamp(min=1) * D).to(x2.dtype).view(-1, 1)

@@ -166,6 +166,10 @@ int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const floa
 int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
                              int accumulate, void* stream);
 int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
+/* out[i, :F] = sum over the in-edges e of node i of x[e, :F] (x is a per-edge tensor in COO order): scatter_add by
+ * destination -- or by SOURCE when `g` is the transposed graph.  The adjoint of the per-edge gathers x[dst] / x[src]
+ * (torch's own gather backward is a sort-based index_put).  Deterministic. */
+int gvqa_graph_edge_rows_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Building blocks exported for tests, benchmarks and the variants' host code

@@ -216,5 +216,6 @@ def test_every_entry_point_rejects_bad_arguments_without_gpu():
     assert lib.gvqa_bn_relu_train_backward(10, 8, None, None, None, None, None, 1e-5, None, None, None, None, None, 0, None) == E_INV
     assert lib.gvqa_graph_rows_to_nodes(C.byref(g), 8, None, 4, None, 8, 0, None) == E_INV       # ld_rows < F
     assert lib.gvqa_graph_segment_sum(C.byref(g), 8, None, 8, None, 8, None) == E_INV
+    assert lib.gvqa_graph_edge_rows_sum(C.byref(g), 8, None, 8, None, 4, None) == E_INV      # ld_out < F
     assert lib.gvqa_graph_finalize(C.byref(_lib.Graph()), None) == E_INV
     assert lib.gvqa_prof_collect(None, None) == E_INV
