@@ -12,22 +12,32 @@
 
 namespace gvqa {
 
-// out[r, :] = sign(r) * sum_t emb[tok[r, t], :]
+// out[r, :] = sign(r) * sum_t emb[tok[r, t], :].  W = 4: a thread owns 4 consecutive channels (D % 4 == 0).
+template <int W>
 __global__ __launch_bounds__(256) void k_embed_sum(int64_t rows, int T, int V, int D, const int64_t* __restrict__ tok,
                                                    const float* __restrict__ emb, const uint8_t* __restrict__ neg,
                                                    float* __restrict__ out) {
+    const int DW = D / W;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * D) return;
-    const int64_t r = i / D;
-    const int c = (int)(i - r * D);
-    float acc = 0.f;
+    if (i >= rows * DW) return;
+    const int64_t r = i / DW;
+    const int c = (int)(i - r * DW) * W;
+    float acc[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) acc[q] = 0.f;
     for (int t = 0; t < T; ++t) {
         int64_t id = tok[r * T + t];
         id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-        const float v = emb[id * D + c];
-        acc += (neg && neg[r]) ? -v : v;
+        if (W == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(emb + id * D + c);
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        } else {
+            acc[0] += emb[id * D + c];
+        }
     }
-    out[i] = acc;
+    const float sg = (neg && neg[r]) ? -1.f : 1.f;
+    if (W == 4) *reinterpret_cast<float4*>(out + r * D + c) = make_float4(sg * acc[0], sg * acc[1], sg * acc[2], sg * acc[3]);
+    else out[r * D + c] = sg * acc[0];
 }
 
 __global__ __launch_bounds__(256) void k_mark(int64_t n, int64_t limit, const int64_t* __restrict__ idx, uint8_t* flags) {
@@ -36,36 +46,56 @@ __global__ __launch_bounds__(256) void k_mark(int64_t n, int64_t limit, const in
 }
 
 // y[e, :] = relu(a[ia[e], :] + b[ib[e], :] + y[e, :] + bias)       (first Linear of an edge-level MLP,
-// node-side column blocks pre-projected per node; either gather may be absent)
+// node-side column blocks pre-projected per node; either gather may be absent).  W = 4: float4 per thread.
+template <int W>
 __global__ __launch_bounds__(256) void k_gather_add_relu(int64_t E, int D, const float* __restrict__ a,
                                                          const int64_t* __restrict__ ia, const float* __restrict__ b,
                                                          const int64_t* __restrict__ ib, const float* __restrict__ bias,
                                                          float* __restrict__ y) {
+    const int DW = D / W;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= E * D) return;
-    const int64_t e = i / D;
-    const int c = (int)(i - e * D);
-    float v = 0.f;
-    if (a) v += a[ia[e] * D + c];
-    if (b) v += b[ib[e] * D + c];
-    v += y[i];
-    y[i] = fmaxf(v + bias[c], 0.f);
+    if (i >= E * DW) return;
+    const int64_t e = i / DW;
+    const int c = (int)(i - e * DW) * W;
+    if (W == 4) {
+        float4 v = *reinterpret_cast<const float4*>(y + e * D + c);
+        const float4 bi = *reinterpret_cast<const float4*>(bias + c);
+        if (a) { const float4 t = *reinterpret_cast<const float4*>(a + ia[e] * D + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (b) { const float4 t = *reinterpret_cast<const float4*>(b + ib[e] * D + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        *reinterpret_cast<float4*>(y + e * D + c) =
+            make_float4(fmaxf(v.x + bi.x, 0.f), fmaxf(v.y + bi.y, 0.f), fmaxf(v.z + bi.z, 0.f), fmaxf(v.w + bi.w, 0.f));
+    } else {
+        float v = y[e * D + c];
+        if (a) v += a[ia[e] * D + c];
+        if (b) v += b[ib[e] * D + c];
+        y[e * D + c] = fmaxf(v + bias[c], 0.f);
+    }
 }
 
 // agg[i, :] = mean over in-edges of m[eid, :] (torch_scatter.scatter_mean: count clamped to >= 1),
 // rows summed in COO order.  One wave per destination node.
+template <int W>
 __global__ __launch_bounds__(256) void k_segment_mean(int N, int D, const float* __restrict__ m,
                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_eid,
                                                       float* __restrict__ agg) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (i >= N) return;
     const int lo = rowptr[i], hi = rowptr[i + 1];
-    const float cnt = (float)max(hi - lo, 1);
-    for (int c = lane; c < D; c += 64) {
-        float acc = 0.f;
-        for (int s = lo; s < hi; ++s) acc += m[(int64_t)csr_eid[s] * D + c];
-        agg[(int64_t)i * D + c] = acc / cnt;
+    const float inv = 1.0f / (float)max(hi - lo, 1);
+    for (int c = lane * W; c < D; c += 64 * W) {
+        if (W == 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = lo; s < hi; ++s) {
+                const float4 v = *reinterpret_cast<const float4*>(m + (int64_t)csr_eid[s] * D + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(agg + (int64_t)i * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        } else {
+            float acc = 0.f;
+            for (int s = lo; s < hi; ++s) acc += m[(int64_t)csr_eid[s] * D + c];
+            agg[(int64_t)i * D + c] = acc * inv;
+        }
     }
 }
 
@@ -147,14 +177,21 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
     do { rc = launch_linear(M_, D, K_, A_, K_, W_, ldw_, b_, act_, C_, D, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
 
     // token-embedding sums (:583-593); reverse edges added for symmetry carry the negated embedding (:590)
-    hipLaunchKernelGGL(k_embed_sum, dim3((unsigned)cdiv(N * D, 256)), dim3(256), 0, stream, N, node_tokens, V, D, x_tokens,
-                       p->embedding, nullptr, P(L.x0));
+    // float4 rows when D % 4 == 0 (workspace slices are 256-byte aligned; the embedding table must be 16-byte aligned)
+    const bool v4 = D % 4 == 0 && ((reinterpret_cast<uintptr_t>(p->embedding) | reinterpret_cast<uintptr_t>(edge_attr_encoded) |
+                                    reinterpret_cast<uintptr_t>(p->edge0_bias) | reinterpret_cast<uintptr_t>(p->node1_0_bias)) & 15) == 0;
+    const int DW = v4 ? D / 4 : D;
+#define ENC_LAUNCH(KERNEL_, ROWS_, ...)                                                                              \
+    do {                                                                                                             \
+        if (v4) hipLaunchKernelGGL(KERNEL_<4>, dim3((unsigned)cdiv((ROWS_) * DW, 256)), dim3(256), 0, stream, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(KERNEL_<1>, dim3((unsigned)cdiv((ROWS_) * DW, 256)), dim3(256), 0, stream, __VA_ARGS__);      \
+    } while (0)
+    ENC_LAUNCH(k_embed_sum, N, N, node_tokens, V, D, x_tokens, p->embedding, (const uint8_t*)nullptr, P(L.x0));
     if (E > 0) {
         GVQA_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)E, stream));
         if (num_added > 0)
             hipLaunchKernelGGL(k_mark, dim3((unsigned)cdiv(num_added, 256)), dim3(256), 0, stream, num_added, E, added_sym_edge, flags);
-        hipLaunchKernelGGL(k_embed_sum, dim3((unsigned)cdiv(E * D, 256)), dim3(256), 0, stream, E, edge_tokens_per_edge, V, D,
-                           edge_tokens, p->embedding, flags, P(L.e0));
+        ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, p->embedding, (const uint8_t*)flags, P(L.e0));
     }
     GVQA_LAUNCH_CHECK();
     // EdgeModel: e' = Lin2(relu(Lin1([x_src || x_dst || e])))                       (:65-76)
@@ -162,21 +199,22 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         LINW(N, D, P(L.x0), p->edge0_weight, 3 * D, nullptr, 0, P(L.S));
         LINW(N, D, P(L.x0), p->edge0_weight + D, 3 * D, nullptr, 0, P(L.Dd));
         LINW(E, D, P(L.e0), p->edge0_weight + 2 * D, 3 * D, nullptr, 0, P(L.Y));
-        hipLaunchKernelGGL(k_gather_add_relu, dim3((unsigned)cdiv(E * D, 256)), dim3(256), 0, stream, E, D, P(L.S), src, P(L.Dd),
-                           dst, p->edge0_bias, P(L.Y));
+        ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.S), src, (const float*)P(L.Dd), dst, p->edge0_bias, P(L.Y));
         GVQA_LAUNCH_CHECK();
         LINW(E, D, P(L.Y), p->edge2_weight, D, p->edge2_bias, 0, edge_attr_encoded);
         // NodeModel part 1: m = Lin2(relu(Lin1([x_src || e'])))                     (:92-95)
         LINW(N, D, P(L.x0), p->node1_0_weight, 2 * D, nullptr, 0, P(L.P));
         LINW(E, D, edge_attr_encoded, p->node1_0_weight + D, 2 * D, nullptr, 0, P(L.Y));
-        hipLaunchKernelGGL(k_gather_add_relu, dim3((unsigned)cdiv(E * D, 256)), dim3(256), 0, stream, E, D, P(L.P), src,
-                           (const float*)nullptr, (const int64_t*)nullptr, p->node1_0_bias, P(L.Y));
+        ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.P), src, (const float*)nullptr, (const int64_t*)nullptr,
+                   p->node1_0_bias, P(L.Y));
         GVQA_LAUNCH_CHECK();
         LINW(E, D, P(L.Y), p->node1_2_weight, D, p->node1_2_bias, 0, P(L.m));
     }
     // scatter_mean by destination                                                   (:96)
-    hipLaunchKernelGGL(k_segment_mean, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, D, P(L.m), g->rowptr, g->csr_eid,
-                       P(L.agg));
+    if (v4) hipLaunchKernelGGL(k_segment_mean<4>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, D, P(L.m), g->rowptr,
+                               g->csr_eid, P(L.agg));
+    else hipLaunchKernelGGL(k_segment_mean<1>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, D, P(L.m), g->rowptr,
+                            g->csr_eid, P(L.agg));
     GVQA_LAUNCH_CHECK();
     // NodeModel part 2: x' = Lin2(relu(Lin1([x || agg])))                           (:97-98)
     LINW(N, D, P(L.x0), p->node2_0_weight, 2 * D, p->node2_0_bias, 0, P(L.t));
@@ -187,6 +225,7 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
     }
     LINW(N, D, P(L.t), p->node2_2_weight, D, p->node2_2_bias, 0, P(L.x2));
 #undef LINW
+#undef ENC_LAUNCH
     // graph LayerNorm                                                               (:608)
     if (B > 0) {
         hipLaunchKernelGGL(k_graph_layernorm, dim3((unsigned)B), dim3(256), 0, stream, D, g->graph_ptr, P(L.x2), p->ln_weight,

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Whole graph side of the pipeline at BASELINE config 3's batch (2048 graphs x 32 nodes x 128 edges), real model widths
+(encoder / gat_seq D = 300, instruction / question 512): scene-graph encoder -> gat_seq (K = 5) -> attention pooling ->
+answer classifier, inference (fused HIP paths) per stage and end to end."""
+import json, os, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+torch.set_grad_enabled(False)
+from graphvqa_amd import synth
+from graphvqa_amd.graph import SceneGraphBatch
+from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+from graphvqa_amd.gat_skip import gat_seq
+from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+dev = torch.device("cuda:0"); tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+gb = synth.config3_batch(); N, E, B, V, D, Q = gb.num_nodes, gb.num_edges, gb.num_graphs, 3000, 300, 512
+def load(m, p):
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()}); return m.to(dev).eval()
+enc = load(GroundTruth_SceneGraph_Encoder(V, 0, D), synth.encoder_params(V, D, seed=1))
+gs = load(gat_seq(D, D, D, Q, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(D, D, D, Q, 5, 4, seed=2))
+pool = load(MyConditionalGlobalAttention(D, Q), synth.attention_pool_params(D, Q, seed=3))
+clf = load(ShortAnswerClassifier(Q, 512, 1842), synth.classifier_params(Q, 512, 1842, seed=4))
+data = types.SimpleNamespace(x=tt(synth.randint(N * 12, 71, 0, V, stream=9).reshape(N, 12)), edge_attr=tt(synth.randint(E, 72, 1, V, stream=9).reshape(E, 1)),
+                             edge_index=tt(gb.edge_index), batch=tt(gb.batch), added_sym_edge=tt(np.arange(0, E, 7, dtype=np.int64)))
+ins, q = tt(synth.normal((5, B, Q), 5)), tt(synth.normal((B, Q), 6))
+def timed(fn, iters=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e3
+g = SceneGraphBatch(data.edge_index, data.batch, N, B)
+xe, ee, _ = enc(data, graph=g); h = gs(xe, data.edge_index, ee, ins, data.batch, graph=g); pf = pool(h, q, data.batch, graph=g)
+res = {"N": N, "E": E, "B": B,
+       "csr_build_ms": timed(lambda: SceneGraphBatch(data.edge_index, data.batch, N, B)),
+       "encoder_ms": timed(lambda: enc(data, graph=g)),
+       "gat_seq_ms": timed(lambda: gs(xe, data.edge_index, ee, ins, data.batch, graph=g)),
+       "pooling_ms": timed(lambda: pool(h, q, data.batch, graph=g)),
+       "classifier_ms": timed(lambda: clf(pf, q))}
+def e2e():
+    gg = SceneGraphBatch(data.edge_index, data.batch, N, B)
+    a, b, _ = enc(data, graph=gg)
+    return clf(pool(gs(a, data.edge_index, b, ins, data.batch, graph=gg), q, data.batch, graph=gg), q)
+res["end_to_end_ms"] = timed(e2e); res["graphs_per_s"] = B / (res["end_to_end_ms"] * 1e-3)
+print(json.dumps(res))
