@@ -17,9 +17,9 @@ constexpr int BN_ROWS = 64;           // rows per block of the column reductions
 // mode 0: sum x;  mode 1: sum (x - mean)^2
 __global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const float* __restrict__ x, const float* __restrict__ mean,
                                                       float* __restrict__ partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;           // row blocks on grid.x (no 65535 limit), column blocks on grid.y
     if (c >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
     const float m = mean ? mean[c] : 0.f;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four independent chains: loads in flight, fixed summation order
     int64_t r = r0;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const fl
         const float v = x[r * C + c] - m;
         a0 += mean ? v * v : v;
     }
-    partial[(int64_t)blockIdx.y * C + c] = (a0 + a1) + (a2 + a3);
+    partial[(int64_t)blockIdx.x * C + c] = (a0 + a1) + (a2 + a3);
 }
 
 // out[c] = scale * sum_b partial[b * blk_stride + c]: a block owns 16 columns, its 16 thread rows sum interleaved
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce(int64_t N, int C, co
                                                             const float* __restrict__ mean, const float* __restrict__ var,
                                                             const float* __restrict__ w, const float* __restrict__ b, float eps,
                                                             float* __restrict__ partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
     const float m = mean[c], invstd = 1.0f / sqrtf(var[c] + eps), wc = w[c], bc = b[c];
     float s0 = 0.f, s1 = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce(int64_t N, int C, co
         s0 += g;
         s1 += g * xh;
     }
-    partial[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0;
-    partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+    partial[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
+    partial[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
 }
 
 __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply(int64_t total, int C, float inv_n, const float* __restrict__ x,
@@ -116,8 +116,8 @@ extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(ws);
     const int nb = (int)cdiv(N, BN_ROWS);
-    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 16));
-    GVQA_REQUIRE(nb <= 65535, GVQA_E_UNSUPPORTED, "bn_relu_train_forward: N too large");
+    GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
+    const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
     hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, nullptr, partial);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_mean);
     hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, save_mean, partial);
@@ -141,8 +141,8 @@ extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(ws);
     const int nb = (int)cdiv(N, BN_ROWS);
-    GVQA_REQUIRE(nb <= 65535, GVQA_E_UNSUPPORTED, "bn_relu_train_backward: N too large");
-    const dim3 grid((unsigned)cdiv(C, 256), (unsigned)nb), cgrid((unsigned)cdiv(C, 16));
+    GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
+    const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
     hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);

@@ -617,7 +617,24 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), GVQA_E_INVALID, "linear: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
     GVQA_REQUIRE(K > 0, GVQA_E_INVALID, "linear: K must be positive");
-    GVQA_REQUIRE(cdiv(M, 128) <= 65535, GVQA_E_INVALID, "linear: M too large for one launch");
+    if (cdiv(M, 128) > 65535) {
+        // more row tiles than grid.y holds: run row chunks (rows are independent; every operand that has M rows moves along)
+        GVQA_REQUIRE(batch == 1, GVQA_E_INVALID, "linear: M too large for a batched launch");
+        const int64_t chunk = (int64_t)65535 * 128;
+        const int64_t ea = (dtype_flags & 1) ? 2 : 4, ec = (dtype_flags & 2) ? 2 : 4;      // element bytes of A / of C, addend, mul
+        auto adv = [](const float* q, int64_t elems, int64_t esz) {
+            return q ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(q) + elems * esz) : q;
+        };
+        for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+            LinearEpilogue e2 = ep;
+            e2.addend = adv(ep.addend, m0 * ep.ld_add, ec);
+            e2.mul = adv(ep.mul, m0 * ep.ld_mul, ec);
+            int rc = launch_linear_t(std::min(chunk, M - m0), N, K, adv(A, m0 * lda, ea), lda, B, ldb, e2,
+                                     const_cast<float*>(adv(C, m0 * ldc, ec)), ldc, 1, 0, 0, 0, dtype_flags, stream);
+            if (rc) return rc;
+        }
+        return GVQA_OK;
+    }
     GVQA_REQUIRE(A && B && C, GVQA_E_INVALID, "linear: null operand");
     GVQA_REQUIRE(lda >= K && ldb >= K && ldc >= N, GVQA_E_INVALID, "linear: leading dimension too small");
     GVQA_REQUIRE((!ep.addend || ep.ld_add >= N) && (!ep.mul || ep.ld_mul >= N), GVQA_E_INVALID,

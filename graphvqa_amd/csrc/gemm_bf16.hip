@@ -16,6 +16,8 @@
 // h = lane >> 5) feeds the 8 consecutive k's [16 kg + 8 h, +8) of row r to one MFMA from ONE b128 read.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "common.h"
@@ -333,7 +335,19 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     if (M == 0 || N == 0) return GVQA_OK;
     GVQA_REQUIRE(A && Wpk && C, GVQA_E_INVALID, "linear_bf16: null operand");
     GVQA_REQUIRE(linear_bf16_supported(K, lda, A, Wpk), GVQA_E_INVALID, "linear_bf16: K / lda must be multiples of 8, operands 16-byte aligned");
-    GVQA_REQUIRE(lda >= K && ldc >= N && cdiv(M, 128) <= 65535, GVQA_E_INVALID, "linear_bf16: bad leading dimension / M too large");
+    GVQA_REQUIRE(lda >= K && ldc >= N, GVQA_E_INVALID, "linear_bf16: bad leading dimension");
+    if (cdiv(M, 128) > 65535) {          // more row tiles than grid.y holds: row chunks
+        const int64_t chunk = (int64_t)65535 * 128, ec = c16 ? 2 : 4;
+        for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+            LinearEpilogue e2 = ep;
+            if (ep.addend) e2.addend = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ep.addend) + m0 * ep.ld_add * ec);
+            if (ep.mul) e2.mul = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ep.mul) + m0 * ep.ld_mul * ec);
+            int rc = launch_linear_bf16(std::min(chunk, M - m0), N, K, P, static_cast<const uint16_t*>(A) + m0 * lda, lda, Wpk, e2,
+                                        static_cast<char*>(C) + m0 * ldc * ec, ldc, c16, stream);
+            if (rc) return rc;
+        }
+        return GVQA_OK;
+    }
     dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 128));
     // vectorised epilogue: whole 8-column chunks, 16-byte aligned rows of C / addend / mul
     const int esz = c16 ? 2 : 4;

@@ -759,3 +759,21 @@ def test_forward_is_hip_graph_capturable(dev):
     cg.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, m(x, ei, ea, ins, b, graph=g))
+
+
+def test_linear_more_row_tiles_than_grid_y(dev):
+    """M beyond 65535 row tiles (8.39 M rows: the edge-logit product of a 65536-graph batch) runs as row chunks."""
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    M, N, K = 65535 * 128 + 300, 8, 8
+    A = torch.randn(M, K, device=dev)
+    B = torch.randn(N, K, device=dev)
+    bias = torch.randn(N, device=dev)
+    add = torch.randn(M, N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gvqa_linear_f32_ex(M, N, K, A.data_ptr(), K, B.data_ptr(), K, bias.data_ptr(), add.data_ptr(), N, None, 0, 1,
+                                      out.data_ptr(), N, st))
+    ref = torch.relu(A @ B.T + bias + add)
+    assert float((out - ref).abs().max()) < 1e-4
+    assert float((out[-300:] - ref[-300:]).abs().max()) < 1e-4          # the rows of the second chunk
