@@ -777,3 +777,69 @@ def test_linear_more_row_tiles_than_grid_y(dev):
     ref = torch.relu(A @ B.T + bias + add)
     assert float((out - ref).abs().max()) < 1e-4
     assert float((out[-300:] - ref[-300:]).abs().max()) < 1e-4          # the rows of the second chunk
+
+
+def test_randomized_variants_head_encoder_vs_oracle(dev):
+    """25 random batches (empty graphs, widths 8 / 12 / 30 / 64, ragged sizes): tapped GINE / GCN conv results, lcgn_seq,
+    pooling + classifier and the scene-graph encoder on the fused HIP paths against the oracle."""
+    import types
+    from graphvqa_amd.baseline_models import gine_seq, gcn_seq
+    from graphvqa_amd.lcgn import lcgn_seq
+    from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    from oracle import ref_torch as R
+
+    def t(a, d=None):
+        x = torch.from_numpy(np.ascontiguousarray(a))
+        return x.to(d) if d else x
+    tp = lambda p: {k: t(v) for k, v in p.items()}
+    worst = {}
+    rng = np.random.default_rng(77)
+    def upd(name, a, b):
+        e = float((a.detach().cpu().double() - b.detach().double()).abs().max()) if a.numel() else 0.0
+        worst[name] = max(worst.get(name, 0.0), e)
+    def rand_batch():
+        B = int(rng.integers(1, 10)); sizes = rng.integers(0, 40, size=B)
+        if sizes.sum() == 0: sizes[0] = 2
+        batch = np.repeat(np.arange(B), sizes).astype(np.int64); offs = np.concatenate([[0], np.cumsum(sizes)])
+        src, dst = [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
+        for g in range(B):
+            n = int(sizes[g])
+            if n == 0: continue
+            e = int(rng.integers(0, 3 * n + 1))
+            src.append(np.concatenate([np.arange(n), rng.integers(0, n, size=e)]) + offs[g]); dst.append(np.concatenate([np.arange(n), rng.integers(0, n, size=e)]) + offs[g])
+        return B, batch, np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64)
+    for case in range(25):
+        B, batch, ei = rand_batch(); N, E = batch.shape[0], ei.shape[1]
+        D = int(rng.choice([8, 12, 30, 64])); Di = int(rng.choice([8, 16]))
+        x, ea, ins = rng.standard_normal((N, D)).astype(np.float32), rng.standard_normal((E, D)).astype(np.float32), rng.standard_normal((5, B, Di)).astype(np.float32)
+        # GINE / GCN tapped convs
+        p = synth.gine_seq_params(D, D, Di, seed=case); m = gine_seq(D, D, Di); m.load_state_dict(tp(p)); m = m.to(dev).eval()
+        out, convs = m(t(x, dev), t(ei, dev), t(ea, dev), t(ins, dev), t(batch, dev), return_convs=True)
+        ro, rc = R.gine_seq(t(x), t(ei), t(ea), t(ins), t(batch), tp(p), return_convs=True)
+        upd("gine.out", out, ro); [upd("gine.conv", a, b) for a, b in zip(convs, rc)]
+        p = synth.gcn_seq_params(D, D, Di, seed=case); m = gcn_seq(D, D, Di); m.load_state_dict(tp(p)); m = m.to(dev).eval()
+        out, convs = m(t(x, dev), t(ei, dev), t(ins, dev), t(batch, dev), return_convs=True)
+        ro, rc = R.gcn_seq(t(x), t(ei), t(ins), t(batch), tp(p), return_convs=True)
+        upd("gcn.out", out, ro); [upd("gcn.conv", a, b) for a, b in zip(convs, rc)]
+        # LCGN
+        O = int(rng.choice([8, 16, 40])); L = int(rng.integers(1, 7))
+        p = synth.lcgn_seq_params(D, O, seed=case, cmd_dim=O, question_dim=O); m = lcgn_seq(D, O, D, 5, gat_cmd_dim=O, question_dim=O)
+        m.load_state_dict(tp(p), strict=False); m = m.to(dev).eval()
+        q, lstm, xc = rng.standard_normal((B, O)).astype(np.float32), rng.standard_normal((L, B, O)).astype(np.float32), rng.standard_normal((N, O)).astype(np.float32)
+        out = m(t(x, dev), t(ei, dev), t(batch, dev), t(q, dev), t(lstm, dev), x_ctx_init=t(xc, dev))
+        upd("lcgn", out, R.lcgn_seq(t(x), t(ei), t(batch), t(q), t(lstm), tp(p), t(xc)))
+        # head
+        Q, A = int(rng.choice([8, 24])), int(rng.choice([5, 33]))
+        pp, pc = synth.attention_pool_params(D, Q, seed=case), synth.classifier_params(Q, 16, A, seed=case)
+        pool, clf = MyConditionalGlobalAttention(D, Q), ShortAnswerClassifier(Q, 16, A)
+        pool.load_state_dict(tp(pp)); clf.load_state_dict(tp(pc)); pool, clf = pool.to(dev).eval(), clf.to(dev).eval()
+        u = rng.standard_normal((B, Q)).astype(np.float32)
+        upd("head", clf(pool(t(x, dev), t(u, dev), t(batch, dev)), t(u, dev)), R.short_answer_logits(R.global_attention_pool(t(x), t(u), t(batch), tp(pp), B), t(u), tp(pc)))
+        # encoder
+        V = 40; pe = synth.encoder_params(V, D, seed=case); enc = GroundTruth_SceneGraph_Encoder(V, 0, D); enc.load_state_dict(tp(pe)); enc = enc.to(dev).eval()
+        xt, et = rng.integers(0, V, size=(N, 12)), rng.integers(1, V, size=(E, 1)); added = rng.choice(E, size=min(E, 5), replace=False).astype(np.int64) if E else np.zeros(0, np.int64)
+        data = types.SimpleNamespace(x=t(xt, dev), edge_attr=t(et, dev), edge_index=t(ei, dev), batch=t(batch, dev), added_sym_edge=t(added, dev))
+        xe, ee, _ = enc(data); rxe, ree = R.scene_graph_encoder(t(xt), t(ei), t(et), t(added), t(batch), B, tp(pe))
+        upd("enc.x", xe, rxe); upd("enc.e", ee, ree)
+    assert all(v < 1e-4 for v in worst.values()), worst
