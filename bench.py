@@ -1,35 +1,63 @@
 #!/usr/bin/env python3
 """Headline benchmark: scene-graph edges/sec through K=5 GAT hops at d=512 (BASELINE.json).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N=1)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
 
-A step = one `gat_seq.forward` (CSR build from COO included) over one synthetic batch resident
-in HBM: BASELINE config 3 -- 2048 graphs x 32 nodes x 128 edges = 64k nodes / 256k edges,
-Dn = De = Di = C = 512, H = 4, K = 5, eval mode, fp32.  With N ranks every rank runs its own batch
-of that size (graphs shard without any data-path exchange -> weak scaling) and the per-graph
-results are all-gathered over RCCL at the end of the step.  Prints ONE JSON line on rank 0.
+N = 1 runs in this process; N > 1 spawns one rank per GPU by itself (re-exec under torch.distributed.run on
+127.0.0.1) unless it was already launched that way (WORLD_SIZE set), so both driver forms work.
+
+A step = one `gat_seq.forward` (CSR build from COO included) over synthetic input resident in HBM: BASELINE config 3
+-- ONE batch of 2048 graphs x 32 nodes x 128 edges = 64k nodes / 256k edges, Dn = De = Di = C = 512, H = 4, K = 5,
+eval mode, fp32 in / fp32 out.  With N ranks that one batch is sharded by graphs (edge-balanced contiguous ranges, 256
+graphs per GPU at N = 8; the reference's DistributedSampler role, mainExplain_gat.py:226-227), the K hops run with no
+communication and the per-graph result rows are all-gathered over RCCL at the end of the step: STRONG scaling
+(`--scaling weak` gives every rank its own full batch instead; the default run reports that number too as
+`weak_value`).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from graphvqa_amd import synth, _lib  # noqa: E402
-
 D, H, K = 512, 4, 5
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+BATCH_SEED = 0x5EED0003
 
 
-def tt(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32-MFMA / vendor comparison legs")
+    ap.add_argument("--with-head", action="store_true",
+                    help="also run global attention pooling + answer classifier each step and all-gather the true [B, 1842] logits")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def self_spawn(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks on this node and pass their output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def mp_algorithmic_bytes(N, E, C, Hh, fused_skip=True):
@@ -40,39 +68,285 @@ def mp_algorithmic_bytes(N, E, C, Hh, fused_skip=True):
     return b + (4 * N * C if fused_skip else 0)
 
 
-def measured_traffic():
-    """HBM bytes per launch of the message-passing kernel from the newest committed PMC passes
-    (profiles/*_pmc_hbm_cfg3.json, scripts/collect_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
-    import glob
+def profile_traffic():
+    """Newest COMMITTED PMC summary (profiles/*_pmc_hbm_cfg3.json) -- reported under `traffic_from_profile` with its file
+    name when the live passes are unavailable; never presented as a live number."""
     try:
-        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_cfg3.json")))[-1]) as f:
-            return json.load(f)["mp_kernel"]["hbm_bytes_per_launch"]
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_cfg3.json")))[-1]
+        with open(path) as f:
+            return {"bytes_per_launch": json.load(f)["mp_kernel"]["hbm_bytes_per_launch"], "file": os.path.relpath(path, ROOT)}
     except Exception:
         return None
 
 
-def measured_copy_bandwidth(dev):
-    """Device-to-device copy of 1 GiB (read + write counted) -- the achievable-HBM yardstick of SURVEY 8(d)."""
-    n = 1 << 28
-    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
-    dst = torch.empty_like(src)
-    for _ in range(2):
-        dst.copy_(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2 * n * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+def live_pmc_traffic():
+    """HBM bytes per launch of the message-passing kernel, measured NOW: two rocprofv3 counter passes (FETCH_SIZE,
+    WRITE_SIZE; counters in their own runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short
+    child run of this same workload.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 64 B per 128 B
+    request of a wide coalesced stream, hence x2.  Returns (bytes or None, detail dict)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, {"error": "rocprofv3 not found"}
+    out = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="gvqa_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                sys.executable, os.path.abspath(__file__), "--pmc-child"], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                shutil.rmtree(d, ignore_errors=True)
+                return None, {"error": f"{ctr} pass failed (rc {r.returncode})", "stderr_tail": r.stderr[-300:]}
+            vals = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == ctr and "k_gat_mp_tiled" in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None, {"error": f"no k_gat_mp_tiled rows in the {ctr} pass"}
+            out[ctr] = {"launches": len(vals), "avg_KiB": sum(vals) / len(vals)}
+    except Exception as e:      # timeouts, permission problems: the bench line must still come out
+        return None, {"error": repr(e)[:200]}
+    rd, wr = out["FETCH_SIZE"]["avg_KiB"] * 1024 * 2, out["WRITE_SIZE"]["avg_KiB"] * 1024
+    return rd + wr, {"read_bytes": rd, "write_bytes": wr, "launches_sampled": out["FETCH_SIZE"]["launches"],
+                     "method": "live rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace passes over `bench.py --pmc-child`; "
+                               "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE"}
 
 
-def cpu_baseline(params):
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(a)
+
+    import numpy as np
+    import torch
+    from graphvqa_amd import synth, _lib
+
+    tt = lambda arr: torch.from_numpy(np.ascontiguousarray(arr))
+    torch.set_grad_enabled(False)       # inference benchmark: the fused path (gradients route gat_seq to the differentiable one)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    force_dist = bool(os.environ.get("GVQA_BENCH_FORCE_DIST"))      # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch
+    from graphvqa_amd.parallel import BatchShard, sharded_step, graph_mean_pool
+
+    lib = _lib.load()
+    params = synth.gat_seq_params(D, D, D, D, K, H, seed=777)
+    m = gat_seq(D, D, D, D, K, dropout=0.1, gat_heads=H)
+    m.load_state_dict({k: tt(v) for k, v in params.items()})
+    m = m.to(dev).eval()
+
+    # THE batch (identical on every rank; each rank keeps its shard in HBM)
+    gb = synth.make_graph_batch(2048, seed=BATCH_SEED, fixed_nodes=32, fixed_rel=96)
+    Nall, Eall, Ball = gb.num_nodes, gb.num_edges, gb.num_graphs
+    x_all, ea_all, ins_all = synth.normal((Nall, D), 1), synth.normal((Eall, D), 2), synth.normal((K, Ball, D), 3)
+
+    def make_shard(r, w):
+        return BatchShard(gb.edge_index, gb.batch, Ball, x_all, ea_all, ins_all, r, w, dev)
+
+    head = None
+    if a.with_head:
+        from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+        pool_m = MyConditionalGlobalAttention(D, D)
+        pool_m.load_state_dict({k: tt(v) for k, v in synth.attention_pool_params(D, D, seed=811).items()})
+        clf = ShortAnswerClassifier(D, 512, 1842)
+        clf.load_state_dict({k: tt(v) for k, v in synth.classifier_params(D, 512, 1842, seed=822).items()})
+        head = (pool_m.to(dev).eval(), clf.to(dev).eval())
+        q_all = synth.normal((Ball, D), 4)
+
+    def runner(shard):
+        q_feat = tt(q_all[shard.graph_range[0]:shard.graph_range[1]]).to(dev) if head is not None else None
+        state = {}
+
+        def forward(s):
+            g = SceneGraphBatch(s.edge_index, s.batch, s.num_nodes, s.num_graphs)     # CSR build from COO: part of every step
+            state["g"] = g
+            return m(s.x, s.edge_index, s.edge_attr, s.instr, s.batch, graph=g)
+
+        def pool(h, s):
+            if head is not None:
+                return head[1](head[0](h, q_feat, s.batch, graph=state["g"]), q_feat)       # true [B_r, 1842] logits
+            return graph_mean_pool(h, s.batch, s.num_graphs, graph=state["g"])
+
+        if dist is None:
+            return (lambda: forward(shard)) if head is None else (lambda: pool(forward(shard), shard))
+        return lambda: sharded_step(shard, forward, pool, force=force_dist)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step, steps, warmup, after_warmup=None):
+        for _ in range(warmup):
+            step()
+        fence()
+        if after_warmup is not None:
+            after_warmup()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    if a.pmc_child:                      # counter pass: a few plain steps, nothing else
+        step = runner(make_shard(0, 1))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return
+
+    strong = a.scaling == "strong"
+    shard = make_shard(rank, world) if strong else make_shard(0, 1)
+    if not strong and rank:             # weak scaling: every rank its own batch of the full size (different values)
+        shard.x = tt(synth.normal((Nall, D), 1 + 10 * rank)).to(dev)
+    step = runner(shard)
+    for _ in range(a.warmup):
+        step()
+    fence()
+    _lib.prof_enable(True)
+    _lib.prof_collect()
+    dt = timed(step, a.steps, 0)
+    prof = _lib.prof_collect()
+    _lib.prof_enable(False)
+    edges_per_step = Eall if strong else world * Eall
+
+    weak = None
+    if strong and world > 1:            # second key: weak scaling (every rank the full batch), fewer steps
+        wsteps = max(3, a.steps // 2)
+        wdt = timed(runner(make_shard(0, 1)), wsteps, 2)
+        weak = {"value": world * Eall / (wdt / wsteps), "ms_per_step": wdt / wsteps * 1e3, "steps": wsteps}
+
+    line = None
+    if rank == 0:
+        N, E, B = shard.num_nodes, shard.num_edges, shard.num_graphs
+        ms_step = dt / a.steps * 1e3
+        mp_ms, mp_n = prof["mp"]
+        mp_avg_s = mp_ms / max(mp_n, 1) * 1e-3
+        alg = mp_algorithmic_bytes(N, E, D, H)
+        alg_base = mp_algorithmic_bytes(N, E, D, H, fused_skip=False)
+        achieved = alg / mp_avg_s / 1e9 if mp_n else None
+        plan = _lib.MpPlan()
+        g0 = SceneGraphBatch(shard.edge_index, shard.batch, N, B)
+        _lib.check(lib.gvqa_gat_mp_plan(g0.c, D, H, plan))
+        kernel = (f"gvqa::k_gat_mp_tiled<{H},{plan.accumulators}> (channel range {plan.channel_range}, {plan.stage_buffers} stage "
+                  f"buffers, {plan.lds_bytes} B LDS, {plan.blocks_per_graph} block(s) per graph)") if plan.tiled else "gvqa::k_gat_*_general"
+        proj_ms, proj_n = prof["proj"]
+        pack_ms, pack_n = prof["pack"]
+        hop_launches = max(mp_n, 1)
+        gemm_s = (proj_ms - pack_ms * (hop_launches / max(pack_n, 1) if pack_n else 0)) / hop_launches * 1e-3 if proj_n else None
+        flops = 2 * N * D * H * D
+        res = {
+            "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
+            "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: ONE batch of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
+                                   "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, CSR build from COO inside the step"
+                                   + ("; + attention pooling + 1842-way classifier, true logits gathered" if head else ""),
+                       "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
+                       "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
+                                       "no communication inside the hops, one RCCL all-gather of per-graph rows per step") if strong
+                       else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step",
+                       "projection_arithmetic": "fp32 operands split into three exact bf16 pieces, six bf16-MFMA piece products, fp32 "
+                                                "accumulate (fp32 error class: tests/test_gpu_split3.py; end to end <= 1e-4 vs the oracle)"
+                       if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT3 else "f32-input MFMA"},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
+                         "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
+            "projection": {"kernel": "gvqa::k_linear_split3" if pack_n else "gvqa::k_linear_f32*",
+                           "flops_per_launch_fp32_equivalent": flops,
+                           "avg_launch_us_incl_pack": proj_ms / hop_launches * 1e3 if proj_n else None,
+                           "pack_us_per_hop": pack_ms / hop_launches * 1e3 if pack_n else 0.0,
+                           "fp32_equivalent_tflops_incl_pack": flops / (proj_ms / hop_launches * 1e-3) / 1e12 if proj_n else None,
+                           "mfma_tflops_gemm_only": (6 if pack_n else 1) * flops / gemm_s / 1e12 if gemm_s else None,
+                           "peak_tflops": {"bf16_mfma": 2500.0, "f32_mfma": 157.3}},
+            "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
+            "gemm_backend": lib.gvqa_gemm_backend().decode(),
+        }
+        if weak is not None:
+            res["weak_value"], res["weak_ms_per_step"], res["weak_steps"] = weak["value"], weak["ms_per_step"], weak["steps"]
+        if world == 1:
+            if not a.no_extras:
+                # the same step on the f32-input MFMA kernels and on the vendor library, for comparison (few steps each)
+                full = runner(make_shard(0, 1))
+                n_x = max(3, a.steps // 4)
+                old = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
+                _lib.prof_enable(True)
+                t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
+                p32 = _lib.prof_collect()
+                _lib.set_option(_lib.OPT_VENDOR_GEMM, 1)
+                t_v = timed(full, n_x, 2, _lib.prof_collect) / n_x
+                pv = _lib.prof_collect()
+                _lib.prof_enable(False)
+                _lib.set_option(_lib.OPT_VENDOR_GEMM, 0)
+                _lib.set_option(_lib.OPT_PROJECTION, old)
+                per = lambda pr: pr["proj"][0] / max(pr["proj"][1], 1) * 1e3
+                res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma", "ms_per_step": t_f32 * 1e3, "value": Eall / t_f32,
+                                              "avg_launch_us": per(p32), "tflops": flops / (per(p32) * 1e-6) / 1e12}
+                res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only)", "ms_per_step": t_v * 1e3,
+                                            "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops / (per(pv) * 1e-6) / 1e12}
+            if not a.no_pmc:
+                traffic, detail = live_pmc_traffic()
+                res["roofline"]["traffic"] = traffic
+                res["roofline"]["traffic_detail"] = detail
+            if res["roofline"]["traffic"] is None:
+                res["roofline"]["traffic_from_profile"] = profile_traffic()
+            if not a.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(params, synth, np, torch)
+        line = json.dumps(res)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would
+        # otherwise be flushed at exit, AFTER our line: flush the C streams first so that the JSON
+        # line is the last thing on stdout.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
+
+
+def cpu_baseline(params, synth, np, torch):
     """The oracle (a torch-CPU restatement of the reference's op sequence) timed on the host cores on
     a bounded sample of the same workload.  torch's CPU scatter/gather ops oversubscribe badly at
     the box's full thread count (256 threads: 100x slower than 16), so the thread count is chosen by
     a quick sweep on a 32-graph sample and reported as `cores`."""
     from oracle import ref_torch as R   # baseline leg only
+    tt = lambda arr: torch.from_numpy(np.ascontiguousarray(arr))
     p = {k: tt(v) for k, v in params.items()}
 
     def make(nb):
@@ -117,149 +391,6 @@ def cpu_baseline(params):
             "sample": f"oracle/ref_torch.gat_seq on {nb} graphs ({N} nodes / {E} edges), d={D}, K={K}, "
                       f"fp32, best of {len(times)} forwards ({best:.2f} s), {best_th} torch threads "
                       f"(best of 8/16/32/64 on a 32-graph sample)"}
-
-
-def main():
-    torch.set_grad_enabled(False)       # inference benchmark: the fused path (gradients route gat_seq to the differentiable one)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-head", action="store_true",
-                    help="also run global attention pooling + answer classifier each step and all-gather the true logits")
-    a = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    force_dist = bool(os.environ.get("GVQA_BENCH_FORCE_DIST"))      # exercise the RCCL path with one rank
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    from graphvqa_amd.gat_skip import gat_seq
-    from graphvqa_amd.parallel import all_gather_graph_rows, graph_mean_pool
-
-    gb = synth.make_graph_batch(2048, seed=0x5EED0003 + rank, fixed_nodes=32, fixed_rel=96)
-    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
-    params = synth.gat_seq_params(D, D, D, D, K, H, seed=777)
-    m = gat_seq(D, D, D, D, K, dropout=0.1, gat_heads=H)
-    m.load_state_dict({k: tt(v) for k, v in params.items()})
-    m = m.to(dev).eval()
-    x = tt(synth.normal((N, D), 1 + 10 * rank)).to(dev)
-    ea = tt(synth.normal((E, D), 2 + 10 * rank)).to(dev)
-    ins = tt(synth.normal((K, B, D), 3 + 10 * rank)).to(dev)
-    ei, batch = tt(gb.edge_index).to(dev), tt(gb.batch).to(dev)
-
-    head = None
-    if a.with_head:
-        from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
-        pool = MyConditionalGlobalAttention(D, D)
-        pool.load_state_dict({k: tt(v) for k, v in synth.attention_pool_params(D, D, seed=811).items()})
-        clf = ShortAnswerClassifier(D, 512, 1842)
-        clf.load_state_dict({k: tt(v) for k, v in synth.classifier_params(D, 512, 1842, seed=822).items()})
-        head = (pool.to(dev).eval(), clf.to(dev).eval())
-        q_feat = tt(synth.normal((B, D), 4 + 10 * rank)).to(dev)
-
-    from graphvqa_amd.graph import SceneGraphBatch
-
-    def step():
-        g = SceneGraphBatch(ei, batch, N, B)            # CSR build from COO: part of every step
-        h = m(x, ei, ea, ins, batch, graph=g)
-        if head is not None:
-            logits = head[1](head[0](h, q_feat, batch, graph=g), q_feat)
-            return all_gather_graph_rows(logits, counts=[B] * world, force=force_dist) if dist is not None else logits
-        if dist is not None:
-            return all_gather_graph_rows(graph_mean_pool(h, batch, B, graph=g), counts=[B] * world, force=force_dist)
-        return h
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    copy_gbs = measured_copy_bandwidth(dev) if rank == 0 else None
-    for _ in range(a.warmup):
-        step()
-    fence()
-    _lib.prof_enable(True)
-    _lib.prof_collect()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = _lib.prof_collect()
-    _lib.prof_enable(False)
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    if rank == 0:
-        ms_step = dt / a.steps * 1e3
-        mp_ms, mp_n = prof["mp"]
-        mp_avg_s = mp_ms / max(mp_n, 1) * 1e-3
-        alg = mp_algorithmic_bytes(N, E, D, H)
-        alg_base = mp_algorithmic_bytes(N, E, D, H, fused_skip=False)
-        achieved = alg / mp_avg_s / 1e9 if mp_n else None
-        res = {
-            "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
-            "value": world * E / (dt / a.steps), "unit": "edges/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 2048 graphs x 32 nodes x 128 edges per GPU "
-                                   "(64k nodes / 256k edges), Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, "
-                                   "CSR build from COO inside the step",
-                       "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
-                       "parallelism": f"graphs sharded over {world} GPU(s), all-gather of per-graph rows"},
-            "roofline": {"bound": "hbm", "kernel": "k_gat_mp_tiled<4,2>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": measured_traffic(), "algorithmic_bytes_per_launch": alg,
-                         "measured_copy_GBps": copy_gbs,
-                         "frac_of_measured_copy": (achieved / copy_gbs) if (achieved and copy_gbs) else None,
-                         "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
-                         "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
-            "projection": (lambda ms, n: {"flops_per_launch": 2 * N * D * H * D, "avg_launch_us": ms / max(n, 1) * 1e3,
-                                          "tflops": 2 * N * D * H * D / (ms / max(n, 1) * 1e-3) / 1e12 if n else None,
-                                          "peak_tflops_f32_mfma": 157.3,
-                                          "frac": 2 * N * D * H * D / (ms / max(n, 1) * 1e-3) / 1e12 / 157.3 if n else None})(*prof["proj"]),
-            "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
-            "gemm_backend": _lib.load().gvqa_gemm_backend().decode(),
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(params)
-        line = json.dumps(res)
-    else:
-        line = None
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if line is not None:
-        # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would
-        # otherwise be flushed at exit, AFTER our line: flush the C streams first so that the JSON
-        # line is the last thing on stdout.
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(line, flush=True)
 
 
 if __name__ == "__main__":

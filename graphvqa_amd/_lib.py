@@ -13,7 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GVQA_LIB", os.path.join(HERE, "lib", "libgvqa_hip.so"))   # GVQA_LIB: A/B a second build
 
 GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other")
+STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack")
+# gvqa_set_option keys / values (include/gvqa.h)
+OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT = 0, 1, 2, 3
+PROJECTION_SPLIT3, PROJECTION_F32 = 0, 1
 NUM_STAGES = len(STAGES)
 
 
@@ -153,6 +156,10 @@ PROTOTYPES = {
     "gvqa_linear_bf16": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                    C.c_void_p]),
+    "gvqa_split3_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gvqa_split3_pack": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gvqa_linear_split3": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_linear_f32_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -196,6 +203,8 @@ PROTOTYPES = {
     "gvqa_graph_segment_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_gat_mp_backward": (C.c_int, [C.POINTER(Graph), C.POINTER(Graph), C.POINTER(GatMpBwdDesc), C.c_void_p]),
     "gvqa_gat_mp_plan": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.POINTER(MpPlan)]),
+    "gvqa_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "gvqa_get_option": (C.c_int, [C.c_int]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),
     "gvqa_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
@@ -233,6 +242,14 @@ def check(rc: int):
     if rc == E_UNSUPPORTED:
         raise GvqaUnsupported(rc, msg)
     raise GvqaError(rc, msg)
+
+
+def set_option(option: int, value: int) -> int:
+    """Sets a process-wide library option; returns the previous value."""
+    lib = load()
+    old = lib.gvqa_get_option(option)
+    check(lib.gvqa_set_option(option, int(value)))
+    return old
 
 
 def prof_enable(on: bool):

@@ -1,6 +1,9 @@
 // Error reporting, version string and in-library stage timing for libgvqa_hip.so.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -15,6 +18,23 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- run-time options (gvqa_set_option); initial values from the environment ---------------------
+static std::atomic<int> g_opt[GVQA_NUM_OPTIONS];
+static std::once_flag g_opt_once;
+static void options_init() {
+    auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+    const char* proj = getenv("GVQA_PROJ");
+    g_opt[GVQA_OPT_PROJECTION] = (proj && !strcmp(proj, "f32")) ? GVQA_PROJECTION_F32 : GVQA_PROJECTION_SPLIT3;
+    const char* be = getenv("GVQA_GEMM_BACKEND");
+    g_opt[GVQA_OPT_VENDOR_GEMM] = (be && !strcmp(be, "rocblas")) ? 1 : 0;
+    g_opt[GVQA_OPT_SPLIT3_MIN_MFLOP] = env_int("GVQA_SPLIT3_MIN_MFLOP", 1000);
+    g_opt[GVQA_OPT_SPLIT3_VARIANT] = env_int("GVQA_SPLIT3_VARIANT", 0);
+}
+int get_option(int option) {
+    std::call_once(g_opt_once, options_init);
+    return (option >= 0 && option < GVQA_NUM_OPTIONS) ? g_opt[option].load(std::memory_order_relaxed) : 0;
 }
 
 // ---- stage timing -------------------------------------------------------------------------
@@ -58,6 +78,15 @@ extern "C" {
 const char* gvqa_last_error(void) { return gvqa::g_err; }
 
 const char* gvqa_version(void) { return "gvqa-hip 0.1 gfx950"; }
+
+int gvqa_set_option(int option, int value) {
+    GVQA_REQUIRE(option >= 0 && option < GVQA_NUM_OPTIONS, GVQA_E_INVALID, "gvqa_set_option: unknown option %d", option);
+    (void)gvqa::get_option(option);                   // environment defaults first
+    gvqa::g_opt[option].store(value, std::memory_order_relaxed);
+    return GVQA_OK;
+}
+
+int gvqa_get_option(int option) { return gvqa::get_option(option); }
 
 int gvqa_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(gvqa::g_prof_mu);

@@ -10,6 +10,7 @@
 namespace gvqa {
 
 void set_error(const char* fmt, ...);
+int get_option(int option);          // gvqa_set_option / environment (capi.hip)
 
 #define GVQA_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
@@ -99,8 +100,12 @@ int launch_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* W, 
 bool linear_bf16_supported(int64_t K, int64_t lda, const void* A, const void* Wpk);
 int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, int64_t lda, const void* Wpk, LinearEpilogue ep,
                        void* C, int64_t ldc, bool c16, hipStream_t stream);
+// fp32-accurate projection from three-piece bf16 splits on the bf16 matrix cores (split3.hip)
+size_t split3_packed_bytes(int64_t rows, int64_t K);
+int launch_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);
+bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
+int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
+                         int64_t ldc, hipStream_t stream);
 const char* gemm_backend_name();
-int launch_split_bf16x3(int64_t rows, int K, const float* x, int64_t ld, int which, void* out, hipStream_t stream);
-bool vendor_bf16_gemm(int64_t M, int64_t N, int64_t K6, const void* A, const void* B, float* C, int64_t ldc, hipStream_t stream);
 
 }  // namespace gvqa

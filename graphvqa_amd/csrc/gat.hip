@@ -698,10 +698,13 @@ int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
 // ==============================================================================================
 // Drivers
 // ==============================================================================================
-// GVQA_PROJ=bf16x3 selects the split-bf16 projection (opt-in; default exact fp32).
-static bool proj_bf16x3_enabled() {
-    static const bool on = []() { const char* v = getenv("GVQA_PROJ"); return v && !strcmp(v, "bf16x3"); }();
-    return on;
+// Projection arithmetic of the hop GEMM xp = h . W_h^T (gat_skip.py:133), GVQA_OPT_PROJECTION:
+//   split3 (default)  fp32-accurate three-piece bf16 split on the bf16 matrix cores (split3.hip)
+//   f32               f32-input MFMA (k_linear_f32*; rocBLAS only when GVQA_OPT_VENDOR_GEMM asks for it)
+// Products too small to fill the chip stay on the f32 kernels (the pack passes would not pay).
+static bool proj_use_split3(int64_t M, int64_t N, int64_t K) {
+    return get_option(GVQA_OPT_PROJECTION) == GVQA_PROJECTION_SPLIT3 && N % 4 == 0 &&
+           2.0 * (double)M * (double)N * (double)K >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
 }
 
 struct SeqLayout {
@@ -729,9 +732,9 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.alpha_csr = take((size_t)E * H);
     L.bn_partial = take(gvqa_bn_train_workspace_bytes(N > 0 ? N : 1, C) / sizeof(float) + 1);
     L.bn_stats = take(2 * C);
-    if (proj_bf16x3_enabled()) {     // bf16 pieces: 6*K uint16 per row = 3*K floats
-        L.a6 = take((size_t)N * 3 * d->node_dim);
-        L.w6 = take(K * H * C * 3 * d->node_dim);
+    if (proj_use_split3(N, (int64_t)(H * C), d->node_dim)) {     // packed three-piece operands (split3.hip)
+        L.a6 = take(split3_packed_bytes(N, d->node_dim) / sizeof(float));
+        L.w6 = take(K * split3_packed_bytes((int64_t)(H * C), d->node_dim) / sizeof(float));
     } else {
         L.a6 = L.w6 = off;
     }
@@ -942,13 +945,14 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                            (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
         if (rc) return rc;
     }
-    const bool split = proj_bf16x3_enabled();
-    uint16_t* a6 = reinterpret_cast<uint16_t*>(base + L.a6);
-    uint16_t* w6 = reinterpret_cast<uint16_t*>(base + L.w6);
-    if (split) {     // weights of all hops -> B' pieces, once per forward
-        StageTimer t(GVQA_STAGE_FOLD, stream);
+    const bool split = proj_use_split3(N, (int64_t)H * C, Dn);
+    char* a6 = base + L.a6;
+    char* w6 = base + L.w6;
+    const size_t w6_hop = split3_packed_bytes((int64_t)H * C, Dn);
+    if (split) {     // node-column weights of all hops -> packed pieces, once per forward
+        StageTimer t(GVQA_STAGE_PACK, stream);
         for (int i = 0; i < K; ++i) {
-            rc = launch_split_bf16x3((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, 1, w6 + (int64_t)i * H * C * 6 * Dn, stream);
+            rc = launch_split3_pack((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, w6 + (size_t)i * w6_hop, stream);
             if (rc) return rc;
         }
     }
@@ -967,14 +971,16 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         }
         {   // xp = h . W_l[:, :Dn]^T   (node half of gat_skip.py:133; instruction half is in T)
             StageTimer t(GVQA_STAGE_PROJ, stream);
-            bool done = false;
             if (split) {
-                rc = launch_split_bf16x3(N, Dn, h, Dn, 0, a6, stream);
+                {
+                    StageTimer tp(GVQA_STAGE_PACK, stream);
+                    rc = launch_split3_pack(N, Dn, h, Dn, a6, stream);
+                    if (rc) return rc;
+                }
+                LinearEpilogue ep0{nullptr, nullptr, 0, nullptr, 0, 0};
+                rc = launch_linear_split3(N, (int64_t)H * C, Dn, a6, w6 + (size_t)i * w6_hop, ep0, P(L.xp), (int64_t)H * C, stream);
                 if (rc) return rc;
-                done = vendor_bf16_gemm(N, (int64_t)H * C, (int64_t)6 * Dn, a6, w6 + (int64_t)i * H * C * 6 * Dn, P(L.xp),
-                                        (int64_t)H * C, stream);
-            }
-            if (!done) {
+            } else {
                 rc = launch_linear(N, (int64_t)H * C, Dn, h, Dn, hops[i].lin_l_weight, Dn + Di, nullptr, 0, P(L.xp),
                                    (int64_t)H * C, 1, 0, 0, 0, stream);
                 if (rc) return rc;

@@ -18,8 +18,6 @@
 #include <algorithm>
 #include <stdlib.h>
 
-#include <hipblaslt/hipblaslt.h>
-
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -359,230 +357,100 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
     store_tile_transposed(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
 }
 
-// ---- vendor backends for PLAIN large projections ------------------------------------------------
-// fp32 GEMMs above a size threshold whose epilogue is nothing or a plain accumulate (C = A.B^T [+ addend],
-// BLAS beta = 1) go to the vendor library (f32-MFMA assembly kernels: 126-150 TF on the projection
-// shapes vs ~100-112 TF for k_linear_f32 above); everything with bias / multiply / activation fused,
-// the tall-skinny logit products and all small shapes stay on the hand-written kernel.  rocBLAS is
-// tried first (measured faster), then hipBLASLt; both are resolved with dlopen at
-// first use, so the library has no link-time dependency on them and loads on machines without
-// them (the hand-written kernel is then used everywhere).
-// GVQA_GEMM_BACKEND = auto (default) | hip (hand-written only) | hipblaslt | rocblas.
+// ---- opt-in vendor backend (comparison only) -----------------------------------------------------
+// The hand-written kernels are the default everywhere.  GVQA_OPT_VENDOR_GEMM (GVQA_GEMM_BACKEND=rocblas) routes PLAIN fp32
+// products (no epilogue, or a plain accumulate through BLAS beta = 1) above 2 GFLOP to rocBLAS so that
+// bench.py can print the vendor's number next to ours (`projection_vendor`); the library is resolved with
+// dlopen at first use -- no link-time or header dependency -- and one handle is kept per device.
 namespace {
+// rocblas-types.h values (stable ABI constants of the C API)
+enum { ROCBLAS_OP_NONE = 111, ROCBLAS_OP_TRANSPOSE = 112, ROCBLAS_DATATYPE_F32_R = 151, ROCBLAS_GEMM_ALGO_STANDARD = 0 };
 typedef void* rb_handle;
 typedef int (*rb_create_t)(rb_handle*);
 typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
 typedef int (*rb_sgemm_t)(rb_handle, int, int, int, int, int, const float*, const float*, int, const float*, int,
                           const float*, float*, int);
-// rocblas_gemm_ex: D = alpha op(A) op(B) + beta C with separate C and D (rocblas_datatype_f32_r = 151)
+// rocblas_gemm_ex: D = alpha op(A) op(B) + beta C with separate C and D
 typedef int (*rb_gemm_ex_t)(rb_handle, int, int, int, int, int, const void*, const void*, int, int, const void*, int, int,
                             const void*, const void*, int, int, void*, int, int, int, int, int32_t, uint32_t);
-struct LtPlan {
-    hipblasLtMatmulDesc_t desc;
-    hipblasLtMatrixLayout_t la, lb, lc;
-    hipblasLtMatmulAlgo_t algo;
-    bool ok;
-};
 struct Vendor {
     bool tried = false;
-    int mode = 0;                 // 0 auto, 1 hip only, 2 hipblaslt only, 3 rocblas only
-    // rocBLAS
     bool rb_ok = false;
-    rb_handle rb = nullptr;
+    rb_create_t rb_create = nullptr;
     rb_set_stream_t rb_set_stream = nullptr;
     rb_sgemm_t rb_sgemm = nullptr;
     rb_gemm_ex_t rb_gemm_ex = nullptr;
-    // hipBLASLt
-    bool lt_ok = false;
-    hipblasLtHandle_t lt = nullptr;
-    decltype(&hipblasLtMatmulDescCreate) lt_desc_create = nullptr;
-    decltype(&hipblasLtMatmulDescSetAttribute) lt_desc_set = nullptr;
-    decltype(&hipblasLtMatrixLayoutCreate) lt_layout_create = nullptr;
-    decltype(&hipblasLtMatmulPreferenceCreate) lt_pref_create = nullptr;
-    decltype(&hipblasLtMatmulPreferenceDestroy) lt_pref_destroy = nullptr;
-    decltype(&hipblasLtMatmulAlgoGetHeuristic) lt_heuristic = nullptr;
-    decltype(&hipblasLtMatmul) lt_matmul = nullptr;
-    std::map<std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int>, LtPlan> plans;
+    std::map<int, rb_handle> handles;      // per device
 };
 Vendor g_vendor;
 std::mutex g_vendor_mu;
-bool g_bf16x3_used = false;
 
 void vendor_init_locked() {
     Vendor& v = g_vendor;
     if (v.tried) return;
     v.tried = true;
-    const char* be = getenv("GVQA_GEMM_BACKEND");
-    if (be && !strcmp(be, "hip")) { v.mode = 1; return; }
-    if (be && !strcmp(be, "hipblaslt")) v.mode = 2;
-    if (be && !strcmp(be, "rocblas")) v.mode = 3;
-    if (v.mode != 3) {
-        void* lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
-        if (lib) {
-            auto create = reinterpret_cast<decltype(&hipblasLtCreate)>(dlsym(lib, "hipblasLtCreate"));
-            v.lt_desc_create = reinterpret_cast<decltype(v.lt_desc_create)>(dlsym(lib, "hipblasLtMatmulDescCreate"));
-            v.lt_desc_set = reinterpret_cast<decltype(v.lt_desc_set)>(dlsym(lib, "hipblasLtMatmulDescSetAttribute"));
-            v.lt_layout_create = reinterpret_cast<decltype(v.lt_layout_create)>(dlsym(lib, "hipblasLtMatrixLayoutCreate"));
-            v.lt_pref_create = reinterpret_cast<decltype(v.lt_pref_create)>(dlsym(lib, "hipblasLtMatmulPreferenceCreate"));
-            v.lt_pref_destroy = reinterpret_cast<decltype(v.lt_pref_destroy)>(dlsym(lib, "hipblasLtMatmulPreferenceDestroy"));
-            v.lt_heuristic = reinterpret_cast<decltype(v.lt_heuristic)>(dlsym(lib, "hipblasLtMatmulAlgoGetHeuristic"));
-            v.lt_matmul = reinterpret_cast<decltype(v.lt_matmul)>(dlsym(lib, "hipblasLtMatmul"));
-            if (create && v.lt_desc_create && v.lt_desc_set && v.lt_layout_create && v.lt_pref_create && v.lt_pref_destroy &&
-                v.lt_heuristic && v.lt_matmul && create(&v.lt) == HIPBLAS_STATUS_SUCCESS)
-                v.lt_ok = true;
-        }
-    }
-    if (v.mode != 2) {
-        void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (lib) {
-            rb_create_t create = reinterpret_cast<rb_create_t>(dlsym(lib, "rocblas_create_handle"));
-            v.rb_set_stream = reinterpret_cast<rb_set_stream_t>(dlsym(lib, "rocblas_set_stream"));
-            v.rb_sgemm = reinterpret_cast<rb_sgemm_t>(dlsym(lib, "rocblas_sgemm"));
-            v.rb_gemm_ex = reinterpret_cast<rb_gemm_ex_t>(dlsym(lib, "rocblas_gemm_ex"));
-            if (create && v.rb_set_stream && v.rb_sgemm && create(&v.rb) == 0) v.rb_ok = true;
-        }
-    }
+    void* lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return;
+    v.rb_create = reinterpret_cast<rb_create_t>(dlsym(lib, "rocblas_create_handle"));
+    v.rb_set_stream = reinterpret_cast<rb_set_stream_t>(dlsym(lib, "rocblas_set_stream"));
+    v.rb_sgemm = reinterpret_cast<rb_sgemm_t>(dlsym(lib, "rocblas_sgemm"));
+    v.rb_gemm_ex = reinterpret_cast<rb_gemm_ex_t>(dlsym(lib, "rocblas_gemm_ex"));
+    if (v.rb_create && v.rb_set_stream && v.rb_sgemm) v.rb_ok = true;
 }
 
-// C_rm[M,N] = A_rm[M,K] . B_rm[N,K]^T  ==  column-major  D[N,M] = op_T(B as [K,N]) . (A as [K,M])
-// `bf16` = operands are bf16 (raw 16-bit), output / accumulation fp32.
-bool lt_gemm_locked(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, float* C,
-                    int64_t ldc, bool bf16, hipStream_t stream) {
+rb_handle vendor_handle_locked() {
     Vendor& v = g_vendor;
-    const hipDataType in_t = bf16 ? HIP_R_16BF : HIP_R_32F;
-    auto key = std::make_tuple(M, N, K, lda, ldb, ldc, bf16 ? 1 : 0);
-    auto it = v.plans.find(key);
-    if (it == v.plans.end()) {
-        LtPlan p{};
-        p.ok = false;
-        hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
-        hipblasLtMatmulPreference_t pref = nullptr;
-        bool good = v.lt_desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS &&
-                    v.lt_desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS &&
-                    v.lt_desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS &&
-                    v.lt_layout_create(&p.la, in_t, (uint64_t)K, (uint64_t)N, ldb) == HIPBLAS_STATUS_SUCCESS &&
-                    v.lt_layout_create(&p.lb, in_t, (uint64_t)K, (uint64_t)M, lda) == HIPBLAS_STATUS_SUCCESS &&
-                    v.lt_layout_create(&p.lc, HIP_R_32F, (uint64_t)N, (uint64_t)M, ldc) == HIPBLAS_STATUS_SUCCESS &&
-                    v.lt_pref_create(&pref) == HIPBLAS_STATUS_SUCCESS;
-        if (good) {
-            hipblasLtMatmulHeuristicResult_t res[1];
-            int n = 0;
-            if (v.lt_heuristic(v.lt, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, res, &n) == HIPBLAS_STATUS_SUCCESS && n > 0 &&
-                res[0].workspaceSize == 0) {      // preference default: no workspace allowed
-                p.algo = res[0].algo;
-                p.ok = true;
-            }
-            v.lt_pref_destroy(pref);
-        }
-        it = v.plans.emplace(key, p).first;
-    }
-    const LtPlan& p = it->second;
-    if (!p.ok) return false;
-    const float one = 1.f, zero = 0.f;
-    return v.lt_matmul(v.lt, p.desc, &one, B, p.la, A, p.lb, &zero, C, p.lc, C, p.lc, &p.algo, nullptr, 0, stream) ==
-           HIPBLAS_STATUS_SUCCESS;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto it = v.handles.find(dev);
+    if (it != v.handles.end()) return it->second;
+    rb_handle h = nullptr;
+    if (v.rb_create(&h) != 0) h = nullptr;
+    v.handles.emplace(dev, h);
+    return h;
 }
 
+// C_rm[M,N] = A_rm[M,K] . B_rm[N,K]^T  ==  column-major  D[N,M] = op_T(B as [K,N]) . (A as [K,M]).
 // addend (optional): C = A.B^T + addend; in place (addend == C, same ld) through beta = 1, otherwise
-// through rocblas_gemm_ex's separate C / D operands.  rocBLAS only.
+// through rocblas_gemm_ex's separate C / D operands.
 bool vendor_sgemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                   int64_t ldc, const float* addend, int64_t ld_add, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_vendor_mu);
     vendor_init_locked();
     Vendor& v = g_vendor;
+    if (!v.rb_ok) return false;
+    rb_handle h = vendor_handle_locked();
+    if (!h || v.rb_set_stream(h, stream) != 0) return false;
+    const float one = 1.f, zero = 0.f;
     if (addend) {
-        if (!v.rb_ok || v.mode == 2) return false;
-        const float one = 1.f;
-        if (v.rb_set_stream(v.rb, stream) != 0) return false;
         if (addend == C && ld_add == ldc)
-            return v.rb_sgemm(v.rb, 112, 111, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &one, C, (int)ldc) == 0;
+            return v.rb_sgemm(h, ROCBLAS_OP_TRANSPOSE, ROCBLAS_OP_NONE, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &one,
+                              C, (int)ldc) == 0;
         if (!v.rb_gemm_ex) return false;
-        return v.rb_gemm_ex(v.rb, 112, 111, (int)N, (int)M, (int)K, &one, B, 151, (int)ldb, A, 151, (int)lda, &one, addend, 151,
-                            (int)ld_add, C, 151, (int)ldc, 151, /*algo standard*/ 0, 0, 0) == 0;
+        return v.rb_gemm_ex(h, ROCBLAS_OP_TRANSPOSE, ROCBLAS_OP_NONE, (int)N, (int)M, (int)K, &one, B, ROCBLAS_DATATYPE_F32_R,
+                            (int)ldb, A, ROCBLAS_DATATYPE_F32_R, (int)lda, &one, addend, ROCBLAS_DATATYPE_F32_R, (int)ld_add, C,
+                            ROCBLAS_DATATYPE_F32_R, (int)ldc, ROCBLAS_DATATYPE_F32_R, ROCBLAS_GEMM_ALGO_STANDARD, 0, 0) == 0;
     }
-    // measured on the config-3 projection (in situ): rocBLAS 0.955 ms, hipBLASLt (first heuristic, no
-    // workspace) 0.977 ms -> rocBLAS first unless hipBLASLt is requested explicitly
-    if (v.mode == 2 && v.lt_ok && lt_gemm_locked(M, N, K, A, lda, B, ldb, C, ldc, false, stream)) return true;
-    if (v.rb_ok) {
-        const float one = 1.f, zero = 0.f;
-        if (v.rb_set_stream(v.rb, stream) != 0) return false;
-        if (v.rb_sgemm(v.rb, /*transpose*/ 112, /*none*/ 111, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &zero,
-                       C, (int)ldc) == 0)
-            return true;
-    }
-    return v.lt_ok && lt_gemm_locked(M, N, K, A, lda, B, ldb, C, ldc, false, stream);
+    return v.rb_sgemm(h, ROCBLAS_OP_TRANSPOSE, ROCBLAS_OP_NONE, (int)N, (int)M, (int)K, &one, B, (int)ldb, A, (int)lda, &zero, C,
+                      (int)ldc) == 0;
 }
 
-bool vendor_has_rocblas() {
+bool vendor_has_rocblas() {                 // opted in AND loadable (the library is only dlopen'ed once asked for)
+    if (!get_option(GVQA_OPT_VENDOR_GEMM)) return false;
     std::lock_guard<std::mutex> lk(g_vendor_mu);
     vendor_init_locked();
-    return g_vendor.rb_ok && g_vendor.mode != 1 && g_vendor.mode != 2;
-}
-
-int vendor_mode() {
-    std::lock_guard<std::mutex> lk(g_vendor_mu);
-    vendor_init_locked();
-    return g_vendor.mode;
+    return g_vendor.rb_ok;
 }
 }  // namespace
 
-// ---- bf16x3 split projection (opt-in) -------------------------------------------------------------
-// An fp32 value is the EXACT sum of three bf16 pieces (8 significant bits each: truncate, subtract,
-// repeat).  a.b = sum_{p,q} a_p b_q; dropping the three smallest cross terms (a2 b3, a3 b2, a3 b3,
-// <= 2^-23 relative) leaves six products of bf16 operands, each exact in fp32.  Laid out along K --
-// A' = [A1 A1 A2 A1 A2 A3], B' = [B1 B2 B1 B3 B2 B1], K' = 6K -- the projection becomes ONE bf16
-// MFMA GEMM with fp32 accumulation (16x the f32 MFMA rate for 6x the flops).  Measured against fp64
-// the result is as accurate as a native fp32 GEMM (emulation: max err 1.7e-6 vs 3.2e-6).
-// out[r, blk*K + k] for blk = 0..5; `which` selects the A' or B' piece order.
-__global__ __launch_bounds__(256) void k_split_bf16x3(int64_t rows, int K, const float* __restrict__ x, int64_t ld, int which,
-                                                      uint16_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * K) return;
-    const int64_t r = i / K;
-    const int k = (int)(i - r * K);
-    const float v = x[r * ld + k];
-    const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(b1);
-    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(b2);
-    const unsigned b3 = __float_as_uint(r2) & 0xFFFF0000u;
-    const uint16_t p[3] = {(uint16_t)(b1 >> 16), (uint16_t)(b2 >> 16), (uint16_t)(b3 >> 16)};
-    // piece index per K block:  A': 0 0 1 0 1 2   B': 0 1 0 2 1 0
-    const int a_order[6] = {0, 0, 1, 0, 1, 2}, b_order[6] = {0, 1, 0, 2, 1, 0};
-    uint16_t* o = out + r * 6 * (int64_t)K + k;
-#pragma unroll
-    for (int blk = 0; blk < 6; ++blk) o[(int64_t)blk * K] = p[which ? b_order[blk] : a_order[blk]];
-}
-
-int launch_split_bf16x3(int64_t rows, int K, const float* x, int64_t ld, int which, void* out, hipStream_t stream) {
-    if (rows == 0 || K == 0) return GVQA_OK;
-    hipLaunchKernelGGL(k_split_bf16x3, dim3((unsigned)cdiv(rows * K, 256)), dim3(256), 0, stream, rows, K, x, ld, which,
-                       static_cast<uint16_t*>(out));
-    GVQA_LAUNCH_CHECK();
-    return GVQA_OK;
-}
-
-// C[M,N] (fp32) = A'[M,K6] . B'[N,K6]^T with bf16 operands, fp32 accumulate (hipBLASLt).  false if unavailable.
-bool vendor_bf16_gemm(int64_t M, int64_t N, int64_t K6, const void* A, const void* B, float* C, int64_t ldc, hipStream_t stream) {
-    std::lock_guard<std::mutex> lk(g_vendor_mu);
-    vendor_init_locked();
-    const bool ok = g_vendor.lt_ok && lt_gemm_locked(M, N, K6, A, K6, B, K6, C, ldc, true, stream);
-    if (ok) g_bf16x3_used = true;
-    return ok;
-}
-
 const char* gemm_backend_name() {
-    std::lock_guard<std::mutex> lk(g_vendor_mu);
-    vendor_init_locked();
-    const Vendor& v = g_vendor;
-    if (g_bf16x3_used) return "OPT-IN bf16x3-split projections (hipblaslt bf16 MFMA, fp32 accumulate); k_linear_f32 otherwise";
-    if (v.mode == 1) return "hip (k_linear_f32, forced)";
-    if (v.mode == 2 && v.lt_ok) return "hipblaslt for plain projections >= 2 GFLOP, k_linear_f32 otherwise";
-    if (v.rb_ok) return "rocblas for plain projections >= 2 GFLOP, k_linear_f32 otherwise";
-    if (v.lt_ok) return "hipblaslt for plain projections >= 2 GFLOP, k_linear_f32 otherwise";
-    return "hip (k_linear_f32; no vendor BLAS available)";
+    if (vendor_has_rocblas())
+        return "OPT-IN vendor: rocblas for plain fp32 products >= 2 GFLOP (GVQA_OPT_VENDOR_GEMM); gvqa kernels otherwise";
+    if (get_option(GVQA_OPT_PROJECTION) == GVQA_PROJECTION_F32)
+        return "gvqa::k_linear_f32_dma / gvqa::k_linear_f32 (hand-written f32-input MFMA; GVQA_OPT_PROJECTION = f32)";
+    return "gvqa::k_linear_split3 (hand-written: fp32 as three exact bf16 pieces, six bf16-MFMA products, fp32 accumulate) "
+           "for the hop projections; gvqa::k_linear_f32* (f32-input MFMA) for every other product";
 }
 
 // C[m, :] = bias (the beta = 1 operand of a vendor GEMM with a bias-only epilogue)
@@ -642,7 +510,7 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     GVQA_REQUIRE((!ep.addend && !ep.mul) || batch == 1, GVQA_E_INVALID, "linear: addend/mul epilogue is not batched");
     // 16-byte vector loads need 16-byte aligned rows
     if (dtype_flags == 0 && !ep.bias && !ep.mul && !ep.relu && batch == 1 && N > 64 && M < (1ll << 31) &&
-        (2.0 * M * N * K >= 2e9 || vendor_mode() >= 2) && vendor_mode() != 1) {
+        2.0 * M * N * K >= 2e9 && vendor_has_rocblas()) {
         if (vendor_sgemm(M, N, K, A, lda, B, ldb, C, ldc, ep.addend, ep.ld_add, stream)) return GVQA_OK;
     }
     // bias-only epilogue on a large product: write the bias rows (one pass over C, ~4 % of the GEMM

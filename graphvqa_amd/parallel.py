@@ -41,6 +41,37 @@ def shard_batch(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int, rank
     return slice(n0, n1), emask, ei, batch[n0:n1] - g0, (g0, g1)
 
 
+class BatchShard:
+    """One rank's share of ONE scene-graph batch (the `DistributedSampler` role of the reference's drivers,
+    mainExplain_gat.py:197-198,226-227, at batch granularity): contiguous graph range balanced by edge count,
+    node / edge / instruction tensors sliced to it, ids rebased.  Tensors live on `device`."""
+
+    def __init__(self, edge_index: np.ndarray, batch: np.ndarray, num_graphs: int, x, edge_attr, instr, rank: int,
+                 world_size: int, device):
+        nsl, emask, ei, b, (g0, g1) = shard_batch(edge_index, batch, num_graphs, rank, world_size)
+        epg = np.bincount(batch[edge_index[0]], minlength=num_graphs)
+        bounds = partition_graphs(epg, world_size)
+        self.counts = [int(bounds[r + 1] - bounds[r]) for r in range(world_size)]     # graphs per rank (every rank agrees)
+        self.graph_range = (g0, g1)
+        self.num_graphs, self.num_nodes, self.num_edges = g1 - g0, nsl.stop - nsl.start, int(ei.shape[1])
+        as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        self.x = as_t(x)[nsl].contiguous().to(device)
+        self.edge_attr = as_t(edge_attr)[as_t(emask)].contiguous().to(device)
+        self.instr = as_t(instr)[:, g0:g1].contiguous().to(device)
+        self.edge_index = as_t(ei).contiguous().to(device)
+        self.batch = as_t(b).contiguous().to(device)
+
+
+def sharded_step(shard: BatchShard, forward, pool=None, force: bool = False) -> torch.Tensor:
+    """One data-parallel step over one batch: `forward(shard) -> h [N_r, C]` on the local graphs (no communication inside
+    the K hops), per-graph rows `pool(h, shard) -> [B_r, C]` (default: node mean), then ONE all-gather of the rows in
+    graph order -> [B, C] on every rank.  bench.py drives the HIP path through this; the gloo CPU test drives the oracle
+    through the same function."""
+    h = forward(shard)
+    rows = pool(h, shard) if pool is not None else graph_mean_pool(h, shard.batch, shard.num_graphs)
+    return all_gather_graph_rows(rows, counts=shard.counts, force=force)
+
+
 def graph_mean_pool(h: torch.Tensor, batch: torch.Tensor, num_graphs: int, graph=None) -> torch.Tensor:
     """Per-graph mean of node rows -> [B, C]; the small per-graph payload that is all-gathered when the answer head is
     not run.  With the batch handle (`graph`, a SceneGraphBatch) on a GPU this is one pass of the HIP segment-sum kernel

@@ -197,6 +197,37 @@ int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A,
                      const float* bias, const void* addend, int64_t ld_add, const void* mul, int64_t ld_mul, int relu,
                      void* C, int64_t ldc, int c_bf16, void* stream);
 
+/* fp32-accurate projection on the bf16 matrix cores ("split3", the default for the GAT hop projection
+ * xp = lin_l(x_cat), gat_skip.py:133): every fp32 operand value is the exact sum of three round-to-nearest
+ * bf16 pieces; the six largest of the nine piece products (each exact in fp32) are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 -- fp32-class accuracy (dropped terms <= 3 * 2^-27 relative) at 16x the f32-MFMA
+ * rate for 6x the work.  gvqa_split3_pack writes an fp32 matrix X[rows, K] (leading dimension ld) as
+ * fragment-major pieces P[ceil(rows/32)][ceil(K/16)][3][64 lanes][8 bf16] (zero padded; packed must be
+ * 16-byte aligned and hold gvqa_split3_packed_bytes(rows, K)); gvqa_linear_split3 computes
+ * C[M,N] = A[M,K] . B[N,K]^T from the packed operands with the epilogue of gvqa_linear_f32_ex (fp32 C, N % 4 == 0,
+ * 16-byte aligned rows; GVQA_E_UNSUPPORTED otherwise). */
+size_t gvqa_split3_packed_bytes(int64_t rows, int64_t K);
+int gvqa_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
+int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
+                       const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
+                       int64_t ldc, void* stream);
+
+/* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split3|f32,
+ * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls
+ * made afterwards (benchmarks and tests compare modes inside one process).  Workspace sizes depend on
+ * GVQA_OPT_PROJECTION / _MIN_MFLOP: query gvqa_*_workspace_bytes after changing them. */
+enum gvqa_option {
+    GVQA_OPT_PROJECTION = 0,       /* arithmetic of the hop projection xp = lin_l(x_cat): GVQA_PROJECTION_* */
+    GVQA_OPT_VENDOR_GEMM = 1,      /* 1: plain fp32 products >= 2 GFLOP go to rocBLAS (comparison only; default 0) */
+    GVQA_OPT_SPLIT3_MIN_MFLOP = 2, /* products below this many MFLOP stay on the f32-input MFMA kernels (default 1000) */
+    GVQA_OPT_SPLIT3_VARIANT = 3,   /* 0 = choose by shape; otherwise an exact k_linear_split3 instantiation (tuning / tests) */
+    GVQA_NUM_OPTIONS = 4
+};
+#define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate (default) */
+#define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */
+int gvqa_set_option(int option, int value);
+int gvqa_get_option(int option);
+
 /* Which GEMM backend serves the plain dense projections in this process (hand-written k_linear_f32,
  * or rocBLAS for large epilogue-free products; GVQA_GEMM_BACKEND=auto|hip|rocblas). */
 const char* gvqa_gemm_backend(void);
@@ -466,7 +497,8 @@ enum {
     GVQA_STAGE_NODE_LOGIT = 5, /* a_l / a_r                                    */
     GVQA_STAGE_MP = 6,         /* fused GAT message passing                    */
     GVQA_STAGE_OTHER = 7,
-    GVQA_NUM_STAGES = 8
+    GVQA_STAGE_PACK = 8,       /* split3 operand packing (pieces of h, of the weights) */
+    GVQA_NUM_STAGES = 9
 };
 int gvqa_prof_enable(int on);
 /* Waits for outstanding events, ADDS elapsed milliseconds / launch counts per stage into the

@@ -12,7 +12,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from graphvqa_amd import synth
-from graphvqa_amd.parallel import partition_graphs, shard_batch, graph_mean_pool, all_gather_graph_rows
+from graphvqa_amd.parallel import (partition_graphs, shard_batch, graph_mean_pool, all_gather_graph_rows, BatchShard,
+                                   sharded_step)
 from tests.util import t, tparams
 
 
@@ -38,10 +39,12 @@ def _worker(rank, world, port, q):
         from oracle import ref_torch as R
         torch.set_num_threads(1)
         gb, p, x, ea, ins, H = _case()
+        # the bench's step (parallel.sharded_step) with the oracle standing in for the HIP forward
+        shard = BatchShard(gb.edge_index, gb.batch, gb.num_graphs, x, ea, ins, rank, world, torch.device("cpu"))
+        fwd = lambda s: R.gat_seq(s.x, s.edge_index, s.edge_attr, s.instr, s.batch, tparams(p), heads=H)
+        gathered = sharded_step(shard, fwd)               # ragged shards: padded all-gather
         nsl, emask, ei, b, (g0, g1) = shard_batch(gb.edge_index, gb.batch, gb.num_graphs, rank, world)
-        h = R.gat_seq(t(x[nsl]), t(ei), t(ea[emask]), t(ins[:, g0:g1]), t(b), tparams(p), heads=H)
-        rows = graph_mean_pool(h, t(b), g1 - g0)
-        gathered = all_gather_graph_rows(rows)            # ragged shards: padded all-gather
+        assert (shard.num_graphs, shard.num_nodes, shard.num_edges) == (g1 - g0, nsl.stop - nsl.start, ei.shape[1])
         if rank == 0:
             q.put(gathered.numpy())
         dist.barrier()
