@@ -46,7 +46,12 @@ class GINEConv(torch.nn.Module):
         p.nn0_bias = _f32c(self.nn[0].bias, "nn.0.bias").data_ptr()
         p.nn2_weight = _f32c(self.nn[2].weight, "nn.2.weight").data_ptr()
         p.nn2_bias = _f32c(self.nn[2].bias, "nn.2.bias").data_ptr()
-        p.eps = float(self.eps.item()) if isinstance(self.eps, Parameter) else self.initial_eps
+        # the VALUE of `eps` (a buffer when train_eps=False, loaded from `convs.i.eps`) is what PyG multiplies by; the host
+        # copy is refreshed only when the tensor changes (in-place edits / load_state_dict bump `_version`)
+        key = (self.eps.data_ptr(), self.eps._version)
+        if getattr(self, "_eps_key", None) != key:
+            self._eps_host, self._eps_key = float(self.eps.detach().reshape(-1)[0].item()), key
+        p.eps = self._eps_host
         return p
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor, size=None, graph=None,

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -607,11 +608,18 @@ static int plan_parts(int64_t B, int C, const TilePlan& p) {
 
 template <int H, int ITEMS>
 static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H, ITEMS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-        attr_set = true;
+    // the 160 KiB dynamic-LDS opt-in is a per-device function attribute: set once per (instantiation, device)
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    GVQA_HIP_CHECK(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H, ITEMS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL((k_gat_mp_tiled<H, ITEMS>), dim3((unsigned)B, (unsigned)a.nparts), dim3(MP_THREADS), p.lds_bytes, stream, a);
     GVQA_LAUNCH_CHECK();

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void k_count(int64_t N, int64_t E, int64_t B,
     if (i < N) {
         int64_t g = batch ? batch[i] : 0;
         int64_t gprev = (i == 0) ? -1 : (batch ? batch[i - 1] : 0);
-        if (g < 0 || g >= B || g < gprev) {
+        // the fill loop below runs from the NEIGHBOUR's id: a malformed neighbour (negative sentinel, id >= B) must not
+        // drive it out of graph_ptr[] or into a billion-iteration spin before finalize can report the batch
+        if (g < 0 || g >= B || g < gprev || gprev < -1 || gprev >= B) {
             stats[ST_INVALID] = 1;
         } else {
             node_graph[i] = (int32_t)g;

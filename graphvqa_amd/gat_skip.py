@@ -485,6 +485,12 @@ class gat_seq(torch.nn.Module):
         if needs_grad or (self.training and self.dropout > 0):
             return self._forward_autograd(x, edge_index, edge_attr, instr, batch, graph, return_attention_weights,
                                           return_hops)
+        if (return_attention_weights or return_hops) and (not graph.intra_graph or self.training):
+            # the cross-graph fallback and the fused batch-statistics path return the final tensor only: the same
+            # (out, alpha, hops) triple comes from the differentiable formulation run without gradients
+            with torch.no_grad():
+                return self._forward_autograd(x, edge_index, edge_attr, instr, batch, graph, return_attention_weights,
+                                              return_hops)
         if not graph.intra_graph:
             return self._forward_unfolded(x, edge_index, edge_attr, instr, batch, graph)
         H, Cc = self.heads, self.out_channels
@@ -496,10 +502,10 @@ class gat_seq(torch.nn.Module):
             hops[i] = conv._params(self.bns[i] if i != K - 1 else None, keep)
         dev = x.device
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
-        alpha = torch.empty((K, E, H), dtype=torch.float32, device=dev) if return_attention_weights else None
-        hop_out = torch.empty((K, N, Cc), dtype=torch.float32, device=dev) if return_hops else None
         if self.training:
             return self._forward_train_bn(lib, graph, d, hops, x, edge_attr, instr, out)
+        alpha = torch.empty((K, E, H), dtype=torch.float32, device=dev) if return_attention_weights else None
+        hop_out = torch.empty((K, N, Cc), dtype=torch.float32, device=dev) if return_hops else None
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_gat_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), dev)
             _lib.check(lib.gvqa_gat_seq_forward(C.byref(graph.c), C.byref(d), hops, x.data_ptr(),

@@ -381,7 +381,73 @@ def gen_encoder():
          x_encoded=xe, edge_attr_encoded=ee)
 
 
+def gen_pipeline():
+    """BASELINE config 1: the reference's own `PipelineModel.forward` (pipeline_model_gat.py:743-821) on the two debug
+    scene graphs 2354786 (N=12, E=40) and 2375429 (N=21, E=85), batch = 2, eval mode, on the stub vocabulary.
+
+    The modules the build replaces -- scene-graph encoder, gat_seq, attention pooling, logit_fc -- get their parameters
+    from graphvqa_amd.synth seeds (regenerated by the tests); the transformer question encoder / program decoder (out of
+    scope) keep torch's seeded default init and only their OUTPUTS that enter the path are recorded:
+    `instr_vectors` [5, B, 512] (:764) and `questions_encoded[0]` [B, 512] (:803).  Every tensor at the seams of
+    :751-816 is captured with forward hooks, nothing in the reference is modified."""
+    stub_dataset_entry()
+    import types
+    import pipeline_model_gat as PM
+    torch.manual_seed(4242)
+    model = PM.PipelineModel()
+    model.eval()
+    enc = model.scene_graph_encoder
+    V, D = enc.sg_vocab_embedding.weight.shape
+    pad = enc.sg_vocab_embedding.padding_idx
+    load_params(enc, synth.encoder_params(V, D, seed=833, pad_idx=pad))
+    load_params(model.gat_seq, synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=909))
+    load_params(model.graph_global_attention_pooling, synth.attention_pool_params(300, 512, seed=811))
+    load_params(model.logit_fc, synth.classifier_params(512, 512, 1842, seed=822, prefix=""))
+    sgs = debug_graphs()
+    ids = ["2354786", "2375429"]
+    gb = batch_scene_graphs([sgs[i] for i in ids])
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    added, off = [], 0
+    for i in ids:
+        n, ei, a = scene_graph_topology(sgs[i])
+        added.append(a + off)
+        off += ei.shape[1]
+    added = np.concatenate(added)
+    x_tok = synth.randint(N * 12, 71, 0, V, stream=9).reshape(N, 12)
+    x_tok[:, 4:] = pad
+    e_tok = synth.randint(E, 72, 1, V, stream=9).reshape(E, 1)
+    TV = model.text_vocab_embedding.weight.shape[0]
+    Lq, Lp = 9, 8
+    questions = synth.randint(Lq * B, 73, 3, TV, stream=9).reshape(Lq, B)
+    programs_input = synth.randint(Lp * B * 5, 74, 3, TV, stream=9).reshape(Lp, B * 5)
+    data = types.SimpleNamespace(x=t(x_tok), edge_attr=t(e_tok), edge_index=t(gb.edge_index), batch=t(gb.batch),
+                                 added_sym_edge=t(added))
+    cap = {}
+    hooks = [model.scene_graph_encoder.register_forward_hook(lambda m, i, o: cap.__setitem__("enc", o)),
+             model.question_encoder.register_forward_hook(lambda m, i, o: cap.__setitem__("q", o)),
+             model.program_decoder.register_forward_hook(lambda m, i, o: cap.__setitem__("dec", o)),
+             model.gat_seq.register_forward_hook(lambda m, i, o: cap.__setitem__("exec", o)),
+             model.graph_global_attention_pooling.register_forward_hook(lambda m, i, o: cap.__setitem__("pool", o))]
+    with torch.no_grad():
+        programs_output, logits = model(t(questions), data, t(programs_input), None)
+    for h in hooks:
+        h.remove()
+    assert logits.shape == (B, 1842) and cap["dec"][1].shape == (5, B, 512)
+    save("pipeline_debug2", dict(case="PipelineModel.forward eval, debug graphs 2354786 + 2375429, batch 2",
+                                 ref="pipeline_model_gat.py:743-821", graphs=ids, vocab=int(V), text_vocab=int(TV), pad_idx=int(pad),
+                                 model_seed=4242, encoder_seed=833, gat_seq_seed=909, pool_seed=811, fc_seed=822,
+                                 note="instr_vectors / question_feature are outputs of the reference's transformer decoder / "
+                                      "encoder (out of scope) under torch.manual_seed(4242) default init"),
+         x_tokens=x_tok, edge_tokens=e_tok, added_sym_edge=added, edge_index=gb.edge_index, batch=gb.batch,
+         questions=questions, programs_input=programs_input,
+         x_encoded=cap["enc"][0], edge_attr_encoded=cap["enc"][1], instr_vectors=cap["dec"][1], question_feature=cap["q"][0],
+         x_executed=cap["exec"], pooled=cap["pool"], short_answer_logits=logits)
+
+
 if __name__ == "__main__":
+    if "--pipeline-only" in sys.argv:
+        gen_pipeline()
+        sys.exit(0)
     if "--encoder-only" in sys.argv:
         gen_encoder()
         sys.exit(0)
@@ -399,3 +465,4 @@ if __name__ == "__main__":
     gen_gat()
     gen_gine_gcn()
     gen_lcgn()
+    gen_pipeline()

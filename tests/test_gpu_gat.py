@@ -322,7 +322,17 @@ def test_large_single_graph_uses_general_kernel(dev):
     assert maxabs(out, ref) < TOL
 
 
-def test_config2_shape_vs_oracle(dev):
+@pytest.fixture(params=["split3", "f32"])
+def projection_mode(request):
+    """Both arithmetics of the hop projection (GVQA_OPT_PROJECTION): the default three-piece bf16 split on the bf16
+    matrix cores, and the f32-input MFMA kernels (k_linear_f32_dma / k_linear_f32)."""
+    from graphvqa_amd import _lib
+    old = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_SPLIT3 if request.param == "split3" else _lib.PROJECTION_F32)
+    yield request.param
+    _lib.set_option(_lib.OPT_PROJECTION, old)
+
+
+def test_config2_shape_vs_oracle(dev, projection_mode):
     """BASELINE config 2 (1k graphs, ~30 nodes / ~60 edges, exact reference dims) against the fp32 oracle."""
     from oracle import ref_torch as R
     gb = synth.config2_batch()
@@ -334,6 +344,37 @@ def test_config2_shape_vs_oracle(dev):
     ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), return_all=True)
     assert maxabs(out, ref) < TOL
     assert maxabs(alpha[4], alphas[4]) < 2e-5
+
+
+def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode):
+    """The kernel instance bench.py times -- k_gat_mp_tiled<4,2> at C = 512, H = 4 with 128-channel ranges (20 stages per
+    graph), one block per graph -- and the hop projection at d = 512, against the fp32 oracle (/root/reference
+    gat_skip.py:249-279 restated) on the first 64 graphs of the config-3 batch, K = 5."""
+    import ctypes, os
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch
+    nb, d = 64, 512
+    gb = synth.config3_batch(nb)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(d, d, d, d, 5, 4, seed=777)
+    x, ea, ins = synth.normal((N, d), 1), synth.normal((E, d), 2), synth.normal((5, B, d), 3)
+    ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), return_all=True)
+    g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
+    plan = _lib.MpPlan()
+    for parts in ("1", None):                 # bench geometry (one block per graph), then the small-batch split
+        if parts:
+            os.environ["GVQA_MP_PARTS"] = parts
+        try:
+            _lib.check(_lib.load().gvqa_gat_mp_plan(ctypes.byref(g.c), d, 4, ctypes.byref(plan)))
+            out, alpha, _ = _run_gat_seq(dev, (d, d, d, 5, 4), p, x, gb.edge_index, ea, ins, gb.batch,
+                                         return_attention_weights=True)
+        finally:
+            os.environ.pop("GVQA_MP_PARTS", None)
+        assert plan.tiled == 1 and plan.channel_range == 128 and plan.accumulators == 2 and plan.stages_per_graph == 20
+        assert plan.blocks_per_graph == (1 if parts else 4)
+        assert maxabs(out, ref) < TOL
+        assert maxabs(alpha[4], alphas[4]) < 2e-5
 
 
 def test_config3_full_size_properties(dev):
@@ -391,9 +432,73 @@ def test_errors_are_loud(dev):
     assert out.shape == (3, 8) and torch.isfinite(out).all()
 
 
+def test_return_flags_are_honoured_on_every_path(dev):
+    """return_attention_weights / return_hops give the same (out, alpha, hops) triple on the fused eval path, in train
+    mode without gradients (batch-statistics BatchNorm) and on cross-graph batches (unfolded fallback)."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.gat_skip import gat_seq
+    H, C, de, di, K = 4, 16, 8, 12, 3
+    gb = synth.make_graph_batch(5, seed=19, nodes_lo=3, nodes_hi=7, rel_per_node=1.2)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=47)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    args = lambda ei: [t(a, device=dev) for a in (x, ei, ea, ins, gb.batch)]
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), p, dev)
+    ref, hs, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
+    out, alpha, hops = m(*args(gb.edge_index), return_attention_weights=True, return_hops=True)
+    assert maxabs(out, ref) < TOL and maxabs(alpha, torch.stack(alphas)) < 2e-5 and maxabs(hops, torch.stack(hs)) < TOL
+    m.train()                                               # dropout 0, no gradients: fused batch-statistics path
+    res = m(*args(gb.edge_index), return_attention_weights=True, return_hops=True)
+    assert isinstance(res, tuple) and len(res) == 3 and res[1].shape == (K, E, H) and res[2].shape == (K, N, C)
+    plain = m(*args(gb.edge_index))
+    assert maxabs(res[0], plain) < 2e-5
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), p, dev)     # fresh running statistics
+    ei_x = gb.edge_index.copy()
+    ei_x[0, 0] = N - 1                                      # an edge from the last graph into the first: cross-graph batch
+    res = m(*args(ei_x), return_attention_weights=True, return_hops=True)
+    refx, hsx, alx = R.gat_seq(t(x), t(ei_x), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
+    assert maxabs(res[0], refx) < TOL and maxabs(res[1], torch.stack(alx)) < 2e-5 and maxabs(res[2], torch.stack(hsx)) < TOL
+
+
+def test_malformed_batch_ids_are_reported_not_followed(dev):
+    """A sentinel / out-of-range graph id in `batch` must come back as an error from the CSR build (never an
+    out-of-bounds fill of graph_ptr[] or a device hang)."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]], dtype=torch.int64, device=dev)
+    for bad in ([0, -(2 ** 62), 1, 1], [0, 0, 2 ** 40, 1], [1, 0, 0, 1]):
+        with pytest.raises(_lib.GvqaError):
+            SceneGraphBatch(ei, torch.tensor(bad, dtype=torch.int64, device=dev), 4, 2)
+    g = SceneGraphBatch(ei, torch.tensor([0, 0, 1, 1], dtype=torch.int64, device=dev), 4, 2)     # still usable afterwards
+    assert g.graph_ptr.tolist() == [0, 2, 4]
+
+
 # ------------------------------------------------------------------------------------------------
 # GINE / GCN variants (SURVEY 8a-6/7)
 # ------------------------------------------------------------------------------------------------
+def test_gine_eps_buffer_value_is_used(dev):
+    """`convs.i.eps` is a state_dict key (PyG GINEConv, train_eps=False buffer): its VALUE scales the root term
+    (1 + eps) x_i -- a loaded or edited buffer must change the result exactly like in the shim."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.baseline_models import GINEConv
+    D, Cc = 12, 8
+    gb = synth.make_graph_batch(3, seed=5, nodes_lo=2, nodes_hi=6, rel_per_node=1.0)
+    N, E = gb.num_nodes, gb.num_edges
+    nn = torch.nn.Sequential(torch.nn.Linear(D, Cc), torch.nn.ReLU(), torch.nn.Linear(Cc, Cc))
+    conv = GINEConv(nn, eps=0.0).to(dev)
+    x, ea = t(synth.normal((N, D), 1), device=dev), t(synth.normal((E, D), 2), device=dev)
+    ei = t(gb.edge_index, device=dev)
+    out0 = conv(x, ei, ea)
+    conv.eps.fill_(0.75)                                    # in place, as load_state_dict does
+    out1 = conv(x, ei, ea)
+    w = {k: v.detach().cpu() for k, v in nn.state_dict().items()}
+    def ref(eps):
+        agg = torch.zeros(N, D).index_add_(0, t(gb.edge_index[1]), torch.relu(x.cpu()[gb.edge_index[0]] + ea.cpu()))
+        hcat = (1 + eps) * x.cpu() + agg
+        return torch.relu(hcat @ w["0.weight"].T + w["0.bias"]) @ w["2.weight"].T + w["2.bias"]
+    assert maxabs(out0, ref(0.0)) < 1e-4 and maxabs(out1, ref(0.75)) < 1e-4 and maxabs(out0, out1) > 1e-3
+
+
 def test_gine_seq_module_and_convs_golden(dev):
     from graphvqa_amd.baseline_models import gine_seq
     meta, g = load_golden("gine_seq_small")
@@ -495,7 +600,7 @@ def test_lcgn_config2_shape_vs_oracle(dev):
     """BASELINE config 5 shape (fp32): config-2 batch, lcgn_seq(in=300, out=512, cmd=512, H=1, 4 iterations), L=10."""
     from oracle import ref_torch as R
     from graphvqa_amd.lcgn import lcgn_seq
-    gb = synth.make_graph_batch(200, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=1.0)
+    gb = synth.config2_batch()
     N, B, O, L = gb.num_nodes, gb.num_graphs, 512, 10
     p = synth.lcgn_seq_params(300, O, seed=808)
     m = _load_module(lcgn_seq(300, O, 300, 5), p, dev)
@@ -540,6 +645,59 @@ def test_scene_graph_encoder_golden(dev):
     xe, ee, _ = enc(data)
     assert maxabs(ee, g["edge_attr_encoded"]) < 5e-5
     assert maxabs(xe, g["x_encoded"]) < TOL
+
+
+def test_encoder_rejects_token_ids_outside_the_table(dev):
+    import types
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    meta, g = load_golden("sg_encoder_debug4")
+    enc = _load_module(GroundTruth_SceneGraph_Encoder(meta["vocab"], meta["pad_idx"], meta["dim"]),
+                       synth.encoder_params(meta["vocab"], meta["dim"], seed=meta["param_seed"], pad_idx=meta["pad_idx"]), dev)
+    def data(x_tok=g["x_tokens"], e_tok=g["edge_tokens"], added=g["added_sym_edge"]):
+        return types.SimpleNamespace(x=t(x_tok, device=dev), edge_attr=t(e_tok, device=dev), edge_index=t(g["edge_index"], device=dev),
+                                     batch=t(g["batch"], device=dev), added_sym_edge=t(added, device=dev))
+    bx = g["x_tokens"].copy(); bx[3, 1] = meta["vocab"]
+    be = g["edge_tokens"].copy(); be[7, 0] = -1
+    ba = g["added_sym_edge"].copy(); ba[0] = g["edge_index"].shape[1]
+    for d in (data(x_tok=bx), data(e_tok=be), data(added=ba)):
+        with pytest.raises(IndexError):
+            enc(d)
+    enc(data())                                            # the valid batch still runs
+
+
+def test_config1_pipeline_forward_golden(dev):
+    """BASELINE config 1 on the HIP path against the REFERENCE'S OWN `PipelineModel.forward` (pipeline_model_gat.py:743-821,
+    captured in tests/golden/pipeline_debug2.npz): debug graphs 2354786 + 2375429, batch 2, through scene-graph encoder ->
+    gat_seq (K = 5) -> global attention pooling -> 1842-way answer logits; the recorded instruction vectors and question
+    feature (outputs of the out-of-scope transformers) are fed at the seams (:764, :803)."""
+    import types
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+    meta, g = load_golden("pipeline_debug2")
+    V = meta["vocab"]
+    enc = _load_module(GroundTruth_SceneGraph_Encoder(V, meta["pad_idx"], 300),
+                       synth.encoder_params(V, 300, seed=meta["encoder_seed"], pad_idx=meta["pad_idx"]), dev)
+    gs = _load_module(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4),
+                      synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=meta["gat_seq_seed"]), dev)
+    pool = _load_module(MyConditionalGlobalAttention(300, 512), synth.attention_pool_params(300, 512, seed=meta["pool_seed"]), dev)
+    clf = _load_module(ShortAnswerClassifier(512, 512, 1842), synth.classifier_params(512, 512, 1842, seed=meta["fc_seed"]), dev)
+    data = types.SimpleNamespace(x=t(g["x_tokens"], device=dev), edge_attr=t(g["edge_tokens"], device=dev),
+                                 edge_index=t(g["edge_index"], device=dev), batch=t(g["batch"], device=dev),
+                                 added_sym_edge=t(g["added_sym_edge"], device=dev))
+    xe, ee, _ = enc(data)
+    assert maxabs(xe, g["x_encoded"]) < TOL and maxabs(ee, g["edge_attr_encoded"]) < 5e-5
+    h = gs(xe, data.edge_index, ee, t(g["instr_vectors"], device=dev), data.batch)
+    assert maxabs(h, g["x_executed"]) < TOL
+    q = t(g["question_feature"], device=dev)
+    pooled = pool(h, q, data.batch)
+    logits = clf(pooled, q)
+    assert logits.shape == (2, 1842)
+    assert maxabs(pooled, g["pooled"]) < TOL and maxabs(logits, g["short_answer_logits"]) < TOL
+    # the path alone from the reference's own encoder outputs (what pipeline_model_gat.py:791 hands over)
+    h2 = gs(t(g["x_encoded"], device=dev), data.edge_index, t(g["edge_attr_encoded"], device=dev),
+            t(g["instr_vectors"], device=dev), data.batch)
+    assert maxabs(h2, g["x_executed"]) < TOL
 
 
 def test_config1_debug_pipeline_chain(dev):
@@ -721,7 +879,7 @@ def test_lcgn_bf16_node_features(dev, pieces):
     with single-piece weights); the fp32 mode keeps 1e-4."""
     from oracle import ref_torch as R
     from graphvqa_amd.lcgn import lcgn_seq
-    gb = synth.make_graph_batch(24, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=1.0)
+    gb = synth.config2_batch()                 # the batch config 5 is defined on: 1000 graphs, ~30k nodes
     N, B, O, L = gb.num_nodes, gb.num_graphs, 512, 10
     p = synth.lcgn_seq_params(300, O, seed=808)
     x, q, lstm = synth.normal((N, 300), 1), synth.normal((B, O), 2), synth.normal((L, B, O), 3)

@@ -137,6 +137,30 @@ def test_scene_graph_encoder():
     assert maxabs(xe, g["x_encoded"]) < 5e-5
 
 
+def test_config1_pipeline_forward_pinned_to_the_reference():
+    """BASELINE config 1: the oracle chain encoder -> gat_seq -> pooling -> logits against tensors captured from the
+    REFERENCE'S OWN `PipelineModel.forward` (pipeline_model_gat.py:743-821) on debug graphs 2354786 + 2375429, batch 2
+    (tests/golden/pipeline_debug2.npz; instruction vectors / question feature are the recorded outputs of the
+    reference's transformer decoder / encoder, which are out of scope)."""
+    meta, g = load_golden("pipeline_debug2")
+    B = int(g["batch"].max()) + 1
+    assert (g["batch"].shape[0], g["edge_index"].shape[1], B) == (33, 125, 2)
+    pe = tparams(synth.encoder_params(meta["vocab"], 300, seed=meta["encoder_seed"], pad_idx=meta["pad_idx"]))
+    pg = tparams(synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=meta["gat_seq_seed"]))
+    pp = tparams(synth.attention_pool_params(300, 512, seed=meta["pool_seed"]))
+    pc = tparams(synth.classifier_params(512, 512, 1842, seed=meta["fc_seed"]))
+    xe, ee = R.scene_graph_encoder(t(g["x_tokens"]), t(g["edge_index"]), t(g["edge_tokens"]), t(g["added_sym_edge"]),
+                                   t(g["batch"]), B, pe)
+    assert maxabs(xe, g["x_encoded"]) < 5e-5 and maxabs(ee, g["edge_attr_encoded"]) < 2e-5
+    h = R.gat_seq(xe, t(g["edge_index"]), ee, t(g["instr_vectors"]), t(g["batch"]), pg)
+    assert maxabs(h, g["x_executed"]) < 1e-4
+    q = t(g["question_feature"])
+    pooled = R.global_attention_pool(h, q, t(g["batch"]), pp, B)
+    assert maxabs(pooled, g["pooled"]) < 1e-4
+    logits = R.short_answer_logits(pooled, q, pc)
+    assert maxabs(logits, g["short_answer_logits"]) < 1e-4
+
+
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_gat_seq_backward_matches_reference_autograd(mode):
     """The oracle's autograd against gradients recorded from the REFERENCE's own gat_seq under autograd
