@@ -80,14 +80,19 @@ def profile_traffic():
 
 
 def live_pmc_traffic():
-    """HBM bytes per launch of the message-passing kernel, measured NOW: two rocprofv3 counter passes (FETCH_SIZE,
-    WRITE_SIZE; counters in their own runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short
-    child run of this same workload.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 64 B per 128 B
-    request of a wide coalesced stream, hence x2.  Returns (bytes or None, detail dict)."""
+    """HBM bytes per launch of the hop kernels, measured NOW: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE;
+    counters in their own runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over a short child run of this
+    same workload -- a few fused steps, then a few unfused ones, so both the fused hop kernel and the stand-alone
+    message-passing kernel are sampled.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 64 B per 128 B
+    request of a wide coalesced stream, hence x2.  Returns {"fused": {...}, "mp": {...}} (bytes per launch) or {"error": ...}."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
-        return None, {"error": "rocprofv3 not found"}
-    out = {}
+        return {"error": "rocprofv3 not found"}
+    import re
+    # the fused hop is the EPI = 2 instantiation (template arguments ..., EPI, heads), demangled or mangled
+    kinds = {"fused": lambda n: bool(re.search(r"k_linear_split3<[^>]*,\s*2,\s*[1248]>", n)) or bool(re.search(r"k_linear_split3.*ELi2ELi[1248]EEEv", n)),
+             "mp": lambda n: "k_gat_mp_tiled" in n}
+    acc = {k: {} for k in kinds}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="gvqa_pmc_", dir="/tmp")
@@ -98,22 +103,27 @@ def live_pmc_traffic():
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 shutil.rmtree(d, ignore_errors=True)
-                return None, {"error": f"{ctr} pass failed (rc {r.returncode})", "stderr_tail": r.stderr[-300:]}
-            vals = []
+                return {"error": f"{ctr} pass failed (rc {r.returncode}): " + r.stderr[-300:]}
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
-                    if row["Counter_Name"] == ctr and "k_gat_mp_tiled" in row["Kernel_Name"]:
-                        vals.append(float(row["Counter_Value"]))
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    for k, match in kinds.items():
+                        if match(row["Kernel_Name"]):
+                            acc[k].setdefault(ctr, []).append(float(row["Counter_Value"]))
             shutil.rmtree(d, ignore_errors=True)
-            if not vals:
-                return None, {"error": f"no k_gat_mp_tiled rows in the {ctr} pass"}
-            out[ctr] = {"launches": len(vals), "avg_KiB": sum(vals) / len(vals)}
     except Exception as e:      # timeouts, permission problems: the bench line must still come out
-        return None, {"error": repr(e)[:200]}
-    rd, wr = out["FETCH_SIZE"]["avg_KiB"] * 1024 * 2, out["WRITE_SIZE"]["avg_KiB"] * 1024
-    return rd + wr, {"read_bytes": rd, "write_bytes": wr, "launches_sampled": out["FETCH_SIZE"]["launches"],
-                     "method": "live rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace passes over `bench.py --pmc-child`; "
-                               "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE"}
+        return {"error": repr(e)[:200]}
+    out = {}
+    for k, v in acc.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            rd, wr = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 1024 * 2, sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) * 1024
+            out[k] = {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_sampled": len(v["FETCH_SIZE"]),
+                      "method": "live rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace passes over `bench.py --pmc-child`; "
+                                "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE"}
+    if not out:
+        out["error"] = "no hop-kernel rows in the counter passes"
+    return out
 
 
 def main():
@@ -214,10 +224,12 @@ def main():
             dt = float(tmax.item())
         return dt
 
-    if a.pmc_child:                      # counter pass: a few plain steps, nothing else
+    if a.pmc_child:                      # counter pass: a few plain steps fused, a few unfused, nothing else
         step = runner(make_shard(0, 1))
-        for _ in range(3):
-            step()
+        for fusion in (1, 0):
+            _lib.set_option(_lib.OPT_HOP_FUSION, fusion)
+            for _ in range(2):
+                step()
         torch.cuda.synchronize()
         return
 
@@ -246,21 +258,47 @@ def main():
     if rank == 0:
         N, E, B = shard.num_nodes, shard.num_edges, shard.num_graphs
         ms_step = dt / a.steps * 1e3
-        mp_ms, mp_n = prof["mp"]
-        mp_avg_s = mp_ms / max(mp_n, 1) * 1e-3
-        alg = mp_algorithmic_bytes(N, E, D, H)
-        alg_base = mp_algorithmic_bytes(N, E, D, H, fused_skip=False)
-        achieved = alg / mp_avg_s / 1e9 if mp_n else None
-        plan = _lib.MpPlan()
         g0 = SceneGraphBatch(shard.edge_index, shard.batch, N, B)
-        _lib.check(lib.gvqa_gat_mp_plan(g0.c, D, H, plan))
-        kernel = (f"gvqa::k_gat_mp_tiled<{H},{plan.accumulators}> (channel range {plan.channel_range}, {plan.stage_buffers} stage "
-                  f"buffers, {plan.lds_bytes} B LDS, {plan.blocks_per_graph} block(s) per graph)") if plan.tiled else "gvqa::k_gat_*_general"
+        hops = a.steps * K
+        fused = prof["mp"][1] == 0 and prof["alpha"][1] > 0       # the default path: projection + aggregation in one kernel
+        flops32 = 2 * N * D * H * D                                # folded projection flops per hop (fp32 equivalent)
+        split3 = prof["pack"][1] > 0
+
+        def mp_roofline(pr, graph):
+            """HBM roofline of the message-passing kernel from a stage profile (unfused runs)."""
+            mp_ms, mp_n = pr["mp"]
+            if not mp_n:
+                return None
+            mp_avg_s = mp_ms / mp_n * 1e-3
+            plan = _lib.MpPlan()
+            _lib.check(lib.gvqa_gat_mp_plan(graph.c, D, H, plan))
+            kernel = (f"gvqa::k_gat_mp_tiled<{H},{plan.accumulators}> (channel range {plan.channel_range}, {plan.stage_buffers} stage "
+                      f"buffers, {plan.lds_bytes} B LDS, {plan.blocks_per_graph} block(s) per graph)") if plan.tiled else "gvqa::k_gat_*_general"
+            alg = mp_algorithmic_bytes(graph.num_nodes, graph.num_edges, D, H)
+            alg_base = mp_algorithmic_bytes(graph.num_nodes, graph.num_edges, D, H, fused_skip=False)
+            ach = alg / mp_avg_s / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": alg,
+                    "frac_without_fused_skip_bytes": alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS,
+                    "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n}
+
         proj_ms, proj_n = prof["proj"]
-        pack_ms, pack_n = prof["pack"]
-        hop_launches = max(mp_n, 1)
-        gemm_s = (proj_ms - pack_ms * (hop_launches / max(pack_n, 1) if pack_n else 0)) / hop_launches * 1e-3 if proj_n else None
-        flops = 2 * N * D * H * D
+        if fused:
+            # dominant kernel: the fused hop (split3 projection + aggregation + epilogue), MFMA-bound.  Algorithmic work per
+            # launch = the six piece products of the folded projection (8(d)'s 2 N Dn H C, x 6) -- the aggregation's
+            # 2 E H C flops (0.4 %) are not counted.
+            avg_s = proj_ms / max(proj_n, 1) * 1e-3
+            ach = 6 * flops32 / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "gvqa::k_linear_split3<2,4,4,2,3,ILV,EPI=2> (fused hop: split3 projection, 256 x 256 tile, "
+                                               "GAT aggregation + skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)",
+                    "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                    "algorithmic_flops_per_launch": 6 * flops32, "fp32_equivalent_tflops": flops32 / avg_s / 1e12,
+                    "fp32_equivalent_frac_of_f32_mfma_peak": flops32 / avg_s / 1e12 / 157.3,
+                    "algorithmic_bytes_per_launch": 6 * N * D + 2 * 4 * N * D + 4 * (E * H + E + N + 1),
+                    "avg_launch_us": avg_s * 1e6, "launches": proj_n,
+                    "dtype_note": "peak = dense bf16 MFMA (MI355X_MICROARCH.md); operands are exact bf16 pieces of fp32 values, fp32 accumulate"}
+        else:
+            roof = mp_roofline(prof, g0)
         res = {
             "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
             "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
@@ -274,22 +312,12 @@ def main():
                        "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
                                        "no communication inside the hops, one RCCL all-gather of per-graph rows per step") if strong
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step",
+                       "hop": ("fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"
+                               if fused else "projection GEMM, then the fused message-passing kernel (xp through HBM)"),
                        "projection_arithmetic": "fp32 operands split into three exact bf16 pieces, six bf16-MFMA piece products, fp32 "
                                                 "accumulate (fp32 error class: tests/test_gpu_split3.py; end to end <= 1e-4 vs the oracle)"
-                       if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT3 else "f32-input MFMA"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg,
-                         "frac_without_fused_skip_bytes": (alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS) if mp_n else None,
-                         "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n},
-            "projection": {"kernel": "gvqa::k_linear_split3" if pack_n else "gvqa::k_linear_f32*",
-                           "flops_per_launch_fp32_equivalent": flops,
-                           "avg_launch_us_incl_pack": proj_ms / hop_launches * 1e3 if proj_n else None,
-                           "pack_us_per_hop": pack_ms / hop_launches * 1e3 if pack_n else 0.0,
-                           "fp32_equivalent_tflops_incl_pack": flops / (proj_ms / hop_launches * 1e-3) / 1e12 if proj_n else None,
-                           "mfma_tflops_gemm_only": (6 if pack_n else 1) * flops / gemm_s / 1e12 if gemm_s else None,
-                           "peak_tflops": {"bf16_mfma": 2500.0, "f32_mfma": 157.3}},
+                       if split3 else "f32-input MFMA"},
+            "roofline": roof,
             "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
             "gemm_backend": lib.gvqa_gemm_backend().decode(),
         }
@@ -297,11 +325,16 @@ def main():
             res["weak_value"], res["weak_ms_per_step"], res["weak_steps"] = weak["value"], weak["ms_per_step"], weak["steps"]
         if world == 1:
             if not a.no_extras:
-                # the same step on the f32-input MFMA kernels and on the vendor library, for comparison (few steps each)
+                # the same step (a) unfused: split3 projection + the message-passing kernel, whose HBM roofline the north star
+                # names; (b) on the f32-input MFMA kernels; (c) on the vendor library -- comparison legs, few steps each
                 full = runner(make_shard(0, 1))
-                n_x = max(3, a.steps // 4)
-                old = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
+                gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
+                n_x = max(5, a.steps // 4)
                 _lib.prof_enable(True)
+                old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 0)
+                t_u = timed(full, n_x, 2, _lib.prof_collect) / n_x
+                pu = _lib.prof_collect()
+                old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
                 t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
                 p32 = _lib.prof_collect()
                 _lib.set_option(_lib.OPT_VENDOR_GEMM, 1)
@@ -309,18 +342,34 @@ def main():
                 pv = _lib.prof_collect()
                 _lib.prof_enable(False)
                 _lib.set_option(_lib.OPT_VENDOR_GEMM, 0)
-                _lib.set_option(_lib.OPT_PROJECTION, old)
-                per = lambda pr: pr["proj"][0] / max(pr["proj"][1], 1) * 1e3
-                res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma", "ms_per_step": t_f32 * 1e3, "value": Eall / t_f32,
-                                              "avg_launch_us": per(p32), "tflops": flops / (per(p32) * 1e-6) / 1e12}
-                res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only)", "ms_per_step": t_v * 1e3,
-                                            "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops / (per(pv) * 1e-6) / 1e12}
+                _lib.set_option(_lib.OPT_PROJECTION, old_p)
+                _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+                per = lambda pr, k="proj": pr[k][0] / max(pr[k][1], 1) * 1e3
+                gemm_u = per(pu) - pu["pack"][0] / max(pu["proj"][1], 1) * 1e3
+                res["unfused_split3"] = {"hop": "gvqa::k_split3_pack + gvqa::k_linear_split3 + gvqa::k_gat_mp_tiled", "ms_per_step": t_u * 1e3,
+                                         "value": Eall / t_u, "projection_us_incl_pack": per(pu), "gemm_only_us": gemm_u,
+                                         "gemm_mfma_tflops": 6 * flops32 / (gemm_u * 1e-6) / 1e12}
+                if gfull is not None:
+                    res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
+                res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma (+ gvqa::k_gat_mp_tiled)", "ms_per_step": t_f32 * 1e3,
+                                              "value": Eall / t_f32, "avg_launch_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
+                res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
+                                            "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
             if not a.no_pmc:
-                traffic, detail = live_pmc_traffic()
-                res["roofline"]["traffic"] = traffic
-                res["roofline"]["traffic_detail"] = detail
-            if res["roofline"]["traffic"] is None:
-                res["roofline"]["traffic_from_profile"] = profile_traffic()
+                pm = live_pmc_traffic()
+                if "fused" in pm and fused:
+                    res["roofline"]["traffic"] = pm["fused"]["bytes"]
+                    res["roofline"]["traffic_detail"] = pm["fused"]
+                if "mp" in pm:
+                    tgt = res.get("mp_kernel_roofline") if fused else res["roofline"]
+                    if tgt is not None:
+                        tgt["traffic"] = pm["mp"]["bytes"]
+                        tgt["traffic_detail"] = pm["mp"]
+                if "error" in pm:
+                    res["roofline"]["traffic_error"] = pm["error"]
+            mpr = res.get("mp_kernel_roofline") if fused else res["roofline"]
+            if mpr is not None and mpr.get("traffic") is None:
+                mpr["traffic_from_profile"] = profile_traffic()
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(params, synth, np, torch)
         line = json.dumps(res)

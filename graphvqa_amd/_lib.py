@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GVQA_LIB", os.path.join(HERE, "lib", "libgvqa_hip.so"))   # GVQA_LIB: A/B a second build
 
 GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack")
+STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack", "alpha")
 # gvqa_set_option keys / values (include/gvqa.h)
-OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT = 0, 1, 2, 3
+OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION = 0, 1, 2, 3, 4
 PROJECTION_SPLIT3, PROJECTION_F32 = 0, 1
 NUM_STAGES = len(STAGES)
 
@@ -41,7 +41,8 @@ class Graph(C.Structure):
                 ("node_graph", C.c_void_p), ("graph_ptr", C.c_void_p), ("stats_dev", C.c_void_p),
                 ("max_graph_nodes", C.c_int32), ("max_graph_edges", C.c_int32),
                 ("max_in_degree", C.c_int32), ("intra_graph", C.c_int32), ("valid", C.c_int32),
-                ("finalized", C.c_int32)]
+                ("finalized", C.c_int32), ("row_group_ptr", C.c_void_p), ("num_row_groups", C.c_int32),
+                ("max_row_group_edges", C.c_int32)]
 
 
 class GatConvParams(C.Structure):

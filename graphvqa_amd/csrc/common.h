@@ -100,6 +100,38 @@ int launch_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* W, 
 bool linear_bf16_supported(int64_t K, int64_t lda, const void* A, const void* Wpk);
 int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, int64_t lda, const void* Wpk, LinearEpilogue ep,
                        void* C, int64_t ldc, bool c16, hipStream_t stream);
+// Fused hop (split3.hip): projection GEMM whose epilogue does the GAT aggregation of whole row groups out of LDS --
+// xp never reaches HBM.  Filled by the gat_seq driver.
+struct FusedHopArgs {
+    const int32_t* group_ptr;   // [G+1] first node of row group r (<= 128 nodes each, graph-aligned)
+    int num_groups;
+    const int32_t* rowptr;      // CSR by destination
+    const int32_t* csr_src;
+    const float* alpha_csr;     // [E, H] attention coefficients in CSR slot order (k_gat_alpha_general)
+    const int32_t* node_graph;
+    const float* graph_term;    // NULL or [B, t_ld]: columns [0, C) head-mean instruction term
+    int64_t t_ld;
+    const float* bias;          // NULL or [C]
+    const float* bn_w;          // all four NULL: no BatchNorm / ReLU
+    const float* bn_b;
+    const float* bn_m;
+    const float* bn_v;
+    const float* skip;          // NULL or [N, skip_ld]
+    int64_t skip_ld;
+    float* out;                 // [N, out_ld]
+    int64_t out_ld;
+    int H, C, cw;               // cw = 256 / H channels of every head per column block
+    int e_cap;                  // LDS capacity in edges per row group
+    float bn_eps;
+    int debug;                  // measurement aid (GVQA_FUSED_DEBUG bit mask): 1 no row image, 2 no aggregation, 4 no store, 8 no epilogue at all
+};
+size_t split3_packed_rows_bytes(int64_t row_tiles, int64_t K);
+int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
+                              hipStream_t stream);
+int launch_split3_pack_heads(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
+int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
+size_t hop_fused_lds_edge_capacity(int H);
+
 // fp32-accurate projection from three-piece bf16 splits on the bf16 matrix cores (split3.hip)
 size_t split3_packed_bytes(int64_t rows, int64_t K);
 int launch_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);

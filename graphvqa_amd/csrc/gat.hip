@@ -715,11 +715,20 @@ static bool proj_use_split3(int64_t M, int64_t N, int64_t K) {
            2.0 * (double)M * (double)N * (double)K >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
 }
 
+// Fused hop (projection + aggregation in one kernel, split3.hip): needs the split3 projection, a row-group plan (every
+// graph <= 128 nodes, intra-graph batch), H dividing 256 and the largest row group's edges within the kernel's LDS budget.
+static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    const int H = d->heads, C = d->out_channels;
+    return get_option(GVQA_OPT_HOP_FUSION) != 0 && proj_use_split3(g->num_nodes, (int64_t)H * C, d->node_dim) &&
+           g->num_row_groups > 0 && g->row_group_ptr && (H == 1 || H == 2 || H == 4 || H == 8) && C % 4 == 0 &&
+           (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H);
+}
+
 struct SeqLayout {
     size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, total;
 };
 
-static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d) {
+static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
     SeqLayout L;
     size_t off = 0;
     auto take = [&](size_t count) {
@@ -734,13 +743,17 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.T = take(K * B * align_up(C + H, 4));
     L.a_edge = take((size_t)E * K * H);
     L.a_node = take((size_t)N * 2 * H);
-    L.xp = take((size_t)N * H * C);
+    const bool fused = g && hop_fusion_applies(g, d);
+    L.xp = take(fused ? 0 : (size_t)N * H * C);                // the fused hop never materialises xp
     L.h0 = take((size_t)N * C);
     L.h1 = take((size_t)N * C);
     L.alpha_csr = take((size_t)E * H);
     L.bn_partial = take(gvqa_bn_train_workspace_bytes(N > 0 ? N : 1, C) / sizeof(float) + 1);
     L.bn_stats = take(2 * C);
-    if (proj_use_split3(N, (int64_t)(H * C), d->node_dim)) {     // packed three-piece operands (split3.hip)
+    if (fused) {     // row-group slots / head-interleaved weight rows
+        L.a6 = take(split3_packed_rows_bytes((int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float));
+        L.w6 = take(K * split3_packed_rows_bytes(cdiv((int64_t)C, 256 / H) * 8, d->node_dim) / sizeof(float));
+    } else if (proj_use_split3(N, (int64_t)(H * C), d->node_dim)) {     // packed three-piece operands (split3.hip)
         L.a6 = take(split3_packed_bytes(N, d->node_dim) / sizeof(float));
         L.w6 = take(K * split3_packed_bytes((int64_t)(H * C), d->node_dim) / sizeof(float));
     } else {
@@ -864,7 +877,7 @@ int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, voi
 
 size_t gvqa_gat_seq_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d) return 0;
-    return seq_layout(g->num_nodes, g->num_edges, g->num_graphs, d).total;
+    return seq_layout(g->num_nodes, g->num_edges, g->num_graphs, d, d->ins_dim >= 0 && d->num_hops >= 1 ? g : nullptr).total;
 }
 
 size_t gvqa_gat_conv_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d) {
@@ -922,7 +935,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     GVQA_REQUIRE(g->intra_graph, GVQA_E_UNSUPPORTED,
                  "gat_seq: an edge joins two graphs of the batch; use gvqa_gat_conv_forward on concatenated inputs");
     const int64_t N = g->num_nodes, E = g->num_edges, B = g->num_graphs;
-    SeqLayout L = seq_layout(N, E, B, d);
+    SeqLayout L = seq_layout(N, E, B, d, g);
     GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "gat_seq: workspace %zu < required %zu", ws_bytes, L.total);
     GVQA_REQUIRE((N == 0 || (x && out)) && (E == 0 || edge_attr) && (d->ins_dim == 0 || B == 0 || instr), GVQA_E_INVALID,
                  "gat_seq: null tensor");
@@ -954,13 +967,16 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         if (rc) return rc;
     }
     const bool split = proj_use_split3(N, (int64_t)H * C, Dn);
+    const bool fused = hop_fusion_applies(g, d);
+    const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
     char* a6 = base + L.a6;
     char* w6 = base + L.w6;
-    const size_t w6_hop = split3_packed_bytes((int64_t)H * C, Dn);
+    const size_t w6_hop = fused ? split3_packed_rows_bytes(cdiv((int64_t)C, fcw) * 8, Dn) : split3_packed_bytes((int64_t)H * C, Dn);
     if (split) {     // node-column weights of all hops -> packed pieces, once per forward
         StageTimer t(GVQA_STAGE_PACK, stream);
         for (int i = 0; i < K; ++i) {
-            rc = launch_split3_pack((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, w6 + (size_t)i * w6_hop, stream);
+            rc = fused ? launch_split3_pack_heads(H, C, fcw, Dn, hops[i].lin_l_weight, Dn + Di, w6 + (size_t)i * w6_hop, stream)
+                       : launch_split3_pack((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, w6 + (size_t)i * w6_hop, stream);
             if (rc) return rc;
         }
     }
@@ -976,6 +992,53 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             rc = launch_linear(N, 2 * H, Dn, h, Dn, P(L.Vn) + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
                                1, 0, 0, 0, aux);
             if (rc) return rc;
+        }
+        if (fused) {
+            // attention coefficients (CSR order) -> row-group slots of h -> projection + aggregation + epilogue in one kernel
+            if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
+            const bool train_bn = bn_stats_out && hops[i].bn_weight;
+            MpArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid; a.node_graph = g->node_graph; a.graph_ptr = g->graph_ptr;
+            a.a_node = P(L.a_node); a.a_edge = P(L.a_edge) + (int64_t)i * H; a.a_edge_stride = (int64_t)K * H;
+            a.graph_term = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr; a.t_ld = Tld;
+            a.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
+            a.alpha_csr = P(L.alpha_csr);
+            a.N = (int)N; a.C = C; a.slope = d->negative_slope;
+            {
+                StageTimer t(GVQA_STAGE_ALPHA, stream);
+                hipLaunchKernelGGL(k_gat_alpha_general, dim3((unsigned)cdiv(N * H, 256)), dim3(256), 0, stream, a, H);
+                GVQA_LAUNCH_CHECK();
+            }
+            {
+                StageTimer tp(GVQA_STAGE_PACK, stream);
+                rc = launch_split3_pack_groups(g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, stream);
+                if (rc) return rc;
+            }
+            FusedHopArgs f;
+            memset(&f, 0, sizeof(f));
+            f.group_ptr = g->row_group_ptr; f.num_groups = g->num_row_groups;
+            f.rowptr = g->rowptr; f.csr_src = g->csr_src; f.alpha_csr = P(L.alpha_csr); f.node_graph = g->node_graph;
+            f.graph_term = a.graph_term; f.t_ld = Tld;
+            f.bias = hops[i].bias;
+            if (!train_bn) { f.bn_w = hops[i].bn_weight; f.bn_b = hops[i].bn_bias; f.bn_m = hops[i].bn_mean; f.bn_v = hops[i].bn_var; }
+            GVQA_REQUIRE(!f.bn_w || (f.bn_b && f.bn_m && f.bn_v), GVQA_E_INVALID,
+                         "gat_seq: BatchNorm needs weight, bias, running_mean and running_var");
+            f.skip = h; f.skip_ld = C; f.out = h_next; f.out_ld = C;
+            f.H = H; f.C = C; f.cw = fcw; f.e_cap = g->max_row_group_edges; f.bn_eps = d->bn_eps;
+            {
+                StageTimer t(GVQA_STAGE_PROJ, stream);
+                rc = launch_hop_fused_split3(Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
+                if (rc) return rc;
+            }
+            if (train_bn) {
+                GVQA_REQUIRE(hops[i].bn_bias, GVQA_E_INVALID, "gat_seq: BatchNorm needs weight and bias");
+                rc = bn_train_forward(N, C, h_next, &hops[i], d->bn_eps, bn_stats_out + (int64_t)i * 2 * C, P(L.bn_partial),
+                                      gvqa_bn_train_workspace_bytes(N, C), stream);
+                if (rc) return rc;
+            }
+            h = h_next;
+            continue;
         }
         {   // xp = h . W_l[:, :Dn]^T   (node half of gat_skip.py:133; instruction half is in T)
             StageTimer t(GVQA_STAGE_PROJ, stream);

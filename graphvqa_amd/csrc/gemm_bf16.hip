@@ -202,7 +202,7 @@ template <bool C16>
 __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, int P, const uint16_t* __restrict__ A, int64_t lda,
                                                          const uint16_t* __restrict__ B, int64_t ldb, LinearEpilogue ep,
                                                          void* C_, int64_t ldc) {
-    constexpr int BM = 128, BN = 128, WR = 2, WC = 2, BK = 64;
+    constexpr int BM = 128, BN = 128, WC = 2, BK = 64;
     constexpr int TILE_BYTES = 128 * BK * 2;                  // one operand tile: 16 KiB
     typedef typename std::conditional<C16, uint16_t, float>::type TC;
     TC* C = static_cast<TC*>(C_);

@@ -7,6 +7,9 @@
 // in the reference's COO order (deterministic, run-to-run bit-identical).
 #include <algorithm>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace gvqa {
@@ -177,8 +180,17 @@ __global__ __launch_bounds__(256) void k_stats(int64_t N, int64_t B, const int32
 }
 
 struct GraphLayout {
-    size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, deg, rank, slot_eid, tile_sum, total;
+    size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, deg, rank, slot_eid, tile_sum, graph_eptr, row_group, total;
 };
+
+constexpr int ROW_GROUP = 128;      // rows of one group of the fused hop kernel (half a 256-row block tile)
+
+// graph_eptr[g] = first CSR slot of graph g's in-edges (g = B: E) -- what the host needs beside graph_ptr to plan row groups
+__global__ __launch_bounds__(256) void k_graph_eptr(int64_t B, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ rowptr,
+                                                    int32_t* __restrict__ graph_eptr) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g <= B) graph_eptr[g] = rowptr[graph_ptr[g]];
+}
 
 static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     GraphLayout L;
@@ -198,6 +210,8 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     L.rank = take(E);
     L.slot_eid = take(E);
     L.tile_sum = take(cdiv(N + 1, SCAN_TILE) + 1);
+    L.graph_eptr = take(B + 1);
+    L.row_group = take(B + 2);            // at most one group per non-empty graph, + the end marker
     L.total = off;
     return L;
 }
@@ -283,9 +297,46 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream_) {
     g->intra_graph = st[ST_NOT_INTRA] ? 0 : 1;
     g->valid = st[ST_INVALID] ? 0 : 1;
     g->finalized = 1;
+    g->row_group_ptr = nullptr;
+    g->num_row_groups = 0;
+    g->max_row_group_edges = 0;
     GVQA_REQUIRE(g->valid, GVQA_E_GRAPH,
                  "graph violates the input contract (edge index out of [0,N), or batch not "
                  "non-decreasing in [0,B))");
+    // Row groups for the fused hop kernel: greedy in order, a group closes when the next graph would not fit.  Planned
+    // on the host from graph_ptr / the graphs' edge offsets (two small copies; this call synchronises anyway).
+    const int64_t B = g->num_graphs, N = g->num_nodes;
+    if (g->intra_graph && N > 0 && B > 0 && g->max_graph_nodes <= ROW_GROUP && B < (1ll << 24)) {
+        GraphLayout L = graph_layout(N, g->num_edges, B);
+        char* base = const_cast<char*>(reinterpret_cast<const char*>(g->rowptr)) - L.rowptr;
+        int32_t* eptr_dev = reinterpret_cast<int32_t*>(base + L.graph_eptr);
+        int32_t* grp_dev = reinterpret_cast<int32_t*>(base + L.row_group);
+        hipLaunchKernelGGL(k_graph_eptr, dim3((unsigned)cdiv(B + 1, 256)), dim3(256), 0, stream, B, g->graph_ptr, g->rowptr, eptr_dev);
+        GVQA_LAUNCH_CHECK();
+        static thread_local std::vector<int32_t> hp, he, hg;
+        hp.resize(B + 1); he.resize(B + 1);
+        GVQA_HIP_CHECK(hipMemcpyAsync(hp.data(), g->graph_ptr, (B + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        GVQA_HIP_CHECK(hipMemcpyAsync(he.data(), eptr_dev, (B + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        GVQA_HIP_CHECK(hipStreamSynchronize(stream));
+        hg.clear();
+        hg.push_back(0);
+        int32_t start = 0, e_start = 0, max_e = 0;
+        for (int64_t q = 0; q < B; ++q) {
+            if (hp[q + 1] - start > ROW_GROUP) {          // graph q does not fit any more: close the group before it
+                max_e = std::max(max_e, he[q] - e_start);
+                hg.push_back(hp[q]);
+                start = hp[q];
+                e_start = he[q];
+            }
+        }
+        max_e = std::max(max_e, he[B] - e_start);
+        hg.push_back((int32_t)N);
+        GVQA_HIP_CHECK(hipMemcpyAsync(grp_dev, hg.data(), hg.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        GVQA_HIP_CHECK(hipStreamSynchronize(stream));     // hg is reused by the next call
+        g->row_group_ptr = grp_dev;
+        g->num_row_groups = (int32_t)hg.size() - 1;
+        g->max_row_group_edges = max_e;
+    }
     return GVQA_OK;
 }
 

@@ -48,6 +48,28 @@ __device__ __forceinline__ uint16_t split3_rn(float f) {
     return (uint16_t)(t >> 16);
 }
 
+// the three pieces of 8 consecutive k's of one row -> the lane's 16-byte slots of the three fragments at `o`
+__device__ __forceinline__ void split3_store(const float (&v)[8], uint16_t* o) {
+    uint16_t p[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        p[0][e] = split3_rn(v[e]);
+        const float r1 = v[e] - bf16_to_f32(p[0][e]);
+        p[1][e] = split3_rn(r1);
+        const float r2 = r1 - bf16_to_f32(p[1][e]);
+        p[2][e] = split3_rn(r2);            // exact: at most 8 significant bits are left
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        uint4 w;
+        w.x = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
+        w.y = (unsigned)p[q][2] | ((unsigned)p[q][3] << 16);
+        w.z = (unsigned)p[q][4] | ((unsigned)p[q][5] << 16);
+        w.w = (unsigned)p[q][6] | ((unsigned)p[q][7] << 16);
+        *reinterpret_cast<uint4*>(o + q * 512) = w;
+    }
+}
+
 // grid (ceil(KB / 4), RT); block 256 = 4 waves, wave w packs k block 4 blockIdx.x + w of row tile blockIdx.y
 __global__ __launch_bounds__(256) void k_split3_pack(int64_t rows, int K, int KB, const float* __restrict__ X, int64_t ld,
                                                      uint16_t* __restrict__ out, int vec) {
@@ -70,25 +92,7 @@ __global__ __launch_bounds__(256) void k_split3_pack(int64_t rows, int K, int KB
                 if (k0 + e < K) v[e] = src[e];
         }
     }
-    uint16_t p[3][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        p[0][e] = split3_rn(v[e]);
-        const float r1 = v[e] - bf16_to_f32(p[0][e]);
-        p[1][e] = split3_rn(r1);
-        const float r2 = r1 - bf16_to_f32(p[1][e]);
-        p[2][e] = split3_rn(r2);            // exact: at most 8 significant bits are left
-    }
-    uint16_t* o = out + ((rt * KB + kb) * 3) * 512 + lane * 8;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        uint4 w;
-        w.x = (unsigned)p[q][0] | ((unsigned)p[q][1] << 16);
-        w.y = (unsigned)p[q][2] | ((unsigned)p[q][3] << 16);
-        w.z = (unsigned)p[q][4] | ((unsigned)p[q][5] << 16);
-        w.w = (unsigned)p[q][6] | ((unsigned)p[q][7] << 16);
-        *reinterpret_cast<uint4*>(o + q * 512) = w;
-    }
+    split3_store(v, out + ((rt * KB + kb) * 3) * 512 + lane * 8);
 }
 
 // ILV: the DMAs of the step two ahead are issued one at a time between the six MFMA groups (their M0 set-up and
@@ -101,18 +105,19 @@ __device__ __forceinline__ void keep_live(const f32x16& v) {
 }
 // STAG > 0: blocks that share a CU (dispatch rounds of 256 blocks) start `stagger` x 8128 cycles apart, so that one
 // block's C stores fall under its neighbours' main loops instead of every CU storing at the same time.
-template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0>
+template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0>
 __global__ __launch_bounds__(64 * WM * WN, (160 * 1024 / (NBUF * (WM * TM + WN * TN) * 3072)) * WM * WN / 4)
 void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int rtA,
                                                                const uint16_t* __restrict__ Bpk, int rtB, LinearEpilogue ep,
-                                                               float* __restrict__ C, int64_t ldc, int stagger) {
+                                                               float* __restrict__ C, int64_t ldc, int stagger, FusedHopArgs fh) {
     constexpr int NW = WM * WN;
     constexpr int FA = WM * TM, FB = WN * TN;          // 32-row operand tiles per block: A rows, B rows (= C columns)
     constexpr int STAGE = (FA + FB) * 3072;            // bytes per K step: 3 pieces x 1 KiB per operand tile
     constexpr int TPW = (FA + FB) / NW;                // (tile, 3 pieces) triples each wave DMAs per K step
     static_assert((FA + FB) % NW == 0, "operand tiles must divide over the waves");
     static_assert(NBUF * STAGE <= 160 * 1024, "LDS ring exceeds 160 KiB");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF * STAGE];
+    static_assert(EPI != 2 || (WM == 2 && WN == 4 && TM == 4 && TN == 2), "the fused-hop epilogue is written for the 256 x 256 tile");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[EPI == 2 ? 160 * 1024 : NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,6 +167,65 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     const unsigned a_off = (unsigned)(wr * TM * 3072 + lane * 16);
     const unsigned b_off = (unsigned)((FA + wc * TN) * 3072 + lane * 16);
 
+    // ---- fused hop (EPI == 2): per-block constants, row-group metadata and the first group's CSR slice start their trips
+    // from HBM before the main loop (their latency hides under it); see the epilogue below ------------------------------
+    constexpr int Hh = FH > 0 ? FH : 1, cw = 256 / Hh, q4 = cw >> 2;
+    constexpr int lq = Hh == 1 ? 6 : Hh == 2 ? 5 : Hh == 4 ? 4 : 3;
+    static_assert(EPI != 2 || FH == 1 || FH == 2 || FH == 4 || FH == 8, "fused hop: H must be 1, 2, 4 or 8");
+    constexpr int NTH = 64 * NW;
+    // LDS of the epilogue: [0, 128 KiB) row image xs; [128, 160 KiB) the groups' regions [rowptr | csr_src | alpha] (RAW global
+    // values, rebased where they are used; every sub-array padded to whole 64-lane DMA instructions).  When a region fits
+    // 16 KiB, group 0's lives in [144, 160 KiB) -- outside the operand ring, so it is filled during the main loop -- and group
+    // 1's in [128, 144 KiB), filled while group 0 is aggregated; otherwise one region at 128 KiB is used twice.
+    const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63);
+    const int reg_words = al_off + ((fh.e_cap * Hh + 63) & ~63);
+    const bool two_regions = EPI == 2 && 2 * reg_words * 4 <= 32 * 1024;
+    const int c4 = tid & (q4 - 1);
+    const int c = bn * cw + c4 * 4;                           // this thread's 4 output channels
+    const bool c_ok = EPI == 2 && c < fh.C;
+    float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bi;
+    int g_ns[2] = {0, 0}, g_cnt[2] = {0, 0}, g_e0[2] = {0, 0}, g_ne[2] = {0, 0};
+    // CSR slice + coefficients of a group -> LDS bytes [byte_base, ...) by LDS-DMA (4 bytes per lane: no alignment constraints);
+    // every wave issues the same number of DMAs (lanes past the end re-load the last word into the padding)
+    auto dma_region = [&](int gi, unsigned byte_base) {
+        const unsigned base = lds_base + byte_base;
+        const int n_rp = g_cnt[gi] + 1, n_src = g_ne[gi], n_al = g_ne[gi] * Hh;
+        const int32_t* rp_g = fh.rowptr + g_ns[gi];
+        const int32_t* src_g = fh.csr_src + g_e0[gi];
+        const float* al_g = fh.alpha_csr + (int64_t)g_e0[gi] * Hh;
+        const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+        for (int u = wbase; u < n_rp; u += NTH)
+            lds_dma4_b(rp_g + min(u + lane, n_rp - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)u * 4u));
+        for (int u = wbase; u < n_src; u += NTH)
+            lds_dma4_b(src_g + min(u + lane, n_src - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(src_off + u) * 4u));
+        for (int u = wbase; u < n_al; u += NTH)
+            lds_dma4_b(al_g + min(u + lane, n_al - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(al_off + u) * 4u));
+    };
+    if constexpr (EPI == 2) {
+        if (c_ok) {
+            if (fh.bias) bi = *reinterpret_cast<const float4*>(fh.bias + c);
+            if (fh.bn_w) {          // torch's eval BatchNorm: y = x (w invstd) + (b - mean w invstd)
+                const float4 w4 = *reinterpret_cast<const float4*>(fh.bn_w + c), b4 = *reinterpret_cast<const float4*>(fh.bn_b + c);
+                const float4 m4 = *reinterpret_cast<const float4*>(fh.bn_m + c), v4 = *reinterpret_cast<const float4*>(fh.bn_v + c);
+                sc.x = w4.x * (1.0f / sqrtf(v4.x + fh.bn_eps)); sc.y = w4.y * (1.0f / sqrtf(v4.y + fh.bn_eps));
+                sc.z = w4.z * (1.0f / sqrtf(v4.z + fh.bn_eps)); sc.w = w4.w * (1.0f / sqrtf(v4.w + fh.bn_eps));
+                sh.x = b4.x - m4.x * sc.x; sh.y = b4.y - m4.y * sc.y; sh.z = b4.z - m4.z * sc.z; sh.w = b4.w - m4.w * sc.w;
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int grp = bm * 2 + gi;
+            if (grp < fh.num_groups) {                        // block-uniform
+                g_ns[gi] = fh.group_ptr[grp];
+                g_cnt[gi] = fh.group_ptr[grp + 1] - g_ns[gi];
+                g_e0[gi] = fh.rowptr[g_ns[gi]];
+                g_ne[gi] = fh.rowptr[g_ns[gi] + g_cnt[gi]] - g_e0[gi];
+            }
+        }
+        // older than every ring DMA: the counted waits of the main loop only get stricter by them, never wrong
+        if (two_regions && g_cnt[0] > 0 && !(fh.debug & 8)) dma_region(0, 144 * 1024);
+    }
+
     // prologue: NBUF - 1 steps in flight
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
@@ -208,6 +272,161 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) keep_live(acc[i][j]);
+        return;
+    }
+    if constexpr (EPI == 2) {
+        // ---- fused GAT aggregation (gat_skip.py:155-168,270-275 on the projected tile) --------------------------
+        // The block's 256 rows are two row groups of <= 128 consecutive nodes that end on graph boundaries, its 256
+        // columns are the channels [bn cw, bn cw + cw) of ALL H heads (weights packed head-interleaved), so every
+        // neighbour row a node of these groups needs is in this tile.  Per group: the four waves that own its rows
+        // put their accumulators into LDS (xs[row][256], 16-byte chunk c at slot c ^ (row & 7)), the group's CSR slice and
+        // attention coefficients are brought in beside it, then all 512 threads do
+        //     out[i, c] = (1/H) sum_h sum_{e: dst = i} alpha[e, h] xs[src_e][h cw + c]  (+ graph term) + bias + skip -> BN -> ReLU
+        // and store `out`.  xp never reaches HBM.
+        if (fh.debug & 8) return;
+        float* xs = reinterpret_cast<float*>(smem);
+        const float inv_h = 1.0f / Hh;
+        const bool relu = fh.bn_w != nullptr;
+        __syncthreads();                                      // main loop done: operand ring free
+        if (two_regions) { if (g_cnt[1] > 0) dma_region(1, 128 * 1024); }
+        else if (g_cnt[0] > 0) dma_region(0, 128 * 1024);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int ns = g_ns[gi], cnt = g_cnt[gi], e0 = g_e0[gi];
+            const bool live = cnt > 0;                        // block-uniform
+            const unsigned region_base = (two_regions && gi == 0) ? 144 * 1024 : 128 * 1024;
+            if (gi == 1) {
+                __syncthreads();                              // group 0's image and (single) region are free
+                if (!two_regions && live) dma_region(1, 128 * 1024);
+            }
+            // epilogue operands of this thread's rows (skip rows, graph ids) start their trip from HBM now, ahead of the LDS work
+            constexpr int MAXIT = 4;
+            const int items = (128 << lq) / NTH;              // rows per thread: 128 q4 / 512
+            float4 sk[MAXIT];
+            int gid[MAXIT];
+            const bool pre = items <= MAXIT;
+            if (pre && live && c_ok) {
+#pragma unroll
+                for (int k = 0; k < MAXIT; ++k) {
+                    const int i = (tid >> lq) + k * (NTH >> lq);
+                    const bool on = k < items && i < cnt;
+                    const int node = ns + (on ? i : 0);
+                    gid[k] = fh.graph_term ? fh.node_graph[node] : 0;
+                    sk[k] = fh.skip ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (live && wr == gi && !(fh.debug & 1)) {
+                const int m = lane & 31, hh = lane >> 5;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = i * 32 + m;
+                            const int chunk = wc * 16 + j * 8 + 2 * q + hh;
+                            *reinterpret_cast<float4*>(xs + r * 256 + ((chunk ^ (r & 7)) << 2)) =
+                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                        }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs (and prefetches) have landed
+            __syncthreads();
+            if (live) {
+                const int* rp_l = reinterpret_cast<const int*>(smem + region_base);
+                const int* src_l = rp_l + src_off;
+                const float* al_l = reinterpret_cast<const float*>(rp_l + al_off);
+                const float4* xs4 = reinterpret_cast<const float4*>(xs);
+                // one output row segment: node i of the group, channels [c, c + 4)
+                auto process = [&](int i_raw, bool have, int gq_pre, float4 sk_pre) {
+                    const bool row_on = i_raw < cnt;
+                    const int i = row_on ? i_raw : 0;
+                    const int lo = rp_l[i] - e0, hi = (row_on && !(fh.debug & 2)) ? rp_l[i + 1] - e0 : lo;
+                    const int node = ns + i;
+                    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (fh.graph_term && hi > lo && c_ok) {   // nodes without in-edges get no instruction term (empty softmax)
+                        const int gq = have ? gq_pre : fh.node_graph[node];
+                        pb = *reinterpret_cast<const float4*>(fh.graph_term + (int64_t)gq * fh.t_ld + c);
+                    }
+                    // EB edges per trip, every LDS read of a trip issued before its FMAs; the trip count is made wave-uniform
+                    // (clamped index, zero weight past the end of the row): a divergent, dependent-load loop was 4x slower
+                    constexpr int EB = Hh <= 2 ? 4 : Hh == 4 ? 2 : 1;      // 8 row reads (32 VGPRs) in flight per trip
+                    // the wave covers 64 / q4 consecutive rows: largest in-degree among them from wave-uniform LDS reads
+                    const int row0 = __builtin_amdgcn_readfirstlane(i_raw - (lane >> lq));
+                    int maxdeg = 0;
+#pragma unroll
+                    for (int r = 0; r < (64 >> lq); ++r) {
+                        const int rr = min(row0 + r, cnt - 1);
+                        maxdeg = max(maxdeg, rp_l[rr + 1] - rp_l[rr]);
+                    }
+                    const int trips = (fh.debug & 2) ? 0 : __builtin_amdgcn_readfirstlane((maxdeg + EB - 1) / EB);
+                    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 b4 = a4;                            // second chain: the FMAs of edge slot 1 do not wait for slot 0's
+                    for (int tr = 0; tr < trips; ++tr) {
+                        const int s0 = lo + tr * EB;
+                        int se[EB];
+                        float al[EB][Hh];
+#pragma unroll
+                        for (int e = 0; e < EB; ++e) {
+                            // unconditional reads at a clamped (always mapped) slot, selected afterwards: no branch in the loop
+                            const bool on = s0 + e < hi;
+                            const int idx = max(min(s0 + e, hi - 1), 0);
+                            const int raw = src_l[idx];
+                            se[e] = on ? raw - ns : 0;
+                            if constexpr (Hh % 4 == 0) {
+#pragma unroll
+                                for (int h4 = 0; h4 < Hh / 4; ++h4) {
+                                    const float4 t4 = *reinterpret_cast<const float4*>(al_l + idx * Hh + h4 * 4);
+                                    al[e][h4 * 4] = on ? t4.x : 0.f; al[e][h4 * 4 + 1] = on ? t4.y : 0.f;
+                                    al[e][h4 * 4 + 2] = on ? t4.z : 0.f; al[e][h4 * 4 + 3] = on ? t4.w : 0.f;
+                                }
+                            } else {
+#pragma unroll
+                                for (int h = 0; h < Hh; ++h) {
+                                    const float t1 = al_l[idx * Hh + h];
+                                    al[e][h] = on ? t1 : 0.f;
+                                }
+                            }
+                        }
+                        float4 v[EB][Hh];
+#pragma unroll
+                        for (int e = 0; e < EB; ++e)
+#pragma unroll
+                            for (int h = 0; h < Hh; ++h) v[e][h] = xs4[se[e] * 64 + (((h << lq) + c4) ^ (se[e] & 7))];
+#pragma unroll
+                        for (int e = 0; e < EB; ++e)
+#pragma unroll
+                            for (int h = 0; h < Hh; ++h) {
+                                float4& t = (e & 1) ? b4 : a4;
+                                t.x += al[e][h] * v[e][h].x; t.y += al[e][h] * v[e][h].y;
+                                t.z += al[e][h] * v[e][h].z; t.w += al[e][h] * v[e][h].w;
+                            }
+                    }
+                    a4.x += b4.x; a4.y += b4.y; a4.z += b4.z; a4.w += b4.w;
+                    float4 r = make_float4(a4.x * inv_h + pb.x, a4.y * inv_h + pb.y, a4.z * inv_h + pb.z, a4.w * inv_h + pb.w);
+                    r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
+                    if (fh.skip && c_ok) {
+                        const float4 s4 = have ? sk_pre : *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c);
+                        r.x += s4.x; r.y += s4.y; r.z += s4.z; r.w += s4.w;
+                    }
+                    if (relu) {
+                        r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
+                        r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
+                    }
+                    if (row_on && c_ok && !(fh.debug & 4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c) = r;
+                };
+                // (whole waves enter `process`: its trip count is a wave-wide maximum; rows past the group's end are masked inside)
+                if (pre) {
+#pragma unroll
+                    for (int k = 0; k < MAXIT; ++k) {          // static indices: the prefetched operands stay in registers
+                        const int i = (tid >> lq) + k * (NTH >> lq);
+                        if (k < items && __builtin_amdgcn_readfirstlane(i - (lane >> lq)) < cnt) process(i, true, gid[k], sk[k]);
+                    }
+                } else {
+                    for (int idx0 = __builtin_amdgcn_readfirstlane(tid & ~63); idx0 < (cnt << lq); idx0 += NTH)
+                        process((idx0 + lane) >> lq, false, 0, make_float4(0.f, 0.f, 0.f, 0.f));
+                }
+            }
+        }
         return;
     }
     auto finish = [&](float4 v, int gr, int gc) {      // bias / addend / mul / activation on 4 consecutive columns, then the store
@@ -348,7 +567,7 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
             hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_>), grid,       \
                                dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C + m0 * ldc, ldc, \
-                               stag_scale > 0 ? stag * stag_scale / 4 : stag);                                           \
+                               stag_scale > 0 ? stag * stag_scale / 4 : stag, FusedHopArgs{});                           \
         } while (0)
         switch (variant) {
             case 10: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, false, false, false, 0, 0); break;
@@ -371,6 +590,122 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
         }
 #undef GVQA_S3_LAUNCH
     }
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// ---- operands of the fused hop ----------------------------------------------------------------------------------
+// A: node rows gathered into row groups -- slot s = 128 r + i holds node group_ptr[r] + i (zeros past the group's end).
+// grid (ceil(KB / 4), 4 G): blockIdx.y = row tile (4 per group)
+__global__ __launch_bounds__(256) void k_split3_pack_groups(const int32_t* __restrict__ group_ptr, int K, int KB,
+                                                            const float* __restrict__ X, int64_t ld, uint16_t* __restrict__ out, int vec) {
+    const int lane = threadIdx.x & 63, kb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (kb >= KB) return;
+    const int64_t rt = blockIdx.y;
+    const int grp = (int)(rt >> 2), i = (int)(rt & 3) * 32 + (lane & 31);
+    const int ns = group_ptr[grp], cnt = group_ptr[grp + 1] - ns;
+    const int k0 = kb * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (i < cnt) {
+        const float* src = X + (int64_t)(ns + i) * ld + k0;
+        if (vec && k0 + 8 <= K) {
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k0 + e < K) v[e] = src[e];
+        }
+    }
+    split3_store(v, out + ((rt * KB + kb) * 3) * 512 + lane * 8);
+}
+
+// B: weight rows head-interleaved -- packed row 256 cb + h cw + cc holds W[h C + cb cw + cc, :] (zeros for channels >= C),
+// so that column block cb of the product carries channels [cb cw, cb cw + cw) of every head.  grid (ceil(KB / 4), 8 ncb)
+__global__ __launch_bounds__(256) void k_split3_pack_heads(int H, int C, int cw, int K, int KB, const float* __restrict__ W,
+                                                           int64_t ldw, uint16_t* __restrict__ out, int vec) {
+    const int lane = threadIdx.x & 63, kb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (kb >= KB) return;
+    const int64_t rt = blockIdx.y;
+    const int r = (int)(rt * 32) + (lane & 31);
+    const int cb = r >> 8, within = r & 255, h = within / cw, ch = cb * cw + (within - h * cw);
+    const int k0 = kb * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (ch < C) {
+        const float* src = W + (int64_t)(h * C + ch) * ldw + k0;
+        if (vec && k0 + 8 <= K) {
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k0 + e < K) v[e] = src[e];
+        }
+    }
+    split3_store(v, out + ((rt * KB + kb) * 3) * 512 + lane * 8);
+}
+
+size_t split3_packed_rows_bytes(int64_t row_tiles, int64_t K) { return (size_t)row_tiles * (size_t)cdiv(K, 16) * 3072; }
+
+int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
+                              hipStream_t stream) {
+    GVQA_REQUIRE(num_groups >= 0 && K > 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split3_pack_groups: bad size");
+    if (num_groups == 0) return GVQA_OK;
+    GVQA_REQUIRE(group_ptr && X && packed, GVQA_E_INVALID, "split3_pack_groups: null operand");
+    const int KB = (int)cdiv(K, 16);
+    const int vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
+    const int64_t RT = (int64_t)num_groups * 4;
+    for (int64_t r0 = 0; r0 < RT; r0 += 65532) {       // grid.y limit, whole groups per launch
+        const int64_t n = std::min<int64_t>(65532, RT - r0);
+        hipLaunchKernelGGL(k_split3_pack_groups, dim3((unsigned)cdiv(KB, 4), (unsigned)n), dim3(256), 0, stream, group_ptr + r0 / 4,
+                           (int)K, KB, X, ld, static_cast<uint16_t*>(packed) + r0 * KB * 1536, vec);
+    }
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int launch_split3_pack_heads(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream) {
+    GVQA_REQUIRE(H > 0 && C > 0 && cw > 0 && H * cw == 256 && K > 0 && ldw >= K, GVQA_E_INVALID, "split3_pack_heads: bad size");
+    GVQA_REQUIRE(W && packed, GVQA_E_INVALID, "split3_pack_heads: null operand");
+    const int KB = (int)cdiv(K, 16), ncb = (int)cdiv(C, cw);
+    const int vec = (reinterpret_cast<uintptr_t>(W) & 15) == 0 && ldw % 4 == 0;
+    hipLaunchKernelGGL(k_split3_pack_heads, dim3((unsigned)cdiv(KB, 4), (unsigned)(ncb * 8)), dim3(256), 0, stream, H, C, cw, (int)K, KB, W,
+                       ldw, static_cast<uint16_t*>(packed), vec);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// edges of one row group the fused epilogue can hold in LDS beside the 128 KiB row image
+size_t hop_fused_lds_edge_capacity(int H) { return (size_t)(8192 - 192 - 128) / (size_t)(H + 1); }      // 32 KiB of words, padded sub-arrays
+
+int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream) {
+    GVQA_REQUIRE(Apk && Bpk && f.out && f.group_ptr && f.rowptr && f.csr_src && f.alpha_csr && f.node_graph, GVQA_E_INVALID,
+                 "hop_fused: null operand");
+    GVQA_REQUIRE(f.H * f.cw == 256 && f.C % 4 == 0 && f.cw % 4 == 0 && (f.cw & (f.cw - 1)) == 0, GVQA_E_UNSUPPORTED,
+                 "hop_fused: needs H in {1,2,4,8} and C %% 4 == 0");
+    GVQA_REQUIRE((size_t)f.e_cap <= hop_fused_lds_edge_capacity(f.H), GVQA_E_UNSUPPORTED, "hop_fused: row group has too many edges for LDS");
+    if (f.num_groups == 0) return GVQA_OK;
+    const int KB = (int)cdiv(K, 16), ncb = (int)cdiv(f.C, f.cw);
+    const int rtA = f.num_groups * 4, rtB = ncb * 8;
+    GVQA_REQUIRE(cdiv(f.num_groups, 2) <= 65535, GVQA_E_UNSUPPORTED, "hop_fused: too many row groups for one launch");
+    dim3 grid((unsigned)ncb, (unsigned)cdiv(f.num_groups, 2));
+    FusedHopArgs f2 = f;
+    if (const char* dbg = getenv("GVQA_FUSED_DEBUG")) f2.debug = atoi(dbg);
+#define GVQA_FUSED_LAUNCH(H_)                                                                                                   \
+    hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, 3, true, false, false, 0, 2, H_>), grid, dim3(512), 0, stream, f.num_groups * 128,  \
+                       ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), rtB, LinearEpilogue{},  \
+                       nullptr, (int64_t)0, 0, f2)
+    switch (f.H) {
+        case 1: GVQA_FUSED_LAUNCH(1); break;
+        case 2: GVQA_FUSED_LAUNCH(2); break;
+        case 4: GVQA_FUSED_LAUNCH(4); break;
+        default: GVQA_FUSED_LAUNCH(8); break;
+    }
+#undef GVQA_FUSED_LAUNCH
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -74,6 +74,12 @@ typedef struct gvqa_graph {
     int32_t intra_graph;        /* 1 iff every edge has batch[src] == batch[dst]               */
     int32_t valid;              /* 1 iff indices in range and batch non-decreasing in [0,B)    */
     int32_t finalized;
+    /* Row groups for the fused hop kernel (valid after finalize): the node range cut, in order, into groups of at most
+     * 128 consecutive nodes that end on graph boundaries (group r = nodes row_group_ptr[r] .. row_group_ptr[r+1]).
+     * num_row_groups == 0: not applicable (a graph with more than 128 nodes, edges across graphs, empty batch). */
+    const int32_t* row_group_ptr;   /* [num_row_groups + 1], device                                */
+    int32_t num_row_groups;
+    int32_t max_row_group_edges;    /* most in-edges of any row group                              */
 } gvqa_graph;
 
 size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
@@ -221,7 +227,10 @@ enum gvqa_option {
     GVQA_OPT_VENDOR_GEMM = 1,      /* 1: plain fp32 products >= 2 GFLOP go to rocBLAS (comparison only; default 0) */
     GVQA_OPT_SPLIT3_MIN_MFLOP = 2, /* products below this many MFLOP stay on the f32-input MFMA kernels (default 1000) */
     GVQA_OPT_SPLIT3_VARIANT = 3,   /* 0 = choose by shape; otherwise an exact k_linear_split3 instantiation (tuning / tests) */
-    GVQA_NUM_OPTIONS = 4
+    GVQA_OPT_HOP_FUSION = 4,       /* 1 (default): gat_seq hops run projection + aggregation as ONE kernel when the batch allows it
+                                      (split3 projection, graphs <= 128 nodes, H in {1,2,4,8}); 0: projection, then the
+                                      message-passing kernel (xp through HBM) */
+    GVQA_NUM_OPTIONS = 5
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate (default) */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */
@@ -498,7 +507,8 @@ enum {
     GVQA_STAGE_MP = 6,         /* fused GAT message passing                    */
     GVQA_STAGE_OTHER = 7,
     GVQA_STAGE_PACK = 8,       /* split3 operand packing (pieces of h, of the weights) */
-    GVQA_NUM_STAGES = 9
+    GVQA_STAGE_ALPHA = 9,      /* attention coefficients as a kernel of their own (fused-hop path) */
+    GVQA_NUM_STAGES = 10
 };
 int gvqa_prof_enable(int on);
 /* Waits for outstanding events, ADDS elapsed milliseconds / launch counts per stage into the

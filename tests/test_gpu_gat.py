@@ -322,14 +322,17 @@ def test_large_single_graph_uses_general_kernel(dev):
     assert maxabs(out, ref) < TOL
 
 
-@pytest.fixture(params=["split3", "f32"])
+@pytest.fixture(params=["fused", "split3+mp", "f32+mp"])
 def projection_mode(request):
-    """Both arithmetics of the hop projection (GVQA_OPT_PROJECTION): the default three-piece bf16 split on the bf16
-    matrix cores, and the f32-input MFMA kernels (k_linear_f32_dma / k_linear_f32)."""
+    """The three ways a hop runs (GVQA_OPT_HOP_FUSION / GVQA_OPT_PROJECTION): projection + aggregation as ONE kernel on the
+    split3 arithmetic (default), split3 projection followed by the message-passing kernel, f32-input MFMA projection
+    (k_linear_f32_dma / k_linear_f32) followed by the message-passing kernel."""
     from graphvqa_amd import _lib
-    old = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_SPLIT3 if request.param == "split3" else _lib.PROJECTION_F32)
+    old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32 if request.param == "f32+mp" else _lib.PROJECTION_SPLIT3)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1 if request.param == "fused" else 0)
     yield request.param
-    _lib.set_option(_lib.OPT_PROJECTION, old)
+    _lib.set_option(_lib.OPT_PROJECTION, old_p)
+    _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
 
 
 def test_config2_shape_vs_oracle(dev, projection_mode):
@@ -362,7 +365,7 @@ def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode)
     ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), return_all=True)
     g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
     plan = _lib.MpPlan()
-    for parts in ("1", None):                 # bench geometry (one block per graph), then the small-batch split
+    for parts in ("1", None) if projection_mode != "fused" else (None,):   # one block per graph, then the small-batch split
         if parts:
             os.environ["GVQA_MP_PARTS"] = parts
         try:
@@ -373,8 +376,67 @@ def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode)
             os.environ.pop("GVQA_MP_PARTS", None)
         assert plan.tiled == 1 and plan.channel_range == 128 and plan.accumulators == 2 and plan.stages_per_graph == 20
         assert plan.blocks_per_graph == (1 if parts else 4)
+        assert (g.c.num_row_groups, g.c.max_row_group_edges) == (16, 512)        # 4 graphs of 32 nodes / 128 edges per row group
         assert maxabs(out, ref) < TOL
         assert maxabs(alpha[4], alphas[4]) < 2e-5
+
+
+@pytest.mark.parametrize("H,C,de,di,lo,hi", [(4, 64, 24, 16, 1, 40), (4, 300, 20, 12, 20, 40), (1, 32, 8, 8, 1, 128), (2, 136, 16, 0, 60, 128),
+                                             (8, 48, 12, 20, 5, 70)])
+def test_fused_hop_kernel_on_ragged_batches(dev, H, C, de, di, lo, hi):
+    """The fused hop (projection + aggregation in one kernel, csrc/split3.hip EPI 2) forced onto small ragged batches:
+    row groups that are not full, graphs of 1 and of exactly 128 nodes, channel counts that do not fill the last column
+    block, every supported head count, train-mode BatchNorm -- against the oracle and against the unfused kernels."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    K = 3
+    gb = synth.make_graph_batch(23, seed=1000 + H * 7 + C, nodes_lo=lo, nodes_hi=hi, rel_per_node=1.6)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=300 + H)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    ref, hs, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        assert _lib.load().gvqa_get_option(_lib.OPT_HOP_FUSION) == 1
+        _lib.prof_enable(True); _lib.prof_collect()
+        out, alpha, hops = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch,
+                                        return_attention_weights=True, return_hops=True)
+        prof = _lib.prof_collect(); _lib.prof_enable(False)
+        assert prof["alpha"][1] == K and prof["mp"][1] == 0            # the fused path ran: no message-passing launches
+        _lib.set_option(_lib.OPT_HOP_FUSION, 0)
+        out_u = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
+        _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+        m = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), p, dev).train()      # batch-statistics BatchNorm
+        out_t = m(*[t(a, device=dev) for a in (x, gb.edge_index, ea, ins, gb.batch)])
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+        _lib.prof_enable(False)
+    assert maxabs(out, ref) < TOL and maxabs(hops, torch.stack(hs)) < TOL and maxabs(alpha, torch.stack(alphas)) < 2e-5
+    assert maxabs(out, out_u) < 2e-5
+    ref_t = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, training_bn=True)
+    assert maxabs(out_t, ref_t) < TOL
+
+
+def test_fused_hop_falls_back_when_a_graph_exceeds_a_row_group(dev):
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch
+    H, C, de, di, K = 4, 32, 8, 8, 2
+    gb = synth.make_graph_batch(3, seed=77, nodes_lo=100, nodes_hi=160, rel_per_node=1.0)
+    assert gb.batch.shape[0] > 0 and np.bincount(gb.batch).max() > 128
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
+    assert g.c.num_row_groups == 0
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=5)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        out = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    assert maxabs(out, R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H)) < TOL
 
 
 def test_config3_full_size_properties(dev):
