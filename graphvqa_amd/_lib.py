@@ -140,6 +140,7 @@ PROTOTYPES = {
     "gvqa_graph_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.POINTER(Graph)]),
     "gvqa_graph_finalize": (C.c_int, [C.POINTER(Graph), C.c_void_p]),
+    "gvqa_graph_finalize_host": (C.c_int, [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gvqa_gat_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(GatDims)]),
     "gvqa_gat_conv_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -148,6 +149,13 @@ PROTOTYPES = {
     "gvqa_gat_seq_forward": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_gat_seq_weight_cache_bytes": (C.c_size_t, [C.POINTER(GatDims), C.c_int32]),
+    "gvqa_gat_seq_weight_layout": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims)]),
+    "gvqa_gat_seq_prepare_weights": (C.c_int, [C.POINTER(GatDims), C.POINTER(GatConvParams), C.c_int32, C.c_void_p, C.c_size_t,
+                                               C.c_void_p]),
+    "gvqa_gat_seq_forward_cached": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_gat_seq_forward_trainbn": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -126,8 +126,10 @@ struct FusedHopArgs {
     int debug;                  // measurement aid (GVQA_FUSED_DEBUG bit mask): 1 no row image, 2 no aggregation, 4 no store, 8 no epilogue at all
 };
 size_t split3_packed_rows_bytes(int64_t row_tiles, int64_t K);
+// Vn / J / a_node: NULL / 0 / NULL, or the folded attention vectors [J = 2 H, K]: a_node[N, J] = X . Vn^T is produced on the way
+bool split3_pack_groups_logits_supported(int J, int64_t K);
 int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
-                              hipStream_t stream);
+                              const float* Vn, int J, float* a_node, hipStream_t stream);
 int launch_split3_pack_heads(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
 size_t hop_fused_lds_edge_capacity(int H);

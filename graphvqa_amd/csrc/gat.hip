@@ -501,6 +501,15 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     }
 }
 
+// attention coefficients of every edge in CSR slot order -> a.alpha_csr (and a.alpha_out in COO order)
+// (one thread per (node, head); a one-thread-per-node variant with all heads in registers and 16-byte accesses measured
+// SLOWER at config 3 -- 31 vs 25 us: a quarter of the threads, and the kernel is bound by its chain of dependent loads)
+static int launch_alpha(const MpArgs& a, int H, hipStream_t stream) {
+    hipLaunchKernelGGL(k_gat_alpha_general, dim3((unsigned)cdiv((int64_t)a.N * H, 256)), dim3(256), 0, stream, a, H);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
 __global__ __launch_bounds__(256) void k_gat_aggregate_general(MpArgs a, int H) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
@@ -724,6 +733,27 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
            (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H);
 }
 
+// ---- weight cache: everything a forward derives from the PARAMETERS alone (folded attention vectors Vn / Ve, per-graph
+// term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
+// not change.  layout: -1 no packed projection weights, 0 plain row order (k_linear_split3), 1 head-interleaved (fused hop).
+struct WeightCacheLayout {
+    size_t Vn, Ve, Gw, w6, w6_hop, total;
+};
+static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout) {
+    WeightCacheLayout W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
+    const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
+    W.Vn = take(K * 2 * H * d->node_dim * sizeof(float));
+    W.Ve = take(K * H * d->edge_dim * sizeof(float));
+    W.Gw = take(K * (C + H) * (size_t)d->ins_dim * sizeof(float));
+    W.w6_hop = layout == 1 ? split3_packed_rows_bytes(cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
+             : layout == 0 ? split3_packed_bytes((int64_t)(H * C), d->node_dim) : 0;
+    W.w6 = take(K * W.w6_hop);
+    W.total = off;
+    return W;
+}
+
 struct SeqLayout {
     size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, total;
 };
@@ -737,28 +767,23 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
         return r;
     };
     const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
-    L.Vn = take(K * 2 * H * d->node_dim);
-    L.Ve = take(K * H * d->edge_dim);
-    L.Gw = take(K * (C + H) * (size_t)d->ins_dim);
+    const bool fused = g && hop_fusion_applies(g, d);
+    const int w_layout = fused ? 1 : proj_use_split3(N, (int64_t)(H * C), d->node_dim) ? 0 : -1;
+    L.Vn = take(weight_cache_layout(d, w_layout).total / sizeof(float));     // Vn | Ve | Gw | packed projection weights
+    L.Ve = L.Gw = L.Vn;
     L.T = take(K * B * align_up(C + H, 4));
     L.a_edge = take((size_t)E * K * H);
     L.a_node = take((size_t)N * 2 * H);
-    const bool fused = g && hop_fusion_applies(g, d);
     L.xp = take(fused ? 0 : (size_t)N * H * C);                // the fused hop never materialises xp
     L.h0 = take((size_t)N * C);
     L.h1 = take((size_t)N * C);
     L.alpha_csr = take((size_t)E * H);
     L.bn_partial = take(gvqa_bn_train_workspace_bytes(N > 0 ? N : 1, C) / sizeof(float) + 1);
     L.bn_stats = take(2 * C);
-    if (fused) {     // row-group slots / head-interleaved weight rows
-        L.a6 = take(split3_packed_rows_bytes((int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float));
-        L.w6 = take(K * split3_packed_rows_bytes(cdiv((int64_t)C, 256 / H) * 8, d->node_dim) / sizeof(float));
-    } else if (proj_use_split3(N, (int64_t)(H * C), d->node_dim)) {     // packed three-piece operands (split3.hip)
-        L.a6 = take(split3_packed_bytes(N, d->node_dim) / sizeof(float));
-        L.w6 = take(K * split3_packed_bytes((int64_t)(H * C), d->node_dim) / sizeof(float));
-    } else {
-        L.a6 = L.w6 = off;
-    }
+    if (fused) L.a6 = take(split3_packed_rows_bytes((int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float));   // row-group slots
+    else if (w_layout == 0) L.a6 = take(split3_packed_bytes(N, d->node_dim) / sizeof(float));
+    else L.a6 = off;
+    L.w6 = L.Vn;
     L.total = off;
     return L;
 }
@@ -899,11 +924,14 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
     auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     const int H = d->heads, C = d->out_channels;
 
-    rc = run_fold(d, p, P(L.Vn), P(L.Ve), nullptr, stream);
+    const WeightCacheLayout WL = weight_cache_layout(d, proj_use_split3(N, (int64_t)d->heads * d->out_channels, d->node_dim) ? 0 : -1);
+    float* Vn1 = reinterpret_cast<float*>(base + L.Vn + WL.Vn);
+    float* Ve1 = reinterpret_cast<float*>(base + L.Vn + WL.Ve);
+    rc = run_fold(d, p, Vn1, Ve1, nullptr, stream);
     if (rc) return rc;
     {   // a_e = edge_attr . V_e^T                       (gat_skip.py:150-151, folded)
         StageTimer t(GVQA_STAGE_EDGE_LOGIT, stream);
-        rc = launch_linear(E, H, d->edge_dim, edge_attr, d->edge_dim, P(L.Ve), d->edge_dim, nullptr, 0, P(L.a_edge), H, 1,
+        rc = launch_linear(E, H, d->edge_dim, edge_attr, d->edge_dim, Ve1, d->edge_dim, nullptr, 0, P(L.a_edge), H, 1,
                            0, 0, 0, stream);
         if (rc) return rc;
     }
@@ -915,7 +943,7 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
     }
     {   // (a_l | a_r) = x . [V_l | V_r]                 (gat_skip.py:134-135, folded)
         StageTimer t(GVQA_STAGE_NODE_LOGIT, stream);
-        rc = launch_linear(N, 2 * H, d->node_dim, x, d->node_dim, P(L.Vn), d->node_dim, nullptr, 0, P(L.a_node), 2 * H, 1,
+        rc = launch_linear(N, 2 * H, d->node_dim, x, d->node_dim, Vn1, d->node_dim, nullptr, 0, P(L.a_node), 2 * H, 1,
                            0, 0, 0, stream);
         if (rc) return rc;
     }
@@ -925,9 +953,29 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
     return launch_gat_mp(g, &m, P(L.alpha_csr), (size_t)E * H * sizeof(float), stream);
 }
 
+static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int layout, char* cache, hipStream_t fold_stream,
+                           hipStream_t stream) {
+    const WeightCacheLayout W = weight_cache_layout(d, layout);
+    const int H = d->heads, C = d->out_channels, K = d->num_hops, Dn = d->node_dim, Di = d->ins_dim;
+    int rc = run_fold(d, hops, reinterpret_cast<float*>(cache + W.Vn), reinterpret_cast<float*>(cache + W.Ve),
+                      Di > 0 ? reinterpret_cast<float*>(cache + W.Gw) : nullptr, fold_stream);
+    if (rc) return rc;
+    if (layout >= 0) {     // node-column weights of all hops -> packed pieces
+        StageTimer t(GVQA_STAGE_PACK, stream);
+        for (int i = 0; i < K; ++i) {
+            GVQA_REQUIRE(hops[i].lin_l_weight, GVQA_E_INVALID, "gat: hop %d has a null weight", i);
+            rc = layout == 1 ? launch_split3_pack_heads(H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
+                             : launch_split3_pack((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream);
+            if (rc) return rc;
+        }
+    }
+    return GVQA_OK;
+}
+
 static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
                                 const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
-                                float* bn_stats_out, void* ws, size_t ws_bytes, void* stream_) {
+                                float* bn_stats_out, void* ws, size_t ws_bytes, void* stream_, const void* wcache = nullptr,
+                                size_t wcache_bytes = 0, int wcache_layout = -2) {
     GVQA_REQUIRE(g && hops, GVQA_E_INVALID, "gat_seq: null argument");
     int rc = check_dims(d, true);
     if (rc) return rc;
@@ -952,34 +1000,41 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     SideStream* ss = side_stream();
     hipStream_t aux = ss ? ss->stream : stream;
     if (ss) { rc = side_fork(ss, stream); if (rc) return rc; }
-    rc = run_fold(d, hops, P(L.Vn), P(L.Ve), Di > 0 ? P(L.Gw) : nullptr, aux);
-    if (rc) return rc;
+    const bool split = proj_use_split3(N, (int64_t)H * C, Dn);
+    const bool fused = hop_fusion_applies(g, d);
+    const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
+    const int need_layout = fused ? 1 : split ? 0 : -1;
+    // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
+    // now into the workspace (the workspace slices have exactly the cache's sub-layout)
+    const WeightCacheLayout WL = weight_cache_layout(d, need_layout);
+    const bool cached = wcache && wcache_layout == need_layout && wcache_bytes >= WL.total;
+    const char* wbase;
+    if (cached) {
+        wbase = static_cast<const char*>(wcache);
+    } else {
+        char* wtmp = base + L.Vn;                              // Vn | Ve | Gw | w6 are carved contiguously below
+        rc = prepare_weights(d, hops, need_layout, wtmp, aux, stream);
+        if (rc) return rc;
+        wbase = wtmp;
+    }
+    const float* Vn_all = reinterpret_cast<const float*>(wbase + WL.Vn);
+    const float* Ve_all = reinterpret_cast<const float*>(wbase + WL.Ve);
+    const float* Gw_all = reinterpret_cast<const float*>(wbase + WL.Gw);
+    const char* w6 = wbase + WL.w6;
+    const size_t w6_hop = WL.w6_hop;
     {   // edge logit terms of ALL hops in one pass over edge_attr: [E, De] x [De, K*H]
         StageTimer t(GVQA_STAGE_EDGE_LOGIT, aux);
-        rc = launch_linear(E, (int64_t)K * H, De, edge_attr, De, P(L.Ve), De, nullptr, 0, P(L.a_edge), (int64_t)K * H, 1, 0,
+        rc = launch_linear(E, (int64_t)K * H, De, edge_attr, De, Ve_all, De, nullptr, 0, P(L.a_edge), (int64_t)K * H, 1, 0,
                            0, 0, aux);
         if (rc) return rc;
     }
     if (Di > 0) {   // per-graph instruction terms of all hops: [K] x ([B, Di] x [Di, C+H])
         StageTimer t(GVQA_STAGE_GRAPH_TERM, aux);
-        rc = launch_linear(B, C + H, Di, instr, Di, P(L.Gw), Di, nullptr, 0, P(L.T), Tld, K, (int64_t)B * Di,
+        rc = launch_linear(B, C + H, Di, instr, Di, Gw_all, Di, nullptr, 0, P(L.T), Tld, K, (int64_t)B * Di,
                            (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
         if (rc) return rc;
     }
-    const bool split = proj_use_split3(N, (int64_t)H * C, Dn);
-    const bool fused = hop_fusion_applies(g, d);
-    const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
     char* a6 = base + L.a6;
-    char* w6 = base + L.w6;
-    const size_t w6_hop = fused ? split3_packed_rows_bytes(cdiv((int64_t)C, fcw) * 8, Dn) : split3_packed_bytes((int64_t)H * C, Dn);
-    if (split) {     // node-column weights of all hops -> packed pieces, once per forward
-        StageTimer t(GVQA_STAGE_PACK, stream);
-        for (int i = 0; i < K; ++i) {
-            rc = fused ? launch_split3_pack_heads(H, C, fcw, Dn, hops[i].lin_l_weight, Dn + Di, w6 + (size_t)i * w6_hop, stream)
-                       : launch_split3_pack((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, w6 + (size_t)i * w6_hop, stream);
-            if (rc) return rc;
-        }
-    }
     const float* h = x;
     for (int i = 0; i < K; ++i) {
         float* h_next;
@@ -987,9 +1042,17 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         else if (i == K - 1) h_next = out;
         else h_next = (i & 1) ? P(L.h1) : P(L.h0);
         if (ss && i > 0) { rc = side_fork(ss, stream); if (rc) return rc; }     // h of this hop is ready on `stream`
-        {   // (a_l | a_r) node halves = h . [V_l | V_r]     (side stream)
+        const bool logits_in_pack = fused && split3_pack_groups_logits_supported(2 * H, Dn);
+        if (logits_in_pack) {
+            // row-group slots of h for the fused hop AND (a_l | a_r) = h . [V_l | V_r] in one pass over h
+            if (ss) { rc = side_join(ss, stream); if (rc) return rc; }      // Vn comes from the fold on the side stream (hop 0)
+            StageTimer tp(GVQA_STAGE_PACK, stream);
+            rc = launch_split3_pack_groups(g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, Vn_all + (int64_t)i * 2 * H * Dn, 2 * H,
+                                           P(L.a_node), stream);
+            if (rc) return rc;
+        } else {   // (a_l | a_r) node halves = h . [V_l | V_r]     (side stream)
             StageTimer t(GVQA_STAGE_NODE_LOGIT, aux);
-            rc = launch_linear(N, 2 * H, Dn, h, Dn, P(L.Vn) + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
+            rc = launch_linear(N, 2 * H, Dn, h, Dn, Vn_all + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
                                1, 0, 0, 0, aux);
             if (rc) return rc;
         }
@@ -1005,14 +1068,14 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             a.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
             a.alpha_csr = P(L.alpha_csr);
             a.N = (int)N; a.C = C; a.slope = d->negative_slope;
-            {
+            {   // (when the logits ride on the pack pass, it ran above, before the coefficients)
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
-                hipLaunchKernelGGL(k_gat_alpha_general, dim3((unsigned)cdiv(N * H, 256)), dim3(256), 0, stream, a, H);
-                GVQA_LAUNCH_CHECK();
+                rc = launch_alpha(a, H, stream);
+                if (rc) return rc;
             }
-            {
+            if (!logits_in_pack) {
                 StageTimer tp(GVQA_STAGE_PACK, stream);
-                rc = launch_split3_pack_groups(g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, stream);
+                rc = launch_split3_pack_groups(g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, nullptr, 0, nullptr, stream);
                 if (rc) return rc;
             }
             FusedHopArgs f;
@@ -1089,6 +1152,37 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
                          const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
                          void* ws, size_t ws_bytes, void* stream) {
     return gat_seq_forward_impl(g, d, hops, x, edge_attr, instr, out, alpha_out, hop_out, nullptr, ws, ws_bytes, stream);
+}
+
+size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout) {
+    if (!d || check_dims(d, true) || layout < -1 || layout > 1) return 0;
+    return weight_cache_layout(d, layout).total;
+}
+
+int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    if (!g || !d || check_dims(d, true)) return -1;
+    if (hop_fusion_applies(g, d)) return 1;
+    return proj_use_split3(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) ? 0 : -1;
+}
+
+int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
+                                 size_t cache_bytes, void* stream) {
+    GVQA_REQUIRE(hops && cache, GVQA_E_INVALID, "gat_seq_prepare_weights: null argument");
+    int rc = check_dims(d, true);
+    if (rc) return rc;
+    GVQA_REQUIRE(layout >= -1 && layout <= 1, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1, 0 or 1");
+    GVQA_REQUIRE(cache_bytes >= weight_cache_layout(d, layout).total, GVQA_E_WORKSPACE, "gat_seq_prepare_weights: cache too small");
+    GVQA_REQUIRE((reinterpret_cast<uintptr_t>(cache) & 255) == 0, GVQA_E_INVALID, "gat_seq_prepare_weights: cache must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return prepare_weights(d, hops, layout, static_cast<char*>(cache), s, s);
+}
+
+int gvqa_gat_seq_forward_cached(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+                                const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
+                                const void* weight_cache, size_t weight_cache_bytes, int32_t weight_cache_layout_id, void* ws,
+                                size_t ws_bytes, void* stream) {
+    return gat_seq_forward_impl(g, d, hops, x, edge_attr, instr, out, alpha_out, hop_out, nullptr, ws, ws_bytes, stream,
+                                weight_cache, weight_cache_bytes, weight_cache_layout_id);
 }
 
 int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,

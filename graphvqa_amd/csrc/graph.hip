@@ -216,6 +216,44 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     return L;
 }
 
+// Row groups for the fused hop kernel: greedy in order, a group closes when the next graph would not fit.  `hp` / `he`:
+// host copies of graph_ptr [B+1] and of the graphs' first in-edge slots [B+1].  The plan is uploaded asynchronously from a
+// small ring of host buffers (a slot is reused only after its upload has completed).
+static int plan_row_groups(gvqa_graph* g, const int32_t* hp, const int32_t* he, hipStream_t stream) {
+    struct Slot { std::vector<int32_t> v; hipEvent_t done = nullptr; bool used = false; };
+    static thread_local Slot ring[4];
+    static thread_local int next = 0;
+    Slot& sl = ring[next];
+    next = (next + 1) & 3;
+    if (sl.used) GVQA_HIP_CHECK(hipEventSynchronize(sl.done));
+    if (!sl.done) GVQA_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    const int64_t B = g->num_graphs, N = g->num_nodes;
+    std::vector<int32_t>& hg = sl.v;
+    hg.clear();
+    hg.push_back(0);
+    int32_t start = 0, e_start = 0, max_e = 0;
+    for (int64_t q = 0; q < B; ++q) {
+        if (hp[q + 1] - start > ROW_GROUP) {          // graph q does not fit any more: close the group before it
+            max_e = std::max(max_e, he[q] - e_start);
+            hg.push_back(hp[q]);
+            start = hp[q];
+            e_start = he[q];
+        }
+    }
+    max_e = std::max(max_e, he[B] - e_start);
+    hg.push_back((int32_t)N);
+    GraphLayout L = graph_layout(N, g->num_edges, B);
+    char* base = const_cast<char*>(reinterpret_cast<const char*>(g->rowptr)) - L.rowptr;
+    int32_t* grp_dev = reinterpret_cast<int32_t*>(base + L.row_group);
+    GVQA_HIP_CHECK(hipMemcpyAsync(grp_dev, hg.data(), hg.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    GVQA_HIP_CHECK(hipEventRecord(sl.done, stream));
+    sl.used = true;
+    g->row_group_ptr = grp_dev;
+    g->num_row_groups = (int32_t)hg.size() - 1;
+    g->max_row_group_edges = max_e;
+    return GVQA_OK;
+}
+
 }  // namespace gvqa
 
 extern "C" {
@@ -303,40 +341,52 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream_) {
     GVQA_REQUIRE(g->valid, GVQA_E_GRAPH,
                  "graph violates the input contract (edge index out of [0,N), or batch not "
                  "non-decreasing in [0,B))");
-    // Row groups for the fused hop kernel: greedy in order, a group closes when the next graph would not fit.  Planned
-    // on the host from graph_ptr / the graphs' edge offsets (two small copies; this call synchronises anyway).
+    // Row groups for the fused hop kernel, planned on the host from graph_ptr / the graphs' edge offsets (two small
+    // copies; this call synchronises anyway).
     const int64_t B = g->num_graphs, N = g->num_nodes;
     if (g->intra_graph && N > 0 && B > 0 && g->max_graph_nodes <= ROW_GROUP && B < (1ll << 24)) {
         GraphLayout L = graph_layout(N, g->num_edges, B);
         char* base = const_cast<char*>(reinterpret_cast<const char*>(g->rowptr)) - L.rowptr;
         int32_t* eptr_dev = reinterpret_cast<int32_t*>(base + L.graph_eptr);
-        int32_t* grp_dev = reinterpret_cast<int32_t*>(base + L.row_group);
         hipLaunchKernelGGL(k_graph_eptr, dim3((unsigned)cdiv(B + 1, 256)), dim3(256), 0, stream, B, g->graph_ptr, g->rowptr, eptr_dev);
         GVQA_LAUNCH_CHECK();
-        static thread_local std::vector<int32_t> hp, he, hg;
+        static thread_local std::vector<int32_t> hp, he;
         hp.resize(B + 1); he.resize(B + 1);
         GVQA_HIP_CHECK(hipMemcpyAsync(hp.data(), g->graph_ptr, (B + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         GVQA_HIP_CHECK(hipMemcpyAsync(he.data(), eptr_dev, (B + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         GVQA_HIP_CHECK(hipStreamSynchronize(stream));
-        hg.clear();
-        hg.push_back(0);
-        int32_t start = 0, e_start = 0, max_e = 0;
-        for (int64_t q = 0; q < B; ++q) {
-            if (hp[q + 1] - start > ROW_GROUP) {          // graph q does not fit any more: close the group before it
-                max_e = std::max(max_e, he[q] - e_start);
-                hg.push_back(hp[q]);
-                start = hp[q];
-                e_start = he[q];
-            }
-        }
-        max_e = std::max(max_e, he[B] - e_start);
-        hg.push_back((int32_t)N);
-        GVQA_HIP_CHECK(hipMemcpyAsync(grp_dev, hg.data(), hg.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        GVQA_HIP_CHECK(hipStreamSynchronize(stream));     // hg is reused by the next call
-        g->row_group_ptr = grp_dev;
-        g->num_row_groups = (int32_t)hg.size() - 1;
-        g->max_row_group_edges = max_e;
+        return plan_row_groups(g, hp.data(), he.data(), stream);
     }
+    return GVQA_OK;
+}
+
+int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host, int32_t max_in_degree,
+                             void* stream_) {
+    using namespace gvqa;
+    GVQA_REQUIRE(g && g->stats_dev, GVQA_E_INVALID, "gvqa_graph_finalize_host: graph not built");
+    GVQA_REQUIRE(graph_ptr_host && graph_edge_ptr_host, GVQA_E_INVALID, "gvqa_graph_finalize_host: null layout");
+    const int64_t B = g->num_graphs, N = g->num_nodes, E = g->num_edges;
+    GVQA_REQUIRE(graph_ptr_host[0] == 0 && graph_ptr_host[B] == N && graph_edge_ptr_host[0] == 0 && graph_edge_ptr_host[B] == E,
+                 GVQA_E_GRAPH, "gvqa_graph_finalize_host: layout does not span the batch (%d..%d nodes, %d..%d edges)",
+                 graph_ptr_host[0], graph_ptr_host[B], graph_edge_ptr_host[0], graph_edge_ptr_host[B]);
+    int32_t mn = 0, me = 0;
+    for (int64_t q = 0; q < B; ++q) {
+        const int32_t n = graph_ptr_host[q + 1] - graph_ptr_host[q], e = graph_edge_ptr_host[q + 1] - graph_edge_ptr_host[q];
+        GVQA_REQUIRE(n >= 0 && e >= 0, GVQA_E_GRAPH, "gvqa_graph_finalize_host: layout not monotone at graph %lld", (long long)q);
+        mn = std::max(mn, n);
+        me = std::max(me, e);
+    }
+    g->max_graph_nodes = mn;
+    g->max_graph_edges = me;
+    g->max_in_degree = max_in_degree > 0 ? max_in_degree : me;      // unknown: the bound that is always true
+    g->intra_graph = 1;         // the loader's promise (what `Batch.from_data_list` produces, gqa_dataset_entry.py:654)
+    g->valid = 1;
+    g->finalized = 1;
+    g->row_group_ptr = nullptr;
+    g->num_row_groups = 0;
+    g->max_row_group_edges = 0;
+    if (N > 0 && B > 0 && mn <= ROW_GROUP && B < (1ll << 24))
+        return plan_row_groups(g, graph_ptr_host, graph_edge_ptr_host, static_cast<hipStream_t>(stream_));
     return GVQA_OK;
 }
 

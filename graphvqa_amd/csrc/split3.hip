@@ -149,19 +149,14 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         src[q] = (isA ? Apk : Bpk) + (int64_t)tile * KB * 1536 + lane * 8;
         dst[q] = lds_base + t * 3072;
     }
+    // one (tile, k step) = three 1 KiB fragments contiguous in global memory and in the LDS stage: ONE M0 set-up, three DMAs
+    auto issue_triple = [&](int buf, int q) {
+        lds_dma16_x3(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
+        src[q] += 1536;
+    };
     auto issue = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                lds_dma16_b(src[q] + p * 512, __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE + p * 1024));
-            src[q] += 1536;
-        }
-    };
-    auto issue_one = [&](int buf, int n) {             // n-th of the 3 TPW DMAs of a step (n is a compile-time constant after unrolling)
-        const int q = n / 3, p = n % 3;
-        lds_dma16_b(src[q] + p * 512, __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE + p * 1024));
-        if (p == 2) src[q] += 1536;
+        for (int q = 0; q < TPW; ++q) issue_triple(buf, q);
     };
 
     const unsigned a_off = (unsigned)(wr * TM * 3072 + lane * 16);
@@ -258,7 +253,8 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j][pb_], af[i][pa_], acc[i][j], 0, 0, 0);      \
         if (ILV && more) {                                                                                         \
-            _Pragma("unroll") for (int n = (g_) * 3 * TPW / 6; n < ((g_) + 1) * 3 * TPW / 6; ++n) issue_one(pf, n); \
+            _Pragma("unroll") for (int q = (g_) * TPW / 6 + ((g_) * TPW % 6 ? 1 : 0); q * 6 < ((g_) + 1) * TPW; ++q)    \
+                if (q * 6 >= (g_) * TPW) issue_triple(pf, q);                                                      \
         }
         GVQA_S3_PAIR(2, 0, 0) GVQA_S3_PAIR(1, 1, 1) GVQA_S3_PAIR(0, 2, 2) GVQA_S3_PAIR(1, 0, 3) GVQA_S3_PAIR(0, 1, 4) GVQA_S3_PAIR(0, 0, 5)
 #undef GVQA_S3_PAIR
@@ -622,6 +618,69 @@ __global__ __launch_bounds__(256) void k_split3_pack_groups(const int32_t* __res
     split3_store(v, out + ((rt * KB + kb) * 3) * 512 + lane * 8);
 }
 
+// The same pack with the attention logits of the node rows computed on the way (the rows are read from HBM once instead
+// of twice): a_node[node, j] = sum_k h[node, k] Vn[j, k], j < J = 2 H (the folded a_l | a_r vectors, gat_skip.py:134-135).
+// One block per 32-slot row tile; wave w walks k blocks w, w + 4, ...; Vn lives in LDS ([J][Kp] floats, zero padded);
+// partial dots are combined across the two k halves of a wave (lane ^ 32) and the four waves in a fixed order.
+template <int J>
+__global__ __launch_bounds__(256) void k_split3_pack_groups_logits(const int32_t* __restrict__ group_ptr, int K, int KB,
+                                                                   const float* __restrict__ X, int64_t ld,
+                                                                   uint16_t* __restrict__ out, int vec,
+                                                                   const float* __restrict__ Vn, float* __restrict__ a_node) {
+    extern __shared__ __attribute__((aligned(16))) float vn_s[];      // [J][Kp] + [4][32][J] partials
+    const int Kp = KB * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < J * Kp; idx += 256) {
+        const int j = idx / Kp, k = idx - j * Kp;
+        vn_s[idx] = k < K ? Vn[(int64_t)j * K + k] : 0.f;
+    }
+    __syncthreads();
+    const int64_t rt = blockIdx.x;
+    const int grp = (int)(rt >> 2), i = (int)(rt & 3) * 32 + (lane & 31);
+    const int ns = group_ptr[grp], cnt = group_ptr[grp + 1] - ns;
+    const bool row_on = i < cnt;
+    const float* row = X + (int64_t)(ns + (row_on ? i : 0)) * ld;
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.f;
+    for (int kb = wave; kb < KB; kb += 4) {
+        const int k0 = kb * 16 + (lane >> 5) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (row_on) {
+            if (vec && k0 + 8 <= K) {
+                const float4 a = *reinterpret_cast<const float4*>(row + k0), b = *reinterpret_cast<const float4*>(row + k0 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + e < K) v[e] = row[k0 + e];
+            }
+        }
+        split3_store(v, out + ((rt * KB + kb) * 3) * 512 + lane * 8);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float4 w0 = *reinterpret_cast<const float4*>(vn_s + j * Kp + k0), w1 = *reinterpret_cast<const float4*>(vn_s + j * Kp + k0 + 4);
+            acc[j] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
+        }
+    }
+    float* part = vn_s + J * Kp;                                    // [4 waves][32 rows][J]
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float t = acc[j] + __shfl_xor(acc[j], 32, 64);        // the two k halves of the row
+        if (lane < 32) part[(wave * 32 + lane) * J + j] = t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * J; idx += 256) {
+        const int r = idx / J, j = idx - r * J;
+        const int ii = (int)(rt & 3) * 32 + r;
+        if (ii < cnt)
+            a_node[(int64_t)(ns + ii) * J + j] = (part[(0 * 32 + r) * J + j] + part[(1 * 32 + r) * J + j]) +
+                                                 (part[(2 * 32 + r) * J + j] + part[(3 * 32 + r) * J + j]);
+    }
+}
+
 // B: weight rows head-interleaved -- packed row 256 cb + h cw + cc holds W[h C + cb cw + cc, :] (zeros for channels >= C),
 // so that column block cb of the product carries channels [cb cw, cb cw + cw) of every head.  grid (ceil(KB / 4), 8 ncb)
 __global__ __launch_bounds__(256) void k_split3_pack_heads(int H, int C, int cw, int K, int KB, const float* __restrict__ W,
@@ -651,14 +710,34 @@ __global__ __launch_bounds__(256) void k_split3_pack_heads(int H, int C, int cw,
 
 size_t split3_packed_rows_bytes(int64_t row_tiles, int64_t K) { return (size_t)row_tiles * (size_t)cdiv(K, 16) * 3072; }
 
+bool split3_pack_groups_logits_supported(int J, int64_t K) {
+    return (J == 2 || J == 4 || J == 8 || J == 16) && ((size_t)J * cdiv(K, 16) * 16 + 4 * 32 * (size_t)J) * sizeof(float) <= 64 * 1024;
+}
+
 int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
-                              hipStream_t stream) {
+                              const float* Vn, int J, float* a_node, hipStream_t stream) {
     GVQA_REQUIRE(num_groups >= 0 && K > 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split3_pack_groups: bad size");
     if (num_groups == 0) return GVQA_OK;
     GVQA_REQUIRE(group_ptr && X && packed, GVQA_E_INVALID, "split3_pack_groups: null operand");
     const int KB = (int)cdiv(K, 16);
     const int vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
     const int64_t RT = (int64_t)num_groups * 4;
+    const size_t lds = ((size_t)J * KB * 16 + 4 * 32 * (size_t)J) * sizeof(float);
+    if (Vn && a_node && (J == 2 || J == 4 || J == 8 || J == 16) && lds <= 64 * 1024) {     // logits on the way (rows read once)
+        uint16_t* o = static_cast<uint16_t*>(packed);
+#define GVQA_PGL(J_) hipLaunchKernelGGL((k_split3_pack_groups_logits<J_>), dim3((unsigned)RT), dim3(256), lds, stream, group_ptr, (int)K, KB, \
+                                        X, ld, o, vec, Vn, a_node)
+        switch (J) {
+            case 2: GVQA_PGL(2); break;
+            case 4: GVQA_PGL(4); break;
+            case 8: GVQA_PGL(8); break;
+            default: GVQA_PGL(16); break;
+        }
+#undef GVQA_PGL
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
+    GVQA_REQUIRE(!a_node, GVQA_E_UNSUPPORTED, "split3_pack_groups: logits on the way need 2 H in {2, 4, 8, 16} and [2 H, K] within 64 KiB of LDS");
     for (int64_t r0 = 0; r0 < RT; r0 += 65532) {       // grid.y limit, whole groups per launch
         const int64_t n = std::min<int64_t>(65532, RT - r0);
         hipLaunchKernelGGL(k_split3_pack_groups, dim3((unsigned)cdiv(KB, 4), (unsigned)n), dim3(256), 0, stream, group_ptr + r0 / 4,

@@ -508,13 +508,26 @@ class gat_seq(torch.nn.Module):
         hop_out = torch.empty((K, N, Cc), dtype=torch.float32, device=dev) if return_hops else None
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_gat_seq_workspace_bytes(C.byref(graph.c), C.byref(d)), dev)
-            _lib.check(lib.gvqa_gat_seq_forward(C.byref(graph.c), C.byref(d), hops, x.data_ptr(),
-                                                edge_attr.data_ptr(), instr.data_ptr(), out.data_ptr(),
-                                                _ptr(alpha), _ptr(hop_out), ws.data_ptr(), ws.numel(),
-                                                _stream(dev)))
+            layout = lib.gvqa_gat_seq_weight_layout(C.byref(graph.c), C.byref(d))
+            cache = self._weight_cache(lib, d, hops, layout, dev)
+            _lib.check(lib.gvqa_gat_seq_forward_cached(C.byref(graph.c), C.byref(d), hops, x.data_ptr(),
+                                                       edge_attr.data_ptr(), instr.data_ptr(), out.data_ptr(),
+                                                       _ptr(alpha), _ptr(hop_out), cache.data_ptr(), cache.numel(), layout,
+                                                       ws.data_ptr(), ws.numel(), _stream(dev)))
         if return_attention_weights or return_hops:
             return out, alpha, hop_out
         return out
+
+    def _weight_cache(self, lib, d, hops, layout, dev) -> Tensor:
+        """Parameter-only products of the forward (folded attention vectors, per-graph term weights, split3-packed
+        projection weights) prepared once per (parameter state, layout, device): the key holds every parameter's storage
+        pointer and in-place version counter, so an optimizer step, load_state_dict or .to() invalidates it."""
+        key = (layout, dev, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if getattr(self, "_wc_key", None) != key:
+            buf = torch.empty(max(int(lib.gvqa_gat_seq_weight_cache_bytes(C.byref(d), layout)), 256), dtype=torch.uint8, device=dev)
+            _lib.check(lib.gvqa_gat_seq_prepare_weights(C.byref(d), hops, layout, buf.data_ptr(), buf.numel(), _stream(dev)))
+            self._wc_buf, self._wc_key = buf, key
+        return self._wc_buf
 
     def _forward_train_bn(self, lib, graph, d, hops, x, edge_attr, instr, out):
         """model.train() with dropout p = 0: BatchNorm uses batch statistics over all N rows

@@ -21,11 +21,33 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class HostLayout:
+    """Per-graph layout of a batch as the LOADER knows it on the host (the reference collates its Batch on the CPU,
+    gqa_dataset_entry.py:631-675): first node of every graph and running in-edge counts by destination graph, int32
+    [B + 1] each.  Passing it to SceneGraphBatch skips the device -> host read-back of the graph statistics (the only
+    synchronisation of the path); the caller then vouches for an intra-graph batch with in-range indices."""
+
+    def __init__(self, graph_ptr, edge_ptr, max_in_degree: int = 0):
+        import numpy as np
+        self.graph_ptr = np.ascontiguousarray(graph_ptr, dtype=np.int32)
+        self.edge_ptr = np.ascontiguousarray(edge_ptr, dtype=np.int32)
+        self.max_in_degree = int(max_in_degree)
+
+    @classmethod
+    def from_numpy(cls, edge_index, batch, num_graphs: int):
+        """From host copies of the COO batch (edge_index [2, E], batch [N]): two bincounts."""
+        import numpy as np
+        nodes = np.bincount(batch, minlength=num_graphs)
+        edges = np.bincount(batch[edge_index[1]], minlength=num_graphs) if edge_index.shape[1] else np.zeros(num_graphs, np.int64)
+        deg = int(np.bincount(edge_index[1]).max()) if edge_index.shape[1] else 0
+        return cls(np.concatenate([[0], np.cumsum(nodes)]), np.concatenate([[0], np.cumsum(edges)]), deg)
+
+
 class SceneGraphBatch:
     """CSR-by-destination view of (edge_index [2,E] int64, batch [N] int64, num_graphs)."""
 
     def __init__(self, edge_index: torch.Tensor, batch: torch.Tensor | None, num_nodes: int,
-                 num_graphs: int | None = None):
+                 num_graphs: int | None = None, host_layout: "HostLayout | None" = None):
         lib = _lib.load()
         if not edge_index.is_cuda:
             raise ValueError("SceneGraphBatch needs CUDA/HIP tensors (edge_index is on %s)" % edge_index.device)
@@ -50,14 +72,25 @@ class SceneGraphBatch:
         with torch.cuda.device(dev):
             _lib.check(lib.gvqa_graph_build(N, E, B, _ptr(edge_index), _ptr(batch), self._ws.data_ptr(),
                                             self._ws.numel(), _stream(dev), C.byref(self.c)))
-            _lib.check(lib.gvqa_graph_finalize(C.byref(self.c), _stream(dev)))
+            if host_layout is not None:       # loader-side layout: no device synchronisation
+                if host_layout.graph_ptr.shape[0] != B + 1:
+                    raise ValueError("host_layout does not match num_graphs")
+                self._host_layout = host_layout
+                _lib.check(lib.gvqa_graph_finalize_host(C.byref(self.c), host_layout.graph_ptr.ctypes.data,
+                                                        host_layout.edge_ptr.ctypes.data, int(host_layout.max_in_degree),
+                                                        _stream(dev)))
+            else:
+                _lib.check(lib.gvqa_graph_finalize(C.byref(self.c), _stream(dev)))
 
     def transposed(self) -> "SceneGraphBatch":
         """CSR by SOURCE of the same batch (flipped edge_index; same COO edge ids): what the backward of the
         message passing walks to scatter gradients to source nodes without atomics.  Built once, cached."""
         if getattr(self, "_transposed", None) is None:
             edge_index, batch = self._keep
-            self._transposed = SceneGraphBatch(edge_index.flip(0), batch, self.num_nodes, self.num_graphs)
+            hl = getattr(self, "_host_layout", None)        # intra-graph batch: the same per-graph counts by source
+            if hl is not None:
+                hl = HostLayout(hl.graph_ptr, hl.edge_ptr, 0)
+            self._transposed = SceneGraphBatch(edge_index.flip(0), batch, self.num_nodes, self.num_graphs, host_layout=hl)
         return self._transposed
 
     # statistics ------------------------------------------------------------------------------

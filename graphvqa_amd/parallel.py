@@ -60,6 +60,15 @@ class BatchShard:
         self.instr = as_t(instr)[:, g0:g1].contiguous().to(device)
         self.edge_index = as_t(ei).contiguous().to(device)
         self.batch = as_t(b).contiguous().to(device)
+        # the loader-side per-graph layout of the shard (host): lets the batch handle skip its statistics read-back
+        self.host_nodes_per_graph = np.bincount(b, minlength=g1 - g0)
+        self.host_edges_per_graph = epg[g0:g1]
+        self.host_max_in_degree = int(np.bincount(ei[1]).max()) if ei.shape[1] else 0
+
+    def host_layout(self):
+        from .graph import HostLayout
+        return HostLayout(np.concatenate([[0], np.cumsum(self.host_nodes_per_graph)]),
+                          np.concatenate([[0], np.cumsum(self.host_edges_per_graph)]), self.host_max_in_degree)
 
 
 def sharded_step(shard: BatchShard, forward, pool=None, force: bool = False) -> torch.Tensor:

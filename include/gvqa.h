@@ -94,6 +94,16 @@ int gvqa_graph_build(int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
  * input violated the contract. */
 int gvqa_graph_finalize(gvqa_graph* g, void* stream);
 
+/* The same WITHOUT a device synchronisation, for feeds whose loader already knows the per-graph layout on the host (the
+ * reference's collate builds its Batch on the CPU, gqa_dataset_entry.py:631-675): graph_ptr_host[B+1] = first node of
+ * every graph, graph_edge_ptr_host[B+1] = running count of in-edges by destination graph (graph g owns CSR slots
+ * [ptr[g], ptr[g+1])), max_in_degree = the largest in-degree or 0 if unknown (the largest graph's edge count is then
+ * assumed).  The statistics and the row-group plan are derived from these on the host; the device-side validation flags
+ * are NOT read back: the caller vouches for an intra-graph batch with in-range indices.  GVQA_E_GRAPH if the layout does
+ * not span [0, N] nodes / [0, E] edges monotonically. */
+int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host,
+                             int32_t max_in_degree, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GAT execution path
  * ---------------------------------------------------------------------------------------- */
@@ -144,6 +154,21 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
                          const float* x, const float* edge_attr, const float* instr,
                          float* out, float* alpha_out, float* hop_out,
                          void* ws, size_t ws_bytes, void* stream);
+
+/* Weight cache: what a gat_seq forward derives from the PARAMETERS alone -- the folded attention vectors, the per-graph
+ * term weights and the split3-packed projection weights of every hop -- prepared once and reused while the weights do not
+ * change (serving).  `layout` is what the batch needs: gvqa_gat_seq_weight_layout(g, d) = -1 (f32 projection), 0 (split3,
+ * plain rows) or 1 (fused hop, head-interleaved rows).  gvqa_gat_seq_forward_cached uses the cache when its layout id
+ * matches the batch's, and recomputes into the workspace otherwise (results are identical either way).  The cache is
+ * caller-owned device memory, 256-byte aligned; the caller re-prepares it after changing any parameter. */
+size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout);
+int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d);
+int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
+                                 size_t cache_bytes, void* stream);
+int gvqa_gat_seq_forward_cached(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+                                const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
+                                const void* weight_cache, size_t weight_cache_bytes, int32_t weight_cache_layout, void* ws,
+                                size_t ws_bytes, void* stream);
 
 /* Same forward with TRAIN-mode BatchNorm (model.train(), gat_skip.py:273-276): after every hop but the
  * last, BN uses the batch statistics over all N node rows (biased variance, eps), then ReLU.  The

@@ -1070,3 +1070,43 @@ def test_randomized_variants_head_encoder_vs_oracle(dev):
         xe, ee, _ = enc(data); rxe, ree = R.scene_graph_encoder(t(xt), t(ei), t(et), t(added), t(batch), B, tp(pe))
         upd("enc.x", xe, rxe); upd("enc.e", ee, ree)
     assert all(v < 1e-4 for v in worst.values()), worst
+
+
+def test_host_layout_handle_and_weight_cache_give_identical_results(dev):
+    """The sync-free batch handle (loader-side per-graph layout, gvqa_graph_finalize_host) must equal the read-back one
+    field by field, and forwards through the weight cache must be bit-identical to uncached ones -- also after the
+    parameters change in place (the cache key follows the version counters)."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    H, C, de, di, K = 4, 64, 24, 16, 3
+    gb = synth.make_graph_batch(37, seed=4242, nodes_lo=1, nodes_hi=50, rel_per_node=1.4)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    ei, batch = t(gb.edge_index, device=dev), t(gb.batch, device=dev)
+    g1 = SceneGraphBatch(ei, batch, N, B)
+    g2 = SceneGraphBatch(ei, batch, N, B, host_layout=HostLayout.from_numpy(gb.edge_index, gb.batch, B))
+    for f in ("max_graph_nodes", "max_graph_edges", "max_in_degree", "intra_graph", "valid", "finalized", "num_row_groups",
+              "max_row_group_edges"):
+        assert getattr(g1.c, f) == getattr(g2.c, f), f
+    torch.cuda.synchronize()
+    rg = lambda g: g._ws[g.c.row_group_ptr - g._ws.data_ptr():][:4 * (g.c.num_row_groups + 1)].view(torch.int32)
+    assert torch.equal(rg(g1), rg(g2)) and torch.equal(g1.rowptr, g2.rowptr) and torch.equal(g1.csr_src, g2.csr_src)
+    with pytest.raises(_lib.GvqaError):
+        SceneGraphBatch(ei, batch, N, B, host_layout=HostLayout(np.arange(B + 1), np.arange(B + 1)))      # does not span the batch
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=31)
+    x, ea, ins = t(synth.normal((N, C), 1), device=dev), t(synth.normal((E, de), 2), device=dev), t(synth.normal((K, B, di), 3), device=dev)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        m = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), p, dev)
+        a = m(x, ei, ea, ins, batch, graph=g1)
+        key1 = m._wc_key
+        b = m(x, ei, ea, ins, batch, graph=g2)                 # second call: served from the cache
+        assert m._wc_key == key1 and torch.equal(a, b)
+        with torch.no_grad():
+            m.convs[1].lin_l.weight.mul_(1.5)                  # in place: version bump -> re-prepared
+        c = m(x, ei, ea, ins, batch, graph=g2)
+        assert m._wc_key != key1 and maxabs(c, a) > 1e-3
+        fresh = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), {k: v.cpu().numpy() for k, v in m.state_dict().items()}, dev)
+        assert torch.equal(fresh(x, ei, ea, ins, batch, graph=g1), c)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
