@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the f32-MFMA / vendor comparison legs")
     ap.add_argument("--with-head", action="store_true",
                     help="also run global attention pooling + answer classifier each step and all-gather the true [B, 1842] logits")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single-GPU estimate of strong scaling: time rank 0's shard of an N-way split of the batch (no collective)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -236,6 +238,13 @@ def main():
         return
 
     strong = a.scaling == "strong"
+    if a.emulate_world > 1 and world == 1:       # one rank's share of an N-way strong-scaling run, on this one GPU
+        sh = make_shard(0, a.emulate_world)
+        t = timed(runner(sh), a.steps, a.warmup) / a.steps
+        print(json.dumps({"emulated_world": a.emulate_world, "graphs": sh.num_graphs, "edges": sh.num_edges, "ms_per_step": t * 1e3,
+                          "note": "rank 0's shard only, no all-gather; whole-job edges/s would be <= "
+                                  f"{Eall / t:.4g} if every rank matched it"}))
+        return
     shard = make_shard(rank, world) if strong else make_shard(0, 1)
     if not strong and rank:             # weak scaling: every rank its own batch of the full size (different values)
         shard.x = tt(synth.normal((Nall, D), 1 + 10 * rank)).to(dev)

@@ -5,9 +5,15 @@ Host-side restatement of the topology rules of the reference's converter
 (gqa_dataset_entry.py:654): nodes = object ids sorted as strings; per node, in
 order: one self-loop, then for each outgoing relation the forward edge and --
 only if the reverse (dst, src) pair is absent from the relation set -- a reverse
-edge flagged in `added_sym_edge`.  Multi-edges are kept.  Token features are
-vocabulary-dependent and not produced here (the builder is a
-"next" row; only the topology is needed by the execution path and its tests).
+edge flagged in `added_sym_edge`.  Multi-edges are kept.
+
+`convert_scene_graph` adds the token features of the same converter (:259-316): 12 token ids per node
+(object name, then its de-duplicated attributes, `<pad>` after them), one token id per edge (`<self>` for
+the self-loop, the relation name for a relation AND for its added reverse edge -- the encoder flips the sign of the
+latter's embedding through `added_sym_edge`, pipeline_model_gat.py:590).  `collate_scene_graphs` is the
+`Batch.from_data_list` step (:654) and `DeviceSceneGraphs` puts the batch on the GPU together with its CSR handle, built
+from the loader-side layout (no device read-back).  Pinned on the four debug graphs against the reference's own converter
+(tests/golden/sg_builder_debug4.npz).
 """
 from __future__ import annotations
 
@@ -39,6 +45,104 @@ def scene_graph_topology(sg: dict):
                 added.append(len(edges) - 1)
     ei = np.asarray(edges, dtype=np.int64).T.copy()
     return len(obj_ids), ei, np.asarray(added, dtype=np.int64)
+
+
+MAX_OBJ_TOKEN_LEN = 12      # gqa_dataset_entry.py:263
+
+_DUMMY = {"objects": {      # what the reference substitutes for an empty scene graph (gqa_dataset_entry.py:196-224)
+    "0": {"name": "<UNK>", "relations": [{"object": "1", "name": "<UNK>"}], "attributes": ["<UNK>"]},
+    "1": {"name": "<UNK>", "relations": [{"object": "0", "name": "<UNK>"}], "attributes": ["<UNK>"]}}}
+
+
+def convert_scene_graph(sg: dict, stoi, pad_token: str = "<pad>", self_token: str = "<self>"):
+    """One GQA scene graph -> (x_tokens [N, 12], edge_index [2, E], edge_tokens [E, 1], added_sym_edge [A]), int64, exactly
+    the tensors of the reference's `convert_one_gqa_scene_graph` (gqa_dataset_entry.py:190-372).  `stoi` maps a string
+    to its id and must return the unknown id for out-of-vocabulary strings (torchtext's defaultdict behaviour; a plain dict
+    is wrapped with unknown = 0).  Attribute tokens keep first-occurrence order (the reference iterates a Python `set`, whose
+    order is not defined -- the encoder sums the 12 embeddings, so only the multiset matters)."""
+    if len(sg["objects"]) == 0:
+        sg = _DUMMY
+    lookup = stoi.__getitem__ if hasattr(stoi, "default_factory") else (lambda w: stoi.get(w, 0))
+    objects = sg["objects"]
+    obj_ids = sorted(objects.keys())
+    node_of = {o: i for i, o in enumerate(obj_ids)}
+    n, ei, added = scene_graph_topology(sg)
+    x = np.full((n, MAX_OBJ_TOKEN_LEN), lookup(pad_token), dtype=np.int64)
+    e_tok = []
+    for i, o in enumerate(obj_ids):
+        obj = objects[o]
+        x[i, 0] = lookup(obj["name"])
+        for a_idx, attr in enumerate(dict.fromkeys(obj["attributes"])):      # de-duplicated (the reference: set(...), :282)
+            x[i, a_idx + 1] = lookup(attr)
+        e_tok.append(lookup(self_token))
+        pairs_i = None
+        for rel in obj["relations"]:
+            e_tok.append(lookup(rel["name"]))
+            if pairs_i is None:
+                pairs_i = _relation_pairs(objects, obj_ids, node_of)
+            if (node_of[rel["object"]], i) not in pairs_i:
+                e_tok.append(lookup(rel["name"]))                             # the added reverse edge re-uses the name (:327)
+    e_tok = np.asarray(e_tok, dtype=np.int64).reshape(-1, 1)
+    assert e_tok.shape[0] == ei.shape[1]
+    return x, ei, e_tok, added
+
+
+def _relation_pairs(objects, obj_ids, node_of):
+    pairs = set()
+    for i, o in enumerate(obj_ids):
+        for rel in objects[o]["relations"]:
+            pairs.add((i, node_of[rel["object"]]))
+    return pairs
+
+
+class CollatedSceneGraphs:
+    """Host-side batch in the path's input contract (what `GQATorchDataset_collate_fn` hands to the model,
+    gqa_dataset_entry.py:631-675): block-diagonal `edge_index`, `batch`, token features, `added_sym_edge` rebased to the
+    batched edge list, and the per-graph layout the loader knows for free."""
+
+    def __init__(self, x_tokens, edge_index, edge_tokens, added_sym_edge, batch, nodes_per_graph, edges_per_graph):
+        self.x, self.edge_index, self.edge_attr, self.added_sym_edge, self.batch = x_tokens, edge_index, edge_tokens, added_sym_edge, batch
+        self.nodes_per_graph, self.edges_per_graph = nodes_per_graph, edges_per_graph
+        self.num_graphs, self.num_nodes, self.num_edges = len(nodes_per_graph), int(x_tokens.shape[0]), int(edge_index.shape[1])
+
+    def host_layout(self):
+        from .graph import HostLayout
+        deg = int(np.bincount(self.edge_index[1]).max()) if self.num_edges else 0
+        # in-edges by DESTINATION graph: every edge stays inside its graph, so they equal the per-graph edge counts
+        return HostLayout(np.concatenate([[0], np.cumsum(self.nodes_per_graph)]), np.concatenate([[0], np.cumsum(self.edges_per_graph)]), deg)
+
+    def to(self, device):
+        return DeviceSceneGraphs(self, device)
+
+
+def collate_scene_graphs(sgs, stoi, pad_token: str = "<pad>", self_token: str = "<self>") -> CollatedSceneGraphs:
+    xs, eis, ets, adds, batch, npg, epg = [], [], [], [], [], [], []
+    n_off = e_off = 0
+    for g, sg in enumerate(sgs):
+        x, ei, et, added = convert_scene_graph(sg, stoi, pad_token, self_token)
+        xs.append(x); eis.append(ei + n_off); ets.append(et); adds.append(added + e_off)
+        batch.append(np.full(x.shape[0], g, dtype=np.int64))
+        npg.append(x.shape[0]); epg.append(ei.shape[1])
+        n_off += x.shape[0]; e_off += ei.shape[1]
+    return CollatedSceneGraphs(np.concatenate(xs), np.concatenate(eis, axis=1), np.concatenate(ets), np.concatenate(adds),
+                               np.concatenate(batch), np.asarray(npg, np.int64), np.asarray(epg, np.int64))
+
+
+class DeviceSceneGraphs:
+    """The collated batch on the GPU -- attribute names as the reference's `Batch` (x, edge_index, edge_attr, batch,
+    added_sym_edge), so `GroundTruth_SceneGraph_Encoder.forward(gt_scene_graphs)` / `gat_seq.forward(...)` take it as is --
+    plus `graph`: the destination-sorted CSR handle built on the device from the COO arrays, finalized from the loader-side
+    layout (no synchronisation)."""
+
+    def __init__(self, c: CollatedSceneGraphs, device):
+        import torch
+        from .graph import SceneGraphBatch
+        dev = torch.device(device)
+        put = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        self.x, self.edge_index, self.edge_attr = put(c.x), put(c.edge_index), put(c.edge_attr)
+        self.batch, self.added_sym_edge = put(c.batch), put(c.added_sym_edge)
+        self.num_graphs, self.num_nodes, self.num_edges = c.num_graphs, c.num_nodes, c.num_edges
+        self.graph = SceneGraphBatch(self.edge_index, self.batch, c.num_nodes, c.num_graphs, host_layout=c.host_layout())
 
 
 def batch_scene_graphs(sgs) -> GraphBatch:

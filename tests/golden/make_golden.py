@@ -444,7 +444,75 @@ def gen_pipeline():
          x_executed=cap["exec"], pooled=cap["pool"], short_answer_logits=logits)
 
 
+def gen_builder():
+    """the reference's OWN `GQA_gt_sg_feature_lookup.convert_one_gqa_scene_graph`
+    (gqa_dataset_entry.py:190-372) on the four debug scene graphs plus an empty one (which it replaces with a 2-node
+    dummy, :196-224), under a stub vocabulary: `gqa_dataset_entry.py` itself is imported unmodified; `torchtext`
+    (absent from the image) is replaced by a Field stub carrying a vocabulary built from the strings of the debug graphs,
+    `Constants` by a module whose ROOT_DIR resolves `GraphVQA/meta_info` to the reference's own meta_info through a
+    scratch symlink under /tmp, `torch_geometric.data` by a plain attribute holder.  Must run in its own process
+    (`--builder-only`): the other generators stub the module this one imports for real."""
+    import collections
+    import pathlib
+    import types
+    scratch = "/tmp/gvqa_golden_root"
+    os.makedirs(scratch, exist_ok=True)
+    link = os.path.join(scratch, "GraphVQA")
+    if not os.path.islink(link):
+        os.symlink(REF, link)
+    for name in ("torchtext", "torchtext.data", "torch_geometric.data", "Constants"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["Constants"].ROOT_DIR = pathlib.Path(scratch)
+
+    class Field:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+            self.pad_token, self.unk_token = "<pad>", "<unk>"
+
+    class Data:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    sys.modules["torchtext"].data = sys.modules["torchtext.data"]
+    sys.modules["torchtext.data"].Field = Field
+    import torch_geometric
+    sys.modules["torch_geometric.data"].Data = Data
+    sys.modules["torch_geometric.data"].Batch = object
+    torch_geometric.data = sys.modules["torch_geometric.data"]
+    import gqa_dataset_entry as G
+
+    sgs = debug_graphs()
+    strings = set()
+    for sg in sgs.values():
+        for o in sg["objects"].values():
+            strings.add(o["name"])
+            strings.update(o["attributes"])
+            strings.update(r["name"] for r in o["relations"])
+    itos = ["<unk>", "<pad>", "<start>", "<end>", "<self>"] + sorted(strings)       # torchtext's specials first, unk = 0
+    stoi = collections.defaultdict(int, {w: i for i, w in enumerate(itos)})
+    G.GQA_gt_sg_feature_lookup.SG_ENCODING_TEXT.vocab = types.SimpleNamespace(stoi=stoi, itos=itos)
+    cases = list(sgs.items()) + [("empty", {"objects": {}})]
+    arrays, sizes = {}, []
+    for idx, (key, sg) in enumerate(cases):
+        d = G.GQA_gt_sg_feature_lookup.convert_one_gqa_scene_graph(None, sg)
+        arrays[f"g{idx}.x"], arrays[f"g{idx}.edge_index"] = d.x.numpy(), d.edge_index.numpy()
+        arrays[f"g{idx}.edge_attr"], arrays[f"g{idx}.added_sym_edge"] = d.edge_attr.numpy(), d.added_sym_edge.numpy()
+        sizes.append([int(d.x.shape[0]), int(d.edge_index.shape[1])])
+    # the INPUT of the fixture: the fields of the debug scene graphs the converter reads (ids, names, attributes, relations)
+    inputs = {k: {"objects": {oid: {"name": o["name"], "attributes": list(o["attributes"]),
+                                    "relations": [{"object": r["object"], "name": r["name"]} for r in o["relations"]]}
+                              for oid, o in sg["objects"].items()}} for k, sg in cases}
+    save("sg_builder_debug4", dict(case="convert_one_gqa_scene_graph on debug_sceneGraphs.json + an empty graph",
+                                   ref="gqa_dataset_entry.py:190-372", graphs=[k for k, _ in cases], sizes=sizes, itos=itos,
+                                   scene_graphs=inputs,
+                                   note="attribute tokens (columns 1.. of x) follow Python set order in the reference: compare as multisets"),
+         **arrays)
+
+
 if __name__ == "__main__":
+    if "--builder-only" in sys.argv:
+        gen_builder()
+        sys.exit(0)
     if "--pipeline-only" in sys.argv:
         gen_pipeline()
         sys.exit(0)

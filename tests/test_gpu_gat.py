@@ -1110,3 +1110,30 @@ def test_host_layout_handle_and_weight_cache_give_identical_results(dev):
         assert torch.equal(fresh(x, ei, ea, ins, batch, graph=g1), c)
     finally:
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+
+
+def test_scene_graph_builder_to_device_feeds_the_path(dev):
+    """SURVEY 8f-3 end to end: scene-graph dicts -> graphvqa_amd.scene_graph.collate_scene_graphs -> DeviceSceneGraphs
+    (token tensors + CSR handle from the loader-side layout, no read-back) -> encoder -> gat_seq; same result as the
+    explicit, synchronising batch handle, and the handle's statistics equal the read-back ones."""
+    from graphvqa_amd.scene_graph import collate_scene_graphs
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch
+    meta, g = load_golden("sg_builder_debug4")
+    stoi = {w: i for i, w in enumerate(meta["itos"])}
+    sgs = [meta["scene_graphs"][k] for k in meta["graphs"]]
+    c = collate_scene_graphs(sgs, stoi)
+    d = c.to(dev)
+    V = len(meta["itos"])
+    enc = _load_module(GroundTruth_SceneGraph_Encoder(V, stoi["<pad>"], 300), synth.encoder_params(V, 300, seed=5, pad_idx=stoi["<pad>"]), dev)
+    gs = _load_module(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=6), dev)
+    ins = t(synth.normal((5, c.num_graphs, 512), 7), device=dev)
+    xe, ee, _ = enc(d, graph=d.graph)
+    h = gs(xe, d.edge_index, ee, ins, d.batch, graph=d.graph)
+    g2 = SceneGraphBatch(d.edge_index, d.batch, c.num_nodes, c.num_graphs)         # statistics read back from the device
+    for f in ("max_graph_nodes", "max_graph_edges", "max_in_degree", "intra_graph", "num_row_groups", "max_row_group_edges"):
+        assert getattr(d.graph.c, f) == getattr(g2.c, f), f
+    xe2, ee2, _ = enc(d, graph=g2)
+    assert torch.equal(xe, xe2) and torch.equal(h, gs(xe2, d.edge_index, ee2, ins, d.batch, graph=g2))
+    assert h.shape == (c.num_nodes, 300) and torch.isfinite(h).all()

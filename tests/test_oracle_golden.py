@@ -186,3 +186,32 @@ def test_gat_seq_backward_matches_reference_autograd(mode):
             rr = rp[k.replace("lin_l", "lin_r")].grad
             rg = rg if rr is None else rg + rr
         assert maxabs(rg, g[key]) < 2e-4 * max(float(np.abs(g[key]).max()), 1e-3 * scale), k
+
+
+def test_scene_graph_builder_pinned_to_the_reference_converter():
+    """graphvqa_amd.scene_graph.convert_scene_graph / collate_scene_graphs against the reference's own
+    `convert_one_gqa_scene_graph` (gqa_dataset_entry.py:190-372) on the four debug scene graphs and an empty one (inputs
+    and outputs in tests/golden/sg_builder_debug4.npz): topology, `added_sym_edge`, per-edge token ids exactly; per-node
+    token ids as multisets (the reference iterates a Python set)."""
+    from graphvqa_amd.scene_graph import convert_scene_graph, collate_scene_graphs
+    meta, g = load_golden("sg_builder_debug4")
+    stoi = {w: i for i, w in enumerate(meta["itos"])}
+    graphs = [meta["scene_graphs"][k] for k in meta["graphs"]]
+    for idx, sg in enumerate(graphs):
+        x, ei, et, added = convert_scene_graph(sg, stoi)
+        assert [x.shape[0], ei.shape[1]] == meta["sizes"][idx]
+        assert np.array_equal(ei, g[f"g{idx}.edge_index"]) and np.array_equal(et, g[f"g{idx}.edge_attr"])
+        assert np.array_equal(added, g[f"g{idx}.added_sym_edge"])
+        assert np.array_equal(x[:, 0], g[f"g{idx}.x"][:, 0])
+        assert np.array_equal(np.sort(x, axis=1), np.sort(g[f"g{idx}.x"], axis=1))
+    c = collate_scene_graphs(graphs, stoi)
+    sizes = meta["sizes"]
+    assert c.num_graphs == len(graphs) and c.num_nodes == sum(s[0] for s in sizes) and c.num_edges == sum(s[1] for s in sizes)
+    assert np.array_equal(c.batch, np.repeat(np.arange(len(graphs)), [s[0] for s in sizes]))
+    n_off = np.concatenate([[0], np.cumsum([s[0] for s in sizes])])
+    e_off = np.concatenate([[0], np.cumsum([s[1] for s in sizes])])
+    for idx in range(len(graphs)):
+        assert np.array_equal(c.edge_index[:, e_off[idx]:e_off[idx + 1]], g[f"g{idx}.edge_index"] + n_off[idx])
+    assert np.array_equal(c.added_sym_edge, np.concatenate([g[f"g{i}.added_sym_edge"] + e_off[i] for i in range(len(graphs))]))
+    hl = c.host_layout()
+    assert hl.graph_ptr.tolist() == n_off.tolist() and hl.edge_ptr.tolist() == e_off.tolist()
