@@ -47,21 +47,41 @@ ins = tt(synth.normal((5, B, 512), 3)).to(dev)
 
 from graphvqa_amd.gat_skip import gat_seq
 m = load(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303))
-dt, prof = timed(lambda: m(x, ei, ea, ins, batch))
-mp_ms, mp_n = prof["mp"]
-alg = 4 * (N * 4 * 300 + 2 * N * 4 + E * 4 + E + (N + 1) + N * 300) + 4 * N * 300
-res["config2_gat_d300"] = {"N": N, "E": E, "B": B, "ms_per_forward": dt * 1e3, "edges_per_s": E / dt,
-                           "mp_us_per_hop": mp_ms / mp_n * 1e3, "mp_alg_bytes": alg,
-                           "mp_GBps": alg / (mp_ms / mp_n * 1e-3) / 1e9, "stage_ms": {k: v[0] for k, v in prof.items()}}
+def gat_modes(run, Nn, Ee, C=300, H=4):
+    """Default path (fused hops) and the unfused one, whose stand-alone message-passing kernel is priced against the HBM roofline
+    with SURVEY 8(d)'s algorithmic bytes (+ 4 N C: the skip rows read by the fused epilogue)."""
+    out = {}
+    dt, prof = timed(run)
+    out["fused"] = {"ms_per_forward": dt * 1e3, "edges_per_s": Ee / dt, "stage_ms": {k: v[0] for k, v in prof.items()}}
+    old = _lib.set_option(_lib.OPT_HOP_FUSION, 0)
+    try:
+        dt, prof = timed(run)
+    finally:
+        _lib.set_option(_lib.OPT_HOP_FUSION, old)
+    mp_ms, mp_n = prof["mp"]
+    alg = 4 * (Nn * H * C + 2 * Nn * H + Ee * H + Ee + (Nn + 1) + Nn * C) + 4 * Nn * C
+    out["unfused"] = {"ms_per_forward": dt * 1e3, "edges_per_s": Ee / dt, "mp_us_per_hop": mp_ms / mp_n * 1e3, "mp_alg_bytes": alg,
+                      "mp_GBps": alg / (mp_ms / mp_n * 1e-3) / 1e9, "mp_frac_of_8TBps": alg / (mp_ms / mp_n * 1e-3) / 8e12,
+                      "stage_ms": {k: v[0] for k, v in prof.items()}}
+    return out
+
+
+res["config2_gat_d300"] = dict(N=N, E=E, B=B, **gat_modes(lambda: m(x, ei, ea, ins, batch), N, E))
 
 # "GQA-shaped" alternative of SURVEY 8(d): E/N ~ 4 (one self loop + ~3 relations per node), same dims
 gb4 = synth.make_graph_batch(1000, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=3.0)
 N4, E4 = gb4.num_nodes, gb4.num_edges
 ei4, batch4 = tt(gb4.edge_index).to(dev), tt(gb4.batch).to(dev)
 x4, ea4 = tt(synth.normal((N4, 300), 1)).to(dev), tt(synth.normal((E4, 300), 2)).to(dev)
-dt, prof = timed(lambda: m(x4, ei4, ea4, ins, batch4))
-res["config2_gat_d300_EoverN4"] = {"N": N4, "E": E4, "ms_per_forward": dt * 1e3, "edges_per_s": E4 / dt,
-                                   "mp_us_per_hop": prof["mp"][0] / prof["mp"][1] * 1e3}
+res["config2_gat_d300_EoverN4"] = dict(N=N4, E=E4, **gat_modes(lambda: m(x4, ei4, ea4, ins, batch4), N4, E4))
+
+# config 3 (the headline batch): the stand-alone message-passing kernel's roofline next to config 2's
+gb3 = synth.config3_batch()
+N3, E3, B3 = gb3.num_nodes, gb3.num_edges, gb3.num_graphs
+m3 = load(gat_seq(512, 512, 512, 512, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(512, 512, 512, 512, 5, 4, seed=777))
+a3 = [tt(v).to(dev) for v in (synth.normal((N3, 512), 1), gb3.edge_index, synth.normal((E3, 512), 2), synth.normal((5, B3, 512), 3), gb3.batch)]
+res["config3_gat_d512"] = dict(N=N3, E=E3, B=B3, **gat_modes(lambda: m3(*a3), N3, E3, C=512))
+del m3, a3
 
 from graphvqa_amd.baseline_models import gine_seq, gcn_seq
 m = load(gine_seq(300, 300, 512), synth.gine_seq_params(300, 300, 512, 404))
