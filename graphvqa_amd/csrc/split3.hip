@@ -226,27 +226,34 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     for (int s = 0; s < NBUF - 1; ++s)
         if (s < KB) issue(s);
     int buf = 0, pf = NBUF - 1;                        // ring slot of step s / of the step issued in iteration s
+    // (measurement aid, STAG == 0 only: `stagger` bits 16 / 32 / 64 = no fragment reads after step 0 / no DMA in the loop /
+    //  no waits and barriers -- wrong results; scripts/bench_split3_loop.py prices the parts of a K step with them)
+    const int dbg = STAG == 0 ? stagger : 0;
+    bf16x8_t af[TM][3], bfr[TN][3];
     for (int s = 0; s < KB; ++s) {
-        // steps s+1 .. s+NBUF-2 may stay in flight (3 TPW DMAs each); near the end fewer were issued
-        const int ahead = min(NBUF - 2, KB - 1 - s);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 3 * TPW) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const bool more = s + NBUF - 1 < KB;
+        if (!(dbg & 64)) {
+            // steps s+1 .. s+NBUF-2 may stay in flight (3 TPW DMAs each); near the end fewer were issued
+            const int ahead = min(NBUF - 2, KB - 1 - s);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 3 * TPW) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const bool more = s + NBUF - 1 < KB && !(dbg & 32);
         if (!ILV && more) issue(pf);                   // refills the slot read in iteration s-1
         const unsigned char* sb = smem + buf * STAGE;
-        bf16x8_t af[TM][3], bfr[TN][3];
+        if (s == 0 || !(dbg & 16)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                af[i][p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + a_off + (i * 3 + p) * 1024));
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + a_off + (i * 3 + p) * 1024));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                bfr[j][p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + b_off + (j * 3 + p) * 1024));
+                for (int p = 0; p < 3; ++p)
+                    bfr[j][p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + b_off + (j * 3 + p) * 1024));
+        }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
         // smallest cross terms first, a1 b1 last; consecutive MFMAs hit different accumulators
 #define GVQA_S3_PAIR(pa_, pb_, g_)                                                                                 \
@@ -548,6 +555,8 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
     const int64_t bm = variant < 20 ? 256 : 128;
     const char* ssv = getenv("GVQA_SPLIT3_STAGGER");      // quarter units of the default start offset (tuning aid)
     const int stag_scale = ssv ? atoi(ssv) : 0;
+    const char* ldv = getenv("GVQA_SPLIT3_LOOP_DEBUG");   // measurement aid: see the main loop
+    const int loop_dbg = ldv ? atoi(ldv) : 0;
     const int64_t rows_per_launch = 65535 * bm;        // grid.y limit: row chunks (rows are independent)
     for (int64_t m0 = 0; m0 < M; m0 += rows_per_launch) {
         const int64_t m = std::min(rows_per_launch, M - m0);
@@ -563,7 +572,7 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
             hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_>), grid,       \
                                dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C + m0 * ldc, ldc, \
-                               stag_scale > 0 ? stag * stag_scale / 4 : stag, FusedHopArgs{});                           \
+                               STAG_ == 0 ? loop_dbg : (stag_scale > 0 ? stag * stag_scale / 4 : stag), FusedHopArgs{});  \
         } while (0)
         switch (variant) {
             case 10: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, false, false, false, 0, 0); break;
