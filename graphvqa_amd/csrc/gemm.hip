@@ -568,7 +568,8 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     else if (N <= 64) GVQA_LAUNCH_LINEAR(128, 64, 2, 2);
     // per-graph products (M = graphs): a 128 x 128 tile is >= 27 us of MFMA issue for its 4 waves however few
     // tiles there are -- when they cannot fill the chip, quarter tiles put 4x the CUs to work
-    else if (tile_sel == 0 && cdiv(M, 128) * cdiv(N, 128) * batch < 128) GVQA_LAUNCH_LINEAR(64, 64, 2, 2);
+    // (measured on the per-graph instruction terms, 5 x [2048 x 516 x 512]: 400 full tiles over 768 resident slots 91 us)
+    else if (tile_sel == 0 && cdiv(M, 128) * cdiv(N, 128) * batch < 512) GVQA_LAUNCH_LINEAR(64, 64, 2, 2);
     else if (tile_sel == 1 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 4, 2);
     else if (tile_sel == 2 && M >= 256) GVQA_LAUNCH_LINEAR(256, 128, 2, 2);
     else if (tile_sel == 3) GVQA_LAUNCH_LINEAR(128, 128, 4, 2);

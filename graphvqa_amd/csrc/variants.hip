@@ -15,6 +15,8 @@
 // relu(ins[g] + ins[g]) = relu(2 ins[g]), a per-GRAPH constant, so the aggregate of that half is
 // in-degree x constant and its share of the first MLP layer is two tiny per-graph GEMMs; only
 // the Dn node channels go through the gather kernel (HBM-bound: E*Dn edge rows streamed once).
+#include <algorithm>
+
 #include "common.h"
 
 namespace gvqa {
@@ -166,6 +168,45 @@ __global__ __launch_bounds__(256) void k_gcn_aggregate(int N, int C, const float
     }
 }
 
+// float4 form (C % 4 == 0, 16-byte aligned rows): work item = (node, 4 channels), consecutive lanes on consecutive channel
+// quads of one node, so every neighbour row is read as whole 16-byte segments (the scalar kernel above: one 4-byte load per lane
+// and 4.7 passes over a 300-channel row).  Same summation order: non-self edges in CSR (= COO) order, then the self loop.
+__global__ __launch_bounds__(256) void k_gcn_aggregate_v4(int N, int C4, const float4* __restrict__ xw, const float4* __restrict__ P,
+                                                          const float* __restrict__ dis, const float4* __restrict__ bias,
+                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
+                                                          const int32_t* __restrict__ node_graph, float4* __restrict__ out) {
+    const int64_t total = (int64_t)N * C4;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int i = (int)(it / C4), q = (int)(it - (int64_t)i * C4);
+        const int lo = rowptr[i], hi = rowptr[i + 1];
+        const float di = dis[i];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = lo; s < hi; ++s) {
+            const int src = csr_src[s];
+            if (src == i) continue;
+            float4 v = xw[(int64_t)src * C4 + q];
+            if (P) {
+                const float4 pg = P[(int64_t)node_graph[src] * C4 + q];
+                v.x += pg.x; v.y += pg.y; v.z += pg.z; v.w += pg.w;
+            }
+            const float w = dis[src] * di;
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        float4 v = xw[(int64_t)i * C4 + q];
+        if (P) {
+            const float4 pg = P[(int64_t)node_graph[i] * C4 + q];
+            v.x += pg.x; v.y += pg.y; v.z += pg.z; v.w += pg.w;
+        }
+        const float w = di * di;
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        if (bias) {
+            const float4 b = bias[q];
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        out[it] = acc;
+    }
+}
+
 struct GineLayout { size_t z, y, tmp, P1, P2, total; };
 static GineLayout gine_layout(int64_t N, int64_t B, int Dn, int Di, int C) {
     GineLayout L; size_t off = 0;
@@ -300,8 +341,17 @@ int gvqa_gcn_conv_forward(const gvqa_graph* g, int32_t Dn, int32_t Di, int32_t C
     }
     StageTimer t(GVQA_STAGE_MP, stream);
     hipLaunchKernelGGL(k_gcn_dis, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, stream, (int)N, g->rowptr, g->csr_src, P(L.dis));
-    hipLaunchKernelGGL(k_gcn_aggregate, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, C, P(L.xw),
-                       Di > 0 ? P(L.P) : nullptr, P(L.dis), p->bias, g->rowptr, g->csr_src, g->node_graph, out);
+    const bool v4 = C % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!p->bias || (reinterpret_cast<uintptr_t>(p->bias) & 15) == 0);
+    if (v4) {
+        const int64_t items = N * (C / 4);
+        hipLaunchKernelGGL(k_gcn_aggregate_v4, dim3((unsigned)std::min<int64_t>(cdiv(items, 256), 256 * 32)), dim3(256), 0, stream, (int)N,
+                           C / 4, reinterpret_cast<const float4*>(P(L.xw)), Di > 0 ? reinterpret_cast<const float4*>(P(L.P)) : nullptr,
+                           P(L.dis), reinterpret_cast<const float4*>(p->bias), g->rowptr, g->csr_src, g->node_graph,
+                           reinterpret_cast<float4*>(out));
+    } else {
+        hipLaunchKernelGGL(k_gcn_aggregate, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, C, P(L.xw),
+                           Di > 0 ? P(L.P) : nullptr, P(L.dis), p->bias, g->rowptr, g->csr_src, g->node_graph, out);
+    }
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

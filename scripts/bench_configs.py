@@ -97,7 +97,10 @@ dt, _ = timed(lambda: m(x, ei, ea, ins, batch))
 res["config4_gine_module_as_written"] = {"ms": dt * 1e3}
 m = load(gcn_seq(300, 300, 512), synth.gcn_seq_params(300, 300, 512, 505))
 dt, prof = timed(lambda: m(x, ei, ins, batch, graph=g, return_convs=True))
-res["gcn_convs"] = {"ms_per_5_convs_plus_module": dt * 1e3, "stage_ms": {k: v[0] for k, v in prof.items()}}
+agg_ms, agg_n = prof["mp"]
+alg = 8 * N * 300 + 4 * E
+res["gcn_convs"] = {"ms_per_5_convs_plus_module": dt * 1e3, "aggregate_us_per_layer": agg_ms / agg_n * 1e3, "aggregate_alg_bytes": alg,
+                    "aggregate_GBps": alg / (agg_ms / agg_n * 1e-3) / 1e9, "stage_ms": {k: v[0] for k, v in prof.items()}}
 
 from graphvqa_amd.lcgn import lcgn_seq
 m = load(lcgn_seq(300, 512, 300, 5), synth.lcgn_seq_params(300, 512, seed=808))
