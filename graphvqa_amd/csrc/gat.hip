@@ -480,6 +480,35 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     float ar = a.a_node ? a.a_node[(int64_t)i * 2 * H + H + h] : 0.f;
     if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[i] * a.t_ld + a.C + h];
     float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int s = min(lo + e, hi - 1);
+            const bool on = lo + e < hi;
+            const int src = on ? a.csr_src[s] : 0;
+            eid[e] = on ? a.csr_eid[s] : 0;
+            const float t = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + a.a_edge[(int64_t)eid[e] * a.a_edge_stride + h] + ar;
+            v[e] = on ? leaky(t, a.slope) : -INFINITY;
+            m = fmaxf(m, v[e]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = lo + e < hi ? expf(v[e] - m) : 0.f;
+            sum += v[e];
+        }
+        const float den = sum + 1e-16f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (lo + e < hi) {
+                float al = v[e] / den;
+                if (a.alpha_out) a.alpha_out[(int64_t)eid[e] * H + h] = al;
+                if (a.alpha_mask) al *= a.alpha_mask[(int64_t)eid[e] * H + h];
+                a.alpha_csr[(int64_t)(lo + e) * H + h] = al;
+            }
+        }
+        return;
+    }
+    float m = -INFINITY;
     for (int s = lo; s < hi; ++s) {
         const float v = leaky((a.a_node ? a.a_node[(int64_t)a.csr_src[s] * 2 * H + h] : 0.f) +
                               a.a_edge[(int64_t)a.csr_eid[s] * a.a_edge_stride + h] + ar, a.slope);
@@ -502,8 +531,9 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
 }
 
 // attention coefficients of every edge in CSR slot order -> a.alpha_csr (and a.alpha_out in COO order)
-// (one thread per (node, head); a one-thread-per-node variant with all heads in registers and 16-byte accesses measured
-// SLOWER at config 3 -- 31 vs 25 us: a quarter of the threads, and the kernel is bound by its chain of dependent loads)
+// (one thread per (node, head), three passes through alpha_csr.  Measured SLOWER at config 3: one thread per node with all heads
+// in registers and 16-byte accesses -- 31 vs 25 us, a quarter of the threads; logits of short rows kept in registers, one
+// round of 8 clamped gathers instead of three dependent passes -- 34 vs 27 us)
 static int launch_alpha(const MpArgs& a, int H, hipStream_t stream) {
     hipLaunchKernelGGL(k_gat_alpha_general, dim3((unsigned)cdiv((int64_t)a.N * H, 256)), dim3(256), 0, stream, a, H);
     GVQA_LAUNCH_CHECK();

@@ -175,10 +175,19 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63);
     const int reg_words = al_off + ((fh.e_cap * Hh + 63) & ~63);
     const bool two_regions = EPI == 2 && 2 * reg_words * 4 <= 32 * 1024;
-    const int c4 = tid & (q4 - 1);
-    const int c = bn * cw + c4 * 4;                           // this thread's 4 output channels
-    const bool c_ok = EPI == 2 && c < fh.C;
-    float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bi;
+    // a thread of the epilogue owns CV adjacent channel quads (8 channels when the head slice is >= 64 wide: the edge loop is
+    // issue-bound, and its index / coefficient / address work is then shared by twice the FMAs) of `items` rows
+    constexpr int CV = (EPI == 2 && q4 >= 16) ? 2 : 1;
+    constexpr int lqv = lq - (CV == 2 ? 1 : 0);               // log2(lanes per row)
+    const int cq = tid & ((q4 / CV) - 1);
+    const int c = bn * cw + cq * CV * 4;                      // first of this thread's 4 CV output channels
+    bool c_ok[CV];
+    float4 bi[CV], sc[CV], sh[CV];
+#pragma unroll
+    for (int v = 0; v < CV; ++v) {
+        c_ok[v] = EPI == 2 && c + 4 * v < fh.C;
+        bi[v] = make_float4(0.f, 0.f, 0.f, 0.f); sh[v] = bi[v]; sc[v] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
     int g_ns[2] = {0, 0}, g_cnt[2] = {0, 0}, g_e0[2] = {0, 0}, g_ne[2] = {0, 0};
     // CSR slice + coefficients of a group -> LDS bytes [byte_base, ...) by LDS-DMA (4 bytes per lane: no alignment constraints);
     // every wave issues the same number of DMAs (lanes past the end re-load the last word into the padding)
@@ -197,14 +206,17 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             lds_dma4_b(al_g + min(u + lane, n_al - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(al_off + u) * 4u));
     };
     if constexpr (EPI == 2) {
-        if (c_ok) {
-            if (fh.bias) bi = *reinterpret_cast<const float4*>(fh.bias + c);
+#pragma unroll
+        for (int v = 0; v < CV; ++v) {
+            if (!c_ok[v]) continue;
+            const int cv = c + 4 * v;
+            if (fh.bias) bi[v] = *reinterpret_cast<const float4*>(fh.bias + cv);
             if (fh.bn_w) {          // torch's eval BatchNorm: y = x (w invstd) + (b - mean w invstd)
-                const float4 w4 = *reinterpret_cast<const float4*>(fh.bn_w + c), b4 = *reinterpret_cast<const float4*>(fh.bn_b + c);
-                const float4 m4 = *reinterpret_cast<const float4*>(fh.bn_m + c), v4 = *reinterpret_cast<const float4*>(fh.bn_v + c);
-                sc.x = w4.x * (1.0f / sqrtf(v4.x + fh.bn_eps)); sc.y = w4.y * (1.0f / sqrtf(v4.y + fh.bn_eps));
-                sc.z = w4.z * (1.0f / sqrtf(v4.z + fh.bn_eps)); sc.w = w4.w * (1.0f / sqrtf(v4.w + fh.bn_eps));
-                sh.x = b4.x - m4.x * sc.x; sh.y = b4.y - m4.y * sc.y; sh.z = b4.z - m4.z * sc.z; sh.w = b4.w - m4.w * sc.w;
+                const float4 w4 = *reinterpret_cast<const float4*>(fh.bn_w + cv), b4 = *reinterpret_cast<const float4*>(fh.bn_b + cv);
+                const float4 m4 = *reinterpret_cast<const float4*>(fh.bn_m + cv), v4 = *reinterpret_cast<const float4*>(fh.bn_v + cv);
+                sc[v].x = w4.x * (1.0f / sqrtf(v4.x + fh.bn_eps)); sc[v].y = w4.y * (1.0f / sqrtf(v4.y + fh.bn_eps));
+                sc[v].z = w4.z * (1.0f / sqrtf(v4.z + fh.bn_eps)); sc[v].w = w4.w * (1.0f / sqrtf(v4.w + fh.bn_eps));
+                sh[v].x = b4.x - m4.x * sc[v].x; sh[v].y = b4.y - m4.y * sc[v].y; sh[v].z = b4.z - m4.z * sc[v].z; sh[v].w = b4.w - m4.w * sc[v].w;
             }
         }
 #pragma unroll
@@ -304,18 +316,21 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             }
             // epilogue operands of this thread's rows (skip rows, graph ids) start their trip from HBM now, ahead of the LDS work
             constexpr int MAXIT = 4;
-            const int items = (128 << lq) / NTH;              // rows per thread: 128 q4 / 512
-            float4 sk[MAXIT];
+            const int items = (128 << lqv) / NTH;             // rows per thread: 128 (q4 / CV) / 512
+            float4 sk[MAXIT][CV];
             int gid[MAXIT];
             const bool pre = items <= MAXIT;
-            if (pre && live && c_ok) {
+            if (pre && live) {
 #pragma unroll
                 for (int k = 0; k < MAXIT; ++k) {
-                    const int i = (tid >> lq) + k * (NTH >> lq);
+                    const int i = (tid >> lqv) + k * (NTH >> lqv);
                     const bool on = k < items && i < cnt;
                     const int node = ns + (on ? i : 0);
                     gid[k] = fh.graph_term ? fh.node_graph[node] : 0;
-                    sk[k] = fh.skip ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int v = 0; v < CV; ++v)
+                        sk[k][v] = (fh.skip && c_ok[v]) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             if (live && wr == gi && !(fh.debug & 1)) {
@@ -339,31 +354,36 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 const int* src_l = rp_l + src_off;
                 const float* al_l = reinterpret_cast<const float*>(rp_l + al_off);
                 const float4* xs4 = reinterpret_cast<const float4*>(xs);
-                // one output row segment: node i of the group, channels [c, c + 4)
-                auto process = [&](int i_raw, bool have, int gq_pre, float4 sk_pre) {
+                // one output row segment: node i of the group, channels [c, c + 4 CV)
+                auto process = [&](int i_raw, bool have, int gq_pre, const float4 (&sk_pre)[CV]) {
                     const bool row_on = i_raw < cnt;
                     const int i = row_on ? i_raw : 0;
                     const int lo = rp_l[i] - e0, hi = (row_on && !(fh.debug & 2)) ? rp_l[i + 1] - e0 : lo;
                     const int node = ns + i;
-                    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (fh.graph_term && hi > lo && c_ok) {   // nodes without in-edges get no instruction term (empty softmax)
+                    float4 pb[CV];
+#pragma unroll
+                    for (int v = 0; v < CV; ++v) pb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (fh.graph_term && hi > lo) {           // nodes without in-edges get no instruction term (empty softmax)
                         const int gq = have ? gq_pre : fh.node_graph[node];
-                        pb = *reinterpret_cast<const float4*>(fh.graph_term + (int64_t)gq * fh.t_ld + c);
+#pragma unroll
+                        for (int v = 0; v < CV; ++v)
+                            if (c_ok[v]) pb[v] = *reinterpret_cast<const float4*>(fh.graph_term + (int64_t)gq * fh.t_ld + c + 4 * v);
                     }
                     // EB edges per trip, every LDS read of a trip issued before its FMAs; the trip count is made wave-uniform
                     // (clamped index, zero weight past the end of the row): a divergent, dependent-load loop was 4x slower
-                    constexpr int EB = Hh <= 2 ? 4 : Hh == 4 ? 2 : 1;      // 8 row reads (32 VGPRs) in flight per trip
-                    // the wave covers 64 / q4 consecutive rows: largest in-degree among them from wave-uniform LDS reads
-                    const int row0 = __builtin_amdgcn_readfirstlane(i_raw - (lane >> lq));
+                    constexpr int EB = (8 / (Hh * CV)) > 0 ? 8 / (Hh * CV) : 1;      // 8 row reads (32 VGPRs) in flight per trip
+                    // the wave covers 64 / (q4 / CV) consecutive rows: largest in-degree among them from wave-uniform LDS reads
+                    const int row0 = __builtin_amdgcn_readfirstlane(i_raw - (lane >> lqv));
                     int maxdeg = 0;
 #pragma unroll
-                    for (int r = 0; r < (64 >> lq); ++r) {
+                    for (int r = 0; r < (64 >> lqv); ++r) {
                         const int rr = min(row0 + r, cnt - 1);
                         maxdeg = max(maxdeg, rp_l[rr + 1] - rp_l[rr]);
                     }
                     const int trips = (fh.debug & 2) ? 0 : __builtin_amdgcn_readfirstlane((maxdeg + EB - 1) / EB);
-                    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    float4 b4 = a4;                            // second chain: the FMAs of edge slot 1 do not wait for slot 0's
+                    float4 a4[CV], b4[CV];                     // two chains per quad: consecutive FMAs do not wait for each other
+#pragma unroll
+                    for (int v = 0; v < CV; ++v) a4[v] = b4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
                     for (int tr = 0; tr < trips; ++tr) {
                         const int s0 = lo + tr * EB;
                         int se[EB];
@@ -390,43 +410,51 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                                 }
                             }
                         }
-                        float4 v[EB][Hh];
+                        float4 v[EB][Hh][CV];
 #pragma unroll
                         for (int e = 0; e < EB; ++e)
 #pragma unroll
-                            for (int h = 0; h < Hh; ++h) v[e][h] = xs4[se[e] * 64 + (((h << lq) + c4) ^ (se[e] & 7))];
+                            for (int h = 0; h < Hh; ++h)
+#pragma unroll
+                                for (int w = 0; w < CV; ++w) v[e][h][w] = xs4[se[e] * 64 + (((h << lq) + cq * CV + w) ^ (se[e] & 7))];
 #pragma unroll
                         for (int e = 0; e < EB; ++e)
 #pragma unroll
-                            for (int h = 0; h < Hh; ++h) {
-                                float4& t = (e & 1) ? b4 : a4;
-                                t.x += al[e][h] * v[e][h].x; t.y += al[e][h] * v[e][h].y;
-                                t.z += al[e][h] * v[e][h].z; t.w += al[e][h] * v[e][h].w;
-                            }
+                            for (int h = 0; h < Hh; ++h)
+#pragma unroll
+                                for (int w = 0; w < CV; ++w) {
+                                    float4& t = ((e * Hh + h) & 1) ? b4[w] : a4[w];
+                                    t.x += al[e][h] * v[e][h][w].x; t.y += al[e][h] * v[e][h][w].y;
+                                    t.z += al[e][h] * v[e][h][w].z; t.w += al[e][h] * v[e][h][w].w;
+                                }
                     }
-                    a4.x += b4.x; a4.y += b4.y; a4.z += b4.z; a4.w += b4.w;
-                    float4 r = make_float4(a4.x * inv_h + pb.x, a4.y * inv_h + pb.y, a4.z * inv_h + pb.z, a4.w * inv_h + pb.w);
-                    r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
-                    if (fh.skip && c_ok) {
-                        const float4 s4 = have ? sk_pre : *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c);
-                        r.x += s4.x; r.y += s4.y; r.z += s4.z; r.w += s4.w;
+#pragma unroll
+                    for (int w = 0; w < CV; ++w) {
+                        float4 r = make_float4((a4[w].x + b4[w].x) * inv_h + pb[w].x, (a4[w].y + b4[w].y) * inv_h + pb[w].y,
+                                               (a4[w].z + b4[w].z) * inv_h + pb[w].z, (a4[w].w + b4[w].w) * inv_h + pb[w].w);
+                        r.x += bi[w].x; r.y += bi[w].y; r.z += bi[w].z; r.w += bi[w].w;
+                        if (fh.skip && c_ok[w]) {
+                            const float4 s4 = have ? sk_pre[w] : *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * w);
+                            r.x += s4.x; r.y += s4.y; r.z += s4.z; r.w += s4.w;
+                        }
+                        if (relu) {
+                            r.x = fmaxf(r.x * sc[w].x + sh[w].x, 0.f); r.y = fmaxf(r.y * sc[w].y + sh[w].y, 0.f);
+                            r.z = fmaxf(r.z * sc[w].z + sh[w].z, 0.f); r.w = fmaxf(r.w * sc[w].w + sh[w].w, 0.f);
+                        }
+                        if (row_on && c_ok[w] && !(fh.debug & 4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
                     }
-                    if (relu) {
-                        r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
-                        r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
-                    }
-                    if (row_on && c_ok && !(fh.debug & 4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c) = r;
                 };
                 // (whole waves enter `process`: its trip count is a wave-wide maximum; rows past the group's end are masked inside)
                 if (pre) {
 #pragma unroll
                     for (int k = 0; k < MAXIT; ++k) {          // static indices: the prefetched operands stay in registers
-                        const int i = (tid >> lq) + k * (NTH >> lq);
-                        if (k < items && __builtin_amdgcn_readfirstlane(i - (lane >> lq)) < cnt) process(i, true, gid[k], sk[k]);
+                        const int i = (tid >> lqv) + k * (NTH >> lqv);
+                        if (k < items && __builtin_amdgcn_readfirstlane(i - (lane >> lqv)) < cnt) process(i, true, gid[k], sk[k]);
                     }
                 } else {
-                    for (int idx0 = __builtin_amdgcn_readfirstlane(tid & ~63); idx0 < (cnt << lq); idx0 += NTH)
-                        process((idx0 + lane) >> lq, false, 0, make_float4(0.f, 0.f, 0.f, 0.f));
+                    const float4 none[CV] = {};
+                    for (int idx0 = __builtin_amdgcn_readfirstlane(tid & ~63); idx0 < (cnt << lqv); idx0 += NTH)
+                        process((idx0 + lane) >> lqv, false, 0, none);
                 }
             }
         }
