@@ -480,35 +480,6 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     float ar = a.a_node ? a.a_node[(int64_t)i * 2 * H + H + h] : 0.f;
     if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[i] * a.t_ld + a.C + h];
     float m = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int s = min(lo + e, hi - 1);
-            const bool on = lo + e < hi;
-            const int src = on ? a.csr_src[s] : 0;
-            eid[e] = on ? a.csr_eid[s] : 0;
-            const float t = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + a.a_edge[(int64_t)eid[e] * a.a_edge_stride + h] + ar;
-            v[e] = on ? leaky(t, a.slope) : -INFINITY;
-            m = fmaxf(m, v[e]);
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = lo + e < hi ? expf(v[e] - m) : 0.f;
-            sum += v[e];
-        }
-        const float den = sum + 1e-16f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (lo + e < hi) {
-                float al = v[e] / den;
-                if (a.alpha_out) a.alpha_out[(int64_t)eid[e] * H + h] = al;
-                if (a.alpha_mask) al *= a.alpha_mask[(int64_t)eid[e] * H + h];
-                a.alpha_csr[(int64_t)(lo + e) * H + h] = al;
-            }
-        }
-        return;
-    }
-    float m = -INFINITY;
     for (int s = lo; s < hi; ++s) {
         const float v = leaky((a.a_node ? a.a_node[(int64_t)a.csr_src[s] * 2 * H + h] : 0.f) +
                               a.a_edge[(int64_t)a.csr_eid[s] * a.a_edge_stride + h] + ar, a.slope);
