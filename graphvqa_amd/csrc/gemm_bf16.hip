@@ -297,6 +297,103 @@ __global__ __launch_bounds__(256) void k_linear_bf16_dma(int M, int N, int K, in
     store_tile_transposed_b<C16>(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
 }
 
+// ---- wide LDS-DMA variant: 256 x 128 tile, 8 waves, ALL weight pieces of a K step resident together -----------------
+// The 128 x 128 kernel above walks the weight pieces as extra K range and re-loads the A tile for each: 15.6 bytes of
+// L2 -> LDS traffic per kFLOP, i.e. the whole 64 B/clk/CU of the L1 path at full MFMA rate -- it is staging-bound at 780 TF.
+// Here a K step brings the A tile ONCE (256 rows x 128 B) and the P piece tiles of W (P x 128 rows x 128 B); a wave (4 x 2
+// layout, 64 x 64 wave tile) reads 2 A + 2 P B fragments per 16-deep sub-step for 4 P MFMAs: 7.6 B/kFLOP at P = 2.  Same
+// XOR swizzle through the lanes' global addresses, same one-barrier-per-K-step ring of two LDS buffers, DMAs of the next step
+// issued between the MFMA groups, transposed accumulators -> register epilogue.
+template <bool C16, int P>
+__global__ __launch_bounds__(512) void k_linear_bf16_wide(int M, int N, int K, const uint16_t* __restrict__ A, int64_t lda,
+                                                          const uint16_t* __restrict__ B, int64_t ldb, LinearEpilogue ep,
+                                                          void* C_, int64_t ldc) {
+    constexpr int BM = 256, BN = 128, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;              // 32 KiB, 16 KiB per piece
+    constexpr int STAGE = A_BYTES + P * B_BYTES;
+    constexpr int NDMA = STAGE / 1024 / 8;                                   // DMA instructions per wave per K step
+    typedef typename std::conditional<C16, uint16_t, float>::type TC;
+    TC* C = static_cast<TC*>(C_);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA d of wave w covers stage rows-of-8 unit u = d * 8 + w: units [0, 32) are A rows, then 16 units per weight piece
+    const uint16_t* src[NDMA];
+    unsigned dst[NDMA];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) {
+        const int u = d * 8 + wave;
+        const bool isA = u < BM / 8;
+        const int ub = isA ? u : (u - BM / 8) % (BN / 8), piece = isA ? 0 : (u - BM / 8) / (BN / 8);
+        const int row = ub * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        src[d] = isA ? A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8
+                     : B + (int64_t)min(n0 + row, N - 1) * ldb + (int64_t)piece * K + chunk * 8;
+        dst[d] = lds_base + (unsigned)u * 1024u;
+    }
+    auto issue_one = [&](int buf, int d) {
+        lds_dma16_b(src[d], __builtin_amdgcn_readfirstlane(dst[d] + buf * STAGE));
+        src[d] += BK;
+    };
+
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    unsigned xo[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
+    const unsigned a_row = (unsigned)((wr * 64 + frow) * 128), b_row = (unsigned)(A_BYTES + (wc * 64 + frow) * 128);
+
+    const int nt = K / BK;
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) issue_one(0, d);
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < nt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            bf16x8 af[2], bf[P][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 128 + xo[kg]));
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bf[p][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + b_row + p * B_BYTES + j * 32 * 128 + xo[kg]));
+            // operands swapped (B fragment first): transposed accumulators, see store_tile_transposed_b
+#pragma unroll
+            for (int p = P - 1; p >= 0; --p) {                    // low-order piece first
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[p][j], af[i], acc[i][j], 0, 0, 0);
+                if (more) {                                       // the next step's DMAs, spread evenly over this step's 4 P MFMA groups
+#pragma unroll
+                    for (int d = 0; d < NDMA; ++d)
+                        if (d * (4 * P) / NDMA == kg * P + (P - 1 - p)) issue_one(cur ^ 1, d);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    store_tile_transposed_b<C16>(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
+}
+
 // Wpk[n, p*Kp + k] = p-th bf16 piece of W[n, k] (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the
 // remainder), zero for K <= k < Kp (K padded up to the GEMM's multiple of 8)
 __global__ __launch_bounds__(256) void k_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* __restrict__ W,
@@ -363,6 +460,20 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     static const bool no_dma = []() { const char* v = getenv("GVQA_BF16_GEMM"); return v && !strcmp(v, "regs"); }();
     // LDS-DMA staging: whole K steps, and the register epilogue's 4-column quads need aligned rows
     const bool quad_ok = N % 4 == 0 && vec_ep_quads;
+    static const bool no_wide = []() { const char* v = getenv("GVQA_BF16_GEMM"); return v && !strcmp(v, "narrow"); }();
+    // wide tile: whole K steps, a grid that fills the chip (>= 256 tiles of 256 x 128)
+    // (measured, MFMA rate at the LCGN shapes: two-piece weights 808-852 TF wide vs 715 narrow; single piece 506-557 wide vs
+    //  578-600 narrow -- without a second piece to share the A fragments the wide tile's longer block lifetime costs more)
+    if (P == 2 && K % 64 == 0 && !no_dma && !no_wide && quad_ok && cdiv(M, 256) * cdiv(N, 128) >= 256) {
+        dim3 gridw((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 256));
+#define GVQA_WIDE(C16_, P_) hipLaunchKernelGGL((k_linear_bf16_wide<C16_, P_>), gridw, dim3(512), 0, stream, (int)M, (int)N, (int)K, a, lda, b, \
+                                               (int64_t)P * K, ep, C, ldc)
+        if (c16) GVQA_WIDE(true, 2);
+        else GVQA_WIDE(false, 2);
+#undef GVQA_WIDE
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
     if (K % 64 == 0 && !no_dma && quad_ok) {
         if (c16) hipLaunchKernelGGL(k_linear_bf16_dma<true>, grid, dim3(256), 0, stream, (int)M, (int)N, (int)K, P, a, lda, b,
                                     (int64_t)P * K, ep, C, ldc);

@@ -143,7 +143,8 @@ def _bf16_pieces(W, pieces):
     return hi if pieces == 1 else hi + (W - hi).bfloat16().float()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (129, 100, 72), (1, 8, 8), (1000, 512, 512), (4100, 1536, 1024)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 64), (129, 100, 72), (1, 8, 8), (1000, 512, 512), (4100, 1536, 1024),
+                                   (8197, 1536, 1024), (33001, 516, 512)])      # the last two: the wide 256 x 128 kernel
 @pytest.mark.parametrize("pieces", [1, 2])
 def test_linear_bf16(dev, M, N, K, pieces):
     """k_linear_bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate) against fp64 on the SAME bf16 operands:
