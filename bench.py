@@ -91,8 +91,8 @@ def live_pmc_traffic():
     if exe is None:
         return {"error": "rocprofv3 not found"}
     import re
-    # the fused hop is the EPI = 2 instantiation (template arguments ..., EPI, heads), demangled or mangled
-    kinds = {"fused": lambda n: bool(re.search(r"k_linear_split3<[^>]*,\s*2,\s*[1248]>", n)) or bool(re.search(r"k_linear_split3.*ELi2ELi[1248]EEEv", n)),
+    # the fused hop is the EPI = 2 instantiation (template arguments ..., EPI, heads, pieces), demangled or mangled
+    kinds = {"fused": lambda n: bool(re.search(r"k_linear_split3<[^>]*,\s*2,\s*[1248],\s*[23]>", n)) or bool(re.search(r"k_linear_split3.*ELi2ELi[1248]ELi[23]EEEv", n)),
              "mp": lambda n: "k_gat_mp_tiled" in n}
     acc = {k: {} for k in kinds}
     try:
@@ -273,7 +273,14 @@ def main():
         hops = a.steps * K
         fused = prof["mp"][1] == 0 and prof["alpha"][1] > 0       # the default path: projection + aggregation in one kernel
         flops32 = 2 * N * D * H * D                                # folded projection flops per hop (fp32 equivalent)
-        split3 = prof["pack"][1] > 0
+        split = prof["pack"][1] > 0                                # a split projection ran (operand packing happened)
+        pieces = 2 if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H else 3
+        products = pieces * (pieces + 1) // 2                      # piece products kept: 3 of 4 (fp16 x 2) or 6 of 9 (bf16 x 3)
+        arith = {2: "fp32 operand rows scaled by a power of two and split into two fp16 pieces (22-23 significant bits), three fp16-MFMA "
+                    "piece products, fp32 accumulate; error vs fp64 not above the f32-input MFMA's (tests/test_gpu_split3.py), end to "
+                    "end <= 1e-4 vs the oracle",
+                 3: "fp32 operands split into three exact bf16 pieces, six bf16-MFMA piece products, fp32 accumulate (fp32 error class: "
+                    "tests/test_gpu_split3.py; end to end <= 1e-4 vs the oracle)"}[pieces]
 
         def mp_roofline(pr, graph):
             """HBM roofline of the message-passing kernel from a stage profile (unfused runs)."""
@@ -295,19 +302,21 @@ def main():
 
         proj_ms, proj_n = prof["proj"]
         if fused:
-            # dominant kernel: the fused hop (split3 projection + aggregation + epilogue), MFMA-bound.  Algorithmic work per
-            # launch = the six piece products of the folded projection (8(d)'s 2 N Dn H C, x 6) -- the aggregation's
+            # dominant kernel: the fused hop (split projection + aggregation + epilogue), MFMA-bound.  Algorithmic work per
+            # launch = the kept piece products of the folded projection (8(d)'s 2 N Dn H C, x 3 or x 6) -- the aggregation's
             # 2 E H C flops (0.4 %) are not counted.
             avg_s = proj_ms / max(proj_n, 1) * 1e-3
-            ach = 6 * flops32 / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": "gvqa::k_linear_split3<2,4,4,2,3,ILV,EPI=2> (fused hop: split3 projection, 256 x 256 tile, "
-                                               "GAT aggregation + skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)",
+            ach = products * flops32 / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": f"gvqa::k_linear_split3<2,4,4,2,NBUF={4 if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces}> (fused hop: "
+                                               f"{pieces}-piece split projection, 256 x 256 tile, GAT aggregation + skip/BN/ReLU epilogue out of "
+                                               "LDS; xp never reaches HBM)",
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
-                    "algorithmic_flops_per_launch": 6 * flops32, "fp32_equivalent_tflops": flops32 / avg_s / 1e12,
+                    "algorithmic_flops_per_launch": products * flops32, "fp32_equivalent_tflops": flops32 / avg_s / 1e12,
                     "fp32_equivalent_frac_of_f32_mfma_peak": flops32 / avg_s / 1e12 / 157.3,
-                    "algorithmic_bytes_per_launch": 6 * N * D + 2 * 4 * N * D + 4 * (E * H + E + N + 1),
+                    "algorithmic_bytes_per_launch": 2 * pieces * N * D + 2 * 4 * N * D + 4 * (E * H + E + N + 1),
                     "avg_launch_us": avg_s * 1e6, "launches": proj_n,
-                    "dtype_note": "peak = dense bf16 MFMA (MI355X_MICROARCH.md); operands are exact bf16 pieces of fp32 values, fp32 accumulate"}
+                    "dtype_note": "peak = dense 16-bit MFMA (bf16 = fp16 rate, MI355X_MICROARCH.md); operands are 16-bit pieces of fp32 "
+                                  "values, fp32 accumulate"}
         else:
             roof = mp_roofline(prof, g0)
         res = {
@@ -326,9 +335,7 @@ def main():
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step",
                        "hop": ("fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"
                                if fused else "projection GEMM, then the fused message-passing kernel (xp through HBM)"),
-                       "projection_arithmetic": "fp32 operands split into three exact bf16 pieces, six bf16-MFMA piece products, fp32 "
-                                                "accumulate (fp32 error class: tests/test_gpu_split3.py; end to end <= 1e-4 vs the oracle)"
-                       if split3 else "f32-input MFMA"},
+                       "projection_arithmetic": arith if split else "f32-input MFMA"},
             "roofline": roof,
             "stage_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
             "gemm_backend": lib.gvqa_gemm_backend().decode(),
@@ -337,8 +344,9 @@ def main():
             res["weak_value"], res["weak_ms_per_step"], res["weak_steps"] = weak["value"], weak["ms_per_step"], weak["steps"]
         if world == 1:
             if not a.no_extras:
-                # the same step (a) unfused: split3 projection + the message-passing kernel, whose HBM roofline the north star
-                # names; (b) on the f32-input MFMA kernels; (c) on the vendor library -- comparison legs, few steps each
+                # the same step (a) unfused: split projection + the message-passing kernel, whose HBM roofline the north star
+                # names; (b) fused on the other split arithmetic; (c) on the f32-input MFMA kernels; (d) on the vendor library --
+                # comparison legs, few steps each
                 full = runner(make_shard(0, 1))
                 gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
                 n_x = max(5, a.steps // 4)
@@ -346,7 +354,13 @@ def main():
                 old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 0)
                 t_u = timed(full, n_x, 2, _lib.prof_collect) / n_x
                 pu = _lib.prof_collect()
-                old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
+                _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+                other = _lib.PROJECTION_SPLIT3 if pieces == 2 else _lib.PROJECTION_SPLIT2H
+                old_p = _lib.set_option(_lib.OPT_PROJECTION, other)
+                t_o = timed(full, n_x, 2, _lib.prof_collect) / n_x
+                po = _lib.prof_collect()
+                _lib.set_option(_lib.OPT_HOP_FUSION, 0)
+                _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
                 t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
                 p32 = _lib.prof_collect()
                 _lib.set_option(_lib.OPT_VENDOR_GEMM, 1)
@@ -358,9 +372,14 @@ def main():
                 _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
                 per = lambda pr, k="proj": pr[k][0] / max(pr[k][1], 1) * 1e3
                 gemm_u = per(pu) - pu["pack"][0] / max(pu["proj"][1], 1) * 1e3
-                res["unfused_split3"] = {"hop": "gvqa::k_split3_pack + gvqa::k_linear_split3 + gvqa::k_gat_mp_tiled", "ms_per_step": t_u * 1e3,
-                                         "value": Eall / t_u, "projection_us_incl_pack": per(pu), "gemm_only_us": gemm_u,
-                                         "gemm_mfma_tflops": 6 * flops32 / (gemm_u * 1e-6) / 1e12}
+                res["unfused_split"] = {"hop": f"gvqa::k_split{'2h' if pieces == 2 else '3'}_pack + gvqa::k_linear_split3<...,NP={pieces}> + "
+                                               "gvqa::k_gat_mp_tiled", "ms_per_step": t_u * 1e3,
+                                        "value": Eall / t_u, "projection_us_incl_pack": per(pu), "gemm_only_us": gemm_u,
+                                        "gemm_mfma_tflops": products * flops32 / (gemm_u * 1e-6) / 1e12}
+                opieces = 5 - pieces
+                res["fused_other_split"] = {"projection": "three exact bf16 pieces, six products" if opieces == 3 else "two scaled fp16 pieces, three products",
+                                            "ms_per_step": t_o * 1e3, "value": Eall / t_o, "avg_launch_us": per(po),
+                                            "mfma_tflops": opieces * (opieces + 1) // 2 * flops32 / (per(po) * 1e-6) / 1e12}
                 if gfull is not None:
                     res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
                 res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma (+ gvqa::k_gat_mp_tiled)", "ms_per_step": t_f32 * 1e3,

@@ -16,7 +16,7 @@ GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, 
 STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack", "alpha")
 # gvqa_set_option keys / values (include/gvqa.h)
 OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION = 0, 1, 2, 3, 4
-PROJECTION_SPLIT3, PROJECTION_F32 = 0, 1
+PROJECTION_SPLIT3, PROJECTION_F32, PROJECTION_SPLIT2H = 0, 1, 2
 NUM_STAGES = len(STAGES)
 
 
@@ -169,6 +169,10 @@ PROTOTYPES = {
     "gvqa_split3_pack": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gvqa_linear_split3": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_split2h_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gvqa_split2h_pack": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "gvqa_linear_split2h": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_linear_f32_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -26,7 +26,8 @@ static std::once_flag g_opt_once;
 static void options_init() {
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
     const char* proj = getenv("GVQA_PROJ");
-    g_opt[GVQA_OPT_PROJECTION] = (proj && !strcmp(proj, "f32")) ? GVQA_PROJECTION_F32 : GVQA_PROJECTION_SPLIT3;
+    g_opt[GVQA_OPT_PROJECTION] = (proj && !strcmp(proj, "f32")) ? GVQA_PROJECTION_F32
+                               : (proj && !strcmp(proj, "split3")) ? GVQA_PROJECTION_SPLIT3 : GVQA_PROJECTION_SPLIT2H;
     const char* be = getenv("GVQA_GEMM_BACKEND");
     g_opt[GVQA_OPT_VENDOR_GEMM] = (be && !strcmp(be, "rocblas")) ? 1 : 0;
     g_opt[GVQA_OPT_SPLIT3_MIN_MFLOP] = env_int("GVQA_SPLIT3_MIN_MFLOP", 1000);

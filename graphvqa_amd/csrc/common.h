@@ -123,23 +123,25 @@ struct FusedHopArgs {
     int H, C, cw;               // cw = 256 / H channels of every head per column block
     int e_cap;                  // LDS capacity in edges per row group
     float bn_eps;
+    int xcd_cols;               // column blocks per XCD of the workgroup -> tile map (1: plain launch order)
     int debug;                  // measurement aid (GVQA_FUSED_DEBUG bit mask): 1 no row image, 2 no aggregation, 4 no store, 8 no epilogue at all
 };
-size_t split3_packed_rows_bytes(int64_t row_tiles, int64_t K);
+// fp32-accurate projection from split operands on the 16-bit matrix cores (split3.hip); np = pieces per value:
+// 3 = three bf16 pieces (exact split, six products), 2 = two scaled fp16 pieces (2^-22 split, three products)
+size_t split_packed_rows_bytes(int np, int64_t row_tiles, int64_t K);
 // Vn / J / a_node: NULL / 0 / NULL, or the folded attention vectors [J = 2 H, K]: a_node[N, J] = X . Vn^T is produced on the way
-bool split3_pack_groups_logits_supported(int J, int64_t K);
-int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
-                              const float* Vn, int J, float* a_node, hipStream_t stream);
-int launch_split3_pack_heads(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
-int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
+bool split_pack_groups_logits_supported(int np, int J, int64_t K);
+int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
+                             const float* Vn, int J, float* a_node, hipStream_t stream);
+int launch_split_pack_heads(int np, int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
+int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
 size_t hop_fused_lds_edge_capacity(int H);
 
-// fp32-accurate projection from three-piece bf16 splits on the bf16 matrix cores (split3.hip)
-size_t split3_packed_bytes(int64_t rows, int64_t K);
-int launch_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);
+size_t split_packed_bytes(int np, int64_t rows, int64_t K);
+int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
-int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
-                         int64_t ldc, hipStream_t stream);
+int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
+                        int64_t ldc, hipStream_t stream);
 const char* gemm_backend_name();
 
 }  // namespace gvqa

@@ -717,26 +717,35 @@ int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
 // Drivers
 // ==============================================================================================
 // Projection arithmetic of the hop GEMM xp = h . W_h^T (gat_skip.py:133), GVQA_OPT_PROJECTION:
-//   split3 (default)  fp32-accurate three-piece bf16 split on the bf16 matrix cores (split3.hip)
+//   split2h           two scaled fp16 pieces per value, three fp16-MFMA products (split3.hip)
+//   split3            three exact bf16 pieces per value, six bf16-MFMA products (split3.hip)
 //   f32               f32-input MFMA (k_linear_f32*; rocBLAS only when GVQA_OPT_VENDOR_GEMM asks for it)
 // Products too small to fill the chip stay on the f32 kernels (the pack passes would not pay).
-static bool proj_use_split3(int64_t M, int64_t N, int64_t K) {
-    return get_option(GVQA_OPT_PROJECTION) == GVQA_PROJECTION_SPLIT3 && N % 4 == 0 &&
-           2.0 * (double)M * (double)N * (double)K >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
+// Returns the pieces per value of the split projection (2 / 3), or 0 for the f32 kernels.
+static int proj_pieces(int64_t M, int64_t N, int64_t K) {
+    const int mode = get_option(GVQA_OPT_PROJECTION);
+    if (mode == GVQA_PROJECTION_F32 || N % 4 != 0 ||
+        2.0 * (double)M * (double)N * (double)K < 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP))
+        return 0;
+    return mode == GVQA_PROJECTION_SPLIT2H ? 2 : 3;
 }
+// weight-cache layout id: -1 no packed projection weights; bit 0: head-interleaved rows (fused hop) instead of plain row order;
+// bit 1: two fp16 pieces instead of three bf16 pieces
+static int weight_layout_id(int pieces, bool heads) { return pieces == 0 ? -1 : (heads ? 1 : 0) | (pieces == 2 ? 2 : 0); }
+static int layout_pieces(int layout) { return layout < 0 ? 0 : (layout & 2) ? 2 : 3; }
 
 // Fused hop (projection + aggregation in one kernel, split3.hip): needs the split3 projection, a row-group plan (every
 // graph <= 128 nodes, intra-graph batch), H dividing 256 and the largest row group's edges within the kernel's LDS budget.
 static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int H = d->heads, C = d->out_channels;
-    return get_option(GVQA_OPT_HOP_FUSION) != 0 && proj_use_split3(g->num_nodes, (int64_t)H * C, d->node_dim) &&
+    return get_option(GVQA_OPT_HOP_FUSION) != 0 && proj_pieces(g->num_nodes, (int64_t)H * C, d->node_dim) != 0 &&
            g->num_row_groups > 0 && g->row_group_ptr && (H == 1 || H == 2 || H == 4 || H == 8) && C % 4 == 0 &&
            (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H);
 }
 
 // ---- weight cache: everything a forward derives from the PARAMETERS alone (folded attention vectors Vn / Ve, per-graph
 // term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
-// not change.  layout: -1 no packed projection weights, 0 plain row order (k_linear_split3), 1 head-interleaved (fused hop).
+// not change.  layout: see weight_layout_id.
 struct WeightCacheLayout {
     size_t Vn, Ve, Gw, w6, w6_hop, total;
 };
@@ -748,8 +757,9 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.Vn = take(K * 2 * H * d->node_dim * sizeof(float));
     W.Ve = take(K * H * d->edge_dim * sizeof(float));
     W.Gw = take(K * (C + H) * (size_t)d->ins_dim * sizeof(float));
-    W.w6_hop = layout == 1 ? split3_packed_rows_bytes(cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
-             : layout == 0 ? split3_packed_bytes((int64_t)(H * C), d->node_dim) : 0;
+    const int np = layout_pieces(layout);
+    W.w6_hop = layout < 0 ? 0 : (layout & 1) ? split_packed_rows_bytes(np, cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
+                                             : split_packed_bytes(np, (int64_t)(H * C), d->node_dim);
     W.w6 = take(K * W.w6_hop);
     W.total = off;
     return W;
@@ -769,7 +779,8 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     };
     const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
     const bool fused = g && hop_fusion_applies(g, d);
-    const int w_layout = fused ? 1 : proj_use_split3(N, (int64_t)(H * C), d->node_dim) ? 0 : -1;
+    const int np = proj_pieces(N, (int64_t)(H * C), d->node_dim);
+    const int w_layout = weight_layout_id(np, fused);
     L.Vn = take(weight_cache_layout(d, w_layout).total / sizeof(float));     // Vn | Ve | Gw | packed projection weights
     L.Ve = L.Gw = L.Vn;
     L.T = take(K * B * align_up(C + H, 4));
@@ -781,8 +792,8 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.alpha_csr = take((size_t)E * H);
     L.bn_partial = take(gvqa_bn_train_workspace_bytes(N > 0 ? N : 1, C) / sizeof(float) + 1);
     L.bn_stats = take(2 * C);
-    if (fused) L.a6 = take(split3_packed_rows_bytes((int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float));   // row-group slots
-    else if (w_layout == 0) L.a6 = take(split3_packed_bytes(N, d->node_dim) / sizeof(float));
+    if (fused) L.a6 = take(split_packed_rows_bytes(np, (int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float));   // row-group slots
+    else if (np) L.a6 = take(split_packed_bytes(np, N, d->node_dim) / sizeof(float));
     else L.a6 = off;
     L.w6 = L.Vn;
     L.total = off;
@@ -925,7 +936,7 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
     auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     const int H = d->heads, C = d->out_channels;
 
-    const WeightCacheLayout WL = weight_cache_layout(d, proj_use_split3(N, (int64_t)d->heads * d->out_channels, d->node_dim) ? 0 : -1);
+    const WeightCacheLayout WL = weight_cache_layout(d, weight_layout_id(proj_pieces(N, (int64_t)d->heads * d->out_channels, d->node_dim), false));
     float* Vn1 = reinterpret_cast<float*>(base + L.Vn + WL.Vn);
     float* Ve1 = reinterpret_cast<float*>(base + L.Vn + WL.Ve);
     rc = run_fold(d, p, Vn1, Ve1, nullptr, stream);
@@ -965,8 +976,9 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
         StageTimer t(GVQA_STAGE_PACK, stream);
         for (int i = 0; i < K; ++i) {
             GVQA_REQUIRE(hops[i].lin_l_weight, GVQA_E_INVALID, "gat: hop %d has a null weight", i);
-            rc = layout == 1 ? launch_split3_pack_heads(H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
-                             : launch_split3_pack((int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream);
+            const int np = layout_pieces(layout);
+            rc = (layout & 1) ? launch_split_pack_heads(np, H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
+                              : launch_split_pack(np, (int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream);
             if (rc) return rc;
         }
     }
@@ -1001,10 +1013,11 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     SideStream* ss = side_stream();
     hipStream_t aux = ss ? ss->stream : stream;
     if (ss) { rc = side_fork(ss, stream); if (rc) return rc; }
-    const bool split = proj_use_split3(N, (int64_t)H * C, Dn);
+    const int np = proj_pieces(N, (int64_t)H * C, Dn);
+    const bool split = np != 0;
     const bool fused = hop_fusion_applies(g, d);
     const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
-    const int need_layout = fused ? 1 : split ? 0 : -1;
+    const int need_layout = weight_layout_id(np, fused);
     // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
     // now into the workspace (the workspace slices have exactly the cache's sub-layout)
     const WeightCacheLayout WL = weight_cache_layout(d, need_layout);
@@ -1043,13 +1056,13 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         else if (i == K - 1) h_next = out;
         else h_next = (i & 1) ? P(L.h1) : P(L.h0);
         if (ss && i > 0) { rc = side_fork(ss, stream); if (rc) return rc; }     // h of this hop is ready on `stream`
-        const bool logits_in_pack = fused && split3_pack_groups_logits_supported(2 * H, Dn);
+        const bool logits_in_pack = fused && split_pack_groups_logits_supported(np, 2 * H, Dn);
         if (logits_in_pack) {
             // row-group slots of h for the fused hop AND (a_l | a_r) = h . [V_l | V_r] in one pass over h
             if (ss) { rc = side_join(ss, stream); if (rc) return rc; }      // Vn comes from the fold on the side stream (hop 0)
             StageTimer tp(GVQA_STAGE_PACK, stream);
-            rc = launch_split3_pack_groups(g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, Vn_all + (int64_t)i * 2 * H * Dn, 2 * H,
-                                           P(L.a_node), stream);
+            rc = launch_split_pack_groups(np, g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, Vn_all + (int64_t)i * 2 * H * Dn, 2 * H,
+                                          P(L.a_node), stream);
             if (rc) return rc;
         } else {   // (a_l | a_r) node halves = h . [V_l | V_r]     (side stream)
             StageTimer t(GVQA_STAGE_NODE_LOGIT, aux);
@@ -1076,7 +1089,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             }
             if (!logits_in_pack) {
                 StageTimer tp(GVQA_STAGE_PACK, stream);
-                rc = launch_split3_pack_groups(g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, nullptr, 0, nullptr, stream);
+                rc = launch_split_pack_groups(np, g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, nullptr, 0, nullptr, stream);
                 if (rc) return rc;
             }
             FusedHopArgs f;
@@ -1092,7 +1105,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             f.H = H; f.C = C; f.cw = fcw; f.e_cap = g->max_row_group_edges; f.bn_eps = d->bn_eps;
             {
                 StageTimer t(GVQA_STAGE_PROJ, stream);
-                rc = launch_hop_fused_split3(Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
+                rc = launch_hop_fused_split(np, Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
                 if (rc) return rc;
             }
             if (train_bn) {
@@ -1109,11 +1122,11 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             if (split) {
                 {
                     StageTimer tp(GVQA_STAGE_PACK, stream);
-                    rc = launch_split3_pack(N, Dn, h, Dn, a6, stream);
+                    rc = launch_split_pack(np, N, Dn, h, Dn, a6, stream);
                     if (rc) return rc;
                 }
                 LinearEpilogue ep0{nullptr, nullptr, 0, nullptr, 0, 0};
-                rc = launch_linear_split3(N, (int64_t)H * C, Dn, a6, w6 + (size_t)i * w6_hop, ep0, P(L.xp), (int64_t)H * C, stream);
+                rc = launch_linear_split(np, N, (int64_t)H * C, Dn, a6, w6 + (size_t)i * w6_hop, ep0, P(L.xp), (int64_t)H * C, stream);
                 if (rc) return rc;
             } else {
                 rc = launch_linear(N, (int64_t)H * C, Dn, h, Dn, hops[i].lin_l_weight, Dn + Di, nullptr, 0, P(L.xp),
@@ -1156,14 +1169,13 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
 }
 
 size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout) {
-    if (!d || check_dims(d, true) || layout < -1 || layout > 1) return 0;
+    if (!d || check_dims(d, true) || layout < -1 || layout > 3) return 0;
     return weight_cache_layout(d, layout).total;
 }
 
 int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true)) return -1;
-    if (hop_fusion_applies(g, d)) return 1;
-    return proj_use_split3(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) ? 0 : -1;
+    return weight_layout_id(proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), hop_fusion_applies(g, d));
 }
 
 int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
@@ -1171,7 +1183,7 @@ int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_par
     GVQA_REQUIRE(hops && cache, GVQA_E_INVALID, "gat_seq_prepare_weights: null argument");
     int rc = check_dims(d, true);
     if (rc) return rc;
-    GVQA_REQUIRE(layout >= -1 && layout <= 1, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1, 0 or 1");
+    GVQA_REQUIRE(layout >= -1 && layout <= 3, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1 .. 3");
     GVQA_REQUIRE(cache_bytes >= weight_cache_layout(d, layout).total, GVQA_E_WORKSPACE, "gat_seq_prepare_weights: cache too small");
     GVQA_REQUIRE((reinterpret_cast<uintptr_t>(cache) & 255) == 0, GVQA_E_INVALID, "gat_seq_prepare_weights: cache must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);

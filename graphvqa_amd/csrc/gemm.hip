@@ -449,8 +449,11 @@ const char* gemm_backend_name() {
         return "OPT-IN vendor: rocblas for plain fp32 products >= 2 GFLOP (GVQA_OPT_VENDOR_GEMM); gvqa kernels otherwise";
     if (get_option(GVQA_OPT_PROJECTION) == GVQA_PROJECTION_F32)
         return "gvqa::k_linear_f32_dma / gvqa::k_linear_f32 (hand-written f32-input MFMA; GVQA_OPT_PROJECTION = f32)";
-    return "gvqa::k_linear_split3 (hand-written: fp32 as three exact bf16 pieces, six bf16-MFMA products, fp32 accumulate) "
-           "for the hop projections; gvqa::k_linear_f32* (f32-input MFMA) for every other product";
+    if (get_option(GVQA_OPT_PROJECTION) == GVQA_PROJECTION_SPLIT3)
+        return "gvqa::k_linear_split3<..., NP=3> (hand-written: fp32 as three exact bf16 pieces, six bf16-MFMA products, fp32 accumulate) "
+               "for the hop projections; gvqa::k_linear_f32* (f32-input MFMA) for every other product";
+    return "gvqa::k_linear_split3<..., NP=2> (hand-written: fp32 rows as two scaled fp16 pieces, three fp16-MFMA products, fp32 "
+           "accumulate) for the hop projections; gvqa::k_linear_f32* (f32-input MFMA) for every other product";
 }
 
 // C[m, :] = bias (the beta = 1 operand of a vendor GEMM with a bias-only epilogue)

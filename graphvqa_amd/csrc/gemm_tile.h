@@ -135,6 +135,17 @@ __device__ __forceinline__ void lds_dma16_x3(const void* gsrc, unsigned lds_dst)
         : "memory");
 }
 
+// the same for two fragments (the two fp16 pieces of split2h)
+__device__ __forceinline__ void lds_dma16_x2(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 // 4 bytes per lane: LDS byte address `lds_dst` + lane * 4 (no alignment requirement beyond 4 bytes on either side)
 __device__ __forceinline__ void lds_dma4_b(const void* gsrc, unsigned lds_dst) {
     unsigned keep;

@@ -38,6 +38,15 @@
 namespace gvqa {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int NP> struct SplitFrag { typedef bf16x8_t type; };
+template <> struct SplitFrag<2> { typedef f16x8_t type; };
+__device__ __forceinline__ f32x16 split_mfma(const bf16x8_t& a, const bf16x8_t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 split_mfma(const f16x8_t& a, const f16x8_t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 // round-to-nearest-even bf16 of a finite fp32; values that would round up to infinity are truncated
 // instead, inf / nan keep their top 16 bits (the remaining pieces are then garbage-in / garbage-out)
@@ -105,15 +114,22 @@ __device__ __forceinline__ void keep_live(const f32x16& v) {
 }
 // STAG > 0: blocks that share a CU (dispatch rounds of 256 blocks) start `stagger` x 8128 cycles apart, so that one
 // block's C stores fall under its neighbours' main loops instead of every CU storing at the same time.
-template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0>
-__global__ __launch_bounds__(64 * WM * WN, (160 * 1024 / (NBUF * (WM * TM + WN * TN) * 3072)) * WM * WN / 4)
+// NP: pieces per operand value -- 3: bf16 x 3 (six products), 2: scaled fp16 x 2 (three products; a_inv / b_inv = the rows'
+// inverse power-of-two scales, applied to the accumulators before anything else in every epilogue)
+template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3>
+__global__ __launch_bounds__(64 * WM * WN, (160 * 1024 / (NBUF * (WM * TM + WN * TN) * NP * 1024)) * WM * WN / 4)
 void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int rtA,
                                                                const uint16_t* __restrict__ Bpk, int rtB, LinearEpilogue ep,
-                                                               float* __restrict__ C, int64_t ldc, int stagger, FusedHopArgs fh) {
+                                                               float* __restrict__ C, int64_t ldc, int stagger, FusedHopArgs fh,
+                                                               const float* __restrict__ a_inv, const float* __restrict__ b_inv) {
+    static_assert(NP == 2 || NP == 3, "two fp16 pieces or three bf16 pieces");
     constexpr int NW = WM * WN;
     constexpr int FA = WM * TM, FB = WN * TN;          // 32-row operand tiles per block: A rows, B rows (= C columns)
-    constexpr int STAGE = (FA + FB) * 3072;            // bytes per K step: 3 pieces x 1 KiB per operand tile
-    constexpr int TPW = (FA + FB) / NW;                // (tile, 3 pieces) triples each wave DMAs per K step
+    constexpr int FRAG = NP * 1024;                    // bytes of one (tile, K step): NP pieces x 1 KiB
+    constexpr int STAGE = (FA + FB) * FRAG;            // bytes per K step
+    constexpr int NG = NP * (NP + 1) / 2;              // piece products kept per K step
+    constexpr int TPW = (FA + FB) / NW;                // (tile, NP pieces) groups each wave DMAs per K step
+    typedef typename SplitFrag<NP>::type frag_t;
     static_assert((FA + FB) % NW == 0, "operand tiles must divide over the waves");
     static_assert(NBUF * STAGE <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static_assert(EPI != 2 || (WM == 2 && WN == 4 && TM == 4 && TN == 2), "the fused-hop epilogue is written for the 256 x 256 tile");
@@ -122,7 +138,17 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    const int bm = blockIdx.y, bn = blockIdx.x;
+    int bm = blockIdx.y, bn = blockIdx.x;
+    if (EPI == 2 && fh.xcd_cols > 1) {
+        // Workgroup w of the launch order runs on XCD w % 8 (each XCD has its own L2).  With the plain order the 8 column blocks
+        // of a row block sit on 8 different XCDs and every L2 streams the whole A operand; here XCD x owns `xcd_cols` column
+        // blocks (whose weights stay in its L2) of every (8 / column groups)-th row block, consecutive workgroups of an XCD
+        // walking the column blocks of one row block.
+        const int w = blockIdx.y * gridDim.x + blockIdx.x, x = w & 7, j = w >> 3;
+        const int ncg = gridDim.x / fh.xcd_cols, cg = x % ncg, rg = x / ncg;
+        bn = cg * fh.xcd_cols + j % fh.xcd_cols;
+        bm = (j / fh.xcd_cols) * (8 / ncg) + rg;
+    }
     const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
     if (STAG > 0) {
         const int slot = ((blockIdx.y * gridDim.x + blockIdx.x) >> 8) % STAG;
@@ -146,21 +172,22 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const int t = wave + q * NW;
         const bool isA = t < FA;
         const int tile = isA ? min(bm * FA + t, rtA - 1) : min(bn * FB + (t - FA), rtB - 1);
-        src[q] = (isA ? Apk : Bpk) + (int64_t)tile * KB * 1536 + lane * 8;
-        dst[q] = lds_base + t * 3072;
+        src[q] = (isA ? Apk : Bpk) + (int64_t)tile * KB * (NP * 512) + lane * 8;
+        dst[q] = lds_base + t * FRAG;
     }
-    // one (tile, k step) = three 1 KiB fragments contiguous in global memory and in the LDS stage: ONE M0 set-up, three DMAs
+    // one (tile, k step) = NP 1 KiB fragments contiguous in global memory and in the LDS stage: ONE M0 set-up, NP DMAs
     auto issue_triple = [&](int buf, int q) {
-        lds_dma16_x3(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
-        src[q] += 1536;
+        if constexpr (NP == 3) lds_dma16_x3(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
+        else lds_dma16_x2(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
+        src[q] += NP * 512;
     };
     auto issue = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < TPW; ++q) issue_triple(buf, q);
     };
 
-    const unsigned a_off = (unsigned)(wr * TM * 3072 + lane * 16);
-    const unsigned b_off = (unsigned)((FA + wc * TN) * 3072 + lane * 16);
+    const unsigned a_off = (unsigned)(wr * TM * FRAG + lane * 16);
+    const unsigned b_off = (unsigned)((FA + wc * TN) * FRAG + lane * 16);
 
     // ---- fused hop (EPI == 2): per-block constants, row-group metadata and the first group's CSR slice start their trips
     // from HBM before the main loop (their latency hides under it); see the epilogue below ------------------------------
@@ -232,6 +259,13 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         // older than every ring DMA: the counted waits of the main loop only get stricter by them, never wrong
         if (two_regions && g_cnt[0] > 0 && !(fh.debug & 8)) dma_region(0, 144 * 1024);
     }
+    // two-piece operands: inverse scales of this wave's rows x the column block's single weight scale (k_split2h_pack, HEADS)
+    float sab[TM];
+    if constexpr (EPI == 2 && NP == 2) {
+        const float sbu = b_inv[bn * 256];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) sab[i] = a_inv[(bm * FA + wr * TM + i) * 32 + (lane & 31)] * sbu;
+    }
 
     // prologue: NBUF - 1 steps in flight
 #pragma unroll
@@ -241,13 +275,14 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     // (measurement aid, STAG == 0 only: `stagger` bits 16 / 32 / 64 = no fragment reads after step 0 / no DMA in the loop /
     //  no waits and barriers -- wrong results; scripts/bench_split3_loop.py prices the parts of a K step with them)
     const int dbg = STAG == 0 ? stagger : 0;
-    bf16x8_t af[TM][3], bfr[TN][3];
+    static_assert(NBUF <= 4, "the counted waits below know at most two steps in flight behind the current one");
+    frag_t af[TM][NP], bfr[TN][NP];
     for (int s = 0; s < KB; ++s) {
         if (!(dbg & 64)) {
-            // steps s+1 .. s+NBUF-2 may stay in flight (3 TPW DMAs each); near the end fewer were issued
+            // steps s+1 .. s+NBUF-2 may stay in flight (NP TPW DMAs each); near the end fewer were issued
             const int ahead = min(NBUF - 2, KB - 1 - s);
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 3 * TPW) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TPW) : "memory");
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * TPW) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * TPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -258,24 +293,28 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    af[i][p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + a_off + (i * 3 + p) * 1024));
+                for (int p = 0; p < NP; ++p)
+                    af[i][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + a_off + (i * NP + p) * 1024));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bfr[j][p] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sb + b_off + (j * 3 + p) * 1024));
+                for (int p = 0; p < NP; ++p)
+                    bfr[j][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + b_off + (j * NP + p) * 1024));
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
         // smallest cross terms first, a1 b1 last; consecutive MFMAs hit different accumulators
 #define GVQA_S3_PAIR(pa_, pb_, g_)                                                                                 \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j][pb_], af[i][pa_], acc[i][j], 0, 0, 0);      \
+            acc[i][j] = split_mfma(bfr[j][pb_], af[i][pa_], acc[i][j]);                                            \
         if (ILV && more) {                                                                                         \
-            _Pragma("unroll") for (int q = (g_) * TPW / 6 + ((g_) * TPW % 6 ? 1 : 0); q * 6 < ((g_) + 1) * TPW; ++q)    \
-                if (q * 6 >= (g_) * TPW) issue_triple(pf, q);                                                      \
+            _Pragma("unroll") for (int q = (g_) * TPW / NG + ((g_) * TPW % NG ? 1 : 0); q * NG < ((g_) + 1) * TPW; ++q) \
+                if (q * NG >= (g_) * TPW) issue_triple(pf, q);                                                     \
         }
-        GVQA_S3_PAIR(2, 0, 0) GVQA_S3_PAIR(1, 1, 1) GVQA_S3_PAIR(0, 2, 2) GVQA_S3_PAIR(1, 0, 3) GVQA_S3_PAIR(0, 1, 4) GVQA_S3_PAIR(0, 0, 5)
+        if constexpr (NP == 3) {
+            GVQA_S3_PAIR(2, 0, 0) GVQA_S3_PAIR(1, 1, 1) GVQA_S3_PAIR(0, 2, 2) GVQA_S3_PAIR(1, 0, 3) GVQA_S3_PAIR(0, 1, 4) GVQA_S3_PAIR(0, 0, 5)
+        } else {
+            GVQA_S3_PAIR(1, 0, 0) GVQA_S3_PAIR(0, 1, 1) GVQA_S3_PAIR(0, 0, 2)
+        }
 #undef GVQA_S3_PAIR
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         buf = buf + 1 == NBUF ? 0 : buf + 1;
@@ -343,8 +382,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                         for (int q = 0; q < 4; ++q) {
                             const int r = i * 32 + m;
                             const int chunk = wc * 16 + j * 8 + 2 * q + hh;
-                            *reinterpret_cast<float4*>(xs + r * 256 + ((chunk ^ (r & 7)) << 2)) =
-                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                            float4 t = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                            if constexpr (NP == 2) { t.x *= sab[i]; t.y *= sab[i]; t.z *= sab[i]; t.w *= sab[i]; }
+                            *reinterpret_cast<float4*>(xs + r * 256 + ((chunk ^ (r & 7)) << 2)) = t;
                         }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs (and prefetches) have landed
@@ -461,6 +501,11 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         return;
     }
     auto finish = [&](float4 v, int gr, int gc) {      // bias / addend / mul / activation on 4 consecutive columns, then the store
+        if constexpr (NP == 2) {                       // undo the operands' power-of-two scales (exact)
+            const float sa = a_inv[gr];
+            const float4 sb = *reinterpret_cast<const float4*>(b_inv + gc);
+            v.x = v.x * sa * sb.x; v.y = v.y * sa * sb.y; v.z = v.z * sa * sb.z; v.w = v.w * sa * sb.w;
+        }
         if (ep.bias) {
             const float4 b4 = *reinterpret_cast<const float4*>(ep.bias + gc);
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
@@ -530,16 +575,242 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     }
 }
 
-size_t split3_packed_bytes(int64_t rows, int64_t K) { return (size_t)cdiv(rows, 32) * (size_t)cdiv(K, 16) * 3072; }
+// packed operand of `row_tiles` 32-row tiles: the fragments, then (two-piece form) one inverse scale per row
+size_t split_packed_rows_bytes(int np, int64_t row_tiles, int64_t K) {
+    return (size_t)row_tiles * (size_t)cdiv(K, 16) * (size_t)np * 1024 + (np == 2 ? (size_t)row_tiles * 32 * sizeof(float) : 0);
+}
+size_t split_packed_bytes(int np, int64_t rows, int64_t K) { return split_packed_rows_bytes(np, cdiv(rows, 32), K); }
+static const float* split2h_inv_scales(const void* packed, int64_t row_tiles, int KB) {
+    return reinterpret_cast<const float*>(static_cast<const char*>(packed) + (size_t)row_tiles * KB * 2048);
+}
 
-int launch_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream) {
-    GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split3_pack: bad size");
+
+// ---- two-piece form ("split2h"): fp32 value x of a row with largest magnitude m is carried as two fp16 pieces of
+// x 2^e, e = 13 - floor(log2 m) (the row's largest magnitude lands in [2^13, 2^14): no overflow, and 27 binades of fp16
+// below it): p1 = RN16(x 2^e), p2 = RN16(x 2^e - p1).  |x 2^e - p1 - p2| <= 2^-22 |x 2^e| (2^-23 typical) while p2 is a
+// normal fp16, <= 2^-25 in absolute terms (2^-38 of the row's largest magnitude) below that.  A dot product keeps
+// p1 q1 + p1 q2 + p2 q1 (exact products, fp32 accumulation by `v_mfma_f32_32x32x16_f16`); the dropped p2 q2 is <= 2^-22 |x y|.
+// Against fp64 the result is as close as the k-ordered fp32 chain of the f32 MFMA or three-piece bf16 (whose errors are the
+// fp32 accumulation's, tests/test_gpu_split3.py) at half the matrix-core work of the latter.  The inverse scale 2^-e of every
+// row is stored behind the fragments and applied (exactly) to the accumulators.
+__device__ __forceinline__ int split2h_exponent(float rowmax) {
+    if (!(rowmax > 0.f) || !(rowmax <= 3.0e38f)) return 0;           // zero rows; inf / nan rows are garbage-in / garbage-out
+    int e;
+    frexpf(rowmax, &e);                                               // rowmax = f 2^e, f in [0.5, 1)
+    return max(-114, min(126, 14 - e));                               // 2^e and 2^-e are normal fp32 numbers
+}
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+__device__ __forceinline__ void split2h_store(const float (&v)[8], float scale, uint16_t* o) {
+    f16x8_t p0, p1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * scale;
+        const _Float16 a = (_Float16)x;
+        p0[e] = a;
+        p1[e] = (_Float16)(x - (float)a);
+    }
+    *reinterpret_cast<uint4*>(o) = __builtin_bit_cast(uint4, p0);
+    *reinterpret_cast<uint4*>(o + 512) = __builtin_bit_cast(uint4, p1);
+}
+
+// which fp32 row a packed row (slot) holds
+enum { PACK_PLAIN = 0, PACK_GROUPS = 1, PACK_HEADS = 2 };
+struct PackRows {
+    const float* X; int64_t ld;
+    int64_t rows;                 // PLAIN: packed row r = X row r
+    const int32_t* group_ptr;     // GROUPS: slot 128 g + i = node group_ptr[g] + i
+    int H, C, cw;                 // HEADS: packed row 256 cb + h cw + cc = W row h C + cb cw + cc
+};
+template <int MAP>
+__device__ __forceinline__ const float* pack_row(const PackRows& pr, int64_t rt, int m, bool& on, int64_t& src_row) {
+    if constexpr (MAP == PACK_PLAIN) {
+        src_row = rt * 32 + m;
+        on = src_row < pr.rows;
+    } else if constexpr (MAP == PACK_GROUPS) {
+        const int grp = (int)(rt >> 2), i = (int)(rt & 3) * 32 + m;
+        const int ns = pr.group_ptr[grp], cnt = pr.group_ptr[grp + 1] - ns;
+        on = i < cnt;
+        src_row = ns + i;
+    } else {
+        const int r = (int)(rt * 32) + m;
+        const int cb = r >> 8, within = r & 255, h = within / pr.cw, ch = cb * pr.cw + (within - h * pr.cw);
+        on = ch < pr.C;
+        src_row = (int64_t)h * pr.C + ch;
+    }
+    if (!on) src_row = 0;
+    return pr.X + src_row * pr.ld;
+}
+__device__ __forceinline__ void load_row8(const float* row, bool on, int k0, int K, int vec, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (!on) return;
+    if (vec && k0 + 8 <= K) {
+        const float4 a = *reinterpret_cast<const float4*>(row + k0), b = *reinterpret_cast<const float4*>(row + k0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (k0 + e < K) v[e] = row[k0 + e];
+    }
+}
+
+// One block (4 waves) per 32-row tile; wave w walks k blocks w, w + 4, ...  Pass 1 finds the rows' largest magnitudes (two k
+// halves of a wave by lane ^ 32, the four waves through LDS), pass 2 writes the scaled pieces.  NIT > 0: a thread's (at most)
+// NIT k blocks stay in registers between the passes (rows read once); NIT == 0: any K, rows read twice.  J > 0 (GROUPS):
+// a_node[node, j] = sum_k x[node, k] Vn[j, k] on the way, as in k_split3_pack_groups_logits.
+template <int MAP, int J, int NIT>
+__global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB, uint16_t* __restrict__ out, float* __restrict__ inv_scale,
+                                                      int vec, const float* __restrict__ Vn, float* __restrict__ a_node) {
+    extern __shared__ __attribute__((aligned(16))) float pk_s[];      // [4][32] row maxima | [J][Kp] Vn | [4][32][J] partial dots
+    constexpr int JJ = J > 0 ? J : 1, NR = NIT > 0 ? NIT : 1;
+    const int Kp = KB * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* mx_s = pk_s;
+    float* vn_s = pk_s + 128;
+    if (J > 0) {
+        for (int idx = tid; idx < J * Kp; idx += 256) {
+            const int j = idx / Kp, k = idx - j * Kp;
+            vn_s[idx] = k < K ? Vn[(int64_t)j * K + k] : 0.f;
+        }
+    }
+    const int64_t rt = blockIdx.x;
+    bool row_on;
+    int64_t src_row;
+    const float* row = pack_row<MAP>(pr, rt, lane & 31, row_on, src_row);
+    const int kh = (lane >> 5) * 8;
+    float v[NR][8];
+    float mx = 0.f;
+    if (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int kb = wave + 4 * it;
+            load_row8(row, row_on && kb < KB, kb * 16 + kh, K, vec, v[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[it][e]));
+        }
+    } else {
+        for (int kb = wave; kb < KB; kb += 4) {
+            load_row8(row, row_on, kb * 16 + kh, K, vec, v[0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[0][e]));
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lane < 32) mx_s[wave * 32 + lane] = mx;
+    __syncthreads();                                                  // (also: Vn is in LDS)
+    const int m = lane & 31;
+    float rowmax = fmaxf(fmaxf(mx_s[m], mx_s[32 + m]), fmaxf(mx_s[64 + m], mx_s[96 + m]));
+    if constexpr (MAP == PACK_HEADS) {
+        // ONE scale per 256-row column block of the fused hop (its epilogue then needs a single factor for all its columns):
+        // the largest magnitude of the block's rows, found by every tile of the block on its own (weights: packed once, cached).
+        // Rows 2^-16 below their block's largest lose the 2^-22 guarantee (absolute error <= 2^-38 of the block's largest).
+        float bmx = 0.f;
+        const int cb = (int)(rt >> 3);
+        for (int r = tid >> 6; r < 256; r += 4) {                     // a wave per row, lanes over k
+            const int h = r / pr.cw, ch = cb * pr.cw + (r - h * pr.cw);
+            if (ch >= pr.C) continue;
+            const float* wrow = pr.X + ((int64_t)h * pr.C + ch) * pr.ld;
+            for (int k = lane; k < K; k += 64) bmx = fmaxf(bmx, fabsf(wrow[k]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bmx = fmaxf(bmx, __shfl_xor(bmx, o, 64));
+        __syncthreads();                                              // every read of mx_s above is done
+        if (lane == 0) mx_s[wave] = bmx;
+        __syncthreads();
+        rowmax = fmaxf(fmaxf(mx_s[0], mx_s[1]), fmaxf(mx_s[2], mx_s[3]));
+    }
+    const int ex = split2h_exponent(rowmax);
+    const float scale = pow2i(ex);
+    if (tid < 32) inv_scale[rt * 32 + tid] = pow2i(-ex);
+    float acc[JJ];
+#pragma unroll
+    for (int j = 0; j < JJ; ++j) acc[j] = 0.f;
+    auto emit = [&](int kb, const float (&w)[8]) {
+        split2h_store(w, scale, out + ((rt * KB + kb) * 2) * 512 + lane * 8);
+        if (J > 0) {
+            const int k0 = kb * 16 + kh;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float4 w0 = *reinterpret_cast<const float4*>(vn_s + j * Kp + k0), w1 = *reinterpret_cast<const float4*>(vn_s + j * Kp + k0 + 4);
+                acc[j] += w[0] * w0.x + w[1] * w0.y + w[2] * w0.z + w[3] * w0.w + w[4] * w1.x + w[5] * w1.y + w[6] * w1.z + w[7] * w1.w;
+            }
+        }
+    };
+    if (NIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NR; ++it)
+            if (wave + 4 * it < KB) emit(wave + 4 * it, v[it]);
+    } else {
+        for (int kb = wave; kb < KB; kb += 4) {
+            load_row8(row, row_on, kb * 16 + kh, K, vec, v[0]);
+            emit(kb, v[0]);
+        }
+    }
+    if (J > 0) {
+        float* part = vn_s + J * Kp;                                  // [4 waves][32 rows][J]
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float t = acc[j] + __shfl_xor(acc[j], 32, 64);      // the two k halves of the row
+            if (lane < 32) part[(wave * 32 + lane) * J + j] = t;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 32 * J; idx += 256) {
+            const int r = idx / J, j = idx - r * J;
+            bool on2;
+            int64_t node;
+            pack_row<MAP>(pr, rt, r, on2, node);
+            if (on2)
+                a_node[node * J + j] = (part[(0 * 32 + r) * J + j] + part[(1 * 32 + r) * J + j]) +
+                                       (part[(2 * 32 + r) * J + j] + part[(3 * 32 + r) * J + j]);
+        }
+    }
+}
+
+static size_t split2h_pack_lds(int J, int KB) { return (128 + (size_t)J * KB * 16 + 4 * 32 * (size_t)J) * sizeof(float); }
+
+template <int MAP>
+static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, void* packed, const float* Vn, int J, float* a_node,
+                                     hipStream_t stream) {
+    const int KB = (int)cdiv(K, 16);
+    const int vec = (reinterpret_cast<uintptr_t>(pr.X) & 15) == 0 && pr.ld % 4 == 0;
+    uint16_t* o = static_cast<uint16_t*>(packed);
+    float* inv = const_cast<float*>(split2h_inv_scales(packed, RT, KB));
+    const size_t lds = split2h_pack_lds(J, KB);
+    const dim3 grid((unsigned)RT), block(256);
+#define GVQA_P2(J_, NIT_) hipLaunchKernelGGL((k_split2h_pack<MAP, J_, NIT_>), grid, block, lds, stream, pr, (int)K, KB, o, inv, vec, Vn, a_node)
+    if (J == 0) {
+        if (KB <= 32) GVQA_P2(0, 8); else GVQA_P2(0, 0);
+    } else if constexpr (MAP == PACK_GROUPS) {
+        const bool regs = KB <= 32;
+        switch (J) {
+            case 2: if (regs) GVQA_P2(2, 8); else GVQA_P2(2, 0); break;
+            case 4: if (regs) GVQA_P2(4, 8); else GVQA_P2(4, 0); break;
+            case 8: if (regs) GVQA_P2(8, 8); else GVQA_P2(8, 0); break;
+            case 16: if (regs) GVQA_P2(16, 8); else GVQA_P2(16, 0); break;
+            default: return GVQA_E_UNSUPPORTED;
+        }
+    } else {
+        return GVQA_E_UNSUPPORTED;
+    }
+#undef GVQA_P2
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream) {
+    GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack: 2 or 3 pieces");
+    GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split_pack: bad size");
     if (rows == 0 || K == 0) return GVQA_OK;
-    GVQA_REQUIRE(X && packed, GVQA_E_INVALID, "split3_pack: null operand");
-    GVQA_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, GVQA_E_INVALID, "split3_pack: packed buffer must be 16-byte aligned");
+    GVQA_REQUIRE(X && packed, GVQA_E_INVALID, "split_pack: null operand");
+    GVQA_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, GVQA_E_INVALID, "split_pack: packed buffer must be 16-byte aligned");
     const int KB = (int)cdiv(K, 16);
     const int64_t RT = cdiv(rows, 32);
     const int vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
+    if (np == 2) {
+        GVQA_REQUIRE(RT < (1ll << 31), GVQA_E_INVALID, "split_pack: too many rows");
+        PackRows pr{X, ld, rows, nullptr, 0, 0, 0};
+        return launch_split2h_pack_tiles<PACK_PLAIN>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
+    }
     for (int64_t r0 = 0; r0 < RT; r0 += 65535) {       // grid.y holds 65535 row tiles
         const int64_t n = std::min<int64_t>(65535, RT - r0);
         hipLaunchKernelGGL(k_split3_pack, dim3((unsigned)cdiv(KB, 4), (unsigned)n), dim3(256), 0, stream, rows - r0 * 32, (int)K, KB,
@@ -566,8 +837,9 @@ static int split3_variant(int64_t M, int64_t N, int KB) {
     return (KB >= 24 && e_big >= e_half - 0.02) ? 14 : 34;
 }
 
-int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
-                         int64_t ldc, hipStream_t stream) {
+int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
+                        int64_t ldc, hipStream_t stream) {
+    GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "linear_split: 2 or 3 pieces");
     GVQA_REQUIRE(M >= 0 && N >= 0 && K > 0, GVQA_E_INVALID, "linear_split3: bad size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 30), GVQA_E_INVALID, "linear_split3: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
@@ -579,8 +851,12 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
     const int KB = (int)cdiv(K, 16), rtB = (int)cdiv(N, 32);
     const uint16_t* a = static_cast<const uint16_t*>(Apk);
     const uint16_t* b = static_cast<const uint16_t*>(Bpk);
-    const int variant = split3_variant(M, N, KB);
-    const int64_t bm = variant < 20 ? 256 : 128;
+    int variant = split3_variant(M, N, KB);            // (a forced variant >= 100 names a two-piece instantiation)
+    if (np == 2 && variant < 100) variant = variant < 20 ? 114 : 134;
+    GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
+    const int64_t bm = variant % 100 < 20 ? 256 : 128;
+    const float* a_inv = np == 2 ? split2h_inv_scales(Apk, cdiv(M, 32), KB) : nullptr;
+    const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
     const char* ssv = getenv("GVQA_SPLIT3_STAGGER");      // quarter units of the default start offset (tuning aid)
     const int stag_scale = ssv ? atoi(ssv) : 0;
     const char* ldv = getenv("GVQA_SPLIT3_LOOP_DEBUG");   // measurement aid: see the main loop
@@ -591,16 +867,19 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
         LinearEpilogue e2 = ep;
         if (ep.addend) e2.addend = ep.addend + m0 * ep.ld_add;
         if (ep.mul) e2.mul = ep.mul + m0 * ep.ld_mul;
-        const uint16_t* a2 = a + (m0 / 32) * (int64_t)KB * 1536;
+        const uint16_t* a2 = a + (m0 / 32) * (int64_t)KB * (np * 512);
+        const float* a_inv2 = a_inv ? a_inv + m0 : nullptr;
         const int rt2 = (int)cdiv(m, 32);
-#define GVQA_S3_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_)                                            \
+#define GVQA_S3_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_) GVQA_SN_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 3)
+#define GVQA_SN_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_)                                       \
         do {                                                                                                             \
             dim3 grid((unsigned)cdiv(N, 32 * WN_ * TN_), (unsigned)cdiv(m, 32 * WM_ * TM_));                              \
             /* a block's MFMA issue time x the STAG_ blocks sharing the SIMDs, split into STAG_ start offsets */         \
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
-            hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_>), grid,       \
+            hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_>), grid, \
                                dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C + m0 * ldc, ldc, \
-                               STAG_ == 0 ? loop_dbg : (stag_scale > 0 ? stag * stag_scale / 4 : stag), FusedHopArgs{});  \
+                               STAG_ == 0 ? loop_dbg : (stag_scale > 0 ? stag * stag_scale / 4 : stag), FusedHopArgs{},   \
+                               a_inv2, b_inv);                                                                           \
         } while (0)
         switch (variant) {
             case 10: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, false, false, false, 0, 0); break;
@@ -619,9 +898,18 @@ int launch_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const
             case 34: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, false, 0, 1); break;
             case 31: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, false, 2, 0); break;
             case 33: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, true, 0, 0); break;
+            // two fp16 pieces: a K step is 2 KiB per tile, so the rings are one step deeper in the same LDS
+            case 113: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2); break;
+            case 114: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2); break;
+            case 115: GVQA_SN_LAUNCH(2, 4, 4, 2, 3, true, false, true, 0, 0, 2); break;
+            case 116: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, false, false, true, 0, 0, 2); break;
+            case 123: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, true, 0, 0, 2); break;
+            case 133: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, true, 0, 0, 2); break;
+            case 134: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, false, 0, 1, 2); break;
             default: return GVQA_E_INVALID;
         }
 #undef GVQA_S3_LAUNCH
+#undef GVQA_SN_LAUNCH
     }
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
@@ -745,20 +1033,28 @@ __global__ __launch_bounds__(256) void k_split3_pack_heads(int H, int C, int cw,
     split3_store(v, out + ((rt * KB + kb) * 3) * 512 + lane * 8);
 }
 
-size_t split3_packed_rows_bytes(int64_t row_tiles, int64_t K) { return (size_t)row_tiles * (size_t)cdiv(K, 16) * 3072; }
-
-bool split3_pack_groups_logits_supported(int J, int64_t K) {
-    return (J == 2 || J == 4 || J == 8 || J == 16) && ((size_t)J * cdiv(K, 16) * 16 + 4 * 32 * (size_t)J) * sizeof(float) <= 64 * 1024;
+bool split_pack_groups_logits_supported(int np, int J, int64_t K) {
+    const size_t lds = np == 2 ? split2h_pack_lds(J, (int)cdiv(K, 16)) : ((size_t)J * cdiv(K, 16) * 16 + 4 * 32 * (size_t)J) * sizeof(float);
+    return (J == 2 || J == 4 || J == 8 || J == 16) && lds <= 64 * 1024;
 }
 
-int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
-                              const float* Vn, int J, float* a_node, hipStream_t stream) {
+int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
+                             const float* Vn, int J, float* a_node, hipStream_t stream) {
+    GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack_groups: 2 or 3 pieces");
     GVQA_REQUIRE(num_groups >= 0 && K > 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split3_pack_groups: bad size");
     if (num_groups == 0) return GVQA_OK;
     GVQA_REQUIRE(group_ptr && X && packed, GVQA_E_INVALID, "split3_pack_groups: null operand");
     const int KB = (int)cdiv(K, 16);
     const int vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ld % 4 == 0;
     const int64_t RT = (int64_t)num_groups * 4;
+    if (np == 2) {
+        const bool with_logits = Vn && a_node;
+        GVQA_REQUIRE(!a_node || (with_logits && split_pack_groups_logits_supported(2, J, K)), GVQA_E_UNSUPPORTED,
+                     "split_pack_groups: logits on the way need 2 H in {2, 4, 8, 16} and [2 H, K] within 64 KiB of LDS");
+        PackRows pr{X, ld, 0, group_ptr, 0, 0, 0};
+        return launch_split2h_pack_tiles<PACK_GROUPS>(pr, RT, K, packed, with_logits ? Vn : nullptr, with_logits ? J : 0,
+                                                      with_logits ? a_node : nullptr, stream);
+    }
     const size_t lds = ((size_t)J * KB * 16 + 4 * 32 * (size_t)J) * sizeof(float);
     if (Vn && a_node && (J == 2 || J == 4 || J == 8 || J == 16) && lds <= 64 * 1024) {     // logits on the way (rows read once)
         uint16_t* o = static_cast<uint16_t*>(packed);
@@ -784,11 +1080,16 @@ int launch_split3_pack_groups(int num_groups, const int32_t* group_ptr, int64_t 
     return GVQA_OK;
 }
 
-int launch_split3_pack_heads(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream) {
+int launch_split_pack_heads(int np, int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream) {
+    GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack_heads: 2 or 3 pieces");
     GVQA_REQUIRE(H > 0 && C > 0 && cw > 0 && H * cw == 256 && K > 0 && ldw >= K, GVQA_E_INVALID, "split3_pack_heads: bad size");
     GVQA_REQUIRE(W && packed, GVQA_E_INVALID, "split3_pack_heads: null operand");
     const int KB = (int)cdiv(K, 16), ncb = (int)cdiv(C, cw);
     const int vec = (reinterpret_cast<uintptr_t>(W) & 15) == 0 && ldw % 4 == 0;
+    if (np == 2) {
+        PackRows pr{W, ldw, 0, nullptr, H, C, cw};
+        return launch_split2h_pack_tiles<PACK_HEADS>(pr, (int64_t)ncb * 8, K, packed, nullptr, 0, nullptr, stream);
+    }
     hipLaunchKernelGGL(k_split3_pack_heads, dim3((unsigned)cdiv(KB, 4), (unsigned)(ncb * 8)), dim3(256), 0, stream, H, C, cw, (int)K, KB, W,
                        ldw, static_cast<uint16_t*>(packed), vec);
     GVQA_LAUNCH_CHECK();
@@ -798,7 +1099,8 @@ int launch_split3_pack_heads(int H, int C, int cw, int64_t K, const float* W, in
 // edges of one row group the fused epilogue can hold in LDS beside the 128 KiB row image
 size_t hop_fused_lds_edge_capacity(int H) { return (size_t)(8192 - 192 - 128) / (size_t)(H + 1); }      // 32 KiB of words, padded sub-arrays
 
-int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream) {
+int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream) {
+    GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "hop_fused: 2 or 3 pieces");
     GVQA_REQUIRE(Apk && Bpk && f.out && f.group_ptr && f.rowptr && f.csr_src && f.alpha_csr && f.node_graph, GVQA_E_INVALID,
                  "hop_fused: null operand");
     GVQA_REQUIRE(f.H * f.cw == 256 && f.C % 4 == 0 && f.cw % 4 == 0 && (f.cw & (f.cw - 1)) == 0, GVQA_E_UNSUPPORTED,
@@ -811,15 +1113,32 @@ int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const F
     dim3 grid((unsigned)ncb, (unsigned)cdiv(f.num_groups, 2));
     FusedHopArgs f2 = f;
     if (const char* dbg = getenv("GVQA_FUSED_DEBUG")) f2.debug = atoi(dbg);
-#define GVQA_FUSED_LAUNCH(H_)                                                                                                   \
-    hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, 3, true, false, false, 0, 2, H_>), grid, dim3(512), 0, stream, f.num_groups * 128,  \
-                       ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), rtB, LinearEpilogue{},  \
-                       nullptr, (int64_t)0, 0, f2)
-    switch (f.H) {
-        case 1: GVQA_FUSED_LAUNCH(1); break;
-        case 2: GVQA_FUSED_LAUNCH(2); break;
-        case 4: GVQA_FUSED_LAUNCH(4); break;
-        default: GVQA_FUSED_LAUNCH(8); break;
+    {
+        const char* xv = getenv("GVQA_FUSED_XCD");
+        const int want = xv ? atoi(xv) : 4;                   // measured at config 3: 458 (plain order) / 452 / 449 / 447 us for 1 / 2 / 4 / 8
+        const int rows = (int)cdiv(f.num_groups, 2);
+        f2.xcd_cols = (ncb == 8 && (want == 2 || want == 4 || want == 8) && rows % (want) == 0) ? want : 1;
+    }
+    const float* a_inv = np == 2 ? split2h_inv_scales(Apk, rtA, KB) : nullptr;
+    const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
+#define GVQA_FUSED_LAUNCH(H_, NBUF_, NP_)                                                                                       \
+    hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, H_, NP_>), grid, dim3(512), 0, stream,     \
+                       f.num_groups * 128, ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), \
+                       rtB, LinearEpilogue{}, nullptr, (int64_t)0, 0, f2, a_inv, b_inv)
+    if (np == 3) {
+        switch (f.H) {
+            case 1: GVQA_FUSED_LAUNCH(1, 3, 3); break;
+            case 2: GVQA_FUSED_LAUNCH(2, 3, 3); break;
+            case 4: GVQA_FUSED_LAUNCH(4, 3, 3); break;
+            default: GVQA_FUSED_LAUNCH(8, 3, 3); break;
+        }
+    } else {        // two fp16 pieces: 32 KiB per K step, four steps in the 128 KiB below the epilogue's CSR regions
+        switch (f.H) {
+            case 1: GVQA_FUSED_LAUNCH(1, 4, 2); break;
+            case 2: GVQA_FUSED_LAUNCH(2, 4, 2); break;
+            case 4: GVQA_FUSED_LAUNCH(4, 4, 2); break;
+            default: GVQA_FUSED_LAUNCH(8, 4, 2); break;
+        }
     }
 #undef GVQA_FUSED_LAUNCH
     GVQA_LAUNCH_CHECK();
@@ -830,16 +1149,32 @@ int launch_hop_fused_split3(int64_t K, const void* Apk, const void* Bpk, const F
 
 extern "C" size_t gvqa_split3_packed_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
-    return gvqa::split3_packed_bytes(rows, K);
+    return gvqa::split_packed_bytes(3, rows, K);
 }
 
 extern "C" int gvqa_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream) {
-    return gvqa::launch_split3_pack(rows, K, X, ld, packed, static_cast<hipStream_t>(stream));
+    return gvqa::launch_split_pack(3, rows, K, X, ld, packed, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K) {
+    if (rows <= 0 || K <= 0) return 0;
+    return gvqa::split_packed_bytes(2, rows, K);
+}
+
+extern "C" int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream) {
+    return gvqa::launch_split_pack(2, rows, K, X, ld, packed, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
+                                   const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
+                                   int64_t ldc, void* stream) {
+    gvqa::LinearEpilogue ep{bias, addend, ld_add, mul, ld_mul, relu};
+    return gvqa::launch_linear_split(2, M, N, K, Apk, Bpk, ep, C, ldc, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
                                   const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                                   int64_t ldc, void* stream) {
     gvqa::LinearEpilogue ep{bias, addend, ld_add, mul, ld_mul, relu};
-    return gvqa::launch_linear_split3(M, N, K, Apk, Bpk, ep, C, ldc, static_cast<hipStream_t>(stream));
+    return gvqa::launch_linear_split(3, M, N, K, Apk, Bpk, ep, C, ldc, static_cast<hipStream_t>(stream));
 }

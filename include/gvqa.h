@@ -157,8 +157,9 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
 
 /* Weight cache: what a gat_seq forward derives from the PARAMETERS alone -- the folded attention vectors, the per-graph
  * term weights and the split3-packed projection weights of every hop -- prepared once and reused while the weights do not
- * change (serving).  `layout` is what the batch needs: gvqa_gat_seq_weight_layout(g, d) = -1 (f32 projection), 0 (split3,
- * plain rows) or 1 (fused hop, head-interleaved rows).  gvqa_gat_seq_forward_cached uses the cache when its layout id
+ * change (serving).  `layout` is what the batch needs: gvqa_gat_seq_weight_layout(g, d) = -1 (f32 projection) or a
+ * bit mask: bit 0 = head-interleaved rows (fused hop) instead of plain row order, bit 1 = two fp16 pieces (split2h)
+ * instead of three bf16 pieces (split3).  gvqa_gat_seq_forward_cached uses the cache when its layout id
  * matches the batch's, and recomputes into the workspace otherwise (results are identical either way).  The cache is
  * caller-owned device memory, 256-byte aligned; the caller re-prepares it after changing any parameter. */
 size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout);
@@ -228,8 +229,8 @@ int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A,
                      const float* bias, const void* addend, int64_t ld_add, const void* mul, int64_t ld_mul, int relu,
                      void* C, int64_t ldc, int c_bf16, void* stream);
 
-/* fp32-accurate projection on the bf16 matrix cores ("split3", the default for the GAT hop projection
- * xp = lin_l(x_cat), gat_skip.py:133): every fp32 operand value is the exact sum of three round-to-nearest
+/* fp32-accurate projection on the 16-bit matrix cores (the GAT hop projection xp = lin_l(x_cat), gat_skip.py:133).
+ * "split3": every fp32 operand value is the exact sum of three round-to-nearest
  * bf16 pieces; the six largest of the nine piece products (each exact in fp32) are accumulated in fp32 by
  * v_mfma_f32_32x32x16_bf16 -- fp32-class accuracy (dropped terms <= 3 * 2^-27 relative) at 16x the f32-MFMA
  * rate for 6x the work.  gvqa_split3_pack writes an fp32 matrix X[rows, K] (leading dimension ld) as
@@ -242,8 +243,21 @@ int gvqa_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* 
 int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
                        const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                        int64_t ldc, void* stream);
+/* "split2h" (the default): every ROW of an operand is scaled by a power of two that puts its largest magnitude into
+ * [2^13, 2^14) and every value is carried as two round-to-nearest fp16 pieces p1 + p2 (|x 2^e - p1 - p2| <= 2^-22 |x 2^e|,
+ * 2^-38 of the row's largest magnitude for values 2^-16 below it); the three largest piece products (exact in fp32) are
+ * accumulated in fp32 by v_mfma_f32_32x32x16_f16 and the accumulators are rescaled exactly.  The split is not exact, but
+ * its error is below the fp32 accumulation's own: against fp64 the result is as close as the f32-input MFMA's or split3's
+ * (tests/test_gpu_split3.py) at half of split3's matrix-core work and two thirds of its operand bytes.  Same calls and layout
+ * with 2 pieces of fp16, followed by one fp32 inverse scale per (padded) row:
+ * P[ceil(rows/32)][ceil(K/16)][2][64 lanes][8 fp16] | inv_scale[32 ceil(rows/32)]. */
+size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K);
+int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
+int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
+                        const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
+                        int64_t ldc, void* stream);
 
-/* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split3|f32,
+/* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls
  * made afterwards (benchmarks and tests compare modes inside one process).  Workspace sizes depend on
  * GVQA_OPT_PROJECTION / _MIN_MFLOP: query gvqa_*_workspace_bytes after changing them. */
@@ -251,14 +265,16 @@ enum gvqa_option {
     GVQA_OPT_PROJECTION = 0,       /* arithmetic of the hop projection xp = lin_l(x_cat): GVQA_PROJECTION_* */
     GVQA_OPT_VENDOR_GEMM = 1,      /* 1: plain fp32 products >= 2 GFLOP go to rocBLAS (comparison only; default 0) */
     GVQA_OPT_SPLIT3_MIN_MFLOP = 2, /* products below this many MFLOP stay on the f32-input MFMA kernels (default 1000) */
-    GVQA_OPT_SPLIT3_VARIANT = 3,   /* 0 = choose by shape; otherwise an exact k_linear_split3 instantiation (tuning / tests) */
+    GVQA_OPT_SPLIT3_VARIANT = 3,   /* 0 = choose by shape; otherwise an exact k_linear_split3 instantiation (tuning / tests;
+                                      < 100: three-piece kernels, >= 100: two-piece kernels) */
     GVQA_OPT_HOP_FUSION = 4,       /* 1 (default): gat_seq hops run projection + aggregation as ONE kernel when the batch allows it
-                                      (split3 projection, graphs <= 128 nodes, H in {1,2,4,8}); 0: projection, then the
+                                      (split projection, graphs <= 128 nodes, H in {1,2,4,8}); 0: projection, then the
                                       message-passing kernel (xp through HBM) */
     GVQA_NUM_OPTIONS = 5
 };
-#define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate (default) */
+#define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */
+#define GVQA_PROJECTION_SPLIT2H 2  /* two scaled fp16 pieces per fp32 value, three fp16-MFMA products, fp32 accumulate (default) */
 int gvqa_set_option(int option, int value);
 int gvqa_get_option(int option);
 

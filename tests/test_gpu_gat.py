@@ -323,14 +323,16 @@ def test_large_single_graph_uses_general_kernel(dev):
     assert maxabs(out, ref) < TOL
 
 
-@pytest.fixture(params=["fused", "split3+mp", "f32+mp"])
+@pytest.fixture(params=["fused", "fused-split3", "split2h+mp", "split3+mp", "f32+mp"])
 def projection_mode(request):
-    """The three ways a hop runs (GVQA_OPT_HOP_FUSION / GVQA_OPT_PROJECTION): projection + aggregation as ONE kernel on the
-    split3 arithmetic (default), split3 projection followed by the message-passing kernel, f32-input MFMA projection
+    """The ways a hop runs (GVQA_OPT_HOP_FUSION / GVQA_OPT_PROJECTION): projection + aggregation as ONE kernel on the split2h
+    arithmetic (default) or on split3, a split projection followed by the message-passing kernel, f32-input MFMA projection
     (k_linear_f32_dma / k_linear_f32) followed by the message-passing kernel."""
     from graphvqa_amd import _lib
-    old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32 if request.param == "f32+mp" else _lib.PROJECTION_SPLIT3)
-    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1 if request.param == "fused" else 0)
+    proj = {"fused": _lib.PROJECTION_SPLIT2H, "fused-split3": _lib.PROJECTION_SPLIT3, "split2h+mp": _lib.PROJECTION_SPLIT2H,
+            "split3+mp": _lib.PROJECTION_SPLIT3, "f32+mp": _lib.PROJECTION_F32}[request.param]
+    old_p = _lib.set_option(_lib.OPT_PROJECTION, proj)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1 if request.param.startswith("fused") else 0)
     yield request.param
     _lib.set_option(_lib.OPT_PROJECTION, old_p)
     _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
@@ -366,7 +368,7 @@ def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode)
     ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), return_all=True)
     g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
     plan = _lib.MpPlan()
-    for parts in ("1", None) if projection_mode != "fused" else (None,):   # one block per graph, then the small-batch split
+    for parts in ("1", None) if not projection_mode.startswith("fused") else (None,):   # one block per graph, then the small-batch split
         if parts:
             os.environ["GVQA_MP_PARTS"] = parts
         try:
@@ -384,7 +386,8 @@ def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode)
 
 @pytest.mark.parametrize("H,C,de,di,lo,hi", [(4, 64, 24, 16, 1, 40), (4, 300, 20, 12, 20, 40), (1, 32, 8, 8, 1, 128), (2, 136, 16, 0, 60, 128),
                                              (8, 48, 12, 20, 5, 70)])
-def test_fused_hop_kernel_on_ragged_batches(dev, H, C, de, di, lo, hi):
+@pytest.mark.parametrize("scheme", ["split2h", "split3"])
+def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
     """The fused hop (projection + aggregation in one kernel, csrc/split3.hip EPI 2) forced onto small ragged batches:
     row groups that are not full, graphs of 1 and of exactly 128 nodes, channel counts that do not fill the last column
     block, every supported head count, train-mode BatchNorm -- against the oracle and against the unfused kernels."""
@@ -398,6 +401,7 @@ def test_fused_hop_kernel_on_ragged_batches(dev, H, C, de, di, lo, hi):
     x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
     ref, hs, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
     old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_SPLIT2H if scheme == "split2h" else _lib.PROJECTION_SPLIT3)
     try:
         assert _lib.load().gvqa_get_option(_lib.OPT_HOP_FUSION) == 1
         _lib.prof_enable(True); _lib.prof_collect()
@@ -412,6 +416,7 @@ def test_fused_hop_kernel_on_ragged_batches(dev, H, C, de, di, lo, hi):
         out_t = m(*[t(a, device=dev) for a in (x, gb.edge_index, ea, ins, gb.batch)])
     finally:
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_PROJECTION, old_p)
         _lib.set_option(_lib.OPT_HOP_FUSION, 1)
         _lib.prof_enable(False)
     assert maxabs(out, ref) < TOL and maxabs(hops, torch.stack(hs)) < TOL and maxabs(alpha, torch.stack(alphas)) < 2e-5
@@ -800,9 +805,9 @@ def test_config1_debug_pipeline_chain(dev):
 
 
 def test_split3_projection_is_fp32_accurate_in_situ(dev):
-    """GVQA_PROJ (read once per process -> subprocess): the default three-piece bf16 split projection (forced onto this
-    small batch with GVQA_SPLIT3_MIN_MFLOP=0) must be as close to the fp64 oracle as the f32-input MFMA kernels on the
-    real-dims golden case recorded from the reference's own gat_seq."""
+    """GVQA_PROJ (read once per process -> subprocess): the split projections (two fp16 pieces = the default, three bf16
+    pieces; forced onto this small batch with GVQA_SPLIT3_MIN_MFLOP=0) must be as close to the fp64 oracle as the f32-input
+    MFMA kernels on the real-dims golden case recorded from the reference's own gat_seq."""
     import os, subprocess, sys, json
     code = r'''
 import json, sys, numpy as np, torch
@@ -823,14 +828,16 @@ print(json.dumps({"err64": float((out - ref).abs().max()), "err_golden": float((
                   "backend": _lib.load().gvqa_gemm_backend().decode()}))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
-    for mode in ("split3", "f32"):
+    for mode in ("split2h", "split3", "f32"):
         env = dict(os.environ, GVQA_PROJ=mode, GVQA_SPLIT3_MIN_MFLOP="0")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert "k_linear_split3" in res["split3"]["backend"] and "split3" not in res["f32"]["backend"]
-    assert res["split3"]["err_golden"] < TOL and res["f32"]["err_golden"] < TOL
-    assert res["split3"]["err64"] < max(2e-5, 3 * res["f32"]["err64"])
+    assert "three exact bf16" in res["split3"]["backend"] and "two scaled fp16" in res["split2h"]["backend"]
+    assert "k_linear_split3" not in res["f32"]["backend"]
+    assert all(r["err_golden"] < TOL for r in res.values()), res
+    assert res["split3"]["err64"] < max(2e-5, 3 * res["f32"]["err64"]), res
+    assert res["split2h"]["err64"] < max(2e-5, 3 * res["f32"]["err64"]), res
 
 
 def test_empty_batch_and_empty_graphs_in_the_middle(dev):

@@ -1,13 +1,15 @@
-"""split3: the fp32-accurate projection on the bf16 matrix cores (csrc/split3.hip) against fp64 and against
-the f32-input MFMA kernel, through the C ABI.  The hop projection it serves is /root/reference gat_skip.py:133."""
+"""The fp32-accurate projections on the 16-bit matrix cores (csrc/split3.hip) -- "split3" (three exact bf16 pieces, six
+products) and "split2h" (two scaled fp16 pieces, three products; the default) -- against fp64 and against the f32-input MFMA
+kernel, through the C ABI.  The hop projection they serve is /root/reference gat_skip.py:133."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-# kernel variants (tile geometry x schedule x epilogue, see launch_linear_split3); 0 = the library's own choice
+# kernel variants (tile geometry x schedule x epilogue, see launch_linear_split); 0 = the library's own choice
 VARIANTS = [0, 10, 11, 14, 21, 28, 29, 30, 34]
+SCHEME_VARIANTS = [("split3", v) for v in VARIANTS] + [("split2h", v) for v in (0, 114, 134)]
 
 
 @pytest.fixture(scope="module")
@@ -18,11 +20,13 @@ def env():
     return _lib, _lib.load(), torch.device("cuda:0")
 
 
-def _pack(env, X):
+def _pack(env, X, scheme="split3"):
     _lib, lib, dev = env
     rows, K = X.shape
-    buf = torch.empty(lib.gvqa_split3_packed_bytes(rows, K), dtype=torch.uint8, device=dev)
-    _lib.check(lib.gvqa_split3_pack(rows, K, X.data_ptr(), X.stride(0), buf.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    nbytes, pack = ((lib.gvqa_split3_packed_bytes, lib.gvqa_split3_pack) if scheme == "split3"
+                    else (lib.gvqa_split2h_packed_bytes, lib.gvqa_split2h_pack))
+    buf = torch.empty(nbytes(rows, K), dtype=torch.uint8, device=dev)
+    _lib.check(pack(rows, K, X.data_ptr(), X.stride(0), buf.data_ptr(), torch.cuda.current_stream().cuda_stream))
     return buf
 
 
@@ -52,17 +56,57 @@ def test_pack_pieces_are_an_exact_split(env, rows, K):
         assert np.all(np.abs(pieces[2][:rows, :K]) <= np.abs(x) * 2.0 ** -16 + 1e-300)
 
 
-def _run(env, A, W, tile, bias=None, addend=None, mul=None, relu=0):
+def _unpack2h(buf, rows, K):
+    """split2h: (pieces [2, rows_padded, K_padded] as fp64 in the SCALED domain, inverse scales [rows_padded])."""
+    RT, KB = -(-rows // 32), -(-K // 16)
+    raw = buf.cpu().numpy()
+    f = raw[:RT * KB * 2048].view(np.float16).reshape(RT, KB, 2, 2, 32, 8)        # [RT, KB, piece, khalf, r, e]
+    f = f.transpose(2, 0, 4, 1, 3, 5).reshape(2, RT * 32, KB * 16).astype(np.float64)
+    inv = raw[RT * KB * 2048:].view(np.float32)
+    assert inv.shape == (RT * 32,)
+    return f, inv.astype(np.float64)
+
+
+@pytest.mark.parametrize("rows,K", [(32, 16), (70, 40), (129, 300), (5, 7), (64, 512), (40, 700)])
+def test_pack_split2h_pieces(env, rows, K):
+    """Row scale: the largest magnitude lands in [2^13, 2^14); pieces are RN16(x s) and RN16(x s - p1), bit for bit; their sum
+    misses x s by at most 2^-22 |x s| (or half an fp16 subnormal step); the stored inverse scale undoes s exactly."""
+    _lib, lib, dev = env
+    g = torch.Generator(device="cpu").manual_seed(rows * 1000 + K)
+    X = (torch.randn(rows, K, generator=g) * torch.exp(4 * torch.randn(rows, K, generator=g)))
+    X[0, 0] = 0.0
+    if rows > 3:
+        X[3] = 0.0                                                        # an all-zero row keeps scale 1
+        X[2] *= 1e-30                                                     # tiny and huge rows get their own scales
+        X[1] *= 1e30
+    X = X.to(dev)
+    pieces, inv = _unpack2h(_pack(env, X, "split2h"), rows, K)
+    x = X.cpu().numpy().astype(np.float64)
+    scale = 1.0 / inv
+    assert np.all(np.log2(scale) == np.round(np.log2(scale)))              # powers of two
+    xs = np.zeros_like(pieces[0]); xs[:rows, :K] = x * scale[:rows, None]
+    mx = np.abs(xs).max(axis=1)
+    nz = mx > 0
+    assert np.all((mx[nz] >= 2.0 ** 13) & (mx[nz] < 2.0 ** 14)) and np.all(scale[~nz] == 1.0)
+    p1 = xs.astype(np.float32).astype(np.float16).astype(np.float64)       # x s is exact in fp32 (power-of-two scale)
+    p2 = (xs - p1).astype(np.float32).astype(np.float16).astype(np.float64)
+    assert np.array_equal(pieces[0], p1) and np.array_equal(pieces[1], p2)
+    assert np.all(np.abs(xs - pieces[0] - pieces[1]) <= np.maximum(np.abs(xs) * 2.0 ** -22, 2.0 ** -25))
+    assert not pieces[:, rows:].any() and not pieces[:, :, K:].any()       # zero padding
+
+
+def _run(env, A, W, tile, bias=None, addend=None, mul=None, relu=0, scheme="split3"):
     _lib, lib, dev = env
     M, K = A.shape
     N = W.shape[0]
     st = torch.cuda.current_stream().cuda_stream
-    a, w = _pack(env, A), _pack(env, W)
+    a, w = _pack(env, A, scheme), _pack(env, W, scheme)
     C = torch.full((M, N), float("nan"), device=dev)
     ptr = lambda t: t.data_ptr() if t is not None else None
     old = _lib.set_option(_lib.OPT_SPLIT3_VARIANT, tile)
+    linear = lib.gvqa_linear_split3 if scheme == "split3" else lib.gvqa_linear_split2h
     try:
-        _lib.check(lib.gvqa_linear_split3(M, N, K, a.data_ptr(), w.data_ptr(), ptr(bias), ptr(addend),
+        _lib.check(linear(M, N, K, a.data_ptr(), w.data_ptr(), ptr(bias), ptr(addend),
                                           addend.stride(0) if addend is not None else 0, ptr(mul),
                                           mul.stride(0) if mul is not None else 0, relu, C.data_ptr(), C.stride(0), st))
     finally:
@@ -71,15 +115,15 @@ def _run(env, A, W, tile, bias=None, addend=None, mul=None, relu=0):
     return C
 
 
-@pytest.mark.parametrize("tile", VARIANTS)
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 132, 40), (1000, 1200, 300), (33, 4, 16), (513, 520, 512)])
-def test_linear_split3_matches_fp64_like_fp32(env, tile, M, N, K):
+@pytest.mark.parametrize("scheme,tile", SCHEME_VARIANTS)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 132, 40), (1000, 1200, 300), (33, 4, 16), (513, 520, 512), (2048, 512, 1024)])
+def test_linear_split_matches_fp64_like_fp32(env, scheme, tile, M, N, K):
     """Error against fp64 must be in the class of an exact-fp32 k-ordered fmaf chain (the f32 MFMA kernel)."""
     _lib, lib, dev = env
     g = torch.Generator(device="cpu").manual_seed(M + 7 * N + 13 * K)
     A = torch.randn(M, K, generator=g).to(dev)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
-    C = _run(env, A, W, tile)
+    C = _run(env, A, W, tile, scheme=scheme)
     ref = A.double() @ W.double().t()
     err = float((C.double() - ref).abs().max())
     C32 = torch.empty(M, N, device=dev)
@@ -91,8 +135,8 @@ def test_linear_split3_matches_fp64_like_fp32(env, tile, M, N, K):
     assert err <= max(2.0 * err32, 2e-6), (err, err32)
 
 
-@pytest.mark.parametrize("tile", VARIANTS)
-def test_linear_split3_epilogues(env, tile):
+@pytest.mark.parametrize("scheme,tile", SCHEME_VARIANTS)
+def test_linear_split_epilogues(env, scheme, tile):
     _lib, lib, dev = env
     g = torch.Generator(device="cpu").manual_seed(5)
     M, N, K = 260, 136, 48
@@ -103,18 +147,22 @@ def test_linear_split3_epilogues(env, tile):
                     ({"addend": add}, base + add.double()),
                     ({"bias": bias, "addend": add, "mul": mul, "relu": 1}, torch.relu((base + bias.double() + add.double()) * mul.double())),
                     ({"relu": 2}, torch.where(base > 0, base, torch.expm1(base)))):
-        C = _run(env, A, W, tile, **kw)
+        C = _run(env, A, W, tile, scheme=scheme, **kw)
         assert float((C.double() - ref).abs().max()) < 2e-5, kw.keys()
 
 
-def test_linear_split3_wide_dynamic_range(env):
-    """Pieces keep fp32 accuracy when operand magnitudes span many binades (where a bf16 or 2-piece product would not)."""
+@pytest.mark.parametrize("scheme", ["split3", "split2h"])
+def test_linear_split_wide_dynamic_range(env, scheme):
+    """Pieces keep fp32 accuracy when operand magnitudes span many binades inside a row and between rows (where a plain bf16 /
+    fp16 product, or an unscaled fp16 split, would not)."""
     _lib, lib, dev = env
     g = torch.Generator(device="cpu").manual_seed(11)
     M, N, K = 384, 256, 512
     A = (torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, K, generator=g))).to(dev)
     W = (torch.randn(N, K, generator=g) * torch.exp(3 * torch.randn(N, K, generator=g))).to(dev)
-    C = _run(env, A, W, 0)
+    A *= torch.exp(10 * torch.randn(M, 1, generator=g)).to(dev)           # rows 2^+-30 apart
+    W *= torch.exp(10 * torch.randn(N, 1, generator=g)).to(dev)
+    C = _run(env, A, W, 0, scheme=scheme)
     C32 = torch.empty(M, N, device=dev)
     _lib.check(lib.gvqa_linear_f32(M, N, K, A.data_ptr(), K, W.data_ptr(), K, None, 0, C32.data_ptr(), N,
                                    torch.cuda.current_stream().cuda_stream))
@@ -122,7 +170,9 @@ def test_linear_split3_wide_dynamic_range(env):
     scale = (A.double().abs() @ W.double().abs().t())                       # sum |a b|: the natural error scale
     rel = float(((C.double() - ref).abs() / scale).max())
     rel32 = float(((C32.double() - ref).abs() / scale).max())
-    assert rel < max(2 * rel32, 2e-7), (rel, rel32)                       # the f32-MFMA fmaf chain's own roundoff class
+    # the f32-MFMA fmaf chain's own roundoff class; split2h's representation bound is 3 * 2^-22 of sum |a b| (both operands and
+    # the dropped p2 q2), reached only when one term carries the whole sum
+    assert rel < max(2 * rel32, 2e-7 if scheme == "split3" else 4e-7), (rel, rel32)
 
 
 def test_linear_split3_rejects_unaligned(env):
@@ -133,3 +183,16 @@ def test_linear_split3_rejects_unaligned(env):
     rc = lib.gvqa_linear_split3(32, 6, 16, a.data_ptr(), w.data_ptr(), None, None, 0, None, 0, 0, C.data_ptr(), 6,
                                 torch.cuda.current_stream().cuda_stream)
     assert rc == _lib.E_UNSUPPORTED
+
+
+def test_split2h_zero_inf_rows(env):
+    """All-zero rows give exact zeros; an infinite operand value poisons its own output row only."""
+    _lib, lib, dev = env
+    g = torch.Generator(device="cpu").manual_seed(3)
+    A, W = torch.randn(64, 32, generator=g).to(dev), torch.randn(32, 32, generator=g).to(dev)
+    A[5] = 0.0
+    A[7, 3] = float("inf")
+    C = _run(env, A, W, 0, scheme="split2h")
+    assert not C[5].any() and not torch.isfinite(C[7]).any()
+    keep = [i for i in range(64) if i != 7]
+    assert float((C[keep].double() - A[keep].double() @ W.double().t()).abs().max()) < 2e-5
