@@ -42,7 +42,7 @@ class Graph(C.Structure):
                 ("max_graph_nodes", C.c_int32), ("max_graph_edges", C.c_int32),
                 ("max_in_degree", C.c_int32), ("intra_graph", C.c_int32), ("valid", C.c_int32),
                 ("finalized", C.c_int32), ("row_group_ptr", C.c_void_p), ("num_row_groups", C.c_int32),
-                ("max_row_group_edges", C.c_int32)]
+                ("max_row_group_edges", C.c_int32), ("row_group_order", C.c_void_p)]
 
 
 class GatConvParams(C.Structure):

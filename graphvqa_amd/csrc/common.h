@@ -105,6 +105,7 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
 struct FusedHopArgs {
     const int32_t* group_ptr;   // [G+1] first node of row group r (<= 128 nodes each, graph-aligned)
     int num_groups;
+    const int32_t* row_order;   // NULL or [N]: slot s of group r is aggregated as local row row_order[group_ptr[r] + s]
     const int32_t* rowptr;      // CSR by destination
     const int32_t* csr_src;
     const float* alpha_csr;     // [E, H] attention coefficients in CSR slot order (k_gat_alpha_general)

@@ -1094,7 +1094,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             }
             FusedHopArgs f;
             memset(&f, 0, sizeof(f));
-            f.group_ptr = g->row_group_ptr; f.num_groups = g->num_row_groups;
+            f.group_ptr = g->row_group_ptr; f.num_groups = g->num_row_groups; f.row_order = g->row_group_order;
             f.rowptr = g->rowptr; f.csr_src = g->csr_src; f.alpha_csr = P(L.alpha_csr); f.node_graph = g->node_graph;
             f.graph_term = a.graph_term; f.t_ld = Tld;
             f.bias = hops[i].bias;

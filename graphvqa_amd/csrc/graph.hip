@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_stats(int64_t N, int64_t B, const int32
 }
 
 struct GraphLayout {
-    size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, deg, rank, slot_eid, tile_sum, graph_eptr, row_group, total;
+    size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, deg, rank, slot_eid, tile_sum, graph_eptr, row_group, row_order, total;
 };
 
 constexpr int ROW_GROUP = 128;      // rows of one group of the fused hop kernel (half a 256-row block tile)
@@ -190,6 +190,25 @@ __global__ __launch_bounds__(256) void k_graph_eptr(int64_t B, const int32_t* __
                                                     int32_t* __restrict__ graph_eptr) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g <= B) graph_eptr[g] = rowptr[graph_ptr[g]];
+}
+
+// order[ns + r] = local index of the row with the r-th most in-edges of its group (ties in row order): the fused hop's edge
+// loop runs to the largest in-degree among the rows a wave covers, so it walks the rows in this order.  One block per group.
+__global__ __launch_bounds__(ROW_GROUP) void k_row_group_order(const int32_t* __restrict__ group_ptr, const int32_t* __restrict__ rowptr,
+                                                               int32_t* __restrict__ order) {
+    __shared__ int deg_s[ROW_GROUP];
+    const int i = threadIdx.x;
+    const int ns = group_ptr[blockIdx.x], cnt = group_ptr[blockIdx.x + 1] - ns;
+    const int d = i < cnt ? rowptr[ns + i + 1] - rowptr[ns + i] : -1;
+    deg_s[i] = d;
+    __syncthreads();
+    if (i >= cnt) return;
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) {
+        const int dj = deg_s[j];
+        rank += (dj > d || (dj == d && j < i)) ? 1 : 0;
+    }
+    order[ns + rank] = i;
 }
 
 static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
@@ -212,6 +231,7 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     L.tile_sum = take(cdiv(N + 1, SCAN_TILE) + 1);
     L.graph_eptr = take(B + 1);
     L.row_group = take(B + 2);            // at most one group per non-empty graph, + the end marker
+    L.row_order = take(N);
     L.total = off;
     return L;
 }
@@ -251,6 +271,10 @@ static int plan_row_groups(gvqa_graph* g, const int32_t* hp, const int32_t* he, 
     g->row_group_ptr = grp_dev;
     g->num_row_groups = (int32_t)hg.size() - 1;
     g->max_row_group_edges = max_e;
+    int32_t* order = reinterpret_cast<int32_t*>(base + L.row_order);
+    hipLaunchKernelGGL(k_row_group_order, dim3((unsigned)g->num_row_groups), dim3(ROW_GROUP), 0, stream, grp_dev, g->rowptr, order);
+    GVQA_LAUNCH_CHECK();
+    g->row_group_order = order;
     return GVQA_OK;
 }
 
@@ -336,6 +360,7 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream_) {
     g->valid = st[ST_INVALID] ? 0 : 1;
     g->finalized = 1;
     g->row_group_ptr = nullptr;
+    g->row_group_order = nullptr;
     g->num_row_groups = 0;
     g->max_row_group_edges = 0;
     GVQA_REQUIRE(g->valid, GVQA_E_GRAPH,
@@ -383,6 +408,7 @@ int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const
     g->valid = 1;
     g->finalized = 1;
     g->row_group_ptr = nullptr;
+    g->row_group_order = nullptr;
     g->num_row_groups = 0;
     g->max_row_group_edges = 0;
     if (N > 0 && B > 0 && mn <= ROW_GROUP && B < (1ll << 24))

@@ -259,6 +259,22 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         // older than every ring DMA: the counted waits of the main loop only get stricter by them, never wrong
         if (two_regions && g_cnt[0] > 0 && !(fh.debug & 8)) dma_region(0, 144 * 1024);
     }
+    // Rows of a group are aggregated in the order fh.row_order gives (most in-edges first: the edge loop's trip count is the
+    // largest in-degree among the rows a wave covers, so rows of similar degree belong together).  Slot -> row for this
+    // thread's slots of both groups, loaded now (a dependent load in front of the skip prefetch otherwise).
+    constexpr int MAXIT = 4;
+    constexpr int items = (128 << lqv) / NTH;                 // rows per thread: 128 (q4 / CV) / 512
+    constexpr bool pre = items <= MAXIT;
+    int ord[2][MAXIT];
+    if constexpr (EPI == 2 && pre) {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int k = 0; k < MAXIT; ++k) {
+                const int slot = (tid >> lqv) + k * (NTH >> lqv);
+                ord[gi][k] = (fh.row_order && k < items && slot < g_cnt[gi]) ? fh.row_order[g_ns[gi] + slot] : slot;
+            }
+    }
     // two-piece operands: inverse scales of this wave's rows x the column block's single weight scale (k_split2h_pack, HEADS)
     float sab[TM];
     if constexpr (EPI == 2 && NP == 2) {
@@ -354,17 +370,14 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 if (!two_regions && live) dma_region(1, 128 * 1024);
             }
             // epilogue operands of this thread's rows (skip rows, graph ids) start their trip from HBM now, ahead of the LDS work
-            constexpr int MAXIT = 4;
-            const int items = (128 << lqv) / NTH;             // rows per thread: 128 (q4 / CV) / 512
             float4 sk[MAXIT][CV];
             int gid[MAXIT];
-            const bool pre = items <= MAXIT;
             if (pre && live) {
 #pragma unroll
                 for (int k = 0; k < MAXIT; ++k) {
-                    const int i = (tid >> lqv) + k * (NTH >> lqv);
-                    const bool on = k < items && i < cnt;
-                    const int node = ns + (on ? i : 0);
+                    const int slot = (tid >> lqv) + k * (NTH >> lqv);
+                    const bool on = k < items && slot < cnt;
+                    const int node = ns + (on ? ord[gi][k] : 0);
                     gid[k] = fh.graph_term ? fh.node_graph[node] : 0;
 #pragma unroll
                     for (int v = 0; v < CV; ++v)
@@ -395,9 +408,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 const float* al_l = reinterpret_cast<const float*>(rp_l + al_off);
                 const float4* xs4 = reinterpret_cast<const float4*>(xs);
                 // one output row segment: node i of the group, channels [c, c + 4 CV)
-                auto process = [&](int i_raw, bool have, int gq_pre, const float4 (&sk_pre)[CV]) {
-                    const bool row_on = i_raw < cnt;
-                    const int i = row_on ? i_raw : 0;
+                auto process = [&](int slot, int row, bool have, int gq_pre, const float4 (&sk_pre)[CV]) {
+                    const bool row_on = slot < cnt;
+                    const int i = row_on ? row : 0;
                     const int lo = rp_l[i] - e0, hi = (row_on && !(fh.debug & 2)) ? rp_l[i + 1] - e0 : lo;
                     const int node = ns + i;
                     float4 pb[CV];
@@ -412,14 +425,10 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     // EB edges per trip, every LDS read of a trip issued before its FMAs; the trip count is made wave-uniform
                     // (clamped index, zero weight past the end of the row): a divergent, dependent-load loop was 4x slower
                     constexpr int EB = (8 / (Hh * CV)) > 0 ? 8 / (Hh * CV) : 1;      // 8 row reads (32 VGPRs) in flight per trip
-                    // the wave covers 64 / (q4 / CV) consecutive rows: largest in-degree among them from wave-uniform LDS reads
-                    const int row0 = __builtin_amdgcn_readfirstlane(i_raw - (lane >> lqv));
-                    int maxdeg = 0;
+                    // the wave covers 64 / (q4 / CV) rows: largest in-degree among them
+                    int maxdeg = hi - lo;
 #pragma unroll
-                    for (int r = 0; r < (64 >> lqv); ++r) {
-                        const int rr = min(row0 + r, cnt - 1);
-                        maxdeg = max(maxdeg, rp_l[rr + 1] - rp_l[rr]);
-                    }
+                    for (int o = 32; o >= (1 << lqv); o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o, 64));
                     const int trips = (fh.debug & 2) ? 0 : __builtin_amdgcn_readfirstlane((maxdeg + EB - 1) / EB);
                     float4 a4[CV], b4[CV];                     // two chains per quad: consecutive FMAs do not wait for each other
 #pragma unroll
@@ -488,13 +497,16 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 if (pre) {
 #pragma unroll
                     for (int k = 0; k < MAXIT; ++k) {          // static indices: the prefetched operands stay in registers
-                        const int i = (tid >> lqv) + k * (NTH >> lqv);
-                        if (k < items && __builtin_amdgcn_readfirstlane(i - (lane >> lqv)) < cnt) process(i, true, gid[k], sk[k]);
+                        const int slot = (tid >> lqv) + k * (NTH >> lqv);
+                        if (k < items && __builtin_amdgcn_readfirstlane(slot - (lane >> lqv)) < cnt) process(slot, ord[gi][k], true, gid[k], sk[k]);
                     }
                 } else {
                     const float4 none[CV] = {};
                     for (int idx0 = __builtin_amdgcn_readfirstlane(tid & ~63); idx0 < (cnt << lqv); idx0 += NTH)
-                        process((idx0 + lane) >> lqv, false, 0, none);
+                    {
+                        const int slot = (idx0 + lane) >> lqv;
+                        process(slot, (fh.row_order && slot < cnt) ? fh.row_order[ns + slot] : slot, false, 0, none);
+                    }
                 }
             }
         }

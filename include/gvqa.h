@@ -80,6 +80,8 @@ typedef struct gvqa_graph {
     const int32_t* row_group_ptr;   /* [num_row_groups + 1], device                                */
     int32_t num_row_groups;
     int32_t max_row_group_edges;    /* most in-edges of any row group                              */
+    const int32_t* row_group_order; /* [N], device: the rows of every group by in-degree, largest first (slot s of group r =
+                                       local row row_group_order[row_group_ptr[r] + s]); the fused hop aggregates in this order */
 } gvqa_graph;
 
 size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
