@@ -31,6 +31,7 @@
 // the transposed 32 x 32 tiles and a lane owns 4 consecutive columns of one C row per register quad: the
 // epilogue is float4 stores straight from registers.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_tile.h"
@@ -116,7 +117,7 @@ __device__ __forceinline__ void keep_live(const f32x16& v) {
 // block's C stores fall under its neighbours' main loops instead of every CU storing at the same time.
 // NP: pieces per operand value -- 3: bf16 x 3 (six products), 2: scaled fp16 x 2 (three products; a_inv / b_inv = the rows'
 // inverse power-of-two scales, applied to the accumulators before anything else in every epilogue)
-template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3>
+template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3, int PIPE = 0>
 __global__ __launch_bounds__(64 * WM * WN, (160 * 1024 / (NBUF * (WM * TM + WN * TN) * NP * 1024)) * WM * WN / 4)
 void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int rtA,
                                                                const uint16_t* __restrict__ Bpk, int rtB, LinearEpilogue ep,
@@ -154,6 +155,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const int slot = ((blockIdx.y * gridDim.x + blockIdx.x) >> 8) % STAG;
         for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
+
+    // (measurement aid, NOSTORE variants: shader-clock cycles and 100 MHz ticks of this block -> C[2 block], C[2 block + 1])
+    const uint64_t clk0 = NOSTORE ? __builtin_readcyclecounter() : 0, rt0 = NOSTORE ? __builtin_amdgcn_s_memrealtime() : 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -283,6 +287,77 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         for (int i = 0; i < TM; ++i) sab[i] = a_inv[(bm * FA + wr * TM + i) * 32 + (lane & 31)] * sbu;
     }
 
+    if constexpr (PIPE) {
+        // ---- software-pipelined main loop: the fragments of step s+1 are read from LDS (into a second register set) while the
+        // matrix cores work on step s, so the LDS reads of all waves -- which leave the barrier together -- no longer sit
+        // between the barrier and the first MFMA.  The whole ring is in flight: iteration s waits for step s+1, and step
+        // s+NBUF goes into the slot of step s (whose fragments every wave finished reading before the barrier).
+        static_assert(!PIPE || (NBUF == 4 && ILV), "pipelined loop: four-slot ring, interleaved DMA issue");
+#pragma unroll
+        for (int s = 0; s < NBUF; ++s)
+            if (s < KB) issue(s);
+        {
+            const int fl = min(NBUF - 1, KB - 1);      // steps 1 .. may stay in flight
+            if (fl >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP * TPW) : "memory");
+            else if (fl == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * TPW) : "memory");
+            else if (fl == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * TPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        frag_t fa[2][TM][NP], fb[2][TN][NP];
+        auto read_frags = [&](int slot, frag_t (&a)[TM][NP], frag_t (&b)[TN][NP]) {
+            const unsigned char* sb = smem + slot * STAGE;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    a[i][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + a_off + (i * NP + p) * 1024));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    b[j][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + b_off + (j * NP + p) * 1024));
+        };
+        read_frags(0, fa[0], fb[0]);
+        int slot = 0;                                  // ring slot of step s
+        // (the wait / barrier / read-ahead also run in the last step, where they fetch a stale slot nobody uses: a run-time
+        //  "is there a next step" branch around the reads makes the compiler wait for ALL LDS reads where the paths join,
+        //  in front of the MFMAs -- and peeling the last step off made it spill)
+        auto body = [&](int s, frag_t (&ca)[TM][NP], frag_t (&cb)[TN][NP], frag_t (&na)[TM][NP], frag_t (&nb)[TN][NP]) {
+            const int nslot = slot + 1 == NBUF ? 0 : slot + 1;
+            {
+                const int ahead = min(NBUF - 2, KB - 2 - s);          // steps s+2 .. may stay in flight (<= 0 at the end)
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP * TPW) : "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * TPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // this wave's reads of step s (issued one iteration ago) are complete: its slot may be refilled after the barrier.
+                // (the builtin, not inline asm: the compiler's own wait-count bookkeeping sees it and does not add an
+                //  lgkmcnt(0) of its own AFTER the reads below, which would serialise them with the MFMAs again)
+                __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0), vmcnt / expcnt untouched
+                __builtin_amdgcn_s_barrier();
+                read_frags(nslot, na, nb);
+            }
+            const bool more = s + NBUF < KB;
+#define GVQA_S3_PAIR(pa_, pb_, g_)                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)          \
+                acc[i][j] = split_mfma(cb[j][pb_], ca[i][pa_], acc[i][j]);                                         \
+            if (more) {                                                                                            \
+                _Pragma("unroll") for (int q = (g_) * TPW / NG + ((g_) * TPW % NG ? 1 : 0); q * NG < ((g_) + 1) * TPW; ++q) \
+                    if (q * NG >= (g_) * TPW) issue_triple(slot, q);                                               \
+            }
+            if constexpr (NP == 3) {
+                GVQA_S3_PAIR(2, 0, 0) GVQA_S3_PAIR(1, 1, 1) GVQA_S3_PAIR(0, 2, 2) GVQA_S3_PAIR(1, 0, 3) GVQA_S3_PAIR(0, 1, 4) GVQA_S3_PAIR(0, 0, 5)
+            } else {
+                GVQA_S3_PAIR(1, 0, 0) GVQA_S3_PAIR(0, 1, 1) GVQA_S3_PAIR(0, 0, 2)
+            }
+#undef GVQA_S3_PAIR
+            slot = nslot;
+        };
+        for (int s = 0; s < KB; s += 2) {
+            body(s, fa[0], fb[0], fa[1], fb[1]);
+            if (s + 1 < KB) body(s + 1, fa[1], fb[1], fa[0], fb[0]);
+        }
+    } else {
     // prologue: NBUF - 1 steps in flight
 #pragma unroll
     for (int s = 0; s < NBUF - 1; ++s)
@@ -336,12 +411,18 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         buf = buf + 1 == NBUF ? 0 : buf + 1;
         pf = pf + 1 == NBUF ? 0 : pf + 1;
     }
+    }
 
     if (NOSTORE) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) keep_live(acc[i][j]);
+        if (tid == 0 && C) {
+            const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+            C[2 * blk] = (float)(__builtin_readcyclecounter() - clk0);
+            C[2 * blk + 1] = (float)(__builtin_amdgcn_s_memrealtime() - rt0);
+        }
         return;
     }
     if constexpr (EPI == 2) {
@@ -864,7 +945,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     const uint16_t* a = static_cast<const uint16_t*>(Apk);
     const uint16_t* b = static_cast<const uint16_t*>(Bpk);
     int variant = split3_variant(M, N, KB);            // (a forced variant >= 100 names a two-piece instantiation)
-    if (np == 2 && variant < 100) variant = variant < 20 ? 114 : 134;
+    if (np == 2 && variant < 100) variant = variant < 20 ? 118 : 134;
     GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
     const int64_t bm = variant % 100 < 20 ? 256 : 128;
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, cdiv(M, 32), KB) : nullptr;
@@ -882,13 +963,14 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
         const uint16_t* a2 = a + (m0 / 32) * (int64_t)KB * (np * 512);
         const float* a_inv2 = a_inv ? a_inv + m0 : nullptr;
         const int rt2 = (int)cdiv(m, 32);
-#define GVQA_S3_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_) GVQA_SN_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 3)
-#define GVQA_SN_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_)                                       \
+#define GVQA_S3_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_) GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 3, 0)
+#define GVQA_SN_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_) GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, 0)
+#define GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_)                                \
         do {                                                                                                             \
             dim3 grid((unsigned)cdiv(N, 32 * WN_ * TN_), (unsigned)cdiv(m, 32 * WM_ * TM_));                              \
             /* a block's MFMA issue time x the STAG_ blocks sharing the SIMDs, split into STAG_ start offsets */         \
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
-            hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_>), grid, \
+            hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_, PIPE_>), grid, \
                                dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C + m0 * ldc, ldc, \
                                STAG_ == 0 ? loop_dbg : (stag_scale > 0 ? stag * stag_scale / 4 : stag), FusedHopArgs{},   \
                                a_inv2, b_inv);                                                                           \
@@ -914,6 +996,8 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
             case 113: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2); break;
             case 114: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2); break;
             case 115: GVQA_SN_LAUNCH(2, 4, 4, 2, 3, true, false, true, 0, 0, 2); break;
+            case 117: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2, 1); break;
+            case 118: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2, 1); break;
             case 116: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, false, false, true, 0, 0, 2); break;
             case 123: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, true, 0, 0, 2); break;
             case 133: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, true, 0, 0, 2); break;
@@ -922,6 +1006,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
         }
 #undef GVQA_S3_LAUNCH
 #undef GVQA_SN_LAUNCH
+#undef GVQA_SP_LAUNCH
     }
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
@@ -1133,6 +1218,7 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
     }
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, rtA, KB) : nullptr;
     const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
+    // (the read-ahead main loop, PIPE, gains 3 % in the plain GEMM and nothing here: 317 us either way for the main loop alone)
 #define GVQA_FUSED_LAUNCH(H_, NBUF_, NP_)                                                                                       \
     hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, H_, NP_>), grid, dim3(512), 0, stream,     \
                        f.num_groups * 128, ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), \

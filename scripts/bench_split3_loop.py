@@ -25,4 +25,8 @@ _lib.set_option(_lib.OPT_SPLIT3_VARIANT, var)
 for rnd in range(2):
     for dbg in (0, 16, 32, 48, 64, 112):
         os.environ["GVQA_SPLIT3_LOOP_DEBUG"] = str(dbg)
-        print(json.dumps({"variant": var, "loop_debug": dbg, "us": round(timeit(), 1)}), flush=True)
+        us = round(timeit(), 1)
+        nb = (M // 256 if var % 100 < 20 else M // 128) * (N // 256)
+        clk = C.flatten()[:2 * nb].view(nb, 2).double().cpu()
+        print(json.dumps({"variant": var, "loop_debug": dbg, "us": us, "block_cycles": round(float(clk[:, 0].mean())),
+                          "block_us": round(float(clk[:, 1].mean()) / 100, 2), "shader_mhz": round(float((clk[:, 0] / clk[:, 1]).mean()) * 100)}), flush=True)
