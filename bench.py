@@ -92,7 +92,13 @@ def live_pmc_traffic():
         return {"error": "rocprofv3 not found"}
     import re
     # the fused hop is the EPI = 2 instantiation (template arguments ..., EPI, heads, pieces), demangled or mangled
-    kinds = {"fused": lambda n: bool(re.search(r"k_linear_split3<[^>]*,\s*2,\s*[1248],\s*[23]>", n)) or bool(re.search(r"k_linear_split3.*ELi2ELi[1248]ELi[23]EEEv", n)),
+    def is_fused(n):
+        m = re.search(r"k_linear_split3<([^>]*)>", n)
+        if m:
+            args = [t.strip() for t in m.group(1).split(",")]
+            return len(args) > 10 and args[9] == "2"               # template argument 10 = EPI
+        return bool(re.search(r"k_linear_split3I(?:L[ib]\d+E){9}Li2E", n))    # mangled
+    kinds = {"fused": is_fused,
              "mp": lambda n: "k_gat_mp_tiled" in n}
     acc = {k: {} for k in kinds}
     try:
@@ -240,8 +246,14 @@ def main():
     strong = a.scaling == "strong"
     if a.emulate_world > 1 and world == 1:       # one rank's share of an N-way strong-scaling run, on this one GPU
         sh = make_shard(0, a.emulate_world)
-        t = timed(runner(sh), a.steps, a.warmup) / a.steps
+        run = runner(sh)
+        t = timed(run, a.steps, a.warmup) / a.steps
+        _lib.prof_enable(True); _lib.prof_collect()
+        timed(run, a.steps, 0)
+        pr = _lib.prof_collect(); _lib.prof_enable(False)
         print(json.dumps({"emulated_world": a.emulate_world, "graphs": sh.num_graphs, "edges": sh.num_edges, "ms_per_step": t * 1e3,
+                          "gpu_stage_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in pr.items() if v[1]},
+                          "gpu_stage_sum_ms": round(sum(v[0] for v in pr.values()) / a.steps, 4),
                           "note": "rank 0's shard only, no all-gather; whole-job edges/s would be <= "
                                   f"{Eall / t:.4g} if every rank matched it"}))
         return

@@ -747,7 +747,8 @@ __device__ __forceinline__ void load_row8(const float* row, bool on, int k0, int
     }
 }
 
-// One block (4 waves) per 32-row tile; wave w walks k blocks w, w + 4, ...  Pass 1 finds the rows' largest magnitudes (two k
+// One block (4 waves) per 32-row tile; wave w walks the k-block PAIRS 2w, 2w + 1, 2w + 8, 2w + 9, ... (a pair is one 128-byte
+// line of every row: its four 16-byte-per-lane loads come from the same wave back to back).  Pass 1 finds the rows' largest magnitudes (two k
 // halves of a wave by lane ^ 32, the four waves through LDS), pass 2 writes the scaled pieces.  NIT > 0: a thread's (at most)
 // NIT k blocks stay in registers between the passes (rows read once); NIT == 0: any K, rows read twice.  J > 0 (GROUPS):
 // a_node[node, j] = sum_k x[node, k] Vn[j, k] on the way, as in k_split3_pack_groups_logits.
@@ -773,16 +774,20 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
     const int kh = (lane >> 5) * 8;
     float v[NR][8];
     float mx = 0.f;
+    auto kb_of = [&](int it) { return ((it >> 1) << 3) + 2 * wave + (it & 1); };
+    const int nit_all = ((KB + 7) >> 3) * 2;                          // iterations that cover every k block (NIT == 0 path)
     if (NIT > 0) {
 #pragma unroll
         for (int it = 0; it < NR; ++it) {
-            const int kb = wave + 4 * it;
+            const int kb = kb_of(it);
             load_row8(row, row_on && kb < KB, kb * 16 + kh, K, vec, v[it]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[it][e]));
         }
     } else {
-        for (int kb = wave; kb < KB; kb += 4) {
+        for (int it = 0; it < nit_all; ++it) {
+            const int kb = kb_of(it);
+            if (kb >= KB) continue;
             load_row8(row, row_on, kb * 16 + kh, K, vec, v[0]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[0][e]));
@@ -832,9 +837,11 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
     if (NIT > 0) {
 #pragma unroll
         for (int it = 0; it < NR; ++it)
-            if (wave + 4 * it < KB) emit(wave + 4 * it, v[it]);
+            if (kb_of(it) < KB) emit(kb_of(it), v[it]);
     } else {
-        for (int kb = wave; kb < KB; kb += 4) {
+        for (int it = 0; it < nit_all; ++it) {
+            const int kb = kb_of(it);
+            if (kb >= KB) continue;
             load_row8(row, row_on, kb * 16 + kh, K, vec, v[0]);
             emit(kb, v[0]);
         }
