@@ -132,8 +132,9 @@ struct FusedHopArgs {
 size_t split_packed_rows_bytes(int np, int64_t row_tiles, int64_t K);
 // Vn / J / a_node: NULL / 0 / NULL, or the folded attention vectors [J = 2 H, K]: a_node[N, J] = X . Vn^T is produced on the way
 bool split_pack_groups_logits_supported(int np, int J, int64_t K);
+// Vn_packed (two-piece form only): NULL or the packed image of Vn (launch_split_pack(2, J, K, Vn, ...)): logits on the matrix cores
 int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
-                             const float* Vn, int J, float* a_node, hipStream_t stream);
+                             const float* Vn, int J, float* a_node, hipStream_t stream, const void* Vn_packed = nullptr);
 int launch_split_pack_heads(int np, int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
 size_t hop_fused_lds_edge_capacity(int H);

@@ -501,11 +501,74 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     }
 }
 
+// The same coefficients, one block per ROW GROUP of the fused hop (<= 128 consecutive nodes, whole graphs): phase 1 is parallel
+// over the group's CSR slots -- index loads and the two gathers of every slot are independent, nothing is read back from global
+// memory -- and leaves a_l[src] + a_e[eid] in LDS; phase 2, one thread per (node, head), runs the three softmax passes out of
+// LDS.  Same operations in the same order as k_gat_alpha_general: bit-identical coefficients, without its three dependent
+// trips to L2 per edge (26 -> 17 us per hop at config 3, 15 -> 12 on a 256-graph shard, launch gaps included; starting the
+// phase-2 operand loads before phase 1 changed nothing).
+__global__ __launch_bounds__(256) void k_gat_alpha_groups(MpArgs a, int H, const int32_t* __restrict__ group_ptr) {
+    extern __shared__ float raw_s[];                        // [slots of the group][H]
+    const int tid = threadIdx.x;
+    const int ns = group_ptr[blockIdx.x], cnt = group_ptr[blockIdx.x + 1] - ns;
+    const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
+    const bool v4 = (H & 3) == 0 && (a.a_edge_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.a_edge) & 15) == 0 &&
+                    (!a.a_node || (reinterpret_cast<uintptr_t>(a.a_node) & 15) == 0);
+    for (int s = tid; s < ne; s += 256) {
+        const int src = a.csr_src[e0 + s], eid = a.csr_eid[e0 + s];
+        const float* an = a.a_node ? a.a_node + (int64_t)src * 2 * H : nullptr;
+        const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
+        if (v4) {
+            for (int h = 0; h < H; h += 4) {
+                const float4 x = an ? *reinterpret_cast<const float4*>(an + h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 y = *reinterpret_cast<const float4*>(ae + h);
+                *reinterpret_cast<float4*>(raw_s + s * H + h) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+            }
+        } else {
+            for (int h = 0; h < H; ++h) raw_s[s * H + h] = (an ? an[h] : 0.f) + ae[h];
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < cnt * H; it += 256) {
+        const int i = it / H, h = it - i * H, node = ns + i;
+        const int lo = a.rowptr[node] - e0, hi = a.rowptr[node + 1] - e0;
+        float ar = a.a_node ? a.a_node[(int64_t)node * 2 * H + H + h] : 0.f;
+        if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[node] * a.t_ld + a.C + h];
+        float m = -INFINITY;
+        for (int s = lo; s < hi; ++s) {
+            const float v = leaky(raw_s[s * H + h] + ar, a.slope);
+            raw_s[s * H + h] = v;
+            m = fmaxf(m, v);
+        }
+        float sum = 0.f;
+        for (int s = lo; s < hi; ++s) {
+            const float ex = expf(raw_s[s * H + h] - m);
+            raw_s[s * H + h] = ex;
+            sum += ex;
+        }
+        const float den = sum + 1e-16f;
+        for (int s = lo; s < hi; ++s) {
+            float al = raw_s[s * H + h] / den;
+            if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+            if (a.alpha_mask) al *= a.alpha_mask[(int64_t)a.csr_eid[e0 + s] * H + h];
+            a.alpha_csr[(int64_t)(e0 + s) * H + h] = al;
+        }
+    }
+}
+
 // attention coefficients of every edge in CSR slot order -> a.alpha_csr (and a.alpha_out in COO order)
 // (one thread per (node, head), three passes through alpha_csr.  Measured SLOWER at config 3: one thread per node with all heads
 // in registers and 16-byte accesses -- 31 vs 25 us, a quarter of the threads; logits of short rows kept in registers, one
 // round of 8 clamped gathers instead of three dependent passes -- 34 vs 27 us)
-static int launch_alpha(const MpArgs& a, int H, hipStream_t stream) {
+static int launch_alpha(const MpArgs& a, int H, hipStream_t stream, const gvqa_graph* g = nullptr) {
+    // row groups planned and the largest group's logits within 64 KiB of LDS: the group kernel
+    if (g && g->num_row_groups > 0 && g->row_group_ptr && (size_t)g->max_row_group_edges * H * sizeof(float) <= 64 * 1024 &&
+        !getenv("GVQA_ALPHA_GENERAL")) {
+        const size_t lds = std::max<size_t>((size_t)g->max_row_group_edges * H * sizeof(float), 16);
+        hipLaunchKernelGGL(k_gat_alpha_groups, dim3((unsigned)g->num_row_groups), dim3(256), lds, stream, a, H, g->row_group_ptr);
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
     hipLaunchKernelGGL(k_gat_alpha_general, dim3((unsigned)cdiv((int64_t)a.N * H, 256)), dim3(256), 0, stream, a, H);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
@@ -747,8 +810,8 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
 // not change.  layout: see weight_layout_id.
 struct WeightCacheLayout {
-    size_t Vn, Ve, Gw, w6, w6_hop, total;
-};
+    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, total;     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
+};                                                             // pack pass computes the attention logits on the matrix cores)
 static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout) {
     WeightCacheLayout W;
     size_t off = 0;
@@ -761,6 +824,8 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.w6_hop = layout < 0 ? 0 : (layout & 1) ? split_packed_rows_bytes(np, cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
                                              : split_packed_bytes(np, (int64_t)(H * C), d->node_dim);
     W.w6 = take(K * W.w6_hop);
+    W.vn2h_hop = layout == 3 ? align_up(split_packed_bytes(2, 2 * (int64_t)H, d->node_dim), 256) : 0;
+    W.vn2h = take(K * W.vn2h_hop);
     W.total = off;
     return W;
 }
@@ -982,6 +1047,14 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
             if (rc) return rc;
         }
     }
+    if (W.vn2h_hop) {      // two-piece images of the folded attention vectors (after the fold, on its stream)
+        StageTimer t(GVQA_STAGE_PACK, fold_stream);
+        for (int i = 0; i < K; ++i) {
+            rc = launch_split_pack(2, 2 * (int64_t)H, Dn, reinterpret_cast<const float*>(cache + W.Vn) + (int64_t)i * 2 * H * Dn, Dn,
+                                   cache + W.vn2h + (size_t)i * W.vn2h_hop, fold_stream);
+            if (rc) return rc;
+        }
+    }
     return GVQA_OK;
 }
 
@@ -1062,7 +1135,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             if (ss) { rc = side_join(ss, stream); if (rc) return rc; }      // Vn comes from the fold on the side stream (hop 0)
             StageTimer tp(GVQA_STAGE_PACK, stream);
             rc = launch_split_pack_groups(np, g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, Vn_all + (int64_t)i * 2 * H * Dn, 2 * H,
-                                          P(L.a_node), stream);
+                                          P(L.a_node), stream, WL.vn2h_hop ? wbase + WL.vn2h + (size_t)i * WL.vn2h_hop : nullptr);
             if (rc) return rc;
         } else {   // (a_l | a_r) node halves = h . [V_l | V_r]     (side stream)
             StageTimer t(GVQA_STAGE_NODE_LOGIT, aux);
@@ -1084,7 +1157,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             a.N = (int)N; a.C = C; a.slope = d->negative_slope;
             {   // (when the logits ride on the pack pass, it ran above, before the coefficients)
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
-                rc = launch_alpha(a, H, stream);
+                rc = launch_alpha(a, H, stream, g);
                 if (rc) return rc;
             }
             if (!logits_in_pack) {

@@ -693,8 +693,7 @@ __device__ __forceinline__ int split2h_exponent(float rowmax) {
     return max(-114, min(126, 14 - e));                               // 2^e and 2^-e are normal fp32 numbers
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
-__device__ __forceinline__ void split2h_store(const float (&v)[8], float scale, uint16_t* o) {
-    f16x8_t p0, p1;
+__device__ __forceinline__ void split2h_store(const float (&v)[8], float scale, uint16_t* o, f16x8_t& p0, f16x8_t& p1) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float x = v[e] * scale;
@@ -751,17 +750,22 @@ __device__ __forceinline__ void load_row8(const float* row, bool on, int k0, int
 // line of every row: its four 16-byte-per-lane loads come from the same wave back to back).  Pass 1 finds the rows' largest magnitudes (two k
 // halves of a wave by lane ^ 32, the four waves through LDS), pass 2 writes the scaled pieces.  NIT > 0: a thread's (at most)
 // NIT k blocks stay in registers between the passes (rows read once); NIT == 0: any K, rows read twice.  J > 0 (GROUPS):
-// a_node[node, j] = sum_k x[node, k] Vn[j, k] on the way, as in k_split3_pack_groups_logits.
-template <int MAP, int J, int NIT>
+// a_node[node, j] = sum_k x[node, k] Vn[j, k] on the way.  LM = 0: fp32 FMAs against Vn in LDS, as in
+// k_split3_pack_groups_logits (one LDS read per FMA: 20 us of a 70 us pass at config 3).  LM = 1: on the matrix cores -- the
+// pieces this lane has just made ARE the A fragment of a 32x32x16 MFMA; against the two-piece image of Vn (`vn_pk`: one 32-row
+// tile, rows >= J zero, packed like any weight operand and cached with the weights) three MFMAs per k block give the tile's
+// logits in the projection's own arithmetic, rescaled exactly by the two inverse scales.
+template <int MAP, int J, int NIT, int LM>
 __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB, uint16_t* __restrict__ out, float* __restrict__ inv_scale,
-                                                      int vec, const float* __restrict__ Vn, float* __restrict__ a_node) {
-    extern __shared__ __attribute__((aligned(16))) float pk_s[];      // [4][32] row maxima | [J][Kp] Vn | [4][32][J] partial dots
-    constexpr int JJ = J > 0 ? J : 1, NR = NIT > 0 ? NIT : 1;
+                                                      int vec, const float* __restrict__ Vn, float* __restrict__ a_node,
+                                                      const uint16_t* __restrict__ vn_pk, const float* __restrict__ vn_inv) {
+    extern __shared__ __attribute__((aligned(16))) float pk_s[];      // [4][32] row maxima | LM 0: [J][Kp] Vn | [4][32][J] partial dots
+    constexpr int JJ = (J > 0 && !LM) ? J : 1, NR = NIT > 0 ? NIT : 1;
     const int Kp = KB * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* mx_s = pk_s;
     float* vn_s = pk_s + 128;
-    if (J > 0) {
+    if (J > 0 && !LM) {
         for (int idx = tid; idx < J * Kp; idx += 256) {
             const int j = idx / Kp, k = idx - j * Kp;
             vn_s[idx] = k < K ? Vn[(int64_t)j * K + k] : 0.f;
@@ -823,9 +827,20 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
     float acc[JJ];
 #pragma unroll
     for (int j = 0; j < JJ; ++j) acc[j] = 0.f;
+    f32x16 lacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
     auto emit = [&](int kb, const float (&w)[8]) {
-        split2h_store(w, scale, out + ((rt * KB + kb) * 2) * 512 + lane * 8);
-        if (J > 0) {
+        f16x8_t p0, p1;
+        split2h_store(w, scale, out + ((rt * KB + kb) * 2) * 512 + lane * 8, p0, p1);
+        if constexpr (J > 0 && LM) {
+            const uint16_t* vb = vn_pk + (int64_t)kb * 1024 + lane * 8;
+            const f16x8_t q0 = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(vb));
+            const f16x8_t q1 = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(vb + 512));
+            lacc = split_mfma(q1, p0, lacc);                      // transposed accumulators, as in the GEMM: lane (m, hh) holds
+            lacc = split_mfma(q0, p1, lacc);                      // columns 8 q + 4 hh + 0..3 of row m in registers 4 q + 0..3
+            lacc = split_mfma(q0, p0, lacc);
+        } else if (J > 0) {
             const int k0 = kb * 16 + kh;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -847,11 +862,24 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
         }
     }
     if (J > 0) {
-        float* part = vn_s + J * Kp;                                  // [4 waves][32 rows][J]
+        float* part = LM ? vn_s : vn_s + J * Kp;                      // [4 waves][32 rows][J]
+        if constexpr (LM) {
+            const int hh = lane >> 5;
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const float t = acc[j] + __shfl_xor(acc[j], 32, 64);      // the two k halves of the row
-            if (lane < 32) part[(wave * 32 + lane) * J + j] = t;
+            for (int q = 0; q < (J + 7) / 8; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 8 * q + 4 * hh + r;
+                    if (j < J) part[(wave * 32 + m) * J + j] = lacc[4 * q + r];
+                }
+            __syncthreads();                                          // every read of the row maxima is done, too
+            if (tid < 32) mx_s[tid] = pow2i(-ex);                     // this row's inverse scale, for the threads that finish it
+        } else {
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) {
+                const float t = acc[j] + __shfl_xor(acc[j], 32, 64);  // the two k halves of the row
+                if (lane < 32) part[(wave * 32 + lane) * J + j] = t;
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < 32 * J; idx += 256) {
@@ -859,27 +887,38 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
             bool on2;
             int64_t node;
             pack_row<MAP>(pr, rt, r, on2, node);
-            if (on2)
-                a_node[node * J + j] = (part[(0 * 32 + r) * J + j] + part[(1 * 32 + r) * J + j]) +
-                                       (part[(2 * 32 + r) * J + j] + part[(3 * 32 + r) * J + j]);
+            if (on2) {
+                float t = (part[(0 * 32 + r) * J + j] + part[(1 * 32 + r) * J + j]) + (part[(2 * 32 + r) * J + j] + part[(3 * 32 + r) * J + j]);
+                if constexpr (LM) t = t * mx_s[r] * vn_inv[j];
+                a_node[node * J + j] = t;
+            }
         }
     }
 }
 
-static size_t split2h_pack_lds(int J, int KB) { return (128 + (size_t)J * KB * 16 + 4 * 32 * (size_t)J) * sizeof(float); }
+static size_t split2h_pack_lds(int J, int KB, bool mfma_logits = false) {
+    return (128 + (mfma_logits ? 0 : (size_t)J * KB * 16) + 4 * 32 * (size_t)J) * sizeof(float);
+}
 
+// Vn_packed: NULL, or the two-piece image of Vn [J, K] (gvqa layout of one 32-row tile + its inverse scales): logits on the
+// matrix cores (LM = 1) instead of fp32 FMAs against the fp32 Vn
 template <int MAP>
 static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, void* packed, const float* Vn, int J, float* a_node,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, const void* Vn_packed = nullptr) {
     const int KB = (int)cdiv(K, 16);
     const int vec = (reinterpret_cast<uintptr_t>(pr.X) & 15) == 0 && pr.ld % 4 == 0;
     uint16_t* o = static_cast<uint16_t*>(packed);
     float* inv = const_cast<float*>(split2h_inv_scales(packed, RT, KB));
-    const size_t lds = split2h_pack_lds(J, KB);
+    const bool lm = J > 0 && Vn_packed != nullptr;
+    const size_t lds = split2h_pack_lds(J, KB, lm);
     const dim3 grid((unsigned)RT), block(256);
-#define GVQA_P2(J_, NIT_) hipLaunchKernelGGL((k_split2h_pack<MAP, J_, NIT_>), grid, block, lds, stream, pr, (int)K, KB, o, inv, vec, Vn, a_node)
+    const uint16_t* vpk = static_cast<const uint16_t*>(Vn_packed);
+    const float* vinv = lm ? split2h_inv_scales(Vn_packed, 1, KB) : nullptr;
+#define GVQA_P2L(J_, NIT_, LM_) hipLaunchKernelGGL((k_split2h_pack<MAP, J_, NIT_, LM_>), grid, block, lds, stream, pr, (int)K, KB, o, inv, vec, Vn, \
+                                                   a_node, vpk, vinv)
+#define GVQA_P2(J_, NIT_) do { if (lm) GVQA_P2L(J_, NIT_, 1); else GVQA_P2L(J_, NIT_, 0); } while (0)
     if (J == 0) {
-        if (KB <= 32) GVQA_P2(0, 8); else GVQA_P2(0, 0);
+        if (KB <= 32) GVQA_P2L(0, 8, 0); else GVQA_P2L(0, 0, 0);
     } else if constexpr (MAP == PACK_GROUPS) {
         const bool regs = KB <= 32;
         switch (J) {
@@ -893,6 +932,7 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
         return GVQA_E_UNSUPPORTED;
     }
 #undef GVQA_P2
+#undef GVQA_P2L
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -1138,12 +1178,12 @@ __global__ __launch_bounds__(256) void k_split3_pack_heads(int H, int C, int cw,
 }
 
 bool split_pack_groups_logits_supported(int np, int J, int64_t K) {
-    const size_t lds = np == 2 ? split2h_pack_lds(J, (int)cdiv(K, 16)) : ((size_t)J * cdiv(K, 16) * 16 + 4 * 32 * (size_t)J) * sizeof(float);
+    const size_t lds = np == 2 ? split2h_pack_lds(J, (int)cdiv(K, 16)) : ((size_t)J * cdiv(K, 16) * 16 + 4 * 32 * (size_t)J) * sizeof(float);   // (fp32-Vn form)
     return (J == 2 || J == 4 || J == 8 || J == 16) && lds <= 64 * 1024;
 }
 
 int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
-                             const float* Vn, int J, float* a_node, hipStream_t stream) {
+                             const float* Vn, int J, float* a_node, hipStream_t stream, const void* Vn_packed) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack_groups: 2 or 3 pieces");
     GVQA_REQUIRE(num_groups >= 0 && K > 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split3_pack_groups: bad size");
     if (num_groups == 0) return GVQA_OK;
@@ -1157,7 +1197,7 @@ int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, i
                      "split_pack_groups: logits on the way need 2 H in {2, 4, 8, 16} and [2 H, K] within 64 KiB of LDS");
         PackRows pr{X, ld, 0, group_ptr, 0, 0, 0};
         return launch_split2h_pack_tiles<PACK_GROUPS>(pr, RT, K, packed, with_logits ? Vn : nullptr, with_logits ? J : 0,
-                                                      with_logits ? a_node : nullptr, stream);
+                                                      with_logits ? a_node : nullptr, stream, with_logits ? Vn_packed : nullptr);
     }
     const size_t lds = ((size_t)J * KB * 16 + 4 * 32 * (size_t)J) * sizeof(float);
     if (Vn && a_node && (J == 2 || J == 4 || J == 8 || J == 16) && lds <= 64 * 1024) {     // logits on the way (rows read once)

@@ -4,6 +4,7 @@ Tolerance: north_star states <= 1e-4 max-abs in fp32 against the reference forwa
 assert that bound against the golden vectors (recorded from the reference's code) and a tighter
 one against the fp64 oracle where sizes allow.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -409,6 +410,13 @@ def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
                                         return_attention_weights=True, return_hops=True)
         prof = _lib.prof_collect(); _lib.prof_enable(False)
         assert prof["alpha"][1] == K and prof["mp"][1] == 0            # the fused path ran: no message-passing launches
+        os.environ["GVQA_ALPHA_GENERAL"] = "1"                         # coefficients by the per-(node, head) kernel instead of the
+        try:                                                           # row-group kernel: same operations, bit-identical
+            _, alpha_g, _ = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch,
+                                         return_attention_weights=True, return_hops=True)
+        finally:
+            os.environ.pop("GVQA_ALPHA_GENERAL", None)
+        assert torch.equal(alpha, alpha_g)
         _lib.set_option(_lib.OPT_HOP_FUSION, 0)
         out_u = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
         _lib.set_option(_lib.OPT_HOP_FUSION, 1)
