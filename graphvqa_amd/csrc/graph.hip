@@ -327,12 +327,8 @@ int gvqa_graph_build(int64_t N, int64_t E, int64_t B, const int64_t* edge_index,
                            P(L.rowptr), P(L.slot_eid), P(L.csr_eid), P(L.csr_src));
         GVQA_LAUNCH_CHECK();
     }
-    int64_t mb = N > B ? N : B;
-    if (mb > 0) {
-        hipLaunchKernelGGL(k_stats, dim3((unsigned)cdiv(mb, 256)), dim3(256), 0, stream, N, B, P(L.rowptr),
-                           P(L.graph_ptr), P(L.stats));
-        GVQA_LAUNCH_CHECK();
-    }
+    // (the size statistics -- k_stats -- are computed by gvqa_graph_finalize, the only reader: gvqa_graph_finalize_host takes
+    //  them from the caller's per-graph layout instead and the step saves the launch)
     memset(out, 0, sizeof(*out));
     out->num_nodes = N;
     out->num_edges = E;
@@ -351,6 +347,14 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream_) {
     GVQA_REQUIRE(g && g->stats_dev, GVQA_E_INVALID, "gvqa_graph_finalize: graph not built");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int32_t st[8];
+    {
+        const int64_t mb = g->num_nodes > g->num_graphs ? g->num_nodes : g->num_graphs;
+        if (mb > 0) {
+            hipLaunchKernelGGL(k_stats, dim3((unsigned)cdiv(mb, 256)), dim3(256), 0, stream, g->num_nodes, g->num_graphs, g->rowptr,
+                               g->graph_ptr, const_cast<int32_t*>(g->stats_dev));
+            GVQA_LAUNCH_CHECK();
+        }
+    }
     GVQA_HIP_CHECK(hipMemcpyAsync(st, g->stats_dev, sizeof(st), hipMemcpyDeviceToHost, stream));
     GVQA_HIP_CHECK(hipStreamSynchronize(stream));
     g->max_graph_nodes = st[ST_MAX_GNODES];
