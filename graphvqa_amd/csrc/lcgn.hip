@@ -282,8 +282,15 @@ __global__ __launch_bounds__(256) void k_lcgn_aggregate_bf16(int N, int C, const
 // Call-invariant weight forms (stacked fp32 matrices + the bf16 pieces of the node-GEMM weights): built by
 // lcgn_pack into a caller-held blob (gvqa_lcgn_pack_weights) or, per call, into the workspace.
 struct LcgnPack {
-    size_t Wx, Wj, Wpc, Wq, bq, Wpk, total;
+    size_t Wx, Wj, Wpc, Wq, bq, Wpk, W2h, total;
+    size_t w2h[8];          // byte offsets of the eight node-GEMM weights' two-piece images inside W2h (fp32 mode)
 };
+// the eight node-GEMM weights in one table: rows, K (order: proj_x_loc, Wx, Wj, proj_x_ctx, output, fin[:, :O], fin[:, O:], init)
+static void lcgn_node_weight_shapes(const gvqa_lcgn_dims* d, int64_t (&rows)[8], int64_t (&K)[8]) {
+    const int64_t O = d->out_channels, Cin = d->in_channels;
+    const int64_t r[8] = {O, 3 * O, 3 * O, O, O, O, O, O}, k[8] = {O, O, 2 * O, O, 2 * O, O, O, Cin};
+    for (int i = 0; i < 8; ++i) { rows[i] = r[i]; K[i] = k[i]; }
+}
 static LcgnPack lcgn_pack_layout(const gvqa_lcgn_dims* d) {
     LcgnPack L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
@@ -291,6 +298,12 @@ static LcgnPack lcgn_pack_layout(const gvqa_lcgn_dims* d) {
     L.Wx = take(3 * O * O); L.Wj = take(3 * O * 2 * O); L.Wpc = take(2 * O * O); L.Wq = take(T * O * O); L.bq = take(T * O);
     // node-GEMM weights as bf16 pieces: (15 O^2 + O K8) elements x <= 2 pieces x 2 bytes
     L.Wpk = take(d->node_bf16 ? 15 * O * O + O * K8 : 0);
+    // fp32 mode: two-piece fp16 images of the same weights (split2h projection arithmetic, split3.hip)
+    int64_t rows[8], Kk[8];
+    lcgn_node_weight_shapes(d, rows, Kk);
+    size_t w2 = 0;
+    for (int i = 0; i < 8; ++i) { L.w2h[i] = w2; w2 += d->node_bf16 ? 0 : align_up(split_packed_bytes(2, rows[i], Kk[i]), 256); }
+    L.W2h = take(w2 / sizeof(float));
     L.total = off;
     return L;
 }
@@ -328,6 +341,17 @@ static int lcgn_pack(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, char* b
         GVQA_HIP_CHECK(hipMemcpyAsync(PB(PL.Wq) + (size_t)t * O * O, p->qinput2_weight[t], (size_t)O * O * 4, hipMemcpyDeviceToDevice, stream));
         GVQA_HIP_CHECK(hipMemcpyAsync(PB(PL.bq) + (size_t)t * O, p->qinput2_bias[t], fo, hipMemcpyDeviceToDevice, stream));
     }
+    if (!d->node_bf16) {     // two-piece images for the fp32 mode's node GEMMs
+        const float* src[8] = {p->proj_x_loc_weight, PB(PL.Wx), PB(PL.Wj), p->proj_x_ctx_weight, p->output_weight, p->fin_weight,
+                               p->fin_weight + O, p->init_weight};
+        const int64_t ldw[8] = {O, O, 2 * O, O, 2 * O, 2 * O, 2 * O, Cin};
+        int64_t rows[8], Kk[8];
+        lcgn_node_weight_shapes(d, rows, Kk);
+        for (int i = 0; i < 8; ++i) {
+            int rc = launch_split_pack(2, rows[i], Kk[i], src[i], ldw[i], blob + PL.W2h + PL.w2h[i], stream);
+            if (rc) return rc;
+        }
+    }
     if (d->node_bf16 && O % 8 == 0) {
         const int PW = d->node_bf16 == 2 ? 1 : 2, K8 = (int)align_up(Cin, 8);
         const PackedWeights w = packed_weights(blob, PL, d);
@@ -345,7 +369,7 @@ static int lcgn_pack(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, char* b
 }
 
 struct LcgnLayout {
-    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, x16, pack, alpha, total;
+    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, x16, pack, alpha, apk, total;
 };
 static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_dims* d) {
     LcgnLayout L; size_t off = 0;
@@ -361,6 +385,8 @@ static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_d
     L.x16 = take(d->node_bf16 ? (N * align_up(d->in_channels, 8) + 1) / 2 : 0);     // x as bf16, K padded to 8
     L.pack = take(lcgn_pack_layout(d).total / sizeof(float));                        // used when params->packed is NULL
     L.alpha = take(E);
+    // fp32 mode: the two-piece image of a node GEMM's A operand (largest: K = 2 O or in_channels)
+    L.apk = take(d->node_bf16 ? 0 : split_packed_bytes(2, N, std::max<int64_t>(2 * (int64_t)d->out_channels, d->in_channels)) / sizeof(float));
     L.total = off;
     return L;
 }
@@ -425,10 +451,18 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     const PackedWeights pkw = packed_weights(blob, PL, d);
     auto PB = [&](size_t off) { return reinterpret_cast<float*>(blob + off); };
     // node GEMM: A is a node tensor (bf16 in nb mode); c_node: C (and addend / mul) are node tensors too
+    // fp32 mode: node GEMMs on the split2h arithmetic (GVQA_OPT_PROJECTION != f32): A packed per product, weights from the blob
+    const bool split_nodes = !nb && get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 && O % 4 == 0;
     auto NODE = [&](int64_t M_, int64_t N_, int64_t K_, const float* A_, int64_t lda_, const float* W_, int64_t ldw_,
-                    const uint16_t* Wpk_, LinearEpilogue ep_, float* C_, int64_t ldc_, bool c_node) -> int {
+                    const uint16_t* Wpk_, LinearEpilogue ep_, float* C_, int64_t ldc_, bool c_node, int widx) -> int {
         if (mf16 && linear_bf16_supported(K_, lda_, A_, Wpk_))
             return launch_linear_bf16(M_, N_, K_, PW, A_, lda_, Wpk_, ep_, C_, ldc_, c_node, stream);
+        if (split_nodes && linear_split3_supported(N_, ep_, C_, ldc_) &&
+            2.0 * (double)M_ * (double)N_ * (double)K_ >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP)) {
+            int rc2 = launch_split_pack(2, M_, K_, A_, lda_, base + L.apk, stream);
+            if (rc2) return rc2;
+            return launch_linear_split(2, M_, N_, K_, base + L.apk, blob + PL.W2h + PL.w2h[widx], ep_, C_, ldc_, stream);
+        }
         return launch_linear_t(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, FA | (c_node ? FC : 0), stream);
     };
 #define NODE_LIN(...) do { rc = NODE(__VA_ARGS__); if (rc) return rc; } while (0)
@@ -453,7 +487,8 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             rc = launch_linear_bf16(N, O, K8, PW, base + L.x16, K8, pkw.init, e, P(L.x_loc), O, true, stream);
             if (rc) return rc;
         } else {
-            LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);
+            if (split_nodes) NODE_LIN(N, O, Cin, x, Cin, p->init_weight, Cin, pkw.init, e, P(L.x_loc), O, true, 7);
+            else LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);      // (x itself is fp32 in every mode)
         }
     }
     LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
@@ -466,11 +501,11 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     LIN((int64_t)T * B, 2 * O, O, P(L.cmd), O, PB(PL.Wpc), O, nullptr, 0, P(L.pc), 2 * O);
     {   // proj_x_loc                                                                            :308
         LinearEpilogue e{p->proj_x_loc_bias, nullptr, 0, nullptr, 0, 0};
-        NODE_LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, pkw.pxl, e, P(L.proj_x_loc), O, true);
+        NODE_LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, pkw.pxl, e, P(L.proj_x_loc), O, true, 0);
     }
     {   // x_loc segment of lin_l / lin_r / cal_x                                                :144-145,230
         LinearEpilogue e{nullptr, nullptr, 0, nullptr, 0, 0};
-        NODE_LIN(N, 3 * O, O, P(L.x_loc), O, PB(PL.Wx), O, pkw.Wx, e, P(L.XL), 3 * O, true);
+        NODE_LIN(N, 3 * O, O, P(L.x_loc), O, PB(PL.Wx), O, pkw.Wx, e, P(L.XL), 3 * O, true, 1);
     }
     // x_ctx (:306) into the x_ctx columns of XC0
     if (nb) hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, O, x_ctx_init,
@@ -487,10 +522,10 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         const float* pc = P(L.pc) + (size_t)t * B * 2 * O;      // [proj_cmd(cmd_t) | cal_cmd(cmd_t)] per graph
         // prod = proj_x_ctx(x_ctx) * proj_x_loc                                                     // :312-313
         LinearEpilogue ep_mul{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0};
-        NODE_LIN(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, pkw.pxc, ep_mul, prod, ldx, true);
+        NODE_LIN(N, O, O, x_ctx, ldx, p->proj_x_ctx_weight, O, pkw.pxc, ep_mul, prod, ldx, true, 3);
         // J = x_joint . [lin_l; lin_r; cal_x]^T = XL + [prod | x_ctx] . Wj^T   (one K = 2O product)  // :144-145,230
         LinearEpilogue ep_add{nullptr, P(L.XL), 3 * O, nullptr, 0, 0};
-        NODE_LIN(N, 3 * O, 2 * O, prod, ldx, PB(PL.Wj), 2 * O, pkw.Wj, ep_add, P(L.J), 3 * O, true);
+        NODE_LIN(N, 3 * O, 2 * O, prod, ldx, PB(PL.Wj), 2 * O, pkw.Wj, ep_add, P(L.J), 3 * O, true, 2);
         // dot-product attention logits per edge                                                     // :154,207
         const dim3 ngrid((unsigned)cdiv(N, 4));
 #define EDGE_LOGIT(KERNEL_, XL_, XR_)                                                                                    \
@@ -532,14 +567,14 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         }
         // x_ctx = output_layer([x_ctx || msg])   (one K = 2O product)                                 // :316-319
         LinearEpilogue ep_o{p->output_bias, nullptr, 0, nullptr, 0, 0};
-        NODE_LIN(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, pkw.out, ep_o, x_ctx_next, ldx, true);
+        NODE_LIN(N, O, 2 * O, x_ctx, ldx, p->output_weight, 2 * O, pkw.out, ep_o, x_ctx_next, ldx, true, 4);
     }
     float* x_ctx_fin = NP((T & 1) ? P(L.XC1) : P(L.XC0), O);
     // out = fin_layer([x_loc || x_ctx]) (fp32 result)                                                // :321-322
     LinearEpilogue ep_f1{p->fin_bias, nullptr, 0, nullptr, 0, 0};
-    NODE_LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, pkw.f1, ep_f1, out, O, false);
+    NODE_LIN(N, O, O, P(L.x_loc), O, p->fin_weight, 2 * O, pkw.f1, ep_f1, out, O, false, 5);
     LinearEpilogue ep_fin{nullptr, out, O, nullptr, 0, 0};
-    NODE_LIN(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, pkw.f2, ep_fin, out, O, false);
+    NODE_LIN(N, O, O, x_ctx_fin, ldx, p->fin_weight + O, 2 * O, pkw.f2, ep_fin, out, O, false, 6);
 #undef LIN
 #undef NODE_LIN
 #undef LINT

@@ -672,10 +672,21 @@ def test_lcgn_seq_golden(dev, name):
     assert torch.equal(out, out2)
 
 
-def test_lcgn_config2_shape_vs_oracle(dev):
-    """BASELINE config 5 shape (fp32): config-2 batch, lcgn_seq(in=300, out=512, cmd=512, H=1, 4 iterations), L=10."""
+@pytest.mark.parametrize("arith", ["split2h", "f32"])
+def test_lcgn_config2_shape_vs_oracle(dev, arith):
+    """BASELINE config 5 shape (fp32): config-2 batch, lcgn_seq(in=300, out=512, cmd=512, H=1, 4 iterations), L=10, with the
+    node GEMMs on the two-piece fp16 arithmetic (default) and on the f32-input MFMA kernels."""
     from oracle import ref_torch as R
+    from graphvqa_amd import _lib
     from graphvqa_amd.lcgn import lcgn_seq
+    old = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_SPLIT2H if arith == "split2h" else _lib.PROJECTION_F32)
+    try:
+        _lcgn_config2_case(dev, R, lcgn_seq)
+    finally:
+        _lib.set_option(_lib.OPT_PROJECTION, old)
+
+
+def _lcgn_config2_case(dev, R, lcgn_seq):
     gb = synth.config2_batch()
     N, B, O, L = gb.num_nodes, gb.num_graphs, 512, 10
     p = synth.lcgn_seq_params(300, O, seed=808)
