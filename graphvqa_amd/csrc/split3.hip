@@ -918,7 +918,7 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
                                                    a_node, vpk, vinv)
 #define GVQA_P2(J_, NIT_) do { if (lm) GVQA_P2L(J_, NIT_, 1); else GVQA_P2L(J_, NIT_, 0); } while (0)
     if (J == 0) {
-        if (KB <= 32) GVQA_P2L(0, 8, 0); else GVQA_P2L(0, 0, 0);
+        if (KB <= 32) GVQA_P2L(0, 8, 0); else if (KB <= 64) GVQA_P2L(0, 16, 0); else GVQA_P2L(0, 0, 0);
     } else if constexpr (MAP == PACK_GROUPS) {
         const bool regs = KB <= 32;
         switch (J) {
