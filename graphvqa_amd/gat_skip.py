@@ -480,8 +480,9 @@ class gat_seq(torch.nn.Module):
             graph = SceneGraphBatch(edge_index, batch, N, B)
         elif graph.num_nodes != N or graph.num_edges != E or graph.num_graphs != B:
             raise ValueError("prebuilt graph does not match the inputs")
+        plist = self._param_list()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or instr.requires_grad or
-                                                  any(p.requires_grad for p in self.parameters()))
+                                                  any(p.requires_grad for p in plist))
         if needs_grad or (self.training and self.dropout > 0):
             return self._forward_autograd(x, edge_index, edge_attr, instr, batch, graph, return_attention_weights,
                                           return_hops)
@@ -496,10 +497,7 @@ class gat_seq(torch.nn.Module):
         H, Cc = self.heads, self.out_channels
         d = _lib.GatDims(self.in_channels, self.edge_attr_dim, self.ins_dim, Cc, H, K, self.negative_slope,
                          self.bns[0].eps if len(self.bns) else 1e-5)
-        hops = (_lib.GatConvParams * K)()
-        keep = []       # parameter tensors referenced by raw pointer stay alive until the call has been enqueued
-        for i, conv in enumerate(self.convs):
-            hops[i] = conv._params(self.bns[i] if i != K - 1 else None, keep)
+        hops, keep = self._hop_params()
         dev = x.device
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
         if self.training:
@@ -518,11 +516,35 @@ class gat_seq(torch.nn.Module):
             return out, alpha, hop_out
         return out
 
+    def _param_list(self):
+        """The module's Parameters and BatchNorm buffers, listed once (walking the module tree costs 50 us per call; Module._apply
+        and load_state_dict keep the Parameter objects, so the list stays valid unless sub-modules are replaced)."""
+        sig = (len(self.convs), len(self.bns), id(self.convs), id(self.bns))
+        if getattr(self, "_plist_sig", None) != sig:
+            self._plist = list(self.parameters()) + [b for bn in self.bns for b in (bn.running_mean, bn.running_var)]
+            self._plist_sig = sig
+        return self._plist
+
+    def _hop_params(self):
+        """The K `gvqa_gat_conv_params` structs of the eval forward, rebuilt only when a tensor's storage moved."""
+        plist = self._param_list()
+        ptrs = tuple(p.data_ptr() for p in plist)
+        if not all(p.dtype == torch.float32 and p.is_contiguous() for p in plist):
+            ptrs = None         # a parameter needs a converted copy per call: nothing to cache
+        if ptrs is None or getattr(self, "_hops_key", None) != ptrs:
+            K = len(self.convs)
+            hops = (_lib.GatConvParams * K)()
+            keep = []   # parameter tensors referenced by raw pointer stay alive as long as the structs are cached
+            for i, conv in enumerate(self.convs):
+                hops[i] = conv._params(self.bns[i] if i != K - 1 else None, keep)
+            self._hops, self._hops_keep, self._hops_key = hops, keep, ptrs
+        return self._hops, self._hops_keep
+
     def _weight_cache(self, lib, d, hops, layout, dev) -> Tensor:
         """Parameter-only products of the forward (folded attention vectors, per-graph term weights, split3-packed
         projection weights) prepared once per (parameter state, layout, device): the key holds every parameter's storage
         pointer and in-place version counter, so an optimizer step, load_state_dict or .to() invalidates it."""
-        key = (layout, dev, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        key = (layout, dev, tuple((p.data_ptr(), p._version) for p in self._param_list()))
         if getattr(self, "_wc_key", None) != key:
             buf = torch.empty(max(int(lib.gvqa_gat_seq_weight_cache_bytes(C.byref(d), layout)), 256), dtype=torch.uint8, device=dev)
             _lib.check(lib.gvqa_gat_seq_prepare_weights(C.byref(d), hops, layout, buf.data_ptr(), buf.numel(), _stream(dev)))
