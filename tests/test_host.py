@@ -197,7 +197,10 @@ def test_every_entry_point_rejects_bad_arguments_without_gpu():
                                      None, 0, None) == E_WS
     assert lib.gvqa_lcgn_pack_bytes(C.byref(ld1)) > 15 * 64 * 4 and lib.gvqa_lcgn_pack_bytes(None) == 0
     ld16 = _lib.LcgnDims(8, 8, 8, 4, 5, 1, 0.2, 1)
-    assert lib.gvqa_lcgn_pack_bytes(C.byref(ld16)) > lib.gvqa_lcgn_pack_bytes(C.byref(ld1))     # + bf16 weight pieces
+    # both modes carry packed node-GEMM weights on top of the stacked fp32 forms: bf16 pieces (bf16 node features) or two-piece
+    # fp16 images with their row scales (fp32 mode)
+    stacks = (3 * 64 + 3 * 128 + 2 * 64 + 4 * 64 + 4 * 8) * 4
+    assert lib.gvqa_lcgn_pack_bytes(C.byref(ld16)) > stacks and lib.gvqa_lcgn_pack_bytes(C.byref(ld1)) > stacks
     assert lib.gvqa_lcgn_pack_weights(C.byref(ld1), C.byref(_lib.LcgnParams()), None, 0, None) == E_INV
     assert lib.gvqa_linear_bf16(4, 4, 12, 2, None, 12, None, None, None, 0, None, 0, 0, None, 4, 0, None) == E_INV
     assert lib.gvqa_pack_weight_bf16(4, 4, 3, None, 4, None, None) == E_INV
