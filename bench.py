@@ -396,6 +396,7 @@ def main():
                     res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
                 res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma (+ gvqa::k_gat_mp_tiled)", "ms_per_step": t_f32 * 1e3,
                                               "value": Eall / t_f32, "avg_launch_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
+                res["projection_error_vs_fp64"] = projection_accuracy(lib, params, shard, torch, np, dev)
                 res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
                                             "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
             if not a.no_pmc:
@@ -414,7 +415,7 @@ def main():
             if mpr is not None and mpr.get("traffic") is None:
                 mpr["traffic_from_profile"] = profile_traffic()
             if not a.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(params, synth, np, torch)
+                res["cpu_baseline"] = cpu_baseline(params, synth, np, torch, m, dev)
         line = json.dumps(res)
     if dist is not None:
         dist.barrier()
@@ -432,7 +433,33 @@ def main():
         print(line, flush=True)
 
 
-def cpu_baseline(params, synth, np, torch):
+def projection_accuracy(lib, params, shard, torch, np, dev):
+    """Max-abs error against an fp64 product of the hop-0 projection (first 8192 node rows x lin_l's node columns) for the three
+    arithmetics, measured now: the two-piece fp16 form must not be above the f32-input MFMA's."""
+    from graphvqa_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    A = shard.x[:8192].contiguous()
+    W = torch.from_numpy(np.ascontiguousarray(params["convs.0.lin_l.weight"][:, :D])).to(dev).contiguous()
+    M, Kd, Nn = A.shape[0], A.shape[1], W.shape[0]
+    ref = A.double() @ W.double().t()
+    out = {"rows": M, "output_max_abs": float(ref.abs().max())}
+    for name, nbytes, pack, linear in (("split2h", lib.gvqa_split2h_packed_bytes, lib.gvqa_split2h_pack, lib.gvqa_linear_split2h),
+                                       ("split3", lib.gvqa_split3_packed_bytes, lib.gvqa_split3_pack, lib.gvqa_linear_split3)):
+        apk = torch.empty(nbytes(M, Kd), dtype=torch.uint8, device=dev)
+        wpk = torch.empty(nbytes(Nn, Kd), dtype=torch.uint8, device=dev)
+        Cm = torch.empty(M, Nn, device=dev)
+        _lib.check(pack(M, Kd, A.data_ptr(), Kd, apk.data_ptr(), st))
+        _lib.check(pack(Nn, Kd, W.data_ptr(), Kd, wpk.data_ptr(), st))
+        _lib.check(linear(M, Nn, Kd, apk.data_ptr(), wpk.data_ptr(), None, None, 0, None, 0, 0, Cm.data_ptr(), Nn, st))
+        out[name] = float((Cm.double() - ref).abs().max())
+    Cm = torch.empty(M, Nn, device=dev)
+    _lib.check(lib.gvqa_linear_f32(M, Nn, Kd, A.data_ptr(), Kd, W.data_ptr(), Kd, None, 0, Cm.data_ptr(), Nn, st))
+    out["f32_mfma"] = float((Cm.double() - ref).abs().max())
+    out["torch_matmul_fp32"] = float(((A @ W.t()).double() - ref).abs().max())
+    return out
+
+
+def cpu_baseline(params, synth, np, torch, model=None, dev=None):
     """The oracle (a torch-CPU restatement of the reference's op sequence) timed on the host cores on
     a bounded sample of the same workload.  torch's CPU scatter/gather ops oversubscribe badly at
     the box's full thread count (256 threads: 100x slower than 16), so the thread count is chosen by
@@ -447,10 +474,12 @@ def cpu_baseline(params, synth, np, torch):
         return E, N, (tt(synth.normal((N, D), 11)), tt(gb.edge_index), tt(synth.normal((E, D), 12)),
                       tt(synth.normal((K, nb, D), 13)), tt(gb.batch), p)
 
+    last = {}
+
     def run(args):
         t0 = time.perf_counter()
         with torch.no_grad():
-            R.gat_seq(*args, heads=H)
+            last["out"] = R.gat_seq(*args, heads=H)
         return time.perf_counter() - t0
 
     ncpu = os.cpu_count() or 1
@@ -478,7 +507,14 @@ def cpu_baseline(params, synth, np, torch):
     if times[0] < 12.0:
         times.append(run(args))
     best = min(times)
-    return {"value": E / best, "unit": "edges/s", "cores": best_th, "kind": "port",
+    parity = None
+    if model is not None:       # the same sample through the product path: the oracle as the checker, live
+        x, ei, ea, ins, batch = (a.to(dev) for a in args[:5])
+        with torch.no_grad():
+            out = model(x, ei, ea, ins, batch).cpu()
+        parity = {"max_abs_dev_vs_oracle": float((out - last["out"]).abs().max()), "bound": 1e-4,
+                  "oracle_output_max_abs": float(last["out"].abs().max())}
+    return {"value": E / best, "unit": "edges/s", "cores": best_th, "kind": "port", "parity_on_sample": parity,
             "host_cpus": ncpu, "cpu_model": cpu_model,
             "sample": f"oracle/ref_torch.gat_seq on {nb} graphs ({N} nodes / {E} edges), d={D}, K={K}, "
                       f"fp32, best of {len(times)} forwards ({best:.2f} s), {best_th} torch threads "
