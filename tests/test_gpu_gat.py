@@ -904,6 +904,44 @@ def test_randomized_gat_seq_vs_oracle(dev, case):
     assert maxabs(out, ref) < TOL, (H, C, de, di, K, B, N, E)
 
 
+@pytest.mark.parametrize("scheme", ["split2h", "split3"])
+@pytest.mark.parametrize("case", range(10))
+def test_randomized_fused_hop_vs_oracle(dev, scheme, case):
+    """The fused hop forced onto randomised small batches (GVQA_OPT_SPLIT3_MIN_MFLOP = 0): head counts, channel counts that
+    are multiples of 4 but of nothing else (partial last column block, K not a multiple of 16), graphs of 1 .. 128 nodes, empty
+    graphs, nodes without in-edges, multi-edges, hop counts, with and without instruction vectors -- against the oracle, and bit
+    for bit against itself when the batch is run a second time."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    r = lambda lo, hi, s: int(synth.randint(1, 7000 + 31 * case + s, lo, hi + 1)[0])
+    H = [1, 2, 4, 8][r(0, 3, 1)]
+    C = [4, 12, 20, 36, 68, 100, 132, 260][r(0, 7, 2)]
+    de, di, K = r(1, 40, 3), (0 if case % 5 == 4 else r(1, 40, 4)), r(1, 5, 5)
+    B = r(1, 30, 6)
+    gb = synth.make_graph_batch(B, seed=800 + case, nodes_lo=1, nodes_hi=[12, 40, 128][case % 3], rel_per_node=r(0, 25, 7) / 10.0)
+    ei = gb.edge_index
+    if case % 2 == 0:                                     # nodes without any in-edge: drop every edge into every fourth node
+        ei = ei[:, ei[1] % 4 != 0]
+    N, E = gb.num_nodes, ei.shape[1]
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=900 + case)
+    x, ea, ins = synth.normal((N, C), 1 + case), synth.normal((E, de), 2 + case), synth.normal((K, B, di), 3 + case)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_SPLIT2H if scheme == "split2h" else _lib.PROJECTION_SPLIT3)
+    try:
+        _lib.prof_enable(True); _lib.prof_collect()
+        out = _run_gat_seq(dev, (C, de, di, K, H), p, x, ei, ea, ins, gb.batch)
+        prof = _lib.prof_collect(); _lib.prof_enable(False)
+        out2 = _run_gat_seq(dev, (C, de, di, K, H), p, x, ei, ea, ins, gb.batch)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_PROJECTION, old_p)
+        _lib.prof_enable(False)
+    assert prof["mp"][1] == 0 and prof["alpha"][1] == K, "the fused path must have run"
+    ref = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(gb.batch), tparams(p), heads=H)
+    assert maxabs(out, ref) < TOL, (H, C, de, di, K, B, N, E)
+    assert torch.equal(out, out2)
+
+
 def test_sharded_execution_equals_full_batch(dev):
     """Multi-GPU correctness by construction: the per-rank shards of `parallel.shard_batch` (graphs
     partitioned by edge count), each run through the HIP path on its own, reproduce the rows of the
