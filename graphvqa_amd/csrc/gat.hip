@@ -141,7 +141,8 @@ struct MpArgs {
     int nparts;               // blocks per graph: block (g, part) owns the channel ranges [part, part+1) * nch / nparts
     int lpn_log;              // log2(lanes per node) in the aggregation mapping
     float slope, bn_eps;
-};
+    int debug;                // measurement aid (GVQA_MP_DEBUG bit mask, tiled kernel): 1 no aggregation loops, 2 no softmax passes,
+};                            // 4 no output stores, 8 no CSR / logit / constant loads in the prologue -- wrong results; scripts/bench_mp_plan.py prices the parts with them
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     for (; pf_t < depth && pf_t < T; ++pf_t) { prefetch(pf_j, pf_c0, pf_buf); advance(pf_j, pf_c0, pf_buf); }
 
     // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
-    for (int s = tid; s < ne; s += MP_THREADS) {
+    for (int s = tid; s < ((a.debug & 8) ? 0 : ne); s += MP_THREADS) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
         src_l[s] = src - n0;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         for (int h = 0; h < H; ++h) alpha_s[s * H + h] = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + ae[h];
     }
     for (int i = tid; i <= tn; i += MP_THREADS) rowp_l[i] = a.rowptr[n0 + i] - e0;
-    for (int c = tid; c < C; c += MP_THREADS) {
+    for (int c = tid; c < ((a.debug & 8) ? 0 : C); c += MP_THREADS) {
         cst[c] = a.graph_term ? a.graph_term[(int64_t)g * a.t_ld + c] : 0.f;
         cst[C + c] = a.bias ? a.bias[c] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
-    for (int it = tid; it < tn * H; it += MP_THREADS) {
+    for (int it = tid; it < ((a.debug & 2) ? 0 : tn * H); it += MP_THREADS) {
         const int i = it / H, h = it - i * H;
         const int lo = rowp_l[i], hi = rowp_l[i + 1];
         float ar = a.a_node ? a.a_node[(int64_t)(n0 + i) * 2 * H + H + h] : 0.f;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         int trips = (it_hi[k] - it_lo[k] + 3) >> 2;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
-        it_trips[k] = __builtin_amdgcn_readfirstlane(trips);
+        it_trips[k] = (a.debug & 1) ? 0 : __builtin_amdgcn_readfirstlane(trips);
     }
 
     int cur_j = 0, cur_c0 = r_lo * a.cw, cur_buf = 0;     // cursor of the stage being consumed
@@ -455,7 +456,9 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                         r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
                         r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
                     }
-                    *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
+                    // (holding the rows back and storing them one stage later, behind the next barrier and prefetch, so that the
+                    //  vmcnt(0) at the top of the next stage does not wait for them: 201 vs 201 us at config 3 -- no gain)
+                    if (!(a.debug & 4)) *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
                 }
             }
         }
@@ -729,6 +732,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
     a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_mask = d->alpha_mask; a.alpha_csr = nullptr;
     a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.nparts = 1; a.lpn_log = 0;
+    { const char* dv = getenv("GVQA_MP_DEBUG"); a.debug = dv ? atoi(dv) : 0; }
     a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
     const int force = d->force;
     const float* graph_term = d->graph_term;

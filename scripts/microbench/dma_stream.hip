@@ -62,6 +62,41 @@ __global__ __launch_bounds__(512) void k_stream(const float* __restrict__ xp, fl
     if (acc == 12345.678f) out[g] = acc;
 }
 
+// The same bytes with ordinary loads into registers (UNR x 16 B per thread in flight), grid-stride over contiguous memory:
+// what a non-DMA streaming kernel gets from the memory system.
+template <int UNR>
+__global__ __launch_bounds__(256) void k_read_regs(const float4* __restrict__ p, size_t n4, float* __restrict__ out) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+// ... and LDS-DMA with NO barrier and no LDS reads: every wave keeps DEPTH 1 KiB DMAs in flight into its own LDS slice
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_read_dma(const float* __restrict__ p, size_t n4, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) char ring[4 * DEPTH * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned base = (unsigned)(size_t)(lds_ptr_t)ring + wave * DEPTH * 1024;
+    const size_t waves = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + wave;
+    size_t chunk = w;                                  // 1 KiB chunks (64 float4), wave-strided
+    const size_t nchunks = n4 / 64;
+    int slot = 0;
+    for (; chunk < nchunks; chunk += waves) {
+        lds_dma16(p + chunk * 256 + lane * 4, __builtin_amdgcn_readfirstlane(base + slot * 1024));
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (reinterpret_cast<float*>(ring)[threadIdx.x] == 12345.678f) out[0] = 1.f;
+}
+
 int main(int argc, char** argv) {
     const int B = 2048, n = 32, H = 4, C = 512;
     const size_t elems = (size_t)B * n * H * C;
@@ -90,6 +125,25 @@ int main(int argc, char** argv) {
         const double us = ms / 20 * 1e3, gbs = elems * 4.0 / (us * 1e-6) / 1e9;
         printf("nbuf=%d cw=%3d mode=%s lds=%6zu B  blocks/CU=%d : %7.1f us  %6.0f GB/s  (%s)\n", c.nbuf, c.cw, c.mode ? "contig " : "strided",
                lds, (int)(163840 / lds), us, gbs, hipGetErrorString(hipGetLastError()));
+    }
+    {
+        const size_t n4 = elems / 4;
+        auto timeit = [&](auto launch, const char* name) {
+            for (int i = 0; i < 3; ++i) launch();
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) launch();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-44s %7.1f us  %6.0f GB/s (%s)\n", name, ms / 20 * 1e3, elems * 4.0 / (ms / 20 * 1e-3) / 1e9, hipGetErrorString(hipGetLastError()));
+        };
+        const float4* p4 = reinterpret_cast<const float4*>(xp);
+        timeit([&]() { hipLaunchKernelGGL(k_read_regs<4>, dim3(256 * 8), dim3(256), 0, 0, p4, n4, out); }, "register loads, 4 x 16 B/thread, 8 blocks/CU");
+        timeit([&]() { hipLaunchKernelGGL(k_read_regs<8>, dim3(256 * 8), dim3(256), 0, 0, p4, n4, out); }, "register loads, 8 x 16 B/thread, 8 blocks/CU");
+        timeit([&]() { hipLaunchKernelGGL(k_read_regs<8>, dim3(256 * 4), dim3(256), 0, 0, p4, n4, out); }, "register loads, 8 x 16 B/thread, 4 blocks/CU");
+        timeit([&]() { hipLaunchKernelGGL(k_read_dma<4>, dim3(256 * 8), dim3(256), 0, 0, xp, n4, out); }, "LDS-DMA, 4 KiB/wave in flight, 8 blocks/CU");
+        timeit([&]() { hipLaunchKernelGGL(k_read_dma<8>, dim3(256 * 4), dim3(256), 0, 0, xp, n4, out); }, "LDS-DMA, 8 KiB/wave in flight, 4 blocks/CU");
+        timeit([&]() { hipLaunchKernelGGL(k_read_dma<16>, dim3(256 * 2), dim3(256), 0, 0, xp, n4, out); }, "LDS-DMA, 16 KiB/wave in flight, 2 blocks/CU");
     }
     return 0;
 }
