@@ -1044,6 +1044,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
             case 114: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2); break;
             case 115: GVQA_SN_LAUNCH(2, 4, 4, 2, 3, true, false, true, 0, 0, 2); break;
             case 117: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2, 1); break;
+            case 119: GVQA_SP_LAUNCH(2, 2, 4, 4, 4, true, false, true, 0, 0, 2, 0); break;     // four waves of 128 x 128 (256 AGPRs)
             case 118: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2, 1); break;
             case 116: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, false, false, true, 0, 0, 2); break;
             case 123: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, true, 0, 0, 2); break;
