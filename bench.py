@@ -397,6 +397,11 @@ def main():
                 res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma (+ gvqa::k_gat_mp_tiled)", "ms_per_step": t_f32 * 1e3,
                                               "value": Eall / t_f32, "avg_launch_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
                 res["projection_error_vs_fp64"] = projection_accuracy(lib, params, shard, torch, np, dev)
+                if fused and pieces == 2 and (N, E) == (Nall, Eall):
+                    fl = mfma_floor(lib, torch, dev, N, H * D, D)
+                    res["roofline"]["matrix_core_floor"] = fl
+                    if fl.get("mfma_only_us"):
+                        res["roofline"]["frac_of_matrix_core_floor"] = fl["mfma_only_us"] / res["roofline"]["avg_launch_us"]
                 res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
                                             "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
             if not a.no_pmc:
@@ -431,6 +436,45 @@ def main():
             pass
         sys.stdout.flush()
         print(line, flush=True)
+
+
+def mfma_floor(lib, torch, dev, M, Nn, Kd):
+    """What the chip sustains on the fused hop's own MFMA stream, measured now: the same 256 x 256-tile two-piece kernel over the
+    same M x N x K with its fragment reads, DMAs, waits and barriers switched off (GVQA_SPLIT3_LOOP_DEBUG = 112, no C store):
+    nothing but the 3 x 2 M N K flops of v_mfma_f32_32x32x16_f16.  Under that load the clock settles near 1.8 GHz (power), so
+    the floor is 1.4 - 1.7 PF (by operand data and box), not the 2.5 PF of the data sheet's 2.4 GHz."""
+    from graphvqa_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        # operand values as in hops 1 .. K-1 (post-ReLU rows: half zeros) -- the sustained clock depends on the data's switching
+        # activity (all-random operands: ~20 % slower for the same instruction stream)
+        A = torch.relu(torch.randn(M, Kd, device=dev)); W = torch.randn(Nn, Kd, device=dev) / Kd ** 0.5
+        apk = torch.empty(lib.gvqa_split2h_packed_bytes(M, Kd), dtype=torch.uint8, device=dev)
+        wpk = torch.empty(lib.gvqa_split2h_packed_bytes(Nn, Kd), dtype=torch.uint8, device=dev)
+        Cm = torch.empty(2 * (M // 256) * (Nn // 256) + 16, device=dev)        # the no-store variants leave block clocks here
+        _lib.check(lib.gvqa_split2h_pack(M, Kd, A.data_ptr(), Kd, apk.data_ptr(), st))
+        _lib.check(lib.gvqa_split2h_pack(Nn, Kd, W.data_ptr(), Kd, wpk.data_ptr(), st))
+        old = _lib.set_option(_lib.OPT_SPLIT3_VARIANT, 113)
+        out = {}
+        try:
+            for key, dbg in (("mfma_only_us", "112"), ("main_loop_us", "0")):
+                os.environ["GVQA_SPLIT3_LOOP_DEBUG"] = dbg
+                run = lambda: _lib.check(lib.gvqa_linear_split2h(M, Nn, Kd, apk.data_ptr(), wpk.data_ptr(), None, None, 0, None, 0, 0,
+                                                                 Cm.data_ptr(), Nn, st))
+                for _ in range(3): run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(10): run()
+                e1.record(); torch.cuda.synchronize()
+                out[key] = e0.elapsed_time(e1) / 10 * 1e3
+        finally:
+            os.environ.pop("GVQA_SPLIT3_LOOP_DEBUG", None)
+            _lib.set_option(_lib.OPT_SPLIT3_VARIANT, old)
+        out["mfma_only_tflops"] = 3 * 2.0 * M * Nn * Kd / (out["mfma_only_us"] * 1e-6) / 1e12
+        out["note"] = "stand-alone kernel, same tile and MFMA stream as the fused hop's main loop; mfma_only = every non-MFMA part of a K step switched off"
+        return out
+    except Exception as e:
+        return {"error": repr(e)[:200]}
 
 
 def projection_accuracy(lib, params, shard, torch, np, dev):
