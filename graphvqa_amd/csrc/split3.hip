@@ -755,18 +755,21 @@ __device__ __forceinline__ void load_row8(const float* row, bool on, int k0, int
 // pieces this lane has just made ARE the A fragment of a 32x32x16 MFMA; against the two-piece image of Vn (`vn_pk`: one 32-row
 // tile, rows >= J zero, packed like any weight operand and cached with the weights) three MFMAs per k block give the tile's
 // logits in the projection's own arithmetic, rescaled exactly by the two inverse scales.
-template <int MAP, int J, int NIT, int LM>
-__global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB, uint16_t* __restrict__ out, float* __restrict__ inv_scale,
+// NWV waves per workgroup (4, or 8 for the hop operand at K <= 512: half the k blocks -- and data registers -- per thread, twice
+// the waves in flight per CU).
+template <int MAP, int J, int NIT, int LM, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, int KB, uint16_t* __restrict__ out, float* __restrict__ inv_scale,
                                                       int vec, const float* __restrict__ Vn, float* __restrict__ a_node,
                                                       const uint16_t* __restrict__ vn_pk, const float* __restrict__ vn_inv) {
-    extern __shared__ __attribute__((aligned(16))) float pk_s[];      // [4][32] row maxima | LM 0: [J][Kp] Vn | [4][32][J] partial dots
+    extern __shared__ __attribute__((aligned(16))) float pk_s[];      // [NWV][32] row maxima | LM 0: [J][Kp] Vn | [NWV][32][J] partial dots
+    constexpr int NTHR = 64 * NWV;
     constexpr int JJ = (J > 0 && !LM) ? J : 1, NR = NIT > 0 ? NIT : 1;
     const int Kp = KB * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* mx_s = pk_s;
-    float* vn_s = pk_s + 128;
+    float* vn_s = pk_s + 32 * NWV;
     if (J > 0 && !LM) {
-        for (int idx = tid; idx < J * Kp; idx += 256) {
+        for (int idx = tid; idx < J * Kp; idx += NTHR) {
             const int j = idx / Kp, k = idx - j * Kp;
             vn_s[idx] = k < K ? Vn[(int64_t)j * K + k] : 0.f;
         }
@@ -778,8 +781,8 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
     const int kh = (lane >> 5) * 8;
     float v[NR][8];
     float mx = 0.f;
-    auto kb_of = [&](int it) { return ((it >> 1) << 3) + 2 * wave + (it & 1); };
-    const int nit_all = ((KB + 7) >> 3) * 2;                          // iterations that cover every k block (NIT == 0 path)
+    auto kb_of = [&](int it) { return (it >> 1) * (2 * NWV) + 2 * wave + (it & 1); };
+    const int nit_all = ((KB + 2 * NWV - 1) / (2 * NWV)) * 2;         // iterations that cover every k block (NIT == 0 path)
     if (NIT > 0) {
 #pragma unroll
         for (int it = 0; it < NR; ++it) {
@@ -801,14 +804,16 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
     if (lane < 32) mx_s[wave * 32 + lane] = mx;
     __syncthreads();                                                  // (also: Vn is in LDS)
     const int m = lane & 31;
-    float rowmax = fmaxf(fmaxf(mx_s[m], mx_s[32 + m]), fmaxf(mx_s[64 + m], mx_s[96 + m]));
+    float rowmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) rowmax = fmaxf(rowmax, mx_s[w * 32 + m]);
     if constexpr (MAP == PACK_HEADS) {
         // ONE scale per 256-row column block of the fused hop (its epilogue then needs a single factor for all its columns):
         // the largest magnitude of the block's rows, found by every tile of the block on its own (weights: packed once, cached).
         // Rows 2^-16 below their block's largest lose the 2^-22 guarantee (absolute error <= 2^-38 of the block's largest).
         float bmx = 0.f;
         const int cb = (int)(rt >> 3);
-        for (int r = tid >> 6; r < 256; r += 4) {                     // a wave per row, lanes over k
+        for (int r = tid >> 6; r < 256; r += NWV) {                   // a wave per row, lanes over k
             const int h = r / pr.cw, ch = cb * pr.cw + (r - h * pr.cw);
             if (ch >= pr.C) continue;
             const float* wrow = pr.X + ((int64_t)h * pr.C + ch) * pr.ld;
@@ -819,7 +824,9 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
         __syncthreads();                                              // every read of mx_s above is done
         if (lane == 0) mx_s[wave] = bmx;
         __syncthreads();
-        rowmax = fmaxf(fmaxf(mx_s[0], mx_s[1]), fmaxf(mx_s[2], mx_s[3]));
+        rowmax = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) rowmax = fmaxf(rowmax, mx_s[w]);
     }
     const int ex = split2h_exponent(rowmax);
     const float scale = pow2i(ex);
@@ -882,13 +889,15 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 32 * J; idx += 256) {
+        for (int idx = tid; idx < 32 * J; idx += NTHR) {
             const int r = idx / J, j = idx - r * J;
             bool on2;
             int64_t node;
             pack_row<MAP>(pr, rt, r, on2, node);
             if (on2) {
                 float t = (part[(0 * 32 + r) * J + j] + part[(1 * 32 + r) * J + j]) + (part[(2 * 32 + r) * J + j] + part[(3 * 32 + r) * J + j]);
+                if constexpr (NWV == 8)
+                    t += (part[(4 * 32 + r) * J + j] + part[(5 * 32 + r) * J + j]) + (part[(6 * 32 + r) * J + j] + part[(7 * 32 + r) * J + j]);
                 if constexpr (LM) t = t * mx_s[r] * vn_inv[j];
                 a_node[node * J + j] = t;
             }
@@ -896,8 +905,8 @@ __global__ __launch_bounds__(256) void k_split2h_pack(PackRows pr, int K, int KB
     }
 }
 
-static size_t split2h_pack_lds(int J, int KB, bool mfma_logits = false) {
-    return (128 + (mfma_logits ? 0 : (size_t)J * KB * 16) + 4 * 32 * (size_t)J) * sizeof(float);
+static size_t split2h_pack_lds(int J, int KB, bool mfma_logits = false, int nwv = 4) {
+    return (32 * (size_t)nwv + (mfma_logits ? 0 : (size_t)J * KB * 16) + (size_t)nwv * 32 * (size_t)J) * sizeof(float);
 }
 
 // Vn_packed: NULL, or the two-piece image of Vn [J, K] (gvqa layout of one 32-row tile + its inverse scales): logits on the
@@ -910,13 +919,17 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
     uint16_t* o = static_cast<uint16_t*>(packed);
     float* inv = const_cast<float*>(split2h_inv_scales(packed, RT, KB));
     const bool lm = J > 0 && Vn_packed != nullptr;
-    const size_t lds = split2h_pack_lds(J, KB, lm);
-    const dim3 grid((unsigned)RT), block(256);
+    // eight waves per tile for the hop operand with MFMA logits at K <= 512 (GVQA_PACK_WAVES=4: the four-wave form, for the A/B)
+    static const bool waves8_ok = []() { const char* v = getenv("GVQA_PACK_WAVES"); return !(v && v[0] == '4'); }();
+    const bool w8 = lm && MAP == PACK_GROUPS && KB <= 32 && waves8_ok;
+    const size_t lds = split2h_pack_lds(J, KB, lm, w8 ? 8 : 4);
+    const dim3 grid((unsigned)RT), block(w8 ? 512 : 256);
     const uint16_t* vpk = static_cast<const uint16_t*>(Vn_packed);
     const float* vinv = lm ? split2h_inv_scales(Vn_packed, 1, KB) : nullptr;
 #define GVQA_P2L(J_, NIT_, LM_) hipLaunchKernelGGL((k_split2h_pack<MAP, J_, NIT_, LM_>), grid, block, lds, stream, pr, (int)K, KB, o, inv, vec, Vn, \
                                                    a_node, vpk, vinv)
-#define GVQA_P2(J_, NIT_) do { if (lm) GVQA_P2L(J_, NIT_, 1); else GVQA_P2L(J_, NIT_, 0); } while (0)
+#define GVQA_P2W8(J_) hipLaunchKernelGGL((k_split2h_pack<MAP, J_, 4, 1, 8>), grid, block, lds, stream, pr, (int)K, KB, o, inv, vec, Vn, a_node, vpk, vinv)
+#define GVQA_P2(J_, NIT_) do { if (w8) GVQA_P2W8(J_); else if (lm) GVQA_P2L(J_, NIT_, 1); else GVQA_P2L(J_, NIT_, 0); } while (0)
     if (J == 0) {
         if (KB <= 32) GVQA_P2L(0, 8, 0); else if (KB <= 64) GVQA_P2L(0, 16, 0); else GVQA_P2L(0, 0, 0);
     } else if constexpr (MAP == PACK_GROUPS) {
@@ -933,6 +946,7 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
     }
 #undef GVQA_P2
 #undef GVQA_P2L
+#undef GVQA_P2W8
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
