@@ -19,6 +19,7 @@ path: CPU tensors raise, and a missing HIP library raises at construction.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Optional
 
@@ -57,6 +58,54 @@ def _inference_only(module: torch.nn.Module, *tensors) -> None:
 
 def _workspace(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class _ProjectionLinear(torch.autograd.Function):
+    """y = x W^T for the hop projection of the differentiable path (gat_skip.py:133): the forward product runs on the library's
+    own GEMMs -- the arithmetic GVQA_OPT_PROJECTION selects (two-piece fp16 / three-piece bf16 split on the 16-bit matrix cores,
+    or the f32-input MFMA kernel), exactly as in the eval path -- and so does dx = dy W in the backward; dW = dy^T x (a [HC, Dn]
+    result reduced over all N rows: a split-K shape the library has no kernel for) is a torch matmul.
+    `w` may be a column slice of a wider weight (its row stride is passed on)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _ProjectionLinear._product(x, w)
+
+    @staticmethod
+    def _product(x, w):
+        lib = _lib.load()
+        M, K = x.shape
+        N = w.shape[0]
+        mode = lib.gvqa_get_option(_lib.OPT_PROJECTION)
+        ok = (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.stride(1) == 1 and
+              N % 4 == 0 and M > 0 and 2.0 * M * N * K >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
+        if not ok:
+            return torch.nn.functional.linear(x, w)
+        dev, st = x.device, _stream(x.device)
+        out = torch.empty((M, N), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            if mode == _lib.PROJECTION_F32:
+                _lib.check(lib.gvqa_linear_f32(M, N, K, x.data_ptr(), K, w.data_ptr(), w.stride(0), None, 0, out.data_ptr(), N, st))
+                return out
+            nbytes, pack, linear = ((lib.gvqa_split2h_packed_bytes, lib.gvqa_split2h_pack, lib.gvqa_linear_split2h)
+                                    if mode == _lib.PROJECTION_SPLIT2H else
+                                    (lib.gvqa_split3_packed_bytes, lib.gvqa_split3_pack, lib.gvqa_linear_split3))
+            apk, wpk = _workspace(nbytes(M, K), dev), _workspace(nbytes(N, K), dev)
+            _lib.check(pack(M, K, x.data_ptr(), K, apk.data_ptr(), st))
+            _lib.check(pack(N, K, w.data_ptr(), w.stride(0), wpk.data_ptr(), st))
+            _lib.check(linear(M, N, K, apk.data_ptr(), wpk.data_ptr(), None, None, 0, None, 0, 0, out.data_ptr(), N, st))
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # dx = dy W = dy (W^T)^T: the same kernels with the (small) weight transposed
+            gx = _ProjectionLinear._product(gy.contiguous(), w.t().contiguous())
+        gw = gy.t() @ x if ctx.needs_input_grad[1] else None
+        return gx, gw
 
 
 class _GatMessagePassing(torch.autograd.Function):
@@ -599,7 +648,7 @@ class gat_seq(torch.nn.Module):
             W_h3, W_i3 = W[:, :Dn].reshape(H, Cc, Dn), W[:, Dn:].reshape(H, Cc, Di)
             att_l, att_r, att_e = conv.att_l.view(H, Cc), conv.att_r.view(H, Cc), conv.att_e.view(H, Cc)
             # projected features: node half per row, instruction half per graph
-            xp = add_graph_rows(F.linear(h, W[:, :Dn]), F.linear(ins, W[:, Dn:]), graph)
+            xp = add_graph_rows(_ProjectionLinear.apply(h, W[:, :Dn]), F.linear(ins, W[:, Dn:]), graph)
             # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
             # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
             V_n = torch.cat((torch.einsum("hck,hc->kh", W_h3, att_l), torch.einsum("hck,hc->kh", W_h3, att_r)), dim=1)
