@@ -66,7 +66,7 @@ struct BwdArgs {
 };
 
 // ---- by destination: dalpha', softmax / leaky backward, da_edge, da_node[:, H:] -------------------
-template <int W, int KC>
+template <int W, int KC, int HT>      // HT: heads whose xp rows are in flight together (H <= HT)
 __global__ __launch_bounds__(256) void k_gat_mp_bwd_dst(BwdArgs a) {
     __shared__ float stage[4][BWD_CAP * BWD_MAXH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,15 +106,57 @@ __global__ __launch_bounds__(256) void k_gat_mp_bwd_dst(BwdArgs a) {
     float t[BWD_MAXH];
 #pragma unroll
     for (int h = 0; h < BWD_MAXH; ++h) t[h] = 0.f;
-    for (int s = lo; s < hi; ++s) {
-        const int src = a.csr_src[s], eid = a.csr_eid[s];
+    // two in-edges per trip: the xp rows of ALL heads of both edges are loaded before the first dot product (one trip to memory per
+    // edge pair instead of one per (edge, head)), and the 2 H wave reductions run interleaved
+    for (int s = lo; s < hi; s += 2) {
+        const bool two = s + 1 < hi;
+        int src[2], eid[2];
+        src[0] = a.csr_src[s]; eid[0] = a.csr_eid[s];
+        src[1] = a.csr_src[two ? s + 1 : s]; eid[1] = a.csr_eid[two ? s + 1 : s];
+        float v[2][HT][KC][W];
 #pragma unroll
-        for (int h = 0; h < BWD_MAXH; ++h) {
-            if (h < H) {
-                float d = dalpha_of(src, h);
-                if (a.mask) d *= a.mask[(int64_t)eid * H + h];
-                t[h] += a.alpha[(int64_t)eid * H + h] * d;
-                if (s - lo < BWD_CAP && lane == 0) stage[wave][(s - lo) * BWD_MAXH + h] = d;
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < HT; ++h)
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int c = (lane + k * 64) * W;
+                    if (h < H && c < C) loadw<W>(a.xp + (int64_t)src[e] * a.xp_ld + (int64_t)h * C + c, v[e][h][k]);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < W; ++q) v[e][h][k][q] = 0.f;
+                    }
+                }
+        float al[2][HT], mk[2][HT], d[2][HT];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                al[e][h] = h < H ? a.alpha[(int64_t)eid[e] * H + h] : 0.f;
+                mk[e][h] = (h < H && a.mask) ? a.mask[(int64_t)eid[e] * H + h] : 1.f;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+#pragma unroll
+                    for (int q = 0; q < W; ++q) acc += v[e][h][k][q] * dco[k][q];
+                d[e][h] = acc;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int h = 0; h < HT; ++h) d[e][h] += __shfl_xor(d[e][h], o, 64);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 1 && !two) break;
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                if (h < H) {
+                    const float dd = a.mask ? d[e][h] * mk[e][h] : d[e][h];
+                    t[h] += al[e][h] * dd;
+                    if (s + e - lo < BWD_CAP && lane == 0) stage[wave][(s + e - lo) * BWD_MAXH + h] = dd;
+                }
             }
         }
     }
@@ -172,27 +214,46 @@ __global__ __launch_bounds__(256) void k_gat_mp_bwd_src(BwdArgs a) {
         for (int k = 0; k < KC; ++k)
 #pragma unroll
             for (int q = 0; q < W; ++q) acc[h][k][q] = 0.f;
-    for (int s = lo; s < hi; ++s) {
-        const int dst = a.t_csr_dst[s], eid = a.t_csr_eid[s];
-        float am[HT];
+    // two out-edges per trip: their index loads, then their coefficient and dout-row loads, are issued together (one dependent
+    // chain per trip instead of one per edge); the second edge of an odd tail is a repeat of the first with zero weight.  The sums
+    // keep the edge order.
+    for (int s = lo; s < hi; s += 2) {
+        const bool two = s + 1 < hi;
+        const int dst0 = a.t_csr_dst[s], eid0 = a.t_csr_eid[s];
+        const int dst1 = a.t_csr_dst[two ? s + 1 : s], eid1 = a.t_csr_eid[two ? s + 1 : s];
+        float am0[HT], am1[HT];
 #pragma unroll
         for (int h = 0; h < HT; ++h) {
-            am[h] = 0.f;
+            am0[h] = am1[h] = 0.f;
             if (h < H) {
-                am[h] = a.alpha[(int64_t)eid * H + h] * inv_h;
-                if (a.mask) am[h] *= a.mask[(int64_t)eid * H + h];
+                am0[h] = a.alpha[(int64_t)eid0 * H + h] * inv_h;
+                am1[h] = two ? a.alpha[(int64_t)eid1 * H + h] * inv_h : 0.f;
+                if (a.mask) { am0[h] *= a.mask[(int64_t)eid0 * H + h]; am1[h] *= a.mask[(int64_t)eid1 * H + h]; }
+            }
+        }
+        float v0[KC][W], v1[KC][W];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int c = (lane + k * 64) * W;
+            if (c < C) {
+                loadw<W>(a.dout + (int64_t)dst0 * a.dout_ld + c, v0[k]);
+                loadw<W>(a.dout + (int64_t)dst1 * a.dout_ld + c, v1[k]);
             }
         }
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int c = (lane + k * 64) * W;
             if (c < C) {
-                float v[W];
-                loadw<W>(a.dout + (int64_t)dst * a.dout_ld + c, v);
 #pragma unroll
                 for (int h = 0; h < HT; ++h)
 #pragma unroll
-                    for (int q = 0; q < W; ++q) acc[h][k][q] += am[h] * v[q];
+                    for (int q = 0; q < W; ++q) acc[h][k][q] += am0[h] * v0[k][q];
+                if (two) {
+#pragma unroll
+                    for (int h = 0; h < HT; ++h)
+#pragma unroll
+                        for (int q = 0; q < W; ++q) acc[h][k][q] += am1[h] * v1[k][q];
+                }
             }
         }
     }
@@ -216,7 +277,8 @@ __global__ __launch_bounds__(256) void k_gat_mp_bwd_src(BwdArgs a) {
 template <int W, int KC>
 static void launch_bwd(const BwdArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)cdiv(a.N, 4));
-    hipLaunchKernelGGL((k_gat_mp_bwd_dst<W, KC>), grid, dim3(256), 0, stream, a);
+    if (a.H <= 4) hipLaunchKernelGGL((k_gat_mp_bwd_dst<W, KC, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_gat_mp_bwd_dst<W, KC, 8>), grid, dim3(256), 0, stream, a);
     if (a.H <= 4) hipLaunchKernelGGL((k_gat_mp_bwd_src<W, KC, 4>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((k_gat_mp_bwd_src<W, KC, 8>), grid, dim3(256), 0, stream, a);
 }
