@@ -386,7 +386,7 @@ def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode)
 
 
 @pytest.mark.parametrize("H,C,de,di,lo,hi", [(4, 64, 24, 16, 1, 40), (4, 300, 20, 12, 20, 40), (1, 32, 8, 8, 1, 128), (2, 136, 16, 0, 60, 128),
-                                             (8, 48, 12, 20, 5, 70)])
+                                             (8, 48, 12, 20, 5, 70), (4, 640, 16, 8, 20, 60), (2, 1040, 8, 0, 30, 90)])
 @pytest.mark.parametrize("scheme", ["split2h", "split3"])
 def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
     """The fused hop (projection + aggregation in one kernel, csrc/split3.hip EPI 2) forced onto small ragged batches:
