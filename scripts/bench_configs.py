@@ -13,7 +13,7 @@ import torch
 torch.set_grad_enabled(False)      # inference measurements: fused path
 
 from graphvqa_amd import synth, _lib
-from graphvqa_amd.graph import SceneGraphBatch
+from graphvqa_amd.graph import SceneGraphBatch, HostLayout
 
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 dev = torch.device("cuda:0")
@@ -66,21 +66,25 @@ def gat_modes(run, Nn, Ee, C=300, H=4):
     return out
 
 
-res["config2_gat_d300"] = dict(N=N, E=E, B=B, **gat_modes(lambda: m(x, ei, ea, ins, batch), N, E))
+# a forward = device CSR build from COO + gat_seq, with the loader-side per-graph layout (no device read-back), as in bench.py
+hl2 = HostLayout.from_numpy(gb.edge_index, gb.batch, B)
+res["config2_gat_d300"] = dict(N=N, E=E, B=B, **gat_modes(lambda: m(x, ei, ea, ins, batch, graph=SceneGraphBatch(ei, batch, N, B, host_layout=hl2)), N, E))
 
 # "GQA-shaped" alternative of SURVEY 8(d): E/N ~ 4 (one self loop + ~3 relations per node), same dims
 gb4 = synth.make_graph_batch(1000, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=3.0)
 N4, E4 = gb4.num_nodes, gb4.num_edges
 ei4, batch4 = tt(gb4.edge_index).to(dev), tt(gb4.batch).to(dev)
 x4, ea4 = tt(synth.normal((N4, 300), 1)).to(dev), tt(synth.normal((E4, 300), 2)).to(dev)
-res["config2_gat_d300_EoverN4"] = dict(N=N4, E=E4, **gat_modes(lambda: m(x4, ei4, ea4, ins, batch4), N4, E4))
+hl4 = HostLayout.from_numpy(gb4.edge_index, gb4.batch, B)
+res["config2_gat_d300_EoverN4"] = dict(N=N4, E=E4, **gat_modes(lambda: m(x4, ei4, ea4, ins, batch4, graph=SceneGraphBatch(ei4, batch4, N4, B, host_layout=hl4)), N4, E4))
 
 # config 3 (the headline batch): the stand-alone message-passing kernel's roofline next to config 2's
 gb3 = synth.config3_batch()
 N3, E3, B3 = gb3.num_nodes, gb3.num_edges, gb3.num_graphs
 m3 = load(gat_seq(512, 512, 512, 512, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(512, 512, 512, 512, 5, 4, seed=777))
 a3 = [tt(v).to(dev) for v in (synth.normal((N3, 512), 1), gb3.edge_index, synth.normal((E3, 512), 2), synth.normal((5, B3, 512), 3), gb3.batch)]
-res["config3_gat_d512"] = dict(N=N3, E=E3, B=B3, **gat_modes(lambda: m3(*a3), N3, E3, C=512))
+hl3 = HostLayout.from_numpy(gb3.edge_index, gb3.batch, B3)
+res["config3_gat_d512"] = dict(N=N3, E=E3, B=B3, **gat_modes(lambda: m3(*a3, graph=SceneGraphBatch(a3[1], a3[4], N3, B3, host_layout=hl3)), N3, E3, C=512))
 del m3, a3
 
 from graphvqa_amd.baseline_models import gine_seq, gcn_seq
