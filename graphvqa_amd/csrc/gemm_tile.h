@@ -146,6 +146,18 @@ __device__ __forceinline__ void lds_dma16_x2(const void* gsrc, unsigned lds_dst)
         : "memory");
 }
 
+// ... and four (two K steps x two fp16 pieces of one operand tile: 4 KiB contiguous on both sides)
+__device__ __forceinline__ void lds_dma16_x4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 // 4 bytes per lane: LDS byte address `lds_dst` + lane * 4 (no alignment requirement beyond 4 bytes on either side)
 __device__ __forceinline__ void lds_dma4_b(const void* gsrc, unsigned lds_dst) {
     unsigned keep;

@@ -117,7 +117,7 @@ __device__ __forceinline__ void keep_live(const f32x16& v) {
 // block's C stores fall under its neighbours' main loops instead of every CU storing at the same time.
 // NP: pieces per operand value -- 3: bf16 x 3 (six products), 2: scaled fp16 x 2 (three products; a_inv / b_inv = the rows'
 // inverse power-of-two scales, applied to the accumulators before anything else in every epilogue)
-template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3, int PIPE = 0>
+template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3, int PIPE = 0, int KS = 1>
 __global__ __launch_bounds__(64 * WM * WN, (160 * 1024 / (NBUF * (WM * TM + WN * TN) * NP * 1024)) * WM * WN / 4)
 void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int rtA,
                                                                const uint16_t* __restrict__ Bpk, int rtB, LinearEpilogue ep,
@@ -132,9 +132,10 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     constexpr int TPW = (FA + FB) / NW;                // (tile, NP pieces) groups each wave DMAs per K step
     typedef typename SplitFrag<NP>::type frag_t;
     static_assert((FA + FB) % NW == 0, "operand tiles must divide over the waves");
-    static_assert(NBUF * STAGE <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    static_assert(NBUF * STAGE * KS <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    static_assert(KS == 1 || (KS == 2 && NP == 2 && NBUF == 2 && !PIPE), "two K steps per stage: two-piece operands, two stages");
     static_assert(EPI != 2 || (WM == 2 && WN == 4 && TM == 4 && TN == 2), "the fused-hop epilogue is written for the 256 x 256 tile");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[EPI == 2 ? 160 * 1024 : NBUF * STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[EPI == 2 ? 160 * 1024 : NBUF * STAGE * KS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,7 +288,53 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         for (int i = 0; i < TM; ++i) sab[i] = a_inv[(bm * FA + wr * TM + i) * 32 + (lane & 31)] * sbu;
     }
 
-    if constexpr (PIPE) {
+    if constexpr (KS == 2) {
+        // ---- two K steps per stage and per barrier: a stage is 4 KiB per operand tile (two k blocks x two pieces, contiguous in
+        // the packed operand), two stages in LDS; the next stage's DMAs (four per tile from one M0 set-up) go out between the
+        // first MFMA groups of the current one.  Half the barriers and waits of the one-step loop; needs an even number of k blocks.
+        constexpr int FRAG2 = 2 * FRAG, STAGE2 = 2 * STAGE;
+        unsigned dst2[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) dst2[q] = lds_base + (wave + q * NW) * FRAG2;
+        auto issue_quad = [&](int b, int q) {
+            lds_dma16_x4(src[q], __builtin_amdgcn_readfirstlane(dst2[q] + b * STAGE2));
+            src[q] += 2 * NP * 512;
+        };
+        const unsigned a_off2 = (unsigned)(wr * TM * FRAG2 + lane * 16);
+        const unsigned b_off2 = (unsigned)((FA + wc * TN) * FRAG2 + lane * 16);
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) issue_quad(0, q);
+        int b = 0;
+        const int KB2 = KB >> 1;
+        frag_t af[TM][NP], bfr[TN][NP];
+        for (int s2 = 0; s2 < KB2; ++s2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bool more = s2 + 1 < KB2;
+            const unsigned char* sb = smem + b * STAGE2;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        af[i][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + a_off2 + i * FRAG2 + sub * FRAG + p * 1024));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        bfr[j][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + b_off2 + j * FRAG2 + sub * FRAG + p * 1024));
+#define GVQA_S2_PAIR(pa_, pb_, g_)                                                                                  \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)        \
+                    acc[i][j] = split_mfma(bfr[j][pb_], af[i][pa_], acc[i][j]);                                     \
+                if (more && sub == 0 && (g_) < TPW) issue_quad(b ^ 1, (g_));
+                GVQA_S2_PAIR(1, 0, 0) GVQA_S2_PAIR(0, 1, 1) GVQA_S2_PAIR(0, 0, 2)
+#undef GVQA_S2_PAIR
+            }
+            b ^= 1;
+        }
+        static_assert(KS == 1 || TPW <= 3, "the next stage's DMAs go out behind the three MFMA groups of the first sub-step");
+    } else if constexpr (PIPE) {
         // ---- software-pipelined main loop: the fragments of step s+1 are read from LDS (into a second register set) while the
         // matrix cores work on step s, so the LDS reads of all waves -- which leave the barrier together -- no longer sit
         // between the barrier and the first MFMA.  The whole ring is in flight: iteration s waits for step s+1, and step
@@ -1006,7 +1053,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     const uint16_t* a = static_cast<const uint16_t*>(Apk);
     const uint16_t* b = static_cast<const uint16_t*>(Bpk);
     int variant = split3_variant(M, N, KB);            // (a forced variant >= 100 names a two-piece instantiation)
-    if (np == 2 && variant < 100) variant = variant < 20 ? 118 : 134;
+    if (np == 2 && variant < 100) variant = variant < 20 ? ((KB & 1) ? 118 : 112) : 134;      // (112: two K steps per barrier)
     GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
     const int64_t bm = variant % 100 < 20 ? 256 : 128;
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, cdiv(M, 32), KB) : nullptr;
@@ -1026,12 +1073,13 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
         const int rt2 = (int)cdiv(m, 32);
 #define GVQA_S3_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_) GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 3, 0)
 #define GVQA_SN_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_) GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, 0)
-#define GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_)                                \
+#define GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_) GVQA_SK_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_, 1)
+#define GVQA_SK_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_, KS_)                           \
         do {                                                                                                             \
             dim3 grid((unsigned)cdiv(N, 32 * WN_ * TN_), (unsigned)cdiv(m, 32 * WM_ * TM_));                              \
             /* a block's MFMA issue time x the STAG_ blocks sharing the SIMDs, split into STAG_ start offsets */         \
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
-            hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_, PIPE_>), grid, \
+            hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_, PIPE_, KS_>), grid, \
                                dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C + m0 * ldc, ldc, \
                                STAG_ == 0 ? loop_dbg : (stag_scale > 0 ? stag * stag_scale / 4 : stag), FusedHopArgs{},   \
                                a_inv2, b_inv);                                                                           \
@@ -1059,6 +1107,8 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
             case 115: GVQA_SN_LAUNCH(2, 4, 4, 2, 3, true, false, true, 0, 0, 2); break;
             case 117: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2, 1); break;
             case 119: GVQA_SP_LAUNCH(2, 2, 4, 4, 4, true, false, true, 0, 0, 2, 0); break;     // four waves of 128 x 128 (256 AGPRs)
+            case 111: if (KB & 1) return GVQA_E_UNSUPPORTED; GVQA_SK_LAUNCH(2, 4, 4, 2, 2, true, false, true, 0, 0, 2, 0, 2); break;   // two K steps per barrier
+            case 112: if (KB & 1) return GVQA_E_UNSUPPORTED; GVQA_SK_LAUNCH(2, 4, 4, 2, 2, true, false, false, 0, 1, 2, 0, 2); break;
             case 118: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2, 1); break;
             case 116: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, false, false, true, 0, 0, 2); break;
             case 123: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, true, 0, 0, 2); break;
@@ -1069,6 +1119,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
 #undef GVQA_S3_LAUNCH
 #undef GVQA_SN_LAUNCH
 #undef GVQA_SP_LAUNCH
+#undef GVQA_SK_LAUNCH
     }
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
@@ -1281,8 +1332,9 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, rtA, KB) : nullptr;
     const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
     // (the read-ahead main loop, PIPE, gains 3 % in the plain GEMM and nothing here: 317 us either way for the main loop alone)
-#define GVQA_FUSED_LAUNCH(H_, NBUF_, NP_)                                                                                       \
-    hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, H_, NP_>), grid, dim3(512), 0, stream,     \
+#define GVQA_FUSED_LAUNCH(H_, NBUF_, NP_) GVQA_FUSED_LAUNCH_K(H_, NBUF_, NP_, 1)
+#define GVQA_FUSED_LAUNCH_K(H_, NBUF_, NP_, KS_)                                                                                \
+    hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, H_, NP_, 0, KS_>), grid, dim3(512), 0, stream, \
                        f.num_groups * 128, ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), \
                        rtB, LinearEpilogue{}, nullptr, (int64_t)0, 0, f2, a_inv, b_inv)
     if (np == 3) {
@@ -1291,6 +1343,15 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
             case 2: GVQA_FUSED_LAUNCH(2, 3, 3); break;
             case 4: GVQA_FUSED_LAUNCH(4, 3, 3); break;
             default: GVQA_FUSED_LAUNCH(8, 3, 3); break;
+        }
+    } else if ((KB & 1) == 0 && !getenv("GVQA_FUSED_KS1")) {
+        // two fp16 pieces, even number of k blocks: two K steps per 64 KiB stage and per barrier, two stages (59.6 k vs 65.3 k
+        // cycles per tile in the main loop, 285 vs 298 us at config 3: part of the saving comes back as a lower clock)
+        switch (f.H) {
+            case 1: GVQA_FUSED_LAUNCH_K(1, 2, 2, 2); break;
+            case 2: GVQA_FUSED_LAUNCH_K(2, 2, 2, 2); break;
+            case 4: GVQA_FUSED_LAUNCH_K(4, 2, 2, 2); break;
+            default: GVQA_FUSED_LAUNCH_K(8, 2, 2, 2); break;
         }
     } else {        // two fp16 pieces: 32 KiB per K step, four steps in the 128 KiB below the epilogue's CSR regions
         switch (f.H) {
@@ -1301,6 +1362,7 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
         }
     }
 #undef GVQA_FUSED_LAUNCH
+#undef GVQA_FUSED_LAUNCH_K
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 # kernel variants (tile geometry x schedule x epilogue, see launch_linear_split); 0 = the library's own choice
 VARIANTS = [0, 10, 11, 14, 21, 28, 29, 30, 34]
-SCHEME_VARIANTS = [("split3", v) for v in VARIANTS] + [("split2h", v) for v in (0, 114, 118, 134)]
+SCHEME_VARIANTS = [("split3", v) for v in VARIANTS] + [("split2h", v) for v in (0, 114, 118, 134)]   # (112: even k-block counts only, own test below)
 
 
 @pytest.fixture(scope="module")
@@ -196,3 +196,16 @@ def test_split2h_zero_inf_rows(env):
     assert not C[5].any() and not torch.isfinite(C[7]).any()
     keep = [i for i in range(64) if i != 7]
     assert float((C[keep].double() - A[keep].double() @ W.double().t()).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (513, 520, 512), (2048, 512, 1024), (300, 132, 32)])
+def test_linear_split2h_two_k_steps_per_barrier(env, M, N, K):
+    """Variant 112: two K steps per LDS stage and per barrier (even number of k blocks only)."""
+    _lib, lib, dev = env
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    C = _run(env, A, W, 112, scheme="split2h")
+    C0 = _run(env, A, W, 114, scheme="split2h")
+    ref = A.double() @ W.double().t()
+    assert float((C.double() - ref).abs().max()) < max(2e-6, 2 * float((C0.double() - ref).abs().max()))
