@@ -319,9 +319,10 @@ def main():
             # 2 E H C flops (0.4 %) are not counted.
             avg_s = proj_ms / max(proj_n, 1) * 1e-3
             ach = products * flops32 / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": f"gvqa::k_linear_split3<2,4,4,2,NBUF={4 if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces}> (fused hop: "
-                                               f"{pieces}-piece split projection, 256 x 256 tile, GAT aggregation + skip/BN/ReLU epilogue out of "
-                                               "LDS; xp never reaches HBM)",
+            ks2 = pieces == 2 and (-(-D // 16)) % 2 == 0                 # two K steps per stage when the k-block count is even
+            roof = {"bound": "mfma", "kernel": f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
+                                               f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
+                                               "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)",
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                     "algorithmic_flops_per_launch": products * flops32, "fp32_equivalent_tflops": flops32 / avg_s / 1e12,
                     "fp32_equivalent_frac_of_f32_mfma_peak": flops32 / avg_s / 1e12 / 157.3,
