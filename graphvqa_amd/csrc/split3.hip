@@ -1,5 +1,8 @@
-// fp32-accurate dense projections on the CDNA4 bf16 matrix cores ("split3"):
+// fp32-accurate dense projections on the CDNA4 16-bit matrix cores:
 //     C[M,N] = A[M,K] . B[N,K]^T  (+bias) (+addend) (*mul) (act),   A, B, C fp32.
+// Two operand forms share the kernels below (template parameter NP = pieces per value): "split3", three exact bf16 pieces and
+// six piece products -- described first -- and "split2h" (the default of the library), two scaled fp16 pieces and three
+// products -- described at k_split2h_pack.
 //
 // This is torch.nn.Linear's math for the node projection xp = lin_l(x_cat) of every GAT hop
 // (/root/reference gat_skip.py:133) -- 76 % of the round-1 step on the f32-input MFMA (157 TF peak).
@@ -27,7 +30,7 @@
 // Kernel: block = WM x WN waves, wave tile (32 TM) x (32 TN), block tile BM x BN = (32 TM WM) x (32 TN WN),
 // K step 16, NBUF-deep LDS ring filled by LDS-DMA two steps ahead (counted `s_waitcnt vmcnt`, ONE raw
 // barrier per K step: it orders "step s has landed for every wave" and "every wave is done reading the
-// buffer that is refilled next").  MFMA operands are swapped (B fragment first) so the accumulators hold
+// buffer that is refilled next"; KS = 2: two K steps per stage and per barrier, two stages).  MFMA operands are swapped (B fragment first) so the accumulators hold
 // the transposed 32 x 32 tiles and a lane owns 4 consecutive columns of one C row per register quad: the
 // epilogue is float4 stores straight from registers.
 #include <algorithm>

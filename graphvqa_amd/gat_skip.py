@@ -590,7 +590,7 @@ class gat_seq(torch.nn.Module):
         return self._hops, self._hops_keep
 
     def _weight_cache(self, lib, d, hops, layout, dev) -> Tensor:
-        """Parameter-only products of the forward (folded attention vectors, per-graph term weights, split3-packed
+        """Parameter-only products of the forward (folded attention vectors, per-graph term weights, packed
         projection weights) prepared once per (parameter state, layout, device): the key holds every parameter's storage
         pointer and in-place version counter, so an optimizer step, load_state_dict or .to() invalidates it."""
         key = (layout, dev, tuple((p.data_ptr(), p._version) for p in self._param_list()))
