@@ -168,42 +168,51 @@ __global__ __launch_bounds__(256) void k_gcn_aggregate(int N, int C, const float
     }
 }
 
-// float4 form (C % 4 == 0, 16-byte aligned rows): work item = (node, 4 channels), consecutive lanes on consecutive channel
-// quads of one node, so every neighbour row is read as whole 16-byte segments (the scalar kernel above: one 4-byte load per lane
-// and 4.7 passes over a 300-channel row).  Same summation order: non-self edges in CSR (= COO) order, then the self loop.
+// float4 form (C % 4 == 0, 16-byte aligned rows): ONE WAVE PER NODE, lanes over the row's channel quads -- the edge indices, the
+// neighbours' normalisers and graph ids are wave-uniform (scalar loads, once per edge instead of once per (edge, quad) as in a
+// thread-per-(node, quad) mapping: 25 us at config 2 = 2.8 TB/s), every neighbour row is read as whole 16-byte segments by
+// consecutive lanes.  Same summation order as the scalar kernel: non-self edges in CSR (= COO) order, then the self loop.
 __global__ __launch_bounds__(256) void k_gcn_aggregate_v4(int N, int C4, const float4* __restrict__ xw, const float4* __restrict__ P,
                                                           const float* __restrict__ dis, const float4* __restrict__ bias,
                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ csr_src,
                                                           const int32_t* __restrict__ node_graph, float4* __restrict__ out) {
-    const int64_t total = (int64_t)N * C4;
-    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
-        const int i = (int)(it / C4), q = (int)(it - (int64_t)i * C4);
-        const int lo = rowptr[i], hi = rowptr[i + 1];
-        const float di = dis[i];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    const float di = dis[i];
+    const float4* pi = P ? P + (int64_t)node_graph[i] * C4 : nullptr;
+    // a lane owns the quads lane, lane + 64 (, ... in further rounds): the edge loop runs once per round of 128 quads
+    for (int q0 = 0; q0 < C4; q0 += 128) {
+        const int qa = q0 + lane, qb = q0 + 64 + lane;
+        const bool ona = qa < C4, onb = qb < C4;
+        float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        auto add = [&](int k, int q, const float4* row, const float4* prow, float w) {
+            float4 v = row[q];
+            if (prow) {
+                const float4 pg = prow[q];
+                v.x += pg.x; v.y += pg.y; v.z += pg.z; v.w += pg.w;
+            }
+            acc[k].x += w * v.x; acc[k].y += w * v.y; acc[k].z += w * v.z; acc[k].w += w * v.w;
+        };
         for (int s = lo; s < hi; ++s) {
             const int src = csr_src[s];
             if (src == i) continue;
-            float4 v = xw[(int64_t)src * C4 + q];
-            if (P) {
-                const float4 pg = P[(int64_t)node_graph[src] * C4 + q];
-                v.x += pg.x; v.y += pg.y; v.z += pg.z; v.w += pg.w;
-            }
+            const float4* row = xw + (int64_t)src * C4;
+            const float4* prow = P ? P + (int64_t)node_graph[src] * C4 : nullptr;
             const float w = dis[src] * di;
-            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+            if (ona) add(0, qa, row, prow, w);
+            if (onb) add(1, qb, row, prow, w);
         }
-        float4 v = xw[(int64_t)i * C4 + q];
-        if (P) {
-            const float4 pg = P[(int64_t)node_graph[i] * C4 + q];
-            v.x += pg.x; v.y += pg.y; v.z += pg.z; v.w += pg.w;
-        }
-        const float w = di * di;
-        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        const float4* row = xw + (int64_t)i * C4;
+        if (ona) add(0, qa, row, pi, di * di);
+        if (onb) add(1, qb, row, pi, di * di);
         if (bias) {
-            const float4 b = bias[q];
-            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            if (ona) { const float4 b = bias[qa]; acc[0].x += b.x; acc[0].y += b.y; acc[0].z += b.z; acc[0].w += b.w; }
+            if (onb) { const float4 b = bias[qb]; acc[1].x += b.x; acc[1].y += b.y; acc[1].z += b.z; acc[1].w += b.w; }
         }
-        out[it] = acc;
+        if (ona) out[(int64_t)i * C4 + qa] = acc[0];
+        if (onb) out[(int64_t)i * C4 + qb] = acc[1];
     }
 }
 
@@ -343,8 +352,7 @@ int gvqa_gcn_conv_forward(const gvqa_graph* g, int32_t Dn, int32_t Di, int32_t C
     hipLaunchKernelGGL(k_gcn_dis, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, stream, (int)N, g->rowptr, g->csr_src, P(L.dis));
     const bool v4 = C % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!p->bias || (reinterpret_cast<uintptr_t>(p->bias) & 15) == 0);
     if (v4) {
-        const int64_t items = N * (C / 4);
-        hipLaunchKernelGGL(k_gcn_aggregate_v4, dim3((unsigned)std::min<int64_t>(cdiv(items, 256), 256 * 32)), dim3(256), 0, stream, (int)N,
+        hipLaunchKernelGGL(k_gcn_aggregate_v4, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N,
                            C / 4, reinterpret_cast<const float4*>(P(L.xw)), Di > 0 ? reinterpret_cast<const float4*>(P(L.P)) : nullptr,
                            P(L.dis), reinterpret_cast<const float4*>(p->bias), g->rowptr, g->csr_src, g->node_graph,
                            reinterpret_cast<float4*>(out));
