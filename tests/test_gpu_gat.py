@@ -942,6 +942,45 @@ def test_randomized_fused_hop_vs_oracle(dev, scheme, case):
     assert torch.equal(out, out2)
 
 
+def test_fused_hop_split2h_scales_on_uneven_operands(dev):
+    """Two-piece projection inside the fused hop when the operand scales are stressed: node rows whose magnitudes differ by
+    10^2 (per-row activation scales), one head's projection weights 10^-4 of the others' (the column block's single weight scale
+    then leaves that head's rows with fewer significant bits) -- the forward must stay within fp32-class distance of the oracle,
+    relative to the output's own scale, and as close as the three-piece (exact split) form."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    H, C, de, di, K = 4, 64, 16, 8, 2
+    gb = synth.make_graph_batch(12, seed=321, nodes_lo=8, nodes_hi=60, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=17)
+    for i in range(K):
+        w = p[f"convs.{i}.lin_l.weight"].copy()
+        w[C:2 * C] *= 1e-4                                             # head 1
+        p[f"convs.{i}.lin_l.weight"] = w
+        if f"convs.{i}.lin_r.weight" in p:                            # the reference's lin_r IS lin_l (one Parameter, two keys)
+            p[f"convs.{i}.lin_r.weight"] = w
+    # (a decade either way: wider row scales make the attention logits so large that ANY fp32 evaluation of the softmax departs
+    #  from the fp64 oracle by tens of per cent, whatever the projection arithmetic; the pack tests cover 10^+-30)
+    x = synth.normal((N, C), 1) * (10.0 ** (synth.uniform01(N, 5)[:, None] * 2 - 1)).astype(np.float32)
+    ea, ins = synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    ref = R.gat_seq(t(x, torch.float64), t(gb.edge_index), t(ea, torch.float64), t(ins, torch.float64), t(gb.batch),
+                    tparams(p, torch.float64), heads=H)
+    scale = float(ref.abs().max())
+    errs = {}
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        for name, mode in (("split2h", _lib.PROJECTION_SPLIT2H), ("split3", _lib.PROJECTION_SPLIT3), ("f32", _lib.PROJECTION_F32)):
+            old_p = _lib.set_option(_lib.OPT_PROJECTION, mode)
+            try:
+                out = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
+            finally:
+                _lib.set_option(_lib.OPT_PROJECTION, old_p)
+            errs[name] = float((out.double().cpu() - ref).abs().max()) / scale
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    assert errs["split2h"] < 1e-5 and errs["split2h"] < 4 * max(errs["split3"], errs["f32"], 1e-7), errs
+
+
 def test_eval_forward_is_hip_graph_capturable(dev):
     """Serving with static shapes: the eval forward on a prebuilt batch handle makes no synchronising call, allocation outside
     torch's allocator, or host read, so torch.cuda.graph can capture it; the replay is bit-identical to the eager call."""
