@@ -500,8 +500,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 __syncthreads();                              // group 0's image and (single) region are free
                 if (!two_regions && live) dma_region(1, 128 * 1024);
             }
-            // epilogue operands of this thread's rows (skip rows, graph ids) start their trip from HBM now, ahead of the LDS work
-            float4 sk[MAXIT][CV];
+            // the graph ids of this thread's rows start their trip from HBM now, ahead of the LDS work.  (The skip rows used to be
+            // fetched here as well: 16 registers held across the row-image write and the barrier put the H = 4 kernel into
+            // scratch; loaded at the top of `process` instead -- still ahead of the edge loop -- 415 -> 406 us per launch.)
             int gid[MAXIT];
             if (pre && live) {
 #pragma unroll
@@ -510,10 +511,6 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     const bool on = k < items && slot < cnt;
                     const int node = ns + (on ? ord[gi][k] : 0);
                     gid[k] = fh.graph_term ? fh.node_graph[node] : 0;
-#pragma unroll
-                    for (int v = 0; v < CV; ++v)
-                        sk[k][v] = (fh.skip && c_ok[v]) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
-                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             if (live && wr == gi && !(fh.debug & 1)) {
@@ -539,7 +536,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 const float* al_l = reinterpret_cast<const float*>(rp_l + al_off);
                 const float4* xs4 = reinterpret_cast<const float4*>(xs);
                 // one output row segment: node i of the group, channels [c, c + 4 CV)
-                auto process = [&](int slot, int row, bool have, int gq_pre, const float4 (&sk_pre)[CV]) {
+                auto process = [&](int slot, int row, bool have, int gq_pre) {
                     const bool row_on = slot < cnt;
                     const int i = row_on ? row : 0;
                     const int lo = rp_l[i] - e0, hi = (row_on && !(fh.debug & 2)) ? rp_l[i + 1] - e0 : lo;
@@ -553,6 +550,11 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                         for (int v = 0; v < CV; ++v)
                             if (c_ok[v]) pb[v] = *reinterpret_cast<const float4*>(fh.graph_term + (int64_t)gq * fh.t_ld + c + 4 * v);
                     }
+                    float4 sq[CV];                            // skip row segment: on its way from here, consumed after the edge loop
+#pragma unroll
+                    for (int v = 0; v < CV; ++v)
+                        sq[v] = (fh.skip && c_ok[v]) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
                     // EB edges per trip, every LDS read of a trip issued before its FMAs; the trip count is made wave-uniform
                     // (clamped index, zero weight past the end of the row): a divergent, dependent-load loop was 4x slower
                     constexpr int EB = (8 / (Hh * CV)) > 0 ? 8 / (Hh * CV) : 1;      // 8 row reads (32 VGPRs) in flight per trip
@@ -614,7 +616,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                                                (a4[w].z + b4[w].z) * inv_h + pb[w].z, (a4[w].w + b4[w].w) * inv_h + pb[w].w);
                         r.x += bi[w].x; r.y += bi[w].y; r.z += bi[w].z; r.w += bi[w].w;
                         if (fh.skip && c_ok[w]) {
-                            const float4 s4 = have ? sk_pre[w] : *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * w);
+                            const float4 s4 = sq[w];
                             r.x += s4.x; r.y += s4.y; r.z += s4.z; r.w += s4.w;
                         }
                         if (relu) {
@@ -629,14 +631,13 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
 #pragma unroll
                     for (int k = 0; k < MAXIT; ++k) {          // static indices: the prefetched operands stay in registers
                         const int slot = (tid >> lqv) + k * (NTH >> lqv);
-                        if (k < items && __builtin_amdgcn_readfirstlane(slot - (lane >> lqv)) < cnt) process(slot, ord[gi][k], true, gid[k], sk[k]);
+                        if (k < items && __builtin_amdgcn_readfirstlane(slot - (lane >> lqv)) < cnt) process(slot, ord[gi][k], true, gid[k]);
                     }
                 } else {
-                    const float4 none[CV] = {};
                     for (int idx0 = __builtin_amdgcn_readfirstlane(tid & ~63); idx0 < (cnt << lqv); idx0 += NTH)
                     {
                         const int slot = (idx0 + lane) >> lqv;
-                        process(slot, (fh.row_order && slot < cnt) ? fh.row_order[ns + slot] : slot, false, 0, none);
+                        process(slot, (fh.row_order && slot < cnt) ? fh.row_order[ns + slot] : slot, false, 0);
                     }
                 }
             }
