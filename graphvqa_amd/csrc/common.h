@@ -144,6 +144,10 @@ int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t l
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
                         int64_t ldc, hipStream_t stream);
+// fp32 Linear with caller scratch: two-piece kernels when applicable, f32-input MFMA otherwise (split3.hip)
+size_t linear_auto_scratch_bytes(int64_t M, int64_t N, int64_t K);
+int launch_linear_auto(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, LinearEpilogue ep,
+                       float* C, int64_t ldc, void* scratch, size_t scratch_bytes, hipStream_t stream);
 const char* gemm_backend_name();
 
 }  // namespace gvqa

@@ -51,12 +51,14 @@ __global__ __launch_bounds__(256) void k_head_features(int64_t B, int Q, const f
     feat[b * 3 * Q + 2 * Q + c] = gv * qv;
 }
 
-struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, total; };
-static PoolLayout pool_layout(int64_t N, int64_t B, int Ch) {
+struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, scratch, scratch_bytes, total; };
+static PoolLayout pool_layout(int64_t N, int64_t B, int Ch, int Dn) {
     PoolLayout L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
     L.h1 = take((size_t)N * Ch); L.xn = take((size_t)N * Ch); L.qh = take((size_t)B * Ch); L.qn = take((size_t)B * Ch);
     L.prod = take((size_t)N * Ch); L.z = take((size_t)N * Ch); L.gate = take((size_t)N);
+    L.scratch_bytes = linear_auto_scratch_bytes(N, Ch, Dn > Ch ? Dn : Ch);      // packed operands of the node MLP products
+    L.scratch = take(L.scratch_bytes / sizeof(float));
     L.total = off;
     return L;
 }
@@ -67,9 +69,8 @@ extern "C" {
 using namespace gvqa;
 
 size_t gvqa_attention_pool_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t channels) {
-    (void)node_dim;
     if (!g) return 0;
-    return pool_layout(g->num_nodes, g->num_graphs, channels).total;
+    return pool_layout(g->num_nodes, g->num_graphs, channels, node_dim).total;
 }
 
 int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, const gvqa_pool_params* p, const float* x,
@@ -80,7 +81,7 @@ int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, con
                  p->ques2_weight && p->ques2_bias && p->gate0_weight && p->gate0_bias && p->gate2_weight && p->gate2_bias,
                  GVQA_E_INVALID, "attention_pool: null weight");
     const int64_t N = g->num_nodes, B = g->num_graphs;
-    PoolLayout L = pool_layout(N, B, Ch);
+    PoolLayout L = pool_layout(N, B, Ch, Dn);
     GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "attention_pool: workspace %zu < required %zu", ws_bytes, L.total);
     if (B == 0) return GVQA_OK;
     GVQA_REQUIRE(u && out && (N == 0 || x), GVQA_E_INVALID, "attention_pool: null tensor");
@@ -91,8 +92,12 @@ int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, con
     int rc;
 #define LIN(M_, N_, K_, A_, W_, b_, act_, C_)                                                                  \
     do { rc = launch_linear(M_, N_, K_, A_, K_, W_, K_, b_, act_, C_, N_, 1, 0, 0, 0, stream); if (rc) return rc; } while (0)
-    LIN(N, Ch, Dn, x, p->node0_weight, p->node0_bias, 1, P(L.h1));                 // node_nn (:160)
-    LIN(N, Ch, Ch, P(L.h1), p->node2_weight, p->node2_bias, 0, P(L.xn));
+    // the three node-sized products: two-piece kernels with the scratch of this workspace (f32-input MFMA when not applicable)
+#define NLIN(K_, A_, W_, b_, act_, C_)                                                                                    \
+    do { LinearEpilogue e_{b_, nullptr, 0, nullptr, 0, act_};                                                             \
+         rc = launch_linear_auto(N, Ch, K_, A_, K_, W_, K_, e_, C_, Ch, base + L.scratch, L.scratch_bytes, stream); if (rc) return rc; } while (0)
+    NLIN(Dn, x, p->node0_weight, p->node0_bias, 1, P(L.h1));                       // node_nn (:160)
+    NLIN(Ch, P(L.h1), p->node2_weight, p->node2_bias, 0, P(L.xn));
     LIN(B, Ch, Ch, u, p->ques0_weight, p->ques0_bias, 1, P(L.qh));                 // ques_nn (:165)
     LIN(B, Ch, Ch, P(L.qh), p->ques2_weight, p->ques2_bias, 0, P(L.qn));
     if (N > 0) {
@@ -100,9 +105,10 @@ int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, con
                            P(L.qn), P(L.xn), P(L.prod));
         GVQA_LAUNCH_CHECK();
     }
-    LIN(N, Ch, Ch, P(L.prod), p->gate0_weight, p->gate0_bias, 1, P(L.z));          // gate_nn (:165)
+    NLIN(Ch, P(L.prod), p->gate0_weight, p->gate0_bias, 1, P(L.z));                // gate_nn (:165)
     LIN(N, 1, Ch, P(L.z), p->gate2_weight, p->gate2_bias, 0, P(L.gate));
 #undef LIN
+#undef NLIN
     hipLaunchKernelGGL(k_graph_attention_pool, dim3((unsigned)B), dim3(256), 0, stream, Ch, g->graph_ptr, P(L.gate), P(L.xn), out);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;

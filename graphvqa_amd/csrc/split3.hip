@@ -1373,6 +1373,30 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
 
 }  // namespace gvqa
 
+namespace gvqa {
+// A plain fp32 Linear, C = A W^T (+ epilogue), for callers that own a scratch buffer: on the two-piece kernels (A and W packed
+// into the scratch per call) when the product is large enough and GVQA_OPT_PROJECTION allows it, on the f32-input MFMA kernels
+// otherwise.  Used by the pooling head's node MLPs ([N, 512] x [512, 512]: 264 -> 150 us per layer at config 3).
+size_t linear_auto_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+    return align_up(split_packed_bytes(2, M, K), 256) + align_up(split_packed_bytes(2, N, K), 256);
+}
+int launch_linear_auto(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, LinearEpilogue ep,
+                       float* C, int64_t ldc, void* scratch, size_t scratch_bytes, hipStream_t stream) {
+    const bool split = get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 && scratch && M > 0 &&
+                       scratch_bytes >= linear_auto_scratch_bytes(M, N, K) && linear_split3_supported(N, ep, C, ldc) &&
+                       (reinterpret_cast<uintptr_t>(scratch) & 255) == 0 &&
+                       2.0 * (double)M * (double)N * (double)K >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
+    if (!split) return launch_linear_t(M, N, K, A, lda, W, ldw, ep, C, ldc, 1, 0, 0, 0, 0, stream);
+    char* apk = static_cast<char*>(scratch);
+    char* wpk = apk + align_up(split_packed_bytes(2, M, K), 256);
+    int rc = launch_split_pack(2, M, K, A, lda, apk, stream);
+    if (rc) return rc;
+    rc = launch_split_pack(2, N, K, W, ldw, wpk, stream);
+    if (rc) return rc;
+    return launch_linear_split(2, M, N, K, apk, wpk, ep, C, ldc, stream);
+}
+}  // namespace gvqa
+
 extern "C" size_t gvqa_split3_packed_bytes(int64_t rows, int64_t K) {
     if (rows <= 0 || K <= 0) return 0;
     return gvqa::split_packed_bytes(3, rows, K);
