@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
-SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip"]
+SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -28,7 +28,16 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, probes: bool = False) -> str:
+    """probes=True: the measurement build (-DGVQA_PROBES: in-kernel phase stamps and ablation switches that the product
+    library does not contain) -> lib/probes/libgvqa_hip.so, loaded by scripts/ through GVQA_LIB."""
+    if probes:
+        return _build(os.path.join(LIBDIR, "probes"), FLAGS + ["-DGVQA_PROBES"], force, verbose)
+    return _build(LIBDIR, FLAGS, force, verbose)
+
+
+def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
+    LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_tile.h"),
                os.path.join(os.path.dirname(HERE), "include", "gvqa.h")]
@@ -57,4 +66,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, probes="--probes" in sys.argv))

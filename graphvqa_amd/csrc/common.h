@@ -137,6 +137,14 @@ int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, i
                              const float* Vn, int J, float* a_node, hipStream_t stream, const void* Vn_packed = nullptr);
 int launch_split_pack_heads(int np, int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
+// hop2.hip: the same hop as a persistent kernel, two 4-wave workgroups per CU (two-piece operands, half-interleaved weights)
+int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
+int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, const float* epc, hipStream_t stream);
+// per-channel epilogue constants of a hop ([3][hop2_consts_ld]: bias | BatchNorm scale | shift) -- parameter-only, weight cache
+int hop2_consts_ld(int H, int C);
+int launch_hop2_consts(int H, int C, const float* bias, const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v,
+                       float eps, float* out, hipStream_t stream);
+size_t hop2_lds_edge_capacity(int H);
 size_t hop_fused_lds_edge_capacity(int H);
 
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);

@@ -117,6 +117,8 @@ struct MpArgs {
     const float* xp;        // [N, xp_ld]: head h of node n at xp[n*xp_ld + h*C .. + C)
     int64_t xp_ld;
     const float* a_node;    // [N, 2H] or NULL (zeros)
+    int a_node_parts;       // 0 / 1: a_node as it is; P > 1: a_node = sum of P partial arrays, part p at a_node + p * a_node_part_stride
+    int64_t a_node_part_stride;   // (the chained hop kernel leaves one partial logit array per column block, hop2.hip)
     const float* a_edge;    // COO-indexed: a_edge[eid * a_edge_stride + h]
     int64_t a_edge_stride;
     const float* graph_term;  // NULL or [B, t_ld]: columns [0,C) head-mean instruction term, [C,C+H) logit offset
@@ -145,6 +147,21 @@ struct MpArgs {
 };                            // 4 no output stores, 8 no CSR / logit / constant loads in the prologue -- wrong results; scripts/bench_mp_plan.py prices the parts with them
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// node logit a_node[idx] (idx = node * 2H + j), the partial arrays added in part order
+__device__ __forceinline__ float a_node_at(const MpArgs& a, int64_t idx) {
+    float v = a.a_node[idx];
+    for (int p = 1; p < a.a_node_parts; ++p) v += a.a_node[idx + (int64_t)p * a.a_node_part_stride];
+    return v;
+}
+__device__ __forceinline__ float4 a_node_at4(const MpArgs& a, int64_t idx) {
+    float4 v = *reinterpret_cast<const float4*>(a.a_node + idx);
+    for (int p = 1; p < a.a_node_parts; ++p) {
+        const float4 w = *reinterpret_cast<const float4*>(a.a_node + idx + (int64_t)p * a.a_node_part_stride);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    return v;
+}
 
 // bias + skip + BatchNorm(eval) + ReLU on 4 consecutive channels (gat_skip.py:168,270,273-275)
 __device__ __forceinline__ float4 mp_epilogue(const MpArgs& a, float4 r, int node, int c) {
@@ -480,11 +497,11 @@ __global__ __launch_bounds__(256) void k_gat_alpha_general(MpArgs a, int H) {
     if (it >= (int64_t)a.N * H) return;
     const int i = (int)(it / H), h = (int)(it - (int64_t)i * H);
     const int lo = a.rowptr[i], hi = a.rowptr[i + 1];
-    float ar = a.a_node ? a.a_node[(int64_t)i * 2 * H + H + h] : 0.f;
+    float ar = a.a_node ? a_node_at(a, (int64_t)i * 2 * H + H + h) : 0.f;
     if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[i] * a.t_ld + a.C + h];
     float m = -INFINITY;
     for (int s = lo; s < hi; ++s) {
-        const float v = leaky((a.a_node ? a.a_node[(int64_t)a.csr_src[s] * 2 * H + h] : 0.f) +
+        const float v = leaky((a.a_node ? a_node_at(a, (int64_t)a.csr_src[s] * 2 * H + h) : 0.f) +
                               a.a_edge[(int64_t)a.csr_eid[s] * a.a_edge_stride + h] + ar, a.slope);
         a.alpha_csr[(int64_t)s * H + h] = v;
         m = fmaxf(m, v);
@@ -516,26 +533,27 @@ __global__ __launch_bounds__(256) void k_gat_alpha_groups(MpArgs a, int H, const
     const int ns = group_ptr[blockIdx.x], cnt = group_ptr[blockIdx.x + 1] - ns;
     const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
     const bool v4 = (H & 3) == 0 && (a.a_edge_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.a_edge) & 15) == 0 &&
-                    (!a.a_node || (reinterpret_cast<uintptr_t>(a.a_node) & 15) == 0);
+                    (!a.a_node || ((reinterpret_cast<uintptr_t>(a.a_node) & 15) == 0 && (a.a_node_part_stride & 3) == 0));
     for (int s = tid; s < ne; s += 256) {
         const int src = a.csr_src[e0 + s], eid = a.csr_eid[e0 + s];
-        const float* an = a.a_node ? a.a_node + (int64_t)src * 2 * H : nullptr;
+        const bool an = a.a_node != nullptr;
+        const int64_t an0 = (int64_t)src * 2 * H;
         const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
         if (v4) {
             for (int h = 0; h < H; h += 4) {
-                const float4 x = an ? *reinterpret_cast<const float4*>(an + h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 x = an ? a_node_at4(a, an0 + h) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 y = *reinterpret_cast<const float4*>(ae + h);
                 *reinterpret_cast<float4*>(raw_s + s * H + h) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
             }
         } else {
-            for (int h = 0; h < H; ++h) raw_s[s * H + h] = (an ? an[h] : 0.f) + ae[h];
+            for (int h = 0; h < H; ++h) raw_s[s * H + h] = (an ? a_node_at(a, an0 + h) : 0.f) + ae[h];
         }
     }
     __syncthreads();
     for (int it = tid; it < cnt * H; it += 256) {
         const int i = it / H, h = it - i * H, node = ns + i;
         const int lo = a.rowptr[node] - e0, hi = a.rowptr[node + 1] - e0;
-        float ar = a.a_node ? a.a_node[(int64_t)node * 2 * H + H + h] : 0.f;
+        float ar = a.a_node ? a_node_at(a, (int64_t)node * 2 * H + H + h) : 0.f;
         if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[node] * a.t_ld + a.C + h];
         float m = -INFINITY;
         for (int s = lo; s < hi; ++s) {
@@ -798,7 +816,10 @@ static int proj_pieces(int64_t M, int64_t N, int64_t K) {
 }
 // weight-cache layout id: -1 no packed projection weights; bit 0: head-interleaved rows (fused hop) instead of plain row order;
 // bit 1: two fp16 pieces instead of three bf16 pieces
-static int weight_layout_id(int pieces, bool heads) { return pieces == 0 ? -1 : (heads ? 1 : 0) | (pieces == 2 ? 2 : 0); }
+// bit 2: half-interleaved rows (hop2.hip) instead of head-interleaved ones (identical for H = 4)
+static int weight_layout_id(int pieces, bool heads, bool hop2 = false) {
+    return pieces == 0 ? -1 : (heads ? 1 : 0) | (pieces == 2 ? 2 : 0) | (heads && hop2 && pieces == 2 ? 4 : 0);
+}
 static int layout_pieces(int layout) { return layout < 0 ? 0 : (layout & 2) ? 2 : 3; }
 
 // Fused hop (projection + aggregation in one kernel, split3.hip): needs the split3 projection, a row-group plan (every
@@ -810,11 +831,19 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
            (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H);
 }
 
+// The hop as the persistent two-workgroups-per-CU kernel of hop2.hip (GVQA_OPT_HOP_FUSION = 2): two-piece operands and the
+// largest row group's CSR slice within that kernel's 16 KiB region; otherwise the 8-wave fused kernel runs.
+static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    return get_option(GVQA_OPT_HOP_FUSION) == 2 && hop_fusion_applies(g, d) &&
+           proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
+           (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads);
+}
+
 // ---- weight cache: everything a forward derives from the PARAMETERS alone (folded attention vectors Vn / Ve, per-graph
 // term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
 // not change.  layout: see weight_layout_id.
 struct WeightCacheLayout {
-    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, total;     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
+    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, total;   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
 };                                                             // pack pass computes the attention logits on the matrix cores)
 static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout) {
     WeightCacheLayout W;
@@ -828,8 +857,10 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.w6_hop = layout < 0 ? 0 : (layout & 1) ? split_packed_rows_bytes(np, cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
                                              : split_packed_bytes(np, (int64_t)(H * C), d->node_dim);
     W.w6 = take(K * W.w6_hop);
-    W.vn2h_hop = layout == 3 ? align_up(split_packed_bytes(2, 2 * (int64_t)H, d->node_dim), 256) : 0;
+    W.vn2h_hop = (layout >= 0 && (layout & 3) == 3) ? align_up(split_packed_bytes(2, 2 * (int64_t)H, d->node_dim), 256) : 0;
     W.vn2h = take(K * W.vn2h_hop);
+    W.epc_hop = (layout >= 0 && (layout & 4)) ? align_up(3 * (size_t)hop2_consts_ld((int)H, (int)C) * sizeof(float), 256) : 0;
+    W.epc = take(K * W.epc_hop);
     W.total = off;
     return W;
 }
@@ -849,7 +880,7 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
     const bool fused = g && hop_fusion_applies(g, d);
     const int np = proj_pieces(N, (int64_t)(H * C), d->node_dim);
-    const int w_layout = weight_layout_id(np, fused);
+    const int w_layout = weight_layout_id(np, fused, fused && hop2_applies(g, d));
     L.Vn = take(weight_cache_layout(d, w_layout).total / sizeof(float));     // Vn | Ve | Gw | packed projection weights
     L.Ve = L.Gw = L.Vn;
     L.T = take(K * B * align_up(C + H, 4));
@@ -1046,8 +1077,17 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
         for (int i = 0; i < K; ++i) {
             GVQA_REQUIRE(hops[i].lin_l_weight, GVQA_E_INVALID, "gat: hop %d has a null weight", i);
             const int np = layout_pieces(layout);
-            rc = (layout & 1) ? launch_split_pack_heads(np, H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
+            rc = (layout & 4) ? launch_split_pack_heads2(H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
+                 : (layout & 1) ? launch_split_pack_heads(np, H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
                               : launch_split_pack(np, (int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream);
+            if (rc) return rc;
+        }
+    }
+    if (W.epc_hop) {       // bias | BatchNorm scale | shift per output channel of every hop
+        StageTimer t(GVQA_STAGE_PACK, stream);
+        for (int i = 0; i < K; ++i) {
+            rc = launch_hop2_consts(H, C, hops[i].bias, hops[i].bn_weight, hops[i].bn_bias, hops[i].bn_mean, hops[i].bn_var, d->bn_eps,
+                                    reinterpret_cast<float*>(cache + W.epc + (size_t)i * W.epc_hop), stream);
             if (rc) return rc;
         }
     }
@@ -1094,7 +1134,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const bool split = np != 0;
     const bool fused = hop_fusion_applies(g, d);
     const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
-    const int need_layout = weight_layout_id(np, fused);
+    const bool hop2 = fused && hop2_applies(g, d);
+    const int need_layout = weight_layout_id(np, fused, hop2);
     // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
     // now into the workspace (the workspace slices have exactly the cache's sub-layout)
     const WeightCacheLayout WL = weight_cache_layout(d, need_layout);
@@ -1182,7 +1223,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             f.H = H; f.C = C; f.cw = fcw; f.e_cap = g->max_row_group_edges; f.bn_eps = d->bn_eps;
             {
                 StageTimer t(GVQA_STAGE_PROJ, stream);
-                rc = launch_hop_fused_split(np, Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
+                rc = hop2 ? launch_hop2(Dn, a6, w6 + (size_t)i * w6_hop, f, reinterpret_cast<const float*>(wbase + WL.epc + (size_t)i * WL.epc_hop), stream)
+                          : launch_hop_fused_split(np, Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
                 if (rc) return rc;
             }
             if (train_bn) {
@@ -1246,13 +1288,14 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
 }
 
 size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout) {
-    if (!d || check_dims(d, true) || layout < -1 || layout > 3) return 0;
+    if (!d || check_dims(d, true) || layout < -1 || layout > 7) return 0;
     return weight_cache_layout(d, layout).total;
 }
 
 int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true)) return -1;
-    return weight_layout_id(proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), hop_fusion_applies(g, d));
+    const bool fused = hop_fusion_applies(g, d);
+    return weight_layout_id(proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), fused, fused && hop2_applies(g, d));
 }
 
 int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
@@ -1260,7 +1303,7 @@ int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_par
     GVQA_REQUIRE(hops && cache, GVQA_E_INVALID, "gat_seq_prepare_weights: null argument");
     int rc = check_dims(d, true);
     if (rc) return rc;
-    GVQA_REQUIRE(layout >= -1 && layout <= 3, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1 .. 3");
+    GVQA_REQUIRE(layout >= -1 && layout <= 7, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1 .. 7");
     GVQA_REQUIRE(cache_bytes >= weight_cache_layout(d, layout).total, GVQA_E_WORKSPACE, "gat_seq_prepare_weights: cache too small");
     GVQA_REQUIRE((reinterpret_cast<uintptr_t>(cache) & 255) == 0, GVQA_E_INVALID, "gat_seq_prepare_weights: cache must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);

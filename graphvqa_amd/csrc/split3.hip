@@ -757,13 +757,25 @@ __device__ __forceinline__ void split2h_store(const float (&v)[8], float scale, 
 }
 
 // which fp32 row a packed row (slot) holds
-enum { PACK_PLAIN = 0, PACK_GROUPS = 1, PACK_HEADS = 2 };
+enum { PACK_PLAIN = 0, PACK_GROUPS = 1, PACK_HEADS = 2, PACK_HEADS2 = 3 };
 struct PackRows {
     const float* X; int64_t ld;
     int64_t rows;                 // PLAIN: packed row r = X row r
     const int32_t* group_ptr;     // GROUPS: slot 128 g + i = node group_ptr[g] + i
     int H, C, cw;                 // HEADS: packed row 256 cb + h cw + cc = W row h C + cb cw + cc
-};
+};                                // HEADS2 (hop2.hip): packed row 256 cb + 64 w + 32 j + t = W row h C + cb cw + j hw + cc, (h, cc) = divmod(32 w + t, hw), hw = cw / 2
+// head and channel of row `within` (0..255) of column block cb
+template <int MAP>
+__device__ __forceinline__ void heads_row(const PackRows& pr, int cb, int within, int& h, int& ch) {
+    if constexpr (MAP == PACK_HEADS2) {
+        const int hw = pr.cw >> 1, u = 32 * (within >> 6) + (within & 31);
+        h = u / hw;
+        ch = cb * pr.cw + ((within >> 5) & 1) * hw + (u - h * hw);
+    } else {
+        h = within / pr.cw;
+        ch = cb * pr.cw + (within - h * pr.cw);
+    }
+}
 template <int MAP>
 __device__ __forceinline__ const float* pack_row(const PackRows& pr, int64_t rt, int m, bool& on, int64_t& src_row) {
     if constexpr (MAP == PACK_PLAIN) {
@@ -776,7 +788,8 @@ __device__ __forceinline__ const float* pack_row(const PackRows& pr, int64_t rt,
         src_row = ns + i;
     } else {
         const int r = (int)(rt * 32) + m;
-        const int cb = r >> 8, within = r & 255, h = within / pr.cw, ch = cb * pr.cw + (within - h * pr.cw);
+        int h, ch;
+        heads_row<MAP>(pr, r >> 8, r & 255, h, ch);
         on = ch < pr.C;
         src_row = (int64_t)h * pr.C + ch;
     }
@@ -858,14 +871,15 @@ __global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, i
     float rowmax = 0.f;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) rowmax = fmaxf(rowmax, mx_s[w * 32 + m]);
-    if constexpr (MAP == PACK_HEADS) {
+    if constexpr (MAP == PACK_HEADS || MAP == PACK_HEADS2) {
         // ONE scale per 256-row column block of the fused hop (its epilogue then needs a single factor for all its columns):
         // the largest magnitude of the block's rows, found by every tile of the block on its own (weights: packed once, cached).
         // Rows 2^-16 below their block's largest lose the 2^-22 guarantee (absolute error <= 2^-38 of the block's largest).
         float bmx = 0.f;
         const int cb = (int)(rt >> 3);
         for (int r = tid >> 6; r < 256; r += NWV) {                   // a wave per row, lanes over k
-            const int h = r / pr.cw, ch = cb * pr.cw + (r - h * pr.cw);
+            int h, ch;
+            heads_row<MAP>(pr, cb, r, h, ch);
             if (ch >= pr.C) continue;
             const float* wrow = pr.X + ((int64_t)h * pr.C + ch) * pr.ld;
             for (int k = lane; k < K; k += 64) bmx = fmaxf(bmx, fabsf(wrow[k]));
@@ -1308,6 +1322,14 @@ int launch_split_pack_heads(int np, int H, int C, int cw, int64_t K, const float
                        ldw, static_cast<uint16_t*>(packed), vec);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
+}
+
+// the half-interleaved weight layout of the two-workgroups-per-CU hop kernel (hop2.hip); two fp16 pieces only
+int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream) {
+    GVQA_REQUIRE(H > 0 && C > 0 && cw >= 2 && H * cw == 256 && K > 0 && ldw >= K, GVQA_E_INVALID, "split_pack_heads2: bad size");
+    GVQA_REQUIRE(W && packed, GVQA_E_INVALID, "split_pack_heads2: null operand");
+    PackRows pr{W, ldw, 0, nullptr, H, C, cw};
+    return launch_split2h_pack_tiles<PACK_HEADS2>(pr, (int64_t)cdiv(C, cw) * 8, K, packed, nullptr, 0, nullptr, stream);
 }
 
 // edges of one row group the fused epilogue can hold in LDS beside the 128 KiB row image

@@ -161,7 +161,8 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
  * term weights and the split3-packed projection weights of every hop -- prepared once and reused while the weights do not
  * change (serving).  `layout` is what the batch needs: gvqa_gat_seq_weight_layout(g, d) = -1 (f32 projection) or a
  * bit mask: bit 0 = head-interleaved rows (fused hop) instead of plain row order, bit 1 = two fp16 pieces (split2h)
- * instead of three bf16 pieces (split3).  gvqa_gat_seq_forward_cached uses the cache when its layout id
+ * instead of three bf16 pieces (split3), bit 2 = half-interleaved rows (the persistent hop kernel, GVQA_OPT_HOP_FUSION = 2)
+ * instead of head-interleaved ones.  gvqa_gat_seq_forward_cached uses the cache when its layout id
  * matches the batch's, and recomputes into the workspace otherwise (results are identical either way).  The cache is
  * caller-owned device memory, 256-byte aligned; the caller re-prepares it after changing any parameter. */
 size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout);
@@ -270,8 +271,10 @@ enum gvqa_option {
     GVQA_OPT_SPLIT3_VARIANT = 3,   /* 0 = choose by shape; otherwise an exact k_linear_split3 instantiation (tuning / tests;
                                       < 100: three-piece kernels, >= 100: two-piece kernels) */
     GVQA_OPT_HOP_FUSION = 4,       /* 1 (default): gat_seq hops run projection + aggregation as ONE kernel when the batch allows it
-                                      (split projection, graphs <= 128 nodes, H in {1,2,4,8}); 0: projection, then the
-                                      message-passing kernel (xp through HBM) */
+                                      (split projection, graphs <= 128 nodes, H in {1,2,4,8}); 2: the same as the persistent
+                                      kernel of csrc/hop2.hip (two 4-wave workgroups per CU: one's aggregation runs under the
+                                      other's matrix-core loop; two-piece operands); 0: projection, then the message-passing
+                                      kernel (xp through HBM) */
     GVQA_NUM_OPTIONS = 5
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
@@ -279,6 +282,10 @@ enum gvqa_option {
 #define GVQA_PROJECTION_SPLIT2H 2  /* two scaled fp16 pieces per fp32 value, three fp16-MFMA products, fp32 accumulate (default) */
 int gvqa_set_option(int option, int value);
 int gvqa_get_option(int option);
+
+/* Resident workgroups per CU of the persistent hop kernel (csrc/hop2.hip) as the HIP runtime reports them for head count H
+ * in {1,2,4,8}: 2 is what its design needs (80 KiB of LDS, <= 256 VGPRs); < 0 = GVQA_E_*.  Diagnostics / tests. */
+int gvqa_hop2_blocks_per_cu(int32_t H);
 
 /* Which GEMM backend serves the plain dense projections in this process (hand-written k_linear_f32,
  * or rocBLAS for large epilogue-free products; GVQA_GEMM_BACKEND=auto|hip|rocblas). */

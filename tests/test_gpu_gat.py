@@ -324,16 +324,16 @@ def test_large_single_graph_uses_general_kernel(dev):
     assert maxabs(out, ref) < TOL
 
 
-@pytest.fixture(params=["fused", "fused-split3", "split2h+mp", "split3+mp", "f32+mp"])
+@pytest.fixture(params=["fused", "fused2", "fused-split3", "split2h+mp", "split3+mp", "f32+mp"])
 def projection_mode(request):
     """The ways a hop runs (GVQA_OPT_HOP_FUSION / GVQA_OPT_PROJECTION): projection + aggregation as ONE kernel on the split2h
     arithmetic (default) or on split3, a split projection followed by the message-passing kernel, f32-input MFMA projection
     (k_linear_f32_dma / k_linear_f32) followed by the message-passing kernel."""
     from graphvqa_amd import _lib
-    proj = {"fused": _lib.PROJECTION_SPLIT2H, "fused-split3": _lib.PROJECTION_SPLIT3, "split2h+mp": _lib.PROJECTION_SPLIT2H,
+    proj = {"fused": _lib.PROJECTION_SPLIT2H, "fused2": _lib.PROJECTION_SPLIT2H, "fused-split3": _lib.PROJECTION_SPLIT3, "split2h+mp": _lib.PROJECTION_SPLIT2H,
             "split3+mp": _lib.PROJECTION_SPLIT3, "f32+mp": _lib.PROJECTION_F32}[request.param]
     old_p = _lib.set_option(_lib.OPT_PROJECTION, proj)
-    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1 if request.param.startswith("fused") else 0)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 2 if request.param == "fused2" else 1 if request.param.startswith("fused") else 0)
     yield request.param
     _lib.set_option(_lib.OPT_PROJECTION, old_p)
     _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
