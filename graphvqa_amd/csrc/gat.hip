@@ -836,14 +836,20 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     return get_option(GVQA_OPT_HOP_FUSION) == 2 && hop_fusion_applies(g, d) &&
            proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
-           (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads);
+           (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, false);
+}
+// ... with the hops chained: a hop's output leaves as the next hop's packed operand, partial logits and per-graph maxima, and
+// the pack pass between hops disappears (eval forward without per-hop fp32 outputs; H >= 4)
+static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    return hop2_applies(g, d) && d->heads >= 4 && d->node_dim == d->out_channels &&
+           (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, true);
 }
 
 // ---- weight cache: everything a forward derives from the PARAMETERS alone (folded attention vectors Vn / Ve, per-graph
 // term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
 // not change.  layout: see weight_layout_id.
 struct WeightCacheLayout {
-    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, total;   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
+    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, bc, vnf, vnf_hop, total;   // bc / vnf: bound constants, MFMA images of Vn (chained hops)   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
 };                                                             // pack pass computes the attention logits on the matrix cores)
 static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout) {
     WeightCacheLayout W;
@@ -861,12 +867,16 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.vn2h = take(K * W.vn2h_hop);
     W.epc_hop = (layout >= 0 && (layout & 4)) ? align_up(3 * (size_t)hop2_consts_ld((int)H, (int)C) * sizeof(float), 256) : 0;
     W.epc = take(K * W.epc_hop);
+    const bool chainw = layout >= 0 && (layout & 4) && H >= 4 && d->node_dim == d->out_channels;
+    W.bc = take(chainw ? K * 4 * sizeof(float) : 0);
+    W.vnf_hop = chainw ? align_up(hop2_vnf_floats((int)H, (int)C) * sizeof(float), 256) : 0;
+    W.vnf = take(K * W.vnf_hop);
     W.total = off;
     return W;
 }
 
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, total;
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PL, PM, Tmax, total;   // a6b ..: chained hops
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
@@ -896,6 +906,12 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     else if (np) L.a6 = take(split_packed_bytes(np, N, d->node_dim) / sizeof(float));
     else L.a6 = off;
     L.w6 = L.Vn;
+    const bool chain = fused && hop2_chain_capable(g, d);
+    const size_t ncb = chain ? (size_t)cdiv((int64_t)C, 256 / (int64_t)H) : 0;
+    L.a6b = take(chain ? split_packed_rows_bytes(2, (int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float) : 0);
+    L.PL = take(ncb * (size_t)N * 2 * H);
+    L.PM = take(2 * ncb * (size_t)B);
+    L.Tmax = take(chain ? K * (size_t)B : 0);
     L.total = off;
     return L;
 }
@@ -1091,6 +1107,19 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
             if (rc) return rc;
         }
     }
+    if (W.vnf_hop) {       // chained hops: bound constants (after the epilogue constants) and MFMA images of the folded vectors (after the fold)
+        StageTimer t(GVQA_STAGE_PACK, stream);
+        for (int i = 0; i < K; ++i) {
+            rc = launch_hop2_bound_consts(H, C, Dn, hops[i].lin_l_weight, Dn + Di, reinterpret_cast<const float*>(cache + W.epc + (size_t)i * W.epc_hop),
+                                          reinterpret_cast<float*>(cache + W.bc) + 4 * i, stream);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < K; ++i) {
+            rc = launch_hop2_vnf(H, Dn, reinterpret_cast<const float*>(cache + W.Vn) + (int64_t)i * 2 * H * Dn,
+                                 reinterpret_cast<float*>(cache + W.vnf + (size_t)i * W.vnf_hop), fold_stream);
+            if (rc) return rc;
+        }
+    }
     if (W.vn2h_hop) {      // two-piece images of the folded attention vectors (after the fold, on its stream)
         StageTimer t(GVQA_STAGE_PACK, fold_stream);
         for (int i = 0; i < K; ++i) {
@@ -1135,6 +1164,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const bool fused = hop_fusion_applies(g, d);
     const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
     const bool hop2 = fused && hop2_applies(g, d);
+    const bool chain = hop2 && hop2_chain_capable(g, d) && !hop_out && !bn_stats_out &&    // (per-hop fp32 outputs / batch statistics need fp32 rows)
+                       split_pack_groups_logits_supported(2, 2 * H, Dn);
     const int need_layout = weight_layout_id(np, fused, hop2);
     // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
     // now into the workspace (the workspace slices have exactly the cache's sub-layout)
@@ -1166,16 +1197,25 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                            (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
         if (rc) return rc;
     }
+    if (chain && Di > 0) {   // largest instruction-term magnitude per (hop, graph): part of the chained hops' output bounds
+        StageTimer t(GVQA_STAGE_GRAPH_TERM, aux);
+        rc = launch_rows_absmax((int64_t)K * B, C, P(L.T), Tld, P(L.Tmax), aux);
+        if (rc) return rc;
+    }
     char* a6 = base + L.a6;
+    const int ncb_chain = (int)cdiv(C, fcw);
     const float* h = x;
     for (int i = 0; i < K; ++i) {
+        if (chain) a6 = base + ((i & 1) ? L.a6b : L.a6);          // hop i reads the operand hop i - 1 (or the pack pass) left
         float* h_next;
         if (hop_out) h_next = hop_out + (int64_t)i * N * C;
         else if (i == K - 1) h_next = out;
         else h_next = (i & 1) ? P(L.h1) : P(L.h0);
         if (ss && i > 0) { rc = side_fork(ss, stream); if (rc) return rc; }     // h of this hop is ready on `stream`
         const bool logits_in_pack = fused && split_pack_groups_logits_supported(np, 2 * H, Dn);
-        if (logits_in_pack) {
+        if (chain && i > 0) {
+            // nothing to prepare: packed rows, partial logits and maxima of h came out of the previous hop's launch
+        } else if (logits_in_pack) {
             // row-group slots of h for the fused hop AND (a_l | a_r) = h . [V_l | V_r] in one pass over h
             if (ss) { rc = side_join(ss, stream); if (rc) return rc; }      // Vn comes from the fold on the side stream (hop 0)
             StageTimer tp(GVQA_STAGE_PACK, stream);
@@ -1196,6 +1236,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             memset(&a, 0, sizeof(a));
             a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid; a.node_graph = g->node_graph; a.graph_ptr = g->graph_ptr;
             a.a_node = P(L.a_node); a.a_edge = P(L.a_edge) + (int64_t)i * H; a.a_edge_stride = (int64_t)K * H;
+            if (chain && i > 0) { a.a_node = P(L.PL); a.a_node_parts = ncb_chain; a.a_node_part_stride = (int64_t)N * 2 * H; }
             a.graph_term = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr; a.t_ld = Tld;
             a.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
             a.alpha_csr = P(L.alpha_csr);
@@ -1205,7 +1246,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 rc = launch_alpha(a, H, stream, g);
                 if (rc) return rc;
             }
-            if (!logits_in_pack) {
+            if (!logits_in_pack && !(chain && i > 0)) {
                 StageTimer tp(GVQA_STAGE_PACK, stream);
                 rc = launch_split_pack_groups(np, g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, nullptr, 0, nullptr, stream);
                 if (rc) return rc;
@@ -1223,7 +1264,22 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             f.H = H; f.C = C; f.cw = fcw; f.e_cap = g->max_row_group_edges; f.bn_eps = d->bn_eps;
             {
                 StageTimer t(GVQA_STAGE_PROJ, stream);
-                rc = hop2 ? launch_hop2(Dn, a6, w6 + (size_t)i * w6_hop, f, reinterpret_cast<const float*>(wbase + WL.epc + (size_t)i * WL.epc_hop), stream)
+                Hop2ChainDesc cd;
+                memset(&cd, 0, sizeof(cd));
+                if (chain) {
+                    if (i < K - 1) {
+                        cd.Pnext = base + ((i & 1) ? L.a6 : L.a6b);
+                        cd.PL = P(L.PL);
+                        cd.VnF = reinterpret_cast<const float*>(wbase + WL.vnf + (size_t)(i + 1) * WL.vnf_hop);
+                        cd.PMout = P(L.PM) + (size_t)((i + 1) & 1) * ncb_chain * B;
+                    }
+                    cd.PMin = i > 0 ? P(L.PM) + (size_t)(i & 1) * ncb_chain * B : nullptr;
+                    cd.Tmax = Di > 0 ? P(L.Tmax) + (size_t)i * B : nullptr;
+                    cd.bc = reinterpret_cast<const float*>(wbase + WL.bc) + 4 * i;
+                    cd.graph_ptr = g->graph_ptr; cd.B = (int)B; cd.N = (int)N;
+                }
+                rc = hop2 ? launch_hop2(Dn, a6, w6 + (size_t)i * w6_hop, f, reinterpret_cast<const float*>(wbase + WL.epc + (size_t)i * WL.epc_hop),
+                                        chain ? &cd : nullptr, stream)
                           : launch_hop_fused_split(np, Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
                 if (rc) return rc;
             }

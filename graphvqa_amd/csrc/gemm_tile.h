@@ -113,6 +113,14 @@ __device__ __forceinline__ void tile_epilogue(ACC& acc, unsigned char* smem, int
     }
 }
 
+__device__ __forceinline__ int split2h_exponent(float rowmax) {
+    if (!(rowmax > 0.f) || !(rowmax <= 3.0e38f)) return 0;           // zero rows; inf / nan rows are garbage-in / garbage-out
+    int e;
+    frexpf(rowmax, &e);                                               // rowmax = f 2^e, f in [0.5, 1)
+    return max(-114, min(126, 14 - e));                               // 2^e and 2^-e are normal fp32 numbers
+}
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+
 typedef __attribute__((address_space(3))) unsigned char* lds_bytes_t;
 __device__ __forceinline__ void lds_dma16_b(const void* gsrc, unsigned lds_dst) {
     unsigned keep;

@@ -23,6 +23,7 @@
 // with (h, cc) = divmod(32 w + t, hw), cw = 256 / H, hw = cw / 2 -- for H = 4 this IS the head-interleaved layout of
 // split3.hip (k_split2h_pack<PACK_HEADS>); launch_split_pack_heads2 produces it for the other head counts.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -33,8 +34,24 @@ namespace gvqa {
 
 typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
 
+// Chaining (CHAIN kernels): instead of fp32 rows, a hop leaves what the NEXT hop's launch consumes -- its input rows as packed
+// two-piece operands, partial attention logits, per-graph maxima -- so that no pack pass runs between hops (gat.hip).
+struct Hop2Chain {
+    uint16_t* Pnext;          // packed output rows (slot layout of Apk; K = C) or NULL: fp32 rows to f.out (last hop)
+    float* a_inv_next;        // [128 G] inverse scales of Pnext's rows
+    float* PL;                // [ncb][N][2H]: the next hop's node logits restricted to each column block's channels
+    const float* VnF;         // MFMA operand image of the next hop's folded attention vectors (k_hop2_vnf)
+    float* PMout;             // [ncb][B]: per graph, largest |output| over each column block's channels
+    const float* PMin;        // [ncb][B] of the input rows (the previous hop's PMout) or NULL: bound from the rows' scales (first hop)
+    const float* Tmax;        // NULL or [B]: largest |instruction term| of this hop per graph
+    const float* bc;          // [4]: largest L1 norm of a weight row | largest |BN scale| | largest |BN shift| | largest |bias| of this hop
+    const int32_t* graph_ptr; // [B + 1]
+    int B, N;
+};
+
 struct Hop2Args {
     FusedHopArgs f;
+    Hop2Chain ch;
     const uint16_t* Apk;      // packed node rows by row-group slot (k_split2h_pack<PACK_GROUPS>)
     const uint16_t* Bpk;      // packed weights of this hop, half-interleaved rows
     const float* a_inv;       // [128 G] inverse scales of the node rows
@@ -52,6 +69,7 @@ struct Hop2Args {
 #ifdef GVQA_PROBES
 static unsigned long long* g_hop2_probe = nullptr;
 static int g_hop2_dbg = 0;
+static int g_hop2_sel_every = 1, g_hop2_sel_which = 0, g_hop2_calls = 0;      // stamps from launches with call number % every == which
 #define GVQA_H2_DBG(bit_) (a.dbg & (bit_))
 #define GVQA_H2_STAMP(slot_) do { if (a.probe && (tid & 63) == 0 && item_no < 32) a.probe[((size_t)blockIdx.x * 32 + item_no) * 32 + (tid >> 6) * 8 + (slot_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -70,9 +88,10 @@ __device__ __forceinline__ int wave_max_i32(int v) {
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-template <int H, int NBUF>
+template <int H, int NBUF, bool CHAIN>
 __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
     static_assert(H == 1 || H == 2 || H == 4 || H == 8, "hop2: H must be 1, 2, 4 or 8");
+    static_assert(!CHAIN || H >= 4, "hop2: the chained epilogue stages a 128 x (256 / H) fp32 tile in LDS");
     static_assert(NBUF == 2 || NBUF == 3, "hop2: two or three ring stages");
     constexpr int STAGE = 12 * 2048;                 // one K step: 4 A tiles + 8 B tiles, two 1 KiB pieces each
     constexpr int CW = 256 / H;                      // channels of every head per column block
@@ -85,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
     constexpr int CPAD = CW < 64 ? 64 : CW;          // constants sub-arrays padded to whole 64-lane DMA instructions
     constexpr bool REGION_EARLY = NBUF * STAGE <= 64 * 1024;   // the CSR region is outside the ring: filled under the main loop
     constexpr unsigned REGION = 64 * 1024;
+    constexpr int TLD = CW + 4;                      // (CHAIN) row stride of the staged output tile, floats
     __shared__ __attribute__((aligned(1024))) unsigned char smem[80 * 1024];
     const FusedHopArgs& fh = a.f;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,7 +124,11 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     // LDS region [64, 80) KiB, in words: rowptr | csr_src | alpha | epilogue constants bias, scale, shift of the column block
+    // (CHAIN) | inverse scales of the group's input rows | scales of its output rows | of its graphs | per-graph output maxima
     const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63), cst_off = al_off + ((fh.e_cap * H + 63) & ~63);
+    const int rinv_off = cst_off + 3 * CPAD, rscl_off = rinv_off + 128, gscl_off = rscl_off + 128, gmax_off = gscl_off + 128;
+    const Hop2Chain& ch = a.ch;
+    const bool chain_out = CHAIN && ch.Pnext != nullptr;
     float* xs = reinterpret_cast<float*>(smem);
     const float inv_h = 1.0f / H;
     const bool relu = fh.bn_w != nullptr;
@@ -144,6 +168,8 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                 lds_dma4_b(a.epc + (int64_t)arr * a.epc_ld + cb * CW + min(c0 + lane, CW - 1),
                            __builtin_amdgcn_readfirstlane(base + (unsigned)(cst_off + arr * CPAD + c0) * 4u));
             }
+            if (CHAIN && wave < 2)                    // inverse scales of the group's 128 input slots (the skip rows are read from the packed operand)
+                lds_dma4_b(a.a_inv + grp * 128 + wave * 64 + lane, __builtin_amdgcn_readfirstlane(base + (unsigned)(rinv_off + wave * 64) * 4u));
         };
         if (REGION_EARLY) dma_region();               // older than every ring DMA: the first wait of the main loop covers it
         // rows of the group are aggregated in the order fh.row_order gives (most in-edges first): slot -> row and the row's
@@ -154,7 +180,15 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
             const int slot = orow + k * RPP;
             const bool on = slot < cnt;
             ord[k] = on ? (fh.row_order ? fh.row_order[ns + slot] : slot) : 0;
-            gid[k] = fh.graph_term ? fh.node_graph[ns + ord[k]] : 0;
+            gid[k] = (CHAIN || fh.graph_term) ? fh.node_graph[ns + ord[k]] : 0;
+        }
+        // (CHAIN) first / last graph of the group, the graph of local row tid; the per-graph maxima start at zero
+        int gf = 0, ngl = 0, my_graph = 0;
+        if constexpr (CHAIN) {
+            gf = fh.node_graph[ns];
+            ngl = fh.node_graph[ns + cnt - 1] - gf + 1;
+            my_graph = (tid < cnt ? fh.node_graph[ns + tid] : gf) - gf;
+            if (tid < 128) reinterpret_cast<unsigned*>(smem + REGION)[gmax_off + tid] = 0u;
         }
         float sab[4];
         {
@@ -256,6 +290,18 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
         const float* al_l = reinterpret_cast<const float*>(rp_l + al_off);
         const float* cst_l = reinterpret_cast<const float*>(rp_l + cst_off);
         const float4* xs4 = reinterpret_cast<const float4*>(xs);
+        [[maybe_unused]] const float* rinv_l = reinterpret_cast<const float*>(rp_l + rinv_off);
+        [[maybe_unused]] float* rscl_l = reinterpret_cast<float*>(smem + REGION) + rscl_off;
+        [[maybe_unused]] float* gscl_l = reinterpret_cast<float*>(smem + REGION) + gscl_off;
+        [[maybe_unused]] unsigned* gmax_l = reinterpret_cast<unsigned*>(smem + REGION) + gmax_off;
+        // (CHAIN) finished output segments stay in registers until the image is free: [half][row of this thread][quad]
+        [[maybe_unused]] float4 res[2][CHAIN ? ITEMS : 1][2];
+        if constexpr (CHAIN) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k) res[hh][k][0] = res[hh][k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half) __syncthreads();                // the first half's image has been read out
@@ -278,8 +324,31 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
             if (!REGION_EARLY && half == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the late region DMAs of this wave have landed
             __syncthreads();
             if (half == 0) GVQA_H2_STAMP(2); else GVQA_H2_STAMP(4);
+            if constexpr (CHAIN) {
+                // Scale of the output rows, decided BEFORE they exist (they are written as fp16 pieces straight from this epilogue):
+                // one power of two per graph from an upper bound of its output magnitudes --
+                //   |out| <= max|BN scale| (M (max L1 norm of a weight row + 1) + max|instruction term| + max|bias|) + max|BN shift|,
+                // M = the largest input magnitude in the graph (a convex combination of projected neighbour rows, plus the skip row).
+                // The bound overshoots the true maximum by 2^5 .. 2^10; the two-piece split keeps 2^-22 relative accuracy down to 2^-27
+                // of the scaled maximum and degrades gracefully below, so 2^15 of overshoot is still invisible at the 1e-4 bar.
+                if (half == 0 && chain_out && tid < ngl) {
+                    const int g = gf + tid;
+                    float M = 0.f;
+                    if (ch.PMin) {
+                        for (int q = 0; q < a.ncb; ++q) M = fmaxf(M, ch.PMin[(int64_t)q * ch.B + g]);
+                    } else {                          // first hop: the rows were packed with exact scales, 2^14 / scale bounds a row
+                        const int r0 = max(ch.graph_ptr[g] - ns, 0), r1 = min(ch.graph_ptr[g + 1] - ns, cnt);
+                        for (int r = r0; r < r1; ++r) M = fmaxf(M, rinv_l[r]);
+                        M *= 16384.f;
+                    }
+                    const float tm = ch.Tmax ? ch.Tmax[g] : 0.f;
+                    const float bound = (ch.bc[1] * (M * (ch.bc[0] + 1.f) + tm + ch.bc[3]) + ch.bc[2]) * 1.001f;
+                    gscl_l[tid] = pow2i(split2h_exponent(bound));
+                }
+                if (half == 1 && chain_out && tid < 128) rscl_l[tid] = tid < cnt ? gscl_l[my_graph] : 1.f;    // (read by the tail, two barriers on)
+            }
             // one output row segment: node `row` of the group, channels [c, c + 8)
-            auto process = [&](int slot, int row, int gq) {
+            auto process = [&](int slot, int row, int gq, float4 (&ro)[2]) {
                 const bool row_on = slot < cnt;
                 const int i = row_on ? row : 0;
                 const int node = ns + i;
@@ -290,8 +359,19 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                     const bool ok = c + 4 * v < fh.C;
                     pbq[v] = (fh.graph_term && ok) ? *reinterpret_cast<const float4*>(fh.graph_term + (int64_t)gq * fh.t_ld + c + 4 * v)
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-                    sq[v] = (fh.skip && ok) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (!CHAIN)
+                        sq[v] = (fh.skip && ok) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                // (CHAIN) the skip row segment comes out of the packed input operand: channels [c, c + 8) of slot i are lane
+                // (i & 31) + 32 ((c >> 3) & 1) of k block c >> 4 -- 16 bytes per piece
+                [[maybe_unused]] uint4 sk1 = make_uint4(0u, 0u, 0u, 0u), sk2 = sk1;
+                if constexpr (CHAIN) {
+                    if (c < fh.C) {
+                        const uint16_t* pp = a.Apk + ((int64_t)((grp * 4 + (i >> 5)) * a.KB + (c >> 4)) * 2) * 512 + ((i & 31) + 32 * ((c >> 3) & 1)) * 8;
+                        sk1 = *reinterpret_cast<const uint4*>(pp);
+                        sk2 = *reinterpret_cast<const uint4*>(pp + 512);
+                    }
                 }
                 const int lo = rp_l[i] - e0, hi = row_on ? rp_l[i + 1] - e0 : lo;
                 // wave-uniform trip count (clamped slot, zero weight past the end of a row): the largest in-degree among the wave's rows
@@ -378,6 +458,12 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                     float4 r = make_float4((a4[w].x + b4[w].x) * inv_h + pb.x, (a4[w].y + b4[w].y) * inv_h + pb.y,
                                            (a4[w].z + b4[w].z) * inv_h + pb.z, (a4[w].w + b4[w].w) * inv_h + pb.w);
                     r.x += bi.x; r.y += bi.y; r.z += bi.z; r.w += bi.w;
+                    if constexpr (CHAIN) {            // (p1 + p2) / scale: the value the projection itself saw, 2^-22 from the fp32 row
+                        const h2_f16x8 h1 = __builtin_bit_cast(h2_f16x8, sk1), h2 = __builtin_bit_cast(h2_f16x8, sk2);
+                        const float rs = rinv_l[i];
+                        sq[w] = make_float4(((float)h1[4 * w] + (float)h2[4 * w]) * rs, ((float)h1[4 * w + 1] + (float)h2[4 * w + 1]) * rs,
+                                            ((float)h1[4 * w + 2] + (float)h2[4 * w + 2]) * rs, ((float)h1[4 * w + 3] + (float)h2[4 * w + 3]) * rs);
+                    }
                     r.x += sq[w].x; r.y += sq[w].y; r.z += sq[w].z; r.w += sq[w].w;
                     if (relu) {                       // torch's eval BatchNorm: y = x (w invstd) + (b - mean w invstd), then ReLU
                         const float4 sc = *reinterpret_cast<const float4*>(cst_l + CPAD + cl + 4 * w);
@@ -385,16 +471,93 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                         r.x = fmaxf(r.x * sc.x + sh.x, 0.f); r.y = fmaxf(r.y * sc.y + sh.y, 0.f);
                         r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
                     }
-                    if (row_on && c + 4 * w < fh.C) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
+                    const bool live = row_on && c + 4 * w < fh.C;
+                    if (chain_out) ro[w] = live ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+                    else if (live) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
+                }
+                if constexpr (CHAIN) {
+                    if (chain_out && row_on) {        // the graph's largest output magnitude (bit patterns of non-negative floats order like integers)
+                        const float m = fmaxf(fmaxf(fmaxf(fabsf(ro[0].x), fabsf(ro[0].y)), fmaxf(fabsf(ro[0].z), fabsf(ro[0].w))),
+                                              fmaxf(fmaxf(fabsf(ro[1].x), fabsf(ro[1].y)), fmaxf(fabsf(ro[1].z), fabsf(ro[1].w))));
+                        atomicMax(&gmax_l[gq - gf], __float_as_uint(m));
+                    }
                 }
             };
             // (whole waves enter `process`: its trip count is a wave-wide maximum; rows past the group's end are masked inside)
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 const int slot = orow + k * RPP;
-                if (__builtin_amdgcn_readfirstlane(slot - (lane / LPR)) < cnt) process(slot, ord[k], gid[k]);
+                if (__builtin_amdgcn_readfirstlane(slot - (lane / LPR)) < cnt) process(slot, ord[k], gid[k], res[CHAIN ? half : 0][CHAIN ? k : 0]);
             }
             if (half == 0) GVQA_H2_STAMP(3); else GVQA_H2_STAMP(5);
+        }
+        if constexpr (CHAIN) {
+            if (chain_out) {
+                // ---- tail: the group's 128 x CW output tile goes through LDS once (row-major, TLD floats per row) and leaves as
+                // (1) the next hop's packed operand, whole 1 KiB fragments per wave store; (2) the next hop's attention logits over
+                // this column block's channels, on the f32-input matrix cores; (3) the per-graph maxima that anchor its scales.
+                __syncthreads();                      // the image has been read out
+                float* T = xs;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int k = 0; k < ITEMS; ++k) {
+                        const int slot = orow + k * RPP;
+                        const int irow = slot < cnt ? ord[k] : slot;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) *reinterpret_cast<float4*>(T + irow * TLD + hh * HW + oct * 8 + 4 * w) = res[hh][k][w];
+                    }
+                __syncthreads();
+                GVQA_H2_STAMP(7);
+                const int trow = wave * 32 + (lane & 31), hf = lane >> 5;
+                {   // (1) wave w packs row tile w: lane (row, k half) turns 8 consecutive channels into its 16 bytes of the two fragments
+                    const float sc = rscl_l[trow];
+#pragma unroll
+                    for (int kbl = 0; kbl < CW / 16; ++kbl) {
+                        const int kbg = cb * (CW / 16) + kbl;
+                        if (kbg >= a.KB) continue;    // (channels >= C of the last column block: zero columns, never read)
+                        const float4 v0 = *reinterpret_cast<const float4*>(T + trow * TLD + kbl * 16 + hf * 8);
+                        const float4 v1 = *reinterpret_cast<const float4*>(T + trow * TLD + kbl * 16 + hf * 8 + 4);
+                        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        h2_f16x8 p0, p1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xsc = vv[e] * sc;
+                            const _Float16 hi16 = (_Float16)xsc;
+                            p0[e] = hi16;
+                            p1[e] = (_Float16)(xsc - (float)hi16);
+                        }
+                        uint16_t* dstp = ch.Pnext + ((int64_t)((grp * 4 + wave) * a.KB + kbg) * 2) * 512 + lane * 8;
+                        *reinterpret_cast<uint4*>(dstp) = __builtin_bit_cast(uint4, p0);
+                        *reinterpret_cast<uint4*>(dstp + 512) = __builtin_bit_cast(uint4, p1);
+                    }
+                    if (lane < 32) ch.a_inv_next[grp * 128 + trow] = 1.0f / sc;      // (a power of two: exact; every column block writes the same value)
+                }
+                {   // (2) D[j][row] = sum_c Vn[j][c] T[row][c]: A operand = the prepared image of the next hop's folded vectors (lane: logit
+                    // j = lane & 31, channel 2 step + (lane >> 5)), B operand = the tile (lane: row = lane & 31, same channel)
+                    f32x16 lacc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+                    const float* vf = ch.VnF + (int64_t)cb * (CW / 8) * 256 + lane * 4;
+#pragma unroll 4
+                    for (int s4 = 0; s4 < CW / 8; ++s4) {
+                        const float4 av = *reinterpret_cast<const float4*>(vf + s4 * 256);
+                        const float* tb = T + trow * TLD + 8 * s4 + hf;
+                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, tb[0], lacc, 0, 0, 0);
+                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, tb[2], lacc, 0, 0, 0);
+                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, tb[4], lacc, 0, 0, 0);
+                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, tb[6], lacc, 0, 0, 0);
+                    }
+                    // lane (row, hf) holds logits j = 8 q + 4 hf + 0..3 of its row in registers 4 q .. 4 q + 3
+                    if (trow < cnt) {
+#pragma unroll
+                        for (int q = 0; q < (2 * H) / 8; ++q)
+                            *reinterpret_cast<float4*>(ch.PL + ((int64_t)cb * ch.N + ns + trow) * (2 * H) + 8 * q + 4 * hf) =
+                                make_float4(lacc[4 * q], lacc[4 * q + 1], lacc[4 * q + 2], lacc[4 * q + 3]);
+                    }
+                }
+                if (tid < ngl) ch.PMout[(int64_t)cb * ch.B + gf + tid] = __uint_as_float(gmax_l[tid]);     // (3)
+            }
         }
         GVQA_H2_STAMP(6);
         grp = grp_n; cb = cb_n; ns = ns_n; cnt = cnt_n; e0 = e0_n; ne = ne_n;
@@ -432,8 +595,96 @@ int launch_hop2_consts(int H, int C, const float* bias, const float* bn_w, const
     return GVQA_OK;
 }
 
-// edges of one row group the kernel can hold in its 16 KiB region (beside rowptr, the padding and the column block's constants)
-size_t hop2_lds_edge_capacity(int H) { return (size_t)(4096 - 192 - 128 - 3 * std::max(256 / H, 64)) / (size_t)(H + 1); }
+// (CHAIN) MFMA operand image of a hop's folded attention vectors Vn [2H, Dn]: for column block cb and matrix-core step s
+// (channels cb CW + 2 s, + 1), lane l holds Vn[l & 31][cb CW + 2 s + (l >> 5)] (zero for l & 31 >= 2H or channels >= Dn);
+// laid out [cb][s / 4][lane][s % 4] so that a lane fetches four steps with one 16-byte load.
+__global__ __launch_bounds__(256) void k_hop2_vnf(int H, int Dn, int ncb, const float* __restrict__ Vn, float* __restrict__ out) {
+    const int cw = 256 / H;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)ncb * cw * 32) return;
+    const int u = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const int64_t blk = idx >> 8;                     // cb * (cw / 8) + s4
+    const int cb = (int)(blk / (cw / 8)), s4 = (int)(blk % (cw / 8));
+    const int j = lane & 31, c = cb * cw + 2 * (4 * s4 + u) + (lane >> 5);
+    out[idx] = (j < 2 * H && c < Dn) ? Vn[(int64_t)j * Dn + c] : 0.f;
+}
+
+// (CHAIN) the four magnitudes behind the output bound of a hop (see the kernel): largest L1 norm of a node-column weight row,
+// largest |BN scale|, |BN shift|, |bias| -> out[4].  One block; parameter-only, runs when the weight cache is prepared.
+__global__ __launch_bounds__(1024) void k_hop2_bound_consts(int rows, int Dn, const float* __restrict__ W, int64_t ldw, int C,
+                                                           const float* __restrict__ epc, int epc_ld, float* __restrict__ out) {
+    __shared__ float red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = wave; r < rows; r += 16) {           // a wave per weight row, lanes over the node columns
+        float l1 = 0.f;
+        for (int k = lane; k < Dn; k += 64) l1 += fabsf(W[(int64_t)r * ldw + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o, 64);
+        m[0] = fmaxf(m[0], l1);
+    }
+    for (int c = tid; c < C; c += 1024) {
+        m[3] = fmaxf(m[3], fabsf(epc[c]));
+        m[1] = fmaxf(m[1], fabsf(epc[epc_ld + c]));
+        m[2] = fmaxf(m[2], fabsf(epc[2 * epc_ld + c]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = m[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if (lane == 0) red[q][wave] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        float v = 0.f;
+        for (int w = 0; w < 16; ++w) v = fmaxf(v, red[tid][w]);
+        out[tid] = v;
+    }
+}
+
+// (CHAIN) out[r] = max_c |T[r, c]|, c < C: the largest instruction-term magnitude per (hop, graph) row.  A wave per row.
+__global__ __launch_bounds__(256) void k_rows_absmax(int64_t rows, int C, const float* __restrict__ T, int64_t ld, float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, fabsf(T[r * ld + c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) out[r] = m;
+}
+
+size_t hop2_vnf_floats(int H, int C) { return (size_t)cdiv(C, 256 / H) * (size_t)(256 / H) * 32; }
+
+int launch_hop2_vnf(int H, int Dn, const float* Vn, float* out, hipStream_t stream) {
+    GVQA_REQUIRE(Vn && out && Dn > 0 && (H == 4 || H == 8), GVQA_E_INVALID, "hop2_vnf: bad argument");
+    const int ncb = (int)cdiv(Dn, 256 / H);
+    hipLaunchKernelGGL(k_hop2_vnf, dim3((unsigned)cdiv((int64_t)hop2_vnf_floats(H, Dn), 256)), dim3(256), 0, stream, H, Dn, ncb, Vn, out);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int launch_hop2_bound_consts(int H, int C, int Dn, const float* W, int64_t ldw, const float* epc, float* out, hipStream_t stream) {
+    GVQA_REQUIRE(W && epc && out, GVQA_E_INVALID, "hop2_bound_consts: null argument");
+    hipLaunchKernelGGL(k_hop2_bound_consts, dim3(1), dim3(1024), 0, stream, H * C, Dn, W, ldw, C, epc, hop2_consts_ld(H, C), out);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int launch_rows_absmax(int64_t rows, int C, const float* T, int64_t ld, float* out, hipStream_t stream) {
+    if (rows <= 0) return GVQA_OK;
+    GVQA_REQUIRE(T && out && C > 0 && ld >= C, GVQA_E_INVALID, "rows_absmax: bad argument");
+    hipLaunchKernelGGL(k_rows_absmax, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, stream, rows, C, T, ld, out);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// edges of one row group the kernel can hold in its 16 KiB region (beside rowptr, the padding, the column block's constants and --
+// chained form -- the four 128-word row / graph arrays)
+size_t hop2_lds_edge_capacity(int H, bool chain) {
+    return (size_t)(4096 - 192 - 128 - 3 * std::max(256 / H, 64) - (chain ? 512 : 0)) / (size_t)(H + 1);
+}
 
 static int hop2_cus() {
     static const int cus = []() {
@@ -444,14 +695,18 @@ static int hop2_cus() {
     return cus;
 }
 
-int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, const float* epc, hipStream_t stream) {
-    GVQA_REQUIRE(Apk && Bpk && epc && f.out && f.group_ptr && f.rowptr && f.csr_src && f.alpha_csr && f.node_graph, GVQA_E_INVALID,
+int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, const float* epc, const Hop2ChainDesc* cd, hipStream_t stream) {
+    const bool chain = cd != nullptr;
+    GVQA_REQUIRE(Apk && Bpk && epc && (f.out || (chain && cd->Pnext)) && f.group_ptr && f.rowptr && f.csr_src && f.alpha_csr && f.node_graph, GVQA_E_INVALID,
                  "hop2: null operand");
     GVQA_REQUIRE(f.H * f.cw == 256 && f.C % 4 == 0 && (f.H == 1 || f.H == 2 || f.H == 4 || f.H == 8), GVQA_E_UNSUPPORTED,
                  "hop2: needs H in {1,2,4,8} and C %% 4 == 0");
-    GVQA_REQUIRE((size_t)f.e_cap <= hop2_lds_edge_capacity(f.H), GVQA_E_UNSUPPORTED, "hop2: row group has too many edges for LDS");
+    GVQA_REQUIRE((size_t)f.e_cap <= hop2_lds_edge_capacity(f.H, chain), GVQA_E_UNSUPPORTED, "hop2: row group has too many edges for LDS");
+    GVQA_REQUIRE(!chain || (f.H >= 4 && K == f.C && cd->bc && cd->graph_ptr && (!cd->Pnext || (cd->PL && cd->VnF && cd->PMout))), GVQA_E_INVALID,
+                 "hop2: chained hop needs H >= 4, node_dim == out_channels and its side arrays");
     if (f.num_groups == 0) return GVQA_OK;
     Hop2Args a;
+    memset(&a, 0, sizeof(a));
     a.f = f;
     a.KB = (int)cdiv(K, 16);
     a.ncb = (int)cdiv(f.C, f.cw);
@@ -465,8 +720,14 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     a.stagger = stag;
     a.epc = epc;
     a.epc_ld = hop2_consts_ld(f.H, f.C);
+    if (chain) {
+        a.ch.Pnext = static_cast<uint16_t*>(cd->Pnext);
+        a.ch.a_inv_next = cd->Pnext ? reinterpret_cast<float*>(static_cast<char*>(cd->Pnext) + (size_t)f.num_groups * 4 * a.KB * 2048) : nullptr;
+        a.ch.PL = cd->PL; a.ch.VnF = cd->VnF; a.ch.PMout = cd->PMout; a.ch.PMin = cd->PMin; a.ch.Tmax = cd->Tmax; a.ch.bc = cd->bc;
+        a.ch.graph_ptr = cd->graph_ptr; a.ch.B = cd->B; a.ch.N = cd->N;
+    }
 #ifdef GVQA_PROBES
-    a.probe = g_hop2_probe;
+    a.probe = (g_hop2_calls++ % g_hop2_sel_every) == g_hop2_sel_which ? g_hop2_probe : nullptr;
     a.dbg = g_hop2_dbg;
 #endif
     const int64_t items = (int64_t)f.num_groups * a.ncb;
@@ -477,16 +738,20 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     if (g_hop2_dbg & 16) wgs = std::min(wgs, hop2_cus());
 #endif
     const dim3 grid((unsigned)wgs), block(256);
-#define GVQA_H2_LAUNCH(H_)                                                                             \
+#define GVQA_H2_LAUNCH(H_, CH_)                                                                        \
     do {                                                                                               \
-        if (nbuf == 3) hipLaunchKernelGGL((k_hop2<H_, 3>), grid, block, 0, stream, a);                 \
-        else hipLaunchKernelGGL((k_hop2<H_, 2>), grid, block, 0, stream, a);                           \
+        if (nbuf == 3) hipLaunchKernelGGL((k_hop2<H_, 3, CH_>), grid, block, 0, stream, a);            \
+        else hipLaunchKernelGGL((k_hop2<H_, 2, CH_>), grid, block, 0, stream, a);                      \
     } while (0)
-    switch (f.H) {
-        case 1: GVQA_H2_LAUNCH(1); break;
-        case 2: GVQA_H2_LAUNCH(2); break;
-        case 4: GVQA_H2_LAUNCH(4); break;
-        default: GVQA_H2_LAUNCH(8); break;
+    if (chain) {
+        if (f.H == 4) GVQA_H2_LAUNCH(4, true); else GVQA_H2_LAUNCH(8, true);
+    } else {
+        switch (f.H) {
+            case 1: GVQA_H2_LAUNCH(1, false); break;
+            case 2: GVQA_H2_LAUNCH(2, false); break;
+            case 4: GVQA_H2_LAUNCH(4, false); break;
+            default: GVQA_H2_LAUNCH(8, false); break;
+        }
     }
 #undef GVQA_H2_LAUNCH
     GVQA_LAUNCH_CHECK();
@@ -499,6 +764,7 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
 // measurement build only (python -m graphvqa_amd.build --probes): device buffer for the kernel's phase stamps
 extern "C" int gvqa_probe_hop2_buffer(void* p) { gvqa::g_hop2_probe = static_cast<unsigned long long*>(p); return 0; }
 extern "C" int gvqa_probe_hop2_debug(int bits) { gvqa::g_hop2_dbg = bits; return 0; }
+extern "C" int gvqa_probe_hop2_select(int every, int which) { gvqa::g_hop2_sel_every = every > 0 ? every : 1; gvqa::g_hop2_sel_which = which; gvqa::g_hop2_calls = 0; return 0; }
 #endif
 
 // resident workgroups of the hop kernel per CU as the runtime sees them (2 expected) -- tests / diagnostics
@@ -506,10 +772,10 @@ extern "C" int gvqa_hop2_blocks_per_cu(int32_t H) {
     int n = 0;
     hipError_t e;
     switch (H) {
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<1, 2>, 256, 0); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<2, 2>, 256, 0); break;
-        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<4, 2>, 256, 0); break;
-        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<8, 2>, 256, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<1, 2, false>, 256, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<2, 2, false>, 256, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<4, 2, false>, 256, 0); break;
+        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<8, 2, false>, 256, 0); break;
         default: return GVQA_E_INVALID;
     }
     return e == hipSuccess ? n : GVQA_E_HIP;

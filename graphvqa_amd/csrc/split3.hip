@@ -737,13 +737,6 @@ static const float* split2h_inv_scales(const void* packed, int64_t row_tiles, in
 // Against fp64 the result is as close as the k-ordered fp32 chain of the f32 MFMA or three-piece bf16 (whose errors are the
 // fp32 accumulation's, tests/test_gpu_split3.py) at half the matrix-core work of the latter.  The inverse scale 2^-e of every
 // row is stored behind the fragments and applied (exactly) to the accumulators.
-__device__ __forceinline__ int split2h_exponent(float rowmax) {
-    if (!(rowmax > 0.f) || !(rowmax <= 3.0e38f)) return 0;           // zero rows; inf / nan rows are garbage-in / garbage-out
-    int e;
-    frexpf(rowmax, &e);                                               // rowmax = f 2^e, f in [0.5, 1)
-    return max(-114, min(126, 14 - e));                               // 2^e and 2^-e are normal fp32 numbers
-}
-__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
 __device__ __forceinline__ void split2h_store(const float (&v)[8], float scale, uint16_t* o, f16x8_t& p0, f16x8_t& p1) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

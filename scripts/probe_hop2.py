@@ -22,8 +22,10 @@ for _ in range(3): m(x, ei, ea, ins, batch, graph=g)
 NWG = 512
 buf = torch.zeros((NWG, 32, 4, 8), dtype=torch.int64, device=dev)
 fn = lib.gvqa_probe_hop2_buffer; fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
+sel = lib.gvqa_probe_hop2_select; sel.argtypes = [ctypes.c_int, ctypes.c_int]; sel.restype = ctypes.c_int
+sel(K, int(os.environ.get("HOP", str(K - 1))))      # which hop's launch leaves its stamps
 fn(buf.data_ptr())
-m(x, ei, ea, ins, batch, graph=g)          # the LAST hop's stamps stay in the buffer
+m(x, ei, ea, ins, batch, graph=g)
 torch.cuda.synchronize(); fn(None)
 full = buf.cpu().numpy().astype(np.int64)
 items = int((full[:, :, 0, 0] > 0).sum(1).max())
@@ -31,7 +33,8 @@ def phases(w):
     q = full[:, :items, w, :7].astype(np.float64)
     d = np.diff(q, axis=2) / 100.0
     return [round(float(v), 2) for v in d.mean((0, 1))]
-print(json.dumps({"phase_us [main, img0+sync, agg0, sync+img1, agg1, tail]": {"wave0": phases(0), "wave3": phases(3)}}))
+print(json.dumps({"phase_us [main, img0+sync, agg0, sync+img1, agg1, tail]": {"wave0": phases(0), "wave3": phases(3)},
+                  "tail_stage_tile_us (chained hops)": round(float(((full[:, :items, 0, 7] - full[:, :items, 0, 5]) / 100.0).mean()), 2)}))
 t = full[:, :, 0, :][:, :, [0, 1, 6, 6]]
 t0 = t[:, :items, 0][t[:, :items, 0] > 0].min()
 st, me, en = [(t[:, :items, k] - t0) / 100.0 for k in range(3)]
