@@ -841,7 +841,8 @@ static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // ... with the hops chained: a hop's output leaves as the next hop's packed operand, partial logits and per-graph maxima, and
 // the pack pass between hops disappears (eval forward without per-hop fp32 outputs; H >= 4)
 static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
-    return hop2_applies(g, d) && d->heads >= 4 && d->node_dim == d->out_channels &&
+    static const bool off = []() { const char* v = getenv("GVQA_HOP2_CHAIN"); return v && v[0] == '0'; }();     // (A/B switch, read once)
+    return !off && hop2_applies(g, d) && d->heads >= 4 && d->node_dim == d->out_channels &&
            (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, true);
 }
 

@@ -71,11 +71,18 @@ static unsigned long long* g_hop2_probe = nullptr;
 static int g_hop2_dbg = 0;
 static int g_hop2_sel_every = 1, g_hop2_sel_which = 0, g_hop2_calls = 0;      // stamps from launches with call number % every == which
 #define GVQA_H2_DBG(bit_) (a.dbg & (bit_))
-#define GVQA_H2_STAMP(slot_) do { if (a.probe && (tid & 63) == 0 && item_no < 32) a.probe[((size_t)blockIdx.x * 32 + item_no) * 32 + (tid >> 6) * 8 + (slot_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GVQA_H2_STAMP(slot_) do { if (a.probe && (tid & 63) == 0 && tid < 256 && item_no < 32) a.probe[((size_t)blockIdx.x * 32 + item_no) * 32 + (tid >> 6) * 8 + (slot_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GVQA_H2_STAMP(slot_) do { } while (0)
 #define GVQA_H2_DBG(bit_) false
 #endif
+
+// (device pass only: on the host pass a "v" constraint on a value of dependent type silently voids the kernel's stub)
+__device__ __forceinline__ void h2_keep_live(const f32x16& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#endif
+}
 
 // largest value of v over the 64 lanes, in an SGPR: four DPP rotations inside the 16-lane rows, then the four rows by v_readlane
 // (__shfl_xor is ds_bpermute: four dependent trips through the LDS crossbar)
@@ -88,8 +95,16 @@ __device__ __forceinline__ int wave_max_i32(int v) {
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-template <int H, int NBUF, bool CHAIN>
-__global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
+// NW = 4: four waves, wave w holds all 128 rows x columns [64 w, +64) (8 accumulators; <= 256 VGPRs, one wave of each workgroup
+// per SIMD).  NW = 8: eight waves as 2 x 4, wave (wr, wc) holds rows [64 wr, +64) x columns [64 wc, +64) (4 accumulators; <= 128
+// VGPRs, TWO waves of each workgroup per SIMD -- so a workgroup whose partner is in its epilogue still has two matrix-core waves
+// on every SIMD to hide each other's fragment reads, DMA issue and barrier waits; a lone wave reaches ~80 % of the pair's rate).
+template <int H, int NBUF, bool CHAIN, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
+    static_assert(NW == 4 || NW == 8, "hop2: four or eight waves");
+    constexpr int NT = 64 * NW;
+    constexpr int TM = 16 / NW;                      // 32-row A tiles per wave
+    constexpr bool PIPE = NW == 4;                   // hand-pipelined edge loop (needs the registers of the four-wave form)
     static_assert(H == 1 || H == 2 || H == 4 || H == 8, "hop2: H must be 1, 2, 4 or 8");
     static_assert(!CHAIN || H >= 4, "hop2: the chained epilogue stages a 128 x (256 / H) fp32 tile in LDS");
     static_assert(NBUF == 2 || NBUF == 3, "hop2: two or three ring stages");
@@ -98,8 +113,9 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
     constexpr int HW = 128 / H;                      // channels of every head in one image half
     constexpr int HC4 = HW / 4;                      // 16-byte chunks per head in an image row (32 chunks per row)
     constexpr int LPR = HW / 8;                      // lanes per row in the aggregation (8 channels each)
-    constexpr int RPP = 256 / LPR;                   // rows per pass of the 256 threads
+    constexpr int RPP = NT / LPR;                    // rows per pass of the workgroup's threads
     constexpr int ITEMS = 128 / RPP;                 // rows per thread and half
+    static_assert(ITEMS >= 1, "hop2: more threads than row segments (H = 8 runs on four waves)");
     constexpr int EB = (4 / H) > 0 ? 4 / H : 1;      // edges per trip of the edge loop (8 row reads in flight, 16 at H = 8)
     constexpr int CPAD = CW < 64 ? 64 : CW;          // constants sub-arrays padded to whole 64-lane DMA instructions
     constexpr bool REGION_EARLY = NBUF * STAGE <= 64 * 1024;   // the CSR region is outside the ring: filled under the main loop
@@ -109,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
     const FusedHopArgs& fh = a.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // wave row / column in the tile (four waves: wr = 0)
     const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
 
     // ---- this workgroup's items: XCD x = blockIdx.x % 8 owns the row groups g = gres (mod GS) x one of CS column-block
@@ -156,14 +173,14 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
             const int32_t* src_g = fh.csr_src + e0;
             const float* al_g = fh.alpha_csr + (int64_t)e0 * H;
             const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-            for (int u = wbase; u < n_rp; u += 256)
+            for (int u = wbase; u < n_rp; u += NT)
                 lds_dma4_b(rp_g + min(u + lane, n_rp - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)u * 4u));
-            for (int u = wbase; u < ne; u += 256)
+            for (int u = wbase; u < ne; u += NT)
                 lds_dma4_b(src_g + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(src_off + u) * 4u));
-            for (int u = wbase; u < n_al; u += 256)
+            for (int u = wbase; u < n_al; u += NT)
                 lds_dma4_b(al_g + min(u + lane, n_al - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(al_off + u) * 4u));
             // constants: one 64-lane instruction covers 64 channels of one array; wave w takes instructions w, w + 4, ...
-            for (int u = wave; u < 3 * (CPAD / 64); u += 4) {
+            for (int u = wave; u < 3 * (CPAD / 64); u += NW) {
                 const int arr = u / (CPAD / 64), c0 = (u % (CPAD / 64)) * 64;
                 lds_dma4_b(a.epc + (int64_t)arr * a.epc_ld + cb * CW + min(c0 + lane, CW - 1),
                            __builtin_amdgcn_readfirstlane(base + (unsigned)(cst_off + arr * CPAD + c0) * 4u));
@@ -190,17 +207,17 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
             my_graph = (tid < cnt ? fh.node_graph[ns + tid] : gf) - gf;
             if (tid < 128) reinterpret_cast<unsigned*>(smem + REGION)[gmax_off + tid] = 0u;
         }
-        float sab[4];
+        float sab[TM];
         {
             const float sbu = a.b_inv[cb * 256];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sab[i] = a.a_inv[(grp * 4 + i) * 32 + (lane & 31)] * sbu;
+            for (int i = 0; i < TM; ++i) sab[i] = a.a_inv[(grp * 4 + wr * TM + i) * 32 + (lane & 31)] * sbu;
         }
 
         // ---- main loop: acc[i][j] (+)= A tile i (rows 32 i ..) x B tile 2 wave + j over K, three piece products per K step
-        f32x16 acc[4][2];
+        f32x16 acc[TM][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -208,19 +225,23 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
         const uint16_t* src[3];
         unsigned dst[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {                 // DMA duty of this wave: operand tiles wave, wave + 4, wave + 8 of the stage
-            const int t = wave + q * 4;
+        for (int q = 0; q < 3; ++q) {
+            // DMA duty of this wave, three units per K step.  Four waves: unit = operand tile wave + 4 q of the stage (both pieces, 2 KiB
+            // contiguous on both sides).  Eight waves: unit = fragment wave + 8 q (tile = unit / 2, piece = unit % 2, 1 KiB).
+            const int u = wave + q * NW;
+            const int t = NW == 4 ? u : (u >> 1), pc = NW == 4 ? 0 : (u & 1);
             const bool isA = t < 4;
             const int tile = isA ? grp * 4 + t : cb * 8 + (t - 4);
-            src[q] = (isA ? a.Apk : a.Bpk) + (int64_t)tile * a.KB * 1024 + lane * 8;
-            dst[q] = lds_base + t * 2048;
+            src[q] = (isA ? a.Apk : a.Bpk) + (int64_t)tile * a.KB * 1024 + pc * 512 + lane * 8;
+            dst[q] = lds_base + t * 2048 + pc * 1024;
         }
-        auto issue_pair = [&](int buf, int q) {       // one (tile, K step): two 1 KiB fragments contiguous on both sides
-            lds_dma16_x2(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
+        auto issue_pair = [&](int buf, int q) {       // unit q of the next K step (consecutive K steps of a tile are 2 KiB apart)
+            if constexpr (NW == 4) lds_dma16_x2(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
+            else lds_dma16_b(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
             src[q] += 1024;
         };
-        const unsigned a_off = (unsigned)(lane * 16);
-        const unsigned b_off = (unsigned)((4 + wave * 2) * 2048 + lane * 16);
+        const unsigned a_off = (unsigned)(wr * TM * 2048 + lane * 16);
+        const unsigned b_off = (unsigned)((4 + wc * 2) * 2048 + lane * 16);
         const int KB = a.KB;
 #pragma unroll
         for (int st = 0; st < NBUF - 1; ++st)
@@ -228,10 +249,13 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) issue_pair(st, q);
         int rb = 0, wb = NBUF - 1;                    // ring slot read in step s / filled in step s
-        h2_f16x8 af[4][2], bfr[2][2];
+        h2_f16x8 af[TM][2], bfr[2][2];
         for (int ks = 0; ks < KB; ++ks) {
             if (!GVQA_H2_DBG(8)) {
-                if (NBUF == 3 && ks + 1 < KB) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // step ks + 1 may stay in flight
+                if (NBUF == 3 && ks + 1 < KB) {       // step ks + 1 may stay in flight
+                    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();         // step ks has landed for every wave; the slot refilled below is read out
             }
@@ -239,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
             const unsigned char* sb = smem + rb * STAGE;
             if (ks == 0 || !GVQA_H2_DBG(4)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
                     af[i][p] = __builtin_bit_cast(h2_f16x8, *reinterpret_cast<const uint4*>(sb + a_off + i * 2048 + p * 1024));
@@ -251,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
             }
             // smallest cross terms first; B fragment first: transposed accumulators (a lane owns 4 consecutive columns of a row)
 #define GVQA_H2_GROUP(pa_, pb_, q_)                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)            \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[j][pb_], af[i][pa_], acc[i][j], 0, 0, 0);    \
             if (more) issue_pair(wb, q_);
             GVQA_H2_GROUP(1, 0, 0) GVQA_H2_GROUP(0, 1, 1) GVQA_H2_GROUP(0, 0, 2)
@@ -265,9 +289,9 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
         GVQA_H2_STAMP(1);
         if (GVQA_H2_DBG(1)) {                         // (measurement: main loop only, accumulators kept live)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+                for (int j = 0; j < 2; ++j) h2_keep_live(acc[i][j]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GVQA_H2_STAMP(6);
             if (s + per_x < count) {
@@ -311,11 +335,11 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                 // row-per-lane ds_write_b128; lane (m, hh) owns columns 8 q + 4 hh + 0..3 of row m of a 32 x 32 tile
                 const int m = lane & 31, hh = lane >> 5;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int r = i * 32 + m;
-                        const int chunk = wave * 8 + 2 * q + hh;
+                        const int r = (wr * TM + i) * 32 + m;
+                        const int chunk = wc * 8 + 2 * q + hh;
                         float4 t = make_float4(acc[i][half][4 * q], acc[i][half][4 * q + 1], acc[i][half][4 * q + 2], acc[i][half][4 * q + 3]);
                         t.x *= sab[i]; t.y *= sab[i]; t.z *= sab[i]; t.w *= sab[i];
                         *reinterpret_cast<float4*>(xs + r * 128 + ((chunk ^ (r & 15)) << 2)) = t;
@@ -433,7 +457,15 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                                 q.z += t.al[e][h] * v[e][h][w].z; q.w += t.al[e][h] * v[e][h][w].w;
                             }
                 };
-                {
+                if constexpr (!PIPE) {                // eight waves: two epilogue waves per SIMD cover each other's latency
+                    for (int tr = 0; tr < trips; ++tr) {
+                        Trip tA;
+                        float4 vA[EB][HU][2];
+                        load_idx(tr, tA);
+                        load_rows(tr, tA, vA);
+                        fma_rows(tA, vA);
+                    }
+                } else {
                     Trip tA, tB, tC, tD;
                     float4 vA[EB][HU][2], vB[EB][HU][2];
                     load_idx(0, tA);
@@ -509,11 +541,12 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                     }
                 __syncthreads();
                 GVQA_H2_STAMP(7);
-                const int trow = wave * 32 + (lane & 31), hf = lane >> 5;
+                const int rtile = wave & 3;           // row tile of this wave (eight waves: two waves per row tile)
+                const int trow = rtile * 32 + (lane & 31), hf = lane >> 5;
                 {   // (1) wave w packs row tile w: lane (row, k half) turns 8 consecutive channels into its 16 bytes of the two fragments
                     const float sc = rscl_l[trow];
 #pragma unroll
-                    for (int kbl = 0; kbl < CW / 16; ++kbl) {
+                    for (int kbl = (wave >> 2) * (CW / 16) / (NW / 4); kbl < ((wave >> 2) + 1) * (CW / 16) / (NW / 4); ++kbl) {
                         const int kbg = cb * (CW / 16) + kbl;
                         if (kbg >= a.KB) continue;    // (channels >= C of the last column block: zero columns, never read)
                         const float4 v0 = *reinterpret_cast<const float4*>(T + trow * TLD + kbl * 16 + hf * 8);
@@ -527,13 +560,13 @@ __global__ __launch_bounds__(256, 2) void k_hop2(Hop2Args a) {
                             p0[e] = hi16;
                             p1[e] = (_Float16)(xsc - (float)hi16);
                         }
-                        uint16_t* dstp = ch.Pnext + ((int64_t)((grp * 4 + wave) * a.KB + kbg) * 2) * 512 + lane * 8;
+                        uint16_t* dstp = ch.Pnext + ((int64_t)((grp * 4 + rtile) * a.KB + kbg) * 2) * 512 + lane * 8;
                         *reinterpret_cast<uint4*>(dstp) = __builtin_bit_cast(uint4, p0);
                         *reinterpret_cast<uint4*>(dstp + 512) = __builtin_bit_cast(uint4, p1);
                     }
-                    if (lane < 32) ch.a_inv_next[grp * 128 + trow] = 1.0f / sc;      // (a power of two: exact; every column block writes the same value)
+                    if (lane < 32 && wave < 4) ch.a_inv_next[grp * 128 + trow] = 1.0f / sc;      // (a power of two: exact; every column block writes the same value)
                 }
-                {   // (2) D[j][row] = sum_c Vn[j][c] T[row][c]: A operand = the prepared image of the next hop's folded vectors (lane: logit
+                if (wave < 4) {   // (2) D[j][row] = sum_c Vn[j][c] T[row][c]: A operand = the prepared image of the next hop's folded vectors (lane: logit
                     // j = lane & 31, channel 2 step + (lane >> 5)), B operand = the tile (lane: row = lane & 31, same channel)
                     f32x16 lacc;
 #pragma unroll
@@ -717,6 +750,7 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     // tuning knobs, read once per process
     static const int stag = []() { const char* v = getenv("GVQA_HOP2_STAGGER"); return v ? atoi(v) : 0; }();
     static const int nbuf = []() { const char* v = getenv("GVQA_HOP2_NBUF"); return v ? atoi(v) : 3; }();
+    static const int waves = []() { const char* v = getenv("GVQA_HOP2_WAVES"); return v ? atoi(v) : 8; }();
     a.stagger = stag;
     a.epc = epc;
     a.epc_ld = hop2_consts_ld(f.H, f.C);
@@ -737,23 +771,25 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
 #ifdef GVQA_PROBES
     if (g_hop2_dbg & 16) wgs = std::min(wgs, hop2_cus());
 #endif
-    const dim3 grid((unsigned)wgs), block(256);
-#define GVQA_H2_LAUNCH(H_, CH_)                                                                        \
-    do {                                                                                               \
-        if (nbuf == 3) hipLaunchKernelGGL((k_hop2<H_, 3, CH_>), grid, block, 0, stream, a);            \
-        else hipLaunchKernelGGL((k_hop2<H_, 2, CH_>), grid, block, 0, stream, a);                      \
+    const dim3 grid((unsigned)wgs);
+#define GVQA_H2_LAUNCH_W(H_, CH_, NW_)                                                                               \
+    do {                                                                                                             \
+        if (nbuf == 3) hipLaunchKernelGGL((k_hop2<H_, 3, CH_, NW_>), grid, dim3(64 * NW_), 0, stream, a);            \
+        else hipLaunchKernelGGL((k_hop2<H_, 2, CH_, NW_>), grid, dim3(64 * NW_), 0, stream, a);                      \
     } while (0)
+#define GVQA_H2_LAUNCH(H_, CH_) do { if (waves == 8) GVQA_H2_LAUNCH_W(H_, CH_, 8); else GVQA_H2_LAUNCH_W(H_, CH_, 4); } while (0)
     if (chain) {
-        if (f.H == 4) GVQA_H2_LAUNCH(4, true); else GVQA_H2_LAUNCH(8, true);
+        if (f.H == 4) GVQA_H2_LAUNCH(4, true); else GVQA_H2_LAUNCH_W(8, true, 4);
     } else {
         switch (f.H) {
             case 1: GVQA_H2_LAUNCH(1, false); break;
             case 2: GVQA_H2_LAUNCH(2, false); break;
             case 4: GVQA_H2_LAUNCH(4, false); break;
-            default: GVQA_H2_LAUNCH(8, false); break;
+            default: GVQA_H2_LAUNCH_W(8, false, 4); break;      // (H = 8: 256 row segments per half, four waves)
         }
     }
 #undef GVQA_H2_LAUNCH
+#undef GVQA_H2_LAUNCH_W
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -772,10 +808,10 @@ extern "C" int gvqa_hop2_blocks_per_cu(int32_t H) {
     int n = 0;
     hipError_t e;
     switch (H) {
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<1, 2, false>, 256, 0); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<2, 2, false>, 256, 0); break;
-        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<4, 2, false>, 256, 0); break;
-        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<8, 2, false>, 256, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<1, 3, false, 8>, 512, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<2, 3, false, 8>, 512, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<4, 3, false, 8>, 512, 0); break;
+        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<8, 3, false, 4>, 256, 0); break;
         default: return GVQA_E_INVALID;
     }
     return e == hipSuccess ? n : GVQA_E_HIP;

@@ -20,6 +20,9 @@ m = gat_seq(D, D, D, Di, K, dropout=0.1, gat_heads=H)
 m.load_state_dict({k: tt(v) for k, v in synth.gat_seq_params(D, D, D, Di, K, H, seed=777).items()}); m = m.to(dev).eval()
 x, ea, ins = tt(synth.normal((N, D), 1)).to(dev), tt(synth.normal((E, D), 2)).to(dev), tt(synth.normal((K, B, Di), 3)).to(dev)
 ei, batch = tt(gb.edge_index).to(dev), tt(gb.batch).to(dev)
+if os.environ.get("ZERO"):        # DVFS probe: all-zero operands (same instruction stream, far less switching energy)
+    x.zero_()
+    for p_ in m.parameters(): p_.data.zero_()
 g = SceneGraphBatch(ei, batch, N, B)
 print(json.dumps({"hop2_blocks_per_cu": _lib.load().gvqa_hop2_blocks_per_cu(H), "N": N, "E": E, "row_groups": g.c.num_row_groups,
                   "max_row_group_edges": g.c.max_row_group_edges}), flush=True)
