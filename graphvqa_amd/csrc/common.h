@@ -140,11 +140,9 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
 // hop2.hip: the same hop as a persistent kernel, two 4-wave workgroups per CU (two-piece operands, half-interleaved weights)
 int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 // cd != NULL: chained hop -- skip rows come out of the packed input; with cd->Pnext the output leaves as the next hop's packed
-// operand + partial logits + per-graph maxima instead of fp32 rows (hop2.hip)
+// operand (+ per-graph maxima, + the slots' inverse scales) instead of fp32 rows (hop2.hip)
 struct Hop2ChainDesc {
     void* Pnext;              // packed output buffer (split_packed_rows_bytes(2, 4 G, C) bytes) or NULL: fp32 rows to FusedHopArgs::out
-    float* PL;                // [ncb][N][2H]
-    const float* VnF;         // launch_hop2_vnf image of the NEXT hop's folded attention vectors
     float* PMout;             // [ncb][B]
     const float* PMin;        // [ncb][B] or NULL (first hop)
     const float* Tmax;        // [B] or NULL
@@ -153,8 +151,6 @@ struct Hop2ChainDesc {
     int B, N;
 };
 int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, const float* epc, const Hop2ChainDesc* cd, hipStream_t stream);
-size_t hop2_vnf_floats(int H, int C);
-int launch_hop2_vnf(int H, int Dn, const float* Vn, float* out, hipStream_t stream);
 int launch_hop2_bound_consts(int H, int C, int Dn, const float* W, int64_t ldw, const float* epc, float* out, hipStream_t stream);
 int launch_rows_absmax(int64_t rows, int C, const float* T, int64_t ld, float* out, hipStream_t stream);
 // per-channel epilogue constants of a hop ([3][hop2_consts_ld]: bias | BatchNorm scale | shift) -- parameter-only, weight cache

@@ -595,6 +595,113 @@ static int launch_alpha(const MpArgs& a, int H, hipStream_t stream, const gvqa_g
     return GVQA_OK;
 }
 
+// Chained hops (hop2.hip): the previous hop left h as PACKED rows (two fp16 pieces by row-group slot) and nothing else, so this
+// form computes the node logits a_node = h . [V_l | V_r] itself -- wave w takes row tile w of the group through all k blocks on
+// the fp16 matrix cores against the two-piece image of the folded vectors (the arithmetic of the pack pass's logits), results
+// in LDS -- and then runs the two coefficient phases of k_gat_alpha_groups with LDS logits.  One pass over the packed rows
+// (4 N Dn bytes) replaces the pack pass's read of h, its write of the pieces and the a_node round trip.
+template <int J>
+__global__ __launch_bounds__(512) void k_gat_alpha_groups_packed(MpArgs a, const int32_t* __restrict__ group_ptr, const uint16_t* __restrict__ Apk,
+                                                                 const float* __restrict__ a_inv, int KB, const uint16_t* __restrict__ vn_pk,
+                                                                 const float* __restrict__ vn_inv) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x16v __attribute__((ext_vector_type(16)));
+    constexpr int H = J / 2;
+    extern __shared__ float raw_s[];                        // [2][128][J] node logits by k half | [slots of the group][H]
+    float* an_s = raw_s;
+    float* rs = raw_s + 2 * 128 * J;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rtile = wave & 3, khalf = wave >> 2;           // eight waves: two per row tile, each half of the k blocks
+    const int grp = blockIdx.x;
+    const int ns = group_ptr[grp], cnt = group_ptr[grp + 1] - ns;
+    const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
+    {
+        f32x16v lacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+        const uint16_t* ap = Apk + (int64_t)(grp * 4 + rtile) * KB * 1024 + lane * 8;
+        const uint16_t* vp = vn_pk + lane * 8;
+        const int kb0 = khalf ? (KB + 1) / 2 : 0, kb1 = khalf ? KB : (KB + 1) / 2;
+#pragma unroll 8
+        for (int kb = kb0; kb < kb1; ++kb) {
+            const f16x8 p0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + (int64_t)kb * 1024));
+            const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + (int64_t)kb * 1024 + 512));
+            const f16x8 q0 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(vp + (int64_t)kb * 1024));
+            const f16x8 q1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(vp + (int64_t)kb * 1024 + 512));
+            lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, p0, lacc, 0, 0, 0);      // transposed accumulators: lane (m, hh) holds logits
+            lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, p1, lacc, 0, 0, 0);      // 8 q + 4 hh + 0..3 of row m in registers 4 q + 0..3
+            lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, p0, lacc, 0, 0, 0);
+        }
+        const int m = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < (J + 7) / 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 8 * q + 4 * hh + r;
+                if (j < J) an_s[(khalf * 128 + rtile * 32 + m) * J + j] = lacc[4 * q + r];
+            }
+    }
+    __syncthreads();
+    for (int it = tid; it < 128 * J; it += 512) {           // the two k halves, then the rows' and vectors' exact power-of-two factors
+        const int r = it / J, j = it - r * J;
+        an_s[it] = (an_s[it] + an_s[128 * J + it]) * a_inv[grp * 128 + r] * vn_inv[j];
+    }
+    __syncthreads();
+    for (int s = tid; s < ne; s += 512) {
+        const int src = a.csr_src[e0 + s] - ns, eid = a.csr_eid[e0 + s];
+        const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
+        for (int h = 0; h < H; ++h) rs[s * H + h] = an_s[src * J + h] + ae[h];
+    }
+    __syncthreads();
+    for (int it = tid; it < cnt * H; it += 512) {
+        const int i = it / H, h = it - i * H, node = ns + i;
+        const int lo = a.rowptr[node] - e0, hi = a.rowptr[node + 1] - e0;
+        float ar = an_s[i * J + H + h];
+        if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[node] * a.t_ld + a.C + h];
+        float m = -INFINITY;
+        for (int s = lo; s < hi; ++s) {
+            const float v = leaky(rs[s * H + h] + ar, a.slope);
+            rs[s * H + h] = v;
+            m = fmaxf(m, v);
+        }
+        float sum = 0.f;
+        for (int s = lo; s < hi; ++s) {
+            const float ex = expf(rs[s * H + h] - m);
+            rs[s * H + h] = ex;
+            sum += ex;
+        }
+        const float den = sum + 1e-16f;
+        for (int s = lo; s < hi; ++s) {
+            float al = rs[s * H + h] / den;
+            if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+            if (a.alpha_mask) al *= a.alpha_mask[(int64_t)a.csr_eid[e0 + s] * H + h];
+            a.alpha_csr[(int64_t)(e0 + s) * H + h] = al;
+        }
+    }
+}
+
+static int launch_alpha_packed(const MpArgs& a, int H, hipStream_t stream, const gvqa_graph* g, const void* Apk, int KB, const void* Vn_packed) {
+    GVQA_REQUIRE(g && g->num_row_groups > 0 && g->row_group_ptr && Apk && Vn_packed, GVQA_E_INVALID, "alpha_packed: null argument");
+    const size_t lds = ((size_t)2 * 128 * 2 * H + (size_t)g->max_row_group_edges * H) * sizeof(float);
+    GVQA_REQUIRE(lds <= 64 * 1024, GVQA_E_UNSUPPORTED, "alpha_packed: row group too large");
+    const uint16_t* ap = static_cast<const uint16_t*>(Apk);
+    const float* a_inv = reinterpret_cast<const float*>(static_cast<const char*>(Apk) + (size_t)g->num_row_groups * 4 * KB * 2048);
+    const uint16_t* vp = static_cast<const uint16_t*>(Vn_packed);
+    const float* v_inv = reinterpret_cast<const float*>(static_cast<const char*>(Vn_packed) + (size_t)KB * 2048);
+    const dim3 grid((unsigned)g->num_row_groups), block(512);
+#define GVQA_AP(J_) hipLaunchKernelGGL((k_gat_alpha_groups_packed<J_>), grid, block, lds, stream, a, g->row_group_ptr, ap, a_inv, KB, vp, v_inv)
+    switch (H) {
+        case 1: GVQA_AP(2); break;
+        case 2: GVQA_AP(4); break;
+        case 4: GVQA_AP(8); break;
+        case 8: GVQA_AP(16); break;
+        default: return GVQA_E_UNSUPPORTED;
+    }
+#undef GVQA_AP
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
 __global__ __launch_bounds__(256) void k_gat_aggregate_general(MpArgs a, int H) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
@@ -842,7 +949,7 @@ static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // the pack pass between hops disappears (eval forward without per-hop fp32 outputs; H >= 4)
 static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
     static const bool off = []() { const char* v = getenv("GVQA_HOP2_CHAIN"); return v && v[0] == '0'; }();     // (A/B switch, read once)
-    return !off && hop2_applies(g, d) && d->heads >= 4 && d->node_dim == d->out_channels &&
+    return !off && hop2_applies(g, d) && d->node_dim == d->out_channels &&
            (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, true);
 }
 
@@ -850,7 +957,7 @@ static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
 // not change.  layout: see weight_layout_id.
 struct WeightCacheLayout {
-    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, bc, vnf, vnf_hop, total;   // bc / vnf: bound constants, MFMA images of Vn (chained hops)   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
+    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, bc, total;   // bc: bound constants of the chained hops   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
 };                                                             // pack pass computes the attention logits on the matrix cores)
 static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout) {
     WeightCacheLayout W;
@@ -868,16 +975,14 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.vn2h = take(K * W.vn2h_hop);
     W.epc_hop = (layout >= 0 && (layout & 4)) ? align_up(3 * (size_t)hop2_consts_ld((int)H, (int)C) * sizeof(float), 256) : 0;
     W.epc = take(K * W.epc_hop);
-    const bool chainw = layout >= 0 && (layout & 4) && H >= 4 && d->node_dim == d->out_channels;
+    const bool chainw = layout >= 0 && (layout & 4) && d->node_dim == d->out_channels;
     W.bc = take(chainw ? K * 4 * sizeof(float) : 0);
-    W.vnf_hop = chainw ? align_up(hop2_vnf_floats((int)H, (int)C) * sizeof(float), 256) : 0;
-    W.vnf = take(K * W.vnf_hop);
     W.total = off;
     return W;
 }
 
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PL, PM, Tmax, total;   // a6b ..: chained hops
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, total;   // a6b ..: chained hops
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
@@ -910,7 +1015,6 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     const bool chain = fused && hop2_chain_capable(g, d);
     const size_t ncb = chain ? (size_t)cdiv((int64_t)C, 256 / (int64_t)H) : 0;
     L.a6b = take(chain ? split_packed_rows_bytes(2, (int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float) : 0);
-    L.PL = take(ncb * (size_t)N * 2 * H);
     L.PM = take(2 * ncb * (size_t)B);
     L.Tmax = take(chain ? K * (size_t)B : 0);
     L.total = off;
@@ -1108,16 +1212,11 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
             if (rc) return rc;
         }
     }
-    if (W.vnf_hop) {       // chained hops: bound constants (after the epilogue constants) and MFMA images of the folded vectors (after the fold)
+    if (W.epc_hop && d->node_dim == d->out_channels) {      // chained hops: bound constants (after the epilogue constants)
         StageTimer t(GVQA_STAGE_PACK, stream);
         for (int i = 0; i < K; ++i) {
             rc = launch_hop2_bound_consts(H, C, Dn, hops[i].lin_l_weight, Dn + Di, reinterpret_cast<const float*>(cache + W.epc + (size_t)i * W.epc_hop),
                                           reinterpret_cast<float*>(cache + W.bc) + 4 * i, stream);
-            if (rc) return rc;
-        }
-        for (int i = 0; i < K; ++i) {
-            rc = launch_hop2_vnf(H, Dn, reinterpret_cast<const float*>(cache + W.Vn) + (int64_t)i * 2 * H * Dn,
-                                 reinterpret_cast<float*>(cache + W.vnf + (size_t)i * W.vnf_hop), fold_stream);
             if (rc) return rc;
         }
     }
@@ -1237,14 +1336,15 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             memset(&a, 0, sizeof(a));
             a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid; a.node_graph = g->node_graph; a.graph_ptr = g->graph_ptr;
             a.a_node = P(L.a_node); a.a_edge = P(L.a_edge) + (int64_t)i * H; a.a_edge_stride = (int64_t)K * H;
-            if (chain && i > 0) { a.a_node = P(L.PL); a.a_node_parts = ncb_chain; a.a_node_part_stride = (int64_t)N * 2 * H; }
             a.graph_term = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr; a.t_ld = Tld;
             a.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
             a.alpha_csr = P(L.alpha_csr);
             a.N = (int)N; a.C = C; a.slope = d->negative_slope;
-            {   // (when the logits ride on the pack pass, it ran above, before the coefficients)
+            {   // (when the logits ride on the pack pass, it ran above, before the coefficients; chained hops: the coefficient kernel
+                //  computes the logits itself from the packed rows the previous hop left)
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
-                rc = launch_alpha(a, H, stream, g);
+                rc = (chain && i > 0) ? launch_alpha_packed(a, H, stream, g, a6, (int)cdiv(Dn, 16), wbase + WL.vn2h + (size_t)i * WL.vn2h_hop)
+                                      : launch_alpha(a, H, stream, g);
                 if (rc) return rc;
             }
             if (!logits_in_pack && !(chain && i > 0)) {
@@ -1270,8 +1370,6 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 if (chain) {
                     if (i < K - 1) {
                         cd.Pnext = base + ((i & 1) ? L.a6 : L.a6b);
-                        cd.PL = P(L.PL);
-                        cd.VnF = reinterpret_cast<const float*>(wbase + WL.vnf + (size_t)(i + 1) * WL.vnf_hop);
                         cd.PMout = P(L.PM) + (size_t)((i + 1) & 1) * ncb_chain * B;
                     }
                     cd.PMin = i > 0 ? P(L.PM) + (size_t)(i & 1) * ncb_chain * B : nullptr;

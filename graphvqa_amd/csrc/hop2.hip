@@ -39,8 +39,6 @@ typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
 struct Hop2Chain {
     uint16_t* Pnext;          // packed output rows (slot layout of Apk; K = C) or NULL: fp32 rows to f.out (last hop)
     float* a_inv_next;        // [128 G] inverse scales of Pnext's rows
-    float* PL;                // [ncb][N][2H]: the next hop's node logits restricted to each column block's channels
-    const float* VnF;         // MFMA operand image of the next hop's folded attention vectors (k_hop2_vnf)
     float* PMout;             // [ncb][B]: per graph, largest |output| over each column block's channels
     const float* PMin;        // [ncb][B] of the input rows (the previous hop's PMout) or NULL: bound from the rows' scales (first hop)
     const float* Tmax;        // NULL or [B]: largest |instruction term| of this hop per graph
@@ -106,7 +104,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
     constexpr int TM = 16 / NW;                      // 32-row A tiles per wave
     constexpr bool PIPE = NW == 4;                   // hand-pipelined edge loop (needs the registers of the four-wave form)
     static_assert(H == 1 || H == 2 || H == 4 || H == 8, "hop2: H must be 1, 2, 4 or 8");
-    static_assert(!CHAIN || H >= 4, "hop2: the chained epilogue stages a 128 x (256 / H) fp32 tile in LDS");
     static_assert(NBUF == 2 || NBUF == 3, "hop2: two or three ring stages");
     constexpr int STAGE = 12 * 2048;                 // one K step: 4 A tiles + 8 B tiles, two 1 KiB pieces each
     constexpr int CW = 256 / H;                      // channels of every head per column block
@@ -120,7 +117,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
     constexpr int CPAD = CW < 64 ? 64 : CW;          // constants sub-arrays padded to whole 64-lane DMA instructions
     constexpr bool REGION_EARLY = NBUF * STAGE <= 64 * 1024;   // the CSR region is outside the ring: filled under the main loop
     constexpr unsigned REGION = 64 * 1024;
-    constexpr int TLD = CW + 4;                      // (CHAIN) row stride of the staged output tile, floats
     __shared__ __attribute__((aligned(1024))) unsigned char smem[80 * 1024];
     const FusedHopArgs& fh = a.f;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,9 +137,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     // LDS region [64, 80) KiB, in words: rowptr | csr_src | alpha | epilogue constants bias, scale, shift of the column block
-    // (CHAIN) | inverse scales of the group's input rows | scales of its output rows | of its graphs | per-graph output maxima
+    // (CHAIN) | inverse scales of the group's input rows | scales of its graphs' output rows | per-graph output maxima
     const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63), cst_off = al_off + ((fh.e_cap * H + 63) & ~63);
-    const int rinv_off = cst_off + 3 * CPAD, rscl_off = rinv_off + 128, gscl_off = rscl_off + 128, gmax_off = gscl_off + 128;
+    const int rinv_off = cst_off + 3 * CPAD, gscl_off = rinv_off + 128, gmax_off = gscl_off + 128;
     const Hop2Chain& ch = a.ch;
     const bool chain_out = CHAIN && ch.Pnext != nullptr;
     float* xs = reinterpret_cast<float*>(smem);
@@ -160,9 +156,16 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
         e0 = fh.rowptr[ns]; ne = fh.rowptr[ns + cnt] - e0;
     }
     [[maybe_unused]] int item_no = 0;
+    [[maybe_unused]] int pm_cb = 0, pm_gf = 0, pm_n = 0, pm_par = 1;
     for (int s = jx; s < count; s += per_x, ++item_no) {
         __syncthreads();                              // the previous item's image and region are free
         GVQA_H2_STAMP(0);
+        if constexpr (CHAIN) {
+            // per-graph maxima of the previous item's column block: they anchor the next hop's scales (complete behind the barrier)
+            // (two arrays, alternating by item: this item clears and fills the other one)
+            if (tid < pm_n) ch.PMout[(int64_t)pm_cb * ch.B + pm_gf + tid] = __uint_as_float(reinterpret_cast<const unsigned*>(smem + REGION)[gmax_off + pm_par * 128 + tid]);
+            pm_par ^= 1;
+        }
         // CSR slice + coefficients of the group and the column block's constants -> LDS [REGION, ...) by LDS-DMA, 4 bytes per lane
         // (RAW global values, rebased where they are used; every sub-array padded to whole 64-lane DMA instructions, lanes past
         // the end re-load the last word)
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
             gf = fh.node_graph[ns];
             ngl = fh.node_graph[ns + cnt - 1] - gf + 1;
             my_graph = (tid < cnt ? fh.node_graph[ns + tid] : gf) - gf;
-            if (tid < 128) reinterpret_cast<unsigned*>(smem + REGION)[gmax_off + tid] = 0u;
+            if (tid < 128) reinterpret_cast<unsigned*>(smem + REGION)[gmax_off + pm_par * 128 + tid] = 0u;
         }
         float sab[TM];
         {
@@ -315,17 +318,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
         const float* cst_l = reinterpret_cast<const float*>(rp_l + cst_off);
         const float4* xs4 = reinterpret_cast<const float4*>(xs);
         [[maybe_unused]] const float* rinv_l = reinterpret_cast<const float*>(rp_l + rinv_off);
-        [[maybe_unused]] float* rscl_l = reinterpret_cast<float*>(smem + REGION) + rscl_off;
         [[maybe_unused]] float* gscl_l = reinterpret_cast<float*>(smem + REGION) + gscl_off;
-        [[maybe_unused]] unsigned* gmax_l = reinterpret_cast<unsigned*>(smem + REGION) + gmax_off;
-        // (CHAIN) finished output segments stay in registers until the image is free: [half][row of this thread][quad]
-        [[maybe_unused]] float4 res[2][CHAIN ? ITEMS : 1][2];
-        if constexpr (CHAIN) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int k = 0; k < ITEMS; ++k) res[hh][k][0] = res[hh][k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        [[maybe_unused]] unsigned* gmax_l = reinterpret_cast<unsigned*>(smem + REGION) + gmax_off + pm_par * 128;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half) __syncthreads();                // the first half's image has been read out
@@ -349,30 +343,34 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
             __syncthreads();
             if (half == 0) GVQA_H2_STAMP(2); else GVQA_H2_STAMP(4);
             if constexpr (CHAIN) {
-                // Scale of the output rows, decided BEFORE they exist (they are written as fp16 pieces straight from this epilogue):
-                // one power of two per graph from an upper bound of its output magnitudes --
+                // Scale of the output rows, decided BEFORE they exist (they leave as fp16 pieces straight from this epilogue): one power
+                // of two per graph from an upper bound of its output magnitudes --
                 //   |out| <= max|BN scale| (M (max L1 norm of a weight row + 1) + max|instruction term| + max|bias|) + max|BN shift|,
                 // M = the largest input magnitude in the graph (a convex combination of projected neighbour rows, plus the skip row).
                 // The bound overshoots the true maximum by 2^5 .. 2^10; the two-piece split keeps 2^-22 relative accuracy down to 2^-27
                 // of the scaled maximum and degrades gracefully below, so 2^15 of overshoot is still invisible at the 1e-4 bar.
-                if (half == 0 && chain_out && tid < ngl) {
-                    const int g = gf + tid;
-                    float M = 0.f;
-                    if (ch.PMin) {
-                        for (int q = 0; q < a.ncb; ++q) M = fmaxf(M, ch.PMin[(int64_t)q * ch.B + g]);
-                    } else {                          // first hop: the rows were packed with exact scales, 2^14 / scale bounds a row
-                        const int r0 = max(ch.graph_ptr[g] - ns, 0), r1 = min(ch.graph_ptr[g + 1] - ns, cnt);
-                        for (int r = r0; r < r1; ++r) M = fmaxf(M, rinv_l[r]);
-                        M *= 16384.f;
+                if (half == 0 && chain_out) {
+                    if (tid < ngl) {
+                        const int g = gf + tid;
+                        float M = 0.f;
+                        if (ch.PMin) {
+                            for (int q = 0; q < a.ncb; ++q) M = fmaxf(M, ch.PMin[(int64_t)q * ch.B + g]);
+                        } else {                      // first hop: the rows were packed with exact scales, 2^14 / scale bounds a row
+                            const int r0 = max(ch.graph_ptr[g] - ns, 0), r1 = min(ch.graph_ptr[g + 1] - ns, cnt);
+                            for (int r = r0; r < r1; ++r) M = fmaxf(M, rinv_l[r]);
+                            M *= 16384.f;
+                        }
+                        const float tm = ch.Tmax ? ch.Tmax[g] : 0.f;
+                        const float bound = (ch.bc[1] * (M * (ch.bc[0] + 1.f) + tm + ch.bc[3]) + ch.bc[2]) * 1.001f;
+                        gscl_l[tid] = pow2i(split2h_exponent(bound));
                     }
-                    const float tm = ch.Tmax ? ch.Tmax[g] : 0.f;
-                    const float bound = (ch.bc[1] * (M * (ch.bc[0] + 1.f) + tm + ch.bc[3]) + ch.bc[2]) * 1.001f;
-                    gscl_l[tid] = pow2i(split2h_exponent(bound));
+                    __syncthreads();
+                    // inverse scales of the output slots (every column block of the group writes the same values)
+                    if (tid < 128) ch.a_inv_next[grp * 128 + tid] = tid < cnt ? 1.0f / gscl_l[my_graph] : 1.f;
                 }
-                if (half == 1 && chain_out && tid < 128) rscl_l[tid] = tid < cnt ? gscl_l[my_graph] : 1.f;    // (read by the tail, two barriers on)
             }
             // one output row segment: node `row` of the group, channels [c, c + 8)
-            auto process = [&](int slot, int row, int gq, float4 (&ro)[2]) {
+            auto process = [&](int slot, int row, int gq) {
                 const bool row_on = slot < cnt;
                 const int i = row_on ? row : 0;
                 const int node = ns + i;
@@ -482,6 +480,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
                         tB = tD;
                     }
                 }
+                [[maybe_unused]] float4 rr[2];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
                     const float4 bi = *reinterpret_cast<const float4*>(cst_l + cl + 4 * w);
@@ -504,14 +503,31 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
                         r.z = fmaxf(r.z * sc.z + sh.z, 0.f); r.w = fmaxf(r.w * sc.w + sh.w, 0.f);
                     }
                     const bool live = row_on && c + 4 * w < fh.C;
-                    if (chain_out) ro[w] = live ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (chain_out) rr[w] = live ? r : make_float4(0.f, 0.f, 0.f, 0.f);
                     else if (live) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
                 }
                 if constexpr (CHAIN) {
-                    if (chain_out && row_on) {        // the graph's largest output magnitude (bit patterns of non-negative floats order like integers)
-                        const float m = fmaxf(fmaxf(fmaxf(fabsf(ro[0].x), fabsf(ro[0].y)), fmaxf(fabsf(ro[0].z), fabsf(ro[0].w))),
-                                              fmaxf(fmaxf(fabsf(ro[1].x), fabsf(ro[1].y)), fmaxf(fabsf(ro[1].z), fabsf(ro[1].w))));
-                        atomicMax(&gmax_l[gq - gf], __float_as_uint(m));
+                    if (chain_out && (c >> 4) < a.KB) {       // (channels >= C inside the last k block: the operand's zero padding)
+                        // the segment leaves as its 16 bytes of the next hop's two operand fragments: slot (rows past the group's end
+                        // write their zeros at their own slot), k block c >> 4, lane (slot & 31) + 32 ((c >> 3) & 1)
+                        const int orow_i = row_on ? i : slot;
+                        const float sc = row_on ? gscl_l[gq - gf] : 1.f;
+                        const float vv[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
+                        h2_f16x8 p0, p1;
+                        float m = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xsc = vv[e] * sc;
+                            const _Float16 hi16 = (_Float16)xsc;
+                            p0[e] = hi16;
+                            p1[e] = (_Float16)(xsc - (float)hi16);
+                            m = fmaxf(m, fabsf(vv[e]));
+                        }
+                        uint16_t* dstp = ch.Pnext + ((int64_t)((grp * 4 + (orow_i >> 5)) * a.KB + (c >> 4)) * 2) * 512 + ((orow_i & 31) + 32 * ((c >> 3) & 1)) * 8;
+                        *reinterpret_cast<uint4*>(dstp) = __builtin_bit_cast(uint4, p0);
+                        *reinterpret_cast<uint4*>(dstp + 512) = __builtin_bit_cast(uint4, p1);
+                        // the graph's largest output magnitude (bit patterns of non-negative floats order like integers)
+                        if (row_on) atomicMax(&gmax_l[gq - gf], __float_as_uint(m));
                     }
                 }
             };
@@ -519,81 +535,24 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 const int slot = orow + k * RPP;
-                if (__builtin_amdgcn_readfirstlane(slot - (lane / LPR)) < cnt) process(slot, ord[k], gid[k], res[CHAIN ? half : 0][CHAIN ? k : 0]);
+                if (__builtin_amdgcn_readfirstlane(slot - (lane / LPR)) < cnt) process(slot, ord[k], gid[k]);
+                else if (CHAIN && chain_out && (c >> 4) < a.KB) {       // a wave of padding slots: zero pieces
+                    uint16_t* dstp = ch.Pnext + ((int64_t)((grp * 4 + (slot >> 5)) * a.KB + (c >> 4)) * 2) * 512 + ((slot & 31) + 32 * ((c >> 3) & 1)) * 8;
+                    *reinterpret_cast<uint4*>(dstp) = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(dstp + 512) = make_uint4(0u, 0u, 0u, 0u);
+                }
             }
             if (half == 0) GVQA_H2_STAMP(3); else GVQA_H2_STAMP(5);
         }
-        if constexpr (CHAIN) {
-            if (chain_out) {
-                // ---- tail: the group's 128 x CW output tile goes through LDS once (row-major, TLD floats per row) and leaves as
-                // (1) the next hop's packed operand, whole 1 KiB fragments per wave store; (2) the next hop's attention logits over
-                // this column block's channels, on the f32-input matrix cores; (3) the per-graph maxima that anchor its scales.
-                __syncthreads();                      // the image has been read out
-                float* T = xs;
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int k = 0; k < ITEMS; ++k) {
-                        const int slot = orow + k * RPP;
-                        const int irow = slot < cnt ? ord[k] : slot;
-#pragma unroll
-                        for (int w = 0; w < 2; ++w) *reinterpret_cast<float4*>(T + irow * TLD + hh * HW + oct * 8 + 4 * w) = res[hh][k][w];
-                    }
-                __syncthreads();
-                GVQA_H2_STAMP(7);
-                const int rtile = wave & 3;           // row tile of this wave (eight waves: two waves per row tile)
-                const int trow = rtile * 32 + (lane & 31), hf = lane >> 5;
-                {   // (1) wave w packs row tile w: lane (row, k half) turns 8 consecutive channels into its 16 bytes of the two fragments
-                    const float sc = rscl_l[trow];
-#pragma unroll
-                    for (int kbl = (wave >> 2) * (CW / 16) / (NW / 4); kbl < ((wave >> 2) + 1) * (CW / 16) / (NW / 4); ++kbl) {
-                        const int kbg = cb * (CW / 16) + kbl;
-                        if (kbg >= a.KB) continue;    // (channels >= C of the last column block: zero columns, never read)
-                        const float4 v0 = *reinterpret_cast<const float4*>(T + trow * TLD + kbl * 16 + hf * 8);
-                        const float4 v1 = *reinterpret_cast<const float4*>(T + trow * TLD + kbl * 16 + hf * 8 + 4);
-                        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        h2_f16x8 p0, p1;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float xsc = vv[e] * sc;
-                            const _Float16 hi16 = (_Float16)xsc;
-                            p0[e] = hi16;
-                            p1[e] = (_Float16)(xsc - (float)hi16);
-                        }
-                        uint16_t* dstp = ch.Pnext + ((int64_t)((grp * 4 + rtile) * a.KB + kbg) * 2) * 512 + lane * 8;
-                        *reinterpret_cast<uint4*>(dstp) = __builtin_bit_cast(uint4, p0);
-                        *reinterpret_cast<uint4*>(dstp + 512) = __builtin_bit_cast(uint4, p1);
-                    }
-                    if (lane < 32 && wave < 4) ch.a_inv_next[grp * 128 + trow] = 1.0f / sc;      // (a power of two: exact; every column block writes the same value)
-                }
-                if (wave < 4) {   // (2) D[j][row] = sum_c Vn[j][c] T[row][c]: A operand = the prepared image of the next hop's folded vectors (lane: logit
-                    // j = lane & 31, channel 2 step + (lane >> 5)), B operand = the tile (lane: row = lane & 31, same channel)
-                    f32x16 lacc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-                    const float* vf = ch.VnF + (int64_t)cb * (CW / 8) * 256 + lane * 4;
-#pragma unroll 4
-                    for (int s4 = 0; s4 < CW / 8; ++s4) {
-                        const float4 av = *reinterpret_cast<const float4*>(vf + s4 * 256);
-                        const float* tb = T + trow * TLD + 8 * s4 + hf;
-                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, tb[0], lacc, 0, 0, 0);
-                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, tb[2], lacc, 0, 0, 0);
-                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, tb[4], lacc, 0, 0, 0);
-                        lacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, tb[6], lacc, 0, 0, 0);
-                    }
-                    // lane (row, hf) holds logits j = 8 q + 4 hf + 0..3 of its row in registers 4 q .. 4 q + 3
-                    if (trow < cnt) {
-#pragma unroll
-                        for (int q = 0; q < (2 * H) / 8; ++q)
-                            *reinterpret_cast<float4*>(ch.PL + ((int64_t)cb * ch.N + ns + trow) * (2 * H) + 8 * q + 4 * hf) =
-                                make_float4(lacc[4 * q], lacc[4 * q + 1], lacc[4 * q + 2], lacc[4 * q + 3]);
-                    }
-                }
-                if (tid < ngl) ch.PMout[(int64_t)cb * ch.B + gf + tid] = __uint_as_float(gmax_l[tid]);     // (3)
-            }
+        if constexpr (CHAIN) {                        // (the item's per-graph maxima leave after the barrier that opens the next item)
+            pm_cb = cb; pm_gf = gf; pm_n = chain_out ? ngl : 0;
         }
         GVQA_H2_STAMP(6);
         grp = grp_n; cb = cb_n; ns = ns_n; cnt = cnt_n; e0 = e0_n; ne = ne_n;
+    }
+    if constexpr (CHAIN) {
+        __syncthreads();
+        if (tid < pm_n) ch.PMout[(int64_t)pm_cb * ch.B + pm_gf + tid] = __uint_as_float(reinterpret_cast<const unsigned*>(smem + REGION)[gmax_off + pm_par * 128 + tid]);
     }
 }
 
@@ -626,20 +585,6 @@ int launch_hop2_consts(int H, int C, const float* bias, const float* bn_w, const
     hipLaunchKernelGGL(k_hop2_consts, dim3((unsigned)cdiv(ld, 256)), dim3(256), 0, stream, C, ld, bias, bn_w, bn_b, bn_m, bn_v, eps, out);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
-}
-
-// (CHAIN) MFMA operand image of a hop's folded attention vectors Vn [2H, Dn]: for column block cb and matrix-core step s
-// (channels cb CW + 2 s, + 1), lane l holds Vn[l & 31][cb CW + 2 s + (l >> 5)] (zero for l & 31 >= 2H or channels >= Dn);
-// laid out [cb][s / 4][lane][s % 4] so that a lane fetches four steps with one 16-byte load.
-__global__ __launch_bounds__(256) void k_hop2_vnf(int H, int Dn, int ncb, const float* __restrict__ Vn, float* __restrict__ out) {
-    const int cw = 256 / H;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)ncb * cw * 32) return;
-    const int u = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
-    const int64_t blk = idx >> 8;                     // cb * (cw / 8) + s4
-    const int cb = (int)(blk / (cw / 8)), s4 = (int)(blk % (cw / 8));
-    const int j = lane & 31, c = cb * cw + 2 * (4 * s4 + u) + (lane >> 5);
-    out[idx] = (j < 2 * H && c < Dn) ? Vn[(int64_t)j * Dn + c] : 0.f;
 }
 
 // (CHAIN) the four magnitudes behind the output bound of a hop (see the kernel): largest L1 norm of a node-column weight row,
@@ -688,16 +633,6 @@ __global__ __launch_bounds__(256) void k_rows_absmax(int64_t rows, int C, const 
     if (lane == 0) out[r] = m;
 }
 
-size_t hop2_vnf_floats(int H, int C) { return (size_t)cdiv(C, 256 / H) * (size_t)(256 / H) * 32; }
-
-int launch_hop2_vnf(int H, int Dn, const float* Vn, float* out, hipStream_t stream) {
-    GVQA_REQUIRE(Vn && out && Dn > 0 && (H == 4 || H == 8), GVQA_E_INVALID, "hop2_vnf: bad argument");
-    const int ncb = (int)cdiv(Dn, 256 / H);
-    hipLaunchKernelGGL(k_hop2_vnf, dim3((unsigned)cdiv((int64_t)hop2_vnf_floats(H, Dn), 256)), dim3(256), 0, stream, H, Dn, ncb, Vn, out);
-    GVQA_LAUNCH_CHECK();
-    return GVQA_OK;
-}
-
 int launch_hop2_bound_consts(int H, int C, int Dn, const float* W, int64_t ldw, const float* epc, float* out, hipStream_t stream) {
     GVQA_REQUIRE(W && epc && out, GVQA_E_INVALID, "hop2_bound_consts: null argument");
     hipLaunchKernelGGL(k_hop2_bound_consts, dim3(1), dim3(1024), 0, stream, H * C, Dn, W, ldw, C, epc, hop2_consts_ld(H, C), out);
@@ -735,8 +670,8 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     GVQA_REQUIRE(f.H * f.cw == 256 && f.C % 4 == 0 && (f.H == 1 || f.H == 2 || f.H == 4 || f.H == 8), GVQA_E_UNSUPPORTED,
                  "hop2: needs H in {1,2,4,8} and C %% 4 == 0");
     GVQA_REQUIRE((size_t)f.e_cap <= hop2_lds_edge_capacity(f.H, chain), GVQA_E_UNSUPPORTED, "hop2: row group has too many edges for LDS");
-    GVQA_REQUIRE(!chain || (f.H >= 4 && K == f.C && cd->bc && cd->graph_ptr && (!cd->Pnext || (cd->PL && cd->VnF && cd->PMout))), GVQA_E_INVALID,
-                 "hop2: chained hop needs H >= 4, node_dim == out_channels and its side arrays");
+    GVQA_REQUIRE(!chain || (K == f.C && cd->bc && cd->graph_ptr && (!cd->Pnext || cd->PMout)), GVQA_E_INVALID,
+                 "hop2: chained hop needs node_dim == out_channels and its side arrays");
     if (f.num_groups == 0) return GVQA_OK;
     Hop2Args a;
     memset(&a, 0, sizeof(a));
@@ -750,14 +685,14 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     // tuning knobs, read once per process
     static const int stag = []() { const char* v = getenv("GVQA_HOP2_STAGGER"); return v ? atoi(v) : 0; }();
     static const int nbuf = []() { const char* v = getenv("GVQA_HOP2_NBUF"); return v ? atoi(v) : 3; }();
-    static const int waves = []() { const char* v = getenv("GVQA_HOP2_WAVES"); return v ? atoi(v) : 8; }();
+    static const int waves = []() { const char* v = getenv("GVQA_HOP2_WAVES"); return v ? atoi(v) : 4; }();
     a.stagger = stag;
     a.epc = epc;
     a.epc_ld = hop2_consts_ld(f.H, f.C);
     if (chain) {
         a.ch.Pnext = static_cast<uint16_t*>(cd->Pnext);
         a.ch.a_inv_next = cd->Pnext ? reinterpret_cast<float*>(static_cast<char*>(cd->Pnext) + (size_t)f.num_groups * 4 * a.KB * 2048) : nullptr;
-        a.ch.PL = cd->PL; a.ch.VnF = cd->VnF; a.ch.PMout = cd->PMout; a.ch.PMin = cd->PMin; a.ch.Tmax = cd->Tmax; a.ch.bc = cd->bc;
+        a.ch.PMout = cd->PMout; a.ch.PMin = cd->PMin; a.ch.Tmax = cd->Tmax; a.ch.bc = cd->bc;
         a.ch.graph_ptr = cd->graph_ptr; a.ch.B = cd->B; a.ch.N = cd->N;
     }
 #ifdef GVQA_PROBES
@@ -779,7 +714,12 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     } while (0)
 #define GVQA_H2_LAUNCH(H_, CH_) do { if (waves == 8) GVQA_H2_LAUNCH_W(H_, CH_, 8); else GVQA_H2_LAUNCH_W(H_, CH_, 4); } while (0)
     if (chain) {
-        if (f.H == 4) GVQA_H2_LAUNCH(4, true); else GVQA_H2_LAUNCH_W(8, true, 4);
+        switch (f.H) {
+            case 1: GVQA_H2_LAUNCH(1, true); break;
+            case 2: GVQA_H2_LAUNCH(2, true); break;
+            case 4: GVQA_H2_LAUNCH(4, true); break;
+            default: GVQA_H2_LAUNCH_W(8, true, 4); break;
+        }
     } else {
         switch (f.H) {
             case 1: GVQA_H2_LAUNCH(1, false); break;
