@@ -93,6 +93,8 @@ def live_pmc_traffic():
     import re
     # the fused hop is the EPI = 2 instantiation (template arguments ..., EPI, heads, pieces), demangled or mangled
     def is_fused(n):
+        if "k_hop2" in n and "k_hop2_" not in n:                   # the persistent hop kernel (csrc/hop2.hip)
+            return True
         m = re.search(r"k_linear_split3<([^>]*)>", n)
         if m:
             args = [t.strip() for t in m.group(1).split(",")]
@@ -236,7 +238,7 @@ def main():
 
     if a.pmc_child:                      # counter pass: a few plain steps fused, a few unfused, nothing else
         step = runner(make_shard(0, 1))
-        for fusion in (1, 0):
+        for fusion in (lib.gvqa_get_option(_lib.OPT_HOP_FUSION), 0):
             _lib.set_option(_lib.OPT_HOP_FUSION, fusion)
             for _ in range(2):
                 step()
@@ -320,11 +322,18 @@ def main():
             avg_s = proj_ms / max(proj_n, 1) * 1e-3
             ach = products * flops32 / avg_s / 1e12
             ks2 = pieces == 2 and (-(-D // 16)) % 2 == 0                 # two K steps per stage when the k-block count is even
-            roof = {"bound": "mfma", "kernel": f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
-                                               f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
-                                               "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)",
+            chained = pieces == 2 and prof["pack"][1] < prof["proj"][1]  # the persistent kernel with chained hops: one pack pass per forward
+            kname = (f"gvqa::k_hop2<H={H},NBUF=3,CHAIN,NW=4> (persistent hop kernel, two 4-wave workgroups per CU, 128 x 256 items: two-piece "
+                     "split projection, GAT aggregation + skip/BN/ReLU epilogue out of LDS, output written as the next hop's packed operand; "
+                     "xp never reaches HBM)") if chained else (
+                     f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
+                     f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
+                     "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)")
+            roof = {"bound": "mfma", "kernel": kname,
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
-                    "algorithmic_flops_per_launch": products * flops32, "fp32_equivalent_tflops": flops32 / avg_s / 1e12,
+                    "algorithmic_flops_per_launch": products * flops32,
+                    "frac_8d_flops": flops32 / avg_s / 1e12 / 2500.0,        # SURVEY 8(d)'s folded-projection flops (one product) on the same peak
+                    "fp32_equivalent_tflops": flops32 / avg_s / 1e12,
                     "fp32_equivalent_frac_of_f32_mfma_peak": flops32 / avg_s / 1e12 / 157.3,
                     "algorithmic_bytes_per_launch": 2 * pieces * N * D + 2 * 4 * N * D + 4 * (E * H + E + N + 1),
                     "avg_launch_us": avg_s * 1e6, "launches": proj_n,
@@ -336,7 +345,9 @@ def main():
             "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
             "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "dtype": ("f32 in/out; 2xfp16-split MFMA, fp32 accumulate" if split and pieces == 2 else
+                      "f32 in/out; 3xbf16-split MFMA (exact split), fp32 accumulate" if split else "f32"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: ONE batch of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
                                    "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, device CSR build from COO inside the step "
@@ -346,7 +357,10 @@ def main():
                        "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
                                        "no communication inside the hops, one RCCL all-gather of per-graph rows per step") if strong
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step",
-                       "hop": ("fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"
+                       "hop": (("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "
+                                "segment softmax) -> ONE persistent kernel for projection + aggregation + epilogue that leaves the next hop's "
+                                "packed operand") if fused and split and pieces == 2 and prof["pack"][1] < prof["proj"][1] else
+                               "fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"
                                if fused else "projection GEMM, then the fused message-passing kernel (xp through HBM)"),
                        "projection_arithmetic": arith if split else "f32-input MFMA"},
             "roofline": roof,
@@ -360,7 +374,8 @@ def main():
                 # the same step (a) unfused: split projection + the message-passing kernel, whose HBM roofline the north star
                 # names; (b) fused on the other split arithmetic; (c) on the f32-input MFMA kernels; (d) on the vendor library --
                 # comparison legs, few steps each
-                full = runner(make_shard(0, 1))
+                full_shard = make_shard(0, 1)
+                full = runner(full_shard)
                 gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
                 n_x = max(5, a.steps // 4)
                 _lib.prof_enable(True)
@@ -405,6 +420,16 @@ def main():
                         res["roofline"]["frac_of_matrix_core_floor"] = fl["mfma_only_us"] / res["roofline"]["avg_launch_us"]
                 res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
                                             "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
+                # the same step by projection arithmetic, side by side (all hand-written kernels except the last line)
+                this_key = "split2h (2 x fp16 pieces, 3 products; default)" if pieces == 2 else "split3 (3 x bf16 pieces, exact split, 6 products)"
+                other_key = "split3 (3 x bf16 pieces, exact split, 6 products; 8-wave fused kernel)" if pieces == 2 else "split2h (2 x fp16 pieces, 3 products)"
+                res["by_arithmetic"] = {
+                    this_key: {"edges_per_s": res["value"], "ms_per_step": ms_step},
+                    other_key: {"edges_per_s": Eall / t_o, "ms_per_step": t_o * 1e3},
+                    "f32-input MFMA (bit-for-bit fp32 products; unfused)": {"edges_per_s": Eall / t_f32, "ms_per_step": t_f32 * 1e3},
+                    "rocBLAS sgemm (vendor, opt-in comparison; unfused)": {"edges_per_s": Eall / t_v, "ms_per_step": t_v * 1e3}}
+                if fused and (N, E) == (Nall, Eall):
+                    res["roofline"]["dvfs_probe"] = dvfs_probe(m, full_shard, full, torch, _lib, n_x)
             if not a.no_pmc:
                 pm = live_pmc_traffic()
                 if "fused" in pm and fused:
@@ -437,6 +462,37 @@ def main():
             pass
         sys.stdout.flush()
         print(line, flush=True)
+
+
+def dvfs_probe(model, shard, step, torch, _lib, n):
+    """Is the hop kernel clock / power limited?  The SAME launches (same grid, same instruction stream, same trip counts -- the graph
+    is unchanged) on all-zero node features and weights: nothing toggles in the matrix cores and data paths, the chip holds a higher
+    clock.  A large gap means the kernel's time is set by the power the data draws, not by issue slots: overlapping more work
+    inside it cannot make it faster, only moving fewer bits / issuing fewer operations can."""
+    try:
+        keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        x_keep = shard.x.clone()
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.zero_()
+            shard.x.zero_()
+        for _ in range(3):
+            step()
+        _lib.prof_enable(True); _lib.prof_collect()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        pz = _lib.prof_collect(); _lib.prof_enable(False)
+        with torch.no_grad():
+            model.load_state_dict(keep)
+            shard.x.copy_(x_keep)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        return {"zero_operand_launch_us": pz["proj"][0] / max(pz["proj"][1], 1) * 1e3,
+                "note": "hop kernel on all-zero node features and weights (identical launches): the gap to avg_launch_us is clock, i.e. power"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
 
 
 def mfma_floor(lib, torch, dev, M, Nn, Kd):

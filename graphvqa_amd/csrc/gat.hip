@@ -844,6 +844,7 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
                  "gat_mp: BatchNorm needs weight, bias, running_mean and running_var");
     if (g->num_nodes == 0) return GVQA_OK;
     MpArgs a;
+    memset(&a, 0, sizeof(a));
     a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid;
     a.node_graph = g->node_graph; a.graph_ptr = g->graph_ptr;
     a.xp = d->xp; a.xp_ld = d->xp_ld ? d->xp_ld : (int64_t)H * C;
@@ -941,7 +942,20 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // The hop as the persistent two-workgroups-per-CU kernel of hop2.hip (GVQA_OPT_HOP_FUSION = 2): two-piece operands and the
 // largest row group's CSR slice within that kernel's 16 KiB region; otherwise the 8-wave fused kernel runs.
 static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
-    return get_option(GVQA_OPT_HOP_FUSION) == 2 && hop_fusion_applies(g, d) &&
+    const int mode = get_option(GVQA_OPT_HOP_FUSION);
+    if (mode != 2 && mode != 3) return false;
+    if (mode == 3) {
+        // by shape: the persistent kernel overlaps one item's epilogue with its CU partner's matrix-core loop, which pays from about
+        // six (row group, column block) items per workgroup slot on (config 3: 8); below that the 8-wave kernel's single large
+        // tile per CU is faster (measured: 256 .. 1024-graph shards and the d = 300 batch of config 2, profiles/r03_*)
+        static const int64_t slots = []() {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return (int64_t)2 * n;
+        }();
+        if ((int64_t)g->num_row_groups * cdiv(d->out_channels, 256 / d->heads) < 6 * slots) return false;
+    }
+    return hop_fusion_applies(g, d) &&
            proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
            (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, false);
 }

@@ -270,11 +270,13 @@ enum gvqa_option {
     GVQA_OPT_SPLIT3_MIN_MFLOP = 2, /* products below this many MFLOP stay on the f32-input MFMA kernels (default 1000) */
     GVQA_OPT_SPLIT3_VARIANT = 3,   /* 0 = choose by shape; otherwise an exact k_linear_split3 instantiation (tuning / tests;
                                       < 100: three-piece kernels, >= 100: two-piece kernels) */
-    GVQA_OPT_HOP_FUSION = 4,       /* 1 (default): gat_seq hops run projection + aggregation as ONE kernel when the batch allows it
-                                      (split projection, graphs <= 128 nodes, H in {1,2,4,8}); 2: the same as the persistent
-                                      kernel of csrc/hop2.hip (two 4-wave workgroups per CU: one's aggregation runs under the
-                                      other's matrix-core loop; two-piece operands); 0: projection, then the message-passing
-                                      kernel (xp through HBM) */
+    GVQA_OPT_HOP_FUSION = 4,       /* how a gat_seq hop runs when the batch allows fusion (split projection, graphs <= 128 nodes, H in {1,2,4,8}):
+                                      0: projection GEMM, then the message-passing kernel (xp through HBM);
+                                      1: projection + aggregation + epilogue as ONE 8-wave kernel, one workgroup per CU (csrc/split3.hip);
+                                      2: the same as the persistent kernel of csrc/hop2.hip (two 4-wave workgroups per CU, one's aggregation
+                                         under the other's matrix-core loop; two-piece operands), hops CHAINED: a hop leaves the next hop's
+                                         packed operand, so only the first hop has a pack pass;
+                                      3 (default): 2 when the batch has >= 6 (row group, column block) items per workgroup slot, else 1 */
     GVQA_NUM_OPTIONS = 5
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */

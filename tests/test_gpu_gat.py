@@ -403,8 +403,9 @@ def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
     ref, hs, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
     old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
     old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_SPLIT2H if scheme == "split2h" else _lib.PROJECTION_SPLIT3)
+    old_f0 = _lib.load().gvqa_get_option(_lib.OPT_HOP_FUSION)
     try:
-        assert _lib.load().gvqa_get_option(_lib.OPT_HOP_FUSION) == 1
+        _lib.set_option(_lib.OPT_HOP_FUSION, 1)
         _lib.prof_enable(True); _lib.prof_collect()
         out, alpha, hops = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch,
                                         return_attention_weights=True, return_hops=True)
@@ -425,7 +426,7 @@ def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
     finally:
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
         _lib.set_option(_lib.OPT_PROJECTION, old_p)
-        _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f0)
         _lib.prof_enable(False)
     assert maxabs(out, ref) < TOL and maxabs(hops, torch.stack(hs)) < TOL and maxabs(alpha, torch.stack(alphas)) < 2e-5
     assert maxabs(out, out_u) < 2e-5
