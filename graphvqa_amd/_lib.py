@@ -217,6 +217,10 @@ PROTOTYPES = {
     "gvqa_gat_mp_backward": (C.c_int, [C.POINTER(Graph), C.POINTER(Graph), C.POINTER(GatMpBwdDesc), C.c_void_p]),
     "gvqa_gat_mp_plan": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.POINTER(MpPlan)]),
     "gvqa_hop2_blocks_per_cu": (C.c_int, [C.c_int32]),
+    "gvqa_scene_graph_collate_sizes": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gvqa_scene_graph_collate": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_set_option": (C.c_int, [C.c_int, C.c_int]),
     "gvqa_get_option": (C.c_int, [C.c_int]),
     "gvqa_prof_enable": (C.c_int, [C.c_int]),

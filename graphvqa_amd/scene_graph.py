@@ -11,7 +11,8 @@ edge flagged in `added_sym_edge`.  Multi-edges are kept.
 (object name, then its de-duplicated attributes, `<pad>` after them), one token id per edge (`<self>` for
 the self-loop, the relation name for a relation AND for its added reverse edge -- the encoder flips the sign of the
 latter's embedding through `added_sym_edge`, pipeline_model_gat.py:590).  `collate_scene_graphs` is the
-`Batch.from_data_list` step (:654) and `DeviceSceneGraphs` puts the batch on the GPU together with its CSR handle, built
+`Batch.from_data_list` step (:654) as a Python restatement; `flatten_scene_graphs` + `collate_flat_scene_graphs` are the feed's
+form: one tokenising pass, then the library's native collate (`gvqa_scene_graph_collate`, csrc/collate.hip).  And `DeviceSceneGraphs` puts the batch on the GPU together with its CSR handle, built
 from the loader-side layout (no device read-back).  Pinned on the four debug graphs against the reference's own converter
 (tests/golden/sg_builder_debug4.npz).
 """
@@ -68,6 +69,7 @@ def convert_scene_graph(sg: dict, stoi, pad_token: str = "<pad>", self_token: st
     node_of = {o: i for i, o in enumerate(obj_ids)}
     n, ei, added = scene_graph_topology(sg)
     x = np.full((n, MAX_OBJ_TOKEN_LEN), lookup(pad_token), dtype=np.int64)
+    pairs = _relation_pairs(objects, obj_ids, node_of)          # once per graph
     e_tok = []
     for i, o in enumerate(obj_ids):
         obj = objects[o]
@@ -75,12 +77,9 @@ def convert_scene_graph(sg: dict, stoi, pad_token: str = "<pad>", self_token: st
         for a_idx, attr in enumerate(dict.fromkeys(obj["attributes"])):      # de-duplicated (the reference: set(...), :282)
             x[i, a_idx + 1] = lookup(attr)
         e_tok.append(lookup(self_token))
-        pairs_i = None
         for rel in obj["relations"]:
             e_tok.append(lookup(rel["name"]))
-            if pairs_i is None:
-                pairs_i = _relation_pairs(objects, obj_ids, node_of)
-            if (node_of[rel["object"]], i) not in pairs_i:
+            if (node_of[rel["object"]], i) not in pairs:
                 e_tok.append(lookup(rel["name"]))                             # the added reverse edge re-uses the name (:327)
     e_tok = np.asarray(e_tok, dtype=np.int64).reshape(-1, 1)
     assert e_tok.shape[0] == ei.shape[1]
@@ -107,6 +106,8 @@ class CollatedSceneGraphs:
 
     def host_layout(self):
         from .graph import HostLayout
+        if getattr(self, "_layout", None) is not None:          # the native collate hands the layout over with the batch
+            return HostLayout(*self._layout)
         deg = int(np.bincount(self.edge_index[1]).max()) if self.num_edges else 0
         # in-edges by DESTINATION graph: every edge stays inside its graph, so they equal the per-graph edge counts
         return HostLayout(np.concatenate([[0], np.cumsum(self.nodes_per_graph)]), np.concatenate([[0], np.cumsum(self.edges_per_graph)]), deg)
@@ -126,6 +127,67 @@ def collate_scene_graphs(sgs, stoi, pad_token: str = "<pad>", self_token: str = 
         n_off += x.shape[0]; e_off += ei.shape[1]
     return CollatedSceneGraphs(np.concatenate(xs), np.concatenate(eis, axis=1), np.concatenate(ets), np.concatenate(adds),
                                np.concatenate(batch), np.asarray(npg, np.int64), np.asarray(epg, np.int64))
+
+
+class FlatSceneGraphs:
+    """Pre-tokenised, flattened scene graphs: the input of the native collate (`gvqa_scene_graph_collate`, csrc/collate.hip).
+    This is what a loader caches per image next to the JSON: the string -> id lookups are vocabulary work (out of the path's
+    scope), everything after them -- node order, self-loops, reverse edges, `added_sym_edge`, batching -- is the C function's."""
+
+    def __init__(self, graph_obj_ptr, name_tok, attr_ptr, attr_tok, rel_ptr, rel_dst, rel_tok, pad_tok, self_tok, unk_tok):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        self.graph_obj_ptr, self.attr_ptr, self.rel_ptr, self.rel_dst = i32(graph_obj_ptr), i32(attr_ptr), i32(rel_ptr), i32(rel_dst)
+        self.name_tok, self.attr_tok, self.rel_tok = i64(name_tok), i64(attr_tok), i64(rel_tok)
+        self.pad_tok, self.self_tok, self.unk_tok = int(pad_tok), int(self_tok), int(unk_tok)
+        self.num_graphs = len(self.graph_obj_ptr) - 1
+
+
+def flatten_scene_graphs(sgs, stoi, pad_token: str = "<pad>", self_token: str = "<self>", unk_token: str = "<unk>") -> FlatSceneGraphs:
+    """Tokenise a list of GQA scene-graph dicts into the flat arrays of `FlatSceneGraphs` (one pass over the JSON; object ids
+    sorted as strings like the converter, gqa_dataset_entry.py:231-232; attribute STRINGS de-duplicated in first-occurrence
+    order, :282)."""
+    lookup = stoi.__getitem__ if hasattr(stoi, "default_factory") else (lambda w: stoi.get(w, 0))
+    gptr, name, aptr, atok, rptr, rdst, rtok = [0], [], [0], [], [0], [], []
+    for sg in sgs:
+        objects = sg["objects"]
+        obj_ids = sorted(objects.keys())
+        node_of = {o: i for i, o in enumerate(obj_ids)}
+        for o in obj_ids:
+            obj = objects[o]
+            name.append(lookup(obj["name"]))
+            atok.extend(lookup(a) for a in dict.fromkeys(obj["attributes"]))
+            aptr.append(len(atok))
+            for rel in obj["relations"]:
+                rdst.append(node_of[rel["object"]])
+                rtok.append(lookup(rel["name"]))
+            rptr.append(len(rdst))
+        gptr.append(len(name))
+    return FlatSceneGraphs(gptr, name, aptr, atok, rptr, rdst, rtok, lookup(pad_token), lookup(self_token), lookup(unk_token))
+
+
+def collate_flat_scene_graphs(flat: FlatSceneGraphs) -> CollatedSceneGraphs:
+    """The batch of `collate_scene_graphs`, produced by the library's native collate from flattened scene graphs: two C calls
+    (sizes, fill), no Python loop."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    sizes = np.zeros(3, np.int64)
+    _lib.check(lib.gvqa_scene_graph_collate_sizes(flat.num_graphs, p(flat.graph_obj_ptr), p(flat.rel_ptr), p(flat.rel_dst), p(sizes)))
+    N, E, A = (int(v) for v in sizes)
+    B = flat.num_graphs
+    x = np.empty((N, MAX_OBJ_TOKEN_LEN), np.int64)
+    ei, et = np.empty((2, E), np.int64), np.empty((E, 1), np.int64)
+    added, batch = np.empty(A, np.int64), np.empty(N, np.int64)
+    gptr, eptr = np.empty(B + 1, np.int32), np.empty(B + 1, np.int32)
+    maxdeg = C.c_int32(0)
+    _lib.check(lib.gvqa_scene_graph_collate(B, p(flat.graph_obj_ptr), p(flat.name_tok), p(flat.attr_ptr), p(flat.attr_tok), p(flat.rel_ptr),
+                                            p(flat.rel_dst), p(flat.rel_tok), flat.pad_tok, flat.self_tok, flat.unk_tok, N, E, A, p(x), p(ei),
+                                            p(et), p(added), p(batch), p(gptr), p(eptr), C.byref(maxdeg)))
+    c = CollatedSceneGraphs(x, ei, et, added, batch, np.diff(gptr).astype(np.int64), np.diff(eptr).astype(np.int64))
+    c._layout = (gptr.astype(np.int64), eptr.astype(np.int64), int(maxdeg.value))
+    return c
 
 
 class DeviceSceneGraphs:

@@ -285,6 +285,25 @@ enum gvqa_option {
 int gvqa_set_option(int option, int value);
 int gvqa_get_option(int option);
 
+/* Scene-graph collate on the host (/root/reference gqa_dataset_entry.py:190-372 converter rules + :631-675 / :654
+ * Batch.from_data_list offsets) over PRE-TOKENISED, flattened scene graphs -- the loader's path into the batch without a Python
+ * loop over nodes and edges.  Per batch of B graphs, objects of a graph in the converter's node order (object ids sorted as
+ * strings): graph_obj_ptr[B+1]; name_tok[O]; attr_ptr[O+1] / attr_tok (tokens of the DISTINCT attribute strings, first
+ * occurrence order, at most 11); rel_ptr[O+1] / rel_dst (destination object as a local index inside its graph) / rel_tok.  A graph
+ * without objects becomes the converter's two-node dummy graph (all tokens unk_tok).  Host pointers throughout.
+ *   gvqa_scene_graph_collate_sizes -> sizes[3] = nodes N, edges E (self-loops, relations, added reverse edges), added reverse edges A
+ *   gvqa_scene_graph_collate       -> x_tokens [N,12], edge_index [2,E] (row 0 sources, row 1 destinations), edge_tokens [E],
+ *                                     added_sym_edge [A] (edge ids), batch [N], graph_ptr / edge_ptr [B+1] (the layout
+ *                                     gvqa_graph_finalize_host takes), *max_in_degree.
+ * GVQA_E_GRAPH: a relation points outside its graph; GVQA_E_INVALID: more than 11 attributes (the reference raises IndexError). */
+int gvqa_scene_graph_collate_sizes(int64_t num_graphs, const int32_t* graph_obj_ptr, const int32_t* rel_ptr, const int32_t* rel_dst,
+                                   int64_t* sizes);
+int gvqa_scene_graph_collate(int64_t num_graphs, const int32_t* graph_obj_ptr, const int64_t* name_tok, const int32_t* attr_ptr,
+                             const int64_t* attr_tok, const int32_t* rel_ptr, const int32_t* rel_dst, const int64_t* rel_tok,
+                             int64_t pad_tok, int64_t self_tok, int64_t unk_tok, int64_t N, int64_t E, int64_t A, int64_t* x_tokens,
+                             int64_t* edge_index, int64_t* edge_tokens, int64_t* added_sym_edge, int64_t* batch, int32_t* graph_ptr,
+                             int32_t* edge_ptr, int32_t* max_in_degree);
+
 /* Resident workgroups per CU of the persistent hop kernel (csrc/hop2.hip) as the HIP runtime reports them for head count H
  * in {1,2,4,8}: 2 is what its design needs (80 KiB of LDS, <= 256 VGPRs); < 0 = GVQA_E_*.  Diagnostics / tests. */
 int gvqa_hop2_blocks_per_cu(int32_t H);

@@ -1358,18 +1358,38 @@ def test_host_layout_handle_and_weight_cache_give_identical_results(dev):
 
 
 def test_scene_graph_builder_to_device_feeds_the_path(dev):
-    """SURVEY 8f-3 end to end: scene-graph dicts -> graphvqa_amd.scene_graph.collate_scene_graphs -> DeviceSceneGraphs
-    (token tensors + CSR handle from the loader-side layout, no read-back) -> encoder -> gat_seq; same result as the
-    explicit, synchronising batch handle, and the handle's statistics equal the read-back ones."""
-    from graphvqa_amd.scene_graph import collate_scene_graphs
+    """SURVEY 8f-3 end to end: scene-graph dicts -> one tokenising pass (flatten_scene_graphs) -> the library's NATIVE collate
+    (gvqa_scene_graph_collate, csrc/collate.hip) -> DeviceSceneGraphs (token tensors + CSR handle from the loader-side layout,
+    no read-back) -> encoder -> gat_seq.  The device tensors are pinned to what the reference's own converter produced
+    (tests/golden/sg_builder_debug4.npz from gqa_dataset_entry.py:190-372): topology, added_sym_edge and edge tokens exactly,
+    node tokens as multisets (the reference iterates a Python set); the result equals the explicit, synchronising batch
+    handle's, whose read-back statistics equal the handle's."""
+    from graphvqa_amd.scene_graph import flatten_scene_graphs, collate_flat_scene_graphs
     from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
     from graphvqa_amd.gat_skip import gat_seq
     from graphvqa_amd.graph import SceneGraphBatch
     meta, g = load_golden("sg_builder_debug4")
     stoi = {w: i for i, w in enumerate(meta["itos"])}
     sgs = [meta["scene_graphs"][k] for k in meta["graphs"]]
-    c = collate_scene_graphs(sgs, stoi)
+    c = collate_flat_scene_graphs(flatten_scene_graphs(sgs, stoi))
     d = c.to(dev)
+    sizes = meta["sizes"]
+    n_off = np.concatenate([[0], np.cumsum([s_[0] for s_ in sizes])])
+    e_off = np.concatenate([[0], np.cumsum([s_[1] for s_ in sizes])])
+    assert (d.num_nodes, d.num_edges) == (int(n_off[-1]), int(e_off[-1]))
+    ei_d, ea_d, x_d = d.edge_index.cpu().numpy(), d.edge_attr.cpu().numpy(), d.x.cpu().numpy()
+    for idx in range(len(sgs)):
+        assert np.array_equal(ei_d[:, e_off[idx]:e_off[idx + 1]], g[f"g{idx}.edge_index"] + n_off[idx])
+        assert np.array_equal(ea_d[e_off[idx]:e_off[idx + 1]], g[f"g{idx}.edge_attr"])
+        assert np.array_equal(x_d[n_off[idx]:n_off[idx + 1], 0], g[f"g{idx}.x"][:, 0])
+        assert np.array_equal(np.sort(x_d[n_off[idx]:n_off[idx + 1]], axis=1), np.sort(g[f"g{idx}.x"], axis=1))
+    assert np.array_equal(d.added_sym_edge.cpu().numpy(), np.concatenate([g[f"g{i}.added_sym_edge"] + e_off[i] for i in range(len(sgs))]))
+    assert np.array_equal(d.batch.cpu().numpy(), np.repeat(np.arange(len(sgs)), [s_[0] for s_ in sizes]))
+    # the device CSR built from these arrays: every COO edge sits in its destination's row, rows in COO order
+    rowptr, csr_src, csr_eid = (getattr(d.graph, k).cpu().numpy() for k in ("rowptr", "csr_src", "csr_eid"))
+    order = np.argsort(ei_d[1], kind="stable")
+    assert np.array_equal(csr_eid, order) and np.array_equal(csr_src, ei_d[0][order])
+    assert np.array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(ei_d[1], minlength=d.num_nodes))]))
     V = len(meta["itos"])
     enc = _load_module(GroundTruth_SceneGraph_Encoder(V, stoi["<pad>"], 300), synth.encoder_params(V, 300, seed=5, pad_idx=stoi["<pad>"]), dev)
     gs = _load_module(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=6), dev)

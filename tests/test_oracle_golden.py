@@ -215,3 +215,35 @@ def test_scene_graph_builder_pinned_to_the_reference_converter():
     assert np.array_equal(c.added_sym_edge, np.concatenate([g[f"g{i}.added_sym_edge"] + e_off[i] for i in range(len(graphs))]))
     hl = c.host_layout()
     assert hl.graph_ptr.tolist() == n_off.tolist() and hl.edge_ptr.tolist() == e_off.tolist()
+
+
+def test_native_collate_pinned_to_the_reference_converter():
+    """The library's host-side collate behind the C ABI (gvqa_scene_graph_collate, csrc/collate.hip; no GPU involved) over the
+    flattened, pre-tokenised scene graphs: the same tensors as the reference's converter + Batch.from_data_list on the four debug
+    graphs and the empty one (tests/golden/sg_builder_debug4.npz), equal to the Python restatement field by field; malformed
+    input is reported, not collated."""
+    import ctypes as C
+    from graphvqa_amd import _lib
+    from graphvqa_amd.scene_graph import collate_scene_graphs, flatten_scene_graphs, collate_flat_scene_graphs
+    meta, g = load_golden("sg_builder_debug4")
+    stoi = {w: i for i, w in enumerate(meta["itos"])}
+    graphs = [meta["scene_graphs"][k] for k in meta["graphs"]]
+    flat = flatten_scene_graphs(graphs, stoi)
+    c, ref = collate_flat_scene_graphs(flat), collate_scene_graphs(graphs, stoi)
+    for k in ("x", "edge_index", "edge_attr", "added_sym_edge", "batch", "nodes_per_graph", "edges_per_graph"):
+        assert np.array_equal(getattr(c, k), getattr(ref, k)), k
+    sizes = meta["sizes"]
+    n_off = np.concatenate([[0], np.cumsum([s[0] for s in sizes])])
+    e_off = np.concatenate([[0], np.cumsum([s[1] for s in sizes])])
+    for idx in range(len(graphs)):
+        assert np.array_equal(c.edge_index[:, e_off[idx]:e_off[idx + 1]], g[f"g{idx}.edge_index"] + n_off[idx])
+        assert np.array_equal(c.edge_attr[e_off[idx]:e_off[idx + 1]], g[f"g{idx}.edge_attr"])
+        assert np.array_equal(np.sort(c.x[n_off[idx]:n_off[idx + 1]], axis=1), np.sort(g[f"g{idx}.x"], axis=1))
+    assert np.array_equal(c.added_sym_edge, np.concatenate([g[f"g{i}.added_sym_edge"] + e_off[i] for i in range(len(graphs))]))
+    hl, hr = c.host_layout(), ref.host_layout()
+    assert hl.graph_ptr.tolist() == n_off.tolist() and hl.edge_ptr.tolist() == e_off.tolist() and hl.max_in_degree == hr.max_in_degree
+    # a relation that points outside its graph
+    bad = flatten_scene_graphs(graphs[:1], stoi)
+    bad.rel_dst[0] = 10 ** 6
+    with pytest.raises(_lib.GvqaError):
+        collate_flat_scene_graphs(bad)
