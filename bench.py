@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU estimate of strong scaling: time rank 0's shard of an N-way split of the batch (no collective)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--floor-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -138,6 +139,8 @@ def live_pmc_traffic():
 
 def main():
     a = parse_args()
+    if a.floor_child:
+        return floor_child()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(a)
 
@@ -495,12 +498,33 @@ def dvfs_probe(model, shard, step, torch, _lib, n):
         return {"error": repr(e)[:200]}
 
 
+PROBES_LIB = os.path.join(ROOT, "graphvqa_amd", "lib", "probes", "libgvqa_hip.so")
+
+
 def mfma_floor(lib, torch, dev, M, Nn, Kd):
-    """What the chip sustains on the fused hop's own MFMA stream, measured now: the same 256 x 256-tile two-piece kernel over the
-    same M x N x K with its fragment reads, DMAs, waits and barriers switched off (GVQA_SPLIT3_LOOP_DEBUG = 112, no C store):
-    nothing but the 3 x 2 M N K flops of v_mfma_f32_32x32x16_f16.  Under that load the clock settles near 1.8 GHz (power), so
-    the floor is 1.4 - 1.7 PF (by operand data and box), not the 2.5 PF of the data sheet's 2.4 GHz."""
+    """What the chip sustains on the hop's own MFMA stream, measured now: the 256 x 256-tile two-piece GEMM over the same
+    M x N x K with its fragment reads, DMAs, waits and barriers switched off, no C store -- nothing but the 3 x 2 M N K flops of
+    v_mfma_f32_32x32x16_f16.  Under that load the clock settles near 1.8 GHz (power), so the floor is 1.4 - 1.7 PF (by operand
+    data and box), not the 2.5 PF of the data sheet's 2.4 GHz.  The switches exist in the MEASUREMENT build of the library only
+    (python -m graphvqa_amd.build --probes): a child process loads it through GVQA_LIB."""
+    if not os.path.exists(PROBES_LIB):
+        return {"error": "measurement build absent (python -m graphvqa_amd.build --probes)"}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--floor-child"], env=dict(os.environ, GVQA_LIB=PROBES_LIB),
+                           capture_output=True, text=True, timeout=180)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": "floor child: " + r.stderr[-200:]}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
+def floor_child():
+    import torch
     from graphvqa_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    M, Nn, Kd = 65536, H * D, D
     st = torch.cuda.current_stream().cuda_stream
     try:
         # operand values as in hops 1 .. K-1 (post-ReLU rows: half zeros) -- the sustained clock depends on the data's switching
@@ -511,27 +535,24 @@ def mfma_floor(lib, torch, dev, M, Nn, Kd):
         Cm = torch.empty(2 * (M // 256) * (Nn // 256) + 16, device=dev)        # the no-store variants leave block clocks here
         _lib.check(lib.gvqa_split2h_pack(M, Kd, A.data_ptr(), Kd, apk.data_ptr(), st))
         _lib.check(lib.gvqa_split2h_pack(Nn, Kd, W.data_ptr(), Kd, wpk.data_ptr(), st))
-        old = _lib.set_option(_lib.OPT_SPLIT3_VARIANT, 113)
+        _lib.set_option(_lib.OPT_SPLIT3_VARIANT, 113)
         out = {}
-        try:
-            for key, dbg in (("mfma_only_us", "112"), ("main_loop_us", "0")):
-                os.environ["GVQA_SPLIT3_LOOP_DEBUG"] = dbg
-                run = lambda: _lib.check(lib.gvqa_linear_split2h(M, Nn, Kd, apk.data_ptr(), wpk.data_ptr(), None, None, 0, None, 0, 0,
-                                                                 Cm.data_ptr(), Nn, st))
-                for _ in range(3): run()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize(); e0.record()
-                for _ in range(10): run()
-                e1.record(); torch.cuda.synchronize()
-                out[key] = e0.elapsed_time(e1) / 10 * 1e3
-        finally:
-            os.environ.pop("GVQA_SPLIT3_LOOP_DEBUG", None)
-            _lib.set_option(_lib.OPT_SPLIT3_VARIANT, old)
+        for key, dbg in (("mfma_only_us", "112"), ("main_loop_us", "0")):
+            os.environ["GVQA_SPLIT3_LOOP_DEBUG"] = dbg
+            run = lambda: _lib.check(lib.gvqa_linear_split2h(M, Nn, Kd, apk.data_ptr(), wpk.data_ptr(), None, None, 0, None, 0, 0,
+                                                             Cm.data_ptr(), Nn, st))
+            for _ in range(3): run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(10): run()
+            e1.record(); torch.cuda.synchronize()
+            out[key] = e0.elapsed_time(e1) / 10 * 1e3
         out["mfma_only_tflops"] = 3 * 2.0 * M * Nn * Kd / (out["mfma_only_us"] * 1e-6) / 1e12
-        out["note"] = "stand-alone kernel, same tile and MFMA stream as the fused hop's main loop; mfma_only = every non-MFMA part of a K step switched off"
-        return out
+        out["note"] = ("stand-alone two-piece GEMM kernel of the measurement build, same MFMA stream as the hop's main loop; "
+                       "mfma_only = every non-MFMA part of a K step switched off")
     except Exception as e:
-        return {"error": repr(e)[:200]}
+        out = {"error": repr(e)[:200]}
+    print(json.dumps(out), flush=True)
 
 
 def projection_accuracy(lib, params, shard, torch, np, dev):

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GVQA_LIB", os.path.join(HERE, "lib", "libgvqa_hip.so"
 GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack", "alpha")
 # gvqa_set_option keys / values (include/gvqa.h)
-OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION = 0, 1, 2, 3, 4
+OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS = 0, 1, 2, 3, 4, 5, 6
 PROJECTION_SPLIT3, PROJECTION_F32, PROJECTION_SPLIT2H = 0, 1, 2
 NUM_STAGES = len(STAGES)
 
@@ -128,7 +128,7 @@ class MpPlan(C.Structure):
 class GatDims(C.Structure):
     _fields_ = [("node_dim", C.c_int32), ("edge_dim", C.c_int32), ("ins_dim", C.c_int32),
                 ("out_channels", C.c_int32), ("heads", C.c_int32), ("num_hops", C.c_int32),
-                ("negative_slope", C.c_float), ("bn_eps", C.c_float)]
+                ("negative_slope", C.c_float), ("bn_eps", C.c_float), ("projection", C.c_int32), ("hop_fusion", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/gvqa.h declares

@@ -33,6 +33,8 @@ static void options_init() {
     g_opt[GVQA_OPT_SPLIT3_MIN_MFLOP] = env_int("GVQA_SPLIT3_MIN_MFLOP", 1000);
     g_opt[GVQA_OPT_SPLIT3_VARIANT] = env_int("GVQA_SPLIT3_VARIANT", 0);
     g_opt[GVQA_OPT_HOP_FUSION] = env_int("GVQA_HOP_FUSION", 3);
+    g_opt[GVQA_OPT_COEFF_KERNEL] = 0;
+    g_opt[GVQA_OPT_MP_PARTS] = 0;
 }
 int get_option(int option) {
     std::call_once(g_opt_once, options_init);

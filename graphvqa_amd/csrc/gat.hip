@@ -148,6 +148,13 @@ struct MpArgs {
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// ablation switches of the tiled kernel: measurement build only
+#ifdef GVQA_PROBES
+#define GVQA_MP_DBG(bit_) (a.debug & (bit_))
+#else
+#define GVQA_MP_DBG(bit_) false
+#endif
+
 // node logit a_node[idx] (idx = node * 2H + j), the partial arrays added in part order
 __device__ __forceinline__ float a_node_at(const MpArgs& a, int64_t idx) {
     float v = a.a_node[idx];
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     for (; pf_t < depth && pf_t < T; ++pf_t) { prefetch(pf_j, pf_c0, pf_buf); advance(pf_j, pf_c0, pf_buf); }
 
     // ---- prologue: local CSR, destination-independent logit terms, epilogue constants ----
-    for (int s = tid; s < ((a.debug & 8) ? 0 : ne); s += MP_THREADS) {
+    for (int s = tid; s < (GVQA_MP_DBG(8) ? 0 : ne); s += MP_THREADS) {
         const int src = a.csr_src[e0 + s];
         const int eid = a.csr_eid[e0 + s];
         src_l[s] = src - n0;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         for (int h = 0; h < H; ++h) alpha_s[s * H + h] = (a.a_node ? a.a_node[(int64_t)src * 2 * H + h] : 0.f) + ae[h];
     }
     for (int i = tid; i <= tn; i += MP_THREADS) rowp_l[i] = a.rowptr[n0 + i] - e0;
-    for (int c = tid; c < ((a.debug & 8) ? 0 : C); c += MP_THREADS) {
+    for (int c = tid; c < (GVQA_MP_DBG(8) ? 0 : C); c += MP_THREADS) {
         cst[c] = a.graph_term ? a.graph_term[(int64_t)g * a.t_ld + c] : 0.f;
         cst[C + c] = a.bias ? a.bias[c] : 0.f;
         float sc = 1.f, sh = 0.f;
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
-    for (int it = tid; it < ((a.debug & 2) ? 0 : tn * H); it += MP_THREADS) {
+    for (int it = tid; it < (GVQA_MP_DBG(2) ? 0 : tn * H); it += MP_THREADS) {
         const int i = it / H, h = it - i * H;
         const int lo = rowp_l[i], hi = rowp_l[i + 1];
         float ar = a.a_node ? a.a_node[(int64_t)(n0 + i) * 2 * H + H + h] : 0.f;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         int trips = (it_hi[k] - it_lo[k] + 3) >> 2;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
-        it_trips[k] = (a.debug & 1) ? 0 : __builtin_amdgcn_readfirstlane(trips);
+        it_trips[k] = GVQA_MP_DBG(1) ? 0 : __builtin_amdgcn_readfirstlane(trips);
     }
 
     int cur_j = 0, cur_c0 = r_lo * a.cw, cur_buf = 0;     // cursor of the stage being consumed
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                     }
                     // (holding the rows back and storing them one stage later, behind the next barrier and prefetch, so that the
                     //  vmcnt(0) at the top of the next stage does not wait for them: 201 vs 201 us at config 3 -- no gain)
-                    if (!(a.debug & 4)) *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
+                    if (!GVQA_MP_DBG(4)) *reinterpret_cast<float4*>(a.out + (int64_t)(n0 + i) * a.out_ld + c) = r;
                 }
             }
         }
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256) void k_gat_alpha_groups(MpArgs a, int H, const
 static int launch_alpha(const MpArgs& a, int H, hipStream_t stream, const gvqa_graph* g = nullptr) {
     // row groups planned and the largest group's logits within 64 KiB of LDS: the group kernel
     if (g && g->num_row_groups > 0 && g->row_group_ptr && (size_t)g->max_row_group_edges * H * sizeof(float) <= 64 * 1024 &&
-        !getenv("GVQA_ALPHA_GENERAL")) {
+        get_option(GVQA_OPT_COEFF_KERNEL) == 0) {
         const size_t lds = std::max<size_t>((size_t)g->max_row_group_edges * H * sizeof(float), 16);
         hipLaunchKernelGGL(k_gat_alpha_groups, dim3((unsigned)g->num_row_groups), dim3(256), lds, stream, a, H, g->row_group_ptr);
         GVQA_LAUNCH_CHECK();
@@ -735,9 +742,15 @@ struct TilePlan {
     size_t lds_bytes;
 };
 
+// plan tunables of the stand-alone kernel: environment overrides exist in the measurement build only (scripts/bench_mp_plan.py)
 static size_t env_size(const char* name, size_t dflt) {
+#ifdef GVQA_PROBES
     const char* v = getenv(name);
     return (v && *v) ? (size_t)strtoull(v, nullptr, 10) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, int nbuf) {
@@ -802,7 +815,7 @@ static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
 // block-wave tail costs less than the repeated prologues).  Target two blocks per CU.  GVQA_MP_PARTS overrides.
 static int plan_parts(int64_t B, int C, const TilePlan& p) {
     const int64_t nch = cdiv(C, p.cw);
-    const size_t forced = env_size("GVQA_MP_PARTS", 0);
+    const size_t forced = (size_t)std::max(get_option(GVQA_OPT_MP_PARTS), 0);
     if (forced) return (int)std::min<int64_t>((int64_t)forced, nch);
     return (int)std::max<int64_t>(1, std::min<int64_t>(nch, cdiv(2 * 256, std::max<int64_t>(B, 1))));
 }
@@ -858,7 +871,9 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
     a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_mask = d->alpha_mask; a.alpha_csr = nullptr;
     a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.nparts = 1; a.lpn_log = 0;
+#ifdef GVQA_PROBES
     { const char* dv = getenv("GVQA_MP_DEBUG"); a.debug = dv ? atoi(dv) : 0; }
+#endif
     a.slope = d->negative_slope; a.bn_eps = d->bn_eps;
     const int force = d->force;
     const float* graph_term = d->graph_term;
@@ -915,8 +930,12 @@ int launch_gat_mp_public(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
 //   f32               f32-input MFMA (k_linear_f32*; rocBLAS only when GVQA_OPT_VENDOR_GEMM asks for it)
 // Products too small to fill the chip stay on the f32 kernels (the pack passes would not pay).
 // Returns the pieces per value of the split projection (2 / 3), or 0 for the f32 kernels.
-static int proj_pieces(int64_t M, int64_t N, int64_t K) {
-    const int mode = get_option(GVQA_OPT_PROJECTION);
+// options a call may override in its dims struct (0 = the process-wide value, else value + 1)
+static int opt_projection(const gvqa_gat_dims* d) { return d && d->projection > 0 ? d->projection - 1 : get_option(GVQA_OPT_PROJECTION); }
+static int opt_hop_fusion(const gvqa_gat_dims* d) { return d && d->hop_fusion > 0 ? d->hop_fusion - 1 : get_option(GVQA_OPT_HOP_FUSION); }
+
+static int proj_pieces(const gvqa_gat_dims* d, int64_t M, int64_t N, int64_t K) {
+    const int mode = opt_projection(d);
     if (mode == GVQA_PROJECTION_F32 || N % 4 != 0 ||
         2.0 * (double)M * (double)N * (double)K < 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP))
         return 0;
@@ -934,15 +953,16 @@ static int layout_pieces(int layout) { return layout < 0 ? 0 : (layout & 2) ? 2 
 // graph <= 128 nodes, intra-graph batch), H dividing 256 and the largest row group's edges within the kernel's LDS budget.
 static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int H = d->heads, C = d->out_channels;
-    return get_option(GVQA_OPT_HOP_FUSION) != 0 && proj_pieces(g->num_nodes, (int64_t)H * C, d->node_dim) != 0 &&
+    return opt_hop_fusion(d) != 0 && proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) != 0 &&
            g->num_row_groups > 0 && g->row_group_ptr && (H == 1 || H == 2 || H == 4 || H == 8) && C % 4 == 0 &&
-           (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H);
+           (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H) &&
+           cdiv(g->num_row_groups, 2) <= 65535;                   // (grid.y of the 8-wave kernel: beyond it the unfused kernels run)
 }
 
 // The hop as the persistent two-workgroups-per-CU kernel of hop2.hip (GVQA_OPT_HOP_FUSION = 2): two-piece operands and the
 // largest row group's CSR slice within that kernel's 16 KiB region; otherwise the 8-wave fused kernel runs.
 static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
-    const int mode = get_option(GVQA_OPT_HOP_FUSION);
+    const int mode = opt_hop_fusion(d);
     if (mode != 2 && mode != 3) return false;
     if (mode == 3) {
         // by shape: the persistent kernel overlaps one item's epilogue with its CU partner's matrix-core loop, which pays from about
@@ -956,14 +976,17 @@ static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
         if ((int64_t)g->num_row_groups * cdiv(d->out_channels, 256 / d->heads) < 6 * slots) return false;
     }
     return hop_fusion_applies(g, d) &&
-           proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
+           proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
            (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, false);
 }
 // ... with the hops chained: a hop's output leaves as the next hop's packed operand, partial logits and per-graph maxima, and
 // the pack pass between hops disappears (eval forward without per-hop fp32 outputs; H >= 4)
 static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
-    static const bool off = []() { const char* v = getenv("GVQA_HOP2_CHAIN"); return v && v[0] == '0'; }();     // (A/B switch, read once)
-    return !off && hop2_applies(g, d) && d->node_dim == d->out_channels &&
+#ifdef GVQA_PROBES
+    static const bool off = []() { const char* v = getenv("GVQA_HOP2_CHAIN"); return v && v[0] == '0'; }();     // (A/B switch of the measurement build)
+    if (off) return false;
+#endif
+    return hop2_applies(g, d) && d->node_dim == d->out_channels &&
            (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, true);
 }
 
@@ -1009,7 +1032,7 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     };
     const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
     const bool fused = g && hop_fusion_applies(g, d);
-    const int np = proj_pieces(N, (int64_t)(H * C), d->node_dim);
+    const int np = proj_pieces(d, N, (int64_t)(H * C), d->node_dim);
     const int w_layout = weight_layout_id(np, fused, fused && hop2_applies(g, d));
     L.Vn = take(weight_cache_layout(d, w_layout).total / sizeof(float));     // Vn | Ve | Gw | packed projection weights
     L.Ve = L.Gw = L.Vn;
@@ -1171,7 +1194,7 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
     auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
     const int H = d->heads, C = d->out_channels;
 
-    const WeightCacheLayout WL = weight_cache_layout(d, weight_layout_id(proj_pieces(N, (int64_t)d->heads * d->out_channels, d->node_dim), false));
+    const WeightCacheLayout WL = weight_cache_layout(d, weight_layout_id(proj_pieces(d, N, (int64_t)d->heads * d->out_channels, d->node_dim), false));
     float* Vn1 = reinterpret_cast<float*>(base + L.Vn + WL.Vn);
     float* Ve1 = reinterpret_cast<float*>(base + L.Vn + WL.Ve);
     rc = run_fold(d, p, Vn1, Ve1, nullptr, stream);
@@ -1273,7 +1296,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     SideStream* ss = side_stream();
     hipStream_t aux = ss ? ss->stream : stream;
     if (ss) { rc = side_fork(ss, stream); if (rc) return rc; }
-    const int np = proj_pieces(N, (int64_t)H * C, Dn);
+    const int np = proj_pieces(d, N, (int64_t)H * C, Dn);
     const bool split = np != 0;
     const bool fused = hop_fusion_applies(g, d);
     const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
@@ -1464,7 +1487,7 @@ size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout) {
 int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true)) return -1;
     const bool fused = hop_fusion_applies(g, d);
-    return weight_layout_id(proj_pieces(g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), fused, fused && hop2_applies(g, d));
+    return weight_layout_id(proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), fused, fused && hop2_applies(g, d));
 }
 
 int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,

@@ -682,10 +682,16 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     a.Bpk = static_cast<const uint16_t*>(Bpk);
     a.a_inv = reinterpret_cast<const float*>(static_cast<const char*>(Apk) + (size_t)f.num_groups * 4 * a.KB * 2048);
     a.b_inv = reinterpret_cast<const float*>(static_cast<const char*>(Bpk) + (size_t)a.ncb * 8 * a.KB * 2048);
-    // tuning knobs, read once per process
+    // Shipped form: three ring stages, four waves, no start offset (profiles/r03_hop2_variants.txt: NBUF 2 +5 %; eight waves equal
+    // without chaining and +9 % with it; a start offset between a CU's two workgroups only adds its own length).  The other
+    // instantiations exist in the measurement build, selected by environment variables read once per process.
+#ifdef GVQA_PROBES
     static const int stag = []() { const char* v = getenv("GVQA_HOP2_STAGGER"); return v ? atoi(v) : 0; }();
     static const int nbuf = []() { const char* v = getenv("GVQA_HOP2_NBUF"); return v ? atoi(v) : 3; }();
     static const int waves = []() { const char* v = getenv("GVQA_HOP2_WAVES"); return v ? atoi(v) : 4; }();
+#else
+    constexpr int stag = 0, nbuf = 3, waves = 4;
+#endif
     a.stagger = stag;
     a.epc = epc;
     a.epc_ld = hop2_consts_ld(f.H, f.C);
@@ -707,12 +713,18 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     if (g_hop2_dbg & 16) wgs = std::min(wgs, hop2_cus());
 #endif
     const dim3 grid((unsigned)wgs);
+#ifdef GVQA_PROBES
 #define GVQA_H2_LAUNCH_W(H_, CH_, NW_)                                                                               \
     do {                                                                                                             \
         if (nbuf == 3) hipLaunchKernelGGL((k_hop2<H_, 3, CH_, NW_>), grid, dim3(64 * NW_), 0, stream, a);            \
         else hipLaunchKernelGGL((k_hop2<H_, 2, CH_, NW_>), grid, dim3(64 * NW_), 0, stream, a);                      \
     } while (0)
 #define GVQA_H2_LAUNCH(H_, CH_) do { if (waves == 8) GVQA_H2_LAUNCH_W(H_, CH_, 8); else GVQA_H2_LAUNCH_W(H_, CH_, 4); } while (0)
+#else
+#define GVQA_H2_LAUNCH_W(H_, CH_, NW_) hipLaunchKernelGGL((k_hop2<H_, 3, CH_, 4>), grid, dim3(256), 0, stream, a)
+#define GVQA_H2_LAUNCH(H_, CH_) GVQA_H2_LAUNCH_W(H_, CH_, 4)
+    (void)nbuf; (void)waves;
+#endif
     if (chain) {
         switch (f.H) {
             case 1: GVQA_H2_LAUNCH(1, true); break;
@@ -748,9 +760,9 @@ extern "C" int gvqa_hop2_blocks_per_cu(int32_t H) {
     int n = 0;
     hipError_t e;
     switch (H) {
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<1, 3, false, 8>, 512, 0); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<2, 3, false, 8>, 512, 0); break;
-        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<4, 3, false, 8>, 512, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<1, 3, false, 4>, 256, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<2, 3, false, 4>, 256, 0); break;
+        case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<4, 3, false, 4>, 256, 0); break;
         case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gvqa::k_hop2<8, 3, false, 4>, 256, 0); break;
         default: return GVQA_E_INVALID;
     }

@@ -41,6 +41,13 @@
 
 namespace gvqa {
 
+// ablation switches of the fused epilogue / the main loop exist in the measurement build only (python -m graphvqa_amd.build --probes)
+#ifdef GVQA_PROBES
+#define GVQA_FH_DBG(bit_) (fh.debug & (bit_))
+#else
+#define GVQA_FH_DBG(bit_) false
+#endif
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 template <int NP> struct SplitFrag { typedef bf16x8_t type; };
@@ -265,7 +272,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             }
         }
         // older than every ring DMA: the counted waits of the main loop only get stricter by them, never wrong
-        if (two_regions && g_cnt[0] > 0 && !(fh.debug & 8)) dma_region(0, 144 * 1024);
+        if (two_regions && g_cnt[0] > 0 && !GVQA_FH_DBG(8)) dma_region(0, 144 * 1024);
     }
     // Rows of a group are aggregated in the order fh.row_order gives (most in-edges first: the edge loop's trip count is the
     // largest in-degree among the rows a wave covers, so rows of similar degree belong together).  Slot -> row for this
@@ -415,7 +422,11 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     int buf = 0, pf = NBUF - 1;                        // ring slot of step s / of the step issued in iteration s
     // (measurement aid, STAG == 0 only: `stagger` bits 16 / 32 / 64 = no fragment reads after step 0 / no DMA in the loop /
     //  no waits and barriers -- wrong results; scripts/bench_split3_loop.py prices the parts of a K step with them)
+#ifdef GVQA_PROBES
     const int dbg = STAG == 0 ? stagger : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     static_assert(NBUF <= 4, "the counted waits below know at most two steps in flight behind the current one");
     frag_t af[TM][NP], bfr[TN][NP];
     for (int s = 0; s < KB; ++s) {
@@ -484,7 +495,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         // attention coefficients are brought in beside it, then all 512 threads do
         //     out[i, c] = (1/H) sum_h sum_{e: dst = i} alpha[e, h] xs[src_e][h cw + c]  (+ graph term) + bias + skip -> BN -> ReLU
         // and store `out`.  xp never reaches HBM.
-        if (fh.debug & 8) return;
+        if (GVQA_FH_DBG(8)) return;
         float* xs = reinterpret_cast<float*>(smem);
         const float inv_h = 1.0f / Hh;
         const bool relu = fh.bn_w != nullptr;
@@ -513,7 +524,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     gid[k] = fh.graph_term ? fh.node_graph[node] : 0;
                 }
             }
-            if (live && wr == gi && !(fh.debug & 1)) {
+            if (live && wr == gi && !GVQA_FH_DBG(1)) {
                 const int m = lane & 31, hh = lane >> 5;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -539,7 +550,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 auto process = [&](int slot, int row, bool have, int gq_pre) {
                     const bool row_on = slot < cnt;
                     const int i = row_on ? row : 0;
-                    const int lo = rp_l[i] - e0, hi = (row_on && !(fh.debug & 2)) ? rp_l[i + 1] - e0 : lo;
+                    const int lo = rp_l[i] - e0, hi = (row_on && !GVQA_FH_DBG(2)) ? rp_l[i + 1] - e0 : lo;
                     const int node = ns + i;
                     float4 pb[CV];
 #pragma unroll
@@ -562,7 +573,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     int maxdeg = hi - lo;
 #pragma unroll
                     for (int o = 32; o >= (1 << lqv); o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o, 64));
-                    const int trips = (fh.debug & 2) ? 0 : __builtin_amdgcn_readfirstlane((maxdeg + EB - 1) / EB);
+                    const int trips = GVQA_FH_DBG(2) ? 0 : __builtin_amdgcn_readfirstlane((maxdeg + EB - 1) / EB);
                     float4 a4[CV], b4[CV];                     // two chains per quad: consecutive FMAs do not wait for each other
 #pragma unroll
                     for (int v = 0; v < CV; ++v) a4[v] = b4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -623,7 +634,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                             r.x = fmaxf(r.x * sc[w].x + sh[w].x, 0.f); r.y = fmaxf(r.y * sc[w].y + sh[w].y, 0.f);
                             r.z = fmaxf(r.z * sc[w].z + sh[w].z, 0.f); r.w = fmaxf(r.w * sc[w].w + sh[w].w, 0.f);
                         }
-                        if (row_on && c_ok[w] && !(fh.debug & 4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
+                        if (row_on && c_ok[w] && !GVQA_FH_DBG(4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
                     }
                 };
                 // (whole waves enter `process`: its trip count is a wave-wide maximum; rows past the group's end are masked inside)
@@ -1069,10 +1080,14 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     const int64_t bm = variant % 100 < 20 ? 256 : 128;
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, cdiv(M, 32), KB) : nullptr;
     const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
+#ifdef GVQA_PROBES
     const char* ssv = getenv("GVQA_SPLIT3_STAGGER");      // quarter units of the default start offset (tuning aid)
     const int stag_scale = ssv ? atoi(ssv) : 0;
     const char* ldv = getenv("GVQA_SPLIT3_LOOP_DEBUG");   // measurement aid: see the main loop
     const int loop_dbg = ldv ? atoi(ldv) : 0;
+#else
+    constexpr int stag_scale = 0, loop_dbg = 0;
+#endif
     const int64_t rows_per_launch = 65535 * bm;        // grid.y limit: row chunks (rows are independent)
     for (int64_t m0 = 0; m0 < M; m0 += rows_per_launch) {
         const int64_t m = std::min(rows_per_launch, M - m0);
@@ -1098,11 +1113,15 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
         switch (variant) {
             case 10: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, false, false, false, 0, 0); break;
             case 11: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, true, false, false, 0, 0); break;
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 13: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, true, false, true, 0, 0); break;
+#endif
             case 20: GVQA_S3_LAUNCH(2, 2, 2, 2, 3, false, false, false, 0, 0); break;
             case 21: GVQA_S3_LAUNCH(2, 2, 2, 2, 3, true, false, false, 0, 0); break;
             case 22: GVQA_S3_LAUNCH(2, 2, 2, 2, 2, true, false, false, 0, 0); break;
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 23: GVQA_S3_LAUNCH(2, 2, 2, 2, 3, true, false, true, 0, 0); break;
+#endif
             case 26: GVQA_S3_LAUNCH(2, 2, 2, 2, 3, true, false, false, 2, 0); break;
             case 27: GVQA_S3_LAUNCH(2, 2, 2, 2, 2, true, false, false, 3, 0); break;
             case 14: GVQA_S3_LAUNCH(2, 4, 4, 2, 3, true, false, false, 0, 1); break;
@@ -1111,19 +1130,37 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
             case 30: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, false, 0, 0); break;
             case 34: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, false, 0, 1); break;
             case 31: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, false, 2, 0); break;
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 33: GVQA_S3_LAUNCH(2, 2, 2, 4, 2, true, false, true, 0, 0); break;
+#endif
             // two fp16 pieces: a K step is 2 KiB per tile, so the rings are one step deeper in the same LDS
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 113: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2); break;
+#endif
             case 114: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2); break;
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 115: GVQA_SN_LAUNCH(2, 4, 4, 2, 3, true, false, true, 0, 0, 2); break;
+#endif
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 117: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, true, 0, 0, 2, 1); break;
+#endif
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 119: GVQA_SP_LAUNCH(2, 2, 4, 4, 4, true, false, true, 0, 0, 2, 0); break;     // four waves of 128 x 128 (256 AGPRs)
+#endif
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 111: if (KB & 1) return GVQA_E_UNSUPPORTED; GVQA_SK_LAUNCH(2, 4, 4, 2, 2, true, false, true, 0, 0, 2, 0, 2); break;   // two K steps per barrier
+#endif
             case 112: if (KB & 1) return GVQA_E_UNSUPPORTED; GVQA_SK_LAUNCH(2, 4, 4, 2, 2, true, false, false, 0, 1, 2, 0, 2); break;
             case 118: GVQA_SP_LAUNCH(2, 4, 4, 2, 4, true, false, false, 0, 1, 2, 1); break;
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 116: GVQA_SN_LAUNCH(2, 4, 4, 2, 4, false, false, true, 0, 0, 2); break;
+#endif
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 123: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, true, 0, 0, 2); break;
+#endif
+#ifdef GVQA_PROBES      /* main-loop-only measurement variant: leaves C unwritten */
             case 133: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, true, 0, 0, 2); break;
+#endif
             case 134: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, false, 0, 1, 2); break;
             default: return GVQA_E_INVALID;
         }
@@ -1341,10 +1378,15 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
     GVQA_REQUIRE(cdiv(f.num_groups, 2) <= 65535, GVQA_E_UNSUPPORTED, "hop_fused: too many row groups for one launch");
     dim3 grid((unsigned)ncb, (unsigned)cdiv(f.num_groups, 2));
     FusedHopArgs f2 = f;
-    if (const char* dbg = getenv("GVQA_FUSED_DEBUG")) f2.debug = atoi(dbg);
+    f2.debug = 0;
     {
+#ifdef GVQA_PROBES
+        if (const char* dbg = getenv("GVQA_FUSED_DEBUG")) f2.debug = atoi(dbg);
         const char* xv = getenv("GVQA_FUSED_XCD");
-        const int want = xv ? atoi(xv) : 4;                   // measured at config 3: 458 (plain order) / 452 / 449 / 447 us for 1 / 2 / 4 / 8
+        const int want = xv ? atoi(xv) : 4;
+#else
+        constexpr int want = 4;                               // measured at config 3: 458 (plain order) / 452 / 449 / 447 us for 1 / 2 / 4 / 8
+#endif
         const int rows = (int)cdiv(f.num_groups, 2);
         f2.xcd_cols = (ncb == 8 && (want == 2 || want == 4 || want == 8) && rows % (want) == 0) ? want : 1;
     }
@@ -1363,7 +1405,11 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
             case 4: GVQA_FUSED_LAUNCH(4, 3, 3); break;
             default: GVQA_FUSED_LAUNCH(8, 3, 3); break;
         }
-    } else if ((KB & 1) == 0 && !getenv("GVQA_FUSED_KS1")) {
+    } else if ((KB & 1) == 0
+#ifdef GVQA_PROBES
+               && !getenv("GVQA_FUSED_KS1")
+#endif
+    ) {
         // two fp16 pieces, even number of k blocks: two K steps per 64 KiB stage and per barrier, two stages (59.6 k vs 65.3 k
         // cycles per tile in the main loop, 285 vs 298 us at config 3: part of the saving comes back as a lower clock)
         switch (f.H) {

@@ -504,6 +504,11 @@ class gat_seq(torch.nn.Module):
         self.edge_attr_dim, self.ins_dim, self.heads = edge_attr_dim, ins_dim, gat_heads
         self.negative_slope = gat_negative_slope
         self.last_stats = None
+        # Per-module overrides of the library's process-wide options (None = follow gvqa_set_option / the environment), carried in the
+        # dims struct of every call -- two models with different settings can live in one process:
+        #   projection: "split2h" | "split3" | "f32"      hop_fusion: 0 | 1 | 2 | 3 (include/gvqa.h, GVQA_OPT_HOP_FUSION)
+        self.projection = None
+        self.hop_fusion = None
 
     def reset_parameters(self):
         for conv in self.convs:
@@ -546,6 +551,10 @@ class gat_seq(torch.nn.Module):
         H, Cc = self.heads, self.out_channels
         d = _lib.GatDims(self.in_channels, self.edge_attr_dim, self.ins_dim, Cc, H, K, self.negative_slope,
                          self.bns[0].eps if len(self.bns) else 1e-5)
+        if self.projection is not None:
+            d.projection = 1 + {"split3": _lib.PROJECTION_SPLIT3, "f32": _lib.PROJECTION_F32, "split2h": _lib.PROJECTION_SPLIT2H}[self.projection]
+        if self.hop_fusion is not None:
+            d.hop_fusion = 1 + int(self.hop_fusion)
         hops, keep = self._hop_params()
         dev = x.device
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)

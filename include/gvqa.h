@@ -133,6 +133,10 @@ typedef struct gvqa_gat_dims {
     int32_t num_hops;    /* K                                                                 */
     float negative_slope;
     float bn_eps;
+    /* Per-call overrides of the process-wide options below (two models with different settings can share a process):
+     * 0 = use gvqa_get_option(...); otherwise the option value + 1. */
+    int32_t projection;  /* GVQA_OPT_PROJECTION value + 1, or 0 */
+    int32_t hop_fusion;  /* GVQA_OPT_HOP_FUSION value + 1, or 0 */
 } gvqa_gat_dims;
 
 /* gat.forward(x, edge_index, edge_attr) with concat=False (gat_skip.py:111-177): `x` is the
@@ -277,7 +281,10 @@ enum gvqa_option {
                                          under the other's matrix-core loop; two-piece operands), hops CHAINED: a hop leaves the next hop's
                                          packed operand, so only the first hop has a pack pass;
                                       3 (default): 2 when the batch has >= 6 (row group, column block) items per workgroup slot, else 1 */
-    GVQA_NUM_OPTIONS = 5
+    GVQA_OPT_COEFF_KERNEL = 5,     /* attention coefficients: 0 (default) the row-group kernel when a row-group plan exists, 1 always the
+                                      per-(node, head) kernel (same operations in the same order: bit-identical; tests) */
+    GVQA_OPT_MP_PARTS = 6,         /* stand-alone message-passing kernel: 0 (default) blocks per graph chosen by batch size, n > 0 exactly n */
+    GVQA_NUM_OPTIONS = 7
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */

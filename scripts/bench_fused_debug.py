@@ -1,4 +1,6 @@
 """Ablation of the fused hop kernel's epilogue (GVQA_FUSED_DEBUG bit mask, read per launch) on the config-3 batch."""
+import os as _os
+_os.environ.setdefault("GVQA_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "graphvqa_amd", "lib", "probes", "libgvqa_hip.so"))   # the measurement build (python -m graphvqa_amd.build --probes)
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,7 @@
 """Stand-alone message-passing kernel (unfused hop) under the plan tunables GVQA_MP_NBUF / GVQA_MP_CW / GVQA_MP_LDS / GVQA_MP_PARTS:
 config 3 and config 2, us per launch and fraction of 8 TB/s with SURVEY 8(d)'s bytes."""
+import os as _os
+_os.environ.setdefault("GVQA_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "graphvqa_amd", "lib", "probes", "libgvqa_hip.so"))   # the measurement build (python -m graphvqa_amd.build --probes)
 import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,8 @@
 """Split projections (pack + GEMM; variants < 100: three bf16 pieces, >= 100: two fp16 pieces) vs the f32-MFMA kernel on the
 config-3 / config-2 hop projection shapes.
 Usage: python scripts/bench_split3.py [out.json]   (GVQA_GEMM_BACKEND=rocblas adds the vendor number to the f32 column)"""
+import os as _os
+_os.environ.setdefault("GVQA_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "graphvqa_amd", "lib", "probes", "libgvqa_hip.so"))   # the measurement build (python -m graphvqa_amd.build --probes)
 import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphvqa_amd import _lib

@@ -1,6 +1,8 @@
 """Prices the parts of a K step of k_linear_split3 (VAR=13: three bf16 pieces, 256 x 256 tile, no C store; VAR=113: the same with
 two fp16 pieces) by switching them off: GVQA_SPLIT3_LOOP_DEBUG bits 16 (no fragment reads after step 0), 32 (no DMA in the
 loop), 64 (no waits / barriers)."""
+import os as _os
+_os.environ.setdefault("GVQA_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "graphvqa_amd", "lib", "probes", "libgvqa_hip.so"))   # the measurement build (python -m graphvqa_amd.build --probes)
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphvqa_amd import _lib

@@ -370,14 +370,13 @@ def test_config3_slice_vs_oracle_on_the_benchmarked_kernel(dev, projection_mode)
     g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
     plan = _lib.MpPlan()
     for parts in ("1", None) if not projection_mode.startswith("fused") else (None,):   # one block per graph, then the small-batch split
-        if parts:
-            os.environ["GVQA_MP_PARTS"] = parts
+        old_parts = _lib.set_option(_lib.OPT_MP_PARTS, int(parts) if parts else 0)
         try:
             _lib.check(_lib.load().gvqa_gat_mp_plan(ctypes.byref(g.c), d, 4, ctypes.byref(plan)))
             out, alpha, _ = _run_gat_seq(dev, (d, d, d, 5, 4), p, x, gb.edge_index, ea, ins, gb.batch,
                                          return_attention_weights=True)
         finally:
-            os.environ.pop("GVQA_MP_PARTS", None)
+            _lib.set_option(_lib.OPT_MP_PARTS, old_parts)
         assert plan.tiled == 1 and plan.channel_range == 128 and plan.accumulators == 2 and plan.stages_per_graph == 20
         assert plan.blocks_per_graph == (1 if parts else 4)
         assert (g.c.num_row_groups, g.c.max_row_group_edges) == (16, 512)        # 4 graphs of 32 nodes / 128 edges per row group
@@ -411,12 +410,12 @@ def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
                                         return_attention_weights=True, return_hops=True)
         prof = _lib.prof_collect(); _lib.prof_enable(False)
         assert prof["alpha"][1] == K and prof["mp"][1] == 0            # the fused path ran: no message-passing launches
-        os.environ["GVQA_ALPHA_GENERAL"] = "1"                         # coefficients by the per-(node, head) kernel instead of the
+        _lib.set_option(_lib.OPT_COEFF_KERNEL, 1)                      # coefficients by the per-(node, head) kernel instead of the
         try:                                                           # row-group kernel: same operations, bit-identical
             _, alpha_g, _ = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch,
                                          return_attention_weights=True, return_hops=True)
         finally:
-            os.environ.pop("GVQA_ALPHA_GENERAL", None)
+            _lib.set_option(_lib.OPT_COEFF_KERNEL, 0)
         assert torch.equal(alpha, alpha_g)
         _lib.set_option(_lib.OPT_HOP_FUSION, 0)
         out_u = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
@@ -519,6 +518,47 @@ def test_checkpoint_like_weights_against_fp64_oracle(dev, projection_mode):
     err, err32 = maxabs(out, ref64) / scale, maxabs(ref32, ref64) / scale
     assert err < 1e-4, (projection_mode, err, err32, scale)
     assert err < max(50 * err32, 2e-6), (projection_mode, err, err32, scale)      # the same order as fp32 arithmetic itself
+
+
+def test_two_models_with_different_settings_share_a_process(dev):
+    """Options travel in the dims struct of a call (gat_seq.projection / .hop_fusion), not only in process-wide state: three
+    modules with different projection arithmetics and hop kernels, called alternately, each give the result of the same module
+    alone under the matching process-wide option, and all agree with the oracle."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    C, de, di, K, H = 64, 24, 16, 3, 4
+    gb = synth.make_graph_batch(23, seed=4321, nodes_lo=3, nodes_hi=40, rel_per_node=1.6)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=11)
+    args = [t(a, device=dev) for a in (synth.normal((N, C), 1), gb.edge_index, synth.normal((E, de), 2), synth.normal((K, B, di), 3), gb.batch)]
+    ref = R.gat_seq(*[a.cpu() for a in args], tparams(p), heads=H)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        settings = [("split2h", 2), ("split3", 1), ("f32", 0)]
+        mods = []
+        for proj, fusion in settings:
+            m = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)
+            m.projection, m.hop_fusion = proj, fusion
+            mods.append(m)
+        outs = [None] * 3
+        for rnd in range(2):                              # interleaved calls
+            for i, m in enumerate(mods):
+                o = m(*args)
+                assert outs[i] is None or torch.equal(outs[i], o)
+                outs[i] = o
+        codes = {"split2h": _lib.PROJECTION_SPLIT2H, "split3": _lib.PROJECTION_SPLIT3, "f32": _lib.PROJECTION_F32}
+        for (proj, fusion), o in zip(settings, outs):
+            op, of = _lib.set_option(_lib.OPT_PROJECTION, codes[proj]), _lib.set_option(_lib.OPT_HOP_FUSION, fusion)
+            try:
+                alone = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)(*args)
+            finally:
+                _lib.set_option(_lib.OPT_PROJECTION, op); _lib.set_option(_lib.OPT_HOP_FUSION, of)
+            assert torch.equal(o, alone), (proj, fusion)
+            assert maxabs(o, ref) < TOL
+        assert not torch.equal(outs[0], outs[2])          # (different arithmetics do differ in the last bits)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
 
 
 def test_fused_hop_falls_back_when_a_graph_exceeds_a_row_group(dev):
