@@ -242,13 +242,19 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
 static int plan_row_groups(gvqa_graph* g, const int32_t* hp, const int32_t* he, hipStream_t stream) {
     // PINNED host buffers: the upload is a true asynchronous DMA (from pageable memory the runtime stages the copy on the
     // calling thread -- 50 us of a 256-graph shard's 450 us step)
-    struct Slot { int32_t* v = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    struct Slot { int32_t* v = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; int device = -1; };
     static thread_local Slot ring[4];
     static thread_local int next = 0;
     Slot& sl = ring[next];
     next = (next + 1) & 3;
+    int dev = -1;
+    GVQA_HIP_CHECK(hipGetDevice(&dev));
     if (sl.used) GVQA_HIP_CHECK(hipEventSynchronize(sl.done));
-    if (!sl.done) GVQA_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (sl.done && sl.device != dev) {                // one host thread driving several GPUs: an event belongs to the device it was created on
+        GVQA_HIP_CHECK(hipEventDestroy(sl.done));
+        sl.done = nullptr;
+    }
+    if (!sl.done) { GVQA_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)); sl.device = dev; }
     const int64_t B = g->num_graphs, N = g->num_nodes;
     if (sl.cap < (size_t)B + 2) {
         if (sl.v) GVQA_HIP_CHECK(hipHostFree(sl.v));
@@ -426,6 +432,32 @@ int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const
     g->max_row_group_edges = 0;
     if (N > 0 && B > 0 && mn <= ROW_GROUP && B < (1ll << 24))
         return plan_row_groups(g, graph_ptr_host, graph_edge_ptr_host, static_cast<hipStream_t>(stream_));
+    return GVQA_OK;
+}
+
+// The deferred check behind gvqa_graph_finalize_host: that call reads nothing back, so a wrong loader-side layout (counts by
+// source on a batch with cross-graph edges, stale counts, out-of-range ids) goes unnoticed and the kernels that size their LDS
+// regions from it would work on wrong bounds.  This call synchronises: it reads the validation flags the build left on the device
+// and the per-graph node / in-edge layout the DEVICE derives from the arrays, and compares them with what the handle holds.
+int gvqa_graph_check_valid(const gvqa_graph* g, void* stream_) {
+    using namespace gvqa;
+    GVQA_REQUIRE(g && g->stats_dev && g->finalized, GVQA_E_INVALID, "gvqa_graph_check_valid: graph not built / finalized");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t B = g->num_graphs, N = g->num_nodes;
+    const int64_t mb = N > B ? N : B;
+    if (mb > 0) {
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)cdiv(mb, 256)), dim3(256), 0, stream, N, B, g->rowptr, g->graph_ptr,
+                           const_cast<int32_t*>(g->stats_dev));
+        GVQA_LAUNCH_CHECK();
+    }
+    int32_t st[8];
+    GVQA_HIP_CHECK(hipMemcpyAsync(st, g->stats_dev, sizeof(st), hipMemcpyDeviceToHost, stream));
+    GVQA_HIP_CHECK(hipStreamSynchronize(stream));
+    GVQA_REQUIRE(!st[ST_INVALID], GVQA_E_GRAPH, "graph violates the input contract (edge index out of [0,N), or batch not non-decreasing in [0,B))");
+    GVQA_REQUIRE(!(st[ST_NOT_INTRA] && g->intra_graph), GVQA_E_GRAPH, "graph handle claims an intra-graph batch, but an edge joins two graphs");
+    GVQA_REQUIRE(st[ST_MAX_GNODES] <= g->max_graph_nodes && st[ST_MAX_GEDGES] <= g->max_graph_edges && st[ST_MAX_DEG] <= g->max_in_degree,
+                 GVQA_E_GRAPH, "graph handle's statistics are below the batch's (largest graph %d nodes / %d in-edges, in-degree %d; handle: %d / %d / %d)",
+                 st[ST_MAX_GNODES], st[ST_MAX_GEDGES], st[ST_MAX_DEG], g->max_graph_nodes, g->max_graph_edges, g->max_in_degree);
     return GVQA_OK;
 }
 

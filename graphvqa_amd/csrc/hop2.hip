@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
     if (jx < count) {
         item_of(jx, grp, cb);
         ns = fh.group_ptr[grp]; cnt = fh.group_ptr[grp + 1] - ns;
-        e0 = fh.rowptr[ns]; ne = fh.rowptr[ns + cnt] - e0;
+        e0 = fh.rowptr[ns]; ne = min(fh.rowptr[ns + cnt] - e0, fh.e_cap);     // (e_cap: a wrong loader-side layout must not overrun the region)
     }
     [[maybe_unused]] int item_no = 0;
     [[maybe_unused]] int pm_cb = 0, pm_gf = 0, pm_n = 0, pm_par = 1;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
         if (s + per_x < count) {
             item_of(s + per_x, grp_n, cb_n);
             ns_n = fh.group_ptr[grp_n]; cnt_n = fh.group_ptr[grp_n + 1] - ns_n;
-            e0_n = fh.rowptr[ns_n]; ne_n = fh.rowptr[ns_n + cnt_n] - e0_n;
+            e0_n = fh.rowptr[ns_n]; ne_n = min(fh.rowptr[ns_n + cnt_n] - e0_n, fh.e_cap);
         }
         const int* rp_l = reinterpret_cast<const int*>(smem + REGION);
         const int* src_l = rp_l + src_off;

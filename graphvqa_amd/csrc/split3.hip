@@ -268,7 +268,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 g_ns[gi] = fh.group_ptr[grp];
                 g_cnt[gi] = fh.group_ptr[grp + 1] - g_ns[gi];
                 g_e0[gi] = fh.rowptr[g_ns[gi]];
-                g_ne[gi] = fh.rowptr[g_ns[gi] + g_cnt[gi]] - g_e0[gi];
+                g_ne[gi] = min(fh.rowptr[g_ns[gi] + g_cnt[gi]] - g_e0[gi], fh.e_cap);     // (a wrong loader-side layout must not overrun the region)
             }
         }
         // older than every ring DMA: the counted waits of the main loop only get stricter by them, never wrong

@@ -575,13 +575,41 @@ class gat_seq(torch.nn.Module):
         return out
 
     def _param_list(self):
-        """The module's Parameters and BatchNorm buffers, listed once (walking the module tree costs 50 us per call; Module._apply
-        and load_state_dict keep the Parameter objects, so the list stays valid unless sub-modules are replaced)."""
+        """The module's Parameters and BatchNorm buffers in a fixed order.  Walking the module tree costs 50 us per call, so the walk
+        is done once and records WHERE each tensor lives (the owning module's `_parameters` / `_buffers` dict and key); every call
+        then re-reads those ~10 K slots (a few us) and notices a replaced Parameter or buffer object (`conv.lin_l.weight =
+        nn.Parameter(...)`, `load_state_dict(assign=True)`, weight tying) -- which `id(self.convs)` alone would not."""
         sig = (len(self.convs), len(self.bns), id(self.convs), id(self.bns))
         if getattr(self, "_plist_sig", None) != sig:
-            self._plist = list(self.parameters()) + [b for bn in self.bns for b in (bn.running_mean, bn.running_var)]
-            self._plist_sig = sig
+            slots = []
+            for mod in self.modules():
+                slots += [(mod._parameters, k) for k, v in mod._parameters.items() if v is not None]
+            for bn in self.bns:
+                slots += [(bn._buffers, "running_mean"), (bn._buffers, "running_var")]
+            self._pslots, self._plist_sig = slots, sig
+            self._plist = [d[k] for d, k in slots]
+        else:
+            cur = [d.get(k) for d, k in self._pslots]
+            if any(a is not b for a, b in zip(cur, self._plist)):
+                if any(a is None for a in cur):          # a slot disappeared: walk again
+                    self._plist_sig = None
+                    return self._param_list()
+                self._plist = cur
         return self._plist
+
+    def invalidate_weight_cache(self):
+        """Drop everything derived from the parameters (folded attention vectors, packed projection weights, hop structs).  The
+        cache keys hold each tensor's storage pointer and in-place version counter, which optimizers, `load_state_dict`, `.to()` and
+        ordinary in-place ops bump; edits through `.data` (`p.data.mul_()`, EMA swaps, manual checkpoint loading) do NOT bump the
+        counter -- call this after them."""
+        self._wc_key = self._wc_buf = None
+        self._hops_key = None
+        self._plist_sig = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)              # .to() / .cuda() / .float(): storages may move or be replaced
+        self.invalidate_weight_cache()
+        return out
 
     def _hop_params(self):
         """The K `gvqa_gat_conv_params` structs of the eval forward, rebuilt only when a tensor's storage moved."""

@@ -37,6 +37,8 @@ class HostLayout:
     def from_numpy(cls, edge_index, batch, num_graphs: int):
         """From host copies of the COO batch (edge_index [2, E], batch [N]): two bincounts."""
         import numpy as np
+        if edge_index.shape[1] and not np.array_equal(batch[edge_index[0]], batch[edge_index[1]]):
+            raise ValueError("HostLayout: an edge joins two graphs of the batch (the loader-side layout is for intra-graph batches)")
         nodes = np.bincount(batch, minlength=num_graphs)
         edges = np.bincount(batch[edge_index[1]], minlength=num_graphs) if edge_index.shape[1] else np.zeros(num_graphs, np.int64)
         deg = int(np.bincount(edge_index[1]).max()) if edge_index.shape[1] else 0
@@ -81,6 +83,13 @@ class SceneGraphBatch:
                                                         _stream(dev)))
             else:
                 _lib.check(lib.gvqa_graph_finalize(C.byref(self.c), _stream(dev)))
+
+    def check_valid(self):
+        """Deferred validation of a handle built from a loader-side layout (synchronises): raises GvqaError if the batch violates
+        the input contract, has cross-graph edges, or exceeds the layout's statistics."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gvqa_graph_check_valid(C.byref(self.c), _stream(self.device)))
+        return self
 
     def transposed(self) -> "SceneGraphBatch":
         """CSR by SOURCE of the same batch (flipped edge_index; same COO edge ids): what the backward of the

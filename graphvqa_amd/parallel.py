@@ -48,6 +48,8 @@ class BatchShard:
 
     def __init__(self, edge_index: np.ndarray, batch: np.ndarray, num_graphs: int, x, edge_attr, instr, rank: int,
                  world_size: int, device):
+        if edge_index.shape[1] and not np.array_equal(batch[edge_index[0]], batch[edge_index[1]]):
+            raise ValueError("BatchShard: an edge joins two graphs of the batch; graphs are the unit of sharding")
         nsl, emask, ei, b, (g0, g1) = shard_batch(edge_index, batch, num_graphs, rank, world_size)
         epg = np.bincount(batch[edge_index[0]], minlength=num_graphs)
         bounds = partition_graphs(epg, world_size)

@@ -101,10 +101,15 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             return self._forward_autograd(x_tok, e_tok, ei, added, graph)
         D, V = self.sg_emb_dim, self.sg_vocab_embedding.num_embeddings
-        if getattr(self, "validate_ids", True):
+        # validate_ids: True = every call, "first" (default) = the first 4 calls of this module (a vocabulary / checkpoint mismatch
+        # shows at once; a blocking host read on every eval step would undo the loader path that never synchronises), False = never
+        mode = getattr(self, "validate_ids", "first")
+        seen = getattr(self, "_validated_calls", 0)
+        if mode is True or (mode == "first" and seen < 4):
+            self._validated_calls = seen + 1
             # nn.Embedding / index assignment in the reference raise on ids outside the table (a vocabulary / checkpoint
             # mismatch); the fused kernels would clamp them silently, so the range is checked here (one small reduction
-            # and host read; set `module.validate_ids = False` to skip it on a trusted feed)
+            # and host read)
             bad = ((x_tok < 0) | (x_tok >= V)).any() | ((e_tok < 0) | (e_tok >= V)).any()
             if added is not None and added.numel():
                 bad = bad | ((added < 0) | (added >= E)).any().to(bad.device)

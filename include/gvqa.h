@@ -86,6 +86,12 @@ typedef struct gvqa_graph {
 
 size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
 
+/* Deferred validation of a handle finalized by gvqa_graph_finalize_host (which reads nothing back): synchronises `stream`, reads
+ * the contract flags the build left on the device and the statistics the device derives from the arrays, and returns GVQA_E_GRAPH
+ * when the batch violates the input contract, has cross-graph edges although the handle says intra-graph, or exceeds the
+ * handle's statistics (the kernels size LDS regions from them).  For loaders: call it on the first batches / in debug runs. */
+int gvqa_graph_check_valid(const gvqa_graph* g, void* stream);
+
 /* Enqueue the CSR build.  `ws` (>= gvqa_graph_workspace_bytes, 256-byte aligned) backs every
  * array `out` points to and must stay alive as long as `out` is used. */
 int gvqa_graph_build(int64_t num_nodes, int64_t num_edges, int64_t num_graphs,

@@ -561,6 +561,65 @@ def test_two_models_with_different_settings_share_a_process(dev):
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
 
 
+def test_weight_cache_follows_replaced_parameters_and_explicit_invalidation(dev):
+    """The eval forward caches folded / packed weights keyed by storage pointer and version counter.  A Parameter OBJECT replaced
+    after the first call (assignment, load_state_dict(assign=True)) and a BatchNorm buffer replaced likewise must be noticed;
+    an edit through `.data` does not bump the counter and needs `invalidate_weight_cache()`."""
+    from graphvqa_amd.gat_skip import gat_seq
+    C, de, di, K, H = 64, 24, 16, 3, 4
+    gb = synth.make_graph_batch(9, seed=77, nodes_lo=3, nodes_hi=30, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=21)
+    p2 = synth.gat_seq_params(C, C, de, di, K, H, seed=22)
+    args = [t(a, device=dev) for a in (synth.normal((N, C), 1), gb.edge_index, synth.normal((E, de), 2), synth.normal((K, B, di), 3), gb.batch)]
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)
+    out0 = m(*args)
+
+    def fresh(params):
+        return _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), params, dev)(*args)
+
+    # (1) a replaced Parameter object (the shared lin_l / lin_r weight of hop 1) and a replaced buffer
+    q = dict(p)
+    q["convs.1.lin_l.weight"] = q["convs.1.lin_r.weight"] = p2["convs.1.lin_l.weight"]
+    q["bns.0.running_var"] = p2["bns.0.running_var"]
+    m.convs[1].lin_l.weight = torch.nn.Parameter(t(q["convs.1.lin_l.weight"], device=dev))
+    m.bns[0].running_var = t(q["bns.0.running_var"], device=dev)
+    out1 = m(*args)
+    assert not torch.equal(out0, out1) and torch.equal(out1, fresh(q))
+    # (2) load_state_dict(assign=True) swaps every tensor object
+    m.load_state_dict({k: t(v, device=dev) for k, v in p2.items()}, assign=True)
+    assert torch.equal(m(*args), fresh(p2))
+    # (3) an edit through .data is invisible to the version counter: explicit invalidation
+    m.convs[0].bias.data.add_(0.5)
+    stale = m(*args)
+    m.invalidate_weight_cache()
+    q2 = dict(p2); q2["convs.0.bias"] = p2["convs.0.bias"] + np.float32(0.5)
+    assert torch.equal(m(*args), fresh(q2))
+    del stale
+
+
+def test_deferred_validation_of_a_loader_side_layout(dev):
+    """gvqa_graph_finalize_host reads nothing back; gvqa_graph_check_valid is its deferred check (SceneGraphBatch.check_valid):
+    passes on a batch that matches its layout, reports cross-graph edges and statistics below the batch's."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    gb = synth.make_graph_batch(12, seed=5, nodes_lo=4, nodes_hi=30, rel_per_node=1.5)
+    N, B = gb.num_nodes, gb.num_graphs
+    ei, batch = t(gb.edge_index, device=dev), t(gb.batch, device=dev)
+    hl = HostLayout.from_numpy(gb.edge_index, gb.batch, B)
+    SceneGraphBatch(ei, batch, N, B, host_layout=hl).check_valid()
+    bad = gb.edge_index.copy()
+    bad[0, 3] = N - 1                                   # an edge from the last graph into the first
+    with pytest.raises(ValueError):
+        HostLayout.from_numpy(bad, gb.batch, B)         # the host-side constructor refuses it ...
+    g = SceneGraphBatch(t(bad, device=dev), batch, N, B, host_layout=hl)        # ... a loader that vouches wrongly is caught by the deferred check
+    with pytest.raises(_lib.GvqaError):
+        g.check_valid()
+    low = HostLayout(hl.graph_ptr, hl.edge_ptr, 1)      # a stale in-degree bound
+    with pytest.raises(_lib.GvqaError):
+        SceneGraphBatch(ei, batch, N, B, host_layout=low).check_valid()
+
+
 def test_fused_hop_falls_back_when_a_graph_exceeds_a_row_group(dev):
     from oracle import ref_torch as R
     from graphvqa_amd import _lib
