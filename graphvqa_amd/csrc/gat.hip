@@ -441,7 +441,9 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
                     for (int e = 0; e < 4; ++e) {      // clamped index, zero weight past the end of the row
                         const int idx = max(min(s + e, hi - 1), 0);
                         sl[e] = src_l[idx];
-                        al[e] = (s + e < hi) ? alpha_s[idx * H + j] : 0.f;
+                        // (read unconditionally, then masked by a multiply: written as a select, hipcc predicates the READ -- an exec-mask
+                        //  save / branch / restore per edge, the bulk of this loop's scalar instructions)
+                        al[e] = alpha_s[idx * H + j] * ((s + e < hi) ? 1.f : 0.f);
                     }
                     float4 v[4];
 #pragma unroll

@@ -586,8 +586,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                             // unconditional reads at a clamped (always mapped) slot, selected afterwards: no branch in the loop
                             const bool on = s0 + e < hi;
                             const int idx = max(min(s0 + e, hi - 1), 0);
-                            const int raw = src_l[idx];
-                            se[e] = on ? raw - ns : 0;
+                            // (always a valid slot of the group: its source row is used as it is, with weight zero when the slot is not
+                            //  this row's; a select on `on` here makes hipcc predicate the read and drain the LDS queue behind it)
+                            se[e] = min(max(src_l[idx] - ns, 0), 127);
                             if constexpr (Hh % 4 == 0) {
 #pragma unroll
                                 for (int h4 = 0; h4 < Hh / 4; ++h4) {
