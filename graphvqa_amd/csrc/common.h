@@ -145,6 +145,7 @@ struct Hop2ChainDesc {
     void* Pnext;              // packed output buffer (split_packed_rows_bytes(2, 4 G, C) bytes) or NULL: fp32 rows to FusedHopArgs::out
     float* PMout;             // [ncb][B]
     const float* PMin;        // [ncb][B] or NULL (first hop)
+    const float* gscale;      // NULL or [B]: output scales per graph decided before the launch (launch_alpha_packed), a_inv_next written there
     const float* Tmax;        // [B] or NULL
     const float* bc;          // [4] launch_hop2_bound_consts of this hop
     const int32_t* graph_ptr; // [B + 1] device

@@ -609,10 +609,19 @@ static int launch_alpha(const MpArgs& a, int H, hipStream_t stream, const gvqa_g
 // the fp16 matrix cores against the two-piece image of the folded vectors (the arithmetic of the pack pass's logits), results
 // in LDS -- and then runs the two coefficient phases of k_gat_alpha_groups with LDS logits.  One pass over the packed rows
 // (4 N Dn bytes) replaces the pack pass's read of h, its write of the pieces and the a_node round trip.
+struct ChainScaleArgs {      // what the hop launch that follows needs decided ahead of it (hop2.hip, chained hops); all NULL: nothing to do
+    const float* PMin;       // [ncb][B] per-graph maxima of this hop's INPUT rows over each column block (left by the previous hop)
+    const float* Tmax;       // NULL or [B]: largest |instruction term| of this hop per graph
+    const float* bc;         // [4]: largest weight-row L1 norm | BN scale | BN shift | bias magnitude of this hop
+    float* gscale;           // [B] out: power-of-two scale of the hop's OUTPUT rows, per graph
+    float* a_inv_next;       // [128 G] out: its inverse per output slot
+    int ncb, B;
+};
+
 template <int J>
 __global__ __launch_bounds__(512) void k_gat_alpha_groups_packed(MpArgs a, const int32_t* __restrict__ group_ptr, const uint16_t* __restrict__ Apk,
                                                                  const float* __restrict__ a_inv, int KB, const uint16_t* __restrict__ vn_pk,
-                                                                 const float* __restrict__ vn_inv) {
+                                                                 const float* __restrict__ vn_inv, ChainScaleArgs cs) {
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     typedef float f32x16v __attribute__((ext_vector_type(16)));
     constexpr int H = J / 2;
@@ -624,6 +633,29 @@ __global__ __launch_bounds__(512) void k_gat_alpha_groups_packed(MpArgs a, const
     const int grp = blockIdx.x;
     const int ns = group_ptr[grp], cnt = group_ptr[grp + 1] - ns;
     const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
+    __shared__ float gs_s[128];
+    if (cs.gscale) {
+        // Scale of the rows the hop is about to produce, one power of two per graph from an upper bound of their magnitudes (the hop
+        // writes them as fp16 pieces straight from its epilogue, hop2.hip):
+        //   |out| <= max|BN scale| (M (max L1 norm of a weight row + 1) + max|instruction term| + max|bias|) + max|BN shift|,
+        // M = the largest input magnitude in the graph.  The bound overshoots by 2^5 .. 2^10; the two-piece split keeps 2^-22 relative
+        // accuracy down to 2^-27 of the scaled maximum and degrades gracefully below.
+        const int gf = a.node_graph[ns], ngl = a.node_graph[ns + cnt - 1] - gf + 1;
+        if (tid < ngl) {
+            const int g = gf + tid;
+            float M = 0.f;
+            for (int q = 0; q < cs.ncb; ++q) M = fmaxf(M, cs.PMin[(int64_t)q * cs.B + g]);
+            const float tm = cs.Tmax ? cs.Tmax[g] : 0.f;
+            const float bound = (cs.bc[1] * (M * (cs.bc[0] + 1.f) + tm + cs.bc[3]) + cs.bc[2]) * 1.001f;
+            int ex = 0;
+            if (bound > 0.f && bound <= 3.0e38f) { int e2; frexpf(bound, &e2); ex = max(-114, min(126, 14 - e2)); }
+            const float sc = __uint_as_float((unsigned)(127 + ex) << 23);
+            gs_s[tid] = sc;
+            cs.gscale[g] = sc;
+        }
+        __syncthreads();
+        if (tid < 128) cs.a_inv_next[grp * 128 + tid] = tid < cnt ? 1.0f / gs_s[a.node_graph[ns + tid] - gf] : 1.f;
+    }
     {
         f32x16v lacc;
 #pragma unroll
@@ -689,7 +721,8 @@ __global__ __launch_bounds__(512) void k_gat_alpha_groups_packed(MpArgs a, const
     }
 }
 
-static int launch_alpha_packed(const MpArgs& a, int H, hipStream_t stream, const gvqa_graph* g, const void* Apk, int KB, const void* Vn_packed) {
+static int launch_alpha_packed(const MpArgs& a, int H, hipStream_t stream, const gvqa_graph* g, const void* Apk, int KB, const void* Vn_packed,
+                               const ChainScaleArgs& cs) {
     GVQA_REQUIRE(g && g->num_row_groups > 0 && g->row_group_ptr && Apk && Vn_packed, GVQA_E_INVALID, "alpha_packed: null argument");
     const size_t lds = ((size_t)2 * 128 * 2 * H + (size_t)g->max_row_group_edges * H) * sizeof(float);
     GVQA_REQUIRE(lds <= 64 * 1024, GVQA_E_UNSUPPORTED, "alpha_packed: row group too large");
@@ -698,7 +731,7 @@ static int launch_alpha_packed(const MpArgs& a, int H, hipStream_t stream, const
     const uint16_t* vp = static_cast<const uint16_t*>(Vn_packed);
     const float* v_inv = reinterpret_cast<const float*>(static_cast<const char*>(Vn_packed) + (size_t)KB * 2048);
     const dim3 grid((unsigned)g->num_row_groups), block(512);
-#define GVQA_AP(J_) hipLaunchKernelGGL((k_gat_alpha_groups_packed<J_>), grid, block, lds, stream, a, g->row_group_ptr, ap, a_inv, KB, vp, v_inv)
+#define GVQA_AP(J_) hipLaunchKernelGGL((k_gat_alpha_groups_packed<J_>), grid, block, lds, stream, a, g->row_group_ptr, ap, a_inv, KB, vp, v_inv, cs)
     switch (H) {
         case 1: GVQA_AP(2); break;
         case 2: GVQA_AP(4); break;
@@ -1021,7 +1054,7 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
 }
 
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, total;   // a6b ..: chained hops
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, total;   // a6b ..: chained hops
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
@@ -1056,6 +1089,7 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.a6b = take(chain ? split_packed_rows_bytes(2, (int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float) : 0);
     L.PM = take(2 * ncb * (size_t)B);
     L.Tmax = take(chain ? K * (size_t)B : 0);
+    L.gscale = take(chain ? (size_t)B : 0);
     L.total = off;
     return L;
 }
@@ -1382,7 +1416,17 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             {   // (when the logits ride on the pack pass, it ran above, before the coefficients; chained hops: the coefficient kernel
                 //  computes the logits itself from the packed rows the previous hop left)
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
-                rc = (chain && i > 0) ? launch_alpha_packed(a, H, stream, g, a6, (int)cdiv(Dn, 16), wbase + WL.vn2h + (size_t)i * WL.vn2h_hop)
+                ChainScaleArgs cs;
+                memset(&cs, 0, sizeof(cs));
+                if (chain && i > 0 && i < K - 1) {        // the hop that follows leaves packed rows: their scales are decided here
+                    cs.PMin = P(L.PM) + (size_t)(i & 1) * ncb_chain * B;
+                    cs.Tmax = Di > 0 ? P(L.Tmax) + (size_t)i * B : nullptr;
+                    cs.bc = reinterpret_cast<const float*>(wbase + WL.bc) + 4 * i;
+                    cs.gscale = P(L.gscale);
+                    cs.a_inv_next = reinterpret_cast<float*>(base + ((i & 1) ? L.a6 : L.a6b) + (size_t)g->num_row_groups * 4 * cdiv(Dn, 16) * 2048);
+                    cs.ncb = ncb_chain; cs.B = (int)B;
+                }
+                rc = (chain && i > 0) ? launch_alpha_packed(a, H, stream, g, a6, (int)cdiv(Dn, 16), wbase + WL.vn2h + (size_t)i * WL.vn2h_hop, cs)
                                       : launch_alpha(a, H, stream, g);
                 if (rc) return rc;
             }
@@ -1412,6 +1456,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                         cd.PMout = P(L.PM) + (size_t)((i + 1) & 1) * ncb_chain * B;
                     }
                     cd.PMin = i > 0 ? P(L.PM) + (size_t)(i & 1) * ncb_chain * B : nullptr;
+                    cd.gscale = (i > 0 && i < K - 1) ? P(L.gscale) : nullptr;
                     cd.Tmax = Di > 0 ? P(L.Tmax) + (size_t)i * B : nullptr;
                     cd.bc = reinterpret_cast<const float*>(wbase + WL.bc) + 4 * i;
                     cd.graph_ptr = g->graph_ptr; cd.B = (int)B; cd.N = (int)N;

@@ -39,6 +39,8 @@ typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
 struct Hop2Chain {
     uint16_t* Pnext;          // packed output rows (slot layout of Apk; K = C) or NULL: fp32 rows to f.out (last hop)
     float* a_inv_next;        // [128 G] inverse scales of Pnext's rows
+    const float* gscale;      // NULL, or [B]: the output rows' power-of-two scale per graph, decided ahead of the launch (by the coefficient
+                              // kernel, which runs between the hops anyway: k_gat_alpha_groups_packed) -- then a_inv_next is written there too
     float* PMout;             // [ncb][B]: per graph, largest |output| over each column block's channels
     const float* PMin;        // [ncb][B] of the input rows (the previous hop's PMout) or NULL: bound from the rows' scales (first hop)
     const float* Tmax;        // NULL or [B]: largest |instruction term| of this hop per graph
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
                 // M = the largest input magnitude in the graph (a convex combination of projected neighbour rows, plus the skip row).
                 // The bound overshoots the true maximum by 2^5 .. 2^10; the two-piece split keeps 2^-22 relative accuracy down to 2^-27
                 // of the scaled maximum and degrades gracefully below, so 2^15 of overshoot is still invisible at the 1e-4 bar.
-                if (half == 0 && chain_out) {
+                if (half == 0 && chain_out && !ch.gscale) {       // (first hop only: later hops get their scales from the coefficient kernel)
                     if (tid < ngl) {
                         const int g = gf + tid;
                         float M = 0.f;
@@ -375,6 +377,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
                 const int i = row_on ? row : 0;
                 const int node = ns + i;
                 // the skip row segment and the graph's instruction term: on their way from here, consumed after the edge loop
+                [[maybe_unused]] float gsc_pre = 1.f;
+                if constexpr (CHAIN) { if (chain_out && ch.gscale) gsc_pre = ch.gscale[gq]; }
                 float4 sq[2], pbq[2];
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
                         // the segment leaves as its 16 bytes of the next hop's two operand fragments: slot (rows past the group's end
                         // write their zeros at their own slot), k block c >> 4, lane (slot & 31) + 32 ((c >> 3) & 1)
                         const int orow_i = row_on ? i : slot;
-                        const float sc = row_on ? gscl_l[gq - gf] : 1.f;
+                        const float sc = row_on ? (ch.gscale ? gsc_pre : gscl_l[gq - gf]) : 1.f;
                         const float vv[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
                         h2_f16x8 p0, p1;
                         float m = 0.f;
@@ -698,7 +702,7 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
     if (chain) {
         a.ch.Pnext = static_cast<uint16_t*>(cd->Pnext);
         a.ch.a_inv_next = cd->Pnext ? reinterpret_cast<float*>(static_cast<char*>(cd->Pnext) + (size_t)f.num_groups * 4 * a.KB * 2048) : nullptr;
-        a.ch.PMout = cd->PMout; a.ch.PMin = cd->PMin; a.ch.Tmax = cd->Tmax; a.ch.bc = cd->bc;
+        a.ch.PMout = cd->PMout; a.ch.PMin = cd->PMin; a.ch.Tmax = cd->Tmax; a.ch.bc = cd->bc; a.ch.gscale = cd->gscale;
         a.ch.graph_ptr = cd->graph_ptr; a.ch.B = cd->B; a.ch.N = cd->N;
     }
 #ifdef GVQA_PROBES

@@ -1,18 +1,38 @@
 #!/bin/bash
-# Evidence run on the GPU box (everything lands under gpurun_out/r/): scripts/collect_profiles.sh
-# bench line (live PMC traffic, comparison legs, CPU baseline), rocprofv3 kernel stats of the default path, BASELINE configs,
-# emulated strong-scaling shards, the distributed step with one rank, stand-alone split GEMM variants, SQ counters of the fused hop.
+# Evidence run on the GPU box (everything lands under gpurun_out/r/; copy what is to be judged into profiles/): scripts/collect_profiles.sh
+# bench line (live PMC traffic, comparison legs, DVFS probe, CPU baseline), rocprofv3 kernel stats of the default path, BASELINE
+# configs, emulated strong-scaling shards, the distributed step with one rank, SQ counters of the hop kernel, phase stamps of
+# the persistent hop kernel (measurement build), training step.
 O=gpurun_out/r; mkdir -p $O; export TMPDIR=/tmp
 python bench.py > $O/bench_cfg3_n1.json 2> $O/bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o ks -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-extras > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof.err )
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_cfg3_kernel_stats.csv 2>/dev/null
-python scripts/bench_configs.py > $O/configs.json 2> $O/configs.err
-for n in 2 4 8; do python bench.py --emulate-world $n --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1; done > $O/emulated_shards.jsonl
+python scripts/bench_configs.py 2>/dev/null | tail -1 > $O/configs.json
+for f in 1 2; do for n in 2 4 8; do GVQA_HOP_FUSION=$f python bench.py --emulate-world $n --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1; done; done > $O/emulated_shards.jsonl
+GVQA_BENCH_FORCE_DIST=1 python bench.py --emulate-world 8 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1 > $O/emulated_shard8_rccl_1rank.json
 GVQA_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1 > $O/bench_cfg3_rccl_1rank.json
-python scripts/bench_split3.py $O/split_variants.json > /dev/null 2>&1
-for v in 113 13; do VAR=$v python scripts/bench_split3_loop.py 2>/dev/null | grep variant | tail -6; done > $O/split_loop_parts.jsonl
-python scripts/bench_fused_debug.py 2>/dev/null | grep debug > $O/fused_epilogue_parts.jsonl
-python scripts/bench_pack.py 2>/dev/null | grep copy_us > $O/pack.jsonl
-bash scripts/pmc_fused.sh $O/pmc_fused 0 > $O/pmc_fused.txt 2>&1
-rm -rf $O/prof $O/pmc_fused
+for f in 1 2; do MODES=$f ROUNDS=2 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel; done > $O/hop_kernels_ab.jsonl
+for z in "" 1; do ZERO=$z MODES=1,2 ROUNDS=1 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel | sed -e "s/^{/{\"zero_operands\": \"$z\", /"; done > $O/dvfs_zero_operands.jsonl
+for h in 1 4; do HOP=$h python scripts/probe_hop2.py 2>/dev/null | head -2; done > $O/hop2_phase_stamps.jsonl
+python scripts/probe_hop2_loop.py 2>/dev/null | grep workgroups_per_cu > $O/hop2_loop_parts.jsonl
+python scripts/bench_train.py 2>/dev/null | tail -1 > $O/train_cfg3.json
+# SQ counters of the hop kernels (separate --pmc passes, kernel trace only)
+for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA"; do
+  tag=$(echo $pass | cut -d' ' -f1)
+  ( cd /tmp && MODES=2,0 ROUNDS=1 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/scripts/bench_hop2.py > /dev/null 2>&1 )
+done
+python - > $O/pmc_hop_kernels.txt <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if ("k_hop2<" in n) or "k_gat_mp_tiled" in n or "k_gat_alpha_groups_packed" in n:
+            acc[n[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in acc.items():
+    print(k)
+    for c, vals in sorted(v.items()):
+        print("   %-28s %14.0f  (n=%d)" % (c, sum(vals) / len(vals), len(vals)))
+PY
+rm -rf $O/prof $O/pmc_SQ_*
 ls -la $O

@@ -2,6 +2,8 @@
 python -m graphvqa_amd.build --probes; run with GVQA_LIB=graphvqa_amd/lib/probes/libgvqa_hip.so).  Per workgroup and item:
 start / main loop end / end on the 100 MHz clock.  Prints mean phase lengths and how much of a workgroup's epilogue time
 its CU partner (workgroup +- grid/2) spends in its main loop."""
+import os as _os
+_os.environ.setdefault("GVQA_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "graphvqa_amd", "lib", "probes", "libgvqa_hip.so"))   # the measurement build (python -m graphvqa_amd.build --probes)
 import ctypes, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

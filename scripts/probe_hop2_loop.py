@@ -1,6 +1,8 @@
 """Main loop of the persistent hop kernel alone (measurement build, GVQA_LIB=graphvqa_amd/lib/probes/libgvqa_hip.so): the epilogue is
 switched off and parts of a K step are removed one at a time, with two workgroups per CU and with one.  Wrong results by design.
 Reports the hop kernel's launch time and the mean main-loop time per item from the in-kernel stamps."""
+import os as _os
+_os.environ.setdefault("GVQA_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "graphvqa_amd", "lib", "probes", "libgvqa_hip.so"))   # the measurement build (python -m graphvqa_amd.build --probes)
 import ctypes, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
