@@ -1,0 +1,323 @@
+// Tall-skinny products of the differentiable path (training): the attention logits a = X V with V = the attention
+// vectors folded through the projection weights ([D, J], J = 2H node columns or K*H edge columns; gat_skip.py:134-135,151 under
+// autograd), and the two products of their backward, dV = X^T G and dX = G V^T.  X is [R, D] with R = nodes or edges (64k / 256k
+// rows of 2 KB at config 3): every kernel here streams X (or dX) through HBM exactly once and is bound by that stream; the
+// arithmetic rides on the f32-input matrix cores (v_mfma_f32_32x32x2_f32, J padded to 32 columns) because a VALU form needs a
+// cross-lane reduction (forward) or an LDS operand per FMA (backward) that costs more than the padding.
+//
+//   k_skinny_fwd      Y[R, J]  = X V         one wave per 32-row tile; V^T k-slices from LDS; transposed accumulators (a lane
+//                                             owns 4 consecutive j of one row: one 16-byte store per 8 columns)
+//   k_skinny_dv       P[b][D, J] = X_b^T G_b  one workgroup per chunk of rows, wave w owns every 4th 32-column tile of D; the
+//                                             row dimension is the MFMA's k; partial results per workgroup (no atomics: the
+//                                             sum order is fixed), reduced by k_skinny_dv_reduce
+//   k_skinny_dx       dX[R, D] = addend + G V^T   J FMAs per element out of registers (a thread keeps the V rows of its 4
+//                                             columns for 4 rows); 16-byte stores
+#include "common.h"
+#include "gemm_tile.h"
+#include <algorithm>
+
+namespace gvqa {
+namespace {
+
+constexpr int SK_JP = 32;          // J padded to the MFMA's 32 columns
+constexpr int SK_ROWS_DV = 256;    // rows per workgroup of k_skinny_dv
+
+// Y = X V.  LDS: Vs[D_pad][32] (k-major, J zero-padded to 32) -- at most 64 KiB for D <= 512.
+__global__ __launch_bounds__(256) void k_skinny_fwd(int64_t R, int D, int J, const float* __restrict__ X, int64_t ldx,
+                                                    const float* __restrict__ V, float* __restrict__ Y) {
+    extern __shared__ float Vs[];
+    const int Dp = (D + 31) & ~31;
+    for (int i = threadIdx.x; i < Dp * SK_JP; i += 256) {
+        const int k = i >> 5, j = i & 31;
+        Vs[i] = (k < D && j < J) ? V[(int64_t)k * J + j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int64_t ntiles = (R + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * 32 + r;
+        const bool row_ok = row < R;
+        const float* xr = X + (row_ok ? row : 0) * ldx;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // k chunk of 32: this lane's 16 consecutive k of its row (64 contiguous bytes), half-waves take the two halves
+        float4 a[4], an[4];
+        auto load = [&](int c, float4 (&dst)[4]) {
+            const int k0 = c * 32 + hf * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 4 * q;
+                dst[q] = (row_ok && k < D) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        const int nch = Dp >> 5;
+        load(0, a);
+        for (int c = 0; c < nch; ++c) {
+            if (c + 1 < nch) load(c + 1, an);
+            const float* vs = Vs + (c * 32 + hf * 16) * SK_JP + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // operands swapped: D'[j][row], so a lane ends up with 4 consecutive j of its row per register quad
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 0) * SK_JP], a[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 1) * SK_JP], a[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 2) * SK_JP], a[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 3) * SK_JP], a[q].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = an[q];
+        }
+        if (row_ok) {
+            float* yr = Y + row * J;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j0 = 8 * q + 4 * hf;
+                if ((J & 3) == 0) {
+                    if (j0 < J) *reinterpret_cast<float4*>(yr + j0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (j0 + t < J) yr[j0 + t] = acc[4 * q + t];
+                }
+            }
+        }
+    }
+}
+
+// Partial dV of one chunk of rows: P[blockIdx.x][d][j] = sum over the chunk's rows of X[row][d] G[row][j].
+// MFMA roles: M = d (32 per tile), N = j (32, zero past J), k = rows (2 per instruction: half-waves).
+template <int DT>   // 32-column tiles of D per wave (D <= 128 DT)
+__global__ __launch_bounds__(256) void k_skinny_dv(int64_t R, int D, int J, const float* __restrict__ X, int64_t ldx,
+                                                   const float* __restrict__ G, float* __restrict__ P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * SK_ROWS_DV;
+    const int nrow = (int)((R - row0 < SK_ROWS_DV) ? (R - row0) : SK_ROWS_DV);
+    f32x16 acc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    int dcol[DT];
+    bool dok[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        dcol[t] = (wave + 4 * t) * 32 + r;
+        dok[t] = dcol[t] < D;
+        if (!dok[t]) dcol[t] = 0;
+    }
+    const bool jok = r < J;
+    constexpr int U = 8;     // row pairs in flight
+    for (int s = 0; s < nrow; s += 2 * U) {
+        float xa[U][DT], gb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int lr = s + 2 * u + hf;
+            const bool ok = lr < nrow;
+            const int64_t row = row0 + (ok ? lr : 0);
+            const float m = ok ? 1.f : 0.f;
+            gb[u] = jok ? G[row * J + r] * m : 0.f;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) xa[u][t] = dok[t] ? X[row * ldx + dcol[t]] * m : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][t], gb[u], acc[t], 0, 0, 0);
+    }
+    // C/D map: column (j) = lane & 31, row (d within the tile) = (i & 3) + 8 (i >> 2) + 4 hf
+    float* p = P + (int64_t)blockIdx.x * D * J;
+    if (jok) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int d0 = (wave + 4 * t) * 32 + 4 * hf;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int d = d0 + (i & 3) + 8 * (i >> 2);
+                if (d < D) p[(int64_t)d * J + r] = acc[t][i];
+            }
+        }
+    }
+}
+
+// dV[i] = sum over the partial results, in a fixed order: 16 groups of a 1024-thread workgroup take every 16th partial (8 loads
+// in flight per thread), then the 16 group sums are added in index order.
+__global__ __launch_bounds__(1024) void k_skinny_dv_reduce(int nparts, int DJ, const float* __restrict__ P, float* __restrict__ dV) {
+    __shared__ float part[16][64];
+    const int col = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (i < DJ) {
+        int b = pg;
+        for (; b + 16 * 7 < nparts; b += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += P[(int64_t)(b + 16 * u) * DJ + i];
+        }
+        for (; b < nparts; b += 16) s[0] += P[(int64_t)b * DJ + i];
+    }
+    part[pg][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (pg == 0 && i < DJ) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][col];
+        dV[i] = t;
+    }
+}
+
+// dX[row][d] = (addend ? addend[row][d] : 0) + sum_j G[row][j] V[d][j]; a thread owns 4 consecutive d of 4 rows.
+template <int JJ>
+__global__ __launch_bounds__(256) void k_skinny_dx(int64_t R, int D, const float* __restrict__ G, const float* __restrict__ V,
+                                                   const float* __restrict__ addend, int64_t ld_add, float* __restrict__ dX,
+                                                   int64_t ldx) {
+    const int d4 = D >> 2;                        // D % 4 == 0
+    const int per_row = d4;
+    const int64_t total = ((R + 3) >> 2) * per_row;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int c = (int)(it % per_row) * 4;
+        const int64_t rq = (it / per_row) * 4;
+        float vt[4][JJ];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) vt[t][j] = V[(int64_t)(c + t) * JJ + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = rq + q;
+            if (row >= R) break;
+            float g[JJ];
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) g[j] = G[row * JJ + j];
+            float4 o = addend ? *reinterpret_cast<const float4*>(addend + row * ld_add + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < JJ; ++j) {
+                o.x = fmaf(g[j], vt[0][j], o.x);
+                o.y = fmaf(g[j], vt[1][j], o.y);
+                o.z = fmaf(g[j], vt[2][j], o.z);
+                o.w = fmaf(g[j], vt[3][j], o.w);
+            }
+            *reinterpret_cast<float4*>(dX + row * ldx + c) = o;
+        }
+    }
+}
+
+// any J <= 32: the same, J a run-time value (V and G re-read per element quad; rarely used widths)
+__global__ __launch_bounds__(256) void k_skinny_dx_any(int64_t R, int D, int J, const float* __restrict__ G, const float* __restrict__ V,
+                                                       const float* __restrict__ addend, int64_t ld_add, float* __restrict__ dX,
+                                                       int64_t ldx) {
+    const int per_row = D >> 2;
+    const int64_t total = R * per_row;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int c = (int)(it % per_row) * 4;
+        const int64_t row = it / per_row;
+        float4 o = addend ? *reinterpret_cast<const float4*>(addend + row * ld_add + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < J; ++j) {
+            const float g = G[row * J + j];
+            o.x = fmaf(g, V[(int64_t)(c + 0) * J + j], o.x);
+            o.y = fmaf(g, V[(int64_t)(c + 1) * J + j], o.y);
+            o.z = fmaf(g, V[(int64_t)(c + 2) * J + j], o.z);
+            o.w = fmaf(g, V[(int64_t)(c + 3) * J + j], o.w);
+        }
+        *reinterpret_cast<float4*>(dX + row * ldx + c) = o;
+    }
+}
+
+}  // namespace
+}  // namespace gvqa
+
+using namespace gvqa;
+
+extern "C" {
+
+int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* V, float* Y, void* stream) {
+    GVQA_REQUIRE(R >= 0 && D > 0 && J > 0 && J <= SK_JP, GVQA_E_INVALID, "gvqa_skinny_forward: J must be in [1, %d]", SK_JP);
+    GVQA_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldx >= D && D <= 1024, GVQA_E_INVALID, "gvqa_skinny_forward: D %% 4 == 0, D <= 1024, ldx %% 4 == 0");
+    if (R == 0) return GVQA_OK;
+    GVQA_REQUIRE(X && V && Y, GVQA_E_INVALID, "gvqa_skinny_forward: null pointer");
+    const int Dp = ((int)D + 31) & ~31;
+    const size_t lds = (size_t)Dp * SK_JP * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * SK_JP * 4));
+        attr_set = true;
+    }
+    const int64_t ntiles = cdiv(R, 32);
+    const int grid = (int)std::min<int64_t>(cdiv(ntiles, 4), 2048);
+    hipLaunchKernelGGL(k_skinny_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, R, (int)D, (int)J, X, ldx, V, Y);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+size_t gvqa_skinny_backward_weight_workspace_bytes(int64_t R, int64_t D, int64_t J) {
+    return (size_t)std::max<int64_t>(cdiv(R, SK_ROWS_DV), 1) * (size_t)D * (size_t)J * sizeof(float) + 256;
+}
+
+int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* G, float* dV,
+                                void* ws, size_t ws_bytes, void* stream) {
+    GVQA_REQUIRE(R >= 0 && D > 0 && J > 0 && J <= SK_JP && D <= 1024 && ldx >= D, GVQA_E_INVALID,
+                 "gvqa_skinny_backward_weight: J in [1, %d], D <= 1024", SK_JP);
+    GVQA_REQUIRE(dV, GVQA_E_INVALID, "gvqa_skinny_backward_weight: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        GVQA_HIP_CHECK(hipMemsetAsync(dV, 0, (size_t)D * J * sizeof(float), st));
+        return GVQA_OK;
+    }
+    GVQA_REQUIRE(X && G && ws, GVQA_E_INVALID, "gvqa_skinny_backward_weight: null pointer");
+    GVQA_REQUIRE(ws_bytes >= gvqa_skinny_backward_weight_workspace_bytes(R, D, J), GVQA_E_WORKSPACE,
+                 "gvqa_skinny_backward_weight: workspace too small");
+    const int nparts = (int)cdiv(R, SK_ROWS_DV);
+    float* P = static_cast<float*>(ws);
+    const int dtiles = (int)cdiv(D, 32), DT = (int)cdiv(dtiles, 4);
+#define GVQA_DV(T) hipLaunchKernelGGL(k_skinny_dv<T>, dim3(nparts), dim3(256), 0, st, R, (int)D, (int)J, X, ldx, G, P)
+    switch (DT) {
+        case 1: GVQA_DV(1); break;
+        case 2: GVQA_DV(2); break;
+        case 3: GVQA_DV(3); break;
+        case 4: GVQA_DV(4); break;
+        case 5: GVQA_DV(5); break;
+        case 6: GVQA_DV(6); break;
+        case 7: GVQA_DV(7); break;
+        default: GVQA_DV(8); break;
+    }
+#undef GVQA_DV
+    GVQA_LAUNCH_CHECK();
+    const int DJ = (int)(D * J);
+    hipLaunchKernelGGL(k_skinny_dv_reduce, dim3((unsigned)cdiv(DJ, 64)), dim3(1024), 0, st, nparts, DJ, P, dV);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, const float* V, const float* addend,
+                               int64_t ld_add, float* dX, int64_t ldx, void* stream) {
+    GVQA_REQUIRE(R >= 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldx >= D && J > 0 && J <= SK_JP, GVQA_E_INVALID,
+                 "gvqa_skinny_backward_input: D %% 4 == 0, ldx %% 4 == 0, J in [1, %d]", SK_JP);
+    GVQA_REQUIRE(!addend || (ld_add % 4 == 0 && ld_add >= D), GVQA_E_INVALID, "gvqa_skinny_backward_input: ld_add %% 4 == 0");
+    if (R == 0) return GVQA_OK;
+    GVQA_REQUIRE(G && V && dX, GVQA_E_INVALID, "gvqa_skinny_backward_input: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = cdiv(R, 4) * (D / 4);
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 8192);
+#define GVQA_DX(JJ) hipLaunchKernelGGL(k_skinny_dx<JJ>, dim3(grid), dim3(256), 0, st, R, (int)D, G, V, addend, ld_add, dX, ldx)
+    switch (J) {
+        case 1: GVQA_DX(1); break;
+        case 2: GVQA_DX(2); break;
+        case 4: GVQA_DX(4); break;
+        case 8: GVQA_DX(8); break;
+        case 12: GVQA_DX(12); break;
+        case 16: GVQA_DX(16); break;
+        case 20: GVQA_DX(20); break;
+        case 24: GVQA_DX(24); break;
+        case 32: GVQA_DX(32); break;
+        default:
+            hipLaunchKernelGGL(k_skinny_dx_any, dim3(grid), dim3(256), 0, st, R, (int)D, (int)J, G, V, addend, ld_add, dX, ldx);
+            break;
+    }
+#undef GVQA_DX
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+}  // extern "C"

@@ -108,6 +108,59 @@ class _ProjectionLinear(torch.autograd.Function):
         return gx, gw
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    """y = x V for a tall x [R, D] and a narrow V [D, J] (J <= 32): the attention logits of the differentiable path,
+    (x_i * att).sum(-1) of gat_skip.py:134-135,151 with att folded through the projection weights.  Forward, dV = x^T dy and
+    dx = dy V^T are the library's kernels (csrc/train.hip): each streams x (or dx) through HBM once."""
+
+    @staticmethod
+    def supported(x, V):
+        return (x.is_cuda and x.dtype == torch.float32 and V.dtype == torch.float32 and x.dim() == 2 and V.dim() == 2 and
+                x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and 1 <= V.shape[1] <= 32 and x.stride(1) == 1 and x.stride(0) % 4 == 0)
+
+    @staticmethod
+    def forward(ctx, x, V):
+        lib = _lib.load()
+        V = V.contiguous()
+        R, D = x.shape
+        J = V.shape[1]
+        y = torch.empty((R, J), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.gvqa_skinny_forward(R, D, J, x.data_ptr(), x.stride(0), V.data_ptr(), y.data_ptr(), _stream(x.device)))
+        ctx.save_for_backward(x, V)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, V = ctx.saved_tensors
+        R, D = x.shape
+        J = V.shape[1]
+        gy = gy.contiguous()
+        gx = gV = None
+        with torch.cuda.device(x.device):
+            st = _stream(x.device)
+            if ctx.needs_input_grad[1]:
+                gV = torch.empty_like(V)
+                ws = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(R, D, J), x.device)
+                _lib.check(lib.gvqa_skinny_backward_weight(R, D, J, x.data_ptr(), x.stride(0), gy.data_ptr(), gV.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), st))
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty((R, D), dtype=torch.float32, device=x.device)
+                _lib.check(lib.gvqa_skinny_backward_input(R, D, J, gy.data_ptr(), V.data_ptr(), None, 0, gx.data_ptr(), D, st))
+        return gx, gV
+
+
+def skinny_linear(x: Tensor, V: Tensor) -> Tensor:
+    """x @ V through the library's tall-skinny kernels (column groups of 32 when V is wider); differentiable."""
+    if not _SkinnyLinear.supported(x, V[:, :1]):
+        return x @ V
+    J = V.shape[1]
+    if J <= 32:
+        return _SkinnyLinear.apply(x, V)
+    return torch.cat([_SkinnyLinear.apply(x, V[:, j:j + 32]) for j in range(0, J, 32)], dim=1)
+
+
 class _GatMessagePassing(torch.autograd.Function):
     """out[i] = (1/H) sum_h sum_{e -> i} alpha[e,h] mask[e,h] xp[src_e, h, :],  alpha = softmax over the in-edges
     of leaky_relu(a_node[src,h] + a_node[dst,H+h] + a_edge[e,h])   (gat_skip.py:155,183-208,162-165).
@@ -678,6 +731,10 @@ class gat_seq(torch.nn.Module):
         p = self.dropout if self.training else 0.0
         h = x
         alphas, hops = [], []
+        # edge logits of ALL hops in one pass over edge_attr (and one pass in the backward): the H columns of every hop side by side
+        V_e_all = torch.cat([torch.einsum("hck,hc->kh", c.lin_e.weight[:, :De].reshape(H, Cc, De), c.att_e.view(H, Cc))
+                             for c in self.convs], dim=1)
+        a_edge_all = skinny_linear(edge_attr, V_e_all)
         for i, conv in enumerate(self.convs):
             ins = instr[i]
             W, We = conv.lin_l.weight, conv.lin_e.weight
@@ -689,11 +746,10 @@ class gat_seq(torch.nn.Module):
             # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
             # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
             V_n = torch.cat((torch.einsum("hck,hc->kh", W_h3, att_l), torch.einsum("hck,hc->kh", W_h3, att_r)), dim=1)
-            V_e = torch.einsum("hck,hc->kh", We[:, :De].reshape(H, Cc, De), att_e)
             U_e = torch.einsum("hck,hc->kh", We[:, De:].reshape(H, Cc, We.shape[1] - De), att_e)
             U_n = torch.cat((torch.einsum("hck,hc->kh", W_i3, att_l) + U_e, torch.einsum("hck,hc->kh", W_i3, att_r)), dim=1)
-            a_node = add_graph_rows(h @ V_n, ins @ U_n, graph)
-            a_edge = edge_attr @ V_e
+            a_node = add_graph_rows(skinny_linear(h, V_n), ins @ U_n, graph)
+            a_edge = a_edge_all[:, i * H:(i + 1) * H]
             mask = None
             if alpha_masks is not None:
                 mask = alpha_masks[i]

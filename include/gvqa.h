@@ -270,6 +270,19 @@ int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const 
                         const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                         int64_t ldc, void* stream);
 
+/* Tall-skinny products of the differentiable path (training; csrc/train.hip): the attention logits
+ * (x_i * att).sum(-1) of gat_skip.py:134-135,151 with the attention vectors folded through the projection weights, a = X V,
+ * V [D, J] row-major with J <= 32 (2H node columns, or the H edge columns of all K hops side by side), and the two products
+ * of their autograd: dV = X^T G and dX = addend + G V^T.  X [R, D] (row stride ldx), Y / G [R, J] contiguous.  Each call
+ * streams X (or dX) through HBM once; dV is summed in a fixed order (partial sums per 256 rows in the workspace, no atomics).
+ * D % 4 == 0, D <= 1024. */
+int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* V, float* Y, void* stream);
+size_t gvqa_skinny_backward_weight_workspace_bytes(int64_t R, int64_t D, int64_t J);
+int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* G, float* dV,
+                                void* ws, size_t ws_bytes, void* stream);
+int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, const float* V, const float* addend,
+                               int64_t ld_add, float* dX, int64_t ldx, void* stream);
+
 /* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls
  * made afterwards (benchmarks and tests compare modes inside one process).  Workspace sizes depend on
