@@ -68,7 +68,7 @@ class GatMpBwdDesc(C.Structure):
     _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("negative_slope", C.c_float), ("xp", C.c_void_p), ("xp_ld", C.c_int64),
                 ("a_node", C.c_void_p), ("a_edge", C.c_void_p), ("a_edge_stride", C.c_int64), ("alpha", C.c_void_p),
                 ("alpha_mask", C.c_void_p), ("dout", C.c_void_p), ("dout_ld", C.c_int64), ("dxp", C.c_void_p),
-                ("dxp_ld", C.c_int64), ("da_node", C.c_void_p), ("da_edge", C.c_void_p)]
+                ("dxp_ld", C.c_int64), ("da_node", C.c_void_p), ("da_edge", C.c_void_p), ("dalpha_node", C.c_void_p)]
 
 
 class BnParams(C.Structure):
@@ -215,6 +215,9 @@ PROTOTYPES = {
                                            C.c_void_p]),
     "gvqa_graph_edge_rows_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_graph_segment_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_graph_head_rows_add": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_graph_head_rows_backward": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_skinny_forward": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_skinny_backward_weight_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "gvqa_skinny_backward_weight": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -58,6 +58,8 @@ struct BwdArgs {
     const float* a_edge; int64_t a_edge_stride;
     const float* alpha;                // [E, H] COO (softmax output, before mask)
     const float* mask;                 // [E, H] COO or NULL
+    const float* dsum;                 // [N, H] or NULL: added to dalpha' of every in-edge of a node before the mask (gradient of
+                                       // s[i,h] = sum_e alpha mask -- the per-graph rows of the projection folded out of xp)
     const float* dout; int64_t dout_ld;
     float* dxp; int64_t dxp_ld;
     float* da_node;                    // [N, 2H]
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256) void k_gat_mp_bwd_dst(BwdArgs a) {
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
                 if (h < H) {
-                    const float dd = a.mask ? d[e][h] * mk[e][h] : d[e][h];
+                    const float dx = d[e][h] + (a.dsum ? a.dsum[(int64_t)i * H + h] : 0.f);
+                    const float dd = a.mask ? dx * mk[e][h] : dx;
                     t[h] += al[e][h] * dd;
                     if (s + e - lo < BWD_CAP && lane == 0) stage[wave][(s + e - lo) * BWD_MAXH + h] = dd;
                 }
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gat_mp_bwd_dst(BwdArgs a) {
                     const int cnt = min(64, hi - s0);
                     for (int j = 0; j < cnt; ++j) {
                         const int src_j = a.csr_src[s0 + j], eid_j = a.csr_eid[s0 + j];
-                        float d = dalpha_of(src_j, h);
+                        float d = dalpha_of(src_j, h) + (a.dsum ? a.dsum[(int64_t)i * H + h] : 0.f);
                         if (a.mask) d *= a.mask[(int64_t)eid_j * H + h];
                         if (lane == j) d_lane = d;
                     }
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(BT_THREADS) void k_gat_mp_bwd_dst_tiled(BwdTiledArg
             v += __shfl_xor(v, 2, 64);
             if (part == 0 && e_it[k] >= 0) {
                 v *= inv_h;
+                if (a.dsum) v += a.dsum[(int64_t)(n0 + dof[k]) * H + h];
                 if (a.mask) v *= a.mask[(int64_t)eid_l[e_it[k]] * H + h];
                 d_s[e_it[k] * H + h] = v;
             }
@@ -511,7 +515,7 @@ extern "C" int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, c
     a.N = (int)g->num_nodes; a.C = C; a.H = H; a.slope = d->negative_slope;
     a.xp = d->xp; a.xp_ld = d->xp_ld ? d->xp_ld : (int64_t)H * C;
     a.a_node = d->a_node; a.a_edge = d->a_edge; a.a_edge_stride = d->a_edge_stride ? d->a_edge_stride : H;
-    a.alpha = d->alpha; a.mask = d->alpha_mask;
+    a.alpha = d->alpha; a.mask = d->alpha_mask; a.dsum = d->dalpha_node;
     a.dout = d->dout; a.dout_ld = d->dout_ld ? d->dout_ld : C;
     a.dxp = d->dxp; a.dxp_ld = d->dxp_ld ? d->dxp_ld : (int64_t)H * C;
     a.da_node = d->da_node; a.da_edge = d->da_edge;

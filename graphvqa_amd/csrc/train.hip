@@ -5,11 +5,12 @@
 // arithmetic rides on the f32-input matrix cores (v_mfma_f32_32x32x2_f32, J padded to 32 columns) because a VALU form needs a
 // cross-lane reduction (forward) or an LDS operand per FMA (backward) that costs more than the padding.
 //
-//   k_skinny_fwd      Y[R, J]  = X V         one wave per 32-row tile; V^T k-slices from LDS; transposed accumulators (a lane
+//   k_skinny_fwd      Y[R, J]  = X V         one wave per 32-row tile (8 per workgroup); V^T k-slices from LDS; transposed accumulators (a lane
 //                                             owns 4 consecutive j of one row: one 16-byte store per 8 columns)
 //   k_skinny_dv       P[b][D, J] = X_b^T G_b  one workgroup per chunk of rows, wave w owns every 4th 32-column tile of D; the
 //                                             row dimension is the MFMA's k; partial results per workgroup (no atomics: the
 //                                             sum order is fixed), reduced by k_skinny_dv_reduce
+//   k_head_rows_add / _bwd                      the per-graph rows of the projection kept out of xp (gvqa.h)
 //   k_skinny_dx       dX[R, D] = addend + G V^T   J FMAs per element out of registers (a thread keeps the V rows of its 4
 //                                             columns for 4 rows); 16-byte stores
 #include "common.h"
@@ -20,14 +21,14 @@ namespace gvqa {
 namespace {
 
 constexpr int SK_JP = 32;          // J padded to the MFMA's 32 columns
-constexpr int SK_ROWS_DV = 256;    // rows per workgroup of k_skinny_dv
+constexpr int SK_ROWS_DV_MIN = 128;    // rows per workgroup of k_skinny_dv: 128 below 128k rows, 256 above
 
 // Y = X V.  LDS: Vs[D_pad][32] (k-major, J zero-padded to 32) -- at most 64 KiB for D <= 512.
-__global__ __launch_bounds__(256) void k_skinny_fwd(int64_t R, int D, int J, const float* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__(512) void k_skinny_fwd(int64_t R, int D, int J, const float* __restrict__ X, int64_t ldx,
                                                     const float* __restrict__ V, float* __restrict__ Y) {
     extern __shared__ float Vs[];
     const int Dp = (D + 31) & ~31;
-    for (int i = threadIdx.x; i < Dp * SK_JP; i += 256) {
+    for (int i = threadIdx.x; i < Dp * SK_JP; i += 512) {
         const int k = i >> 5, j = i & 31;
         Vs[i] = (k < D && j < J) ? V[(int64_t)k * J + j] : 0.f;
     }
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void k_skinny_fwd(int64_t R, int D, int J, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hf = lane >> 5;
     const int64_t ntiles = (R + 31) >> 5;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
         const int64_t row = tile * 32 + r;
         const bool row_ok = row < R;
         const float* xr = X + (row_ok ? row : 0) * ldx;
@@ -48,25 +49,36 @@ __global__ __launch_bounds__(256) void k_skinny_fwd(int64_t R, int D, int J, con
             const int k0 = c * 32 + hf * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                // always a load (a conditional one is compiled into a predicated load + wait, which serialises the stream): rows
+                // past R read row 0 and are not stored; k past D re-reads k = 0 against a zero row of Vs
                 const int k = k0 + 4 * q;
-                dst[q] = (row_ok && k < D) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[q] = *reinterpret_cast<const float4*>(xr + (k < D ? k : 0));
             }
         };
         const int nch = Dp >> 5;
-        load(0, a);
-        for (int c = 0; c < nch; ++c) {
-            if (c + 1 < nch) load(c + 1, an);
+        auto fma = [&](int c, const float4 (&av)[4]) {
             const float* vs = Vs + (c * 32 + hf * 16) * SK_JP + r;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // operands swapped: D'[j][row], so a lane ends up with 4 consecutive j of its row per register quad
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 0) * SK_JP], a[q].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 1) * SK_JP], a[q].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 2) * SK_JP], a[q].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 3) * SK_JP], a[q].w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 0) * SK_JP], av[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 1) * SK_JP], av[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 2) * SK_JP], av[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[(4 * q + 3) * SK_JP], av[q].w, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = an[q];
+        };
+        // two chunks' loads in flight: the next chunk's are issued before this chunk's MFMAs (scheduling barriers keep the
+        // compiler from sinking them behind a vmcnt(0))
+        load(0, a);
+        for (int c = 0; c < nch; c += 2) {
+            load(c + 1, an);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(c, a);
+            __builtin_amdgcn_sched_barrier(0);
+            load(c + 2, a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nch) fma(c + 1, an);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (row_ok) {
             float* yr = Y + row * J;
@@ -89,11 +101,11 @@ __global__ __launch_bounds__(256) void k_skinny_fwd(int64_t R, int D, int J, con
 // MFMA roles: M = d (32 per tile), N = j (32, zero past J), k = rows (2 per instruction: half-waves).
 template <int DT>   // 32-column tiles of D per wave (D <= 128 DT)
 __global__ __launch_bounds__(256) void k_skinny_dv(int64_t R, int D, int J, const float* __restrict__ X, int64_t ldx,
-                                                   const float* __restrict__ G, float* __restrict__ P) {
+                                                   const float* __restrict__ G, float* __restrict__ P, int chunk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hf = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * SK_ROWS_DV;
-    const int nrow = (int)((R - row0 < SK_ROWS_DV) ? (R - row0) : SK_ROWS_DV);
+    const int64_t row0 = (int64_t)blockIdx.x * chunk;
+    const int nrow = (int)((R - row0 < chunk) ? (R - row0) : chunk);
     f32x16 acc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -108,23 +120,44 @@ __global__ __launch_bounds__(256) void k_skinny_dv(int64_t R, int D, int J, cons
         if (!dok[t]) dcol[t] = 0;
     }
     const bool jok = r < J;
-    constexpr int U = 8;     // row pairs in flight
-    for (int s = 0; s < nrow; s += 2 * U) {
-        float xa[U][DT], gb[U];
+    const int jcol = jok ? r : 0;
+    constexpr int U = 8;     // row pairs per step; two steps' loads are in flight (the next step's are issued before this step's MFMAs)
+    // unconditional loads from clamped addresses (conditional loads are compiled into predicated loads with a wait each: the
+    // stream would be serialised)
+    // (only G is masked -- rows past the chunk and columns past J multiply X by zero; columns of X past D land in accumulators
+    // that are not stored -- and the mask is applied when the value is consumed, not where it is loaded, so that a step's 40
+    // loads are all issued before anything waits for them)
+    auto load = [&](int s, float (&xa)[U][DT], float (&gb)[U], float (&gm)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int lr = s + 2 * u + hf;
             const bool ok = lr < nrow;
             const int64_t row = row0 + (ok ? lr : 0);
-            const float m = ok ? 1.f : 0.f;
-            gb[u] = jok ? G[row * J + r] * m : 0.f;
+            gm[u] = (ok && jok) ? 1.f : 0.f;
+            gb[u] = G[row * J + jcol];
 #pragma unroll
-            for (int t = 0; t < DT; ++t) xa[u][t] = dok[t] ? X[row * ldx + dcol[t]] * m : 0.f;
+            for (int t = 0; t < DT; ++t) xa[u][t] = X[row * ldx + dcol[t]];
         }
+    };
+    auto fma = [&](const float (&xa)[U][DT], const float (&gb)[U], const float (&gm)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            const float gv = gb[u] * gm[u];
 #pragma unroll
-            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][t], gb[u], acc[t], 0, 0, 0);
+            for (int t = 0; t < DT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][t], gv, acc[t], 0, 0, 0);
+        }
+    };
+    float xa0[U][DT], gb0[U], gm0[U], xa1[U][DT], gb1[U], gm1[U];
+    load(0, xa0, gb0, gm0);
+    for (int s = 0; s < nrow; s += 4 * U) {
+        load(s + 2 * U, xa1, gb1, gm1);             // rows past the chunk are masked to zero
+        __builtin_amdgcn_sched_barrier(0);
+        fma(xa0, gb0, gm0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(s + 4 * U, xa0, gb0, gm0);
+        __builtin_amdgcn_sched_barrier(0);
+        fma(xa1, gb1, gm1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // C/D map: column (j) = lane & 31, row (d within the tile) = (i & 3) + 8 (i >> 2) + 4 hf
     float* p = P + (int64_t)blockIdx.x * D * J;
@@ -168,26 +201,27 @@ __global__ __launch_bounds__(1024) void k_skinny_dv_reduce(int nparts, int DJ, c
     }
 }
 
-// dX[row][d] = (addend ? addend[row][d] : 0) + sum_j G[row][j] V[d][j]; a thread owns 4 consecutive d of 4 rows.
+// dX[row][d] = (addend ? addend[row][d] : 0) + sum_j G[row][j] V[d][j]; a thread owns 4 consecutive d and keeps their V rows
+// in registers over SK_DX_ROWS rows.
+constexpr int SK_DX_ROWS = 16;
 template <int JJ>
 __global__ __launch_bounds__(256) void k_skinny_dx(int64_t R, int D, const float* __restrict__ G, const float* __restrict__ V,
                                                    const float* __restrict__ addend, int64_t ld_add, float* __restrict__ dX,
                                                    int64_t ldx) {
-    const int d4 = D >> 2;                        // D % 4 == 0
-    const int per_row = d4;
-    const int64_t total = ((R + 3) >> 2) * per_row;
+    const int per_row = D >> 2;                   // D % 4 == 0
+    const int64_t total = ((R + SK_DX_ROWS - 1) / SK_DX_ROWS) * per_row;
     for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
         const int c = (int)(it % per_row) * 4;
-        const int64_t rq = (it / per_row) * 4;
+        const int64_t r0 = (it / per_row) * SK_DX_ROWS;
         float vt[4][JJ];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int j = 0; j < JJ; ++j) vt[t][j] = V[(int64_t)(c + t) * JJ + j];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t row = rq + q;
-            if (row >= R) break;
+        const int nr = (int)((R - r0 < SK_DX_ROWS) ? (R - r0) : SK_DX_ROWS);
+#pragma unroll 2
+        for (int q = 0; q < nr; ++q) {
+            const int64_t row = r0 + q;
             float g[JJ];
 #pragma unroll
             for (int j = 0; j < JJ; ++j) g[j] = G[row * JJ + j];
@@ -225,6 +259,89 @@ __global__ __launch_bounds__(256) void k_skinny_dx_any(int64_t R, int D, int J, 
     }
 }
 
+// ---- per-graph rows of the projection kept out of xp (gvqa.h: gvqa_graph_head_rows_*) ----------------------------------------
+constexpr int HR_MAXH = 8;
+
+// y[i, c..c+3] += (1/H) sum_h s[i,h] R[g(i), h, c..c+3]; a thread per (row, 4 channels)
+template <int H>
+__global__ __launch_bounds__(256) void k_head_rows_add(int64_t N, int C, const int32_t* __restrict__ node_graph,
+                                                       const int32_t* __restrict__ rowptr, const float* __restrict__ R,
+                                                       const float* __restrict__ s, float* __restrict__ y, int64_t ldy) {
+    const int per_row = C >> 2;
+    const int64_t total = N * per_row;
+    const float inv_h = 1.0f / H;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int64_t i = it / per_row;
+        const int c = (int)(it - i * per_row) * 4;
+        const float* r = R + (int64_t)node_graph[i] * H * C + c;
+        const float ones = rowptr[i + 1] > rowptr[i] ? 1.f : 0.f;      // s without a mask: 1, or 0 for a node without in-edges
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(r + (int64_t)h * C);
+            const float w = s ? s[i * H + h] : ones;
+            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+        }
+        float4* o = reinterpret_cast<float4*>(y + i * ldy + c);
+        float4 cur = *o;
+        cur.x = fmaf(acc.x, inv_h, cur.x); cur.y = fmaf(acc.y, inv_h, cur.y); cur.z = fmaf(acc.z, inv_h, cur.z); cur.w = fmaf(acc.w, inv_h, cur.w);
+        *o = cur;
+    }
+}
+
+// one workgroup per graph: dR[g,h,c] = (1/H) sum_{i in g} s[i,h] dy[i,c] (threads over channels, nodes in order) and, when asked
+// for, ds[i,h] = (1/H) dy[i,:] . R[g,h,:] (a wave per node, lanes over channels)
+template <int H>
+__global__ __launch_bounds__(256) void k_head_rows_bwd(int C, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ rowptr,
+                                                       const float* __restrict__ dy, int64_t ld_dy,
+                                                       const float* __restrict__ R, const float* __restrict__ s, float* __restrict__ dR,
+                                                       float* __restrict__ ds) {
+    const int g = blockIdx.x;
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+    const float inv_h = 1.0f / H;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float4 acc[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = n0; i < n1; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(dy + (int64_t)i * ld_dy + c);
+            const float ones = rowptr[i + 1] > rowptr[i] ? 1.f : 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float w = s ? s[(int64_t)i * H + h] : ones;
+                acc[h].x = fmaf(w, v.x, acc[h].x); acc[h].y = fmaf(w, v.y, acc[h].y);
+                acc[h].z = fmaf(w, v.z, acc[h].z); acc[h].w = fmaf(w, v.w, acc[h].w);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+            *reinterpret_cast<float4*>(dR + ((int64_t)g * H + h) * C + c) =
+                make_float4(acc[h].x * inv_h, acc[h].y * inv_h, acc[h].z * inv_h, acc[h].w * inv_h);
+    }
+    if (!ds) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = n0 + wave; i < n1; i += 4) {
+        float acc[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(dy + (int64_t)i * ld_dy + c);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float4 r = *reinterpret_cast<const float4*>(R + ((int64_t)g * H + h) * C + c);
+                acc[h] += v.x * r.x + v.y * r.y + v.z * r.z + v.w * r.w;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float v = acc[h];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) ds[(int64_t)i * H + h] = v * inv_h;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace gvqa
 
@@ -245,14 +362,14 @@ int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t
         attr_set = true;
     }
     const int64_t ntiles = cdiv(R, 32);
-    const int grid = (int)std::min<int64_t>(cdiv(ntiles, 4), 2048);
-    hipLaunchKernelGGL(k_skinny_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, R, (int)D, (int)J, X, ldx, V, Y);
+    const int grid = (int)std::min<int64_t>(cdiv(ntiles, 8), 512);
+    hipLaunchKernelGGL(k_skinny_fwd, dim3(grid), dim3(512), lds, (hipStream_t)stream, R, (int)D, (int)J, X, ldx, V, Y);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
 
 size_t gvqa_skinny_backward_weight_workspace_bytes(int64_t R, int64_t D, int64_t J) {
-    return (size_t)std::max<int64_t>(cdiv(R, SK_ROWS_DV), 1) * (size_t)D * (size_t)J * sizeof(float) + 256;
+    return (size_t)std::max<int64_t>(cdiv(R, SK_ROWS_DV_MIN), 1) * (size_t)D * (size_t)J * sizeof(float) + 256;
 }
 
 int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* G, float* dV,
@@ -268,10 +385,11 @@ int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X,
     GVQA_REQUIRE(X && G && ws, GVQA_E_INVALID, "gvqa_skinny_backward_weight: null pointer");
     GVQA_REQUIRE(ws_bytes >= gvqa_skinny_backward_weight_workspace_bytes(R, D, J), GVQA_E_WORKSPACE,
                  "gvqa_skinny_backward_weight: workspace too small");
-    const int nparts = (int)cdiv(R, SK_ROWS_DV);
+    const int chunk = R >= (1 << 17) ? 2 * SK_ROWS_DV_MIN : SK_ROWS_DV_MIN;
+    const int nparts = (int)cdiv(R, chunk);
     float* P = static_cast<float*>(ws);
     const int dtiles = (int)cdiv(D, 32), DT = (int)cdiv(dtiles, 4);
-#define GVQA_DV(T) hipLaunchKernelGGL(k_skinny_dv<T>, dim3(nparts), dim3(256), 0, st, R, (int)D, (int)J, X, ldx, G, P)
+#define GVQA_DV(T) hipLaunchKernelGGL(k_skinny_dv<T>, dim3(nparts), dim3(256), 0, st, R, (int)D, (int)J, X, ldx, G, P, chunk)
     switch (DT) {
         case 1: GVQA_DV(1); break;
         case 2: GVQA_DV(2); break;
@@ -298,8 +416,8 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
     if (R == 0) return GVQA_OK;
     GVQA_REQUIRE(G && V && dX, GVQA_E_INVALID, "gvqa_skinny_backward_input: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = cdiv(R, 4) * (D / 4);
-    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 8192);
+    const int64_t total = cdiv(R, SK_DX_ROWS) * (D / 4);
+    const int grid = (int)std::min<int64_t>(cdiv(std::max<int64_t>(total, R * (D / 4) / 4), 256), 8192);
 #define GVQA_DX(JJ) hipLaunchKernelGGL(k_skinny_dx<JJ>, dim3(grid), dim3(256), 0, st, R, (int)D, G, V, addend, ld_add, dX, ldx)
     switch (J) {
         case 1: GVQA_DX(1); break;
@@ -316,6 +434,56 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
             break;
     }
 #undef GVQA_DX
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, float* y, int64_t ld_y,
+                             void* stream) {
+    GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_head_rows_add: graph not built");
+    GVQA_REQUIRE(C > 0 && C % 4 == 0 && ld_y % 4 == 0 && ld_y >= C && H >= 1 && H <= HR_MAXH, GVQA_E_INVALID,
+                 "graph_head_rows_add: C %% 4 == 0, 1 <= H <= %d", HR_MAXH);
+    if (g->num_nodes == 0) return GVQA_OK;
+    GVQA_REQUIRE(R && y, GVQA_E_INVALID, "graph_head_rows_add: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = g->num_nodes * (C / 4);
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 16384);
+#define GVQA_HRA(HH) hipLaunchKernelGGL(k_head_rows_add<HH>, dim3(grid), dim3(256), 0, st, g->num_nodes, (int)C, g->node_graph, g->rowptr, R, s, y, ld_y)
+    switch (H) {
+        case 1: GVQA_HRA(1); break;
+        case 2: GVQA_HRA(2); break;
+        case 3: GVQA_HRA(3); break;
+        case 4: GVQA_HRA(4); break;
+        case 5: GVQA_HRA(5); break;
+        case 6: GVQA_HRA(6); break;
+        case 7: GVQA_HRA(7); break;
+        default: GVQA_HRA(8); break;
+    }
+#undef GVQA_HRA
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, const float* dy, int64_t ld_dy, const float* R,
+                                  const float* s, float* dR, float* ds, void* stream) {
+    GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_head_rows_backward: graph not built");
+    GVQA_REQUIRE(C > 0 && C % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= C && H >= 1 && H <= HR_MAXH, GVQA_E_INVALID,
+                 "graph_head_rows_backward: C %% 4 == 0, 1 <= H <= %d", HR_MAXH);
+    if (g->num_graphs == 0) return GVQA_OK;
+    GVQA_REQUIRE(dR && (dy || g->num_nodes == 0) && (!ds || R), GVQA_E_INVALID, "graph_head_rows_backward: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+#define GVQA_HRB(HH) hipLaunchKernelGGL(k_head_rows_bwd<HH>, dim3((unsigned)g->num_graphs), dim3(256), 0, st, (int)C, g->graph_ptr, g->rowptr, dy, ld_dy, R, s, dR, ds)
+    switch (H) {
+        case 1: GVQA_HRB(1); break;
+        case 2: GVQA_HRB(2); break;
+        case 3: GVQA_HRB(3); break;
+        case 4: GVQA_HRB(4); break;
+        case 5: GVQA_HRB(5); break;
+        case 6: GVQA_HRB(6); break;
+        case 7: GVQA_HRB(7); break;
+        default: GVQA_HRB(8); break;
+    }
+#undef GVQA_HRB
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -164,14 +164,21 @@ def skinny_linear(x: Tensor, V: Tensor) -> Tensor:
 class _GatMessagePassing(torch.autograd.Function):
     """out[i] = (1/H) sum_h sum_{e -> i} alpha[e,h] mask[e,h] xp[src_e, h, :],  alpha = softmax over the in-edges
     of leaky_relu(a_node[src,h] + a_node[dst,H+h] + a_edge[e,h])   (gat_skip.py:155,183-208,162-165).
-    Forward and backward are HIP kernels; returns (out [N, C], alpha [E, H])."""
+    Forward and backward are HIP kernels; returns (out [N, C], alpha [E, H]).
+    `graph_rows` [B, H*C] (optional): rows added to xp per GRAPH -- the instruction half of lin_l([h | ins[batch]]),
+    gat_skip.py:133,263-264 -- i.e. the op computes MP(xp + graph_rows[batch]) without forming that [N, H*C] sum or its adjoint:
+    out = MP(xp) + (1/H) sum_h s[i,h] graph_rows[g,h,:] with s[i,h] = sum_{e->i} alpha mask (gvqa_graph_head_rows_*)."""
 
     @staticmethod
-    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope):
+    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope, graph_rows=None):
         lib = _lib.load()
         xp, a_node, a_edge = _f32c(xp, "xp"), _f32c(a_node, "a_node"), _f32c(a_edge, "a_edge")
         if mask is not None:
             mask = _f32c(mask, "alpha_mask")
+        if graph_rows is not None:
+            graph_rows = _f32c(graph_rows, "graph_rows")
+            if graph_rows.shape != (graph.num_graphs, heads * channels):
+                raise ValueError("gat_message_passing: graph_rows must be [num_graphs, heads * channels]")
         N, E, dev = graph.num_nodes, graph.num_edges, xp.device
         if xp.shape != (N, heads * channels) or a_node.shape != (N, 2 * heads) or a_edge.shape != (E, heads):
             raise ValueError("gat_message_passing: operand shapes do not match the graph")
@@ -184,7 +191,13 @@ class _GatMessagePassing(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = _workspace(4 * E * heads, dev)
             _lib.check(lib.gvqa_gat_message_passing(C.byref(graph.c), C.byref(m), ws.data_ptr(), ws.numel(), _stream(dev)))
-        ctx.save_for_backward(xp, a_node, a_edge, alpha, mask)
+            s = None
+            if graph_rows is not None:
+                if mask is not None:          # s[i,h] = sum over the in-edges of alpha * mask (1 when nothing is dropped)
+                    s = _edge_rows_sum_raw(alpha * mask, graph)
+                _lib.check(lib.gvqa_graph_head_rows_add(C.byref(graph.c), channels, heads, graph_rows.data_ptr(), _ptr(s),
+                                                        out.data_ptr(), channels, _stream(dev)))
+        ctx.save_for_backward(xp, a_node, a_edge, alpha, mask, graph_rows, s)
         ctx.graph, ctx.dims = graph, (heads, channels, slope)
         ctx.mark_non_differentiable(alpha)
         return out, alpha
@@ -192,20 +205,29 @@ class _GatMessagePassing(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dalpha):
         lib = _lib.load()
-        xp, a_node, a_edge, alpha, mask = ctx.saved_tensors
+        xp, a_node, a_edge, alpha, mask, graph_rows, s = ctx.saved_tensors
         heads, channels, slope = ctx.dims
         graph, dev = ctx.graph, xp.device
         dout = dout.contiguous()
         dxp, da_node, da_edge = torch.empty_like(xp), torch.empty_like(a_node), torch.empty_like(a_edge)
+        d_rows = ds = None
+        if graph_rows is not None:
+            d_rows = torch.empty_like(graph_rows)
+            if mask is not None:              # without a mask s == 1 and the term is constant under the softmax
+                ds = torch.empty((graph.num_nodes, heads), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.gvqa_graph_head_rows_backward(C.byref(graph.c), channels, heads, dout.data_ptr(), channels,
+                                                             graph_rows.data_ptr(), _ptr(s), d_rows.data_ptr(), _ptr(ds), _stream(dev)))
         d = _lib.GatMpBwdDesc()
         d.C, d.H, d.negative_slope = channels, heads, slope
         d.xp, d.a_node, d.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
         d.alpha, d.alpha_mask, d.dout = alpha.data_ptr(), _ptr(mask), dout.data_ptr()
         d.dxp, d.da_node, d.da_edge = dxp.data_ptr(), da_node.data_ptr(), da_edge.data_ptr()
+        d.dalpha_node = _ptr(ds)
         with torch.cuda.device(dev):
             gt = graph.transposed()
             _lib.check(lib.gvqa_gat_mp_backward(C.byref(graph.c), C.byref(gt.c), C.byref(d), _stream(dev)))
-        return dxp, da_node, da_edge, None, None, None, None, None
+        return dxp, da_node, da_edge, None, None, None, None, None, d_rows
 
 
 class _BatchNormReluTrain(torch.autograd.Function):
@@ -418,11 +440,11 @@ def graph_softmax(score: Tensor, graph: SceneGraphBatch) -> Tensor:
 
 
 def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: SceneGraphBatch, heads: int, channels: int,
-                        negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None):
+                        negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None, graph_rows: Optional[Tensor] = None):
     """Differentiable GAT message passing on the HIP kernels: (out [N, C], alpha [E, H]).
     xp [N, H*C] projected features, a_node [N, 2H] = (a_l | a_r), a_edge [E, H]; alpha_mask [E, H] multiplies alpha
-    after the softmax (attention dropout: mask / (1 - p))."""
-    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope)
+    after the softmax (attention dropout: mask / (1 - p)); graph_rows [B, H*C]: rows added to xp per graph (kept out of xp)."""
+    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, graph_rows)
 
 
 class gat(torch.nn.Module):
@@ -742,7 +764,8 @@ class gat_seq(torch.nn.Module):
             W_h3, W_i3 = W[:, :Dn].reshape(H, Cc, Dn), W[:, Dn:].reshape(H, Cc, Di)
             att_l, att_r, att_e = conv.att_l.view(H, Cc), conv.att_r.view(H, Cc), conv.att_e.view(H, Cc)
             # projected features: node half per row, instruction half per graph
-            xp = add_graph_rows(_ProjectionLinear.apply(h, W[:, :Dn]), F.linear(ins, W[:, Dn:]), graph)
+            # (the per-graph rows ride through the message passing as `graph_rows`: the [N, H*C] sum is never formed)
+            xp, xp_rows = _ProjectionLinear.apply(h, W[:, :Dn]), F.linear(ins, W[:, Dn:])
             # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
             # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
             V_n = torch.cat((torch.einsum("hck,hc->kh", W_h3, att_l), torch.einsum("hck,hc->kh", W_h3, att_r)), dim=1)
@@ -755,7 +778,7 @@ class gat_seq(torch.nn.Module):
                 mask = alpha_masks[i]
             elif p > 0:
                 mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p)
-            out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask)
+            out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask, graph_rows=xp_rows)
             if conv.bias is not None:
                 out = out + conv.bias
             h = out + h

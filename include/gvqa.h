@@ -274,7 +274,7 @@ int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const 
  * (x_i * att).sum(-1) of gat_skip.py:134-135,151 with the attention vectors folded through the projection weights, a = X V,
  * V [D, J] row-major with J <= 32 (2H node columns, or the H edge columns of all K hops side by side), and the two products
  * of their autograd: dV = X^T G and dX = addend + G V^T.  X [R, D] (row stride ldx), Y / G [R, J] contiguous.  Each call
- * streams X (or dX) through HBM once; dV is summed in a fixed order (partial sums per 256 rows in the workspace, no atomics).
+ * streams X (or dX) through HBM once; dV is summed in a fixed order (partial sums per 128 or 256 rows in the workspace, no atomics).
  * D % 4 == 0, D <= 1024. */
 int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* V, float* Y, void* stream);
 size_t gvqa_skinny_backward_weight_workspace_bytes(int64_t R, int64_t D, int64_t J);
@@ -394,8 +394,24 @@ typedef struct gvqa_gat_mp_bwd_desc {
     int64_t dxp_ld;             /* 0 -> H*C                                                              */
     float* da_node;             /* [N, 2H]                                                               */
     float* da_edge;             /* [E, H] COO                                                            */
+    const float* dalpha_node;   /* NULL or [N, H]: a term added to dL/d(alpha[e,h]) of every in-edge e of node i, before the
+                                   mask -- the gradient of s[i,h] = sum_{e->i} alpha mask when per-graph rows of the projection
+                                   are kept out of xp (gvqa_graph_head_rows_add / _backward below)          */
 } gvqa_gat_mp_bwd_desc;
 int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_gat_mp_bwd_desc* d, void* stream);
+
+/* Per-graph rows of the hop projection kept out of xp (differentiable path).  lin_l acts on [h | ins[batch]] (gat_skip.py:133,
+ * 263-264): xp[i,h,:] = xp_node[i,h,:] + R[g(i),h,:] with R = ins W_i^T one row per GRAPH.  The aggregation is linear in xp, so
+ *     out[i,:] = MP(xp_node)[i,:] + (1/H) sum_h s[i,h] R[g(i),h,:],   s[i,h] = sum_{e->i} alpha[e,h] mask[e,h]   (without a mask: 1, or 0 for a node with no in-edge)
+ * and the [N, H*C] sum xp_node + R[batch] (and its adjoint, a segment sum over [N, H*C]) is never formed:
+ *   gvqa_graph_head_rows_add       y[i,:] += (1/H) sum_h s[i,h] R[g(i),h,:]                (s NULL: the mask-free values)
+ *   gvqa_graph_head_rows_backward  dR[g,h,:] = (1/H) sum_{i in g} s[i,h] dy[i,:];  ds[i,h] = (1/H) dy[i,:] . R[g(i),h,:]
+ *                                  (ds NULL: not computed; it is what gvqa_gat_mp_bwd_desc.dalpha_node takes)
+ * R / dR [B, H*C] contiguous, y / dy [N, C] with row strides, s / ds [N, H] contiguous.  C % 4 == 0, H <= 8. */
+int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, float* y, int64_t ld_y,
+                             void* stream);
+int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, const float* dy, int64_t ld_dy, const float* R,
+                                  const float* s, float* dR, float* ds, void* stream);
 
 /* Host-only introspection: the geometry gvqa_gat_message_passing would use for this (finalized)
  * graph -- LDS-tiled streaming kernel or general CSR kernels -- without launching anything. */

@@ -545,7 +545,42 @@ def test_edge_logits_of_all_hops_share_one_pass(dev):
     X = torch.randn((3000, 64), generator=g).to(dev)
     V = torch.randn((64, 40), generator=g).to(dev).requires_grad_(True)
     Y = skinny_linear(X, V)
-    assert float((Y.double() - X.double() @ V.detach().double()).abs().max()) <= 2e-5
+    assert float((Y.detach().double() - X.double() @ V.detach().double()).abs().max()) <= 2e-5
     Y.square().sum().backward()
     ref = X.double().t() @ (2 * (X.double() @ V.detach().double()))
     assert float((V.grad.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("C,H,with_mask,hub", [(32, 4, False, False), (12, 4, True, False), (300, 4, True, True), (512, 8, True, False),
+                                               (64, 1, True, True), (36, 3, False, True), (128, 2, True, False)])
+def test_message_passing_with_per_graph_rows_kept_out_of_xp(dev, C, H, with_mask, hub):
+    """gat_message_passing(xp, ..., graph_rows=R) == MP(xp + R[batch]) in value and in every gradient (xp, logits, R) -- the
+    instruction half of lin_l folded out of the [N, H*C] tensor -- against fp64 autograd through the oracle's restatement of the
+    explicit form; with attention dropout masks (s != 1: the logits feel R) and without; hub nodes beyond the tiled backward."""
+    from graphvqa_amd.gat_skip import gat_message_passing
+    from graphvqa_amd.graph import SceneGraphBatch
+    gb = synth.make_graph_batch(7, seed=0xC00 + C, nodes_lo=1, nodes_hi=40, rel_per_node=2.0)
+    ei = gb.edge_index.copy()
+    if hub:
+        n0 = int((gb.batch == 0).sum())
+        ei = np.concatenate([ei, np.stack([np.arange(70) % n0, np.zeros(70, np.int64)])], axis=1)
+    ei = ei[:, ei[1] % 5 != 3]                   # some nodes lose every in-edge (self loops included): their output is exactly 0
+    N, E, B = gb.num_nodes, ei.shape[1], gb.num_graphs
+    rng = np.random.default_rng(C * 11 + H)
+    xp = rng.standard_normal((N, H * C)).astype(np.float32)
+    a_node = rng.standard_normal((N, 2 * H)).astype(np.float32)
+    a_edge = rng.standard_normal((E, H)).astype(np.float32)
+    rows = rng.standard_normal((B, H * C)).astype(np.float32)
+    mask = ((rng.random((E, H)) > 0.3) / 0.7).astype(np.float32) if with_mask else None
+    w = rng.standard_normal((N, C)).astype(np.float32)
+    g = SceneGraphBatch(t(ei, device=dev), t(gb.batch, device=dev), N, B)
+    xs = [t(a, device=dev).requires_grad_(True) for a in (xp, a_node, a_edge, rows)]
+    out, alpha = gat_message_passing(xs[0], xs[1], xs[2], g, H, C, 0.2, None if mask is None else t(mask, device=dev), graph_rows=xs[3])
+    (out * t(w, device=dev)).sum().backward()
+    rs = [t(a).double().requires_grad_(True) for a in (xp, a_node, a_edge, rows)]
+    ref_out, ref_alpha = _mp_reference(rs[0] + rs[3][t(gb.batch).long()], rs[1], rs[2], None if mask is None else t(mask).double(),
+                                       t(ei), N, H, C, 0.2)
+    (ref_out * t(w).double()).sum().backward()
+    assert maxabs(out, ref_out) < 2e-5 and maxabs(alpha, ref_alpha) < 1e-6
+    for got, ref, name in zip(xs, rs, ("dxp", "da_node", "da_edge", "d_graph_rows")):
+        assert _rel(got.grad, ref.grad) < 2e-5, name
