@@ -81,6 +81,9 @@ struct LinearEpilogue {
     const float* mul;       // [M, ld_mul] or NULL; bf16 when C is bf16
     int64_t ld_mul;
     int relu;               // activation: 0 none, 1 ReLU, 2 ELU(alpha = 1)
+    // batched launches of the split GEMM (gridDim.z > 1; split-K chunks of the TN product): strides per batch of the packed
+    // operands (16-bit elements), of C (floats) and of the operands' inverse-scale arrays (floats)
+    int64_t zs_a, zs_b, zs_c, zs_ia, zs_ib;
 };
 
 // GEMM entry used by the orchestration code (defined in gemm.hip).
@@ -165,7 +168,8 @@ size_t split_packed_bytes(int np, int64_t rows, int64_t K);
 int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
-                        int64_t ldc, hipStream_t stream);
+                        int64_t ldc, hipStream_t stream, int batch = 1,
+                        const float* a_inv_batched = nullptr, const float* b_inv_batched = nullptr);
 // fp32 Linear with caller scratch: two-piece kernels when applicable, f32-input MFMA otherwise (split3.hip)
 size_t linear_auto_scratch_bytes(int64_t M, int64_t N, int64_t K);
 int launch_linear_auto(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, LinearEpilogue ep,

@@ -151,6 +151,12 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     int bm = blockIdx.y, bn = blockIdx.x;
+    if (EPI != 2 && gridDim.z > 1) {                   // batched launch (split-K chunks): this batch's operands and result
+        const int64_t z = blockIdx.z;
+        Apk += z * ep.zs_a; Bpk += z * ep.zs_b; C += z * ep.zs_c;
+        if (a_inv) a_inv += z * ep.zs_ia;
+        if (b_inv) b_inv += z * ep.zs_ib;
+    }
     if (EPI == 2 && fh.xcd_cols > 1) {
         // Workgroup w of the launch order runs on XCD w % 8 (each XCD has its own L2).  With the plain order the 8 column blocks
         // of a row block sit on 8 different XCDs and every L2 streams the whole A operand; here XCD x owns `xcd_cols` column
@@ -1061,8 +1067,10 @@ static int split3_variant(int64_t M, int64_t N, int KB) {
     return (KB >= 24 && e_big >= e_half - 0.02) ? 14 : 34;
 }
 
+// batch > 1: gridDim.z batches with the strides of ep.zs_* (split-K chunks of the TN product); a_inv_batched / b_inv_batched:
+// the operands' inverse scales when they do not sit behind the fragments (two-piece operands)
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
-                        int64_t ldc, hipStream_t stream) {
+                        int64_t ldc, hipStream_t stream, int batch, const float* a_inv_batched, const float* b_inv_batched) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "linear_split: 2 or 3 pieces");
     GVQA_REQUIRE(M >= 0 && N >= 0 && K > 0, GVQA_E_INVALID, "linear_split3: bad size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 30), GVQA_E_INVALID, "linear_split3: size overflow");
@@ -1079,8 +1087,9 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     if (np == 2 && variant < 100) variant = variant < 20 ? ((KB & 1) ? 118 : 112) : 134;      // (112: two K steps per barrier)
     GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
     const int64_t bm = variant % 100 < 20 ? 256 : 128;
-    const float* a_inv = np == 2 ? split2h_inv_scales(Apk, cdiv(M, 32), KB) : nullptr;
-    const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
+    GVQA_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || M <= 65535 * bm), GVQA_E_INVALID, "linear_split: bad batch count");
+    const float* a_inv = np == 2 ? (a_inv_batched ? a_inv_batched : split2h_inv_scales(Apk, cdiv(M, 32), KB)) : nullptr;
+    const float* b_inv = np == 2 ? (b_inv_batched ? b_inv_batched : split2h_inv_scales(Bpk, rtB, KB)) : nullptr;
 #ifdef GVQA_PROBES
     const char* ssv = getenv("GVQA_SPLIT3_STAGGER");      // quarter units of the default start offset (tuning aid)
     const int stag_scale = ssv ? atoi(ssv) : 0;
@@ -1103,7 +1112,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
 #define GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_) GVQA_SK_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_, 1)
 #define GVQA_SK_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_, KS_)                           \
         do {                                                                                                             \
-            dim3 grid((unsigned)cdiv(N, 32 * WN_ * TN_), (unsigned)cdiv(m, 32 * WM_ * TM_));                              \
+            dim3 grid((unsigned)cdiv(N, 32 * WN_ * TN_), (unsigned)cdiv(m, 32 * WM_ * TM_), (unsigned)batch);             \
             /* a block's MFMA issue time x the STAG_ blocks sharing the SIMDs, split into STAG_ start offsets */         \
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
             hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_, PIPE_, KS_>), grid, \

@@ -342,7 +342,131 @@ __global__ __launch_bounds__(256) void k_head_rows_bwd(int C, const int32_t* __r
     }
 }
 
+// ---- C = X^T Y on the fp16 matrix cores (the weight gradient dW = dy^T x of the hop projection: a reduction over all N rows) ------
+// The split GEMM of csrc/split3.hip contracts over the contiguous dimension of fragment-major packed operands, so both operands
+// are packed TRANSPOSED here (k_split2h_pack_t: X [R, M] -> two-piece fp16 fragments of X^T, rows of X = the k dimension), in
+// split-K chunks of KC rows: chunk z is a complete packed operand [M x KC], the GEMM runs once with gridDim.z = S chunks into S
+// partial results, and k_splitk_reduce adds them in a fixed order.  One power-of-two scale per operand (from its largest
+// magnitude, k_absmax or the producer's): a piece pair carries 22 bits below each ELEMENT's own exponent as long as the element
+// is within 2^18 of the largest one (fp16's exponent range), and what is smaller still contributes less than fp32 rounding of
+// the sum.
+typedef _Float16 tn_f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void k_absmax(int64_t rows, int cols, const float* __restrict__ X, int64_t ld, unsigned* __restrict__ out) {
+    // a workgroup walks whole rows (blockIdx.x, then + gridDim.x); four 16-byte loads of a thread in flight
+    const int c4 = cols >> 2;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    auto upd = [](float m, const float4& v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); };
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float4* xr = reinterpret_cast<const float4*>(X + r * ld);
+        int c = threadIdx.x;
+        for (; c + 768 < c4; c += 1024) {
+            const float4 a = xr[c], b = xr[c + 256], d = xr[c + 512], e = xr[c + 768];
+            m0 = upd(m0, a); m1 = upd(m1, b); m2 = upd(m2, d); m3 = upd(m3, e);
+        }
+        for (; c < c4; c += 256) m0 = upd(m0, xr[c]);
+    }
+    float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    // one atomic per workgroup: atomics on one address serialise at ~20 ns each
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like their bit patterns
+}
+
+constexpr int TN_SLAB_ROWS = 64, TN_SLAB_COLS = 256, TN_LDS_LD = 260;
+// grid (ceil(M / 256), S * KC / 64); a workgroup turns a [64 rows x 256 columns] slab of X into 4 k blocks x 8 column tiles
+__global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const float* __restrict__ X, int64_t ldx,
+                                                        const float* __restrict__ absmax, int KC, int T, uint16_t* __restrict__ P,
+                                                        float* __restrict__ inv) {
+    __shared__ float Xs[TN_SLAB_ROWS * TN_LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * TN_SLAB_ROWS;
+    const int c0 = blockIdx.x * TN_SLAB_COLS;
+    const int z = (int)(r0 / KC), kb0 = (int)((r0 - (int64_t)z * KC) >> 4), KBc = KC >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + i * 256, row = idx >> 6, c = (idx & 63) * 4;
+        const bool ok = r0 + row < R && c0 + c < M;
+        const float* src = X + (ok ? (r0 + row) * ldx + c0 + c : 0);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        const float m = ok ? 1.f : 0.f;
+        v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+        *reinterpret_cast<float4*>(&Xs[row * TN_LDS_LD + c]) = v;
+    }
+    const int e = split2h_exponent(*absmax);
+    const float scale = pow2i(e);
+    if (kb0 == 0 && c0 + tid < T * 32) inv[(int64_t)z * T * 32 + c0 + tid] = pow2i(-e);
+    __syncthreads();
+    const int mloc = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int u = wave + 4 * j, kbl = u >> 3, tl = u & 7;
+        const int tile = blockIdx.x * 8 + tl;
+        if (tile >= T) continue;
+        tn_f16x8 p0, p1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = Xs[(kbl * 16 + kh * 8 + i) * TN_LDS_LD + tl * 32 + mloc] * scale;
+            const _Float16 a = (_Float16)x;
+            p0[i] = a;
+            p1[i] = (_Float16)(x - (float)a);
+        }
+        uint16_t* o = P + ((int64_t)z * T + tile) * KBc * 1024 + (int64_t)(kb0 + kbl) * 1024 + lane * 8;
+        *reinterpret_cast<uint4*>(o) = __builtin_bit_cast(uint4, p0);
+        *reinterpret_cast<uint4*>(o + 512) = __builtin_bit_cast(uint4, p1);
+    }
+}
+
+// C[m, n] = sum_z P[z][m][n], z in order
+__global__ __launch_bounds__(256) void k_splitk_reduce(int S, int M, int N, const float* __restrict__ P, float* __restrict__ C, int64_t ldc) {
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4, MN = (int64_t)M * N;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int64_t m = it / n4;
+        const int n = (int)(it - m * n4) * 4;
+        float4 acc = *reinterpret_cast<const float4*>(P + m * N + n);
+        for (int z = 1; z < S; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(P + (int64_t)z * MN + m * N + n);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(C + m * ldc + n) = acc;
+    }
+}
+
+struct TnPlan {
+    int S, KC, KBc, TA, TB;
+    size_t off_pa, off_pb, off_ia, off_ib, off_part, off_max, total;
+};
+static TnPlan tn_plan(int64_t R, int64_t M, int64_t N) {
+    TnPlan p;
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
+    int64_t S = std::max<int64_t>(1, std::min<int64_t>((256 + tiles - 1) / tiles, cdiv(R, 1024)));
+    S = std::min<int64_t>(S, 1024);
+    const int64_t KC = cdiv(cdiv(std::max<int64_t>(R, 1), S), 64) * 64;
+    p.S = (int)cdiv(std::max<int64_t>(R, 1), KC);
+    p.KC = (int)KC; p.KBc = (int)(KC / 16);
+    p.TA = (int)cdiv(M, 32); p.TB = (int)cdiv(N, 32);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    p.off_pa = take((size_t)p.S * p.TA * p.KBc * 2048);
+    p.off_pb = take((size_t)p.S * p.TB * p.KBc * 2048);
+    p.off_ia = take((size_t)p.S * p.TA * 32 * 4);
+    p.off_ib = take((size_t)p.S * p.TB * 32 * 4);
+    p.off_part = take((size_t)p.S * M * N * 4);
+    p.off_max = take(256);
+    p.total = off;
+    return p;
+}
+
 }  // namespace
+
+// split GEMM of csrc/split3.hip
+int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
+                        int64_t ldc, hipStream_t stream, int batch, const float* a_inv_batched, const float* b_inv_batched);
 }  // namespace gvqa
 
 using namespace gvqa;
@@ -485,6 +609,65 @@ int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, con
     }
 #undef GVQA_HRB
     GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+size_t gvqa_linear_tn_workspace_bytes(int64_t R, int64_t M, int64_t N) {
+    if (R < 0 || M <= 0 || N <= 0) return 0;
+    return tn_plan(R, M, N).total;
+}
+
+int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy,
+                           const float* x_absmax, const float* y_absmax, float* C, int64_t ldc, void* ws, size_t ws_bytes,
+                           void* stream) {
+    GVQA_REQUIRE(R >= 0 && M > 0 && N > 0 && M < (1ll << 30) && N < (1ll << 30) && R < (1ll << 40), GVQA_E_INVALID, "linear_tn: bad size");
+    GVQA_REQUIRE(M % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldc % 4 == 0 && ldx >= M && ldy >= N && ldc >= N,
+                 GVQA_E_INVALID, "linear_tn: M, N and the leading dimensions must be multiples of 4");
+    GVQA_REQUIRE(C, GVQA_E_INVALID, "linear_tn: null result");
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        GVQA_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st));
+        return GVQA_OK;
+    }
+    GVQA_REQUIRE(X && Y && ws, GVQA_E_INVALID, "linear_tn: null operand");
+    const TnPlan p = tn_plan(R, M, N);
+    GVQA_REQUIRE(ws_bytes >= p.total, GVQA_E_WORKSPACE, "linear_tn: workspace too small (%zu < %zu)", ws_bytes, p.total);
+    char* base = static_cast<char*>(ws);
+    uint16_t* PA = reinterpret_cast<uint16_t*>(base + p.off_pa);
+    uint16_t* PB = reinterpret_cast<uint16_t*>(base + p.off_pb);
+    float* IA = reinterpret_cast<float*>(base + p.off_ia);
+    float* IB = reinterpret_cast<float*>(base + p.off_ib);
+    float* part = reinterpret_cast<float*>(base + p.off_part);
+    unsigned* mx = reinterpret_cast<unsigned*>(base + p.off_max);
+    if (!x_absmax || !y_absmax) {
+        GVQA_HIP_CHECK(hipMemsetAsync(mx, 0, 8, st));
+        if (!x_absmax) {
+            hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)M, X, ldx, mx);
+            x_absmax = reinterpret_cast<const float*>(mx);
+        }
+        if (!y_absmax) {
+            hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)N, Y, ldy, mx + 1);
+            y_absmax = reinterpret_cast<const float*>(mx + 1);
+        }
+        GVQA_LAUNCH_CHECK();
+    }
+    const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
+    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(M, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax, p.KC,
+                       p.TA, PA, IA);
+    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(N, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax, p.KC,
+                       p.TB, PB, IB);
+    GVQA_LAUNCH_CHECK();
+    LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
+    ep.zs_a = (int64_t)p.TA * p.KBc * 1024; ep.zs_b = (int64_t)p.TB * p.KBc * 1024; ep.zs_c = M * N;
+    ep.zs_ia = (int64_t)p.TA * 32; ep.zs_ib = (int64_t)p.TB * 32;
+    float* dst = p.S == 1 ? C : part;
+    const int rc = launch_linear_split(2, M, N, p.KC, PA, PB, ep, dst, p.S == 1 ? ldc : N, st, p.S, IA, IB);
+    if (rc != GVQA_OK) return rc;
+    if (p.S > 1) {
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<int64_t>(cdiv(M * (N / 4), 256), 4096)), dim3(256), 0, st, p.S, (int)M, (int)N,
+                           part, C, ldc);
+        GVQA_LAUNCH_CHECK();
+    }
     return GVQA_OK;
 }
 

@@ -63,8 +63,8 @@ def _workspace(nbytes: int, device) -> Tensor:
 class _ProjectionLinear(torch.autograd.Function):
     """y = x W^T for the hop projection of the differentiable path (gat_skip.py:133): the forward product runs on the library's
     own GEMMs -- the arithmetic GVQA_OPT_PROJECTION selects (two-piece fp16 / three-piece bf16 split on the 16-bit matrix cores,
-    or the f32-input MFMA kernel), exactly as in the eval path -- and so does dx = dy W in the backward; dW = dy^T x (a [HC, Dn]
-    result reduced over all N rows: a split-K shape the library has no kernel for) is a torch matmul.
+    or the f32-input MFMA kernel), exactly as in the eval path -- and so do dx = dy W and dW = dy^T x (a [HC, Dn] result reduced
+    over all N rows: the library's transposed-pack split-K product, gvqa_linear_tn_split2h) in the backward.
     `w` may be a column slice of a wider weight (its row stride is passed on)."""
 
     @staticmethod
@@ -104,8 +104,29 @@ class _ProjectionLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dx = dy W = dy (W^T)^T: the same kernels with the (small) weight transposed
             gx = _ProjectionLinear._product(gy.contiguous(), w.t().contiguous())
-        gw = gy.t() @ x if ctx.needs_input_grad[1] else None
+        gw = _ProjectionLinear._weight_grad(gy, x) if ctx.needs_input_grad[1] else None
         return gx, gw
+
+    @staticmethod
+    def _weight_grad(gy, x):
+        """dW = dy^T x, a reduction over all rows: the library's split-K product on the fp16 matrix cores (gvqa_linear_tn_split2h)
+        under the two-piece arithmetic, torch's fp32 matmul otherwise (small products, other GVQA_OPT_PROJECTION settings)."""
+        lib = _lib.load()
+        R, M = gy.shape
+        N = x.shape[1]
+        ok = (gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and M % 4 == 0 and N % 4 == 0 and R > 0 and
+              x.stride(1) == 1 and x.stride(0) % 4 == 0 and lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H and
+              2.0 * R * M * N >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
+        if not ok:
+            return gy.t() @ x
+        gy = gy.contiguous()
+        dev = gy.device
+        gw = torch.empty((M, N), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = _workspace(lib.gvqa_linear_tn_workspace_bytes(R, M, N), dev)
+            _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, gy.data_ptr(), M, x.data_ptr(), x.stride(0), None, None, gw.data_ptr(), N,
+                                                  ws.data_ptr(), ws.numel(), _stream(dev)))
+        return gw
 
 
 class _SkinnyLinear(torch.autograd.Function):

@@ -283,6 +283,17 @@ int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X,
 int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, const float* V, const float* addend,
                                int64_t ld_add, float* dX, int64_t ldx, void* stream);
 
+/* C[M, N] = X^T Y for X [R, M], Y [R, N] (row strides ldx / ldy): the weight gradient dW = dy^T x of the hop projection under
+ * autograd (torch.nn.Linear's backward at gat_skip.py:133 -- a reduction over all R = N_nodes rows).  Both operands are packed
+ * transposed into two-piece fp16 fragments (one power-of-two scale per operand), the split GEMM of gvqa_linear_split2h runs over
+ * split-K chunks of rows (gridDim.z), and the partial results are added in a fixed order (no atomics).  x_absmax / y_absmax:
+ * device pointers to one float >= max|X| / max|Y| when the producer knows it, else NULL (computed here, one extra pass).
+ * M, N, ldx, ldy, ldc multiples of 4. */
+size_t gvqa_linear_tn_workspace_bytes(int64_t R, int64_t M, int64_t N);
+int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy,
+                           const float* x_absmax, const float* y_absmax, float* C, int64_t ldc, void* ws, size_t ws_bytes,
+                           void* stream);
+
 /* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls
  * made afterwards (benchmarks and tests compare modes inside one process).  Workspace sizes depend on

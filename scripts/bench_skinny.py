@@ -23,3 +23,15 @@ for R, D, J in ((65536, 512, 8), (262144, 512, 20), (29785, 300, 8)):
     print(json.dumps({"R": R, "D": D, "J": J, "forward_us": round(f, 1), "forward_TBps": round(b / f / 1e6, 2), "dV_us": round(w, 1),
                       "dV_TBps": round(b / w / 1e6, 2), "dX_us": round(i, 1), "dX_TBps": round(b / i / 1e6, 2),
                       "torch_mm_us": [round(t_f, 1), round(t_w, 1), round(t_i, 1)]}))
+
+# the weight-gradient product dW = dy^T x (gvqa_linear_tn_split2h) against torch's fp32 matmul
+for R, M, N in ((65536, 2048, 512), (29785, 1200, 300)):
+    X = torch.randn(R, M, device=dev); Y = torch.randn(R, N, device=dev); Cc = torch.empty(M, N, device=dev)
+    ws = torch.empty(lib.gvqa_linear_tn_workspace_bytes(R, M, N), dtype=torch.uint8, device=dev)
+    mx = torch.tensor([float(X.abs().max()), float(Y.abs().max())], device=dev)
+    t_all = timed(lambda: lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), M, Y.data_ptr(), N, None, None, Cc.data_ptr(), N, ws.data_ptr(), ws.numel(), st))
+    t_known = timed(lambda: lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), M, Y.data_ptr(), N, mx.data_ptr(), mx.data_ptr() + 4, Cc.data_ptr(), N, ws.data_ptr(), ws.numel(), st))
+    t_torch = timed(lambda: torch.mm(X.t(), Y))
+    ref = X.double().t() @ Y.double()
+    print(json.dumps({"tn_product": [R, M, N], "us": round(t_all, 1), "us_with_known_maxima": round(t_known, 1), "torch_mm_us": round(t_torch, 1),
+                      "max_err_vs_fp64": float((Cc.double() - ref).abs().max()), "torch_max_err_vs_fp64": float((torch.mm(X.t(), Y).double() - ref).abs().max())}))

@@ -584,3 +584,32 @@ def test_message_passing_with_per_graph_rows_kept_out_of_xp(dev, C, H, with_mask
     assert maxabs(out, ref_out) < 2e-5 and maxabs(alpha, ref_alpha) < 1e-6
     for got, ref, name in zip(xs, rs, ("dxp", "da_node", "da_edge", "d_graph_rows")):
         assert _rel(got.grad, ref.grad) < 2e-5, name
+
+
+@pytest.mark.parametrize("R,M,N,ldx", [(5000, 256, 128, 256), (65536, 2048, 512, 2048), (1000, 36, 300, 40), (63, 512, 512, 512),
+                                       (70001, 1200, 300, 1200), (0, 64, 32, 64)])
+def test_transposed_split_product_vs_fp64(dev, R, M, N, ldx):
+    """gvqa_linear_tn_split2h: C = X^T Y (the weight gradient of the hop projection) against an fp64 product, next to torch's own
+    fp32 matmul on the same operands; ragged R / M / N, a strided X, columns of very different magnitude, the empty case."""
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(R + M + N)
+    X = torch.randn((max(R, 1), ldx), generator=g).to(dev)[:R]
+    Y = torch.randn((max(R, 1), N), generator=g).to(dev)[:R]
+    if R:
+        X[:, : M // 2] *= 1e-3                       # half of the columns far below the operand's largest magnitude
+        Y[:, ::3] *= 50.0
+    C_ = torch.full((M, N), 3.0, device=dev)
+    ws = torch.empty(max(lib.gvqa_linear_tn_workspace_bytes(R, M, N), 256), dtype=torch.uint8, device=dev)
+    _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), ldx, Y.data_ptr(), N, None, None, C_.data_ptr(), N, ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream().cuda_stream))
+    ref = X[:, :M].double().t() @ Y.double()
+    if R == 0:
+        assert bool((C_ == 0).all())
+        return
+    # error relative to what the sum can resolve: |X|^T |Y| (the bound fp32 matmul itself is held to)
+    bound = (X[:, :M].double().abs().t() @ Y.double().abs())
+    err = float(((C_.double() - ref).abs() / bound.clamp_min(1e-30)).max())
+    err_torch = float((((X[:, :M].t() @ Y).double() - ref).abs() / bound.clamp_min(1e-30)).max())
+    assert err <= max(2e-6, 2.0 * err_torch), (err, err_torch)
+    assert float((C_.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
