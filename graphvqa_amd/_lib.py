@@ -63,12 +63,16 @@ class GatMpDesc(C.Structure):
                 ("alpha_out", C.c_void_p), ("alpha_mask", C.c_void_p), ("force", C.c_int32)]
 
 
+ABSMAX_SLOTS = 256        # GVQA_ABSMAX_SLOTS
+
+
 class GatMpBwdDesc(C.Structure):
     """Mirror of `struct gvqa_gat_mp_bwd_desc`."""
     _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("negative_slope", C.c_float), ("xp", C.c_void_p), ("xp_ld", C.c_int64),
                 ("a_node", C.c_void_p), ("a_edge", C.c_void_p), ("a_edge_stride", C.c_int64), ("alpha", C.c_void_p),
                 ("alpha_mask", C.c_void_p), ("dout", C.c_void_p), ("dout_ld", C.c_int64), ("dxp", C.c_void_p),
-                ("dxp_ld", C.c_int64), ("da_node", C.c_void_p), ("da_edge", C.c_void_p), ("dalpha_node", C.c_void_p)]
+                ("dxp_ld", C.c_int64), ("da_node", C.c_void_p), ("da_edge", C.c_void_p), ("dalpha_node", C.c_void_p),
+                ("dxp_absmax", C.c_void_p)]
 
 
 class BnParams(C.Structure):
@@ -220,7 +224,7 @@ PROTOTYPES = {
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_linear_tn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "gvqa_linear_tn_split2h": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                         C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_skinny_forward": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_skinny_backward_weight_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "gvqa_skinny_backward_weight": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

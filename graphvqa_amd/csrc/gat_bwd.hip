@@ -62,6 +62,7 @@ struct BwdArgs {
                                        // s[i,h] = sum_e alpha mask -- the per-graph rows of the projection folded out of xp)
     const float* dout; int64_t dout_ld;
     float* dxp; int64_t dxp_ld;
+    unsigned* dxp_absmax;              // NULL or [GVQA_ABSMAX_SLOTS] (zeroed): largest |dxp| per slot, as uint bit patterns
     float* da_node;                    // [N, 2H]
     float* da_edge;                    // [E, H]
     // forward graph (CSR by destination) and transposed graph (CSR by source)
@@ -261,6 +262,18 @@ __global__ __launch_bounds__(256) void k_gat_mp_bwd_src(BwdArgs a) {
                 }
             }
         }
+    }
+    if (a.dxp_absmax) {      // largest magnitude of the rows this wave writes (the scale of the weight-gradient product's operand)
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int q = 0; q < W; ++q) m = fmaxf(m, fabsf(acc[h][k][q]));      // (unused heads / channels hold zeros)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) atomicMax(a.dxp_absmax + (j & (GVQA_ABSMAX_SLOTS - 1)), __float_as_uint(m));
     }
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
@@ -518,11 +531,13 @@ extern "C" int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, c
     a.alpha = d->alpha; a.mask = d->alpha_mask; a.dsum = d->dalpha_node;
     a.dout = d->dout; a.dout_ld = d->dout_ld ? d->dout_ld : C;
     a.dxp = d->dxp; a.dxp_ld = d->dxp_ld ? d->dxp_ld : (int64_t)H * C;
+    a.dxp_absmax = reinterpret_cast<unsigned*>(d->dxp_absmax);
     a.da_node = d->da_node; a.da_edge = d->da_edge;
     a.rowptr = g->rowptr; a.csr_src = g->csr_src; a.csr_eid = g->csr_eid;
     a.t_rowptr = gt->rowptr; a.t_csr_dst = gt->csr_src; a.t_csr_eid = gt->csr_eid;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageTimer timer(GVQA_STAGE_MP, stream);
+    if (a.dxp_absmax) GVQA_HIP_CHECK(hipMemsetAsync(a.dxp_absmax, 0, GVQA_ABSMAX_SLOTS * sizeof(unsigned), stream));
     const bool vec = C % 4 == 0 && a.xp_ld % 4 == 0 && a.dout_ld % 4 == 0 && a.dxp_ld % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.xp) | reinterpret_cast<uintptr_t>(a.dout) |
                        reinterpret_cast<uintptr_t>(a.dxp)) & 15) == 0;

@@ -380,9 +380,10 @@ __global__ __launch_bounds__(256) void k_absmax(int64_t rows, int cols, const fl
 constexpr int TN_SLAB_ROWS = 64, TN_SLAB_COLS = 256, TN_LDS_LD = 260;
 // grid (ceil(M / 256), S * KC / 64); a workgroup turns a [64 rows x 256 columns] slab of X into 4 k blocks x 8 column tiles
 __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const float* __restrict__ X, int64_t ldx,
-                                                        const float* __restrict__ absmax, int KC, int T, uint16_t* __restrict__ P,
-                                                        float* __restrict__ inv) {
+                                                        const float* __restrict__ absmax, int nmax, int KC, int T,
+                                                        uint16_t* __restrict__ P, float* __restrict__ inv) {
     __shared__ float Xs[TN_SLAB_ROWS * TN_LDS_LD];
+    __shared__ float mx_s[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * TN_SLAB_ROWS;
     const int c0 = blockIdx.x * TN_SLAB_COLS;
@@ -397,10 +398,16 @@ __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const 
         v.x *= m; v.y *= m; v.z *= m; v.w *= m;
         *reinterpret_cast<float4*>(&Xs[row * TN_LDS_LD + c]) = v;
     }
-    const int e = split2h_exponent(*absmax);
+    {   // the operand's largest magnitude = the maximum over the producer's slices
+        float m = tid < nmax ? absmax[tid] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) mx_s[wave] = m;
+    }
+    __syncthreads();
+    const int e = split2h_exponent(fmaxf(fmaxf(mx_s[0], mx_s[1]), fmaxf(mx_s[2], mx_s[3])));
     const float scale = pow2i(e);
     if (kb0 == 0 && c0 + tid < T * 32) inv[(int64_t)z * T * 32 + c0 + tid] = pow2i(-e);
-    __syncthreads();
     const int mloc = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -618,8 +625,10 @@ size_t gvqa_linear_tn_workspace_bytes(int64_t R, int64_t M, int64_t N) {
 }
 
 int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy,
-                           const float* x_absmax, const float* y_absmax, float* C, int64_t ldc, void* ws, size_t ws_bytes,
-                           void* stream) {
+                           const float* x_absmax, int x_absmax_n, const float* y_absmax, int y_absmax_n, float* C, int64_t ldc,
+                           void* ws, size_t ws_bytes, void* stream) {
+    GVQA_REQUIRE((!x_absmax || (x_absmax_n >= 1 && x_absmax_n <= GVQA_ABSMAX_SLOTS)) && (!y_absmax || (y_absmax_n >= 1 && y_absmax_n <= GVQA_ABSMAX_SLOTS)),
+                 GVQA_E_INVALID, "linear_tn: 1 <= absmax count <= %d", GVQA_ABSMAX_SLOTS);
     GVQA_REQUIRE(R >= 0 && M > 0 && N > 0 && M < (1ll << 30) && N < (1ll << 30) && R < (1ll << 40), GVQA_E_INVALID, "linear_tn: bad size");
     GVQA_REQUIRE(M % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldc % 4 == 0 && ldx >= M && ldy >= N && ldc >= N,
                  GVQA_E_INVALID, "linear_tn: M, N and the leading dimensions must be multiples of 4");
@@ -643,19 +652,19 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
         GVQA_HIP_CHECK(hipMemsetAsync(mx, 0, 8, st));
         if (!x_absmax) {
             hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)M, X, ldx, mx);
-            x_absmax = reinterpret_cast<const float*>(mx);
+            x_absmax = reinterpret_cast<const float*>(mx); x_absmax_n = 1;
         }
         if (!y_absmax) {
             hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)N, Y, ldy, mx + 1);
-            y_absmax = reinterpret_cast<const float*>(mx + 1);
+            y_absmax = reinterpret_cast<const float*>(mx + 1); y_absmax_n = 1;
         }
         GVQA_LAUNCH_CHECK();
     }
     const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
-    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(M, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax, p.KC,
-                       p.TA, PA, IA);
-    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(N, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax, p.KC,
-                       p.TB, PB, IB);
+    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(M, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax, x_absmax_n,
+                       p.KC, p.TA, PA, IA);
+    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(N, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax, y_absmax_n,
+                       p.KC, p.TB, PB, IB);
     GVQA_LAUNCH_CHECK();
     LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
     ep.zs_a = (int64_t)p.TA * p.KBc * 1024; ep.zs_b = (int64_t)p.TB * p.KBc * 1024; ep.zs_c = M * N;

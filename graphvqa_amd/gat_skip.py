@@ -119,13 +119,15 @@ class _ProjectionLinear(torch.autograd.Function):
               2.0 * R * M * N >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
         if not ok:
             return gy.t() @ x
+        # the producer of dy may have left its largest magnitudes with the tensor (the message-passing backward does): no pass over dy
+        am = getattr(gy, "_gvqa_absmax", None) if gy.is_contiguous() else None
         gy = gy.contiguous()
         dev = gy.device
         gw = torch.empty((M, N), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_linear_tn_workspace_bytes(R, M, N), dev)
-            _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, gy.data_ptr(), M, x.data_ptr(), x.stride(0), None, None, gw.data_ptr(), N,
-                                                  ws.data_ptr(), ws.numel(), _stream(dev)))
+            _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, gy.data_ptr(), M, x.data_ptr(), x.stride(0), _ptr(am), 0 if am is None else am.numel(),
+                                                  None, 0, gw.data_ptr(), N, ws.data_ptr(), ws.numel(), _stream(dev)))
         return gw
 
 
@@ -245,9 +247,12 @@ class _GatMessagePassing(torch.autograd.Function):
         d.alpha, d.alpha_mask, d.dout = alpha.data_ptr(), _ptr(mask), dout.data_ptr()
         d.dxp, d.da_node, d.da_edge = dxp.data_ptr(), da_node.data_ptr(), da_edge.data_ptr()
         d.dalpha_node = _ptr(ds)
+        am = torch.empty(_lib.ABSMAX_SLOTS, dtype=torch.float32, device=dev)      # largest |dxp| in slices, for the consumer of dxp
+        d.dxp_absmax = am.data_ptr()
         with torch.cuda.device(dev):
             gt = graph.transposed()
             _lib.check(lib.gvqa_gat_mp_backward(C.byref(graph.c), C.byref(gt.c), C.byref(d), _stream(dev)))
+        dxp._gvqa_absmax = am
         return dxp, da_node, da_edge, None, None, None, None, None, d_rows
 
 

@@ -287,12 +287,13 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
  * autograd (torch.nn.Linear's backward at gat_skip.py:133 -- a reduction over all R = N_nodes rows).  Both operands are packed
  * transposed into two-piece fp16 fragments (one power-of-two scale per operand), the split GEMM of gvqa_linear_split2h runs over
  * split-K chunks of rows (gridDim.z), and the partial results are added in a fixed order (no atomics).  x_absmax / y_absmax:
- * device pointers to one float >= max|X| / max|Y| when the producer knows it, else NULL (computed here, one extra pass).
+ * device pointers to x_absmax_n / y_absmax_n (<= GVQA_ABSMAX_SLOTS) floats whose maximum is >= max|X| / max|Y| when the
+ * producer knows it (gvqa_gat_mp_bwd_desc.dxp_absmax), else NULL (computed here, one extra pass over the operand).
  * M, N, ldx, ldy, ldc multiples of 4. */
 size_t gvqa_linear_tn_workspace_bytes(int64_t R, int64_t M, int64_t N);
 int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy,
-                           const float* x_absmax, const float* y_absmax, float* C, int64_t ldc, void* ws, size_t ws_bytes,
-                           void* stream);
+                           const float* x_absmax, int x_absmax_n, const float* y_absmax, int y_absmax_n, float* C, int64_t ldc,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls
@@ -389,6 +390,7 @@ int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, voi
  * gather / utils.softmax / scatter_add (gat_skip.py:155,183-208) and the head mean (:162-165); the "next"
  * row SURVEY 8f-4.  `g` is the forward graph, `gt` the TRANSPOSED one: gvqa_graph_build + finalize on the
  * flipped edge_index (row 0 <-> row 1) of the same batch.  Deterministic (no atomics). */
+#define GVQA_ABSMAX_SLOTS 256      /* slices of a largest-magnitude reduction (one atomic address each) */
 typedef struct gvqa_gat_mp_bwd_desc {
     int32_t C, H;
     float negative_slope;
@@ -408,6 +410,8 @@ typedef struct gvqa_gat_mp_bwd_desc {
     const float* dalpha_node;   /* NULL or [N, H]: a term added to dL/d(alpha[e,h]) of every in-edge e of node i, before the
                                    mask -- the gradient of s[i,h] = sum_{e->i} alpha mask when per-graph rows of the projection
                                    are kept out of xp (gvqa_graph_head_rows_add / _backward below)          */
+    float* dxp_absmax;          /* NULL or [GVQA_ABSMAX_SLOTS] floats (written): the largest |dxp| in slices -- the operand scale
+                                   gvqa_linear_tn_split2h takes, without a pass over dxp                     */
 } gvqa_gat_mp_bwd_desc;
 int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_gat_mp_bwd_desc* d, void* stream);
 

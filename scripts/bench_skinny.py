@@ -29,8 +29,8 @@ for R, M, N in ((65536, 2048, 512), (29785, 1200, 300)):
     X = torch.randn(R, M, device=dev); Y = torch.randn(R, N, device=dev); Cc = torch.empty(M, N, device=dev)
     ws = torch.empty(lib.gvqa_linear_tn_workspace_bytes(R, M, N), dtype=torch.uint8, device=dev)
     mx = torch.tensor([float(X.abs().max()), float(Y.abs().max())], device=dev)
-    t_all = timed(lambda: lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), M, Y.data_ptr(), N, None, None, Cc.data_ptr(), N, ws.data_ptr(), ws.numel(), st))
-    t_known = timed(lambda: lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), M, Y.data_ptr(), N, mx.data_ptr(), mx.data_ptr() + 4, Cc.data_ptr(), N, ws.data_ptr(), ws.numel(), st))
+    t_all = timed(lambda: lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), M, Y.data_ptr(), N, None, 0, None, 0, Cc.data_ptr(), N, ws.data_ptr(), ws.numel(), st))
+    t_known = timed(lambda: lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), M, Y.data_ptr(), N, mx.data_ptr(), 1, mx.data_ptr() + 4, 1, Cc.data_ptr(), N, ws.data_ptr(), ws.numel(), st))
     t_torch = timed(lambda: torch.mm(X.t(), Y))
     ref = X.double().t() @ Y.double()
     print(json.dumps({"tn_product": [R, M, N], "us": round(t_all, 1), "us_with_known_maxima": round(t_known, 1), "torch_mm_us": round(t_torch, 1),

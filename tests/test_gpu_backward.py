@@ -601,7 +601,7 @@ def test_transposed_split_product_vs_fp64(dev, R, M, N, ldx):
         Y[:, ::3] *= 50.0
     C_ = torch.full((M, N), 3.0, device=dev)
     ws = torch.empty(max(lib.gvqa_linear_tn_workspace_bytes(R, M, N), 256), dtype=torch.uint8, device=dev)
-    _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), ldx, Y.data_ptr(), N, None, None, C_.data_ptr(), N, ws.data_ptr(), ws.numel(),
+    _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), ldx, Y.data_ptr(), N, None, 0, None, 0, C_.data_ptr(), N, ws.data_ptr(), ws.numel(),
                                           torch.cuda.current_stream().cuda_stream))
     ref = X[:, :M].double().t() @ Y.double()
     if R == 0:
@@ -613,3 +613,34 @@ def test_transposed_split_product_vs_fp64(dev, R, M, N, ldx):
     err_torch = float((((X[:, :M].t() @ Y).double() - ref).abs() / bound.clamp_min(1e-30)).max())
     assert err <= max(2e-6, 2.0 * err_torch), (err, err_torch)
     assert float((C_.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_message_passing_backward_reports_the_largest_gradient_magnitude(dev):
+    """gvqa_gat_mp_bwd_desc.dxp_absmax: the slices' maximum equals max|dxp| exactly, and the weight-gradient product fed with it
+    equals the one that measures the operand itself."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_message_passing, _ProjectionLinear
+    from graphvqa_amd.graph import SceneGraphBatch
+    gb = synth.make_graph_batch(40, seed=77, nodes_lo=5, nodes_hi=40, rel_per_node=2.0)
+    N, E, H, C = gb.num_nodes, gb.num_edges, 4, 64
+    rng = np.random.default_rng(3)
+    g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, gb.num_graphs)
+    xp = t(rng.standard_normal((N, H * C)).astype(np.float32), device=dev).requires_grad_(True)
+    seen = {}
+    xp.register_hook(lambda gr: seen.setdefault("g", gr))
+    out, _ = gat_message_passing(xp, t(rng.standard_normal((N, 2 * H)).astype(np.float32), device=dev),
+                                 t(rng.standard_normal((E, H)).astype(np.float32), device=dev), g, H, C)
+    (out * t(rng.standard_normal((N, C)).astype(np.float32), device=dev)).sum().backward()
+    am = getattr(seen["g"], "_gvqa_absmax", None)
+    assert am is not None and am.numel() == _lib.ABSMAX_SLOTS
+    assert float(am.max()) == float(xp.grad.abs().max())
+    x = t(rng.standard_normal((N, 128)).astype(np.float32), device=dev)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        with_hint = _ProjectionLinear._weight_grad(seen["g"], x)
+        without = _ProjectionLinear._weight_grad(seen["g"].clone(), x)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    assert torch.equal(with_hint, without)
+    ref = seen["g"].double().t() @ x.double()
+    assert float((with_hint.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
