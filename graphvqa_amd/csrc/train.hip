@@ -444,6 +444,68 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(int S, int M, int N, cons
     }
 }
 
+// ---- attention vectors folded through a projection weight, and the adjoint (gvqa.h: gvqa_fold_attention_*) ----------------------
+// V[k, h] = sum_c W[h C + c, k] att_a[h C + c]  (and V[k, H + h] with att_b): grid (ceil(Kin / 64), H), 1024 threads = 64 columns
+// x 16 slices of c; the slices' sums are added in index order
+__global__ __launch_bounds__(1024) void k_fold_att_fwd(int H, int C, int Kin, const float* __restrict__ W, int64_t ldw,
+                                                       const float* __restrict__ att_a, const float* __restrict__ att_b,
+                                                       float* __restrict__ V, int J) {
+    __shared__ float pa[16][64], pb[16][64];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + col, h = blockIdx.y;
+    float sa = 0.f, sb = 0.f;
+    if (k < Kin) {
+        for (int c = part; c < C; c += 16) {
+            const int r = h * C + c;
+            const float w = W[(int64_t)r * ldw + k];
+            sa = fmaf(w, att_a[r], sa);
+            if (att_b) sb = fmaf(w, att_b[r], sb);
+        }
+    }
+    pa[part][col] = sa; pb[part][col] = sb;
+    __syncthreads();
+    if (part == 0 && k < Kin) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ta += pa[q][col]; tb += pb[q][col]; }
+        V[(int64_t)k * J + h] = ta;
+        if (att_b) V[(int64_t)k * J + H + h] = tb;
+    }
+}
+// dW[r, k] = att_a[r] dV[k, h] + att_b[r] dV[k, H + h]  (r = h C + c): a thread per (row, column)
+__global__ __launch_bounds__(256) void k_fold_att_bwd_w(int H, int C, int Kin, const float* __restrict__ att_a, const float* __restrict__ att_b,
+                                                        const float* __restrict__ dV, int J, float* __restrict__ dW, int64_t ld_dw) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Kin) return;
+    for (int r = blockIdx.y; r < H * C; r += gridDim.y) {
+        const int h = r / C;
+        float v = att_a[r] * dV[(int64_t)k * J + h];
+        if (att_b) v = fmaf(att_b[r], dV[(int64_t)k * J + H + h], v);
+        dW[(int64_t)r * ld_dw + k] = v;
+    }
+}
+// datt_a[r] = sum_k W[r, k] dV[k, h]  (and datt_b with dV[k, H + h]): a wave per row
+__global__ __launch_bounds__(256) void k_fold_att_bwd_att(int H, int C, int Kin, const float* __restrict__ W, int64_t ldw,
+                                                          const float* __restrict__ dV, int J, float* __restrict__ datt_a,
+                                                          float* __restrict__ datt_b) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= H * C) return;
+    const int h = r / C;
+    float sa = 0.f, sb = 0.f;
+    for (int k = lane; k < Kin; k += 64) {
+        const float w = W[(int64_t)r * ldw + k];
+        sa = fmaf(w, dV[(int64_t)k * J + h], sa);
+        if (datt_b) sb = fmaf(w, dV[(int64_t)k * J + H + h], sb);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+    if (lane == 0) {
+        datt_a[r] = sa;
+        if (datt_b) datt_b[r] = sb;
+    }
+}
+
 struct TnPlan {
     int S, KC, KBc, TA, TB;
     size_t off_pa, off_pb, off_ia, off_ib, off_part, off_max, total;
@@ -677,6 +739,34 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
                            part, C, ldc);
         GVQA_LAUNCH_CHECK();
     }
+    return GVQA_OK;
+}
+
+int gvqa_fold_attention_forward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
+                                float* V, void* stream) {
+    GVQA_REQUIRE(H >= 1 && H <= 65535 && C >= 1 && Kin >= 1 && ldw >= Kin && H * C < (1ll << 31) && Kin < (1ll << 31), GVQA_E_INVALID,
+                 "fold_attention_forward: bad sizes");
+    GVQA_REQUIRE(W && att_a && V, GVQA_E_INVALID, "fold_attention_forward: null tensor");
+    const int J = (int)(att_b ? 2 * H : H);
+    hipLaunchKernelGGL(k_fold_att_fwd, dim3((unsigned)cdiv(Kin, 64), (unsigned)H), dim3(1024), 0, (hipStream_t)stream, (int)H, (int)C, (int)Kin,
+                       W, ldw, att_a, att_b, V, J);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+int gvqa_fold_attention_backward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
+                                 const float* dV, float* dW, int64_t ld_dw, float* datt_a, float* datt_b, void* stream) {
+    GVQA_REQUIRE(H >= 1 && H <= 65535 && C >= 1 && Kin >= 1 && ldw >= Kin && H * C < (1ll << 31) && Kin < (1ll << 31), GVQA_E_INVALID,
+                 "fold_attention_backward: bad sizes");
+    GVQA_REQUIRE(W && att_a && dV && (!dW || ld_dw >= Kin) && (!att_b == !datt_b || !datt_a), GVQA_E_INVALID,
+                 "fold_attention_backward: null tensor / leading dimension");
+    hipStream_t st = (hipStream_t)stream;
+    const int J = (int)(att_b ? 2 * H : H);
+    if (dW) hipLaunchKernelGGL(k_fold_att_bwd_w, dim3((unsigned)cdiv(Kin, 256), (unsigned)std::min<int64_t>(H * C, 1024)), dim3(256), 0, st, (int)H,
+                               (int)C, (int)Kin, att_a, att_b, dV, J, dW, ld_dw);
+    if (datt_a) hipLaunchKernelGGL(k_fold_att_bwd_att, dim3((unsigned)cdiv(H * C, 4)), dim3(256), 0, st, (int)H, (int)C, (int)Kin, W, ldw, dV, J,
+                                   datt_a, att_b ? datt_b : nullptr);
+    GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
 

@@ -184,6 +184,49 @@ def skinny_linear(x: Tensor, V: Tensor) -> Tensor:
     return torch.cat([_SkinnyLinear.apply(x, V[:, j:j + 32]) for j in range(0, J, 32)], dim=1)
 
 
+class _FoldAttention(torch.autograd.Function):
+    """V [Kin, J]: the attention vectors folded through a projection weight, so that (x W^T * att).sum(-1) = x V
+    (gat_skip.py:134-135,151): V[k, h] = sum_c W[h C + c, k] att_a[h, c] and, with att_b, V[k, H + h] likewise (J = 2H).
+    Forward and adjoint are the library's kernels (gvqa_fold_attention_*), one launch each over W."""
+
+    @staticmethod
+    def forward(ctx, W, att_a, att_b, heads):
+        lib = _lib.load()
+        W = _f32c(W, "weight")
+        HC, Kin = W.shape
+        Cc = HC // heads
+        a = _f32c(att_a.reshape(-1), "att")
+        b = None if att_b is None else _f32c(att_b.reshape(-1), "att")
+        V = torch.empty((Kin, heads * (1 if b is None else 2)), dtype=torch.float32, device=W.device)
+        with torch.cuda.device(W.device):
+            _lib.check(lib.gvqa_fold_attention_forward(heads, Cc, Kin, W.data_ptr(), Kin, a.data_ptr(), _ptr(b), V.data_ptr(), _stream(W.device)))
+        ctx.save_for_backward(W, a, b)
+        ctx.heads, ctx.shapes = heads, (att_a.shape, None if att_b is None else att_b.shape)
+        return V
+
+    @staticmethod
+    def backward(ctx, dV):
+        lib = _lib.load()
+        W, a, b = ctx.saved_tensors
+        heads = ctx.heads
+        HC, Kin = W.shape
+        dV = dV.contiguous()
+        dW = torch.empty_like(W) if ctx.needs_input_grad[0] else None
+        want_att = ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2])
+        da = torch.empty_like(a) if want_att else None
+        db = torch.empty_like(b) if (want_att and b is not None) else None
+        with torch.cuda.device(W.device):
+            _lib.check(lib.gvqa_fold_attention_backward(heads, HC // heads, Kin, W.data_ptr(), Kin, a.data_ptr(), _ptr(b), dV.data_ptr(),
+                                                        _ptr(dW), Kin, _ptr(da), _ptr(db), _stream(W.device)))
+        sa, sb = ctx.shapes
+        return dW, (None if da is None else da.view(sa)), (None if db is None else db.view(sb)), None
+
+
+def fold_attention(W: Tensor, att_a: Tensor, att_b: Optional[Tensor], heads: int) -> Tensor:
+    """[Kin, H] (or [Kin, 2H] with att_b): attention vectors folded through the projection weight W [H*C, Kin]; differentiable."""
+    return _FoldAttention.apply(W, att_a, att_b, heads)
+
+
 class _GatMessagePassing(torch.autograd.Function):
     """out[i] = (1/H) sum_h sum_{e -> i} alpha[e,h] mask[e,h] xp[src_e, h, :],  alpha = softmax over the in-edges
     of leaky_relu(a_node[src,h] + a_node[dst,H+h] + a_edge[e,h])   (gat_skip.py:155,183-208,162-165).
@@ -539,11 +582,8 @@ class gat(torch.nn.Module):
         import torch.nn.functional as F
         H, Cc, N, E = self.heads, self.out_channels, x.shape[0], edge_index.shape[1]
         xp = F.linear(x, self.lin_l.weight)
-        W3, We3 = self.lin_l.weight.view(H, Cc, -1), self.lin_e.weight.view(H, Cc, -1)
-        V_n = torch.cat((torch.einsum("hck,hc->kh", W3, self.att_l.view(H, Cc)),
-                         torch.einsum("hck,hc->kh", W3, self.att_r.view(H, Cc))), dim=1)
-        a_node = x @ V_n
-        a_edge = edge_attr @ torch.einsum("hck,hc->kh", We3, self.att_e.view(H, Cc))
+        a_node = skinny_linear(x, fold_attention(self.lin_l.weight, self.att_l, self.att_r, H))
+        a_edge = skinny_linear(edge_attr, fold_attention(self.lin_e.weight, self.att_e, None, H))
         p = self.dropout if self.training else 0.0
         mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p) if p > 0 else None
         out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask)
@@ -780,23 +820,20 @@ class gat_seq(torch.nn.Module):
         h = x
         alphas, hops = [], []
         # edge logits of ALL hops in one pass over edge_attr (and one pass in the backward): the H columns of every hop side by side
-        V_e_all = torch.cat([torch.einsum("hck,hc->kh", c.lin_e.weight[:, :De].reshape(H, Cc, De), c.att_e.view(H, Cc))
-                             for c in self.convs], dim=1)
-        a_edge_all = skinny_linear(edge_attr, V_e_all)
+        # (att_e through lin_e, one launch per hop: rows [:De] act on edge_attr, rows [De:] on the instruction half, :257-260)
+        folds_e = [fold_attention(c.lin_e.weight, c.att_e, None, H) for c in self.convs]
+        a_edge_all = skinny_linear(edge_attr, torch.cat([f[:De] for f in folds_e], dim=1))
         for i, conv in enumerate(self.convs):
             ins = instr[i]
             W, We = conv.lin_l.weight, conv.lin_e.weight
-            Di = W.shape[1] - Dn
-            W_h3, W_i3 = W[:, :Dn].reshape(H, Cc, Dn), W[:, Dn:].reshape(H, Cc, Di)
-            att_l, att_r, att_e = conv.att_l.view(H, Cc), conv.att_r.view(H, Cc), conv.att_e.view(H, Cc)
             # projected features: node half per row, instruction half per graph
             # (the per-graph rows ride through the message passing as `graph_rows`: the [N, H*C] sum is never formed)
             xp, xp_rows = _ProjectionLinear.apply(h, W[:, :Dn]), F.linear(ins, W[:, Dn:])
             # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
             # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
-            V_n = torch.cat((torch.einsum("hck,hc->kh", W_h3, att_l), torch.einsum("hck,hc->kh", W_h3, att_r)), dim=1)
-            U_e = torch.einsum("hck,hc->kh", We[:, De:].reshape(H, Cc, We.shape[1] - De), att_e)
-            U_n = torch.cat((torch.einsum("hck,hc->kh", W_i3, att_l) + U_e, torch.einsum("hck,hc->kh", W_i3, att_r)), dim=1)
+            fold_n = fold_attention(W, conv.att_l, conv.att_r, H)              # [Dn + Di, 2H]: att_l | att_r through lin_l
+            V_n, U_e = fold_n[:Dn], folds_e[i][De:]
+            U_n = torch.cat((fold_n[Dn:, :H] + U_e, fold_n[Dn:, H:]), dim=1)
             a_node = add_graph_rows(skinny_linear(h, V_n), ins @ U_n, graph)
             a_edge = a_edge_all[:, i * H:(i + 1) * H]
             mask = None

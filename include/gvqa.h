@@ -283,6 +283,16 @@ int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X,
 int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, const float* V, const float* addend,
                                int64_t ld_add, float* dX, int64_t ldx, void* stream);
 
+/* Attention vectors folded through a projection weight (differentiable path): with W [H*C, Kin] (row stride ldw; lin_l or
+ * lin_e, gat_skip.py:133,150) and att [H*C] (att_l / att_r / att_e, :134-135,151), (x W^T * att).sum(-1) = x V with
+ *     V[k, h] = sum_c W[h C + c, k] att_a[h C + c],   V[k, H + h] = the same with att_b     (V [Kin, J], J = 2H, or H when att_b is NULL)
+ * and the adjoint: dW[r, k] = att_a[r] dV[k, h(r)] + att_b[r] dV[k, H + h(r)] (written, row stride ld_dw; NULL: skipped),
+ * datt_a[r] = sum_k W[r, k] dV[k, h(r)] (NULL: skipped), datt_b likewise.  Fixed summation order. */
+int gvqa_fold_attention_forward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
+                                float* V, void* stream);
+int gvqa_fold_attention_backward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
+                                 const float* dV, float* dW, int64_t ld_dw, float* datt_a, float* datt_b, void* stream);
+
 /* C[M, N] = X^T Y for X [R, M], Y [R, N] (row strides ldx / ldy): the weight gradient dW = dy^T x of the hop projection under
  * autograd (torch.nn.Linear's backward at gat_skip.py:133 -- a reduction over all R = N_nodes rows).  Both operands are packed
  * transposed into two-piece fp16 fragments (one power-of-two scale per operand), the split GEMM of gvqa_linear_split2h runs over

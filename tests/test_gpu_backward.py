@@ -644,3 +644,26 @@ def test_message_passing_backward_reports_the_largest_gradient_magnitude(dev):
     assert torch.equal(with_hint, without)
     ref = seen["g"].double().t() @ x.double()
     assert float((with_hint.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("H,C,Kin,two", [(4, 512, 1024, True), (4, 300, 812, True), (1, 30, 17, False), (8, 64, 100, True), (2, 5, 3, False)])
+def test_fold_attention_vs_fp64_einsum(dev, H, C, Kin, two):
+    """gvqa_fold_attention_forward / _backward against the fp64 einsum they replace: V = att folded through W, dW, datt."""
+    from graphvqa_amd.gat_skip import fold_attention
+    g = torch.Generator().manual_seed(H * 1000 + C + Kin)
+    W = torch.randn((H * C, Kin), generator=g).to(dev).requires_grad_(True)
+    a = torch.randn((1, H, C), generator=g).to(dev).requires_grad_(True)
+    b = torch.randn((1, H, C), generator=g).to(dev).requires_grad_(True) if two else None
+    G = torch.randn((Kin, H * (2 if two else 1)), generator=g).to(dev)
+    V = fold_attention(W, a, b, H)
+    (V * G).sum().backward()
+    Wd, ad = W.detach().double().requires_grad_(True), a.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True) if two else None
+    ref = torch.einsum("hck,hc->kh", Wd.view(H, C, Kin), ad.view(H, C))
+    if two:
+        ref = torch.cat((ref, torch.einsum("hck,hc->kh", Wd.view(H, C, Kin), bd.view(H, C))), dim=1)
+    (ref * G.double()).sum().backward()
+    assert _rel(V.detach(), ref) < 2e-6 and _rel(W.grad, Wd.grad) < 2e-6 and _rel(a.grad, ad.grad) < 2e-6
+    assert a.grad.shape == a.shape
+    if two:
+        assert _rel(b.grad, bd.grad) < 2e-6
