@@ -219,9 +219,10 @@ PROTOTYPES = {
                                            C.c_void_p]),
     "gvqa_graph_edge_rows_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_graph_segment_sum": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
-    "gvqa_graph_head_rows_add": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gvqa_graph_head_rows_add": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_graph_head_rows_backward": (C.c_int, [C.POINTER(Graph), C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_linear_tn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "gvqa_linear_tn_split2h": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -34,22 +34,28 @@ __global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const fl
     partial[(int64_t)blockIdx.x * C + c] = (a0 + a1) + (a2 + a3);
 }
 
-// out[c] = scale * sum_b partial[b * blk_stride + c]: a block owns 16 columns, its 16 thread rows sum interleaved
-// row blocks, then an LDS tree -- 32 blocks and 16-deep load chains instead of 2 blocks and nblocks-deep ones.
-__global__ __launch_bounds__(256) void k_bn_col_finish(int nblocks, int C, const float* __restrict__ partial, int64_t blk_stride,
-                                                       float scale, float* __restrict__ out) {
-    __shared__ float red[16][17];
+// out[c] = scale * sum_b partial[b * blk_stride + c]: a block owns 16 columns, its 64 thread rows sum interleaved
+// row blocks (16-deep load chains at 1024 row blocks), then the 64 sums are added in index order
+__global__ __launch_bounds__(1024) void k_bn_col_finish(int nblocks, int C, const float* __restrict__ partial, int64_t blk_stride,
+                                                        float scale, float* __restrict__ out) {
+    __shared__ float red[64][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
-    float acc = 0.f;
-    if (c < C)
-        for (int b = ry; b < nblocks; b += 16) acc += partial[(int64_t)b * blk_stride + c];
-    red[ry][cx] = acc;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int b = ry;
+        for (; b + 64 < nblocks; b += 128) {
+            a0 += partial[(int64_t)b * blk_stride + c];
+            a1 += partial[(int64_t)(b + 64) * blk_stride + c];
+        }
+        if (b < nblocks) a0 += partial[(int64_t)b * blk_stride + c];
+    }
+    red[ry][cx] = a0 + a1;
     __syncthreads();
     if (ry == 0 && c < C) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        for (int k = 0; k < 64; ++k) t += red[k][cx];
         out[c] = t * scale;
     }
 }
@@ -119,9 +125,9 @@ extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, 
     GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
     const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
     hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, nullptr, partial);
-    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_mean);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_mean);
     hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, save_mean, partial);
-    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_var);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_var);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
     hipLaunchKernelGGL(k_bn_relu_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, x, save_mean, save_var, weight, bias,
                        eps, y);
@@ -144,8 +150,8 @@ extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x,
     GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
     const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
     hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
-    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
-    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(256), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
     hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, 1.0f / (float)N, x, dy, save_mean,
                        save_var, weight, bias, eps, dbias, dweight, dx);

@@ -262,29 +262,40 @@ __global__ __launch_bounds__(256) void k_skinny_dx_any(int64_t R, int D, int J, 
 // ---- per-graph rows of the projection kept out of xp (gvqa.h: gvqa_graph_head_rows_*) ----------------------------------------
 constexpr int HR_MAXH = 8;
 
-// y[i, c..c+3] += (1/H) sum_h s[i,h] R[g(i), h, c..c+3]; a thread per (row, 4 channels)
+// y[i, c..c+3] += (1/H) sum_h s[i,h] R[g(i), h, c..c+3] + bias[c..] + skip[i, c..]; a thread per (row, 4 channels)
 template <int H>
 __global__ __launch_bounds__(256) void k_head_rows_add(int64_t N, int C, const int32_t* __restrict__ node_graph,
                                                        const int32_t* __restrict__ rowptr, const float* __restrict__ R,
-                                                       const float* __restrict__ s, float* __restrict__ y, int64_t ldy) {
+                                                       const float* __restrict__ s, const float* __restrict__ bias,
+                                                       const float* __restrict__ skip, int64_t ld_skip, float* __restrict__ y, int64_t ldy) {
     const int per_row = C >> 2;
     const int64_t total = N * per_row;
     const float inv_h = 1.0f / H;
     for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
         const int64_t i = it / per_row;
         const int c = (int)(it - i * per_row) * 4;
-        const float* r = R + (int64_t)node_graph[i] * H * C + c;
-        const float ones = rowptr[i + 1] > rowptr[i] ? 1.f : 0.f;      // s without a mask: 1, or 0 for a node without in-edges
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (R) {
+            const float* r = R + (int64_t)node_graph[i] * H * C + c;
+            const float ones = rowptr[i + 1] > rowptr[i] ? 1.f : 0.f;      // s without a mask: 1, or 0 for a node without in-edges
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float4 v = *reinterpret_cast<const float4*>(r + (int64_t)h * C);
-            const float w = s ? s[i * H + h] : ones;
-            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+            for (int h = 0; h < H; ++h) {
+                const float4 v = *reinterpret_cast<const float4*>(r + (int64_t)h * C);
+                const float w = s ? s[i * H + h] : ones;
+                acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+            }
         }
         float4* o = reinterpret_cast<float4*>(y + i * ldy + c);
         float4 cur = *o;
         cur.x = fmaf(acc.x, inv_h, cur.x); cur.y = fmaf(acc.y, inv_h, cur.y); cur.z = fmaf(acc.z, inv_h, cur.z); cur.w = fmaf(acc.w, inv_h, cur.w);
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + c);
+            cur.x += b.x; cur.y += b.y; cur.z += b.z; cur.w += b.w;
+        }
+        if (skip) {
+            const float4 k = *reinterpret_cast<const float4*>(skip + i * ld_skip + c);
+            cur.x += k.x; cur.y += k.y; cur.z += k.z; cur.w += k.w;
+        }
         *o = cur;
     }
 }
@@ -295,16 +306,18 @@ template <int H>
 __global__ __launch_bounds__(256) void k_head_rows_bwd(int C, const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ rowptr,
                                                        const float* __restrict__ dy, int64_t ld_dy,
                                                        const float* __restrict__ R, const float* __restrict__ s, float* __restrict__ dR,
-                                                       float* __restrict__ ds) {
+                                                       float* __restrict__ ds, float* __restrict__ dcol) {
     const int g = blockIdx.x;
     const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
     const float inv_h = 1.0f / H;
     for (int c = threadIdx.x * 4; c < C; c += 1024) {
         float4 acc[H];
+        float4 col = make_float4(0.f, 0.f, 0.f, 0.f);                  // sum over the graph's rows of dy (bias gradient, per graph)
 #pragma unroll
         for (int h = 0; h < H; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = n0; i < n1; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(dy + (int64_t)i * ld_dy + c);
+            col.x += v.x; col.y += v.y; col.z += v.z; col.w += v.w;
             const float ones = rowptr[i + 1] > rowptr[i] ? 1.f : 0.f;
 #pragma unroll
             for (int h = 0; h < H; ++h) {
@@ -313,10 +326,13 @@ __global__ __launch_bounds__(256) void k_head_rows_bwd(int C, const int32_t* __r
                 acc[h].z = fmaf(w, v.z, acc[h].z); acc[h].w = fmaf(w, v.w, acc[h].w);
             }
         }
+        if (dR) {
 #pragma unroll
-        for (int h = 0; h < H; ++h)
-            *reinterpret_cast<float4*>(dR + ((int64_t)g * H + h) * C + c) =
-                make_float4(acc[h].x * inv_h, acc[h].y * inv_h, acc[h].z * inv_h, acc[h].w * inv_h);
+            for (int h = 0; h < H; ++h)
+                *reinterpret_cast<float4*>(dR + ((int64_t)g * H + h) * C + c) =
+                    make_float4(acc[h].x * inv_h, acc[h].y * inv_h, acc[h].z * inv_h, acc[h].w * inv_h);
+        }
+        if (dcol) *reinterpret_cast<float4*>(dcol + (int64_t)g * C + c) = col;
     }
     if (!ds) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -631,17 +647,17 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
     return GVQA_OK;
 }
 
-int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, float* y, int64_t ld_y,
-                             void* stream) {
+int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, const float* bias,
+                             const float* skip, int64_t ld_skip, float* y, int64_t ld_y, void* stream) {
     GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_head_rows_add: graph not built");
     GVQA_REQUIRE(C > 0 && C % 4 == 0 && ld_y % 4 == 0 && ld_y >= C && H >= 1 && H <= HR_MAXH, GVQA_E_INVALID,
                  "graph_head_rows_add: C %% 4 == 0, 1 <= H <= %d", HR_MAXH);
     if (g->num_nodes == 0) return GVQA_OK;
-    GVQA_REQUIRE(R && y, GVQA_E_INVALID, "graph_head_rows_add: null tensor");
+    GVQA_REQUIRE(y && (!skip || (ld_skip % 4 == 0 && ld_skip >= C)), GVQA_E_INVALID, "graph_head_rows_add: null tensor / skip stride");
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = g->num_nodes * (C / 4);
     const int grid = (int)std::min<int64_t>(cdiv(total, 256), 16384);
-#define GVQA_HRA(HH) hipLaunchKernelGGL(k_head_rows_add<HH>, dim3(grid), dim3(256), 0, st, g->num_nodes, (int)C, g->node_graph, g->rowptr, R, s, y, ld_y)
+#define GVQA_HRA(HH) hipLaunchKernelGGL(k_head_rows_add<HH>, dim3(grid), dim3(256), 0, st, g->num_nodes, (int)C, g->node_graph, g->rowptr, R, s, bias, skip, ld_skip, y, ld_y)
     switch (H) {
         case 1: GVQA_HRA(1); break;
         case 2: GVQA_HRA(2); break;
@@ -658,14 +674,14 @@ int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const fl
 }
 
 int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, const float* dy, int64_t ld_dy, const float* R,
-                                  const float* s, float* dR, float* ds, void* stream) {
+                                  const float* s, float* dR, float* ds, float* dcol, void* stream) {
     GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_head_rows_backward: graph not built");
     GVQA_REQUIRE(C > 0 && C % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= C && H >= 1 && H <= HR_MAXH, GVQA_E_INVALID,
                  "graph_head_rows_backward: C %% 4 == 0, 1 <= H <= %d", HR_MAXH);
     if (g->num_graphs == 0) return GVQA_OK;
-    GVQA_REQUIRE(dR && (dy || g->num_nodes == 0) && (!ds || R), GVQA_E_INVALID, "graph_head_rows_backward: null tensor");
+    GVQA_REQUIRE((dR || dcol) && (dy || g->num_nodes == 0) && (!ds || R), GVQA_E_INVALID, "graph_head_rows_backward: null tensor");
     hipStream_t st = (hipStream_t)stream;
-#define GVQA_HRB(HH) hipLaunchKernelGGL(k_head_rows_bwd<HH>, dim3((unsigned)g->num_graphs), dim3(256), 0, st, (int)C, g->graph_ptr, g->rowptr, dy, ld_dy, R, s, dR, ds)
+#define GVQA_HRB(HH) hipLaunchKernelGGL(k_head_rows_bwd<HH>, dim3((unsigned)g->num_graphs), dim3(256), 0, st, (int)C, g->graph_ptr, g->rowptr, dy, ld_dy, R, s, dR, ds, dcol)
     switch (H) {
         case 1: GVQA_HRB(1); break;
         case 2: GVQA_HRB(2); break;

@@ -233,10 +233,11 @@ class _GatMessagePassing(torch.autograd.Function):
     Forward and backward are HIP kernels; returns (out [N, C], alpha [E, H]).
     `graph_rows` [B, H*C] (optional): rows added to xp per GRAPH -- the instruction half of lin_l([h | ins[batch]]),
     gat_skip.py:133,263-264 -- i.e. the op computes MP(xp + graph_rows[batch]) without forming that [N, H*C] sum or its adjoint:
-    out = MP(xp) + (1/H) sum_h s[i,h] graph_rows[g,h,:] with s[i,h] = sum_{e->i} alpha mask (gvqa_graph_head_rows_*)."""
+    out = MP(xp) + (1/H) sum_h s[i,h] graph_rows[g,h,:] with s[i,h] = sum_{e->i} alpha mask (gvqa_graph_head_rows_*).
+    `bias` [C] and `skip` [N, C] (optional) are added in the same pass (gat_skip.py:167-168, :270)."""
 
     @staticmethod
-    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope, graph_rows=None):
+    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope, graph_rows=None, bias=None, skip=None):
         lib = _lib.load()
         xp, a_node, a_edge = _f32c(xp, "xp"), _f32c(a_node, "a_node"), _f32c(a_edge, "a_edge")
         if mask is not None:
@@ -258,13 +259,20 @@ class _GatMessagePassing(torch.autograd.Function):
             ws = _workspace(4 * E * heads, dev)
             _lib.check(lib.gvqa_gat_message_passing(C.byref(graph.c), C.byref(m), ws.data_ptr(), ws.numel(), _stream(dev)))
             s = None
-            if graph_rows is not None:
-                if mask is not None:          # s[i,h] = sum over the in-edges of alpha * mask (1 when nothing is dropped)
+            if bias is not None:
+                bias = _f32c(bias, "bias")
+            if skip is not None:
+                skip = _f32c(skip, "skip")
+                if skip.shape != (N, channels):
+                    raise ValueError("gat_message_passing: skip must be [N, channels]")
+            if graph_rows is not None or bias is not None or skip is not None:
+                if graph_rows is not None and mask is not None:   # s[i,h] = sum over the in-edges of alpha * mask (1 when nothing is dropped)
                     s = _edge_rows_sum_raw(alpha * mask, graph)
-                _lib.check(lib.gvqa_graph_head_rows_add(C.byref(graph.c), channels, heads, graph_rows.data_ptr(), _ptr(s),
-                                                        out.data_ptr(), channels, _stream(dev)))
+                _lib.check(lib.gvqa_graph_head_rows_add(C.byref(graph.c), channels, heads, _ptr(graph_rows), _ptr(s), _ptr(bias), _ptr(skip),
+                                                        channels, out.data_ptr(), channels, _stream(dev)))
         ctx.save_for_backward(xp, a_node, a_edge, alpha, mask, graph_rows, s)
         ctx.graph, ctx.dims = graph, (heads, channels, slope)
+        ctx.has_bias, ctx.has_skip = bias is not None, skip is not None
         ctx.mark_non_differentiable(alpha)
         return out, alpha
 
@@ -276,14 +284,17 @@ class _GatMessagePassing(torch.autograd.Function):
         graph, dev = ctx.graph, xp.device
         dout = dout.contiguous()
         dxp, da_node, da_edge = torch.empty_like(xp), torch.empty_like(a_node), torch.empty_like(a_edge)
-        d_rows = ds = None
-        if graph_rows is not None:
-            d_rows = torch.empty_like(graph_rows)
-            if mask is not None:              # without a mask s == 1 and the term is constant under the softmax
-                ds = torch.empty((graph.num_nodes, heads), dtype=torch.float32, device=dev)
+        d_rows = ds = dcol = None
+        if graph_rows is not None or ctx.has_bias:
+            if graph_rows is not None:
+                d_rows = torch.empty_like(graph_rows)
+                if mask is not None:          # without a mask s == 1 and the term is constant under the softmax
+                    ds = torch.empty((graph.num_nodes, heads), dtype=torch.float32, device=dev)
+            if ctx.has_bias:                  # per-graph column sums of dout; their sum is the bias gradient
+                dcol = torch.empty((graph.num_graphs, channels), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(lib.gvqa_graph_head_rows_backward(C.byref(graph.c), channels, heads, dout.data_ptr(), channels,
-                                                             graph_rows.data_ptr(), _ptr(s), d_rows.data_ptr(), _ptr(ds), _stream(dev)))
+                _lib.check(lib.gvqa_graph_head_rows_backward(C.byref(graph.c), channels, heads, dout.data_ptr(), channels, _ptr(graph_rows),
+                                                             _ptr(s), _ptr(d_rows), _ptr(ds), _ptr(dcol), _stream(dev)))
         d = _lib.GatMpBwdDesc()
         d.C, d.H, d.negative_slope = channels, heads, slope
         d.xp, d.a_node, d.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
@@ -296,7 +307,8 @@ class _GatMessagePassing(torch.autograd.Function):
             gt = graph.transposed()
             _lib.check(lib.gvqa_gat_mp_backward(C.byref(graph.c), C.byref(gt.c), C.byref(d), _stream(dev)))
         dxp._gvqa_absmax = am
-        return dxp, da_node, da_edge, None, None, None, None, None, d_rows
+        d_bias = dcol.sum(0) if dcol is not None else None
+        return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, (dout if ctx.has_skip else None)
 
 
 class _BatchNormReluTrain(torch.autograd.Function):
@@ -509,11 +521,13 @@ def graph_softmax(score: Tensor, graph: SceneGraphBatch) -> Tensor:
 
 
 def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: SceneGraphBatch, heads: int, channels: int,
-                        negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None, graph_rows: Optional[Tensor] = None):
+                        negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None, graph_rows: Optional[Tensor] = None,
+                        bias: Optional[Tensor] = None, skip: Optional[Tensor] = None):
     """Differentiable GAT message passing on the HIP kernels: (out [N, C], alpha [E, H]).
     xp [N, H*C] projected features, a_node [N, 2H] = (a_l | a_r), a_edge [E, H]; alpha_mask [E, H] multiplies alpha
-    after the softmax (attention dropout: mask / (1 - p)); graph_rows [B, H*C]: rows added to xp per graph (kept out of xp)."""
-    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, graph_rows)
+    after the softmax (attention dropout: mask / (1 - p)); graph_rows [B, H*C]: rows added to xp per graph (kept out of xp);
+    bias [C], skip [N, C]: added to the result in the same pass."""
+    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, graph_rows, bias, skip)
 
 
 class gat(torch.nn.Module):
@@ -841,10 +855,9 @@ class gat_seq(torch.nn.Module):
                 mask = alpha_masks[i]
             elif p > 0:
                 mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p)
-            out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask, graph_rows=xp_rows)
-            if conv.bias is not None:
-                out = out + conv.bias
-            h = out + h
+            # aggregation + head mean (:155-165) + bias (:167-168) + skip (:270) in one op
+            h, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask, graph_rows=xp_rows,
+                                           bias=conv.bias, skip=h)
             if i != K - 1:
                 h = _bn_relu_train(self.bns[i], h) if self.training else torch.relu(self.bns[i](h))
                 if feature_masks is not None:

@@ -429,14 +429,16 @@ int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_g
  * 263-264): xp[i,h,:] = xp_node[i,h,:] + R[g(i),h,:] with R = ins W_i^T one row per GRAPH.  The aggregation is linear in xp, so
  *     out[i,:] = MP(xp_node)[i,:] + (1/H) sum_h s[i,h] R[g(i),h,:],   s[i,h] = sum_{e->i} alpha[e,h] mask[e,h]   (without a mask: 1, or 0 for a node with no in-edge)
  * and the [N, H*C] sum xp_node + R[batch] (and its adjoint, a segment sum over [N, H*C]) is never formed:
- *   gvqa_graph_head_rows_add       y[i,:] += (1/H) sum_h s[i,h] R[g(i),h,:]                (s NULL: the mask-free values)
- *   gvqa_graph_head_rows_backward  dR[g,h,:] = (1/H) sum_{i in g} s[i,h] dy[i,:];  ds[i,h] = (1/H) dy[i,:] . R[g(i),h,:]
- *                                  (ds NULL: not computed; it is what gvqa_gat_mp_bwd_desc.dalpha_node takes)
- * R / dR [B, H*C] contiguous, y / dy [N, C] with row strides, s / ds [N, H] contiguous.  C % 4 == 0, H <= 8. */
-int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, float* y, int64_t ld_y,
-                             void* stream);
+ *   gvqa_graph_head_rows_add       y[i,:] += (1/H) sum_h s[i,h] R[g(i),h,:] + bias[:] + skip[i,:]   (s NULL: the mask-free values;
+ *                                  R / bias / skip NULL: term absent -- bias gat_skip.py:167-168 and the skip connection :270 ride along)
+ *   gvqa_graph_head_rows_backward  dR[g,h,:] = (1/H) sum_{i in g} s[i,h] dy[i,:];  ds[i,h] = (1/H) dy[i,:] . R[g(i),h,:];
+ *                                  dcol[g,:] = sum_{i in g} dy[i,:] (the bias gradient per graph)   (each output NULL: not computed;
+ *                                  ds is what gvqa_gat_mp_bwd_desc.dalpha_node takes)
+ * R / dR [B, H*C] contiguous, dcol [B, C], y / dy / skip [N, C] with row strides, s / ds [N, H] contiguous.  C % 4 == 0, H <= 8. */
+int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, const float* bias,
+                             const float* skip, int64_t ld_skip, float* y, int64_t ld_y, void* stream);
 int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, const float* dy, int64_t ld_dy, const float* R,
-                                  const float* s, float* dR, float* ds, void* stream);
+                                  const float* s, float* dR, float* ds, float* dcol, void* stream);
 
 /* Host-only introspection: the geometry gvqa_gat_message_passing would use for this (finalized)
  * graph -- LDS-tiled streaming kernel or general CSR kernels -- without launching anything. */

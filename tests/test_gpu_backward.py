@@ -574,15 +574,28 @@ def test_message_passing_with_per_graph_rows_kept_out_of_xp(dev, C, H, with_mask
     mask = ((rng.random((E, H)) > 0.3) / 0.7).astype(np.float32) if with_mask else None
     w = rng.standard_normal((N, C)).astype(np.float32)
     g = SceneGraphBatch(t(ei, device=dev), t(gb.batch, device=dev), N, B)
-    xs = [t(a, device=dev).requires_grad_(True) for a in (xp, a_node, a_edge, rows)]
-    out, alpha = gat_message_passing(xs[0], xs[1], xs[2], g, H, C, 0.2, None if mask is None else t(mask, device=dev), graph_rows=xs[3])
+    bias, skip = rng.standard_normal(C).astype(np.float32), rng.standard_normal((N, C)).astype(np.float32)
+    xs = [t(a, device=dev).requires_grad_(True) for a in (xp, a_node, a_edge, rows, bias, skip)]
+    out, alpha = gat_message_passing(xs[0], xs[1], xs[2], g, H, C, 0.2, None if mask is None else t(mask, device=dev), graph_rows=xs[3],
+                                     bias=xs[4], skip=xs[5])
     (out * t(w, device=dev)).sum().backward()
-    rs = [t(a).double().requires_grad_(True) for a in (xp, a_node, a_edge, rows)]
+    rs = [t(a).double().requires_grad_(True) for a in (xp, a_node, a_edge, rows, bias, skip)]
     ref_out, ref_alpha = _mp_reference(rs[0] + rs[3][t(gb.batch).long()], rs[1], rs[2], None if mask is None else t(mask).double(),
                                        t(ei), N, H, C, 0.2)
+    ref_out = ref_out + rs[4] + rs[5]
     (ref_out * t(w).double()).sum().backward()
     assert maxabs(out, ref_out) < 2e-5 and maxabs(alpha, ref_alpha) < 1e-6
-    for got, ref, name in zip(xs, rs, ("dxp", "da_node", "da_edge", "d_graph_rows")):
+    for got, ref, name in zip(xs, rs, ("dxp", "da_node", "da_edge", "d_graph_rows", "d_bias", "d_skip")):
+        assert _rel(got.grad, ref.grad) < 2e-5, name
+    # bias / skip without per-graph rows
+    ys = [t(a, device=dev).requires_grad_(True) for a in (xp, bias, skip)]
+    out2, _ = gat_message_passing(ys[0], xs[1].detach(), xs[2].detach(), g, H, C, 0.2, None, bias=ys[1], skip=ys[2])
+    (out2 * t(w, device=dev)).sum().backward()
+    qs = [t(a).double().requires_grad_(True) for a in (xp, bias, skip)]
+    ref2, _ = _mp_reference(qs[0], rs[1].detach(), rs[2].detach(), None, t(ei), N, H, C, 0.2)
+    ((ref2 + qs[1] + qs[2]) * t(w).double()).sum().backward()
+    assert maxabs(out2, ref2 + qs[1] + qs[2]) < 2e-5
+    for got, ref, name in zip(ys, qs, ("dxp", "d_bias", "d_skip")):
         assert _rel(got.grad, ref.grad) < 2e-5, name
 
 

@@ -35,6 +35,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.GatConvParams) == 10 * 8
     assert C.sizeof(_lib.GatDims) == 10 * 4 and _lib.GatDims.projection.offset == 32 and _lib.GatDims.hop_fusion.offset == 36
     assert C.sizeof(_lib.LcgnDims) == 8 * 4
+    assert C.sizeof(_lib.GatMpBwdDesc) == 16 + 15 * 8 and _lib.GatMpBwdDesc.dalpha_node.offset == 120 and _lib.GatMpBwdDesc.dxp_absmax.offset == 128
 
 
 def test_argument_validation_without_gpu():
