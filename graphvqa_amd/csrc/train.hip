@@ -394,10 +394,15 @@ __global__ __launch_bounds__(256) void k_absmax(int64_t rows, int cols, const fl
 }
 
 constexpr int TN_SLAB_ROWS = 64, TN_SLAB_COLS = 256, TN_LDS_LD = 260;
-// grid (ceil(M / 256), S * KC / 64); a workgroup turns a [64 rows x 256 columns] slab of X into 4 k blocks x 8 column tiles
+// grid (ceil(M / 256), S * KC / 64); a workgroup turns a [64 rows x 256 columns] slab of X into 4 k blocks x 8 column tiles.
+// NT: the same slab also leaves the fragments of X itself (rows = rows of X, k = its columns: 2 row tiles x 16 k blocks) in the
+// layout gvqa_split2h_pack writes, with the operand's one scale for every row -- the backward of a projection needs dy both
+// ways (dx = dy W contracts over dy's columns, dW = dy^T x over its rows), and reads it once.
+struct PackNt { uint16_t* P; float* inv; int RT, KB; };
+template <bool NT>
 __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const float* __restrict__ X, int64_t ldx,
                                                         const float* __restrict__ absmax, int nmax, int KC, int T,
-                                                        uint16_t* __restrict__ P, float* __restrict__ inv) {
+                                                        uint16_t* __restrict__ P, float* __restrict__ inv, PackNt nt) {
     __shared__ float Xs[TN_SLAB_ROWS * TN_LDS_LD];
     __shared__ float mx_s[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,13 +428,13 @@ __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const 
     __syncthreads();
     const int e = split2h_exponent(fmaxf(fmaxf(mx_s[0], mx_s[1]), fmaxf(mx_s[2], mx_s[3])));
     const float scale = pow2i(e);
-    if (kb0 == 0 && c0 + tid < T * 32) inv[(int64_t)z * T * 32 + c0 + tid] = pow2i(-e);
+    if (P && kb0 == 0 && c0 + tid < T * 32) inv[(int64_t)z * T * 32 + c0 + tid] = pow2i(-e);
     const int mloc = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int u = wave + 4 * j, kbl = u >> 3, tl = u & 7;
         const int tile = blockIdx.x * 8 + tl;
-        if (tile >= T) continue;
+        if (tile >= T || !P) continue;
         tn_f16x8 p0, p1;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -441,6 +446,31 @@ __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const 
         uint16_t* o = P + ((int64_t)z * T + tile) * KBc * 1024 + (int64_t)(kb0 + kbl) * 1024 + lane * 8;
         *reinterpret_cast<uint4*>(o) = __builtin_bit_cast(uint4, p0);
         *reinterpret_cast<uint4*>(o + 512) = __builtin_bit_cast(uint4, p1);
+    }
+    if constexpr (NT) {
+        const int64_t rt0 = r0 >> 5;
+        if (blockIdx.x == 0 && tid < TN_SLAB_ROWS && rt0 + (tid >> 5) < nt.RT) nt.inv[r0 + tid] = pow2i(-e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int u = wave + 4 * j, rtl = u >> 4, kbl = u & 15;
+            const int64_t rt = rt0 + rtl;
+            const int kb = (c0 >> 4) + kbl;
+            if (rt >= nt.RT || kb >= nt.KB) continue;
+            const float* xr = &Xs[(rtl * 32 + mloc) * TN_LDS_LD + kbl * 16 + kh * 8];
+            const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            tn_f16x8 p0, p1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = v[i] * scale;
+                const _Float16 hi = (_Float16)x;
+                p0[i] = hi;
+                p1[i] = (_Float16)(x - (float)hi);
+            }
+            uint16_t* o = nt.P + (rt * nt.KB + kb) * 1024 + lane * 8;
+            *reinterpret_cast<uint4*>(o) = __builtin_bit_cast(uint4, p0);
+            *reinterpret_cast<uint4*>(o + 512) = __builtin_bit_cast(uint4, p1);
+        }
     }
 }
 
@@ -542,6 +572,28 @@ static TnPlan tn_plan(int64_t R, int64_t M, int64_t N) {
     p.off_ia = take((size_t)p.S * p.TA * 32 * 4);
     p.off_ib = take((size_t)p.S * p.TB * 32 * 4);
     p.off_part = take((size_t)p.S * M * N * 4);
+    p.off_max = take(256);
+    p.total = off;
+    return p;
+}
+
+// backward of y = x W^T: dx = dy W (contracts over dy's columns) and dW = dy^T x (over its rows)
+struct LbPlan {
+    TnPlan tn;
+    int KCw, KBw, RT, TBw;
+    size_t off_nt, off_inv_nt, off_wt, off_inv_wt, off_max, total;
+};
+static LbPlan lb_plan(int64_t R, int64_t M, int64_t K) {
+    LbPlan p;
+    p.tn = tn_plan(R, M, K);
+    p.KCw = (int)(cdiv(M, 64) * 64); p.KBw = p.KCw / 16;
+    p.RT = (int)cdiv(std::max<int64_t>(R, 1), 32); p.TBw = (int)cdiv(K, 32);
+    size_t off = p.tn.total;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    p.off_nt = take((size_t)p.RT * p.KBw * 2048);
+    p.off_inv_nt = take(((size_t)p.RT * 32 + 64) * 4);
+    p.off_wt = take((size_t)p.TBw * p.KBw * 2048);
+    p.off_inv_wt = take((size_t)p.TBw * 32 * 4);
     p.off_max = take(256);
     p.total = off;
     return p;
@@ -739,10 +791,10 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
         GVQA_LAUNCH_CHECK();
     }
     const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
-    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(M, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax, x_absmax_n,
-                       p.KC, p.TA, PA, IA);
-    hipLaunchKernelGGL(k_split2h_pack_t, dim3((unsigned)cdiv(N, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax, y_absmax_n,
-                       p.KC, p.TB, PB, IB);
+    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(M, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax,
+                       x_absmax_n, p.KC, p.TA, PA, IA, PackNt{});
+    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(N, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax,
+                       y_absmax_n, p.KC, p.TB, PB, IB, PackNt{});
     GVQA_LAUNCH_CHECK();
     LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
     ep.zs_a = (int64_t)p.TA * p.KBc * 1024; ep.zs_b = (int64_t)p.TB * p.KBc * 1024; ep.zs_c = M * N;
@@ -783,6 +835,81 @@ int gvqa_fold_attention_backward(int64_t H, int64_t C, int64_t Kin, const float*
     if (datt_a) hipLaunchKernelGGL(k_fold_att_bwd_att, dim3((unsigned)cdiv(H * C, 4)), dim3(256), 0, st, (int)H, (int)C, (int)Kin, W, ldw, dV, J,
                                    datt_a, att_b ? datt_b : nullptr);
     GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64_t K) {
+    if (R < 0 || M <= 0 || K <= 0) return 0;
+    return lb_plan(R, M, K).total;
+}
+
+int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
+                                 const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
+                                 float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream) {
+    GVQA_REQUIRE(R >= 0 && M > 0 && K > 0 && M < (1ll << 30) && K < (1ll << 30) && R < (1ll << 31), GVQA_E_INVALID, "linear_backward: bad size");
+    GVQA_REQUIRE(M % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= M, GVQA_E_INVALID, "linear_backward: M, K, ld_dy multiples of 4");
+    GVQA_REQUIRE((!dx || (W && ldw % 4 == 0 && ldw >= K && ld_dx % 4 == 0 && ld_dx >= K)) && (!dW || (x && ldx % 4 == 0 && ldx >= K && ld_dw % 4 == 0 && ld_dw >= K)),
+                 GVQA_E_INVALID, "linear_backward: operands of the requested gradients (leading dimensions multiples of 4)");
+    GVQA_REQUIRE(!dy_absmax || (dy_absmax_n >= 1 && dy_absmax_n <= GVQA_ABSMAX_SLOTS), GVQA_E_INVALID, "linear_backward: 1 <= absmax count <= %d", GVQA_ABSMAX_SLOTS);
+    if (!dx && !dW) return GVQA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        if (dW) GVQA_HIP_CHECK(hipMemset2DAsync(dW, (size_t)ld_dw * 4, 0, (size_t)K * 4, (size_t)M, st));
+        return GVQA_OK;
+    }
+    GVQA_REQUIRE(dy && ws, GVQA_E_INVALID, "linear_backward: null operand");
+    const LbPlan p = lb_plan(R, M, K);
+    GVQA_REQUIRE(ws_bytes >= p.total, GVQA_E_WORKSPACE, "linear_backward: workspace too small (%zu < %zu)", ws_bytes, p.total);
+    char* base = static_cast<char*>(ws);
+    uint16_t* PA = reinterpret_cast<uint16_t*>(base + p.tn.off_pa);
+    uint16_t* PB = reinterpret_cast<uint16_t*>(base + p.tn.off_pb);
+    float* IA = reinterpret_cast<float*>(base + p.tn.off_ia);
+    float* IB = reinterpret_cast<float*>(base + p.tn.off_ib);
+    float* part = reinterpret_cast<float*>(base + p.tn.off_part);
+    uint16_t* PN = reinterpret_cast<uint16_t*>(base + p.off_nt);
+    float* IN = reinterpret_cast<float*>(base + p.off_inv_nt);
+    uint16_t* PW = reinterpret_cast<uint16_t*>(base + p.off_wt);
+    float* IW = reinterpret_cast<float*>(base + p.off_inv_wt);
+    unsigned* mx = reinterpret_cast<unsigned*>(base + p.off_max);       // [0] dy, [1] x, [2] W
+    GVQA_HIP_CHECK(hipMemsetAsync(mx, 0, 16, st));
+    if (!dy_absmax) {
+        hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)M, dy, ld_dy, mx);
+        dy_absmax = reinterpret_cast<const float*>(mx); dy_absmax_n = 1;
+    }
+    if (dW) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)K, x, ldx, mx + 1);
+    if (dx) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(M, 1024)), dim3(256), 0, st, M, (int)K, W, ldw, mx + 2);
+    const unsigned slabs = (unsigned)((int64_t)p.tn.S * p.tn.KC / TN_SLAB_ROWS);
+    const dim3 gdy((unsigned)cdiv(M, TN_SLAB_COLS), slabs);
+    if (dx) hipLaunchKernelGGL(k_split2h_pack_t<true>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA,
+                               dW ? PA : nullptr, IA, PackNt{PN, IN, p.RT, p.KBw});
+    else hipLaunchKernelGGL(k_split2h_pack_t<false>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA, PA, IA,
+                            PackNt{});
+    GVQA_LAUNCH_CHECK();
+    if (dx) {
+        // B operand: W^T [K x M] = the transposed pack of W as ONE chunk of KCw rows
+        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(K, TN_SLAB_COLS), (unsigned)(p.KCw / TN_SLAB_ROWS)), dim3(256), 0, st, M, (int)K,
+                           W, ldw, reinterpret_cast<const float*>(mx + 2), 1, p.KCw, p.TBw, PW, IW, PackNt{});
+        GVQA_LAUNCH_CHECK();
+        LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
+        const int rc = launch_linear_split(2, R, K, p.KCw, PN, PW, ep, dx, ld_dx, st, 1, IN, IW);
+        if (rc != GVQA_OK) return rc;
+    }
+    if (dW) {
+        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(K, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)K, x, ldx,
+                           reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.TB, PB, IB, PackNt{});
+        GVQA_LAUNCH_CHECK();
+        LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
+        ep.zs_a = (int64_t)p.tn.TA * p.tn.KBc * 1024; ep.zs_b = (int64_t)p.tn.TB * p.tn.KBc * 1024; ep.zs_c = M * K;
+        ep.zs_ia = (int64_t)p.tn.TA * 32; ep.zs_ib = (int64_t)p.tn.TB * 32;
+        float* dst = p.tn.S == 1 ? dW : part;
+        const int rc = launch_linear_split(2, M, K, p.tn.KC, PA, PB, ep, dst, p.tn.S == 1 ? ld_dw : K, st, p.tn.S, IA, IB);
+        if (rc != GVQA_OK) return rc;
+        if (p.tn.S > 1) {
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<int64_t>(cdiv(M * (K / 4), 256), 4096)), dim3(256), 0, st, p.tn.S, (int)M,
+                               (int)K, part, dW, ld_dw);
+            GVQA_LAUNCH_CHECK();
+        }
+    }
     return GVQA_OK;
 }
 

@@ -100,11 +100,39 @@ class _ProjectionLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        fused = _ProjectionLinear._backward_fused(gy, x, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        if fused is not None:
+            return fused
         gx = None
         if ctx.needs_input_grad[0]:
             # dx = dy W = dy (W^T)^T: the same kernels with the (small) weight transposed
             gx = _ProjectionLinear._product(gy.contiguous(), w.t().contiguous())
         gw = _ProjectionLinear._weight_grad(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+    @staticmethod
+    def _backward_fused(gy, x, w, want_x, want_w):
+        """dx = dy W and dW = dy^T x in one library call under the two-piece arithmetic (gvqa_linear_backward_split2h: dy is read and
+        packed once for both products); None when the shapes / settings are not the ones it takes."""
+        lib = _lib.load()
+        R, M = gy.shape
+        K = x.shape[1]
+        ok = (gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and w.dtype == torch.float32 and M % 4 == 0 and
+              K % 4 == 0 and R > 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and w.stride(1) == 1 and w.stride(0) % 4 == 0 and
+              lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H and
+              2.0 * R * M * K >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
+        if not ok or not (want_x or want_w):
+            return None
+        am = getattr(gy, "_gvqa_absmax", None) if gy.is_contiguous() else None
+        gy = gy.contiguous()
+        dev = gy.device
+        gx = torch.empty((R, K), dtype=torch.float32, device=dev) if want_x else None
+        gw = torch.empty((M, K), dtype=torch.float32, device=dev) if want_w else None
+        with torch.cuda.device(dev):
+            ws = _workspace(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dev)
+            _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
+                                                        _ptr(am), 0 if am is None else am.numel(), _ptr(gx), K, _ptr(gw), K,
+                                                        ws.data_ptr(), ws.numel(), _stream(dev)))
         return gx, gw
 
     @staticmethod

@@ -680,3 +680,37 @@ def test_fold_attention_vs_fp64_einsum(dev, H, C, Kin, two):
     assert a.grad.shape == a.shape
     if two:
         assert _rel(b.grad, bd.grad) < 2e-6
+
+
+@pytest.mark.parametrize("R,M,K,ldw,which", [(5000, 256, 128, 128, "both"), (65536, 2048, 512, 1024, "both"), (1000, 36, 300, 300, "both"),
+                                             (63, 512, 512, 512, "dx"), (70001, 1200, 300, 812, "dw"), (4097, 100, 64, 64, "both")])
+def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which):
+    """gvqa_linear_backward_split2h: dx = dy W and dW = dy^T x from ONE pass over dy, against fp64 products and next to torch's fp32
+    matmuls; W as a column slice of a wider weight (row stride), ragged sizes, rows of dy of very different magnitude (the packed
+    rows share the operand's one scale), either gradient alone."""
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(R + M + K)
+    dy = torch.randn((R, M), generator=g).to(dev)
+    dy[::7] *= 1e-3
+    dy[::11] *= 30.0
+    W = torch.randn((M, ldw), generator=g).to(dev)[:, :K]
+    x = torch.randn((R, K), generator=g).to(dev)
+    dx = torch.full((R, K), 5.0, device=dev) if which in ("both", "dx") else None
+    dW = torch.full((M, K), 5.0, device=dev) if which in ("both", "dw") else None
+    ws = torch.empty(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dtype=torch.uint8, device=dev)
+    p = lambda a: None if a is None else a.data_ptr()
+    _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, p(dx), K, p(dW), K,
+                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    if dx is not None:
+        ref = dy.double() @ W.double()
+        bound = dy.double().abs() @ W.double().abs()
+        err = float(((dx.double() - ref).abs() / bound.clamp_min(1e-30)).max())
+        err_t = float((((dy @ W).double() - ref).abs() / bound.clamp_min(1e-30)).max())
+        assert err <= max(2e-6, 2.0 * err_t), (err, err_t)
+    if dW is not None:
+        ref = dy.double().t() @ x.double()
+        bound = dy.double().abs().t() @ x.double().abs()
+        err = float(((dW.double() - ref).abs() / bound.clamp_min(1e-30)).max())
+        err_t = float((((dy.t() @ x).double() - ref).abs() / bound.clamp_min(1e-30)).max())
+        assert err <= max(2e-6, 2.0 * err_t), (err, err_t)
