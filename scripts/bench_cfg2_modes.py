@@ -18,7 +18,8 @@ m.load_state_dict({k: tt(v) for k, v in synth.gat_seq_params(300, 300, 300, 512,
 hl = HostLayout.from_numpy(gb.edge_index, gb.batch, B)
 run = lambda: m(x, ei, ea, ins, batch, graph=SceneGraphBatch(ei, batch, N, B, host_layout=hl))
 for mode in [int(v) for v in os.environ.get("MODES", "1,2,0").split(",")]:
-    m.hop_fusion = mode
+    m.hop_fusion = mode % 10
+    _lib.set_option(_lib.OPT_MP_PARTS, mode // 10)      # MODES=20: unfused with two blocks per graph in the message-passing kernel
     for _ in range(5): run()
     torch.cuda.synchronize(); _lib.prof_enable(True); _lib.prof_collect()
     steps = 20; t0 = time.perf_counter()

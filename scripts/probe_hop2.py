@@ -35,8 +35,7 @@ def phases(w):
     q = full[:, :items, w, :7].astype(np.float64)
     d = np.diff(q, axis=2) / 100.0
     return [round(float(v), 2) for v in d.mean((0, 1))]
-print(json.dumps({"phase_us [main, img0+sync, agg0, sync+img1, agg1, tail]": {"wave0": phases(0), "wave3": phases(3)},
-                  "tail_stage_tile_us (chained hops)": round(float(((full[:, :items, 0, 7] - full[:, :items, 0, 5]) / 100.0).mean()), 2)}))
+print(json.dumps({"phase_us [main, img0+sync, agg0, sync+img1, agg1, tail]": {"wave0": phases(0), "wave3": phases(3)}}))
 t = full[:, :, 0, :][:, :, [0, 1, 6, 6]]
 t0 = t[:, :items, 0][t[:, :items, 0] > 0].min()
 st, me, en = [(t[:, :items, k] - t0) / 100.0 for k in range(3)]
