@@ -228,8 +228,8 @@ PROTOTYPES = {
                                          C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "gvqa_linear_backward_split2h": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                               C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                               C.c_size_t, C.c_void_p]),
+                                               C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_fold_attention_forward": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_fold_attention_backward": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

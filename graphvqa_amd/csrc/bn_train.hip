@@ -104,6 +104,72 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply(int64_t total, int C,
     }
 }
 
+// The same two passes with 16-byte accesses (C % 4 == 0): a thread owns 4 consecutive channels -- their constants live in
+// registers -- and walks rows; TPR threads per row (a power of two >= C / 4, at most 256), 256 / TPR rows per workgroup trip.
+__global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce_v4(int64_t N, int C, int TPR, const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ mean, const float* __restrict__ var,
+                                                               const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                               float* __restrict__ partial) {
+    __shared__ float4 red[2][256];
+    const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
+    for (int c4b = 0; c4b < (C >> 2); c4b += TPR) {       // (uniform trip count: the barriers below are reached by every thread)
+        const bool on = c4b + tcol < (C >> 2);
+        const int c = on ? (c4b + tcol) * 4 : 0;
+        const float4 m = *reinterpret_cast<const float4*>(mean + c), v = *reinterpret_cast<const float4*>(var + c);
+        const float4 wc = *reinterpret_cast<const float4*>(w + c), bc = *reinterpret_cast<const float4*>(b + c);
+        const float4 is = make_float4(1.0f / sqrtf(v.x + eps), 1.0f / sqrtf(v.y + eps), 1.0f / sqrtf(v.z + eps), 1.0f / sqrtf(v.w + eps));
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        for (int64_t r = r0 + trow; on && r < r1; r += RPB) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c), gv = *reinterpret_cast<const float4*>(dy + r * C + c);
+            const float4 xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
+            const float4 g = make_float4(xh.x * wc.x + bc.x > 0.f ? gv.x : 0.f, xh.y * wc.y + bc.y > 0.f ? gv.y : 0.f,
+                                         xh.z * wc.z + bc.z > 0.f ? gv.z : 0.f, xh.w * wc.w + bc.w > 0.f ? gv.w : 0.f);
+            s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+            s1.x += g.x * xh.x; s1.y += g.y * xh.y; s1.z += g.z * xh.z; s1.w += g.w * xh.w;
+        }
+        // the RPB thread rows of this column group, added in index order
+        red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+        __syncthreads();
+        if (trow == 0 && on) {
+            for (int q = 1; q < RPB; ++q) {
+                const float4 a0 = red[0][q * TPR + tcol], a1 = red[1][q * TPR + tcol];
+                s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+                s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+            }
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * C + c) = s0;
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * C + c) = s1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_bwd_apply_v4(int64_t N, int C, int TPR, float inv_n, const float* __restrict__ x,
+                                                              const float* __restrict__ dy, const float* __restrict__ mean,
+                                                              const float* __restrict__ var, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float eps, const float* __restrict__ dbias,
+                                                              const float* __restrict__ dweight, float* __restrict__ dx) {
+    const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
+    for (int c4 = tcol; c4 < (C >> 2); c4 += TPR) {
+        const int c = c4 * 4;
+        const float4 m = *reinterpret_cast<const float4*>(mean + c), v = *reinterpret_cast<const float4*>(var + c);
+        const float4 wc = *reinterpret_cast<const float4*>(w + c), bc = *reinterpret_cast<const float4*>(b + c);
+        const float4 db = *reinterpret_cast<const float4*>(dbias + c), dw = *reinterpret_cast<const float4*>(dweight + c);
+        const float4 is = make_float4(1.0f / sqrtf(v.x + eps), 1.0f / sqrtf(v.y + eps), 1.0f / sqrtf(v.z + eps), 1.0f / sqrtf(v.w + eps));
+        auto one = [&](float xv, float gv, float mm, float ii, float ww, float bb, float dbb, float dww) {
+            const float xh = (xv - mm) * ii;
+            const float g = xh * ww + bb > 0.f ? gv : 0.f;
+            return ww * ii * (g - dbb * inv_n - xh * dww * inv_n);
+        };
+        for (int64_t r = (int64_t)blockIdx.x * RPB + trow; r < N; r += (int64_t)gridDim.x * RPB) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c), gv = *reinterpret_cast<const float4*>(dy + r * C + c);
+            *reinterpret_cast<float4*>(dx + r * C + c) =
+                make_float4(one(xv.x, gv.x, m.x, is.x, wc.x, bc.x, db.x, dw.x), one(xv.y, gv.y, m.y, is.y, wc.y, bc.y, db.y, dw.y),
+                            one(xv.z, gv.z, m.z, is.z, wc.z, bc.z, db.z, dw.z), one(xv.w, gv.w, m.w, is.w, wc.w, bc.w, db.w, dw.w));
+        }
+    }
+}
+
 }  // namespace
 }  // namespace gvqa
 
@@ -149,12 +215,20 @@ extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x,
     const int nb = (int)cdiv(N, BN_ROWS);
     GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
     const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
-    hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
+    // 16-byte form when the rows allow it (same operations per element, same summation order within a row block's thread rows)
+    const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    int TPR = 1;
+    while (TPR < 256 && TPR < C / 4) TPR <<= 1;
+    if (v4) hipLaunchKernelGGL(k_bn_relu_bwd_reduce_v4, dim3((unsigned)nb), dim3(256), 0, stream, N, (int)C, TPR, x, dy, save_mean, save_var, weight,
+                               bias, eps, partial);
+    else hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
-    hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, 1.0f / (float)N, x, dy, save_mean,
-                       save_var, weight, bias, eps, dbias, dweight, dx);
+    if (v4) hipLaunchKernelGGL(k_bn_relu_bwd_apply_v4, dim3((unsigned)std::min<int64_t>(cdiv(N, 256 / TPR), 4096)), dim3(256), 0, stream, N, (int)C,
+                               TPR, 1.0f / (float)N, x, dy, save_mean, save_var, weight, bias, eps, dbias, dweight, dx);
+    else hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, 1.0f / (float)N, x, dy, save_mean,
+                            save_var, weight, bias, eps, dbias, dweight, dx);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -845,7 +845,7 @@ size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64_t K) {
 
 int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
                                  const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
-                                 float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream) {
+                                 int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream) {
     GVQA_REQUIRE(R >= 0 && M > 0 && K > 0 && M < (1ll << 30) && K < (1ll << 30) && R < (1ll << 31), GVQA_E_INVALID, "linear_backward: bad size");
     GVQA_REQUIRE(M % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= M, GVQA_E_INVALID, "linear_backward: M, K, ld_dy multiples of 4");
     GVQA_REQUIRE((!dx || (W && ldw % 4 == 0 && ldw >= K && ld_dx % 4 == 0 && ld_dx >= K)) && (!dW || (x && ldx % 4 == 0 && ldx >= K && ld_dw % 4 == 0 && ld_dw >= K)),
@@ -891,6 +891,7 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
                            W, ldw, reinterpret_cast<const float*>(mx + 2), 1, p.KCw, p.TBw, PW, IW, PackNt{});
         GVQA_LAUNCH_CHECK();
         LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
+        if (dx_accumulate) { ep.addend = dx; ep.ld_add = ld_dx; }      // dx += dy W (the GEMM's epilogue reads the element it writes)
         const int rc = launch_linear_split(2, R, K, p.KCw, PN, PW, ep, dx, ld_dx, st, 1, IN, IW);
         if (rc != GVQA_OK) return rc;
     }

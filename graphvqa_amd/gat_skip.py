@@ -111,7 +111,7 @@ class _ProjectionLinear(torch.autograd.Function):
         return gx, gw
 
     @staticmethod
-    def _backward_fused(gy, x, w, want_x, want_w):
+    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None):
         """dx = dy W and dW = dy^T x in one library call under the two-piece arithmetic (gvqa_linear_backward_split2h: dy is read and
         packed once for both products); None when the shapes / settings are not the ones it takes."""
         lib = _lib.load()
@@ -126,13 +126,13 @@ class _ProjectionLinear(torch.autograd.Function):
         am = getattr(gy, "_gvqa_absmax", None) if gy.is_contiguous() else None
         gy = gy.contiguous()
         dev = gy.device
-        gx = torch.empty((R, K), dtype=torch.float32, device=dev) if want_x else None
+        gx = (gx_init if gx_init is not None else torch.empty((R, K), dtype=torch.float32, device=dev)) if want_x else None
         gw = torch.empty((M, K), dtype=torch.float32, device=dev) if want_w else None
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dev)
             _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
-                                                        _ptr(am), 0 if am is None else am.numel(), _ptr(gx), K, _ptr(gw), K,
-                                                        ws.data_ptr(), ws.numel(), _stream(dev)))
+                                                        _ptr(am), 0 if am is None else am.numel(), _ptr(gx), K,
+                                                        int(gx_init is not None and want_x), _ptr(gw), K, ws.data_ptr(), ws.numel(), _stream(dev)))
         return gx, gw
 
     @staticmethod
@@ -255,6 +255,57 @@ def fold_attention(W: Tensor, att_a: Tensor, att_b: Optional[Tensor], heads: int
     return _FoldAttention.apply(W, att_a, att_b, heads)
 
 
+class _NodeProducts(torch.autograd.Function):
+    """(xp, a) = (h W^T, h V) for the hop's node rows: the projection (gat_skip.py:133) and the folded attention logits (:134-135)
+    as ONE autograd node, so that the backward forms dh = da V^T + dxp W in place (the projection's GEMM accumulates onto the
+    logit products' input gradient) instead of two tensors and an add.  Falls back to the two separate ops' arithmetic."""
+
+    @staticmethod
+    def forward(ctx, h, W, V):
+        ctx.save_for_backward(h, W, V)
+        with torch.no_grad():
+            return _ProjectionLinear._product(h, W), skinny_linear(h, V)
+
+    @staticmethod
+    def backward(ctx, gxp, ga):
+        h, W, V = ctx.saved_tensors
+        lib = _lib.load()
+        want_h, want_w, want_v = ctx.needs_input_grad
+        R, D = h.shape
+        J = V.shape[1]
+        gV = gh = None
+        ok = _SkinnyLinear.supported(h, V) and J in (1, 2, 4, 8, 12, 16, 20, 24, 32)
+        ga = ga.contiguous()
+        Vc = V.contiguous()
+        if want_v:
+            if ok:
+                gV = torch.empty_like(Vc)
+                with torch.cuda.device(h.device):
+                    ws = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(R, D, J), h.device)
+                    _lib.check(lib.gvqa_skinny_backward_weight(R, D, J, h.data_ptr(), h.stride(0), ga.data_ptr(), gV.data_ptr(), ws.data_ptr(),
+                                                               ws.numel(), _stream(h.device)))
+            else:
+                gV = h.t() @ ga
+        if want_h:
+            if ok:
+                gh = torch.empty((R, D), dtype=torch.float32, device=h.device)
+                with torch.cuda.device(h.device):
+                    _lib.check(lib.gvqa_skinny_backward_input(R, D, J, ga.data_ptr(), Vc.data_ptr(), None, 0, gh.data_ptr(), D, _stream(h.device)))
+            else:
+                gh = ga @ Vc.t()
+        fused = _ProjectionLinear._backward_fused(gxp, h, W, want_h, want_w, gx_init=gh)
+        if fused is not None:
+            gh2, gW = fused
+            return (gh2 if want_h else None), gW, gV
+        gW = None
+        if want_h:
+            gx = _ProjectionLinear._product(gxp.contiguous(), W.t().contiguous())
+            gh = gx + gh
+        if want_w:
+            gW = _ProjectionLinear._weight_grad(gxp, h)
+        return gh, gW, gV
+
+
 class _GatMessagePassing(torch.autograd.Function):
     """out[i] = (1/H) sum_h sum_{e -> i} alpha[e,h] mask[e,h] xp[src_e, h, :],  alpha = softmax over the in-edges
     of leaky_relu(a_node[src,h] + a_node[dst,H+h] + a_edge[e,h])   (gat_skip.py:155,183-208,162-165).
@@ -274,6 +325,9 @@ class _GatMessagePassing(torch.autograd.Function):
             graph_rows = _f32c(graph_rows, "graph_rows")
             if graph_rows.shape != (graph.num_graphs, heads * channels):
                 raise ValueError("gat_message_passing: graph_rows must be [num_graphs, heads * channels]")
+            if not graph.intra_graph:
+                raise ValueError("gat_message_passing: graph_rows needs a batch without cross-graph edges (a message would carry the "
+                                 "source graph's row); add the rows to xp instead")
         N, E, dev = graph.num_nodes, graph.num_edges, xp.device
         if xp.shape != (N, heads * channels) or a_node.shape != (N, 2 * heads) or a_edge.shape != (E, heads):
             raise ValueError("gat_message_passing: operand shapes do not match the graph")
@@ -870,13 +924,13 @@ class gat_seq(torch.nn.Module):
             W, We = conv.lin_l.weight, conv.lin_e.weight
             # projected features: node half per row, instruction half per graph
             # (the per-graph rows ride through the message passing as `graph_rows`: the [N, H*C] sum is never formed)
-            xp, xp_rows = _ProjectionLinear.apply(h, W[:, :Dn]), F.linear(ins, W[:, Dn:])
-            # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
-            # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
             fold_n = fold_attention(W, conv.att_l, conv.att_r, H)              # [Dn + Di, 2H]: att_l | att_r through lin_l
             V_n, U_e = fold_n[:Dn], folds_e[i][De:]
+            (xp, a_part), xp_rows = _NodeProducts.apply(h, W[:, :Dn], V_n), F.linear(ins, W[:, Dn:])
+            # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
+            # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
             U_n = torch.cat((fold_n[Dn:, :H] + U_e, fold_n[Dn:, H:]), dim=1)
-            a_node = add_graph_rows(skinny_linear(h, V_n), ins @ U_n, graph)
+            a_node = add_graph_rows(a_part, ins @ U_n, graph)
             a_edge = a_edge_all[:, i * H:(i + 1) * H]
             mask = None
             if alpha_masks is not None:
@@ -884,6 +938,10 @@ class gat_seq(torch.nn.Module):
             elif p > 0:
                 mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p)
             # aggregation + head mean (:155-165) + bias (:167-168) + skip (:270) in one op
+            # (per-graph rows stay out of xp when every edge stays inside its graph -- any batch the reference's collate makes;
+            # with cross-graph edges a message carries the SOURCE graph's row and the sum is formed)
+            if not graph.intra_graph:
+                xp, xp_rows = add_graph_rows(xp, xp_rows, graph), None
             h, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask, graph_rows=xp_rows,
                                            bias=conv.bias, skip=h)
             if i != K - 1:

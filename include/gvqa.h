@@ -308,12 +308,13 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
 /* Backward of the hop projection y = x W^T (torch.nn.Linear at gat_skip.py:133 under autograd) on the two-piece arithmetic:
  * dx [R, K] = dy W and / or dW [M, K] = dy^T x (either may be NULL: skipped) for dy [R, M], W [M, K], x [R, K].  dy is read ONCE:
  * one pass leaves both of its packed forms (rows as rows for dx, rows as the contraction for dW), W^T is packed transposed, the
- * split GEMM runs for dx and -- over split-K chunks -- for dW (fixed-order reduction).  dy_absmax as in gvqa_linear_tn_split2h.
+ * split GEMM runs for dx (dx_accumulate != 0: dx += dy W, e.g. on top of the logit products' input gradient) and -- over split-K
+ * chunks -- for dW (fixed-order reduction).  dy_absmax as in gvqa_linear_tn_split2h.
  * M, K and all leading dimensions multiples of 4. */
 size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64_t K);
 int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
                                  const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
-                                 float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream);
+                                 int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream);
 
 /* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls

@@ -700,7 +700,7 @@ def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which):
     dW = torch.full((M, K), 5.0, device=dev) if which in ("both", "dw") else None
     ws = torch.empty(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dtype=torch.uint8, device=dev)
     p = lambda a: None if a is None else a.data_ptr()
-    _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, p(dx), K, p(dW), K,
+    _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, p(dx), K, 0, p(dW), K,
                                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
     if dx is not None:
         ref = dy.double() @ W.double()
@@ -714,3 +714,9 @@ def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which):
         err = float(((dW.double() - ref).abs() / bound.clamp_min(1e-30)).max())
         err_t = float((((dy.t() @ x).double() - ref).abs() / bound.clamp_min(1e-30)).max())
         assert err <= max(2e-6, 2.0 * err_t), (err, err_t)
+    if dx is not None:       # dx_accumulate: the product lands on top of what dx holds (the logit products' input gradient in the hop)
+        add = torch.randn((R, K), generator=g).to(dev)
+        acc = add.clone()
+        _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, acc.data_ptr(), K, 1,
+                                                    None, K, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        assert float((acc - (add + dx)).abs().max()) <= 1e-6 * max(float(dx.abs().max()), 1.0)
