@@ -69,11 +69,11 @@ def test_message_passing_backward_vs_autograd(dev, C, H, with_mask):
         assert _rel(got.grad, ref.grad) < 2e-5, name
 
 
-def _grads_vs_oracle(dev, train, alpha_masks=None, feature_masks=None, dims=(32, 32, 48, 3, 4), seed=5):
+def _grads_vs_oracle(dev, train, alpha_masks=None, feature_masks=None, dims=(32, 32, 48, 3, 4), seed=5, graphs=5):
     from oracle import ref_torch as R
     from graphvqa_amd.gat_skip import gat_seq
     dn, de, di, K, H = dims
-    gb = synth.make_graph_batch(5, seed=0xA11CE + seed, nodes_lo=6, nodes_hi=20, rel_per_node=1.5)
+    gb = synth.make_graph_batch(graphs, seed=0xA11CE + seed, nodes_lo=6, nodes_hi=20, rel_per_node=1.5)
     N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
     p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=seed)
     rng = np.random.default_rng(seed)
@@ -720,3 +720,28 @@ def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which):
         _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, acc.data_ptr(), K, 1,
                                                     None, K, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
         assert float((acc - (add + dx)).abs().max()) <= 1e-6 * max(float(dx.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_gat_seq_gradients_on_the_library_products(dev, train):
+    """The gradient checks above run below the size at which the projection leaves torch (GVQA_OPT_SPLIT3_MIN_MFLOP); here the
+    threshold is 0, so the forward projection, dx = dy W and dW = dy^T x (gvqa_linear_backward_split2h), the tall-skinny logit
+    products and the attention folds are ALL the library's kernels -- at the small dims and at the reference's real widths
+    (d = 300, ins 512, H = 4, 60 ragged graphs) -- and every parameter / input gradient is held to the oracle's fp64 autograd."""
+    from graphvqa_amd import _lib
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        _grads_vs_oracle(dev, train=train)
+        _grads_vs_oracle(dev, train=train, dims=(300, 300, 512, 2, 4), seed=9, graphs=60)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+
+
+def test_gat_seq_gradients_with_dropout_masks_on_the_library_products(dev):
+    """The same with attention and feature dropout masks (s != 1: the per-graph rows reach the logits' gradient)."""
+    from graphvqa_amd import _lib
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        test_gat_seq_gradients_with_dropout_masks(dev)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
