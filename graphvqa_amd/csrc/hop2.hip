@@ -61,6 +61,7 @@ struct Hop2Args {
     int KB, ncb;
     int stagger;              // start delay of the second workgroup of every CU, in s_sleep(127) units (~8128 cycles each)
 #ifdef GVQA_PROBES
+    int item_map;                // 0 the XCD-aware item list, 1 row-group-major (scripts/bench_hop2.py MAP=1)
     int dbg;                     // ablation switches (wrong results): 1 no epilogue, 2 no DMA in the loop, 4 no fragment reads after step 0,
                                  // 8 no waits / barriers in the loop, 16 (launcher) one workgroup per CU
     unsigned long long* probe;   // NULL or [workgroups][32 items][4 waves][8]: 100 MHz stamps 0 item start, 1 main loop end, 2/4 image of half 0/1 in place, 3/5 half aggregated, 6 item end (scripts/probe_hop2.py)
@@ -129,8 +130,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
     // ---- this workgroup's items: XCD x = blockIdx.x % 8 owns the row groups g = gres (mod GS) x one of CS column-block
     // ranges; its workgroups take every per_x-th item of that list, column blocks fastest
     const int x = blockIdx.x & 7, jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
-    const int CS = a.ncb >= 2 ? 2 : 1, GS = 8 / CS;
-    const int cpart = x % CS, gres = x / CS;
+#ifdef GVQA_PROBES
+    const bool rgm = a.item_map == 1;            // (measurement: row-group-major -- workgroup w walks ALL column blocks of the row groups w, w + grid, ...)
+#else
+    constexpr bool rgm = false;
+#endif
+    const int CS = rgm ? 1 : (a.ncb >= 2 ? 2 : 1), GS = rgm ? (int)gridDim.x : 8 / CS;
+    const int cpart = rgm ? 0 : x % CS, gres = rgm ? (int)blockIdx.x : x / CS;
+    const int s_begin = rgm ? 0 : jx, s_step = rgm ? 1 : per_x;
     const int n0 = (a.ncb + CS - 1) / CS;
     const int ncp = cpart == 0 ? n0 : a.ncb - n0, cb0 = cpart == 0 ? 0 : n0;
     const int ng = fh.num_groups > gres ? (fh.num_groups - gres + GS - 1) / GS : 0;
@@ -152,14 +159,14 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
     // item metadata travels one item ahead (two dependent scalar loads: off the critical path of the item that uses them)
     auto item_of = [&](int s, int& grp, int& cb) { const int gi = s / ncp; grp = gi * GS + gres; cb = cb0 + (s - gi * ncp); };
     int grp = 0, cb = 0, ns = 0, cnt = 0, e0 = 0, ne = 0;
-    if (jx < count) {
-        item_of(jx, grp, cb);
+    if (s_begin < count) {
+        item_of(s_begin, grp, cb);
         ns = fh.group_ptr[grp]; cnt = fh.group_ptr[grp + 1] - ns;
         e0 = fh.rowptr[ns]; ne = min(fh.rowptr[ns + cnt] - e0, fh.e_cap);     // (e_cap: a wrong loader-side layout must not overrun the region)
     }
     [[maybe_unused]] int item_no = 0;
     [[maybe_unused]] int pm_cb = 0, pm_gf = 0, pm_n = 0, pm_par = 1;
-    for (int s = jx; s < count; s += per_x, ++item_no) {
+    for (int s = s_begin; s < count; s += s_step, ++item_no) {
         __syncthreads();                              // the previous item's image and region are free
         GVQA_H2_STAMP(0);
         if constexpr (CHAIN) {
@@ -299,8 +306,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
                 for (int j = 0; j < 2; ++j) h2_keep_live(acc[i][j]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GVQA_H2_STAMP(6);
-            if (s + per_x < count) {
-                item_of(s + per_x, grp, cb);
+            if (s + s_step < count) {
+                item_of(s + s_step, grp, cb);
                 ns = fh.group_ptr[grp]; cnt = fh.group_ptr[grp + 1] - ns;
                 e0 = fh.rowptr[ns]; ne = fh.rowptr[ns + cnt] - e0;
             }
@@ -309,8 +316,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
         if (!REGION_EARLY) dma_region();
         // the next item's metadata starts its trip now
         int grp_n = 0, cb_n = 0, ns_n = 0, cnt_n = 0, e0_n = 0, ne_n = 0;
-        if (s + per_x < count) {
-            item_of(s + per_x, grp_n, cb_n);
+        if (s + s_step < count) {
+            item_of(s + s_step, grp_n, cb_n);
             ns_n = fh.group_ptr[grp_n]; cnt_n = fh.group_ptr[grp_n + 1] - ns_n;
             e0_n = fh.rowptr[ns_n]; ne_n = min(fh.rowptr[ns_n + cnt_n] - e0_n, fh.e_cap);
         }
@@ -708,6 +715,8 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
 #ifdef GVQA_PROBES
     a.probe = (g_hop2_calls++ % g_hop2_sel_every) == g_hop2_sel_which ? g_hop2_probe : nullptr;
     a.dbg = g_hop2_dbg;
+    static const int imap = []() { const char* v = getenv("GVQA_HOP2_MAP"); return v ? atoi(v) : 0; }();
+    a.item_map = imap;
 #endif
     const int64_t items = (int64_t)f.num_groups * a.ncb;
     int wgs = 2 * hop2_cus();
