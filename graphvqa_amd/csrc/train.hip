@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm_tile.h"
 #include <algorithm>
+#include <mutex>
 
 namespace gvqa {
 namespace {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void k_absmax(int64_t rows, int cols, const fl
 }
 
 constexpr int TN_SLAB_ROWS = 64, TN_SLAB_COLS = 256, TN_LDS_LD = 260;
-// grid (ceil(M / 256), S * KC / 64); a workgroup turns a [64 rows x 256 columns] slab of X into 4 k blocks x 8 column tiles.
+// grid (S * KC / 64, ceil(M / 256)); a workgroup turns a [64 rows x 256 columns] slab of X into 4 k blocks x 8 column tiles.
 // NT: the same slab also leaves the fragments of X itself (rows = rows of X, k = its columns: 2 row tiles x 16 k blocks) in the
 // layout gvqa_split2h_pack writes, with the operand's one scale for every row -- the backward of a projection needs dy both
 // ways (dx = dy W contracts over dy's columns, dW = dy^T x over its rows), and reads it once.
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const 
     __shared__ float Xs[TN_SLAB_ROWS * TN_LDS_LD];
     __shared__ float mx_s[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)blockIdx.y * TN_SLAB_ROWS;
-    const int c0 = blockIdx.x * TN_SLAB_COLS;
+    const int64_t r0 = (int64_t)blockIdx.x * TN_SLAB_ROWS;         // (row slabs on grid.x: no 65535 limit)
+    const int c0 = blockIdx.y * TN_SLAB_COLS;
     const int z = (int)(r0 / KC), kb0 = (int)((r0 - (int64_t)z * KC) >> 4), KBc = KC >> 4;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int u = wave + 4 * j, kbl = u >> 3, tl = u & 7;
-        const int tile = blockIdx.x * 8 + tl;
+        const int tile = blockIdx.y * 8 + tl;
         if (tile >= T || !P) continue;
         tn_f16x8 p0, p1;
 #pragma unroll
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void k_split2h_pack_t(int64_t R, int M, const 
     }
     if constexpr (NT) {
         const int64_t rt0 = r0 >> 5;
-        if (blockIdx.x == 0 && tid < TN_SLAB_ROWS && rt0 + (tid >> 5) < nt.RT) nt.inv[r0 + tid] = pow2i(-e);
+        if (blockIdx.y == 0 && tid < TN_SLAB_ROWS && rt0 + (tid >> 5) < nt.RT) nt.inv[r0 + tid] = pow2i(-e);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int u = wave + 4 * j, rtl = u >> 4, kbl = u & 15;
@@ -617,10 +618,16 @@ int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t
     GVQA_REQUIRE(X && V && Y, GVQA_E_INVALID, "gvqa_skinny_forward: null pointer");
     const int Dp = ((int)D + 31) & ~31;
     const size_t lds = (size_t)Dp * SK_JP * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * SK_JP * 4));
-        attr_set = true;
+    {   // the dynamic-LDS opt-in is a per-device function attribute: set once per device
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        GVQA_HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * SK_JP * 4));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     const int64_t ntiles = cdiv(R, 32);
     const int grid = (int)std::min<int64_t>(cdiv(ntiles, 8), 512);
@@ -791,9 +798,9 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
         GVQA_LAUNCH_CHECK();
     }
     const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
-    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(M, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax,
+    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(M, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax,
                        x_absmax_n, p.KC, p.TA, PA, IA, PackNt{});
-    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(N, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax,
+    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(N, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax,
                        y_absmax_n, p.KC, p.TB, PB, IB, PackNt{});
     GVQA_LAUNCH_CHECK();
     LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
@@ -879,7 +886,7 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
     if (dW) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)K, x, ldx, mx + 1);
     if (dx) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(M, 1024)), dim3(256), 0, st, M, (int)K, W, ldw, mx + 2);
     const unsigned slabs = (unsigned)((int64_t)p.tn.S * p.tn.KC / TN_SLAB_ROWS);
-    const dim3 gdy((unsigned)cdiv(M, TN_SLAB_COLS), slabs);
+    const dim3 gdy(slabs, (unsigned)cdiv(M, TN_SLAB_COLS));
     if (dx) hipLaunchKernelGGL(k_split2h_pack_t<true>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA,
                                dW ? PA : nullptr, IA, PackNt{PN, IN, p.RT, p.KBw});
     else hipLaunchKernelGGL(k_split2h_pack_t<false>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA, PA, IA,
@@ -887,7 +894,7 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
     GVQA_LAUNCH_CHECK();
     if (dx) {
         // B operand: W^T [K x M] = the transposed pack of W as ONE chunk of KCw rows
-        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(K, TN_SLAB_COLS), (unsigned)(p.KCw / TN_SLAB_ROWS)), dim3(256), 0, st, M, (int)K,
+        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)(p.KCw / TN_SLAB_ROWS), (unsigned)cdiv(K, TN_SLAB_COLS)), dim3(256), 0, st, M, (int)K,
                            W, ldw, reinterpret_cast<const float*>(mx + 2), 1, p.KCw, p.TBw, PW, IW, PackNt{});
         GVQA_LAUNCH_CHECK();
         LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
@@ -896,7 +903,7 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
         if (rc != GVQA_OK) return rc;
     }
     if (dW) {
-        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3((unsigned)cdiv(K, TN_SLAB_COLS), slabs), dim3(256), 0, st, R, (int)K, x, ldx,
+        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(K, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)K, x, ldx,
                            reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.TB, PB, IB, PackNt{});
         GVQA_LAUNCH_CHECK();
         LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
