@@ -98,6 +98,73 @@ __global__ __launch_bounds__(512) void k_skinny_fwd(int64_t R, int D, int J, con
     }
 }
 
+// The same for J <= 16 on v_mfma_f32_16x16x4_f32 (half the padding, half the matrix-core time: the 32-wide form is bound by
+// it at node-sized X): one wave per 16-row tile, a lane loads 16 bytes of its row per 16-k step (16 rows x 64 contiguous bytes
+// per instruction), four steps in flight; D'[j][row]: lane (row = l % 16, g = l / 16) ends with j = 4 g .. 4 g + 3 of its row.
+typedef float sk_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_skinny_fwd16(int64_t R, int D, int J, const float* __restrict__ X, int64_t ldx,
+                                                      const float* __restrict__ V, float* __restrict__ Y) {
+    extern __shared__ float Vs[];                 // [D padded to 64][16], k-major, J zero-padded to 16
+    const int Dp = (D + 63) & ~63;
+    for (int i = threadIdx.x; i < Dp * 16; i += 512) {
+        const int k = i >> 4, j = i & 15;
+        Vs[i] = (k < D && j < J) ? V[(int64_t)k * J + j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t ntiles = (R + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
+        const int64_t row = tile * 16 + r;
+        const bool row_ok = row < R;
+        const float* xr = X + (row_ok ? row : 0) * ldx;
+        sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float4 a[4], an[4];
+        // a group = 64 k = four 16-k steps; always loads (rows past R read row 0 and are not stored; k past D re-reads k = 0 against
+        // a zero row of Vs)
+        auto load = [&](int c, float4 (&dst)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = c * 64 + q * 16 + 4 * g;
+                dst[q] = *reinterpret_cast<const float4*>(xr + (k < D ? k : 0));
+            }
+        };
+        auto fma = [&](int c, const float4 (&av)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* vs = Vs + (c * 64 + q * 16 + 4 * g) * 16 + r;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[0], av[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[16], av[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[32], av[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vs[48], av[q].w, acc, 0, 0, 0);
+            }
+        };
+        const int nch = Dp >> 6;
+        load(0, a);
+        for (int c = 0; c < nch; c += 2) {
+            load(c + 1, an);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(c, a);
+            __builtin_amdgcn_sched_barrier(0);
+            load(c + 2, a);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nch) fma(c + 1, an);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (row_ok) {
+            float* yr = Y + row * J;
+            const int j0 = 4 * g;
+            if ((J & 3) == 0) {
+                if (j0 < J) *reinterpret_cast<float4*>(yr + j0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (j0 + t < J) yr[j0 + t] = acc[t];
+            }
+        }
+    }
+}
+
 // Partial dV of one chunk of rows: P[blockIdx.x][d][j] = sum over the chunk's rows of X[row][d] G[row][j].
 // MFMA roles: M = d (32 per tile), N = j (32, zero past J), k = rows (2 per instruction: half-waves).
 template <int DT>   // 32-column tiles of D per wave (D <= 128 DT)
@@ -202,39 +269,54 @@ __global__ __launch_bounds__(1024) void k_skinny_dv_reduce(int nparts, int DJ, c
     }
 }
 
-// dX[row][d] = (addend ? addend[row][d] : 0) + sum_j G[row][j] V[d][j]; a thread owns 4 consecutive d and keeps their V rows
-// in registers over SK_DX_ROWS rows.
-constexpr int SK_DX_ROWS = 16;
+// dX[row][d] = (addend ? addend[row][d] : 0) + sum_j G[row][j] V[d][j].  A workgroup owns 32 consecutive rows: their G rows go
+// to LDS once (read back as broadcasts), a thread owns 4 consecutive d of 16 of the rows and keeps the V rows of its columns in
+// registers; 16-byte stores.
+constexpr int SK_DX_ROWS = 32;
 template <int JJ>
 __global__ __launch_bounds__(256) void k_skinny_dx(int64_t R, int D, const float* __restrict__ G, const float* __restrict__ V,
                                                    const float* __restrict__ addend, int64_t ld_add, float* __restrict__ dX,
                                                    int64_t ldx) {
+    __shared__ __attribute__((aligned(16))) float gs[SK_DX_ROWS * JJ];
     const int per_row = D >> 2;                   // D % 4 == 0
-    const int64_t total = ((R + SK_DX_ROWS - 1) / SK_DX_ROWS) * per_row;
-    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
-        const int c = (int)(it % per_row) * 4;
-        const int64_t r0 = (it / per_row) * SK_DX_ROWS;
-        float vt[4][JJ];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < JJ; ++j) vt[t][j] = V[(int64_t)(c + t) * JJ + j];
+    for (int64_t rb = blockIdx.x; rb * SK_DX_ROWS < R; rb += gridDim.x) {
+        const int64_t r0 = rb * SK_DX_ROWS;
         const int nr = (int)((R - r0 < SK_DX_ROWS) ? (R - r0) : SK_DX_ROWS);
+        __syncthreads();                          // the previous tile's readers are done
+        for (int i = threadIdx.x; i < nr * JJ; i += 256) gs[i] = G[r0 * JJ + i];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < per_row * 2; idx += 256) {
+            const int half = idx / per_row, c = (idx - half * per_row) * 4;
+            float vt[4][JJ];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < JJ; ++j) vt[t][j] = V[(int64_t)(c + t) * JJ + j];
+            const int q1 = min(nr, half * 16 + 16);
 #pragma unroll 2
-        for (int q = 0; q < nr; ++q) {
-            const int64_t row = r0 + q;
-            float g[JJ];
+            for (int q = half * 16; q < q1; ++q) {
+                const int64_t row = r0 + q;
+                float4 o = addend ? *reinterpret_cast<const float4*>(addend + row * ld_add + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float g[JJ];
+                if constexpr (JJ % 4 == 0) {      // four coefficients per LDS read
 #pragma unroll
-            for (int j = 0; j < JJ; ++j) g[j] = G[row * JJ + j];
-            float4 o = addend ? *reinterpret_cast<const float4*>(addend + row * ld_add + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int j = 0; j < JJ; j += 4) {
+                        const float4 g4 = *reinterpret_cast<const float4*>(&gs[q * JJ + j]);
+                        g[j] = g4.x; g[j + 1] = g4.y; g[j + 2] = g4.z; g[j + 3] = g4.w;
+                    }
+                } else {
 #pragma unroll
-            for (int j = 0; j < JJ; ++j) {
-                o.x = fmaf(g[j], vt[0][j], o.x);
-                o.y = fmaf(g[j], vt[1][j], o.y);
-                o.z = fmaf(g[j], vt[2][j], o.z);
-                o.w = fmaf(g[j], vt[3][j], o.w);
+                    for (int j = 0; j < JJ; ++j) g[j] = gs[q * JJ + j];
+                }
+#pragma unroll
+                for (int j = 0; j < JJ; ++j) {
+                    o.x = fmaf(g[j], vt[0][j], o.x);
+                    o.y = fmaf(g[j], vt[1][j], o.y);
+                    o.z = fmaf(g[j], vt[2][j], o.z);
+                    o.w = fmaf(g[j], vt[3][j], o.w);
+                }
+                *reinterpret_cast<float4*>(dX + row * ldx + c) = o;
             }
-            *reinterpret_cast<float4*>(dX + row * ldx + c) = o;
         }
     }
 }
@@ -629,6 +711,14 @@ int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
+    if (J <= 16) {       // (at most 64 KiB of LDS: below the default limit)
+        const int Dp16 = ((int)D + 63) & ~63;
+        const int grid16 = (int)std::min<int64_t>(cdiv(cdiv(R, 16), 8), 512);
+        hipLaunchKernelGGL(k_skinny_fwd16, dim3(grid16), dim3(512), (size_t)Dp16 * 16 * sizeof(float), (hipStream_t)stream, R, (int)D, (int)J, X,
+                           ldx, V, Y);
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
     const int64_t ntiles = cdiv(R, 32);
     const int grid = (int)std::min<int64_t>(cdiv(ntiles, 8), 512);
     hipLaunchKernelGGL(k_skinny_fwd, dim3(grid), dim3(512), lds, (hipStream_t)stream, R, (int)D, (int)J, X, ldx, V, Y);
@@ -684,8 +774,8 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
     if (R == 0) return GVQA_OK;
     GVQA_REQUIRE(G && V && dX, GVQA_E_INVALID, "gvqa_skinny_backward_input: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = cdiv(R, SK_DX_ROWS) * (D / 4);
-    const int grid = (int)std::min<int64_t>(cdiv(std::max<int64_t>(total, R * (D / 4) / 4), 256), 8192);
+    const int64_t total = R * (D / 4);                                 // (run-time-J kernel: a thread per element quad)
+    const int grid = (int)std::min<int64_t>(cdiv(R, SK_DX_ROWS), 16384);
 #define GVQA_DX(JJ) hipLaunchKernelGGL(k_skinny_dx<JJ>, dim3(grid), dim3(256), 0, st, R, (int)D, G, V, addend, ld_add, dX, ldx)
     switch (J) {
         case 1: GVQA_DX(1); break;
@@ -698,7 +788,8 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
         case 24: GVQA_DX(24); break;
         case 32: GVQA_DX(32); break;
         default:
-            hipLaunchKernelGGL(k_skinny_dx_any, dim3(grid), dim3(256), 0, st, R, (int)D, (int)J, G, V, addend, ld_add, dX, ldx);
+            hipLaunchKernelGGL(k_skinny_dx_any, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, st, R, (int)D, (int)J, G, V, addend,
+                               ld_add, dX, ldx);
             break;
     }
 #undef GVQA_DX

@@ -16,6 +16,9 @@ for z in "" 1; do ZERO=$z MODES=1,2 ROUNDS=1 python scripts/bench_hop2.py 2>/dev
 for h in 1 4; do HOP=$h python scripts/probe_hop2.py 2>/dev/null | head -2; done > $O/hop2_phase_stamps.jsonl
 python scripts/probe_hop2_loop.py 2>/dev/null | grep workgroups_per_cu > $O/hop2_loop_parts.jsonl
 python scripts/bench_train.py 2>/dev/null | tail -1 > $O/train_cfg3.json
+python scripts/bench_skinny.py 2>/dev/null | grep "^{" > $O/train_products.jsonl
+( cd /tmp && TRAIN_ONLY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/tprof -o ks -- python $GRAFT_REPO_ROOT/scripts/bench_train.py > /dev/null 2>&1 )
+cp $(find $O/tprof -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv 2>/dev/null
 # SQ counters of the hop kernels (separate --pmc passes, kernel trace only)
 for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA"; do
   tag=$(echo $pass | cut -d' ' -f1)
@@ -34,5 +37,5 @@ for k, v in acc.items():
     for c, vals in sorted(v.items()):
         print("   %-28s %14.0f  (n=%d)" % (c, sum(vals) / len(vals), len(vals)))
 PY
-rm -rf $O/prof $O/pmc_SQ_*
+rm -rf $O/prof $O/tprof $O/pmc_SQ_*
 ls -la $O
