@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Training step of gat_seq at BASELINE config 3 (64k nodes / 256k edges, d=512, K=5): forward + backward through the
+"""Training step of gat_seq at BASELINE config 3 (64k nodes / 256k edges, d=512, K=5; CONFIG=2: config 2, d=300): forward + backward through the
 differentiable path (HIP message passing + HIP backward, torch GEMMs / BatchNorm / dropout), and the two backward
 kernels alone.  Prints one JSON object."""
 import ctypes as C, json, os, sys, time
@@ -10,12 +10,18 @@ from graphvqa_amd.gat_skip import gat_seq, gat_message_passing
 from graphvqa_amd.graph import SceneGraphBatch
 
 dev = torch.device("cuda:0"); tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-D, H, K = 512, 4, 5
-gb = synth.config3_batch(); N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
-m = gat_seq(D, D, D, D, K, dropout=0.1, gat_heads=H)
-m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.gat_seq_params(D, D, D, D, K, H, seed=777).items()})
+H, K = 4, 5
+if os.environ.get("CONFIG") == "2":        # BASELINE config 2: d = 300, instruction vectors 512, 1000 graphs of ~30 nodes
+    D, DI = 300, 512
+    gb = synth.config2_batch()
+else:
+    D, DI = 512, 512
+    gb = synth.config3_batch()
+N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+m = gat_seq(D, D, D, DI, K, dropout=0.1, gat_heads=H)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.gat_seq_params(D, D, D, DI, K, H, seed=777).items()})
 m = m.to(dev).train()
-x, ea, ins = tt(synth.normal((N, D), 1)), tt(synth.normal((E, D), 2)), tt(synth.normal((K, B, D), 3))
+x, ea, ins = tt(synth.normal((N, D), 1)), tt(synth.normal((E, D), 2)), tt(synth.normal((K, B, DI), 3))
 ei, batch = tt(gb.edge_index), tt(gb.batch)
 g = SceneGraphBatch(ei, batch, N, B); g.transposed()
 opt = torch.optim.SGD(m.parameters(), lr=1e-3)
