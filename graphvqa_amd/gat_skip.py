@@ -111,7 +111,7 @@ class _ProjectionLinear(torch.autograd.Function):
         return gx, gw
 
     @staticmethod
-    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None):
+    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None, gw_out=None):
         """dx = dy W and dW = dy^T x in one library call under the two-piece arithmetic (gvqa_linear_backward_split2h: dy is read and
         packed once for both products); None when the shapes / settings are not the ones it takes."""
         lib = _lib.load()
@@ -121,18 +121,19 @@ class _ProjectionLinear(torch.autograd.Function):
               K % 4 == 0 and R > 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and w.stride(1) == 1 and w.stride(0) % 4 == 0 and
               lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H and
               2.0 * R * M * K >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
-        if not ok or not (want_x or want_w):
+        if not ok or not (want_x or want_w) or (gw_out is not None and (gw_out.stride(1) != 1 or gw_out.stride(0) % 4 != 0)):
             return None
         am = getattr(gy, "_gvqa_absmax", None) if gy.is_contiguous() else None
         gy = gy.contiguous()
         dev = gy.device
         gx = (gx_init if gx_init is not None else torch.empty((R, K), dtype=torch.float32, device=dev)) if want_x else None
-        gw = torch.empty((M, K), dtype=torch.float32, device=dev) if want_w else None
+        gw = (gw_out if gw_out is not None else torch.empty((M, K), dtype=torch.float32, device=dev)) if want_w else None      # (gw_out: a column block of a wider gradient, row stride = its width)
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dev)
             _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
                                                         _ptr(am), 0 if am is None else am.numel(), _ptr(gx), K,
-                                                        int(gx_init is not None and want_x), _ptr(gw), K, ws.data_ptr(), ws.numel(), _stream(dev)))
+                                                        int(gx_init is not None and want_x), _ptr(gw), K if gw is None else gw.stride(0),
+                                                        ws.data_ptr(), ws.numel(), _stream(dev)))
         return gx, gw
 
     @staticmethod
@@ -255,55 +256,78 @@ def fold_attention(W: Tensor, att_a: Tensor, att_b: Optional[Tensor], heads: int
     return _FoldAttention.apply(W, att_a, att_b, heads)
 
 
-class _NodeProducts(torch.autograd.Function):
-    """(xp, a) = (h W^T, h V) for the hop's node rows: the projection (gat_skip.py:133) and the folded attention logits (:134-135)
-    as ONE autograd node, so that the backward forms dh = da V^T + dxp W in place (the projection's GEMM accumulates onto the
-    logit products' input gradient) instead of two tensors and an add.  Falls back to the two separate ops' arithmetic."""
+class _HopProducts(torch.autograd.Function):
+    """Everything a hop multiplies by its lin_l weight, as ONE autograd node (gat_skip.py:133-135 on x_cat = [h | ins[batch]], :263-264):
+        xp      = h W[:, :Dn]^T            [N, H*C]   node half of the projection (library GEMM)
+        a_part  = h F[:Dn]                 [N, 2H]    node half of the folded logits (F = att_l | att_r through W)
+        xp_rows = ins W[:, Dn:]^T          [B, H*C]   instruction half, one row per graph
+        a_rows  = ins [F[Dn:, :H] + U_e | F[Dn:, H:]]   [B, 2H]   (U_e: the edge's instruction term, :257-260, on the source half)
+    The backward writes ONE full-size dW (left columns from the split-K product, right columns from the per-graph rows) and one
+    full-size dF -- no column slices of W or F in the autograd graph, hence no zero-padded slice gradients to fill and add."""
 
     @staticmethod
-    def forward(ctx, h, W, V):
-        ctx.save_for_backward(h, W, V)
+    def forward(ctx, h, ins, W, F_, U_e, Dn):
+        heads2 = F_.shape[1]
+        H = heads2 // 2
         with torch.no_grad():
-            return _ProjectionLinear._product(h, W), skinny_linear(h, V)
+            xp = _ProjectionLinear._product(h, W[:, :Dn])
+            a_part = skinny_linear(h, F_[:Dn])
+            xp_rows = torch.nn.functional.linear(ins, W[:, Dn:])
+            U_n = F_[Dn:].clone()
+            U_n[:, :H] += U_e
+            a_rows = ins @ U_n
+        ctx.save_for_backward(h, ins, W, F_, U_n)
+        ctx.Dn = Dn
+        return xp, a_part, xp_rows, a_rows
 
     @staticmethod
-    def backward(ctx, gxp, ga):
-        h, W, V = ctx.saved_tensors
+    def backward(ctx, gxp, ga, g_rows, g_arows):
+        h, ins, W, F_, U_n = ctx.saved_tensors
+        Dn = ctx.Dn
         lib = _lib.load()
-        want_h, want_w, want_v = ctx.needs_input_grad
+        want_h, want_ins, want_w, want_f, want_ue = ctx.needs_input_grad[:5]
         R, D = h.shape
-        J = V.shape[1]
-        gV = gh = None
-        ok = _SkinnyLinear.supported(h, V) and J in (1, 2, 4, 8, 12, 16, 20, 24, 32)
+        H2 = F_.shape[1]
+        H = H2 // 2
+        dev = h.device
+        V = F_[:Dn]                                           # contiguous row block
         ga = ga.contiguous()
-        Vc = V.contiguous()
-        if want_v:
+        gh = gF = gW = gins = gUe = None
+        ok = _SkinnyLinear.supported(h, V) and H2 in (2, 4, 8, 16)
+        if want_f or want_ue:
+            gF = torch.empty_like(F_)
             if ok:
-                gV = torch.empty_like(Vc)
-                with torch.cuda.device(h.device):
-                    ws = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(R, D, J), h.device)
-                    _lib.check(lib.gvqa_skinny_backward_weight(R, D, J, h.data_ptr(), h.stride(0), ga.data_ptr(), gV.data_ptr(), ws.data_ptr(),
-                                                               ws.numel(), _stream(h.device)))
+                with torch.cuda.device(dev):
+                    ws = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(R, D, H2), dev)
+                    _lib.check(lib.gvqa_skinny_backward_weight(R, D, H2, h.data_ptr(), h.stride(0), ga.data_ptr(), gF.data_ptr(), ws.data_ptr(),
+                                                               ws.numel(), _stream(dev)))
             else:
-                gV = h.t() @ ga
+                torch.mm(h.t(), ga, out=gF[:Dn])
+            torch.mm(ins.t(), g_arows, out=gF[Dn:])           # d a_rows / d U_n = ins^T g_arows: rows [Dn:] of dF ...
+            if want_ue:
+                gUe = gF[Dn:, :H].clone()                     # ... whose source half is dU_e as well
         if want_h:
             if ok:
-                gh = torch.empty((R, D), dtype=torch.float32, device=h.device)
-                with torch.cuda.device(h.device):
-                    _lib.check(lib.gvqa_skinny_backward_input(R, D, J, ga.data_ptr(), Vc.data_ptr(), None, 0, gh.data_ptr(), D, _stream(h.device)))
+                gh = torch.empty((R, D), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.gvqa_skinny_backward_input(R, D, H2, ga.data_ptr(), V.data_ptr(), None, 0, gh.data_ptr(), D, _stream(dev)))
             else:
-                gh = ga @ Vc.t()
-        fused = _ProjectionLinear._backward_fused(gxp, h, W, want_h, want_w, gx_init=gh)
-        if fused is not None:
-            gh2, gW = fused
-            return (gh2 if want_h else None), gW, gV
-        gW = None
-        if want_h:
-            gx = _ProjectionLinear._product(gxp.contiguous(), W.t().contiguous())
-            gh = gx + gh
+                gh = ga @ V.t()
         if want_w:
-            gW = _ProjectionLinear._weight_grad(gxp, h)
-        return gh, gW, gV
+            gW = torch.empty_like(W)
+            gW[:, Dn:] = g_rows.t() @ ins                     # instruction half: dW_i = d xp_rows^T ins
+        Wh = W[:, :Dn]
+        fused = _ProjectionLinear._backward_fused(gxp, h, Wh, want_h, want_w, gx_init=gh, gw_out=None if gW is None else gW[:, :Dn])
+        if fused is not None:
+            gh = fused[0] if want_h else None
+        else:
+            if want_h:
+                gh = _ProjectionLinear._product(gxp.contiguous(), Wh.t().contiguous()) + gh
+            if want_w:
+                gW[:, :Dn] = _ProjectionLinear._weight_grad(gxp, h)
+        if want_ins:
+            gins = g_rows @ W[:, Dn:] + g_arows @ U_n.t()
+        return gh, gins, gW, (gF if want_f else None), gUe, None
 
 
 class _GatMessagePassing(torch.autograd.Function):
@@ -924,13 +948,11 @@ class gat_seq(torch.nn.Module):
             W, We = conv.lin_l.weight, conv.lin_e.weight
             # projected features: node half per row, instruction half per graph
             # (the per-graph rows ride through the message passing as `graph_rows`: the [N, H*C] sum is never formed)
-            fold_n = fold_attention(W, conv.att_l, conv.att_r, H)              # [Dn + Di, 2H]: att_l | att_r through lin_l
-            V_n, U_e = fold_n[:Dn], folds_e[i][De:]
-            (xp, a_part), xp_rows = _NodeProducts.apply(h, W[:, :Dn], V_n), F.linear(ins, W[:, Dn:])
             # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
             # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
-            U_n = torch.cat((fold_n[Dn:, :H] + U_e, fold_n[Dn:, H:]), dim=1)
-            a_node = add_graph_rows(a_part, ins @ U_n, graph)
+            fold_n = fold_attention(W, conv.att_l, conv.att_r, H)              # [Dn + Di, 2H]: att_l | att_r through lin_l
+            xp, a_part, xp_rows, a_rows = _HopProducts.apply(h, ins, W, fold_n, folds_e[i][De:], Dn)
+            a_node = add_graph_rows(a_part, a_rows, graph)
             a_edge = a_edge_all[:, i * H:(i + 1) * H]
             mask = None
             if alpha_masks is not None:
