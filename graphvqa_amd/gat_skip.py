@@ -633,6 +633,16 @@ def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: Scene
     xp [N, H*C] projected features, a_node [N, 2H] = (a_l | a_r), a_edge [E, H]; alpha_mask [E, H] multiplies alpha
     after the softmax (attention dropout: mask / (1 - p)); graph_rows [B, H*C]: rows added to xp per graph (kept out of xp);
     bias [C], skip [N, C]: added to the result in the same pass."""
+    if channels % 4 != 0 and (graph_rows is not None or bias is not None or skip is not None):
+        # the one-pass kernels move 16 bytes at a time: other widths take the explicit form (same math, torch adds)
+        if graph_rows is not None:
+            xp = add_graph_rows(xp, graph_rows, graph)
+        out, alpha = _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, None, None, None)
+        if bias is not None:
+            out = out + bias
+        if skip is not None:
+            out = out + skip
+        return out, alpha
     return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, graph_rows, bias, skip)
 
 

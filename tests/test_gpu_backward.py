@@ -745,3 +745,17 @@ def test_gat_seq_gradients_with_dropout_masks_on_the_library_products(dev):
         test_gat_seq_gradients_with_dropout_masks(dev)
     finally:
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+
+
+@pytest.mark.parametrize("threshold", [None, 0])
+def test_gat_seq_gradients_at_widths_the_library_products_do_not_take(dev, threshold):
+    """Widths that are not multiples of 4 (d = 30, ins 22, H = 2): every product of the differentiable path takes its torch
+    form, the message passing and the per-graph rows stay on the kernels; all gradients against the oracle's fp64 autograd."""
+    from graphvqa_amd import _lib
+    old = None if threshold is None else _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, threshold)
+    try:
+        _grads_vs_oracle(dev, train=True, dims=(30, 18, 22, 2, 2), seed=13, graphs=9)
+        _grads_vs_oracle(dev, train=False, dims=(36, 20, 24, 3, 1), seed=14, graphs=9)
+    finally:
+        if old is not None:
+            _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
