@@ -62,11 +62,39 @@ __global__ __launch_bounds__(1024) void k_bn_col_finish(int nblocks, int C, cons
 
 __global__ __launch_bounds__(256) void k_bn_relu_apply(int64_t total, int C, const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ w,
-                                                       const float* __restrict__ b, float eps, float* __restrict__ y) {
+                                                       const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                       const uint8_t* __restrict__ keep, float kscale) {
+    // keep != NULL: feature dropout applied on the way out (gat_skip.py:276): y *= keep[i] ? kscale : 0
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const float invstd = 1.0f / sqrtf(var[c] + eps);
-        y[i] = fmaxf((x[i] - mean[c]) * invstd * w[c] + b[c], 0.f);
+        const float v = fmaxf((x[i] - mean[c]) * invstd * w[c] + b[c], 0.f);
+        y[i] = keep ? (keep[i] ? v * kscale : 0.f) : v;
+    }
+}
+
+// the same with 16-byte accesses (C % 4 == 0): a thread owns 4 consecutive channels and walks rows
+__global__ __launch_bounds__(256) void k_bn_relu_apply_v4(int64_t N, int C, int TPR, const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                          const uint8_t* __restrict__ keep, float kscale) {
+    const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
+    for (int c4 = tcol; c4 < (C >> 2); c4 += TPR) {
+        const int c = c4 * 4;
+        const float4 m = *reinterpret_cast<const float4*>(mean + c), v = *reinterpret_cast<const float4*>(var + c);
+        const float4 wc = *reinterpret_cast<const float4*>(w + c), bc = *reinterpret_cast<const float4*>(b + c);
+        const float4 is = make_float4(1.0f / sqrtf(v.x + eps), 1.0f / sqrtf(v.y + eps), 1.0f / sqrtf(v.z + eps), 1.0f / sqrtf(v.w + eps));
+        for (int64_t r = (int64_t)blockIdx.x * RPB + trow; r < N; r += (int64_t)gridDim.x * RPB) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+            // (x - mean) * invstd * w + b, in the scalar kernel's operation order
+            float4 o = make_float4(fmaxf((xv.x - m.x) * is.x * wc.x + bc.x, 0.f), fmaxf((xv.y - m.y) * is.y * wc.y + bc.y, 0.f),
+                                   fmaxf((xv.z - m.z) * is.z * wc.z + bc.z, 0.f), fmaxf((xv.w - m.w) * is.w * wc.w + bc.w, 0.f));
+            if (keep) {
+                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + r * C + c);
+                o.x = k4.x ? o.x * kscale : 0.f; o.y = k4.y ? o.y * kscale : 0.f; o.z = k4.z ? o.z * kscale : 0.f; o.w = k4.w ? o.w * kscale : 0.f;
+            }
+            *reinterpret_cast<float4*>(y + r * C + c) = o;
+        }
     }
 }
 
@@ -74,7 +102,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(int64_t total, int C, con
 __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce(int64_t N, int C, const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ var,
                                                             const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, const uint8_t* __restrict__ keep, float kscale) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
     const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
@@ -82,7 +110,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce(int64_t N, int C, co
     float s0 = 0.f, s1 = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
         const float xh = (x[r * C + c] - m) * invstd;
-        const float g = xh * wc + bc > 0.f ? dy[r * C + c] : 0.f;
+        float g = xh * wc + bc > 0.f ? dy[r * C + c] : 0.f;
+        if (keep) g = keep[r * C + c] ? g * kscale : 0.f;
         s0 += g;
         s1 += g * xh;
     }
@@ -94,12 +123,14 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply(int64_t total, int C,
                                                            const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ var, const float* __restrict__ w,
                                                            const float* __restrict__ b, float eps, const float* __restrict__ dbias,
-                                                           const float* __restrict__ dweight, float* __restrict__ dx) {
+                                                           const float* __restrict__ dweight, float* __restrict__ dx,
+                                                           const uint8_t* __restrict__ keep, float kscale) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const float invstd = 1.0f / sqrtf(var[c] + eps);
         const float xh = (x[i] - mean[c]) * invstd;
-        const float g = xh * w[c] + b[c] > 0.f ? dy[i] : 0.f;
+        float g = xh * w[c] + b[c] > 0.f ? dy[i] : 0.f;
+        if (keep) g = keep[i] ? g * kscale : 0.f;
         dx[i] = w[c] * invstd * (g - dbias[c] * inv_n - xh * dweight[c] * inv_n);
     }
 }
@@ -109,7 +140,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply(int64_t total, int C,
 __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce_v4(int64_t N, int C, int TPR, const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ mean, const float* __restrict__ var,
                                                                const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                               float* __restrict__ partial) {
+                                                               float* __restrict__ partial, const uint8_t* __restrict__ keep, float kscale) {
     __shared__ float4 red[2][256];
     const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
     const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
@@ -121,7 +152,12 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce_v4(int64_t N, int C,
         const float4 is = make_float4(1.0f / sqrtf(v.x + eps), 1.0f / sqrtf(v.y + eps), 1.0f / sqrtf(v.z + eps), 1.0f / sqrtf(v.w + eps));
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
         for (int64_t r = r0 + trow; on && r < r1; r += RPB) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c), gv = *reinterpret_cast<const float4*>(dy + r * C + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+            float4 gv = *reinterpret_cast<const float4*>(dy + r * C + c);
+            if (keep) {
+                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + r * C + c);
+                gv.x = k4.x ? gv.x * kscale : 0.f; gv.y = k4.y ? gv.y * kscale : 0.f; gv.z = k4.z ? gv.z * kscale : 0.f; gv.w = k4.w ? gv.w * kscale : 0.f;
+            }
             const float4 xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
             const float4 g = make_float4(xh.x * wc.x + bc.x > 0.f ? gv.x : 0.f, xh.y * wc.y + bc.y > 0.f ? gv.y : 0.f,
                                          xh.z * wc.z + bc.z > 0.f ? gv.z : 0.f, xh.w * wc.w + bc.w > 0.f ? gv.w : 0.f);
@@ -148,7 +184,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply_v4(int64_t N, int C, 
                                                               const float* __restrict__ dy, const float* __restrict__ mean,
                                                               const float* __restrict__ var, const float* __restrict__ w,
                                                               const float* __restrict__ b, float eps, const float* __restrict__ dbias,
-                                                              const float* __restrict__ dweight, float* __restrict__ dx) {
+                                                              const float* __restrict__ dweight, float* __restrict__ dx,
+                                                              const uint8_t* __restrict__ keep, float kscale) {
     const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
     for (int c4 = tcol; c4 < (C >> 2); c4 += TPR) {
         const int c = c4 * 4;
@@ -162,7 +199,12 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply_v4(int64_t N, int C, 
             return ww * ii * (g - dbb * inv_n - xh * dww * inv_n);
         };
         for (int64_t r = (int64_t)blockIdx.x * RPB + trow; r < N; r += (int64_t)gridDim.x * RPB) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c), gv = *reinterpret_cast<const float4*>(dy + r * C + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+            float4 gv = *reinterpret_cast<const float4*>(dy + r * C + c);
+            if (keep) {
+                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + r * C + c);
+                gv.x = k4.x ? gv.x * kscale : 0.f; gv.y = k4.y ? gv.y * kscale : 0.f; gv.z = k4.z ? gv.z * kscale : 0.f; gv.w = k4.w ? gv.w * kscale : 0.f;
+            }
             *reinterpret_cast<float4*>(dx + r * C + c) =
                 make_float4(one(xv.x, gv.x, m.x, is.x, wc.x, bc.x, db.x, dw.x), one(xv.y, gv.y, m.y, is.y, wc.y, bc.y, db.y, dw.y),
                             one(xv.z, gv.z, m.z, is.z, wc.z, bc.z, db.z, dw.z), one(xv.w, gv.w, m.w, is.w, wc.w, bc.w, db.w, dw.w));
@@ -180,6 +222,12 @@ extern "C" size_t gvqa_bn_train_workspace_bytes(int64_t N, int32_t C) {
 
 extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
                                           float* y, float* save_mean, float* save_var, void* ws, size_t ws_bytes, void* stream_) {
+    return gvqa_bn_relu_dropout_train_forward(N, C, x, weight, bias, eps, nullptr, 1.0f, y, save_mean, save_var, ws, ws_bytes, stream_);
+}
+
+extern "C" int gvqa_bn_relu_dropout_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                                  const uint8_t* keep, float keep_scale, float* y, float* save_mean, float* save_var,
+                                                  void* ws, size_t ws_bytes, void* stream_) {
     using namespace gvqa;
     GVQA_REQUIRE(N >= 0 && C > 0, GVQA_E_INVALID, "bn_relu_train_forward: bad sizes");
     if (N == 0) return GVQA_OK;
@@ -195,8 +243,13 @@ extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, 
     hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, save_mean, partial);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_var);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
-    hipLaunchKernelGGL(k_bn_relu_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, x, save_mean, save_var, weight, bias,
-                       eps, y);
+    const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
+    int TPR = 1;
+    while (TPR < 256 && TPR < C / 4) TPR <<= 1;
+    if (v4) hipLaunchKernelGGL(k_bn_relu_apply_v4, dim3((unsigned)std::min<int64_t>(cdiv(N, 256 / TPR), 4096)), dim3(256), 0, stream, N, (int)C, TPR, x,
+                               save_mean, save_var, weight, bias, eps, y, keep, keep_scale);
+    else hipLaunchKernelGGL(k_bn_relu_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, x, save_mean, save_var, weight, bias,
+                            eps, y, keep, keep_scale);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -204,6 +257,14 @@ extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, 
 extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
                                            const float* save_mean, const float* save_var, float eps, const float* dy, float* dx,
                                            float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream_) {
+    return gvqa_bn_relu_dropout_train_backward(N, C, x, weight, bias, save_mean, save_var, eps, nullptr, 1.0f, dy, dx, dweight, dbias, ws, ws_bytes,
+                                               stream_);
+}
+
+extern "C" int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+                                                   const float* save_mean, const float* save_var, float eps, const uint8_t* keep,
+                                                   float keep_scale, const float* dy, float* dx, float* dweight, float* dbias, void* ws,
+                                                   size_t ws_bytes, void* stream_) {
     using namespace gvqa;
     GVQA_REQUIRE(N >= 0 && C > 0, GVQA_E_INVALID, "bn_relu_train_backward: bad sizes");
     if (N == 0) return GVQA_OK;
@@ -216,19 +277,21 @@ extern "C" int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x,
     GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
     const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
     // 16-byte form when the rows allow it (same operations per element, same summation order within a row block's thread rows)
-    const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     int TPR = 1;
     while (TPR < 256 && TPR < C / 4) TPR <<= 1;
     if (v4) hipLaunchKernelGGL(k_bn_relu_bwd_reduce_v4, dim3((unsigned)nb), dim3(256), 0, stream, N, (int)C, TPR, x, dy, save_mean, save_var, weight,
-                               bias, eps, partial);
-    else hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial);
+                               bias, eps, partial, keep, keep_scale);
+    else hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial, keep,
+                            keep_scale);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
     if (v4) hipLaunchKernelGGL(k_bn_relu_bwd_apply_v4, dim3((unsigned)std::min<int64_t>(cdiv(N, 256 / TPR), 4096)), dim3(256), 0, stream, N, (int)C,
-                               TPR, 1.0f / (float)N, x, dy, save_mean, save_var, weight, bias, eps, dbias, dweight, dx);
+                               TPR, 1.0f / (float)N, x, dy, save_mean, save_var, weight, bias, eps, dbias, dweight, dx, keep, keep_scale);
     else hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, 1.0f / (float)N, x, dy, save_mean,
-                            save_var, weight, bias, eps, dbias, dweight, dx);
+                            save_var, weight, bias, eps, dbias, dweight, dx, keep, keep_scale);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

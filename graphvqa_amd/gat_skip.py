@@ -419,44 +419,51 @@ class _GatMessagePassing(torch.autograd.Function):
 
 class _BatchNormReluTrain(torch.autograd.Function):
     """relu(BatchNorm1d(x)) with batch statistics (gat_skip.py:273-275 under model.train()), HIP forward and backward.
-    Returns (y, batch mean, biased batch variance); the module updates the running statistics."""
+    Returns (y, batch mean, biased batch variance); the module updates the running statistics.
+    `keep` [N, C] uint8 (optional) with `keep_scale` = 1 / (1 - p): feature dropout (gat_skip.py:276) applied in the same passes,
+    y = relu(bn(x)) * (keep ? keep_scale : 0) -- the mask is drawn by the caller with torch's generator."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, keep=None, keep_scale=1.0):
         lib = _lib.load()
         x, weight, bias = _f32c(x, "x"), _f32c(weight, "bn.weight"), _f32c(bias, "bn.bias")
         N, Cc = x.shape
+        if keep is not None and (keep.dtype != torch.uint8 or keep.shape != x.shape or not keep.is_contiguous() or keep.device != x.device):
+            raise ValueError("bn_relu_train: keep must be a contiguous uint8 [N, C] tensor on x's device")
         y, mean, var = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
         with torch.cuda.device(x.device):
             ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
-            _lib.check(lib.gvqa_bn_relu_train_forward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps, y.data_ptr(),
-                                                      mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
-        ctx.save_for_backward(x, weight, bias, mean, var)
-        ctx.eps = eps
+            _lib.check(lib.gvqa_bn_relu_dropout_train_forward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps, _ptr(keep),
+                                                              float(keep_scale), y.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(),
+                                                              ws.numel(), _stream(x.device)))
+        ctx.save_for_backward(x, weight, bias, mean, var, keep)
+        ctx.eps, ctx.keep_scale = eps, float(keep_scale)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
         lib = _lib.load()
-        x, weight, bias, mean, var = ctx.saved_tensors
+        x, weight, bias, mean, var, keep = ctx.saved_tensors
         N, Cc = x.shape
         dy = dy.contiguous()
         dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(bias)
         with torch.cuda.device(x.device):
             ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
-            _lib.check(lib.gvqa_bn_relu_train_backward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
-                                                       var.data_ptr(), ctx.eps, dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-                                                       db.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
-        return dx, dw, db, None
+            _lib.check(lib.gvqa_bn_relu_dropout_train_backward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
+                                                               var.data_ptr(), ctx.eps, _ptr(keep), ctx.keep_scale, dy.data_ptr(), dx.data_ptr(),
+                                                               dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
+        return dx, dw, db, None, None, None
 
 
-def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor) -> Tensor:
-    """relu(bn(x)) in training mode on the HIP kernels, with torch's running-statistics update (momentum, unbiased
-    variance, num_batches_tracked)."""
+def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor, p: float = 0.0) -> Tensor:
+    """dropout_p(relu(bn(x))) in training mode on the HIP kernels, with torch's running-statistics update (momentum, unbiased
+    variance, num_batches_tracked).  p > 0: the keep mask is drawn here with torch's generator (one byte per element) and applied
+    inside the BatchNorm passes, forward and backward."""
     if bn.weight is None or bn.bias is None or x.shape[0] < 2:
-        return torch.relu(bn(x))
-    y, mean, var = _BatchNormReluTrain.apply(x, bn.weight, bn.bias, bn.eps)
+        return torch.nn.functional.dropout(torch.relu(bn(x)), p=p, training=p > 0)
+    keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p) if p > 0 else None
+    y, mean, var = _BatchNormReluTrain.apply(x, bn.weight, bn.bias, bn.eps, keep, 1.0 / (1.0 - p) if p > 0 else 1.0)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -977,11 +984,12 @@ class gat_seq(torch.nn.Module):
             h, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask, graph_rows=xp_rows,
                                            bias=conv.bias, skip=h)
             if i != K - 1:
-                h = _bn_relu_train(self.bns[i], h) if self.training else torch.relu(self.bns[i](h))
-                if feature_masks is not None:
-                    h = h * feature_masks[i]
+                if feature_masks is not None:                  # (tests: given masks)
+                    h = (_bn_relu_train(self.bns[i], h) if self.training else torch.relu(self.bns[i](h))) * feature_masks[i]
+                elif self.training:                            # BatchNorm + ReLU + feature dropout (:273-276) in the same passes
+                    h = _bn_relu_train(self.bns[i], h, p)
                 else:
-                    h = F.dropout(h, p=p, training=p > 0)
+                    h = torch.relu(self.bns[i](h))
             alphas.append(alpha)
             hops.append(h)
         if return_attention_weights or return_hops:

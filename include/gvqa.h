@@ -204,6 +204,16 @@ int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, const float
 int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
                                 const float* save_mean, const float* save_var, float eps, const float* dy, float* dx,
                                 float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
+/* The same with feature dropout (gat_skip.py:276, F.dropout after BatchNorm + ReLU) applied in the same passes:
+ * y = relu(bn(x)) * (keep[i] ? keep_scale : 0) with keep [N, C] bytes drawn by the caller (torch's generator: masks are the
+ * caller's randomness) and keep_scale = 1 / (1 - p); the backward takes dL/dy of THAT y.  keep NULL: no dropout. */
+int gvqa_bn_relu_dropout_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                       const uint8_t* keep, float keep_scale, float* y, float* save_mean, float* save_var, void* ws,
+                                       size_t ws_bytes, void* stream);
+int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+                                        const float* save_mean, const float* save_var, float eps, const uint8_t* keep,
+                                        float keep_scale, const float* dy, float* dx, float* dweight, float* dbias, void* ws,
+                                        size_t ws_bytes, void* stream);
 
 /* Per-graph rows <-> node rows (glue of the differentiable path: the per-graph instruction terms).
  * rows_to_nodes: out[i, :F] (= or +=) rows[graph(i), :F];  segment_sum (its adjoint): out[b, :F] = sum of x[i, :F]

@@ -759,3 +759,25 @@ def test_gat_seq_gradients_at_widths_the_library_products_do_not_take(dev, thres
     finally:
         if old is not None:
             _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+
+
+@pytest.mark.parametrize("N,C", [(257, 64), (1000, 300), (4097, 512), (33, 30)])
+def test_bn_relu_with_feature_dropout_in_the_same_passes(dev, N, C):
+    """_BatchNormReluTrain with a keep mask: y = relu(bn(x)) * keep / (1 - p) and its gradients (x, weight, bias) against torch
+    autograd applying the same mask; widths with and without the 16-byte form."""
+    from graphvqa_amd.gat_skip import _BatchNormReluTrain
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn((N, C), generator=g).to(dev).requires_grad_(True)
+    w = (1.0 + 0.3 * torch.randn(C, generator=g)).to(dev).requires_grad_(True)
+    b = (0.2 * torch.randn(C, generator=g)).to(dev).requires_grad_(True)
+    keep = (torch.rand((N, C), generator=g) > 0.25).to(torch.uint8).to(dev)
+    gy = torch.randn((N, C), generator=g).to(dev)
+    y, mean, var = _BatchNormReluTrain.apply(x, w, b, 1e-5, keep, 1.0 / 0.75)
+    y.backward(gy)
+    xr, wr, br = [v.detach().double().requires_grad_(True) for v in (x, w, b)]
+    ref = torch.relu(torch.nn.functional.batch_norm(xr, None, None, wr, br, True, 0.0, 1e-5)) * keep.double() / 0.75
+    ref.backward(gy.double())
+    assert maxabs(y, ref) < 2e-5
+    assert maxabs(mean, xr.mean(0)) < 1e-5 and maxabs(var, xr.var(0, unbiased=False)) < 1e-5
+    for got, r, name in ((x.grad, xr.grad, "dx"), (w.grad, wr.grad, "dw"), (b.grad, br.grad, "db")):
+        assert _rel(got, r) < 2e-5, name
