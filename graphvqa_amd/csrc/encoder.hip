@@ -8,6 +8,13 @@
 // Restructuring: the concatenations [x_src || x_dst || e] / [x_src || e'] / [x || agg] are never
 // built -- the first Linear of every MLP is split by column block; node-side blocks are projected
 // per NODE (N x D x D) and gathered, only the edge-side blocks cost E x D x D.
+//
+// Round 3 (the encoder was 4.0 of the 6.6 ms of the whole graph side at config-3 batch size, 2.4 ms of it four edge-sized
+// f32-MFMA products): (i) the edge block of the first EdgeModel Linear acts on e0 = +-sum_t emb[tok] and is linear, so it is
+// applied to the EMBEDDING TABLE once (V x D x D) and the per-edge product becomes the token gather that was there anyway
+// (k_embed_sum on the projected table); (ii) edge_attr' = Y W2^T + b2 feeds the next Linear with nothing in between, so that
+// product is folded into one on Y with W' = Wn_e W2, b' = Wn_e b2 -- Y is packed once for both; (iii) all node- and edge-sized
+// products run on the two-piece fp16 kernels (split3.hip), x0 packed once for its four products.
 #include "common.h"
 
 namespace gvqa {
@@ -128,13 +135,31 @@ __global__ __launch_bounds__(256) void k_graph_layernorm(int D, const int32_t* _
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) out[i] = (x[i] - mean) / sd * ww + bb;
 }
 
-struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, total; };
+// C[i, k] = sum_j A[i, j] B[j, k]  (parameter-sized products: the folded weight W' = Wn_e W2 and bias b' = Wn_e b2)
+__global__ __launch_bounds__(256) void k_small_matmul_nn(int M, int N, int K, const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc) {
+    const int k = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (k >= N || i >= M) return;
+    float a0 = 0.f, a1 = 0.f;
+    int j = 0;
+    for (; j + 2 <= K; j += 2) {
+        a0 = fmaf(A[(int64_t)i * lda + j], B[(int64_t)j * ldb + k], a0);
+        a1 = fmaf(A[(int64_t)i * lda + j + 1], B[(int64_t)(j + 1) * ldb + k], a1);
+    }
+    if (j < K) a0 = fmaf(A[(int64_t)i * lda + j], B[(int64_t)j * ldb + k], a0);
+    C[(int64_t)i * ldc + k] = a0 + a1;
+}
+
+struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, apk_n, apk_e, wpk, total; };
 static EncLayout enc_layout(int64_t N, int64_t E, int D) {
     EncLayout L; size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
     const size_t nd = (size_t)N * D * 4, ed = (size_t)E * D * 4;
     L.x0 = take(nd); L.e0 = take(ed); L.S = take(nd); L.Dd = take(nd); L.P = take(nd); L.Y = take(ed); L.m = take(ed);
     L.agg = take(nd); L.t = take(nd); L.x2 = take(nd); L.flags = take((size_t)E + 1);
+    // folded weight / bias, packed two-piece operands (node rows, edge rows, one weight at a time)
+    L.wf = take((size_t)D * D * 4); L.bf = take((size_t)D * 4);
+    L.apk_n = take(split_packed_bytes(2, N, D)); L.apk_e = take(split_packed_bytes(2, E, D)); L.wpk = take(split_packed_bytes(2, D, D));
     L.total = off;
     return L;
 }
@@ -186,14 +211,83 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         if (v4) hipLaunchKernelGGL(KERNEL_<4>, dim3((unsigned)cdiv((ROWS_) * DW, 256)), dim3(256), 0, stream, __VA_ARGS__);   \
         else hipLaunchKernelGGL(KERNEL_<1>, dim3((unsigned)cdiv((ROWS_) * DW, 256)), dim3(256), 0, stream, __VA_ARGS__);      \
     } while (0)
+    // ---- products on the two-piece kernels, table / fold restructuring (header): 16-byte rows and vectors, the table fits the
+    // e0 slot, the products are large enough for the packs to pay ----
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool fast = v4 && E > 0 && V <= E && get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 &&
+                      2.0 * (double)N * D * D >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP) && al16(p->edge2_bias) &&
+                      al16(p->node1_2_bias) && al16(p->node2_0_bias) && al16(p->node2_2_bias) && al16(x_encoded);
     ENC_LAUNCH(k_embed_sum, N, N, node_tokens, V, D, x_tokens, p->embedding, (const uint8_t*)nullptr, P(L.x0));
     if (E > 0) {
         GVQA_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)E, stream));
         if (num_added > 0)
             hipLaunchKernelGGL(k_mark, dim3((unsigned)cdiv(num_added, 256)), dim3(256), 0, stream, num_added, E, added_sym_edge, flags);
-        ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, p->embedding, (const uint8_t*)flags, P(L.e0));
+        if (!fast) ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, p->embedding, (const uint8_t*)flags, P(L.e0));
     }
     GVQA_LAUNCH_CHECK();
+    if (fast) {
+        char* apk_n = base + L.apk_n; char* apk_e = base + L.apk_e; char* wpk = base + L.wpk;
+        // C = Apk W^T (+ epilogue): the weight block is packed into the one weight slot (stream order keeps the slot's uses apart)
+        auto prod = [&](int64_t M, const char* apk, const float* W, int64_t ldw, LinearEpilogue ep, float* C) -> int {
+            int r = launch_split_pack(2, D, D, W, ldw, wpk, stream);
+            if (r) return r;
+            return launch_linear_split(2, M, D, D, apk, wpk, ep, C, D, stream);
+        };
+        const LinearEpilogue none{nullptr, nullptr, 0, nullptr, 0, 0};
+        float* Te = P(L.e0);                                                 // [V, D] = emb W_e^T  (edge block of EdgeModel's first Linear)
+        rc = launch_linear(V, D, D, p->embedding, D, p->edge0_weight + 2 * D, 3 * D, nullptr, 0, Te, D, 1, 0, 0, 0, stream);
+        if (rc) return rc;
+        ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, (const float*)Te, (const uint8_t*)flags, P(L.Y));
+        GVQA_LAUNCH_CHECK();
+        rc = launch_split_pack(2, N, D, P(L.x0), D, apk_n, stream);          // x0 packed once for its four products
+        if (rc) return rc;
+        if ((rc = prod(N, apk_n, p->edge0_weight, 3 * D, none, P(L.S)))) return rc;
+        if ((rc = prod(N, apk_n, p->edge0_weight + D, 3 * D, none, P(L.Dd)))) return rc;
+        if ((rc = prod(N, apk_n, p->node1_0_weight, 2 * D, none, P(L.P)))) return rc;
+        {
+            LinearEpilogue ep{p->node2_0_bias, nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(N, apk_n, p->node2_0_weight, 2 * D, ep, P(L.t)))) return rc;
+        }
+        ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.S), src, (const float*)P(L.Dd), dst, p->edge0_bias, P(L.Y));
+        // W' = Wn_e W2, b' = Wn_e b2: node1_0's edge block applied to edge_attr' = Y W2^T + b2 without forming it first
+        hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 256), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
+                           (int64_t)2 * D, p->edge2_weight, (int64_t)D, P(L.wf), (int64_t)D);
+        hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node1_0_weight + D, (int64_t)2 * D,
+                           p->edge2_bias, (int64_t)1, P(L.bf), (int64_t)1);
+        GVQA_LAUNCH_CHECK();
+        rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);           // Y packed once for both of its products
+        if (rc) return rc;
+        {
+            LinearEpilogue ep{p->edge2_bias, nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(E, apk_e, p->edge2_weight, D, ep, edge_attr_encoded))) return rc;
+            LinearEpilogue ef{P(L.bf), nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(E, apk_e, P(L.wf), D, ef, P(L.Y)))) return rc;     // (the fp32 Y is free: its packed image is the operand)
+        }
+        ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.P), src, (const float*)nullptr, (const int64_t*)nullptr,
+                   p->node1_0_bias, P(L.Y));
+        GVQA_LAUNCH_CHECK();
+        rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
+        if (rc) return rc;
+        {
+            LinearEpilogue ep{p->node1_2_bias, nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(E, apk_e, p->node1_2_weight, D, ep, P(L.m)))) return rc;
+        }
+        if (v4) hipLaunchKernelGGL(k_segment_mean<4>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, D, P(L.m), g->rowptr, g->csr_eid,
+                                   P(L.agg));
+        GVQA_LAUNCH_CHECK();
+        rc = launch_split_pack(2, N, D, P(L.agg), D, apk_n, stream);
+        if (rc) return rc;
+        {
+            LinearEpilogue ep{nullptr, P(L.t), D, nullptr, 0, 1};            // t = relu(t + agg W^T)  (t holds x0's block + bias)
+            if ((rc = prod(N, apk_n, p->node2_0_weight + D, 2 * D, ep, P(L.t)))) return rc;
+        }
+        rc = launch_split_pack(2, N, D, P(L.t), D, apk_n, stream);
+        if (rc) return rc;
+        {
+            LinearEpilogue ep{p->node2_2_bias, nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(N, apk_n, p->node2_2_weight, D, ep, P(L.x2)))) return rc;
+        }
+    } else {
     // EdgeModel: e' = Lin2(relu(Lin1([x_src || x_dst || e])))                       (:65-76)
     if (E > 0) {
         LINW(N, D, P(L.x0), p->edge0_weight, 3 * D, nullptr, 0, P(L.S));
@@ -224,6 +318,7 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         if (rc) return rc;
     }
     LINW(N, D, P(L.t), p->node2_2_weight, D, p->node2_2_bias, 0, P(L.x2));
+    }
 #undef LINW
 #undef ENC_LAUNCH
     // graph LayerNorm                                                               (:608)

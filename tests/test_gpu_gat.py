@@ -1501,3 +1501,47 @@ def test_scene_graph_builder_to_device_feeds_the_path(dev):
     xe2, ee2, _ = enc(d, graph=g2)
     assert torch.equal(xe, xe2) and torch.equal(h, gs(xe2, d.edge_index, ee2, ins, d.batch, graph=g2))
     assert h.shape == (c.num_nodes, 300) and torch.isfinite(h).all()
+
+
+def test_scene_graph_encoder_on_the_two_piece_products(dev):
+    """The encoder's large-batch form (csrc/encoder.hip: edge block of the first Linear applied to the embedding table, the
+    edge_attr' product folded into the next Linear, all node- / edge-sized products on the two-piece kernels) against (i) the
+    reference's own encoder outputs (golden, with the size threshold at 0 so that the form is taken), (ii) the oracle on 300
+    ragged graphs at the real width d = 300 with negated symmetric edges, (iii) the small-batch form (f32-input products) on the
+    same inputs."""
+    import types
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        meta, g = load_golden("sg_encoder_debug4")
+        E0 = g["edge_index"].shape[1]
+        if meta["vocab"] <= E0:                         # (the form needs the projected table to fit the per-edge slot it replaces)
+            enc = GroundTruth_SceneGraph_Encoder(meta["vocab"], meta["pad_idx"], meta["dim"])
+            _load_module(enc, synth.encoder_params(meta["vocab"], meta["dim"], seed=meta["param_seed"], pad_idx=meta["pad_idx"]), dev)
+            data = types.SimpleNamespace(x=t(g["x_tokens"], device=dev), edge_attr=t(g["edge_tokens"], device=dev),
+                                         edge_index=t(g["edge_index"], device=dev), batch=t(g["batch"], device=dev),
+                                         added_sym_edge=t(g["added_sym_edge"], device=dev))
+            xe, ee, _ = enc(data)
+            assert maxabs(ee, g["edge_attr_encoded"]) < 5e-5 and maxabs(xe, g["x_encoded"]) < TOL
+        gb = synth.make_graph_batch(300, seed=0xE1C, nodes_lo=3, nodes_hi=40, rel_per_node=2.0)
+        N, E, B, V, D = gb.num_nodes, gb.num_edges, gb.num_graphs, 1500, 300
+        assert V <= E
+        pe = synth.encoder_params(V, D, seed=21)
+        xt = synth.randint(N * 12, 5, 0, V, stream=3).reshape(N, 12); et = synth.randint(E, 6, 1, V, stream=3).reshape(E, 1)
+        added = np.arange(0, E, 5, dtype=np.int64)
+        enc = _load_module(GroundTruth_SceneGraph_Encoder(V, 0, D), pe, dev)
+        data = types.SimpleNamespace(x=t(xt, device=dev), edge_attr=t(et, device=dev), edge_index=t(gb.edge_index, device=dev),
+                                     batch=t(gb.batch, device=dev), added_sym_edge=t(added, device=dev))
+        xe, ee, _ = enc(data)
+        rxe, ree = R.scene_graph_encoder(t(xt), t(gb.edge_index), t(et), t(added), t(gb.batch), B, tparams(pe))
+        assert maxabs(ee, ree) < 1e-4 * (1.0 + float(ree.abs().max())) and maxabs(xe, rxe) < TOL
+        prev = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)        # the f32-input form on the same inputs
+        try:
+            xe32, ee32, _ = enc(data)
+        finally:
+            _lib.set_option(_lib.OPT_PROJECTION, prev)
+        assert maxabs(ee, ee32) < 1e-4 * (1.0 + float(ree.abs().max())) and maxabs(xe, xe32) < TOL
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
