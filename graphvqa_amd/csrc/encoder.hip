@@ -135,19 +135,25 @@ __global__ __launch_bounds__(256) void k_graph_layernorm(int D, const int32_t* _
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) out[i] = (x[i] - mean) / sd * ww + bb;
 }
 
-// C[i, k] = sum_j A[i, j] B[j, k]  (parameter-sized products: the folded weight W' = Wn_e W2 and bias b' = Wn_e b2)
+// C[i, k] = sum_j A[i, j] B[j, k]  (parameter-sized products: the folded weight W' = Wn_e W2 and bias b' = Wn_e b2).
+// 64 columns x 4 slices of j per workgroup, eight loads in flight per thread, the slices' sums added in index order.
 __global__ __launch_bounds__(256) void k_small_matmul_nn(int M, int N, int K, const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc) {
-    const int k = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (k >= N || i >= M) return;
-    float a0 = 0.f, a1 = 0.f;
-    int j = 0;
-    for (; j + 2 <= K; j += 2) {
-        a0 = fmaf(A[(int64_t)i * lda + j], B[(int64_t)j * ldb + k], a0);
-        a1 = fmaf(A[(int64_t)i * lda + j + 1], B[(int64_t)(j + 1) * ldb + k], a1);
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + col, i = blockIdx.y;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < N) {
+        int j = sl;
+        for (; j + 12 < K; j += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fmaf(A[(int64_t)i * lda + j + 4 * u], B[(int64_t)(j + 4 * u) * ldb + k], a[u]);
+        }
+        for (; j < K; j += 4) a[0] = fmaf(A[(int64_t)i * lda + j], B[(int64_t)j * ldb + k], a[0]);
     }
-    if (j < K) a0 = fmaf(A[(int64_t)i * lda + j], B[(int64_t)j * ldb + k], a0);
-    C[(int64_t)i * ldc + k] = a0 + a1;
+    part[sl][col] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (sl == 0 && k < N) C[(int64_t)i * ldc + k] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, apk_n, apk_e, wpk, total; };
@@ -250,7 +256,7 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         }
         ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.S), src, (const float*)P(L.Dd), dst, p->edge0_bias, P(L.Y));
         // W' = Wn_e W2, b' = Wn_e b2: node1_0's edge block applied to edge_attr' = Y W2^T + b2 without forming it first
-        hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 256), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
+        hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
                            (int64_t)2 * D, p->edge2_weight, (int64_t)D, P(L.wf), (int64_t)D);
         hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node1_0_weight + D, (int64_t)2 * D,
                            p->edge2_bias, (int64_t)1, P(L.bf), (int64_t)1);
