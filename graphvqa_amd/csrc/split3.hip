@@ -1085,8 +1085,11 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     const uint16_t* b = static_cast<const uint16_t*>(Bpk);
     int variant = split3_variant(M, N, KB);            // (a forced variant >= 100 names a two-piece instantiation)
     if (np == 2 && variant < 100) variant = variant < 20 ? ((KB & 1) ? 118 : 112) : 134;      // (112: two K steps per barrier)
+    // narrow results whose last 256-column tile would be at most half full (N = 300: 2 x 256 columns computed for 300) take
+    // 128-column tiles instead (3 x 128): a quarter less matrix-core work at a lower arithmetic intensity per tile
+    if (np == 2 && get_option(GVQA_OPT_SPLIT3_VARIANT) < 10 && N % 256 != 0 && N % 256 <= 128 && N <= 1024) variant = 124;
     GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
-    const int64_t bm = variant % 100 < 20 ? 256 : 128;
+    const int64_t bm = variant % 100 < 20 ? 256 : 128;     // (rows per tile: 1x = 256, 2x / 3x = 128)
     GVQA_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || M <= 65535 * bm), GVQA_E_INVALID, "linear_split: bad batch count");
     const float* a_inv = np == 2 ? (a_inv_batched ? a_inv_batched : split2h_inv_scales(Apk, cdiv(M, 32), KB)) : nullptr;
     const float* b_inv = np == 2 ? (b_inv_batched ? b_inv_batched : split2h_inv_scales(Bpk, rtB, KB)) : nullptr;
@@ -1172,6 +1175,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
             case 133: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, true, 0, 0, 2); break;
 #endif
             case 134: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, false, 0, 1, 2); break;
+            case 124: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, false, 0, 1, 2); break;       // 128 x 128 tile
             default: return GVQA_E_INVALID;
         }
 #undef GVQA_S3_LAUNCH
