@@ -14,8 +14,28 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, edge_gather, edge_scatter_add
+from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, edge_gather, edge_scatter_add, _ProjectionLinear
 from .graph import SceneGraphBatch, _stream
+
+
+class _NoGradRow(torch.autograd.Function):
+    """Identity on a [V, D] table whose row `row` receives no gradient (nn.Embedding's padding_idx rule for a use of the table
+    that is not an embedding lookup)."""
+
+    @staticmethod
+    def forward(ctx, w, row):
+        ctx.row = row
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        g[ctx.row].zero_()
+        return g, None
+
+
+def _no_grad_row(w, row):
+    return _NoGradRow.apply(w, int(row))
 
 
 class _EdgeModel(torch.nn.Module):
@@ -59,25 +79,43 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         self.graph_layer_norm = _GraphLayerNorm(sg_emb_dim)
 
     def _forward_autograd(self, x_tok, e_tok, ei, added, graph):
-        """Differentiable formulation of pipeline_model_gat.py:575-610 (training): embeddings and MLPs are torch ops,
-        the per-edge gathers and the scatter_mean use the HIP CSR row-sum kernel (as adjoint / forward), the graph LayerNorm's per-graph reductions / broadcasts run on the HIP
-        per-graph ops with their adjoints (my_graph_layernorm.py:57-78: eps OUTSIDE the square root)."""
+        """Differentiable formulation of pipeline_model_gat.py:575-610 (training), in the split-column form of the fused path
+        (csrc/encoder.hip): the concatenations [x_src | x_dst | e], [x_src | e'], [x | agg] are never built -- the first Linear of
+        every MLP is applied by column block, node blocks per NODE and gathered (HIP gathers with CSR row sums as adjoints), the
+        edge block of EdgeModel's first Linear to the embedding TABLE (the per-edge product becomes the token lookup; its weight
+        gradient a [V, D] product instead of a reduction over all E rows).  Every node- / edge-sized product is the library's
+        (`_ProjectionLinear`: two-piece split GEMMs forward, dx and dW from one pass over dy); the graph LayerNorm's per-graph
+        reductions / broadcasts run on the HIP per-graph ops with their adjoints (my_graph_layernorm.py:57-78: eps OUTSIDE the
+        square root)."""
+        F = torch.nn.functional
         emb, m, D = self.sg_vocab_embedding, self.scene_graph_encoding_layer, self.sg_emb_dim
         N = x_tok.shape[0]
-        x = emb(x_tok).sum(dim=-2)
-        e = emb(e_tok)
+        proj = _ProjectionLinear.apply
+        e0, e2l = m.edge_model.edge_mlp[0], m.edge_model.edge_mlp[2]
+        n10, n12 = m.node_model.node_mlp_1[0], m.node_model.node_mlp_1[2]
+        n20, n22 = m.node_model.node_mlp_2[0], m.node_model.node_mlp_2[2]
+        x = emb(x_tok).sum(dim=-2)                                                       # :583-587
+        # edge tokens through the PROJECTED table (nn.Embedding's rule that the padding row gets no gradient is kept by the lookup
+        # of the reference's own module below: the table product sees the weight with that row's gradient masked)
+        table = _no_grad_row(emb.weight, emb.padding_idx) if emb.padding_idx is not None else emb.weight
+        te = F.linear(table, e0.weight[:, 2 * D:])                                       # [V, D]
+        ye = F.embedding(e_tok, te)                                                      # [E, T, D]
         if added is not None and added.numel():
-            sign = torch.ones(e.shape[0], device=e.device)
-            sign[added.to(e.device)] = -1.0                                              # :590
-            e = e * sign.view(-1, 1, 1)
-        e = e.sum(dim=-2)
+            sign = torch.ones(ye.shape[0], device=ye.device)
+            sign[added.to(ye.device)] = -1.0                                             # :590
+            ye = ye * sign.view(-1, 1, 1)
+        ye = ye.sum(dim=-2)
         dst = ei[1]
-        x_src = edge_gather(x, graph, "src")                                             # HIP adjoints (CSR row sums)
-        e2 = m.edge_model.edge_mlp(torch.cat([x_src, edge_gather(x, graph, "dst"), e], dim=1))   # EdgeModel :65-76
-        mm = m.node_model.node_mlp_1(torch.cat([x_src, e2], dim=1))                      # NodeModel :78-98
+        # EdgeModel :65-76
+        y1 = torch.relu(edge_gather(proj(x, e0.weight[:, :D]), graph, "src") + edge_gather(proj(x, e0.weight[:, D:2 * D]), graph, "dst")
+                        + ye + e0.bias)
+        e2 = proj(y1, e2l.weight) + e2l.bias
+        # NodeModel :78-98
+        y3 = torch.relu(edge_gather(proj(x, n10.weight[:, :D]), graph, "src") + proj(e2, n10.weight[:, D:]) + n10.bias)
+        mm = proj(y3, n12.weight) + n12.bias
         cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(mm.dtype)
         agg = edge_scatter_add(mm, graph) / cnt.view(-1, 1)                              # scatter_mean :96
-        x2 = m.node_model.node_mlp_2(torch.cat([x, agg], dim=1))
+        x2 = proj(torch.relu(proj(x, n20.weight[:, :D]) + proj(agg, n20.weight[:, D:]) + n20.bias), n22.weight) + n22.bias
         gp = graph.graph_ptr.long()
         norm = ((gp[1:] - gp[:-1]).clamp(min=1) * D).to(x2.dtype).view(-1, 1)
         mean = graph_segment_sum(x2, graph).sum(dim=-1, keepdim=True) / norm

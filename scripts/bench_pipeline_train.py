@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Training step of the whole graph side at BASELINE config 3's batch (2048 graphs x 32 nodes x 128 edges), real model widths
+(d = 300, instruction / question 512): scene-graph encoder -> gat_seq (K = 5, dropout 0.1) -> attention pooling -> answer
+classifier, cross-entropy, backward, SGD.  One JSON line: step time and the forward / backward split per module (cumulative)."""
+import json, os, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from graphvqa_amd import synth
+from graphvqa_amd.graph import SceneGraphBatch
+from graphvqa_amd.sg_encoder import GroundTruth_SceneGraph_Encoder
+from graphvqa_amd.gat_skip import gat_seq
+from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention, ShortAnswerClassifier
+dev = torch.device("cuda:0"); tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+gb = synth.config3_batch(); N, E, B, V, D, Q = gb.num_nodes, gb.num_edges, gb.num_graphs, 3000, 300, 512
+def load(m, p):
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()}); return m.to(dev).train()
+enc = load(GroundTruth_SceneGraph_Encoder(V, 0, D), synth.encoder_params(V, D, seed=1))
+gs = load(gat_seq(D, D, D, Q, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(D, D, D, Q, 5, 4, seed=2))
+pool = load(MyConditionalGlobalAttention(D, Q), synth.attention_pool_params(D, Q, seed=3))
+clf = load(ShortAnswerClassifier(Q, 512, 1842), synth.classifier_params(Q, 512, 1842, seed=4))
+data = types.SimpleNamespace(x=tt(synth.randint(N * 12, 71, 0, V, stream=9).reshape(N, 12)), edge_attr=tt(synth.randint(E, 72, 1, V, stream=9).reshape(E, 1)),
+                             edge_index=tt(gb.edge_index), batch=tt(gb.batch), added_sym_edge=tt(np.arange(0, E, 7, dtype=np.int64)))
+ins, q = tt(synth.normal((5, B, Q), 5)), tt(synth.normal((B, Q), 6))
+y = tt(synth.randint(B, 8, 0, 1842, stream=2))
+g = SceneGraphBatch(data.edge_index, data.batch, N, B); g.transposed()
+params = [p for m in (enc, gs, pool, clf) for p in m.parameters()]
+opt = torch.optim.SGD(params, lr=1e-3)
+def step(upto=4, backward=True):
+    opt.zero_grad(set_to_none=True)
+    xe, ee, _ = enc(data, graph=g)
+    out = xe
+    if upto >= 2: out = gs(xe, data.edge_index, ee, ins, data.batch, graph=g)
+    if upto >= 3: out = pool(out, q, data.batch, graph=g)
+    if upto >= 4:
+        loss = torch.nn.functional.cross_entropy(clf(out, q), y)
+    else:
+        loss = out.square().mean() + (ee.square().mean() if upto == 1 else 0)
+    if backward:
+        loss.backward()
+        if upto >= 4: opt.step()
+def timed(fn, iters=8):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e3
+res = {"N": N, "E": E, "B": B, "train_step_ms": timed(step)}
+res["cumulative_forward_backward_ms"] = {name: timed(lambda u=u: step(u)) for name, u in (("encoder", 1), ("+gat_seq", 2), ("+pooling", 3))}
+res["cumulative_forward_only_ms"] = {name: timed(lambda u=u: step(u, False)) for name, u in (("encoder", 1), ("+gat_seq", 2), ("+pooling", 3), ("+classifier", 4))}
+print(json.dumps(res))
