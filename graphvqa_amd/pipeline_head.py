@@ -15,7 +15,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, graph_softmax
+from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, graph_softmax, _ProjectionLinear, skinny_linear
 from .graph import SceneGraphBatch, _stream
 
 
@@ -40,8 +40,13 @@ class MyConditionalGlobalAttention(torch.nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or u.requires_grad or any(q.requires_grad for q in self.parameters())):
             # differentiable formulation (pipeline_model_gat.py:149-181): the MLPs are torch ops, the per-graph
             # broadcast / softmax / sum run on the HIP per-graph kernels and their adjoints
-            xn = self.node_nn(x)
-            gate = graph_softmax(self.gate_nn(graph_rows(self.ques_nn(u), graph) * xn), graph)
+            # (node-sized Linears on the library's products -- two-piece split GEMMs forward, dx and dW from one pass over dy -- and the
+            # final 512 -> 1 gate product on the tall-skinny kernels; torch's own Linear below the size at which those pay)
+            def lin(t, layer):
+                return _ProjectionLinear.apply(t, layer.weight) + layer.bias
+            xn = lin(torch.relu(lin(x, self.node_nn[0])), self.node_nn[2])
+            z = torch.relu(lin(graph_rows(self.ques_nn(u), graph) * xn, self.gate_nn[0]))
+            gate = graph_softmax(skinny_linear(z, self.gate_nn[2].weight.t()) + self.gate_nn[2].bias, graph)
             return graph_segment_sum(gate * xn, graph)
         p = _lib.PoolParams()
         keep = []
