@@ -94,17 +94,18 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         e0, e2l = m.edge_model.edge_mlp[0], m.edge_model.edge_mlp[2]
         n10, n12 = m.node_model.node_mlp_1[0], m.node_model.node_mlp_1[2]
         n20, n22 = m.node_model.node_mlp_2[0], m.node_model.node_mlp_2[2]
-        x = emb(x_tok).sum(dim=-2)                                                       # :583-587
-        # edge tokens through the PROJECTED table (nn.Embedding's rule that the padding row gets no gradient is kept by the lookup
-        # of the reference's own module below: the table product sees the weight with that row's gradient masked)
+        # token sums as fused gather-sums (no [N, T, D] intermediate); nn.Embedding's rule that the padding row gets no gradient is
+        # kept by masking that row's gradient of the table (the row itself takes part as stored, exactly like emb(tokens))
         table = _no_grad_row(emb.weight, emb.padding_idx) if emb.padding_idx is not None else emb.weight
+        x = F.embedding_bag(x_tok, table, mode="sum")                                    # :583-587
+        # edge tokens through the PROJECTED table
         te = F.linear(table, e0.weight[:, 2 * D:])                                       # [V, D]
-        ye = F.embedding(e_tok, te)                                                      # [E, T, D]
+        psw = None
         if added is not None and added.numel():
-            sign = torch.ones(ye.shape[0], device=ye.device)
-            sign[added.to(ye.device)] = -1.0                                             # :590
-            ye = ye * sign.view(-1, 1, 1)
-        ye = ye.sum(dim=-2)
+            sign = torch.ones(e_tok.shape[0], device=te.device)
+            sign[added.to(te.device)] = -1.0                                             # :590
+            psw = sign.view(-1, 1).expand(e_tok.shape).contiguous()
+        ye = F.embedding_bag(e_tok, te, mode="sum", per_sample_weights=psw)              # [E, D]
         dst = ei[1]
         # EdgeModel :65-76
         y1 = torch.relu(edge_gather(proj(x, e0.weight[:, :D]), graph, "src") + edge_gather(proj(x, e0.weight[:, D:2 * D]), graph, "dst")
