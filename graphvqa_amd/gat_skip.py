@@ -65,28 +65,32 @@ class _ProjectionLinear(torch.autograd.Function):
     own GEMMs -- the arithmetic GVQA_OPT_PROJECTION selects (two-piece fp16 / three-piece bf16 split on the 16-bit matrix cores,
     or the f32-input MFMA kernel), exactly as in the eval path -- and so do dx = dy W and dW = dy^T x (a [HC, Dn] result reduced
     over all N rows: the library's transposed-pack split-K product, gvqa_linear_tn_split2h) in the backward.
-    `w` may be a column slice of a wider weight (its row stride is passed on)."""
+    `w` may be a column slice of a wider weight (its row stride is passed on).  `bias` (optional, [N]) is added in the product's
+    epilogue (no pass over y for it); its gradient is the column sum of dy."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, bias=None):
         ctx.save_for_backward(x, w)
-        return _ProjectionLinear._product(x, w)
+        ctx.has_bias = bias is not None
+        return _ProjectionLinear._product(x, w, bias)
 
     @staticmethod
-    def _product(x, w):
+    def _product(x, w, bias=None):
         lib = _lib.load()
         M, K = x.shape
         N = w.shape[0]
         mode = lib.gvqa_get_option(_lib.OPT_PROJECTION)
         ok = (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.stride(1) == 1 and
               N % 4 == 0 and M > 0 and 2.0 * M * N * K >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
+        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16 != 0):
+            ok = False
         if not ok:
-            return torch.nn.functional.linear(x, w)
+            return torch.nn.functional.linear(x, w, bias)
         dev, st = x.device, _stream(x.device)
         out = torch.empty((M, N), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if mode == _lib.PROJECTION_F32:
-                _lib.check(lib.gvqa_linear_f32(M, N, K, x.data_ptr(), K, w.data_ptr(), w.stride(0), None, 0, out.data_ptr(), N, st))
+                _lib.check(lib.gvqa_linear_f32(M, N, K, x.data_ptr(), K, w.data_ptr(), w.stride(0), _ptr(bias), 0, out.data_ptr(), N, st))
                 return out
             nbytes, pack, linear = ((lib.gvqa_split2h_packed_bytes, lib.gvqa_split2h_pack, lib.gvqa_linear_split2h)
                                     if mode == _lib.PROJECTION_SPLIT2H else
@@ -94,21 +98,22 @@ class _ProjectionLinear(torch.autograd.Function):
             apk, wpk = _workspace(nbytes(M, K), dev), _workspace(nbytes(N, K), dev)
             _lib.check(pack(M, K, x.data_ptr(), K, apk.data_ptr(), st))
             _lib.check(pack(N, K, w.data_ptr(), w.stride(0), wpk.data_ptr(), st))
-            _lib.check(linear(M, N, K, apk.data_ptr(), wpk.data_ptr(), None, None, 0, None, 0, 0, out.data_ptr(), N, st))
+            _lib.check(linear(M, N, K, apk.data_ptr(), wpk.data_ptr(), _ptr(bias), None, 0, None, 0, 0, out.data_ptr(), N, st))
         return out
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         fused = _ProjectionLinear._backward_fused(gy, x, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if fused is not None:
-            return fused
+            return fused[0], fused[1], gb
         gx = None
         if ctx.needs_input_grad[0]:
             # dx = dy W = dy (W^T)^T: the same kernels with the (small) weight transposed
             gx = _ProjectionLinear._product(gy.contiguous(), w.t().contiguous())
         gw = _ProjectionLinear._weight_grad(gy, x) if ctx.needs_input_grad[1] else None
-        return gx, gw
+        return gx, gw, gb
 
     @staticmethod
     def _backward_fused(gy, x, w, want_x, want_w, gx_init=None, gw_out=None):

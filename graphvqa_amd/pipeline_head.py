@@ -43,7 +43,7 @@ class MyConditionalGlobalAttention(torch.nn.Module):
             # (node-sized Linears on the library's products -- two-piece split GEMMs forward, dx and dW from one pass over dy -- and the
             # final 512 -> 1 gate product on the tall-skinny kernels; torch's own Linear below the size at which those pay)
             def lin(t, layer):
-                return _ProjectionLinear.apply(t, layer.weight) + layer.bias
+                return _ProjectionLinear.apply(t, layer.weight, layer.bias)
             xn = lin(torch.relu(lin(x, self.node_nn[0])), self.node_nn[2])
             z = torch.relu(lin(graph_rows(self.ques_nn(u), graph) * xn, self.gate_nn[0]))
             gate = graph_softmax(skinny_linear(z, self.gate_nn[2].weight.t()) + self.gate_nn[2].bias, graph)

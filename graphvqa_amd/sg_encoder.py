@@ -108,15 +108,16 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         ye = F.embedding_bag(e_tok, te, mode="sum", per_sample_weights=psw)              # [E, D]
         dst = ei[1]
         # EdgeModel :65-76
-        y1 = torch.relu(edge_gather(proj(x, e0.weight[:, :D]), graph, "src") + edge_gather(proj(x, e0.weight[:, D:2 * D]), graph, "dst")
+        # (biases ride in the products' epilogues: where a sum of products has one bias, the first product takes it)
+        y1 = torch.relu(edge_gather(proj(x, e0.weight[:, :D], None), graph, "src") + edge_gather(proj(x, e0.weight[:, D:2 * D], None), graph, "dst")
                         + ye + e0.bias)
-        e2 = proj(y1, e2l.weight) + e2l.bias
+        e2 = proj(y1, e2l.weight, e2l.bias)
         # NodeModel :78-98
-        y3 = torch.relu(edge_gather(proj(x, n10.weight[:, :D]), graph, "src") + proj(e2, n10.weight[:, D:]) + n10.bias)
-        mm = proj(y3, n12.weight) + n12.bias
+        y3 = torch.relu(edge_gather(proj(x, n10.weight[:, :D], None), graph, "src") + proj(e2, n10.weight[:, D:], n10.bias))
+        mm = proj(y3, n12.weight, n12.bias)
         cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(mm.dtype)
         agg = edge_scatter_add(mm, graph) / cnt.view(-1, 1)                              # scatter_mean :96
-        x2 = proj(torch.relu(proj(x, n20.weight[:, :D]) + proj(agg, n20.weight[:, D:]) + n20.bias), n22.weight) + n22.bias
+        x2 = proj(torch.relu(proj(x, n20.weight[:, :D], n20.bias) + proj(agg, n20.weight[:, D:], None)), n22.weight, n22.bias)
         gp = graph.graph_ptr.long()
         norm = ((gp[1:] - gp[:-1]).clamp(min=1) * D).to(x2.dtype).view(-1, 1)
         mean = graph_segment_sum(x2, graph).sum(dim=-1, keepdim=True) / norm
