@@ -175,6 +175,22 @@ static EncLayout enc_layout(int64_t N, int64_t E, int D) {
 extern "C" {
 using namespace gvqa;
 
+int gvqa_embed_sum(int64_t rows, int32_t T, int32_t V, int32_t D, const int64_t* tokens, const float* table, const uint8_t* negate,
+                   float* out, void* stream_) {
+    GVQA_REQUIRE(rows >= 0 && T > 0 && V > 0 && D > 0, GVQA_E_INVALID, "embed_sum: bad dims");
+    if (rows == 0) return GVQA_OK;
+    GVQA_REQUIRE(tokens && table && out, GVQA_E_INVALID, "embed_sum: null tensor");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool v4 = D % 4 == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int DW = v4 ? D / 4 : D;
+    if (v4) hipLaunchKernelGGL(k_embed_sum<4>, dim3((unsigned)cdiv(rows * DW, 256)), dim3(256), 0, stream, rows, (int)T, (int)V, (int)D, tokens, table,
+                               negate, out);
+    else hipLaunchKernelGGL(k_embed_sum<1>, dim3((unsigned)cdiv(rows * DW, 256)), dim3(256), 0, stream, rows, (int)T, (int)V, (int)D, tokens, table,
+                            negate, out);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
 size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D) {
     if (!g || D <= 0) return 0;
     return enc_layout(g->num_nodes, g->num_edges, D).total;

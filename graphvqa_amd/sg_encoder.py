@@ -34,6 +34,36 @@ class _NoGradRow(torch.autograd.Function):
         return g, None
 
 
+class _EmbedSum(torch.autograd.Function):
+    """out[r] = (+-) sum_t table[tokens[r, t]] (pipeline_model_gat.py:583-593): the fused gather-sum kernel of the inference path
+    forward (gvqa_embed_sum); the table gradient by torch's own sort-based embedding backward on the rows' gradients repeated per
+    token (deterministic, like nn.Embedding's)."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, negate):
+        lib = _lib.load()
+        table = _f32c(table, "table")
+        tokens = tokens.contiguous()
+        rows, T = tokens.shape
+        V, D = table.shape
+        out = torch.empty((rows, D), dtype=torch.float32, device=table.device)
+        with torch.cuda.device(table.device):
+            _lib.check(lib.gvqa_embed_sum(rows, T, V, D, tokens.data_ptr(), table.data_ptr(), None if negate is None else negate.data_ptr(),
+                                          out.data_ptr(), _stream(table.device)))
+        ctx.save_for_backward(tokens, negate)
+        ctx.V = V
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        tokens, negate = ctx.saved_tensors
+        rows, T = tokens.shape
+        if negate is not None:
+            g = g * (1.0 - 2.0 * negate.to(g.dtype)).view(-1, 1)
+        ge = g.unsqueeze(1).expand(rows, T, g.shape[1]).reshape(rows * T, g.shape[1])
+        return None, torch.ops.aten.embedding_dense_backward(ge, tokens.reshape(-1), ctx.V, -1, False), None
+
+
 def _no_grad_row(w, row):
     return _NoGradRow.apply(w, int(row))
 
@@ -97,15 +127,15 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         # token sums as fused gather-sums (no [N, T, D] intermediate); nn.Embedding's rule that the padding row gets no gradient is
         # kept by masking that row's gradient of the table (the row itself takes part as stored, exactly like emb(tokens))
         table = _no_grad_row(emb.weight, emb.padding_idx) if emb.padding_idx is not None else emb.weight
-        x = F.embedding_bag(x_tok, table, mode="sum")                                    # :583-587
+        self._check_ids(x_tok, e_tok, added, ei.shape[1])                                # (the kernel clamps: out-of-table ids raise here)
+        x = _EmbedSum.apply(x_tok, table, None)                                          # :583-587
         # edge tokens through the PROJECTED table
         te = F.linear(table, e0.weight[:, 2 * D:])                                       # [V, D]
-        psw = None
+        neg = None
         if added is not None and added.numel():
-            sign = torch.ones(e_tok.shape[0], device=te.device)
-            sign[added.to(te.device)] = -1.0                                             # :590
-            psw = sign.view(-1, 1).expand(e_tok.shape).contiguous()
-        ye = F.embedding_bag(e_tok, te, mode="sum", per_sample_weights=psw)              # [E, D]
+            neg = torch.zeros(e_tok.shape[0], dtype=torch.uint8, device=te.device)
+            neg[added.to(te.device)] = 1                                                 # :590
+        ye = _EmbedSum.apply(e_tok, te, neg)                                             # [E, D]
         dst = ei[1]
         # EdgeModel :65-76
         # (biases ride in the products' epilogues: where a sum of products has one bias, the first product takes it)
@@ -126,6 +156,22 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         out = xc / (graph_rows(var.sqrt(), graph) + self.graph_layer_norm.eps)
         return out * self.graph_layer_norm.weight + self.graph_layer_norm.bias, e2, None
 
+    def _check_ids(self, x_tok, e_tok, added, E):
+        """validate_ids: True = every call, "first" (default) = the first 4 calls of this module (a vocabulary / checkpoint mismatch
+        shows at once; a blocking host read on every step would undo the loader path that never synchronises), False = never.
+        nn.Embedding / index assignment in the reference raise on ids outside the table (a vocabulary / checkpoint mismatch); the
+        kernels would clamp them silently, so the range is checked here (one small reduction and host read)."""
+        V = self.sg_vocab_embedding.num_embeddings
+        mode = getattr(self, "validate_ids", "first")
+        seen = getattr(self, "_validated_calls", 0)
+        if mode is True or (mode == "first" and seen < 4):
+            self._validated_calls = seen + 1
+            bad = ((x_tok < 0) | (x_tok >= V)).any() | ((e_tok < 0) | (e_tok >= V)).any()
+            if added is not None and added.numel():
+                bad = bad | ((added < 0) | (added >= E)).any().to(bad.device)
+            if bool(bad.item()):
+                raise IndexError(f"scene-graph token id outside [0, {V}) or added_sym_edge index outside [0, {E})")
+
     def forward(self, gt_scene_graphs, graph: SceneGraphBatch | None = None):
         lib = _lib.load()
         d = gt_scene_graphs
@@ -141,20 +187,7 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             return self._forward_autograd(x_tok, e_tok, ei, added, graph)
         D, V = self.sg_emb_dim, self.sg_vocab_embedding.num_embeddings
-        # validate_ids: True = every call, "first" (default) = the first 4 calls of this module (a vocabulary / checkpoint mismatch
-        # shows at once; a blocking host read on every eval step would undo the loader path that never synchronises), False = never
-        mode = getattr(self, "validate_ids", "first")
-        seen = getattr(self, "_validated_calls", 0)
-        if mode is True or (mode == "first" and seen < 4):
-            self._validated_calls = seen + 1
-            # nn.Embedding / index assignment in the reference raise on ids outside the table (a vocabulary / checkpoint
-            # mismatch); the fused kernels would clamp them silently, so the range is checked here (one small reduction
-            # and host read)
-            bad = ((x_tok < 0) | (x_tok >= V)).any() | ((e_tok < 0) | (e_tok >= V)).any()
-            if added is not None and added.numel():
-                bad = bad | ((added < 0) | (added >= E)).any().to(bad.device)
-            if bool(bad.item()):
-                raise IndexError(f"scene-graph token id outside [0, {V}) or added_sym_edge index outside [0, {E})")
+        self._check_ids(x_tok, e_tok, added, E)
         m = self.scene_graph_encoding_layer
         p = _lib.EncoderParams()
         keep = []

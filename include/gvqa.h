@@ -647,6 +647,11 @@ typedef struct gvqa_encoder_params {
  * added_sym_edge int64 [num_added] (indices of edges whose embedding is negated), edge_index int64
  * [2, E] (the same COO the graph was built from).  Outputs x_encoded [N, D], edge_attr_encoded [E, D]
  * -- exactly the (x, edge_attr) the execution path consumes (pipeline_model_gat.py:751, 791). */
+/* out[r, :] = (negate && negate[r] ? -1 : +1) * sum_t table[tokens[r, t], :]  -- the token-embedding sums of the scene-graph encoder
+ * (pipeline_model_gat.py:583-593; `negate`: one byte per row, the rows of `added_sym_edge`, :590), on any [V, D] table (the embedding
+ * itself, or its projection through the edge block of EdgeModel's first Linear).  Token ids are clamped to the table. */
+int gvqa_embed_sum(int64_t rows, int32_t T, int32_t V, int32_t D, const int64_t* tokens, const float* table, const uint8_t* negate,
+                   float* out, void* stream);
 size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D);
 int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t node_tokens, int32_t edge_tokens_per_edge,
                             const gvqa_encoder_params* p, const int64_t* x_tokens, const int64_t* edge_tokens,
