@@ -14,7 +14,7 @@ import torch
 from torch.nn import Sequential as Seq, Linear as Lin, ReLU, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, edge_gather, edge_scatter_add, _ProjectionLinear
+from .gat_skip import _f32c, _workspace, graph_rows, graph_segment_sum, edge_scatter_add, _ProjectionLinear, _edge_rows_sum_raw
 from .graph import SceneGraphBatch, _stream
 
 
@@ -62,6 +62,38 @@ class _EmbedSum(torch.autograd.Function):
             g = g * (1.0 - 2.0 * negate.to(g.dtype)).view(-1, 1)
         ge = g.unsqueeze(1).expand(rows, T, g.shape[1]).reshape(rows * T, g.shape[1])
         return None, torch.ops.aten.embedding_dense_backward(ge, tokens.reshape(-1), ctx.V, -1, False), None
+
+
+class _GatherAddRelu(torch.autograd.Function):
+    """relu(a[src] + b[dst] + y + bias) per edge in one pass (gvqa_gather_add_relu): the first Linear of an edge-level MLP with its
+    node-side column blocks projected per node (pipeline_model_gat.py:65-76,92-95).  b may be None.  Backward: the ReLU mask on the
+    incoming gradient once, then the gathers' adjoints as CSR row sums (by source on the transposed graph, by destination on the
+    forward one), the bias gradient as its column sum."""
+
+    @staticmethod
+    def forward(ctx, a, b, y, bias, graph):
+        lib = _lib.load()
+        a, y, bias = _f32c(a, "a"), _f32c(y, "y"), _f32c(bias, "bias")
+        b = None if b is None else _f32c(b, "b")
+        ei = graph._keep[0]
+        E, D = y.shape
+        out = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            _lib.check(lib.gvqa_gather_add_relu(E, D, a.data_ptr(), ei[0].data_ptr(), None if b is None else b.data_ptr(),
+                                                None if b is None else ei[1].data_ptr(), bias.data_ptr(), y.data_ptr(), out.data_ptr(),
+                                                _stream(y.device)))
+        ctx.save_for_backward(out)
+        ctx.graph, ctx.has_b = graph, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dpre = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0.0)
+        da = _edge_rows_sum_raw(dpre, ctx.graph.transposed()) if ctx.needs_input_grad[0] else None
+        db = _edge_rows_sum_raw(dpre, ctx.graph) if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        dbias = dpre.sum(0) if ctx.needs_input_grad[3] else None
+        return da, db, dpre, dbias, None
 
 
 def _no_grad_row(w, row):
@@ -139,11 +171,10 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         dst = ei[1]
         # EdgeModel :65-76
         # (biases ride in the products' epilogues: where a sum of products has one bias, the first product takes it)
-        y1 = torch.relu(edge_gather(proj(x, e0.weight[:, :D], None), graph, "src") + edge_gather(proj(x, e0.weight[:, D:2 * D], None), graph, "dst")
-                        + ye + e0.bias)
+        y1 = _GatherAddRelu.apply(proj(x, e0.weight[:, :D], None), proj(x, e0.weight[:, D:2 * D], None), ye, e0.bias, graph)
         e2 = proj(y1, e2l.weight, e2l.bias)
         # NodeModel :78-98
-        y3 = torch.relu(edge_gather(proj(x, n10.weight[:, :D], None), graph, "src") + proj(e2, n10.weight[:, D:], n10.bias))
+        y3 = _GatherAddRelu.apply(proj(x, n10.weight[:, :D], None), None, proj(e2, n10.weight[:, D:], None), n10.bias, graph)
         mm = proj(y3, n12.weight, n12.bias)
         cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(mm.dtype)
         agg = edge_scatter_add(mm, graph) / cnt.view(-1, 1)                              # scatter_mean :96
