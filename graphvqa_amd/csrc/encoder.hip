@@ -58,8 +58,11 @@ template <int W>
 __global__ __launch_bounds__(256) void k_gather_add_relu(int64_t E, int D, const float* __restrict__ a,
                                                          const int64_t* __restrict__ ia, const float* __restrict__ b,
                                                          const int64_t* __restrict__ ib, const float* __restrict__ bias,
-                                                         float* __restrict__ y, const float* __restrict__ yin = nullptr) {
+                                                         float* __restrict__ y, const float* __restrict__ yin = nullptr,
+                                                         int64_t lda = 0, int64_t ldb = 0) {
     if (!yin) yin = y;                                 // (in place unless a separate input is given)
+    if (lda == 0) lda = D;                             // (row strides of the gathered tables: column blocks of a wider product)
+    if (ldb == 0) ldb = D;
     const int DW = D / W;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= E * DW) return;
@@ -68,14 +71,14 @@ __global__ __launch_bounds__(256) void k_gather_add_relu(int64_t E, int D, const
     if (W == 4) {
         float4 v = *reinterpret_cast<const float4*>(yin + e * D + c);
         const float4 bi = *reinterpret_cast<const float4*>(bias + c);
-        if (a) { const float4 t = *reinterpret_cast<const float4*>(a + ia[e] * D + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        if (b) { const float4 t = *reinterpret_cast<const float4*>(b + ib[e] * D + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (a) { const float4 t = *reinterpret_cast<const float4*>(a + ia[e] * lda + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (b) { const float4 t = *reinterpret_cast<const float4*>(b + ib[e] * ldb + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
         *reinterpret_cast<float4*>(y + e * D + c) =
             make_float4(fmaxf(v.x + bi.x, 0.f), fmaxf(v.y + bi.y, 0.f), fmaxf(v.z + bi.z, 0.f), fmaxf(v.w + bi.w, 0.f));
     } else {
         float v = yin[e * D + c];
-        if (a) v += a[ia[e] * D + c];
-        if (b) v += b[ib[e] * D + c];
+        if (a) v += a[ia[e] * lda + c];
+        if (b) v += b[ib[e] * ldb + c];
         y[e * D + c] = fmaxf(v + bias[c], 0.f);
     }
 }
@@ -176,17 +179,18 @@ static EncLayout enc_layout(int64_t N, int64_t E, int D) {
 extern "C" {
 using namespace gvqa;
 
-int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, const int64_t* ia, const float* b, const int64_t* ib, const float* bias,
-                         const float* y_in, float* y_out, void* stream_) {
+int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, int64_t lda, const int64_t* ia, const float* b, int64_t ldb, const int64_t* ib,
+                         const float* bias, const float* y_in, float* y_out, void* stream_) {
     GVQA_REQUIRE(E >= 0 && D > 0, GVQA_E_INVALID, "gather_add_relu: bad dims");
     if (E == 0) return GVQA_OK;
-    GVQA_REQUIRE(bias && y_in && y_out && (!a || ia) && (!b || ib), GVQA_E_INVALID, "gather_add_relu: null tensor");
+    GVQA_REQUIRE(bias && y_in && y_out && (!a || (ia && lda >= D)) && (!b || (ib && ldb >= D)), GVQA_E_INVALID, "gather_add_relu: null tensor / stride");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    const bool v4 = D % 4 == 0 && al(a) && al(b) && al(bias) && al(y_in) && al(y_out);
+    const bool v4 = D % 4 == 0 && al(a) && al(b) && al(bias) && al(y_in) && al(y_out) && lda % 4 == 0 && ldb % 4 == 0;
     const int DW = v4 ? D / 4 : D;
-    if (v4) hipLaunchKernelGGL(k_gather_add_relu<4>, dim3((unsigned)cdiv(E * DW, 256)), dim3(256), 0, stream, E, (int)D, a, ia, b, ib, bias, y_out, y_in);
-    else hipLaunchKernelGGL(k_gather_add_relu<1>, dim3((unsigned)cdiv(E * DW, 256)), dim3(256), 0, stream, E, (int)D, a, ia, b, ib, bias, y_out, y_in);
+    if (v4) hipLaunchKernelGGL(k_gather_add_relu<4>, dim3((unsigned)cdiv(E * DW, 256)), dim3(256), 0, stream, E, (int)D, a, ia, b, ib, bias, y_out, y_in, lda, ldb);
+    else hipLaunchKernelGGL(k_gather_add_relu<1>, dim3((unsigned)cdiv(E * DW, 256)), dim3(256), 0, stream, E, (int)D, a, ia, b, ib, bias, y_out, y_in, lda,
+                            ldb);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

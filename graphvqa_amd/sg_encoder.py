@@ -73,15 +73,18 @@ class _GatherAddRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, y, bias, graph):
         lib = _lib.load()
-        a, y, bias = _f32c(a, "a"), _f32c(y, "y"), _f32c(bias, "bias")
-        b = None if b is None else _f32c(b, "b")
+        def rows(t_, name):                           # a column block of a wider product keeps its row stride
+            if t_ is None or (t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1):
+                return t_
+            return _f32c(t_, name)
+        a, b, y, bias = rows(a, "a"), rows(b, "b"), _f32c(y, "y"), _f32c(bias, "bias")
         ei = graph._keep[0]
         E, D = y.shape
         out = torch.empty_like(y)
         with torch.cuda.device(y.device):
-            _lib.check(lib.gvqa_gather_add_relu(E, D, a.data_ptr(), ei[0].data_ptr(), None if b is None else b.data_ptr(),
-                                                None if b is None else ei[1].data_ptr(), bias.data_ptr(), y.data_ptr(), out.data_ptr(),
-                                                _stream(y.device)))
+            _lib.check(lib.gvqa_gather_add_relu(E, D, a.data_ptr(), a.stride(0), ei[0].data_ptr(), None if b is None else b.data_ptr(),
+                                                0 if b is None else b.stride(0), None if b is None else ei[1].data_ptr(), bias.data_ptr(),
+                                                y.data_ptr(), out.data_ptr(), _stream(y.device)))
         ctx.save_for_backward(out)
         ctx.graph, ctx.has_b = graph, b is not None
         return out
@@ -171,14 +174,17 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         dst = ei[1]
         # EdgeModel :65-76
         # (biases ride in the products' epilogues: where a sum of products has one bias, the first product takes it)
-        y1 = _GatherAddRelu.apply(proj(x, e0.weight[:, :D], None), proj(x, e0.weight[:, D:2 * D], None), ye, e0.bias, graph)
+        # the four per-node column blocks that act on x -- EdgeModel's x_src and x_dst, node_mlp_1's x_src, node_mlp_2's x -- as ONE
+        # product [N, D] x [D, 4D] (x packed once forward, its gradient one product backward)
+        xs, xd, xp1, xt = proj(x, torch.cat((e0.weight[:, :D], e0.weight[:, D:2 * D], n10.weight[:, :D], n20.weight[:, :D]), 0), None).split(D, 1)
+        y1 = _GatherAddRelu.apply(xs, xd, ye, e0.bias, graph)
         e2 = proj(y1, e2l.weight, e2l.bias)
         # NodeModel :78-98
-        y3 = _GatherAddRelu.apply(proj(x, n10.weight[:, :D], None), None, proj(e2, n10.weight[:, D:], None), n10.bias, graph)
+        y3 = _GatherAddRelu.apply(xp1, None, proj(e2, n10.weight[:, D:], None), n10.bias, graph)
         mm = proj(y3, n12.weight, n12.bias)
         cnt = torch.bincount(dst, minlength=N).clamp(min=1).to(mm.dtype)
         agg = edge_scatter_add(mm, graph) / cnt.view(-1, 1)                              # scatter_mean :96
-        x2 = proj(torch.relu(proj(x, n20.weight[:, :D], n20.bias) + proj(agg, n20.weight[:, D:], None)), n22.weight, n22.bias)
+        x2 = proj(torch.relu(xt + proj(agg, n20.weight[:, D:], n20.bias)), n22.weight, n22.bias)
         gp = graph.graph_ptr.long()
         norm = ((gp[1:] - gp[:-1]).clamp(min=1) * D).to(x2.dtype).view(-1, 1)
         mean = graph_segment_sum(x2, graph).sum(dim=-1, keepdim=True) / norm

@@ -654,9 +654,9 @@ int gvqa_embed_sum(int64_t rows, int32_t T, int32_t V, int32_t D, const int64_t*
                    float* out, void* stream);
 /* y_out[e, :] = relu(a[ia[e], :] + b[ib[e], :] + y_in[e, :] + bias): the first Linear of an edge-level MLP of the encoder once its
  * node-side column blocks are projected per node (pipeline_model_gat.py:65-76,92-95): per-edge gathers, sum, bias and ReLU in one
- * pass.  a / b may be NULL (term absent); y_out may be y_in. */
-int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, const int64_t* ia, const float* b, const int64_t* ib, const float* bias,
-                         const float* y_in, float* y_out, void* stream);
+ * pass.  a / b may be NULL (term absent) and have row strides lda / ldb (column blocks of one wider per-node product); y_out may be y_in. */
+int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, int64_t lda, const int64_t* ia, const float* b, int64_t ldb, const int64_t* ib,
+                         const float* bias, const float* y_in, float* y_out, void* stream);
 size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D);
 int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t node_tokens, int32_t edge_tokens_per_edge,
                             const gvqa_encoder_params* p, const int64_t* x_tokens, const int64_t* edge_tokens,
