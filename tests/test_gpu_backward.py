@@ -781,3 +781,15 @@ def test_bn_relu_with_feature_dropout_in_the_same_passes(dev, N, C):
     assert maxabs(mean, xr.mean(0)) < 1e-5 and maxabs(var, xr.var(0, unbiased=False)) < 1e-5
     for got, r, name in ((x.grad, xr.grad, "dx"), (w.grad, wr.grad, "dw"), (b.grad, br.grad, "db")):
         assert _rel(got, r) < 2e-5, name
+
+
+def test_config1_pipeline_end_to_end_gradients_on_the_library_products(dev):
+    """The end-to-end gradient check (encoder -> gat_seq -> pooling -> classifier against the oracle's autograd) with the size
+    threshold at 0: the encoder's and the pooling head's differentiable paths then run every product on the library's kernels
+    (split GEMMs forward, one-call backward, gather-sum / gather-add-relu ops), not torch's."""
+    from graphvqa_amd import _lib
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        test_config1_pipeline_end_to_end_gradients(dev)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
