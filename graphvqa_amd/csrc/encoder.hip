@@ -290,14 +290,20 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
             LinearEpilogue ep{p->node2_0_bias, nullptr, 0, nullptr, 0, 0};
             if ((rc = prod(N, apk_n, p->node2_0_weight, 2 * D, ep, P(L.t)))) return rc;
         }
-        ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.S), src, (const float*)P(L.Dd), dst, p->edge0_bias, P(L.Y));
         // W' = Wn_e W2, b' = Wn_e b2: node1_0's edge block applied to edge_attr' = Y W2^T + b2 without forming it first
         hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
                            (int64_t)2 * D, p->edge2_weight, (int64_t)D, P(L.wf), (int64_t)D);
         hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node1_0_weight + D, (int64_t)2 * D,
                            p->edge2_bias, (int64_t)1, P(L.bf), (int64_t)1);
         GVQA_LAUNCH_CHECK();
-        rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);           // Y packed once for both of its products
+        // Y = relu(S[src] + Dd[dst] + Y + b) goes straight into its packed form (the gathers ride in the pack pass: the fp32 Y is
+        // only ever a matrix-core operand), packed once for both of its products
+        const bool gpack = D <= 512 && al16(p->edge0_bias) && al16(p->node1_0_bias);
+        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, P(L.S), src, D, P(L.Dd), dst, D, p->edge0_bias, apk_e, stream);
+        else {
+            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.S), src, (const float*)P(L.Dd), dst, p->edge0_bias, P(L.Y));
+            rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
+        }
         if (rc) return rc;
         {
             LinearEpilogue ep{p->edge2_bias, nullptr, 0, nullptr, 0, 0};
@@ -305,10 +311,12 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
             LinearEpilogue ef{P(L.bf), nullptr, 0, nullptr, 0, 0};
             if ((rc = prod(E, apk_e, P(L.wf), D, ef, P(L.Y)))) return rc;     // (the fp32 Y is free: its packed image is the operand)
         }
-        ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.P), src, (const float*)nullptr, (const int64_t*)nullptr,
-                   p->node1_0_bias, P(L.Y));
-        GVQA_LAUNCH_CHECK();
-        rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
+        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, P(L.P), src, D, nullptr, nullptr, 0, p->node1_0_bias, apk_e, stream);
+        else {
+            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.P), src, (const float*)nullptr, (const int64_t*)nullptr,
+                       p->node1_0_bias, P(L.Y));
+            rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
+        }
         if (rc) return rc;
         {
             LinearEpilogue ep{p->node1_2_bias, nullptr, 0, nullptr, 0, 0};

@@ -768,12 +768,17 @@ __device__ __forceinline__ void split2h_store(const float (&v)[8], float scale, 
 }
 
 // which fp32 row a packed row (slot) holds
-enum { PACK_PLAIN = 0, PACK_GROUPS = 1, PACK_HEADS = 2, PACK_HEADS2 = 3 };
+enum { PACK_PLAIN = 0, PACK_GROUPS = 1, PACK_HEADS = 2, PACK_HEADS2 = 3, PACK_GATHER = 4 };
 struct PackRows {
     const float* X; int64_t ld;
     int64_t rows;                 // PLAIN: packed row r = X row r
     const int32_t* group_ptr;     // GROUPS: slot 128 g + i = node group_ptr[g] + i
     int H, C, cw;                 // HEADS: packed row 256 cb + h cw + cc = W row h C + cb cw + cc
+    // GATHER (rows as PLAIN): the packed value is relu(X[r, k] + ga[gia[r], k] + gb[gib[r], k] + gbias[k]) -- the first Linear of an
+    // edge-level MLP of the scene-graph encoder with its node-side column blocks gathered on the way into the operand (gb may be NULL)
+    const float* ga; const int64_t* gia; int64_t glda;
+    const float* gb; const int64_t* gib; int64_t gldb;
+    const float* gbias;
 };                                // HEADS2 (hop2.hip): packed row 256 cb + 64 w + 32 j + t = W row h C + cb cw + j hw + cc, (h, cc) = divmod(32 w + t, hw), hw = cw / 2
 // head and channel of row `within` (0..255) of column block cb
 template <int MAP>
@@ -789,7 +794,7 @@ __device__ __forceinline__ void heads_row(const PackRows& pr, int cb, int within
 }
 template <int MAP>
 __device__ __forceinline__ const float* pack_row(const PackRows& pr, int64_t rt, int m, bool& on, int64_t& src_row) {
-    if constexpr (MAP == PACK_PLAIN) {
+    if constexpr (MAP == PACK_PLAIN || MAP == PACK_GATHER) {
         src_row = rt * 32 + m;
         on = src_row < pr.rows;
     } else if constexpr (MAP == PACK_GROUPS) {
@@ -818,6 +823,23 @@ __device__ __forceinline__ void load_row8(const float* row, bool on, int k0, int
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if (k0 + e < K) v[e] = row[k0 + e];
+    }
+}
+
+// GATHER map: v = relu(v + a_row[k0..] + b_row[k0..] + bias[k0..]) on the 8 values just loaded (K % 4 == 0, 16-byte rows)
+__device__ __forceinline__ void gather_add_relu8(const float* arow, const float* brow, const float* bias, bool on, int k0, int K, float (&v)[8]) {
+    if (!on) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = k0 + 4 * h;
+        if (k >= K) { v[4 * h] = v[4 * h + 1] = v[4 * h + 2] = v[4 * h + 3] = 0.f; continue; }
+        const float4 a = *reinterpret_cast<const float4*>(arow + k), bi = *reinterpret_cast<const float4*>(bias + k);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (brow) b = *reinterpret_cast<const float4*>(brow + k);
+        v[4 * h + 0] = fmaxf(v[4 * h + 0] + a.x + b.x + bi.x, 0.f);
+        v[4 * h + 1] = fmaxf(v[4 * h + 1] + a.y + b.y + bi.y, 0.f);
+        v[4 * h + 2] = fmaxf(v[4 * h + 2] + a.z + b.z + bi.z, 0.f);
+        v[4 * h + 3] = fmaxf(v[4 * h + 3] + a.w + b.w + bi.w, 0.f);
     }
 }
 
@@ -858,11 +880,18 @@ __global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, i
     float mx = 0.f;
     auto kb_of = [&](int it) { return (it >> 1) * (2 * NWV) + 2 * wave + (it & 1); };
     const int nit_all = ((KB + 2 * NWV - 1) / (2 * NWV)) * 2;         // iterations that cover every k block (NIT == 0 path)
+    [[maybe_unused]] const float* g_arow = nullptr;
+    [[maybe_unused]] const float* g_brow = nullptr;
+    if constexpr (MAP == PACK_GATHER) {                               // (launched with NIT > 0 only: the rows stay in registers)
+        g_arow = pr.ga + (row_on ? pr.gia[src_row] : 0) * pr.glda;
+        g_brow = pr.gb ? pr.gb + (row_on ? pr.gib[src_row] : 0) * pr.gldb : nullptr;
+    }
     if (NIT > 0) {
 #pragma unroll
         for (int it = 0; it < NR; ++it) {
             const int kb = kb_of(it);
             load_row8(row, row_on && kb < KB, kb * 16 + kh, K, vec, v[it]);
+            if constexpr (MAP == PACK_GATHER) gather_add_relu8(g_arow, g_brow, pr.gbias, row_on && kb < KB, kb * 16 + kh, K, v[it]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[it][e]));
         }
@@ -1025,6 +1054,21 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
 #undef GVQA_P2W8
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
+}
+
+// The two-piece pack of relu(Y + a[ia] + b[ib] + bias) (PackRows GATHER): K % 4 == 0, K <= 512, 16-byte aligned rows
+int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t ld, const float* a, const int64_t* ia, int64_t lda,
+                               const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    GVQA_REQUIRE(rows >= 0 && K > 0 && K % 4 == 0 && K <= 512 && ld % 4 == 0 && ld >= K && lda % 4 == 0 && (!b || ldb % 4 == 0), GVQA_E_UNSUPPORTED,
+                 "split_pack_gather: K %% 4 == 0, K <= 512, row strides multiples of 4");
+    if (rows == 0) return GVQA_OK;
+    GVQA_REQUIRE(Y && a && ia && bias && packed && (!b || ib) && al(Y) && al(a) && al(b) && al(bias) && al(packed), GVQA_E_INVALID,
+                 "split_pack_gather: null / unaligned operand");
+    const int64_t RT = cdiv(rows, 32);
+    GVQA_REQUIRE(RT < (1ll << 31), GVQA_E_INVALID, "split_pack_gather: too many rows");
+    PackRows pr{Y, ld, rows, nullptr, 0, 0, 0, a, ia, lda, b, ib, ldb, bias};
+    return launch_split2h_pack_tiles<PACK_GATHER>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
 }
 
 int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream) {
