@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_small_matmul_nn(int M, int N, int K, co
     if (sl == 0 && k < N) C[(int64_t)i * ldc + k] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
-struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, apk_n, apk_e, wpk, total; };
+struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, apk_n, apk_e, wpk, Z, wc, wpk4, total; };
 static EncLayout enc_layout(int64_t N, int64_t E, int D) {
     EncLayout L; size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
@@ -170,6 +170,8 @@ static EncLayout enc_layout(int64_t N, int64_t E, int D) {
     // folded weight / bias, packed two-piece operands (node rows, edge rows, one weight at a time)
     L.wf = take((size_t)D * D * 4); L.bf = take((size_t)D * 4);
     L.apk_n = take(split_packed_bytes(2, N, D)); L.apk_e = take(split_packed_bytes(2, E, D)); L.wpk = take(split_packed_bytes(2, D, D));
+    // the four per-node column blocks that act on x0 as one product: result [N, 4D], stacked weight [4D, D] and its packed image
+    L.Z = take(4 * nd); L.wc = take((size_t)4 * D * D * 4); L.wpk4 = take(split_packed_bytes(2, 4 * (int64_t)D, D));
     L.total = off;
     return L;
 }
@@ -281,14 +283,23 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         if (rc) return rc;
         ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, (const float*)Te, (const uint8_t*)flags, P(L.Y));
         GVQA_LAUNCH_CHECK();
-        rc = launch_split_pack(2, N, D, P(L.x0), D, apk_n, stream);          // x0 packed once for its four products
-        if (rc) return rc;
-        if ((rc = prod(N, apk_n, p->edge0_weight, 3 * D, none, P(L.S)))) return rc;
-        if ((rc = prod(N, apk_n, p->edge0_weight + D, 3 * D, none, P(L.Dd)))) return rc;
-        if ((rc = prod(N, apk_n, p->node1_0_weight, 2 * D, none, P(L.P)))) return rc;
+        // the four per-node column blocks that act on x0 -- EdgeModel's x_src and x_dst, node_mlp_1's x_src, node_mlp_2's x -- as ONE
+        // product Z [N, 4D] = x0 [W_s; W_d; W_p; W_t]^T: the blocks are stacked (parameter-sized copies), packed once, x0 packed once
+        float* Z = P(L.Z);
+        const int64_t ldz = 4 * (int64_t)D;
         {
-            LinearEpilogue ep{p->node2_0_bias, nullptr, 0, nullptr, 0, 0};
-            if ((rc = prod(N, apk_n, p->node2_0_weight, 2 * D, ep, P(L.t)))) return rc;
+            float* Wc = P(L.wc);
+            const float* blk[4] = {p->edge0_weight, p->edge0_weight + D, p->node1_0_weight, p->node2_0_weight};
+            const int64_t bld[4] = {3 * (int64_t)D, 3 * (int64_t)D, 2 * (int64_t)D, 2 * (int64_t)D};
+            for (int q = 0; q < 4; ++q)
+                GVQA_HIP_CHECK(hipMemcpy2DAsync(Wc + (size_t)q * D * D, (size_t)D * 4, blk[q], (size_t)bld[q] * 4, (size_t)D * 4, (size_t)D,
+                                                hipMemcpyDeviceToDevice, stream));
+            rc = launch_split_pack(2, N, D, P(L.x0), D, apk_n, stream);
+            if (rc) return rc;
+            rc = launch_split_pack(2, ldz, D, Wc, D, base + L.wpk4, stream);
+            if (rc) return rc;
+            rc = launch_linear_split(2, N, ldz, D, apk_n, base + L.wpk4, none, Z, ldz, stream);
+            if (rc) return rc;
         }
         // W' = Wn_e W2, b' = Wn_e b2: node1_0's edge block applied to edge_attr' = Y W2^T + b2 without forming it first
         hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
@@ -299,9 +310,9 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         // Y = relu(S[src] + Dd[dst] + Y + b) goes straight into its packed form (the gathers ride in the pack pass: the fp32 Y is
         // only ever a matrix-core operand), packed once for both of its products
         const bool gpack = D <= 512 && al16(p->edge0_bias) && al16(p->node1_0_bias);
-        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, P(L.S), src, D, P(L.Dd), dst, D, p->edge0_bias, apk_e, stream);
+        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, Z, src, ldz, Z + D, dst, ldz, p->edge0_bias, apk_e, stream);
         else {
-            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.S), src, (const float*)P(L.Dd), dst, p->edge0_bias, P(L.Y));
+            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)Z, src, (const float*)(Z + D), dst, p->edge0_bias, P(L.Y), (const float*)nullptr, ldz, ldz);
             rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
         }
         if (rc) return rc;
@@ -311,10 +322,10 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
             LinearEpilogue ef{P(L.bf), nullptr, 0, nullptr, 0, 0};
             if ((rc = prod(E, apk_e, P(L.wf), D, ef, P(L.Y)))) return rc;     // (the fp32 Y is free: its packed image is the operand)
         }
-        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, P(L.P), src, D, nullptr, nullptr, 0, p->node1_0_bias, apk_e, stream);
+        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, Z + 2 * D, src, ldz, nullptr, nullptr, 0, p->node1_0_bias, apk_e, stream);
         else {
-            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)P(L.P), src, (const float*)nullptr, (const int64_t*)nullptr,
-                       p->node1_0_bias, P(L.Y));
+            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)(Z + 2 * D), src, (const float*)nullptr, (const int64_t*)nullptr,
+                       p->node1_0_bias, P(L.Y), (const float*)nullptr, ldz, (int64_t)0);
             rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
         }
         if (rc) return rc;
@@ -328,7 +339,7 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         rc = launch_split_pack(2, N, D, P(L.agg), D, apk_n, stream);
         if (rc) return rc;
         {
-            LinearEpilogue ep{nullptr, P(L.t), D, nullptr, 0, 1};            // t = relu(t + agg W^T)  (t holds x0's block + bias)
+            LinearEpilogue ep{p->node2_0_bias, Z + 3 * D, ldz, nullptr, 0, 1};   // t = relu(x0's block + agg W^T + bias)
             if ((rc = prod(N, apk_n, p->node2_0_weight + D, 2 * D, ep, P(L.t)))) return rc;
         }
         rc = launch_split_pack(2, N, D, P(L.t), D, apk_n, stream);
