@@ -9,7 +9,8 @@ from graphvqa_amd import synth, _lib
 from graphvqa_amd.graph import SceneGraphBatch, HostLayout
 from graphvqa_amd.gat_skip import gat_seq
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)); dev = torch.device("cuda:0")
-gb = synth.config2_batch(); N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+gb = synth.config3_batch() if os.environ.get("BATCH") == "3" else synth.config2_batch()      # BATCH=3: config-3 batch at config-2 widths (the pipeline bench)
+N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
 ei, batch = tt(gb.edge_index).to(dev), tt(gb.batch).to(dev)
 x, ea = tt(synth.normal((N, 300), 1)).to(dev), tt(synth.normal((E, 300), 2)).to(dev)
 ins = tt(synth.normal((5, B, 512), 3)).to(dev)
