@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 # kernel variants (tile geometry x schedule x epilogue, see launch_linear_split); 0 = the library's own choice
 VARIANTS = [0, 10, 11, 14, 21, 28, 29, 30, 34]
-SCHEME_VARIANTS = [("split3", v) for v in VARIANTS] + [("split2h", v) for v in (0, 114, 118, 134)]   # (112: even k-block counts only, own test below)
+SCHEME_VARIANTS = [("split3", v) for v in VARIANTS] + [("split2h", v) for v in (0, 114, 118, 124, 134)]   # (112: even k-block counts only, own test below)
 
 
 @pytest.fixture(scope="module")
