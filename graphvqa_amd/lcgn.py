@@ -15,7 +15,8 @@ import torch.nn as nn
 from torch.nn import Linear, Parameter
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _glorot, gat_message_passing, graph_rows, edge_gather
+from .gat_skip import (_f32c, _workspace, _glorot, _ProjectionLinear, gat_message_passing, graph_rows,
+                       edge_gather)
 from .graph import SceneGraphBatch, _stream
 
 
@@ -87,8 +88,9 @@ class lcgn_seq(nn.Module):
         self.gat_cmd_dim, self.gat_heads, self.negative_slope = gat_cmd_dim, gat_heads, gat_negative_slope
 
     def _forward_autograd(self, x, edge_index, q, lstm, graph, x_ctx_init):
-        """Differentiable / training formulation of lcgn.py:303-323: dense layers (with the module's dropouts) are torch
-        ops; the per-graph command broadcasts, the softmax-weighted neighbour sum and their backward run on the HIP
+        """Differentiable / training formulation of lcgn.py:303-323: the node-sized dense layers (with the module's
+        dropouts) and their dx / dW run on the library's own products (_ProjectionLinear: the arithmetic
+        GVQA_OPT_PROJECTION selects, as in the eval path), the per-question layers are torch ops; the per-graph command broadcasts, the softmax-weighted neighbour sum and their backward run on the HIP
         per-graph / message-passing kernels (the dot-product logit x_l[src] . (proj_cmd * x_r)[dst], lcgn.py:154,207,
         enters the message passing as its per-edge term).  fp32 node tensors only."""
         if self.node_feature_dtype != torch.float32:
@@ -98,20 +100,27 @@ class lcgn_seq(nn.Module):
             raise NotImplementedError("lcgn_seq: gat_heads != 1 is not implemented (reference default 1)")
         O, N, E = self.out_channels, x.shape[0], edge_index.shape[1]
         L = self.lcgn
-        src, dst = edge_index[0], edge_index[1]
-        x_loc = self.init_sg_emb_input(x)                                             # :305
+        proj = _ProjectionLinear.apply              # node-sized products + their dx / dW on the library's own GEMMs
+        init, p_loc, p_ctx = self.init_sg_emb_input, self.proj_x_loc, self.proj_x_ctx
+        x_loc = init[1](proj(x, init[0].weight, init[0].bias))                        # :305
         x_ctx = x_ctx_init                                                            # :306
         q_emb = torch.relu(self.qInput1(q))                                           # :307
-        proj_x_loc = self.proj_x_loc(x_loc)                                           # :308
+        proj_x_loc = proj(p_loc[0](x_loc), p_loc[1].weight, p_loc[1].bias)            # :308
         lo = lstm.transpose(1, 0)                                                     # [B, L, O]
         zeros2 = torch.zeros((N, 2), device=x.device)
         p_att = L.dropout if self.training else 0.0
+        # lin_l / lin_r / cal_x act on x_joint = [x_loc | x_ctx | proj_x_ctx(x_ctx) * proj_x_loc] (:312-313, :144-145, :230) as
+        # one stacked [3O, 3O] weight; its x_loc column block multiplies an iteration-invariant operand: applied once
+        w_joint = torch.cat([L.lin_l.weight, L.lin_r.weight, L.cal_x.weight], dim=0)
+        z_loc = proj(x_loc, w_joint[:, :O]).split(O, dim=1)
+        w_iter = w_joint[:, O:]
         for t in range(self.MAX_ITER_NUM):
             q_cmd = getattr(self, "qInput2_%d" % t)(q_emb)                            # :292-300
             att = torch.softmax(self.cmd_inter2logits(q_cmd[:, None, :] * lo).squeeze(-1), dim=-1)
             cmd = torch.bmm(att[:, None, :], lo).squeeze(1)
-            x_joint = torch.cat([x_loc, x_ctx, self.proj_x_ctx(x_ctx) * proj_x_loc], dim=-1)    # :312-313
-            x_l, x_r, x_val = L.lin_l(x_joint), L.lin_r(x_joint), L.cal_x(x_joint)    # :144-145,230
+            x_pair = torch.cat([x_ctx, proj(p_ctx[0](x_ctx), p_ctx[1].weight, p_ctx[1].bias) * proj_x_loc], dim=-1)
+            z = proj(x_pair, w_iter).split(O, dim=1)
+            x_l, x_r, x_val = z[0] + z_loc[0], z[1] + z_loc[1], z[2] + z_loc[2]
             y = graph_rows(L.proj_cmd(cmd), graph) * x_r                              # :148-154
             a_edge = (edge_gather(x_l, graph, "src") * edge_gather(y, graph, "dst")).sum(dim=-1, keepdim=True)   # :207
             mask = torch.bernoulli(torch.full((E, 1), 1.0 - p_att, device=x.device)) / (1.0 - p_att) if p_att > 0 else None
@@ -119,8 +128,8 @@ class lcgn_seq(nn.Module):
             msg = agg * graph_rows(L.cal_cmd(cmd), graph)                             # :231 (edges are intra-graph)
             if L.bias is not None:
                 msg = msg + L.bias
-            x_ctx = self.output_layer(torch.cat([x_ctx, msg], dim=-1))                # :316-319
-        return self.fin_layer(torch.cat([x_loc, x_ctx], dim=-1))                      # :321-322
+            x_ctx = proj(torch.cat([x_ctx, msg], dim=-1), self.output_layer.weight, self.output_layer.bias)   # :316-319
+        return proj(torch.cat([x_loc, x_ctx], dim=-1), self.fin_layer.weight, self.fin_layer.bias)           # :321-322
 
     def forward(self, x, edge_index, batch, q_encoding, lstm_outputs, edge_attr=None, instr_vectors=None,
                 graph: SceneGraphBatch | None = None, x_ctx_init: torch.Tensor | None = None):

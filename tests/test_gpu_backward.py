@@ -747,6 +747,17 @@ def test_gat_seq_gradients_with_dropout_masks_on_the_library_products(dev):
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
 
 
+def test_lcgn_seq_gradients_on_the_library_products(dev):
+    """lcgn_seq's node-sized layers (init / proj_x_loc / proj_x_ctx / the stacked lin_l|lin_r|cal_x with its iteration-invariant
+    x_loc block / output_layer / fin_layer, lcgn.py:305-322) forced onto the library's products and one-call backward."""
+    from graphvqa_amd import _lib
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        test_lcgn_seq_gradients_vs_oracle(dev)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+
+
 @pytest.mark.parametrize("threshold", [None, 0])
 def test_gat_seq_gradients_at_widths_the_library_products_do_not_take(dev, threshold):
     """Widths that are not multiples of 4 (d = 30, ins 22, H = 2): every product of the differentiable path takes its torch
