@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the f32-MFMA / vendor comparison legs")
     ap.add_argument("--with-head", action="store_true",
                     help="also run global attention pooling + answer classifier each step and all-gather the true [B, 1842] logits")
+    ap.add_argument("--pipelined-gather", action="store_true",
+                    help="N > 1: enqueue the all-gather of step i on RCCL's stream so that it overlaps the hops of step i + 1 (default: every "
+                         "step waits for its own; with ONE rank the pipelined form measures 0.01-0.05 ms per step slower -- two more "
+                         "cross-stream waits -- and more ranks cannot be measured on the one-GPU boxes)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single-GPU estimate of strong scaling: time rank 0's shard of an N-way split of the batch (no collective)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -170,7 +174,7 @@ def main():
 
     from graphvqa_amd.gat_skip import gat_seq
     from graphvqa_amd.graph import SceneGraphBatch
-    from graphvqa_amd.parallel import BatchShard, sharded_step, graph_mean_pool
+    from graphvqa_amd.parallel import BatchShard, PipelinedSteps, sharded_step, graph_mean_pool
 
     lib = _lib.load()
     params = synth.gat_seq_params(D, D, D, D, K, H, seed=777)
@@ -196,6 +200,8 @@ def main():
         head = (pool_m.to(dev).eval(), clf.to(dev).eval())
         q_all = synth.normal((Ball, D), 4)
 
+    pipes = []
+
     def runner(shard):
         q_feat = tt(q_all[shard.graph_range[0]:shard.graph_range[1]]).to(dev) if head is not None else None
         state = {}
@@ -214,9 +220,17 @@ def main():
 
         if dist is None:
             return (lambda: forward(shard)) if head is None else (lambda: pool(forward(shard), shard))
-        return lambda: sharded_step(shard, forward, pool, force=force_dist)
+        if not a.pipelined_gather:
+            return lambda: sharded_step(shard, forward, pool, force=force_dist)
+        # the loop over batches: step i's per-graph rows are gathered on RCCL's stream while step i + 1's hops run; every
+        # gathered result is complete before the timed region's closing synchronize (device-wide)
+        pipe = PipelinedSteps()
+        pipes.append(pipe)
+        return lambda: pipe.step(shard, forward, pool, force=force_dist)
 
     def fence():
+        for pipe in pipes:
+            pipe.drain()                 # orders the compute stream after the last step's all-gather
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -344,6 +358,8 @@ def main():
                                   "values, fp32 accumulate"}
         else:
             roof = mp_roofline(prof, g0)
+        gather_note = ("" if dist is None else " (each step waits for its own)" if not a.pipelined_gather else
+                       " (enqueued on RCCL's stream: it overlaps the next step's hops; all gathered before the closing synchronize)")
         res = {
             "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
             "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
@@ -358,8 +374,8 @@ def main():
                                    + ("; + attention pooling + 1842-way classifier, true logits gathered" if head else ""),
                        "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
                        "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
-                                       "no communication inside the hops, one RCCL all-gather of per-graph rows per step") if strong
-                       else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step",
+                                       "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
+                       else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
                        "hop": (("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "
                                 "segment softmax) -> ONE persistent kernel for projection + aggregation + epilogue that leaves the next hop's "
                                 "packed operand") if fused and split and pieces == 2 and prof["pack"][1] < prof["proj"][1] else

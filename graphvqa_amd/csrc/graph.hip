@@ -477,12 +477,13 @@ __global__ __launch_bounds__(256) void k_graph_rows_to_nodes(int64_t N, int F, c
     }
 }
 __global__ __launch_bounds__(256) void k_graph_segment_sum(int F, const int32_t* __restrict__ graph_ptr, const float* __restrict__ x,
-                                                           int64_t ldx, float* __restrict__ out, int64_t ldo) {
+                                                           int64_t ldx, float* __restrict__ out, int64_t ldo, int mean) {
     const int c = blockIdx.y * 256 + threadIdx.x, b = blockIdx.x;      // graphs on grid.x (no 65535 limit)
     if (c >= F) return;
     float acc = 0.f;
-    for (int i = graph_ptr[b]; i < graph_ptr[b + 1]; ++i) acc += x[(int64_t)i * ldx + c];
-    out[(int64_t)b * ldo + c] = acc;
+    const int lo = graph_ptr[b], hi = graph_ptr[b + 1];
+    for (int i = lo; i < hi; ++i) acc += x[(int64_t)i * ldx + c];
+    out[(int64_t)b * ldo + c] = mean ? acc / (float)max(hi - lo, 1) : acc;      // (scatter_mean: divides by max(count, 1))
 }
 }  // namespace gvqa
 
@@ -530,17 +531,27 @@ int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, 
     return GVQA_OK;
 }
 
-int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream) {
-    using namespace gvqa;
+namespace gvqa {
+static int graph_segment_reduce(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, int mean,
+                                void* stream) {
     GVQA_REQUIRE(g && g->valid, GVQA_E_INVALID, "graph_segment_sum: graph not built");
     GVQA_REQUIRE(F >= 0 && F < 65535ll * 256 && ld_x >= F && ld_out >= F, GVQA_E_INVALID, "graph_segment_sum: bad sizes");
     if (g->num_graphs == 0 || F == 0) return GVQA_OK;
     GVQA_REQUIRE((x || g->num_nodes == 0) && out, GVQA_E_INVALID, "graph_segment_sum: null tensor");
     const dim3 grid((unsigned)g->num_graphs, (unsigned)cdiv(F, 256));
     hipLaunchKernelGGL(k_graph_segment_sum, grid, dim3(256), 0, static_cast<hipStream_t>(stream), (int)F, g->graph_ptr, x, ld_x, out,
-                       ld_out);
+                       ld_out, mean);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
+}
+}  // namespace gvqa
+
+int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream) {
+    return gvqa::graph_segment_reduce(g, F, x, ld_x, out, ld_out, 0, stream);
+}
+
+int gvqa_graph_segment_mean(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream) {
+    return gvqa::graph_segment_reduce(g, F, x, ld_x, out, ld_out, 1, stream);
 }
 
 }  // extern "C"

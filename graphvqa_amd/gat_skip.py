@@ -558,12 +558,12 @@ class _GraphSegmentSum(torch.autograd.Function):
         return dx, None
 
 
-def _segment_sum_raw(x: Tensor, graph: SceneGraphBatch) -> Tensor:
+def _segment_sum_raw(x: Tensor, graph: SceneGraphBatch, mean: bool = False) -> Tensor:
     lib = _lib.load()
     out = torch.empty((graph.num_graphs, x.shape[1]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.gvqa_graph_segment_sum(C.byref(graph.c), x.shape[1], x.data_ptr(), x.shape[1], out.data_ptr(), x.shape[1],
-                                              _stream(x.device)))
+        _lib.check((lib.gvqa_graph_segment_mean if mean else lib.gvqa_graph_segment_sum)(
+            C.byref(graph.c), x.shape[1], x.data_ptr(), x.shape[1], out.data_ptr(), x.shape[1], _stream(x.device)))
     return out
 
 

@@ -85,25 +85,42 @@ def sharded_step(shard: BatchShard, forward, pool=None, force: bool = False) -> 
 
 def graph_mean_pool(h: torch.Tensor, batch: torch.Tensor, num_graphs: int, graph=None) -> torch.Tensor:
     """Per-graph mean of node rows -> [B, C]; the small per-graph payload that is all-gathered when the answer head is
-    not run.  With the batch handle (`graph`, a SceneGraphBatch) on a GPU this is one pass of the HIP segment-sum kernel
+    not run.  With the batch handle (`graph`, a SceneGraphBatch) on a GPU this is one pass of the HIP segment-mean kernel
     over h (deterministic); the torch formulation (index_add_) serves the CPU tests."""
     if graph is not None and h.is_cuda:
-        from .gat_skip import _segment_sum_raw
-        gp = graph.graph_ptr
-        cnt = (gp[1:] - gp[:-1]).clamp(min=1).to(h.dtype)
-        return _segment_sum_raw(h.contiguous(), graph) / cnt[:, None]
+        from .gat_skip import _segment_sum_raw, _f32c
+        return _segment_sum_raw(_f32c(h, "h"), graph, mean=True)       # gvqa_graph_segment_mean: one launch
     out = torch.zeros((num_graphs, h.shape[1]), dtype=h.dtype, device=h.device)
     out.index_add_(0, batch, h)
     cnt = torch.bincount(batch, minlength=num_graphs).clamp(min=1).to(h.dtype)
     return out / cnt[:, None]
 
 
-def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False) -> torch.Tensor:
+class GatheredRows:
+    """Result of an all-gather of per-graph rows that may still be in flight: `wait()` orders the current stream (host
+    thread for gloo) after the collective and returns the [sum B_r, C] rows in graph order."""
+
+    def __init__(self, out, work=None, counts=None, mx=0):
+        self._out, self._work, self._counts, self._mx = out, work, counts, mx
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        counts, mx, out = self._counts, self._mx, self._out
+        if counts is None or all(c == mx for c in counts):
+            return out
+        return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(len(counts))])
+
+
+def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False, async_op: bool = False):
     """All-gather per-graph rows [B_r, C] from every rank into [sum B_r, C] (rank order).
-    Ragged shards are padded to the largest B_r (one collective, latency-bound at these sizes)."""
+    Ragged shards are padded to the largest B_r (one collective, latency-bound at these sizes).
+    async_op=True: the collective is enqueued on the backend's own stream (ordered after the current stream's work so far)
+    and a GatheredRows handle is returned instead of the tensor -- the caller's stream goes on with the next batch."""
     import torch.distributed as dist
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
-        return rows
+        return GatheredRows(rows) if async_op else rows
     world = dist.get_world_size()
     if counts is None:
         c = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
@@ -114,10 +131,31 @@ def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False) 
     if rows.shape[0] < mx:
         rows = torch.cat([rows, rows.new_zeros((mx - rows.shape[0], rows.shape[1]))])
     out = torch.empty((world * mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    dist.all_gather_into_tensor(out, rows.contiguous())
-    if all(c == mx for c in counts):
-        return out
-    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])
+    work = dist.all_gather_into_tensor(out, rows.contiguous(), async_op=async_op)
+    res = GatheredRows(out, work if async_op else None, counts, mx)
+    return res if async_op else res.wait()
+
+
+class PipelinedSteps:
+    """The steady-state loop over batches (the reference's eval loop, mainExplain_gat.py:226-227 + :791 per batch) with the
+    exchange off the critical path: the all-gather of batch i's per-graph rows runs on the collective's stream while the K
+    hops of batch i + 1 run on the compute stream (graphs are independent units: nothing in batch i + 1 reads batch i's
+    gathered rows).  `step` returns the PREVIOUS batch's gathered rows (None on the first call), `drain` the last one's."""
+
+    def __init__(self):
+        self._pending = None
+
+    def step(self, shard: BatchShard, forward, pool=None, force: bool = False):
+        h = forward(shard)
+        rows = pool(h, shard) if pool is not None else graph_mean_pool(h, shard.batch, shard.num_graphs)
+        nxt = all_gather_graph_rows(rows, counts=shard.counts, force=force, async_op=True)
+        prev = self.drain()
+        self._pending = nxt
+        return prev
+
+    def drain(self):
+        prev, self._pending = self._pending, None
+        return None if prev is None else prev.wait()
 
 
 def allreduce_gradients(parameters, bucket_bytes: int = 64 << 20, average: bool = True) -> int:

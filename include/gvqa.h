@@ -221,6 +221,9 @@ int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const float* x, co
 int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
                              int accumulate, void* stream);
 int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
+/* The same divided by max(node count of graph b, 1): the per-graph mean rows that a sharded step all-gathers when the answer
+ * head is not run (torch_scatter's scatter_mean by graph).  One launch. */
+int gvqa_graph_segment_mean(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
 /* out[i, :F] = sum over the in-edges e of node i of x[e, :F] (x is a per-edge tensor in COO order): scatter_add by
  * destination -- or by SOURCE when `g` is the transposed graph.  The adjoint of the per-edge gathers x[dst] / x[src]
  * (torch's own gather backward is a sort-based index_put).  Deterministic. */

@@ -1240,6 +1240,37 @@ def test_sharded_execution_equals_full_batch(dev):
     assert maxabs(torch.cat(parts), full) < 1e-6
 
 
+def test_per_graph_mean_rows_and_pipelined_steps(dev):
+    """The rows a sharded step all-gathers: gvqa_graph_segment_mean (one launch; scatter_mean's max(count, 1) divisor,
+    ragged graphs incl. single-node ones) against torch's index_add formulation in fp64; PipelinedSteps on one device
+    (no process group) hands every batch's rows back one call later."""
+    from graphvqa_amd.graph import SceneGraphBatch
+    from graphvqa_amd.parallel import BatchShard, PipelinedSteps, graph_mean_pool
+    gb = synth.make_graph_batch(53, seed=0xA11, nodes_lo=1, nodes_hi=40, rel_per_node=1.2)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    for F in (300, 512, 7):
+        h = t(synth.normal((N, F), 5), device=dev)
+        g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
+        got = graph_mean_pool(h, t(gb.batch, device=dev), B, graph=g)
+        want = graph_mean_pool(h.double().cpu(), t(gb.batch), B)
+        assert got.shape == (B, F) and maxabs(got, want) < 1e-5
+    x, ea, ins = synth.normal((N, 16), 1), synth.normal((E, 8), 2), synth.normal((2, B, 8), 3)
+    shards = [BatchShard(gb.edge_index, gb.batch, B, x * (i + 1.0), ea, ins, 0, 1, dev) for i in range(3)]
+    pipe = PipelinedSteps()
+    state = {}
+
+    def fwd(s):
+        state["g"] = SceneGraphBatch(s.edge_index, s.batch, s.num_nodes, s.num_graphs)
+        return s.x
+
+    pool = lambda h, s: graph_mean_pool(h, s.batch, s.num_graphs, graph=state["g"])
+    got = [pipe.step(s, fwd, pool) for s in shards] + [pipe.drain()]
+    assert got[0] is None and pipe.drain() is None
+    base = graph_mean_pool(t(x).double(), t(gb.batch), B)
+    for i in range(3):
+        assert maxabs(got[i + 1], base * (i + 1.0)) < 1e-5
+
+
 def _lcgn_bf16_storage_emulation(x, edge_index, batch, q, lstm, p, x_ctx_init, T=4, slope=0.2, pieces=2):
     """CPU restatement of lcgn_seq.forward with the per-node tensors rounded to bf16 at exactly the points
     where the bf16-node-feature mode stores them, and the node-GEMM weights replaced by the bf16 pieces the

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from graphvqa_amd import synth
 from graphvqa_amd.parallel import (partition_graphs, shard_batch, graph_mean_pool, all_gather_graph_rows, BatchShard,
-                                   sharded_step)
+                                   sharded_step, PipelinedSteps)
 from tests.util import t, tparams
 
 
@@ -92,6 +92,61 @@ def test_two_rank_gloo_matches_single_process():
         assert pr.exitcode == 0
     assert got.shape == want.shape
     assert np.abs(got - want).max() < 1e-5
+
+
+def _pipeline_worker(rank, world, port, q):
+    """Three batches through PipelinedSteps (the all-gather of batch i in flight while batch i + 1 is computed): every
+    batch's gathered rows must equal the blocking sharded_step's on the same batch."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_torch as R
+        torch.set_num_threads(1)
+        gb, p, x, ea, ins, H = _case()
+        fwd = lambda s: R.gat_seq(s.x, s.edge_index, s.edge_attr, s.instr, s.batch, tparams(p), heads=H)
+        shards = [BatchShard(gb.edge_index, gb.batch, gb.num_graphs, x * (1.0 + 0.5 * i), ea, ins, rank, world, torch.device("cpu"))
+                  for i in range(3)]
+        want = [sharded_step(s, fwd) for s in shards]
+        pipe, got = PipelinedSteps(), []
+        for s in shards:
+            prev = pipe.step(s, fwd)
+            if prev is not None:
+                got.append(prev)
+        assert len(got) == 2
+        got.append(pipe.drain())
+        assert pipe.drain() is None
+        err = max(float((g - w).abs().max()) for g, w in zip(got, want))
+        shapes = [tuple(g.shape) for g in got]
+        if rank == 0:
+            q.put((err, shapes, gb.num_graphs))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_steps_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    err, shapes, B = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert err == 0.0 and all(sh[0] == B for sh in shapes), (err, shapes)
+
+
+def test_pipelined_steps_without_a_process_group():
+    pipe = PipelinedSteps()
+    gb, p, x, ea, ins, H = _case()
+    shard = BatchShard(gb.edge_index, gb.batch, gb.num_graphs, x, ea, ins, 0, 1, torch.device("cpu"))
+    fwd = lambda s: s.x
+    assert pipe.step(shard, fwd) is None
+    second = pipe.step(shard, fwd)
+    want = graph_mean_pool(shard.x, shard.batch, shard.num_graphs)
+    assert torch.equal(second, want) and torch.equal(pipe.drain(), want) and pipe.drain() is None
 
 
 def _grad_worker(rank, world, port, q):
