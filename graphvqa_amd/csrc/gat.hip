@@ -1028,8 +1028,13 @@ static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // ---- weight cache: everything a forward derives from the PARAMETERS alone (folded attention vectors Vn / Ve, per-graph
 // term weights Gw, split3-packed projection weights of every hop) can be prepared once and reused while the weights do
 // not change.  layout: see weight_layout_id.
+// The per-graph instruction terms [K] x ([B, Di] x [Di, C + H]) as ONE batched two-piece product (weights packed in the cache,
+// the instruction vectors packed per call): dims it takes (the f32-input MFMA kernel serves the rest)
+static bool graph_term_split_dims(const gvqa_gat_dims* d) {
+    return d->ins_dim > 0 && d->ins_dim % 4 == 0 && (d->out_channels + d->heads) % 4 == 0;
+}
 struct WeightCacheLayout {
-    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, bc, total;   // bc: bound constants of the chained hops   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
+    size_t Vn, Ve, Gw, w6, w6_hop, vn2h, vn2h_hop, epc, epc_hop, bc, gw2h, gw2h_hop, total;   // gw2h: two-piece images of every hop's Gw (the per-graph instruction terms as a batched split product)   // bc: bound constants of the chained hops   // epc: per-channel epilogue constants of every hop (hop2.hip)     // vn2h: two-piece images of every hop's Vn (fused hop on split2h: the
 };                                                             // pack pass computes the attention logits on the matrix cores)
 static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout) {
     WeightCacheLayout W;
@@ -1049,12 +1054,14 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.epc = take(K * W.epc_hop);
     const bool chainw = layout >= 0 && (layout & 4) && d->node_dim == d->out_channels;
     W.bc = take(chainw ? K * 4 * sizeof(float) : 0);
+    W.gw2h_hop = (layout_pieces(layout) == 2 && graph_term_split_dims(d)) ? align_up(split_packed_bytes(2, (int64_t)(C + H), d->ins_dim), 256) : 0;
+    W.gw2h = take(K * W.gw2h_hop);
     W.total = off;
     return W;
 }
 
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, total;   // a6b ..: chained hops
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, ipk, ipk_hop, total;   // a6b ..: chained hops
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
@@ -1090,6 +1097,10 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.PM = take(2 * ncb * (size_t)B);
     L.Tmax = take(chain ? K * (size_t)B : 0);
     L.gscale = take(chain ? (size_t)B : 0);
+    // packed instruction vectors of the K hops (two-piece graph-term product): one image of K B rows, a hop = B / 32 whole
+    // row tiles of it (other B: the f32-input kernel; K separate images measured slower than it at config 2, 55 vs 30 us)
+    L.ipk_hop = (np == 2 && graph_term_split_dims(d) && B > 0 && B % 32 == 0) ? (size_t)(B / 32) * (size_t)cdiv((int64_t)d->ins_dim, 16) * 2048 : 0;
+    L.ipk = take(L.ipk_hop ? split_packed_bytes(2, (int64_t)K * (int64_t)B, d->ins_dim) / sizeof(float) + 1 : 0);
     L.total = off;
     return L;
 }
@@ -1293,6 +1304,14 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
             if (rc) return rc;
         }
     }
+    if (W.gw2h_hop) {      // two-piece images of the per-graph term weights (after the fold, on its stream)
+        StageTimer t(GVQA_STAGE_PACK, fold_stream);
+        for (int i = 0; i < K; ++i) {
+            rc = launch_split_pack(2, (int64_t)(C + H), Di, reinterpret_cast<const float*>(cache + W.Gw) + (int64_t)i * (C + H) * Di, Di,
+                                   cache + W.gw2h + (size_t)i * W.gw2h_hop, fold_stream);
+            if (rc) return rc;
+        }
+    }
     if (W.vn2h_hop) {      // two-piece images of the folded attention vectors (after the fold, on its stream)
         StageTimer t(GVQA_STAGE_PACK, fold_stream);
         for (int i = 0; i < K; ++i) {
@@ -1366,8 +1385,29 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     }
     if (Di > 0) {   // per-graph instruction terms of all hops: [K] x ([B, Di] x [Di, C+H])
         StageTimer t(GVQA_STAGE_GRAPH_TERM, aux);
-        rc = launch_linear(B, C + H, Di, instr, Di, Gw_all, Di, nullptr, 0, P(L.T), Tld, K, (int64_t)B * Di,
-                           (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
+        const bool term_split = np == 2 && WL.gw2h_hop && L.ipk_hop && B <= 65535 * 128 &&
+                                2.0 * (double)K * (double)B * (double)(C + H) * (double)Di >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
+        if (term_split) {
+            // ONE batched two-piece product on the fp16 matrix cores (config 3: the stage 85 -> 58 us): instruction rows packed
+            // now (row scales), weights from the cache
+            char* ipk = base + L.ipk;
+            const int KBi = (int)cdiv(Di, 16);
+            LinearEpilogue ep{};
+            rc = launch_split_pack(2, (int64_t)K * B, Di, instr, Di, ipk, aux);
+            if (rc) return rc;
+            const float* a_inv = reinterpret_cast<const float*>(ipk + (size_t)(K * B / 32) * KBi * 2048);
+            ep.zs_ia = B;
+            ep.zs_a = (int64_t)(L.ipk_hop / sizeof(uint16_t));
+            ep.zs_b = (int64_t)(WL.gw2h_hop / sizeof(uint16_t));
+            ep.zs_ib = (int64_t)(WL.gw2h_hop / sizeof(float));
+            ep.zs_c = (int64_t)B * Tld;
+            const char* gw2h = wbase + WL.gw2h;
+            const float* b_inv = reinterpret_cast<const float*>(gw2h + (size_t)cdiv((int64_t)(C + H), 32) * KBi * 2048);
+            rc = launch_linear_split(2, B, C + H, Di, ipk, gw2h, ep, P(L.T), Tld, aux, K, a_inv, b_inv);
+        } else {
+            rc = launch_linear(B, C + H, Di, instr, Di, Gw_all, Di, nullptr, 0, P(L.T), Tld, K, (int64_t)B * Di,
+                               (int64_t)(C + H) * Di, (int64_t)B * Tld, aux);
+        }
         if (rc) return rc;
     }
     if (chain && Di > 0) {   // largest instruction-term magnitude per (hop, graph): part of the chained hops' output bounds

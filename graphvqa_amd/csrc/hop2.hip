@@ -148,7 +148,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_hop2(Hop2Args a) {
     // LDS region [64, 80) KiB, in words: rowptr | csr_src | alpha | epilogue constants bias, scale, shift of the column block
     // (CHAIN) | inverse scales of the group's input rows | scales of its graphs' output rows | per-graph output maxima
     const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63), cst_off = al_off + ((fh.e_cap * H + 63) & ~63);
-    const int rinv_off = cst_off + 3 * CPAD, gscl_off = rinv_off + 128, gmax_off = gscl_off + 128;
+    // (the per-graph maxima are cleared BEFORE the main loop and flushed at the top of the NEXT item, while the operand ring --
+    //  three 24 KiB stages: 8 KiB more than the 64 KiB below the region -- is live: they must sit past the ring's last byte.
+    //  Small row groups (few edges: short sub-arrays) would otherwise place them inside it.)
+    constexpr int RING_SPILL = REGION_EARLY ? 0 : (NBUF * STAGE - 64 * 1024) / 4;
+    const int rinv_off = cst_off + 3 * CPAD, gscl_off = rinv_off + 128, gmax_off = max(gscl_off + 128, RING_SPILL);
     const Hop2Chain& ch = a.ch;
     const bool chain_out = CHAIN && ch.Pnext != nullptr;
     float* xs = reinterpret_cast<float*>(smem);

@@ -433,6 +433,68 @@ def test_fused_hop_kernel_on_ragged_batches(dev, scheme, H, C, de, di, lo, hi):
     assert maxabs(out_t, ref_t) < TOL
 
 
+@pytest.mark.parametrize("H,C,K,seed,graphs,lo,hi,rel", [(2, 64, 3, 2, 1, 20, 20, 1.3), (4, 256, 3, 1, 3, 5, 30, 1.3), (2, 128, 4, 2, 1, 20, 20, 1.3),
+                                                         (4, 260, 3, 1, 3, 5, 30, 1.3), (1, 132, 5, 3, 23, 2, 24, 1.3), (2, 300, 3, 5, 2, 100, 128, 1.3),
+                                                         (4, 300, 5, 7, 200, 20, 40, 1.0), (8, 64, 4, 4, 5, 3, 30, 0.5), (4, 512, 5, 9, 40, 1, 12, 0.3)])
+def test_chained_hops_on_small_and_sparse_row_groups(dev, H, C, K, seed, graphs, lo, hi, rel):
+    """Chained persistent hops (GVQA_OPT_HOP_FUSION = 2, three or more hops: at least one hop reads AND leaves packed rows) on
+    row groups with FEW edges -- one to three small graphs, config-2-like sparse graphs (E/N = 2).  The kernel's LDS sub-arrays
+    are then short and its per-graph maxima (cleared before the main loop, flushed at the top of the next item) used to land
+    inside the operand ring's third stage: garbage maxima -> a garbage output scale -> rows flushed to zero two hops later
+    (found in round 3; batches with >= 282 edges per row group at H = 4 -- config 3 -- were never affected)."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    de, di = 16, 8
+    gb = synth.make_graph_batch(graphs, seed=seed, nodes_lo=lo, nodes_hi=hi, rel_per_node=rel)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=500 + H)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 2)
+    try:
+        _lib.prof_enable(True); _lib.prof_collect()
+        out, alpha, _ = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch, return_attention_weights=True)
+        out2 = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch)
+        prof = _lib.prof_collect()
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+        _lib.prof_enable(False)
+    assert prof["mp"][1] == 0 and prof["alpha"][1] == 2 * K          # the fused kernels ran, both calls
+    assert maxabs(out, ref) < TOL and maxabs(alpha, torch.stack(alphas)) < 2e-5
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+@pytest.mark.parametrize("H,C,di", [(4, 64, 48), (2, 300, 512), (4, 36, 20)])
+def test_instruction_terms_as_one_batched_two_piece_product(dev, fusion, H, C, di):
+    """The per-graph instruction terms of all hops ([K] x ([B, Di] x [Di, C + H]), gat_skip.py:133,263-264 folded per graph):
+    with B a whole number of 32-row tiles they are ONE batched split product (weights packed in the cache, instruction rows
+    packed per call) -- forced here with the size threshold at 0, under every hop kernel, and held to the oracle; the result
+    must also agree with the f32-input product the other batch sizes take (same batch, threshold back up)."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    K, de = 3, 16
+    gb = synth.make_graph_batch(64, seed=3100 + C, nodes_lo=2, nodes_hi=24, rel_per_node=1.3)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=500 + H)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), 3.0 * synth.normal((K, B, di), 3)
+    ref, _, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, fusion)
+    try:
+        plain, alpha_p, _ = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch, return_attention_weights=True)
+        old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+        try:
+            out, alpha, _ = _run_gat_seq(dev, (C, de, di, K, H), p, x, gb.edge_index, ea, ins, gb.batch, return_attention_weights=True)
+        finally:
+            _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    finally:
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+    assert maxabs(out, ref) < TOL and maxabs(alpha, torch.stack(alphas)) < 2e-5
+    assert maxabs(plain, ref) < TOL and maxabs(out, plain) < 5e-5 and maxabs(alpha, alpha_p) < 2e-5
+
+
 @pytest.mark.parametrize("H,C,de,di,lo,hi", [(4, 64, 24, 16, 1, 40), (4, 300, 20, 12, 20, 40), (1, 32, 8, 8, 1, 128), (2, 136, 16, 0, 60, 128),
                                              (8, 48, 12, 20, 5, 70), (4, 640, 16, 8, 20, 60), (2, 1040, 8, 0, 30, 90)])
 def test_persistent_hop_kernel_chained_on_ragged_batches(dev, H, C, de, di, lo, hi):
