@@ -1,0 +1,71 @@
+"""Randomised parity sweep of gat_seq's eval forward against the oracle (gat_skip.py:249-279 restated, oracle/ref_torch.py):
+random head counts, widths, hop counts, batch shapes (single-node graphs to 128-node graphs, sparse to dense, 1 to 300 graphs),
+every hop kernel (GVQA_OPT_HOP_FUSION 0 / 1 / 2 / 3), library products forced (size threshold 0) or left to the default rule,
+with and without the attention-weight / per-hop outputs.  Prints one line per failing case and a summary line.
+Used by tests/test_gpu_gat.py (a fixed-seed sample) and scripts/fuzz_gat_seq.py (SEED=<int> CASES=<n>, any number of cases)."""
+import numpy as np
+import torch
+from graphvqa_amd import synth, _lib
+from graphvqa_amd.gat_skip import gat_seq
+from oracle import ref_torch as R
+
+t = lambda a, device=None: torch.from_numpy(np.ascontiguousarray(a)).to(device) if device is not None else torch.from_numpy(np.ascontiguousarray(a))
+
+
+def case(rng):
+    H = int(rng.choice([1, 2, 4, 4, 4, 8]))
+    C = int(rng.choice([4, 12, 32, 36, 64, 68, 100, 128, 132, 256, 260, 300, 304, 512, 516]))
+    if H == 8 and C > 256:
+        C = 64
+    K = int(rng.integers(1, 6))
+    de = int(rng.choice([4, 16, 20, 300])) if C >= 256 else int(rng.choice([4, 16, 20]))
+    di = int(rng.choice([0, 8, 12, 512])) if C >= 256 else int(rng.choice([0, 8, 12]))
+    shape = rng.choice(["tiny", "ragged", "big", "single", "sparse", "dense", "many"])
+    graphs, lo, hi, rel = {"tiny": (int(rng.integers(1, 4)), 1, 30, 1.3), "ragged": (int(rng.integers(5, 40)), 1, 60, float(rng.uniform(0.5, 2.5))),
+                           "big": (int(rng.integers(1, 6)), 90, 128, float(rng.uniform(0.5, 2.0))), "single": (int(rng.integers(1, 20)), 1, 2, 1.0),
+                           "sparse": (int(rng.integers(10, 200)), 5, 40, float(rng.uniform(0.0, 0.5))),
+                           "dense": (int(rng.integers(3, 30)), 10, 40, float(rng.uniform(3.0, 6.0))),
+                           "many": (int(rng.choice([64, 96, 128, 300])), 2, 24, 1.2)}[str(shape)]
+    return dict(H=H, C=C, K=K, de=de, di=di, graphs=graphs, lo=lo, hi=hi, rel=rel, shape=str(shape), fusion=int(rng.choice([0, 1, 2, 2, 3])),
+                force=bool(rng.integers(0, 2)), alpha=bool(rng.integers(0, 2)), hops=bool(rng.integers(0, 4) == 0), seed=int(rng.integers(1, 1 << 30)),
+                ins_scale=float(rng.choice([0.0, 1.0, 4.0])))
+
+
+def run(c, dev):
+    gb = synth.make_graph_batch(c["graphs"], seed=c["seed"], nodes_lo=c["lo"], nodes_hi=c["hi"], rel_per_node=c["rel"])
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    H, C, K, de, di = c["H"], c["C"], c["K"], c["de"], c["di"]
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=c["seed"] % 1000 + 1)
+    x, ea = synth.normal((N, C), 1 + c["seed"] % 7), synth.normal((E, de), 2)
+    ins = (c["ins_scale"] * synth.normal((K, B, max(di, 1)), 3))[:, :, :di].astype(np.float32)
+    tp = {k: t(v) for k, v in p.items()}
+    ref, hs, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tp, heads=H, return_all=True)
+    m = gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H)
+    m.load_state_dict({k: t(v) for k, v in p.items()})
+    m = m.to(dev).eval()
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, c["fusion"])
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0) if c["force"] else None
+    try:
+        kw = {}
+        if c["alpha"]: kw["return_attention_weights"] = True
+        if c["hops"]: kw["return_hops"] = True
+        with torch.no_grad():               # the fused inference path (gradients route gat_seq to the differentiable one)
+            res = m(t(x, dev), t(gb.edge_index, dev), t(ea, dev), t(ins, dev), t(gb.batch, dev), **kw)
+            res2 = m(t(x, dev), t(gb.edge_index, dev), t(ea, dev), t(ins, dev), t(gb.batch, dev))      # cached weights, plain outputs
+    finally:
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+        if old is not None:
+            _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    out = res[0] if isinstance(res, tuple) else res
+    errs = {"out": float((out.cpu() - ref).abs().max()), "out2": float((res2.cpu() - ref).abs().max())}
+    if isinstance(res, tuple):
+        if c["alpha"] and res[1] is not None and E > 0:
+            errs["alpha"] = float((res[1].cpu() - torch.stack(alphas)).abs().max())
+        if c["hops"] and res[-1] is not None:
+            errs["hops"] = float((res[-1].cpu() - torch.stack(hs)).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    ok = all(np.isfinite(v) for v in errs.values()) and errs["out"] < 1e-4 * scale and errs["out2"] < 1e-4 * scale and \
+        errs.get("alpha", 0.0) < 5e-5 and errs.get("hops", 0.0) < 1e-4 * scale
+    return ok, errs, (N, E, B)
+
+

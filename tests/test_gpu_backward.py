@@ -69,11 +69,11 @@ def test_message_passing_backward_vs_autograd(dev, C, H, with_mask):
         assert _rel(got.grad, ref.grad) < 2e-5, name
 
 
-def _grads_vs_oracle(dev, train, alpha_masks=None, feature_masks=None, dims=(32, 32, 48, 3, 4), seed=5, graphs=5):
+def _grads_vs_oracle(dev, train, alpha_masks=None, feature_masks=None, dims=(32, 32, 48, 3, 4), seed=5, graphs=5, nodes=(6, 20), rel=1.5):
     from oracle import ref_torch as R
     from graphvqa_amd.gat_skip import gat_seq
     dn, de, di, K, H = dims
-    gb = synth.make_graph_batch(graphs, seed=0xA11CE + seed, nodes_lo=6, nodes_hi=20, rel_per_node=1.5)
+    gb = synth.make_graph_batch(graphs, seed=0xA11CE + seed, nodes_lo=nodes[0], nodes_hi=nodes[1], rel_per_node=rel)
     N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
     p = synth.gat_seq_params(dn, dn, de, di, K, H, seed=seed)
     rng = np.random.default_rng(seed)
@@ -108,9 +108,10 @@ def _grads_vs_oracle(dev, train, alpha_masks=None, feature_masks=None, dims=(32,
     (ref * t(w).double()).sum().backward()
     assert maxabs(out, ref) < 1e-4
     worst = {}
-    floor = 1e-2 * max(float(r.grad.abs().max()) for r in list(rs) + [v for v in rp.values() if v.grad is not None])
+    floor = 1e-2 * max(float(r.grad.abs().max()) for r in list(rs) + [v for v in rp.values() if v.grad is not None] if r.grad.numel())
     for got, r, name in zip(xs, rs, ("x", "edge_attr", "instr_vectors")):
-        worst[name] = _rel(got.grad, r.grad, floor)
+        if r.numel():                                   # (ins_dim = 0: no instruction vectors)
+            worst[name] = _rel(got.grad, r.grad, floor)
     sd = dict(m.named_parameters())
     for k, r in rp.items():
         if not r.requires_grad or k.endswith("lin_r.weight"):

@@ -466,6 +466,21 @@ def test_chained_hops_on_small_and_sparse_row_groups(dev, H, C, K, seed, graphs,
     assert torch.equal(out, out2)
 
 
+def test_randomised_parity_sweep(dev):
+    """A fixed-seed sample of tests/fuzz.py: random head counts, widths, hop counts, batch shapes (single-node graphs to 128-node
+    graphs, sparse to dense, 1 to 300 graphs), every hop kernel, library products forced or not, with and without the attention /
+    per-hop outputs -- each against the oracle (scripts/fuzz_gat_seq.py runs any number of further cases)."""
+    from tests.fuzz import case, run
+    rng = np.random.default_rng(20260929)
+    bad = []
+    for _ in range(90):
+        c = case(rng)
+        ok, errs, sz = run(c, dev)
+        if not ok:
+            bad.append((c, errs, sz))
+    assert not bad, bad[:3]
+
+
 @pytest.mark.parametrize("fusion", [0, 1, 2])
 @pytest.mark.parametrize("H,C,di", [(4, 64, 48), (2, 300, 512), (4, 36, 20)])
 def test_instruction_terms_as_one_batched_two_piece_product(dev, fusion, H, C, di):
