@@ -466,6 +466,36 @@ def test_chained_hops_on_small_and_sparse_row_groups(dev, H, C, K, seed, graphs,
     assert torch.equal(out, out2)
 
 
+def test_default_rule_takes_the_chained_kernel_on_a_large_sparse_batch(dev):
+    """The regime the round-3 defect lived in, under DEFAULT options: 3400 config-2-like graphs (20-40 nodes, E/N = 2: about
+    250 edges per row group) at d = 256 / H = 4 / K = 4 give six or more items per workgroup slot, so GVQA_OPT_HOP_FUSION = 3
+    picks the persistent chained kernel by itself (one pack pass, no message-passing launches); every row against the oracle."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    H, C, de, di, K = 4, 256, 16, 32, 4
+    gb = synth.make_graph_batch(3400, seed=0x5EED0002, nodes_lo=20, nodes_hi=40, rel_per_node=1.0)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=61)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    assert _lib.load().gvqa_get_option(_lib.OPT_HOP_FUSION) == 3
+    from graphvqa_amd.gat_skip import gat_seq
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)
+    args = [t(a, device=dev) for a in (x, gb.edge_index, ea, ins, gb.batch)]
+    first = m(*args)                                   # prepares the weight cache
+    _lib.prof_enable(True); _lib.prof_collect()
+    try:
+        out = m(*args)
+        prof = _lib.prof_collect()
+    finally:
+        _lib.prof_enable(False)
+    # chained: ONE pack pass (hop 0), a coefficient and a hop launch per hop, no message-passing launches
+    assert prof["mp"][1] == 0 and prof["alpha"][1] == K and prof["proj"][1] == K and prof["pack"][1] == 1, prof
+    assert torch.equal(first, out)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H)
+    assert maxabs(out, ref) < TOL
+
+
 def test_randomised_parity_sweep(dev):
     """A fixed-seed sample of tests/fuzz.py: random head counts, widths, hop counts, batch shapes (single-node graphs to 128-node
     graphs, sparse to dense, 1 to 300 graphs), every hop kernel, library products forced or not, with and without the attention /
