@@ -144,6 +144,8 @@ PROTOTYPES = {
     "gvqa_graph_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.POINTER(Graph)]),
     "gvqa_graph_finalize": (C.c_int, [C.POINTER(Graph), C.c_void_p]),
+    "gvqa_graph_build_grouped": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Graph)]),
     "gvqa_graph_check_valid": (C.c_int, [C.POINTER(Graph), C.c_void_p]),
     "gvqa_graph_finalize_host": (C.c_int, [C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gvqa_gat_conv_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.POINTER(GatDims)]),

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_stats(int64_t N, int64_t B, const int32
 }
 
 struct GraphLayout {
-    size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, deg, rank, slot_eid, tile_sum, graph_eptr, row_group, row_order, total;
+    size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, row_group, row_group_e, deg, rank, slot_eid, tile_sum, graph_eptr, row_order, total;
 };
 
 constexpr int ROW_GROUP = 128;      // rows of one group of the fused hop kernel (half a 256-row block tile)
@@ -211,6 +211,83 @@ __global__ __launch_bounds__(ROW_GROUP) void k_row_group_order(const int32_t* __
     order[ns + rank] = i;
 }
 
+
+// ---- grouped build: the whole CSR build of a loader-side layout in ONE launch --------------------------------------------
+// When the loader vouches that the COO edges are grouped by graph (graph g's edges are COO positions [edge_ptr[g],
+// edge_ptr[g + 1]) -- what Batch.from_data_list yields, gqa_dataset_entry.py:654), a row group's in-edges are a contiguous COO
+// range, and one workgroup per row group does histogram, scan, placement, the in-row ordering by edge id and the row order out
+// of LDS: one upload + one launch instead of a memset, seven kernels and an upload (28 -> 8 us of a step's stage time).
+constexpr int GROUPED_EDGE_CAP = 8192;       // COO edges of one row group held in LDS (40 KiB)
+__global__ __launch_bounds__(256) void k_build_grouped(int64_t N, int64_t E, int64_t B, const int64_t* __restrict__ edge_index,
+                                                       const int64_t* __restrict__ batch, const int32_t* __restrict__ group_ptr,
+                                                       const int32_t* __restrict__ group_eptr, const int32_t* __restrict__ graph_ptr,
+                                                       int32_t* __restrict__ rowptr, int32_t* __restrict__ csr_src,
+                                                       int32_t* __restrict__ csr_eid, int32_t* __restrict__ node_graph,
+                                                       int32_t* __restrict__ order, int32_t* __restrict__ stats) {
+    __shared__ int deg_s[ROW_GROUP], start_s[ROW_GROUP], cursor_s[ROW_GROUP], scan_s[8];
+    __shared__ int eid_s[GROUPED_EDGE_CAP];
+    __shared__ unsigned char row_s[GROUPED_EDGE_CAP];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const int ns = group_ptr[r], cnt = group_ptr[r + 1] - ns;
+    const int e0 = group_eptr[r], ne = group_eptr[r + 1] - e0;
+    if (tid < ROW_GROUP) deg_s[tid] = 0;
+    __syncthreads();
+    // an edge of this COO range must join two nodes of this group (the loader's promise); anything else is flagged and skipped
+    auto edge_ok = [&](int64_t s, int64_t d) { return s >= ns && s < ns + cnt && d >= ns && d < ns + cnt; };
+    for (int k = tid; k < ne; k += 256) {
+        const int64_t s = edge_index[e0 + k], d = edge_index[E + e0 + k];
+        if (edge_ok(s, d)) {
+            atomicAdd(&deg_s[(int)d - ns], 1);
+        } else {
+            if (s >= 0 && s < N && d >= 0 && d < N && batch && batch[s] != batch[d]) stats[ST_NOT_INTRA] = 1;
+            stats[ST_INVALID] = 1;
+        }
+    }
+    __syncthreads();
+    int total = 0;
+    const int mydeg = tid < cnt ? deg_s[tid] : 0;
+    const int ex = block_exclusive_scan(mydeg, &total, scan_s);
+    if (tid < cnt) {
+        start_s[tid] = ex;
+        cursor_s[tid] = ex;
+        rowptr[ns + tid] = e0 + ex;
+        // node -> graph, checked against the uploaded layout
+        const int64_t g = batch ? batch[ns + tid] : 0;
+        if (g < 0 || g >= B || graph_ptr[g] > ns + tid || graph_ptr[g + 1] <= ns + tid) stats[ST_INVALID] = 1;
+        else node_graph[ns + tid] = (int32_t)g;
+    }
+    if (tid == 0 && r == (int)gridDim.x - 1) rowptr[N] = (int32_t)E;
+    if (total != ne && tid == 0) stats[ST_INVALID] = 1;
+    __syncthreads();
+    for (int k = tid; k < ne; k += 256) {
+        const int64_t s = edge_index[e0 + k], d = edge_index[E + e0 + k];
+        if (edge_ok(s, d)) {
+            const int slot = atomicAdd(&cursor_s[(int)d - ns], 1);
+            eid_s[slot] = e0 + k;
+            row_s[slot] = (unsigned char)((int)d - ns);
+        }
+    }
+    __syncthreads();
+    // in-row order by original edge id (rows are short: the O(deg^2) count needs no sort), then the CSR arrays
+    for (int slot = tid; slot < total; slot += 256) {
+        const int e = eid_s[slot], row = row_s[slot];
+        const int lo = start_s[row], hi = lo + deg_s[row];
+        int pos = lo;
+        for (int t = lo; t < hi; ++t) pos += eid_s[t] < e ? 1 : 0;
+        csr_eid[e0 + pos] = e;
+        csr_src[e0 + pos] = (int32_t)edge_index[e];
+    }
+    // rows of the group by in-degree, largest first (ties in row order): what k_row_group_order computes
+    if (tid < cnt) {
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const int dj = deg_s[j];
+            rank += (dj > mydeg || (dj == mydeg && j < tid)) ? 1 : 0;
+        }
+        order[ns + rank] = tid;
+    }
+}
+
 static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     GraphLayout L;
     size_t off = 0;
@@ -225,12 +302,13 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     L.node_graph = take(N);
     L.graph_ptr = take(B + 1);
     L.stats = take(8);
+    L.row_group = take(B + 2);            // at most one group per non-empty graph, + the end marker
+    L.row_group_e = take(B + 2);          // (grouped build: first COO edge of every row group)
     L.deg = take(N + 1);
     L.rank = take(E);
     L.slot_eid = take(E);
     L.tile_sum = take(cdiv(N + 1, SCAN_TILE) + 1);
     L.graph_eptr = take(B + 1);
-    L.row_group = take(B + 2);            // at most one group per non-empty graph, + the end marker
     L.row_order = take(N);
     L.total = off;
     return L;
@@ -432,6 +510,88 @@ int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const
     g->max_row_group_edges = 0;
     if (N > 0 && B > 0 && mn <= ROW_GROUP && B < (1ll << 24))
         return plan_row_groups(g, graph_ptr_host, graph_edge_ptr_host, static_cast<hipStream_t>(stream_));
+    return GVQA_OK;
+}
+
+int gvqa_graph_build_grouped(int64_t N, int64_t E, int64_t B, const int64_t* edge_index, const int64_t* batch,
+                             const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host, int32_t max_in_degree,
+                             void* ws, size_t ws_bytes, void* stream_, gvqa_graph* out) {
+    using namespace gvqa;
+    GVQA_REQUIRE(out && graph_ptr_host && graph_edge_ptr_host, GVQA_E_INVALID, "gvqa_graph_build_grouped: null argument");
+    GVQA_REQUIRE(N >= 0 && E >= 0 && B >= 0 && N < (1ll << 31) - 1 && E < (1ll << 31) - 1, GVQA_E_INVALID, "gvqa_graph_build_grouped: bad size");
+    if (N == 0 || E == 0 || B == 0 || B >= (1ll << 24) || !edge_index || (!batch && B != 1)) return GVQA_E_UNSUPPORTED;   // (quietly: the caller takes the general pair)
+    GraphLayout L = graph_layout(N, E, B);
+    GVQA_REQUIRE(ws && ws_bytes >= L.total, GVQA_E_WORKSPACE, "gvqa_graph_build_grouped: workspace %zu < required %zu", ws_bytes, L.total);
+    GVQA_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, GVQA_E_INVALID, "gvqa_graph_build_grouped: workspace must be 256-byte aligned");
+    const int32_t *hp = graph_ptr_host, *he = graph_edge_ptr_host;
+    GVQA_REQUIRE(hp[0] == 0 && hp[B] == N && he[0] == 0 && he[B] == E, GVQA_E_GRAPH,
+                 "gvqa_graph_build_grouped: layout does not span the batch (%d..%d nodes, %d..%d edges)", hp[0], hp[B], he[0], he[B]);
+    int32_t mn = 0, me = 0;
+    for (int64_t q = 0; q < B; ++q) {
+        const int32_t n = hp[q + 1] - hp[q], e = he[q + 1] - he[q];
+        GVQA_REQUIRE(n >= 0 && e >= 0, GVQA_E_GRAPH, "gvqa_graph_build_grouped: layout not monotone at graph %lld", (long long)q);
+        mn = std::max(mn, n);
+        me = std::max(me, e);
+    }
+    if (mn > ROW_GROUP) return GVQA_E_UNSUPPORTED;
+    // staging image of the contiguous device range [graph_ptr | stats | row_group | row_group_e] (pinned ring, as plan_row_groups)
+    const size_t span = L.row_group_e + align_up((size_t)(B + 2) * sizeof(int32_t), 256) - L.graph_ptr;
+    struct Slot { char* v = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; int device = -1; };
+    static thread_local Slot ring[4];
+    static thread_local int next = 0;
+    Slot& sl = ring[next];
+    int dev = -1;
+    GVQA_HIP_CHECK(hipGetDevice(&dev));
+    if (sl.used) GVQA_HIP_CHECK(hipEventSynchronize(sl.done));
+    if (sl.done && sl.device != dev) { GVQA_HIP_CHECK(hipEventDestroy(sl.done)); sl.done = nullptr; }
+    if (!sl.done) { GVQA_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)); sl.device = dev; }
+    if (sl.cap < span) {
+        if (sl.v) GVQA_HIP_CHECK(hipHostFree(sl.v));
+        sl.v = nullptr; sl.cap = 0;
+        const size_t want = std::max<size_t>(span, 16384) * 2;
+        GVQA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.v), want, hipHostMallocDefault));
+        sl.cap = want;
+    }
+    memset(sl.v, 0, span);
+    int32_t* s_gp = reinterpret_cast<int32_t*>(sl.v);
+    int32_t* s_grp = reinterpret_cast<int32_t*>(sl.v + (L.row_group - L.graph_ptr));
+    int32_t* s_gre = reinterpret_cast<int32_t*>(sl.v + (L.row_group_e - L.graph_ptr));
+    memcpy(s_gp, hp, (size_t)(B + 1) * sizeof(int32_t));
+    int G = 0;
+    int32_t start = 0, e_start = 0, max_e = 0;
+    s_grp[0] = 0; s_gre[0] = 0;
+    for (int64_t q = 0; q < B; ++q) {
+        if (hp[q + 1] - start > ROW_GROUP) {          // graph q does not fit any more: close the group before it
+            max_e = std::max(max_e, he[q] - e_start);
+            ++G;
+            s_grp[G] = hp[q]; s_gre[G] = he[q];
+            start = hp[q]; e_start = he[q];
+        }
+    }
+    max_e = std::max(max_e, he[B] - e_start);
+    ++G;
+    s_grp[G] = (int32_t)N; s_gre[G] = (int32_t)E;
+    if (max_e > GROUPED_EDGE_CAP) return GVQA_E_UNSUPPORTED;      // (nothing enqueued yet; the slot is not consumed)
+    next = (next + 1) & 3;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageTimer timer(GVQA_STAGE_GRAPH, stream);
+    char* base = static_cast<char*>(ws);
+    auto P = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
+    GVQA_HIP_CHECK(hipMemcpyAsync(base + L.graph_ptr, sl.v, span, hipMemcpyHostToDevice, stream));
+    GVQA_HIP_CHECK(hipEventRecord(sl.done, stream));
+    sl.used = true;
+    hipLaunchKernelGGL(k_build_grouped, dim3((unsigned)G), dim3(256), 0, stream, N, E, B, edge_index, batch, P(L.row_group), P(L.row_group_e),
+                       P(L.graph_ptr), P(L.rowptr), P(L.csr_src), P(L.csr_eid), P(L.node_graph), P(L.row_order), P(L.stats));
+    GVQA_LAUNCH_CHECK();
+    memset(out, 0, sizeof(*out));
+    out->num_nodes = N; out->num_edges = E; out->num_graphs = B;
+    out->rowptr = P(L.rowptr); out->csr_src = P(L.csr_src); out->csr_eid = P(L.csr_eid);
+    out->node_graph = P(L.node_graph); out->graph_ptr = P(L.graph_ptr); out->stats_dev = P(L.stats);
+    out->max_graph_nodes = mn; out->max_graph_edges = me;
+    out->max_in_degree = max_in_degree > 0 ? max_in_degree : me;
+    out->intra_graph = 1; out->valid = 1; out->finalized = 1;
+    out->row_group_ptr = P(L.row_group); out->num_row_groups = G; out->max_row_group_edges = max_e;
+    out->row_group_order = P(L.row_order);
     return GVQA_OK;
 }
 

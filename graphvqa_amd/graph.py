@@ -27,11 +27,14 @@ class HostLayout:
     [B + 1] each.  Passing it to SceneGraphBatch skips the device -> host read-back of the graph statistics (the only
     synchronisation of the path); the caller then vouches for an intra-graph batch with in-range indices."""
 
-    def __init__(self, graph_ptr, edge_ptr, max_in_degree: int = 0):
+    def __init__(self, graph_ptr, edge_ptr, max_in_degree: int = 0, coo_grouped: bool = False):
         import numpy as np
         self.graph_ptr = np.ascontiguousarray(graph_ptr, dtype=np.int32)
         self.edge_ptr = np.ascontiguousarray(edge_ptr, dtype=np.int32)
         self.max_in_degree = int(max_in_degree)
+        # the loader also vouches that the COO edges are grouped by graph (graph g's edges = COO positions [edge_ptr[g],
+        # edge_ptr[g + 1]): what Batch.from_data_list yields, gqa_dataset_entry.py:654) -> the one-launch CSR build
+        self.coo_grouped = bool(coo_grouped)
 
     @classmethod
     def from_numpy(cls, edge_index, batch, num_graphs: int):
@@ -42,7 +45,9 @@ class HostLayout:
         nodes = np.bincount(batch, minlength=num_graphs)
         edges = np.bincount(batch[edge_index[1]], minlength=num_graphs) if edge_index.shape[1] else np.zeros(num_graphs, np.int64)
         deg = int(np.bincount(edge_index[1]).max()) if edge_index.shape[1] else 0
-        return cls(np.concatenate([[0], np.cumsum(nodes)]), np.concatenate([[0], np.cumsum(edges)]), deg)
+        eg = batch[edge_index[1]]
+        grouped = bool(eg.shape[0] == 0 or np.all(eg[1:] >= eg[:-1]))
+        return cls(np.concatenate([[0], np.cumsum(nodes)]), np.concatenate([[0], np.cumsum(edges)]), deg, coo_grouped=grouped)
 
 
 class SceneGraphBatch:
@@ -71,12 +76,21 @@ class SceneGraphBatch:
         self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
         self._keep = (edge_index, batch)
         self.c = _lib.Graph()
+        if host_layout is not None and host_layout.graph_ptr.shape[0] != B + 1:
+            raise ValueError("host_layout does not match num_graphs")
         with torch.cuda.device(dev):
+            if host_layout is not None and host_layout.coo_grouped:
+                # COO edges grouped by graph: build + plan as one upload and one launch (falls through when out of its reach)
+                rc = lib.gvqa_graph_build_grouped(N, E, B, _ptr(edge_index), _ptr(batch), host_layout.graph_ptr.ctypes.data,
+                                                  host_layout.edge_ptr.ctypes.data, int(host_layout.max_in_degree),
+                                                  self._ws.data_ptr(), self._ws.numel(), _stream(dev), C.byref(self.c))
+                if rc != _lib.E_UNSUPPORTED:
+                    _lib.check(rc)
+                    self._host_layout = host_layout
+                    return
             _lib.check(lib.gvqa_graph_build(N, E, B, _ptr(edge_index), _ptr(batch), self._ws.data_ptr(),
                                             self._ws.numel(), _stream(dev), C.byref(self.c)))
             if host_layout is not None:       # loader-side layout: no device synchronisation
-                if host_layout.graph_ptr.shape[0] != B + 1:
-                    raise ValueError("host_layout does not match num_graphs")
                 self._host_layout = host_layout
                 _lib.check(lib.gvqa_graph_finalize_host(C.byref(self.c), host_layout.graph_ptr.ctypes.data,
                                                         host_layout.edge_ptr.ctypes.data, int(host_layout.max_in_degree),
@@ -98,7 +112,7 @@ class SceneGraphBatch:
             edge_index, batch = self._keep
             hl = getattr(self, "_host_layout", None)        # intra-graph batch: the same per-graph counts by source
             if hl is not None:
-                hl = HostLayout(hl.graph_ptr, hl.edge_ptr, 0)
+                hl = HostLayout(hl.graph_ptr, hl.edge_ptr, 0, coo_grouped=hl.coo_grouped)
             self._transposed = SceneGraphBatch(edge_index.flip(0), batch, self.num_nodes, self.num_graphs, host_layout=hl)
         return self._transposed
 

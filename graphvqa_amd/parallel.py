@@ -66,11 +66,14 @@ class BatchShard:
         self.host_nodes_per_graph = np.bincount(b, minlength=g1 - g0)
         self.host_edges_per_graph = epg[g0:g1]
         self.host_max_in_degree = int(np.bincount(ei[1]).max()) if ei.shape[1] else 0
+        eg = b[ei[1]] if ei.shape[1] else np.zeros(0, np.int64)
+        self.host_coo_grouped = bool(eg.shape[0] == 0 or np.all(eg[1:] >= eg[:-1]))      # COO edges in graph order (one-launch CSR build)
 
     def host_layout(self):
         from .graph import HostLayout
         return HostLayout(np.concatenate([[0], np.cumsum(self.host_nodes_per_graph)]),
-                          np.concatenate([[0], np.cumsum(self.host_edges_per_graph)]), self.host_max_in_degree)
+                          np.concatenate([[0], np.cumsum(self.host_edges_per_graph)]), self.host_max_in_degree,
+                          coo_grouped=self.host_coo_grouped)
 
 
 def sharded_step(shard: BatchShard, forward, pool=None, force: bool = False) -> torch.Tensor:

@@ -107,10 +107,12 @@ class CollatedSceneGraphs:
     def host_layout(self):
         from .graph import HostLayout
         if getattr(self, "_layout", None) is not None:          # the native collate hands the layout over with the batch
-            return HostLayout(*self._layout)
+            return HostLayout(*self._layout, coo_grouped=True)
         deg = int(np.bincount(self.edge_index[1]).max()) if self.num_edges else 0
         # in-edges by DESTINATION graph: every edge stays inside its graph, so they equal the per-graph edge counts
-        return HostLayout(np.concatenate([[0], np.cumsum(self.nodes_per_graph)]), np.concatenate([[0], np.cumsum(self.edges_per_graph)]), deg)
+        # (the collate concatenates the graphs' edge lists in graph order: the COO edges are grouped by graph)
+        return HostLayout(np.concatenate([[0], np.cumsum(self.nodes_per_graph)]), np.concatenate([[0], np.cumsum(self.edges_per_graph)]), deg,
+                          coo_grouped=True)
 
     def to(self, device):
         return DeviceSceneGraphs(self, device)

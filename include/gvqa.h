@@ -112,6 +112,19 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream);
 int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host,
                              int32_t max_in_degree, void* stream);
 
+/* gvqa_graph_build + gvqa_graph_finalize_host as ONE upload and ONE launch, for loader-side layouts whose COO edges are also
+ * grouped by graph: graph g's edges are the COO positions [graph_edge_ptr_host[g], graph_edge_ptr_host[g+1]) -- what the
+ * reference's collate produces (Batch.from_data_list concatenates the graphs' edge lists, gqa_dataset_entry.py:654).  A row
+ * group's in-edges are then one contiguous COO range and a workgroup per row group builds its CSR slice, the in-row order by
+ * edge id and the row order out of LDS.  Same arrays, bit for bit, as the general pair.  Returns GVQA_E_UNSUPPORTED -- with
+ * nothing enqueued and no error string -- when the shape is outside its reach (an empty batch, a graph of more than 128 nodes,
+ * a row group of more than 8192 edges): the caller then uses gvqa_graph_build + gvqa_graph_finalize_host.  An edge outside its
+ * group's node range (a layout that is not grouped after all) is flagged on the device like any contract violation
+ * (gvqa_graph_check_valid). */
+int gvqa_graph_build_grouped(int64_t num_nodes, int64_t num_edges, int64_t num_graphs, const int64_t* edge_index,
+                             const int64_t* batch, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host,
+                             int32_t max_in_degree, void* ws, size_t ws_bytes, void* stream, gvqa_graph* out);
+
 /* ------------------------------------------------------------------------------------------
  * GAT execution path
  * ---------------------------------------------------------------------------------------- */

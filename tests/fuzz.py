@@ -27,7 +27,7 @@ def case(rng):
                            "dense": (int(rng.integers(3, 30)), 10, 40, float(rng.uniform(3.0, 6.0))),
                            "many": (int(rng.choice([64, 96, 128, 300])), 2, 24, 1.2)}[str(shape)]
     return dict(H=H, C=C, K=K, de=de, di=di, graphs=graphs, lo=lo, hi=hi, rel=rel, shape=str(shape), fusion=int(rng.choice([0, 1, 2, 2, 3])),
-                force=bool(rng.integers(0, 2)), alpha=bool(rng.integers(0, 2)), hops=bool(rng.integers(0, 4) == 0), seed=int(rng.integers(1, 1 << 30)),
+                force=bool(rng.integers(0, 2)), layout=bool(rng.integers(0, 2)), alpha=bool(rng.integers(0, 2)), hops=bool(rng.integers(0, 4) == 0), seed=int(rng.integers(1, 1 << 30)),
                 ins_scale=float(rng.choice([0.0, 1.0, 4.0])))
 
 
@@ -49,6 +49,9 @@ def run(c, dev):
         kw = {}
         if c["alpha"]: kw["return_attention_weights"] = True
         if c["hops"]: kw["return_hops"] = True
+        if c.get("layout"):                  # loader-side per-graph layout: the one-launch grouped CSR build, no statistics read-back
+            from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+            kw["graph"] = SceneGraphBatch(t(gb.edge_index, dev), t(gb.batch, dev), N, B, host_layout=HostLayout.from_numpy(gb.edge_index, gb.batch, B))
         with torch.no_grad():               # the fused inference path (gradients route gat_seq to the differentiable one)
             res = m(t(x, dev), t(gb.edge_index, dev), t(ea, dev), t(ins, dev), t(gb.batch, dev), **kw)
             res2 = m(t(x, dev), t(gb.edge_index, dev), t(ea, dev), t(ins, dev), t(gb.batch, dev))      # cached weights, plain outputs
