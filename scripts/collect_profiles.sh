@@ -9,8 +9,8 @@ python bench.py > $O/bench_cfg3_n1.json 2> $O/bench.err
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_cfg3_kernel_stats.csv 2>/dev/null
 python scripts/bench_configs.py 2>/dev/null | tail -1 > $O/configs.json
 for f in 1 2; do for n in 2 4 8; do GVQA_HOP_FUSION=$f python bench.py --emulate-world $n --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1; done; done > $O/emulated_shards.jsonl
-GVQA_BENCH_FORCE_DIST=1 python bench.py --emulate-world 8 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1 > $O/emulated_shard8_rccl_1rank.json
-GVQA_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1 > $O/bench_cfg3_rccl_1rank.json
+GVQA_BENCH_FORCE_DIST=1 python bench.py --emulate-world 8 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | grep emulated_world > $O/emulated_shard8_rccl_1rank.json
+GVQA_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | grep "\"metric\"" > $O/bench_cfg3_rccl_1rank.json
 for f in 1 2; do MODES=$f ROUNDS=2 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel; done > $O/hop_kernels_ab.jsonl
 for z in "" 1; do ZERO=$z MODES=1,2 ROUNDS=1 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel | sed -e "s/^{/{\"zero_operands\": \"$z\", /"; done > $O/dvfs_zero_operands.jsonl
 for h in 1 4; do HOP=$h python scripts/probe_hop2.py 2>/dev/null | head -2; done > $O/hop2_phase_stamps.jsonl
