@@ -563,6 +563,19 @@ def test_default_rule_takes_the_chained_kernel_on_a_large_sparse_batch(dev):
     assert maxabs(out, ref) < TOL
 
 
+def test_batch_sixteen_times_the_benchmark_keeps_its_indices(dev):
+    """scripts/check_large_batch.py at 32768 graphs (1 M nodes, 4.2 M edges, d = 512: N H C = 2^31 elements, packed operands and
+    edge tensors of several GB) through the default eval path, with and without a loader-side layout: first / middle / last
+    64-graph windows against the oracle.  (131072 graphs -- 4.2 M nodes, 16.8 M edges, 165 ms -- checked by hand in round 3.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_large_batch.py")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GRAPHS="32768"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["N*H*C"] == 2 ** 31 and res["read_back_max_abs_err"] < TOL and res["host_layout_max_abs_err"] < TOL, res
+
+
 def test_randomised_parity_sweep(dev):
     """A fixed-seed sample of tests/fuzz.py: random head counts, widths, hop counts, batch shapes (single-node graphs to 128-node
     graphs, sparse to dense, 1 to 300 graphs), every hop kernel, library products forced or not, with and without the attention /
