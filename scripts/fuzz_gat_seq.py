@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of gat_seq's eval forward against the oracle (tests/fuzz.py): prints one line per failing case and a
-summary line.  SEED=<int> CASES=<n> python scripts/fuzz_gat_seq.py   (round 3: seeds 1-4, 2050 cases, 0 failures)"""
+summary line.  SEED=<int> CASES=<n> python scripts/fuzz_gat_seq.py   (round 3: seeds 1-4, 7-9, 4150 cases, 0 failures)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

