@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
 SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip", "collate.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(target: str, deps) -> bool:
@@ -60,8 +60,9 @@ def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB])
+    if jobs or force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl",
+             "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB])
     return LIB
 
 

@@ -225,12 +225,16 @@ __global__ __launch_bounds__(256) void k_build_grouped(int64_t N, int64_t E, int
                                                        int32_t* __restrict__ csr_eid, int32_t* __restrict__ node_graph,
                                                        int32_t* __restrict__ order, int32_t* __restrict__ stats) {
     __shared__ int deg_s[ROW_GROUP], start_s[ROW_GROUP], cursor_s[ROW_GROUP], scan_s[8];
+    __shared__ int gid_s[ROW_GROUP];          // graph id of the group's rows: a row group packs SEVERAL graphs
     __shared__ int eid_s[GROUPED_EDGE_CAP];
     __shared__ unsigned char row_s[GROUPED_EDGE_CAP];
     const int tid = threadIdx.x, r = blockIdx.x;
     const int ns = group_ptr[r], cnt = group_ptr[r + 1] - ns;
     const int e0 = group_eptr[r], ne = group_eptr[r + 1] - e0;
-    if (tid < ROW_GROUP) deg_s[tid] = 0;
+    if (tid < ROW_GROUP) {
+        deg_s[tid] = 0;
+        gid_s[tid] = (batch && tid < cnt) ? (int)batch[ns + tid] : 0;
+    }
     __syncthreads();
     // an edge of this COO range must join two nodes of this group (the loader's promise); anything else is flagged and skipped
     auto edge_ok = [&](int64_t s, int64_t d) { return s >= ns && s < ns + cnt && d >= ns && d < ns + cnt; };
@@ -238,6 +242,9 @@ __global__ __launch_bounds__(256) void k_build_grouped(int64_t N, int64_t E, int
         const int64_t s = edge_index[e0 + k], d = edge_index[E + e0 + k];
         if (edge_ok(s, d)) {
             atomicAdd(&deg_s[(int)d - ns], 1);
+            // inside the group but across two of its graphs: a legal edge for the general kernels, yet this handle says
+            // intra_graph = 1 and the fused hops rely on it -- flagged for gvqa_graph_check_valid (the edge is still placed)
+            if (gid_s[(int)s - ns] != gid_s[(int)d - ns]) stats[ST_NOT_INTRA] = 1;
         } else {
             if (s >= 0 && s < N && d >= 0 && d < N && batch && batch[s] != batch[d]) stats[ST_NOT_INTRA] = 1;
             stats[ST_INVALID] = 1;
@@ -317,6 +324,18 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
 // Row groups for the fused hop kernel: greedy in order, a group closes when the next graph would not fit.  `hp` / `he`:
 // host copies of graph_ptr [B+1] and of the graphs' first in-edge slots [B+1].  The plan is uploaded asynchronously from a
 // small ring of host buffers (a slot is reused only after its upload has completed).
+// The cut rule both planners share.  A group closes before graph q when q's nodes would not fit any more, or when the group's
+// graph IDS would span more than ROW_GROUP: the hop kernels keep per-graph state of a group in LDS arrays indexed by
+// node_graph[row] - node_graph[first row] (scales, output maxima: 128 entries), and empty graphs between two non-empty ones
+// take ids without taking rows.  `gfirst`: the first non-empty graph of the open group, -1 while it has no rows.
+static inline bool row_group_closes_before(const int32_t* hp, int64_t q, int32_t start, int64_t& gfirst) {
+    const int32_t n = hp[q + 1] - hp[q];
+    const bool close = (hp[q + 1] - start > ROW_GROUP) || (n > 0 && gfirst >= 0 && q - gfirst >= ROW_GROUP);
+    if (close) gfirst = -1;
+    if (n > 0 && gfirst < 0) gfirst = q;
+    return close;
+}
+
 static int plan_row_groups(gvqa_graph* g, const int32_t* hp, const int32_t* he, hipStream_t stream) {
     // PINNED host buffers: the upload is a true asynchronous DMA (from pageable memory the runtime stages the copy on the
     // calling thread -- 50 us of a 256-graph shard's 450 us step)
@@ -345,8 +364,9 @@ static int plan_row_groups(gvqa_graph* g, const int32_t* hp, const int32_t* he, 
         hg{sl.v, 0};
     hg.push_back(0);
     int32_t start = 0, e_start = 0, max_e = 0;
+    int64_t gfirst = -1;
     for (int64_t q = 0; q < B; ++q) {
-        if (hp[q + 1] - start > ROW_GROUP) {          // graph q does not fit any more: close the group before it
+        if (row_group_closes_before(hp, q, start, gfirst)) {
             max_e = std::max(max_e, he[q] - e_start);
             hg.push_back(hp[q]);
             start = hp[q];
@@ -560,8 +580,9 @@ int gvqa_graph_build_grouped(int64_t N, int64_t E, int64_t B, const int64_t* edg
     int G = 0;
     int32_t start = 0, e_start = 0, max_e = 0;
     s_grp[0] = 0; s_gre[0] = 0;
+    int64_t gfirst = -1;
     for (int64_t q = 0; q < B; ++q) {
-        if (hp[q + 1] - start > ROW_GROUP) {          // graph q does not fit any more: close the group before it
+        if (row_group_closes_before(hp, q, start, gfirst)) {
             max_e = std::max(max_e, he[q] - e_start);
             ++G;
             s_grp[G] = hp[q]; s_gre[G] = he[q];

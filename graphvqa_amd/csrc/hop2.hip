@@ -767,9 +767,9 @@ int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs&
 
 #ifdef GVQA_PROBES
 // measurement build only (python -m graphvqa_amd.build --probes): device buffer for the kernel's phase stamps
-extern "C" int gvqa_probe_hop2_buffer(void* p) { gvqa::g_hop2_probe = static_cast<unsigned long long*>(p); return 0; }
-extern "C" int gvqa_probe_hop2_debug(int bits) { gvqa::g_hop2_dbg = bits; return 0; }
-extern "C" int gvqa_probe_hop2_select(int every, int which) { gvqa::g_hop2_sel_every = every > 0 ? every : 1; gvqa::g_hop2_sel_which = which; gvqa::g_hop2_calls = 0; return 0; }
+extern "C" GVQA_API int gvqa_probe_hop2_buffer(void* p) { gvqa::g_hop2_probe = static_cast<unsigned long long*>(p); return 0; }
+extern "C" GVQA_API int gvqa_probe_hop2_debug(int bits) { gvqa::g_hop2_dbg = bits; return 0; }
+extern "C" GVQA_API int gvqa_probe_hop2_select(int every, int which) { gvqa::g_hop2_sel_every = every > 0 ? every : 1; gvqa::g_hop2_sel_which = which; gvqa::g_hop2_calls = 0; return 0; }
 #endif
 
 // resident workgroups of the hop kernel per CU as the runtime sees them (2 expected) -- tests / diagnostics

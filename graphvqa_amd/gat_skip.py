@@ -128,7 +128,7 @@ class _ProjectionLinear(torch.autograd.Function):
               2.0 * R * M * K >= 1e6 * lib.gvqa_get_option(_lib.OPT_SPLIT3_MIN_MFLOP))
         if not ok or not (want_x or want_w) or (gw_out is not None and (gw_out.stride(1) != 1 or gw_out.stride(0) % 4 != 0)):
             return None
-        am = getattr(gy, "_gvqa_absmax", None) if gy.is_contiguous() else None
+        am = _absmax_hint(gy)
         gy = gy.contiguous()
         dev = gy.device
         gx = (gx_init if gx_init is not None else torch.empty((R, K), dtype=torch.float32, device=dev)) if want_x else None
@@ -154,7 +154,7 @@ class _ProjectionLinear(torch.autograd.Function):
         if not ok:
             return gy.t() @ x
         # the producer of dy may have left its largest magnitudes with the tensor (the message-passing backward does): no pass over dy
-        am = getattr(gy, "_gvqa_absmax", None) if gy.is_contiguous() else None
+        am = _absmax_hint(gy)
         gy = gy.contiguous()
         dev = gy.device
         gw = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -163,6 +163,18 @@ class _ProjectionLinear(torch.autograd.Function):
             _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, gy.data_ptr(), M, x.data_ptr(), x.stride(0), _ptr(am), 0 if am is None else am.numel(),
                                                   None, 0, gw.data_ptr(), N, ws.data_ptr(), ws.numel(), _stream(dev)))
         return gw
+
+
+def _absmax_hint(gy: Tensor):
+    """The per-slice largest magnitudes a producer left with its gradient tensor (`_gvqa_absmax`: the message-passing backward
+    does, so that the split products need no pass over dy) -- honoured only if the tensor is still the one, and in the state,
+    the producer described: same storage address, same in-place version counter, contiguous.  gvqa_linear_tn_split2h's contract
+    is `hint >= max|dy|`; a stale hint would mean fp16 overflow in dW."""
+    hint = getattr(gy, "_gvqa_absmax", None)
+    if hint is None or not gy.is_contiguous():
+        return None
+    am, ptr, version = hint
+    return am if (gy.data_ptr() == ptr and gy._version == version) else None
 
 
 class _SkinnyLinear(torch.autograd.Function):
@@ -417,7 +429,9 @@ class _GatMessagePassing(torch.autograd.Function):
         with torch.cuda.device(dev):
             gt = graph.transposed()
             _lib.check(lib.gvqa_gat_mp_backward(C.byref(graph.c), C.byref(gt.c), C.byref(d), _stream(dev)))
-        dxp._gvqa_absmax = am
+        # the hint is valid for THIS tensor in THIS state only: autograd may accumulate a second consumer's gradient into dxp in
+        # place, a hook may rescale it -- either bumps the version counter and the consumer then measures the maxima itself
+        dxp._gvqa_absmax = (am, dxp.data_ptr(), dxp._version)
         d_bias = dcol.sum(0) if dcol is not None else None
         return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, (dout if ctx.has_skip else None)
 
@@ -465,7 +479,8 @@ def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor, p: float = 0.0) -> Tenso
     """dropout_p(relu(bn(x))) in training mode on the HIP kernels, with torch's running-statistics update (momentum, unbiased
     variance, num_batches_tracked).  p > 0: the keep mask is drawn here with torch's generator (one byte per element) and applied
     inside the BatchNorm passes, forward and backward."""
-    if bn.weight is None or bn.bias is None or x.shape[0] < 2:
+    if bn.weight is None or bn.bias is None or x.shape[0] < 2 or p >= 1.0:
+        # (p = 1: F.dropout returns zeros -- gat_skip.py:276 -- and BatchNorm still updates its running statistics)
         return torch.nn.functional.dropout(torch.relu(bn(x)), p=p, training=p > 0)
     keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p) if p > 0 else None
     y, mean, var = _BatchNormReluTrain.apply(x, bn.weight, bn.bias, bn.eps, keep, 1.0 / (1.0 - p) if p > 0 else 1.0)
@@ -645,8 +660,9 @@ def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: Scene
     xp [N, H*C] projected features, a_node [N, 2H] = (a_l | a_r), a_edge [E, H]; alpha_mask [E, H] multiplies alpha
     after the softmax (attention dropout: mask / (1 - p)); graph_rows [B, H*C]: rows added to xp per graph (kept out of xp);
     bias [C], skip [N, C]: added to the result in the same pass."""
-    if channels % 4 != 0 and (graph_rows is not None or bias is not None or skip is not None):
-        # the one-pass kernels move 16 bytes at a time: other widths take the explicit form (same math, torch adds)
+    if (channels % 4 != 0 or heads > 8) and (graph_rows is not None or bias is not None or skip is not None):
+        # the one-pass kernels move 16 bytes at a time and hold at most 8 heads: other shapes take the explicit form (same math,
+        # torch adds)
         if graph_rows is not None:
             xp = add_graph_rows(xp, graph_rows, graph)
         out, alpha = _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, None, None, None)

@@ -194,12 +194,13 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         return out * self.graph_layer_norm.weight + self.graph_layer_norm.bias, e2, None
 
     def _check_ids(self, x_tok, e_tok, added, E):
-        """validate_ids: True = every call, "first" (default) = the first 4 calls of this module (a vocabulary / checkpoint mismatch
+        """validate_ids: True (default) = every call, like the reference's nn.Embedding / index assignment, which raise on ANY call;
+        "first" = opt-in for the loader path that never synchronises: the first 4 calls of this module only (a vocabulary / checkpoint mismatch
         shows at once; a blocking host read on every step would undo the loader path that never synchronises), False = never.
         nn.Embedding / index assignment in the reference raise on ids outside the table (a vocabulary / checkpoint mismatch); the
         kernels would clamp them silently, so the range is checked here (one small reduction and host read)."""
         V = self.sg_vocab_embedding.num_embeddings
-        mode = getattr(self, "validate_ids", "first")
+        mode = getattr(self, "validate_ids", True)
         seen = getattr(self, "_validated_calls", 0)
         if mode is True or (mode == "first" and seen < 4):
             self._validated_calls = seen + 1

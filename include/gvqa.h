@@ -35,6 +35,14 @@
 extern "C" {
 #endif
 
+/* Export macro: the library is built with -fvisibility=hidden; only the entry points declared here (all `gvqa_*`) are
+ * dynamic symbols of libgvqa_hip.so (tests/test_host.py checks `nm -D`). */
+#if defined(__GNUC__) || defined(__clang__)
+#define GVQA_API __attribute__((visibility("default")))
+#else
+#define GVQA_API
+#endif
+
 #define GVQA_OK 0
 #define GVQA_E_INVALID (-1)    /* bad argument (null pointer, negative size, unsupported shape) */
 #define GVQA_E_WORKSPACE (-2)  /* workspace too small */
@@ -42,9 +50,9 @@ extern "C" {
 #define GVQA_E_GRAPH (-4)      /* malformed graph (index out of range, batch not sorted) */
 #define GVQA_E_UNSUPPORTED (-5)
 
-const char* gvqa_last_error(void);
+GVQA_API const char* gvqa_last_error(void);
 /* Library / build identification, e.g. "gvqa-hip 0.1 gfx950". */
-const char* gvqa_version(void);
+GVQA_API const char* gvqa_version(void);
 
 /* ------------------------------------------------------------------------------------------
  * Graph container: destination-sorted CSR of a batched (block-diagonal) scene-graph batch.
@@ -84,23 +92,23 @@ typedef struct gvqa_graph {
                                        local row row_group_order[row_group_ptr[r] + s]); the fused hop aggregates in this order */
 } gvqa_graph;
 
-size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
+GVQA_API size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
 
 /* Deferred validation of a handle finalized by gvqa_graph_finalize_host (which reads nothing back): synchronises `stream`, reads
  * the contract flags the build left on the device and the statistics the device derives from the arrays, and returns GVQA_E_GRAPH
  * when the batch violates the input contract, has cross-graph edges although the handle says intra-graph, or exceeds the
  * handle's statistics (the kernels size LDS regions from them).  For loaders: call it on the first batches / in debug runs. */
-int gvqa_graph_check_valid(const gvqa_graph* g, void* stream);
+GVQA_API int gvqa_graph_check_valid(const gvqa_graph* g, void* stream);
 
 /* Enqueue the CSR build.  `ws` (>= gvqa_graph_workspace_bytes, 256-byte aligned) backs every
  * array `out` points to and must stay alive as long as `out` is used. */
-int gvqa_graph_build(int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+GVQA_API int gvqa_graph_build(int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                      const int64_t* edge_index /* [2,E] */, const int64_t* batch /* [N] or NULL (one graph) */,
                      void* ws, size_t ws_bytes, void* stream, gvqa_graph* out);
 
 /* Copy the statistics to the host struct (synchronises `stream`).  Returns GVQA_E_GRAPH if the
  * input violated the contract. */
-int gvqa_graph_finalize(gvqa_graph* g, void* stream);
+GVQA_API int gvqa_graph_finalize(gvqa_graph* g, void* stream);
 
 /* The same WITHOUT a device synchronisation, for feeds whose loader already knows the per-graph layout on the host (the
  * reference's collate builds its Batch on the CPU, gqa_dataset_entry.py:631-675): graph_ptr_host[B+1] = first node of
@@ -109,7 +117,7 @@ int gvqa_graph_finalize(gvqa_graph* g, void* stream);
  * assumed).  The statistics and the row-group plan are derived from these on the host; the device-side validation flags
  * are NOT read back: the caller vouches for an intra-graph batch with in-range indices.  GVQA_E_GRAPH if the layout does
  * not span [0, N] nodes / [0, E] edges monotonically. */
-int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host,
+GVQA_API int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host,
                              int32_t max_in_degree, void* stream);
 
 /* gvqa_graph_build + gvqa_graph_finalize_host as ONE upload and ONE launch, for loader-side layouts whose COO edges are also
@@ -121,7 +129,7 @@ int gvqa_graph_finalize_host(gvqa_graph* g, const int32_t* graph_ptr_host, const
  * a row group of more than 8192 edges): the caller then uses gvqa_graph_build + gvqa_graph_finalize_host.  An edge outside its
  * group's node range (a layout that is not grouped after all) is flagged on the device like any contract violation
  * (gvqa_graph_check_valid). */
-int gvqa_graph_build_grouped(int64_t num_nodes, int64_t num_edges, int64_t num_graphs, const int64_t* edge_index,
+GVQA_API int gvqa_graph_build_grouped(int64_t num_nodes, int64_t num_edges, int64_t num_graphs, const int64_t* edge_index,
                              const int64_t* batch, const int32_t* graph_ptr_host, const int32_t* graph_edge_ptr_host,
                              int32_t max_in_degree, void* ws, size_t ws_bytes, void* stream, gvqa_graph* out);
 
@@ -163,8 +171,8 @@ typedef struct gvqa_gat_dims {
  * [E, edge_dim] (COO order).  out [N, C].  alpha_out: NULL or [E, H] in COO edge order
  * (return_attention_weights, gat_skip.py:170-175).  dims.ins_dim must be 0, num_hops 1.
  * Works for any graph (no intra-graph requirement). */
-size_t gvqa_gat_conv_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d);
-int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* p,
+GVQA_API size_t gvqa_gat_conv_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d);
+GVQA_API int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* p,
                           const float* x, const float* edge_attr, float* out, float* alpha_out,
                           void* ws, size_t ws_bytes, void* stream);
 
@@ -174,8 +182,8 @@ int gvqa_gat_conv_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvq
  * out [N,C] (Dn == C).  alpha_out: NULL or [K,E,H].  hop_out: NULL or [K,N,C] (h after every hop).
  * Requires g->intra_graph (true for any PyG batch); otherwise GVQA_E_UNSUPPORTED and the caller
  * falls back to K gvqa_gat_conv_forward calls on concatenated inputs. */
-size_t gvqa_gat_seq_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d);
-int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops /* [K], host */,
+GVQA_API size_t gvqa_gat_seq_workspace_bytes(const gvqa_graph* g, const gvqa_gat_dims* d);
+GVQA_API int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops /* [K], host */,
                          const float* x, const float* edge_attr, const float* instr,
                          float* out, float* alpha_out, float* hop_out,
                          void* ws, size_t ws_bytes, void* stream);
@@ -188,11 +196,11 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
  * instead of head-interleaved ones.  gvqa_gat_seq_forward_cached uses the cache when its layout id
  * matches the batch's, and recomputes into the workspace otherwise (results are identical either way).  The cache is
  * caller-owned device memory, 256-byte aligned; the caller re-prepares it after changing any parameter. */
-size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout);
-int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d);
-int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
+GVQA_API size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout);
+GVQA_API int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d);
+GVQA_API int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
                                  size_t cache_bytes, void* stream);
-int gvqa_gat_seq_forward_cached(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
+GVQA_API int gvqa_gat_seq_forward_cached(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
                                 const float* edge_attr, const float* instr, float* out, float* alpha_out, float* hop_out,
                                 const void* weight_cache, size_t weight_cache_bytes, int32_t weight_cache_layout, void* ws,
                                 size_t ws_bytes, void* stream);
@@ -203,7 +211,7 @@ int gvqa_gat_seq_forward_cached(const gvqa_graph* g, const gvqa_gat_dims* d, con
  * reproducible against torch's RNG).  bn_stats_out [K-1, 2, C] receives per hop the batch mean and
  * the biased batch variance, from which the caller updates running_mean / running_var
  * (momentum, unbiased variance) exactly as torch does.  bn_mean / bn_var of `hops` are ignored. */
-int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops,
+GVQA_API int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops,
                                  const float* x, const float* edge_attr, const float* instr, float* out,
                                  float* bn_stats_out, void* ws, size_t ws_bytes, void* stream);
 
@@ -211,19 +219,19 @@ int gvqa_gat_seq_forward_trainbn(const gvqa_graph* g, const gvqa_gat_dims* d, co
  * the differentiable path).  x, y, dy, dx: fp32 [N, C] contiguous.  save_mean / save_var [C]: batch mean and BIASED
  * variance (the caller updates running statistics).  dx = w invstd (g - sum(g)/N - xhat sum(g xhat)/N),
  * g = dy [y > 0].  ws: gvqa_bn_train_workspace_bytes(N, C).  Deterministic. */
-size_t gvqa_bn_train_workspace_bytes(int64_t N, int32_t C);
-int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+GVQA_API size_t gvqa_bn_train_workspace_bytes(int64_t N, int32_t C);
+GVQA_API int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
                                float* y, float* save_mean, float* save_var, void* ws, size_t ws_bytes, void* stream);
-int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+GVQA_API int gvqa_bn_relu_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
                                 const float* save_mean, const float* save_var, float eps, const float* dy, float* dx,
                                 float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
 /* The same with feature dropout (gat_skip.py:276, F.dropout after BatchNorm + ReLU) applied in the same passes:
  * y = relu(bn(x)) * (keep[i] ? keep_scale : 0) with keep [N, C] bytes drawn by the caller (torch's generator: masks are the
  * caller's randomness) and keep_scale = 1 / (1 - p); the backward takes dL/dy of THAT y.  keep NULL: no dropout. */
-int gvqa_bn_relu_dropout_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+GVQA_API int gvqa_bn_relu_dropout_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
                                        const uint8_t* keep, float keep_scale, float* y, float* save_mean, float* save_var, void* ws,
                                        size_t ws_bytes, void* stream);
-int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+GVQA_API int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
                                         const float* save_mean, const float* save_var, float eps, const uint8_t* keep,
                                         float keep_scale, const float* dy, float* dx, float* dweight, float* dbias, void* ws,
                                         size_t ws_bytes, void* stream);
@@ -231,16 +239,16 @@ int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const float* x, co
 /* Per-graph rows <-> node rows (glue of the differentiable path: the per-graph instruction terms).
  * rows_to_nodes: out[i, :F] (= or +=) rows[graph(i), :F];  segment_sum (its adjoint): out[b, :F] = sum of x[i, :F]
  * over the nodes of graph b.  Deterministic. */
-int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
+GVQA_API int gvqa_graph_rows_to_nodes(const gvqa_graph* g, int64_t F, const float* rows, int64_t ld_rows, float* out, int64_t ld_out,
                              int accumulate, void* stream);
-int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
+GVQA_API int gvqa_graph_segment_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
 /* The same divided by max(node count of graph b, 1): the per-graph mean rows that a sharded step all-gathers when the answer
  * head is not run (torch_scatter's scatter_mean by graph).  One launch. */
-int gvqa_graph_segment_mean(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
+GVQA_API int gvqa_graph_segment_mean(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
 /* out[i, :F] = sum over the in-edges e of node i of x[e, :F] (x is a per-edge tensor in COO order): scatter_add by
  * destination -- or by SOURCE when `g` is the transposed graph.  The adjoint of the per-edge gathers x[dst] / x[src]
  * (torch's own gather backward is a sort-based index_put).  Deterministic. */
-int gvqa_graph_edge_rows_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
+GVQA_API int gvqa_graph_edge_rows_sum(const gvqa_graph* g, int64_t F, const float* x, int64_t ld_x, float* out, int64_t ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Building blocks exported for tests, benchmarks and the variants' host code
@@ -248,13 +256,13 @@ int gvqa_graph_edge_rows_sum(const gvqa_graph* g, int64_t F, const float* x, int
 /* C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (optionally ReLU) in exact fp32 on the MFMA f32 path.
  * lda/ldb/ldc in elements.  This is torch.nn.Linear's math (F.linear) for the dense
  * projections (gat_skip.py:133,150).  bias may be NULL. */
-int gvqa_linear_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+GVQA_API int gvqa_linear_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                     const float* B, int64_t ldb, const float* bias, int relu,
                     float* C, int64_t ldc, void* stream);
 /* Same with the full epilogue: v = acc + bias[n]; v += addend[m*ld_add + n]; v *= mul[m*ld_mul + n];
  * activation (`relu`: 0 none, 1 ReLU, 2 ELU).  addend may alias C (accumulate a second product in place: split-source concatenations,
  * lcgn.py:316-319).  bias / addend / mul may be NULL. */
-int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+GVQA_API int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_add,
                        const float* mul, int64_t ld_mul, int relu, float* C, int64_t ldc, void* stream);
 
@@ -263,8 +271,8 @@ int gvqa_linear_f32_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t 
  * gvqa_linear_bf16 computes C[M,N] = sum_p A[M,K] . Wpk_p[N,K]^T with fp32 accumulation and the epilogue of
  * gvqa_linear_f32_ex.  A is bf16 [M, lda]; C, addend and mul are bf16 when c_bf16 != 0, fp32 otherwise; bias
  * is fp32.  K and lda must be multiples of 8, A and Wpk 16-byte aligned. */
-int gvqa_pack_weight_bf16(int64_t rows, int64_t K, int pieces, const float* W, int64_t ldw, void* Wpk, void* stream);
-int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A, int64_t lda, const void* Wpk,
+GVQA_API int gvqa_pack_weight_bf16(int64_t rows, int64_t K, int pieces, const float* W, int64_t ldw, void* Wpk, void* stream);
+GVQA_API int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A, int64_t lda, const void* Wpk,
                      const float* bias, const void* addend, int64_t ld_add, const void* mul, int64_t ld_mul, int relu,
                      void* C, int64_t ldc, int c_bf16, void* stream);
 
@@ -277,9 +285,9 @@ int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, const void* A,
  * 16-byte aligned and hold gvqa_split3_packed_bytes(rows, K)); gvqa_linear_split3 computes
  * C[M,N] = A[M,K] . B[N,K]^T from the packed operands with the epilogue of gvqa_linear_f32_ex (fp32 C, N % 4 == 0,
  * 16-byte aligned rows; GVQA_E_UNSUPPORTED otherwise). */
-size_t gvqa_split3_packed_bytes(int64_t rows, int64_t K);
-int gvqa_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
-int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
+GVQA_API size_t gvqa_split3_packed_bytes(int64_t rows, int64_t K);
+GVQA_API int gvqa_split3_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
+GVQA_API int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
                        const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                        int64_t ldc, void* stream);
 /* "split2h" (the default): every ROW of an operand is scaled by a power of two that puts its largest magnitude into
@@ -290,9 +298,9 @@ int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const v
  * (tests/test_gpu_split3.py) at half of split3's matrix-core work and two thirds of its operand bytes.  Same calls and layout
  * with 2 pieces of fp16, followed by one fp32 inverse scale per (padded) row:
  * P[ceil(rows/32)][ceil(K/16)][2][64 lanes][8 fp16] | inv_scale[32 ceil(rows/32)]. */
-size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K);
-int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
-int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
+GVQA_API size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K);
+GVQA_API int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
+GVQA_API int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
                         const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                         int64_t ldc, void* stream);
 
@@ -302,11 +310,11 @@ int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const 
  * of their autograd: dV = X^T G and dX = addend + G V^T.  X [R, D] (row stride ldx), Y / G [R, J] contiguous.  Each call
  * streams X (or dX) through HBM once; dV is summed in a fixed order (partial sums per 128 or 256 rows in the workspace, no atomics).
  * D % 4 == 0, D <= 1024. */
-int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* V, float* Y, void* stream);
-size_t gvqa_skinny_backward_weight_workspace_bytes(int64_t R, int64_t D, int64_t J);
-int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* G, float* dV,
+GVQA_API int gvqa_skinny_forward(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* V, float* Y, void* stream);
+GVQA_API size_t gvqa_skinny_backward_weight_workspace_bytes(int64_t R, int64_t D, int64_t J);
+GVQA_API int gvqa_skinny_backward_weight(int64_t R, int64_t D, int64_t J, const float* X, int64_t ldx, const float* G, float* dV,
                                 void* ws, size_t ws_bytes, void* stream);
-int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, const float* V, const float* addend,
+GVQA_API int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, const float* V, const float* addend,
                                int64_t ld_add, float* dX, int64_t ldx, void* stream);
 
 /* Attention vectors folded through a projection weight (differentiable path): with W [H*C, Kin] (row stride ldw; lin_l or
@@ -314,9 +322,9 @@ int gvqa_skinny_backward_input(int64_t R, int64_t D, int64_t J, const float* G, 
  *     V[k, h] = sum_c W[h C + c, k] att_a[h C + c],   V[k, H + h] = the same with att_b     (V [Kin, J], J = 2H, or H when att_b is NULL)
  * and the adjoint: dW[r, k] = att_a[r] dV[k, h(r)] + att_b[r] dV[k, H + h(r)] (written, row stride ld_dw; NULL: skipped),
  * datt_a[r] = sum_k W[r, k] dV[k, h(r)] (NULL: skipped), datt_b likewise.  Fixed summation order. */
-int gvqa_fold_attention_forward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
+GVQA_API int gvqa_fold_attention_forward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
                                 float* V, void* stream);
-int gvqa_fold_attention_backward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
+GVQA_API int gvqa_fold_attention_backward(int64_t H, int64_t C, int64_t Kin, const float* W, int64_t ldw, const float* att_a, const float* att_b,
                                  const float* dV, float* dW, int64_t ld_dw, float* datt_a, float* datt_b, void* stream);
 
 /* C[M, N] = X^T Y for X [R, M], Y [R, N] (row strides ldx / ldy): the weight gradient dW = dy^T x of the hop projection under
@@ -326,8 +334,8 @@ int gvqa_fold_attention_backward(int64_t H, int64_t C, int64_t Kin, const float*
  * device pointers to x_absmax_n / y_absmax_n (<= GVQA_ABSMAX_SLOTS) floats whose maximum is >= max|X| / max|Y| when the
  * producer knows it (gvqa_gat_mp_bwd_desc.dxp_absmax), else NULL (computed here, one extra pass over the operand).
  * M, N, ldx, ldy, ldc multiples of 4. */
-size_t gvqa_linear_tn_workspace_bytes(int64_t R, int64_t M, int64_t N);
-int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy,
+GVQA_API size_t gvqa_linear_tn_workspace_bytes(int64_t R, int64_t M, int64_t N);
+GVQA_API int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy,
                            const float* x_absmax, int x_absmax_n, const float* y_absmax, int y_absmax_n, float* C, int64_t ldc,
                            void* ws, size_t ws_bytes, void* stream);
 
@@ -337,8 +345,8 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
  * split GEMM runs for dx (dx_accumulate != 0: dx += dy W, e.g. on top of the logit products' input gradient) and -- over split-K
  * chunks -- for dW (fixed-order reduction).  dy_absmax as in gvqa_linear_tn_split2h.
  * M, K and all leading dimensions multiples of 4. */
-size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64_t K);
-int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
+GVQA_API size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64_t K);
+GVQA_API int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
                                  const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
                                  int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream);
 
@@ -367,8 +375,8 @@ enum gvqa_option {
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */
 #define GVQA_PROJECTION_SPLIT2H 2  /* two scaled fp16 pieces per fp32 value, three fp16-MFMA products, fp32 accumulate (default) */
-int gvqa_set_option(int option, int value);
-int gvqa_get_option(int option);
+GVQA_API int gvqa_set_option(int option, int value);
+GVQA_API int gvqa_get_option(int option);
 
 /* Scene-graph collate on the host (/root/reference gqa_dataset_entry.py:190-372 converter rules + :631-675 / :654
  * Batch.from_data_list offsets) over PRE-TOKENISED, flattened scene graphs -- the loader's path into the batch without a Python
@@ -381,9 +389,9 @@ int gvqa_get_option(int option);
  *                                     added_sym_edge [A] (edge ids), batch [N], graph_ptr / edge_ptr [B+1] (the layout
  *                                     gvqa_graph_finalize_host takes), *max_in_degree.
  * GVQA_E_GRAPH: a relation points outside its graph; GVQA_E_INVALID: more than 11 attributes (the reference raises IndexError). */
-int gvqa_scene_graph_collate_sizes(int64_t num_graphs, const int32_t* graph_obj_ptr, const int32_t* rel_ptr, const int32_t* rel_dst,
+GVQA_API int gvqa_scene_graph_collate_sizes(int64_t num_graphs, const int32_t* graph_obj_ptr, const int32_t* rel_ptr, const int32_t* rel_dst,
                                    int64_t* sizes);
-int gvqa_scene_graph_collate(int64_t num_graphs, const int32_t* graph_obj_ptr, const int64_t* name_tok, const int32_t* attr_ptr,
+GVQA_API int gvqa_scene_graph_collate(int64_t num_graphs, const int32_t* graph_obj_ptr, const int64_t* name_tok, const int32_t* attr_ptr,
                              const int64_t* attr_tok, const int32_t* rel_ptr, const int32_t* rel_dst, const int64_t* rel_tok,
                              int64_t pad_tok, int64_t self_tok, int64_t unk_tok, int64_t N, int64_t E, int64_t A, int64_t* x_tokens,
                              int64_t* edge_index, int64_t* edge_tokens, int64_t* added_sym_edge, int64_t* batch, int32_t* graph_ptr,
@@ -391,11 +399,11 @@ int gvqa_scene_graph_collate(int64_t num_graphs, const int32_t* graph_obj_ptr, c
 
 /* Resident workgroups per CU of the persistent hop kernel (csrc/hop2.hip) as the HIP runtime reports them for head count H
  * in {1,2,4,8}: 2 is what its design needs (80 KiB of LDS, <= 256 VGPRs); < 0 = GVQA_E_*.  Diagnostics / tests. */
-int gvqa_hop2_blocks_per_cu(int32_t H);
+GVQA_API int gvqa_hop2_blocks_per_cu(int32_t H);
 
 /* Which GEMM backend serves the plain dense projections in this process (hand-written k_linear_f32,
  * or rocBLAS for large epilogue-free products; GVQA_GEMM_BACKEND=auto|hip|rocblas). */
-const char* gvqa_gemm_backend(void);
+GVQA_API const char* gvqa_gemm_backend(void);
 
 /* The fused GAT message-passing kernel on its own (SURVEY 2.1 K4-K9 + K11): attention logits
  * -> leaky-relu -> softmax over incoming edges -> alpha-weighted sum of projected source
@@ -430,7 +438,7 @@ typedef struct gvqa_gat_mp_desc {
     int32_t force;              /* 0 = auto, 1 = LDS-tiled kernel, 2 = general CSR kernel            */
 } gvqa_gat_mp_desc;
 /* ws: >= 4*E*H bytes, used by the general kernel only. */
-int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream);
+GVQA_API int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of gvqa_gat_message_passing in its bare form (no graph terms / scale / bias / skip / BN:
  * out[i] = (1/H) sum_h sum_{e->i} alpha[e,h] mask[e,h] xp[src_e,h,:]) -- what autograd does through PyG's
@@ -460,7 +468,7 @@ typedef struct gvqa_gat_mp_bwd_desc {
     float* dxp_absmax;          /* NULL or [GVQA_ABSMAX_SLOTS] floats (written): the largest |dxp| in slices -- the operand scale
                                    gvqa_linear_tn_split2h takes, without a pass over dxp                     */
 } gvqa_gat_mp_bwd_desc;
-int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_gat_mp_bwd_desc* d, void* stream);
+GVQA_API int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_gat_mp_bwd_desc* d, void* stream);
 
 /* Per-graph rows of the hop projection kept out of xp (differentiable path).  lin_l acts on [h | ins[batch]] (gat_skip.py:133,
  * 263-264): xp[i,h,:] = xp_node[i,h,:] + R[g(i),h,:] with R = ins W_i^T one row per GRAPH.  The aggregation is linear in xp, so
@@ -472,9 +480,9 @@ int gvqa_gat_mp_backward(const gvqa_graph* g, const gvqa_graph* gt, const gvqa_g
  *                                  dcol[g,:] = sum_{i in g} dy[i,:] (the bias gradient per graph)   (each output NULL: not computed;
  *                                  ds is what gvqa_gat_mp_bwd_desc.dalpha_node takes)
  * R / dR [B, H*C] contiguous, dcol [B, C], y / dy / skip [N, C] with row strides, s / ds [N, H] contiguous.  C % 4 == 0, H <= 8. */
-int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, const float* bias,
+GVQA_API int gvqa_graph_head_rows_add(const gvqa_graph* g, int64_t C, int64_t H, const float* R, const float* s, const float* bias,
                              const float* skip, int64_t ld_skip, float* y, int64_t ld_y, void* stream);
-int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, const float* dy, int64_t ld_dy, const float* R,
+GVQA_API int gvqa_graph_head_rows_backward(const gvqa_graph* g, int64_t C, int64_t H, const float* dy, int64_t ld_dy, const float* R,
                                   const float* s, float* dR, float* ds, float* dcol, void* stream);
 
 /* Host-only introspection: the geometry gvqa_gat_message_passing would use for this (finalized)
@@ -489,7 +497,7 @@ typedef struct gvqa_mp_plan {
     int64_t lds_bytes;         /* dynamic LDS per block                                                      */
     int32_t blocks_per_graph;  /* > 1 for small batches: the channel ranges of a graph are split over several blocks */
 } gvqa_mp_plan;
-int gvqa_gat_mp_plan(const gvqa_graph* g, int32_t C, int32_t H, gvqa_mp_plan* out);
+GVQA_API int gvqa_gat_mp_plan(const gvqa_graph* g, int32_t C, int32_t H, gvqa_mp_plan* out);
 
 /* ------------------------------------------------------------------------------------------
  * GINE / GCN variants (baseline_and_test_models/pipeline_model_{gine,gcn}.py:622-674)
@@ -504,7 +512,7 @@ typedef struct gvqa_bn_params {     /* one eval-mode BatchNorm1d: bns.j.{weight,
 /* out = relu(bn_{S-1}(... relu(bn_0(x)) ...)): what gine_seq.forward / gcn_seq.forward return as
  * written -- they compute conv_res and discard it (pipeline_model_gine.py:665-671,
  * pipeline_model_gcn.py:660-666).  x, out [N, C]; `stages` is a host array. */
-int gvqa_bn_relu_chain(int64_t N, int32_t C, int32_t num_stages, const gvqa_bn_params* stages, float bn_eps,
+GVQA_API int gvqa_bn_relu_chain(int64_t N, int32_t C, int32_t num_stages, const gvqa_bn_params* stages, float bn_eps,
                        const float* x, float* out, void* stream);
 
 typedef struct gvqa_gine_params {   /* GINEConv(Seq(Lin, ReLU, Lin)): convs.i.nn.{0,2}.{weight,bias}, convs.i.eps */
@@ -519,8 +527,8 @@ typedef struct gvqa_gine_params {   /* GINEConv(Seq(Lin, ReLU, Lin)): convs.i.nn
  * wide, pipeline_model_gine.py:651-665): out = nn((1+eps) x_i + sum_{j->i} relu(x_j + e_ji)).
  * h [N, node_dim], edge_attr [E, node_dim] (COO order), ins [B, ins_dim] (NULL when ins_dim == 0:
  * h / edge_attr are then the full inputs), out [N, C].  ins_dim > 0 needs an intra-graph batch. */
-size_t gvqa_gine_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
-int gvqa_gine_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
+GVQA_API size_t gvqa_gine_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
+GVQA_API int gvqa_gine_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
                            const gvqa_gine_params* p, const float* h, const float* edge_attr, const float* ins,
                            float* out, void* ws, size_t ws_bytes, void* stream);
 
@@ -532,8 +540,8 @@ typedef struct gvqa_gcn_params {    /* PyG 1.6/1.7 GCNConv: convs.i.weight [in, 
 /* PyG GCNConv on x = [h || ins[batch]] (pipeline_model_gcn.py:651-660): unit edge weights,
  * add_remaining_self_loops (existing self loops collapse into one per node), symmetric
  * normalisation.  h [N, node_dim], ins [B, ins_dim] or NULL, out [N, C].  Any graph. */
-size_t gvqa_gcn_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
-int gvqa_gcn_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
+GVQA_API size_t gvqa_gcn_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
+GVQA_API int gvqa_gcn_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
                           const gvqa_gcn_params* p, const float* h, const float* ins, float* out,
                           void* ws, size_t ws_bytes, void* stream);
 
@@ -587,16 +595,16 @@ typedef struct gvqa_lcgn_params {   /* lcgn_seq state_dict (lcgn.py:255-282), de
  * proj_cmd / cal_cmd, and in the bf16 modes the bf16 pieces of the node-GEMM weights).  A caller whose
  * weights do not change between forwards builds them once and passes them in params->packed; they must be
  * rebuilt when any weight, or dims->{in,out}_channels / num_iters / node_bf16, changes. */
-size_t gvqa_lcgn_pack_bytes(const gvqa_lcgn_dims* d);
-int gvqa_lcgn_pack_weights(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, void* packed, size_t packed_bytes,
+GVQA_API size_t gvqa_lcgn_pack_bytes(const gvqa_lcgn_dims* d);
+GVQA_API int gvqa_lcgn_pack_weights(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, void* packed, size_t packed_bytes,
                            void* stream);
 
 /* lcgn_seq.forward(x, edge_index, batch, q_encoding, lstm_outputs) in eval mode (lcgn.py:303-323).
  * x [N, in], q_encoding [B, Q], lstm_outputs [L, B, O], x_ctx_init [N, O] = the noise the reference
  * draws with torch.randn on the CPU generator (lcgn.py:306; the caller draws it the same way),
  * out [N, O].  Needs a finalized intra-graph batch. */
-size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* d);
-int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p,
+GVQA_API size_t gvqa_lcgn_seq_workspace_bytes(const gvqa_graph* g, const gvqa_lcgn_dims* d);
+GVQA_API int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p,
                           const float* x, const float* q_encoding, const float* lstm_outputs,
                           const float* x_ctx_init, float* out, void* ws, size_t ws_bytes, void* stream);
 
@@ -621,8 +629,8 @@ typedef struct gvqa_pool_params {     /* MyConditionalGlobalAttention: {node,que
 
 /* x' = node_nn(x); gate = gate_nn(ques_nn(u)[batch] * x'); softmax over the nodes of each graph;
  * out[g] = sum_n gate[n] x'[n].  x [N, node_dim], u [B, Ch], out [B, Ch]. */
-size_t gvqa_attention_pool_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t channels);
-int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t node_dim, int32_t channels, const gvqa_pool_params* p,
+GVQA_API size_t gvqa_attention_pool_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t channels);
+GVQA_API int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t node_dim, int32_t channels, const gvqa_pool_params* p,
                                 const float* x, const float* u, float* out, void* ws, size_t ws_bytes, void* stream);
 
 typedef struct gvqa_classifier_params {   /* logit_fc.{1,4}.{weight,bias} */
@@ -633,8 +641,8 @@ typedef struct gvqa_classifier_params {   /* logit_fc.{1,4}.{weight,bias} */
 } gvqa_classifier_params;
 
 /* logits = fc2(ELU(fc1([g || q || g*q])))  (eval: dropouts inactive).  g_feat, q [B, Q]; logits [B, A]. */
-size_t gvqa_answer_logits_workspace_bytes(int64_t B, int32_t Q, int32_t hidden);
-int gvqa_answer_logits_forward(int64_t B, int32_t Q, int32_t hidden, int32_t A, const gvqa_classifier_params* p,
+GVQA_API size_t gvqa_answer_logits_workspace_bytes(int64_t B, int32_t Q, int32_t hidden);
+GVQA_API int gvqa_answer_logits_forward(int64_t B, int32_t Q, int32_t hidden, int32_t A, const gvqa_classifier_params* p,
                                const float* g_feat, const float* q, float* logits, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -666,15 +674,15 @@ typedef struct gvqa_encoder_params {
 /* out[r, :] = (negate && negate[r] ? -1 : +1) * sum_t table[tokens[r, t], :]  -- the token-embedding sums of the scene-graph encoder
  * (pipeline_model_gat.py:583-593; `negate`: one byte per row, the rows of `added_sym_edge`, :590), on any [V, D] table (the embedding
  * itself, or its projection through the edge block of EdgeModel's first Linear).  Token ids are clamped to the table. */
-int gvqa_embed_sum(int64_t rows, int32_t T, int32_t V, int32_t D, const int64_t* tokens, const float* table, const uint8_t* negate,
+GVQA_API int gvqa_embed_sum(int64_t rows, int32_t T, int32_t V, int32_t D, const int64_t* tokens, const float* table, const uint8_t* negate,
                    float* out, void* stream);
 /* y_out[e, :] = relu(a[ia[e], :] + b[ib[e], :] + y_in[e, :] + bias): the first Linear of an edge-level MLP of the encoder once its
  * node-side column blocks are projected per node (pipeline_model_gat.py:65-76,92-95): per-edge gathers, sum, bias and ReLU in one
  * pass.  a / b may be NULL (term absent) and have row strides lda / ldb (column blocks of one wider per-node product); y_out may be y_in. */
-int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, int64_t lda, const int64_t* ia, const float* b, int64_t ldb, const int64_t* ib,
+GVQA_API int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, int64_t lda, const int64_t* ia, const float* b, int64_t ldb, const int64_t* ib,
                          const float* bias, const float* y_in, float* y_out, void* stream);
-size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D);
-int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t node_tokens, int32_t edge_tokens_per_edge,
+GVQA_API size_t gvqa_sg_encoder_workspace_bytes(const gvqa_graph* g, int32_t D);
+GVQA_API int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t node_tokens, int32_t edge_tokens_per_edge,
                             const gvqa_encoder_params* p, const int64_t* x_tokens, const int64_t* edge_tokens,
                             const int64_t* added_sym_edge, int64_t num_added, const int64_t* edge_index, float ln_eps,
                             float* x_encoded, float* edge_attr_encoded, void* ws, size_t ws_bytes, void* stream);
@@ -697,10 +705,10 @@ enum {
     GVQA_STAGE_ALPHA = 9,      /* attention coefficients as a kernel of their own (fused-hop path) */
     GVQA_NUM_STAGES = 10
 };
-int gvqa_prof_enable(int on);
+GVQA_API int gvqa_prof_enable(int on);
 /* Waits for outstanding events, ADDS elapsed milliseconds / launch counts per stage into the
  * arrays (each GVQA_NUM_STAGES long) and clears the internal list. */
-int gvqa_prof_collect(double* ms_by_stage, int64_t* launches_by_stage);
+GVQA_API int gvqa_prof_collect(double* ms_by_stage, int64_t* launches_by_stage);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ gb = synth.config3_batch(); N, E, B, V, D, Q = gb.num_nodes, gb.num_edges, gb.nu
 def load(m, p):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()}); return m.to(dev).eval()
 enc = load(GroundTruth_SceneGraph_Encoder(V, 0, D), synth.encoder_params(V, D, seed=1))
+enc.validate_ids = "first"        # the sync-free loader path opts in: ids checked on the first calls only
 gs = load(gat_seq(D, D, D, Q, 5, dropout=0.1, gat_heads=4), synth.gat_seq_params(D, D, D, Q, 5, 4, seed=2))
 pool = load(MyConditionalGlobalAttention(D, Q), synth.attention_pool_params(D, Q, seed=3))
 clf = load(ShortAnswerClassifier(Q, 512, 1842), synth.classifier_params(Q, 512, 1842, seed=4))

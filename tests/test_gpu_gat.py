@@ -242,6 +242,44 @@ def test_gat_seq_real_dims_golden(dev, name):
     assert maxabs(alpha[0], g["alpha0"]) < 1e-5 and maxabs(alpha[4], g["alpha4"]) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["gat_seq_debug2_d300", "gat_seq_debug4_d300"])
+def test_integration_md_stub_runs(dev, name):
+    """INTEGRATION.md section 2 -- the ctypes stub a maintainer of the reference would copy in place of the body of
+    gat_seq.forward (gat_skip.py:249-279) -- is extracted from the document and EXECUTED on the reference-recorded goldens.
+    A stale structure in the document (round 3: two missing members) overruns the library's writes / reads garbage options;
+    here it fails the build instead.  The module handed to the stub has the reference's attribute structure (convs / bns)."""
+    from tests.util import integration_md_stub, ROOT
+    from graphvqa_amd.gat_skip import gat_seq
+    cwd = os.getcwd()
+    os.chdir(ROOT)                       # the document loads the library by its repo-relative path
+    try:
+        ns = {}
+        exec(compile(integration_md_stub(), "INTEGRATION.md#2", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    meta, g = load_golden(name)
+    s = meta["input_seeds"]
+    N, E, B = g["batch"].shape[0], g["edge_index"].shape[1], int(g["batch"].max()) + 1
+    x, ea = synth.normal((N, 300), s["x"]), synth.normal((E, 300), s["edge_attr"])
+    ins = synth.normal((5, B, 512), s["instr"])
+    p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=meta["param_seed"])
+    mod = gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4)
+    mod.load_state_dict(tparams(p))
+    mod = mod.to(dev).eval()
+    # canary bytes behind the caller-side structures would not help (the overrun was inside ctypes' own allocation), so the
+    # check is the result itself plus a second call after unrelated allocations
+    for _ in range(2):
+        out = ns["gat_seq_forward"](mod, t(x, device=dev), t(g["edge_index"], device=dev), t(ea, device=dev),
+                                    t(ins, device=dev), t(g["batch"], device=dev))
+        torch.cuda.synchronize()
+        assert maxabs(out, g["out"]) < TOL
+        _ = [torch.empty(1 << 16, device=dev) for _ in range(4)]
+    import ctypes as C
+    from graphvqa_amd import _lib
+    assert C.sizeof(ns["Graph"]) == C.sizeof(_lib.Graph) and C.sizeof(ns["Dims"]) == C.sizeof(_lib.GatDims)
+    assert C.sizeof(ns["HopParams"]) == C.sizeof(_lib.GatConvParams)
+
+
 @pytest.mark.parametrize("H,C", [(1, 16), (2, 24), (4, 100), (8, 8)])
 def test_gat_seq_vs_fp64_oracle_heads(dev, H, C):
     """Other head counts / widths against the oracle evaluated in float64."""
@@ -466,6 +504,49 @@ def test_chained_hops_on_small_and_sparse_row_groups(dev, H, C, K, seed, graphs,
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("layout", ["device", "loader"])
+def test_row_groups_never_span_more_than_128_graph_ids(dev, layout):
+    """the chained hop kernels index per-graph LDS state (scales, output maxima: 128 entries) by
+    node_graph[row] - node_graph[first row of the group]; EMPTY graphs between two non-empty ones take ids without rows, so
+    'at most 128 rows' did not imply 'at most 128 ids'.  Both planners now close a group at 128 ids; a batch whose few small
+    graphs sit 200 ids apart runs the chained kernel (hop_fusion = 2) and is held to the oracle."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    from graphvqa_amd.gat_skip import gat_seq
+    H, C, K, de, di = 4, 64, 4, 16, 8
+    small = synth.make_graph_batch(9, seed=31, nodes_lo=3, nodes_hi=9, rel_per_node=1.5)
+    ids = np.array([0, 1, 2, 203, 204, 470, 471, 472, 800])            # the 9 graphs keep their order, ids far apart
+    B = 801
+    batch = ids[small.batch]
+    ei = small.edge_index
+    N, E = small.num_nodes, small.num_edges
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=77)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    ref = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(batch), tparams(p), heads=H)
+    hl = HostLayout.from_numpy(ei, batch, B) if layout == "loader" else None
+    g = SceneGraphBatch(t(ei, device=dev), t(batch, device=dev), N, B, host_layout=hl)
+    G = g.c.num_row_groups
+    assert G >= 4                                                        # 128 rows would have held all 9 graphs in one group
+    rg = g._view(g.c.row_group_ptr, G + 1).cpu().numpy()
+    ng = g.node_graph.cpu().numpy()
+    for r in range(G):
+        assert ng[rg[r + 1] - 1] - ng[rg[r]] < 128
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), p, dev)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 2)
+    try:
+        _lib.prof_enable(True); _lib.prof_collect()
+        out = m(t(x, device=dev), t(ei, device=dev), t(ea, device=dev), t(ins, device=dev), t(batch, device=dev), graph=g)
+        prof = _lib.prof_collect()
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+        _lib.prof_enable(False)
+    assert prof["mp"][1] == 0 and prof["alpha"][1] == K
+    assert maxabs(out, ref) < TOL
+
+
 def test_grouped_one_launch_csr_build_equals_the_general_build(dev):
     """gvqa_graph_build_grouped (loader-side layout + COO edges grouped by graph: one upload, one launch) must produce the
     general pair's arrays bit for bit -- rowptr, csr_src, csr_eid (in-row order by edge id, multi-edges), node_graph, graph_ptr,
@@ -522,6 +603,21 @@ def test_grouped_one_launch_csr_build_equals_the_general_build(dev):
     lie = HostLayout(good.graph_ptr, good.edge_ptr, good.max_in_degree, coo_grouped=True)
     with pytest.raises(_lib.GvqaError):
         SceneGraphBatch(t(ei_s, device=dev), t(gb.batch, device=dev), gb.num_nodes, gb.num_graphs, host_layout=lie).check_valid()
+    # an edge between two graphs of ONE row group (a group packs several graphs) passes the node-range check; the
+    # handle says intra_graph = 1 and the fused hops rely on it -> must be flagged for check_valid, like the general build's flag
+    sm = synth.make_graph_batch(6, seed=7, nodes_lo=4, nodes_hi=9, rel_per_node=1.0)          # 6 small graphs = one row group
+    assert sm.num_nodes <= 128
+    gp = np.searchsorted(sm.batch, np.arange(sm.num_graphs + 1))
+    ei_x = sm.edge_index.copy()
+    k = int(np.nonzero(sm.batch[ei_x[1]] == 2)[0][0])              # an in-edge of graph 2 ...
+    ei_x[0, k] = gp[4]                                               # ... now comes from a node of graph 4 (COO position unchanged)
+    claim = HostLayout.from_numpy(sm.edge_index, sm.batch, sm.num_graphs)       # the layout of the clean batch: still "grouped"
+    assert claim.coo_grouped
+    gx = SceneGraphBatch(t(ei_x, device=dev), t(sm.batch, device=dev), sm.num_nodes, sm.num_graphs, host_layout=claim)
+    assert gx.c.num_row_groups == 1 and gx.intra_graph
+    with pytest.raises(_lib.GvqaError, match="joins two graphs"):
+        gx.check_valid()
+    SceneGraphBatch(t(sm.edge_index, device=dev), t(sm.batch, device=dev), sm.num_nodes, sm.num_graphs, host_layout=claim).check_valid()
     # a graph of more than 128 nodes: out of the grouped build's reach -> the general pair, silently
     big = synth.make_graph_batch(2, seed=6, nodes_lo=150, nodes_hi=200, rel_per_node=1.0)
     hb = HostLayout.from_numpy(big.edge_index, big.batch, big.num_graphs)

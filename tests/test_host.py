@@ -9,7 +9,7 @@ import torch
 
 from graphvqa_amd import synth
 from graphvqa_amd.scene_graph import scene_graph_topology, batch_scene_graphs
-from tests.util import ROOT, load_golden
+from tests.util import ROOT, load_golden, integration_md_stub, header_struct_members
 
 
 def test_library_exports_every_declared_symbol():
@@ -36,6 +36,66 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.GatDims) == 10 * 4 and _lib.GatDims.projection.offset == 32 and _lib.GatDims.hop_fusion.offset == 36
     assert C.sizeof(_lib.LcgnDims) == 8 * 4
     assert C.sizeof(_lib.GatMpBwdDesc) == 16 + 15 * 8 and _lib.GatMpBwdDesc.dalpha_node.offset == 120 and _lib.GatMpBwdDesc.dxp_absmax.offset == 128
+
+
+def _ctypes_members(cls):
+    import ctypes as C
+    kinds = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int32: "i32", C.c_int64: "i64", C.c_float: "f32", C.c_size_t: "size"}
+    out = []
+    for name, typ in cls._fields_:
+        if hasattr(typ, "_length_"):
+            out.append((name, kinds[typ._type_], typ._length_))
+        else:
+            out.append((name, kinds[typ], 0))
+    return out
+
+
+_HEADER_STRUCTS = {"Graph": "gvqa_graph", "GatConvParams": "gvqa_gat_conv_params", "GatDims": "gvqa_gat_dims",
+                   "GatMpDesc": "gvqa_gat_mp_desc", "GatMpBwdDesc": "gvqa_gat_mp_bwd_desc", "MpPlan": "gvqa_mp_plan",
+                   "BnParams": "gvqa_bn_params", "GineParams": "gvqa_gine_params", "GcnParams": "gvqa_gcn_params",
+                   "LcgnDims": "gvqa_lcgn_dims", "LcgnParams": "gvqa_lcgn_params", "PoolParams": "gvqa_pool_params",
+                   "ClassifierParams": "gvqa_classifier_params", "EncoderParams": "gvqa_encoder_params"}
+
+
+def test_every_ctypes_structure_matches_the_header_member_for_member():
+    """Parsed from include/gvqa.h, not from hand-kept offsets: names, kinds (pointer / int32 / int64 / float / size_t), array
+    lengths and order of every structure the binding mirrors."""
+    import ctypes as C
+    from graphvqa_amd import _lib
+    mirrored = {n for n in dir(_lib) if isinstance(getattr(_lib, n), type) and issubclass(getattr(_lib, n), C.Structure)
+                and getattr(_lib, n) is not C.Structure}
+    assert mirrored == set(_HEADER_STRUCTS), mirrored ^ set(_HEADER_STRUCTS)
+    for cls, cname in _HEADER_STRUCTS.items():
+        assert _ctypes_members(getattr(_lib, cls)) == header_struct_members(cname), cname
+
+
+def test_integration_stub_structs_match_the_header():
+    """INTEGRATION.md section 2 is the binding a maintainer copies: its fenced block is EXECUTED here (it dlopens the library
+    and defines the structures; the forward itself runs on the GPU tier) and its three structures are held to the header."""
+    import subprocess, sys
+    code = integration_md_stub() + """
+import json, ctypes as C
+kinds = {C.c_void_p: "ptr", C.c_int32: "i32", C.c_int64: "i64", C.c_float: "f32", C.c_size_t: "size"}
+print(json.dumps({n: [(f, kinds[t], 0) for f, t in c._fields_] for n, c in (("gvqa_graph", Graph),
+      ("gvqa_gat_conv_params", HopParams), ("gvqa_gat_dims", Dims))}))
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    for cname, members in got.items():
+        assert [tuple(m) for m in members] == header_struct_members(cname), cname
+
+
+def test_dynamic_symbols_are_the_c_abi_only():
+    """-fvisibility=hidden + GVQA_API + the linker's version script: `nm -D` shows gvqa_* and nothing else defined."""
+    import shutil, subprocess
+    from graphvqa_amd import _lib, build
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    r = subprocess.run([nm, "-D", "--defined-only", build.build()], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = [l.split()[-1] for l in r.stdout.splitlines() if l.strip()]
+    assert syms and all(s.startswith("gvqa_") for s in syms), [s for s in syms if not s.startswith("gvqa_")][:10]
+    assert set(syms) == set(_lib.PROTOTYPES), set(syms) ^ set(_lib.PROTOTYPES)
 
 
 def test_argument_validation_without_gpu():
@@ -224,3 +284,10 @@ def test_every_entry_point_rejects_bad_arguments_without_gpu():
     assert lib.gvqa_graph_edge_rows_sum(C.byref(g), 8, None, 8, None, 4, None) == E_INV      # ld_out < F
     assert lib.gvqa_graph_finalize(C.byref(_lib.Graph()), None) == E_INV
     assert lib.gvqa_prof_collect(None, None) == E_INV
+
+
+def test_package_all_lists_every_module():
+    import graphvqa_amd
+    here = os.path.dirname(graphvqa_amd.__file__)
+    mods = {f[:-3] for f in os.listdir(here) if f.endswith(".py") and f != "__init__.py"}
+    assert set(graphvqa_amd.__all__) == mods, set(graphvqa_amd.__all__) ^ mods
