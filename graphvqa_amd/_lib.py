@@ -306,8 +306,13 @@ def set_option(option: int, value: int) -> int:
     return old
 
 
-def prof_enable(on: bool):
-    check(load().gvqa_prof_enable(1 if on else 0))
+def prof_enable(on: bool, stages=None):
+    """stages: None = every stage; else an iterable of stage names (STAGES) -- only those record events (each event pair costs the
+    stream a few microseconds: a timed region keeps just the kernel it reports on)."""
+    v = 1 if on else 0
+    if on and stages:
+        v |= sum(1 << (1 + STAGES.index(s)) for s in stages)
+    check(load().gvqa_prof_enable(v))
 
 
 def prof_collect():

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
-SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip", "collate.hip", "train.hip"]
+SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "hopagg.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip", "collate.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

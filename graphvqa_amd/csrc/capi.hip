@@ -48,11 +48,12 @@ struct ProfSlot {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static unsigned g_prof_mask = ~0u;          // stages that record events (gvqa_prof_enable)
 static std::vector<ProfSlot> g_prof_live;     // recorded, not yet collected
 static std::vector<ProfSlot> g_prof_free;     // event pairs available for reuse
 
 StageTimer::StageTimer(int st, hipStream_t s) : stage(st), stream(s), slot(nullptr) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || !((g_prof_mask >> st) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfSlot ps;
     if (!g_prof_free.empty()) {
@@ -95,6 +96,7 @@ int gvqa_get_option(int option) { return gvqa::get_option(option); }
 int gvqa_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(gvqa::g_prof_mu);
     gvqa::g_prof_on = on != 0;
+    gvqa::g_prof_mask = (on & 1) && (on >> 1) ? (unsigned)(on >> 1) : ~0u;
     return GVQA_OK;
 }
 

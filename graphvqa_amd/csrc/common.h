@@ -164,6 +164,45 @@ int launch_hop2_consts(int H, int C, const float* bias, const float* bn_w, const
 size_t hop2_lds_edge_capacity(int H, bool chain);
 size_t hop_fused_lds_edge_capacity(int H);
 
+// hopagg.hip: the hop "aggregate first" (heads concatenated along K; H = 4): rows live chunk-major in HBM between hops
+struct AlphaX4Args {
+    const int32_t *group_ptr, *rowptr, *csr_src, *csr_eid, *node_graph;
+    const float* X4;            // [G][NQ][128][4]
+    const float* Vn;            // [2 H][Dn] folded attention vectors of this hop
+    const float* a_edge;        // [E, stride] edge halves of the logits (COO order), this hop's H columns
+    int64_t a_edge_stride;
+    const float* graph_term;    // NULL or [B, t_ld]: columns [C, C + H) = per-graph logit offsets
+    int64_t t_ld;
+    float* alpha_csr;           // [E, H] out, CSR slot order
+    float* alpha_out;           // NULL or [E, H] out, COO order
+    int Dn, NQ, C;
+    float slope;
+};
+struct HopAggArgs {
+    const int32_t *group_ptr, *rowptr, *csr_src, *node_graph;
+    const float* alpha_csr;     // [E, H] CSR slot order
+    const float* X4in;          // [G][NQ][128][4] input rows (also the skip rows)
+    const uint16_t* Wk;         // [NCT][NQ][2][64][8] packed weights
+    const float* binv;          // [32 NCT] inverse scales of the output columns
+    const float* epc;           // [3][epc_ld] bias | BatchNorm scale | shift per output channel (k_hop2_consts)
+    int epc_ld;
+    const float* graph_term;    // NULL or [B, t_ld]: columns [0, C) per-graph instruction term (head mean)
+    int64_t t_ld;
+    const float* gmax_in;       // [B] largest |x| per graph of the input rows
+    float* gmax_out;            // NULL or [B]: the same of the output rows
+    float* X4out;               // NULL or [G][C / 4][128][4]: output rows, chunk-major (the next hop's input)
+    float* out;                 // NULL or [N, out_ld]: output rows, row-major
+    int64_t out_ld;
+    int C, NQ, NCT, relu;
+};
+bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges);
+size_t hopagg_packed_w_bytes(int C, int Dn, int H);
+int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream);
+int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream);
+size_t alpha_x4_lds_bytes(int H, int Dn, int e_cap);
+int launch_alpha_x4(const gvqa_graph* g, int H, const AlphaX4Args& a, hipStream_t stream);
+int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream);
+
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);
 int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);
 int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t ld, const float* a, const int64_t* ia, int64_t lda,

@@ -983,6 +983,8 @@ static int weight_layout_id(int pieces, bool heads, bool hop2 = false) {
     return pieces == 0 ? -1 : (heads ? 1 : 0) | (pieces == 2 ? 2 : 0) | (heads && hop2 && pieces == 2 ? 4 : 0);
 }
 static int layout_pieces(int layout) { return layout < 0 ? 0 : (layout & 2) ? 2 : 3; }
+// bit 3: K'-concatenated two-piece weights with per-column scales (the aggregate-first hop, hopagg.hip); excludes bits 0 and 2
+constexpr int LAYOUT_AGGFIRST = 2 | 8;
 
 // Fused hop (projection + aggregation in one kernel, split3.hip): needs the split3 projection, a row-group plan (every
 // graph <= 128 nodes, intra-graph batch), H dividing 256 and the largest row group's edges within the kernel's LDS budget.
@@ -992,6 +994,33 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
            g->num_row_groups > 0 && g->row_group_ptr && (H == 1 || H == 2 || H == 4 || H == 8) && C % 4 == 0 &&
            (size_t)g->max_row_group_edges <= hop_fused_lds_edge_capacity(H) &&
            cdiv(g->num_row_groups, 2) <= 65535;                   // (grid.y of the 8-wave kernel: beyond it the unfused kernels run)
+}
+
+// The hop "aggregate first" (hopagg.hip, GVQA_OPT_HOP_FUSION = 4; taken by the default rule 3 when the batch fills the chip):
+// H = 4, C == Dn <= 512, the two-piece projection, a row-group plan with <= 1024 edges per group.  Rows travel chunk-major
+// between hops; per-hop fp32 outputs and the attention weights are served, batch-statistics BatchNorm is not.
+constexpr bool kAggFirstByDefault = false;
+static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    const int mode = opt_hop_fusion(d);
+    if (mode != 4 && mode != 3) return false;
+    const int H = d->heads, C = d->out_channels;
+    if (!(proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
+          hopagg_supported(H, C, d->node_dim, g->max_row_group_edges) &&
+          alpha_x4_lds_bytes(H, d->node_dim, g->max_row_group_edges) <= 64 * 1024))
+        return false;
+    if (mode == 3 && !kAggFirstByDefault) return false;
+    if (mode == 3) {
+        // one workgroup per row group, one resident per CU: the default rule takes it when the row groups fill the CUs in
+        // whole rounds to within 15 % (config 3: 512 groups on 256 CUs); smaller / ragged batches keep the item-granular kernels
+        static const int64_t cus = []() {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return (int64_t)n;
+        }();
+        const int64_t G = g->num_row_groups, rounds = cdiv(G, cus);
+        if (G * 100 < rounds * cus * 85) return false;
+    }
+    return true;
 }
 
 // The hop as the persistent two-workgroups-per-CU kernel of hop2.hip (GVQA_OPT_HOP_FUSION = 2): two-piece operands and the
@@ -1045,12 +1074,14 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
     W.Ve = take(K * H * d->edge_dim * sizeof(float));
     W.Gw = take(K * (C + H) * (size_t)d->ins_dim * sizeof(float));
     const int np = layout_pieces(layout);
-    W.w6_hop = layout < 0 ? 0 : (layout & 1) ? split_packed_rows_bytes(np, cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
-                                             : split_packed_bytes(np, (int64_t)(H * C), d->node_dim);
+    const bool aggw = layout >= 0 && (layout & 8);
+    W.w6_hop = layout < 0 ? 0 : aggw ? align_up(hopagg_packed_w_bytes((int)C, d->node_dim, (int)H), 256)
+                          : (layout & 1) ? split_packed_rows_bytes(np, cdiv((int64_t)C, 256 / (int64_t)H) * 8, d->node_dim)
+                                         : split_packed_bytes(np, (int64_t)(H * C), d->node_dim);
     W.w6 = take(K * W.w6_hop);
-    W.vn2h_hop = (layout >= 0 && (layout & 3) == 3) ? align_up(split_packed_bytes(2, 2 * (int64_t)H, d->node_dim), 256) : 0;
+    W.vn2h_hop = (layout >= 0 && (layout & 3) == 3 && !aggw) ? align_up(split_packed_bytes(2, 2 * (int64_t)H, d->node_dim), 256) : 0;
     W.vn2h = take(K * W.vn2h_hop);
-    W.epc_hop = (layout >= 0 && (layout & 4)) ? align_up(3 * (size_t)hop2_consts_ld((int)H, (int)C) * sizeof(float), 256) : 0;
+    W.epc_hop = (layout >= 0 && (layout & (4 | 8))) ? align_up(3 * (size_t)hop2_consts_ld((int)H, (int)C) * sizeof(float), 256) : 0;
     W.epc = take(K * W.epc_hop);
     const bool chainw = layout >= 0 && (layout & 4) && d->node_dim == d->out_channels;
     W.bc = take(chainw ? K * 4 * sizeof(float) : 0);
@@ -1061,7 +1092,7 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
 }
 
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, ipk, ipk_hop, total;   // a6b ..: chained hops
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, ipk, ipk_hop, x4a, x4b, gma, gmb, total;   // a6b ..: chained hops; x4a ..: aggregate-first hops
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
@@ -1076,7 +1107,10 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     const bool fused = g && hop_fusion_applies(g, d);
     const int np = proj_pieces(d, N, (int64_t)(H * C), d->node_dim);
     const int w_layout = weight_layout_id(np, fused, fused && hop2_applies(g, d));
-    L.Vn = take(weight_cache_layout(d, w_layout).total / sizeof(float));     // Vn | Ve | Gw | packed projection weights
+    const bool aggf = g && hopagg_applies(g, d);
+    // Vn | Ve | Gw | packed projection weights (aggregate-first batches: the larger of the two forms -- a batch-statistics forward of
+    // the same batch takes the other hop kernels)
+    L.Vn = take(std::max(weight_cache_layout(d, w_layout).total, aggf ? weight_cache_layout(d, LAYOUT_AGGFIRST).total : (size_t)0) / sizeof(float));
     L.Ve = L.Gw = L.Vn;
     L.T = take(K * B * align_up(C + H, 4));
     L.a_edge = take((size_t)E * K * H);
@@ -1095,6 +1129,11 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     const size_t ncb = chain ? (size_t)cdiv((int64_t)C, 256 / (int64_t)H) : 0;
     L.a6b = take(chain ? split_packed_rows_bytes(2, (int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float) : 0);
     L.PM = take(2 * ncb * (size_t)B);
+    {   // aggregate-first hops: the rows chunk-major (two buffers: a hop reads one, writes the other), per-graph maxima likewise
+        const size_t x4 = aggf ? (size_t)g->num_row_groups * (size_t)cdiv((int64_t)d->node_dim, 4) * 128 * 4 : 0;
+        L.x4a = take(x4); L.x4b = take(x4);
+        L.gma = take(aggf ? (size_t)B : 0); L.gmb = take(aggf ? (size_t)B : 0);
+    }
     L.Tmax = take(chain ? K * (size_t)B : 0);
     L.gscale = take(chain ? (size_t)B : 0);
     // packed instruction vectors of the K hops (two-piece graph-term product): one image of K B rows, a hop = B / 32 whole
@@ -1282,7 +1321,8 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
         for (int i = 0; i < K; ++i) {
             GVQA_REQUIRE(hops[i].lin_l_weight, GVQA_E_INVALID, "gat: hop %d has a null weight", i);
             const int np = layout_pieces(layout);
-            rc = (layout & 4) ? launch_split_pack_heads2(H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
+            rc = (layout & 8) ? launch_hopagg_pack_w(H, C, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
+                 : (layout & 4) ? launch_split_pack_heads2(H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
                  : (layout & 1) ? launch_split_pack_heads(np, H, C, 256 / H, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream)
                               : launch_split_pack(np, (int64_t)H * C, Dn, hops[i].lin_l_weight, Dn + Di, cache + W.w6 + (size_t)i * W.w6_hop, stream);
             if (rc) return rc;
@@ -1296,7 +1336,7 @@ static int prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* h
             if (rc) return rc;
         }
     }
-    if (W.epc_hop && d->node_dim == d->out_channels) {      // chained hops: bound constants (after the epilogue constants)
+    if (W.epc_hop && (layout & 4) && d->node_dim == d->out_channels) {      // chained hops: bound constants (after the epilogue constants)
         StageTimer t(GVQA_STAGE_PACK, stream);
         for (int i = 0; i < K; ++i) {
             rc = launch_hop2_bound_consts(H, C, Dn, hops[i].lin_l_weight, Dn + Di, reinterpret_cast<const float*>(cache + W.epc + (size_t)i * W.epc_hop),
@@ -1358,7 +1398,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const bool hop2 = fused && hop2_applies(g, d);
     const bool chain = hop2 && hop2_chain_capable(g, d) && !hop_out && !bn_stats_out &&    // (per-hop fp32 outputs / batch statistics need fp32 rows)
                        split_pack_groups_logits_supported(2, 2 * H, Dn);
-    const int need_layout = weight_layout_id(np, fused, hop2);
+    const bool aggf = hopagg_applies(g, d) && !bn_stats_out;          // (batch-statistics BatchNorm needs fp32 rows between the passes)
+    const int need_layout = aggf ? LAYOUT_AGGFIRST : weight_layout_id(np, fused, hop2);
     // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
     // now into the workspace (the workspace slices have exactly the cache's sub-layout)
     const WeightCacheLayout WL = weight_cache_layout(d, need_layout);
@@ -1414,6 +1455,64 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         StageTimer t(GVQA_STAGE_GRAPH_TERM, aux);
         rc = launch_rows_absmax((int64_t)K * B, C, P(L.T), Tld, P(L.Tmax), aux);
         if (rc) return rc;
+    }
+    if (aggf) {
+        // ---- aggregate-first hops (hopagg.hip): x -> chunk-major rows + per-graph maxima once, then per hop TWO launches --
+        // coefficient kernel (node logits from the chunks + segment softmax) and the hop kernel -- rows staying chunk-major.
+        if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
+        float* X4[2] = {P(L.x4a), P(L.x4b)};
+        float* GM[2] = {P(L.gma), P(L.gmb)};
+        const int NQ = (int)cdiv(Dn, 4);
+        {
+            StageTimer tp(GVQA_STAGE_PACK, stream);
+            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < K; ++i) {
+            const float* gterm = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr;
+            {
+                StageTimer t(GVQA_STAGE_ALPHA, stream);
+                AlphaX4Args ax;
+                memset(&ax, 0, sizeof(ax));
+                ax.group_ptr = g->row_group_ptr; ax.rowptr = g->rowptr; ax.csr_src = g->csr_src; ax.csr_eid = g->csr_eid; ax.node_graph = g->node_graph;
+                ax.X4 = X4[i & 1]; ax.Vn = Vn_all + (int64_t)i * 2 * H * Dn;
+                ax.a_edge = P(L.a_edge) + (int64_t)i * H; ax.a_edge_stride = (int64_t)K * H;
+                ax.graph_term = gterm; ax.t_ld = Tld;
+                ax.alpha_csr = P(L.alpha_csr); ax.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
+                ax.Dn = Dn; ax.NQ = NQ; ax.C = C; ax.slope = d->negative_slope;
+                rc = launch_alpha_x4(g, H, ax, stream);
+                if (rc) return rc;
+            }
+            {
+                StageTimer t(GVQA_STAGE_PROJ, stream);
+                HopAggArgs ha;
+                memset(&ha, 0, sizeof(ha));
+                ha.group_ptr = g->row_group_ptr; ha.rowptr = g->rowptr; ha.csr_src = g->csr_src; ha.node_graph = g->node_graph;
+                ha.alpha_csr = P(L.alpha_csr); ha.X4in = X4[i & 1];
+                const char* wk = w6 + (size_t)i * w6_hop;
+                ha.NCT = (int)cdiv(C, 32); ha.NQ = NQ; ha.C = C;
+                ha.Wk = reinterpret_cast<const uint16_t*>(wk);
+                ha.binv = reinterpret_cast<const float*>(wk + (size_t)ha.NCT * NQ * 2048);
+                ha.epc = reinterpret_cast<const float*>(wbase + WL.epc + (size_t)i * WL.epc_hop); ha.epc_ld = hop2_consts_ld(H, C);
+                ha.graph_term = gterm; ha.t_ld = Tld;
+                ha.gmax_in = GM[i & 1];
+                const bool last = i == K - 1;
+                ha.X4out = last ? nullptr : X4[(i + 1) & 1];
+                ha.gmax_out = last ? nullptr : GM[(i + 1) & 1];
+                ha.out = hop_out ? hop_out + (int64_t)i * N * C : (last ? out : nullptr);
+                ha.out_ld = C;
+                ha.relu = hops[i].bn_weight != nullptr;
+                GVQA_REQUIRE(!hops[i].bn_weight || (hops[i].bn_bias && hops[i].bn_mean && hops[i].bn_var), GVQA_E_INVALID,
+                             "gat_seq: BatchNorm needs weight, bias, running_mean and running_var");
+                rc = launch_hopagg(H, ha, g->num_row_groups, stream);
+                if (rc) return rc;
+            }
+        }
+        if (hop_out) {
+            StageTimer t(GVQA_STAGE_OTHER, stream);
+            GVQA_HIP_CHECK(hipMemcpyAsync(out, hop_out + (int64_t)(K - 1) * N * C, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        }
+        return GVQA_OK;
     }
     char* a6 = base + L.a6;
     const int ncb_chain = (int)cdiv(C, fcw);
@@ -1567,12 +1666,13 @@ int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa
 }
 
 size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout) {
-    if (!d || check_dims(d, true) || layout < -1 || layout > 7) return 0;
+    if (!d || check_dims(d, true) || layout < -1 || layout > 15) return 0;
     return weight_cache_layout(d, layout).total;
 }
 
 int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true)) return -1;
+    if (hopagg_applies(g, d)) return LAYOUT_AGGFIRST;
     const bool fused = hop_fusion_applies(g, d);
     return weight_layout_id(proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), fused, fused && hop2_applies(g, d));
 }
@@ -1582,7 +1682,7 @@ int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_par
     GVQA_REQUIRE(hops && cache, GVQA_E_INVALID, "gat_seq_prepare_weights: null argument");
     int rc = check_dims(d, true);
     if (rc) return rc;
-    GVQA_REQUIRE(layout >= -1 && layout <= 7, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1 .. 7");
+    GVQA_REQUIRE(layout >= -1 && layout <= 15, GVQA_E_INVALID, "gat_seq_prepare_weights: layout must be -1 .. 15");
     GVQA_REQUIRE(cache_bytes >= weight_cache_layout(d, layout).total, GVQA_E_WORKSPACE, "gat_seq_prepare_weights: cache too small");
     GVQA_REQUIRE((reinterpret_cast<uintptr_t>(cache) & 255) == 0, GVQA_E_INVALID, "gat_seq_prepare_weights: cache must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -1,0 +1,499 @@
+// The GAT hop "aggregate first": heads concatenated along K (gfx950).
+//
+// Same math as the fused hops of split3.hip / hop2.hip (/root/reference gat_skip.py:133,155-168,270-275), re-associated:
+//
+//     out[i, c] = (1/H) sum_h sum_{e -> i} alpha[e, h] (h W_h^T)[src_e, c]                     (project, then aggregate)
+//               = (1/H) sum_h sum_k ( sum_{e -> i} alpha[e, h] x[src_e, k] ) W[h C + c, k]     (aggregate, then project)
+//               = (1/H) sum_{k'} A'[i, k'] W'[c, k'],   k' = (k, h),  A'[i, (k, h)] = sum_{e -> i} alpha[e, h] x[src_e, k]
+//
+// -- ONE GEMM with K' = H Dn whose A operand is the attention-weighted neighbour sum, formed on the fly.  What that buys on this
+// chip: the projected features xp ([rows, H C]: a 128 KiB fp32 LDS image per row group in the other two kernels) never exist,
+// not even in LDS; the aggregation is no longer an epilogue behind the matrix-core loop (27 % of the 8-wave kernel's time,
+// run with the matrix cores idle) but ~60 VALU instructions per lane and K step INSIDE the loop, beside the other waves' MFMAs;
+// the epilogue is register -> global (scale, per-graph term, bias, skip, BatchNorm, ReLU); and a workgroup owns ALL C output
+// columns of its 128 rows, so the aggregation is computed once per row group, every weight tile is shared by all eight waves,
+// and a row group's result (per-graph maxima, rows) is complete when its workgroup ends.
+//
+//   * Workgroup = one row group (<= 128 rows, whole graphs: every neighbour row is in the tile) x all C <= 512 columns; 8 waves
+//     as 2 (64-row halves) x 4 (128-column slices), 8 accumulators of 32 x 32 per wave.  One workgroup per CU (LDS).
+//   * K step = 16 k' = KPH = 16 / H node columns x H heads.  Per step the workgroup DMAs the step's weight tiles (16 column tiles
+//     x two fp16 pieces = 32 KiB, three-stage ring) and the next x chunk (128 rows x KPH floats = 2 KiB, four-stage ring:
+//     x lives in HBM "chunk-major" -- [row group][k / KPH][128 rows][KPH] -- so a chunk is one contiguous 2 KiB read).
+//   * Producer: lane (node i, head h) of the 512 threads keeps its node's first 8 in-edges (source slot, alpha) in REGISTERS for
+//     the whole tile (they do not change from step to step; further edges come from the CSR slice in LDS) and per step forms
+//     sum_e alpha_e x[src_e, 4 columns] from the x chunk in LDS, scales it by the graph's power-of-two scale, splits it into two
+//     fp16 pieces and writes its 2 x 8 bytes straight into the MFMA A-fragment image of the NEXT step.
+//     Scale: |A'| <= max |x| over the graph (the softmax weights sum to <= 1), so the EXACT per-graph maximum of the input rows --
+//     left by the previous hop's epilogue (first hop: by the layout pass) -- anchors the two pieces; no a-priori output bound.
+//   * Weights: packed K'-concatenated, W'[c, 16 s + KPH h + kk] = W[h C + c, KPH s + kk], one power-of-two scale per OUTPUT
+//     COLUMN (not per block: a weight row far below its neighbours keeps its 22 bits).
+//
+// H = 4 only (KPH = 4: a chunk row is one float4); other head counts take the other hop kernels.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "gemm_tile.h"
+
+namespace gvqa {
+
+typedef _Float16 ha_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ha_f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HA_ROWS = 128;          // rows of a row group / tile
+constexpr int HA_DMAX = 8;            // in-edges of a node kept in registers
+constexpr int HA_ECAP = 1024;         // in-edges of a row group held in LDS (beyond the registers' 8 per node)
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weights -> K'-concatenated packed fragments.  One block per 32-channel column tile: Wk[ct][s][piece][lane][8] with lane
+// (m, khalf) holding W'[32 ct + m, 16 s + 8 khalf + e], e = 0..7, scaled by the channel's power of two; binv[c] = its inverse.
+__global__ __launch_bounds__(256) void k_hopagg_pack_w(int H, int C, int Dn, int NQ, const float* __restrict__ W, int64_t ldw,
+                                                       uint16_t* __restrict__ out, float* __restrict__ binv) {
+    __shared__ float mx_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ct = blockIdx.x, KPH = 16 / H;
+    if (tid < 32) mx_s[tid] = 0.f;
+    __syncthreads();
+    // largest magnitude of every output channel over its H weight rows: a wave per (channel, head) row, lanes over k
+    for (int rr = wave; rr < 32 * H; rr += 4) {
+        const int m = rr / H, h = rr - m * H, c = ct * 32 + m;
+        float v = 0.f;
+        if (c < C) {
+            const float* wrow = W + ((int64_t)h * C + c) * ldw;
+            for (int k = lane; k < Dn; k += 64) v = fmaxf(v, fabsf(wrow[k]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(&mx_s[m]), __float_as_uint(v));
+    }
+    __syncthreads();
+    const int m = lane & 31, khalf = lane >> 5, c = ct * 32 + m;
+    const int ex = split2h_exponent(mx_s[m]);
+    const float scale = pow2i(ex);
+    if (tid < 32) binv[ct * 32 + tid] = pow2i(-split2h_exponent(mx_s[tid]));
+    for (int s = wave; s < NQ; s += 4) {
+        ha_f16x8 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kp = 8 * khalf + e, h = kp / KPH, kk = kp - h * KPH, k = s * KPH + kk;
+            const float w = (c < C && k < Dn) ? W[((int64_t)h * C + c) * ldw + k] * scale : 0.f;
+            const _Float16 hi = (_Float16)w;
+            p0[e] = hi;
+            p1[e] = (_Float16)(w - (float)hi);
+        }
+        uint16_t* dst = out + ((int64_t)(ct * NQ + s) * 2) * 512 + lane * 8;
+        *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, p0);
+        *reinterpret_cast<uint4*>(dst + 512) = __builtin_bit_cast(uint4, p1);
+    }
+}
+
+size_t hopagg_packed_w_bytes(int C, int Dn, int H) {
+    const size_t nct = (size_t)cdiv(C, 32), nq = (size_t)cdiv(Dn, 16 / H);
+    return nct * nq * 2048 + align_up(nct * 32 * sizeof(float), 256);
+}
+
+int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream) {
+    GVQA_REQUIRE(W && packed && (H == 1 || H == 2 || H == 4 || H == 8) && C > 0 && Dn > 0, GVQA_E_INVALID, "hopagg_pack_w: bad argument");
+    const int nct = (int)cdiv(C, 32), nq = (int)cdiv(Dn, 16 / H);
+    float* binv = reinterpret_cast<float*>(static_cast<char*>(packed) + (size_t)nct * nq * 2048);
+    hipLaunchKernelGGL(k_hopagg_pack_w, dim3((unsigned)nct), dim3(256), 0, stream, H, C, Dn, nq, W, ldw, static_cast<uint16_t*>(packed), binv);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Row-major fp32 rows -> the chunk-major layout X4[group][k / 4][128 slots][4] (slots past the group's rows: zeros), and the largest
+// magnitude of every graph's rows -> gmax[B].  One block per row group; the rows go through LDS 128 columns at a time so that
+// both sides move whole lines (reads: 512 B per row; writes: a chunk = 2 KiB contiguous).
+__global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ group_ptr, const int32_t* __restrict__ node_graph, int D, int NQ,
+                                                    const float* __restrict__ X, int64_t ld, float* __restrict__ X4, float* __restrict__ gmax) {
+    __shared__ float4 slab[HA_ROWS][33];         // 32 chunks (+1: the column walk of the write phase is conflict-free)
+    __shared__ unsigned gm_s[HA_ROWS];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int ns = group_ptr[t], cnt = group_ptr[t + 1] - ns;
+    const int gf = node_graph[ns];
+    if (tid < HA_ROWS) gm_s[tid] = 0u;
+    __syncthreads();
+    float rowmax[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rowmax[u] = 0.f;
+    for (int q0 = 0; q0 < NQ; q0 += 32) {
+        // read: thread (r, p) = 16 bytes of row r; 32 threads cover 512 contiguous bytes of a row
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = u * 512 + tid, r = idx >> 5, p = idx & 31, q = q0 + p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < cnt && q < NQ) {
+                const float* src = X + (int64_t)(ns + r) * ld + q * 4;
+                if (q * 4 + 4 <= D) v = *reinterpret_cast<const float4*>(src);
+                else { v.x = src[0]; if (q * 4 + 1 < D) v.y = src[1]; if (q * 4 + 2 < D) v.z = src[2]; }
+            }
+            slab[r][p] = v;
+            rowmax[u] = fmaxf(rowmax[u], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        __syncthreads();
+        // write: thread (p, r): chunk q0 + p, slot r -- 128 consecutive threads cover a chunk's 2 KiB
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = u * 512 + tid, p = idx >> 7, r = idx & 127, q = q0 + p;
+            if (q < NQ) *reinterpret_cast<float4*>(X4 + (((int64_t)t * NQ + q) * HA_ROWS + r) * 4) = slab[r][p];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int r = (u * 512 + tid) >> 5;
+        if (r < cnt) atomicMax(&gm_s[node_graph[ns + r] - gf], __float_as_uint(rowmax[u]));
+    }
+    __syncthreads();
+    const int ngl = node_graph[ns + cnt - 1] - gf + 1;
+    if (tid < ngl) gmax[gf + tid] = __uint_as_float(gm_s[tid]);
+}
+
+int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream) {
+    GVQA_REQUIRE(g && g->num_row_groups > 0 && X && X4 && gmax && D > 0 && ld >= D && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
+                 GVQA_E_INVALID, "rows_to_x4: bad argument");
+    hipLaunchKernelGGL(k_rows_to_x4, dim3((unsigned)g->num_row_groups), dim3(512), 0, stream, g->row_group_ptr, g->node_graph, D, (int)cdiv(D, 4), X, ld,
+                       X4, gmax);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Attention coefficients of a hop whose input rows are in the chunk-major layout: node logits a_node = x . [V_l | V_r]^T from
+// the group's chunks (one coalesced pass: 4 Dn bytes per row; fp32 FMAs against the folded vectors in LDS), then the two
+// coefficient phases of k_gat_alpha_groups (gat.hip) out of LDS -- gat_skip.py:134-135,180-208.
+
+template <int H>
+__global__ __launch_bounds__(512) void k_gat_alpha_x4(AlphaX4Args a) {
+    constexpr int J = 2 * H;
+    extern __shared__ float ax_s[];                 // Vn [J][NQ * 4] | partial logits [4][128][J] | raw logits [slots][H]
+    const int tid = threadIdx.x, grp = blockIdx.x;
+    const int Kp = a.NQ * 4;
+    float* vn_s = ax_s;
+    float* part = vn_s + J * Kp;
+    float* rs = part + 4 * HA_ROWS * J;
+    const int ns = a.group_ptr[grp], cnt = a.group_ptr[grp + 1] - ns;
+    const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
+    for (int idx = tid; idx < J * Kp; idx += 512) {
+        const int j = idx / Kp, k = idx - j * Kp;
+        vn_s[idx] = k < a.Dn ? a.Vn[(int64_t)j * a.Dn + k] : 0.f;
+    }
+    __syncthreads();
+    {
+        const int r = tid & 127, p = tid >> 7;      // row slot, quarter of the chunks (a wave walks one chunk at a time: the Vn reads broadcast)
+        float acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = 0.f;
+        const float4* xp = reinterpret_cast<const float4*>(a.X4) + (int64_t)grp * a.NQ * HA_ROWS + r;
+#pragma unroll 4
+        for (int q = p; q < a.NQ; q += 4) {
+            const float4 x = xp[(int64_t)q * HA_ROWS];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(vn_s + j * Kp + q * 4);
+                acc[j] += x.x * v.x + x.y * v.y + x.z * v.z + x.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) part[(p * HA_ROWS + r) * J + j] = acc[j];
+    }
+    __syncthreads();
+    float* an_s = part;                             // [128][J] node logits (the first quarter's slots)
+    for (int it = tid; it < HA_ROWS * J; it += 512)
+        an_s[it] = (part[it] + part[HA_ROWS * J + it]) + (part[2 * HA_ROWS * J + it] + part[3 * HA_ROWS * J + it]);
+    __syncthreads();
+    for (int s = tid; s < ne; s += 512) {
+        const int src = a.csr_src[e0 + s] - ns, eid = a.csr_eid[e0 + s];
+        const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
+#pragma unroll
+        for (int h = 0; h < H; ++h) rs[s * H + h] = an_s[src * J + h] + ae[h];
+    }
+    __syncthreads();
+    for (int it = tid; it < cnt * H; it += 512) {
+        const int i = it / H, h = it - i * H, node = ns + i;
+        const int lo = a.rowptr[node] - e0, hi = a.rowptr[node + 1] - e0;
+        float ar = an_s[i * J + H + h];
+        if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[node] * a.t_ld + a.C + h];
+        float m = -INFINITY;
+        for (int s = lo; s < hi; ++s) {
+            float v = rs[s * H + h] + ar;
+            v = v > 0.f ? v : v * a.slope;
+            rs[s * H + h] = v;
+            m = fmaxf(m, v);
+        }
+        float sum = 0.f;
+        for (int s = lo; s < hi; ++s) {
+            const float ex = expf(rs[s * H + h] - m);
+            rs[s * H + h] = ex;
+            sum += ex;
+        }
+        const float den = sum + 1e-16f;
+        for (int s = lo; s < hi; ++s) {
+            const float al = rs[s * H + h] / den;
+            if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
+            a.alpha_csr[(int64_t)(e0 + s) * H + h] = al;
+        }
+    }
+}
+
+size_t alpha_x4_lds_bytes(int H, int Dn, int e_cap) {
+    return ((size_t)2 * H * cdiv(Dn, 4) * 4 + (size_t)4 * HA_ROWS * 2 * H + (size_t)e_cap * H) * sizeof(float);
+}
+
+int launch_alpha_x4(const gvqa_graph* g, int H, const AlphaX4Args& a, hipStream_t stream) {
+    GVQA_REQUIRE(g && g->num_row_groups > 0 && H == 4, GVQA_E_UNSUPPORTED, "alpha_x4: H = 4 and a row-group plan");
+    const size_t lds = alpha_x4_lds_bytes(H, a.Dn, g->max_row_group_edges);
+    GVQA_REQUIRE(lds <= 64 * 1024, GVQA_E_UNSUPPORTED, "alpha_x4: row group too large");
+    hipLaunchKernelGGL((k_gat_alpha_x4<4>), dim3((unsigned)g->num_row_groups), dim3(512), lds, stream, a);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int ha_wave_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// LDS map (bytes): weight ring 3 x 32 KiB | A' ring 2 x 8 KiB | x ring 4 x 2 KiB | CSR slice: src [ECAP] ints, alpha [ECAP][4] floats |
+// per-row: 1 / (scale H), graph id, in-degree | per-graph output maxima
+constexpr unsigned HA_BSTAGE = 16 * 2048, HA_B0 = 0, HA_A0 = 3 * HA_BSTAGE, HA_X0 = HA_A0 + 2 * 8192, HA_SRC0 = HA_X0 + 4 * 2048,
+                   HA_AL0 = HA_SRC0 + HA_ECAP * 4, HA_ROW0 = HA_AL0 + HA_ECAP * 16, HA_GM0 = HA_ROW0 + 3 * HA_ROWS * 4, HA_LDS = HA_GM0 + HA_ROWS * 4;
+static_assert(HA_LDS <= 160 * 1024, "hopagg: LDS");
+
+__global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
+    constexpr int H = 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[HA_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+    const int t = blockIdx.x;
+    const int ns = a.group_ptr[t], cnt = a.group_ptr[t + 1] - ns;
+    const int e0 = a.rowptr[ns], ne = min(a.rowptr[ns + cnt] - e0, HA_ECAP);
+    const int NQ = a.NQ, NCT = a.NCT;
+
+    // ---- DMA duties of this wave: weight units (column tile, K step) = 2 KiB (both pieces), tiles wave and wave + 8; one
+    // 256-byte slice of every x chunk
+    const uint16_t* wsrc[2];
+    bool wok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ct = wave + 8 * u;
+        wok[u] = ct < NCT;
+        wsrc[u] = a.Wk + (int64_t)(wok[u] ? ct : 0) * NQ * 1024 + lane * 8;
+    }
+    const float* xsrc = a.X4in + (int64_t)t * NQ * (HA_ROWS * 4) + wave * 64 + lane;
+    auto issue_b = [&](int s) {
+        const unsigned base = lds_base + HA_B0 + (unsigned)(s % 3) * HA_BSTAGE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (wok[u]) lds_dma16_x2(wsrc[u] + (int64_t)s * 1024, __builtin_amdgcn_readfirstlane(base + (unsigned)(wave + 8 * u) * 2048u));
+    };
+    auto issue_x = [&](int q) {
+        lds_dma4_b(xsrc + (int64_t)q * (HA_ROWS * 4), __builtin_amdgcn_readfirstlane(lds_base + HA_X0 + (unsigned)(q & 3) * 2048u + (unsigned)wave * 256u));
+    };
+    const int n_issue = 2 * ((wok[0] ? 1 : 0) + (wok[1] ? 1 : 0)) + 1;      // DMA instructions of this wave per K step (wave-uniform)
+    issue_b(0);
+    if (NQ > 1) issue_b(1);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < NQ) issue_x(q);
+    // CSR slice of the group -> LDS (edges past a node's first 8: read from here every K step)
+    {
+        const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+        for (int u = wbase; u < ne; u += 512)
+            lds_dma4_b(a.csr_src + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_SRC0 + (unsigned)u * 4u));
+        for (int u = wbase; u < ne * H; u += 512)
+            lds_dma4_b(a.alpha_csr + (int64_t)e0 * H + min(u + lane, ne * H - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_AL0 + (unsigned)u * 4u));
+    }
+
+    // ---- this lane's producer item: node i = 16 wave + a, head h = 2 hhi + hlo; its first 8 in-edges in registers
+    const int pa = (lane >> 1) & 15, hlo = lane & 1, hhi = lane >> 5;
+    const int pi = wave * 16 + pa, ph = 2 * hhi + hlo;
+    const bool p_on = pi < cnt;
+    const int plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
+    const int pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
+    int se[HA_DMAX];
+    float al[HA_DMAX];
+#pragma unroll
+    for (int e = 0; e < HA_DMAX; ++e) {
+        const int idx = max(min(plo + e, ne - 1), 0);
+        const bool on = e < pdeg;
+        se[e] = ne > 0 ? min(max(a.csr_src[e0 + idx] - ns, 0), HA_ROWS - 1) : 0;
+        const float av = ne > 0 ? a.alpha_csr[(int64_t)(e0 + idx) * H + ph] : 0.f;
+        al[e] = on ? av : 0.f;
+    }
+    const int ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);      // wave-uniform trips through the LDS slice
+    float pscale = 1.f;
+    {
+        const int g = a.node_graph[ns + min(pi, cnt - 1)];
+        const int ex = split2h_exponent(a.gmax_in[g]);
+        pscale = pow2i(ex);
+        float* row_l = reinterpret_cast<float*>(smem + HA_ROW0);
+        if (hlo == 0 && hhi == 0) {
+            row_l[pi] = p_on ? pow2i(-ex) * (1.0f / H) : 0.f;
+            reinterpret_cast<int*>(row_l)[HA_ROWS + pi] = g;
+            reinterpret_cast<int*>(row_l)[2 * HA_ROWS + pi] = pdeg;
+        }
+        if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
+    }
+    const unsigned a_wr_off = (unsigned)((pi >> 5) * 2048 + ((pi & 31) + 32 * hhi) * 16 + hlo * 8);
+    const int* src_l = reinterpret_cast<const int*>(smem + HA_SRC0);
+    const float* al_l = reinterpret_cast<const float*>(smem + HA_AL0);
+
+    // A'(q) from x chunk q -> A' slot q & 1
+    auto produce = [&](int q) {
+        const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + (q & 3) * 2048);
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        float4 xv[HA_DMAX];
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) xv[e] = xs[se[e]];
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) {
+            float4& v = (e & 1) ? v1 : v0;
+            v.x += al[e] * xv[e].x; v.y += al[e] * xv[e].y; v.z += al[e] * xv[e].z; v.w += al[e] * xv[e].w;
+        }
+        for (int e = 0; e < ovtrips; ++e) {
+            const int k = HA_DMAX + e;
+            const int idx = max(min(plo + k, plo + pdeg - 1), 0);
+            const int s = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);
+            const float w = al_l[idx * H + ph];
+            const float av = k < pdeg ? w : 0.f;
+            const float4 x = xs[s];
+            v0.x += av * x.x; v0.y += av * x.y; v0.z += av * x.z; v0.w += av * x.w;
+        }
+        const float tx = (v0.x + v1.x) * pscale, ty = (v0.y + v1.y) * pscale, tz = (v0.z + v1.z) * pscale, tw = (v0.w + v1.w) * pscale;
+        ha_f16x4 hi, lo;
+        hi[0] = (_Float16)tx; hi[1] = (_Float16)ty; hi[2] = (_Float16)tz; hi[3] = (_Float16)tw;
+        lo[0] = (_Float16)(tx - (float)hi[0]); lo[1] = (_Float16)(ty - (float)hi[1]);
+        lo[2] = (_Float16)(tz - (float)hi[2]); lo[3] = (_Float16)(tw - (float)hi[3]);
+        unsigned char* dst = smem + HA_A0 + (q & 1) * 8192 + a_wr_off;
+        *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
+        *reinterpret_cast<uint2*>(dst + 1024) = __builtin_bit_cast(uint2, lo);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // rings' first stages, CSR slice and per-row arrays are in place
+    produce(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const unsigned a_off = (unsigned)(wr * 2 * 2048 + lane * 16);
+    const unsigned b_off = (unsigned)(wc * 4 * 2048 + lane * 16);
+    for (int s = 0; s < NQ; ++s) {
+        // the slots refilled here were read out two steps ago (weights) / three (x)
+        if (s + 2 < NQ) issue_b(s + 2);
+        if (s + 3 < NQ) issue_x(s + 3);
+        const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;
+        const unsigned char* sb = smem + HA_B0 + (s % 3) * HA_BSTAGE + b_off;
+        ha_f16x8 af[2][2], bfr[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[i][p] = __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(sa + i * 2048 + p * 1024));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bfr[j][p] = __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(sb + j * 2048 + p * 1024));
+        // smallest cross terms first; weight fragment first: transposed accumulators (a lane owns 4 consecutive columns of a row)
+#define GVQA_HA_GROUP(pa_, pb_)                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[j][pb_], af[i][pa_], acc[i][j], 0, 0, 0);
+        GVQA_HA_GROUP(1, 0)
+        if (s + 1 < NQ) produce(s + 1);               // next step's operand, beside this step's products
+        GVQA_HA_GROUP(0, 1)
+        GVQA_HA_GROUP(0, 0)
+#undef GVQA_HA_GROUP
+        // this wave's DMAs of step s + 1 (issued one iteration ago) have landed, its A' writes are out; then everybody's
+        if (s + 3 < NQ) {                             // (this step's n_issue instructions may stay in flight)
+            if (n_issue == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else if (n_issue == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue, register -> global: lane (m, hh) owns columns 8 q + 4 hh + 0..3 of row m of tile (i, j)
+    const int m = lane & 31, hh = lane >> 5;
+    const float* row_l = reinterpret_cast<const float*>(smem + HA_ROW0);
+    unsigned* gm_l = reinterpret_cast<unsigned*>(smem + HA_GM0);
+    const int gf = a.node_graph[ns];
+    const int C = a.C;
+    const int CQ = C >> 2;                            // chunks of the output rows (C % 4 == 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wr * 64 + i * 32 + m;
+        const bool row_on = r < cnt;
+        const float rf = row_l[r];
+        const int g = reinterpret_cast<const int*>(row_l)[HA_ROWS + r];
+        const bool has_in = reinterpret_cast<const int*>(row_l)[2 * HA_ROWS + r] > 0;
+        const int64_t node = ns + r;
+        float vmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (wc * 4 + j) * 32 + 8 * q + 4 * hh;
+                if (c0 >= C) continue;
+                const float4 bv = *reinterpret_cast<const float4*>(a.binv + c0);
+                const float4 bi = *reinterpret_cast<const float4*>(a.epc + c0);
+                const float4 sk = *reinterpret_cast<const float4*>(a.X4in + (((int64_t)t * NQ + (c0 >> 2)) * HA_ROWS + r) * 4);
+                float4 tg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.graph_term && has_in) tg = *reinterpret_cast<const float4*>(a.graph_term + (int64_t)g * a.t_ld + c0);     // (no in-edges: empty softmax, no term)
+                float4 v;
+                v.x = acc[i][j][4 * q] * (rf * bv.x) + tg.x + bi.x + sk.x;
+                v.y = acc[i][j][4 * q + 1] * (rf * bv.y) + tg.y + bi.y + sk.y;
+                v.z = acc[i][j][4 * q + 2] * (rf * bv.z) + tg.z + bi.z + sk.z;
+                v.w = acc[i][j][4 * q + 3] * (rf * bv.w) + tg.w + bi.w + sk.w;
+                if (a.relu) {                         // torch's eval BatchNorm: y = x (w invstd) + (b - mean w invstd), then ReLU
+                    const float4 sc = *reinterpret_cast<const float4*>(a.epc + a.epc_ld + c0);
+                    const float4 sh = *reinterpret_cast<const float4*>(a.epc + 2 * a.epc_ld + c0);
+                    v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+                    v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+                }
+                if (!row_on) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.X4out) *reinterpret_cast<float4*>(a.X4out + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4) = v;
+                if (a.out && row_on) *reinterpret_cast<float4*>(a.out + node * a.out_ld + c0) = v;
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            }
+        if (a.gmax_out && row_on) atomicMax(&gm_l[g - gf], __float_as_uint(vmax));
+    }
+    if (a.gmax_out) {
+        __syncthreads();
+        const int ngl = a.node_graph[ns + cnt - 1] - gf + 1;
+        if (tid < ngl) a.gmax_out[gf + tid] = __uint_as_float(gm_l[tid]);
+    }
+}
+
+bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges) {
+    return H == 4 && C == Dn && C % 4 == 0 && C >= 32 && C <= 512 && max_row_group_edges <= HA_ECAP;
+}
+
+int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream) {
+    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.alpha_csr && a.node_graph && a.X4in && a.Wk && a.binv && a.epc && a.gmax_in &&
+                 (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
+    GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1, GVQA_E_UNSUPPORTED, "hopagg: needs C %% 4 == 0 and C <= 512");
+    if (num_groups == 0) return GVQA_OK;
+    hipLaunchKernelGGL(k_hopagg4, dim3((unsigned)num_groups), dim3(512), 0, stream, a);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+}  // namespace gvqa

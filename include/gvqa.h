@@ -705,6 +705,9 @@ enum {
     GVQA_STAGE_ALPHA = 9,      /* attention coefficients as a kernel of their own (fused-hop path) */
     GVQA_NUM_STAGES = 10
 };
+/* on = 0: off.  on = 1: every stage.  Otherwise bit 0 set and bits 1.. = a stage mask (bit 1 + s selects GVQA_STAGE_s): only
+ * those stages record events -- an event pair costs the stream ~3 us, and bench.py keeps only the dominant kernel's stage on
+ * inside its timed region (e.g. 1 | (1 << (1 + GVQA_STAGE_PROJ))). */
 GVQA_API int gvqa_prof_enable(int on);
 /* Waits for outstanding events, ADDS elapsed milliseconds / launch counts per stage into the
  * arrays (each GVQA_NUM_STAGES long) and clears the internal list. */

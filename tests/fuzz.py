@@ -31,8 +31,49 @@ def case(rng):
                 ins_scale=float(rng.choice([0.0, 1.0, 4.0])))
 
 
+STRATA = ("tiny_groups", "sparse_e_over_n_1", "hubs", "partial_k_block", "many_small", "big_graphs")
+
+
+def stratified_case(rng, fusion, stratum, K):
+    """One case of the GPU tier's stratified sweep: a given hop kernel x batch regime x hop count, everything else random.
+    The regimes are the ones the kernels' state spaces turn on -- row groups made of one to three tiny graphs (short LDS
+    sub-arrays: the round-3 defect's regime), sparse batches with E/N ~ 1 (self-loops only, or no edges on some nodes), hubs
+    (one node of every graph receives most edges: long edge loops beside empty rows), widths with a partial last k block
+    (C % 16 != 0, and widths past a column block), many small graphs per row group (per-graph scale arrays), 90-128-node graphs
+    (one graph per row group)."""
+    H = int(rng.choice([1, 2, 4, 4, 8]))
+    widths = {"partial_k_block": [4, 12, 36, 68, 100, 132, 260, 300], "big_graphs": [32, 64, 128], "many_small": [32, 64, 100, 256]}
+    C = int(rng.choice(widths.get(stratum, [32, 64, 128, 256, 304, 512])))
+    if H == 8 and C > 256:
+        C = 64
+    de = int(rng.choice([4, 16, 20]))
+    di = int(rng.choice([0, 8, 12])) if C < 256 else int(rng.choice([0, 8, 512]))
+    graphs, lo, hi, rel = {"tiny_groups": (int(rng.integers(1, 4)), 1, 12, float(rng.uniform(0.5, 1.5))),
+                           "sparse_e_over_n_1": (int(rng.integers(20, 200)), 3, 40, float(rng.uniform(0.0, 0.15))),
+                           "hubs": (int(rng.integers(2, 24)), 12, 60, float(rng.uniform(2.0, 5.0))),
+                           "partial_k_block": (int(rng.integers(4, 40)), 1, 50, float(rng.uniform(0.5, 2.5))),
+                           "many_small": (int(rng.choice([64, 130, 200, 300])), 1, 6, 1.0),
+                           "big_graphs": (int(rng.integers(1, 6)), 90, 128, float(rng.uniform(0.5, 2.0)))}[stratum]
+    return dict(H=H, C=C, K=K, de=de, di=di, graphs=graphs, lo=lo, hi=hi, rel=rel, shape=stratum, fusion=fusion, force=True,
+                layout=bool(rng.integers(0, 2)), alpha=bool(rng.integers(0, 3) == 0), hops=bool(rng.integers(0, 5) == 0),
+                seed=int(rng.integers(1, 1 << 30)), ins_scale=float(rng.choice([0.0, 1.0, 4.0])), hub=stratum == "hubs")
+
+
+def _with_hubs(gb, seed):
+    """Three quarters of every graph's relation edges redirected to the graph's first node (self-loops, sources and the COO order
+    stay): in-degrees of tens to hundreds beside rows that keep only their self-loop."""
+    ei = gb.edge_index.copy()
+    first = np.searchsorted(gb.batch, gb.batch[ei[1]])           # first node of the destination's graph
+    rel = ei[0] != ei[1]
+    pick = rel & (synth.uniform01(ei.shape[1], seed, stream=9) < 0.75)
+    ei[1, pick] = first[pick]
+    return synth.GraphBatch(edge_index=ei, batch=gb.batch, num_graphs=gb.num_graphs)
+
+
 def run(c, dev):
     gb = synth.make_graph_batch(c["graphs"], seed=c["seed"], nodes_lo=c["lo"], nodes_hi=c["hi"], rel_per_node=c["rel"])
+    if c.get("hub"):
+        gb = _with_hubs(gb, c["seed"])
     N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
     H, C, K, de, di = c["H"], c["C"], c["K"], c["de"], c["di"]
     p = synth.gat_seq_params(C, C, de, di, K, H, seed=c["seed"] % 1000 + 1)

@@ -687,6 +687,25 @@ def test_randomised_parity_sweep(dev):
     assert not bad, bad[:3]
 
 
+@pytest.mark.parametrize("stratum", ["tiny_groups", "sparse_e_over_n_1", "hubs", "partial_k_block", "many_small", "big_graphs"])
+@pytest.mark.parametrize("fusion", [0, 1, 2, 3])
+def test_stratified_parity_sweep(dev, fusion, stratum):
+    """The parity net sized to the kernels' state space: every hop kernel (0 GEMM + message passing, 1 the
+    8-wave fused kernel, 2 the persistent chained kernel, 3 the default rule) x every batch regime of tests/fuzz.STRATA x K = 1..5,
+    five random cases each = 25 cases per test, 600 in all, library products forced (size threshold 0) so that the named kernel
+    is the one that runs; each case against the oracle at 1e-4 (alpha 5e-5), twice (fresh and cached weights)."""
+    from tests.fuzz import stratified_case, run, STRATA
+    rng = np.random.default_rng(1000 * fusion + STRATA.index(stratum) + 20260930)
+    bad = []
+    for K in range(1, 6):
+        for _ in range(5):
+            c = stratified_case(rng, fusion, stratum, K)
+            ok, errs, sz = run(c, dev)
+            if not ok:
+                bad.append((c, errs, sz))
+    assert not bad, (len(bad), bad[:3])
+
+
 @pytest.mark.parametrize("fusion", [0, 1, 2])
 @pytest.mark.parametrize("H,C,di", [(4, 64, 48), (2, 300, 512), (4, 36, 20)])
 def test_instruction_terms_as_one_batched_two_piece_product(dev, fusion, H, C, di):
