@@ -18,6 +18,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
 SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "hopagg.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip", "collate.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# per-file additions.  hopagg.hip: no SLP vectorisation -- its K step interleaves scalar fp32 FMAs with MFMAs, and packed fp32 math
+# (v_pk_fma_f32, what the SLP pass makes of adjacent FMAs) costs the matrix-core stream more than two plain FMAs (MI355X_MICROARCH.md)
+EXTRA_FLAGS = {"hopagg.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -47,7 +50,7 @@ def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -194,6 +194,7 @@ struct HopAggArgs {
     float* out;                 // NULL or [N, out_ld]: output rows, row-major
     int64_t out_ld;
     int C, NQ, NCT, relu;
+    int dbg;                    // measurement build only (GVQA_HOPAGG_DEBUG): 1 no producer in the loop, 2 no weight DMA, 4 no MFMAs, 8 no fragment reads after step 0, 16 no waits / barriers, 32 no epilogue
 };
 bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges);
 size_t hopagg_packed_w_bytes(int C, int Dn, int H);

@@ -254,6 +254,25 @@ int launch_alpha_x4(const gvqa_graph* g, int H, const AlphaX4Args& a, hipStream_
 
 // ------------------------------------------------------------------------------------------------------------------------------
 
+// LDS-DMA with the global address as SGPR base + 32-bit VGPR offset (no 64-bit address registers per lane): 2 x 16 bytes per lane,
+// 1 KiB apart on both sides / 4 bytes per lane
+__device__ __forceinline__ void ha_dma16_x2(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ void ha_dma4(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 __device__ __forceinline__ int ha_wave_max(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
@@ -283,30 +302,26 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
 
     // ---- DMA duties of this wave: weight units (column tile, K step) = 2 KiB (both pieces), tiles wave and wave + 8; one
     // 256-byte slice of every x chunk
-    const uint16_t* wsrc[2];
-    bool wok[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int ct = wave + 8 * u;
-        wok[u] = ct < NCT;
-        wsrc[u] = a.Wk + (int64_t)(wok[u] ? ct : 0) * NQ * 1024 + lane * 8;
-    }
-    const float* xsrc = a.X4in + (int64_t)t * NQ * (HA_ROWS * 4) + wave * 64 + lane;
-    auto issue_b = [&](int s) {
-        const unsigned base = lds_base + HA_B0 + (unsigned)(s % 3) * HA_BSTAGE;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (wok[u]) lds_dma16_x2(wsrc[u] + (int64_t)s * 1024, __builtin_amdgcn_readfirstlane(base + (unsigned)(wave + 8 * u) * 2048u));
+    // (every wave issues the same five DMA instructions in every K step -- column tiles past the last one re-load the last tile into
+    //  their own, unused ring slot; steps past the last one re-load the last step -- so that the step is branch-free and the counted
+    //  waits are the same everywhere)
+    const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
+    const uint16_t* wbase0 = a.Wk + (int64_t)min(wave, NCT - 1) * NQ * 1024;            // (wave-uniform: SGPRs)
+    const uint16_t* wbase1 = a.Wk + (int64_t)min(wave + 8, NCT - 1) * NQ * 1024;
+    const float* xbase = a.X4in + (int64_t)t * NQ * (HA_ROWS * 4) + wave * 64;
+    auto issue_b_unit = [&](int st, int u) {           // weight unit u of step st (clamped) -> ring slot st % 3
+        ha_dma16_x2((u ? wbase1 : wbase0) + (int64_t)min(st, NQ - 1) * 1024, lane16,
+                    __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + (unsigned)(st % 3) * HA_BSTAGE + (unsigned)(wave + 8 * u) * 2048u));
     };
-    auto issue_x = [&](int q) {
-        lds_dma4_b(xsrc + (int64_t)q * (HA_ROWS * 4), __builtin_amdgcn_readfirstlane(lds_base + HA_X0 + (unsigned)(q & 3) * 2048u + (unsigned)wave * 256u));
+    auto issue_b = [&](int st) { issue_b_unit(st, 0); issue_b_unit(st, 1); };
+    auto issue_x = [&](int q) {                        // this wave's 256 bytes of x chunk q (clamped) -> ring slot q & 3
+        ha_dma4(xbase + (int64_t)min(q, NQ - 1) * (HA_ROWS * 4), lane4,
+                __builtin_amdgcn_readfirstlane(lds_base + HA_X0 + (unsigned)(q & 3) * 2048u + (unsigned)wave * 256u));
     };
-    const int n_issue = 2 * ((wok[0] ? 1 : 0) + (wok[1] ? 1 : 0)) + 1;      // DMA instructions of this wave per K step (wave-uniform)
     issue_b(0);
-    if (NQ > 1) issue_b(1);
+    issue_b(1);
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-        if (q < NQ) issue_x(q);
+    for (int q = 0; q < 3; ++q) issue_x(q);
     // CSR slice of the group -> LDS (edges past a node's first 8: read from here every K step)
     {
         const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -317,21 +332,32 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     }
 
     // ---- this lane's producer item: node i = 16 wave + a, head h = 2 hhi + hlo; its first 8 in-edges in registers
-    const int pa = (lane >> 1) & 15, hlo = lane & 1, hhi = lane >> 5;
-    const int pi = wave * 16 + pa, ph = 2 * hhi + hlo;
+    // (the four heads of a node are the four lanes of a quad: every lane fetches ONE of the node's source rows per batch of four
+    //  edges and the quad shares them through DPP -- two row reads per lane and step instead of eight; the x gathers were a quarter
+    //  of the step's LDS cycles)
+    const int pa = lane >> 2, ph = lane & 3, hlo = ph & 1, hhi = ph >> 1;
+    const int pi = wave * 16 + pa;
     const bool p_on = pi < cnt;
     const int plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
     const int pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
-    int se[HA_DMAX];
-    float al[HA_DMAX];
+    float al[HA_DMAX];                                // this head's coefficients of the node's first 8 in-edges (0 past the last)
 #pragma unroll
     for (int e = 0; e < HA_DMAX; ++e) {
         const int idx = max(min(plo + e, ne - 1), 0);
-        const bool on = e < pdeg;
-        se[e] = ne > 0 ? min(max(a.csr_src[e0 + idx] - ns, 0), HA_ROWS - 1) : 0;
         const float av = ne > 0 ? a.alpha_csr[(int64_t)(e0 + idx) * H + ph] : 0.f;
-        al[e] = on ? av : 0.f;
+        al[e] = e < pdeg ? av : 0.f;
     }
+    unsigned sep;                                     // byte offsets (slot x 16) of the chunk rows this lane fetches: edge ph | edge 4 + ph << 16
+    {
+        const int i0 = max(min(plo + ph, ne - 1), 0), i1 = max(min(plo + 4 + ph, ne - 1), 0);
+        const unsigned s0 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i0] - ns, 0), HA_ROWS - 1) * 16u : 0u;
+        const unsigned s1 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
+        sep = s0 | (s1 << 16);
+    }
+    // value of quad lane E_ (compile-time) in every lane of the quad
+#define GVQA_HA_QB(v_, E_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v_)), (E_) * 0x55, 0xf, 0xf, true))
+#define GVQA_HA_QFMA(acc_, w_, x_, E_) do { acc_.x += (w_) * GVQA_HA_QB((x_).x, E_); acc_.y += (w_) * GVQA_HA_QB((x_).y, E_); \
+                                            acc_.z += (w_) * GVQA_HA_QB((x_).z, E_); acc_.w += (w_) * GVQA_HA_QB((x_).w, E_); } while (0)
     const int ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);      // wave-uniform trips through the LDS slice
     float pscale = 1.f;
     {
@@ -350,25 +376,22 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     const int* src_l = reinterpret_cast<const int*>(smem + HA_SRC0);
     const float* al_l = reinterpret_cast<const float*>(smem + HA_AL0);
 
-    // A'(q) from x chunk q -> A' slot q & 1
+    // A'(q) from x chunk q -> A' slot q & 1 (the first chunk, ahead of the loop; inside the loop the same operations are spread
+    // between the MFMAs of a step)
     auto produce = [&](int q) {
         const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + (q & 3) * 2048);
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        float4 xv[HA_DMAX];
-#pragma unroll
-        for (int e = 0; e < HA_DMAX; ++e) xv[e] = xs[se[e]];
-#pragma unroll
-        for (int e = 0; e < HA_DMAX; ++e) {
-            float4& v = (e & 1) ? v1 : v0;
-            v.x += al[e] * xv[e].x; v.y += al[e] * xv[e].y; v.z += al[e] * xv[e].z; v.w += al[e] * xv[e].w;
-        }
+        const float4 xr0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep & 0xFFFFu));
+        const float4 xr1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));
+        GVQA_HA_QFMA(v0, al[0], xr0, 0); GVQA_HA_QFMA(v0, al[1], xr0, 1); GVQA_HA_QFMA(v0, al[2], xr0, 2); GVQA_HA_QFMA(v0, al[3], xr0, 3);
+        GVQA_HA_QFMA(v1, al[4], xr1, 0); GVQA_HA_QFMA(v1, al[5], xr1, 1); GVQA_HA_QFMA(v1, al[6], xr1, 2); GVQA_HA_QFMA(v1, al[7], xr1, 3);
         for (int e = 0; e < ovtrips; ++e) {
             const int k = HA_DMAX + e;
             const int idx = max(min(plo + k, plo + pdeg - 1), 0);
-            const int s = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);
+            const int sr = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);
             const float w = al_l[idx * H + ph];
             const float av = k < pdeg ? w : 0.f;
-            const float4 x = xs[s];
+            const float4 x = xs[sr];
             v0.x += av * x.x; v0.y += av * x.y; v0.z += av * x.z; v0.w += av * x.w;
         }
         const float tx = (v0.x + v1.x) * pscale, ty = (v0.y + v1.y) * pscale, tz = (v0.z + v1.z) * pscale, tw = (v0.w + v1.w) * pscale;
@@ -397,39 +420,117 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
 
     const unsigned a_off = (unsigned)(wr * 2 * 2048 + lane * 16);
     const unsigned b_off = (unsigned)(wc * 4 * 2048 + lane * 16);
-    for (int s = 0; s < NQ; ++s) {
-        // the slots refilled here were read out two steps ago (weights) / three (x)
-        if (s + 2 < NQ) issue_b(s + 2);
-        if (s + 3 < NQ) issue_x(s + 3);
-        const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;
-        const unsigned char* sb = smem + HA_B0 + (s % 3) * HA_BSTAGE + b_off;
-        ha_f16x8 af[2][2], bfr[4][2];
+#ifdef GVQA_PROBES
+#define GVQA_HA_DBG(bit_) (a.dbg & (bit_))
+#else
+#define GVQA_HA_DBG(bit_) false
+#endif
+    // One K step, laid out by hand.  A wave issues in order and an MFMA occupies the SIMD's matrix pipe for 32 cycles, so everything
+    // else a step needs -- 5 DMA instructions, 12 fragment reads, the producer's 8 row reads, ~70 VALU operations and 2 LDS writes --
+    // has to sit IN the gaps between this wave's MFMAs (about 4 issue slots each), not in front of or behind them.  History (us per
+    // launch at config 3): DMAs at the top of the step, producer as a block between the piece products 468; branch-free step with
+    // the DMAs between MFMA groups and the producer interleaved (sched_group_barrier) 452; fragment reads issued just ahead of the
+    // product that needs them instead of 20 reads in front of the first MFMA 436; then the ROTATION below.
+    //   All eight waves leave the step's barrier together and every one needs LDS data before its first MFMA: ~300 cycles of idle
+    // pipe per step, 20 % of it.  So the third piece product of step s - 1 (a hi x b hi: registers only) is issued AFTER the barrier
+    // that opens step s, under the reads of step s -- which costs a second register set for the b-hi fragments (16 registers; the
+    // loop body is written for two steps with the sets swapped).
+    ha_f16x8 afh[2], afl[2], bh0[4], bh1[4], bl[4];      // a hi / a lo fragments, b hi (two sets), b lo
+#define GVQA_HA_MFX(i_, j_, a_, b_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[j_], a_[i_], acc[i_][j_], 0, 0, 0)
+#define GVQA_HA_MF4(i_, a_, b_) do { if (!GVQA_HA_DBG(4)) { GVQA_HA_MFX(i_, 0, a_, b_); GVQA_HA_MFX(i_, 1, a_, b_); GVQA_HA_MFX(i_, 2, a_, b_); GVQA_HA_MFX(i_, 3, a_, b_); } } while (0)
+#define GVQA_HA_FMA4(acc_, w_, x_) do { acc_.x += (w_) * (x_).x; acc_.y += (w_) * (x_).y; acc_.z += (w_) * (x_).z; acc_.w += (w_) * (x_).w; } while (0)
+    auto rd = [&](const unsigned char* p_) { return __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(p_)); };
+    // step s with its b-hi fragments read into BN_ while BO_ still feeds the previous step's last product
+#define GVQA_HA_STEP(s_, BO_, BN_)                                                                                          \
+    {                                                                                                                       \
+        const int s = (s_);                                                                                                 \
+        const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + ((s + 1) & 3) * 2048);                            \
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                        \
+        if (ovtrips > 0) {                                                                                                  \
+            for (int e = 0; e < ovtrips; ++e) {                                                                             \
+                const int k = HA_DMAX + e;                                                                                  \
+                const int idx = max(min(plo + k, plo + pdeg - 1), 0);                                                       \
+                const int sr = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);                                                   \
+                const float w = al_l[idx * H + ph];                                                                         \
+                const float av = k < pdeg ? w : 0.f;                                                                        \
+                const float4 x = xs[sr];                                                                                    \
+                GVQA_HA_FMA4(v0, av, x);                                                                                    \
+            }                                                                                                               \
+        }                                                                                                                   \
+        /* ---- from here to the barrier ONE basic block ---- */                                                            \
+        const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;                                                    \
+        const unsigned char* sb = smem + HA_B0 + (s % 3) * HA_BSTAGE + b_off;                                               \
+        float4 xr;                                                                                                          \
+        afl[0] = rd(sa + 1024); afl[1] = rd(sa + 2048 + 1024);                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) BN_[j] = rd(sb + j * 2048);                                           \
+        /* (a hi, b hi) of the PREVIOUS step: registers only, under the reads above */                                      \
+        if (s > 0) { GVQA_HA_MF4(0, afh, BO_); GVQA_HA_MF4(1, afh, BO_); }                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (!GVQA_HA_DBG(2)) issue_b_unit(s + 2, 0);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        /* (a lo, b hi); a hi, b lo and the first four x rows travel under it */                                            \
+        GVQA_HA_MF4(0, afl, BN_); GVQA_HA_MF4(1, afl, BN_);                                                                 \
+        afh[0] = rd(sa); afh[1] = rd(sa + 2048);                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bl[j] = rd(sb + j * 2048 + 1024);                                     \
+        xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep & 0xFFFFu));                \
+        _Pragma("unroll") for (int z = 0; z < 4; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        if (!GVQA_HA_DBG(2)) issue_b_unit(s + 2, 1);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        /* (a hi, b lo) with the producer: 8 x (4 FMAs), the second four x rows re-using xa */                              \
+        GVQA_HA_MF4(0, afh, bl);                                                                                            \
+        if (!GVQA_HA_DBG(1)) { GVQA_HA_QFMA(v0, al[0], xr, 0); GVQA_HA_QFMA(v0, al[1], xr, 1); GVQA_HA_QFMA(v0, al[2], xr, 2); GVQA_HA_QFMA(v0, al[3], xr, 3); } \
+        _Pragma("unroll") for (int z = 0; z < 4; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        issue_x(s + 3);                                                                                                     \
+        xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        GVQA_HA_MF4(1, afh, bl);                                                                                            \
+        if (!GVQA_HA_DBG(1)) {                                                                                              \
+            GVQA_HA_QFMA(v0, al[4], xr, 0); GVQA_HA_QFMA(v0, al[5], xr, 1); GVQA_HA_QFMA(v0, al[6], xr, 2); GVQA_HA_QFMA(v0, al[7], xr, 3); \
+            /* scale by the graph's power of two, split into two fp16 pieces, 2 x 8 bytes into the A-fragment image of step s + 1 */ \
+            const float psc = s + 1 < NQ ? pscale : 0.f;                                                                    \
+            const float tx = v0.x * psc, ty = v0.y * psc, tz = v0.z * psc, tw = v0.w * psc;                                 \
+            ha_f16x4 hi, lo;                                                                                                \
+            hi[0] = (_Float16)tx; hi[1] = (_Float16)ty; hi[2] = (_Float16)tz; hi[3] = (_Float16)tw;                         \
+            lo[0] = (_Float16)(tx - (float)hi[0]); lo[1] = (_Float16)(ty - (float)hi[1]);                                   \
+            lo[2] = (_Float16)(tz - (float)hi[2]); lo[3] = (_Float16)(tw - (float)hi[3]);                                   \
+            unsigned char* dst = smem + HA_A0 + ((s + 1) & 1) * 8192 + a_wr_off;      /* (last step: a free slot, never read) */ \
+            *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);                                                 \
+            *reinterpret_cast<uint2*>(dst + 1024) = __builtin_bit_cast(uint2, lo);                                          \
+        }                                                                                                                   \
+        _Pragma("unroll") for (int z = 0; z < 4; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 13, 0); } \
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
+        /* this wave's DMAs of step s + 1 (issued one step ago) have landed, its A' writes are out; then everybody's */     \
+        if (!GVQA_HA_DBG(16)) {                                                                                             \
+            asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
+            __builtin_amdgcn_s_barrier();                                                                                   \
+        }                                                                                                                   \
+    }
+    // (an odd number of steps runs one more with an all-zero A operand -- the producer's scale is 0 past the last chunk, the weight
+    //  DMA re-loads the last step's tiles -- so that the two-step body needs no tail variant)
+    for (int sq = 0; sq < NQ; sq += 2) {
+        GVQA_HA_STEP(sq, bh1, bh0)
+        GVQA_HA_STEP(sq + 1, bh0, bh1)
+    }
+    GVQA_HA_MF4(0, afh, bh1); GVQA_HA_MF4(1, afh, bh1);      // the last step's (a hi, b hi)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (the clamped re-loads of the last steps)
+#undef GVQA_HA_STEP
+#undef GVQA_HA_MFX
+#undef GVQA_HA_MF4
+
+#ifdef GVQA_PROBES
+    if (a.dbg & 32) {                                 // (measurement: no epilogue; the accumulators kept live)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) af[i][p] = __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(sa + i * 2048 + p * 1024));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) bfr[j][p] = __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(sb + j * 2048 + p * 1024));
-        // smallest cross terms first; weight fragment first: transposed accumulators (a lane owns 4 consecutive columns of a row)
-#define GVQA_HA_GROUP(pa_, pb_)                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                  \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfr[j][pb_], af[i][pa_], acc[i][j], 0, 0, 0);
-        GVQA_HA_GROUP(1, 0)
-        if (s + 1 < NQ) produce(s + 1);               // next step's operand, beside this step's products
-        GVQA_HA_GROUP(0, 1)
-        GVQA_HA_GROUP(0, 0)
-#undef GVQA_HA_GROUP
-        // this wave's DMAs of step s + 1 (issued one iteration ago) have landed, its A' writes are out; then everybody's
-        if (s + 3 < NQ) {                             // (this step's n_issue instructions may stay in flight)
-            if (n_issue == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-            else if (n_issue == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
     }
-
+#endif
     // ---- epilogue, register -> global: lane (m, hh) owns columns 8 q + 4 hh + 0..3 of row m of tile (i, j)
     const int m = lane & 31, hh = lane >> 5;
     const float* row_l = reinterpret_cast<const float*>(smem + HA_ROW0);
@@ -491,6 +592,14 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
                  (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
     GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1, GVQA_E_UNSUPPORTED, "hopagg: needs C %% 4 == 0 and C <= 512");
     if (num_groups == 0) return GVQA_OK;
+#ifdef GVQA_PROBES
+    static const int dbg = []() { const char* v = getenv("GVQA_HOPAGG_DEBUG"); return v ? atoi(v) : 0; }();
+    HopAggArgs b = a;
+    b.dbg = dbg;
+    hipLaunchKernelGGL(k_hopagg4, dim3((unsigned)num_groups), dim3(512), 0, stream, b);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+#endif
     hipLaunchKernelGGL(k_hopagg4, dim3((unsigned)num_groups), dim3(512), 0, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
