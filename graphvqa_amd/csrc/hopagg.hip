@@ -288,12 +288,17 @@ constexpr unsigned HA_BSTAGE = 16 * 2048, HA_B0 = 0, HA_A0 = 3 * HA_BSTAGE, HA_X
                    HA_AL0 = HA_SRC0 + HA_ECAP * 4, HA_ROW0 = HA_AL0 + HA_ECAP * 16, HA_GM0 = HA_ROW0 + 3 * HA_ROWS * 4, HA_LDS = HA_GM0 + HA_ROWS * 4;
 static_assert(HA_LDS <= 160 * 1024, "hopagg: LDS");
 
+// WR x WC waves, RT row tiles x TN column tiles of 32 x 32 per wave: <2, 4, 2, 4> covers 512 columns (config 3: d = 512), <4, 2, 1, 5>
+// 320 (the reference's real width, d = 300: ten column tiles, no empty MFMA columns beyond the 20 that pad 300 to 320).
+template <int WR, int WC, int RT, int TN>
 __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
+    static_assert(WR * WC == 8 && WR * RT == 4 && WC * TN <= 16, "hopagg: eight waves over 128 rows and at most 16 column tiles");
     constexpr int H = 4;
+    constexpr int NM = RT * TN;                       // MFMAs of one piece product per wave
     __shared__ __attribute__((aligned(1024))) unsigned char smem[HA_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WC, wc = wave % WC;
     const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
     const int t = blockIdx.x;
     const int ns = a.group_ptr[t], cnt = a.group_ptr[t + 1] - ns;
@@ -404,11 +409,11 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
         *reinterpret_cast<uint2*>(dst + 1024) = __builtin_bit_cast(uint2, lo);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[RT][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -418,8 +423,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const unsigned a_off = (unsigned)(wr * 2 * 2048 + lane * 16);
-    const unsigned b_off = (unsigned)(wc * 4 * 2048 + lane * 16);
+    const unsigned a_off = (unsigned)(wr * RT * 2048 + lane * 16);
+    const unsigned b_off = (unsigned)(wc * TN * 2048 + lane * 16);
 #ifdef GVQA_PROBES
 #define GVQA_HA_DBG(bit_) (a.dbg & (bit_))
 #else
@@ -435,9 +440,11 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     // pipe per step, 20 % of it.  So the third piece product of step s - 1 (a hi x b hi: registers only) is issued AFTER the barrier
     // that opens step s, under the reads of step s -- which costs a second register set for the b-hi fragments (16 registers; the
     // loop body is written for two steps with the sets swapped).
-    ha_f16x8 afh[2], afl[2], bh0[4], bh1[4], bl[4];      // a hi / a lo fragments, b hi (two sets), b lo
-#define GVQA_HA_MFX(i_, j_, a_, b_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[j_], a_[i_], acc[i_][j_], 0, 0, 0)
-#define GVQA_HA_MF4(i_, a_, b_) do { if (!GVQA_HA_DBG(4)) { GVQA_HA_MFX(i_, 0, a_, b_); GVQA_HA_MFX(i_, 1, a_, b_); GVQA_HA_MFX(i_, 2, a_, b_); GVQA_HA_MFX(i_, 3, a_, b_); } } while (0)
+    ha_f16x8 afh[RT], afl[RT], bh0[TN], bh1[TN], bl[TN];      // a hi / a lo fragments, b hi (two sets), b lo
+    // products n = lo .. hi - 1 of a piece product (n -> row tile n / TN, column tile n % TN)
+#define GVQA_HA_MFR(lo_, hi_, a_, b_) do { if (!GVQA_HA_DBG(4)) { _Pragma("unroll") for (int n_ = (lo_); n_ < (hi_); ++n_)                  \
+        acc[n_ / TN][n_ % TN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[n_ % TN], a_[n_ / TN], acc[n_ / TN][n_ % TN], 0, 0, 0); } } while (0)
+    constexpr int NH = NM / 2;                        // the (a hi, b lo) product is issued in two parts around the x DMA
 #define GVQA_HA_FMA4(acc_, w_, x_) do { acc_.x += (w_) * (x_).x; acc_.y += (w_) * (x_).y; acc_.z += (w_) * (x_).z; acc_.w += (w_) * (x_).w; } while (0)
     auto rd = [&](const unsigned char* p_) { return __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(p_)); };
     // step s with its b-hi fragments read into BN_ while BO_ still feeds the previous step's last product
@@ -461,34 +468,34 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
         const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;                                                    \
         const unsigned char* sb = smem + HA_B0 + (s % 3) * HA_BSTAGE + b_off;                                               \
         float4 xr;                                                                                                          \
-        afl[0] = rd(sa + 1024); afl[1] = rd(sa + 2048 + 1024);                                                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) BN_[j] = rd(sb + j * 2048);                                           \
+        _Pragma("unroll") for (int i = 0; i < RT; ++i) afl[i] = rd(sa + i * 2048 + 1024);                                   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) BN_[j] = rd(sb + j * 2048);                                          \
         /* (a hi, b hi) of the PREVIOUS step: registers only, under the reads above */                                      \
-        if (s > 0) { GVQA_HA_MF4(0, afh, BO_); GVQA_HA_MF4(1, afh, BO_); }                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                                  \
+        if (s > 0) GVQA_HA_MFR(0, NM, afh, BO_);                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, RT + TN, 0);                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         if (!GVQA_HA_DBG(2)) issue_b_unit(s + 2, 0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a lo, b hi); a hi, b lo and the first four x rows travel under it */                                            \
-        GVQA_HA_MF4(0, afl, BN_); GVQA_HA_MF4(1, afl, BN_);                                                                 \
-        afh[0] = rd(sa); afh[1] = rd(sa + 2048);                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) bl[j] = rd(sb + j * 2048 + 1024);                                     \
+        GVQA_HA_MFR(0, NM, afl, BN_);                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < RT; ++i) afh[i] = rd(sa + i * 2048);                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bl[j] = rd(sb + j * 2048 + 1024);                                    \
         xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep & 0xFFFFu));                \
-        _Pragma("unroll") for (int z = 0; z < 4; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                                  \
+        _Pragma("unroll") for (int z = 0; z < (RT + TN + 2) / 2; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - (RT + TN + 2) / 2, 0);                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         if (!GVQA_HA_DBG(2)) issue_b_unit(s + 2, 1);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a hi, b lo) with the producer: 8 x (4 FMAs), the second four x rows re-using xa */                              \
-        GVQA_HA_MF4(0, afh, bl);                                                                                            \
+        GVQA_HA_MFR(0, NH, afh, bl);                                                                                        \
         if (!GVQA_HA_DBG(1)) { GVQA_HA_QFMA(v0, al[0], xr, 0); GVQA_HA_QFMA(v0, al[1], xr, 1); GVQA_HA_QFMA(v0, al[2], xr, 2); GVQA_HA_QFMA(v0, al[3], xr, 3); } \
-        _Pragma("unroll") for (int z = 0; z < 4; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); } \
+        _Pragma("unroll") for (int z = 0; z < NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 32 / NH, 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         issue_x(s + 3);                                                                                                     \
         xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        GVQA_HA_MF4(1, afh, bl);                                                                                            \
+        GVQA_HA_MFR(NH, NM, afh, bl);                                                                                       \
         if (!GVQA_HA_DBG(1)) {                                                                                              \
             GVQA_HA_QFMA(v0, al[4], xr, 0); GVQA_HA_QFMA(v0, al[5], xr, 1); GVQA_HA_QFMA(v0, al[6], xr, 2); GVQA_HA_QFMA(v0, al[7], xr, 3); \
             /* scale by the graph's power of two, split into two fp16 pieces, 2 x 8 bytes into the A-fragment image of step s + 1 */ \
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
             *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);                                                 \
             *reinterpret_cast<uint2*>(dst + 1024) = __builtin_bit_cast(uint2, lo);                                          \
         }                                                                                                                   \
-        _Pragma("unroll") for (int z = 0; z < 4; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 13, 0); } \
+        _Pragma("unroll") for (int z = 0; z < NM - NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (52 + NM - NH - 1) / (NM - NH), 0); } \
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
         /* this wave's DMAs of step s + 1 (issued one step ago) have landed, its A' writes are out; then everybody's */     \
         if (!GVQA_HA_DBG(16)) {                                                                                             \
@@ -516,18 +523,21 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
         GVQA_HA_STEP(sq, bh1, bh0)
         GVQA_HA_STEP(sq + 1, bh0, bh1)
     }
-    GVQA_HA_MF4(0, afh, bh1); GVQA_HA_MF4(1, afh, bh1);      // the last step's (a hi, b hi)
+    GVQA_HA_MFR(0, NM, afh, bh1);                    // the last step's (a hi, b hi)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (the clamped re-loads of the last steps)
 #undef GVQA_HA_STEP
-#undef GVQA_HA_MFX
-#undef GVQA_HA_MF4
+#undef GVQA_HA_MFR
 
 #ifdef GVQA_PROBES
     if (a.dbg & 32) {                                 // (measurement: no epilogue; the accumulators kept live)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < TN; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)          /* (host pass: a "v" constraint on a value of dependent type silently voids the kernel's stub) */
+                asm volatile("" ::"v"(acc[i][j]));
+#endif
+            }
         return;
     }
 #endif
@@ -539,8 +549,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     const int C = a.C;
     const int CQ = C >> 2;                            // chunks of the output rows (C % 4 == 0)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wr * 64 + i * 32 + m;
+    for (int i = 0; i < RT; ++i) {
+        const int r = (wr * RT + i) * 32 + m;
         const bool row_on = r < cnt;
         const float rf = row_l[r];
         const int g = reinterpret_cast<const int*>(row_l)[HA_ROWS + r];
@@ -548,10 +558,10 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
         const int64_t node = ns + r;
         float vmax = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c0 = (wc * 4 + j) * 32 + 8 * q + 4 * hh;
+                const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
                 if (c0 >= C) continue;
                 const float4 bv = *reinterpret_cast<const float4*>(a.binv + c0);
                 const float4 bi = *reinterpret_cast<const float4*>(a.epc + c0);
@@ -596,11 +606,13 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
     static const int dbg = []() { const char* v = getenv("GVQA_HOPAGG_DEBUG"); return v ? atoi(v) : 0; }();
     HopAggArgs b = a;
     b.dbg = dbg;
-    hipLaunchKernelGGL(k_hopagg4, dim3((unsigned)num_groups), dim3(512), 0, stream, b);
+    if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5>), dim3((unsigned)num_groups), dim3(512), 0, stream, b);
+    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4>), dim3((unsigned)num_groups), dim3(512), 0, stream, b);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 #endif
-    hipLaunchKernelGGL(k_hopagg4, dim3((unsigned)num_groups), dim3(512), 0, stream, a);
+    if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5>), dim3((unsigned)num_groups), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4>), dim3((unsigned)num_groups), dim3(512), 0, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

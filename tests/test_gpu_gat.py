@@ -706,6 +706,79 @@ def test_stratified_parity_sweep(dev, fusion, stratum):
     assert not bad, (len(bad), bad[:3])
 
 
+@pytest.mark.parametrize("stratum", ["tiny_groups", "sparse_e_over_n_1", "hubs", "partial_k_block", "many_small", "big_graphs"])
+def test_aggregate_first_hop_parity_sweep(dev, stratum):
+    """GVQA_OPT_HOP_FUSION = 4, the aggregate-first hop kernel (csrc/hopagg.hip: heads concatenated along K, the attention-weighted
+    neighbour sum formed inside the matrix-core loop, rows chunk-major between hops, per-output-column weight scales): H = 4 cases
+    of every batch regime x K = 1..5, three cases each, against the oracle at 1e-4 (alpha 5e-5); widths 32..512 take the kernel
+    (both wave layouts: <= 320 and <= 512 columns), narrower ones its fallback.  The kernel must actually have run."""
+    from tests.fuzz import stratified_case, run, STRATA
+    from graphvqa_amd import _lib
+    rng = np.random.default_rng(4000 + STRATA.index(stratum))
+    bad, ran = [], 0
+    for K in range(1, 6):
+        for rep in range(3):
+            c = stratified_case(rng, 4, stratum, K)
+            c["H"] = 4
+            if rep == 0:
+                c["C"] = [512, 300, 64, 320, 128][K - 1]          # every K once on a wide width
+                c["di"] = 8
+            if c["C"] % 4:
+                c["C"] = 64
+            _lib.prof_enable(True); _lib.prof_collect()
+            ok, errs, sz = run(c, dev)
+            pr = _lib.prof_collect(); _lib.prof_enable(False)
+            if c["C"] >= 32:
+                assert pr["mp"][1] == 0 and pr["proj"][1] == 2 * K and pr["node_logit"][1] == 0, (c, pr)      # 2 forwards: K hop kernels each, nothing unfused
+                ran += 1
+            if not ok:
+                bad.append((c, errs, sz))
+    assert ran >= 10 and not bad, (ran, len(bad), bad[:3])
+
+
+@pytest.mark.parametrize("fusion", [1, 2, 4])
+def test_weight_rows_spanning_2_to_the_24_inside_one_column_block(dev, fusion):
+    """VERDICT r03 #6, the dynamic range of split2h's weight scales.  The 8-wave and the persistent fused kernels share ONE
+    power-of-two scale per 256-row column block of the packed weights: a row 2^-k below its block's largest keeps 22 - max(0, k - 16)
+    significant bits, i.e. an ABSOLUTE error <= 2^-38 of the block's largest row whatever k (the second fp16 piece goes subnormal, it
+    does not vanish); the aggregate-first kernel (4) scales every output column by itself.  Here every fifth output channel's weight
+    rows are scaled by 2^-24 (low pieces deep in the fp16 subnormals) and the following BatchNorm amplifies exactly those channels
+    by 2^12 (weight 4096, running variance 1: a 'checkpoint' that restores the small channels' range) -- the worst case for a
+    shared block scale.  All three kernels must stay within 1e-4 of the fp64 oracle on every hop's output."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    H, C, K, de, di = 4, 64, 3, 8, 12
+    gb = synth.make_graph_batch(40, seed=91, nodes_lo=8, nodes_hi=30, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=92)
+    tiny = np.arange(0, C, 5)
+    for i in range(K):
+        w = p[f"convs.{i}.lin_l.weight"].copy()          # [H C, Dn + Di]
+        for h in range(H):
+            w[h * C + tiny] *= np.float32(2.0 ** -24)
+        p[f"convs.{i}.lin_l.weight"] = w
+        p[f"convs.{i}.lin_r.weight"] = w
+        if i < K - 1:
+            g = p[f"bns.{i}.weight"].copy()
+            g[tiny] = 4096.0
+            p[f"bns.{i}.weight"] = g
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.0, gat_heads=H), p, dev)
+    m.hop_fusion = fusion
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        out, _, hops = m(t(x, device=dev), t(gb.edge_index, device=dev), t(ea, device=dev), t(ins, device=dev), t(gb.batch, device=dev),
+                         return_hops=True)
+        out2 = m(t(x, device=dev), t(gb.edge_index, device=dev), t(ea, device=dev), t(ins, device=dev), t(gb.batch, device=dev))
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    ref, hs, _ = R.gat_seq(t(x, torch.float64), t(gb.edge_index), t(ea, torch.float64), t(ins, torch.float64), t(gb.batch),
+                           tparams(p, torch.float64), heads=H, return_all=True)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxabs(hops, torch.stack(hs)) < TOL * scale and maxabs(out, ref) < TOL * scale and maxabs(out2, ref) < TOL * scale
+
+
 @pytest.mark.parametrize("fusion", [0, 1, 2])
 @pytest.mark.parametrize("H,C,di", [(4, 64, 48), (2, 300, 512), (4, 36, 20)])
 def test_instruction_terms_as_one_batched_two_piece_product(dev, fusion, H, C, di):
