@@ -212,6 +212,8 @@ __device__ __forceinline__ float4 mp_epilogue(const MpArgs& a, float4 r, int nod
 // the DMA queue early): CSR, alpha and the per-channel epilogue constants all live in LDS.
 // grid = B.  dynamic LDS = [alpha e_cap*H][src e_cap][rowptr n_cap+1][consts 4*C][2 stage buffers].
 // ----------------------------------------------------------------------------------------------
+// quads (4 slots) of a graph's padded edge table: every node rounds up to whole quads (<= 3 pad slots each) + one all-zero quad
+__host__ __device__ inline int mp_padded_quads(int e_cap, int n_cap) { return (e_cap + 3 * n_cap) / 4 + 2; }
 constexpr int MP_THREADS = 512;  // 8 waves: more LDS-latency hiding per resident graph
 constexpr int MP_ITEMS = 4;      // float4 accumulators per thread
 
@@ -236,11 +238,23 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t off_src = (size_t)a.e_cap * H * 4;
     const size_t off_row = (off_src + (size_t)a.e_cap * 4 + 15) & ~(size_t)15;
-    const size_t off_cst = (off_row + (size_t)(a.n_cap + 1) * 4 + 15) & ~(size_t)15;
+    // padded edge table (built once per graph, read by every stage): every node's in-edge list padded to whole QUADS -- 4 slots --
+    // with zero-weight entries, coefficients head-major, so that a trip of the aggregation loop is two 16-byte LDS reads (4 source
+    // rows, 4 coefficients of this stage's head) + 4 row reads + 16 FMAs and nothing else (before: 12 scalar LDS reads, clamps,
+    // masks and address arithmetic per trip -- ~56 VALU instructions for 16 FMAs).  The last quad is an all-zero one: lanes whose
+    // node has fewer quads than the wave's longest read it instead (wave-uniform trip count, no divergence).
+    const int EPQ = mp_padded_quads(a.e_cap, a.n_cap);
+    const size_t off_ps = (off_row + (size_t)(a.n_cap + 1) * 4 + 15) & ~(size_t)15;
+    const size_t off_ap = (off_ps + (size_t)(a.n_cap + 1) * 4 + 15) & ~(size_t)15;
+    const size_t off_sq = off_ap + (size_t)H * EPQ * 16;
+    const size_t off_cst = off_sq + (size_t)EPQ * 16;
     const size_t off_buf = off_cst + (size_t)5 * a.C * 4;
     float* alpha_s = reinterpret_cast<float*>(smem);
     int* src_l = reinterpret_cast<int*>(smem + off_src);
     int* rowp_l = reinterpret_cast<int*>(smem + off_row);
+    int* pst_l = reinterpret_cast<int*>(smem + off_ps);         // [tn + 1] first quad of node i's padded list
+    float* alpha_p = reinterpret_cast<float*>(smem + off_ap);   // [H][4 EPQ]
+    int* srcq = reinterpret_cast<int*>(smem + off_sq);          // [4 EPQ] local source row of every padded slot
     float* cst = reinterpret_cast<float*>(smem + off_cst);      // [pbar | bias | scale | shift | gscale][C]
     // stage buffers hold whole DMA rounds of MP_THREADS units
     const size_t buf_bytes = (((size_t)a.n_cap * (a.cw >> 2) + MP_THREADS - 1) / MP_THREADS) * MP_THREADS * 16;
@@ -326,6 +340,23 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         cst[3 * C + c] = sh;
         cst[4 * C + c] = a.graph_scale ? a.graph_scale[(int64_t)g * a.gs_ld + c] : 1.f;
     }
+    for (int u = tid; u < (H + 1) * EPQ; u += MP_THREADS)      // padded table: all slots zero weight / row 0 first (alpha_p | srcq are contiguous)
+        reinterpret_cast<float4*>(alpha_p)[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tid < 64) {     // quad starts: exclusive scan of ceil(deg / 4) over the graph's nodes (one wave: chunks per lane, then a wave scan)
+        const int per = (tn + 63) >> 6, b0 = min(tid * per, tn), b1 = min(b0 + per, tn);
+        int sum = 0;
+        for (int i = b0; i < b1; ++i) sum += (rowp_l[i + 1] - rowp_l[i] + 3) >> 2;
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o, 64);
+            if (tid >= o) inc += v;
+        }
+        int run = inc - sum;
+        for (int i = b0; i < b1; ++i) { pst_l[i] = run; run += (rowp_l[i + 1] - rowp_l[i] + 3) >> 2; }
+        if (tid == 63) pst_l[tn] = inc;
+    }
     __syncthreads();
     // ---- leaky-relu + softmax over the incoming edges of each (node, head) ----
     for (int it = tid; it < (GVQA_MP_DBG(2) ? 0 : tn * H); it += MP_THREADS) {
@@ -350,7 +381,9 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
             float al = alpha_s[s * H + h] / den;
             if (a.alpha_out && part == 0) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
             if (a.alpha_mask) al *= a.alpha_mask[(int64_t)a.csr_eid[e0 + s] * H + h];
-            alpha_s[s * H + h] = al;
+            const int ps = 4 * pst_l[i] + (s - lo);            // the slot of this edge in the padded table
+            alpha_p[h * 4 * EPQ + ps] = al;
+            if (h == 0) srcq[ps] = src_l[s];
         }
     }
 
@@ -374,17 +407,18 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     // Per-item row extents and the wave-uniform trip count of the 4-wide edge loop are the same in
     // every stage: computed once per graph.  (Wave-uniform trips + branch-free body: a divergent
     // loop costs ~8 scalar instructions of exec-mask handling per trip.)
-    int it_lo[ITEMS], it_hi[ITEMS], it_trips[ITEMS];
+    int it_q0[ITEMS], it_own[ITEMS], it_trips[ITEMS];       // first quad / own quads / the wave's longest list, per item
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();           // rowp_l / alpha_s complete before they are read below
+    __builtin_amdgcn_s_barrier();           // the padded table is complete before it is read below
+    const int zq = EPQ - 1;                 // the all-zero quad
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const int i = i_base + k * i_step;
         const bool valid = q < q4cap && i < tn;
         const int ii = min(i, tn - 1);
-        it_lo[k] = valid ? rowp_l[ii] : 0;
-        it_hi[k] = valid ? rowp_l[ii + 1] : 0;
-        int trips = (it_hi[k] - it_lo[k] + 3) >> 2;
+        it_q0[k] = valid ? pst_l[ii] : zq;
+        it_own[k] = valid ? pst_l[ii + 1] - pst_l[ii] : 0;
+        int trips = it_own[k];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
         it_trips[k] = GVQA_MP_DBG(1) ? 0 : __builtin_amdgcn_readfirstlane(trips);
@@ -429,30 +463,21 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         const bool lane_on = q < q4c;
         const int qq = lane_on ? q : 0;
         if (j < H) {
+            const int4* sq4 = reinterpret_cast<const int4*>(srcq);
+            const float4* ap4 = reinterpret_cast<const float4*>(alpha_p) + j * EPQ;       // this stage's head
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
-                const int lo = it_lo[k], hi = it_hi[k], trips = it_trips[k];
+                const int q0 = it_q0[k], own = it_own[k], trips = it_trips[k];
                 float4 s4 = acc[k];
                 for (int tr = 0; tr < trips; ++tr) {
-                    const int s = lo + tr * 4;
-                    int sl[4];
-                    float al[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {      // clamped index, zero weight past the end of the row
-                        const int idx = max(min(s + e, hi - 1), 0);
-                        sl[e] = src_l[idx];
-                        // (read unconditionally, then masked by a multiply: written as a select, hipcc predicates the READ -- an exec-mask
-                        //  save / branch / restore per edge, the bulk of this loop's scalar instructions)
-                        al[e] = alpha_s[idx * H + j] * ((s + e < hi) ? 1.f : 0.f);
-                    }
-                    float4 v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = buf4[sl[e] * q4c + qq];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s4.x += al[e] * v[e].x; s4.y += al[e] * v[e].y;
-                        s4.z += al[e] * v[e].z; s4.w += al[e] * v[e].w;
-                    }
+                    const int pq = tr < own ? q0 + tr : zq;     // (past this node's list: the all-zero quad)
+                    const int4 sl = sq4[pq];
+                    const float4 al = ap4[pq];
+                    const float4 v0 = buf4[sl.x * q4c + qq], v1 = buf4[sl.y * q4c + qq], v2 = buf4[sl.z * q4c + qq], v3 = buf4[sl.w * q4c + qq];
+                    s4.x += al.x * v0.x; s4.y += al.x * v0.y; s4.z += al.x * v0.z; s4.w += al.x * v0.w;
+                    s4.x += al.y * v1.x; s4.y += al.y * v1.y; s4.z += al.y * v1.z; s4.w += al.y * v1.w;
+                    s4.x += al.z * v2.x; s4.y += al.z * v2.y; s4.z += al.z * v2.z; s4.w += al.z * v2.w;
+                    s4.x += al.w * v3.x; s4.y += al.w * v3.y; s4.z += al.w * v3.z; s4.w += al.w * v3.w;
                 }
                 acc[k] = s4;
             }
@@ -469,7 +494,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
             for (int k = 0; k < ITEMS; ++k) {
                 const int i = i_base + k * i_step;
                 if (i < tn) {
-                    const bool has_edges = rowp_l[i + 1] > rowp_l[i];
+                    const bool has_edges = it_own[k] > 0;
                     float4 r = make_float4(acc[k].x * inv_h, acc[k].y * inv_h, acc[k].z * inv_h, acc[k].w * inv_h);
                     if (a.graph_scale) { r.x *= gs.x; r.y *= gs.y; r.z *= gs.z; r.w *= gs.w; }
                     if (has_edges) { r.x += pb.x; r.y += pb.y; r.z += pb.z; r.w += pb.w; }
@@ -792,6 +817,8 @@ static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, 
     size_t off = e_cap * H * 4;
     off = align_up(off + e_cap * 4, 16);
     off = align_up(off + (n_cap + 1) * 4, 16);
+    off = align_up(off + (n_cap + 1) * 4, 16);                                      // quad starts
+    off += (size_t)(H + 1) * (size_t)mp_padded_quads((int)e_cap, (int)n_cap) * 16;  // padded coefficients (head-major) + source rows
     off += (size_t)5 * C * 4;
     return off + (size_t)nbuf * align_up(n_cap * (size_t)(cw / 4), MP_THREADS) * 16;
 }
