@@ -127,6 +127,18 @@ struct FusedHopArgs {
     int H, C, cw;               // cw = 256 / H channels of every head per column block
     int e_cap;                  // LDS capacity in edges per row group
     float bn_eps;
+    // chained hops on the 8-wave kernel (k_linear_split3<..., EPI = 2, ..., CHN = 1>; all NULL / 0 otherwise): the skip rows are read
+    // back from the packed INPUT operand, the output leaves as the NEXT hop's packed operand (hop2.hip does the same)
+    const uint16_t* ch_apk;     // the packed input rows (= the A operand), for the skip connection
+    const float* ch_a_inv;      // [128 G] their inverse scales
+    uint16_t* ch_pnext;         // NULL (last hop: fp32 rows to `out`) or the next hop's packed operand
+    float* ch_a_inv_next;       // [128 G] its inverse scales (written here on the first hop, by the coefficient kernel afterwards)
+    const float* ch_gscale;     // NULL (first hop: scales from a bound, decided in the kernel) or [B] per-graph output scales
+    float* ch_pmout;            // [ncb][B] per-graph output maxima by column block
+    const float* ch_tmax;       // NULL or [B] largest |instruction term| per graph
+    const float* ch_bc;         // [4] bound constants of this hop (launch_hop2_bound_consts)
+    const int32_t* ch_graph_ptr;
+    int ch_B, ch_KB;
     int xcd_cols;               // column blocks per XCD of the workgroup -> tile map (1: plain launch order)
     int debug;                  // measurement aid (GVQA_FUSED_DEBUG bit mask): 1 no row image, 2 no aggregation, 4 no store, 8 no epilogue at all
 };
@@ -139,7 +151,11 @@ bool split_pack_groups_logits_supported(int np, int J, int64_t K);
 int launch_split_pack_groups(int np, int num_groups, const int32_t* group_ptr, int64_t K, const float* X, int64_t ld, void* packed,
                              const float* Vn, int J, float* a_node, hipStream_t stream, const void* Vn_packed = nullptr);
 int launch_split_pack_heads(int np, int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
-int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream);
+// cd != NULL (two-piece operands, H = 4): chained hop, as launch_hop2's
+struct Hop2ChainDesc;
+int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream,
+                           const Hop2ChainDesc* cd = nullptr);
+size_t hop_fused_chain_lds_edge_capacity(int H);
 // hop2.hip: the same hop as a persistent kernel, two 4-wave workgroups per CU (two-piece operands, half-interleaved weights)
 int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 // cd != NULL: chained hop -- skip rows come out of the packed input; with cd->Pnext the output leaves as the next hop's packed

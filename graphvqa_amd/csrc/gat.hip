@@ -1050,6 +1050,22 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     return true;
 }
 
+// Chained hops on the 8-WAVE kernel (launch_hop_fused_split with a chain descriptor): a hop writes the next hop's packed operand
+// from its epilogue, as the persistent kernel's chained form does, on the kernel whose launches are the shorter ones (round 4, same
+// box: 391 vs 415 us per hop at config 3, forward 2.40 vs 2.51 ms; config 2's d = 300 batch 0.72 -> 0.69 ms; a 256-graph shard
+// loses its 12 us pack pass per hop).  H = 4 -- the head-interleaved weight rows then ARE the half-interleaved ones of the persistent
+// kernel: one cache layout, id 7, serves both.  Shape conditions (the batch-level ones are hop_fusion_applies'):
+static bool chain8_shape_ok(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    // (below ~128 row groups every launch of a hop is latency-bound and the chained coefficient kernel -- it reads the packed rows
+    //  through the matrix cores -- costs more than the pack pass it replaces: 0.428 vs 0.413 ms on a 256-graph shard; GVQA_OPT_HOP_FUSION
+    //  = 1 / 2 ask for a kernel explicitly and chain regardless)
+    if (opt_hop_fusion(d) == 3 && g->num_row_groups < 128) return false;
+    return d->heads == 4 && d->node_dim == d->out_channels &&
+           proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
+           (size_t)g->max_row_group_edges <= hop_fused_chain_lds_edge_capacity(d->heads) &&
+           split_pack_groups_logits_supported(2, 2 * d->heads, d->node_dim);
+}
+
 // The hop as the persistent two-workgroups-per-CU kernel of hop2.hip (GVQA_OPT_HOP_FUSION = 2): two-piece operands and the
 // largest row group's CSR slice within that kernel's 16 KiB region; otherwise the 8-wave fused kernel runs.
 static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
@@ -1065,6 +1081,7 @@ static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
             return (int64_t)2 * n;
         }();
         if ((int64_t)g->num_row_groups * cdiv(d->out_channels, 256 / d->heads) < 6 * slots) return false;
+        if (chain8_shape_ok(g, d)) return false;          // the chained 8-wave kernel is the faster of the two wherever it applies
     }
     return hop_fusion_applies(g, d) &&
            proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
@@ -1079,6 +1096,10 @@ static bool hop2_chain_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
 #endif
     return hop2_applies(g, d) && d->node_dim == d->out_channels &&
            (size_t)g->max_row_group_edges <= hop2_lds_edge_capacity(d->heads, true);
+}
+
+static bool fused_chain8_capable(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    return hop_fusion_applies(g, d) && !hop2_applies(g, d) && chain8_shape_ok(g, d);
 }
 
 // ---- weight cache: everything a forward derives from the PARAMETERS alone (folded attention vectors Vn / Ve, per-graph
@@ -1133,7 +1154,8 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     const size_t K = d->num_hops, H = d->heads, C = d->out_channels;
     const bool fused = g && hop_fusion_applies(g, d);
     const int np = proj_pieces(d, N, (int64_t)(H * C), d->node_dim);
-    const int w_layout = weight_layout_id(np, fused, fused && hop2_applies(g, d));
+    const bool chain8 = fused && fused_chain8_capable(g, d);
+    const int w_layout = weight_layout_id(np, fused, fused && (hop2_applies(g, d) || chain8));
     const bool aggf = g && hopagg_applies(g, d);
     // Vn | Ve | Gw | packed projection weights (aggregate-first batches: the larger of the two forms -- a batch-statistics forward of
     // the same batch takes the other hop kernels)
@@ -1152,7 +1174,7 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     else if (np) L.a6 = take(split_packed_bytes(np, N, d->node_dim) / sizeof(float));
     else L.a6 = off;
     L.w6 = L.Vn;
-    const bool chain = fused && hop2_chain_capable(g, d);
+    const bool chain = fused && (hop2_chain_capable(g, d) || chain8);
     const size_t ncb = chain ? (size_t)cdiv((int64_t)C, 256 / (int64_t)H) : 0;
     L.a6b = take(chain ? split_packed_rows_bytes(2, (int64_t)g->num_row_groups * 4, d->node_dim) / sizeof(float) : 0);
     L.PM = take(2 * ncb * (size_t)B);
@@ -1423,10 +1445,11 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const bool fused = hop_fusion_applies(g, d);
     const int fcw = 256 / H;                                   // channels of every head per column block of the fused hop
     const bool hop2 = fused && hop2_applies(g, d);
-    const bool chain = hop2 && hop2_chain_capable(g, d) && !hop_out && !bn_stats_out &&    // (per-hop fp32 outputs / batch statistics need fp32 rows)
+    const bool chain8_ok = fused && fused_chain8_capable(g, d);        // (decides the cache layout: must not depend on the outputs asked for)
+    const bool chain = ((hop2 && hop2_chain_capable(g, d)) || chain8_ok) && !hop_out && !bn_stats_out &&    // (per-hop fp32 outputs / batch statistics need fp32 rows)
                        split_pack_groups_logits_supported(2, 2 * H, Dn);
     const bool aggf = hopagg_applies(g, d) && !bn_stats_out;          // (batch-statistics BatchNorm needs fp32 rows between the passes)
-    const int need_layout = aggf ? LAYOUT_AGGFIRST : weight_layout_id(np, fused, hop2);
+    const int need_layout = aggf ? LAYOUT_AGGFIRST : weight_layout_id(np, fused, hop2 || chain8_ok);
     // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
     // now into the workspace (the workspace slices have exactly the cache's sub-layout)
     const WeightCacheLayout WL = weight_cache_layout(d, need_layout);
@@ -1629,7 +1652,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 }
                 rc = hop2 ? launch_hop2(Dn, a6, w6 + (size_t)i * w6_hop, f, reinterpret_cast<const float*>(wbase + WL.epc + (size_t)i * WL.epc_hop),
                                         chain ? &cd : nullptr, stream)
-                          : launch_hop_fused_split(np, Dn, a6, w6 + (size_t)i * w6_hop, f, stream);
+                          : launch_hop_fused_split(np, Dn, a6, w6 + (size_t)i * w6_hop, f, stream, chain ? &cd : nullptr);
                 if (rc) return rc;
             }
             if (train_bn) {
@@ -1701,7 +1724,8 @@ int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true)) return -1;
     if (hopagg_applies(g, d)) return LAYOUT_AGGFIRST;
     const bool fused = hop_fusion_applies(g, d);
-    return weight_layout_id(proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), fused, fused && hop2_applies(g, d));
+    return weight_layout_id(proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim), fused,
+                            fused && (hop2_applies(g, d) || fused_chain8_capable(g, d)));
 }
 
 int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,

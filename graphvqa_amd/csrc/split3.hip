@@ -127,7 +127,9 @@ __device__ __forceinline__ void keep_live(const f32x16& v) {
 // block's C stores fall under its neighbours' main loops instead of every CU storing at the same time.
 // NP: pieces per operand value -- 3: bf16 x 3 (six products), 2: scaled fp16 x 2 (three products; a_inv / b_inv = the rows'
 // inverse power-of-two scales, applied to the accumulators before anything else in every epilogue)
-template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3, int PIPE = 0, int KS = 1>
+// CHN = 1 (EPI = 2, NP = 2): chained hops -- skip rows out of the packed input, output as the next hop's packed operand + per-graph
+// maxima (the epilogue of hop2.hip's CHAIN form on this kernel's 256 x 256 tile: no pack pass between hops)
+template <int WM, int WN, int TM, int TN, int NBUF, bool ILV, bool PRIO, bool NOSTORE, int STAG = 0, int EPI = 0, int FH = 0, int NP = 3, int PIPE = 0, int KS = 1, int CHN = 0>
 __global__ __launch_bounds__(64 * WM * WN, (160 * 1024 / (NBUF * (WM * TM + WN * TN) * NP * 1024)) * WM * WN / 4)
 void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int rtA,
                                                                const uint16_t* __restrict__ Bpk, int rtB, LinearEpilogue ep,
@@ -145,6 +147,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     static_assert(NBUF * STAGE * KS <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static_assert(KS == 1 || (KS == 2 && NP == 2 && NBUF == 2 && !PIPE), "two K steps per stage: two-piece operands, two stages");
     static_assert(EPI != 2 || (WM == 2 && WN == 4 && TM == 4 && TN == 2), "the fused-hop epilogue is written for the 256 x 256 tile");
+    static_assert(CHN == 0 || (EPI == 2 && NP == 2 && FH == 4), "chained epilogue: fused hop, two-piece operands, H = 4");
+    constexpr bool CH = CHN != 0;
+    constexpr unsigned CH_TAIL = 160 * 1024 - 3072;    // (CH) per group: inverse scales of the input slots | output scales by graph | output maxima by graph
     __shared__ __attribute__((aligned(1024))) unsigned char smem[EPI == 2 ? 160 * 1024 : NBUF * STAGE * KS];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -222,7 +227,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     // 1's in [128, 144 KiB), filled while group 0 is aggregated; otherwise one region at 128 KiB is used twice.
     const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63);
     const int reg_words = al_off + ((fh.e_cap * Hh + 63) & ~63);
-    const bool two_regions = EPI == 2 && 2 * reg_words * 4 <= 32 * 1024;
+    const bool two_regions = EPI == 2 && (CH ? reg_words * 4 <= 13 * 1024 : 2 * reg_words * 4 <= 32 * 1024);      // (CH: the last 3 KiB are taken)
     // a thread of the epilogue owns CV adjacent channel quads (8 channels when the head slice is >= 64 wide: the edge loop is
     // issue-bound, and its index / coefficient / address work is then shared by twice the FMAs) of `items` rows
     constexpr int CV = (EPI == 2 && q4 >= 16) ? 2 : 1;
@@ -286,6 +291,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     constexpr int MAXIT = 4;
     constexpr int items = (128 << lqv) / NTH;                 // rows per thread: 128 (q4 / CV) / 512
     constexpr bool pre = items <= MAXIT;
+    static_assert(!CH || pre, "chained epilogue: rows per thread within the prefetch window");
     int ord[2][MAXIT];
     if constexpr (EPI == 2 && pre) {
 #pragma unroll
@@ -527,7 +533,21 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     const int slot = (tid >> lqv) + k * (NTH >> lqv);
                     const bool on = k < items && slot < cnt;
                     const int node = ns + (on ? ord[gi][k] : 0);
-                    gid[k] = fh.graph_term ? fh.node_graph[node] : 0;
+                    gid[k] = (CH || fh.graph_term) ? fh.node_graph[node] : 0;
+                }
+            }
+            // (CH) this group's input-slot scales and cleared output maxima -> LDS tail; first / number of graph ids of the group
+            [[maybe_unused]] float* rinv_l = reinterpret_cast<float*>(smem + CH_TAIL + gi * 1536);
+            [[maybe_unused]] float* gscl_l = rinv_l + 128;
+            [[maybe_unused]] unsigned* gmax_l = reinterpret_cast<unsigned*>(rinv_l + 256);
+            [[maybe_unused]] int gf = 0, ngl = 0;
+            [[maybe_unused]] const int grp = bm * 2 + gi;
+            [[maybe_unused]] const bool chain_out = CH && fh.ch_pnext != nullptr;
+            if constexpr (CH) {
+                if (live) {
+                    gf = fh.node_graph[ns];
+                    ngl = fh.node_graph[ns + cnt - 1] - gf + 1;
+                    if (tid < 128) { rinv_l[tid] = fh.ch_a_inv[grp * 128 + tid]; gmax_l[tid] = 0u; }
                 }
             }
             if (live && wr == gi && !GVQA_FH_DBG(1)) {
@@ -547,6 +567,25 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs (and prefetches) have landed
             __syncthreads();
+            if constexpr (CH) {
+                // first hop of a chain: the output rows' power-of-two scale per graph from an upper bound of their magnitudes (hop2.hip):
+                //   |out| <= max|BN scale| (M (max L1 norm of a weight row + 1) + max|instruction term| + max|bias|) + max|BN shift|,
+                // M = 2^14 / (smallest input scale of the graph's rows); later hops get their scales from the coefficient kernel
+                if (live && chain_out && !fh.ch_gscale) {       // (block-uniform)
+                    if (tid < ngl) {
+                        const int g = gf + tid;
+                        const int r0 = max(fh.ch_graph_ptr[g] - ns, 0), r1 = min(fh.ch_graph_ptr[g + 1] - ns, cnt);
+                        float M = 0.f;
+                        for (int r = r0; r < r1; ++r) M = fmaxf(M, rinv_l[r]);
+                        M *= 16384.f;
+                        const float tm = fh.ch_tmax ? fh.ch_tmax[g] : 0.f;
+                        const float bound = (fh.ch_bc[1] * (M * (fh.ch_bc[0] + 1.f) + tm + fh.ch_bc[3]) + fh.ch_bc[2]) * 1.001f;
+                        gscl_l[tid] = pow2i(split2h_exponent(bound));
+                    }
+                    __syncthreads();
+                    if (tid < 128) fh.ch_a_inv_next[grp * 128 + tid] = tid < cnt ? 1.0f / gscl_l[fh.node_graph[ns + tid] - gf] : 1.f;
+                }
+            }
             if (live) {
                 const int* rp_l = reinterpret_cast<const int*>(smem + region_base);
                 const int* src_l = rp_l + src_off;
@@ -561,17 +600,33 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     float4 pb[CV];
 #pragma unroll
                     for (int v = 0; v < CV; ++v) pb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    [[maybe_unused]] int gq = 0;
+                    if constexpr (CH) gq = have ? gq_pre : fh.node_graph[node];
                     if (fh.graph_term && hi > lo) {           // nodes without in-edges get no instruction term (empty softmax)
-                        const int gq = have ? gq_pre : fh.node_graph[node];
+                        if constexpr (!CH) gq = have ? gq_pre : fh.node_graph[node];
 #pragma unroll
                         for (int v = 0; v < CV; ++v)
                             if (c_ok[v]) pb[v] = *reinterpret_cast<const float4*>(fh.graph_term + (int64_t)gq * fh.t_ld + c + 4 * v);
                     }
                     float4 sq[CV];                            // skip row segment: on its way from here, consumed after the edge loop
+                    // (CH) ... out of the packed input operand: channels [c, c + 8) of slot i are lane (i & 31) + 32 ((c >> 3) & 1) of
+                    // k block c >> 4 -- 16 bytes per piece; (p1 + p2) / scale is the value the projection itself saw
+                    [[maybe_unused]] uint4 sk1 = make_uint4(0u, 0u, 0u, 0u), sk2 = sk1;
+                    [[maybe_unused]] float gsc_pre = 1.f;
+                    if constexpr (CH) {
+                        static_assert(!CH || CV == 2, "chained epilogue: 8 channels per thread");
+                        if (c < fh.C) {
+                            const uint16_t* pp = fh.ch_apk + ((int64_t)((grp * 4 + (i >> 5)) * fh.ch_KB + (c >> 4)) * 2) * 512 + ((i & 31) + 32 * ((c >> 3) & 1)) * 8;
+                            sk1 = *reinterpret_cast<const uint4*>(pp);
+                            sk2 = *reinterpret_cast<const uint4*>(pp + 512);
+                        }
+                        if (chain_out && fh.ch_gscale) gsc_pre = fh.ch_gscale[gq];
+                    } else {
 #pragma unroll
-                    for (int v = 0; v < CV; ++v)
-                        sq[v] = (fh.skip && c_ok[v]) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int v = 0; v < CV; ++v)
+                            sq[v] = (fh.skip && c_ok[v]) ? *reinterpret_cast<const float4*>(fh.skip + (int64_t)node * fh.skip_ld + c + 4 * v)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                     // EB edges per trip, every LDS read of a trip issued before its FMAs; the trip count is made wave-uniform
                     // (clamped index, zero weight past the end of the row): a divergent, dependent-load loop was 4x slower
                     constexpr int EB = (8 / (Hh * CV)) > 0 ? 8 / (Hh * CV) : 1;      // 8 row reads (32 VGPRs) in flight per trip
@@ -628,12 +683,18 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                                     t.z += al[e][h] * v[e][h][w].z; t.w += al[e][h] * v[e][h][w].w;
                                 }
                     }
+                    [[maybe_unused]] float4 rr[CV];
 #pragma unroll
                     for (int w = 0; w < CV; ++w) {
                         float4 r = make_float4((a4[w].x + b4[w].x) * inv_h + pb[w].x, (a4[w].y + b4[w].y) * inv_h + pb[w].y,
                                                (a4[w].z + b4[w].z) * inv_h + pb[w].z, (a4[w].w + b4[w].w) * inv_h + pb[w].w);
                         r.x += bi[w].x; r.y += bi[w].y; r.z += bi[w].z; r.w += bi[w].w;
-                        if (fh.skip && c_ok[w]) {
+                        if constexpr (CH) {
+                            const f16x8_t h1 = __builtin_bit_cast(f16x8_t, sk1), h2 = __builtin_bit_cast(f16x8_t, sk2);
+                            const float rs = rinv_l[i];
+                            r.x += ((float)h1[4 * w] + (float)h2[4 * w]) * rs; r.y += ((float)h1[4 * w + 1] + (float)h2[4 * w + 1]) * rs;
+                            r.z += ((float)h1[4 * w + 2] + (float)h2[4 * w + 2]) * rs; r.w += ((float)h1[4 * w + 3] + (float)h2[4 * w + 3]) * rs;
+                        } else if (fh.skip && c_ok[w]) {
                             const float4 s4 = sq[w];
                             r.x += s4.x; r.y += s4.y; r.z += s4.z; r.w += s4.w;
                         }
@@ -641,7 +702,31 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                             r.x = fmaxf(r.x * sc[w].x + sh[w].x, 0.f); r.y = fmaxf(r.y * sc[w].y + sh[w].y, 0.f);
                             r.z = fmaxf(r.z * sc[w].z + sh[w].z, 0.f); r.w = fmaxf(r.w * sc[w].w + sh[w].w, 0.f);
                         }
-                        if (row_on && c_ok[w] && !GVQA_FH_DBG(4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
+                        if (CH && chain_out) rr[w] = (row_on && c_ok[w]) ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+                        else if (row_on && c_ok[w] && !GVQA_FH_DBG(4)) *reinterpret_cast<float4*>(fh.out + (int64_t)node * fh.out_ld + c + 4 * w) = r;
+                    }
+                    if constexpr (CH) {
+                        if (chain_out && (c >> 4) < fh.ch_KB) {   // (channels >= C inside the last k block: the operand's zero padding)
+                            // the segment leaves as its 16 bytes of the next hop's two operand fragments: slot (rows past the group's end
+                            // write their zeros at their own slot), k block c >> 4, lane (slot & 31) + 32 ((c >> 3) & 1)
+                            const int orow_i = row_on ? i : slot;
+                            const float scl = row_on ? (fh.ch_gscale ? gsc_pre : gscl_l[gq - gf]) : 1.f;
+                            const float vv[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
+                            f16x8_t p0, p1;
+                            float mxv = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float xsc = vv[e] * scl;
+                                const _Float16 hi16 = (_Float16)xsc;
+                                p0[e] = hi16;
+                                p1[e] = (_Float16)(xsc - (float)hi16);
+                                mxv = fmaxf(mxv, fabsf(vv[e]));
+                            }
+                            uint16_t* dstp = fh.ch_pnext + ((int64_t)((grp * 4 + (orow_i >> 5)) * fh.ch_KB + (c >> 4)) * 2) * 512 + ((orow_i & 31) + 32 * ((c >> 3) & 1)) * 8;
+                            *reinterpret_cast<uint4*>(dstp) = __builtin_bit_cast(uint4, p0);
+                            *reinterpret_cast<uint4*>(dstp + 512) = __builtin_bit_cast(uint4, p1);
+                            if (row_on) atomicMax(&gmax_l[gq - gf], __float_as_uint(mxv));      // (bit patterns of non-negative floats order like integers)
+                        }
                     }
                 };
                 // (whole waves enter `process`: its trip count is a wave-wide maximum; rows past the group's end are masked inside)
@@ -650,6 +735,11 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     for (int k = 0; k < MAXIT; ++k) {          // static indices: the prefetched operands stay in registers
                         const int slot = (tid >> lqv) + k * (NTH >> lqv);
                         if (k < items && __builtin_amdgcn_readfirstlane(slot - (lane >> lqv)) < cnt) process(slot, ord[gi][k], true, gid[k]);
+                        else if (CH && chain_out && k < items && (c >> 4) < fh.ch_KB) {       // a wave of padding slots: zero pieces
+                            uint16_t* dstp = fh.ch_pnext + ((int64_t)((grp * 4 + (slot >> 5)) * fh.ch_KB + (c >> 4)) * 2) * 512 + ((slot & 31) + 32 * ((c >> 3) & 1)) * 8;
+                            *reinterpret_cast<uint4*>(dstp) = make_uint4(0u, 0u, 0u, 0u);
+                            *reinterpret_cast<uint4*>(dstp + 512) = make_uint4(0u, 0u, 0u, 0u);
+                        }
                     }
                 } else {
                     for (int idx0 = __builtin_amdgcn_readfirstlane(tid & ~63); idx0 < (cnt << lqv); idx0 += NTH)
@@ -657,6 +747,12 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                         const int slot = (idx0 + lane) >> lqv;
                         process(slot, (fh.row_order && slot < cnt) ? fh.row_order[ns + slot] : slot, false, 0);
                     }
+                }
+            }
+            if constexpr (CH) {        // the group's per-graph output maxima of this column block: they anchor the next hop's scales
+                if (live && chain_out) {    // (block-uniform)
+                    __syncthreads();
+                    if (tid < ngl) fh.ch_pmout[(int64_t)bn * fh.ch_B + gf + tid] = __uint_as_float(gmax_l[tid]);
                 }
             }
         }
@@ -1422,8 +1518,9 @@ int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, in
 
 // edges of one row group the fused epilogue can hold in LDS beside the 128 KiB row image
 size_t hop_fused_lds_edge_capacity(int H) { return (size_t)(8192 - 192 - 128) / (size_t)(H + 1); }      // 32 KiB of words, padded sub-arrays
+size_t hop_fused_chain_lds_edge_capacity(int H) { return (size_t)(8192 - 768 - 192 - 128) / (size_t)(H + 1); }      // (3 KiB of the 32 hold the chain's per-group arrays)
 
-int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream) {
+int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream, const Hop2ChainDesc* cd) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "hop_fused: 2 or 3 pieces");
     GVQA_REQUIRE(Apk && Bpk && f.out && f.group_ptr && f.rowptr && f.csr_src && f.alpha_csr && f.node_graph, GVQA_E_INVALID,
                  "hop_fused: null operand");
@@ -1450,6 +1547,26 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
     }
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, rtA, KB) : nullptr;
     const float* b_inv = np == 2 ? split2h_inv_scales(Bpk, rtB, KB) : nullptr;
+    if (cd) {       // chained hop (hop2.hip's protocol on this kernel): skip rows out of the packed input, output as the next hop's operand
+        GVQA_REQUIRE(np == 2 && f.H == 4 && K == f.C && cd->bc && cd->graph_ptr && (!cd->Pnext || cd->PMout) && (cd->Pnext || f.out), GVQA_E_INVALID,
+                     "hop_fused: a chained hop needs two-piece operands, H = 4, node_dim == out_channels and its side arrays");
+        GVQA_REQUIRE((size_t)f.e_cap <= hop_fused_chain_lds_edge_capacity(f.H), GVQA_E_UNSUPPORTED, "hop_fused: row group has too many edges for a chained hop");
+        f2.ch_apk = static_cast<const uint16_t*>(Apk);
+        f2.ch_a_inv = a_inv;
+        f2.ch_pnext = static_cast<uint16_t*>(cd->Pnext);
+        f2.ch_a_inv_next = cd->Pnext ? reinterpret_cast<float*>(static_cast<char*>(cd->Pnext) + (size_t)f.num_groups * 4 * KB * 2048) : nullptr;
+        f2.ch_gscale = cd->gscale; f2.ch_pmout = cd->PMout; f2.ch_tmax = cd->Tmax; f2.ch_bc = cd->bc; f2.ch_graph_ptr = cd->graph_ptr;
+        f2.ch_B = cd->B; f2.ch_KB = KB;
+#define GVQA_FUSED_CHAIN(NBUF_, KS_)                                                                                            \
+        hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, 4, 2, 0, KS_, 1>), grid, dim3(512), 0, stream, \
+                           f.num_groups * 128, ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), \
+                           rtB, LinearEpilogue{}, nullptr, (int64_t)0, 0, f2, a_inv, b_inv)
+        if ((KB & 1) == 0) GVQA_FUSED_CHAIN(2, 2);
+        else GVQA_FUSED_CHAIN(4, 1);
+#undef GVQA_FUSED_CHAIN
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
     // (the read-ahead main loop, PIPE, gains 3 % in the plain GEMM and nothing here: 317 us either way for the main loop alone)
 #define GVQA_FUSED_LAUNCH(H_, NBUF_, NP_) GVQA_FUSED_LAUNCH_K(H_, NBUF_, NP_, 1)
 #define GVQA_FUSED_LAUNCH_K(H_, NBUF_, NP_, KS_)                                                                                \

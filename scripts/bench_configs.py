@@ -19,16 +19,21 @@ tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 dev = torch.device("cuda:0")
 
 
-def timed(fn, warmup=3, steps=10):
+def timed(fn, warmup=3, steps=20):
+    """Wall time per call WITHOUT the in-library stage timers (their HIP events cost a launch-bound forward 5-10 %), then the stage
+    breakdown from a second pass with them on."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    _lib.prof_enable(True); _lib.prof_collect()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    _lib.prof_enable(True); _lib.prof_collect()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
     prof = _lib.prof_collect(); _lib.prof_enable(False)
     return dt, {k: (v[0] / steps, v[1] // steps) for k, v in prof.items() if v[1]}
 
