@@ -373,14 +373,20 @@ def main():
             avg_s = proj_ms / max(proj_n, 1) * 1e-3
             ach = flops32 / avg_s / 1e12                                 # the folded projection's 2 N Dn H C flops per launch
             issued = products * flops32 / avg_s / 1e12                   # what the matrix cores execute: 3 (6) piece products of them
+            hk = m.hop_kernel(g0)                                         # what the library says it runs for this batch (gvqa_gat_seq_hop_kernel)
             ks2 = pieces == 2 and (-(-D // 16)) % 2 == 0                 # two K steps per stage when the k-block count is even
-            chained = pieces == 2 and prof["pack"][1] < prof["proj"][1]  # the persistent kernel with chained hops: one pack pass per forward
-            kname = (f"gvqa::k_hop2<H={H},NBUF=3,CHAIN,NW=4> (persistent hop kernel, two 4-wave workgroups per CU, 128 x 256 items: two-piece "
-                     "split projection, GAT aggregation + skip/BN/ReLU epilogue out of LDS, output written as the next hop's packed operand; "
-                     "xp never reaches HBM)") if chained else (
-                     f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
-                     f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
-                     "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)")
+            kname = {
+                "fused8_chained": f"gvqa::k_linear_split3<2,4,4,2,NBUF={2 if ks2 else 4},ILV,EPI=2,H={H},NP=2,KS={2 if ks2 else 1},CHN=1> (fused hop, 8 waves, 256 x 256 "
+                                  "tile: two-piece split projection, GAT aggregation + skip/BN/ReLU epilogue out of LDS, skip rows out of the packed input, "
+                                  "output written as the next hop's packed operand; xp never reaches HBM)",
+                "persistent_chained": f"gvqa::k_hop2<H={H},NBUF=3,CHAIN,NW=4> (persistent hop kernel, two 4-wave workgroups per CU, 128 x 256 items; output "
+                                      "written as the next hop's packed operand; xp never reaches HBM)",
+                "aggregate_first": "gvqa::k_hopagg4<2,4,2,4> (aggregate-first hop: heads concatenated along K, the attention-weighted neighbour sum formed "
+                                   "inside the matrix-core loop, register -> global epilogue; rows chunk-major between hops)",
+                "persistent": f"gvqa::k_hop2<H={H},NBUF=3,NW=4> (persistent hop kernel, a pack pass per hop)",
+            }.get(hk, f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
+                      f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
+                      "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)")
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                     "algorithmic_flops_per_launch": flops32,
@@ -411,9 +417,10 @@ def main():
                        "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
                                        "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
+                       "hop_kernel": m.hop_kernel(g0) if fused else "unfused",
                        "hop": (("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "
-                                "segment softmax) -> ONE persistent kernel for projection + aggregation + epilogue that leaves the next hop's "
-                                "packed operand") if fused and split and pieces == 2 and prof["pack"][1] < prof["proj"][1] else
+                                "segment softmax) -> ONE kernel for projection + aggregation + epilogue that leaves the next hop's "
+                                "packed operand (two launches per hop, one pack pass per forward)") if fused and split and pieces == 2 and prof["pack"][1] < prof["proj"][1] else
                                "fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"
                                if fused else "projection GEMM, then the fused message-passing kernel (xp through HBM)"),
                        "projection_arithmetic": arith if split else "f32-input MFMA"},

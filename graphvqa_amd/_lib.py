@@ -18,6 +18,7 @@ STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp
 OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS = 0, 1, 2, 3, 4, 5, 6
 PROJECTION_SPLIT3, PROJECTION_F32, PROJECTION_SPLIT2H = 0, 1, 2
 NUM_STAGES = len(STAGES)
+HOP_KERNELS = ("unfused", "fused8", "persistent", "fused8_chained", "persistent_chained", "aggregate_first")      # GVQA_HOP_*
 
 
 class GvqaLibraryError(RuntimeError):
@@ -158,6 +159,7 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_gat_seq_weight_cache_bytes": (C.c_size_t, [C.POINTER(GatDims), C.c_int32]),
     "gvqa_gat_seq_weight_layout": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims)]),
+    "gvqa_gat_seq_hop_kernel": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims)]),
     "gvqa_gat_seq_prepare_weights": (C.c_int, [C.POINTER(GatDims), C.POINTER(GatConvParams), C.c_int32, C.c_void_p, C.c_size_t,
                                                C.c_void_p]),
     "gvqa_gat_seq_forward_cached": (C.c_int, [C.POINTER(Graph), C.POINTER(GatDims), C.POINTER(GatConvParams),

@@ -1728,6 +1728,16 @@ int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
                             fused && (hop2_applies(g, d) || fused_chain8_capable(g, d)));
 }
 
+int gvqa_gat_seq_hop_kernel(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    if (!g || !d || check_dims(d, true) || !g->finalized) return GVQA_E_INVALID;
+    if (!g->intra_graph) return GVQA_E_UNSUPPORTED;
+    if (hopagg_applies(g, d)) return GVQA_HOP_AGGREGATE_FIRST;
+    if (!hop_fusion_applies(g, d)) return GVQA_HOP_UNFUSED;
+    const bool logits = split_pack_groups_logits_supported(2, 2 * d->heads, d->node_dim);
+    if (hop2_applies(g, d)) return (hop2_chain_capable(g, d) && logits) ? GVQA_HOP_PERSISTENT_CHAINED : GVQA_HOP_PERSISTENT;
+    return (fused_chain8_capable(g, d) && logits) ? GVQA_HOP_FUSED8_CHAINED : GVQA_HOP_FUSED8;
+}
+
 int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
                                  size_t cache_bytes, void* stream) {
     GVQA_REQUIRE(hops && cache, GVQA_E_INVALID, "gat_seq_prepare_weights: null argument");

@@ -848,12 +848,7 @@ class gat_seq(torch.nn.Module):
         if not graph.intra_graph:
             return self._forward_unfolded(x, edge_index, edge_attr, instr, batch, graph)
         H, Cc = self.heads, self.out_channels
-        d = _lib.GatDims(self.in_channels, self.edge_attr_dim, self.ins_dim, Cc, H, K, self.negative_slope,
-                         self.bns[0].eps if len(self.bns) else 1e-5)
-        if self.projection is not None:
-            d.projection = 1 + {"split3": _lib.PROJECTION_SPLIT3, "f32": _lib.PROJECTION_F32, "split2h": _lib.PROJECTION_SPLIT2H}[self.projection]
-        if self.hop_fusion is not None:
-            d.hop_fusion = 1 + int(self.hop_fusion)
+        d = self._dims()
         hops, keep = self._hop_params()
         dev = x.device
         out = torch.empty((N, Cc), dtype=torch.float32, device=dev)
@@ -909,6 +904,24 @@ class gat_seq(torch.nn.Module):
         out = super()._apply(fn, *a, **kw)              # .to() / .cuda() / .float(): storages may move or be replaced
         self.invalidate_weight_cache()
         return out
+
+    def _dims(self) -> "_lib.GatDims":
+        K, H, Cc = len(self.convs), self.heads, self.out_channels
+        d = _lib.GatDims(self.in_channels, self.edge_attr_dim, self.ins_dim, Cc, H, K, self.negative_slope,
+                         self.bns[0].eps if len(self.bns) else 1e-5)
+        if self.projection is not None:
+            d.projection = 1 + {"split3": _lib.PROJECTION_SPLIT3, "f32": _lib.PROJECTION_F32, "split2h": _lib.PROJECTION_SPLIT2H}[self.projection]
+        if self.hop_fusion is not None:
+            d.hop_fusion = 1 + int(self.hop_fusion)
+        return d
+
+    def hop_kernel(self, graph: SceneGraphBatch) -> str:
+        """Which hop kernel an eval forward of `graph` runs under this module's settings (one of _lib.HOP_KERNELS)."""
+        d = self._dims()
+        rc = _lib.load().gvqa_gat_seq_hop_kernel(C.byref(graph.c), C.byref(d))
+        if rc < 0:
+            _lib.check(rc)
+        return _lib.HOP_KERNELS[rc]
 
     def _hop_params(self):
         """The K `gvqa_gat_conv_params` structs of the eval forward, rebuilt only when a tensor's storage moved."""

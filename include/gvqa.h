@@ -198,6 +198,16 @@ GVQA_API int gvqa_gat_seq_forward(const gvqa_graph* g, const gvqa_gat_dims* d, c
  * caller-owned device memory, 256-byte aligned; the caller re-prepares it after changing any parameter. */
 GVQA_API size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t layout);
 GVQA_API int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d);
+/* Which hop kernel an eval forward of this batch runs under the current options (introspection: bench.py labels its line with it,
+ * tests assert it): GVQA_HOP_* below, or a negative status.  Plain outputs assumed (per-hop fp32 outputs / batch statistics take
+ * the unchained form of the same kernel). */
+#define GVQA_HOP_UNFUSED 0            /* projection GEMM + gvqa::k_gat_mp_tiled                                          */
+#define GVQA_HOP_FUSED8 1             /* the 8-wave fused kernel, a pack pass per hop                                     */
+#define GVQA_HOP_PERSISTENT 2         /* the persistent kernel (hop2.hip), a pack pass per hop                            */
+#define GVQA_HOP_FUSED8_CHAINED 3     /* the 8-wave fused kernel, hops chained through packed operands (default when H = 4) */
+#define GVQA_HOP_PERSISTENT_CHAINED 4 /* the persistent kernel, hops chained                                              */
+#define GVQA_HOP_AGGREGATE_FIRST 5    /* hopagg.hip: heads concatenated along K (GVQA_OPT_HOP_FUSION = 4)                  */
+GVQA_API int gvqa_gat_seq_hop_kernel(const gvqa_graph* g, const gvqa_gat_dims* d);
 GVQA_API int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
                                  size_t cache_bytes, void* stream);
 GVQA_API int gvqa_gat_seq_forward_cached(const gvqa_graph* g, const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, const float* x,
@@ -366,7 +376,12 @@ enum gvqa_option {
                                       2: the same as the persistent kernel of csrc/hop2.hip (two 4-wave workgroups per CU, one's aggregation
                                          under the other's matrix-core loop; two-piece operands), hops CHAINED: a hop leaves the next hop's
                                          packed operand, so only the first hop has a pack pass;
-                                      3 (default): 2 when the batch has >= 6 (row group, column block) items per workgroup slot, else 1 */
+                                      3 (default): with H = 4 and >= 128 row groups, 1 with the hops chained (the 8-wave kernel writes the next
+                                         hop's packed operand too: the faster of the two chained forms, round 4); otherwise 2 when the batch has
+                                         >= 6 (row group, column block) items per workgroup slot, else 1;
+                                      4: the aggregate-first kernel of csrc/hopagg.hip (H = 4, C == node_dim <= 512: heads concatenated along K,
+                                         the attention-weighted neighbour sum formed inside the matrix-core loop, rows chunk-major between hops);
+                                         falls back to 1 where it does not apply.  Modes 1 and 2 chain whenever the batch allows. */
     GVQA_OPT_COEFF_KERNEL = 5,     /* attention coefficients: 0 (default) the row-group kernel when a row-group plan exists, 1 always the
                                       per-(node, head) kernel (same operations in the same order: bit-identical; tests) */
     GVQA_OPT_MP_PARTS = 6,         /* stand-alone message-passing kernel: 0 (default) blocks per graph chosen by batch size, n > 0 exactly n */
