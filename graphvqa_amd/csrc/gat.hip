@@ -1196,10 +1196,12 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
 // Side stream for work that is independent of the projection GEMM of the same hop (HBM-bound
 // logit / fold kernels under the MFMA-bound projection).  One non-blocking stream and a pair of
 // events per host thread; fork = side waits for everything already enqueued on the caller's
-// stream, join = caller's stream waits for the side stream.  OFF by default (GVQA_OVERLAP=1 turns it
-// on): measured at config 3 the projection's blocks fill every CU, the side-stream kernels mostly
-// wait for it anyway and the step gains only 1.2 % (6.23 vs 6.30 ms) while per-stage timings
-// stop being additive.
+// stream, join = caller's stream waits for the side stream.  OFF by default (GVQA_OVERLAP=1 turns it on).  Round 1 forked and
+// joined around every hop's projection: the projection's blocks fill every CU, the side kernels waited for it anyway (+1.2 %).
+// Round 4 re-cut it to what a fused forward does BEFORE its first hop -- the all-hops edge-logit pass, the per-graph instruction
+// terms and the chained hops' term maxima beside hop 0's pack pass, ONE fork and ONE join per forward -- and measured it again,
+// alternating on one box: 2.76 / 2.81 ms with, 2.63 / 2.63 ms without.  The kernels that would overlap are HBM-bound alike (they
+// share the bandwidth) and the two cross-stream dependencies cost this runtime more than the small GEMM hides.  It stays off.
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
@@ -1509,15 +1511,15 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     if (aggf) {
         // ---- aggregate-first hops (hopagg.hip): x -> chunk-major rows + per-graph maxima once, then per hop TWO launches --
         // coefficient kernel (node logits from the chunks + segment softmax) and the hop kernel -- rows staying chunk-major.
-        if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
         float* X4[2] = {P(L.x4a), P(L.x4b)};
         float* GM[2] = {P(L.gma), P(L.gmb)};
         const int NQ = (int)cdiv(Dn, 4);
         {
             StageTimer tp(GVQA_STAGE_PACK, stream);
-            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream);
+            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream);      // (beside the edge logits / graph terms on the side stream)
             if (rc) return rc;
         }
+        if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
         for (int i = 0; i < K; ++i) {
             const float* gterm = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr;
             {
@@ -1567,24 +1569,26 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     char* a6 = base + L.a6;
     const int ncb_chain = (int)cdiv(C, fcw);
     const float* h = x;
+    bool aux_pending = ss != nullptr;                 // the side stream's pre-hop work has not been joined yet
     for (int i = 0; i < K; ++i) {
         if (chain) a6 = base + ((i & 1) ? L.a6b : L.a6);          // hop i reads the operand hop i - 1 (or the pack pass) left
         float* h_next;
         if (hop_out) h_next = hop_out + (int64_t)i * N * C;
         else if (i == K - 1) h_next = out;
         else h_next = (i & 1) ? P(L.h1) : P(L.h0);
-        if (ss && i > 0) { rc = side_fork(ss, stream); if (rc) return rc; }     // h of this hop is ready on `stream`
+        if (ss && i > 0 && !fused) { rc = side_fork(ss, stream); if (rc) return rc; }     // (unfused hops: the node-logit product runs beside the projection) h of this hop is ready on `stream`
         const bool logits_in_pack = fused && split_pack_groups_logits_supported(np, 2 * H, Dn);
         if (chain && i > 0) {
             // nothing to prepare: packed rows, partial logits and maxima of h came out of the previous hop's launch
         } else if (logits_in_pack) {
             // row-group slots of h for the fused hop AND (a_l | a_r) = h . [V_l | V_r] in one pass over h
-            if (ss) { rc = side_join(ss, stream); if (rc) return rc; }      // Vn comes from the fold on the side stream (hop 0)
+            if (ss && aux_pending && !cached) { rc = side_join(ss, stream); if (rc) return rc; aux_pending = false; }      // Vn comes from the fold on the side stream (hop 0, uncached weights)
             StageTimer tp(GVQA_STAGE_PACK, stream);
             rc = launch_split_pack_groups(np, g->num_row_groups, g->row_group_ptr, Dn, h, Dn, a6, Vn_all + (int64_t)i * 2 * H * Dn, 2 * H,
                                           P(L.a_node), stream, WL.vn2h_hop ? wbase + WL.vn2h + (size_t)i * WL.vn2h_hop : nullptr);
             if (rc) return rc;
         } else {   // (a_l | a_r) node halves = h . [V_l | V_r]     (side stream)
+            if (ss && fused && i > 0) { rc = side_fork(ss, stream); if (rc) return rc; aux_pending = true; }     // h of this hop is ready on `stream`
             StageTimer t(GVQA_STAGE_NODE_LOGIT, aux);
             rc = launch_linear(N, 2 * H, Dn, h, Dn, Vn_all + (int64_t)i * 2 * H * Dn, Dn, nullptr, 0, P(L.a_node), 2 * H,
                                1, 0, 0, 0, aux);
@@ -1592,7 +1596,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         }
         if (fused) {
             // attention coefficients (CSR order) -> row-group slots of h -> projection + aggregation + epilogue in one kernel
-            if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
+            if (ss && aux_pending) { rc = side_join(ss, stream); if (rc) return rc; aux_pending = false; }      // edge logits / graph terms of the side stream: before the first coefficient kernel
             const bool train_bn = bn_stats_out && hops[i].bn_weight;
             MpArgs a;
             memset(&a, 0, sizeof(a));

@@ -678,22 +678,28 @@ class gat(torch.nn.Module):
     """Edge- and instruction-conditioned GAT layer (reference class `gat`, gat_skip.py:16-213).
 
     forward(x, edge_index, edge_attr, size=None, return_attention_weights=None) -> out [N, C]
-    (concat=False) or (out, (edge_index, alpha [E, H])).  No self-loops are added
-    (gat_skip.py:111-177 never uses `add_self_loops`).
+    (concat=False) / [N, H C] (concat=True) or (out, (edge_index, alpha [E, H])).  No self-loops are added
+    (gat_skip.py:111-177 never uses `add_self_loops`).  `in_channels` may be a pair (gat_skip.py:78-80): separate `lin_l` /
+    `lin_r`, `x` then a pair (x_l, x_r) of node tensors over the SAME node set (x_r may be None); graphs with different
+    source / destination node sets are not taken (GraphVQA has none).  The eval fast path (one C call, gvqa_gat_conv_forward)
+    serves the form gat_seq uses -- int in_channels, concat=False; everything else runs the HIP message passing per call
+    (concat=True: once per head) around torch-side projections.
     """
 
-    def __init__(self, in_channels: int, out_channels: int, edge_in_channels: int, heads: int = 1,
+    def __init__(self, in_channels, out_channels: int, edge_in_channels: int, heads: int = 1,
                  concat: bool = True, negative_slope: float = 0.2, dropout: float = 0.0,
                  add_self_loops: bool = True, bias: bool = True, **kwargs):
         super().__init__()
-        if not isinstance(in_channels, int):
-            raise NotImplementedError("bipartite (tuple) in_channels is not on the GraphVQA path")
         _lib.load()   # fail loudly at construction when the HIP library is missing
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.concat, self.negative_slope, self.dropout = concat, negative_slope, dropout
         self.add_self_loops = add_self_loops
-        self.lin_l = Linear(in_channels, heads * out_channels, bias=False)
-        self.lin_r = self.lin_l                      # shared (gat_skip.py:76-77); separate state_dict key
+        if isinstance(in_channels, int):
+            self.lin_l = Linear(in_channels, heads * out_channels, bias=False)
+            self.lin_r = self.lin_l                  # shared (gat_skip.py:76-77); separate state_dict key
+        else:
+            self.lin_l = Linear(in_channels[0], heads * out_channels, bias=False)     # gat_skip.py:79-80
+            self.lin_r = Linear(in_channels[1], heads * out_channels, bias=False)
         self.lin_e = Linear(edge_in_channels, heads * out_channels, bias=False)
         self.att_e = Parameter(torch.empty(1, heads, out_channels))
         self.att_l = Parameter(torch.empty(1, heads, out_channels))
@@ -709,6 +715,8 @@ class gat(torch.nn.Module):
     def reset_parameters(self):
         for t in (self.lin_l.weight, self.lin_e.weight, self.att_l, self.att_r, self.att_e):
             _glorot(t)
+        if self.lin_r is not self.lin_l:
+            _glorot(self.lin_r.weight)
         if self.bias is not None:
             with torch.no_grad():
                 self.bias.zero_()
@@ -736,27 +744,59 @@ class gat(torch.nn.Module):
 
     def _forward_autograd(self, x, edge_index, edge_attr, graph, want_alpha):
         """Differentiable single layer (gat_skip.py:125-177): projections and logits as torch ops, message passing and
-        its backward on the HIP kernels; attention dropout (:205) as a drawn mask in training."""
+        its backward on the HIP kernels; attention dropout (:205) as a drawn mask in training.  Also the general form: a pair
+        (x_l, x_r) with separate lin_l / lin_r (:136-143), and concat=True (:162-163) -- the message passing then runs once per
+        head (H = 1 calls on that head's columns), the heads' results side by side."""
         import torch.nn.functional as F
-        H, Cc, N, E = self.heads, self.out_channels, x.shape[0], edge_index.shape[1]
-        xp = F.linear(x, self.lin_l.weight)
-        a_node = skinny_linear(x, fold_attention(self.lin_l.weight, self.att_l, self.att_r, H))
+        pair = isinstance(x, (tuple, list))
+        x_l, x_r = (x[0], x[1]) if pair else (x, x)
+        H, Cc, N, E = self.heads, self.out_channels, x_l.shape[0], edge_index.shape[1]
+        xp = F.linear(x_l, self.lin_l.weight)
+        if not pair:
+            a_node = skinny_linear(x_l, fold_attention(self.lin_l.weight, self.att_l, self.att_r, H))
+        else:
+            a_l = skinny_linear(x_l, fold_attention(self.lin_l.weight, self.att_l, None, H))
+            a_r = skinny_linear(x_r, fold_attention(self.lin_r.weight, self.att_r, None, H)) if x_r is not None else torch.zeros_like(a_l)
+            a_node = torch.cat((a_l, a_r), dim=1)
         a_edge = skinny_linear(edge_attr, fold_attention(self.lin_e.weight, self.att_e, None, H))
         p = self.dropout if self.training else 0.0
-        mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p) if p > 0 else None
-        out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask)
+        mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=xp.device)) / (1.0 - p) if p > 0 else None
+        if not self.concat:
+            out, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask)
+        else:
+            outs, alphas = [], []
+            for h in range(H):
+                o_h, al_h = gat_message_passing(xp[:, h * Cc:(h + 1) * Cc].contiguous(),
+                                                torch.stack((a_node[:, h], a_node[:, H + h]), dim=1).contiguous(),
+                                                a_edge[:, h:h + 1].contiguous(), graph, 1, Cc, self.negative_slope,
+                                                None if mask is None else mask[:, h:h + 1].contiguous())
+                outs.append(o_h); alphas.append(al_h)
+            out, alpha = torch.cat(outs, dim=1), torch.cat(alphas, dim=1)
         if self.bias is not None:
             out = out + self.bias
         return (out, (edge_index, alpha)) if want_alpha else out
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor, size=None,
                 return_attention_weights=None, graph: Optional[SceneGraphBatch] = None):
-        assert x.dim() == 2, "Static graphs not supported in `GATConv`."      # gat_skip.py:132
-        if self.concat:
-            raise NotImplementedError("concat=True is not used by GraphVQA (gat_skip.py:232) and not implemented")
+        pair = isinstance(x, (tuple, list))
+        assert (x[0] if pair else x).dim() == 2, "Static graphs not supported in `GATConv`."      # gat_skip.py:132,137
         lib = _lib.load()
-        x = _f32c(x, "x")
         edge_attr = _f32c(edge_attr, "edge_attr")
+        if pair or self.concat or self.lin_r is not self.lin_l:
+            # the forms gat_seq never uses (gat_skip.py:78-80,136-143,162-163): the general formulation, with or without gradients
+            if not pair and self.lin_r is not self.lin_l:
+                x = (x, x)
+            if pair:
+                x = (_f32c(x[0], "x[0]"), None if x[1] is None else _f32c(x[1], "x[1]"))
+                if x[1] is not None and x[1].shape[0] != x[0].shape[0]:
+                    raise NotImplementedError("gat: source and destination node sets of different sizes (bipartite graphs) are not supported")
+            else:
+                x = _f32c(x, "x")
+            n_nodes = (x[0] if pair else x).shape[0]
+            if graph is None:
+                graph = SceneGraphBatch(edge_index, None, n_nodes, 1)
+            return self._forward_autograd(x, edge_index, edge_attr, graph, isinstance(return_attention_weights, bool))
+        x = _f32c(x, "x")
         N, E = x.shape[0], edge_index.shape[1]
         if graph is None:
             graph = SceneGraphBatch(edge_index, None, N, 1)

@@ -69,12 +69,19 @@ def gat_conv(x, edge_index, edge_attr, p, prefix="", heads=4, negative_slope=0.2
     bias = p.get(prefix + "bias", None)
     H = heads
     C = W_l.shape[0] // H
-    N = x.shape[0]
+    N = (x[0] if isinstance(x, (tuple, list)) else x).shape[0]
     src, dst = edge_index[0], edge_index[1]
 
-    xp = F.linear(x, W_l).view(-1, H, C)                       # gat_skip.py:133
-    a_l = (xp * att_l).sum(dim=-1)                             # :134
-    a_r = (xp * att_r).sum(dim=-1)                             # :135
+    if isinstance(x, (tuple, list)):                           # (x_l, x_r): tuple in_channels, separate lin_r (gat_skip.py:78-80,136-143)
+        x_l, x_r = x
+        N = x_r.shape[0] if x_r is not None else x_l.shape[0]
+        xp = F.linear(x_l, W_l).view(-1, H, C)                 # :138
+        a_l = (xp * att_l).sum(dim=-1)                         # :139
+        a_r = (F.linear(x_r, p[prefix + "lin_r.weight"]).view(-1, H, C) * att_r).sum(dim=-1) if x_r is not None else 0.0 * a_l   # :141-142
+    else:
+        xp = F.linear(x, W_l).view(-1, H, C)                   # gat_skip.py:133
+        a_l = (xp * att_l).sum(dim=-1)                         # :134
+        a_r = (xp * att_r).sum(dim=-1)                         # :135
     e = F.linear(edge_attr, W_e).view(-1, H, C)                # :150
     a_e = (e * att_e).sum(dim=-1)                              # :151
 

@@ -105,6 +105,46 @@ def debug_graphs():
 
 
 # ----------------------------------------------------------------------------
+def gen_gat_concat_pair():
+    """The parts of the reference's `gat` class that gat_seq does not use (gat_skip.py:78-80,136-143,162-163): concat=True (heads side
+    by side, bias [H C]) and tuple in_channels (separate lin_l / lin_r applied to a pair (x_l, x_r) of node tensors)."""
+    import gat_skip
+    H, C, e_in = 4, 8, 20
+    ei = small_multigraph(31, n=12, e=45)
+    N, E = 12, ei.shape[1]
+    ea = synth.normal((E, e_in), 33)
+    # A. concat=True, one node tensor
+    conv = gat_skip.gat(in_channels=24, out_channels=C, edge_in_channels=e_in, heads=H, concat=True, negative_slope=0.2, dropout=0.0, bias=True)
+    pa = {"lin_l.weight": synth.glorot((H * C, 24), 301), "lin_e.weight": synth.glorot((H * C, e_in), 302),
+          "att_l": synth.glorot((1, H, C), 303), "att_r": synth.glorot((1, H, C), 304), "att_e": synth.glorot((1, H, C), 305),
+          "bias": synth.normal((H * C,), 306)}
+    pa["lin_r.weight"] = pa["lin_l.weight"]
+    load_params(conv, pa)
+    x = synth.normal((N, 24), 32)
+    with torch.no_grad():
+        out_a, (_, alpha_a) = conv(t(x), t(ei), t(ea), return_attention_weights=True)
+    # B. tuple in_channels (24, 16), concat=False: separate lin_r on x_r; C. the same with concat=True
+    xr = synth.normal((N, 16), 34)
+    pb = dict(pa)
+    pb["lin_r.weight"] = synth.glorot((H * C, 16), 307)
+    pb["bias"] = synth.normal((C,), 308)
+    conv_b = gat_skip.gat(in_channels=(24, 16), out_channels=C, edge_in_channels=e_in, heads=H, concat=False, negative_slope=0.2, dropout=0.0, bias=True)
+    load_params(conv_b, pb)
+    with torch.no_grad():
+        out_b, (_, alpha_b) = conv_b((t(x), t(xr)), t(ei), t(ea), return_attention_weights=True)
+    pc = dict(pb)
+    pc["bias"] = pa["bias"]
+    conv_c = gat_skip.gat(in_channels=(24, 16), out_channels=C, edge_in_channels=e_in, heads=H, concat=True, negative_slope=0.2, dropout=0.0, bias=True)
+    load_params(conv_c, pc)
+    with torch.no_grad():
+        out_c = conv_c((t(x), t(xr)), t(ei), t(ea))
+    save("gat_conv_concat_pair", dict(case="gat.forward concat=True / tuple in_channels", ref="gat_skip.py:78-80,136-143,162-163",
+                                      heads=H, out_channels=C, edge_in=e_in, in_channels=[24, 16],
+                                      param_seeds="glorot 301-305, 307; normal bias 306 (H C), 308 (C)"),
+         x=x, x_r=xr, edge_index=ei, edge_attr=ea, out_concat=out_a, alpha_concat=alpha_a, out_pair=out_b, alpha_pair=alpha_b,
+         out_pair_concat=out_c, **{"p_" + k.replace(".", "_"): v for k, v in pb.items() if k != "bias"}, p_bias_hc=pa["bias"], p_bias_c=pb["bias"])
+
+
 def gen_gat():
     import gat_skip
 
@@ -519,6 +559,10 @@ if __name__ == "__main__":
     if "--encoder-only" in sys.argv:
         gen_encoder()
         sys.exit(0)
+    if "--gat-variants-only" in sys.argv:
+        stub_dataset_entry()
+        gen_gat_concat_pair()
+        sys.exit(0)
     if "--grads-only" in sys.argv:
         dn, de, di, K, H = 32, 24, 16, 5, 4
         gb = synth.make_graph_batch(8, seed=21, nodes_lo=1, nodes_hi=12, rel_per_node=1.5)
@@ -531,6 +575,7 @@ if __name__ == "__main__":
     gen_head()
     sys.exit(0) if "--head-only" in sys.argv else None
     gen_gat()
+    gen_gat_concat_pair()
     gen_gine_gcn()
     gen_lcgn()
     gen_pipeline()

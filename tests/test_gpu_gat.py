@@ -242,6 +242,33 @@ def test_gat_seq_real_dims_golden(dev, name):
     assert maxabs(alpha[0], g["alpha0"]) < 1e-5 and maxabs(alpha[4], g["alpha4"]) < 1e-5
 
 
+def test_gat_concat_and_pair_inputs_golden(dev):
+    """The parts of the reference's public `gat` class that gat_seq does not use -- concat=True (heads side by side, bias [H C]) and
+    tuple in_channels with a pair (x_l, x_r) of node tensors (gat_skip.py:78-80,136-143,162-163) -- against outputs recorded from
+    the reference's own class; also state_dict keys / shapes, and gradients flowing (the general form is differentiable)."""
+    from graphvqa_amd.gat_skip import gat
+    meta, g = load_golden("gat_conv_concat_pair")
+    H, C, e_in = meta["heads"], meta["out_channels"], meta["edge_in"]
+    base = {"lin_l.weight": g["p_lin_l_weight"], "lin_e.weight": g["p_lin_e_weight"], "att_l": g["p_att_l"], "att_r": g["p_att_r"], "att_e": g["p_att_e"]}
+    x, xr, ei, ea = t(g["x"], device=dev), t(g["x_r"], device=dev), t(g["edge_index"], device=dev), t(g["edge_attr"], device=dev)
+    conv = _load_module(gat(24, C, e_in, heads=H, concat=True, dropout=0.0), dict(base, **{"lin_r.weight": g["p_lin_l_weight"], "bias": g["p_bias_hc"]}), dev)
+    out, (_, alpha) = conv(x, ei, ea, return_attention_weights=True)
+    assert out.shape == (12, H * C) and maxabs(out, g["out_concat"]) < TOL and maxabs(alpha, g["alpha_concat"]) < 1e-5
+    conv_b = gat((24, 16), C, e_in, heads=H, concat=False, dropout=0.0)
+    assert conv_b.state_dict()["lin_r.weight"].shape == (H * C, 16) and conv_b.lin_r is not conv_b.lin_l
+    _load_module(conv_b, dict(base, **{"lin_r.weight": g["p_lin_r_weight"], "bias": g["p_bias_c"]}), dev)
+    out, (_, alpha) = conv_b((x, xr), ei, ea, return_attention_weights=True)
+    assert maxabs(out, g["out_pair"]) < TOL and maxabs(alpha, g["alpha_pair"]) < 1e-5
+    conv_c = _load_module(gat((24, 16), C, e_in, heads=H, concat=True, dropout=0.0), dict(base, **{"lin_r.weight": g["p_lin_r_weight"], "bias": g["p_bias_hc"]}), dev)
+    assert maxabs(conv_c((x, xr), ei, ea), g["out_pair_concat"]) < TOL
+    with torch.enable_grad():
+        xg = x.clone().requires_grad_(True)
+        conv_c((xg, xr), ei, ea).square().sum().backward()
+        assert xg.grad is not None and torch.isfinite(xg.grad).all() and conv_c.lin_r.weight.grad is not None
+    with pytest.raises(NotImplementedError):
+        conv_c((x, xr[:5]), ei, ea)
+
+
 @pytest.mark.parametrize("name", ["gat_seq_debug2_d300", "gat_seq_debug4_d300"])
 def test_integration_md_stub_runs(dev, name):
     """INTEGRATION.md section 2 -- the ctypes stub a maintainer of the reference would copy in place of the body of

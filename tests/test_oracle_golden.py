@@ -27,6 +27,23 @@ def test_gat_conv_small():
     assert np.all(s[9] == 0)
 
 
+def test_gat_conv_concat_and_pair_inputs():
+    """concat=True and tuple in_channels of the reference's `gat` (gat_skip.py:78-80,136-143,162-163), recorded from its own class."""
+    meta, g = load_golden("gat_conv_concat_pair")
+    H = meta["heads"]
+    base = {"lin_l.weight": g["p_lin_l_weight"], "lin_e.weight": g["p_lin_e_weight"], "att_l": g["p_att_l"], "att_r": g["p_att_r"],
+            "att_e": g["p_att_e"]}
+    pa = tparams(dict(base, **{"lin_r.weight": g["p_lin_l_weight"], "bias": g["p_bias_hc"]}))
+    out, alpha = R.gat_conv(t(g["x"]), t(g["edge_index"]), t(g["edge_attr"]), pa, heads=H, concat=True, return_attention_weights=True)
+    assert maxabs(out, g["out_concat"]) < TOL and maxabs(alpha, g["alpha_concat"]) < TOL
+    pb = tparams(dict(base, **{"lin_r.weight": g["p_lin_r_weight"], "bias": g["p_bias_c"]}))
+    out, alpha = R.gat_conv((t(g["x"]), t(g["x_r"])), t(g["edge_index"]), t(g["edge_attr"]), pb, heads=H, return_attention_weights=True)
+    assert maxabs(out, g["out_pair"]) < TOL and maxabs(alpha, g["alpha_pair"]) < TOL
+    pc = tparams(dict(base, **{"lin_r.weight": g["p_lin_r_weight"], "bias": g["p_bias_hc"]}))
+    out = R.gat_conv((t(g["x"]), t(g["x_r"])), t(g["edge_index"]), t(g["edge_attr"]), pc, heads=H, concat=True)
+    assert maxabs(out, g["out_pair_concat"]) < TOL
+
+
 def test_gat_seq_small_all_hops():
     meta, g = load_golden("gat_seq_small")
     p = tparams(synth.gat_seq_params(meta["dn"], meta["dn"], meta["de"], meta["di"], meta["K"],
