@@ -645,7 +645,8 @@ def test_message_passing_backward_reports_the_largest_gradient_magnitude(dev):
     out, _ = gat_message_passing(xp, t(rng.standard_normal((N, 2 * H)).astype(np.float32), device=dev),
                                  t(rng.standard_normal((E, H)).astype(np.float32), device=dev), g, H, C)
     (out * t(rng.standard_normal((N, C)).astype(np.float32), device=dev)).sum().backward()
-    am = getattr(seen["g"], "_gvqa_absmax", None)
+    from graphvqa_amd.gat_skip import _absmax_hint
+    am = _absmax_hint(seen["g"])          # (the hint rides with the tensor's storage address and version counter: ADVICE r03)
     assert am is not None and am.numel() == _lib.ABSMAX_SLOTS
     assert float(am.max()) == float(xp.grad.abs().max())
     x = t(rng.standard_normal((N, 128)).astype(np.float32), device=dev)
@@ -658,6 +659,18 @@ def test_message_passing_backward_reports_the_largest_gradient_magnitude(dev):
     assert torch.equal(with_hint, without)
     ref = seen["g"].double().t() @ x.double()
     assert float((with_hint.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # a stale hint is not honoured: after an in-place change of the gradient tensor (a second consumer's accumulation, a hook)
+    # the version counter differs, the consumer measures the operand itself and the product stays right -- with the old hint the
+    # fp16 operand would overflow
+    gbig = seen["g"]
+    gbig.mul_(4096.0)
+    assert _absmax_hint(gbig) is None
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        big = _ProjectionLinear._weight_grad(gbig, x)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    assert torch.isfinite(big).all() and float((big.double() - 4096.0 * ref).abs().max()) <= 2e-6 * 4096.0 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("H,C,Kin,two", [(4, 512, 1024, True), (4, 300, 812, True), (1, 30, 17, False), (8, 64, 100, True), (2, 5, 3, False)])
