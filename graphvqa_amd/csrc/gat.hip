@@ -659,6 +659,18 @@ __global__ __launch_bounds__(512) void k_gat_alpha_groups_packed(MpArgs a, const
     const int ns = group_ptr[grp], cnt = group_ptr[grp + 1] - ns;
     const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
     __shared__ float gs_s[128];
+    // this thread's first edge slot: source row, edge id and the edge halves of the logits start their trips from HBM now, ahead of
+    // the matrix-core logits (they depend on nothing computed here: two dependent loads off the critical path of phase 1)
+    int pf_src = 0;
+    float pf_ae[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) pf_ae[h] = 0.f;
+    if (tid < ne) {
+        pf_src = a.csr_src[e0 + tid] - ns;
+        const float* ae = a.a_edge + (int64_t)a.csr_eid[e0 + tid] * a.a_edge_stride;
+#pragma unroll
+        for (int h = 0; h < H; ++h) pf_ae[h] = ae[h];
+    }
     if (cs.gscale) {
         // Scale of the rows the hop is about to produce, one power of two per graph from an upper bound of their magnitudes (the hop
         // writes them as fp16 pieces straight from its epilogue, hop2.hip):
@@ -713,7 +725,11 @@ __global__ __launch_bounds__(512) void k_gat_alpha_groups_packed(MpArgs a, const
         an_s[it] = (an_s[it] + an_s[128 * J + it]) * a_inv[grp * 128 + r] * vn_inv[j];
     }
     __syncthreads();
-    for (int s = tid; s < ne; s += 512) {
+    if (tid < ne) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) rs[tid * H + h] = an_s[pf_src * J + h] + pf_ae[h];
+    }
+    for (int s = tid + 512; s < ne; s += 512) {
         const int src = a.csr_src[e0 + s] - ns, eid = a.csr_eid[e0 + s];
         const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
         for (int h = 0; h < H; ++h) rs[s * H + h] = an_s[src * J + h] + ae[h];
