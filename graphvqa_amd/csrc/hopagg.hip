@@ -359,10 +359,15 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
         const unsigned s1 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         sep = s0 | (s1 << 16);
     }
-    // value of quad lane E_ (compile-time) in every lane of the quad
-#define GVQA_HA_QB(v_, E_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v_)), (E_) * 0x55, 0xf, 0xf, true))
-#define GVQA_HA_QFMA(acc_, w_, x_, E_) do { acc_.x += (w_) * GVQA_HA_QB((x_).x, E_); acc_.y += (w_) * GVQA_HA_QB((x_).y, E_); \
-                                            acc_.z += (w_) * GVQA_HA_QB((x_).z, E_); acc_.w += (w_) * GVQA_HA_QB((x_).w, E_); } while (0)
+    // acc += w * (x of quad lane E_): ONE instruction, v_fmac_f32 with a DPP quad broadcast on its first source (the compiler does not
+    // fold its own v_mov_b32_dpp into the FMA here: 32 extra VALU operations per lane and K step, an eighth of the step's issue slots)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GVQA_HA_QF1(acc_, w_, x_, E_) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #E_ "," #E_ "," #E_ "," #E_ "] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc_) : "v"(x_), "v"(w_))
+#else
+#define GVQA_HA_QF1(acc_, w_, x_, E_) do { (acc_) += (w_) * (x_); } while (0)
+#endif
+#define GVQA_HA_QFMA(acc_, w_, x_, E_) do { GVQA_HA_QF1((acc_).x, w_, (x_).x, E_); GVQA_HA_QF1((acc_).y, w_, (x_).y, E_); \
+                                            GVQA_HA_QF1((acc_).z, w_, (x_).z, E_); GVQA_HA_QF1((acc_).w, w_, (x_).w, E_); } while (0)
     const int ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);      // wave-uniform trips through the LDS slice
     float pscale = 1.f;
     {
