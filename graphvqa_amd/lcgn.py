@@ -104,7 +104,8 @@ class lcgn_seq(nn.Module):
         init, p_loc, p_ctx = self.init_sg_emb_input, self.proj_x_loc, self.proj_x_ctx
         x_loc = init[1](proj(x, init[0].weight, init[0].bias))                        # :305
         x_ctx = x_ctx_init                                                            # :306
-        q_emb = torch.relu(self.qInput1(q))                                           # :307
+        plin = lambda m, v: proj(v, m.weight, m.bias)      # per-question Linears ([B, .]-sized): the library's f32-input kernel, not torch's vendor GEMM
+        q_emb = torch.relu(plin(self.qInput1, q))                                     # :307
         proj_x_loc = proj(p_loc[0](x_loc), p_loc[1].weight, p_loc[1].bias)            # :308
         lo = lstm.transpose(1, 0)                                                     # [B, L, O]
         zeros2 = torch.zeros((N, 2), device=x.device)
@@ -115,17 +116,18 @@ class lcgn_seq(nn.Module):
         z_loc = proj(x_loc, w_joint[:, :O]).split(O, dim=1)
         w_iter = w_joint[:, O:]
         for t in range(self.MAX_ITER_NUM):
-            q_cmd = getattr(self, "qInput2_%d" % t)(q_emb)                            # :292-300
-            att = torch.softmax(self.cmd_inter2logits(q_cmd[:, None, :] * lo).squeeze(-1), dim=-1)
-            cmd = torch.bmm(att[:, None, :], lo).squeeze(1)
+            q_cmd = plin(getattr(self, "qInput2_%d" % t), q_emb)                      # :292-300
+            # cmd_inter2logits is a [1, O] Linear: its product with q_cmd * lstm_out is a weighted sum over channels
+            att = torch.softmax(((q_cmd * self.cmd_inter2logits.weight)[:, None, :] * lo).sum(dim=-1) + self.cmd_inter2logits.bias, dim=-1)
+            cmd = (att[:, :, None] * lo).sum(dim=1)                                    # (a weighted sum over the L question tokens: no batched GEMM)
             x_pair = torch.cat([x_ctx, proj(p_ctx[0](x_ctx), p_ctx[1].weight, p_ctx[1].bias) * proj_x_loc], dim=-1)
             z = proj(x_pair, w_iter).split(O, dim=1)
             x_l, x_r, x_val = z[0] + z_loc[0], z[1] + z_loc[1], z[2] + z_loc[2]
-            y = graph_rows(L.proj_cmd(cmd), graph) * x_r                              # :148-154
+            y = graph_rows(plin(L.proj_cmd, cmd), graph) * x_r                        # :148-154
             a_edge = (edge_gather(x_l, graph, "src") * edge_gather(y, graph, "dst")).sum(dim=-1, keepdim=True)   # :207
             mask = torch.bernoulli(torch.full((E, 1), 1.0 - p_att, device=x.device)) / (1.0 - p_att) if p_att > 0 else None
             agg, _ = gat_message_passing(x_val, zeros2, a_edge, graph, 1, O, self.negative_slope, mask)   # :209-238
-            msg = agg * graph_rows(L.cal_cmd(cmd), graph)                             # :231 (edges are intra-graph)
+            msg = agg * graph_rows(plin(L.cal_cmd, cmd), graph)                       # :231 (edges are intra-graph)
             if L.bias is not None:
                 msg = msg + L.bias
             x_ctx = proj(torch.cat([x_ctx, msg], dim=-1), self.output_layer.weight, self.output_layer.bias)   # :316-319
