@@ -20,8 +20,14 @@ from torch import Tensor
 from torch.nn import Linear, Parameter, ReLU, Sequential
 
 from . import _lib
-from .gat_skip import _f32c, _workspace, _glorot, _inference_only
+from .gat_skip import (_f32c, _workspace, _glorot, _ProjectionLinear, _LibMatmul, graph_rows, edge_gather,
+                       edge_scatter_add)
 from .graph import SceneGraphBatch, _stream
+
+
+def _wants_grad(module: torch.nn.Module, *tensors) -> bool:
+    return torch.is_grad_enabled() and (any(isinstance(v, Tensor) and v.requires_grad for v in tensors) or
+                                        any(q.requires_grad for q in module.parameters()))
 
 
 class GINEConv(torch.nn.Module):
@@ -59,7 +65,6 @@ class GINEConv(torch.nn.Module):
         """x [N, D], edge_attr [E, D] (PyG requires equal widths).  With `ins` [B, Di] (and an
         intra-graph `graph`), x / edge_attr are the node / edge halves and the instruction halves
         are handled per graph without concatenation."""
-        _inference_only(self, x, edge_attr)
         lib = _lib.load()
         x, edge_attr = _f32c(x, "x"), _f32c(edge_attr, "edge_attr")
         if x.shape[1] != edge_attr.shape[1]:
@@ -67,6 +72,8 @@ class GINEConv(torch.nn.Module):
         N = x.shape[0]
         if graph is None:
             graph = SceneGraphBatch(edge_index, None, N, 1)
+        if _wants_grad(self, x, edge_attr, ins):
+            return self._forward_autograd(x, edge_attr, graph, ins)
         Dn, Di = x.shape[1], 0 if ins is None else ins.shape[1]
         Cc = self.nn[2].weight.shape[0]
         if self.nn[0].weight.shape[1] != Dn + Di:
@@ -79,6 +86,23 @@ class GINEConv(torch.nn.Module):
                                                   edge_attr.data_ptr(), None if ins is None else _f32c(ins, "ins").data_ptr(),
                                                   out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
         return out
+
+
+    def _forward_autograd(self, x, edge_attr, graph, ins):
+        """Differentiable GINEConv (what autograd does through PyG's propagate, pipeline_model_gine.py:628,665): the per-edge
+        gathers, the per-destination sum and their adjoints are the HIP CSR kernels (edge_gather / edge_scatter_add, deterministic),
+        the two dense layers and their dx / dW the library's products; relu / adds are elementwise torch ops.  With `ins` the
+        instruction halves of x / edge_attr are the per-graph rows broadcast by the HIP per-graph op (its adjoint: a segment sum)."""
+        if ins is not None:
+            rows = graph_rows(_f32c(ins, "ins"), graph)                       # [N, Di] = ins[batch]
+            x = torch.cat((x, rows), dim=-1)
+            edge_attr = torch.cat((edge_attr, edge_gather(rows, graph, "src")), dim=-1)
+        if self.nn[0].weight.shape[1] != x.shape[1]:
+            raise ValueError("feature width does not match the layer")
+        msg = torch.relu(edge_gather(x, graph, "src") + edge_attr)            # message: relu(x_j + e_ji)
+        z = edge_scatter_add(msg, graph) + (1.0 + self.eps) * x
+        proj = _ProjectionLinear.apply
+        return proj(torch.relu(proj(z, self.nn[0].weight, self.nn[0].bias)), self.nn[2].weight, self.nn[2].bias)
 
 
 class GCNConv(torch.nn.Module):
@@ -102,7 +126,6 @@ class GCNConv(torch.nn.Module):
                 self.bias.zero_()
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight=None, graph=None, ins: Tensor | None = None):
-        _inference_only(self, x)
         if edge_weight is not None:
             raise NotImplementedError("edge weights are not used by GraphVQA (pipeline_model_gcn.py:660)")
         lib = _lib.load()
@@ -113,6 +136,8 @@ class GCNConv(torch.nn.Module):
         Dn, Di = x.shape[1], 0 if ins is None else ins.shape[1]
         if Dn + Di != self.in_channels:
             raise ValueError("feature width does not match the layer")
+        if _wants_grad(self, x, ins):
+            return self._forward_autograd(x, graph, ins)
         p = _lib.GcnParams(_f32c(self.weight, "weight").data_ptr(),
                            None if self.bias is None else _f32c(self.bias, "bias").data_ptr())
         out = torch.empty((N, self.out_channels), dtype=torch.float32, device=x.device)
@@ -122,6 +147,24 @@ class GCNConv(torch.nn.Module):
                                                  None if ins is None else _f32c(ins, "ins").data_ptr(), out.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _stream(x.device)))
         return out
+
+
+    def _forward_autograd(self, x, graph, ins):
+        """Differentiable GCNConv (PyG 1.6/1.7 gcn_norm with add_remaining_self_loops, then propagate; pipeline_model_gcn.py:628,660):
+        out = D^-1/2 (A' + I) D^-1/2 (x W) + b, A' = the edges that are not self loops.  x W (and dx, dW) on the library's
+        products -- with `ins` the instruction rows' product is one row per GRAPH, broadcast by the HIP per-graph op --, the
+        neighbour sum and its adjoint on the HIP CSR kernels (deterministic)."""
+        src, dst = graph._keep[0][0], graph._keep[0][1]
+        Dn, N = x.shape[1], x.shape[0]
+        xw = _ProjectionLinear.apply(x, self.weight[:Dn].t().contiguous())
+        if ins is not None:
+            xw = xw + graph_rows(_LibMatmul.apply(_f32c(ins, "ins"), self.weight[Dn:]), graph)
+        not_loop = src != dst
+        deg = torch.bincount(dst[not_loop], minlength=N).to(torch.float32) + 1.0
+        dis = deg.rsqrt()
+        norm = (dis[src] * dis[dst] * not_loop.to(torch.float32)).unsqueeze(1)
+        out = edge_scatter_add(norm * edge_gather(xw, graph, "src"), graph) + (dis * dis).unsqueeze(1) * xw
+        return out if self.bias is None else out + self.bias
 
 
 def _bn_relu_chain(x: Tensor, bns) -> Tensor:
@@ -141,18 +184,18 @@ def _bn_relu_chain(x: Tensor, bns) -> Tensor:
 
 
 class _SeqBase(torch.nn.Module):
-    def _check(self):
-        if self.training:
-            raise NotImplementedError("the HIP path implements inference; call .eval() (SURVEY 8f-4)")
+    def _bn_relu_step(self, h, i):
+        """One (BatchNorm, ReLU, dropout) stage of the differentiable chain (pipeline_model_gine.py:668-670)."""
+        import torch.nn.functional as F
+        return F.dropout(torch.relu(self.bns[i](h)), p=self.dropout, training=self.training)
 
     def _as_written_autograd(self, x):
         """What the reference module returns, differentiably: the conv results are discarded
         (pipeline_model_gine.py:665-671 / pipeline_model_gcn.py:660-666), so the output -- in training too -- is x pushed
         through (BatchNorm, ReLU, dropout) of every layer but the last; no graph work is involved."""
-        import torch.nn.functional as F
         h = x
-        for bn in self.bns:
-            h = F.dropout(torch.relu(bn(h)), p=self.dropout, training=self.training)
+        for i in range(len(self.bns)):
+            h = self._bn_relu_step(h, i)
         return h
 
     def reset_parameters(self):
@@ -176,16 +219,14 @@ class gine_seq(_SeqBase):
         self.dropout = dropout
 
     def forward(self, x, edge_index, edge_attr, instr_vectors, batch, graph=None, return_convs=False):
-        if not return_convs and (self.training or (torch.is_grad_enabled() and (
-                x.requires_grad or any(q.requires_grad for q in self.bns.parameters())))):
+        grad = self.training or _wants_grad(self, x, edge_attr, instr_vectors)
+        if grad and not return_convs:
             return self._as_written_autograd(_f32c(x, "x"))
-        _inference_only(self, x, edge_attr, instr_vectors)
-        self._check()
-        out = _bn_relu_chain(x, list(self.bns))           # conv_res is discarded by the reference
-        if not return_convs:
-            return out
         # kernel-level target: the five conv results the reference computes (and drops); hop i sees
         # h = x after i BN/ReLU stages and instruction vector i
+        out = None if grad else _bn_relu_chain(x, list(self.bns))           # conv_res is discarded by the reference
+        if not return_convs:
+            return out
         N, B = x.shape[0], instr_vectors.shape[1]
         if graph is None:
             graph = SceneGraphBatch(edge_index, batch, N, B)
@@ -198,8 +239,8 @@ class gine_seq(_SeqBase):
                 convs.append(conv(torch.cat((h, ins[batch]), -1), edge_index,
                                   torch.cat((edge_attr, ins[batch[edge_index[0]]]), -1), graph=graph))
             if i != len(self.convs) - 1:
-                h = _bn_relu_chain(h, [self.bns[i]])
-        return out, convs
+                h = self._bn_relu_step(h, i) if grad else _bn_relu_chain(h, [self.bns[i]])
+        return (h if grad else out), convs
 
 
 class gcn_seq(_SeqBase):
@@ -213,12 +254,10 @@ class gcn_seq(_SeqBase):
         self.dropout = dropout
 
     def forward(self, x, edge_index, instr_vectors, batch, graph=None, return_convs=False):
-        if not return_convs and (self.training or (torch.is_grad_enabled() and (
-                x.requires_grad or any(q.requires_grad for q in self.bns.parameters())))):
+        grad = self.training or _wants_grad(self, x, instr_vectors)
+        if grad and not return_convs:
             return self._as_written_autograd(_f32c(x, "x"))
-        _inference_only(self, x, instr_vectors)
-        self._check()
-        out = _bn_relu_chain(x, list(self.bns))
+        out = None if grad else _bn_relu_chain(x, list(self.bns))
         if not return_convs:
             return out
         N, B = x.shape[0], instr_vectors.shape[1]
@@ -226,7 +265,8 @@ class gcn_seq(_SeqBase):
             graph = SceneGraphBatch(edge_index, batch, N, B)
         convs, h = [], _f32c(x, "x")
         for i, conv in enumerate(self.convs):
-            convs.append(conv(h, edge_index, graph=graph, ins=_f32c(instr_vectors[i], "instr_vectors")))
+            ins = _f32c(instr_vectors[i], "instr_vectors")
+            convs.append(conv(h, edge_index, graph=graph, ins=ins))
             if i != len(self.convs) - 1:
-                h = _bn_relu_chain(h, [self.bns[i]])
-        return out, convs
+                h = self._bn_relu_step(h, i) if grad else _bn_relu_chain(h, [self.bns[i]])
+        return (h if grad else out), convs

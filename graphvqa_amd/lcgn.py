@@ -20,6 +20,19 @@ from .gat_skip import (_f32c, _workspace, _glorot, _ProjectionLinear, gat_messag
 from .graph import SceneGraphBatch, _stream
 
 
+class _StoreBf16(torch.autograd.Function):
+    """A per-node tensor as the bf16-node-feature mode keeps it in HBM: rounded to bf16 (to nearest even) in the forward, the
+    gradient passed straight through -- the rounding is a storage format, not part of the model."""
+
+    @staticmethod
+    def forward(ctx, v):
+        return v.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class gat_lcgn(nn.Module):
     """Parameter container of the reference's `gat_lcgn` layer (lcgn.py:63-118).  Its compute is fused
     into `lcgn_seq.forward`; calling it on its own is not part of the GraphVQA path."""
@@ -92,37 +105,38 @@ class lcgn_seq(nn.Module):
         dropouts) and their dx / dW run on the library's own products (_ProjectionLinear: the arithmetic
         GVQA_OPT_PROJECTION selects, as in the eval path), the per-question layers are torch ops; the per-graph command broadcasts, the softmax-weighted neighbour sum and their backward run on the HIP
         per-graph / message-passing kernels (the dot-product logit x_l[src] . (proj_cmd * x_r)[dst], lcgn.py:154,207,
-        enters the message passing as its per-edge term).  fp32 node tensors only."""
-        if self.node_feature_dtype != torch.float32:
-            raise NotImplementedError("lcgn_seq: the differentiable path keeps fp32 node tensors "
-                                      "(node_feature_dtype=torch.bfloat16 is an inference storage mode)")
+        enters the message passing as its per-edge term).
+        node_feature_dtype = bfloat16 (BASELINE config 5): the per-node tensors are rounded to bf16 at the points where the
+        inference kernels store them (x, x_loc, proj_x_loc, the x_loc block of the joint projection, x_ctx, the gated product,
+        x_l | x_r | x_val, the message), with a straight-through gradient; the fp32 master weights are used as they are (the
+        inference path multiplies by their two bf16 pieces: 16 of their 24 bits) and gradients stay fp32."""
+        rb = _StoreBf16.apply if self.node_feature_dtype == torch.bfloat16 else (lambda v: v)
         if self.gat_heads != 1:
             raise NotImplementedError("lcgn_seq: gat_heads != 1 is not implemented (reference default 1)")
         O, N, E = self.out_channels, x.shape[0], edge_index.shape[1]
         L = self.lcgn
         proj = _ProjectionLinear.apply              # node-sized products + their dx / dW on the library's own GEMMs
         init, p_loc, p_ctx = self.init_sg_emb_input, self.proj_x_loc, self.proj_x_ctx
-        x_loc = init[1](proj(x, init[0].weight, init[0].bias))                        # :305
-        x_ctx = x_ctx_init                                                            # :306
+        x_loc = init[1](rb(proj(rb(x), init[0].weight, init[0].bias)))                # :305
+        x_ctx = rb(x_ctx_init)                                                        # :306
         plin = lambda m, v: proj(v, m.weight, m.bias)      # per-question Linears ([B, .]-sized): the library's f32-input kernel, not torch's vendor GEMM
         q_emb = torch.relu(plin(self.qInput1, q))                                     # :307
-        proj_x_loc = proj(p_loc[0](x_loc), p_loc[1].weight, p_loc[1].bias)            # :308
+        proj_x_loc = rb(proj(p_loc[0](x_loc), p_loc[1].weight, p_loc[1].bias))        # :308
         lo = lstm.transpose(1, 0)                                                     # [B, L, O]
         zeros2 = torch.zeros((N, 2), device=x.device)
         p_att = L.dropout if self.training else 0.0
         # lin_l / lin_r / cal_x act on x_joint = [x_loc | x_ctx | proj_x_ctx(x_ctx) * proj_x_loc] (:312-313, :144-145, :230) as
         # one stacked [3O, 3O] weight; its x_loc column block multiplies an iteration-invariant operand: applied once
         w_joint = torch.cat([L.lin_l.weight, L.lin_r.weight, L.cal_x.weight], dim=0)
-        z_loc = proj(x_loc, w_joint[:, :O]).split(O, dim=1)
+        z_loc = rb(proj(x_loc, w_joint[:, :O]))
         w_iter = w_joint[:, O:]
         for t in range(self.MAX_ITER_NUM):
             q_cmd = plin(getattr(self, "qInput2_%d" % t), q_emb)                      # :292-300
             # cmd_inter2logits is a [1, O] Linear: its product with q_cmd * lstm_out is a weighted sum over channels
             att = torch.softmax(((q_cmd * self.cmd_inter2logits.weight)[:, None, :] * lo).sum(dim=-1) + self.cmd_inter2logits.bias, dim=-1)
             cmd = (att[:, :, None] * lo).sum(dim=1)                                    # (a weighted sum over the L question tokens: no batched GEMM)
-            x_pair = torch.cat([x_ctx, proj(p_ctx[0](x_ctx), p_ctx[1].weight, p_ctx[1].bias) * proj_x_loc], dim=-1)
-            z = proj(x_pair, w_iter).split(O, dim=1)
-            x_l, x_r, x_val = z[0] + z_loc[0], z[1] + z_loc[1], z[2] + z_loc[2]
+            x_pair = torch.cat([x_ctx, rb(proj(p_ctx[0](x_ctx), p_ctx[1].weight, p_ctx[1].bias) * proj_x_loc)], dim=-1)
+            x_l, x_r, x_val = rb(proj(x_pair, w_iter) + z_loc).split(O, dim=1)
             y = graph_rows(plin(L.proj_cmd, cmd), graph) * x_r                        # :148-154
             a_edge = (edge_gather(x_l, graph, "src") * edge_gather(y, graph, "dst")).sum(dim=-1, keepdim=True)   # :207
             mask = torch.bernoulli(torch.full((E, 1), 1.0 - p_att, device=x.device)) / (1.0 - p_att) if p_att > 0 else None
@@ -130,7 +144,7 @@ class lcgn_seq(nn.Module):
             msg = agg * graph_rows(plin(L.cal_cmd, cmd), graph)                       # :231 (edges are intra-graph)
             if L.bias is not None:
                 msg = msg + L.bias
-            x_ctx = proj(torch.cat([x_ctx, msg], dim=-1), self.output_layer.weight, self.output_layer.bias)   # :316-319
+            x_ctx = rb(proj(torch.cat([x_ctx, rb(msg)], dim=-1), self.output_layer.weight, self.output_layer.bias))   # :316-319
         return proj(torch.cat([x_loc, x_ctx], dim=-1), self.fin_layer.weight, self.fin_layer.bias)           # :321-322
 
     def forward(self, x, edge_index, batch, q_encoding, lstm_outputs, edge_attr=None, instr_vectors=None,
