@@ -223,7 +223,8 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);
 int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);
 int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t ld, const float* a, const int64_t* ia, int64_t lda,
-                               const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream);
+                               const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream,
+                               const int64_t* tok = nullptr, int V = 0, const uint8_t* neg = nullptr);   // tok: Y rows are +-Y[tok[r]] (a table)
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
                         int64_t ldc, hipStream_t stream, int batch = 1,

@@ -110,6 +110,52 @@ __global__ __launch_bounds__(256) void k_segment_mean(int N, int D, const float*
     }
 }
 
+// agg[i, :] = mean over the in-edges e of node i of relu(y[e, :] + a[src_e, :] + bias)  -- the activation of node_mlp_1's first
+// Linear (:92-94), averaged per destination BEFORE the second Linear: scatter_mean(Lin2(relu(.))) = Lin2'(scatter_mean(relu(.)))
+// with the bias kept for nodes that have an in-edge (the mean of zero rows is zero, :96), so the edge-sized product, its
+// operand pack and the [E, D] message tensor become one node-sized product.  Rows summed in COO order (deterministic).
+// Also add[i, :] += has_in_edge(i) * cvec[:]: the folded bias term, in place on the addend of the next product.
+// One thread per (node, 4 channels).
+__global__ __launch_bounds__(256) void k_gather_relu_segment_mean(int64_t N, int D, const float* __restrict__ y, const float* __restrict__ a,
+                                                                  int64_t lda, const float* __restrict__ bias, const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_eid,
+                                                                  float* __restrict__ agg, const float* __restrict__ cvec,
+                                                                  float* __restrict__ add, int64_t ld_add) {
+    const int DW = D / 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * DW) return;
+    const int64_t i = t / DW;
+    const int c = (int)(t - i * DW) * 4;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    const float4 bi = *reinterpret_cast<const float4*>(bias + c);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = lo;
+    for (; s + 1 < hi; s += 2) {                            // two edges' rows in flight
+        const float4 y0 = *reinterpret_cast<const float4*>(y + (int64_t)csr_eid[s] * D + c);
+        const float4 y1 = *reinterpret_cast<const float4*>(y + (int64_t)csr_eid[s + 1] * D + c);
+        const float4 a0 = *reinterpret_cast<const float4*>(a + (int64_t)csr_src[s] * lda + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(a + (int64_t)csr_src[s + 1] * lda + c);
+        acc.x += fmaxf(y0.x + a0.x + bi.x, 0.f); acc.y += fmaxf(y0.y + a0.y + bi.y, 0.f);
+        acc.z += fmaxf(y0.z + a0.z + bi.z, 0.f); acc.w += fmaxf(y0.w + a0.w + bi.w, 0.f);
+        acc.x += fmaxf(y1.x + a1.x + bi.x, 0.f); acc.y += fmaxf(y1.y + a1.y + bi.y, 0.f);
+        acc.z += fmaxf(y1.z + a1.z + bi.z, 0.f); acc.w += fmaxf(y1.w + a1.w + bi.w, 0.f);
+    }
+    if (s < hi) {
+        const float4 y0 = *reinterpret_cast<const float4*>(y + (int64_t)csr_eid[s] * D + c);
+        const float4 a0 = *reinterpret_cast<const float4*>(a + (int64_t)csr_src[s] * lda + c);
+        acc.x += fmaxf(y0.x + a0.x + bi.x, 0.f); acc.y += fmaxf(y0.y + a0.y + bi.y, 0.f);
+        acc.z += fmaxf(y0.z + a0.z + bi.z, 0.f); acc.w += fmaxf(y0.w + a0.w + bi.w, 0.f);
+    }
+    const float inv = 1.0f / (float)max(hi - lo, 1);
+    *reinterpret_cast<float4*>(agg + i * D + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if (hi > lo) {
+        float4 v = *reinterpret_cast<float4*>(add + i * ld_add + c);
+        const float4 cv = *reinterpret_cast<const float4*>(cvec + c);
+        v.x += cv.x; v.y += cv.y; v.z += cv.z; v.w += cv.w;
+        *reinterpret_cast<float4*>(add + i * ld_add + c) = v;
+    }
+}
+
 // Per-graph LayerNorm over nodes x channels (my_graph_layernorm.py:57-78): mean, then the variance
 // of the centred values, out = xc / (sqrt(var) + eps) * w[0] + b[0].  One block per graph.
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -160,7 +206,7 @@ __global__ __launch_bounds__(256) void k_small_matmul_nn(int M, int N, int K, co
     if (sl == 0 && k < N) C[(int64_t)i * ldc + k] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
-struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, apk_n, apk_e, wpk, Z, wc, wpk4, total; };
+struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, wf2, bf2, apk_n, apk_e, wpk, Z, wc, wpk4, total; };
 static EncLayout enc_layout(int64_t N, int64_t E, int D) {
     EncLayout L; size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
@@ -168,7 +214,7 @@ static EncLayout enc_layout(int64_t N, int64_t E, int D) {
     L.x0 = take(nd); L.e0 = take(ed); L.S = take(nd); L.Dd = take(nd); L.P = take(nd); L.Y = take(ed); L.m = take(ed);
     L.agg = take(nd); L.t = take(nd); L.x2 = take(nd); L.flags = take((size_t)E + 1);
     // folded weight / bias, packed two-piece operands (node rows, edge rows, one weight at a time)
-    L.wf = take((size_t)D * D * 4); L.bf = take((size_t)D * 4);
+    L.wf = take((size_t)D * D * 4); L.bf = take((size_t)D * 4); L.wf2 = take((size_t)D * D * 4); L.bf2 = take((size_t)D * 4);
     L.apk_n = take(split_packed_bytes(2, N, D)); L.apk_e = take(split_packed_bytes(2, E, D)); L.wpk = take(split_packed_bytes(2, D, D));
     // the four per-node column blocks that act on x0 as one product: result [N, 4D], stacked weight [4D, D] and its packed image
     L.Z = take(4 * nd); L.wc = take((size_t)4 * D * D * 4); L.wpk4 = take(split_packed_bytes(2, 4 * (int64_t)D, D));
@@ -281,8 +327,14 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         float* Te = P(L.e0);                                                 // [V, D] = emb W_e^T  (edge block of EdgeModel's first Linear)
         rc = launch_linear(V, D, D, p->embedding, D, p->edge0_weight + 2 * D, 3 * D, nullptr, 0, Te, D, 1, 0, 0, 0, stream);
         if (rc) return rc;
-        ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, (const float*)Te, (const uint8_t*)flags, P(L.Y));
-        GVQA_LAUNCH_CHECK();
+        // (one token per edge -- the GQA relation name -- and the gather pack below applies: the "sum" is a row of Te, fetched inside
+        //  the pack pass; otherwise the token sums are formed here)
+        const bool gpack = D <= 512 && al16(p->edge0_bias) && al16(p->node1_0_bias);
+        const bool tok_in_pack = gpack && edge_tokens_per_edge == 1;
+        if (!tok_in_pack) {
+            ENC_LAUNCH(k_embed_sum, E, E, edge_tokens_per_edge, V, D, edge_tokens, (const float*)Te, (const uint8_t*)flags, P(L.Y));
+            GVQA_LAUNCH_CHECK();
+        }
         // the four per-node column blocks that act on x0 -- EdgeModel's x_src and x_dst, node_mlp_1's x_src, node_mlp_2's x -- as ONE
         // product Z [N, 4D] = x0 [W_s; W_d; W_p; W_t]^T: the blocks are stacked (parameter-sized copies), packed once, x0 packed once
         float* Z = P(L.Z);
@@ -309,8 +361,8 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         GVQA_LAUNCH_CHECK();
         // Y = relu(S[src] + Dd[dst] + Y + b) goes straight into its packed form (the gathers ride in the pack pass: the fp32 Y is
         // only ever a matrix-core operand), packed once for both of its products
-        const bool gpack = D <= 512 && al16(p->edge0_bias) && al16(p->node1_0_bias);
-        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, Z, src, ldz, Z + D, dst, ldz, p->edge0_bias, apk_e, stream);
+        if (tok_in_pack) rc = launch_split2h_pack_gather(E, D, Te, D, Z, src, ldz, Z + D, dst, ldz, p->edge0_bias, apk_e, stream, edge_tokens, V, flags);
+        else if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, Z, src, ldz, Z + D, dst, ldz, p->edge0_bias, apk_e, stream);
         else {
             ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)Z, src, (const float*)(Z + D), dst, p->edge0_bias, P(L.Y), (const float*)nullptr, ldz, ldz);
             rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
@@ -322,25 +374,24 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
             LinearEpilogue ef{P(L.bf), nullptr, 0, nullptr, 0, 0};
             if ((rc = prod(E, apk_e, P(L.wf), D, ef, P(L.Y)))) return rc;     // (the fp32 Y is free: its packed image is the operand)
         }
-        if (gpack) rc = launch_split2h_pack_gather(E, D, P(L.Y), D, Z + 2 * D, src, ldz, nullptr, nullptr, 0, p->node1_0_bias, apk_e, stream);
-        else {
-            ENC_LAUNCH(k_gather_add_relu, E, E, D, (const float*)(Z + 2 * D), src, (const float*)nullptr, (const int64_t*)nullptr,
-                       p->node1_0_bias, P(L.Y), (const float*)nullptr, ldz, (int64_t)0);
-            rc = launch_split_pack(2, E, D, P(L.Y), D, apk_e, stream);
-        }
-        if (rc) return rc;
-        {
-            LinearEpilogue ep{p->node1_2_bias, nullptr, 0, nullptr, 0, 0};
-            if ((rc = prod(E, apk_e, p->node1_2_weight, D, ep, P(L.m)))) return rc;
-        }
-        if (v4) hipLaunchKernelGGL(k_segment_mean<4>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, D, P(L.m), g->rowptr, g->csr_eid,
-                                   P(L.agg));
+        // NodeModel: scatter_mean(Lin2(relu(pre))) feeding node_mlp_2's first Linear (:92-98) has nothing non-linear between the
+        // relu and that Linear's own: the mean is taken on relu(pre) ([E, D] read once, [N, D] written), and Lin2 and the agg block
+        // of node_mlp_2's first Linear act on it as ONE node-sized product with W'' = W2_agg W1_2 (parameter-sized); the bias
+        // W2_agg b1_2 belongs to the nodes that have an in-edge and is added to their rows of the product's addend (x0's block).
+        // Gone: an edge-sized product, its gather + pack pass over [E, D], the message tensor m and its segment mean.
+        hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node2_0_weight + D,
+                           (int64_t)2 * D, p->node1_2_weight, (int64_t)D, P(L.wf2), (int64_t)D);
+        hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node2_0_weight + D, (int64_t)2 * D,
+                           p->node1_2_bias, (int64_t)1, P(L.bf2), (int64_t)1);
+        hipLaunchKernelGGL(k_gather_relu_segment_mean, dim3((unsigned)cdiv(N * (D / 4), 256)), dim3(256), 0, stream, N, (int)D, (const float*)P(L.Y),
+                           (const float*)(Z + 2 * D), ldz, p->node1_0_bias, g->rowptr, g->csr_src, g->csr_eid, P(L.agg), (const float*)P(L.bf2),
+                           Z + 3 * D, ldz);
         GVQA_LAUNCH_CHECK();
         rc = launch_split_pack(2, N, D, P(L.agg), D, apk_n, stream);
         if (rc) return rc;
         {
-            LinearEpilogue ep{p->node2_0_bias, Z + 3 * D, ldz, nullptr, 0, 1};   // t = relu(x0's block + agg W^T + bias)
-            if ((rc = prod(N, apk_n, p->node2_0_weight + D, 2 * D, ep, P(L.t)))) return rc;
+            LinearEpilogue ep{p->node2_0_bias, Z + 3 * D, ldz, nullptr, 0, 1};   // t = relu(x0's block (+ folded bias) + mean W''^T + bias)
+            if ((rc = prod(N, apk_n, P(L.wf2), D, ep, P(L.t)))) return rc;
         }
         rc = launch_split_pack(2, N, D, P(L.t), D, apk_n, stream);
         if (rc) return rc;

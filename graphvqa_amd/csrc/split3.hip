@@ -875,6 +875,9 @@ struct PackRows {
     const float* ga; const int64_t* gia; int64_t glda;
     const float* gb; const int64_t* gib; int64_t gldb;
     const float* gbias;
+    // GATHER, optional: row r of X is itself a gather, X[r, :] = (gneg[r] ? -1 : 1) * T[clamp(gtok[r], 0, gV - 1), :] with T = pr.X
+    // (the one-token embedding "sum" of an edge against the projected table: k_embed_sum's pass folded into this one)
+    const int64_t* gtok; int gV; const uint8_t* gneg;
 };                                // HEADS2 (hop2.hip): packed row 256 cb + 64 w + 32 j + t = W row h C + cb cw + j hw + cc, (h, cc) = divmod(32 w + t, hw), hw = cw / 2
 // head and channel of row `within` (0..255) of column block cb
 template <int MAP>
@@ -978,16 +981,29 @@ __global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, i
     const int nit_all = ((KB + 2 * NWV - 1) / (2 * NWV)) * 2;         // iterations that cover every k block (NIT == 0 path)
     [[maybe_unused]] const float* g_arow = nullptr;
     [[maybe_unused]] const float* g_brow = nullptr;
+    [[maybe_unused]] float g_sign = 1.f;
     if constexpr (MAP == PACK_GATHER) {                               // (launched with NIT > 0 only: the rows stay in registers)
         g_arow = pr.ga + (row_on ? pr.gia[src_row] : 0) * pr.glda;
         g_brow = pr.gb ? pr.gb + (row_on ? pr.gib[src_row] : 0) * pr.gldb : nullptr;
+        if (pr.gtok) {
+            int64_t id = row_on ? pr.gtok[src_row] : 0;
+            id = id < 0 ? 0 : (id >= pr.gV ? pr.gV - 1 : id);
+            row = pr.X + id * pr.ld;
+            g_sign = (pr.gneg && row_on && pr.gneg[src_row]) ? -1.f : 1.f;
+        }
     }
     if (NIT > 0) {
 #pragma unroll
         for (int it = 0; it < NR; ++it) {
             const int kb = kb_of(it);
             load_row8(row, row_on && kb < KB, kb * 16 + kh, K, vec, v[it]);
-            if constexpr (MAP == PACK_GATHER) gather_add_relu8(g_arow, g_brow, pr.gbias, row_on && kb < KB, kb * 16 + kh, K, v[it]);
+            if constexpr (MAP == PACK_GATHER) {
+                if (pr.gtok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[it][e] *= g_sign;
+                }
+                gather_add_relu8(g_arow, g_brow, pr.gbias, row_on && kb < KB, kb * 16 + kh, K, v[it]);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[it][e]));
         }
@@ -1154,7 +1170,8 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
 
 // The two-piece pack of relu(Y + a[ia] + b[ib] + bias) (PackRows GATHER): K % 4 == 0, K <= 512, 16-byte aligned rows
 int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t ld, const float* a, const int64_t* ia, int64_t lda,
-                               const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream) {
+                               const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream,
+                               const int64_t* tok, int V, const uint8_t* neg) {
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     GVQA_REQUIRE(rows >= 0 && K > 0 && K % 4 == 0 && K <= 512 && ld % 4 == 0 && ld >= K && lda % 4 == 0 && (!b || ldb % 4 == 0), GVQA_E_UNSUPPORTED,
                  "split_pack_gather: K %% 4 == 0, K <= 512, row strides multiples of 4");
@@ -1163,7 +1180,8 @@ int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t 
                  "split_pack_gather: null / unaligned operand");
     const int64_t RT = cdiv(rows, 32);
     GVQA_REQUIRE(RT < (1ll << 31), GVQA_E_INVALID, "split_pack_gather: too many rows");
-    PackRows pr{Y, ld, rows, nullptr, 0, 0, 0, a, ia, lda, b, ib, ldb, bias};
+    GVQA_REQUIRE(!tok || V > 0, GVQA_E_INVALID, "split_pack_gather: token rows need the table's row count");
+    PackRows pr{Y, ld, rows, nullptr, 0, 0, 0, a, ia, lda, b, ib, ldb, bias, tok, V, neg};
     return launch_split2h_pack_tiles<PACK_GATHER>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
 }
 

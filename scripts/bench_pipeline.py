@@ -30,6 +30,10 @@ def timed(fn, iters=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e3
 g = SceneGraphBatch(data.edge_index, data.batch, N, B)
 xe, ee, _ = enc(data, graph=g); h = gs(xe, data.edge_index, ee, ins, data.batch, graph=g); pf = pool(h, q, data.batch, graph=g)
+if os.environ.get("STAGE"):          # one stage only (for a per-kernel profile of that stage): STAGE=encoder|gat_seq|pooling|classifier
+    fn = {"encoder": lambda: enc(data, graph=g), "gat_seq": lambda: gs(xe, data.edge_index, ee, ins, data.batch, graph=g),
+          "pooling": lambda: pool(h, q, data.batch, graph=g), "classifier": lambda: clf(pf, q)}[os.environ["STAGE"]]
+    print(json.dumps({os.environ["STAGE"] + "_ms": timed(fn, 20)})); sys.exit(0)
 res = {"N": N, "E": E, "B": B,
        "csr_build_ms": timed(lambda: SceneGraphBatch(data.edge_index, data.batch, N, B)),
        "encoder_ms": timed(lambda: enc(data, graph=g)),
