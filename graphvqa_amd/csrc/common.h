@@ -84,6 +84,11 @@ struct LinearEpilogue {
     // batched launches of the split GEMM (gridDim.z > 1; split-K chunks of the TN product): strides per batch of the packed
     // operands (16-bit elements), of C (floats) and of the operands' inverse-scale arrays (floats)
     int64_t zs_a, zs_b, zs_c, zs_ia, zs_ib;
+    // split GEMM, two-piece operands: the finished rows' dot product with a vector, in 16 partial sums per row (slot = the wave
+    // column that owns those output columns; unused slots are not written: clear the array first).  rowdot_out [M, 16];
+    // sum over a row's 16 slots = (finished row) . rowdot_w[0:N].  C may be NULL then (the rows themselves are not stored).
+    const float* rowdot_w;
+    float* rowdot_out;
 };
 
 // GEMM entry used by the orchestration code (defined in gemm.hip).
@@ -225,6 +230,8 @@ int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t l
 int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t ld, const float* a, const int64_t* ia, int64_t lda,
                                const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream,
                                const int64_t* tok = nullptr, int V = 0, const uint8_t* neg = nullptr);   // tok: Y rows are +-Y[tok[r]] (a table)
+int launch_split2h_pack_rowmul(int64_t rows, int64_t K, const float* X, int64_t ld, const float* R, const int32_t* idx, int64_t ldr, void* packed,
+                               hipStream_t stream);
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
                         int64_t ldc, hipStream_t stream, int batch = 1,

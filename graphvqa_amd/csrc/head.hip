@@ -21,19 +21,52 @@ __global__ __launch_bounds__(256) void k_scale_rows_by_graph(int64_t N, int C, c
 
 // One block per graph: softmax of the node gates (PyG: exp(g - max) / (sum + 1e-16)), then
 // out[g, :] = sum_n p_n xn[n, :] with nodes added in order (scatter_add order).
+// PARTS = 16: gate[n] = sum of the 16 partial dot products the gate_nn product's epilogue left per node (split3.hip, rowdot) +
+// gate_bias[0], summed in slot order (deterministic); PARTS = 1: gate[n] as is.  Graphs of up to 256 nodes keep their softmax
+// weights in LDS (one expf per node instead of one per node and channel).
+template <int PARTS>
 __global__ __launch_bounds__(256) void k_graph_attention_pool(int C, const int32_t* __restrict__ graph_ptr,
-                                                              const float* __restrict__ gate, const float* __restrict__ xn,
-                                                              float* __restrict__ out) {
-    const int g = blockIdx.x;
-    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1];
+                                                              const float* __restrict__ gate, const float* __restrict__ gate_bias,
+                                                              const float* __restrict__ xn, float* __restrict__ out) {
+    __shared__ float p_s[256];
+    __shared__ float red[8];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int n0 = graph_ptr[g], n1 = graph_ptr[g + 1], cnt = n1 - n0;
+    auto gate_of = [&](int n) {
+        if (PARTS == 1) return gate[n];
+        const float4* q = reinterpret_cast<const float4*>(gate + (int64_t)n * 16);
+        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+        return ((((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)))) + gate_bias[0];
+    };
+    if (cnt <= 256) {
+        const float gv = tid < cnt ? gate_of(n0 + tid) : -INFINITY;
+        float m = gv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float ev = tid < cnt ? expf(gv - m) : 0.f;
+        p_s[tid] = ev;
+        __syncthreads();
+        float den = 0.f;
+        for (int n = 0; n < cnt; ++n) den += p_s[n];                  // in node order, like the scatter_add of the reference
+        den += 1e-16f;
+        for (int c = tid; c < C; c += 256) {
+            float acc = 0.f;
+            for (int n = 0; n < cnt; ++n) acc += (p_s[n] / den) * xn[(int64_t)(n0 + n) * C + c];
+            out[(int64_t)g * C + c] = acc;
+        }
+        return;
+    }
     float m = -INFINITY;
-    for (int n = n0; n < n1; ++n) m = fmaxf(m, gate[n]);
+    for (int n = n0; n < n1; ++n) m = fmaxf(m, gate_of(n));
     float den = 0.f;
-    for (int n = n0; n < n1; ++n) den += expf(gate[n] - m);
+    for (int n = n0; n < n1; ++n) den += expf(gate_of(n) - m);
     den += 1e-16f;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = tid; c < C; c += 256) {
         float acc = 0.f;
-        for (int n = n0; n < n1; ++n) acc += (expf(gate[n] - m) / den) * xn[(int64_t)n * C + c];
+        for (int n = n0; n < n1; ++n) acc += (expf(gate_of(n) - m) / den) * xn[(int64_t)n * C + c];
         out[(int64_t)g * C + c] = acc;
     }
 }
@@ -51,12 +84,12 @@ __global__ __launch_bounds__(256) void k_head_features(int64_t B, int Q, const f
     feat[b * 3 * Q + 2 * Q + c] = gv * qv;
 }
 
-struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, scratch, scratch_bytes, total; };
+struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, scratch, scratch_bytes, total; };      // gate: [N, 16] partial sums, or [N]
 static PoolLayout pool_layout(int64_t N, int64_t B, int Ch, int Dn) {
     PoolLayout L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
     L.h1 = take((size_t)N * Ch); L.xn = take((size_t)N * Ch); L.qh = take((size_t)B * Ch); L.qn = take((size_t)B * Ch);
-    L.prod = take((size_t)N * Ch); L.z = take((size_t)N * Ch); L.gate = take((size_t)N);
+    L.prod = take((size_t)N * Ch); L.z = take((size_t)N * Ch); L.gate = take((size_t)N * 16);
     L.scratch_bytes = linear_auto_scratch_bytes(N, Ch, Dn > Ch ? Dn : Ch);      // packed operands of the node MLP products
     L.scratch = take(L.scratch_bytes / sizeof(float));
     L.total = off;
@@ -100,16 +133,47 @@ int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, con
     NLIN(Ch, P(L.h1), p->node2_weight, p->node2_bias, 0, P(L.xn));
     LIN(B, Ch, Ch, u, p->ques0_weight, p->ques0_bias, 1, P(L.qh));                 // ques_nn (:165)
     LIN(B, Ch, Ch, P(L.qh), p->ques2_weight, p->ques2_bias, 0, P(L.qn));
-    if (N > 0) {
-        hipLaunchKernelGGL(k_scale_rows_by_graph, dim3((unsigned)cdiv(N * Ch, 256)), dim3(256), 0, stream, N, Ch, g->node_graph,
-                           P(L.qn), P(L.xn), P(L.prod));
-        GVQA_LAUNCH_CHECK();
+    // gate_nn on ques_nn(u)[batch] * x' (:165).  Large batches on the two-piece kernels: the per-graph row scaling rides in the
+    // operand pack (the product tensor is only ever a matrix-core operand), and the 512 -> 1 second Linear is the first product's
+    // epilogue (16 partial dot products per node, summed in order by the pooling kernel: z is never stored)
+    const bool fused = get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 && N > 0 && Ch % 4 == 0 && Ch <= 512 &&
+                       L.scratch_bytes >= linear_auto_scratch_bytes(N, Ch, Ch) &&
+                       2.0 * (double)N * Ch * Ch >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP) &&
+                       ((reinterpret_cast<uintptr_t>(p->gate0_bias) | reinterpret_cast<uintptr_t>(p->gate2_weight)) & 15) == 0;
+    bool parts = false;
+    if (fused) {
+        char* apk = base + L.scratch;
+        char* wpk = apk + align_up(split_packed_bytes(2, N, Ch), 256);
+        rc = launch_split2h_pack_rowmul(N, Ch, P(L.xn), Ch, P(L.qn), g->node_graph, Ch, apk, stream);
+        if (rc) return rc;
+        rc = launch_split_pack(2, Ch, Ch, p->gate0_weight, Ch, wpk, stream);
+        if (rc) return rc;
+        GVQA_HIP_CHECK(hipMemsetAsync(P(L.gate), 0, (size_t)N * 16 * sizeof(float), stream));
+        LinearEpilogue ep{p->gate0_bias, nullptr, 0, nullptr, 0, 1};
+        ep.rowdot_w = p->gate2_weight;
+        ep.rowdot_out = P(L.gate);
+        rc = launch_linear_split(2, N, Ch, Ch, apk, wpk, ep, nullptr, Ch, stream);
+        if (rc == GVQA_OK) parts = true;
+        else if (rc != GVQA_E_UNSUPPORTED) return rc;
+        else {                                                         // (a tile shape without the row-dot epilogue: store z, then the small product)
+            LinearEpilogue e1{p->gate0_bias, nullptr, 0, nullptr, 0, 1};
+            rc = launch_linear_split(2, N, Ch, Ch, apk, wpk, e1, P(L.z), Ch, stream);
+            if (rc) return rc;
+            LIN(N, 1, Ch, P(L.z), p->gate2_weight, p->gate2_bias, 0, P(L.gate));
+        }
+    } else {
+        if (N > 0) {
+            hipLaunchKernelGGL(k_scale_rows_by_graph, dim3((unsigned)cdiv(N * Ch, 256)), dim3(256), 0, stream, N, Ch, g->node_graph,
+                               P(L.qn), P(L.xn), P(L.prod));
+            GVQA_LAUNCH_CHECK();
+        }
+        NLIN(Ch, P(L.prod), p->gate0_weight, p->gate0_bias, 1, P(L.z));                // gate_nn (:165)
+        LIN(N, 1, Ch, P(L.z), p->gate2_weight, p->gate2_bias, 0, P(L.gate));
     }
-    NLIN(Ch, P(L.prod), p->gate0_weight, p->gate0_bias, 1, P(L.z));                // gate_nn (:165)
-    LIN(N, 1, Ch, P(L.z), p->gate2_weight, p->gate2_bias, 0, P(L.gate));
 #undef LIN
 #undef NLIN
-    hipLaunchKernelGGL(k_graph_attention_pool, dim3((unsigned)B), dim3(256), 0, stream, Ch, g->graph_ptr, P(L.gate), P(L.xn), out);
+    if (parts) hipLaunchKernelGGL(k_graph_attention_pool<16>, dim3((unsigned)B), dim3(256), 0, stream, Ch, g->graph_ptr, P(L.gate), p->gate2_bias, P(L.xn), out);
+    else hipLaunchKernelGGL(k_graph_attention_pool<1>, dim3((unsigned)B), dim3(256), 0, stream, Ch, g->graph_ptr, P(L.gate), p->gate2_bias, P(L.xn), out);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

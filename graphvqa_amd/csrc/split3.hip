@@ -758,7 +758,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         }
         return;
     }
-    auto finish = [&](float4 v, int gr, int gc) {      // bias / addend / mul / activation on 4 consecutive columns, then the store
+    auto finish = [&](float4 v, int gr, int gc) -> float4 {      // bias / addend / mul / activation on 4 consecutive columns, then the store (C NULL: no store)
         if constexpr (NP == 2) {                       // undo the operands' power-of-two scales (exact)
             const float sa = a_inv[gr];
             const float4 sb = *reinterpret_cast<const float4*>(b_inv + gc);
@@ -781,7 +781,8 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             v.x = v.x > 0.f ? v.x : expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : expf(v.y) - 1.f;
             v.z = v.z > 0.f ? v.z : expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : expf(v.w) - 1.f;
         }
-        *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
+        if (C) *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
+        return v;
     };
     // transposed accumulators: lane (m = lane & 31, h = lane >> 5) owns columns 8 q + 4 h + 0..3 of row m of tile (i, j)
     if (EPI == 0) {
@@ -811,6 +812,14 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const int rr = lane >> 3, cc = lane & 7;       // read side: row within an 8-row pass, 16-byte chunk
         unsigned char* img = smem + wave * 8192;
         int flip = 0;
+        // ep.rowdot_w: the finished row's dot product with a vector, rd[i][ps] = this lane's 4-column share of row (i, ps * 8 + rr)
+        // over the wave's TN tiles (the pooling head's 512 -> 1 gate Linear on top of gate_nn's first layer: the layer's output is
+        // only ever that dot product's operand)
+        float rd[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) rd[i][ps] = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -822,14 +831,32 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                     *reinterpret_cast<float4*>(t + m * 128 + (((2 * q + h) ^ (m & 7)) << 4)) =
                         make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 const int gc = (bn * FB + wc * TN + j) * 32 + cc * 4;
+                float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ep.rowdot_w && gc < N) w4 = *reinterpret_cast<const float4*>(ep.rowdot_w + gc);
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     const int r = ps * 8 + rr;
                     const float4 v = *reinterpret_cast<const float4*>(t + r * 128 + ((cc ^ (r & 7)) << 4));
                     const int gr = (bm * FA + wr * TM + i) * 32 + r;
-                    if (gr < M && gc < N) finish(v, gr, gc);
+                    if (gr < M && gc < N) {
+                        const float4 o = finish(v, gr, gc);
+                        rd[i][ps] += (o.x * w4.x + o.y * w4.y) + (o.z * w4.z + o.w * w4.w);
+                    }
                 }
             }
+        if (ep.rowdot_w) {       // (uniform) the 8 lanes of a row -> one partial per (row, wave column): slot bn WN + wc of the row's 16
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    float tsum = rd[i][ps];
+                    tsum += __shfl_xor(tsum, 1, 64);
+                    tsum += __shfl_xor(tsum, 2, 64);
+                    tsum += __shfl_xor(tsum, 4, 64);
+                    const int gr = (bm * FA + wr * TM + i) * 32 + ps * 8 + rr;
+                    if (cc == 0 && gr < M) ep.rowdot_out[(int64_t)gr * 16 + bn * WN + wc] = tsum;
+                }
+        }
     }
 }
 
@@ -878,6 +905,9 @@ struct PackRows {
     // GATHER, optional: row r of X is itself a gather, X[r, :] = (gneg[r] ? -1 : 1) * T[clamp(gtok[r], 0, gV - 1), :] with T = pr.X
     // (the one-token embedding "sum" of an edge against the projected table: k_embed_sum's pass folded into this one)
     const int64_t* gtok; int gV; const uint8_t* gneg;
+    // GATHER, optional: gop = 1 -- the packed value is X[r, k] * ga[gi32[r], k] (rows scaled by a per-graph row: the pooling head's
+    // ques_nn(u)[batch] * x', pipeline_model_gat.py:165, formed on the way into gate_nn's operand); gia NULL, gi32 the int32 index
+    const int32_t* gi32; int gop;
 };                                // HEADS2 (hop2.hip): packed row 256 cb + 64 w + 32 j + t = W row h C + cb cw + j hw + cc, (h, cc) = divmod(32 w + t, hw), hw = cw / 2
 // head and channel of row `within` (0..255) of column block cb
 template <int MAP>
@@ -942,6 +972,18 @@ __device__ __forceinline__ void gather_add_relu8(const float* arow, const float*
     }
 }
 
+// GATHER map, gop = 1: v *= a_row[k0..]
+__device__ __forceinline__ void gather_mul8(const float* arow, bool on, int k0, int K, float (&v)[8]) {
+    if (!on) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = k0 + 4 * h;
+        if (k >= K) { v[4 * h] = v[4 * h + 1] = v[4 * h + 2] = v[4 * h + 3] = 0.f; continue; }
+        const float4 a = *reinterpret_cast<const float4*>(arow + k);
+        v[4 * h + 0] *= a.x; v[4 * h + 1] *= a.y; v[4 * h + 2] *= a.z; v[4 * h + 3] *= a.w;
+    }
+}
+
 // One block (4 waves) per 32-row tile; wave w walks the k-block PAIRS 2w, 2w + 1, 2w + 8, 2w + 9, ... (a pair is one 128-byte
 // line of every row: its four 16-byte-per-lane loads come from the same wave back to back).  Pass 1 finds the rows' largest magnitudes (two k
 // halves of a wave by lane ^ 32, the four waves through LDS), pass 2 writes the scaled pieces.  NIT > 0: a thread's (at most)
@@ -983,7 +1025,7 @@ __global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, i
     [[maybe_unused]] const float* g_brow = nullptr;
     [[maybe_unused]] float g_sign = 1.f;
     if constexpr (MAP == PACK_GATHER) {                               // (launched with NIT > 0 only: the rows stay in registers)
-        g_arow = pr.ga + (row_on ? pr.gia[src_row] : 0) * pr.glda;
+        g_arow = pr.ga + (row_on ? (pr.gia ? pr.gia[src_row] : (int64_t)pr.gi32[src_row]) : 0) * pr.glda;
         g_brow = pr.gb ? pr.gb + (row_on ? pr.gib[src_row] : 0) * pr.gldb : nullptr;
         if (pr.gtok) {
             int64_t id = row_on ? pr.gtok[src_row] : 0;
@@ -1002,7 +1044,8 @@ __global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[it][e] *= g_sign;
                 }
-                gather_add_relu8(g_arow, g_brow, pr.gbias, row_on && kb < KB, kb * 16 + kh, K, v[it]);
+                if (pr.gop == 1) gather_mul8(g_arow, row_on && kb < KB, kb * 16 + kh, K, v[it]);
+                else gather_add_relu8(g_arow, g_brow, pr.gbias, row_on && kb < KB, kb * 16 + kh, K, v[it]);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[it][e]));
@@ -1185,6 +1228,20 @@ int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t 
     return launch_split2h_pack_tiles<PACK_GATHER>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
 }
 
+// The two-piece pack of X[r, :] * R[idx[r], :] (PackRows GATHER, gop = 1): K % 4 == 0, K <= 512, 16-byte aligned rows
+int launch_split2h_pack_rowmul(int64_t rows, int64_t K, const float* X, int64_t ld, const float* R, const int32_t* idx, int64_t ldr, void* packed,
+                               hipStream_t stream) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    GVQA_REQUIRE(rows >= 0 && K > 0 && K % 4 == 0 && K <= 512 && ld % 4 == 0 && ld >= K && ldr % 4 == 0 && ldr >= K, GVQA_E_UNSUPPORTED,
+                 "split_pack_rowmul: K %% 4 == 0, K <= 512, row strides multiples of 4");
+    if (rows == 0) return GVQA_OK;
+    GVQA_REQUIRE(X && R && idx && packed && al(X) && al(R) && al(packed), GVQA_E_INVALID, "split_pack_rowmul: null / unaligned operand");
+    const int64_t RT = cdiv(rows, 32);
+    GVQA_REQUIRE(RT < (1ll << 31), GVQA_E_INVALID, "split_pack_rowmul: too many rows");
+    PackRows pr{X, ld, rows, nullptr, 0, 0, 0, R, nullptr, ldr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, idx, 1};
+    return launch_split2h_pack_tiles<PACK_GATHER>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
+}
+
 int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack: 2 or 3 pieces");
     GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split_pack: bad size");
@@ -1233,7 +1290,9 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     GVQA_REQUIRE(M >= 0 && N >= 0 && K > 0, GVQA_E_INVALID, "linear_split3: bad size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 30), GVQA_E_INVALID, "linear_split3: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
-    GVQA_REQUIRE(Apk && Bpk && C, GVQA_E_INVALID, "linear_split3: null operand");
+    GVQA_REQUIRE(Apk && Bpk && (C || ep.rowdot_w), GVQA_E_INVALID, "linear_split3: null operand");
+    GVQA_REQUIRE(!ep.rowdot_w || (ep.rowdot_out && np == 2 && batch == 1 && (reinterpret_cast<uintptr_t>(ep.rowdot_w) & 15) == 0), GVQA_E_INVALID,
+                 "linear_split: the row-dot epilogue needs its output, two-piece operands, one batch, a 16-byte aligned vector");
     GVQA_REQUIRE(ldc >= N && (!ep.addend || ep.ld_add >= N) && (!ep.mul || ep.ld_mul >= N), GVQA_E_INVALID,
                  "linear_split3: leading dimension too small");
     GVQA_REQUIRE(linear_split3_supported(N, ep, C, ldc), GVQA_E_UNSUPPORTED,
@@ -1265,6 +1324,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
         LinearEpilogue e2 = ep;
         if (ep.addend) e2.addend = ep.addend + m0 * ep.ld_add;
         if (ep.mul) e2.mul = ep.mul + m0 * ep.ld_mul;
+        if (ep.rowdot_out) e2.rowdot_out = ep.rowdot_out + m0 * 16;
         const uint16_t* a2 = a + (m0 / 32) * (int64_t)KB * (np * 512);
         const float* a_inv2 = a_inv ? a_inv + m0 : nullptr;
         const int rt2 = (int)cdiv(m, 32);
@@ -1274,10 +1334,11 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
 #define GVQA_SK_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, NP_, PIPE_, KS_)                           \
         do {                                                                                                             \
             dim3 grid((unsigned)cdiv(N, 32 * WN_ * TN_), (unsigned)cdiv(m, 32 * WM_ * TM_), (unsigned)batch);             \
+            if (e2.rowdot_w && (EPI_ != 1 || grid.x * WN_ > 16)) return GVQA_E_UNSUPPORTED;   /* 16 partial slots per row */     \
             /* a block's MFMA issue time x the STAG_ blocks sharing the SIMDs, split into STAG_ start offsets */         \
             const int stag = STAG_ > 0 ? (int)((int64_t)KB * 6 * TM_ * TN_ * 32 / 8128) : 0;                              \
             hipLaunchKernelGGL((k_linear_split3<WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 0, NP_, PIPE_, KS_>), grid, \
-                               dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C + m0 * ldc, ldc, \
+                               dim3(64 * WM_ * WN_), 0, stream, (int)m, (int)N, KB, a2, rt2, b, rtB, e2, C ? C + m0 * ldc : nullptr, ldc, \
                                STAG_ == 0 ? loop_dbg : (stag_scale > 0 ? stag * stag_scale / 4 : stag), FusedHopArgs{},   \
                                a_inv2, b_inv);                                                                           \
         } while (0)

@@ -1325,6 +1325,41 @@ def test_pool_and_classifier_golden(dev, name):
     assert maxabs(logits, g["logits"]) < TOL
 
 
+@pytest.mark.parametrize("in_c,ch", [(300, 512), (64, 128), (40, 72)])
+def test_pooling_head_on_the_fused_products_vs_oracle(dev, in_c, ch):
+    """The pooling head's large-batch form (pipeline_model_gat.py:149-181): node_nn / gate_nn on the two-piece kernels, the
+    per-graph row scaling inside gate_nn's operand pack, gate_nn's 512 -> 1 Linear as 16 partial dot products in the first
+    product's epilogue, summed in order by the pooling kernel.  Golden and small tests run below the size threshold; here it
+    is 0 so that this form is the one exercised -- ragged graphs, an empty graph, one-node graphs, a graph past the pooling
+    kernel's 256-node LDS path -- against the fp64 oracle, and against the small-batch form on the same inputs."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.pipeline_head import MyConditionalGlobalAttention
+    counts = np.array([33, 1, 0, 300, 7, 128, 1, 64] + [int(v) for v in synth.randint(40, 5, 1, 60)], dtype=np.int64)
+    batch = np.repeat(np.arange(len(counts)), counts)
+    N, B = int(counts.sum()), len(counts)
+    pp = synth.attention_pool_params(in_c, ch, seed=17)
+    rng = np.random.default_rng(7)
+    for k in list(pp):
+        if k.endswith("bias"):
+            pp[k] = (pp[k] + 0.2 * rng.standard_normal(pp[k].shape)).astype(np.float32)
+    pool = _load_module(MyConditionalGlobalAttention(in_c, ch), pp, dev)
+    x, u = synth.normal((N, in_c), 1), synth.normal((B, ch), 2)
+    ref = R.global_attention_pool(t(x).double(), t(u).double(), t(batch), {k: v.double() for k, v in tparams(pp).items()}, B)
+    small = pool(t(x, device=dev), t(u, device=dev), t(batch, device=dev))
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        fused = pool(t(x, device=dev), t(u, device=dev), t(batch, device=dev))
+        again = pool(t(x, device=dev), t(u, device=dev), t(batch, device=dev))
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxabs(small, ref) < TOL * scale
+    assert maxabs(fused, ref) < TOL * scale
+    assert torch.equal(fused, again)                      # partial sums are combined in a fixed order
+    assert float(fused[2].abs().max()) == 0.0             # the empty graph pools to zeros (scatter_add of nothing)
+
+
 # ------------------------------------------------------------------------------------------------
 # "next" row 8f-1: scene-graph encoder; and config 1: encoder -> gat_seq -> pooling -> logits
 # ------------------------------------------------------------------------------------------------
