@@ -121,7 +121,7 @@ class EncoderParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("embedding", "edge0_weight", "edge0_bias", "edge2_weight", "edge2_bias",
                                           "node1_0_weight", "node1_0_bias", "node1_2_weight", "node1_2_bias",
                                           "node2_0_weight", "node2_0_bias", "node2_2_weight", "node2_2_bias",
-                                          "ln_weight", "ln_bias")]
+                                          "ln_weight", "ln_bias", "packed")] + [("packed_bytes", C.c_size_t)]
 
 
 class MpPlan(C.Structure):
@@ -209,6 +209,8 @@ PROTOTYPES = {
     "gvqa_answer_logits_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ClassifierParams),
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_sg_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(Graph), C.c_int32]),
+    "gvqa_sg_encoder_pack_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gvqa_sg_encoder_pack_weights": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(EncoderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_sg_encoder_forward": (C.c_int, [C.POINTER(Graph), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.POINTER(EncoderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -206,26 +206,97 @@ __global__ __launch_bounds__(256) void k_small_matmul_nn(int M, int N, int K, co
     if (sl == 0 && k < N) C[(int64_t)i * ldc + k] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
-struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, wf, bf, wf2, bf2, apk_n, apk_e, wpk, Z, wc, wpk4, total; };
+struct EncLayout { size_t x0, e0, S, Dd, P, Y, m, agg, t, x2, flags, apk_n, apk_e, Z, wts, total; };
+static size_t enc_pack_total(int64_t V, int D);
 static EncLayout enc_layout(int64_t N, int64_t E, int D) {
     EncLayout L; size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
     const size_t nd = (size_t)N * D * 4, ed = (size_t)E * D * 4;
     L.x0 = take(nd); L.e0 = take(ed); L.S = take(nd); L.Dd = take(nd); L.P = take(nd); L.Y = take(ed); L.m = take(ed);
     L.agg = take(nd); L.t = take(nd); L.x2 = take(nd); L.flags = take((size_t)E + 1);
-    // folded weight / bias, packed two-piece operands (node rows, edge rows, one weight at a time)
-    L.wf = take((size_t)D * D * 4); L.bf = take((size_t)D * 4); L.wf2 = take((size_t)D * D * 4); L.bf2 = take((size_t)D * 4);
-    L.apk_n = take(split_packed_bytes(2, N, D)); L.apk_e = take(split_packed_bytes(2, E, D)); L.wpk = take(split_packed_bytes(2, D, D));
-    // the four per-node column blocks that act on x0 as one product: result [N, 4D], stacked weight [4D, D] and its packed image
-    L.Z = take(4 * nd); L.wc = take((size_t)4 * D * D * 4); L.wpk4 = take(split_packed_bytes(2, 4 * (int64_t)D, D));
+    // packed two-piece operands (node rows, edge rows); the four per-node column blocks that act on x0 as one product: [N, 4D]
+    L.apk_n = take(split_packed_bytes(2, N, D)); L.apk_e = take(split_packed_bytes(2, E, D));
+    L.Z = take(4 * nd);
+    // weight-only forms when the caller passes none (gvqa_encoder_params.packed): the projected table takes the e0 slot (V <= E)
+    L.wts = take(enc_pack_total(0, D));
     L.total = off;
     return L;
 }
+
+// Call-invariant weight forms of the large-batch encoder path (gvqa_sg_encoder_pack_weights): the projected table, the stacked per-node
+// blocks packed, the two folded weights / biases, and the packed images of the four [D, D] weights the split products take.
+struct EncPack { size_t Te, wpk4, wf, bf, wf2, bf2, pk_e2, pk_wf, pk_wf2, pk_n22, wc, total; };
+static EncPack enc_pack_layout(int64_t V, int D) {
+    EncPack L; size_t off = 0;
+    auto take = [&](size_t bytes) { size_t r = off; off += align_up(bytes, 256); return r; };
+    const size_t dd = (size_t)D * D * 4, pk = split_packed_bytes(2, D, D);
+    L.Te = take((size_t)V * D * 4); L.wpk4 = take(split_packed_bytes(2, 4 * (int64_t)D, D));
+    L.wf = take(dd); L.bf = take((size_t)D * 4); L.wf2 = take(dd); L.bf2 = take((size_t)D * 4);
+    L.pk_e2 = take(pk); L.pk_wf = take(pk); L.pk_wf2 = take(pk); L.pk_n22 = take(pk);
+    L.wc = take(4 * dd);                                   // (staging: the stacked fp32 blocks)
+    L.total = off;
+    return L;
+}
+static bool enc_fast_weights_ok(int D, const gvqa_encoder_params* p) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return D % 4 == 0 && al16(p->embedding) && al16(p->edge0_bias) && al16(p->node1_0_bias) && al16(p->edge2_bias) && al16(p->node1_2_bias) &&
+           al16(p->node2_0_bias) && al16(p->node2_2_bias);
+}
+// everything of the large-batch path that depends on the weights only, into `base` (EncPack layout)
+static int enc_pack_weights(int64_t V, int D, const gvqa_encoder_params* p, char* base, float* Te, hipStream_t stream) {
+    const EncPack L = enc_pack_layout(Te ? 0 : V, D);      // (Te given: the table lives elsewhere, the layout is the V = 0 one)
+    auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+    if (!Te) Te = P(L.Te);
+    // Te [V, D] = emb W_e^T  (edge block of EdgeModel's first Linear applied to the table)
+    int rc = launch_linear(V, D, D, p->embedding, D, p->edge0_weight + 2 * D, 3 * D, nullptr, 0, Te, D, 1, 0, 0, 0, stream);
+    if (rc) return rc;
+    // the four per-node column blocks that act on x0, stacked [4D, D] and packed
+    float* Wc = P(L.wc);
+    const float* blk[4] = {p->edge0_weight, p->edge0_weight + D, p->node1_0_weight, p->node2_0_weight};
+    const int64_t bld[4] = {3 * (int64_t)D, 3 * (int64_t)D, 2 * (int64_t)D, 2 * (int64_t)D};
+    for (int q = 0; q < 4; ++q)
+        GVQA_HIP_CHECK(hipMemcpy2DAsync(Wc + (size_t)q * D * D, (size_t)D * 4, blk[q], (size_t)bld[q] * 4, (size_t)D * 4, (size_t)D,
+                                        hipMemcpyDeviceToDevice, stream));
+    if ((rc = launch_split_pack(2, 4 * (int64_t)D, D, Wc, D, base + L.wpk4, stream))) return rc;
+    // W' = Wn_e W2, b' = Wn_e b2 (node_mlp_1's edge block on edge_attr' = Y W2^T + b2);  W'' = W2_agg W1_2, c = W2_agg b1_2
+    hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
+                       (int64_t)2 * D, p->edge2_weight, (int64_t)D, P(L.wf), (int64_t)D);
+    hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node1_0_weight + D, (int64_t)2 * D,
+                       p->edge2_bias, (int64_t)1, P(L.bf), (int64_t)1);
+    hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node2_0_weight + D,
+                       (int64_t)2 * D, p->node1_2_weight, (int64_t)D, P(L.wf2), (int64_t)D);
+    hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node2_0_weight + D, (int64_t)2 * D,
+                       p->node1_2_bias, (int64_t)1, P(L.bf2), (int64_t)1);
+    GVQA_LAUNCH_CHECK();
+    if ((rc = launch_split_pack(2, D, D, p->edge2_weight, D, base + L.pk_e2, stream))) return rc;
+    if ((rc = launch_split_pack(2, D, D, P(L.wf), D, base + L.pk_wf, stream))) return rc;
+    if ((rc = launch_split_pack(2, D, D, P(L.wf2), D, base + L.pk_wf2, stream))) return rc;
+    return launch_split_pack(2, D, D, p->node2_2_weight, D, base + L.pk_n22, stream);
+}
+
+static size_t enc_pack_total(int64_t V, int D) { return enc_pack_layout(V, D).total; }
 
 }  // namespace gvqa
 
 extern "C" {
 using namespace gvqa;
+
+size_t gvqa_sg_encoder_pack_bytes(int32_t V, int32_t D) {
+    if (V <= 0 || D <= 0) return 0;
+    return enc_pack_layout(V, D).total;
+}
+
+int gvqa_sg_encoder_pack_weights(int32_t V, int32_t D, const gvqa_encoder_params* p, void* packed, size_t packed_bytes, void* stream) {
+    GVQA_REQUIRE(p && packed && V > 0 && D > 0, GVQA_E_INVALID, "sg_encoder_pack_weights: bad argument");
+    GVQA_REQUIRE(p->embedding && p->edge0_weight && p->edge0_bias && p->edge2_weight && p->edge2_bias && p->node1_0_weight &&
+                 p->node1_0_bias && p->node1_2_weight && p->node1_2_bias && p->node2_0_weight && p->node2_0_bias &&
+                 p->node2_2_weight && p->node2_2_bias, GVQA_E_INVALID, "sg_encoder_pack_weights: null weight");
+    GVQA_REQUIRE(packed_bytes >= enc_pack_layout(V, D).total && (reinterpret_cast<uintptr_t>(packed) & 255) == 0, GVQA_E_WORKSPACE,
+                 "sg_encoder_pack_weights: buffer too small / not 256-byte aligned");
+    GVQA_REQUIRE(enc_fast_weights_ok(D, p) && get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32, GVQA_E_UNSUPPORTED,
+                 "sg_encoder_pack_weights: the packed forms belong to the two-piece path (D %% 4 == 0, 16-byte aligned vectors)");
+    return enc_pack_weights(V, D, p, static_cast<char*>(packed), nullptr, static_cast<hipStream_t>(stream));
+}
 
 int gvqa_gather_add_relu(int64_t E, int32_t D, const float* a, int64_t lda, const int64_t* ia, const float* b, int64_t ldb, const int64_t* ib,
                          const float* bias, const float* y_in, float* y_out, void* stream_) {
@@ -304,7 +375,10 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
     // ---- products on the two-piece kernels, table / fold restructuring (header): 16-byte rows and vectors, the table fits the
     // e0 slot, the products are large enough for the packs to pay ----
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    const bool fast = v4 && E > 0 && V <= E && get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 &&
+    // weight-only forms: the caller's (gvqa_sg_encoder_pack_weights, made once per set of weights) or made per call in the workspace
+    // (the projected table then takes the per-edge slot it replaces: V <= E)
+    const bool cached = p->packed && p->packed_bytes >= enc_pack_layout(V, D).total && (reinterpret_cast<uintptr_t>(p->packed) & 255) == 0;
+    const bool fast = v4 && E > 0 && (cached || V <= E) && get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 &&
                       2.0 * (double)N * D * D >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP) && al16(p->edge2_bias) &&
                       al16(p->node1_2_bias) && al16(p->node2_0_bias) && al16(p->node2_2_bias) && al16(x_encoded);
     ENC_LAUNCH(k_embed_sum, N, N, node_tokens, V, D, x_tokens, p->embedding, (const uint8_t*)nullptr, P(L.x0));
@@ -316,17 +390,17 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
     }
     GVQA_LAUNCH_CHECK();
     if (fast) {
-        char* apk_n = base + L.apk_n; char* apk_e = base + L.apk_e; char* wpk = base + L.wpk;
-        // C = Apk W^T (+ epilogue): the weight block is packed into the one weight slot (stream order keeps the slot's uses apart)
-        auto prod = [&](int64_t M, const char* apk, const float* W, int64_t ldw, LinearEpilogue ep, float* C) -> int {
-            int r = launch_split_pack(2, D, D, W, ldw, wpk, stream);
-            if (r) return r;
-            return launch_linear_split(2, M, D, D, apk, wpk, ep, C, D, stream);
+        char* apk_n = base + L.apk_n; char* apk_e = base + L.apk_e;
+        const EncPack W = enc_pack_layout(cached ? V : 0, D);
+        char* wb = cached ? static_cast<char*>(const_cast<void*>(p->packed)) : base + L.wts;
+        float* Te = cached ? reinterpret_cast<float*>(wb + W.Te) : P(L.e0);    // [V, D] = emb W_e^T  (edge block of EdgeModel's first Linear)
+        if (!cached && (rc = enc_pack_weights(V, D, p, wb, Te, stream))) return rc;
+        auto WP = [&](size_t off) { return reinterpret_cast<float*>(wb + off); };
+        // C = Apk Wpk^T (+ epilogue)
+        auto prod = [&](int64_t M, const char* apk, size_t wpk_off, LinearEpilogue ep, float* C) -> int {
+            return launch_linear_split(2, M, D, D, apk, wb + wpk_off, ep, C, D, stream);
         };
         const LinearEpilogue none{nullptr, nullptr, 0, nullptr, 0, 0};
-        float* Te = P(L.e0);                                                 // [V, D] = emb W_e^T  (edge block of EdgeModel's first Linear)
-        rc = launch_linear(V, D, D, p->embedding, D, p->edge0_weight + 2 * D, 3 * D, nullptr, 0, Te, D, 1, 0, 0, 0, stream);
-        if (rc) return rc;
         // (one token per edge -- the GQA relation name -- and the gather pack below applies: the "sum" is a row of Te, fetched inside
         //  the pack pass; otherwise the token sums are formed here)
         const bool gpack = D <= 512 && al16(p->edge0_bias) && al16(p->node1_0_bias);
@@ -336,29 +410,14 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
             GVQA_LAUNCH_CHECK();
         }
         // the four per-node column blocks that act on x0 -- EdgeModel's x_src and x_dst, node_mlp_1's x_src, node_mlp_2's x -- as ONE
-        // product Z [N, 4D] = x0 [W_s; W_d; W_p; W_t]^T: the blocks are stacked (parameter-sized copies), packed once, x0 packed once
+        // product Z [N, 4D] = x0 [W_s; W_d; W_p; W_t]^T: the blocks stacked and packed once (weight-only), x0 packed once
         float* Z = P(L.Z);
         const int64_t ldz = 4 * (int64_t)D;
-        {
-            float* Wc = P(L.wc);
-            const float* blk[4] = {p->edge0_weight, p->edge0_weight + D, p->node1_0_weight, p->node2_0_weight};
-            const int64_t bld[4] = {3 * (int64_t)D, 3 * (int64_t)D, 2 * (int64_t)D, 2 * (int64_t)D};
-            for (int q = 0; q < 4; ++q)
-                GVQA_HIP_CHECK(hipMemcpy2DAsync(Wc + (size_t)q * D * D, (size_t)D * 4, blk[q], (size_t)bld[q] * 4, (size_t)D * 4, (size_t)D,
-                                                hipMemcpyDeviceToDevice, stream));
-            rc = launch_split_pack(2, N, D, P(L.x0), D, apk_n, stream);
-            if (rc) return rc;
-            rc = launch_split_pack(2, ldz, D, Wc, D, base + L.wpk4, stream);
-            if (rc) return rc;
-            rc = launch_linear_split(2, N, ldz, D, apk_n, base + L.wpk4, none, Z, ldz, stream);
-            if (rc) return rc;
-        }
-        // W' = Wn_e W2, b' = Wn_e b2: node1_0's edge block applied to edge_attr' = Y W2^T + b2 without forming it first
-        hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node1_0_weight + D,
-                           (int64_t)2 * D, p->edge2_weight, (int64_t)D, P(L.wf), (int64_t)D);
-        hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node1_0_weight + D, (int64_t)2 * D,
-                           p->edge2_bias, (int64_t)1, P(L.bf), (int64_t)1);
-        GVQA_LAUNCH_CHECK();
+        rc = launch_split_pack(2, N, D, P(L.x0), D, apk_n, stream);
+        if (rc) return rc;
+        rc = launch_linear_split(2, N, ldz, D, apk_n, wb + W.wpk4, none, Z, ldz, stream);
+        if (rc) return rc;
+        // (W' = Wn_e W2, b' = Wn_e b2: node1_0's edge block applied to edge_attr' = Y W2^T + b2 without forming it first -- weight-only)
         // Y = relu(S[src] + Dd[dst] + Y + b) goes straight into its packed form (the gathers ride in the pack pass: the fp32 Y is
         // only ever a matrix-core operand), packed once for both of its products
         if (tok_in_pack) rc = launch_split2h_pack_gather(E, D, Te, D, Z, src, ldz, Z + D, dst, ldz, p->edge0_bias, apk_e, stream, edge_tokens, V, flags);
@@ -370,34 +429,30 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         if (rc) return rc;
         {
             LinearEpilogue ep{p->edge2_bias, nullptr, 0, nullptr, 0, 0};
-            if ((rc = prod(E, apk_e, p->edge2_weight, D, ep, edge_attr_encoded))) return rc;
-            LinearEpilogue ef{P(L.bf), nullptr, 0, nullptr, 0, 0};
-            if ((rc = prod(E, apk_e, P(L.wf), D, ef, P(L.Y)))) return rc;     // (the fp32 Y is free: its packed image is the operand)
+            if ((rc = prod(E, apk_e, W.pk_e2, ep, edge_attr_encoded))) return rc;
+            LinearEpilogue ef{WP(W.bf), nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(E, apk_e, W.pk_wf, ef, P(L.Y)))) return rc;     // (the fp32 Y is free: its packed image is the operand)
         }
         // NodeModel: scatter_mean(Lin2(relu(pre))) feeding node_mlp_2's first Linear (:92-98) has nothing non-linear between the
         // relu and that Linear's own: the mean is taken on relu(pre) ([E, D] read once, [N, D] written), and Lin2 and the agg block
         // of node_mlp_2's first Linear act on it as ONE node-sized product with W'' = W2_agg W1_2 (parameter-sized); the bias
         // W2_agg b1_2 belongs to the nodes that have an in-edge and is added to their rows of the product's addend (x0's block).
         // Gone: an edge-sized product, its gather + pack pass over [E, D], the message tensor m and its segment mean.
-        hipLaunchKernelGGL(k_small_matmul_nn, dim3((unsigned)cdiv(D, 64), (unsigned)D), dim3(256), 0, stream, D, D, D, p->node2_0_weight + D,
-                           (int64_t)2 * D, p->node1_2_weight, (int64_t)D, P(L.wf2), (int64_t)D);
-        hipLaunchKernelGGL(k_small_matmul_nn, dim3(1, (unsigned)D), dim3(256), 0, stream, D, 1, D, p->node2_0_weight + D, (int64_t)2 * D,
-                           p->node1_2_bias, (int64_t)1, P(L.bf2), (int64_t)1);
         hipLaunchKernelGGL(k_gather_relu_segment_mean, dim3((unsigned)cdiv(N * (D / 4), 256)), dim3(256), 0, stream, N, (int)D, (const float*)P(L.Y),
-                           (const float*)(Z + 2 * D), ldz, p->node1_0_bias, g->rowptr, g->csr_src, g->csr_eid, P(L.agg), (const float*)P(L.bf2),
+                           (const float*)(Z + 2 * D), ldz, p->node1_0_bias, g->rowptr, g->csr_src, g->csr_eid, P(L.agg), (const float*)WP(W.bf2),
                            Z + 3 * D, ldz);
         GVQA_LAUNCH_CHECK();
         rc = launch_split_pack(2, N, D, P(L.agg), D, apk_n, stream);
         if (rc) return rc;
         {
             LinearEpilogue ep{p->node2_0_bias, Z + 3 * D, ldz, nullptr, 0, 1};   // t = relu(x0's block (+ folded bias) + mean W''^T + bias)
-            if ((rc = prod(N, apk_n, P(L.wf2), D, ep, P(L.t)))) return rc;
+            if ((rc = prod(N, apk_n, W.pk_wf2, ep, P(L.t)))) return rc;
         }
         rc = launch_split_pack(2, N, D, P(L.t), D, apk_n, stream);
         if (rc) return rc;
         {
             LinearEpilogue ep{p->node2_2_bias, nullptr, 0, nullptr, 0, 0};
-            if ((rc = prod(N, apk_n, p->node2_2_weight, D, ep, P(L.x2)))) return rc;
+            if ((rc = prod(N, apk_n, W.pk_n22, ep, P(L.x2)))) return rc;
         }
     } else {
     // EdgeModel: e' = Lin2(relu(Lin1([x_src || x_dst || e])))                       (:65-76)

@@ -245,6 +245,20 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         na = 0 if added is None else int(added.numel())
         added_c = None if na == 0 else added.to(dev).contiguous()
         with torch.cuda.device(dev):
+            # call-invariant weight forms (projected table, stacked / folded / packed weights): rebuilt only when a weight tensor
+            # was replaced or modified in place (data_ptr / autograd version counter) or the projection arithmetic changed
+            key = (str(dev), lib.gvqa_get_option(_lib.OPT_PROJECTION)) + tuple((t.data_ptr(), t._version) for t in keep)
+            if getattr(self, "_packed_key", None) != key:
+                nbytes = lib.gvqa_sg_encoder_pack_bytes(V, D)
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                rc = lib.gvqa_sg_encoder_pack_weights(V, D, C.byref(p), packed.data_ptr(), nbytes, _stream(dev))
+                if rc == _lib.E_UNSUPPORTED:
+                    packed = None                      # shapes / settings the large-batch path does not take: nothing to cache
+                else:
+                    _lib.check(rc)
+                self._packed, self._packed_key = packed, key
+            if self._packed is not None:
+                p.packed, p.packed_bytes = self._packed.data_ptr(), self._packed.numel()
             ws = _workspace(lib.gvqa_sg_encoder_workspace_bytes(C.byref(graph.c), D), dev)
             _lib.check(lib.gvqa_sg_encoder_forward(C.byref(graph.c), V, D, x_tok.shape[1], e_tok.shape[1], C.byref(p),
                                                    x_tok.data_ptr(), e_tok.data_ptr(),

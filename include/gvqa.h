@@ -680,7 +680,20 @@ typedef struct gvqa_encoder_params {
     const float* node2_2_bias;
     const float* ln_weight;        /* graph_layer_norm.weight [1] or NULL                                      */
     const float* ln_bias;          /* graph_layer_norm.bias   [1] or NULL                                      */
+    const void* packed;            /* NULL, or the output of gvqa_sg_encoder_pack_weights for these weights, V and D:
+                                      skips the per-call weight-only work of the large-batch path (projected table, stacked /
+                                      folded weights, packed weight operands)                                   */
+    size_t packed_bytes;
 } gvqa_encoder_params;
+
+/* Call-invariant weight forms of the encoder's large-batch path: emb W_e^T (the edge block of EdgeModel's first Linear applied to
+ * the embedding table, pipeline_model_gat.py:65-76), the four per-node column blocks stacked, the folded products W_n1e W_e2 and
+ * W_n2agg W_n12 with their bias vectors, and the two-piece packed images of every weight operand.  A caller whose weights do not
+ * change between forwards builds them once (256-byte aligned buffer of gvqa_sg_encoder_pack_bytes(V, D) bytes) and passes them in
+ * params->packed; rebuild when any weight changes.  GVQA_E_UNSUPPORTED when the large-batch path cannot take these weights
+ * (D % 4 != 0, unaligned vectors, GVQA_OPT_PROJECTION = f32): call forward without `packed` then. */
+GVQA_API size_t gvqa_sg_encoder_pack_bytes(int32_t V, int32_t D);
+GVQA_API int gvqa_sg_encoder_pack_weights(int32_t V, int32_t D, const gvqa_encoder_params* p, void* packed, size_t packed_bytes, void* stream);
 
 /* x_tokens int64 [N, node_tokens], edge_tokens int64 [E, edge_tokens_per_edge] (COO order),
  * added_sym_edge int64 [num_added] (indices of edges whose embedding is negated), edge_index int64

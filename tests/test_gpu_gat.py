@@ -1985,7 +1985,7 @@ def test_scene_graph_encoder_on_the_two_piece_products(dev):
     try:
         meta, g = load_golden("sg_encoder_debug4")
         E0 = g["edge_index"].shape[1]
-        if meta["vocab"] <= E0:                         # (the form needs the projected table to fit the per-edge slot it replaces)
+        if True:                                        # (the module caches the projected table with the weights: any vocabulary size)
             enc = GroundTruth_SceneGraph_Encoder(meta["vocab"], meta["pad_idx"], meta["dim"])
             _load_module(enc, synth.encoder_params(meta["vocab"], meta["dim"], seed=meta["param_seed"], pad_idx=meta["pad_idx"]), dev)
             data = types.SimpleNamespace(x=t(g["x_tokens"], device=dev), edge_attr=t(g["edge_tokens"], device=dev),
@@ -2011,5 +2011,26 @@ def test_scene_graph_encoder_on_the_two_piece_products(dev):
         finally:
             _lib.set_option(_lib.OPT_PROJECTION, prev)
         assert maxabs(ee, ee32) < 1e-4 * (1.0 + float(ree.abs().max())) and maxabs(xe, xe32) < TOL
+        # (iv) the weight-only forms are cached with the module: a weight modified in place (version counter) or replaced makes the
+        # next call rebuild them -- same result as a module loaded with the new weights
+        assert enc._packed is None                      # (the f32-input call just made has no packed forms)
+        pe2 = {k: v.copy() for k, v in pe.items()}
+        k2 = "scene_graph_encoding_layer.node_model.node_mlp_1.2.weight"
+        pe2[k2] = (pe2[k2] * 1.5).astype(np.float32)
+        enc(data)
+        with torch.no_grad():
+            dict(enc.named_parameters())[k2].mul_(1.5)
+        enc(data)
+        key = enc._packed_key
+        xe_b, ee_b, _ = enc(data)
+        assert enc._packed is not None and enc._packed_key == key
+        xe_c, ee_c, _ = _load_module(GroundTruth_SceneGraph_Encoder(V, 0, D), pe2, dev)(data)
+        assert torch.equal(xe_b, xe_c) and torch.equal(ee_b, ee_c) and maxabs(xe_b, xe) > 1e-4
+        # (v) several tokens per edge: the token sums are formed first (the one-token gather inside the pack pass does not apply)
+        et2 = synth.randint(E * 2, 8, 1, V, stream=3).reshape(E, 2)
+        data2 = types.SimpleNamespace(x=data.x, edge_attr=t(et2, device=dev), edge_index=data.edge_index, batch=data.batch, added_sym_edge=data.added_sym_edge)
+        xe2, ee2, _ = enc(data2)
+        rxe2, ree2 = R.scene_graph_encoder(t(xt), t(gb.edge_index), t(et2), t(added), t(gb.batch), B, tparams(pe2))
+        assert maxabs(ee2, ree2) < 1e-4 * (1.0 + float(ree2.abs().max())) and maxabs(xe2, rxe2) < TOL
     finally:
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
