@@ -89,6 +89,16 @@ struct LinearEpilogue {
     // sum over a row's 16 slots = (finished row) . rowdot_w[0:N].  C may be NULL then (the rows themselves are not stored).
     const float* rowdot_w;
     float* rowdot_out;
+    // split GEMM, two-piece operands, N <= 512: the finished rows written as the NEXT product's packed A operand (the layout and
+    // scales k_split2h_pack would give them; a buffer of split_packed_bytes(2, M, N) bytes) -- a chain of products without a pack
+    // pass in between.  C may be NULL (or receives the fp32 rows as well).  pk_mul [*, pk_mul_ld] / pk_mul_idx [M]: the packed value
+    // is the finished value times row pk_mul_idx[r] of pk_mul.  (pk_inv / pk_KB / pk_RT are filled in by the launcher.)
+    uint16_t* pk_out;
+    const float* pk_mul;
+    const int32_t* pk_mul_idx;
+    int64_t pk_mul_ld;
+    float* pk_inv;
+    int pk_KB, pk_RT;
 };
 
 // GEMM entry used by the orchestration code (defined in gemm.hip).

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_head_features(int64_t B, int Q, const f
     feat[b * 3 * Q + 2 * Q + c] = gv * qv;
 }
 
-struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, scratch, scratch_bytes, total; };      // gate: [N, 16] partial sums, or [N]
+struct PoolLayout { size_t h1, xn, qh, qn, prod, z, gate, scratch, scratch_bytes, apk2, total; };      // gate: [N, 16] partial sums, or [N]
 static PoolLayout pool_layout(int64_t N, int64_t B, int Ch, int Dn) {
     PoolLayout L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
@@ -92,6 +92,7 @@ static PoolLayout pool_layout(int64_t N, int64_t B, int Ch, int Dn) {
     L.prod = take((size_t)N * Ch); L.z = take((size_t)N * Ch); L.gate = take((size_t)N * 16);
     L.scratch_bytes = linear_auto_scratch_bytes(N, Ch, Dn > Ch ? Dn : Ch);      // packed operands of the node MLP products
     L.scratch = take(L.scratch_bytes / sizeof(float));
+    L.apk2 = take(split_packed_bytes(2, N, Ch) / sizeof(float) + 64);     // second packed-operand slot of the chained products
     L.total = off;
     return L;
 }
@@ -129,8 +130,6 @@ int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, con
 #define NLIN(K_, A_, W_, b_, act_, C_)                                                                                    \
     do { LinearEpilogue e_{b_, nullptr, 0, nullptr, 0, act_};                                                             \
          rc = launch_linear_auto(N, Ch, K_, A_, K_, W_, K_, e_, C_, Ch, base + L.scratch, L.scratch_bytes, stream); if (rc) return rc; } while (0)
-    NLIN(Dn, x, p->node0_weight, p->node0_bias, 1, P(L.h1));                       // node_nn (:160)
-    NLIN(Ch, P(L.h1), p->node2_weight, p->node2_bias, 0, P(L.xn));
     LIN(B, Ch, Ch, u, p->ques0_weight, p->ques0_bias, 1, P(L.qh));                 // ques_nn (:165)
     LIN(B, Ch, Ch, P(L.qh), p->ques2_weight, p->ques2_bias, 0, P(L.qn));
     // gate_nn on ques_nn(u)[batch] * x' (:165).  Large batches on the two-piece kernels: the per-graph row scaling rides in the
@@ -140,12 +139,45 @@ int gvqa_attention_pool_forward(const gvqa_graph* g, int32_t Dn, int32_t Ch, con
                        L.scratch_bytes >= linear_auto_scratch_bytes(N, Ch, Ch) &&
                        2.0 * (double)N * Ch * Ch >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP) &&
                        ((reinterpret_cast<uintptr_t>(p->gate0_bias) | reinterpret_cast<uintptr_t>(p->gate2_weight)) & 15) == 0;
+    // node_nn (:160).  Chained form (large batches, <= 512 channels): x is packed once; node_nn's first product leaves its result as
+    // the second's packed operand (h1 never exists in fp32), the second leaves x' in fp32 (the pooling sum needs it) AND
+    // ques_nn(u)[batch] * x' as gate_nn's packed operand: one pack pass instead of three (split3.hip, packed-output epilogue)
+    bool chained = false;
+    char* apk1 = base + L.scratch;
+    char* wpk1 = apk1 + align_up(split_packed_bytes(2, N, Dn > Ch ? Dn : Ch), 256);
+    char* apk2 = base + L.apk2;
+    const bool al_ok = ((reinterpret_cast<uintptr_t>(p->node0_bias) | reinterpret_cast<uintptr_t>(p->node2_bias)) & 15) == 0;
+    if (fused && al_ok && 2.0 * (double)N * Ch * Dn >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP)) {
+        rc = launch_split_pack(2, N, Dn, x, Dn, apk1, stream);
+        if (rc) return rc;
+        rc = launch_split_pack(2, Ch, Dn, p->node0_weight, Dn, wpk1, stream);
+        if (rc) return rc;
+        LinearEpilogue e1{p->node0_bias, nullptr, 0, nullptr, 0, 1};
+        e1.pk_out = reinterpret_cast<uint16_t*>(apk2);
+        rc = launch_linear_split(2, N, Ch, Dn, apk1, wpk1, e1, nullptr, Ch, stream);
+        if (rc == GVQA_OK) {
+            rc = launch_split_pack(2, Ch, Ch, p->node2_weight, Ch, wpk1, stream);
+            if (rc) return rc;
+            LinearEpilogue e2{p->node2_bias, nullptr, 0, nullptr, 0, 0};
+            e2.pk_out = reinterpret_cast<uint16_t*>(apk1);
+            e2.pk_mul = P(L.qn); e2.pk_mul_idx = g->node_graph; e2.pk_mul_ld = Ch;
+            rc = launch_linear_split(2, N, Ch, Ch, apk2, wpk1, e2, P(L.xn), Ch, stream);
+            if (rc) return rc;
+            chained = true;
+        } else if (rc != GVQA_E_UNSUPPORTED) return rc;
+    }
+    if (!chained) {
+        NLIN(Dn, x, p->node0_weight, p->node0_bias, 1, P(L.h1));
+        NLIN(Ch, P(L.h1), p->node2_weight, p->node2_bias, 0, P(L.xn));
+    }
     bool parts = false;
     if (fused) {
-        char* apk = base + L.scratch;
-        char* wpk = apk + align_up(split_packed_bytes(2, N, Ch), 256);
-        rc = launch_split2h_pack_rowmul(N, Ch, P(L.xn), Ch, P(L.qn), g->node_graph, Ch, apk, stream);
-        if (rc) return rc;
+        char* apk = apk1;
+        char* wpk = wpk1;
+        if (!chained) {
+            rc = launch_split2h_pack_rowmul(N, Ch, P(L.xn), Ch, P(L.qn), g->node_graph, Ch, apk, stream);
+            if (rc) return rc;
+        }
         rc = launch_split_pack(2, Ch, Ch, p->gate0_weight, Ch, wpk, stream);
         if (rc) return rc;
         GVQA_HIP_CHECK(hipMemsetAsync(P(L.gate), 0, (size_t)N * 16 * sizeof(float), stream));

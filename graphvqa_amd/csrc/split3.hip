@@ -50,6 +50,7 @@ namespace gvqa {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 template <int NP> struct SplitFrag { typedef bf16x8_t type; };
 template <> struct SplitFrag<2> { typedef f16x8_t type; };
 __device__ __forceinline__ f32x16 split_mfma(const bf16x8_t& a, const bf16x8_t& b, const f32x16& c) {
@@ -139,11 +140,13 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     constexpr int NW = WM * WN;
     constexpr int FA = WM * TM, FB = WN * TN;          // 32-row operand tiles per block: A rows, B rows (= C columns)
     constexpr int FRAG = NP * 1024;                    // bytes of one (tile, K step): NP pieces x 1 KiB
-    constexpr int STAGE = (FA + FB) * FRAG;            // bytes per K step
     constexpr int NG = NP * (NP + 1) / 2;              // piece products kept per K step
-    constexpr int TPW = (FA + FB) / NW;                // (tile, NP pieces) groups each wave DMAs per K step
+    constexpr int TPW = (FA + FB + NW - 1) / NW;       // (tile, NP pieces) groups each wave DMAs per K step
+    // (FA + FB not a multiple of the wave count -- the 128 x 512 tile: 20 tiles, 8 waves --: every wave still issues TPW groups, so
+    //  that the counted waits are uniform; the surplus groups re-read the last B tile into unused slots of the padded stage)
+    constexpr int STAGE = TPW * NW * FRAG;             // bytes per K step
     typedef typename SplitFrag<NP>::type frag_t;
-    static_assert((FA + FB) % NW == 0, "operand tiles must divide over the waves");
+    static_assert(EPI != 3 || (NP == 2 && KS == 1 && !NOSTORE), "packed-output epilogue: two-piece operands");
     static_assert(NBUF * STAGE * KS <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static_assert(KS == 1 || (KS == 2 && NP == 2 && NBUF == 2 && !PIPE), "two K steps per stage: two-piece operands, two stages");
     static_assert(EPI != 2 || (WM == 2 && WN == 4 && TM == 4 && TN == 2), "the fused-hop epilogue is written for the 256 x 256 tile");
@@ -758,6 +761,86 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         }
         return;
     }
+    if constexpr (EPI == 3) {
+        // ---- the finished rows leave as the NEXT product's packed A operand (two fp16 pieces, fragment-major, one power-of-two scale
+        // per row: exactly what k_split2h_pack would make of them), optionally also as fp32 rows (C).  The workgroup owns whole rows
+        // (gridDim.x == 1, N <= 32 FB), so a row's largest magnitude is known here: the 4 column waves of a row meet through LDS.
+        // ep.pk_mul: the packed value is the finished value times a per-graph row (the pooling head's ques_nn(u)[batch] * x').
+        // No pass over the result between two chained products: the pack kernel's read + write of [M, N] is gone.
+        __builtin_amdgcn_s_barrier();                              // main loop done everywhere: the ring is free
+        float* mx_l = reinterpret_cast<float*>(smem);              // [FA * 32 rows][WN]
+        const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int lr = (wr * TM + i) * 32 + m, gr = bm * FA * 32 + lr;
+            const bool on = gr < M;
+            const float sa = on ? a_inv[gr] : 0.f;
+            const float* mrow = (ep.pk_mul && on) ? ep.pk_mul + (int64_t)ep.pk_mul_idx[gr] * ep.pk_mul_ld : nullptr;
+            float mx = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gc = (wc * TN + j) * 32 + 8 * q + 4 * h;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (on && gc < N) {
+                        const float4 sb = *reinterpret_cast<const float4*>(b_inv + gc);
+                        v = make_float4(acc[i][j][4 * q] * sa * sb.x, acc[i][j][4 * q + 1] * sa * sb.y, acc[i][j][4 * q + 2] * sa * sb.z,
+                                        acc[i][j][4 * q + 3] * sa * sb.w);
+                        if (ep.bias) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(ep.bias + gc);
+                            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                        }
+                        if (ep.addend) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
+                            v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                        }
+                        if (ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (C) *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
+                        if (mrow) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(mrow + gc);
+                            v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
+                        }
+                    }
+                    acc[i][j][4 * q] = v.x; acc[i][j][4 * q + 1] = v.y; acc[i][j][4 * q + 2] = v.z; acc[i][j][4 * q + 3] = v.w;
+                    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (h == 0) mx_l[lr * WN + wc] = mx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int lr = (wr * TM + i) * 32 + m, rt = bm * FA + wr * TM + i;
+            if (rt >= ep.pk_RT) continue;                          // (wave-uniform: a tile past the operand's last one)
+            float full = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) full = fmaxf(full, mx_l[lr * WN + w]);
+            const int ex = split2h_exponent(full);
+            const float scale = pow2i(ex);
+            if (wc == 0 && h == 0) ep.pk_inv[rt * 32 + m] = pow2i(-ex);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kb = (wc * TN + j) * 2 + (q >> 1);   // k block of the next product these 4 columns belong to
+                    if (kb >= ep.pk_KB) continue;
+                    f16x4_t p0, p1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[i][j][4 * q + r] * scale;
+                        const _Float16 a = (_Float16)x;
+                        p0[r] = a;
+                        p1[r] = (_Float16)(x - (float)a);
+                    }
+                    // lane (m, k half = q & 1) of the fragment holds 8 consecutive k: this thread's 4 are its half h
+                    uint16_t* o = ep.pk_out + ((int64_t)(rt * ep.pk_KB + kb) * 2) * 512 + (m + 32 * (q & 1)) * 8 + 4 * h;
+                    *reinterpret_cast<uint2*>(o) = __builtin_bit_cast(uint2, p0);
+                    *reinterpret_cast<uint2*>(o + 512) = __builtin_bit_cast(uint2, p1);
+                }
+        }
+        return;
+    }
     auto finish = [&](float4 v, int gr, int gc) -> float4 {      // bias / addend / mul / activation on 4 consecutive columns, then the store (C NULL: no store)
         if constexpr (NP == 2) {                       // undo the operands' power-of-two scales (exact)
             const float sa = a_inv[gr];
@@ -1290,7 +1373,14 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     GVQA_REQUIRE(M >= 0 && N >= 0 && K > 0, GVQA_E_INVALID, "linear_split3: bad size");
     GVQA_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 30), GVQA_E_INVALID, "linear_split3: size overflow");
     if (M == 0 || N == 0) return GVQA_OK;
-    GVQA_REQUIRE(Apk && Bpk && (C || ep.rowdot_w), GVQA_E_INVALID, "linear_split3: null operand");
+    GVQA_REQUIRE(Apk && Bpk && (C || ep.rowdot_w || ep.pk_out), GVQA_E_INVALID, "linear_split3: null operand");
+    if (ep.pk_out) {      // the result as the next product's packed operand: whole rows per workgroup (128 x 512 tile)
+        GVQA_REQUIRE(np == 2 && batch == 1 && !ep.mul && !ep.rowdot_w && ep.relu != 2 && M <= 65535ll * 128, GVQA_E_INVALID,
+                     "linear_split: packed output takes two-piece operands, one batch, bias / addend / ReLU epilogues");
+        if (N > 512) return GVQA_E_UNSUPPORTED;
+        GVQA_REQUIRE((reinterpret_cast<uintptr_t>(ep.pk_out) & 15) == 0 && (!ep.pk_mul || (ep.pk_mul_idx && ep.pk_mul_ld % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(ep.pk_mul) & 15) == 0)), GVQA_E_INVALID, "linear_split: packed output / row multiplier alignment");
+    }
     GVQA_REQUIRE(!ep.rowdot_w || (ep.rowdot_out && np == 2 && batch == 1 && (reinterpret_cast<uintptr_t>(ep.rowdot_w) & 15) == 0), GVQA_E_INVALID,
                  "linear_split: the row-dot epilogue needs its output, two-piece operands, one batch, a 16-byte aligned vector");
     GVQA_REQUIRE(ldc >= N && (!ep.addend || ep.ld_add >= N) && (!ep.mul || ep.ld_mul >= N), GVQA_E_INVALID,
@@ -1301,12 +1391,14 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     const uint16_t* a = static_cast<const uint16_t*>(Apk);
     const uint16_t* b = static_cast<const uint16_t*>(Bpk);
     int variant = split3_variant(M, N, KB);            // (a forced variant >= 100 names a two-piece instantiation)
+    const int forced_variant = ep.pk_out ? 140 : 0;
     if (np == 2 && variant < 100) variant = variant < 20 ? ((KB & 1) ? 118 : 112) : 134;      // (112: two K steps per barrier)
     // narrow results whose last 256-column tile would be at most half full (N = 300: 2 x 256 columns computed for 300) take
     // 128-column tiles instead (3 x 128): a quarter less matrix-core work at a lower arithmetic intensity per tile
     if (np == 2 && get_option(GVQA_OPT_SPLIT3_VARIANT) < 10 && N % 256 != 0 && N % 256 <= 128 && N <= 1024) variant = 124;
+    if (forced_variant) variant = forced_variant;
     GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
-    const int64_t bm = variant % 100 < 20 ? 256 : 128;     // (rows per tile: 1x = 256, 2x / 3x = 128)
+    const int64_t bm = variant % 100 < 20 ? 256 : 128;     // (rows per tile: 1x = 256, 2x / 3x / 4x = 128)
     GVQA_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || M <= 65535 * bm), GVQA_E_INVALID, "linear_split: bad batch count");
     const float* a_inv = np == 2 ? (a_inv_batched ? a_inv_batched : split2h_inv_scales(Apk, cdiv(M, 32), KB)) : nullptr;
     const float* b_inv = np == 2 ? (b_inv_batched ? b_inv_batched : split2h_inv_scales(Bpk, rtB, KB)) : nullptr;
@@ -1325,6 +1417,11 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
         if (ep.addend) e2.addend = ep.addend + m0 * ep.ld_add;
         if (ep.mul) e2.mul = ep.mul + m0 * ep.ld_mul;
         if (ep.rowdot_out) e2.rowdot_out = ep.rowdot_out + m0 * 16;
+        if (ep.pk_out) {                                   // (one launch: M <= 65535 x 128 checked above)
+            e2.pk_KB = (int)cdiv(N, 16);
+            e2.pk_RT = (int)cdiv(M, 32);
+            e2.pk_inv = const_cast<float*>(split2h_inv_scales(ep.pk_out, e2.pk_RT, e2.pk_KB));
+        }
         const uint16_t* a2 = a + (m0 / 32) * (int64_t)KB * (np * 512);
         const float* a_inv2 = a_inv ? a_inv + m0 : nullptr;
         const int rt2 = (int)cdiv(m, 32);
@@ -1395,6 +1492,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
 #endif
             case 134: GVQA_SN_LAUNCH(2, 2, 2, 4, 3, true, false, false, 0, 1, 2); break;
             case 124: GVQA_SN_LAUNCH(2, 2, 2, 2, 3, true, false, false, 0, 1, 2); break;       // 128 x 128 tile
+            case 140: GVQA_SN_LAUNCH(2, 4, 2, 4, 3, true, false, false, 0, 3, 2); break;       // 128 x 512 tile, result as a packed operand
             default: return GVQA_E_INVALID;
         }
 #undef GVQA_S3_LAUNCH
