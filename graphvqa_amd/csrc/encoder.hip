@@ -446,13 +446,20 @@ int gvqa_sg_encoder_forward(const gvqa_graph* g, int32_t V, int32_t D, int32_t n
         if (rc) return rc;
         {
             LinearEpilogue ep{p->node2_0_bias, Z + 3 * D, ldz, nullptr, 0, 1};   // t = relu(x0's block (+ folded bias) + mean W''^T + bias)
-            if ((rc = prod(N, apk_n, W.pk_wf2, ep, P(L.t)))) return rc;
-        }
-        rc = launch_split_pack(2, N, D, P(L.t), D, apk_n, stream);
-        if (rc) return rc;
-        {
-            LinearEpilogue ep{p->node2_2_bias, nullptr, 0, nullptr, 0, 0};
-            if ((rc = prod(N, apk_n, W.pk_n22, ep, P(L.x2)))) return rc;
+            // t is only ever node_mlp_2's second operand: it leaves the product packed (split3.hip, packed-output epilogue; the edge
+            // rows' slot is free by now), or in fp32 + a pack pass where that epilogue does not apply
+            const bool room = E >= N;                              // (the edge rows' packed slot holds N packed rows)
+            ep.pk_out = reinterpret_cast<uint16_t*>(apk_e);
+            rc = room ? launch_linear_split(2, N, D, D, apk_n, wb + W.pk_wf2, ep, nullptr, D, stream) : GVQA_E_UNSUPPORTED;
+            const char* apk_t = apk_e;
+            if (rc == GVQA_E_UNSUPPORTED) {
+                ep.pk_out = nullptr;
+                if ((rc = prod(N, apk_n, W.pk_wf2, ep, P(L.t)))) return rc;
+                if ((rc = launch_split_pack(2, N, D, P(L.t), D, apk_n, stream))) return rc;
+                apk_t = apk_n;
+            } else if (rc) return rc;
+            LinearEpilogue e2{p->node2_2_bias, nullptr, 0, nullptr, 0, 0};
+            if ((rc = prod(N, apk_t, W.pk_n22, e2, P(L.x2)))) return rc;
         }
     } else {
     // EdgeModel: e' = Lin2(relu(Lin1([x_src || x_dst || e])))                       (:65-76)
