@@ -7,12 +7,12 @@ N = 1 runs in this process; N > 1 spawns one rank per GPU by itself (re-exec und
 127.0.0.1) unless it was already launched that way (WORLD_SIZE set), so both driver forms work.
 
 A step = one `gat_seq.forward` (CSR build from COO included) over synthetic input resident in HBM: BASELINE config 3
--- ONE batch of 2048 graphs x 32 nodes x 128 edges = 64k nodes / 256k edges, Dn = De = Di = C = 512, H = 4, K = 5,
-eval mode, fp32 in / fp32 out.  With N ranks that one batch is sharded by graphs (edge-balanced contiguous ranges, 256
-graphs per GPU at N = 8; the reference's DistributedSampler role, mainExplain_gat.py:226-227), the K hops run with no
-communication and the per-graph result rows are all-gathered over RCCL at the end of the step: STRONG scaling
-(`--scaling weak` gives every rank its own full batch instead; the default run reports that number too as
-`weak_value`).  Prints ONE JSON line on rank 0.
+-- a batch of 2048 graphs x 32 nodes x 128 edges = 64k nodes / 256k edges, Dn = De = Di = C = 512, H = 4, K = 5,
+eval mode, fp32 in / fp32 out.  With N ranks every rank runs its OWN batch of that size (WEAK scaling: the reference's
+data-parallel form -- DistributedSampler + a per-process batch_size, mainExplain_gat.py:226-236), the K hops run with no
+communication and the per-graph result rows are all-gathered over RCCL at the end of the step.  The same run also times
+the STRONG form -- ONE such batch sharded by graphs (edge-balanced contiguous ranges, 256 graphs per GPU at N = 8) --
+and prints it as `strong_value` (`--scaling strong` swaps the two).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import csv
@@ -39,7 +39,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak",
+                    help="N > 1 -- weak (default): every rank its own full config-3 batch, the reference's data-parallel form (DistributedSampler + "
+                         "a per-process batch_size, mainExplain_gat.py:226-236); strong: ONE config-3 batch sharded by graphs over the ranks.  The "
+                         "line carries the other form's number as well (`strong_value` / `weak_value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32-MFMA / vendor comparison legs")
@@ -324,11 +327,15 @@ def main():
     _lib.prof_enable(False)
     edges_per_step = Eall if strong else world * Eall
 
-    weak = None
-    if strong and world > 1:            # second key: weak scaling (every rank the full batch), fewer steps
-        wsteps = max(3, a.steps // 2)
-        wdt = timed(runner(make_shard(0, 1)), wsteps, 2)
-        weak = {"value": world * Eall / (wdt / wsteps), "ms_per_step": wdt / wsteps * 1e3, "steps": wsteps}
+    other = None
+    if world > 1:                       # second key: the OTHER scaling form on the same ranks (fewer steps)
+        osteps = max(3, a.steps // 2)
+        oshard = make_shard(0, 1) if strong else make_shard(rank, world)
+        if strong and rank:
+            oshard.x = tt(synth.normal((Nall, D), 1 + 10 * rank)).to(dev)
+        odt = timed(runner(oshard), osteps, 2)
+        other = {"value": (world * Eall if strong else Eall) / (odt / osteps), "ms_per_step": odt / osteps * 1e3, "steps": osteps,
+                 "graphs_per_gpu": oshard.num_graphs}
 
     line = None
     if rank == 0:
@@ -409,7 +416,8 @@ def main():
             "dtype": ("f32 in/out; 2xfp16-split MFMA, fp32 accumulate" if split and pieces == 2 else
                       "f32 in/out; 3xbf16-split MFMA (exact split), fp32 accumulate" if split else "f32"),
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: ONE batch of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
+            "config": {"workload": "BASELINE configs[2]: " + ("ONE batch" if strong or world == 1 else f"{world} batches (one per GPU)") +
+                                   " of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
                                    "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, device CSR build from COO inside the step "
                                    "(per-graph node / edge counts supplied by the host loader, no device read-back; weight-only products cached)"
                                    + ("; + attention pooling + 1842-way classifier, true logits gathered" if head else ""),
@@ -432,8 +440,12 @@ def main():
         }
         if rccl_ranks_seen is not None:
             res["rccl_ranks_seen"] = rccl_ranks_seen
-        if weak is not None:
-            res["weak_value"], res["weak_ms_per_step"], res["weak_steps"] = weak["value"], weak["ms_per_step"], weak["steps"]
+        if other is not None:
+            o = "weak" if strong else "strong"
+            res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other["value"], other["ms_per_step"], other["steps"]
+            res[o + "_note"] = ("every rank its own full batch" if strong else
+                                f"ONE config-3 batch sharded by graphs over the {world} ranks ({other['graphs_per_gpu']} graphs on rank 0): "
+                                "whole-batch edges / max-over-ranks step time")
         if world == 1:
             if not a.no_extras:
                 # the same step (a) unfused: split projection + the message-passing kernel, whose HBM roofline the north star
