@@ -125,6 +125,8 @@ def live_pmc_traffic():
     def is_fused(n):
         if "k_hop2" in n and "k_hop2_" not in n:                   # the persistent hop kernel (csrc/hop2.hip)
             return True
+        if "k_hopagg4" in n:                                       # the aggregate-first hop kernel (csrc/hopagg.hip), per-hop or one-launch form
+            return True
         m = re.search(r"k_linear_split3<([^>]*)>", n)
         if m:
             args = [t.strip() for t in m.group(1).split(",")]
@@ -377,6 +379,9 @@ def main():
             # dominant kernel: the fused hop (split projection + aggregation + epilogue), MFMA-bound.  Algorithmic work per
             # launch = the kept piece products of the folded projection (8(d)'s 2 N Dn H C, x 3 or x 6) -- the aggregation's
             # 2 E H C flops (0.4 %) are not counted.
+            hk0 = m.hop_kernel(g0)
+            if hk0 == "aggregate_first_seq":
+                proj_n *= K                                              # one launch = K hops: per-hop figures below
             avg_s = proj_ms / max(proj_n, 1) * 1e-3
             ach = flops32 / avg_s / 1e12                                 # the folded projection's 2 N Dn H C flops per launch
             issued = products * flops32 / avg_s / 1e12                   # what the matrix cores execute: 3 (6) piece products of them
@@ -388,8 +393,10 @@ def main():
                                   "output written as the next hop's packed operand; xp never reaches HBM)",
                 "persistent_chained": f"gvqa::k_hop2<H={H},NBUF=3,CHAIN,NW=4> (persistent hop kernel, two 4-wave workgroups per CU, 128 x 256 items; output "
                                       "written as the next hop's packed operand; xp never reaches HBM)",
-                "aggregate_first": "gvqa::k_hopagg4<2,4,2,4> (aggregate-first hop: heads concatenated along K, the attention-weighted neighbour sum formed "
-                                   "inside the matrix-core loop, register -> global epilogue; rows chunk-major between hops)",
+                "aggregate_first": "gvqa::k_hopagg4<2,4,2,4,SEQ=0> (aggregate-first hop: heads concatenated along K, the attention-weighted neighbour sum formed "
+                                   "inside the matrix-core loop, register -> global epilogue with its loads a batch ahead; rows chunk-major between hops)",
+                "aggregate_first_seq": "gvqa::k_hopagg4<2,4,2,4,SEQ=1> (aggregate-first hops, the K hops as ONE launch: a workgroup walks all hops of its "
+                                       "row group, coefficient phase inside the workgroup; avg_launch_us is per hop = launch / K)",
                 "persistent": f"gvqa::k_hop2<H={H},NBUF=3,NW=4> (persistent hop kernel, a pack pass per hop)",
             }.get(hk, f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
                       f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
@@ -400,7 +407,11 @@ def main():
                     "issued_flops_per_launch": products * flops32, "issued_tflops": issued,
                     "mfma_utilisation": issued / 2500.0,     # matrix-core utilisation: two thirds of the issued flops are the price of fp32 accuracy on 16-bit cores
                     "frac_of_f32_mfma_peak": ach / 157.3,    # the same algorithmic flops against the pipe the reference's dtype would use
-                    "algorithmic_bytes_per_launch": 2 * pieces * N * D + 2 * 4 * N * D + 4 * (E * H + E + N + 1),
+                    # rows in once + rows out once (+ the hop's weights, CSR, coefficients): the 8-wave / persistent kernels read their
+                    # input as two-piece packed rows (2 x 2 B per value) and the skip rows out of the same operand, the aggregate-first
+                    # kernel reads fp32 chunk-major rows
+                    "algorithmic_bytes_per_launch": ((4 * N * D + 4 * N * D + 2 * 2 * H * D * D) if hk.startswith("aggregate_first") else
+                                                     (2 * pieces * N * D + 2 * 4 * N * D)) + 4 * (E * H + E + N + 1),
                     "avg_launch_us": avg_s * 1e6, "launches": proj_n,
                     "dtype_note": "peak = dense 16-bit MFMA (bf16 = fp16 rate, MI355X_MICROARCH.md); operands are 16-bit pieces of fp32 "
                                   "values, fp32 accumulate"}
@@ -426,7 +437,12 @@ def main():
                                        "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
                        "hop_kernel": m.hop_kernel(g0) if fused else "unfused",
-                       "hop": (("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "
+                       "hop": ("aggregate-first: x -> chunk-major rows once; every hop = coefficient kernel (fp32 node logits from the chunks + segment "
+                               "softmax) -> ONE kernel that forms the attention-weighted neighbour sums inside its matrix-core loop (heads concatenated "
+                               "along K), epilogue register -> global (two launches per hop)" if fused and m.hop_kernel(g0) == "aggregate_first" else
+                               "aggregate-first, the K hops as ONE launch (coefficient phase of hops 1 .. K - 1 inside the workgroups)"
+                               if fused and m.hop_kernel(g0) == "aggregate_first_seq" else
+                               ("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "
                                 "segment softmax) -> ONE kernel for projection + aggregation + epilogue that leaves the next hop's "
                                 "packed operand (two launches per hop, one pack pass per forward)") if fused and split and pieces == 2 and prof["pack"][1] < prof["proj"][1] else
                                "fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"

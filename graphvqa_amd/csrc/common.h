@@ -208,6 +208,7 @@ struct AlphaX4Args {
     float* alpha_out;           // NULL or [E, H] out, COO order
     int Dn, NQ, C;
     float slope;
+    const float* a_node_in;     // NULL or [N, 2 H]: the node logits, left by the previous hop's launch (X4 / Vn are then not read)
 };
 struct HopAggArgs {
     const int32_t *group_ptr, *rowptr, *csr_src, *node_graph;
@@ -225,9 +226,35 @@ struct HopAggArgs {
     float* out;                 // NULL or [N, out_ld]: output rows, row-major
     int64_t out_ld;
     int C, NQ, NCT, relu;
+    const float* Vn_next;       // with a_node_out: [2 H][Dn] folded attention vectors of the NEXT hop
+    float* a_node_out;          // NULL or [N, 2 H]: the next hop's node logits of the rows this launch produces
     int dbg;                    // measurement build only (GVQA_HOPAGG_DEBUG): 1 no producer in the loop, 2 no weight DMA, 4 no MFMAs, 8 no fragment reads after step 0, 16 no waits / barriers, 32 no epilogue
 };
+// The K hops of gat_seq as ONE launch of the aggregate-first kernel (k_hopagg4<..., SEQ>): per-hop operands.  The HopAggArgs beside it
+// carry the batch (CSR, row groups), hop 0's coefficients (alpha_csr, from k_gat_alpha_x4), the per-graph maxima of the input rows
+// (gmax_in), the final rows (out) and the shapes; Wk / binv / epc / graph_term / relu / X4in / X4out of HopAggArgs are not read.
+// (per-hop operands as base + hop x stride: the weight cache and the workspace lay the hops out at constant strides, and a table
+//  indexed by the hop would be copied from the kernel arguments to scratch)
+constexpr int HA_MAXHOPS = 8;
+struct HopAggSeq {
+    const uint16_t* Wk;         // packed weights of hop 0; hop i at + i w_hop_bytes; their inverse column scales binv_off_bytes behind
+    int64_t w_hop_bytes, binv_off_bytes;
+    const float* epc;           // bias | BatchNorm scale | shift of hop 0; hop i at + i epc_hop floats
+    int64_t epc_hop;
+    const float* graph_term;    // NULL or [K][B, t_ld]: per-graph instruction term [0, C) and logit offsets [C, C + H); hop i at + i t_hop floats
+    int64_t t_hop;
+    const float* Vn;            // [K][2 H][Dn] folded attention vectors (hop i + 1's are read by hop i's coefficient phase)
+    const int32_t* csr_eid;     // [E] CSR slot -> COO edge id
+    const float* a_edge;        // [E, a_edge_stride] edge halves of the logits, COO order; hop i's H columns start at column i H
+    int64_t a_edge_stride;
+    float *X4a, *X4b;           // chunk-major row buffers: hop i reads (i odd ? X4b : X4a) and writes the other
+    float slope;
+    int K;
+    unsigned relu_mask;         // bit i: hop i ends in BatchNorm + ReLU
+    unsigned long long* stamps; // measurement build only: [groups][K][8] 100 MHz timestamps of wave 0 at the phase boundaries of every hop
+};
 bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges);
+int launch_hopagg_seq(int H, const HopAggArgs& a, const HopAggSeq& hs, int num_groups, hipStream_t stream);
 size_t hopagg_packed_w_bytes(int C, int Dn, int H);
 int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream);

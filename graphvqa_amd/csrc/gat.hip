@@ -1042,10 +1042,10 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // The hop "aggregate first" (hopagg.hip, GVQA_OPT_HOP_FUSION = 4; taken by the default rule 3 when the batch fills the chip):
 // H = 4, C == Dn <= 512, the two-piece projection, a row-group plan with <= 1024 edges per group.  Rows travel chunk-major
 // between hops; per-hop fp32 outputs and the attention weights are served, batch-statistics BatchNorm is not.
-constexpr bool kAggFirstByDefault = false;
+constexpr bool kAggFirstByDefault = true;            // (since the epilogue's loads run a batch ahead: 386-400 vs 389-428 us per hop for the chained 8-wave kernel, same boxes)
 static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int mode = opt_hop_fusion(d);
-    if (mode != 4 && mode != 3) return false;
+    if (mode != 4 && mode != 5 && mode != 3) return false;
     const int H = d->heads, C = d->out_channels;
     if (!(proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
           hopagg_supported(H, C, d->node_dim, g->max_row_group_edges) &&
@@ -1062,8 +1062,15 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
         }();
         const int64_t G = g->num_row_groups, rounds = cdiv(G, cus);
         if (G * 100 < rounds * cus * 85) return false;
+        if (C <= 320) return false;                    // (the 4 x 2-wave layout of narrow rows is issue-bound: d = 300, 149 vs 110 us per hop)
     }
     return true;
+}
+
+// ... and its K hops as ONE launch (GVQA_OPT_HOP_FUSION = 5; k_hopagg4<..., SEQ>): plain outputs only -- the attention weights and
+// per-hop fp32 rows are served by the per-hop launches
+static bool hopagg_seq_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    return opt_hop_fusion(d) == 5 && d->num_hops >= 2 && d->num_hops <= HA_MAXHOPS && hopagg_applies(g, d);
 }
 
 // Chained hops on the 8-WAVE kernel (launch_hop_fused_split with a chain descriptor): a hop writes the next hop's packed operand
@@ -1536,8 +1543,10 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             if (rc) return rc;
         }
         if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
+        const bool aggseq = hopagg_seq_applies(g, d) && !alpha_out && !hop_out;
         for (int i = 0; i < K; ++i) {
             const float* gterm = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr;
+            if (aggseq && i > 0) break;               // (one launch: hops 1 .. K - 1 compute their coefficients inside it)
             {
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
                 AlphaX4Args ax;
@@ -1548,6 +1557,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 ax.graph_term = gterm; ax.t_ld = Tld;
                 ax.alpha_csr = P(L.alpha_csr); ax.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
                 ax.Dn = Dn; ax.NQ = NQ; ax.C = C; ax.slope = d->negative_slope;
+                ax.a_node_in = (i > 0 && !aggseq) ? P(L.a_node) : nullptr;          // (left by hop i - 1's launch)
                 rc = launch_alpha_x4(g, H, ax, stream);
                 if (rc) return rc;
             }
@@ -1570,8 +1580,34 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 ha.out = hop_out ? hop_out + (int64_t)i * N * C : (last ? out : nullptr);
                 ha.out_ld = C;
                 ha.relu = hops[i].bn_weight != nullptr;
+                if (!last && !aggseq) {               // the next hop's node logits leave with the rows
+                    ha.Vn_next = Vn_all + (int64_t)(i + 1) * 2 * H * Dn;
+                    ha.a_node_out = P(L.a_node);
+                }
                 GVQA_REQUIRE(!hops[i].bn_weight || (hops[i].bn_bias && hops[i].bn_mean && hops[i].bn_var), GVQA_E_INVALID,
                              "gat_seq: BatchNorm needs weight, bias, running_mean and running_var");
+                if (aggseq) {
+                    // ---- the K hops as ONE launch: a workgroup walks all hops of its row group (rows ping-pong between the two
+                    // chunk-major buffers, coefficients of hops 1 .. K - 1 computed in the workgroup)
+                    HopAggSeq hs;
+                    memset(&hs, 0, sizeof(hs));
+                    hs.Wk = reinterpret_cast<const uint16_t*>(w6); hs.w_hop_bytes = (int64_t)w6_hop; hs.binv_off_bytes = (int64_t)ha.NCT * NQ * 2048;
+                    hs.epc = reinterpret_cast<const float*>(wbase + WL.epc); hs.epc_hop = (int64_t)(WL.epc_hop / sizeof(float));
+                    hs.graph_term = Di > 0 ? P(L.T) : nullptr; hs.t_hop = (int64_t)B * Tld;
+                    hs.Vn = Vn_all;
+                    hs.csr_eid = g->csr_eid; hs.a_edge = P(L.a_edge); hs.a_edge_stride = (int64_t)K * H;
+                    hs.X4a = X4[0]; hs.X4b = X4[1];
+                    hs.slope = d->negative_slope; hs.K = K;
+                    for (int j = 0; j < K; ++j) {
+                        GVQA_REQUIRE(!hops[j].bn_weight || (hops[j].bn_bias && hops[j].bn_mean && hops[j].bn_var), GVQA_E_INVALID,
+                                     "gat_seq: BatchNorm needs weight, bias, running_mean and running_var");
+                        if (hops[j].bn_weight) hs.relu_mask |= 1u << j;
+                    }
+                    ha.out = out; ha.X4out = nullptr; ha.gmax_out = nullptr;
+                    rc = launch_hopagg_seq(H, ha, hs, g->num_row_groups, stream);
+                    if (rc) return rc;
+                    continue;
+                }
                 rc = launch_hopagg(H, ha, g->num_row_groups, stream);
                 if (rc) return rc;
             }
@@ -1751,6 +1787,7 @@ int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d) {
 int gvqa_gat_seq_hop_kernel(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true) || !g->finalized) return GVQA_E_INVALID;
     if (!g->intra_graph) return GVQA_E_UNSUPPORTED;
+    if (hopagg_seq_applies(g, d)) return GVQA_HOP_AGGREGATE_FIRST_SEQ;
     if (hopagg_applies(g, d)) return GVQA_HOP_AGGREGATE_FIRST;
     if (!hop_fusion_applies(g, d)) return GVQA_HOP_UNFUSED;
     const bool logits = split_pack_groups_logits_supported(2, 2 * d->heads, d->node_dim);

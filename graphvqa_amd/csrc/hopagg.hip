@@ -41,6 +41,7 @@ namespace gvqa {
 
 typedef _Float16 ha_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ha_f16x4 __attribute__((ext_vector_type(4)));
+typedef float ha_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HA_ROWS = 128;          // rows of a row group / tile
 constexpr int HA_DMAX = 8;            // in-edges of a node kept in registers
@@ -177,6 +178,10 @@ __global__ __launch_bounds__(512) void k_gat_alpha_x4(AlphaX4Args a) {
     float* rs = part + 4 * HA_ROWS * J;
     const int ns = a.group_ptr[grp], cnt = a.group_ptr[grp + 1] - ns;
     const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
+    float* an_s = part;                             // [128][J] node logits (the first quarter's slots of `part`)
+    if (a.a_node_in) {       // the node logits came with the rows (the previous hop's epilogue): no pass over the chunks
+        for (int it = tid; it < cnt * J; it += 512) an_s[it] = a.a_node_in[(int64_t)ns * J + it];
+    } else {
     for (int idx = tid; idx < J * Kp; idx += 512) {
         const int j = idx / Kp, k = idx - j * Kp;
         vn_s[idx] = k < a.Dn ? a.Vn[(int64_t)j * a.Dn + k] : 0.f;
@@ -201,9 +206,9 @@ __global__ __launch_bounds__(512) void k_gat_alpha_x4(AlphaX4Args a) {
         for (int j = 0; j < J; ++j) part[(p * HA_ROWS + r) * J + j] = acc[j];
     }
     __syncthreads();
-    float* an_s = part;                             // [128][J] node logits (the first quarter's slots)
     for (int it = tid; it < HA_ROWS * J; it += 512)
         an_s[it] = (part[it] + part[HA_ROWS * J + it]) + (part[2 * HA_ROWS * J + it] + part[3 * HA_ROWS * J + it]);
+    }
     __syncthreads();
     for (int s = tid; s < ne; s += 512) {
         const int src = a.csr_src[e0 + s] - ns, eid = a.csr_eid[e0 + s];
@@ -273,6 +278,15 @@ __device__ __forceinline__ void ha_dma4(const void* sbase, unsigned voff, unsign
                  : "memory");
 }
 
+// a wave-uniform pointer the compiler has lost track of (re-pointed inside the hop loop) back into SGPRs: the DMA helpers above take
+// their base as an "s" operand, which inline asm does not legalise
+template <typename T>
+__device__ __forceinline__ const T* ha_uniform(const T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int ha_wave_max(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
@@ -287,15 +301,34 @@ __device__ __forceinline__ int ha_wave_max(int v) {
 constexpr unsigned HA_BSTAGE = 16 * 2048, HA_B0 = 0, HA_A0 = 3 * HA_BSTAGE, HA_X0 = HA_A0 + 2 * 8192, HA_SRC0 = HA_X0 + 4 * 2048,
                    HA_AL0 = HA_SRC0 + HA_ECAP * 4, HA_ROW0 = HA_AL0 + HA_ECAP * 16, HA_GM0 = HA_ROW0 + 3 * HA_ROWS * 4, HA_LDS = HA_GM0 + HA_ROWS * 4;
 static_assert(HA_LDS <= 160 * 1024, "hopagg: LDS");
+// One-launch form (SEQ): + the second set of per-graph maxima | the slice's COO edge ids.  BETWEEN two hops of a tile the idle rings
+// hold the next hop's coefficient phase: weight-ring stage 2 = the next hop's folded attention vectors Vn [8][C] | edge halves of the
+// logits, head-major [4][ECAP]; A' ring = partial node logits [WC][128][8] (summed in place into wave column 0's slots).  The
+// priming DMAs of the next hop go to weight-ring stages 0 / 1 and the x ring: no overlap with these.
+constexpr unsigned HA_CC0 = HA_LDS, HA_LDS1 = HA_CC0 + 4 * 512 * 4;       // + per-column constants of the epilogue [4][512]: inverse weight scale | bias | BN scale | BN shift
+constexpr unsigned HA_GM1 = HA_LDS1, HA_EID0 = HA_GM1 + HA_ROWS * 4, HA_LDS_SEQ = HA_EID0 + HA_ECAP * 4;
+constexpr unsigned HA_VN0 = HA_B0 + 2 * HA_BSTAGE, HA_ST0 = HA_VN0 + 16384;
+static_assert(HA_LDS_SEQ <= 160 * 1024 && HA_ST0 + HA_ECAP * 16 <= HA_A0, "hopagg (one launch): LDS");
 
 // WR x WC waves, RT row tiles x TN column tiles of 32 x 32 per wave: <2, 4, 2, 4> covers 512 columns (config 3: d = 512), <4, 2, 1, 5>
 // 320 (the reference's real width, d = 300: ten column tiles, no empty MFMA columns beyond the 20 that pad 300 to 320).
-template <int WR, int WC, int RT, int TN>
-__global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
+// SEQ: the K hops of gat_seq as ONE launch.  A workgroup owns all output columns of its rows and its rows are whole graphs, so hop
+// i + 1 of a row group needs nothing from another workgroup: rows (chunk-major, through HBM / L2: written by the epilogue, DMA'd
+// back by the next hop), per-graph maxima and attention coefficients are group-local.  Between two hops the workgroup runs the
+// coefficient phase itself (gat_skip.py:134-135,180-208): node logits a_node = h . [V_l | V_r]^T of the rows it has just finished
+// (out of the accumulator registers, against Vn in LDS), then leaky-relu + segment softmax per (node, head) -- the lane that owns
+// the producer item (node, head) of the main loop computes exactly the coefficients it will use.  Hop 0's coefficients come from
+// the stand-alone kernel (k_gat_alpha_x4), as in the per-hop form.
+// LGT (per-hop launches): the node logits of the NEXT hop, a_node = h . [V_l | V_r]^T of the rows this launch produces, leave with them
+// (out of the accumulator registers, as in the one-launch form) -- the next hop's coefficient kernel then skips its pass over the
+// rows (134 MB at config 3: 38 -> 1x us).
+template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false>
+__global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) {
+    static_assert(!(SEQ && LGT), "hopagg: the one-launch form computes its logits itself");
     static_assert(WR * WC == 8 && WR * RT == 4 && WC * TN <= 16, "hopagg: eight waves over 128 rows and at most 16 column tiles");
     constexpr int H = 4;
     constexpr int NM = RT * TN;                       // MFMAs of one piece product per wave
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[HA_LDS];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SEQ ? HA_LDS_SEQ : HA_LDS1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
@@ -311,30 +344,33 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     //  their own, unused ring slot; steps past the last one re-load the last step -- so that the step is branch-free and the counted
     //  waits are the same everywhere)
     const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
-    const uint16_t* wbase0 = a.Wk + (int64_t)min(wave, NCT - 1) * NQ * 1024;            // (wave-uniform: SGPRs)
-    const uint16_t* wbase1 = a.Wk + (int64_t)min(wave + 8, NCT - 1) * NQ * 1024;
-    const float* xbase = a.X4in + (int64_t)t * NQ * (HA_ROWS * 4) + wave * 64;
+    // operands of the current hop (SEQ: re-pointed at the top of every hop; wave-uniform: SGPRs)
+    const uint16_t* Wk_h = a.Wk;
+    const float *binv_h = a.binv, *epc_h = a.epc, *gterm_h = a.graph_term, *X4in_h = a.X4in;
+    float *X4out_h = a.X4out, *out_h = a.out;
+    int relu_h = a.relu;
+    const uint16_t *wbase0 = nullptr, *wbase1 = nullptr;
+    const float* xbase = nullptr;
     auto issue_b_unit = [&](int st, int u) {           // weight unit u of step st (clamped) -> ring slot st % 3
-        ha_dma16_x2((u ? wbase1 : wbase0) + (int64_t)min(st, NQ - 1) * 1024, lane16,
+        ha_dma16_x2(ha_uniform((u ? wbase1 : wbase0) + (int64_t)min(st, NQ - 1) * 1024), lane16,
                     __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + (unsigned)(st % 3) * HA_BSTAGE + (unsigned)(wave + 8 * u) * 2048u));
     };
     auto issue_b = [&](int st) { issue_b_unit(st, 0); issue_b_unit(st, 1); };
     auto issue_x = [&](int q) {                        // this wave's 256 bytes of x chunk q (clamped) -> ring slot q & 3
-        ha_dma4(xbase + (int64_t)min(q, NQ - 1) * (HA_ROWS * 4), lane4,
+        ha_dma4(ha_uniform(xbase + (int64_t)min(q, NQ - 1) * (HA_ROWS * 4)), lane4,
                 __builtin_amdgcn_readfirstlane(lds_base + HA_X0 + (unsigned)(q & 3) * 2048u + (unsigned)wave * 256u));
     };
-    issue_b(0);
-    issue_b(1);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) issue_x(q);
     // CSR slice of the group -> LDS (edges past a node's first 8: read from here every K step)
-    {
+    auto dma_csr_slice = [&]() {
         const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
         for (int u = wbase; u < ne; u += 512)
             lds_dma4_b(a.csr_src + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_SRC0 + (unsigned)u * 4u));
+        if constexpr (SEQ)
+            for (int u = wbase; u < ne; u += 512)
+                lds_dma4_b(hs.csr_eid + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_EID0 + (unsigned)u * 4u));
         for (int u = wbase; u < ne * H; u += 512)
             lds_dma4_b(a.alpha_csr + (int64_t)e0 * H + min(u + lane, ne * H - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_AL0 + (unsigned)u * 4u));
-    }
+    };
 
     // ---- this lane's producer item: node i = 16 wave + a, head h = 2 hhi + hlo; its first 8 in-edges in registers
     // (the four heads of a node are the four lanes of a quad: every lane fetches ONE of the node's source rows per batch of four
@@ -343,22 +379,23 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     const int pa = lane >> 2, ph = lane & 3, hlo = ph & 1, hhi = ph >> 1;
     const int pi = wave * 16 + pa;
     const bool p_on = pi < cnt;
-    const int plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
-    const int pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
+    int plo = 0, pdeg = 0;                            // (hop-invariant; loaded in the first hop's prologue, behind its priming DMAs)
     float al[HA_DMAX];                                // this head's coefficients of the node's first 8 in-edges (0 past the last)
+    unsigned sep = 0u;                                // byte offsets (slot x 16) of the chunk rows this lane fetches: edge ph | edge 4 + ph << 16
+    auto load_lane_items = [&]() {
+        plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
+        pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
 #pragma unroll
-    for (int e = 0; e < HA_DMAX; ++e) {
-        const int idx = max(min(plo + e, ne - 1), 0);
-        const float av = ne > 0 ? a.alpha_csr[(int64_t)(e0 + idx) * H + ph] : 0.f;
-        al[e] = e < pdeg ? av : 0.f;
-    }
-    unsigned sep;                                     // byte offsets (slot x 16) of the chunk rows this lane fetches: edge ph | edge 4 + ph << 16
-    {
+        for (int e = 0; e < HA_DMAX; ++e) {
+            const int idx = max(min(plo + e, ne - 1), 0);
+            const float av = ne > 0 ? a.alpha_csr[(int64_t)(e0 + idx) * H + ph] : 0.f;
+            al[e] = e < pdeg ? av : 0.f;
+        }
         const int i0 = max(min(plo + ph, ne - 1), 0), i1 = max(min(plo + 4 + ph, ne - 1), 0);
         const unsigned s0 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i0] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         const unsigned s1 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         sep = s0 | (s1 << 16);
-    }
+    };
     // acc += w * (x of quad lane E_): ONE instruction, v_fmac_f32 with a DPP quad broadcast on its first source (the compiler does not
     // fold its own v_mov_b32_dpp into the FMA here: 32 extra VALU operations per lane and K step, an eighth of the step's issue slots)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -368,20 +405,22 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
 #endif
 #define GVQA_HA_QFMA(acc_, w_, x_, E_) do { GVQA_HA_QF1((acc_).x, w_, (x_).x, E_); GVQA_HA_QF1((acc_).y, w_, (x_).y, E_); \
                                             GVQA_HA_QF1((acc_).z, w_, (x_).z, E_); GVQA_HA_QF1((acc_).w, w_, (x_).w, E_); } while (0)
-    const int ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);      // wave-uniform trips through the LDS slice
+    int ovtrips = 0;                                  // wave-uniform trips through the LDS slice
     float pscale = 1.f;
-    {
-        const int g = a.node_graph[ns + min(pi, cnt - 1)];
-        const int ex = split2h_exponent(a.gmax_in[g]);
+    int pg = 0;                                       // graph of this lane's node
+    // the rows' power-of-two scale from their graph's largest input magnitude; per-row arrays of the epilogue
+    auto set_row_scale = [&](float gmax_of_graph, bool first) {
+        const int ex = split2h_exponent(gmax_of_graph);
         pscale = pow2i(ex);
         float* row_l = reinterpret_cast<float*>(smem + HA_ROW0);
         if (hlo == 0 && hhi == 0) {
             row_l[pi] = p_on ? pow2i(-ex) * (1.0f / H) : 0.f;
-            reinterpret_cast<int*>(row_l)[HA_ROWS + pi] = g;
-            reinterpret_cast<int*>(row_l)[2 * HA_ROWS + pi] = pdeg;
+            if (first) {
+                reinterpret_cast<int*>(row_l)[HA_ROWS + pi] = pg;
+                reinterpret_cast<int*>(row_l)[2 * HA_ROWS + pi] = pdeg;
+            }
         }
-        if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
-    }
+    };
     const unsigned a_wr_off = (unsigned)((pi >> 5) * 2048 + ((pi & 31) + 32 * hhi) * 16 + hlo * 8);
     const int* src_l = reinterpret_cast<const int*>(smem + HA_SRC0);
     const float* al_l = reinterpret_cast<const float*>(smem + HA_AL0);
@@ -413,20 +452,6 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
         *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
         *reinterpret_cast<uint2*>(dst + 1024) = __builtin_bit_cast(uint2, lo);
     };
-
-    f32x16 acc[RT][TN];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                  // rings' first stages, CSR slice and per-row arrays are in place
-    produce(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 
     const unsigned a_off = (unsigned)(wr * RT * 2048 + lane * 16);
     const unsigned b_off = (unsigned)(wc * TN * 2048 + lane * 16);
@@ -524,14 +549,77 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     }
     // (an odd number of steps runs one more with an all-zero A operand -- the producer's scale is 0 past the last chunk, the weight
     //  DMA re-loads the last step's tiles -- so that the two-step body needs no tail variant)
+    f32x16 acc[RT][TN];
+    const int nhops = SEQ ? hs.K : 1;
+#ifdef GVQA_PROBES
+#define GVQA_HA_STAMP(hop_, k_) do { if (SEQ && hs.stamps && tid == 0) hs.stamps[((int64_t)t * hs.K + (hop_)) * 8 + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GVQA_HA_STAMP(hop_, k_) do { } while (0)
+#endif
+    // (Tried, one launch: workgroups of the first dispatch round started up to 8 x 5 .. 25 us apart, so that the CUs' epilogues -- 0.5 MB
+    //  of row reads and writes per tile, all CUs within the same ~35 us of a hop -- spread over the hop period: 2.34 / 2.32 / 2.30 /
+    //  2.50 ms per launch against 2.26-2.30 without, measurement build.  The epilogues are not limited by each other.)
+    for (int hop = 0; hop < nhops; ++hop) {
+    GVQA_HA_STAMP(hop, 0);                            // hop begins
+    [[maybe_unused]] const bool more = hop + 1 < nhops;           // (SEQ) another hop follows: rows leave chunk-major, coefficient phase behind the epilogue
+    if constexpr (SEQ) {
+        const char* wk_ = reinterpret_cast<const char*>(hs.Wk) + hop * hs.w_hop_bytes;
+        Wk_h = reinterpret_cast<const uint16_t*>(wk_);
+        binv_h = reinterpret_cast<const float*>(wk_ + hs.binv_off_bytes);
+        epc_h = hs.epc + hop * hs.epc_hop;
+        gterm_h = hs.graph_term ? hs.graph_term + hop * hs.t_hop : nullptr;
+        relu_h = (int)((hs.relu_mask >> hop) & 1u);
+        X4in_h = (hop & 1) ? hs.X4b : hs.X4a;
+        X4out_h = more ? ((hop & 1) ? hs.X4a : hs.X4b) : nullptr;
+        out_h = more ? nullptr : a.out;
+    }
+    wbase0 = Wk_h + (int64_t)min(wave, NCT - 1) * NQ * 1024;            // (wave-uniform: SGPRs)
+    wbase1 = Wk_h + (int64_t)min(wave + 8, NCT - 1) * NQ * 1024;
+    xbase = X4in_h + (int64_t)t * NQ * (HA_ROWS * 4) + wave * 64;
+    {   // the epilogue's per-column constants -> LDS [4][512] (one 1 KiB unit per wave; lanes past C re-read the row's last 16 bytes into the padding)
+        const int npr = (a.C + 255) >> 8;             // units per row
+        if (wave < 4 * npr) {
+            const int k = wave / npr, hf = wave - k * npr;
+            const float* rowp = k == 0 ? binv_h : epc_h + (int64_t)(k - 1) * a.epc_ld;
+            lds_dma16_b(rowp + min(hf * 256 + lane * 4, a.C - 4), __builtin_amdgcn_readfirstlane(lds_base + HA_CC0 + (unsigned)(k * 512 + hf * 256) * 4u));
+        }
+    }
+    if (!SEQ || hop == 0) {            // (SEQ, later hops: the previous hop's coefficient phase primed the weight ring and wrote x chunks 0 .. 2 into the x ring)
+        issue_b(0);
+        issue_b(1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) issue_x(q);
+    }
+    if (!SEQ || hop == 0) {
+        dma_csr_slice();
+        load_lane_items();
+        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);
+        pg = a.node_graph[ns + min(pi, cnt - 1)];
+        set_row_scale(a.gmax_in[pg], true);
+        if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
+        if constexpr (SEQ) { if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM1)[tid] = 0u; }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // rings' first stages, CSR slice and per-row arrays are in place
+    produce(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    GVQA_HA_STAMP(hop, 1);                            // rings primed, first A' chunk produced
+
     for (int sq = 0; sq < NQ; sq += 2) {
         GVQA_HA_STEP(sq, bh1, bh0)
         GVQA_HA_STEP(sq + 1, bh0, bh1)
     }
     GVQA_HA_MFR(0, NM, afh, bh1);                    // the last step's (a hi, b hi)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (the clamped re-loads of the last steps)
-#undef GVQA_HA_STEP
-#undef GVQA_HA_MFR
+    GVQA_HA_STAMP(hop, 2);                            // main loop done
 
 #ifdef GVQA_PROBES
     if (a.dbg & 32) {                                 // (measurement: no epilogue; the accumulators kept live)
@@ -547,55 +635,306 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a) {
     }
 #endif
     // ---- epilogue, register -> global: lane (m, hh) owns columns 8 q + 4 hh + 0..3 of row m of tile (i, j)
-    const int m = lane & 31, hh = lane >> 5;
+    int m = lane & 31, hh = lane >> 5;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (SEQ: opaque per hop -- otherwise the epilogue's 64-bit row / column offsets, invariant across hops, are all hoisted out of the
+    //  hop loop and spilled: 690 bytes of scratch per lane)
+    if constexpr (SEQ) asm volatile("" : "+v"(m), "+v"(hh));
+#endif
     const float* row_l = reinterpret_cast<const float*>(smem + HA_ROW0);
-    unsigned* gm_l = reinterpret_cast<unsigned*>(smem + HA_GM0);
+    unsigned* gm_l = reinterpret_cast<unsigned*>(smem + ((SEQ && (hop & 1)) ? HA_GM1 : HA_GM0));
     const int gf = a.node_graph[ns];
     const int C = a.C;
     const int CQ = C >> 2;                            // chunks of the output rows (C % 4 == 0)
+    [[maybe_unused]] float tlog = 0.f;                // (SEQ) the next hop's per-graph logit offset of this lane's (node, head)
+    if constexpr (LGT) {
+        __syncthreads();                              // every wave's ring DMAs have landed: weight-ring stage 2 takes the next hop's Vn
+        const int nvn = 8 * C;
+        for (int u = wave * 256; u < nvn; u += 2048)
+            lds_dma16_b(a.Vn_next + min(u + lane * 4, nvn - 4), __builtin_amdgcn_readfirstlane(lds_base + HA_VN0 + (unsigned)u * 4u));
+    }
+    if constexpr (SEQ) {
+        if (more) {                                   // (block-uniform)
+            // every wave's ring DMAs have landed: weight-ring stage 2 takes the next hop's folded attention vectors and the edge
+            // halves of its logits (gathered through the slice's COO edge ids, head-major), stages 0 / 1 the next hop's first two
+            // weight steps -- all on their way during the epilogue's loads below
+            __syncthreads();
+            const float* vn_next = hs.Vn + (int64_t)(hop + 1) * 8 * C;
+            const float* gterm_next = hs.graph_term ? hs.graph_term + (hop + 1) * hs.t_hop : nullptr;
+            const int nvn = 8 * C;                    // floats of Vn [2 H][C] (C == Dn)
+            for (int u = wave * 256; u < nvn; u += 2048)
+                lds_dma16_b(vn_next + min(u + lane * 4, nvn - 4), __builtin_amdgcn_readfirstlane(lds_base + HA_VN0 + (unsigned)u * 4u));
+            const int* eid_l = reinterpret_cast<const int*>(smem + HA_EID0);
+            const float* ae = hs.a_edge + (int64_t)(hop + 1) * H;
+            for (int u = wave * 64; u < ne; u += 512) {
+                const float* src = ae + (int64_t)eid_l[min(u + lane, ne - 1)] * hs.a_edge_stride;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int r = (wr * RT + i) * 32 + m;
-        const bool row_on = r < cnt;
-        const float rf = row_l[r];
-        const int g = reinterpret_cast<const int*>(row_l)[HA_ROWS + r];
-        const bool has_in = reinterpret_cast<const int*>(row_l)[2 * HA_ROWS + r] > 0;
-        const int64_t node = ns + r;
-        float vmax = 0.f;
+                for (int h = 0; h < H; ++h)
+                    lds_dma4_b(src + h, __builtin_amdgcn_readfirstlane(lds_base + HA_ST0 + (unsigned)(h * HA_ECAP + u) * 4u));
+            }
+            if (gterm_next && p_on) tlog = gterm_next[(int64_t)pg * a.t_ld + C + ph];
+            const uint16_t* wkn = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(hs.Wk) + (hop + 1) * hs.w_hop_bytes);
+            wbase0 = wkn + (int64_t)min(wave, NCT - 1) * NQ * 1024;
+            wbase1 = wkn + (int64_t)min(wave + 8, NCT - 1) * NQ * 1024;
+            issue_b(0);
+            issue_b(1);
+        }
+    }
+    GVQA_HA_STAMP(hop, 3);                            // coefficient-phase DMAs and the next hop's weight priming issued
+    // node logits a_node[r, jj] = sum_c h[r, c] Vn[jj, c], jj < 2 H (a_l | a_r halves, gat_skip.py:134-135) of the finished rows in
+    // the accumulator registers against Vn in LDS: this lane's columns (packed fp32 FMAs: two columns per instruction, even and odd
+    // columns in separate chains), the wave's partial sums -> part[wc][row][0..8) in the idle A' ring
+    auto node_logits_to_part = [&]() {
+            const float* vn_l = reinterpret_cast<const float*>(smem + HA_VN0);
+            ha_f32x2 an2[RT][8];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+                for (int jj = 0; jj < 8; ++jj) an2[i][jj] = ha_f32x2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
+                    if (c0 >= C) continue;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const float4 vn = *reinterpret_cast<const float4*>(vn_l + jj * C + c0);
+                        const ha_f32x2 v01{vn.x, vn.y}, v23{vn.z, vn.w};
+#pragma unroll
+                        for (int i = 0; i < RT; ++i) {
+                            const ha_f32x2 a01{acc[i][j][4 * q], acc[i][j][4 * q + 1]}, a23{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            an2[i][jj] = a01 * v01 + an2[i][jj];
+                            an2[i][jj] = a23 * v23 + an2[i][jj];
+                        }
+                    }
+                }
+            GVQA_HA_STAMP(hop, 5);                            // rows stored, node-logit FMAs done
+            // the two column halves of a row (lanes m and m + 32) meet; lane m leaves the wave's partial at part[wc][r][0..8)
+            float* part = reinterpret_cast<float*>(smem + HA_A0);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                float an[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    an[jj] = an2[i][jj][0] + an2[i][jj][1];
+                    an[jj] += __shfl_xor(an[jj], 32, 64);
+                }
+                if (hh == 0) {
+                    float* dst = part + ((wc * HA_ROWS) + (wr * RT + i) * 32 + m) * 8;
+                    *reinterpret_cast<float4*>(dst) = make_float4(an[0], an[1], an[2], an[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(an[4], an[5], an[6], an[7]);
+                }
+            }
+        };
+    [[maybe_unused]] const bool defer = SEQ && more;   // (SEQ, another hop follows) the rows are stored behind the barrier below, from the accumulator registers
+    // The loads of a batch -- row i, half of column tile j: two skip-row chunks and two per-graph term chunks per lane -- are issued one
+    // batch AHEAD of the arithmetic and stores that consume them (two register sets; whole column tiles per batch spill).  Written as a plain loop the epilogue came out
+    // as 32 x (loads, wait for all of them, arithmetic, store): one 16-byte skip read in flight per lane, 29 us per tile of pure
+    // latency.  The per-column constants come from LDS.
+    {
+        const float* cc_l = reinterpret_cast<const float*>(smem + HA_CC0);
+        constexpr int NB = RT * TN * 2;
+        float rf_[RT], tmask_[RT], vmax_[RT];
+        int g_[RT];
+        bool on_[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int r = (wr * RT + i) * 32 + m;
+            on_[i] = r < cnt;
+            rf_[i] = row_l[r];
+            g_[i] = reinterpret_cast<const int*>(row_l)[HA_ROWS + r];
+            tmask_[i] = (gterm_h && reinterpret_cast<const int*>(row_l)[2 * HA_ROWS + r] > 0) ? 1.f : 0.f;     // (no in-edges: empty softmax, no term)
+            vmax_[i] = 0.f;
+        }
+        const float* gt_ = gterm_h ? gterm_h : binv_h;        // (no instruction terms: a mapped address -- row 0 of the column scales --, the mask is 0)
+        const int64_t gt_ld = gterm_h ? a.t_ld : 0;
+        float4 skA[2], tgA[2], skB[2], tgB[2];
+        auto load_batch = [&](int b, float4 (&sk)[2], float4 (&tg)[2]) {
+            const int i = b / (2 * TN), j = (b >> 1) % TN, qp = b & 1;
+            int r = (wr * RT + i) * 32 + m, hb = hh;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(r), "+v"(hb));             // (addresses formed here, per batch: carried from batch to batch -- row parts, column parts -- they spill)
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cc = min((wc * TN + j) * 32 + 8 * (2 * qp + u) + 4 * hb, C - 4);       // (columns past C: clamped re-reads, never used)
+                sk[u] = *reinterpret_cast<const float4*>(X4in_h + (((int64_t)t * NQ + (cc >> 2)) * HA_ROWS + r) * 4);
+                tg[u] = *reinterpret_cast<const float4*>(gt_ + (int64_t)g_[i] * gt_ld + cc);
+            }
+        };
+        auto consume_batch = [&](int b, const float4 (&sk_)[2], const float4 (&tg_)[2]) {
+            const int i = b / (2 * TN), j = (b >> 1) % TN, qp = b & 1;
+            int r = (wr * RT + i) * 32 + m;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(r));
+#endif
+            const int64_t node = ns + r;
+            const float rf = rf_[i], tm = tmask_[i];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = 2 * qp + u;
+                const float4 (&sk)[2] = sk_;
+                const float4 (&tg)[2] = tg_;
                 const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
                 if (c0 >= C) continue;
-                const float4 bv = *reinterpret_cast<const float4*>(a.binv + c0);
-                const float4 bi = *reinterpret_cast<const float4*>(a.epc + c0);
-                const float4 sk = *reinterpret_cast<const float4*>(a.X4in + (((int64_t)t * NQ + (c0 >> 2)) * HA_ROWS + r) * 4);
-                float4 tg = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.graph_term && has_in) tg = *reinterpret_cast<const float4*>(a.graph_term + (int64_t)g * a.t_ld + c0);     // (no in-edges: empty softmax, no term)
+                const float4 bv = *reinterpret_cast<const float4*>(cc_l + c0);
+                const float4 bi = *reinterpret_cast<const float4*>(cc_l + 512 + c0);
                 float4 v;
-                v.x = acc[i][j][4 * q] * (rf * bv.x) + tg.x + bi.x + sk.x;
-                v.y = acc[i][j][4 * q + 1] * (rf * bv.y) + tg.y + bi.y + sk.y;
-                v.z = acc[i][j][4 * q + 2] * (rf * bv.z) + tg.z + bi.z + sk.z;
-                v.w = acc[i][j][4 * q + 3] * (rf * bv.w) + tg.w + bi.w + sk.w;
-                if (a.relu) {                         // torch's eval BatchNorm: y = x (w invstd) + (b - mean w invstd), then ReLU
-                    const float4 sc = *reinterpret_cast<const float4*>(a.epc + a.epc_ld + c0);
-                    const float4 sh = *reinterpret_cast<const float4*>(a.epc + 2 * a.epc_ld + c0);
+                v.x = acc[i][j][4 * q] * (rf * bv.x) + tg[u].x * tm + bi.x + sk[u].x;
+                v.y = acc[i][j][4 * q + 1] * (rf * bv.y) + tg[u].y * tm + bi.y + sk[u].y;
+                v.z = acc[i][j][4 * q + 2] * (rf * bv.z) + tg[u].z * tm + bi.z + sk[u].z;
+                v.w = acc[i][j][4 * q + 3] * (rf * bv.w) + tg[u].w * tm + bi.w + sk[u].w;
+                if (relu_h) {                         // torch's eval BatchNorm: y = x (w invstd) + (b - mean w invstd), then ReLU
+                    const float4 sc = *reinterpret_cast<const float4*>(cc_l + 1024 + c0);
+                    const float4 sh = *reinterpret_cast<const float4*>(cc_l + 1536 + c0);
                     v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
                     v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
                 }
-                if (!row_on) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.X4out) *reinterpret_cast<float4*>(a.X4out + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4) = v;
-                if (a.out && row_on) *reinterpret_cast<float4*>(a.out + node * a.out_ld + c0) = v;
-                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                if (!on_[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!defer) {
+                    if (X4out_h) *reinterpret_cast<float4*>(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4) = v;
+                    if (out_h && on_[i]) *reinterpret_cast<float4*>(out_h + node * a.out_ld + c0) = v;
+                }
+                vmax_[i] = fmaxf(vmax_[i], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                if constexpr (SEQ || LGT) {           // the finished values stay in the accumulator registers: stores and node logits below
+                    acc[i][j][4 * q] = v.x; acc[i][j][4 * q + 1] = v.y; acc[i][j][4 * q + 2] = v.z; acc[i][j][4 * q + 3] = v.w;
+                }
             }
-        if (a.gmax_out && row_on) atomicMax(&gm_l[g - gf], __float_as_uint(vmax));
+        };
+        load_batch(0, skA, tgA);
+#pragma unroll
+        for (int b = 0; b < NB; b += 2) {
+            if (b + 1 < NB) load_batch(b + 1, skB, tgB);
+            consume_batch(b, skA, tgA);
+            if (b + 1 < NB) {
+                if (b + 2 < NB) load_batch(b + 2, skA, tgA);
+                consume_batch(b + 1, skB, tgB);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+            if ((SEQ ? more : a.gmax_out != nullptr) && on_[i]) atomicMax(&gm_l[g_[i] - gf], __float_as_uint(vmax_[i]));
     }
-    if (a.gmax_out) {
+    if constexpr (!SEQ) {
+        if constexpr (LGT) {
+            // (this wave's Vn DMAs are older than the epilogue loads it has consumed -- loads return in order --: complete; then everybody's)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            node_logits_to_part();
+            __syncthreads();
+            const float* part = reinterpret_cast<const float*>(smem + HA_A0);
+            float2 sacc = *reinterpret_cast<const float2*>(part + tid * 2);
+#pragma unroll
+            for (int w = 1; w < WC; ++w) {
+                const float2 pw = *reinterpret_cast<const float2*>(part + w * HA_ROWS * 8 + tid * 2);
+                sacc.x += pw.x; sacc.y += pw.y;
+            }
+            if ((tid >> 2) < cnt) *reinterpret_cast<float2*>(a.a_node_out + (int64_t)(ns + (tid >> 2)) * 8 + (tid & 3) * 2) = sacc;
+        }
+        if (a.gmax_out) {
+            __syncthreads();
+            const int ngl = a.node_graph[ns + cnt - 1] - gf + 1;
+            if (tid < ngl) a.gmax_out[gf + tid] = __uint_as_float(gm_l[tid]);
+        }
+    } else if (more) {
+        // ---- coefficient phase of hop + 1, inside the workgroup ---------------------------------------------------------------
+        GVQA_HA_STAMP(hop, 4);                                // epilogue arithmetic done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's Vn / edge-half / weight DMAs have landed (no store is in flight yet)
+        __syncthreads();                                      // ... everybody's; the per-graph maxima are complete; the x ring is idle
+        // the rows leave chunk-major -- this workgroup's OWN input of the next hop (its DMAs bring them back from step 0 on, its
+        // epilogue reads the skip rows): workgroup scope, the waves of a workgroup share the CU's vector L1 and its XCD's L2; the
+        // stores only have to be complete before the barrier that opens the next hop's loop.  (Agent-scope fences write back and
+        // invalidate the XCD's whole L2, every hop of every tile: 2.37 ms per launch against 2.19 for the per-hop launches.)  Chunks
+        // 0 .. 2 also go straight into the x ring: the next hop needs no priming DMA for them.
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(m), "+v"(hh));                // (opaque again: the row / chunk offsets are recomputed here, not carried -- spilled -- from the pass above)
+#endif
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int r = (wr * RT + i) * 32 + m;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
+                    if (c0 >= C) continue;
+                    const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    *reinterpret_cast<float4*>(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4) = v;
+                    if (j == 0 && q < 2 && c0 < 12) *reinterpret_cast<float4*>(smem + HA_X0 + (c0 >> 2) * 2048 + r * 16) = v;
+                }
+        }
+        node_logits_to_part();
         __syncthreads();
-        const int ngl = a.node_graph[ns + cnt - 1] - gf + 1;
-        if (tid < ngl) a.gmax_out[gf + tid] = __uint_as_float(gm_l[tid]);
+        {   // a_node = sum over the WC wave columns, in place in wave column 0's slots (thread: 2 of the 128 x 8 values)
+            float* part = reinterpret_cast<float*>(smem + HA_A0);
+            float2 sacc = *reinterpret_cast<const float2*>(part + tid * 2);
+#pragma unroll
+            for (int w = 1; w < WC; ++w) {
+                const float2 pw = *reinterpret_cast<const float2*>(part + w * HA_ROWS * 8 + tid * 2);
+                sacc.x += pw.x; sacc.y += pw.y;
+            }
+            *reinterpret_cast<float2*>(part + tid * 2) = sacc;
+        }
+        __syncthreads();
+        GVQA_HA_STAMP(hop, 6);                                // node logits reduced
+        {   // leaky-relu + segment softmax of this lane's (node pi, head ph) over its in-edges (gat_skip.py:183-190; the denominator's
+            // + 1e-16 as in torch_geometric.utils.softmax); the coefficients go to the slice in LDS and, the first 8, to registers
+            const float* an_s = reinterpret_cast<const float*>(smem + HA_A0);
+            float* st = reinterpret_cast<float*>(smem + HA_ST0) + ph * HA_ECAP + plo;
+            float* al_w = reinterpret_cast<float*>(smem + HA_AL0);
+            const float ar = an_s[pi * 8 + H + ph] + tlog;
+            // the first 8 in-edges in registers, branch-free (clamped slots, masked afterwards: all reads of a stage issued together);
+            // edges beyond them (wave-uniform trip count) through the slice in LDS
+            float lg[HA_DMAX];
+            int srs[HA_DMAX];
+#pragma unroll
+            for (int e = 0; e < HA_DMAX; ++e) srs[e] = min(max(src_l[max(min(plo + e, ne - 1), 0)] - ns, 0), HA_ROWS - 1);
+#pragma unroll
+            for (int e = 0; e < HA_DMAX; ++e) lg[e] = st[min(e, max(pdeg - 1, 0))];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < HA_DMAX; ++e) {
+                float v = lg[e] + an_s[srs[e] * 8 + ph] + ar;
+                v = v > 0.f ? v : v * hs.slope;
+                lg[e] = e < pdeg ? v : -INFINITY;
+                mx = fmaxf(mx, lg[e]);
+            }
+            for (int e = HA_DMAX; e < pdeg; ++e) {
+                const int sr = min(max(src_l[plo + e] - ns, 0), HA_ROWS - 1);
+                float v = st[e] + an_s[sr * 8 + ph] + ar;
+                v = v > 0.f ? v : v * hs.slope;
+                st[e] = v;
+                mx = fmaxf(mx, v);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < HA_DMAX; ++e) {
+                lg[e] = e < pdeg ? expf(lg[e] - mx) : 0.f;
+                sum += lg[e];
+            }
+            for (int e = HA_DMAX; e < pdeg; ++e) {
+                const float ex = expf(st[e] - mx);
+                st[e] = ex;
+                sum += ex;
+            }
+            const float den = sum + 1e-16f;
+#pragma unroll
+            for (int e = 0; e < HA_DMAX; ++e) al[e] = lg[e] / den;            // (0 past the node's last edge)
+            for (int e = HA_DMAX; e < pdeg; ++e) al_w[(plo + e) * H + ph] = st[e] / den;     // (the loop reads the slice from a node's ninth edge on)
+            // the next hop's input rows are the rows just produced: their graph's largest magnitude anchors the two-piece scale
+            set_row_scale(__uint_as_float(gm_l[pg - gf]), false);
+            unsigned* gm_n = reinterpret_cast<unsigned*>(smem + ((hop & 1) ? HA_GM0 : HA_GM1));
+            if (tid < HA_ROWS) gm_n[tid] = 0u;
+        }
+        // (no barrier here: the next hop's first LDS writes and its first x DMA come behind the wait + barrier at its top, which
+        //  also completes the row stores above)
+        GVQA_HA_STAMP(hop, 7);                                // coefficients of the next hop in place
     }
+    }   // hop
+#undef GVQA_HA_STEP
+#undef GVQA_HA_MFR
+#undef GVQA_HA_STAMP
 }
 
 bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges) {
@@ -607,17 +946,54 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
                  (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
     GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1, GVQA_E_UNSUPPORTED, "hopagg: needs C %% 4 == 0 and C <= 512");
     if (num_groups == 0) return GVQA_OK;
+    HopAggArgs b = a;
+    HopAggSeq none;
+    memset(&none, 0, sizeof(none));
 #ifdef GVQA_PROBES
     static const int dbg = []() { const char* v = getenv("GVQA_HOPAGG_DEBUG"); return v ? atoi(v) : 0; }();
-    HopAggArgs b = a;
     b.dbg = dbg;
-    if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5>), dim3((unsigned)num_groups), dim3(512), 0, stream, b);
-    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4>), dim3((unsigned)num_groups), dim3(512), 0, stream, b);
+#endif
+    GVQA_REQUIRE(!a.a_node_out || a.Vn_next, GVQA_E_INVALID, "hopagg: node logits out need the next hop's folded attention vectors");
+    if (a.a_node_out) {
+        if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
+        else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
+    } else if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
+    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
+}
+
+// The K hops as one launch (see k_hopagg4<..., SEQ>): one workgroup per row group walks all hops of its rows.
+int launch_hopagg_seq(int H, const HopAggArgs& a, const HopAggSeq& hs, int num_groups, hipStream_t stream) {
+    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.alpha_csr && a.node_graph && a.gmax_in && a.out && hs.csr_eid && hs.a_edge &&
+                 hs.X4a && hs.X4b && hs.Wk && hs.epc && hs.Vn && hs.K >= 1 && hs.K <= HA_MAXHOPS, GVQA_E_INVALID, "hopagg_seq: null operand / hop count");
+    GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1 && a.NQ * 4 == a.C, GVQA_E_UNSUPPORTED, "hopagg_seq: needs C == Dn, C %% 4 == 0 and C <= 512");
+    if (num_groups == 0) return GVQA_OK;
+    HopAggArgs b = a;
+#ifdef GVQA_PROBES
+    static const int dbg = []() { const char* v = getenv("GVQA_HOPAGG_DEBUG"); return v ? atoi(v) : 0; }();
+    b.dbg = dbg & ~32;
+    // GVQA_HOPAGG_STAMPS=<path>: after every launch the phase stamps of all workgroups are copied back (synchronously) and written there
+    static const char* stamp_path = getenv("GVQA_HOPAGG_STAMPS");
+    HopAggSeq h2 = hs;
+    unsigned long long* dstamps = nullptr;
+    const size_t nst = (size_t)num_groups * hs.K * 8;
+    if (stamp_path && hipMalloc(&dstamps, nst * 8) == hipSuccess) { (void)hipMemsetAsync(dstamps, 0, nst * 8, stream); h2.stamps = dstamps; }
+    if (dstamps) {
+        if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, h2);
+        else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, h2);
+        unsigned long long* host = static_cast<unsigned long long*>(malloc(nst * 8));
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(host, dstamps, nst * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_path, "wb")) { int hdr[2] = {num_groups, hs.K}; fwrite(hdr, sizeof(int), 2, f); fwrite(host, 8, nst, f); fclose(f); }
+        free(host);
+        (void)hipFree(dstamps);
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
 #endif
-    if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5>), dim3((unsigned)num_groups), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4>), dim3((unsigned)num_groups), dim3(512), 0, stream, a);
+    if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, hs);
+    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, hs);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -207,6 +207,7 @@ GVQA_API int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims
 #define GVQA_HOP_FUSED8_CHAINED 3     /* the 8-wave fused kernel, hops chained through packed operands (default when H = 4) */
 #define GVQA_HOP_PERSISTENT_CHAINED 4 /* the persistent kernel, hops chained                                              */
 #define GVQA_HOP_AGGREGATE_FIRST 5    /* hopagg.hip: heads concatenated along K (GVQA_OPT_HOP_FUSION = 4)                  */
+#define GVQA_HOP_AGGREGATE_FIRST_SEQ 6 /* the same, the K hops as ONE launch (GVQA_OPT_HOP_FUSION = 5)                     */
 GVQA_API int gvqa_gat_seq_hop_kernel(const gvqa_graph* g, const gvqa_gat_dims* d);
 GVQA_API int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
                                  size_t cache_bytes, void* stream);
@@ -381,7 +382,11 @@ enum gvqa_option {
                                          >= 6 (row group, column block) items per workgroup slot, else 1;
                                       4: the aggregate-first kernel of csrc/hopagg.hip (H = 4, C == node_dim <= 512: heads concatenated along K,
                                          the attention-weighted neighbour sum formed inside the matrix-core loop, rows chunk-major between hops);
-                                         falls back to 1 where it does not apply.  Modes 1 and 2 chain whenever the batch allows. */
+                                         falls back to 1 where it does not apply.  Modes 1 and 2 chain whenever the batch allows;
+                                      5: mode 4 with the K hops as ONE launch: a workgroup owns all output columns of its row group (whole
+                                         graphs), so hop i + 1 of its rows needs nothing from another workgroup -- it runs the coefficient
+                                         phase (node logits, leaky-relu, segment softmax) itself between two hops; rows travel chunk-major
+                                         through L2 / HBM.  Plain outputs only (attention weights / per-hop rows: mode 4's launches). */
     GVQA_OPT_COEFF_KERNEL = 5,     /* attention coefficients: 0 (default) the row-group kernel when a row-group plan exists, 1 always the
                                       per-(node, head) kernel (same operations in the same order: bit-identical; tests) */
     GVQA_OPT_MP_PARTS = 6,         /* stand-alone message-passing kernel: 0 (default) blocks per graph chosen by batch size, n > 0 exactly n */

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Phase stamps of the one-launch aggregate-first kernel (k_hopagg4<..., SEQ>, hop_fusion = 5), measurement build:
+
+    GVQA_LIB=graphvqa_amd/lib/probes/libgvqa_hip.so GVQA_HOPAGG_STAMPS=/tmp/ha_stamps.bin python scripts/probe_hopagg_seq.py
+
+Every workgroup's wave 0 stamps the 100 MHz clock at 8 phase boundaries of every hop; printed: the mean / max duration of every
+phase over workgroups, per hop, and the launch's span."""
+import json, os, struct, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+torch.set_grad_enabled(False)
+from graphvqa_amd import synth, _lib
+from graphvqa_amd.gat_skip import gat_seq
+from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+path = os.environ.get("GVQA_HOPAGG_STAMPS")
+assert path, "set GVQA_HOPAGG_STAMPS (and GVQA_LIB to the measurement build)"
+D, H, K, DI = int(os.environ.get("D", "512")), 4, 5, 512
+dev = torch.device("cuda:0")
+tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+gb = synth.config3_batch(int(os.environ.get("GRAPHS", "2048"))) if D == 512 else synth.config2_batch()
+N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+m = gat_seq(D, D, D, DI, K, dropout=0.1, gat_heads=H)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.gat_seq_params(D, D, D, DI, K, H, seed=777).items()})
+m = m.to(dev).eval()
+m.hop_fusion = 5
+x, ea, ins = tt(synth.normal((N, D), 1)), tt(synth.normal((E, D), 2)), tt(synth.normal((K, B, DI), 3))
+ei, bt = tt(gb.edge_index), tt(gb.batch)
+g = SceneGraphBatch(ei, bt, N, B, host_layout=HostLayout.from_numpy(gb.edge_index, gb.batch, B))
+for _ in range(4):
+    m(x, ei, ea, ins, bt, graph=g)
+torch.cuda.synchronize()
+raw = open(path, "rb").read()
+G, KK = struct.unpack("ii", raw[:8])
+st = np.frombuffer(raw[8:], dtype=np.uint64).reshape(G, KK, 8).astype(np.float64) / 100.0      # us
+names = ["prime+produce0", "main loop", "B1+issue DMAs", "epilogue arith", "wait+B2+stores+logit FMAs", "reduce part", "B4 softmax..", "-> next hop"]
+t0 = st[:, 0, 0].min()
+out = {"groups": G, "K": KK, "span_us": round(float(st.max() - t0), 1), "first_start_spread_us": round(float(st[:, 0, 0].max() - t0), 1)}
+for hop in range(KK):
+    row = {}
+    last = 7 if hop + 1 < KK else 3
+    for k in range(last):
+        d = st[:, hop, k + 1] - st[:, hop, k]
+        row[names[k]] = [round(float(d.mean()), 2), round(float(d.max()), 2)]
+    if hop + 1 < KK:
+        d = st[:, hop + 1, 0] - st[:, hop, 0]
+        row["hop total"] = [round(float(d.mean()), 2), round(float(d.max()), 2)]
+    out[f"hop{hop} [mean, max] us"] = row
+print(json.dumps(out))

@@ -763,6 +763,40 @@ def test_aggregate_first_hop_parity_sweep(dev, stratum):
     assert ran >= 10 and not bad, (ran, len(bad), bad[:3])
 
 
+@pytest.mark.parametrize("stratum", ["tiny_groups", "sparse_e_over_n_1", "hubs", "partial_k_block", "many_small", "big_graphs"])
+def test_aggregate_first_one_launch_parity_sweep(dev, stratum):
+    """GVQA_OPT_HOP_FUSION = 5: the K hops of the aggregate-first kernel as ONE launch (k_hopagg4<..., SEQ>: a workgroup walks all
+    hops of its row group, rows ping-pong chunk-major between two buffers, the coefficients of hops 1 .. K - 1 -- node logits out
+    of the accumulator registers, leaky-relu, segment softmax -- computed inside the workgroup).  H = 4 cases of every batch regime
+    x K = 2..5 against the oracle at 1e-4; the plain-output forward must have been ONE hop launch + one coefficient launch, and a
+    forward that asks for attention weights / per-hop rows the per-hop launches (same numbers)."""
+    from tests.fuzz import stratified_case, run, STRATA
+    from graphvqa_amd import _lib
+    rng = np.random.default_rng(5000 + STRATA.index(stratum))
+    bad, ran = [], 0
+    for K in range(2, 6):
+        for rep in range(3):
+            c = stratified_case(rng, 5, stratum, K)
+            c["H"] = 4
+            if rep == 0:
+                c["C"] = [300, 512, 64, 320][K - 2]               # every K once on a wide width
+                c["di"] = 8
+            if c["C"] % 4:
+                c["C"] = 64
+            extra = c["alpha"] or c["hops"]
+            _lib.prof_enable(True); _lib.prof_collect()
+            ok, errs, sz = run(c, dev)
+            pr = _lib.prof_collect(); _lib.prof_enable(False)
+            if c["C"] >= 32:
+                # two forwards: the plain one = 1 hop launch + 1 coefficient launch; the other the same, or K + K when it returns more
+                assert pr["mp"][1] == 0 and pr["node_logit"][1] == 0 and pr["proj"][1] == (K + 1 if extra else 2) and \
+                    pr["alpha"][1] == (K + 1 if extra else 2), (c, pr)
+                ran += 1
+            if not ok:
+                bad.append((c, errs, sz))
+    assert ran >= 8 and not bad, (ran, len(bad), bad[:3])
+
+
 @pytest.mark.parametrize("fusion", [1, 2, 4])
 def test_weight_rows_spanning_2_to_the_24_inside_one_column_block(dev, fusion):
     """VERDICT r03 #6, the dynamic range of split2h's weight scales.  The 8-wave and the persistent fused kernels share ONE
