@@ -228,6 +228,13 @@ struct HopAggArgs {
     int C, NQ, NCT, relu;
     const float* Vn_next;       // with a_node_out: [2 H][Dn] folded attention vectors of the NEXT hop
     float* a_node_out;          // NULL or [N, 2 H]: the next hop's node logits of the rows this launch produces
+    // coefficients computed in the launch's prologue (instead of alpha_csr from a coefficient kernel):
+    const float* a_node_in;     // NULL or [N, 2 H]: node logits of the input rows (the previous launch's a_node_out)
+    const float* a_edge;        // [E, a_edge_stride] edge halves of the logits, COO order, this hop's H columns
+    int64_t a_edge_stride;
+    const int32_t* csr_eid;     // [E] CSR slot -> COO edge id
+    float* alpha_out;           // NULL or [E, H]: the attention weights, COO order
+    float slope;
     int dbg;                    // measurement build only (GVQA_HOPAGG_DEBUG): 1 no producer in the loop, 2 no weight DMA, 4 no MFMAs, 8 no fragment reads after step 0, 16 no waits / barriers, 32 no epilogue
 };
 // The K hops of gat_seq as ONE launch of the aggregate-first kernel (k_hopagg4<..., SEQ>): per-hop operands.  The HopAggArgs beside it

@@ -1547,7 +1547,10 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         for (int i = 0; i < K; ++i) {
             const float* gterm = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr;
             if (aggseq && i > 0) break;               // (one launch: hops 1 .. K - 1 compute their coefficients inside it)
-            {
+            // hops 1 .. K - 1 of the per-hop form: the previous launch left their node logits, the hop kernel computes its coefficients
+            // in its own prologue -- no coefficient kernel
+            const bool in_prologue = i > 0 && !aggseq;
+            if (!in_prologue) {
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
                 AlphaX4Args ax;
                 memset(&ax, 0, sizeof(ax));
@@ -1557,7 +1560,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 ax.graph_term = gterm; ax.t_ld = Tld;
                 ax.alpha_csr = P(L.alpha_csr); ax.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
                 ax.Dn = Dn; ax.NQ = NQ; ax.C = C; ax.slope = d->negative_slope;
-                ax.a_node_in = (i > 0 && !aggseq) ? P(L.a_node) : nullptr;          // (left by hop i - 1's launch)
+                ax.a_node_in = nullptr;
                 rc = launch_alpha_x4(g, H, ax, stream);
                 if (rc) return rc;
             }
@@ -1583,6 +1586,13 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 if (!last && !aggseq) {               // the next hop's node logits leave with the rows
                     ha.Vn_next = Vn_all + (int64_t)(i + 1) * 2 * H * Dn;
                     ha.a_node_out = P(L.a_node);
+                }
+                if (in_prologue) {                    // (in place: a workgroup reads its rows' logits before it writes the next hop's)
+                    ha.alpha_csr = nullptr;
+                    ha.a_node_in = P(L.a_node);
+                    ha.a_edge = P(L.a_edge) + (int64_t)i * H; ha.a_edge_stride = (int64_t)K * H; ha.csr_eid = g->csr_eid;
+                    ha.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
+                    ha.slope = d->negative_slope;
                 }
                 GVQA_REQUIRE(!hops[i].bn_weight || (hops[i].bn_bias && hops[i].bn_mean && hops[i].bn_var), GVQA_E_INVALID,
                              "gat_seq: BatchNorm needs weight, bias, running_mean and running_var");

@@ -322,9 +322,12 @@ static_assert(HA_LDS_SEQ <= 160 * 1024 && HA_ST0 + HA_ECAP * 16 <= HA_A0, "hopag
 // LGT (per-hop launches): the node logits of the NEXT hop, a_node = h . [V_l | V_r]^T of the rows this launch produces, leave with them
 // (out of the accumulator registers, as in the one-launch form) -- the next hop's coefficient kernel then skips its pass over the
 // rows (134 MB at config 3: 38 -> 1x us).
-template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false>
+// ALP (per-hop launches): the hop's attention coefficients are computed in this launch's PROLOGUE -- node logits left by the previous
+// launch (a_node_in), edge halves gathered through the slice's COO edge ids, leaky-relu + segment softmax by the lane that owns the
+// producer item (node, head) -- under the latency of the priming DMAs: no coefficient kernel, no alpha_csr round trip.
+template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false, bool ALP = false>
 __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) {
-    static_assert(!(SEQ && LGT), "hopagg: the one-launch form computes its logits itself");
+    static_assert(!(SEQ && (LGT || ALP)), "hopagg: the one-launch form computes its logits and coefficients itself");
     static_assert(WR * WC == 8 && WR * RT == 4 && WC * TN <= 16, "hopagg: eight waves over 128 rows and at most 16 column tiles");
     constexpr int H = 4;
     constexpr int NM = RT * TN;                       // MFMAs of one piece product per wave
@@ -424,6 +427,52 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     const unsigned a_wr_off = (unsigned)((pi >> 5) * 2048 + ((pi & 31) + 32 * hhi) * 16 + hlo * 8);
     const int* src_l = reinterpret_cast<const int*>(smem + HA_SRC0);
     const float* al_l = reinterpret_cast<const float*>(smem + HA_AL0);
+    // leaky-relu + segment softmax of this lane's (node pi, head ph) over its in-edges (gat_skip.py:183-190; the denominator's + 1e-16 as
+    // in torch_geometric.utils.softmax) from LDS: node logits an_s [128][8] (a_l | a_r halves), this head's edge halves st[e] of the node's
+    // in-edges (overwritten), the per-graph logit offset; the coefficients of the first 8 in-edges go to registers, further ones to the
+    // slice in LDS
+    auto coeffs_from_lds = [&](const float* an_s, float* st, float tlog, float slope_) {
+        float* al_w = reinterpret_cast<float*>(smem + HA_AL0);
+        const float ar = an_s[pi * 8 + H + ph] + tlog;
+        // the first 8 in-edges in registers, branch-free (clamped slots, masked afterwards: all reads of a stage issued together);
+        // edges beyond them (wave-uniform trip count) through the slice in LDS
+        float lg[HA_DMAX];
+        int srs[HA_DMAX];
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) srs[e] = min(max(src_l[max(min(plo + e, ne - 1), 0)] - ns, 0), HA_ROWS - 1);
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) lg[e] = st[min(e, max(pdeg - 1, 0))];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) {
+            float v = lg[e] + an_s[srs[e] * 8 + ph] + ar;
+            v = v > 0.f ? v : v * slope_;
+            lg[e] = e < pdeg ? v : -INFINITY;
+            mx = fmaxf(mx, lg[e]);
+        }
+        for (int e = HA_DMAX; e < pdeg; ++e) {
+            const int sr = min(max(src_l[plo + e] - ns, 0), HA_ROWS - 1);
+            float v = st[e] + an_s[sr * 8 + ph] + ar;
+            v = v > 0.f ? v : v * slope_;
+            st[e] = v;
+            mx = fmaxf(mx, v);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) {
+            lg[e] = e < pdeg ? expf(lg[e] - mx) : 0.f;
+            sum += lg[e];
+        }
+        for (int e = HA_DMAX; e < pdeg; ++e) {
+            const float ex = expf(st[e] - mx);
+            st[e] = ex;
+            sum += ex;
+        }
+        const float den = sum + 1e-16f;
+#pragma unroll
+        for (int e = 0; e < HA_DMAX; ++e) al[e] = lg[e] / den;            // (0 past the node's last edge)
+        for (int e = HA_DMAX; e < pdeg; ++e) al_w[(plo + e) * H + ph] = st[e] / den;     // (the loop reads the slice from a node's ninth edge on)
+    };
 
     // A'(q) from x chunk q -> A' slot q & 1 (the first chunk, ahead of the loop; inside the loop the same operations are spread
     // between the MFMAs of a step)
@@ -590,7 +639,30 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #pragma unroll
         for (int q = 0; q < 3; ++q) issue_x(q);
     }
-    if (!SEQ || hop == 0) {
+    [[maybe_unused]] float tlog0 = 0.f;
+    if constexpr (ALP) {
+        // everything the coefficients need starts its trip from HBM now: the slice's sources (LDS), this group's node logits (LDS:
+        // weight-ring stage 2, idle until step 0), the edge halves of the logits gathered through the COO edge ids (LDS, head-major)
+        const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+        for (int u = wbase; u < ne; u += 512)
+            lds_dma4_b(a.csr_src + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_SRC0 + (unsigned)u * 4u));
+        const int nan = cnt * 8;
+        for (int u = wave * 256; u < nan; u += 2048)
+            lds_dma16_b(a.a_node_in + (int64_t)ns * 8 + min(u + lane * 4, nan - 4), __builtin_amdgcn_readfirstlane(lds_base + HA_VN0 + (unsigned)u * 4u));
+        for (int u = wbase; u < ne; u += 512) {
+            const float* src = a.a_edge + (int64_t)a.csr_eid[e0 + min(u + lane, ne - 1)] * a.a_edge_stride;
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                lds_dma4_b(src + h, __builtin_amdgcn_readfirstlane(lds_base + HA_ST0 + (unsigned)(h * HA_ECAP + u) * 4u));
+        }
+        plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
+        pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
+        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);
+        pg = a.node_graph[ns + min(pi, cnt - 1)];
+        if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pg * a.t_ld + a.C + ph];
+        set_row_scale(a.gmax_in[pg], true);
+        if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
+    } else if (!SEQ || hop == 0) {
         dma_csr_slice();
         load_lane_items();
         ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);
@@ -608,6 +680,20 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // rings' first stages, CSR slice and per-row arrays are in place
+    if constexpr (ALP) {
+        coeffs_from_lds(reinterpret_cast<const float*>(smem + HA_VN0), reinterpret_cast<float*>(smem + HA_ST0) + ph * HA_ECAP + plo, tlog0, a.slope);
+        const int i0 = max(min(plo + ph, ne - 1), 0), i1 = max(min(plo + 4 + ph, ne - 1), 0);
+        const unsigned s0 = ne > 0 ? (unsigned)min(max(src_l[i0] - ns, 0), HA_ROWS - 1) * 16u : 0u;
+        const unsigned s1 = ne > 0 ? (unsigned)min(max(src_l[i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
+        sep = s0 | (s1 << 16);
+        if (a.alpha_out) {                            // (block-uniform) the attention weights are asked for: COO order, [E, H]
+            const float* al_w = reinterpret_cast<const float*>(smem + HA_AL0);
+#pragma unroll
+            for (int e = 0; e < HA_DMAX; ++e)
+                if (e < pdeg) a.alpha_out[(int64_t)a.csr_eid[e0 + plo + e] * H + ph] = al[e];
+            for (int e = HA_DMAX; e < pdeg; ++e) a.alpha_out[(int64_t)a.csr_eid[e0 + plo + e] * H + ph] = al_w[(plo + e) * H + ph];
+        }
+    }
     produce(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -882,46 +968,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             // + 1e-16 as in torch_geometric.utils.softmax); the coefficients go to the slice in LDS and, the first 8, to registers
             const float* an_s = reinterpret_cast<const float*>(smem + HA_A0);
             float* st = reinterpret_cast<float*>(smem + HA_ST0) + ph * HA_ECAP + plo;
-            float* al_w = reinterpret_cast<float*>(smem + HA_AL0);
-            const float ar = an_s[pi * 8 + H + ph] + tlog;
-            // the first 8 in-edges in registers, branch-free (clamped slots, masked afterwards: all reads of a stage issued together);
-            // edges beyond them (wave-uniform trip count) through the slice in LDS
-            float lg[HA_DMAX];
-            int srs[HA_DMAX];
-#pragma unroll
-            for (int e = 0; e < HA_DMAX; ++e) srs[e] = min(max(src_l[max(min(plo + e, ne - 1), 0)] - ns, 0), HA_ROWS - 1);
-#pragma unroll
-            for (int e = 0; e < HA_DMAX; ++e) lg[e] = st[min(e, max(pdeg - 1, 0))];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < HA_DMAX; ++e) {
-                float v = lg[e] + an_s[srs[e] * 8 + ph] + ar;
-                v = v > 0.f ? v : v * hs.slope;
-                lg[e] = e < pdeg ? v : -INFINITY;
-                mx = fmaxf(mx, lg[e]);
-            }
-            for (int e = HA_DMAX; e < pdeg; ++e) {
-                const int sr = min(max(src_l[plo + e] - ns, 0), HA_ROWS - 1);
-                float v = st[e] + an_s[sr * 8 + ph] + ar;
-                v = v > 0.f ? v : v * hs.slope;
-                st[e] = v;
-                mx = fmaxf(mx, v);
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < HA_DMAX; ++e) {
-                lg[e] = e < pdeg ? expf(lg[e] - mx) : 0.f;
-                sum += lg[e];
-            }
-            for (int e = HA_DMAX; e < pdeg; ++e) {
-                const float ex = expf(st[e] - mx);
-                st[e] = ex;
-                sum += ex;
-            }
-            const float den = sum + 1e-16f;
-#pragma unroll
-            for (int e = 0; e < HA_DMAX; ++e) al[e] = lg[e] / den;            // (0 past the node's last edge)
-            for (int e = HA_DMAX; e < pdeg; ++e) al_w[(plo + e) * H + ph] = st[e] / den;     // (the loop reads the slice from a node's ninth edge on)
+            coeffs_from_lds(an_s, st, tlog, hs.slope);
             // the next hop's input rows are the rows just produced: their graph's largest magnitude anchors the two-piece scale
             set_row_scale(__uint_as_float(gm_l[pg - gf]), false);
             unsigned* gm_n = reinterpret_cast<unsigned*>(smem + ((hop & 1) ? HA_GM0 : HA_GM1));
@@ -942,7 +989,7 @@ bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges) {
 }
 
 int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream) {
-    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.alpha_csr && a.node_graph && a.X4in && a.Wk && a.binv && a.epc && a.gmax_in &&
+    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && (a.alpha_csr || a.a_node_in) && a.node_graph && a.X4in && a.Wk && a.binv && a.epc && a.gmax_in &&
                  (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
     GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1, GVQA_E_UNSUPPORTED, "hopagg: needs C %% 4 == 0 and C <= 512");
     if (num_groups == 0) return GVQA_OK;
@@ -954,11 +1001,19 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
     b.dbg = dbg;
 #endif
     GVQA_REQUIRE(!a.a_node_out || a.Vn_next, GVQA_E_INVALID, "hopagg: node logits out need the next hop's folded attention vectors");
-    if (a.a_node_out) {
-        if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
-        else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false, true>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
-    } else if (a.NCT <= 10) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
-    else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false>), dim3((unsigned)num_groups), dim3(512), 0, stream, b, none);
+    GVQA_REQUIRE(!a.a_node_in || (a.a_edge && a.csr_eid), GVQA_E_INVALID, "hopagg: coefficients in the prologue need the edge halves and the COO edge ids");
+    const dim3 grid((unsigned)num_groups), block(512);
+    const bool lg = a.a_node_out != nullptr, ap = a.a_node_in != nullptr, narrow = a.NCT <= 10;
+#define GVQA_HA_LAUNCH(LG_, AP_)                                                                                             \
+    do {                                                                                                                     \
+        if (narrow) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, LG_, AP_>), grid, block, 0, stream, b, none);             \
+        else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false, LG_, AP_>), grid, block, 0, stream, b, none);                    \
+    } while (0)
+    if (lg && ap) GVQA_HA_LAUNCH(true, true);
+    else if (lg) GVQA_HA_LAUNCH(true, false);
+    else if (ap) GVQA_HA_LAUNCH(false, true);
+    else GVQA_HA_LAUNCH(false, false);
+#undef GVQA_HA_LAUNCH
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
