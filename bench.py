@@ -345,7 +345,7 @@ def main():
         ms_step = dt / a.steps * 1e3
         g0 = SceneGraphBatch(shard.edge_index, shard.batch, N, B)
         hops = a.steps * K
-        fused = prof["mp"][1] == 0 and prof["alpha"][1] > 0       # the default path: projection + aggregation in one kernel
+        fused = prof["mp"][1] == 0 and prof["proj"][1] > 0        # the default path: projection + aggregation in one kernel
         flops32 = 2 * N * D * H * D                                # folded projection flops per hop (fp32 equivalent)
         split = prof["pack"][1] > 0                                # a split projection ran (operand packing happened)
         pieces = 2 if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H else 3
@@ -437,9 +437,10 @@ def main():
                                        "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
                        "hop_kernel": m.hop_kernel(g0) if fused else "unfused",
-                       "hop": ("aggregate-first: x -> chunk-major rows once; every hop = coefficient kernel (fp32 node logits from the chunks + segment "
-                               "softmax) -> ONE kernel that forms the attention-weighted neighbour sums inside its matrix-core loop (heads concatenated "
-                               "along K), epilogue register -> global (two launches per hop)" if fused and m.hop_kernel(g0) == "aggregate_first" else
+                       "hop": ("aggregate-first: x -> chunk-major rows once (+ hop 0's node logits); every hop = ONE kernel: attention coefficients in its "
+                               "prologue (node logits left by the previous launch, edge halves, segment softmax), the attention-weighted neighbour sums "
+                               "formed inside its matrix-core loop (heads concatenated along K), epilogue register -> global with the next hop's node "
+                               "logits (one launch per hop, no coefficient kernel)" if fused and m.hop_kernel(g0) == "aggregate_first" else
                                "aggregate-first, the K hops as ONE launch (coefficient phase of hops 1 .. K - 1 inside the workgroups)"
                                if fused and m.hop_kernel(g0) == "aggregate_first_seq" else
                                ("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "

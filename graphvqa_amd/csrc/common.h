@@ -264,7 +264,8 @@ bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges);
 int launch_hopagg_seq(int H, const HopAggArgs& a, const HopAggSeq& hs, int num_groups, hipStream_t stream);
 size_t hopagg_packed_w_bytes(int C, int Dn, int H);
 int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream);
-int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream);
+int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream,
+                      const float* Vn = nullptr, float* a_node = nullptr);      // Vn: [8][D] folded vectors of hop 0 -> a_node [N, 8]
 size_t alpha_x4_lds_bytes(int H, int Dn, int e_cap);
 int launch_alpha_x4(const gvqa_graph* g, int H, const AlphaX4Args& a, hipStream_t stream);
 int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream);

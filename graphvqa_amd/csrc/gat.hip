@@ -1539,7 +1539,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         const int NQ = (int)cdiv(Dn, 4);
         {
             StageTimer tp(GVQA_STAGE_PACK, stream);
-            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream);      // (beside the edge logits / graph terms on the side stream)
+            // (+ hop 0's node logits, out of the slab it moves the rows through)
+            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream, Vn_all, P(L.a_node));
             if (rc) return rc;
         }
         if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
@@ -1549,7 +1550,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             if (aggseq && i > 0) break;               // (one launch: hops 1 .. K - 1 compute their coefficients inside it)
             // hops 1 .. K - 1 of the per-hop form: the previous launch left their node logits, the hop kernel computes its coefficients
             // in its own prologue -- no coefficient kernel
-            const bool in_prologue = i > 0 && !aggseq;
+            const bool in_prologue = !aggseq;         // (hop 0's node logits came with the layout pass)
             if (!in_prologue) {
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
                 AlphaX4Args ax;
@@ -1560,7 +1561,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 ax.graph_term = gterm; ax.t_ld = Tld;
                 ax.alpha_csr = P(L.alpha_csr); ax.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
                 ax.Dn = Dn; ax.NQ = NQ; ax.C = C; ax.slope = d->negative_slope;
-                ax.a_node_in = nullptr;
+                ax.a_node_in = P(L.a_node);           // (the one-launch form: hop 0's coefficients from this kernel, its node logits from the layout pass)
                 rc = launch_alpha_x4(g, H, ax, stream);
                 if (rc) return rc;
             }

@@ -108,10 +108,19 @@ int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void
 // Row-major fp32 rows -> the chunk-major layout X4[group][k / 4][128 slots][4] (slots past the group's rows: zeros), and the largest
 // magnitude of every graph's rows -> gmax[B].  One block per row group; the rows go through LDS 128 columns at a time so that
 // both sides move whole lines (reads: 512 B per row; writes: a chunk = 2 KiB contiguous).
+// Vn != NULL: the node logits of hop 0, a_node[node, j] = sum_k x[node, k] Vn[j, k], j < 8 (folded a_l | a_r vectors, gat_skip.py:134-135),
+// leave with the rows (out of the slab in LDS: thread (row, quarter) takes every fourth chunk) -- hop 0 needs no pass of its own over x.
 __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ group_ptr, const int32_t* __restrict__ node_graph, int D, int NQ,
-                                                    const float* __restrict__ X, int64_t ld, float* __restrict__ X4, float* __restrict__ gmax) {
+                                                    const float* __restrict__ X, int64_t ld, float* __restrict__ X4, float* __restrict__ gmax,
+                                                    const float* __restrict__ Vn, float* __restrict__ a_node) {
     __shared__ float4 slab[HA_ROWS][33];         // 32 chunks (+1: the column walk of the write phase is conflict-free)
     __shared__ unsigned gm_s[HA_ROWS];
+    __shared__ float4 vn_s[8][32];               // Vn columns of the current 128-column block
+    float lg[4][8];                              // thread (r4 = tid & 31, pj = tid >> 5): rows r4 + 32 k, chunks pj and pj + 16 of every block
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lg[k][j] = 0.f;
     const int tid = threadIdx.x, t = blockIdx.x;
     const int ns = group_ptr[t], cnt = group_ptr[t + 1] - ns;
     const int gf = node_graph[ns];
@@ -134,7 +143,30 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
             slab[r][p] = v;
             rowmax[u] = fmaxf(rowmax[u], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
+        if (Vn && tid < 256) {
+            const int j = tid >> 5, p = tid & 31, k = (q0 + p) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k + 4 <= D) v = *reinterpret_cast<const float4*>(Vn + (int64_t)j * D + k);
+            else if (k < D) { v.x = Vn[(int64_t)j * D + k]; if (k + 1 < D) v.y = Vn[(int64_t)j * D + k + 1]; if (k + 2 < D) v.z = Vn[(int64_t)j * D + k + 2]; }
+            vn_s[j][p] = v;
+        }
         __syncthreads();
+        if (Vn) {                                // (four rows per Vn read: the phase is LDS-bound)
+            const int r4 = tid & 31, pj = tid >> 5;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int p = pj + 16 * pp;
+                float4 x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = slab[r4 + 32 * k][p];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 w = vn_s[j][p];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lg[k][j] += x[k].x * w.x + x[k].y * w.y + x[k].z * w.z + x[k].w * w.w;
+                }
+            }
+        }
         // write: thread (p, r): chunk q0 + p, slot r -- 128 consecutive threads cover a chunk's 2 KiB
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -151,13 +183,32 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
     __syncthreads();
     const int ngl = node_graph[ns + cnt - 1] - gf + 1;
     if (tid < ngl) gmax[gf + tid] = __uint_as_float(gm_s[tid]);
+    if (Vn) {                                    // the sixteen chunk classes of a row meet through the slab's first 64 KiB
+        float* part = reinterpret_cast<float*>(&slab[0][0]);           // [16][128][8]
+        const int r4 = tid & 31, pj = tid >> 5;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float* dst = part + (pj * HA_ROWS + r4 + 32 * k) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(lg[k][0], lg[k][1], lg[k][2], lg[k][3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(lg[k][4], lg[k][5], lg[k][6], lg[k][7]);
+        }
+        __syncthreads();
+        for (int it = tid; it < cnt * 8; it += 512) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sacc += part[c * HA_ROWS * 8 + it];
+            a_node[(int64_t)ns * 8 + it] = sacc;
+        }
+    }
 }
 
-int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream) {
+int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream, const float* Vn, float* a_node) {
     GVQA_REQUIRE(g && g->num_row_groups > 0 && X && X4 && gmax && D > 0 && ld >= D && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
                  GVQA_E_INVALID, "rows_to_x4: bad argument");
+    GVQA_REQUIRE(!Vn == !a_node, GVQA_E_INVALID, "rows_to_x4: node logits need both the folded vectors and their destination");
     hipLaunchKernelGGL(k_rows_to_x4, dim3((unsigned)g->num_row_groups), dim3(512), 0, stream, g->row_group_ptr, g->node_graph, D, (int)cdiv(D, 4), X, ld,
-                       X4, gmax);
+                       X4, gmax, Vn, a_node);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

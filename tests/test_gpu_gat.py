@@ -756,7 +756,7 @@ def test_aggregate_first_hop_parity_sweep(dev, stratum):
             ok, errs, sz = run(c, dev)
             pr = _lib.prof_collect(); _lib.prof_enable(False)
             if c["C"] >= 32:
-                assert pr["mp"][1] == 0 and pr["proj"][1] == 2 * K and pr["node_logit"][1] == 0 and pr["alpha"][1] == 2, (c, pr)      # 2 forwards: K hop kernels each + hop 0's coefficient kernel, nothing unfused
+                assert pr["mp"][1] == 0 and pr["proj"][1] == 2 * K and pr["node_logit"][1] == 0 and pr["alpha"][1] == 0, (c, pr)      # 2 forwards: K hop kernels each, no coefficient kernel, nothing unfused
                 ran += 1
             if not ok:
                 bad.append((c, errs, sz))
@@ -789,8 +789,8 @@ def test_aggregate_first_one_launch_parity_sweep(dev, stratum):
             pr = _lib.prof_collect(); _lib.prof_enable(False)
             if c["C"] >= 32:
                 # two forwards: the plain one = 1 hop launch + hop 0's coefficient launch; the other the same, or K hop launches when it
-                # returns more (hops 1 .. K - 1 of the per-hop form compute their coefficients in their own prologues)
-                assert pr["mp"][1] == 0 and pr["node_logit"][1] == 0 and pr["proj"][1] == (K + 1 if extra else 2) and pr["alpha"][1] == 2, (c, pr)
+                # returns more (the per-hop form computes its coefficients in the hop kernels' own prologues: no coefficient launch)
+                assert pr["mp"][1] == 0 and pr["node_logit"][1] == 0 and pr["proj"][1] == (K + 1 if extra else 2) and pr["alpha"][1] == (1 if extra else 2), (c, pr)
                 ran += 1
             if not ok:
                 bad.append((c, errs, sz))
