@@ -886,6 +886,16 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }
         const float* gt_ = gterm_h ? gterm_h : binv_h;        // (no instruction terms: a mapped address -- row 0 of the column scales --, the mask is 0)
         const int64_t gt_ld = gterm_h ? a.t_ld : 0;
+        // (LGT: the next hop's node logits are accumulated as the values are finished -- their LDS reads and FMAs run under the
+        //  latency of the batches' loads instead of as a pass of their own: even / odd columns in separate packed chains)
+        [[maybe_unused]] ha_f32x2 an2[LGT ? RT : 1][8];
+        if constexpr (LGT) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) an2[i][jj] = ha_f32x2{0.f, 0.f};
+        }
+        [[maybe_unused]] const float* vn_l = reinterpret_cast<const float*>(smem + HA_VN0);
         float4 skA[2], tgA[2], skB[2], tgB[2];
         auto load_batch = [&](int b, float4 (&sk)[2], float4 (&tg)[2]) {
             const int i = b / (2 * TN), j = (b >> 1) % TN, qp = b & 1;
@@ -934,12 +944,25 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                     if (out_h && on_[i]) *reinterpret_cast<float4*>(out_h + node * a.out_ld + c0) = v;
                 }
                 vmax_[i] = fmaxf(vmax_[i], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-                if constexpr (SEQ || LGT) {           // the finished values stay in the accumulator registers: stores and node logits below
+                if constexpr (SEQ) {                  // the finished values stay in the accumulator registers: stores and node logits below
                     acc[i][j][4 * q] = v.x; acc[i][j][4 * q + 1] = v.y; acc[i][j][4 * q + 2] = v.z; acc[i][j][4 * q + 3] = v.w;
+                }
+                if constexpr (LGT) {
+                    const ha_f32x2 a01{v.x, v.y}, a23{v.z, v.w};
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const float4 vn = *reinterpret_cast<const float4*>(vn_l + jj * C + c0);
+                        an2[i][jj] = a01 * ha_f32x2{vn.x, vn.y} + an2[i][jj];
+                        an2[i][jj] = a23 * ha_f32x2{vn.z, vn.w} + an2[i][jj];
+                    }
                 }
             }
         };
         load_batch(0, skA, tgA);
+        if constexpr (LGT) {                          // Vn of the next hop is in place everywhere (the first batch's loads travel meanwhile)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
 #pragma unroll
         for (int b = 0; b < NB; b += 2) {
             if (b + 1 < NB) load_batch(b + 1, skB, tgB);
@@ -952,14 +975,29 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #pragma unroll
         for (int i = 0; i < RT; ++i)
             if ((SEQ ? more : a.gmax_out != nullptr) && on_[i]) atomicMax(&gm_l[g_[i] - gf], __float_as_uint(vmax_[i]));
+        if constexpr (LGT) {
+            // the two column halves of a row (lanes m and m + 32) meet; lane m leaves the wave's partial at part[wc][r][0..8) (A' ring, idle)
+            float* part = reinterpret_cast<float*>(smem + HA_A0);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                float an[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    an[jj] = an2[i][jj][0] + an2[i][jj][1];
+                    an[jj] += __shfl_xor(an[jj], 32, 64);
+                }
+                if (hh == 0) {
+                    float* dst = part + ((wc * HA_ROWS) + (wr * RT + i) * 32 + m) * 8;
+                    *reinterpret_cast<float4*>(dst) = make_float4(an[0], an[1], an[2], an[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(an[4], an[5], an[6], an[7]);
+                }
+            }
+        }
     }
     if constexpr (!SEQ) {
         if constexpr (LGT) {
-            // (this wave's Vn DMAs are older than the epilogue loads it has consumed -- loads return in order --: complete; then everybody's)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the partial logits are in LDS; the row stores need not be complete)
             __builtin_amdgcn_s_barrier();
-            node_logits_to_part();
-            __syncthreads();
             const float* part = reinterpret_cast<const float*>(smem + HA_A0);
             float2 sacc = *reinterpret_cast<const float2*>(part + tid * 2);
 #pragma unroll

@@ -893,7 +893,7 @@ class gat_seq(torch.nn.Module):
         self.last_stats = None
         # Per-module overrides of the library's process-wide options (None = follow gvqa_set_option / the environment), carried in the
         # dims struct of every call -- two models with different settings can live in one process:
-        #   projection: "split2h" | "split3" | "f32"      hop_fusion: 0 | 1 | 2 | 3 (include/gvqa.h, GVQA_OPT_HOP_FUSION)
+        #   projection: "split2h" | "split3" | "f32"      hop_fusion: 0 .. 5 (include/gvqa.h, GVQA_OPT_HOP_FUSION)
         self.projection = None
         self.hop_fusion = None
 

@@ -9,12 +9,12 @@ python bench.py > $O/bench_cfg3_n1.json 2> $O/bench.err
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_cfg3_kernel_stats.csv 2>/dev/null
 python scripts/bench_configs.py 2>/dev/null | tail -1 > $O/configs.json
 # the three chained / fused hop forms on this box, config 3 and config 2 (hop kernel us, forward wall ms, stage split)
-for c in 3 2; do for f in 1 2 4 0; do CONFIG=$c FUSION=$f python scripts/bench_hopagg.py 2>/dev/null | tail -1; done; done > $O/hop_forms_ab.jsonl
+for c in 3 2; do for f in 3 1 2 4 5 0; do CONFIG=$c FUSION=$f python scripts/bench_hopagg.py 2>/dev/null | tail -1; done; done > $O/hop_forms_ab.jsonl
 ( export GVQA_LIB=graphvqa_amd/lib/probes/libgvqa_hip.so; for d in 0 1 2 4 32; do GVQA_HOPAGG_DEBUG=$d python scripts/bench_hopagg.py 2>/dev/null | tail -1; done ) > $O/hopagg_loop_parts.jsonl
 for f in 1 2; do for n in 2 4 8; do GVQA_HOP_FUSION=$f python bench.py --emulate-world $n --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1; done; done > $O/emulated_shards.jsonl
 GVQA_BENCH_FORCE_DIST=1 python bench.py --emulate-world 8 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | grep emulated_world > $O/emulated_shard8_rccl_1rank.json
 GVQA_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | grep "\"metric\"" > $O/bench_cfg3_rccl_1rank.json
-for f in 1 2 4; do MODES=$f ROUNDS=2 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel; done > $O/hop_kernels_ab.jsonl
+for f in 4 1 2; do MODES=$f ROUNDS=2 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel; done > $O/hop_kernels_ab.jsonl
 for z in "" 1; do ZERO=$z MODES=1,2 ROUNDS=1 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel | sed -e "s/^{/{\"zero_operands\": \"$z\", /"; done > $O/dvfs_zero_operands.jsonl
 for h in 1 4; do HOP=$h python scripts/probe_hop2.py 2>/dev/null | head -2; done > $O/hop2_phase_stamps.jsonl
 python scripts/probe_hop2_loop.py 2>/dev/null | grep workgroups_per_cu > $O/hop2_loop_parts.jsonl
@@ -25,7 +25,7 @@ cp $(find $O/tprof -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.cs
 # SQ counters of the hop kernels (separate --pmc passes, kernel trace only)
 for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  ( cd /tmp && MODES=1,2,0 ROUNDS=1 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/scripts/bench_hop2.py > /dev/null 2>&1 )
+  ( cd /tmp && MODES=4,1,2,0 ROUNDS=1 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/scripts/bench_hop2.py > /dev/null 2>&1 )
 done
 python - > $O/pmc_hop_kernels.txt <<PY
 import csv, glob, collections
