@@ -186,6 +186,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GVQA_BENCH_ONE_DEVICE"):          # (test hook: N ranks on ONE GPU -- with GVQA_BENCH_BACKEND=gloo -- to exercise the N > 1 control flow on a one-GPU box)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -197,7 +199,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GVQA_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; gloo only for the one-GPU test hook above
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     rccl_ranks_seen = None
     if dist is not None:                 # audit trail for the scaling record: how many ranks RCCL itself connected
         ones = torch.ones(1, dtype=torch.float32, device=dev)

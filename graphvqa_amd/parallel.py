@@ -133,6 +133,11 @@ def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False, 
     mx = max(counts)
     if rows.shape[0] < mx:
         rows = torch.cat([rows, rows.new_zeros((mx - rows.shape[0], rows.shape[1]))])
+    if rows.is_cuda and dist.get_backend() == "gloo":      # (gloo has no device all-gather: test set-ups with N ranks on one GPU go through the host)
+        host = torch.empty((world * mx, rows.shape[1]), dtype=rows.dtype)
+        dist.all_gather_into_tensor(host, rows.contiguous().cpu())
+        res = GatheredRows(host.to(rows.device), None, counts, mx)
+        return res if async_op else res.wait()
     out = torch.empty((world * mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
     work = dist.all_gather_into_tensor(out, rows.contiguous(), async_op=async_op)
     res = GatheredRows(out, work if async_op else None, counts, mx)
