@@ -45,4 +45,18 @@ for hop in range(KK):
         d = st[:, hop + 1, 0] - st[:, hop, 0]
         row["hop total"] = [round(float(d.mean()), 2), round(float(d.max()), 2)]
     out[f"hop{hop} [mean, max] us"] = row
+# where the spread is: per workgroup, the main loop averaged over its hops (a persistent property of the CU / XCD it ran on?) against
+# the hop-to-hop variation inside a workgroup; by XCD (workgroup w of the launch order runs on XCD w % 8) and by dispatch round
+ml = st[:, :, 2] - st[:, :, 1]                       # [G, K] main-loop us
+per_wg = ml.mean(axis=1)
+q = lambda a, p: round(float(np.percentile(a, p)), 1)
+out["main_loop_per_workgroup_us (mean over hops) [min, p10, median, p90, max]"] = [q(per_wg, 0), q(per_wg, 10), q(per_wg, 50), q(per_wg, 90), q(per_wg, 100)]
+out["main_loop_within_workgroup_std_us (median over workgroups)"] = round(float(np.median(ml.std(axis=1))), 2)
+out["main_loop_by_xcd_us"] = [round(float(per_wg[x::8].mean()), 1) for x in range(8)]
+cus = 256
+if G > cus:
+    out["main_loop_by_round_us"] = [round(float(per_wg[:cus].mean()), 1), round(float(per_wg[cus:].mean()), 1)]
+    out["round2_start_spread_us"] = round(float(st[cus:, 0, 0].max() - st[cus:, 0, 0].min()), 1)
+wg_total = st[:, KK - 1, 2] - st[:, 0, 0]
+out["workgroup_total_us [min, median, max]"] = [q(wg_total, 0), q(wg_total, 50), q(wg_total, 100)]
 print(json.dumps(out))
