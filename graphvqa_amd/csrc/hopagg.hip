@@ -44,7 +44,8 @@ typedef _Float16 ha_f16x4 __attribute__((ext_vector_type(4)));
 typedef float ha_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HA_ROWS = 128;          // rows of a row group / tile
-constexpr int HA_DMAX = 8;            // in-edges of a node kept in registers
+constexpr int HA_DMAX = 8;            // in-edges of a node kept in registers, fetched by the node's quad (one row per lane and batch of four)
+constexpr int HA_NOV = 8;             // ... and the next ones ("overflow": source slot + coefficient in registers too, one row read per lane and edge)
 constexpr int HA_ECAP = 1024;         // in-edges of a row group held in LDS (beyond the registers' 8 per node)
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -459,7 +460,16 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #endif
 #define GVQA_HA_QFMA(acc_, w_, x_, E_) do { GVQA_HA_QF1((acc_).x, w_, (x_).x, E_); GVQA_HA_QF1((acc_).y, w_, (x_).y, E_); \
                                             GVQA_HA_QF1((acc_).z, w_, (x_).z, E_); GVQA_HA_QF1((acc_).w, w_, (x_).w, E_); } while (0)
-    int ovtrips = 0;                                  // wave-uniform trips through the LDS slice
+    int ovtrips = 0;                                  // wave-uniform trips through the LDS slice (edges past the HA_DMAX + HA_NOV a node keeps in registers)
+    // Edges 9 .. 16 of a node ("overflow").  A K step walked them through the slice in LDS: per edge two DEPENDENT reads (source slot,
+    // then the row) plus the coefficient -- ~140 cycles per edge and step for the whole wave (the trip count is the wave's largest
+    // in-degree), 128 steps per tile.  At config 3 (in-degree 1 + Poisson(3), largest 15) three of four row groups have such a node:
+    // phase stamps put 9 us per trip and tile on the main loop, 165 (no overflow) .. 229 us (7 trips) -- and the slowest workgroup is
+    // what a launch waits for.  Now source offsets and coefficients of these edges sit in registers as well: one independent row
+    // read + 4 FMAs per edge and step.
+    int ovn = 0;                                      // wave-uniform: how many of them this wave uses
+    float al_o[HA_NOV];
+    unsigned so2[HA_NOV / 2];                         // their rows' byte offsets in a chunk (slot x 16), two per register
     float pscale = 1.f;
     int pg = 0;                                       // graph of this lane's node
     // the rows' power-of-two scale from their graph's largest input magnitude; per-row arrays of the epilogue
@@ -534,8 +544,16 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         const float4 xr1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));
         GVQA_HA_QFMA(v0, al[0], xr0, 0); GVQA_HA_QFMA(v0, al[1], xr0, 1); GVQA_HA_QFMA(v0, al[2], xr0, 2); GVQA_HA_QFMA(v0, al[3], xr0, 3);
         GVQA_HA_QFMA(v1, al[4], xr1, 0); GVQA_HA_QFMA(v1, al[5], xr1, 1); GVQA_HA_QFMA(v1, al[6], xr1, 2); GVQA_HA_QFMA(v1, al[7], xr1, 3);
+        if (ovn > 0) {
+#pragma unroll
+            for (int e = 0; e < HA_NOV; ++e)
+                if (e < ovn) {
+                    const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + ((so2[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+                    v1.x += al_o[e] * x.x; v1.y += al_o[e] * x.y; v1.z += al_o[e] * x.z; v1.w += al_o[e] * x.w;
+                }
+        }
         for (int e = 0; e < ovtrips; ++e) {
-            const int k = HA_DMAX + e;
+            const int k = HA_DMAX + HA_NOV + e;
             const int idx = max(min(plo + k, plo + pdeg - 1), 0);
             const int sr = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);
             const float w = al_l[idx * H + ph];
@@ -583,9 +601,16 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         const int s = (s_);                                                                                                 \
         const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + ((s + 1) & 3) * 2048);                            \
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                        \
+        if (ovn > 0) {                                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < HA_NOV; ++e)                                                              \
+                if (e < ovn) {                                                                                              \
+                    const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + ((so2[e >> 1] >> (16 * (e & 1))) & 0xFFFFu)); \
+                    GVQA_HA_FMA4(v0, al_o[e], x);                                                                           \
+                }                                                                                                           \
+        }                                                                                                                   \
         if (ovtrips > 0) {                                                                                                  \
             for (int e = 0; e < ovtrips; ++e) {                                                                             \
-                const int k = HA_DMAX + e;                                                                                  \
+                const int k = HA_DMAX + HA_NOV + e;                                                                         \
                 const int idx = max(min(plo + k, plo + pdeg - 1), 0);                                                       \
                 const int sr = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);                                                   \
                 const float w = al_l[idx * H + ph];                                                                         \
@@ -708,7 +733,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }
         plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
         pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
-        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);
+        ovn = min(max(ha_wave_max(pdeg) - HA_DMAX, 0), HA_NOV);
+        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX - HA_NOV, 0);
         pg = a.node_graph[ns + min(pi, cnt - 1)];
         if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pg * a.t_ld + a.C + ph];
         set_row_scale(a.gmax_in[pg], true);
@@ -716,7 +742,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     } else if (!SEQ || hop == 0) {
         dma_csr_slice();
         load_lane_items();
-        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX, 0);
+        ovn = min(max(ha_wave_max(pdeg) - HA_DMAX, 0), HA_NOV);
+        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX - HA_NOV, 0);
         pg = a.node_graph[ns + min(pi, cnt - 1)];
         set_row_scale(a.gmax_in[pg], true);
         if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
@@ -745,6 +772,23 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             for (int e = HA_DMAX; e < pdeg; ++e) a.alpha_out[(int64_t)a.csr_eid[e0 + plo + e] * H + ph] = al_w[(plo + e) * H + ph];
         }
     }
+    if (ovn > 0) {                                    // (wave-uniform) the overflow edges' coefficients and row offsets out of the slice in LDS
+#pragma unroll
+        for (int e = 0; e < HA_NOV; ++e) {
+            const int k = HA_DMAX + e;
+            const int idx = max(min(plo + k, ne - 1), 0);
+            const float w = al_l[idx * H + ph];
+            al_o[e] = k < pdeg ? w : 0.f;
+            const unsigned off = (unsigned)min(max(src_l[idx] - ns, 0), HA_ROWS - 1) * 16u;
+            if (e & 1) so2[e >> 1] |= off << 16;
+            else so2[e >> 1] = off;
+        }
+    } else if constexpr (SEQ) {                       // (defined on every path: otherwise they stay live -- and spill -- across the previous hop's epilogue)
+#pragma unroll
+        for (int e = 0; e < HA_NOV; ++e) al_o[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < HA_NOV / 2; ++e) so2[e] = 0u;
+    }
     produce(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -757,6 +801,10 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     GVQA_HA_MFR(0, NM, afh, bh1);                    // the last step's (a hi, b hi)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (the clamped re-loads of the last steps)
     GVQA_HA_STAMP(hop, 2);                            // main loop done
+#ifdef GVQA_PROBES
+    if (SEQ && hs.stamps && tid == 0 && hop + 1 == nhops)      // (the last hop uses stamps 0 .. 3 only: slot 7 = where the workgroup ran)
+        hs.stamps[((int64_t)t * hs.K + hop) * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32) | __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
+#endif
 
 #ifdef GVQA_PROBES
     if (a.dbg & 32) {                                 // (measurement: no epilogue; the accumulators kept live)

@@ -31,7 +31,9 @@ for _ in range(4):
 torch.cuda.synchronize()
 raw = open(path, "rb").read()
 G, KK = struct.unpack("ii", raw[:8])
-st = np.frombuffer(raw[8:], dtype=np.uint64).reshape(G, KK, 8).astype(np.float64) / 100.0      # us
+raw_st = np.frombuffer(raw[8:], dtype=np.uint64).reshape(G, KK, 8)
+hwid = raw_st[:, KK - 1, 7]                            # XCC_ID << 32 | HW_ID of wave 0 (gfx9 HW_ID: cu_id [11:8], sh_id [12], se_id [15:13])
+st = raw_st.astype(np.float64) / 100.0      # us
 names = ["prime+produce0", "main loop", "B1+issue DMAs", "epilogue arith", "wait+B2+stores+logit FMAs", "reduce part", "B4 softmax..", "-> next hop"]
 t0 = st[:, 0, 0].min()
 out = {"groups": G, "K": KK, "span_us": round(float(st.max() - t0), 1), "first_start_spread_us": round(float(st[:, 0, 0].max() - t0), 1)}
@@ -57,6 +59,21 @@ cus = 256
 if G > cus:
     out["main_loop_by_round_us"] = [round(float(per_wg[:cus].mean()), 1), round(float(per_wg[cus:].mean()), 1)]
     out["round2_start_spread_us"] = round(float(st[cus:, 0, 0].max() - st[cus:, 0, 0].min()), 1)
+xcc = (hwid >> np.uint64(32)).astype(np.int64) & 0xF
+hw = (hwid & np.uint64(0xFFFFFFFF)).astype(np.int64)
+cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+where = xcc * 1000 + se * 100 + sh * 10 + cu * 0          # (xcc, se, sh)
+order = np.argsort(-per_wg)
+out["slowest_20 [workgroup, main_loop_us, xcc, se, sh, cu]"] = [[int(i), round(float(per_wg[i]), 1), int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])] for i in order[:20]]
+out["fastest_10 [workgroup, main_loop_us, xcc, se, sh, cu]"] = [[int(i), round(float(per_wg[i]), 1), int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])] for i in order[-10:]]
+by_cu = {}
+for i in range(G):
+    by_cu.setdefault((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])), []).append(float(per_wg[i]))
+out["distinct_cus_seen"] = len(by_cu)
+out["main_loop_by_cu_id_us (mean over xcc / se / sh)"] = {str(c): round(float(np.mean([np.mean(v) for k, v in by_cu.items() if k[3] == c])), 1) for c in sorted({k[3] for k in by_cu})}
+out["main_loop_by_se_us"] = {str(c): round(float(np.mean([np.mean(v) for k, v in by_cu.items() if k[1] == c])), 1) for c in sorted({k[1] for k in by_cu})}
+hist, edges = np.histogram(per_wg, bins=12)
+out["main_loop_histogram"] = [[round(float(edges[i]), 0), int(hist[i])] for i in range(len(hist))]
 wg_total = st[:, KK - 1, 2] - st[:, 0, 0]
 out["workgroup_total_us [min, median, max]"] = [q(wg_total, 0), q(wg_total, 50), q(wg_total, 100)]
 print(json.dumps(out))
