@@ -384,7 +384,7 @@ def main():
             # 2 E H C flops (0.4 %) are not counted.
             hk0 = m.hop_kernel(g0)
             if hk0 == "aggregate_first_seq":
-                proj_n *= K                                              # one launch = K hops: per-hop figures below
+                proj_n *= K                                              # one launch = K hops: per-hop figures below (traffic likewise)
             avg_s = proj_ms / max(proj_n, 1) * 1e-3
             ach = flops32 / avg_s / 1e12                                 # the folded projection's 2 N Dn H C flops per launch
             issued = products * flops32 / avg_s / 1e12                   # what the matrix cores execute: 3 (6) piece products of them
@@ -530,8 +530,9 @@ def main():
             if not a.no_pmc:
                 pm = live_pmc_traffic()
                 if "fused" in pm and fused:
-                    res["roofline"]["traffic"] = pm["fused"]["bytes"]
-                    res["roofline"]["traffic_detail"] = pm["fused"]
+                    per_hop = K if m.hop_kernel(g0) == "aggregate_first_seq" else 1       # (one launch = K hops: bytes per hop, like avg_launch_us)
+                    res["roofline"]["traffic"] = pm["fused"]["bytes"] / per_hop
+                    res["roofline"]["traffic_detail"] = dict(pm["fused"], hops_per_launch=per_hop)
                 if "mp" in pm:
                     tgt = res.get("mp_kernel_roofline") if fused else res["roofline"]
                     if tgt is not None:

@@ -379,7 +379,7 @@ static_assert(HA_LDS_SEQ <= 160 * 1024 && HA_ST0 + HA_ECAP * 16 <= HA_A0, "hopag
 // producer item (node, head) -- under the latency of the priming DMAs: no coefficient kernel, no alpha_csr round trip.
 template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false, bool ALP = false>
 __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) {
-    static_assert(!(SEQ && (LGT || ALP)), "hopagg: the one-launch form computes its logits and coefficients itself");
+    static_assert(!(SEQ && (LGT || ALP)), "hopagg: the one-launch form computes its logits and coefficients itself (hop 0's in its first prologue, as ALP does)");
     static_assert(WR * WC == 8 && WR * RT == 4 && WC * TN <= 16, "hopagg: eight waves over 128 rows and at most 16 column tiles");
     constexpr int H = 4;
     constexpr int NM = RT * TN;                       // MFMAs of one piece product per wave
@@ -716,7 +716,11 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         for (int q = 0; q < 3; ++q) issue_x(q);
     }
     [[maybe_unused]] float tlog0 = 0.f;
-    if constexpr (ALP) {
+    // (the one-launch form computes hop 0's coefficients the same way, in the prologue of its first hop: its operands ride in `hs`)
+    [[maybe_unused]] const float* ae0_ = SEQ ? hs.a_edge : a.a_edge;
+    [[maybe_unused]] const int32_t* eid0_ = SEQ ? hs.csr_eid : a.csr_eid;
+    [[maybe_unused]] const int64_t aes0_ = SEQ ? hs.a_edge_stride : a.a_edge_stride;
+    if ((ALP && !SEQ) || (SEQ && hop == 0)) {
         // everything the coefficients need starts its trip from HBM now: the slice's sources (LDS), this group's node logits (LDS:
         // weight-ring stage 2, idle until step 0), the edge halves of the logits gathered through the COO edge ids (LDS, head-major)
         const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -726,10 +730,12 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         for (int u = wave * 256; u < nan; u += 2048)
             lds_dma16_b(a.a_node_in + (int64_t)ns * 8 + min(u + lane * 4, nan - 4), __builtin_amdgcn_readfirstlane(lds_base + HA_VN0 + (unsigned)u * 4u));
         for (int u = wbase; u < ne; u += 512) {
-            const float* src = a.a_edge + (int64_t)a.csr_eid[e0 + min(u + lane, ne - 1)] * a.a_edge_stride;
+            const int eid = eid0_[e0 + min(u + lane, ne - 1)];
+            const float* src = ae0_ + (int64_t)eid * aes0_;
 #pragma unroll
             for (int h = 0; h < H; ++h)
                 lds_dma4_b(src + h, __builtin_amdgcn_readfirstlane(lds_base + HA_ST0 + (unsigned)(h * HA_ECAP + u) * 4u));
+            if constexpr (SEQ) reinterpret_cast<int*>(smem + HA_EID0)[min(u + lane, ne - 1)] = eid;     // (the later hops gather through the ids in LDS)
         }
         plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
         pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
@@ -739,7 +745,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pg * a.t_ld + a.C + ph];
         set_row_scale(a.gmax_in[pg], true);
         if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
-    } else if (!SEQ || hop == 0) {
+        if constexpr (SEQ) { if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM1)[tid] = 0u; }
+    } else if (!SEQ && !ALP) {
         dma_csr_slice();
         load_lane_items();
         ovn = min(max(ha_wave_max(pdeg) - HA_DMAX, 0), HA_NOV);
@@ -758,13 +765,13 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // rings' first stages, CSR slice and per-row arrays are in place
-    if constexpr (ALP) {
-        coeffs_from_lds(reinterpret_cast<const float*>(smem + HA_VN0), reinterpret_cast<float*>(smem + HA_ST0) + ph * HA_ECAP + plo, tlog0, a.slope);
+    if ((ALP && !SEQ) || (SEQ && hop == 0)) {
+        coeffs_from_lds(reinterpret_cast<const float*>(smem + HA_VN0), reinterpret_cast<float*>(smem + HA_ST0) + ph * HA_ECAP + plo, tlog0, SEQ ? hs.slope : a.slope);
         const int i0 = max(min(plo + ph, ne - 1), 0), i1 = max(min(plo + 4 + ph, ne - 1), 0);
         const unsigned s0 = ne > 0 ? (unsigned)min(max(src_l[i0] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         const unsigned s1 = ne > 0 ? (unsigned)min(max(src_l[i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         sep = s0 | (s1 << 16);
-        if (a.alpha_out) {                            // (block-uniform) the attention weights are asked for: COO order, [E, H]
+        if (!SEQ && a.alpha_out) {                    // (block-uniform) the attention weights are asked for: COO order, [E, H]
             const float* al_w = reinterpret_cast<const float*>(smem + HA_AL0);
 #pragma unroll
             for (int e = 0; e < HA_DMAX; ++e)
@@ -1157,7 +1164,7 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
 
 // The K hops as one launch (see k_hopagg4<..., SEQ>): one workgroup per row group walks all hops of its rows.
 int launch_hopagg_seq(int H, const HopAggArgs& a, const HopAggSeq& hs, int num_groups, hipStream_t stream) {
-    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.alpha_csr && a.node_graph && a.gmax_in && a.out && hs.csr_eid && hs.a_edge &&
+    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.a_node_in && a.node_graph && a.gmax_in && a.out && hs.csr_eid && hs.a_edge &&
                  hs.X4a && hs.X4b && hs.Wk && hs.epc && hs.Vn && hs.K >= 1 && hs.K <= HA_MAXHOPS, GVQA_E_INVALID, "hopagg_seq: null operand / hop count");
     GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1 && a.NQ * 4 == a.C, GVQA_E_UNSUPPORTED, "hopagg_seq: needs C == Dn, C %% 4 == 0 and C <= 512");
     if (num_groups == 0) return GVQA_OK;

@@ -652,6 +652,42 @@ def test_grouped_one_launch_csr_build_equals_the_general_build(dev):
     assert hb.coo_grouped and gbig.c.num_row_groups == 0 and gbig.c.max_graph_nodes >= 150
 
 
+def test_default_rule_takes_the_one_launch_aggregate_first_form_at_config3(dev):
+    """Under DEFAULT options the benchmark's shape (2048 graphs x 32 nodes, d = 512, H = 4, K = 5: 512 row groups = two whole rounds of
+    256 CUs) runs as: layout pass (+ hop 0's node logits), then ONE launch for the five hops -- no coefficient kernel, no
+    message-passing launch; a forward that returns the attention weights takes one launch per hop, coefficients in the hop kernels'
+    prologues, and gives the same rows; alpha sums to one per destination and head."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch
+    d, H, K = 512, 4, 5
+    gb = synth.config3_batch()
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(d, d, d, d, K, H, seed=777)
+    x, ea, ins = synth.normal((N, d), 1), synth.normal((E, d), 2), synth.normal((K, B, d), 3)
+    assert _lib.load().gvqa_get_option(_lib.OPT_HOP_FUSION) == 3
+    m = _load_module(gat_seq(d, d, d, d, K, dropout=0.1, gat_heads=H), p, dev)
+    args = [t(a, device=dev) for a in (x, gb.edge_index, ea, ins, gb.batch)]
+    g = SceneGraphBatch(args[1], args[4], N, B)
+    assert m.hop_kernel(g) == "aggregate_first_seq"
+    first = m(*args)                                   # prepares the weight cache
+    _lib.prof_enable(True); _lib.prof_collect()
+    try:
+        out = m(*args)
+        prof = _lib.prof_collect()
+        out_a, alpha, _ = m(*args, return_attention_weights=True)
+        prof_a = _lib.prof_collect()
+    finally:
+        _lib.prof_enable(False)
+    assert prof["mp"][1] == 0 and prof["alpha"][1] == 0 and prof["proj"][1] == 1 and prof["pack"][1] == 1 and prof["node_logit"][1] == 0, prof
+    assert prof_a["mp"][1] == 0 and prof_a["alpha"][1] == 0 and prof_a["proj"][1] == K and prof_a["pack"][1] == 1, prof_a
+    assert torch.equal(first, out)
+    assert maxabs(out, out_a) < 2e-5
+    a_last = alpha[-1]
+    sums = torch.zeros(N, H, device=dev).index_add_(0, args[1][1], a_last)
+    assert maxabs(sums, torch.ones_like(sums)) < 1e-5
+
+
 def test_default_rule_takes_the_chained_kernel_on_a_large_sparse_batch(dev):
     """The regime the round-3 defect lived in, under DEFAULT options: 3400 config-2-like graphs (20-40 nodes, E/N = 2: about
     250 edges per row group) at d = 256 / H = 4 / K = 4 give six or more items per workgroup slot, so GVQA_OPT_HOP_FUSION = 3
@@ -788,9 +824,9 @@ def test_aggregate_first_one_launch_parity_sweep(dev, stratum):
             ok, errs, sz = run(c, dev)
             pr = _lib.prof_collect(); _lib.prof_enable(False)
             if c["C"] >= 32:
-                # two forwards: the plain one = 1 hop launch + hop 0's coefficient launch; the other the same, or K hop launches when it
-                # returns more (the per-hop form computes its coefficients in the hop kernels' own prologues: no coefficient launch)
-                assert pr["mp"][1] == 0 and pr["node_logit"][1] == 0 and pr["proj"][1] == (K + 1 if extra else 2) and pr["alpha"][1] == (1 if extra else 2), (c, pr)
+                # two forwards: the plain one = 1 hop launch; the other the same, or K hop launches when it returns more (both forms
+                # compute their coefficients inside the hop kernels: no coefficient launch)
+                assert pr["mp"][1] == 0 and pr["node_logit"][1] == 0 and pr["proj"][1] == (K + 1 if extra else 2) and pr["alpha"][1] == 0, (c, pr)
                 ran += 1
             if not ok:
                 bad.append((c, errs, sz))
@@ -1076,10 +1112,11 @@ def test_fused_hop_falls_back_when_a_graph_exceeds_a_row_group(dev):
     assert maxabs(out, R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=H)) < TOL
 
 
-@pytest.fixture(params=[1, 2])
+@pytest.fixture(params=[1, 2, 3])
 def hop_kernel(request):
     """GVQA_OPT_HOP_FUSION: 1 = the 8-wave fused hop (csrc/split3.hip), 2 = the persistent two-workgroups-per-CU kernel with chained
-    hops (csrc/hop2.hip)."""
+    hops (csrc/hop2.hip), 3 = the default rule (at config 3: the aggregate-first kernel of csrc/hopagg.hip -- one launch for the K
+    hops on plain-output forwards, one launch per hop when the attention weights are returned; sub-batches fall back to 1)."""
     from graphvqa_amd import _lib
     old = _lib.set_option(_lib.OPT_HOP_FUSION, request.param)
     yield request.param
