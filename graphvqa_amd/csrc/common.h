@@ -196,23 +196,9 @@ size_t hop2_lds_edge_capacity(int H, bool chain);
 size_t hop_fused_lds_edge_capacity(int H);
 
 // hopagg.hip: the hop "aggregate first" (heads concatenated along K; H = 4): rows live chunk-major in HBM between hops
-struct AlphaX4Args {
-    const int32_t *group_ptr, *rowptr, *csr_src, *csr_eid, *node_graph;
-    const float* X4;            // [G][NQ][128][4]
-    const float* Vn;            // [2 H][Dn] folded attention vectors of this hop
-    const float* a_edge;        // [E, stride] edge halves of the logits (COO order), this hop's H columns
-    int64_t a_edge_stride;
-    const float* graph_term;    // NULL or [B, t_ld]: columns [C, C + H) = per-graph logit offsets
-    int64_t t_ld;
-    float* alpha_csr;           // [E, H] out, CSR slot order
-    float* alpha_out;           // NULL or [E, H] out, COO order
-    int Dn, NQ, C;
-    float slope;
-    const float* a_node_in;     // NULL or [N, 2 H]: the node logits, left by the previous hop's launch (X4 / Vn are then not read)
-};
 struct HopAggArgs {
     const int32_t *group_ptr, *rowptr, *csr_src, *node_graph;
-    const float* alpha_csr;     // [E, H] CSR slot order
+    const float* alpha_csr;     // (unused since the coefficients are computed in the hop kernel's prologue; kept for layout stability of callers' memset + fill)
     const float* X4in;          // [G][NQ][128][4] input rows (also the skip rows)
     const uint16_t* Wk;         // [NCT][NQ][2][64][8] packed weights
     const float* binv;          // [32 NCT] inverse scales of the output columns
@@ -238,7 +224,7 @@ struct HopAggArgs {
     int dbg;                    // measurement build only (GVQA_HOPAGG_DEBUG): 1 no producer in the loop, 2 no weight DMA, 4 no MFMAs, 8 no fragment reads after step 0, 16 no waits / barriers, 32 no epilogue
 };
 // The K hops of gat_seq as ONE launch of the aggregate-first kernel (k_hopagg4<..., SEQ>): per-hop operands.  The HopAggArgs beside it
-// carry the batch (CSR, row groups), hop 0's coefficients (alpha_csr, from k_gat_alpha_x4), the per-graph maxima of the input rows
+// carry the batch (CSR, row groups), hop 0's node logits (a_node_in, from the layout pass), the per-graph maxima of the input rows
 // (gmax_in), the final rows (out) and the shapes; Wk / binv / epc / graph_term / relu / X4in / X4out of HopAggArgs are not read.
 // (per-hop operands as base + hop x stride: the weight cache and the workspace lay the hops out at constant strides, and a table
 //  indexed by the hop would be copied from the kernel arguments to scratch)
@@ -266,8 +252,6 @@ size_t hopagg_packed_w_bytes(int C, int Dn, int H);
 int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream,
                       const float* Vn = nullptr, float* a_node = nullptr);      // Vn: [8][D] folded vectors of hop 0 -> a_node [N, 8]
-size_t alpha_x4_lds_bytes(int H, int Dn, int e_cap);
-int launch_alpha_x4(const gvqa_graph* g, int H, const AlphaX4Args& a, hipStream_t stream);
 int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream);
 
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);

@@ -1048,8 +1048,7 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (mode != 4 && mode != 5 && mode != 3) return false;
     const int H = d->heads, C = d->out_channels;
     if (!(proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
-          hopagg_supported(H, C, d->node_dim, g->max_row_group_edges) &&
-          alpha_x4_lds_bytes(H, d->node_dim, g->max_row_group_edges) <= 64 * 1024))
+          hopagg_supported(H, C, d->node_dim, g->max_row_group_edges)))
         return false;
     if (mode == 3 && !kAggFirstByDefault) return false;
     if (mode == 3) {
@@ -1551,23 +1550,9 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         for (int i = 0; i < K; ++i) {
             const float* gterm = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr;
             if (aggseq && i > 0) break;               // (one launch: hops 1 .. K - 1 compute their coefficients inside it)
-            // hops 1 .. K - 1 of the per-hop form: the previous launch left their node logits, the hop kernel computes its coefficients
-            // in its own prologue -- no coefficient kernel
-            const bool in_prologue = true;            // (hop 0's node logits came with the layout pass; the one-launch form does the same in its first hop's prologue)
-            if (!in_prologue) {
-                StageTimer t(GVQA_STAGE_ALPHA, stream);
-                AlphaX4Args ax;
-                memset(&ax, 0, sizeof(ax));
-                ax.group_ptr = g->row_group_ptr; ax.rowptr = g->rowptr; ax.csr_src = g->csr_src; ax.csr_eid = g->csr_eid; ax.node_graph = g->node_graph;
-                ax.X4 = X4[i & 1]; ax.Vn = Vn_all + (int64_t)i * 2 * H * Dn;
-                ax.a_edge = P(L.a_edge) + (int64_t)i * H; ax.a_edge_stride = (int64_t)K * H;
-                ax.graph_term = gterm; ax.t_ld = Tld;
-                ax.alpha_csr = P(L.alpha_csr); ax.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
-                ax.Dn = Dn; ax.NQ = NQ; ax.C = C; ax.slope = d->negative_slope;
-                ax.a_node_in = P(L.a_node);           // (the one-launch form: hop 0's coefficients from this kernel, its node logits from the layout pass)
-                rc = launch_alpha_x4(g, H, ax, stream);
-                if (rc) return rc;
-            }
+            // every hop computes its attention coefficients in its own prologue: hop 0's node logits came with the layout pass, hop i's
+            // with hop i - 1's rows (the one-launch form: between two hops, inside the workgroup) -- no coefficient kernel
+            const bool in_prologue = true;
             {
                 StageTimer t(GVQA_STAGE_PROJ, stream);
                 HopAggArgs ha;

@@ -215,99 +215,9 @@ int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, fl
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Attention coefficients of a hop whose input rows are in the chunk-major layout: node logits a_node = x . [V_l | V_r]^T from
-// the group's chunks (one coalesced pass: 4 Dn bytes per row; fp32 FMAs against the folded vectors in LDS), then the two
-// coefficient phases of k_gat_alpha_groups (gat.hip) out of LDS -- gat_skip.py:134-135,180-208.
-
-template <int H>
-__global__ __launch_bounds__(512) void k_gat_alpha_x4(AlphaX4Args a) {
-    constexpr int J = 2 * H;
-    extern __shared__ float ax_s[];                 // Vn [J][NQ * 4] | partial logits [4][128][J] | raw logits [slots][H]
-    const int tid = threadIdx.x, grp = blockIdx.x;
-    const int Kp = a.NQ * 4;
-    float* vn_s = ax_s;
-    float* part = vn_s + J * Kp;
-    float* rs = part + 4 * HA_ROWS * J;
-    const int ns = a.group_ptr[grp], cnt = a.group_ptr[grp + 1] - ns;
-    const int e0 = a.rowptr[ns], ne = a.rowptr[ns + cnt] - e0;
-    float* an_s = part;                             // [128][J] node logits (the first quarter's slots of `part`)
-    if (a.a_node_in) {       // the node logits came with the rows (the previous hop's epilogue): no pass over the chunks
-        for (int it = tid; it < cnt * J; it += 512) an_s[it] = a.a_node_in[(int64_t)ns * J + it];
-    } else {
-    for (int idx = tid; idx < J * Kp; idx += 512) {
-        const int j = idx / Kp, k = idx - j * Kp;
-        vn_s[idx] = k < a.Dn ? a.Vn[(int64_t)j * a.Dn + k] : 0.f;
-    }
-    __syncthreads();
-    {
-        const int r = tid & 127, p = tid >> 7;      // row slot, quarter of the chunks (a wave walks one chunk at a time: the Vn reads broadcast)
-        float acc[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) acc[j] = 0.f;
-        const float4* xp = reinterpret_cast<const float4*>(a.X4) + (int64_t)grp * a.NQ * HA_ROWS + r;
-#pragma unroll 4
-        for (int q = p; q < a.NQ; q += 4) {
-            const float4 x = xp[(int64_t)q * HA_ROWS];
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(vn_s + j * Kp + q * 4);
-                acc[j] += x.x * v.x + x.y * v.y + x.z * v.z + x.w * v.w;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < J; ++j) part[(p * HA_ROWS + r) * J + j] = acc[j];
-    }
-    __syncthreads();
-    for (int it = tid; it < HA_ROWS * J; it += 512)
-        an_s[it] = (part[it] + part[HA_ROWS * J + it]) + (part[2 * HA_ROWS * J + it] + part[3 * HA_ROWS * J + it]);
-    }
-    __syncthreads();
-    for (int s = tid; s < ne; s += 512) {
-        const int src = a.csr_src[e0 + s] - ns, eid = a.csr_eid[e0 + s];
-        const float* ae = a.a_edge + (int64_t)eid * a.a_edge_stride;
-#pragma unroll
-        for (int h = 0; h < H; ++h) rs[s * H + h] = an_s[src * J + h] + ae[h];
-    }
-    __syncthreads();
-    for (int it = tid; it < cnt * H; it += 512) {
-        const int i = it / H, h = it - i * H, node = ns + i;
-        const int lo = a.rowptr[node] - e0, hi = a.rowptr[node + 1] - e0;
-        float ar = an_s[i * J + H + h];
-        if (a.graph_term) ar += a.graph_term[(int64_t)a.node_graph[node] * a.t_ld + a.C + h];
-        float m = -INFINITY;
-        for (int s = lo; s < hi; ++s) {
-            float v = rs[s * H + h] + ar;
-            v = v > 0.f ? v : v * a.slope;
-            rs[s * H + h] = v;
-            m = fmaxf(m, v);
-        }
-        float sum = 0.f;
-        for (int s = lo; s < hi; ++s) {
-            const float ex = expf(rs[s * H + h] - m);
-            rs[s * H + h] = ex;
-            sum += ex;
-        }
-        const float den = sum + 1e-16f;
-        for (int s = lo; s < hi; ++s) {
-            const float al = rs[s * H + h] / den;
-            if (a.alpha_out) a.alpha_out[(int64_t)a.csr_eid[e0 + s] * H + h] = al;
-            a.alpha_csr[(int64_t)(e0 + s) * H + h] = al;
-        }
-    }
-}
-
-size_t alpha_x4_lds_bytes(int H, int Dn, int e_cap) {
-    return ((size_t)2 * H * cdiv(Dn, 4) * 4 + (size_t)4 * HA_ROWS * 2 * H + (size_t)e_cap * H) * sizeof(float);
-}
-
-int launch_alpha_x4(const gvqa_graph* g, int H, const AlphaX4Args& a, hipStream_t stream) {
-    GVQA_REQUIRE(g && g->num_row_groups > 0 && H == 4, GVQA_E_UNSUPPORTED, "alpha_x4: H = 4 and a row-group plan");
-    const size_t lds = alpha_x4_lds_bytes(H, a.Dn, g->max_row_group_edges);
-    GVQA_REQUIRE(lds <= 64 * 1024, GVQA_E_UNSUPPORTED, "alpha_x4: row group too large");
-    hipLaunchKernelGGL((k_gat_alpha_x4<4>), dim3((unsigned)g->num_row_groups), dim3(512), lds, stream, a);
-    GVQA_LAUNCH_CHECK();
-    return GVQA_OK;
-}
+// (Round 4, first half: a stand-alone coefficient kernel for chunk-major rows, k_gat_alpha_x4, stood here -- fp32 node logits from the
+//  group's chunks + the two softmax phases, 38 us per hop at config 3.  Its work moved into the hop kernel: node logits leave with the
+//  rows (LGT / the layout pass), the softmax runs in the hop kernel's prologue (ALP) or between two hops of the one launch (SEQ).)
 
 // ------------------------------------------------------------------------------------------------------------------------------
 
@@ -369,16 +279,17 @@ static_assert(HA_LDS_SEQ <= 160 * 1024 && HA_ST0 + HA_ECAP * 16 <= HA_A0, "hopag
 // back by the next hop), per-graph maxima and attention coefficients are group-local.  Between two hops the workgroup runs the
 // coefficient phase itself (gat_skip.py:134-135,180-208): node logits a_node = h . [V_l | V_r]^T of the rows it has just finished
 // (out of the accumulator registers, against Vn in LDS), then leaky-relu + segment softmax per (node, head) -- the lane that owns
-// the producer item (node, head) of the main loop computes exactly the coefficients it will use.  Hop 0's coefficients come from
-// the stand-alone kernel (k_gat_alpha_x4), as in the per-hop form.
+// the producer item (node, head) of the main loop computes exactly the coefficients it will use.  Hop 0's coefficients are computed in
+// the first hop's prologue from the node logits the layout pass left (as ALP does in the per-hop form).
 // LGT (per-hop launches): the node logits of the NEXT hop, a_node = h . [V_l | V_r]^T of the rows this launch produces, leave with them
-// (out of the accumulator registers, as in the one-launch form) -- the next hop's coefficient kernel then skips its pass over the
-// rows (134 MB at config 3: 38 -> 1x us).
+// (accumulated as the finished values leave the epilogue: 8 packed FMAs per float4 against the next hop's Vn in LDS) -- the next launch's
+// prologue (ALP) turns them into coefficients; nothing passes over the rows (134 MB at config 3) for the logits.
 // ALP (per-hop launches): the hop's attention coefficients are computed in this launch's PROLOGUE -- node logits left by the previous
 // launch (a_node_in), edge halves gathered through the slice's COO edge ids, leaky-relu + segment softmax by the lane that owns the
 // producer item (node, head) -- under the latency of the priming DMAs: no coefficient kernel, no alpha_csr round trip.
-template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false, bool ALP = false>
+template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false, bool ALP = !SEQ>
 __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) {
+    static_assert(SEQ || ALP, "hopagg: the per-hop form computes its coefficients in its prologue (the form fed by a coefficient kernel was removed with that kernel)");
     static_assert(!(SEQ && (LGT || ALP)), "hopagg: the one-launch form computes its logits and coefficients itself (hop 0's in its first prologue, as ALP does)");
     static_assert(WR * WC == 8 && WR * RT == 4 && WC * TN <= 16, "hopagg: eight waves over 128 rows and at most 16 column tiles");
     constexpr int H = 4;
@@ -415,18 +326,6 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         ha_dma4(ha_uniform(xbase + (int64_t)min(q, NQ - 1) * (HA_ROWS * 4)), lane4,
                 __builtin_amdgcn_readfirstlane(lds_base + HA_X0 + (unsigned)(q & 3) * 2048u + (unsigned)wave * 256u));
     };
-    // CSR slice of the group -> LDS (edges past a node's first 8: read from here every K step)
-    auto dma_csr_slice = [&]() {
-        const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-        for (int u = wbase; u < ne; u += 512)
-            lds_dma4_b(a.csr_src + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_SRC0 + (unsigned)u * 4u));
-        if constexpr (SEQ)
-            for (int u = wbase; u < ne; u += 512)
-                lds_dma4_b(hs.csr_eid + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_EID0 + (unsigned)u * 4u));
-        for (int u = wbase; u < ne * H; u += 512)
-            lds_dma4_b(a.alpha_csr + (int64_t)e0 * H + min(u + lane, ne * H - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_AL0 + (unsigned)u * 4u));
-    };
-
     // ---- this lane's producer item: node i = 16 wave + a, head h = 2 hhi + hlo; its first 8 in-edges in registers
     // (the four heads of a node are the four lanes of a quad: every lane fetches ONE of the node's source rows per batch of four
     //  edges and the quad shares them through DPP -- two row reads per lane and step instead of eight; the x gathers were a quarter
@@ -437,20 +336,6 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     int plo = 0, pdeg = 0;                            // (hop-invariant; loaded in the first hop's prologue, behind its priming DMAs)
     float al[HA_DMAX];                                // this head's coefficients of the node's first 8 in-edges (0 past the last)
     unsigned sep = 0u;                                // byte offsets (slot x 16) of the chunk rows this lane fetches: edge ph | edge 4 + ph << 16
-    auto load_lane_items = [&]() {
-        plo = p_on ? a.rowptr[ns + pi] - e0 : 0;
-        pdeg = p_on ? min(a.rowptr[ns + pi + 1] - e0, HA_ECAP) - plo : 0;
-#pragma unroll
-        for (int e = 0; e < HA_DMAX; ++e) {
-            const int idx = max(min(plo + e, ne - 1), 0);
-            const float av = ne > 0 ? a.alpha_csr[(int64_t)(e0 + idx) * H + ph] : 0.f;
-            al[e] = e < pdeg ? av : 0.f;
-        }
-        const int i0 = max(min(plo + ph, ne - 1), 0), i1 = max(min(plo + 4 + ph, ne - 1), 0);
-        const unsigned s0 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i0] - ns, 0), HA_ROWS - 1) * 16u : 0u;
-        const unsigned s1 = ne > 0 ? (unsigned)min(max(a.csr_src[e0 + i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
-        sep = s0 | (s1 << 16);
-    };
     // acc += w * (x of quad lane E_): ONE instruction, v_fmac_f32 with a DPP quad broadcast on its first source (the compiler does not
     // fold its own v_mov_b32_dpp into the FMA here: 32 extra VALU operations per lane and K step, an eighth of the step's issue slots)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -743,15 +628,6 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         ovtrips = max(ha_wave_max(pdeg) - HA_DMAX - HA_NOV, 0);
         pg = a.node_graph[ns + min(pi, cnt - 1)];
         if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pg * a.t_ld + a.C + ph];
-        set_row_scale(a.gmax_in[pg], true);
-        if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
-        if constexpr (SEQ) { if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM1)[tid] = 0u; }
-    } else if (!SEQ && !ALP) {
-        dma_csr_slice();
-        load_lane_items();
-        ovn = min(max(ha_wave_max(pdeg) - HA_DMAX, 0), HA_NOV);
-        ovtrips = max(ha_wave_max(pdeg) - HA_DMAX - HA_NOV, 0);
-        pg = a.node_graph[ns + min(pi, cnt - 1)];
         set_row_scale(a.gmax_in[pg], true);
         if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
         if constexpr (SEQ) { if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM1)[tid] = 0u; }
@@ -1133,8 +1009,8 @@ bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges) {
 }
 
 int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream) {
-    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && (a.alpha_csr || a.a_node_in) && a.node_graph && a.X4in && a.Wk && a.binv && a.epc && a.gmax_in &&
-                 (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
+    GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.a_node_in && a.a_edge && a.csr_eid && a.node_graph && a.X4in && a.Wk && a.binv && a.epc &&
+                 a.gmax_in && (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
     GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1, GVQA_E_UNSUPPORTED, "hopagg: needs C %% 4 == 0 and C <= 512");
     if (num_groups == 0) return GVQA_OK;
     HopAggArgs b = a;
@@ -1145,18 +1021,15 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
     b.dbg = dbg;
 #endif
     GVQA_REQUIRE(!a.a_node_out || a.Vn_next, GVQA_E_INVALID, "hopagg: node logits out need the next hop's folded attention vectors");
-    GVQA_REQUIRE(!a.a_node_in || (a.a_edge && a.csr_eid), GVQA_E_INVALID, "hopagg: coefficients in the prologue need the edge halves and the COO edge ids");
     const dim3 grid((unsigned)num_groups), block(512);
-    const bool lg = a.a_node_out != nullptr, ap = a.a_node_in != nullptr, narrow = a.NCT <= 10;
-#define GVQA_HA_LAUNCH(LG_, AP_)                                                                                             \
+    const bool lg = a.a_node_out != nullptr, narrow = a.NCT <= 10;
+#define GVQA_HA_LAUNCH(LG_)                                                                                                  \
     do {                                                                                                                     \
-        if (narrow) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, LG_, AP_>), grid, block, 0, stream, b, none);             \
-        else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false, LG_, AP_>), grid, block, 0, stream, b, none);                    \
+        if (narrow) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, LG_, true>), grid, block, 0, stream, b, none);            \
+        else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false, LG_, true>), grid, block, 0, stream, b, none);                   \
     } while (0)
-    if (lg && ap) GVQA_HA_LAUNCH(true, true);
-    else if (lg) GVQA_HA_LAUNCH(true, false);
-    else if (ap) GVQA_HA_LAUNCH(false, true);
-    else GVQA_HA_LAUNCH(false, false);
+    if (lg) GVQA_HA_LAUNCH(true);
+    else GVQA_HA_LAUNCH(false);
 #undef GVQA_HA_LAUNCH
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
