@@ -117,11 +117,11 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
     __shared__ float4 slab[HA_ROWS][33];         // 32 chunks (+1: the column walk of the write phase is conflict-free)
     __shared__ unsigned gm_s[HA_ROWS];
     __shared__ float4 vn_s[8][32];               // Vn columns of the current 128-column block
-    float lg[4][8];                              // thread (r4 = tid & 31, pj = tid >> 5): rows r4 + 32 k, chunks pj and pj + 16 of every block
-#pragma unroll
+    ha_f32x2 lg[4][8];                           // thread (r4 = tid & 31, pj = tid >> 5): rows r4 + 32 k, chunks pj and pj + 16 of every block
+#pragma unroll                                   // (even / odd columns in separate packed chains: v_pk_fma_f32, half the VALU issue of the phase)
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lg[k][j] = 0.f;
+        for (int j = 0; j < 8; ++j) lg[k][j] = ha_f32x2{0.f, 0.f};
     const int tid = threadIdx.x, t = blockIdx.x;
     const int ns = group_ptr[t], cnt = group_ptr[t + 1] - ns;
     const int gf = node_graph[ns];
@@ -164,7 +164,10 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
                 for (int j = 0; j < 8; ++j) {
                     const float4 w = vn_s[j][p];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) lg[k][j] += x[k].x * w.x + x[k].y * w.y + x[k].z * w.z + x[k].w * w.w;
+                    for (int k = 0; k < 4; ++k) {
+                        lg[k][j] = ha_f32x2{x[k].x, x[k].y} * ha_f32x2{w.x, w.y} + lg[k][j];
+                        lg[k][j] = ha_f32x2{x[k].z, x[k].w} * ha_f32x2{w.z, w.w} + lg[k][j];
+                    }
                 }
             }
         }
@@ -191,8 +194,8 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float* dst = part + (pj * HA_ROWS + r4 + 32 * k) * 8;
-            *reinterpret_cast<float4*>(dst) = make_float4(lg[k][0], lg[k][1], lg[k][2], lg[k][3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(lg[k][4], lg[k][5], lg[k][6], lg[k][7]);
+            *reinterpret_cast<float4*>(dst) = make_float4(lg[k][0][0] + lg[k][0][1], lg[k][1][0] + lg[k][1][1], lg[k][2][0] + lg[k][2][1], lg[k][3][0] + lg[k][3][1]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(lg[k][4][0] + lg[k][4][1], lg[k][5][0] + lg[k][5][1], lg[k][6][0] + lg[k][6][1], lg[k][7][0] + lg[k][7][1]);
         }
         __syncthreads();
         for (int it = tid; it < cnt * 8; it += 512) {
