@@ -1528,7 +1528,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         }
         if (rc) return rc;
     }
-    if (chain && Di > 0) {   // largest instruction-term magnitude per (hop, graph): part of the chained hops' output bounds
+    if (chain && Di > 0 && !aggf) {   // largest instruction-term magnitude per (hop, graph): part of the chained hops' output bounds (the aggregate-first kernel scales by exact maxima)
         StageTimer t(GVQA_STAGE_GRAPH_TERM, aux);
         rc = launch_rows_absmax((int64_t)K * B, C, P(L.T), Tld, P(L.Tmax), aux);
         if (rc) return rc;
