@@ -489,12 +489,20 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         const int s = (s_);                                                                                                 \
         const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + ((s + 1) & 3) * 2048);                            \
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                        \
+        /* a node's 9th and 10th in-edge (most overflow is one or two edges): their rows are only FETCHED here -- the FMAs sit  \
+           further down, unconditional (zero rows, zero coefficients without overflow), so that the LDS round trip does not hold \
+           back the wave's first MFMAs of the step; edges 11 .. 16 (rare) are still consumed here */                         \
+        float4 xo0 = make_float4(0.f, 0.f, 0.f, 0.f), xo1 = xo0;                                                             \
         if (ovn > 0) {                                                                                                      \
-            _Pragma("unroll") for (int e = 0; e < HA_NOV; ++e)                                                              \
-                if (e < ovn) {                                                                                              \
-                    const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + ((so2[e >> 1] >> (16 * (e & 1))) & 0xFFFFu)); \
-                    GVQA_HA_FMA4(v0, al_o[e], x);                                                                           \
-                }                                                                                                           \
+            xo0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] & 0xFFFFu));        \
+            xo1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] >> 16));            \
+            if (ovn > 2) {                                                                                                  \
+                _Pragma("unroll") for (int e = 2; e < HA_NOV; ++e)                                                          \
+                    if (e < ovn) {                                                                                          \
+                        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + ((so2[e >> 1] >> (16 * (e & 1))) & 0xFFFFu)); \
+                        GVQA_HA_FMA4(v0, al_o[e], x);                                                                       \
+                    }                                                                                                       \
+            }                                                                                                               \
         }                                                                                                                   \
         if (ovtrips > 0) {                                                                                                  \
             for (int e = 0; e < ovtrips; ++e) {                                                                             \
@@ -532,8 +540,9 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a hi, b lo) with the producer: 8 x (4 FMAs), the second four x rows re-using xa */                              \
         GVQA_HA_MFR(0, NH, afh, bl);                                                                                        \
-        if (!GVQA_HA_DBG(1)) { GVQA_HA_QFMA(v0, al[0], xr, 0); GVQA_HA_QFMA(v0, al[1], xr, 1); GVQA_HA_QFMA(v0, al[2], xr, 2); GVQA_HA_QFMA(v0, al[3], xr, 3); } \
-        _Pragma("unroll") for (int z = 0; z < NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 32 / NH, 0); } \
+        if (!GVQA_HA_DBG(1)) { GVQA_HA_QFMA(v0, al[0], xr, 0); GVQA_HA_QFMA(v0, al[1], xr, 1); GVQA_HA_QFMA(v0, al[2], xr, 2); GVQA_HA_QFMA(v0, al[3], xr, 3); \
+                               GVQA_HA_FMA4(v0, al_o[0], xo0); GVQA_HA_FMA4(v0, al_o[1], xo1); }                              \
+        _Pragma("unroll") for (int z = 0; z < NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (40 + NH - 1) / NH, 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         issue_x(s + 3);                                                                                                     \
         xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));                    \
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             if (e & 1) so2[e >> 1] |= off << 16;
             else so2[e >> 1] = off;
         }
-    } else if constexpr (SEQ) {                       // (defined on every path: otherwise they stay live -- and spill -- across the previous hop's epilogue)
+    } else {                                          // (defined on every path: coefficients 0 and 1 are used unconditionally in the K step; SEQ: otherwise they stay live -- and spill -- across the previous hop's epilogue)
 #pragma unroll
         for (int e = 0; e < HA_NOV; ++e) al_o[e] = 0.f;
 #pragma unroll
