@@ -357,6 +357,81 @@ __global__ __launch_bounds__(256) void k_linear_f32_dma(int M, int N, int K, con
     store_tile_transposed(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Skinny streaming product C[M, N <= 32] = A[M, K] B[N, K]^T (the all-hops edge logits: [E, De] x [De, K H], 537 MB of edge features
+// read once at config 3).  HBM-bound: what matters is bytes in flight per CU.  The register-staged 128 x 32 kernel keeps one 16 KiB A
+// tile per workgroup on its way (three workgroups per CU: 48 KiB) and reaches 4.1 TB/s; here the A tiles go HBM -> LDS by
+// `global_load_lds_dwordx4` into a FOUR-stage ring (three tiles = 48 KiB in flight per workgroup, two workgroups per CU), one barrier
+// per K step, the 16 f32 MFMAs of a wave per step a small fraction of its time.  Tile format and swizzle as in k_linear_f32_dma.
+__global__ __launch_bounds__(256) void k_linear_f32_skinny_dma(int M, int N, int K, const float* __restrict__ A, int64_t lda,
+                                                               const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc) {
+    constexpr int BM = 128, BK = 32, NS = 4;
+    constexpr int A_BYTES = BM * BK * 4, B_BYTES = 32 * BK * 4, STAGE = A_BYTES + B_BYTES;       // 16 KiB + 4 KiB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // DMA duty of this wave per K step: A row groups wave, wave + 4, wave + 8, wave + 12 (8 rows x 128 bytes each) and B row group wave
+    const float* pa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (j * 4 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        pa[j] = A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 4;
+    }
+    const float* pb;
+    {
+        const int row = wave * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        pb = B + (int64_t)min(row, N - 1) * ldb + chunk * 4;
+    }
+    const int nt = K / BK;
+    auto issue = [&](int t) {                    // K step t (clamped: steps past the last re-load it into a free slot, so that the counted waits stay uniform)
+        const int tt = min(t, nt - 1);
+        const unsigned dst = lds_base + (unsigned)(t % NS) * STAGE + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_dma16_b(pa[j] + (int64_t)tt * BK, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+        lds_dma16_b(pb + (int64_t)tt * BK, __builtin_amdgcn_readfirstlane(dst + A_BYTES));
+    };
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    unsigned xo[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
+    const unsigned a_row = (unsigned)((wave * 32 + frow) * 128), b_row = (unsigned)(frow * 128);
+    issue(0); issue(1); issue(2);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");         // this wave's DMAs of step t have landed (steps t + 1, t + 2: 5 each may be in flight)
+        __builtin_amdgcn_s_barrier();                               // ... everybody's; everybody is done with the slot of step t - 1
+        issue(t + 3);
+        const unsigned char* at = smem + (t % NS) * STAGE;
+        const unsigned char* bt = at + A_BYTES;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const float4 af = *reinterpret_cast<const float4*>(at + a_row + xo[kg]);
+            const float4 bf = *reinterpret_cast<const float4*>(bt + b_row + xo[kg]);
+            // (operands swapped, B first: a lane owns 4 consecutive columns of one C row per register quad)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.z, af.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.w, af.w, acc, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the clamped re-loads of the last steps)
+    const int row = m0 + wave * 32 + frow;
+    if (row < M) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 8 * q + 4 * fh;
+            if (c0 < N) *reinterpret_cast<float4*>(C + (int64_t)row * ldc + c0) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+}
+
 // ---- opt-in vendor backend (comparison only) -----------------------------------------------------
 // The hand-written kernels are the default everywhere.  GVQA_OPT_VENDOR_GEMM (GVQA_GEMM_BACKEND=rocblas) routes PLAIN fp32
 // products (no epilogue, or a plain accumulate through BLAS beta = 1) above 2 GFLOP to rocBLAS so that
@@ -567,7 +642,12 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     // the LDS-DMA kernel stores C (and reads bias / addend / mul) as float4: whole 4-column quads, 16-byte aligned rows
     auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
     const bool ep4_ok = N % 4 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul) && al16(ep.bias, 4);
-    if (N <= 32) GVQA_LAUNCH_LINEAR(128, 32, 4, 1);
+    // tall skinny streams (the all-hops edge logits): the four-stage LDS-DMA ring keeps three A tiles per workgroup in flight
+    if (N <= 32 && N % 4 == 0 && K % 32 == 0 && K >= 96 && vec && batch == 1 && M >= 16384 && !ep.bias && !ep.addend && !ep.mul && !ep.relu &&
+        ep4_ok && tile_sel == 0) {
+        hipLaunchKernelGGL(k_linear_f32_skinny_dma, dim3((unsigned)cdiv(M, 128)), dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc);
+    }
+    else if (N <= 32) GVQA_LAUNCH_LINEAR(128, 32, 4, 1);
     else if (N <= 64) GVQA_LAUNCH_LINEAR(128, 64, 2, 2);
     // per-graph products (M = graphs): a 128 x 128 tile is >= 27 us of MFMA issue for its 4 waves however few
     // tiles there are -- when they cannot fill the chip, quarter tiles put 4x the CUs to work

@@ -103,6 +103,24 @@ def test_linear_f32(dev, M, N, K):
         assert maxabs(out2, ref2) < 2e-6 * (float(ref2.abs().max()) + 1) * np.sqrt(K)
 
 
+@pytest.mark.parametrize("M,N,K,ldc", [(20000, 20, 512, 20), (16385, 4, 96, 8), (65536 + 77, 32, 128, 32), (40000, 8, 300 // 32 * 32, 12)])
+def test_linear_tall_skinny_stream(dev, M, N, K, ldc):
+    """The LDS-DMA streaming kernel for tall skinny plain products (k_linear_f32_skinny_dma: M >= 16384, N <= 32, N % 4 == 0, K % 32 == 0 --
+    the all-hops edge logits [E, De] x [De, K H]): ragged last row tile, N from 4 to 32, result rows wider than N (the columns beyond stay
+    untouched), against fp64."""
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    A = t(synth.normal((M, K), 21), device=dev)
+    B = t(synth.normal((N, K), 22), device=dev)
+    out = torch.full((M, ldc), 7.0, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gvqa_linear_f32(M, N, K, A.data_ptr(), K, B.data_ptr(), K, None, 0, out.data_ptr(), ldc, st))
+    ref = A.double() @ B.double().T
+    assert maxabs(out[:, :N], ref) < 2e-6 * (float(ref.abs().max()) + 1.0) * np.sqrt(K)
+    if ldc > N:
+        assert bool((out[:, N:] == 7.0).all())
+
+
 @pytest.mark.parametrize("vendor", [0, 1])
 def test_linear_large_epilogue_branches(dev, vendor):
     """Large products with no epilogue, an accumulate (separate or in place) or a bias: on the hand-written kernels
