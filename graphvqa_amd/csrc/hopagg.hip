@@ -130,8 +130,11 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
     float rowmax[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) rowmax[u] = 0.f;
-    for (int q0 = 0; q0 < NQ; q0 += 32) {
-        // read: thread (r, p) = 16 bytes of row r; 32 threads cover 512 contiguous bytes of a row
+    // read: thread (r, p) = 16 bytes of row r; 32 threads cover 512 contiguous bytes of a row.  The loads of block q0 + 32 are issued as soon
+    // as block q0 sits in the slab -- they travel under its node-logit FMAs, its chunk writes and both barriers (issued at the top of the
+    // iteration, every block's read latency was exposed: 82 us for 268 MB)
+    float4 pre[8], prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_block = [&](int q0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = u * 512 + tid, r = idx >> 5, p = idx & 31, q = q0 + p;
@@ -141,16 +144,27 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
                 if (q * 4 + 4 <= D) v = *reinterpret_cast<const float4*>(src);
                 else { v.x = src[0]; if (q * 4 + 1 < D) v.y = src[1]; if (q * 4 + 2 < D) v.z = src[2]; }
             }
-            slab[r][p] = v;
-            rowmax[u] = fmaxf(rowmax[u], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            pre[u] = v;
         }
         if (Vn && tid < 256) {
             const int j = tid >> 5, p = tid & 31, k = (q0 + p) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k + 4 <= D) v = *reinterpret_cast<const float4*>(Vn + (int64_t)j * D + k);
             else if (k < D) { v.x = Vn[(int64_t)j * D + k]; if (k + 1 < D) v.y = Vn[(int64_t)j * D + k + 1]; if (k + 2 < D) v.z = Vn[(int64_t)j * D + k + 2]; }
-            vn_s[j][p] = v;
+            prev = v;
         }
+    };
+    load_block(0);
+    for (int q0 = 0; q0 < NQ; q0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = u * 512 + tid, r = idx >> 5, p = idx & 31;
+            const float4 v = pre[u];
+            slab[r][p] = v;
+            rowmax[u] = fmaxf(rowmax[u], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        if (Vn && tid < 256) vn_s[tid >> 5][tid & 31] = prev;
+        if (q0 + 32 < NQ) load_block(q0 + 32);
         __syncthreads();
         if (Vn) {                                // (four rows per Vn read: the phase is LDS-bound)
             const int r4 = tid & 31, pj = tid >> 5;
