@@ -342,6 +342,13 @@ def main():
         other = {"value": (world * Eall if strong else Eall) / (odt / osteps), "ms_per_step": odt / osteps * 1e3, "steps": osteps,
                  "graphs_per_gpu": oshard.num_graphs}
 
+    # the exchange itself, both forms on the step's own payload ([graphs, D] rows per rank), every rank taking part: RCCL's
+    # all_gather_into_tensor against the direct one-hop push to all peers -- so that the first N > 1 record says
+    # which one this topology wants.  Behind a watchdog: a comparison leg must not be able to hang the bench line.
+    gather_ab_res, gather_hung = (None, False)
+    if dist is not None and not os.environ.get("GVQA_BENCH_NO_GATHER_AB"):
+        gather_ab_res, gather_hung = gather_ab(dist, torch, dev, shard.num_graphs, D)
+
     line = None
     if rank == 0:
         N, E, B = shard.num_nodes, shard.num_edges, shard.num_graphs
@@ -460,6 +467,8 @@ def main():
         }
         if rccl_ranks_seen is not None:
             res["rccl_ranks_seen"] = rccl_ranks_seen
+        if gather_ab_res is not None:
+            res["allgather_ab"] = gather_ab_res
         if other is not None:
             o = "weak" if strong else "strong"
             res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other["value"], other["ms_per_step"], other["steps"]
@@ -551,7 +560,7 @@ def main():
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(params, synth, np, torch, m, dev)
         line = json.dumps(res)
-    if dist is not None:
+    if dist is not None and not gather_hung:
         dist.barrier()
         dist.destroy_process_group()
     if line is not None:
@@ -565,6 +574,47 @@ def main():
             pass
         sys.stdout.flush()
         print(line, flush=True)
+    if gather_hung:                      # a comparison thread is stuck inside the backend: leave without its clean-up
+        os._exit(0)
+
+
+def gather_ab(dist, torch, dev, nrows, ncols, reps=20, timeout_s=45.0):
+    """Average time of one all-gather of [nrows, ncols] fp32 rows per rank, max over ranks, for both forms of
+    graphvqa_amd.parallel.all_gather_graph_rows.  Returns (result, hung)."""
+    import threading
+    from graphvqa_amd.parallel import all_gather_graph_rows
+    out = {"rows_per_rank": int(nrows), "bytes_per_rank": int(nrows) * int(ncols) * 4, "world_size": dist.get_world_size(), "reps": reps}
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)
+            rows = torch.randn(nrows, ncols, device=dev)
+            counts = [nrows] * dist.get_world_size()
+            for algo in ("collective", "direct"):
+                for _ in range(3):
+                    all_gather_graph_rows(rows, counts=counts, force=True, algo=algo)
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    all_gather_graph_rows(rows, counts=counts, force=True, algo=algo)
+                torch.cuda.synchronize()
+                tm = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                out[algo + "_us"] = float(tm.item()) * 1e6
+            out["note"] = ("collective = all_gather_into_tensor (the backend picks algorithm / protocol); direct = one grouped batch of isend / irecv "
+                           "to and from every peer (one hop on a fully connected node); the step uses GVQA_ALLGATHER="
+                           + os.environ.get("GVQA_ALLGATHER", "collective"))
+        except Exception as e:           # the bench line must still come out
+            out["error"] = repr(e)[:300]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        res = dict(out)
+        res["error"] = f"no result after {timeout_s} s"
+        return res, True
+    return out, False
 
 
 def dvfs_probe(model, shard, step, torch, _lib, n):

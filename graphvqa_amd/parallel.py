@@ -10,6 +10,8 @@ every rank overwrites the same dump file, mainExplain_gat.py:938-942).  Backend:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -116,14 +118,59 @@ class GatheredRows:
         return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(len(counts))])
 
 
-def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False, async_op: bool = False):
+def _gather_algo(algo=None) -> str:
+    """`collective` = one `all_gather_into_tensor` (RCCL picks ring / tree + protocol); `direct` = every rank pushes its rows to
+    all peers at once (one grouped batch of point-to-point sends / receives: on the fully connected xGMI topology of an 8-GPU node
+    the 7 sends leave on 7 different links in ONE hop, where a ring serialises 7 steps each bound by one link).
+    Default from GVQA_ALLGATHER (collective)."""
+    algo = algo or os.environ.get("GVQA_ALLGATHER", "collective")
+    if algo not in ("collective", "direct"):
+        raise ValueError(f"all-gather algorithm {algo!r}: expected 'collective' or 'direct'")
+    return algo
+
+
+class _Works:
+    """Several in-flight point-to-point requests behind one wait()."""
+
+    def __init__(self, reqs, keep=None):
+        self._reqs, self._keep = reqs, keep          # (`keep`: the send buffer stays alive until the requests completed)
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+        self._keep = None
+
+
+def _direct_all_gather(out: torch.Tensor, rows: torch.Tensor, mx: int, async_op: bool):
+    """out[r * mx:(r + 1) * mx] <- rank r's rows, by ONE grouped batch of isend / irecv to and from every peer (own slot: a
+    device copy).  Receives land in place in `out`: no staging buffer, no second pass."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out[rank * mx:(rank + 1) * mx].copy_(rows)
+    ops = []
+    for d in range(1, world):                      # peer order rotated by rank: at every position of the batch the world's sends form a permutation
+        to, frm = (rank + d) % world, (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, rows, to))
+        ops.append(dist.P2POp(dist.irecv, out[frm * mx:(frm + 1) * mx], frm))
+    if not ops:
+        return None
+    works = _Works(dist.batch_isend_irecv(ops), rows)
+    if async_op:
+        return works
+    works.wait()
+    return None
+
+
+def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False, async_op: bool = False, algo=None):
     """All-gather per-graph rows [B_r, C] from every rank into [sum B_r, C] (rank order).
     Ragged shards are padded to the largest B_r (one collective, latency-bound at these sizes).
     async_op=True: the collective is enqueued on the backend's own stream (ordered after the current stream's work so far)
-    and a GatheredRows handle is returned instead of the tensor -- the caller's stream goes on with the next batch."""
+    and a GatheredRows handle is returned instead of the tensor -- the caller's stream goes on with the next batch.
+    algo: 'collective' | 'direct' (see _gather_algo; default from GVQA_ALLGATHER)."""
     import torch.distributed as dist
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return GatheredRows(rows) if async_op else rows
+    algo = _gather_algo(algo)
     world = dist.get_world_size()
     if counts is None:
         c = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
@@ -133,13 +180,20 @@ def all_gather_graph_rows(rows: torch.Tensor, counts=None, force: bool = False, 
     mx = max(counts)
     if rows.shape[0] < mx:
         rows = torch.cat([rows, rows.new_zeros((mx - rows.shape[0], rows.shape[1]))])
+    rows = rows.contiguous()
     if rows.is_cuda and dist.get_backend() == "gloo":      # (gloo has no device all-gather: test set-ups with N ranks on one GPU go through the host)
         host = torch.empty((world * mx, rows.shape[1]), dtype=rows.dtype)
-        dist.all_gather_into_tensor(host, rows.contiguous().cpu())
+        if algo == "direct":
+            _direct_all_gather(host, rows.cpu(), mx, False)
+        else:
+            dist.all_gather_into_tensor(host, rows.cpu())
         res = GatheredRows(host.to(rows.device), None, counts, mx)
         return res if async_op else res.wait()
     out = torch.empty((world * mx, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    work = dist.all_gather_into_tensor(out, rows.contiguous(), async_op=async_op)
+    if algo == "direct":
+        work = _direct_all_gather(out, rows, mx, async_op)
+    else:
+        work = dist.all_gather_into_tensor(out, rows, async_op=async_op)
     res = GatheredRows(out, work if async_op else None, counts, mx)
     return res if async_op else res.wait()
 

@@ -195,3 +195,46 @@ def test_gradient_allreduce_matches_single_process():
     for k, v in params.items():
         ref = np.zeros_like(got[k]) if v.grad is None else v.grad.numpy()
         assert np.abs(got[k] - ref).max() < 1e-9 * (1.0 + np.abs(ref).max()), k
+
+
+def _direct_worker(rank, world, port, q):
+    """The direct one-hop exchange (every rank pushes its rows to all peers in one grouped batch of isend / irecv) against the
+    collective, on ragged per-rank row counts; blocking, in flight (async_op) and through the environment switch."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        counts = [3 + 2 * r for r in range(world)]                  # ragged: 3, 5, 7 ...
+        rows = torch.arange(counts[rank] * 6, dtype=torch.float32).reshape(counts[rank], 6) + 1000.0 * rank
+        want = torch.cat([torch.arange(c * 6, dtype=torch.float32).reshape(c, 6) + 1000.0 * r for r, c in enumerate(counts)])
+        coll = all_gather_graph_rows(rows, counts=counts, algo="collective")
+        direct = all_gather_graph_rows(rows, counts=counts, algo="direct")
+        inflight = all_gather_graph_rows(rows, counts=None, algo="direct", async_op=True)      # (counts exchanged by the function)
+        os.environ["GVQA_ALLGATHER"] = "direct"
+        by_env = all_gather_graph_rows(rows, counts=counts)
+        del os.environ["GVQA_ALLGATHER"]
+        ok = all(torch.equal(v, want) for v in (coll, direct, inflight.wait(), by_env))
+        bad = False
+        try:
+            all_gather_graph_rows(rows, counts=counts, algo="ring-of-fire")
+        except ValueError:
+            bad = True
+        dist.barrier()
+        if rank == 0:
+            q.put((ok, bad, tuple(direct.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_one_hop_all_gather_equals_the_collective_three_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, 3, port, q)) for r in range(3)]
+    for pr in procs:
+        pr.start()
+    ok, bad, shape = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert ok and bad and shape == (15, 6)
