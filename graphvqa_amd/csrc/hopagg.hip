@@ -249,12 +249,39 @@ __device__ __forceinline__ void ha_dma16_x2(const void* sbase, unsigned voff, un
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
+// GVQA_HA_NT (A/B build switch; bits: 1 x-chunk DMAs, 2 skip-row loads, 4 row stores): the ROW traffic of the hop kernel -- x chunks in, skip rows in, result rows out: 16 + 8 MiB per XCD and
+// hop, each line touched once or re-used only ~100 us later -- carries the non-temporal hint, so that it does not push the hop's 4 MiB of
+// weight tiles (re-used by all 32 workgroups of an XCD) out of the XCD's 4 MiB L2.
+#ifndef GVQA_HA_NT
+#define GVQA_HA_NT 0
+#endif
+#if GVQA_HA_NT & 1
+#define GVQA_HA_NT_STR " nt"
+#else
+#define GVQA_HA_NT_STR ""
+#endif
 __device__ __forceinline__ void ha_dma4(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" GVQA_HA_NT_STR "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
+}
+typedef float ha_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ha_row_load(const float* p) {
+#if GVQA_HA_NT & 2
+    const ha_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ha_f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void ha_row_store(float* p, const float4& v) {
+#if GVQA_HA_NT & 4
+    __builtin_nontemporal_store(ha_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<ha_f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
 }
 
 // a wave-uniform pointer the compiler has lost track of (re-pointed inside the hop loop) back into SGPRs: the DMA helpers above take
@@ -863,7 +890,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int cc = min((wc * TN + j) * 32 + 8 * (2 * qp + u) + 4 * hb, C - 4);       // (columns past C: clamped re-reads, never used)
-                sk[u] = *reinterpret_cast<const float4*>(X4in_h + (((int64_t)t * NQ + (cc >> 2)) * HA_ROWS + r) * 4);
+                sk[u] = ha_row_load(X4in_h + (((int64_t)t * NQ + (cc >> 2)) * HA_ROWS + r) * 4);
                 tg[u] = *reinterpret_cast<const float4*>(gt_ + (int64_t)g_[i] * gt_ld + cc);
             }
         };
@@ -897,8 +924,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                 }
                 if (!on_[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!defer) {
-                    if (X4out_h) *reinterpret_cast<float4*>(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4) = v;
-                    if (out_h && on_[i]) *reinterpret_cast<float4*>(out_h + node * a.out_ld + c0) = v;
+                    if (X4out_h) ha_row_store(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4, v);
+                    if (out_h && on_[i]) ha_row_store(out_h + node * a.out_ld + c0, v);
                 }
                 vmax_[i] = fmaxf(vmax_[i], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
                 if constexpr (SEQ) {                  // the finished values stay in the accumulator registers: stores and node logits below
@@ -992,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                     const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
                     if (c0 >= C) continue;
                     const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                    *reinterpret_cast<float4*>(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4) = v;
+                    ha_row_store(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4, v);
                     if (j == 0 && q < 2 && c0 < 12) *reinterpret_cast<float4*>(smem + HA_X0 + (c0 >> 2) * 2048 + r * 16) = v;
                 }
         }
