@@ -237,7 +237,8 @@ def main():
 
     pipes = []
 
-    def runner(shard):
+    def runner(shard, pipelined=None):
+        pipelined = a.pipelined_gather if pipelined is None else pipelined
         q_feat = tt(q_all[shard.graph_range[0]:shard.graph_range[1]]).to(dev) if head is not None else None
         state = {}
 
@@ -255,7 +256,7 @@ def main():
 
         if dist is None:
             return (lambda: forward(shard)) if head is None else (lambda: pool(forward(shard), shard))
-        if not a.pipelined_gather:
+        if not pipelined:
             return lambda: sharded_step(shard, forward, pool, force=force_dist)
         # the loop over batches: step i's per-graph rows are gathered on RCCL's stream while step i + 1's hops run; every
         # gathered result is complete before the timed region's closing synchronize (device-wide)
@@ -341,6 +342,12 @@ def main():
         odt = timed(runner(oshard), osteps, 2)
         other = {"value": (world * Eall if strong else Eall) / (odt / osteps), "ms_per_step": odt / osteps * 1e3, "steps": osteps,
                  "graphs_per_gpu": oshard.num_graphs}
+
+    other_gather = None
+    if world > 1:                       # third key: the same steps with the exchange the OTHER way round (blocking <-> in flight under the next step's hops)
+        gsteps = max(3, a.steps // 2)
+        gdt = timed(runner(shard, pipelined=not a.pipelined_gather), gsteps, 2)
+        other_gather = {"value": edges_per_step / (gdt / gsteps), "ms_per_step": gdt / gsteps * 1e3, "steps": gsteps}
 
     # the exchange itself, both forms on the step's own payload ([graphs, D] rows per rank), every rank taking part: RCCL's
     # all_gather_into_tensor against the direct one-hop push to all peers -- so that the first N > 1 record says
@@ -469,6 +476,11 @@ def main():
             res["rccl_ranks_seen"] = rccl_ranks_seen
         if gather_ab_res is not None:
             res["allgather_ab"] = gather_ab_res
+        if other_gather is not None:
+            o = "blocking_gather" if a.pipelined_gather else "pipelined_gather"
+            res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other_gather["value"], other_gather["ms_per_step"], other_gather["steps"]
+            res[o + "_note"] = ("the same steps with every step waiting for its own all-gather" if a.pipelined_gather else
+                                "the same steps with step i's all-gather in flight on the collective's stream under step i + 1's hops (parallel.PipelinedSteps)")
         if other is not None:
             o = "weak" if strong else "strong"
             res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other["value"], other["ms_per_step"], other["steps"]
