@@ -1052,15 +1052,20 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
         return false;
     if (mode == 3 && !kAggFirstByDefault) return false;
     if (mode == 3) {
-        // one workgroup per row group, one resident per CU: the default rule takes it when the row groups fill the CUs in
-        // whole rounds to within 15 % (config 3: 512 groups on 256 CUs); smaller / ragged batches keep the item-granular kernels
+        // one workgroup per row group, one resident per CU: the default rule takes it when the row groups fill the CUs' last round
+        // well enough (config 3: 512 groups on 256 CUs); smaller / ragged batches keep the item-granular kernels.  Thresholds from a
+        // sweep of batch sizes at config-3 widths (profiles/r04d_sweep_batch_sizes.jsonl, forward wall ms, one launch vs chained
+        // 8-wave): 425 groups (0.83 of two rounds) 2.13 vs 2.29; 550 (0.72 of three) 3.18 vs 2.90; 725 (0.94 of three) 3.32 vs 3.82 --
+        // a workgroup's hops run faster when the last round is thin (fewer CUs draw power), so two rounds pay from ~0.72 on, three
+        // from ~0.80; one round and four or more keep the earlier 0.85.
         static const int64_t cus = []() {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
             return (int64_t)n;
         }();
         const int64_t G = g->num_row_groups, rounds = cdiv(G, cus);
-        if (G * 100 < rounds * cus * 85) return false;
+        const int64_t fill_pct = rounds == 2 ? 76 : rounds == 3 ? 82 : 85;
+        if (G * 100 < rounds * cus * fill_pct) return false;
         if (C <= 320) return false;                    // (the 4 x 2-wave layout of narrow rows is issue-bound: d = 300, 149 vs 110 us per hop)
     }
     return true;
