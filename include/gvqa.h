@@ -378,7 +378,7 @@ enum gvqa_option {
                                          under the other's matrix-core loop; two-piece operands), hops CHAINED: a hop leaves the next hop's
                                          packed operand, so only the first hop has a pack pass;
                                       3 (default): mode 5's form (plain outputs; mode 4's otherwise) when H = 4, C == node_dim, 320 < C <= 512 and the
-                                         batch's row groups fill the CUs in whole rounds (to within 15 %); else with H = 4 and >= 128 row groups, 1 with the hops chained (the 8-wave kernel writes the next
+                                         batch's row groups fill the CUs' last round (two rounds from 0.76 full, three from 0.82, else 0.85); else with H = 4 and >= 128 row groups, 1 with the hops chained (the 8-wave kernel writes the next
                                          hop's packed operand too: the faster of the two chained forms, round 4); otherwise 2 when the batch has
                                          >= 6 (row group, column block) items per workgroup slot, else 1;
                                       4: the aggregate-first kernel of csrc/hopagg.hip (H = 4, C == node_dim <= 512: heads concatenated along K,
