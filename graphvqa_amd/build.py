@@ -39,6 +39,12 @@ def build(force: bool = False, verbose: bool = False, probes: bool = False) -> s
     return _build(LIBDIR, FLAGS, force, verbose)
 
 
+def build_variant(name: str, defines, force: bool = False, verbose: bool = False) -> str:
+    """An A/B build with extra -D switches -> lib/<name>/libgvqa_hip.so (loaded through GVQA_LIB; scripts/ab_nt.sh uses
+    `--variant nt6 GVQA_HA_NT=6` and friends).  Never loaded by the product path."""
+    return _build(os.path.join(LIBDIR, name), FLAGS + ["-D" + d for d in defines], force, verbose)
+
+
 def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
     LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
@@ -70,4 +76,8 @@ def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, probes="--probes" in sys.argv))
+    if "--variant" in sys.argv:          # python -m graphvqa_amd.build --variant nt6 GVQA_HA_NT=6
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if not a.startswith("--")], force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, probes="--probes" in sys.argv))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the hop kernel's row traffic with the non-temporal hint (GVQA_HA_NT builds under graphvqa_amd/lib/nt<mask>/) against the default
-# library on ONE box: parity of every variant first (aggregate-first tests + a short randomised sweep), then bench.py alternated.
+# library on ONE box (build the variants first, here: for m in 7 6 4; do python -m graphvqa_amd.build --variant nt$m GVQA_HA_NT=$m; done):
+# parity of every variant first (aggregate-first tests + a short randomised sweep), then bench.py alternated.
 O=gpurun_out/nt; mkdir -p $O; export TMPDIR=/tmp
 V="${VARIANTS:-7 6 4}"
 for v in $V; do
