@@ -218,14 +218,16 @@ def gcn_seq(x, edge_index, instr_vectors, batch, p, return_convs=False):
 # LCGN variant (baseline_and_test_models/lcgn.py)
 # ----------------------------------------------------------------------------
 def lcgn_conv(x_joint, edge_index, cmd, batch, p, prefix="lcgn.", heads=1, negative_slope=0.2,
-              return_attention_weights=False):
-    """`gat_lcgn.forward` + `message` (lcgn.py:120-238), eval mode, concat=False."""
+              return_attention_weights=False, node_store=None):
+    """`gat_lcgn.forward` + `message` (lcgn.py:120-238), eval mode, concat=False.
+    node_store: see lcgn_seq (applied to x_l, x_r, x_val and the aggregated message)."""
+    st = node_store if node_store is not None else (lambda v: v)
     H = heads
     C = p[prefix + "lin_l.weight"].shape[0] // H
     N = x_joint.shape[0]
     src, dst = edge_index[0], edge_index[1]
-    x_l = F.linear(x_joint, p[prefix + "lin_l.weight"]).view(-1, H, C)      # :144
-    x_r = F.linear(x_joint, p[prefix + "lin_r.weight"]).view(-1, H, C)      # :145
+    x_l = st(F.linear(x_joint, p[prefix + "lin_l.weight"])).view(-1, H, C)      # :144
+    x_r = st(F.linear(x_joint, p[prefix + "lin_r.weight"])).view(-1, H, C)      # :145
     proj_cmd = F.linear(cmd, p[prefix + "proj_cmd.weight"])                 # :148
     cal_cmd = F.linear(cmd, p[prefix + "cal_cmd.weight"])                   # :149
     onehot = F.one_hot(batch).to(x_joint.dtype)                             # :150
@@ -235,12 +237,13 @@ def lcgn_conv(x_joint, edge_index, cmd, batch, p, prefix="lcgn.", heads=1, negat
     alpha = torch.sum(x_l.index_select(0, src) * x_mul.index_select(0, dst), dim=-1)  # :207
     alpha = F.leaky_relu(alpha, negative_slope)
     alpha = segment_softmax(alpha, dst, N)
-    x_val = F.linear(x_joint.index_select(0, src), p[prefix + "cal_x.weight"]).view(-1, H, C)  # :230
+    x_val = st(F.linear(x_joint.index_select(0, src), p[prefix + "cal_x.weight"])).view(-1, H, C)  # :230
     x_fin = x_val * cal_cmd.index_select(0, src)                            # :231
     out = scatter_add_rows(x_fin * alpha.unsqueeze(-1), dst, N).mean(dim=1)  # concat=False
     bias = p.get(prefix + "bias", None)
     if bias is not None:
         out = out + bias
+    out = st(out)
     if return_attention_weights:
         return out, alpha
     return out
@@ -257,25 +260,40 @@ def lcgn_extract_command(q_emb, lstm_outputs, t, p):
 
 
 def lcgn_seq(x, edge_index, batch, q_encoding, lstm_outputs, p, x_ctx_init, max_iter=4, heads=1,
-             return_all=False):
+             return_all=False, node_store=None):
     """`lcgn_seq.forward` (lcgn.py:303-323), eval mode.  `x_ctx_init` stands in for the
     reference's `torch.randn(x_loc.size())` drawn on the CPU generator (lcgn.py:306): the caller
-    draws it with the same seed/call so both sides see identical noise."""
-    x_loc = F.linear(x, p["init_sg_emb_input.0.weight"], p["init_sg_emb_input.0.bias"])
-    x_ctx = x_ctx_init
+    draws it with the same seed/call so both sides see identical noise.
+
+    node_store (BASELINE config 5, "bf16 node features"): a callable applied to every PER-NODE tensor
+    at the point where the reference materialises it -- the input features, x_loc, proj_x_loc(x_loc),
+    x_ctx (initial and after every iteration), the proj_x_ctx * proj_x_loc product, gat_lcgn's x_l /
+    x_r / x_val and its aggregated message -- e.g. `bf16_storage` below.  Everything else (weights,
+    per-question tensors, logits, softmax, accumulation) stays in the dtype of the inputs: run in
+    float64 this is "the reference's arithmetic done exactly, on node tensors that are stored in
+    bf16", the oracle-side model of the storage choice (the reference itself has no such mode)."""
+    st = node_store if node_store is not None else (lambda v: v)
+    x = st(x)
+    x_loc = st(F.linear(x, p["init_sg_emb_input.0.weight"], p["init_sg_emb_input.0.bias"]))
+    x_ctx = st(x_ctx_init)
     q_emb = F.relu(F.linear(q_encoding, p["qInput1.weight"], p["qInput1.bias"]))
-    proj_x_loc = F.linear(x_loc, p["proj_x_loc.1.weight"], p["proj_x_loc.1.bias"])
+    proj_x_loc = st(F.linear(x_loc, p["proj_x_loc.1.weight"], p["proj_x_loc.1.bias"]))
     ctxs = []
     for t in range(max_iter):
         cmd = lcgn_extract_command(q_emb, lstm_outputs, t, p)
         proj_x_ctx = F.linear(x_ctx, p["proj_x_ctx.1.weight"], p["proj_x_ctx.1.bias"])
-        x_joint = torch.cat([x_loc, x_ctx, proj_x_ctx * proj_x_loc], dim=-1)
-        msg = lcgn_conv(x_joint, edge_index, cmd, batch, p, "lcgn.", heads)
-        x_ctx = F.linear(torch.cat([x_ctx, msg], dim=-1), p["output_layer.weight"],
-                         p["output_layer.bias"])
+        x_joint = torch.cat([x_loc, x_ctx, st(proj_x_ctx * proj_x_loc)], dim=-1)
+        msg = lcgn_conv(x_joint, edge_index, cmd, batch, p, "lcgn.", heads, node_store=node_store)
+        x_ctx = st(F.linear(torch.cat([x_ctx, msg], dim=-1), p["output_layer.weight"],
+                            p["output_layer.bias"]))
         ctxs.append(x_ctx)
     out = F.linear(torch.cat([x_loc, x_ctx], dim=-1), p["fin_layer.weight"], p["fin_layer.bias"])
     return (out, ctxs) if return_all else out
+
+
+def bf16_storage(v):
+    """node_store for lcgn_seq: round to bfloat16 (nearest even) and come back in the working dtype."""
+    return v.to(torch.bfloat16).to(v.dtype)
 
 
 # ----------------------------------------------------------------------------

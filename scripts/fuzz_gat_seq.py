@@ -5,7 +5,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 torch.set_grad_enabled(False)
-from tests.fuzz import case, run
+from tests.fuzz import case, run, STATS
 
 
 def main():
@@ -21,7 +21,7 @@ def main():
         if not ok:
             bad += 1
             print("FAIL", json.dumps(c), errs, sz, flush=True)
-    print(json.dumps({"cases": n, "failed": bad, "seed": int(os.environ.get("SEED", "1"))}))
+    print(json.dumps({"cases": n, "failed": bad, "seed": int(os.environ.get("SEED", "1")), "bound_census": STATS}))
 
 
 if __name__ == "__main__":

@@ -31,6 +31,8 @@ def case(rng):
                 ins_scale=float(rng.choice([0.0, 1.0, 4.0])))
 
 
+SCALED_BOUND_ABOVE = 32.0      # |oracle output| up to here: 1e-4 absolute; above: 1e-4 x (peak / 32)
+STATS = {"cases": 0, "scaled_bound_cases": 0, "largest_ref_peak": 0.0}      # census of the bound used, over every run() of the process
 STRATA = ("tiny_groups", "sparse_e_over_n_1", "hubs", "partial_k_block", "many_small", "big_graphs")
 
 
@@ -107,8 +109,18 @@ def run(c, dev):
             errs["alpha"] = float((res[1].cpu() - torch.stack(alphas)).abs().max())
         if c["hops"] and res[-1] is not None:
             errs["hops"] = float((res[-1].cpu() - torch.stack(hs)).abs().max())
-    scale = max(1.0, float(ref.abs().max()))
-    ok = all(np.isfinite(v) for v in errs.values()) and errs["out"] < 1e-4 * scale and errs["out2"] < 1e-4 * scale and \
+    # north_star's bound is 1e-4 MAX-ABS: asserted as such whenever the oracle's outputs stay within 32 in magnitude (config 3 peaks
+    # at 24); only beyond that -- fp32 itself resolves 2^-18 of 32 -- does the bound scale with the output, and the callers count how
+    # many cases took the scaled form (errs["scaled_bound"])
+    peak = max(float(ref.abs().max()), max((float(h.abs().max()) for h in hs), default=0.0) if c["hops"] else 0.0)
+    scale = 1.0 if peak <= SCALED_BOUND_ABOVE else peak / SCALED_BOUND_ABOVE
+    errs["scaled_bound"] = scale > 1.0
+    STATS["cases"] += 1
+    STATS["scaled_bound_cases"] += int(scale > 1.0)
+    STATS["largest_ref_peak"] = max(STATS["largest_ref_peak"], peak)
+    errs["ref_peak"] = peak
+    vals = [v for k, v in errs.items() if k not in ("scaled_bound", "ref_peak")]
+    ok = all(np.isfinite(v) for v in vals) and errs["out"] < 1e-4 * scale and errs["out2"] < 1e-4 * scale and \
         errs.get("alpha", 0.0) < 5e-5 and errs.get("hops", 0.0) < 1e-4 * scale
     return ok, errs, (N, E, B)
 

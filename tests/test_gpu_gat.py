@@ -851,6 +851,24 @@ def test_aggregate_first_one_launch_parity_sweep(dev, stratum):
     assert ran >= 8 and not bad, (ran, len(bad), bad[:3])
 
 
+def test_parity_sweep_bound_census(dev):
+    """tests/fuzz.run asserts north_star's 1e-4 MAX-ABS whenever the oracle's outputs stay within 32 in magnitude and a bound scaled
+    by peak / 32 only above that (VERDICT r04 #3a).  This test reports how many of the sweeps' cases (run earlier in this file, same
+    process) took the scaled form, and holds the scaled share under a quarter: the net is an absolute-bound net."""
+    import json
+    from tests.fuzz import STATS, case, run
+    if STATS["cases"] == 0:               # run alone (-k): a small sample so that the census is not vacuous
+        rng = np.random.default_rng(7)
+        for _ in range(12):
+            ok, errs, _ = run(case(rng), dev)
+            assert ok, errs
+    print("parity sweep bound census:", json.dumps(STATS))
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/fuzz_bound_census.json", "w") as f:
+            json.dump(STATS, f)
+    assert STATS["scaled_bound_cases"] <= 0.25 * STATS["cases"], STATS
+
+
 @pytest.mark.parametrize("fusion", [1, 2, 4])
 def test_weight_rows_spanning_2_to_the_24_inside_one_column_block(dev, fusion):
     """VERDICT r03 #6, the dynamic range of split2h's weight scales.  The 8-wave and the persistent fused kernels share ONE
@@ -1166,12 +1184,28 @@ def test_config3_full_size_properties(dev, hop_kernel):
     # (4) rows of the FULL-BATCH output against the oracle on a middle and on the last 64-graph window (graphs are independent, so
     # the oracle runs on the window alone): the row blocks the workgroup -> tile maps of the hop kernels move around
     from oracle import ref_torch as R
+    refs = []
     for g0 in (B // 2 - 32, B - 64):
         n0, n1 = g0 * 32, (g0 + 64) * 32
         sel = (gb.edge_index[0] >= n0) & (gb.edge_index[0] < n1)
         ei_w = gb.edge_index[:, sel] - n0
         ref_w = R.gat_seq(t(x[n0:n1]), t(ei_w), t(ea[sel]), t(ins[:, g0:g0 + 64]), t(gb.batch[n0:n1] - g0), tparams(p), heads=4)
         assert maxabs(out[n0:n1], ref_w) < TOL, g0
+        refs.append((n0, n1, ref_w))
+    # (5) the PLAIN-output forward -- under the default rule the K hops as ONE launch, the form bench.py times (VERDICT r04 #3b) --
+    # DIRECTLY against the same oracle windows, first window included; the launch count says which form ran
+    from graphvqa_amd import _lib
+    _lib.prof_enable(True); _lib.prof_collect()
+    out_plain = _run_gat_seq(dev, (d, d, d, 5, 4), p, x, gb.edge_index, ea, ins, gb.batch)
+    torch.cuda.synchronize()
+    pr = _lib.prof_collect(); _lib.prof_enable(False)
+    if hop_kernel == 3:
+        assert pr["proj"][1] == 1 and pr["mp"][1] == 0 and pr["alpha"][1] == 0, pr          # one hop launch for K = 5, no coefficient kernel
+    n0, n1 = 0, 64 * 32
+    sel = gb.edge_index[0] < n1
+    refs.append((n0, n1, R.gat_seq(t(x[n0:n1]), t(gb.edge_index[:, sel]), t(ea[sel]), t(ins[:, :64]), t(gb.batch[n0:n1]), tparams(p), heads=4)))
+    for n0, n1, ref_w in refs:
+        assert maxabs(out_plain[n0:n1], ref_w) < TOL, (n0, n1)
 
 
 def test_gat_seq_train_mode_batchnorm_golden(dev):
@@ -1854,8 +1888,19 @@ def test_lcgn_bf16_node_features(dev, pieces):
                                        pieces=pieces)
     ref = R.lcgn_seq(t(x), t(gb.edge_index), t(gb.batch), t(q), t(lstm), tparams(p), t(x_ctx))
     scale = float(ref.abs().max())
-    print("lcgn bf16 pieces=%d: vs emulation %.3e, vs fp32 oracle %.3e, scale %.3e" % (pieces, maxabs(out, emu), maxabs(out, ref), scale))
+    # the ORACLE's model of the storage choice (VERDICT r04 #3c): the reference's op sequence in fp64 with every per-node tensor
+    # rounded to bf16 where the reference materialises it (oracle/ref_torch.lcgn_seq(node_store=bf16_storage)); weights exact.
+    # What is left between it and the device is the weight pieces (two bf16 pieces: 2^-17 relative), fp32 accumulation and the
+    # roundings that flip between the two -- bounded at 2.5e-3 of the output scale for two-piece weights, 4 x tighter than the
+    # storage effect itself (~1e-2 here); single-piece weights (bf16 weights: another 2^-9 on every product) are not held to it
+    d64 = lambda v: t(v).double()
+    ref_st = R.lcgn_seq(d64(x), t(gb.edge_index), t(gb.batch), d64(q), d64(lstm), {k: v.double() for k, v in tparams(p).items()}, d64(x_ctx),
+                        node_store=R.bf16_storage).float()
+    print("lcgn bf16 pieces=%d: vs emulation %.3e, vs bf16-storage fp64 oracle %.3e, vs fp32 oracle %.3e, scale %.3e" %
+          (pieces, maxabs(out, emu), maxabs(out, ref_st), maxabs(out, ref), scale))
     assert maxabs(out, emu) < 3e-3 * max(scale, 1.0)
+    if pieces == 2:
+        assert maxabs(out, ref_st) < 2.5e-3 * max(scale, 1.0)
     assert maxabs(out, ref) < (3e-2 if pieces == 2 else 5e-2) * scale
     m32 = _load_module(lcgn_seq(300, O, 300, 5), p, dev)
     out32 = m32(*args, x_ctx_init=t(x_ctx, device=dev))
