@@ -193,6 +193,17 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         out = xc / (graph_rows(var.sqrt(), graph) + self.graph_layer_norm.eps)
         return out * self.graph_layer_norm.weight + self.graph_layer_norm.bias, e2, None
 
+    def invalidate_weight_cache(self):
+        """Drop the packed / folded / projected weight forms of the eval forward.  The cache key holds every parameter's identity,
+        storage pointer and in-place version counter, which optimizers, `load_state_dict`, `.to()` and ordinary in-place ops bump;
+        edits through `.data` (`p.data.copy_()`, EMA swaps, manual checkpoint loading) do NOT -- call this after them."""
+        self._packed = self._packed_key = self._packed_event = None
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)              # .to() / .cuda() / .float(): storages may move or be replaced
+        self.invalidate_weight_cache()
+        return out
+
     def _check_ids(self, x_tok, e_tok, added, E):
         """validate_ids: True (default) = every call, like the reference's nn.Embedding / index assignment, which raise on ANY call;
         "first" = opt-in for the loader path that never synchronises: the first 4 calls of this module only (a vocabulary / checkpoint mismatch
@@ -228,7 +239,7 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
         self._check_ids(x_tok, e_tok, added, E)
         m = self.scene_graph_encoding_layer
         p = _lib.EncoderParams()
-        keep = []
+        keep, srcs, copied = [], [], False
         for name, t in (("embedding", self.sg_vocab_embedding.weight),
                         ("edge0_weight", m.edge_model.edge_mlp[0].weight), ("edge0_bias", m.edge_model.edge_mlp[0].bias),
                         ("edge2_weight", m.edge_model.edge_mlp[2].weight), ("edge2_bias", m.edge_model.edge_mlp[2].bias),
@@ -239,24 +250,35 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
                         ("ln_weight", self.graph_layer_norm.weight), ("ln_bias", self.graph_layer_norm.bias)):
             tc = _f32c(t, name)
             keep.append(tc)
+            copied = copied or tc is not t            # a temporary (non-contiguous / non-fp32 parameter): its address says nothing next call
+            srcs.append(t)
             setattr(p, name, tc.data_ptr())
         xe = torch.empty((N, D), dtype=torch.float32, device=dev)
         ee = torch.empty((E, D), dtype=torch.float32, device=dev)
         na = 0 if added is None else int(added.numel())
         added_c = None if na == 0 else added.to(dev).contiguous()
         with torch.cuda.device(dev):
-            # call-invariant weight forms (projected table, stacked / folded / packed weights): rebuilt only when a weight tensor
-            # was replaced or modified in place (data_ptr / autograd version counter) or the projection arithmetic changed
-            key = (str(dev), lib.gvqa_get_option(_lib.OPT_PROJECTION)) + tuple((t.data_ptr(), t._version) for t in keep)
-            if getattr(self, "_packed_key", None) != key:
+            # call-invariant weight forms (projected table, stacked / folded / packed weights): rebuilt only when a PARAMETER was replaced
+            # (object identity), moved (data_ptr) or modified in place (autograd version counter), or the projection arithmetic changed.
+            # Edits through `.data` do not bump the counter: invalidate_weight_cache() after them (as gat_seq documents).  A parameter
+            # that had to be copied to contiguous fp32 is never cached (the copy's address is recycled by the allocator).
+            st = _stream(dev)
+            key = None if copied else (str(dev), lib.gvqa_get_option(_lib.OPT_PROJECTION)) + tuple((id(t), t.data_ptr(), t._version) for t in srcs)
+            if key is None or getattr(self, "_packed_key", None) != key:
                 nbytes = lib.gvqa_sg_encoder_pack_bytes(V, D)
                 packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                rc = lib.gvqa_sg_encoder_pack_weights(V, D, C.byref(p), packed.data_ptr(), nbytes, _stream(dev))
+                rc = lib.gvqa_sg_encoder_pack_weights(V, D, C.byref(p), packed.data_ptr(), nbytes, st)
                 if rc == _lib.E_UNSUPPORTED:
                     packed = None                      # shapes / settings the large-batch path does not take: nothing to cache
                 else:
                     _lib.check(rc)
                 self._packed, self._packed_key = packed, key
+                # the pack ran on THIS stream: a forward on another stream waits for it
+                self._packed_event = torch.cuda.Event()
+                self._packed_event.record(torch.cuda.current_stream(dev))
+                self._packed_stream = st
+            elif getattr(self, "_packed_stream", st) != st and getattr(self, "_packed_event", None) is not None:
+                torch.cuda.current_stream(dev).wait_event(self._packed_event)
             if self._packed is not None:
                 p.packed, p.packed_bytes = self._packed.data_ptr(), self._packed.numel()
             ws = _workspace(lib.gvqa_sg_encoder_workspace_bytes(C.byref(graph.c), D), dev)

@@ -2160,6 +2160,24 @@ def test_scene_graph_encoder_on_the_two_piece_products(dev):
         assert enc._packed is not None and enc._packed_key == key
         xe_c, ee_c, _ = _load_module(GroundTruth_SceneGraph_Encoder(V, 0, D), pe2, dev)(data)
         assert torch.equal(xe_b, xe_c) and torch.equal(ee_b, ee_c) and maxabs(xe_b, xe) > 1e-4
+        # (iv-b) ADVICE r04: an edit through .data does not bump the version counter -- the documented hook drops the cached forms;
+        # a forward on ANOTHER stream than the one that packed waits for the pack (event), and reuses the cache
+        dict(enc.named_parameters())[k2].data.mul_(2.0)
+        xe_stale, _, _ = enc(data)
+        assert torch.equal(xe_stale, xe_b)                # (the stale result: what the hook is for)
+        enc.invalidate_weight_cache()
+        pe3 = dict(pe2); pe3[k2] = (pe2[k2] * 2.0).astype(np.float32)
+        side = torch.cuda.Stream()
+        xe_d, ee_d, _ = enc(data)
+        key = enc._packed_key
+        with torch.cuda.stream(side):
+            xe_s, ee_s, _ = enc(data)
+        side.synchronize()
+        assert enc._packed_key == key
+        xe_e, ee_e, _ = _load_module(GroundTruth_SceneGraph_Encoder(V, 0, D), pe3, dev)(data)
+        assert torch.equal(xe_d, xe_e) and torch.equal(ee_d, ee_e) and torch.equal(xe_s, xe_e) and torch.equal(ee_s, ee_e)
+        dict(enc.named_parameters())[k2].data.mul_(0.5)
+        enc.invalidate_weight_cache()
         # (v) several tokens per edge: the token sums are formed first (the one-token gather inside the pack pass does not apply)
         et2 = synth.randint(E * 2, 8, 1, V, stream=3).reshape(E, 2)
         data2 = types.SimpleNamespace(x=data.x, edge_attr=t(et2, device=dev), edge_index=data.edge_index, batch=data.batch, added_sym_edge=data.added_sym_edge)
