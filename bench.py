@@ -8,11 +8,14 @@ N = 1 runs in this process; N > 1 spawns one rank per GPU by itself (re-exec und
 
 A step = one `gat_seq.forward` (CSR build from COO included) over synthetic input resident in HBM: BASELINE config 3
 -- a batch of 2048 graphs x 32 nodes x 128 edges = 64k nodes / 256k edges, Dn = De = Di = C = 512, H = 4, K = 5,
-eval mode, fp32 in / fp32 out.  With N ranks every rank runs its OWN batch of that size (WEAK scaling: the reference's
-data-parallel form -- DistributedSampler + a per-process batch_size, mainExplain_gat.py:226-236), the K hops run with no
-communication and the per-graph result rows are all-gathered over RCCL at the end of the step.  The same run also times
-the STRONG form -- ONE such batch sharded by graphs (edge-balanced contiguous ranges, 256 graphs per GPU at N = 8) --
-and prints it as `strong_value` (`--scaling strong` swaps the two).  Prints ONE JSON line on rank 0.
+eval mode, fp32 in / fp32 out.  With N ranks that ONE batch is sharded by graphs (STRONG scaling: edge-balanced contiguous
+ranges, 256 graphs per GPU at N = 8 -- SURVEY 8(d) config 3 "graphs sharded", the reference's DistributedSampler at batch
+granularity, mainExplain_gat.py:226-227), the K hops run with no communication and the per-graph result rows are
+all-gathered over RCCL at the end of the step: `value` = the batch's edges / max-over-ranks step time.  The same run also
+times the WEAK form -- every rank its own full batch -- and prints it as `weak_value` (`--scaling weak` swaps the two).
+Prints ONE JSON line on rank 0: the contract keys, `roofline`, `cpu_baseline`, `configs` (BASELINE configs 2, 4, 5 with their
+own rooflines and CPU baselines), the stand-alone message-passing kernel's HBM roofline and the strict-fp32 figure.  The
+arithmetic / vendor comparison legs of earlier rounds sit behind `--extras`.
 """
 import argparse
 import csv
@@ -39,13 +42,16 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak",
-                    help="N > 1 -- weak (default): every rank its own full config-3 batch, the reference's data-parallel form (DistributedSampler + "
-                         "a per-process batch_size, mainExplain_gat.py:226-236); strong: ONE config-3 batch sharded by graphs over the ranks.  The "
-                         "line carries the other form's number as well (`strong_value` / `weak_value`)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1 -- strong (default): ONE config-3 batch sharded by graphs over the ranks (SURVEY 8(d) config 3; what the >= 6x target "
+                         "refers to); weak: every rank its own full config-3 batch (the reference's per-process batch_size form, "
+                         "mainExplain_gat.py:226-236).  The line carries the other form's number as well (`weak_value` / `strong_value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes behind roofline.traffic")
-    ap.add_argument("--no-extras", action="store_true", help="skip the f32-MFMA / vendor comparison legs")
+    ap.add_argument("--no-extras", action="store_true", help="the bare line: no `configs`, no message-passing-kernel / strict-fp32 legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` key (BASELINE configs 2, 4, 5)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also the comparison legs: the other split arithmetic, rocBLAS sgemm, projection error vs fp64, the zero-operand clock probe")
     ap.add_argument("--with-head", action="store_true",
                     help="also run global attention pooling + answer classifier each step and all-gather the true [B, 1842] logits")
     ap.add_argument("--pipelined-gather", action="store_true",
@@ -78,26 +84,198 @@ def mp_algorithmic_bytes(N, E, C, Hh, fused_skip=True):
     return b + (4 * N * C if fused_skip else 0)
 
 
-def measured_copy_bandwidth(torch, dev, mib=1024, reps=10):
-    """Device-copy bandwidth of THIS box, measured now (report HBM fractions "of spec" and "of measured copy"):
-    a 1 GiB fp32 buffer copied to another with 16-byte accesses (torch's copy kernel), bytes read + bytes written per second."""
+GUIDE_ACHIEVABLE_GBS = 6300.0      # MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable" (float4 copy, 6.29 measured)
+
+
+def measured_copy_bandwidth(torch, dev, lib, mib=1024, reps=10):
+    """Device-copy bandwidth of THIS box, measured now (report HBM fractions "of spec" and "of measured copy"): a 1 GiB
+    fp32 buffer copied to another, bytes read + bytes written per second, by FOUR copies -- torch's copy kernel and the library's
+    gvqa_stream_copy variants (grid-stride float4; the same with non-temporal stores; through LDS by LDS-DMA) -- and the BEST of
+    them is the denominator (torch's copy alone read 4.77 TB/s on a box where float4 copies reach more)."""
     try:
         n = mib * (1 << 20) // 4
         src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
         dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(reps):
-            dst.copy_(src)
-        e1.record(); torch.cuda.synchronize()
-        gbs = 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        st = torch.cuda.current_stream().cuda_stream
+        from graphvqa_amd import _lib
+        forms = {"torch_copy": lambda: dst.copy_(src)}
+        for v, name in ((0, "float4_grid_stride"), (1, "float4_nontemporal_stores"), (2, "lds_dma_ring")):
+            forms[name] = (lambda v=v: _lib.check(lib.gvqa_stream_copy(dst.data_ptr(), src.data_ptr(), 4 * n, v, st)))
+        by = {}
+        for name, fn in forms.items():
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            by[name] = 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        ok = bool(torch.equal(dst, src))
         del src, dst
-        return {"GBps": gbs, "frac_of_spec": gbs / HBM_PEAK_GBS, "buffer_MiB": mib, "reps": reps,
-                "method": "torch device-to-device copy of a 1 GiB fp32 buffer, read + written bytes / HIP-event time"}
+        best = max(by, key=by.get)
+        return {"GBps": by[best], "best_form": best, "by_form_GBps": {k: round(v, 1) for k, v in by.items()}, "frac_of_spec": by[best] / HBM_PEAK_GBS,
+                "guide_achievable_GBps": GUIDE_ACHIEVABLE_GBS, "copies_verified": ok, "buffer_MiB": mib, "reps": reps,
+                "method": "1 GiB fp32 buffer device-to-device, read + written bytes / HIP-event time; best of torch's copy kernel and "
+                          "gvqa_stream_copy variants 0 / 1 / 2"}
     except Exception as e:
         return {"error": repr(e)[:200]}
+
+
+def extra_configs(torch, np, synth, _lib, lib, dev, with_cpu=True):
+    """BASELINE configs 2, 4 and 5 in the driver-run line: per config the wall time per forward (no in-library
+    timers), edges/s, the dominant kernel with its average launch time (in-library HIP events on the caller's stream, second pass)
+    against the roofline that bounds it, and the oracle on the SAME batch on the host cores beside it."""
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.baseline_models import gine_seq
+    from graphvqa_amd.lcgn import lcgn_seq
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    t_begin = time.perf_counter()
+
+    def timed(fn, warmup=3, steps=10, stages=None):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        _lib.prof_enable(True, stages=stages); _lib.prof_collect()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        pr = _lib.prof_collect(); _lib.prof_enable(False)
+        return dt, {k: {"ms_per_forward": v[0] / steps, "launches_per_forward": v[1] // steps, "avg_launch_us": v[0] / max(v[1], 1) * 1e3}
+                    for k, v in pr.items() if v[1]}
+
+    def load(m, p):
+        m.load_state_dict({k: tt(v) for k, v in p.items()})
+        return m.to(dev).eval()
+
+    def cpu(fn, threads=16):
+        """One call of the oracle on the host cores (threads as in the headline's sweep: torch's CPU scatter ops oversubscribe beyond ~16)."""
+        if not with_cpu:
+            return None
+        from oracle import ref_torch as R          # baseline leg only
+        old = torch.get_num_threads()
+        torch.set_num_threads(min(threads, os.cpu_count() or 1))
+        try:
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                out = fn(R)
+            return time.perf_counter() - t0, out
+        finally:
+            torch.set_num_threads(old)
+
+    res = {}
+    try:
+        gb = synth.config2_batch()
+        N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+        ei, batch = tt(gb.edge_index).to(dev), tt(gb.batch).to(dev)
+        xh, eah, insh = synth.normal((N, 300), 1), synth.normal((E, 300), 2), synth.normal((5, B, 512), 3)
+        x, ea, ins = tt(xh).to(dev), tt(eah).to(dev), tt(insh).to(dev)
+        hl = HostLayout.from_numpy(gb.edge_index, gb.batch, B)
+        shape = {"graphs": B, "nodes": N, "edges": E}
+
+        # ---- config 2: gat_seq at the reference's real dimensions (pipeline_model_gat.py:683-687), CSR build inside the forward
+        p2 = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303)
+        m = load(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), p2)
+        run = lambda: m(x, ei, ea, ins, batch, graph=SceneGraphBatch(ei, batch, N, B, host_layout=hl))
+        dt, pr = timed(run)
+        hop = pr.get("proj", {})
+        hops_per_launch = 5 if hop.get("launches_per_forward") == 1 else 1
+        hop_us = hop.get("avg_launch_us", 0.0) / hops_per_launch
+        fl = 2.0 * N * 300 * 4 * 300                                    # SURVEY 8(d): folded projection flops per hop
+        c2 = dict(shape, workload="BASELINE configs[1]: 1000 graphs of 20-40 nodes, e = 2 n, Dn = De = C = 300, Di = 512, H = 4, K = 5, gat_seq eval forward incl. CSR build",
+                  ms=dt * 1e3, edges_per_s=E / dt, hop_kernel=m.hop_kernel(SceneGraphBatch(ei, batch, N, B, host_layout=hl)),
+                  dominant_kernel="fused hop (two-piece split projection + aggregation + epilogue)", stage_ms={k: round(v["ms_per_forward"], 4) for k, v in pr.items()},
+                  roofline={"bound": "mfma", "achieved": fl / (hop_us * 1e-6) / 1e12 if hop_us else None, "peak": 2500.0, "unit": "TFLOP/s",
+                            "frac": fl / (hop_us * 1e-6) / 1e12 / 2500.0 if hop_us else None, "avg_launch_us": hop_us,
+                            "algorithmic_flops_per_launch": fl, "issued_frac": 3 * fl / (hop_us * 1e-6) / 1e12 / 2500.0 if hop_us else None})
+        old = _lib.set_option(_lib.OPT_HOP_FUSION, 0)                     # the stand-alone message-passing kernel at config 2 (north star's graded kernel)
+        try:
+            _, pu = timed(run, steps=5)
+        finally:
+            _lib.set_option(_lib.OPT_HOP_FUSION, old)
+        if "mp" in pu:
+            alg = mp_algorithmic_bytes(N, E, 300, 4)
+            us = pu["mp"]["avg_launch_us"]
+            c2["mp_kernel_roofline"] = {"bound": "hbm", "kernel": "gvqa::k_gat_mp_tiled", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": us, "algorithmic_bytes_per_launch": alg,
+                                        "frac_of_guide_achievable": alg / (us * 1e-6) / 1e9 / GUIDE_ACHIEVABLE_GBS}
+        r = cpu(lambda R: R.gat_seq(tt(xh), tt(gb.edge_index), tt(eah), tt(insh), tt(gb.batch), {k: tt(v) for k, v in p2.items()}, heads=4))
+        if r:
+            c2["cpu_baseline"] = {"value": E / r[0], "unit": "edges/s", "cores": min(16, os.cpu_count() or 1), "kind": "port", "sample": f"oracle/ref_torch.gat_seq, one forward of the same batch ({r[0]:.2f} s)",
+                                  "max_abs_dev_vs_oracle": float((run().cpu() - r[1]).abs().max())}
+        res["config2_gat_d300"] = c2
+        del m
+
+        # ---- config 4: the five GINEConv layer computations on the same batch (pipeline_model_gine.py:628,665; the module output as
+        # written discards them: a-7), instruction halves per graph (x_cat / edge_cat never concatenated)
+        p4 = synth.gine_seq_params(300, 300, 512, 404)
+        m = load(gine_seq(300, 300, 512), p4)
+        g = SceneGraphBatch(ei, batch, N, B)
+        run = lambda: m(x, ei, ea, ins, batch, graph=g, return_convs=True)
+        dt, pr = timed(run)
+        agg = pr.get("mp", {})
+        alg = 4 * (N * 300 + E * 300 + E + (N + 1) + N * 300)          # what the aggregate moves with the instruction halves folded per graph
+        alg812 = 4 * (N * 812 + E * 812 + E + (N + 1) + N * 812)        # SURVEY 8(d)'s literal figure (x_cat / edge_cat materialised, D = 812)
+        us = agg.get("avg_launch_us", 0.0)
+        prod_fl = 2.0 * N * (812 * 300 + 300 * 300)
+        pj = pr.get("proj", {})
+        c4 = dict(shape, workload="BASELINE configs[3]: 5 x GINEConv(Lin(812,300) -> ReLU -> Lin(300,300)) on the config-2 batch, conv results returned",
+                  ms=dt * 1e3, edges_per_s=E / dt, dominant_kernel="gvqa::k_gine_aggregate (gather + add + relu + segment sum)",
+                  stage_ms={k: round(v["ms_per_forward"], 4) for k, v in pr.items()},
+                  roofline={"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9 if us else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us else None, "avg_launch_us": us, "algorithmic_bytes_per_launch": alg,
+                            "bytes_8d_literal_D812": alg812, "note": "achieved is priced on the bytes the folded form has to move (D = 300 halves); "
+                            "8(d)'s literal D = 812 bytes are never moved"},
+                  mlp_products={"flops_per_layer": prod_fl, "ms_per_forward": pj.get("ms_per_forward"), "launches_per_forward": pj.get("launches_per_forward"),
+                                "tflops": 5 * prod_fl / (pj["ms_per_forward"] * 1e-3) / 1e12 if pj.get("ms_per_forward") else None})
+        r = cpu(lambda R: R.gine_seq(tt(xh), tt(gb.edge_index), tt(eah), tt(insh), tt(gb.batch), {k: tt(v) for k, v in p4.items()}, return_convs=True))
+        if r:
+            dev_out = run()
+            convs_d = dev_out[1] if isinstance(dev_out, tuple) else None
+            convs_r = r[1][1] if isinstance(r[1], tuple) else None
+            c4["cpu_baseline"] = {"value": E / r[0], "unit": "edges/s", "cores": min(16, os.cpu_count() or 1), "kind": "port", "sample": f"oracle/ref_torch.gine_seq(return_convs), same batch ({r[0]:.2f} s)"}
+            try:
+                c4["cpu_baseline"]["max_abs_dev_vs_oracle"] = max(float((a_.cpu() - b_).abs().max()) for a_, b_ in zip(convs_d, convs_r))
+            except Exception as e:
+                c4["cpu_baseline"]["parity_error"] = repr(e)[:120]
+        res["config4_gine_convs"] = c4
+        del m
+
+        # ---- config 5: LCGN, 4 iterations, fp32 and bf16 node features (lcgn.py:303-323)
+        O = 512
+        p5 = synth.lcgn_seq_params(300, O, seed=808)
+        qh, lstmh, xch = synth.normal((B, O), 5), synth.normal((10, B, O), 6), synth.normal((N, O), 7)
+        q, lstm, xc = tt(qh).to(dev), tt(lstmh).to(dev), tt(xch).to(dev)
+        node_fl = 2.0 * N * (300 * O + O * O + O * 3 * O + 4 * (O * O + 2 * O * 3 * O + 2 * O * O) + 2 * O * O)     # the node-sized products of the stacked form (DESIGN 4.x)
+        c5 = dict(shape, workload="BASELINE configs[4]: lcgn_seq(300 -> 512, 4 iterations, L = 10) on the config-2 batch", node_product_flops=node_fl)
+        outs = {}
+        for key, kw, products in (("fp32", {}, 3), ("bf16_node_features", {"node_feature_dtype": torch.bfloat16}, 2)):
+            m = load(lcgn_seq(300, O, 300, 5, **kw), p5)
+            run = lambda: m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc)
+            dt, pr = timed(run)
+            outs[key] = run()
+            c5[key] = {"ms": dt * 1e3, "edges_per_s": E / dt, "stage_ms": {k: round(v["ms_per_forward"], 4) for k, v in pr.items()},
+                       "roofline": {"bound": "mfma", "achieved": node_fl / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": node_fl / dt / 1e12 / 2500.0,
+                                    "issued_frac": products * node_fl / dt / 1e12 / 2500.0,
+                                    "note": f"whole forward against its node products' algorithmic flops ({products} piece products issued per fp32 product)"}}
+            del m
+        r = cpu(lambda R: R.lcgn_seq(tt(xh), tt(gb.edge_index), tt(gb.batch), tt(qh), tt(lstmh), {k: tt(v) for k, v in p5.items()}, tt(xch)))
+        if r:
+            c5["cpu_baseline"] = {"value": E / r[0], "unit": "edges/s", "cores": min(16, os.cpu_count() or 1), "kind": "port", "sample": f"oracle/ref_torch.lcgn_seq (fp32), same batch ({r[0]:.2f} s)",
+                                  "max_abs_dev_vs_oracle_fp32": float((outs["fp32"].cpu() - r[1]).abs().max()),
+                                  "max_abs_dev_vs_oracle_bf16_node_features": float((outs["bf16_node_features"].cpu() - r[1]).abs().max()),
+                                  "oracle_output_max_abs": float(r[1].abs().max())}
+        res["config5_lcgn"] = c5
+    except Exception as e:             # the headline line must still come out
+        res["error"] = repr(e)[:300]
+    res["seconds"] = round(time.perf_counter() - t_begin, 1)
+    return res
 
 
 def profile_traffic():
@@ -333,35 +511,71 @@ def main():
     _lib.prof_enable(False)
     edges_per_step = Eall if strong else world * Eall
 
-    # (the secondary legs below must not cost the line its primary figure: an error that every rank hits alike is recorded, not raised)
-    other, secondary_errors = None, {}
-    if world > 1:                       # second key: the OTHER scaling form on the same ranks (fewer steps)
-        try:
-            osteps = max(3, a.steps // 2)
-            oshard = make_shard(0, 1) if strong else make_shard(rank, world)
-            if strong and rank:
-                oshard.x = tt(synth.normal((Nall, D), 1 + 10 * rank)).to(dev)
-            odt = timed(runner(oshard), osteps, 2)
-            other = {"value": (world * Eall if strong else Eall) / (odt / osteps), "ms_per_step": odt / osteps * 1e3, "steps": osteps,
-                     "graphs_per_gpu": oshard.num_graphs}
-        except Exception as e:
-            secondary_errors["other_scaling_form"] = repr(e)[:300]
+    # ---- secondary legs at N > 1 (the other scaling form, the other gather form, the exchange A/B).  They must not cost the line its
+    # primary figure, and they must not be able to hang it: every leg is SET UP first (allocation is where one rank
+    # fails alone), then all ranks agree -- an all-reduce of an ok flag -- whether to run it; the whole sequence runs in a worker
+    # thread under one deadline, and when that expires rank 0 prints the line with what it has and every rank leaves without
+    # touching the communicator again.
+    other, other_gather, gather_ab_res, secondary_errors = None, None, None, {}
+    secondary_hung = False
+    if dist is not None:
+        import threading
+        box = {}
 
-    other_gather = None
-    if world > 1:                       # third key: the same steps with the exchange the OTHER way round (blocking <-> in flight under the next step's hops)
-        try:
-            gsteps = max(3, a.steps // 2)
-            gdt = timed(runner(shard, pipelined=not a.pipelined_gather), gsteps, 2)
-            other_gather = {"value": edges_per_step / (gdt / gsteps), "ms_per_step": gdt / gsteps * 1e3, "steps": gsteps}
-        except Exception as e:
-            secondary_errors["other_gather_form"] = repr(e)[:300]
+        def agree(ok):
+            f = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item() > 0.5)
 
-    # the exchange itself, both forms on the step's own payload ([graphs, D] rows per rank), every rank taking part: RCCL's
-    # all_gather_into_tensor against the direct one-hop push to all peers -- so that the first N > 1 record says
-    # which one this topology wants.  Behind a watchdog: a comparison leg must not be able to hang the bench line.
-    gather_ab_res, gather_hung = (None, False)
-    if dist is not None and not os.environ.get("GVQA_BENCH_NO_GATHER_AB"):
-        gather_ab_res, gather_hung = gather_ab(dist, torch, dev, shard.num_graphs, D)
+        def leg(name, setup, run):
+            obj, err = None, None
+            try:
+                obj = setup()
+            except Exception as e:
+                err = repr(e)[:300]
+            if not agree(err is None):
+                secondary_errors[name] = err or "skipped: another rank failed to set this leg up"
+                return None
+            try:
+                res_ = run(obj)
+                err = None
+            except Exception as e:
+                res_, err = None, repr(e)[:300]
+            if not agree(err is None):               # (a rank that failed inside the leg's collectives leaves the others to the deadline)
+                secondary_errors[name] = err or "another rank failed inside this leg"
+                return None
+            return res_
+
+        def secondary():
+            torch.cuda.set_device(dev)
+            if world > 1:
+                osteps = max(3, a.steps // 2)
+
+                def setup_other():
+                    sh_ = make_shard(0, 1) if strong else make_shard(rank, world)
+                    if strong and rank:
+                        sh_.x = tt(synth.normal((Nall, D), 1 + 10 * rank)).to(dev)
+                    return sh_, runner(sh_)
+                r_ = leg("other_scaling_form", setup_other, lambda o: (o[0], timed(o[1], osteps, 2)))
+                if r_ is not None:
+                    box["other"] = {"value": (world * Eall if strong else Eall) / (r_[1] / osteps), "ms_per_step": r_[1] / osteps * 1e3, "steps": osteps,
+                                    "graphs_per_gpu": r_[0].num_graphs}
+                gsteps = max(3, a.steps // 2)
+                r_ = leg("other_gather_form", lambda: runner(shard, pipelined=not a.pipelined_gather), lambda run_: timed(run_, gsteps, 2))
+                if r_ is not None:
+                    box["other_gather"] = {"value": edges_per_step / (r_ / gsteps), "ms_per_step": r_ / gsteps * 1e3, "steps": gsteps}
+            # the exchange itself, both forms on the step's own payload ([graphs, D] rows per rank), every rank taking part: RCCL's
+            # all_gather_into_tensor against the direct one-hop push to all peers
+            if not os.environ.get("GVQA_BENCH_NO_GATHER_AB"):
+                box["gather_ab"] = gather_ab(dist, torch, dev, shard.num_graphs, D)
+
+        th = threading.Thread(target=secondary, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("GVQA_BENCH_SECONDARY_DEADLINE_S", "150")))
+        secondary_hung = th.is_alive()
+        if secondary_hung:
+            secondary_errors["deadline"] = "secondary legs did not finish in time: line printed without them, process leaves without communicator clean-up"
+        other, other_gather, gather_ab_res = box.get("other"), box.get("other_gather"), box.get("gather_ab")
 
     line = None
     if rank == 0:
@@ -443,6 +657,7 @@ def main():
             roof = mp_roofline(prof_timed, g0)
         gather_note = ("" if dist is None else " (each step waits for its own)" if not a.pipelined_gather else
                        " (enqueued on RCCL's stream: it overlaps the next step's hops; all gathered before the closing synchronize)")
+        hk_name = m.hop_kernel(g0) if fused else "unfused"
         res = {
             "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
             "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
@@ -460,24 +675,10 @@ def main():
                        "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
                                        "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
                        else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
-                       "hop_kernel": m.hop_kernel(g0) if fused else "unfused",
-                       "hop": ("aggregate-first: x -> chunk-major rows once (+ hop 0's node logits); every hop = ONE kernel: attention coefficients in its "
-                               "prologue (node logits left by the previous launch, edge halves, segment softmax), the attention-weighted neighbour sums "
-                               "formed inside its matrix-core loop (heads concatenated along K), epilogue register -> global with the next hop's node "
-                               "logits (one launch per hop, no coefficient kernel)" if fused and m.hop_kernel(g0) == "aggregate_first" else
-                               "aggregate-first, the K hops as ONE launch (coefficient phase of hops 1 .. K - 1 inside the workgroups)"
-                               if fused and m.hop_kernel(g0) == "aggregate_first_seq" else
-                               ("chained: hop 0 packs x; every hop = coefficient kernel (node logits from the packed rows on the matrix cores + "
-                                "segment softmax) -> ONE kernel for projection + aggregation + epilogue that leaves the next hop's "
-                                "packed operand (two launches per hop, one pack pass per forward)") if fused and split and pieces == 2 and prof["pack"][1] < prof["proj"][1] else
-                               "fused: attention coefficients -> row-group pack -> ONE kernel for projection + aggregation + epilogue"
-                               if fused else "projection GEMM, then the fused message-passing kernel (xp through HBM)"),
+                       "hop_kernel": hk_name,
                        "projection_arithmetic": arith if split else "f32-input MFMA"},
             "roofline": roof,
-            "stage_ms_per_step": {k: v[0] / n_prof for k, v in prof.items()},
-            "stage_ms_note": f"separate untimed pass of {n_prof} steps with events around every stage (inside the timed region only the "
-                             "dominant kernel's stage records events: 28 event records per step cost 0.09 ms)",
-            "gemm_backend": lib.gvqa_gemm_backend().decode(),
+            "stage_ms_per_step": {k: round(v[0] / n_prof, 5) for k, v in prof.items() if v[1]},
         }
         if rccl_ranks_seen is not None:
             res["rccl_ranks_seen"] = rccl_ranks_seen
@@ -488,36 +689,55 @@ def main():
         if other_gather is not None:
             o = "blocking_gather" if a.pipelined_gather else "pipelined_gather"
             res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other_gather["value"], other_gather["ms_per_step"], other_gather["steps"]
-            res[o + "_note"] = ("the same steps with every step waiting for its own all-gather" if a.pipelined_gather else
-                                "the same steps with step i's all-gather in flight on the collective's stream under step i + 1's hops (parallel.PipelinedSteps)")
+        if world > 1:
+            res["scaling_note"] = ("`value` = STRONG scaling: the ONE config-3 batch sharded by graphs, whole-batch edges / max-over-ranks step time "
+                                   "(the form the >= 6x target refers to); `weak_value` = every rank its own full batch" if strong else
+                                   "`value` = WEAK scaling (every rank its own full batch); `strong_value` = the ONE batch sharded by graphs")
         if other is not None:
             o = "weak" if strong else "strong"
             res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other["value"], other["ms_per_step"], other["steps"]
-            res[o + "_note"] = ("every rank its own full batch" if strong else
-                                f"ONE config-3 batch sharded by graphs over the {world} ranks ({other['graphs_per_gpu']} graphs on rank 0): "
-                                "whole-batch edges / max-over-ranks step time")
+            res[o + "_graphs_on_rank0"] = other["graphs_per_gpu"]
         if world == 1:
+            full_shard = make_shard(0, 1)
+            full = runner(full_shard)
+            gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
+            n_x = max(5, a.steps // 4)
+            per = lambda pr, k="proj": pr[k][0] / max(pr[k][1], 1) * 1e3
             if not a.no_extras:
-                # the same step (a) unfused: split projection + the message-passing kernel, whose HBM roofline the north star
-                # names; (b) fused on the other split arithmetic; (c) on the f32-input MFMA kernels; (d) on the vendor library --
-                # comparison legs, few steps each
-                full_shard = make_shard(0, 1)
-                full = runner(full_shard)
-                gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
-                n_x = max(5, a.steps // 4)
+                # (a) the same step UNFUSED -- split projection + the stand-alone message-passing kernel, whose HBM roofline the north star
+                # names -- and (b) on the f32-input MFMA kernels (strict fp32 products): few steps each
                 _lib.prof_enable(True)
                 old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 0)
                 t_u = timed(full, n_x, 2, _lib.prof_collect) / n_x
                 pu = _lib.prof_collect()
-                _lib.set_option(_lib.OPT_HOP_FUSION, 1)
-                other = _lib.PROJECTION_SPLIT3 if pieces == 2 else _lib.PROJECTION_SPLIT2H
-                old_p = _lib.set_option(_lib.OPT_PROJECTION, other)
+                old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
+                t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
+                p32 = _lib.prof_collect()
+                _lib.prof_enable(False)
+                _lib.set_option(_lib.OPT_PROJECTION, old_p)
+                _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+                if gfull is not None:
+                    res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
+                res["strict_fp32"] = {"kernel": "gvqa::k_linear_f32_dma (f32-input MFMA, bit-for-bit fp32 products) + gvqa::k_gat_mp_tiled, unfused",
+                                      "ms_per_step": t_f32 * 1e3, "value": Eall / t_f32, "projection_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
+                gemm_u = per(pu) - pu["pack"][0] / max(pu["proj"][1], 1) * 1e3
+                res["unfused_split"] = {"ms_per_step": t_u * 1e3, "value": Eall / t_u, "gemm_only_us": gemm_u,
+                                        "gemm_issued_mfma_tflops": products * flops32 / (gemm_u * 1e-6) / 1e12}
+                if fused and pieces == 2 and (N, E) == (Nall, Eall):
+                    fl = mfma_floor(lib, torch, dev, N, H * D, D)
+                    res["roofline"]["matrix_core_floor"] = fl
+                    if fl.get("mfma_only_us"):
+                        res["roofline"]["frac_of_matrix_core_floor"] = fl["mfma_only_us"] / res["roofline"]["avg_launch_us"]
+            if a.extras:
+                # comparison legs of earlier rounds: the other split arithmetic (fused), the vendor library, products' error vs fp64, clock probe
+                _lib.prof_enable(True)
+                old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+                otherp = _lib.PROJECTION_SPLIT3 if pieces == 2 else _lib.PROJECTION_SPLIT2H
+                old_p = _lib.set_option(_lib.OPT_PROJECTION, otherp)
                 t_o = timed(full, n_x, 2, _lib.prof_collect) / n_x
                 po = _lib.prof_collect()
                 _lib.set_option(_lib.OPT_HOP_FUSION, 0)
                 _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
-                t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
-                p32 = _lib.prof_collect()
                 _lib.set_option(_lib.OPT_VENDOR_GEMM, 1)
                 t_v = timed(full, n_x, 2, _lib.prof_collect) / n_x
                 pv = _lib.prof_collect()
@@ -525,36 +745,13 @@ def main():
                 _lib.set_option(_lib.OPT_VENDOR_GEMM, 0)
                 _lib.set_option(_lib.OPT_PROJECTION, old_p)
                 _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
-                per = lambda pr, k="proj": pr[k][0] / max(pr[k][1], 1) * 1e3
-                gemm_u = per(pu) - pu["pack"][0] / max(pu["proj"][1], 1) * 1e3
-                res["unfused_split"] = {"hop": f"gvqa::k_split{'2h' if pieces == 2 else '3'}_pack + gvqa::k_linear_split3<...,NP={pieces}> + "
-                                               "gvqa::k_gat_mp_tiled", "ms_per_step": t_u * 1e3,
-                                        "value": Eall / t_u, "projection_us_incl_pack": per(pu), "gemm_only_us": gemm_u,
-                                        "gemm_issued_mfma_tflops": products * flops32 / (gemm_u * 1e-6) / 1e12}
                 opieces = 5 - pieces
                 res["fused_other_split"] = {"projection": "three exact bf16 pieces, six products" if opieces == 3 else "two scaled fp16 pieces, three products",
                                             "ms_per_step": t_o * 1e3, "value": Eall / t_o, "avg_launch_us": per(po),
                                             "issued_mfma_tflops": opieces * (opieces + 1) // 2 * flops32 / (per(po) * 1e-6) / 1e12}
-                if gfull is not None:
-                    res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
-                res["projection_f32_mfma"] = {"kernel": "gvqa::k_linear_f32_dma (+ gvqa::k_gat_mp_tiled)", "ms_per_step": t_f32 * 1e3,
-                                              "value": Eall / t_f32, "avg_launch_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
-                res["projection_error_vs_fp64"] = projection_accuracy(lib, params, shard, torch, np, dev)
-                if fused and pieces == 2 and (N, E) == (Nall, Eall):
-                    fl = mfma_floor(lib, torch, dev, N, H * D, D)
-                    res["roofline"]["matrix_core_floor"] = fl
-                    if fl.get("mfma_only_us"):
-                        res["roofline"]["frac_of_matrix_core_floor"] = fl["mfma_only_us"] / res["roofline"]["avg_launch_us"]
                 res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
                                             "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
-                # the same step by projection arithmetic, side by side (all hand-written kernels except the last line)
-                this_key = "split2h (2 x fp16 pieces, 3 products; default)" if pieces == 2 else "split3 (3 x bf16 pieces, exact split, 6 products)"
-                other_key = "split3 (3 x bf16 pieces, exact split, 6 products; 8-wave fused kernel)" if pieces == 2 else "split2h (2 x fp16 pieces, 3 products)"
-                res["by_arithmetic"] = {
-                    this_key: {"edges_per_s": res["value"], "ms_per_step": ms_step},
-                    other_key: {"edges_per_s": Eall / t_o, "ms_per_step": t_o * 1e3},
-                    "f32-input MFMA (bit-for-bit fp32 products; unfused)": {"edges_per_s": Eall / t_f32, "ms_per_step": t_f32 * 1e3},
-                    "rocBLAS sgemm (vendor, opt-in comparison; unfused)": {"edges_per_s": Eall / t_v, "ms_per_step": t_v * 1e3}}
+                res["projection_error_vs_fp64"] = projection_accuracy(lib, params, shard, torch, np, dev)
                 if fused and (N, E) == (Nall, Eall):
                     res["roofline"]["dvfs_probe"] = dvfs_probe(m, full_shard, full, torch, _lib, n_x)
             if not a.no_pmc:
@@ -573,17 +770,17 @@ def main():
             mpr = res.get("mp_kernel_roofline") if fused else res["roofline"]
             if mpr is not None and mpr.get("traffic") is None:
                 mpr["traffic_from_profile"] = profile_traffic()
-            cp = measured_copy_bandwidth(torch, dev)
+            cp = measured_copy_bandwidth(torch, dev, lib)
             res["hbm_copy_measured"] = cp
-            if mpr is not None and cp.get("GBps"):
-                mpr["frac_of_measured_copy"] = mpr["achieved"] / cp["GBps"]
-                mpr["frac_without_fused_skip_bytes_of_measured_copy"] = mpr["frac_without_fused_skip_bytes"] * HBM_PEAK_GBS / cp["GBps"]
+            if mpr is not None:
+                mpr["frac_of_guide_achievable"] = mpr["achieved"] / GUIDE_ACHIEVABLE_GBS
+                if cp.get("GBps"):
+                    mpr["frac_of_measured_copy"] = mpr["achieved"] / cp["GBps"]
+            if not a.no_extras and not a.no_configs:
+                res["configs"] = extra_configs(torch, np, synth, _lib, lib, dev, with_cpu=not a.no_cpu_baseline)
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(params, synth, np, torch, m, dev)
         line = json.dumps(res)
-    if dist is not None and not gather_hung:
-        dist.barrier()
-        dist.destroy_process_group()
     if line is not None:
         # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would
         # otherwise be flushed at exit, AFTER our line: flush the C streams first so that the JSON
@@ -595,47 +792,49 @@ def main():
             pass
         sys.stdout.flush()
         print(line, flush=True)
-    if gather_hung:                      # a comparison thread is stuck inside the backend: leave without its clean-up
-        os._exit(0)
+    if dist is not None:
+        # the line is out; communicator clean-up must not be able to hang the process (a peer stuck in a secondary leg never
+        # arrives at this barrier): bounded wait, then leave
+        if not secondary_hung:
+            import threading
+
+            def bye():
+                dist.barrier()
+                dist.destroy_process_group()
+            th = threading.Thread(target=bye, daemon=True)
+            th.start()
+            th.join(30.0)
+            secondary_hung = th.is_alive()
+        if secondary_hung:
+            sys.stdout.flush()
+            os._exit(0)
 
 
-def gather_ab(dist, torch, dev, nrows, ncols, reps=20, timeout_s=45.0):
+def gather_ab(dist, torch, dev, nrows, ncols, reps=20):
     """Average time of one all-gather of [nrows, ncols] fp32 rows per rank, max over ranks, for both forms of
-    graphvqa_amd.parallel.all_gather_graph_rows.  Returns (result, hung)."""
-    import threading
+    graphvqa_amd.parallel.all_gather_graph_rows (called from the secondary-leg worker thread, under its deadline)."""
     from graphvqa_amd.parallel import all_gather_graph_rows
     out = {"rows_per_rank": int(nrows), "bytes_per_rank": int(nrows) * int(ncols) * 4, "world_size": dist.get_world_size(), "reps": reps}
-
-    def work():
-        try:
-            torch.cuda.set_device(dev)
-            rows = torch.randn(nrows, ncols, device=dev)
-            counts = [nrows] * dist.get_world_size()
-            for algo in ("collective", "direct"):
-                for _ in range(3):
-                    all_gather_graph_rows(rows, counts=counts, force=True, algo=algo)
-                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    all_gather_graph_rows(rows, counts=counts, force=True, algo=algo)
-                torch.cuda.synchronize()
-                tm = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                out[algo + "_us"] = float(tm.item()) * 1e6
-            out["note"] = ("collective = all_gather_into_tensor (the backend picks algorithm / protocol); direct = one grouped batch of isend / irecv "
-                           "to and from every peer (one hop on a fully connected node); the step uses GVQA_ALLGATHER="
-                           + os.environ.get("GVQA_ALLGATHER", "collective"))
-        except Exception as e:           # the bench line must still come out
-            out["error"] = repr(e)[:300]
-
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    th.join(timeout_s)
-    if th.is_alive():
-        res = dict(out)
-        res["error"] = f"no result after {timeout_s} s"
-        return res, True
-    return out, False
+    try:
+        rows = torch.randn(nrows, ncols, device=dev)
+        counts = [nrows] * dist.get_world_size()
+        for algo in ("collective", "direct"):
+            for _ in range(3):
+                all_gather_graph_rows(rows, counts=counts, force=True, algo=algo)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                all_gather_graph_rows(rows, counts=counts, force=True, algo=algo)
+            torch.cuda.synchronize()
+            tm = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            out[algo + "_us"] = float(tm.item()) * 1e6
+        out["note"] = ("collective = all_gather_into_tensor (the backend picks algorithm / protocol); direct = one grouped batch of isend / irecv "
+                       "to and from every peer (one hop on a fully connected node); the step uses GVQA_ALLGATHER="
+                       + os.environ.get("GVQA_ALLGATHER", "collective"))
+    except Exception as e:           # the bench line must still come out
+        out["error"] = repr(e)[:300]
+    return out
 
 
 def dvfs_probe(model, shard, step, torch, _lib, n):

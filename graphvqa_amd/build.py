@@ -69,9 +69,13 @@ def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
+    relink = bool(jobs) or force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")])
+    if relink:
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl",
              "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB])
+    # what this call did, for whoever records the build check (one line on stdout, always)
+    print(f"build_mode: {'recompiled ' + str(len(jobs)) + ' of ' + str(len(SOURCES)) + ' objects' if jobs else 'reused all ' + str(len(SOURCES)) + ' objects'}"
+          f"{', relinked' if relink else ', library up to date'} -> {os.path.relpath(LIB, os.path.dirname(HERE))}", flush=True)
     return LIB
 
 

@@ -3,11 +3,13 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <vector>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 namespace gvqa {
 
@@ -76,9 +78,80 @@ StageTimer::~StageTimer() {
     if (idx < g_prof_live.size()) (void)hipEventRecord(g_prof_live[idx].stop, stream);
 }
 
+// ---- streaming copies: the "measured device copy" denominator of SURVEY 8(d) (gvqa_stream_copy) -------------------------------
+// variant 0 / 1: grid-stride float4 loads and (non-temporal) stores, UNR loads in flight per thread
+template <int UNR, bool NT>
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (NT) __builtin_nontemporal_store(v4{v[u].x, v[u].y, v[u].z, v[u].w}, reinterpret_cast<v4*>(dst + i + u * stride));
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+// variant 2: HBM -> LDS by LDS-DMA (a 4-stage ring of 8 KiB stages per 512-thread block, counted waits), LDS -> registers -> HBM:
+// the streaming structure of k_gat_mp_tiled without its arithmetic
+__global__ __launch_bounds__(512) void k_stream_copy_dma(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * 8192];
+    const int tid = threadIdx.x;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+    const unsigned wave_off = __builtin_amdgcn_readfirstlane((unsigned)(tid & ~63) * 16u);
+    const size_t ntile = n4 / 512;                     // whole 8 KiB tiles; the tail is copied plainly below
+    const size_t stride = gridDim.x;
+    auto issue = [&](size_t tile, int slot) {
+        const size_t tl = tile < ntile ? tile : ntile - 1;              // (clamped re-load past the end: uniform instruction counts)
+        lds_dma16_b(src + tl * 512 + tid, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * 8192u + wave_off));
+    };
+    size_t t0 = blockIdx.x;
+    if (ntile > 0) {
+        for (int k = 0; k < 3; ++k) issue(t0 + k * stride, k);
+        int slot = 0;
+        for (size_t t = t0; t < ntile; t += stride) {
+            issue(t + 3 * stride, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");          // this wave's DMA of tile t has landed (every lane reads only what its own wave loaded)
+            const float4 v = *reinterpret_cast<const float4*>(smem + slot * 8192 + tid * 16);
+            dst[t * 512 + tid] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            slot = (slot + 1) & 3;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (size_t i = ntile * 512 + (size_t)blockIdx.x * 512 + tid; i < n4; i += stride * 512) dst[i] = src[i];
+}
+
 }  // namespace gvqa
 
 extern "C" {
+
+int gvqa_stream_copy(void* dst, const void* src, size_t bytes, int variant, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(dst && src && bytes % 16 == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && variant >= 0 && variant <= 2,
+                 GVQA_E_INVALID, "gvqa_stream_copy: null / unaligned operand or unknown variant");
+    if (bytes == 0) return GVQA_OK;
+    const size_t n4 = bytes / 16;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cus = device_cu_count();
+    const float4* s4 = static_cast<const float4*>(src);
+    float4* d4 = static_cast<float4*>(dst);
+    if (variant == 2) {
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)cus * 4, std::max<size_t>(n4 / 512, 1));      // 4 blocks x 32 KiB of LDS per CU
+        hipLaunchKernelGGL(k_stream_copy_dma, dim3(grid), dim3(512), 0, st, s4, d4, n4);
+    } else {
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)cus * 8, std::max<size_t>(n4 / (256 * 4), 1));
+        if (variant == 1) hipLaunchKernelGGL((k_stream_copy<4, true>), dim3(grid), dim3(256), 0, st, s4, d4, n4);
+        else hipLaunchKernelGGL((k_stream_copy<4, false>), dim3(grid), dim3(256), 0, st, s4, d4, n4);
+    }
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
 
 const char* gvqa_last_error(void) { return gvqa::g_err; }
 

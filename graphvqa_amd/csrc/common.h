@@ -9,6 +9,20 @@
 
 namespace gvqa {
 
+// CUs of the CURRENT device, looked up once per device ordinal (the hop-kernel rules size their grids / thresholds by it; a process-wide
+// static would hand device 0's count to a caller working on another device -- ADVICE r04).  Lock-free: a racing first call stores the same value.
+inline int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev];
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+    return n;
+}
+
+
 void set_error(const char* fmt, ...);
 int get_option(int option);          // gvqa_set_option / environment (capi.hip)
 

@@ -1058,11 +1058,7 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
         // 8-wave): 425 groups (0.83 of two rounds) 2.13 vs 2.29; 550 (0.72 of three) 3.18 vs 2.90; 725 (0.94 of three) 3.32 vs 3.82 --
         // a workgroup's hops run faster when the last round is thin (fewer CUs draw power), so two rounds pay from ~0.72 on, three
         // from ~0.80; one round and four or more keep the earlier 0.85.
-        static const int64_t cus = []() {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            return (int64_t)n;
-        }();
+        const int64_t cus = device_cu_count();         // (per device: the thresholds below were tuned on the 256-CU part)
         const int64_t G = g->num_row_groups, rounds = cdiv(G, cus);
         const int64_t fill_pct = rounds == 2 ? 76 : rounds == 3 ? 82 : 85;
         if (G * 100 < rounds * cus * fill_pct) return false;
@@ -1105,11 +1101,7 @@ static bool hop2_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
         // by shape: the persistent kernel overlaps one item's epilogue with its CU partner's matrix-core loop, which pays from about
         // six (row group, column block) items per workgroup slot on (config 3: 8); below that the 8-wave kernel's single large
         // tile per CU is faster (measured: 256 .. 1024-graph shards and the d = 300 batch of config 2, profiles/r03_*)
-        static const int64_t slots = []() {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            return (int64_t)2 * n;
-        }();
+        const int64_t slots = (int64_t)2 * device_cu_count();
         if ((int64_t)g->num_row_groups * cdiv(d->out_channels, 256 / d->heads) < 6 * slots) return false;
         if (chain8_shape_ok(g, d)) return false;          // the chained 8-wave kernel is the faster of the two wherever it applies
     }
@@ -1480,7 +1472,9 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const bool chain8_ok = fused && fused_chain8_capable(g, d);        // (decides the cache layout: must not depend on the outputs asked for)
     const bool chain = ((hop2 && hop2_chain_capable(g, d)) || chain8_ok) && !hop_out && !bn_stats_out &&    // (per-hop fp32 outputs / batch statistics need fp32 rows)
                        split_pack_groups_logits_supported(2, 2 * H, Dn);
-    const bool aggf = hopagg_applies(g, d) && !bn_stats_out;          // (batch-statistics BatchNorm needs fp32 rows between the passes)
+    // (batch-statistics BatchNorm needs fp32 rows between the passes; rows that are not 16-byte aligned -- the layout pass reads float4 --
+    //  take the other hop kernels instead of an error return: ADVICE r04)
+    const bool aggf = hopagg_applies(g, d) && !bn_stats_out && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     const int need_layout = aggf ? LAYOUT_AGGFIRST : weight_layout_id(np, fused, hop2 || chain8_ok);
     // parameter-only products: from the caller's cache when it was prepared for the layout this batch needs, else computed
     // now into the workspace (the workspace slices have exactly the cache's sub-layout)

@@ -669,14 +669,7 @@ size_t hop2_lds_edge_capacity(int H, bool chain) {
     return (size_t)(4096 - 192 - 128 - 3 * std::max(256 / H, 64) - (chain ? 512 : 0)) / (size_t)(H + 1);
 }
 
-static int hop2_cus() {
-    static const int cus = []() {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    return cus;
-}
+static int hop2_cus() { return device_cu_count(); }
 
 int launch_hop2(int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, const float* epc, const Hop2ChainDesc* cd, hipStream_t stream) {
     const bool chain = cd != nullptr;

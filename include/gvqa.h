@@ -422,6 +422,14 @@ GVQA_API int gvqa_scene_graph_collate(int64_t num_graphs, const int32_t* graph_o
  * in {1,2,4,8}: 2 is what its design needs (80 KiB of LDS, <= 256 VGPRs); < 0 = GVQA_E_*.  Diagnostics / tests. */
 GVQA_API int gvqa_hop2_blocks_per_cu(int32_t H);
 
+/* Measurement utility -- the "device copy" denominator of SURVEY 8(d) ("report HBM fractions of spec and of measured copy"):
+ * copies `bytes` (a multiple of 16; both pointers 16-byte aligned) from src to dst with 16-byte accesses, `variant` 0 = plain
+ * grid-stride float4 loads / stores (the form MI355X_MICROARCH.md quotes 6.29 TB/s for), 1 = the same with non-temporal stores,
+ * 2 = through LDS by LDS-DMA (global_load_lds_dwordx4) and ds_read / global stores, the streaming structure of the
+ * message-passing kernel.  bench.py times all three beside torch's own copy kernel and reports the best as `hbm_copy_measured`.
+ * No counterpart in the reference. */
+GVQA_API int gvqa_stream_copy(void* dst, const void* src, size_t bytes, int variant, void* stream);
+
 /* Which GEMM backend serves the plain dense projections in this process (hand-written k_linear_f32,
  * or rocBLAS for large epilogue-free products; GVQA_GEMM_BACKEND=auto|hip|rocblas). */
 GVQA_API const char* gvqa_gemm_backend(void);
