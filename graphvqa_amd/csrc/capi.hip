@@ -37,6 +37,7 @@ static void options_init() {
     g_opt[GVQA_OPT_HOP_FUSION] = env_int("GVQA_HOP_FUSION", 3);
     g_opt[GVQA_OPT_COEFF_KERNEL] = 0;
     g_opt[GVQA_OPT_MP_PARTS] = 0;
+    g_opt[GVQA_OPT_HOP_COEFFS] = env_int("GVQA_HOP_COEFFS", 0);
 }
 int get_option(int option) {
     std::call_once(g_opt_once, options_init);

@@ -168,6 +168,21 @@ struct FusedHopArgs {
     const float* ch_bc;         // [4] bound constants of this hop (launch_hop2_bound_consts)
     const int32_t* ch_graph_ptr;
     int ch_B, ch_KB;
+    // ... with the attention coefficients computed INSIDE the hop kernel (CHN = 2; ic_a_edge != NULL): no coefficient kernel, no alpha_csr.
+    // The node logits of this hop arrive as `ic_parts_in` partial sets [part][N][2 H] (hop 0: one set, from the pack pass; later hops: one
+    // per column block of the previous hop, whose epilogue left ic_lp_out = its rows . Vn_next over its own channels) and are summed
+    // per row group in the kernel; the edge halves are gathered through csr_eid; leaky-relu + segment softmax per (node, head) in LDS.
+    const int32_t* ic_csr_eid;  // [E] COO edge id of CSR slot s
+    const float* ic_a_edge;     // edge halves of this hop's logits: ic_a_edge[eid * ic_a_edge_stride + h]
+    int64_t ic_a_edge_stride;
+    const float* ic_lp_in;      // [ic_parts_in][N][2 H] partial node logits of this hop
+    int ic_parts_in;
+    int64_t ic_lp_stride;       // floats between two partial sets (N * 2 H)
+    float* ic_lp_out;           // NULL (last hop) or [ncb][N][2 H]: the NEXT hop's partial node logits, this column block's set
+    const float* ic_vn_next;    // [2 H][C] folded attention vectors of the next hop (gat_skip.py:134-135 folded into the weights)
+    const float* ic_pmin;       // NULL (first hop) or [ic_parts_in][B]: per-graph maxima of this hop's input rows by column block
+    float* ic_alpha_out;        // NULL or [E, H] (COO order): the attention weights, written by column block 0
+    float ic_slope;
     int xcd_cols;               // column blocks per XCD of the workgroup -> tile map (1: plain launch order)
     int debug;                  // measurement aid (GVQA_FUSED_DEBUG bit mask): 1 no row image, 2 no aggregation, 4 no store, 8 no epilogue at all
 };
@@ -185,6 +200,7 @@ struct Hop2ChainDesc;
 int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream,
                            const Hop2ChainDesc* cd = nullptr);
 size_t hop_fused_chain_lds_edge_capacity(int H);
+size_t hop_fused_ic_lds_edge_capacity(int H);
 // hop2.hip: the same hop as a persistent kernel, two 4-wave workgroups per CU (two-piece operands, half-interleaved weights)
 int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 // cd != NULL: chained hop -- skip rows come out of the packed input; with cd->Pnext the output leaves as the next hop's packed

@@ -1081,11 +1081,17 @@ static bool hopagg_seq_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // box: 391 vs 415 us per hop at config 3, forward 2.40 vs 2.51 ms; config 2's d = 300 batch 0.72 -> 0.69 ms; a 256-graph shard
 // loses its 12 us pack pass per hop).  H = 4 -- the head-interleaved weight rows then ARE the half-interleaved ones of the persistent
 // kernel: one cache layout, id 7, serves both.  Shape conditions (the batch-level ones are hop_fusion_applies'):
+// In-kernel attention coefficients for the chained 8-wave hops (k_linear_split3<..., CHN = 2>, GVQA_OPT_HOP_COEFFS): both row groups'
+// CSR slices resident in LDS at once
+static bool chain8_in_kernel_coeffs(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    return get_option(GVQA_OPT_HOP_COEFFS) != 0 && d->heads == 4 && (size_t)g->max_row_group_edges <= hop_fused_ic_lds_edge_capacity(4);
+}
 static bool chain8_shape_ok(const gvqa_graph* g, const gvqa_gat_dims* d) {
     // (below ~128 row groups every launch of a hop is latency-bound and the chained coefficient kernel -- it reads the packed rows
     //  through the matrix cores -- costs more than the pack pass it replaces: 0.428 vs 0.413 ms on a 256-graph shard; GVQA_OPT_HOP_FUSION
-    //  = 1 / 2 ask for a kernel explicitly and chain regardless)
-    if (opt_hop_fusion(d) == 3 && g->num_row_groups < 128) return false;
+    //  = 1 / 2 ask for a kernel explicitly and chain regardless.  With the coefficients computed inside the hop kernel there is no
+    //  coefficient kernel to pay for: chained at every size)
+    if (opt_hop_fusion(d) == 3 && g->num_row_groups < 128 && !chain8_in_kernel_coeffs(g, d)) return false;
     return d->heads == 4 && d->node_dim == d->out_channels &&
            proj_pieces(d, g->num_nodes, (int64_t)d->heads * d->out_channels, d->node_dim) == 2 &&
            (size_t)g->max_row_group_edges <= hop_fused_chain_lds_edge_capacity(d->heads) &&
@@ -1162,7 +1168,7 @@ static WeightCacheLayout weight_cache_layout(const gvqa_gat_dims* d, int layout)
 }
 
 struct SeqLayout {
-    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, ipk, ipk_hop, x4a, x4b, gma, gmb, total;   // a6b ..: chained hops; x4a ..: aggregate-first hops
+    size_t Vn, Ve, Gw, T, a_edge, a_node, xp, h0, h1, alpha_csr, bn_partial, bn_stats, a6, w6, a6b, PM, Tmax, gscale, ipk, ipk_hop, x4a, x4b, gma, gmb, lp0, lp1, total;   // a6b ..: chained hops; x4a ..: aggregate-first hops
 };
 
 static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims* d, const gvqa_graph* g = nullptr) {
@@ -1205,6 +1211,10 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
         L.x4a = take(x4); L.x4b = take(x4);
         L.gma = take(aggf ? (size_t)B : 0); L.gmb = take(aggf ? (size_t)B : 0);
     }
+    // in-kernel coefficients: the next hop's partial node logits by column block, two buffers (a hop reads one, writes the other)
+    const bool ic_lp = chain && chain8 && chain8_in_kernel_coeffs(g, d);
+    L.lp0 = take(ic_lp ? ncb * (size_t)N * 2 * H : 0);
+    L.lp1 = take(ic_lp ? ncb * (size_t)N * 2 * H : 0);
     L.Tmax = take(chain ? K * (size_t)B : 0);
     L.gscale = take(chain ? (size_t)B : 0);
     // packed instruction vectors of the K hops (two-piece graph-term product): one image of K B rows, a hop = B / 32 whole
@@ -1619,6 +1629,8 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     }
     char* a6 = base + L.a6;
     const int ncb_chain = (int)cdiv(C, fcw);
+    // chained 8-wave hops with the attention coefficients computed inside the hop kernel (CHN = 2): no coefficient launch at all
+    const bool ic = chain && chain8_ok && !hop2 && chain8_in_kernel_coeffs(g, d);
     const float* h = x;
     bool aux_pending = ss != nullptr;                 // the side stream's pre-hop work has not been joined yet
     for (int i = 0; i < K; ++i) {
@@ -1657,7 +1669,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
             a.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
             a.alpha_csr = P(L.alpha_csr);
             a.N = (int)N; a.C = C; a.slope = d->negative_slope;
-            {   // (when the logits ride on the pack pass, it ran above, before the coefficients; chained hops: the coefficient kernel
+            if (!ic) {   // (when the logits ride on the pack pass, it ran above, before the coefficients; chained hops: the coefficient kernel
                 //  computes the logits itself from the packed rows the previous hop left)
                 StageTimer t(GVQA_STAGE_ALPHA, stream);
                 ChainScaleArgs cs;
@@ -1704,6 +1716,22 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                     cd.Tmax = Di > 0 ? P(L.Tmax) + (size_t)i * B : nullptr;
                     cd.bc = reinterpret_cast<const float*>(wbase + WL.bc) + 4 * i;
                     cd.graph_ptr = g->graph_ptr; cd.B = (int)B; cd.N = (int)N;
+                    if (ic) {
+                        // hop 0: ONE set of node logits, from the pack pass; hop i > 0: one set per column block of hop i - 1.  Output
+                        // scales of hops 1 .. K - 2 from the per-graph maxima hop i - 1 left (PMin), inside the kernel.
+                        cd.gscale = nullptr;
+                        f.alpha_csr = nullptr;
+                        f.ic_csr_eid = g->csr_eid;
+                        f.ic_a_edge = a.a_edge; f.ic_a_edge_stride = a.a_edge_stride;
+                        f.ic_lp_in = i == 0 ? P(L.a_node) : P((i & 1) ? L.lp1 : L.lp0);
+                        f.ic_parts_in = i == 0 ? 1 : ncb_chain;
+                        f.ic_lp_stride = (int64_t)N * 2 * H;
+                        f.ic_lp_out = i < K - 1 ? P((i & 1) ? L.lp0 : L.lp1) : nullptr;
+                        f.ic_vn_next = i < K - 1 ? Vn_all + (int64_t)(i + 1) * 2 * H * Dn : nullptr;
+                        f.ic_pmin = (i > 0 && i < K - 1) ? cd.PMin : nullptr;
+                        f.ic_alpha_out = a.alpha_out;
+                        f.ic_slope = d->negative_slope;
+                    }
                 }
                 rc = hop2 ? launch_hop2(Dn, a6, w6 + (size_t)i * w6_hop, f, reinterpret_cast<const float*>(wbase + WL.epc + (size_t)i * WL.epc_hop),
                                         chain ? &cd : nullptr, stream)

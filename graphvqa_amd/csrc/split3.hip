@@ -152,6 +152,13 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     static_assert(EPI != 2 || (WM == 2 && WN == 4 && TM == 4 && TN == 2), "the fused-hop epilogue is written for the 256 x 256 tile");
     static_assert(CHN == 0 || (EPI == 2 && NP == 2 && FH == 4), "chained epilogue: fused hop, two-piece operands, H = 4");
     constexpr bool CH = CHN != 0;
+    // CHN = 2: ... and the hop's attention coefficients are computed IN this kernel (no coefficient kernel, no alpha_csr round trip):
+    // partial node logits (left by the previous hop's column blocks / the pack pass) summed per row group, edge halves gathered through
+    // csr_eid, leaky-relu + segment softmax per (node, head) in LDS between the main loop and the row image (gat_skip.py:180-190); the
+    // epilogue leaves the NEXT hop's partial node logits of this column block (its finished rows . Vn_next over its own channels).
+    constexpr bool IC = CHN == 2;
+    constexpr unsigned IC_VN0 = 141 * 1024;            // (IC) [2 H][64] slice of the next hop's folded attention vectors: between the two 13 KiB regions
+    constexpr unsigned IC_NG0 = 143 * 1024;            // (IC) [2][128] graph ids of the two groups' nodes
     constexpr unsigned CH_TAIL = 160 * 1024 - 3072;    // (CH) per group: inverse scales of the input slots | output scales by graph | output maxima by graph
     __shared__ __attribute__((aligned(1024))) unsigned char smem[EPI == 2 ? 160 * 1024 : NBUF * STAGE * KS];
 
@@ -229,7 +236,8 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     // 16 KiB, group 0's lives in [144, 160 KiB) -- outside the operand ring, so it is filled during the main loop -- and group
     // 1's in [128, 144 KiB), filled while group 0 is aggregated; otherwise one region at 128 KiB is used twice.
     const int src_off = 192, al_off = src_off + ((fh.e_cap + 63) & ~63);
-    const int reg_words = al_off + ((fh.e_cap * Hh + 63) & ~63);
+    const int eid_off = al_off + ((fh.e_cap * Hh + 63) & ~63);          // (IC) the slots' COO edge ids
+    const int reg_words = eid_off + (IC ? ((fh.e_cap + 63) & ~63) : 0);
     const bool two_regions = EPI == 2 && (CH ? reg_words * 4 <= 13 * 1024 : 2 * reg_words * 4 <= 32 * 1024);      // (CH: the last 3 KiB are taken)
     // a thread of the epilogue owns CV adjacent channel quads (8 channels when the head slice is >= 64 wide: the edge loop is
     // issue-bound, and its index / coefficient / address work is then shared by twice the FMAs) of `items` rows
@@ -252,14 +260,20 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const int n_rp = g_cnt[gi] + 1, n_src = g_ne[gi], n_al = g_ne[gi] * Hh;
         const int32_t* rp_g = fh.rowptr + g_ns[gi];
         const int32_t* src_g = fh.csr_src + g_e0[gi];
-        const float* al_g = fh.alpha_csr + (int64_t)g_e0[gi] * Hh;
+        [[maybe_unused]] const float* al_g = IC ? nullptr : fh.alpha_csr + (int64_t)g_e0[gi] * Hh;
         const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
         for (int u = wbase; u < n_rp; u += NTH)
             lds_dma4_b(rp_g + min(u + lane, n_rp - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)u * 4u));
         for (int u = wbase; u < n_src; u += NTH)
             lds_dma4_b(src_g + min(u + lane, n_src - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(src_off + u) * 4u));
-        for (int u = wbase; u < n_al; u += NTH)
-            lds_dma4_b(al_g + min(u + lane, n_al - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(al_off + u) * 4u));
+        if constexpr (IC) {                                   // (the coefficients are made here: the slots' edge ids instead)
+            const int32_t* eid_g = fh.ic_csr_eid + g_e0[gi];
+            for (int u = wbase; u < n_src; u += NTH)
+                lds_dma4_b(eid_g + min(u + lane, n_src - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(eid_off + u) * 4u));
+        } else {
+            for (int u = wbase; u < n_al; u += NTH)
+                lds_dma4_b(al_g + min(u + lane, n_al - 1), __builtin_amdgcn_readfirstlane(base + (unsigned)(al_off + u) * 4u));
+        }
     };
     if constexpr (EPI == 2) {
 #pragma unroll
@@ -287,6 +301,24 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         }
         // older than every ring DMA: the counted waits of the main loop only get stricter by them, never wrong
         if (two_regions && g_cnt[0] > 0 && !GVQA_FH_DBG(8)) dma_region(0, 144 * 1024);
+        if constexpr (IC) {
+            // both groups' regions are needed together (the coefficient phase runs before the first row image): the second one and the
+            // next hop's folded-vector slice of this column block also start now -- [128, 144 KiB) is above the operand ring
+            if (g_cnt[1] > 0) dma_region(1, 128 * 1024);
+            if (wave >= 4 && wave < 8) {      // the nodes' graph ids (instruction-term offsets, output scales and maxima are per graph) and input-slot scales
+                const int gi = (wave - 4) >> 1, u = ((wave - 4) & 1) * 64;
+                if (g_cnt[gi] > 0) {
+                    lds_dma4_b(fh.node_graph + g_ns[gi] + min(u + lane, g_cnt[gi] - 1), __builtin_amdgcn_readfirstlane(lds_base + IC_NG0 + (unsigned)(gi * 128 + u) * 4u));
+                    lds_dma4_b(fh.ch_a_inv + (bm * 2 + gi) * 128 + u + lane, __builtin_amdgcn_readfirstlane(lds_base + CH_TAIL + (unsigned)(gi * 1536 + u * 4)));
+                }
+            }
+            if (tid < 256) reinterpret_cast<unsigned*>(smem + CH_TAIL + (tid >> 7) * 1536 + 1024)[tid & 127] = 0u;      // the groups' output maxima
+            if (fh.ic_lp_out && wave < 2) {
+                const int j = (wave * 64 + lane) >> 4, part = lane & 15;
+                lds_dma16_b(fh.ic_vn_next + (int64_t)j * fh.C + min(bn * cw + part * 4, fh.C - 4),
+                            __builtin_amdgcn_readfirstlane(lds_base + IC_VN0 + (unsigned)wave * 1024u));
+            }
+        }
     }
     // Rows of a group are aggregated in the order fh.row_order gives (most in-edges first: the edge loop's trip count is the
     // largest in-degree among the rows a wave covers, so rows of similar degree belong together).  Slot -> row for this
@@ -515,8 +547,183 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const float inv_h = 1.0f / Hh;
         const bool relu = fh.bn_w != nullptr;
         __syncthreads();                                      // main loop done: operand ring free
+        if constexpr (IC) {
+            // ---- attention coefficients of both row groups (gat_skip.py:180-190), in LDS.  Every wave's DMAs have landed (the main
+            // loop's last wait is vmcnt(0)) and the barrier above made them visible: rowptr | src | eid of both groups and their nodes'
+            // graph ids are in place.  ALL global reads of the phase -- edge halves through the edge ids, partial node logits, per-graph
+            // logit offsets -- are issued before the first one is consumed: one memory latency for the phase, not one per read (the
+            // first version of this phase ran gather, sums and offsets one after the other, group by group: +9 us per workgroup).
+            float* an_s = reinterpret_cast<float*>(smem);     // [2][128][2 H] node logits, in the free operand ring
+            if (!GVQA_FH_DBG(32)) {
+            const int* ng_l = reinterpret_cast<const int*>(smem + IC_NG0);
+            const int r = tid >> 2, hq = tid & 3;             // thread (row r, head hq) of the softmax
+            const int sg = tid >> 8, sr = (tid & 255) >> 1, sh = tid & 1;     // thread (group sg, row sr, logit half sh) of the partial sums
+            constexpr int SPT = 2;                            // slots per thread and group: the capacity is 522 edges <= 2 x 512
+            float4 ae[2][SPT];
+            int eidv[2][SPT];
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int* eid_w = reinterpret_cast<const int*>(smem + (gi == 0 ? 144 * 1024 : 128 * 1024)) + eid_off;
+#pragma unroll
+                for (int k = 0; k < SPT; ++k) eidv[gi][k] = eid_w[min(tid + k * NTH, max(g_ne[gi] - 1, 0))];
+            }
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int k = 0; k < SPT; ++k)
+                    ae[gi][k] = (tid + k * NTH < g_ne[gi]) ? *reinterpret_cast<const float4*>(fh.ic_a_edge + (int64_t)eidv[gi][k] * fh.ic_a_edge_stride)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            float tl[2] = {0.f, 0.f};
+            if (fh.graph_term) {
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+                    if (r < g_cnt[gi]) tl[gi] = fh.graph_term[(int64_t)ng_l[gi * 128 + r] * fh.t_ld + fh.C + hq];
+            }
+            // output scales of the rows this hop leaves (packed), one power of two per graph: thread (group tid >> 7, graph tid & 127 of the group)
+            [[maybe_unused]] const int zg = tid >> 7, zt = tid & 127;
+            [[maybe_unused]] int z_gf = 0, z_ngl = 0;
+            float zM = 0.f, ztm = 0.f;
+            float4 zbc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool z_on = fh.ch_pnext != nullptr && tid < 256 && (zg == 0 ? g_cnt[0] : g_cnt[1]) > 0;
+            if (z_on) {
+                const int cnt_z = zg == 0 ? g_cnt[0] : g_cnt[1], ns_z = zg == 0 ? g_ns[0] : g_ns[1];
+                z_gf = ng_l[zg * 128];
+                z_ngl = ng_l[zg * 128 + cnt_z - 1] - z_gf + 1;
+                if (zt < z_ngl) {
+                    const int g = z_gf + zt;
+                    if (fh.ic_pmin) {                          // the graph's largest INPUT magnitude as the previous hop's column blocks left it
+                        for (int q = 0; q < fh.ic_parts_in; ++q) zM = fmaxf(zM, fh.ic_pmin[(int64_t)q * fh.ch_B + g]);
+                    } else {                                   // first hop: from the input slots' scales (M = 2^14 / the smallest one)
+                        const float* rinv_z = reinterpret_cast<const float*>(smem + CH_TAIL + zg * 1536);
+                        const int r0 = max(fh.ch_graph_ptr[g] - ns_z, 0), r1 = min(fh.ch_graph_ptr[g + 1] - ns_z, cnt_z);
+                        for (int rr_ = r0; rr_ < r1; ++rr_) zM = fmaxf(zM, rinv_z[rr_]);
+                        zM *= 16384.f;
+                    }
+                    ztm = fh.ch_tmax ? fh.ch_tmax[g] : 0.f;
+                    zbc = make_float4(fh.ch_bc[0], fh.ch_bc[1], fh.ch_bc[2], fh.ch_bc[3]);
+                }
+            }
+            float4 sum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            {   // node logits: the partial sets summed in a fixed order (deterministic)
+                const int cnt_s = sg == 0 ? g_cnt[0] : g_cnt[1], ns_s = sg == 0 ? g_ns[0] : g_ns[1];
+                if (sr < cnt_s) {
+                    const float* lp = fh.ic_lp_in + (int64_t)(ns_s + sr) * 8 + sh * 4;
+                    if (fh.ic_parts_in == 8) {                // (C = 512: all eight reads in flight together)
+                        float4 v4[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v4[q] = *reinterpret_cast<const float4*>(lp + (int64_t)q * fh.ic_lp_stride);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { sum4.x += v4[q].x; sum4.y += v4[q].y; sum4.z += v4[q].z; sum4.w += v4[q].w; }
+                    } else {
+                        for (int q = 0; q < fh.ic_parts_in; ++q) {
+                            const float4 v4 = *reinterpret_cast<const float4*>(lp + (int64_t)q * fh.ic_lp_stride);
+                            sum4.x += v4.x; sum4.y += v4.y; sum4.z += v4.z; sum4.w += v4.w;
+                        }
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(an_s + (sg * 128 + sr) * 8 + sh * 4) = sum4;
+            if (z_on && zt < z_ngl) {
+                //   |out| <= max|BN scale| (M (max L1 norm of a weight row + 1) + max|instruction term| + max|bias|) + max|BN shift|   (hop2.hip)
+                const float bound = (zbc.y * (zM * (zbc.x + 1.f) + ztm + zbc.w) + zbc.z) * 1.001f;
+                reinterpret_cast<float*>(smem + CH_TAIL + zg * 1536)[128 + zt] = pow2i(split2h_exponent(bound));
+            }
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                float* al_w = reinterpret_cast<float*>(smem + (gi == 0 ? 144 * 1024 : 128 * 1024)) + al_off;
+#pragma unroll
+                for (int k = 0; k < SPT; ++k)
+                    if (tid + k * NTH < g_ne[gi]) *reinterpret_cast<float4*>(al_w + (tid + k * NTH) * 4) = ae[gi][k];
+            }
+            __syncthreads();
+            // leaky-relu + segment softmax of (row r, head hq) of BOTH groups: the first 8 in-edges of a row branch-free in registers
+            // (clamped slots, masked afterwards: every LDS read of a stage issued together, the two groups' chains interleaved), further
+            // ones through the region in LDS
+            {
+                constexpr int DR = 8;
+                float v[2][DR], ar2[2], mx2[2] = {-INFINITY, -INFINITY};
+                int lo2[2], dg2[2];
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int* rp_w = reinterpret_cast<const int*>(smem + (gi == 0 ? 144 * 1024 : 128 * 1024));
+                    const bool on_r = r < g_cnt[gi];
+                    const int rr_ = on_r ? r : 0;
+                    lo2[gi] = rp_w[rr_] - g_e0[gi];
+                    dg2[gi] = on_r ? min(rp_w[rr_ + 1] - g_e0[gi], g_ne[gi]) - lo2[gi] : 0;
+                    ar2[gi] = an_s[(gi * 128 + rr_) * 8 + 4 + hq] + tl[gi];
+                }
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int* rp_w = reinterpret_cast<const int*>(smem + (gi == 0 ? 144 * 1024 : 128 * 1024));
+                    const int* src_w = rp_w + src_off;
+                    const float* al_w = reinterpret_cast<const float*>(rp_w + al_off);
+                    const float* an_g = an_s + gi * 128 * 8;
+                    const int last = max(lo2[gi] + dg2[gi] - 1, 0);
+                    int sn[DR];
+#pragma unroll
+                    for (int e = 0; e < DR; ++e) sn[e] = min(max(src_w[min(lo2[gi] + e, last)] - g_ns[gi], 0), 127);
+#pragma unroll
+                    for (int e = 0; e < DR; ++e) {
+                        const float raw = an_g[sn[e] * 8 + hq] + al_w[min(lo2[gi] + e, last) * 4 + hq];
+                        float t_ = raw + ar2[gi];
+                        t_ = t_ > 0.f ? t_ : t_ * fh.ic_slope;
+                        v[gi][e] = e < dg2[gi] ? t_ : -INFINITY;
+                        mx2[gi] = fmaxf(mx2[gi], v[gi][e]);
+                    }
+                }
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int* rp_w = reinterpret_cast<const int*>(smem + (gi == 0 ? 144 * 1024 : 128 * 1024));
+                    const int* src_w = rp_w + src_off;
+                    float* al_w = reinterpret_cast<float*>(const_cast<int*>(rp_w) + al_off);
+                    const int* eid_w = rp_w + eid_off;
+                    const float* an_g = an_s + gi * 128 * 8;
+                    const int lo = lo2[gi], hi = lo + dg2[gi];
+                    for (int sl = lo + DR; sl < hi; ++sl) {   // (rows with more than 8 in-edges)
+                        const float raw = an_g[min(max(src_w[sl] - g_ns[gi], 0), 127) * 8 + hq] + al_w[sl * 4 + hq];
+                        float t_ = raw + ar2[gi];
+                        t_ = t_ > 0.f ? t_ : t_ * fh.ic_slope;
+                        al_w[sl * 4 + hq] = t_;
+                        mx2[gi] = fmaxf(mx2[gi], t_);
+                    }
+                    float den = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DR; ++e) {
+                        v[gi][e] = e < dg2[gi] ? __expf(v[gi][e] - mx2[gi]) : 0.f;
+                        den += v[gi][e];
+                    }
+                    for (int sl = lo + DR; sl < hi; ++sl) {
+                        const float ex = __expf(al_w[sl * 4 + hq] - mx2[gi]);
+                        al_w[sl * 4 + hq] = ex;
+                        den += ex;
+                    }
+                    den += 1e-16f;                           // torch_geometric.utils.softmax
+                    const float rden = 1.0f / den;
+#pragma unroll
+                    for (int e = 0; e < DR; ++e)
+                        if (e < dg2[gi]) {
+                            const float al = v[gi][e] * rden;
+                            al_w[(lo + e) * 4 + hq] = al;
+                            if (fh.ic_alpha_out && bn == 0) fh.ic_alpha_out[(int64_t)eid_w[lo + e] * 4 + hq] = al;
+                        }
+                    for (int sl = lo + DR; sl < hi; ++sl) {
+                        const float al = al_w[sl * 4 + hq] * rden;
+                        al_w[sl * 4 + hq] = al;
+                        if (fh.ic_alpha_out && bn == 0) fh.ic_alpha_out[(int64_t)eid_w[sl] * 4 + hq] = al;
+                    }
+                }
+            }
+            __syncthreads();                                  // coefficients in place; an_s (in the ring) is free for the row image
+            if (z_on) {                                       // the next operand's inverse slot scales (every column block writes the same values)
+                const int cnt_z = zg == 0 ? g_cnt[0] : g_cnt[1];
+                const float* gscl_z = reinterpret_cast<const float*>(smem + CH_TAIL + zg * 1536) + 128;
+                fh.ch_a_inv_next[(bm * 2 + zg) * 128 + zt] = zt < cnt_z ? 1.0f / gscl_z[ng_l[zg * 128 + zt] - z_gf] : 1.f;
+            }
+            }
+        } else {
         if (two_regions) { if (g_cnt[1] > 0) dma_region(1, 128 * 1024); }
         else if (g_cnt[0] > 0) dma_region(0, 128 * 1024);
+        }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             const int ns = g_ns[gi], cnt = g_cnt[gi], e0 = g_e0[gi];
@@ -546,7 +753,13 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             [[maybe_unused]] int gf = 0, ngl = 0;
             [[maybe_unused]] const int grp = bm * 2 + gi;
             [[maybe_unused]] const bool chain_out = CH && fh.ch_pnext != nullptr;
-            if constexpr (CH) {
+            if constexpr (IC) {
+                if (live) {                                   // (graph ids, input-slot scales and cleared maxima came in before the main loop)
+                    const int* ng_g = reinterpret_cast<const int*>(smem + IC_NG0) + gi * 128;
+                    gf = ng_g[0];
+                    ngl = ng_g[cnt - 1] - gf + 1;
+                }
+            } else if constexpr (CH) {
                 if (live) {
                     gf = fh.node_graph[ns];
                     ngl = fh.node_graph[ns + cnt - 1] - gf + 1;
@@ -574,13 +787,17 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 // first hop of a chain: the output rows' power-of-two scale per graph from an upper bound of their magnitudes (hop2.hip):
                 //   |out| <= max|BN scale| (M (max L1 norm of a weight row + 1) + max|instruction term| + max|bias|) + max|BN shift|,
                 // M = 2^14 / (smallest input scale of the graph's rows); later hops get their scales from the coefficient kernel
-                if (live && chain_out && !fh.ch_gscale) {       // (block-uniform)
+                if (!IC && live && chain_out && !fh.ch_gscale) {       // (block-uniform; IC: decided in the coefficient phase, for both groups)
                     if (tid < ngl) {
                         const int g = gf + tid;
                         const int r0 = max(fh.ch_graph_ptr[g] - ns, 0), r1 = min(fh.ch_graph_ptr[g + 1] - ns, cnt);
                         float M = 0.f;
-                        for (int r = r0; r < r1; ++r) M = fmaxf(M, rinv_l[r]);
-                        M *= 16384.f;
+                        if (IC && fh.ic_pmin) {                // the graph's largest INPUT magnitude as the previous hop's column blocks left it
+                            for (int q = 0; q < fh.ic_parts_in; ++q) M = fmaxf(M, fh.ic_pmin[(int64_t)q * fh.ch_B + g]);
+                        } else {
+                            for (int r = r0; r < r1; ++r) M = fmaxf(M, rinv_l[r]);
+                            M *= 16384.f;
+                        }
                         const float tm = fh.ch_tmax ? fh.ch_tmax[g] : 0.f;
                         const float bound = (fh.ch_bc[1] * (M * (fh.ch_bc[0] + 1.f) + tm + fh.ch_bc[3]) + fh.ch_bc[2]) * 1.001f;
                         gscl_l[tid] = pow2i(split2h_exponent(bound));
@@ -729,6 +946,34 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                             *reinterpret_cast<uint4*>(dstp) = __builtin_bit_cast(uint4, p0);
                             *reinterpret_cast<uint4*>(dstp + 512) = __builtin_bit_cast(uint4, p1);
                             if (row_on) atomicMax(&gmax_l[gq - gf], __float_as_uint(mxv));      // (bit patterns of non-negative floats order like integers)
+                        }
+                    }
+                    if constexpr (IC) {
+                        if (fh.ic_lp_out && !GVQA_FH_DBG(16)) {                    // (block-uniform; whole waves are here: the shuffles below are safe)
+                            // the next hop's node logits, this column block's share: a_node[node, j] += sum_c h_next[node, c] Vn_next[j, c]
+                            // over the thread's 8 channels, then the row's 8 lanes meet by a transposed reduction (lane cq ends up with j = cq)
+                            const float* vn_l = reinterpret_cast<const float*>(smem + IC_VN0) + cq * 8;
+                            float pl[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float4 va = *reinterpret_cast<const float4*>(vn_l + j * 64), vb = *reinterpret_cast<const float4*>(vn_l + j * 64 + 4);
+                                pl[j] = (rr[0].x * va.x + rr[0].y * va.y) + (rr[0].z * va.z + rr[0].w * va.w) +
+                                        ((rr[1].x * vb.x + rr[1].y * vb.y) + (rr[1].z * vb.z + rr[1].w * vb.w));
+                            }
+                            float s1[4], s2[2];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float mine = (cq & 4) ? pl[4 + k] : pl[k], other = (cq & 4) ? pl[k] : pl[4 + k];
+                                s1[k] = mine + __shfl_xor(other, 4, 64);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const float mine = (cq & 2) ? s1[2 + k] : s1[k], other = (cq & 2) ? s1[k] : s1[2 + k];
+                                s2[k] = mine + __shfl_xor(other, 2, 64);
+                            }
+                            const float mine = (cq & 1) ? s2[1] : s2[0], other = (cq & 1) ? s2[0] : s2[1];
+                            const float tot = mine + __shfl_xor(other, 1, 64);
+                            if (row_on) fh.ic_lp_out[(int64_t)bn * fh.ic_lp_stride + (int64_t)node * 8 + cq] = tot;
                         }
                     }
                 };
@@ -1696,10 +1941,16 @@ int launch_split_pack_heads2(int H, int C, int cw, int64_t K, const float* W, in
 // edges of one row group the fused epilogue can hold in LDS beside the 128 KiB row image
 size_t hop_fused_lds_edge_capacity(int H) { return (size_t)(8192 - 192 - 128) / (size_t)(H + 1); }      // 32 KiB of words, padded sub-arrays
 size_t hop_fused_chain_lds_edge_capacity(int H) { return (size_t)(8192 - 768 - 192 - 128) / (size_t)(H + 1); }      // (3 KiB of the 32 hold the chain's per-group arrays)
+// in-kernel coefficients (CHN = 2): BOTH groups' regions [rowptr | src | raw logits -> alpha | eid] resident at once, 13 KiB each (sub-arrays padded to 64 words)
+size_t hop_fused_ic_lds_edge_capacity(int H) {
+    size_t e = (size_t)(13 * 256 - 192) / (size_t)(H + 2);
+    while (e > 0 && 192 + 2 * ((e + 63) & ~(size_t)63) + ((e * H + 63) & ~(size_t)63) > 13 * 256) --e;
+    return e;
+}
 
 int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, const FusedHopArgs& f, hipStream_t stream, const Hop2ChainDesc* cd) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "hop_fused: 2 or 3 pieces");
-    GVQA_REQUIRE(Apk && Bpk && f.out && f.group_ptr && f.rowptr && f.csr_src && f.alpha_csr && f.node_graph, GVQA_E_INVALID,
+    GVQA_REQUIRE(Apk && Bpk && (f.out || (cd && cd->Pnext)) && f.group_ptr && f.rowptr && f.csr_src && (f.alpha_csr || f.ic_a_edge) && f.node_graph, GVQA_E_INVALID,
                  "hop_fused: null operand");
     GVQA_REQUIRE(f.H * f.cw == 256 && f.C % 4 == 0 && f.cw % 4 == 0 && (f.cw & (f.cw - 1)) == 0, GVQA_E_UNSUPPORTED,
                  "hop_fused: needs H in {1,2,4,8} and C %% 4 == 0");
@@ -1734,12 +1985,19 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
         f2.ch_a_inv_next = cd->Pnext ? reinterpret_cast<float*>(static_cast<char*>(cd->Pnext) + (size_t)f.num_groups * 4 * KB * 2048) : nullptr;
         f2.ch_gscale = cd->gscale; f2.ch_pmout = cd->PMout; f2.ch_tmax = cd->Tmax; f2.ch_bc = cd->bc; f2.ch_graph_ptr = cd->graph_ptr;
         f2.ch_B = cd->B; f2.ch_KB = KB;
-#define GVQA_FUSED_CHAIN(NBUF_, KS_)                                                                                            \
-        hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, 4, 2, 0, KS_, 1>), grid, dim3(512), 0, stream, \
+#define GVQA_FUSED_CHAIN(NBUF_, KS_, CHN_)                                                                                      \
+        hipLaunchKernelGGL((k_linear_split3<2, 4, 4, 2, NBUF_, true, false, false, 0, 2, 4, 2, 0, KS_, CHN_>), grid, dim3(512), 0, stream, \
                            f.num_groups * 128, ncb * 256, KB, static_cast<const uint16_t*>(Apk), rtA, static_cast<const uint16_t*>(Bpk), \
                            rtB, LinearEpilogue{}, nullptr, (int64_t)0, 0, f2, a_inv, b_inv)
-        if ((KB & 1) == 0) GVQA_FUSED_CHAIN(2, 2);
-        else GVQA_FUSED_CHAIN(4, 1);
+        if (f.ic_a_edge) {      // coefficients inside the kernel (CHN = 2)
+            GVQA_REQUIRE(f.ic_csr_eid && f.ic_lp_in && f.ic_parts_in >= 1 && (!f.ic_lp_out || f.ic_vn_next) && (size_t)f.e_cap <= hop_fused_ic_lds_edge_capacity(f.H) &&
+                         (f.ic_a_edge_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(f.ic_a_edge) & 15) == 0 && f.C >= 4, GVQA_E_INVALID,
+                         "hop_fused: in-kernel coefficients need the slots' edge ids, 16-byte aligned edge halves, partial node logits and a row group within %zu edges",
+                         hop_fused_ic_lds_edge_capacity(f.H));
+            if ((KB & 1) == 0) GVQA_FUSED_CHAIN(2, 2, 2);
+            else GVQA_FUSED_CHAIN(4, 1, 2);
+        } else if ((KB & 1) == 0) GVQA_FUSED_CHAIN(2, 2, 1);
+        else GVQA_FUSED_CHAIN(4, 1, 1);
 #undef GVQA_FUSED_CHAIN
         GVQA_LAUNCH_CHECK();
         return GVQA_OK;

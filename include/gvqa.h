@@ -391,7 +391,13 @@ enum gvqa_option {
     GVQA_OPT_COEFF_KERNEL = 5,     /* attention coefficients: 0 (default) the row-group kernel when a row-group plan exists, 1 always the
                                       per-(node, head) kernel (same operations in the same order: bit-identical; tests) */
     GVQA_OPT_MP_PARTS = 6,         /* stand-alone message-passing kernel: 0 (default) blocks per graph chosen by batch size, n > 0 exactly n */
-    GVQA_NUM_OPTIONS = 7
+    GVQA_OPT_HOP_COEFFS = 7,       /* chained hops on the 8-wave kernel: 1 = attention coefficients computed INSIDE the hop kernel -- partial node logits
+                                      left by the previous hop's column blocks, edge halves gathered through the CSR edge ids, leaky-relu + segment
+                                      softmax in LDS: one launch per hop, no coefficient kernel, no pack pass after hop 0 (row groups within 522 edges
+                                      at H = 4).  0 (default) = the coefficient kernels of rounds 3 / 4.  Built and parity-green in round 5, and
+                                      measured a wash: the phase costs the hop kernel what the two small launches it replaces cost (256-graph shard
+                                      0.409 vs 0.414 ms, config 2 0.723 vs 0.705 ms per forward; profiles/r05_hop_coeffs_ab.txt) */
+    GVQA_NUM_OPTIONS = 8
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */

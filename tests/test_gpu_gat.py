@@ -851,6 +851,61 @@ def test_aggregate_first_one_launch_parity_sweep(dev, stratum):
     assert ran >= 8 and not bad, (ran, len(bad), bad[:3])
 
 
+@pytest.mark.parametrize("shape", ["shard256_d512", "config2_like_d300", "ragged_d64", "tiny", "isolated_nodes", "dense_row_groups", "one_hop", "no_instructions"])
+def test_chained_hops_with_in_kernel_coefficients(dev, shape):
+    """GVQA_OPT_HOP_COEFFS = 1 (default): the chained 8-wave hop kernel computes its attention coefficients itself (csrc/split3.hip,
+    CHN = 2: partial node logits left by the previous hop's column blocks summed per row group, edge halves gathered through the CSR
+    edge ids, leaky-relu + segment softmax in LDS, gat_skip.py:180-190) -- no coefficient launch, one pack pass per forward -- against
+    the oracle, against the coefficient-kernel form (GVQA_OPT_HOP_COEFFS = 0) and with the attention weights returned.  Row groups
+    beyond the kernel's LDS capacity (522 edges at H = 4) must take the coefficient kernels by themselves."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    H = 4
+    C, de, di, K, graphs, lo, hi, rel = {"shard256_d512": (512, 64, 64, 5, 256, 32, 32, 3.0), "config2_like_d300": (300, 40, 512, 5, 300, 20, 40, 1.0),
+                                         "ragged_d64": (64, 16, 12, 4, 37, 1, 60, 1.7), "tiny": (32, 8, 8, 3, 2, 1, 5, 1.0),
+                                         "isolated_nodes": (128, 8, 8, 3, 40, 3, 30, 0.0), "dense_row_groups": (64, 8, 8, 3, 6, 100, 128, 6.0),
+                                         "one_hop": (256, 8, 16, 1, 20, 10, 40, 2.0), "no_instructions": (68, 8, 0, 3, 25, 5, 50, 1.5)}[shape]
+    gb = synth.make_graph_batch(graphs, seed=0x1C0 + len(shape), nodes_lo=lo, nodes_hi=hi, rel_per_node=rel)
+    ei = gb.edge_index
+    if shape == "isolated_nodes":                     # every third node loses ALL its in-edges (self-loop included): empty softmax rows
+        ei = ei[:, ei[1] % 3 != 0]
+    N, E, B = gb.num_nodes, ei.shape[1], gb.num_graphs
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=77)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, max(di, 1)), 3)[:, :, :di]
+    ref, _, alphas = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(gb.batch), tparams(p), heads=H, return_all=True)
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)
+    args = [t(a, device=dev) for a in (x, ei, ea, ins, gb.batch)]
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+    res = {}
+    try:
+        for coeffs in (1, 0):
+            old_c = _lib.set_option(_lib.OPT_HOP_COEFFS, coeffs)
+            try:
+                m(*args)                                              # (weight cache for this layout)
+                _lib.prof_enable(True); _lib.prof_collect()
+                out = m(*args)
+                pr = _lib.prof_collect()
+                out_a, alpha = m(*args, return_attention_weights=True)[:2]
+                pr_a = _lib.prof_collect(); _lib.prof_enable(False)
+            finally:
+                _lib.set_option(_lib.OPT_HOP_COEFFS, old_c)
+                _lib.prof_enable(False)
+            res[coeffs] = (out, out_a, alpha, pr, pr_a)
+            assert maxabs(out, ref) < TOL and maxabs(out_a, ref) < TOL, (shape, coeffs)
+            if E:
+                assert maxabs(alpha, torch.stack(alphas)) < 2e-5, (shape, coeffs)
+            assert pr["mp"][1] == 0 and pr["proj"][1] == K and pr["pack"][1] == 1, (shape, coeffs, pr)       # chained: one pack pass, K hop launches
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+    in_kernel = shape != "dense_row_groups"
+    assert res[1][3]["alpha"][1] == (0 if in_kernel else K) and res[1][4]["alpha"][1] == (0 if in_kernel else K), (shape, res[1][3])
+    assert res[0][3]["alpha"][1] == K
+    assert maxabs(res[1][0], res[0][0]) < 2e-5 and torch.equal(res[1][0], res[1][1])      # the two forms agree; asking for alpha changes nothing
+
+
 def test_parity_sweep_bound_census(dev):
     """tests/fuzz.run asserts north_star's 1e-4 MAX-ABS whenever the oracle's outputs stay within 32 in magnitude and a bound scaled
     by peak / 32 only above that (VERDICT r04 #3a).  This test reports how many of the sweeps' cases (run earlier in this file, same
