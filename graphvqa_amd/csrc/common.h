@@ -183,6 +183,7 @@ struct FusedHopArgs {
     const float* ic_pmin;       // NULL (first hop) or [ic_parts_in][B]: per-graph maxima of this hop's input rows by column block
     float* ic_alpha_out;        // NULL or [E, H] (COO order): the attention weights, written by column block 0
     float ic_slope;
+    int pair_blocks;            // (set by launch_hop_fused_split) row blocks that take TWO row groups; the blocks behind them take one each (half tiles)
     int xcd_cols;               // column blocks per XCD of the workgroup -> tile map (1: plain launch order)
     int debug;                  // measurement aid (GVQA_FUSED_DEBUG bit mask): 1 no row image, 2 no aggregation, 4 no store, 8 no epilogue at all
 };

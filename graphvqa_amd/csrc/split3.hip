@@ -182,6 +182,15 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         bn = cg * fh.xcd_cols + j % fh.xcd_cols;
         bm = (j / fh.xcd_cols) * (8 / ncg) + rg;
     }
+    // fused hop: the first fh.pair_blocks row blocks take TWO row groups (256 rows), the rest ONE (the last partial round of a launch run
+    // as half tiles: the four waves of the empty half skip their fragment reads and MFMAs -- 585 workgroups on 256 CUs are three
+    // rounds for 2.29 rounds of work at config 2; 510 pairs + 145 singles are two rounds and a short one)
+    int rtf = bm * FA, grp0 = bm * 2;              // first A row tile / first row group of this block
+    bool single = false;
+    if constexpr (EPI == 2) {
+        if (bm >= fh.pair_blocks) { grp0 = 2 * fh.pair_blocks + (bm - fh.pair_blocks); single = true; }
+        rtf = grp0 * 4;
+    }
     const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
     if (STAG > 0) {
         const int slot = ((blockIdx.y * gridDim.x + blockIdx.x) >> 8) % STAG;
@@ -207,7 +216,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
         const bool isA = t < FA;
-        const int tile = isA ? min(bm * FA + t, rtA - 1) : min(bn * FB + (t - FA), rtB - 1);
+        const int tile = isA ? min(rtf + t, rtA - 1) : min(bn * FB + (t - FA), rtB - 1);
         src[q] = (isA ? Apk : Bpk) + (int64_t)tile * KB * (NP * 512) + lane * 8;
         dst[q] = lds_base + t * FRAG;
     }
@@ -291,8 +300,8 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-            const int grp = bm * 2 + gi;
-            if (grp < fh.num_groups) {                        // block-uniform
+            const int grp = grp0 + gi;
+            if (grp < fh.num_groups && !(single && gi == 1)) {                        // block-uniform
                 g_ns[gi] = fh.group_ptr[grp];
                 g_cnt[gi] = fh.group_ptr[grp + 1] - g_ns[gi];
                 g_e0[gi] = fh.rowptr[g_ns[gi]];
@@ -309,7 +318,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 const int gi = (wave - 4) >> 1, u = ((wave - 4) & 1) * 64;
                 if (g_cnt[gi] > 0) {
                     lds_dma4_b(fh.node_graph + g_ns[gi] + min(u + lane, g_cnt[gi] - 1), __builtin_amdgcn_readfirstlane(lds_base + IC_NG0 + (unsigned)(gi * 128 + u) * 4u));
-                    lds_dma4_b(fh.ch_a_inv + (bm * 2 + gi) * 128 + u + lane, __builtin_amdgcn_readfirstlane(lds_base + CH_TAIL + (unsigned)(gi * 1536 + u * 4)));
+                    lds_dma4_b(fh.ch_a_inv + (grp0 + gi) * 128 + u + lane, __builtin_amdgcn_readfirstlane(lds_base + CH_TAIL + (unsigned)(gi * 1536 + u * 4)));
                 }
             }
             if (tid < 256) reinterpret_cast<unsigned*>(smem + CH_TAIL + (tid >> 7) * 1536 + 1024)[tid & 127] = 0u;      // the groups' output maxima
@@ -342,9 +351,11 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     if constexpr (EPI == 2 && NP == 2) {
         const float sbu = b_inv[bn * 256];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) sab[i] = a_inv[(bm * FA + wr * TM + i) * 32 + (lane & 31)] * sbu;
+        for (int i = 0; i < TM; ++i) sab[i] = a_inv[min(rtf + wr * TM + i, rtA - 1) * 32 + (lane & 31)] * sbu;
     }
 
+    // (fused hop) the waves of a row half without a row group take no part in the products (they still issue their DMAs and meet the barriers)
+    const bool mm_on = EPI != 2 || __builtin_amdgcn_readfirstlane((int)(wr == 0 || g_cnt[1] > 0)) != 0;
     if constexpr (KS == 2) {
         // ---- two K steps per stage and per barrier: a stage is 4 KiB per operand tile (two k blocks x two pieces, contiguous in
         // the packed operand), two stages in LDS; the next stage's DMAs (four per tile from one M0 set-up) go out between the
@@ -371,6 +382,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             const unsigned char* sb = smem + b * STAGE2;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                if (mm_on) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -381,9 +393,10 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
                         bfr[j][p] = __builtin_bit_cast(frag_t, *reinterpret_cast<const uint4*>(sb + b_off2 + j * FRAG2 + sub * FRAG + p * 1024));
+                }
 #define GVQA_S2_PAIR(pa_, pb_, g_)                                                                                  \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)        \
-                    acc[i][j] = split_mfma(bfr[j][pb_], af[i][pa_], acc[i][j]);                                     \
+                if (mm_on) { _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)        \
+                    acc[i][j] = split_mfma(bfr[j][pb_], af[i][pa_], acc[i][j]); }                                   \
                 if (more && sub == 0 && (g_) < TPW) issue_quad(b ^ 1, (g_));
                 GVQA_S2_PAIR(1, 0, 0) GVQA_S2_PAIR(0, 1, 1) GVQA_S2_PAIR(0, 0, 2)
 #undef GVQA_S2_PAIR
@@ -488,7 +501,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const bool more = s + NBUF - 1 < KB && !(dbg & 32);
         if (!ILV && more) issue(pf);                   // refills the slot read in iteration s-1
         const unsigned char* sb = smem + buf * STAGE;
-        if (s == 0 || !(dbg & 16)) {
+        if (mm_on && (s == 0 || !(dbg & 16))) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -503,8 +516,8 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         if (PRIO) __builtin_amdgcn_s_setprio(1);
         // smallest cross terms first, a1 b1 last; consecutive MFMAs hit different accumulators
 #define GVQA_S3_PAIR(pa_, pb_, g_)                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
-            acc[i][j] = split_mfma(bfr[j][pb_], af[i][pa_], acc[i][j]);                                            \
+        if (mm_on) { _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)              \
+            acc[i][j] = split_mfma(bfr[j][pb_], af[i][pa_], acc[i][j]); }                                          \
         if (ILV && more) {                                                                                         \
             _Pragma("unroll") for (int q = (g_) * TPW / NG + ((g_) * TPW % NG ? 1 : 0); q * NG < ((g_) + 1) * TPW; ++q) \
                 if (q * NG >= (g_) * TPW) issue_triple(pf, q);                                                     \
@@ -717,7 +730,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             if (z_on) {                                       // the next operand's inverse slot scales (every column block writes the same values)
                 const int cnt_z = zg == 0 ? g_cnt[0] : g_cnt[1];
                 const float* gscl_z = reinterpret_cast<const float*>(smem + CH_TAIL + zg * 1536) + 128;
-                fh.ch_a_inv_next[(bm * 2 + zg) * 128 + zt] = zt < cnt_z ? 1.0f / gscl_z[ng_l[zg * 128 + zt] - z_gf] : 1.f;
+                fh.ch_a_inv_next[(grp0 + zg) * 128 + zt] = zt < cnt_z ? 1.0f / gscl_z[ng_l[zg * 128 + zt] - z_gf] : 1.f;
             }
             }
         } else {
@@ -751,7 +764,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             [[maybe_unused]] float* gscl_l = rinv_l + 128;
             [[maybe_unused]] unsigned* gmax_l = reinterpret_cast<unsigned*>(rinv_l + 256);
             [[maybe_unused]] int gf = 0, ngl = 0;
-            [[maybe_unused]] const int grp = bm * 2 + gi;
+            [[maybe_unused]] const int grp = grp0 + gi;
             [[maybe_unused]] const bool chain_out = CH && fh.ch_pnext != nullptr;
             if constexpr (IC) {
                 if (live) {                                   // (graph ids, input-slot scales and cleared maxima came in before the main loop)
@@ -1959,8 +1972,24 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
     const int KB = (int)cdiv(K, 16), ncb = (int)cdiv(f.C, f.cw);
     const int rtA = f.num_groups * 4, rtB = ncb * 8;
     GVQA_REQUIRE(cdiv(f.num_groups, 2) <= 65535, GVQA_E_UNSUPPORTED, "hop_fused: too many row groups for one launch");
-    dim3 grid((unsigned)ncb, (unsigned)cdiv(f.num_groups, 2));
+    // Row blocks: pairs of row groups (256-row tiles), and -- when the pairs leave a last round of workgroups at most half full -- that
+    // round's groups one per block (half tiles: twice the workgroups, each about 0.6 of a full tile's time).
+    int pair_blocks = (int)cdiv(f.num_groups, 2), single_blocks = 0;
+    if (get_option(GVQA_OPT_HOP_HALF_TILES) != 0 && f.num_groups >= 2) {
+        const int64_t cus = device_cu_count(), P = (int64_t)pair_blocks * ncb;
+        const int64_t rem_wg = P % cus;                                   // pair workgroups of the last partial round
+        if (get_option(GVQA_OPT_HOP_HALF_TILES) == 2) {                   // (measurement: every block one row group)
+            pair_blocks = 0;
+            single_blocks = f.num_groups;
+        } else if (rem_wg > 0 && 2 * rem_wg <= cus) {
+            const int rem_blocks = (int)std::min<int64_t>(cdiv(rem_wg, ncb), pair_blocks);
+            pair_blocks -= rem_blocks;
+            single_blocks = f.num_groups - 2 * pair_blocks;
+        }
+    }
+    dim3 grid((unsigned)ncb, (unsigned)(pair_blocks + single_blocks));
     FusedHopArgs f2 = f;
+    f2.pair_blocks = single_blocks > 0 ? pair_blocks : (int)cdiv(f.num_groups, 2);
     f2.debug = 0;
     {
 #ifdef GVQA_PROBES
@@ -1970,7 +1999,7 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
 #else
         constexpr int want = 4;                               // measured at config 3: 458 (plain order) / 452 / 449 / 447 us for 1 / 2 / 4 / 8
 #endif
-        const int rows = (int)cdiv(f.num_groups, 2);
+        const int rows = single_blocks > 0 ? 1 : (int)cdiv(f.num_groups, 2);          // (half tiles change the block -> group map: plain launch order)
         f2.xcd_cols = (ncb == 8 && (want == 2 || want == 4 || want == 8) && rows % (want) == 0) ? want : 1;
     }
     const float* a_inv = np == 2 ? split2h_inv_scales(Apk, rtA, KB) : nullptr;

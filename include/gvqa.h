@@ -397,7 +397,10 @@ enum gvqa_option {
                                       at H = 4).  0 (default) = the coefficient kernels of rounds 3 / 4.  Built and parity-green in round 5, and
                                       measured a wash: the phase costs the hop kernel what the two small launches it replaces cost (256-graph shard
                                       0.409 vs 0.414 ms, config 2 0.723 vs 0.705 ms per forward; profiles/r05_hop_coeffs_ab.txt) */
-    GVQA_NUM_OPTIONS = 8
+    GVQA_OPT_HOP_HALF_TILES = 8,   /* 8-wave fused hop: 1 (default) the row blocks of a launch's last PARTIAL round of workgroups take one row group each (128-row
+                                      half tiles, the empty half's waves skip their products) when that shortens the launch -- config 2: 585 workgroups
+                                      = three rounds on 256 CUs for 2.29 rounds of work -> 510 + 145 half tiles; 0 = every block two row groups */
+    GVQA_NUM_OPTIONS = 9
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */
