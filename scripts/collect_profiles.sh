@@ -3,15 +3,17 @@
 # bench line (live PMC traffic, comparison legs, DVFS probe, CPU baseline), rocprofv3 kernel stats of the default path, BASELINE
 # configs, emulated strong-scaling shards, the distributed step with one rank, SQ counters of the hop kernel, phase stamps of
 # the persistent hop kernel (measurement build), training step.
-O=gpurun_out/r; mkdir -p $O; export TMPDIR=/tmp
+O=gpurun_out/r05; mkdir -p $O; export TMPDIR=/tmp
 python bench.py > $O/bench_cfg3_n1.json 2> $O/bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o ks -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-extras > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof.err )
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_cfg3_kernel_stats.csv 2>/dev/null
 python scripts/bench_configs.py 2>/dev/null | tail -1 > $O/configs.json
+python scripts/bench_lcgn_stages.py 2>/dev/null | grep "^{" > $O/lcgn_stages.jsonl
+( GVQA_BENCH_ONE_DEVICE=1 GVQA_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 2>/dev/null | grep "\"metric\"" > $O/bench_n2_gloo_one_device.json )
 # the three chained / fused hop forms on this box, config 3 and config 2 (hop kernel us, forward wall ms, stage split)
 for c in 3 2; do for f in 3 1 2 4 5 0; do CONFIG=$c FUSION=$f python scripts/bench_hopagg.py 2>/dev/null | tail -1; done; done > $O/hop_forms_ab.jsonl
 ( export GVQA_LIB=graphvqa_amd/lib/probes/libgvqa_hip.so; for d in 0 1 2 4 32; do GVQA_HOPAGG_DEBUG=$d python scripts/bench_hopagg.py 2>/dev/null | tail -1; done ) > $O/hopagg_loop_parts.jsonl
-for f in 1 2; do for n in 2 4 8; do GVQA_HOP_FUSION=$f python bench.py --emulate-world $n --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1; done; done > $O/emulated_shards.jsonl
+for f in 3 1 2; do for n in 2 4 8 16; do GVQA_HOP_FUSION=$f python bench.py --emulate-world $n --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | tail -1; done; done > $O/emulated_shards.jsonl
 GVQA_BENCH_FORCE_DIST=1 python bench.py --emulate-world 8 --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | grep emulated_world > $O/emulated_shard8_rccl_1rank.json
 GVQA_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc --no-extras 2>/dev/null | grep "\"metric\"" > $O/bench_cfg3_rccl_1rank.json
 for f in 4 1 2; do MODES=$f ROUNDS=2 python scripts/bench_hop2.py 2>/dev/null | grep hop_kernel; done > $O/hop_kernels_ab.jsonl
@@ -25,7 +27,7 @@ cp $(find $O/tprof -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.cs
 # SQ counters of the hop kernels (separate --pmc passes, kernel trace only)
 for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  ( cd /tmp && MODES=4,1,2,0 ROUNDS=1 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/scripts/bench_hop2.py > /dev/null 2>&1 )
+  ( cd /tmp && MODES=5,4,1,2,0 ROUNDS=1 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/scripts/bench_hop2.py > /dev/null 2>&1 )
 done
 python - > $O/pmc_hop_kernels.txt <<PY
 import csv, glob, collections
