@@ -540,12 +540,16 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         const int s = (s_);                                                                                                 \
         const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + ((s + 1) & 3) * 2048);                            \
         float4 v0;                                                                                                          \
-        if (OV_) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                      \
+        if ((OV_) == 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
         /* a node's 9th and 10th in-edge (most overflow is one or two edges): their rows are only FETCHED here -- the FMAs sit  \
            further down, unconditional (zero rows, zero coefficients without overflow), so that the LDS round trip does not hold \
            back the wave's first MFMAs of the step; edges 11 .. 16 (rare) are still consumed here */                         \
-        float4 xo0 = make_float4(0.f, 0.f, 0.f, 0.f), xo1 = xo0;                                                             \
-        if (OV_ && ovn > 0) {                                                                                               \
+        float4 xo0, xo1;                                                                                                    \
+        if ((OV_) == 1) {       /* one or two overflow edges in the wave (the common overflow): both rows fetched unconditionally (slot 0, weight 0 when absent) */ \
+            xo0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] & 0xFFFFu));        \
+            xo1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] >> 16));            \
+        }                                                                                                                   \
+        if ((OV_) == 2) {                                                                                                   \
             xo0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] & 0xFFFFu));        \
             xo1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] >> 16));            \
             if (ovn > 2) {                                                                                                  \
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                     }                                                                                                       \
             }                                                                                                               \
         }                                                                                                                   \
-        if (OV_ && ovtrips > 0) {                                                                                           \
+        if ((OV_) == 2 && ovtrips > 0) {                                                                                    \
             for (int e = 0; e < ovtrips; ++e) {                                                                             \
                 const int k = HA_DMAX + HA_NOV + e;                                                                         \
                 const int idx = max(min(plo + k, plo + pdeg - 1), 0);                                                       \
@@ -592,10 +596,10 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a hi, b lo) with the producer: 8 x (4 FMAs), the second four x rows re-using xa */                              \
         GVQA_HA_MFR(0, NH, afh, bl);                                                                                        \
-        if (!GVQA_HA_DBG(1)) { if (OV_) GVQA_HA_QFMA(v0, al[0], xr, 0); else GVQA_HA_QMUL(v0, al[0], xr, 0);                  \
+        if (!GVQA_HA_DBG(1)) { if ((OV_) == 2) GVQA_HA_QFMA(v0, al[0], xr, 0); else GVQA_HA_QMUL(v0, al[0], xr, 0);           \
                                GVQA_HA_QFMA(v0, al[1], xr, 1); GVQA_HA_QFMA(v0, al[2], xr, 2); GVQA_HA_QFMA(v0, al[3], xr, 3); \
                                if (OV_) { GVQA_HA_FMA4(v0, al_o[0], xo0); GVQA_HA_FMA4(v0, al_o[1], xo1); } }                 \
-        else if (!(OV_)) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
+        else if ((OV_) != 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
         _Pragma("unroll") for (int z = 0; z < NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (40 + NH - 1) / NH, 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         issue_x(s + 3);                                                                                                     \
@@ -746,7 +750,12 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #ifndef GVQA_HA_OV_ALWAYS
 #define GVQA_HA_OV_ALWAYS 0                           // (A/B build switch: 1 = every wave takes the overflow-capable body, as in round 4)
 #endif
-    if (GVQA_HA_OV_ALWAYS || ovn > 0 || ovtrips > 0) {                    // (wave-uniform; both bodies meet the same barriers)
+    if (GVQA_HA_OV_ALWAYS || ovn > 2 || ovtrips > 0) {                    // (wave-uniform; all three bodies meet the same barriers)
+        for (int sq = 0; sq < NQ; sq += 2) {
+            GVQA_HA_STEP(sq, bh1, bh0, 2)
+            GVQA_HA_STEP(sq + 1, bh0, bh1, 2)
+        }
+    } else if (ovn > 0) {
         for (int sq = 0; sq < NQ; sq += 2) {
             GVQA_HA_STEP(sq, bh1, bh0, 1)
             GVQA_HA_STEP(sq + 1, bh0, bh1, 1)
