@@ -41,6 +41,7 @@ namespace gvqa {
 
 typedef _Float16 ha_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ha_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ha_f16x2 __attribute__((ext_vector_type(2)));
 typedef float ha_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HA_ROWS = 128;          // rows of a row group / tile
@@ -529,6 +530,19 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #define GVQA_HA_MFR(lo_, hi_, a_, b_) do { if (!GVQA_HA_DBG(4)) { _Pragma("unroll") for (int n_ = (lo_); n_ < (hi_); ++n_)                  \
         acc[n_ / TN][n_ % TN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[n_ % TN], a_[n_ / TN], acc[n_ / TN][n_ % TN], 0, 0, 0); } } while (0)
     constexpr int NH = NM / 2;                        // the (a hi, b lo) product is issued in two parts around the x DMA
+    // two values scaled by a power of two and split into fp16 pieces, packed two to a register: hi = f16(p v), lo = f16(p v - hi), each ONE
+    // v_fma_mix instruction (the multiply by the scale rides in the FMA; hipcc's own lowering of the same expressions: v_mul + v_cvt_pk for
+    // the packed hi AND a second v_fma_mixlo for the hi the subtraction reads -- 14 VALU per four values against 8).  Same bits: p v is
+    // exact (p a power of two), and p v - hi is exact in fp32.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GVQA_HA_SPLIT_C)
+#define GVQA_HA_SPLIT2(hi_, lo_, p_, a_, b_)                                                                                          \
+    asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %4, 0\n\t"                                                          \
+        "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %2, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"       \
+        : "=&v"(hi_), "=&v"(lo_) : "v"(p_), "v"(a_), "v"(b_))
+#else           /* (host pass; GVQA_HA_SPLIT_C: A/B build with the compiler's lowering) */
+#define GVQA_HA_SPLIT2(hi_, lo_, p_, a_, b_) do { const float ta_ = (a_) * (p_), tb_ = (b_) * (p_); ha_f16x2 h_, l_; h_[0] = (_Float16)ta_; h_[1] = (_Float16)tb_; \
+        l_[0] = (_Float16)(ta_ - (float)h_[0]); l_[1] = (_Float16)(tb_ - (float)h_[1]); (hi_) = __builtin_bit_cast(unsigned, h_); (lo_) = __builtin_bit_cast(unsigned, l_); } while (0)
+#endif
 #define GVQA_HA_FMA4(acc_, w_, x_) do { acc_.x += (w_) * (x_).x; acc_.y += (w_) * (x_).y; acc_.z += (w_) * (x_).z; acc_.w += (w_) * (x_).w; } while (0)
     auto rd = [&](const unsigned char* p_) { return __builtin_bit_cast(ha_f16x8, *reinterpret_cast<const uint4*>(p_)); };
     // step s with its b-hi fragments read into BN_ while BO_ still feeds the previous step's last product
@@ -610,14 +624,11 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             GVQA_HA_QFMA(v0, al[4], xr, 0); GVQA_HA_QFMA(v0, al[5], xr, 1); GVQA_HA_QFMA(v0, al[6], xr, 2); GVQA_HA_QFMA(v0, al[7], xr, 3); \
             /* scale by the graph's power of two, split into two fp16 pieces, 2 x 8 bytes into the A-fragment image of step s + 1 */ \
             const float psc = s + 1 < NQ ? pscale : 0.f;                                                                    \
-            const float tx = v0.x * psc, ty = v0.y * psc, tz = v0.z * psc, tw = v0.w * psc;                                 \
-            ha_f16x4 hi, lo;                                                                                                \
-            hi[0] = (_Float16)tx; hi[1] = (_Float16)ty; hi[2] = (_Float16)tz; hi[3] = (_Float16)tw;                         \
-            lo[0] = (_Float16)(tx - (float)hi[0]); lo[1] = (_Float16)(ty - (float)hi[1]);                                   \
-            lo[2] = (_Float16)(tz - (float)hi[2]); lo[3] = (_Float16)(tw - (float)hi[3]);                                   \
+            uint2 hi, lo;                                                                                                   \
+            GVQA_HA_SPLIT2(hi.x, lo.x, psc, v0.x, v0.y); GVQA_HA_SPLIT2(hi.y, lo.y, psc, v0.z, v0.w);                       \
             unsigned char* dst = smem + HA_A0 + ((s + 1) & 1) * 8192 + a_wr_off;      /* (last step: a free slot, never read) */ \
-            *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);                                                 \
-            *reinterpret_cast<uint2*>(dst + 1024) = __builtin_bit_cast(uint2, lo);                                          \
+            *reinterpret_cast<uint2*>(dst) = hi;                                                                            \
+            *reinterpret_cast<uint2*>(dst + 1024) = lo;                                                                     \
         }                                                                                                                   \
         _Pragma("unroll") for (int z = 0; z < NM - NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (52 + NM - NH - 1) / (NM - NH), 0); } \
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
