@@ -136,12 +136,15 @@ def extra_configs(torch, np, synth, _lib, lib, dev, with_cpu=True):
     def timed(fn, warmup=3, steps=10, stages=None):
         for _ in range(warmup):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        dt = None
+        for _ in range(3):                  # best of three rounds: one allocator / host hiccup in a 10-step round showed up as 7.8 ms for a 1.4 ms forward
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t0) / steps
+            dt = t1 if dt is None else min(dt, t1)
         _lib.prof_enable(True, stages=stages); _lib.prof_collect()
         for _ in range(steps):
             fn()

@@ -113,6 +113,14 @@ struct LinearEpilogue {
     int64_t pk_mul_ld;
     float* pk_inv;
     int pk_KB, pk_RT;
+    // split GEMM, two-piece operands: the A operand as TWO K segments with their own row scales -- k blocks [0, a2_kb0) from the packed
+    // A operand itself (an image of a2_kb0 k blocks), k blocks [a2_kb0, KB) from `a2` (a packed image of the same M rows, a2_KB = KB -
+    // a2_kb0 k blocks, inverse row scales a2_inv).  At the switch the accumulators are multiplied by the rows' ratio of the two scales
+    // (powers of two: exact).  What it is for: [u | v] . W^T where u and v were packed by different producers (epilogues of earlier
+    // products), without a pack pass over the concatenation (LCGN: [prod | x_ctx], [x_ctx | msg], lcgn.py:313,316).
+    const uint16_t* a2;
+    const float* a2_inv;
+    int a2_kb0, a2_KB;
 };
 
 // GEMM entry used by the orchestration code (defined in gemm.hip).

@@ -369,7 +369,7 @@ static int lcgn_pack(const gvqa_lcgn_dims* d, const gvqa_lcgn_params* p, char* b
 }
 
 struct LcgnLayout {
-    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, x16, pack, alpha, apk, total;
+    size_t x_loc, proj_x_loc, q_emb, q_cmd, cmd, pc, XC0, XC1, XL, J, logit, x16, pack, alpha, apk, pk5, pk_one, total;
 };
 static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_dims* d) {
     LcgnLayout L; size_t off = 0;
@@ -387,6 +387,10 @@ static LcgnLayout lcgn_layout(int64_t N, int64_t E, int64_t B, const gvqa_lcgn_d
     L.alpha = take(E);
     // fp32 mode: the two-piece image of a node GEMM's A operand (largest: K = 2 O or in_channels)
     L.apk = take(d->node_bf16 ? 0 : split_packed_bytes(2, N, std::max<int64_t>(2 * (int64_t)d->out_channels, d->in_channels)) / sizeof(float));
+    // fp32 mode, chained products: x_loc | x_ctx (two buffers) | prod | msg as packed two-piece images [N, O] (written by the producing
+    // products' epilogues; msg by one pack pass)
+    L.pk_one = d->node_bf16 ? 0 : align_up(split_packed_bytes(2, N, d->out_channels), 256);
+    L.pk5 = take(5 * L.pk_one / sizeof(float));
     L.total = off;
     return L;
 }
@@ -484,6 +488,86 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     };
 
     if (!p->packed) { StageTimer tw(GVQA_STAGE_FOLD, stream); rc = lcgn_pack(d, p, blob, stream); if (rc) return rc; }
+    // ---- fp32 mode, CHAINED node products (round 5): x_loc, x_ctx and prod exist only as packed two-piece operands, written by the
+    // epilogue of the product that makes them (k_linear_split3<..., EPI = 3>); the two K = 2 O products take [prod | x_ctx] and
+    // [x_ctx | msg] as two K segments with their own row scales (LinearEpilogue::a2).  Pack passes per forward: x, the initial x_ctx and
+    // msg once per iteration (2 + T) instead of 5 + 3 T; no fp32 x_loc / x_ctx / prod rows at all.
+    const bool chained = split_nodes && O % 32 == 0 && O <= 512 && Cin % 4 == 0 && N <= 65535ll * 128 &&
+                         2.0 * (double)N * (double)O * (double)O >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
+    if (chained) {
+        char* pkb = base + L.pk5;
+        char *xloc_pk = pkb, *xc_pk[2] = {pkb + L.pk_one, pkb + 2 * L.pk_one}, *prod_pk = pkb + 3 * L.pk_one, *msg_pk = pkb + 4 * L.pk_one;
+        const int KBO = O / 16;
+        const size_t inv_off = (size_t)cdiv(N, 32) * KBO * 2048;                 // inverse row scales behind an [N, O] image
+        auto W2 = [&](int widx) { return blob + PL.W2h + PL.w2h[widx]; };
+        auto PACK = [&](const float* X_, int64_t K_, int64_t ld_, char* dst_) -> int {
+            StageTimer tk(GVQA_STAGE_PACK, stream);
+            return launch_split_pack(2, N, K_, X_, ld_, dst_, stream);
+        };
+        // one product: A (packed, K1 columns) [+ second segment], weights image widx, epilogue, fp32 rows to C_ and / or packed rows to pk_
+        auto PROD = [&](int64_t N_, int64_t K1_, const char* A_, const char* A2_, int widx, LinearEpilogue ep_, float* C_, int64_t ldc_, char* pk_) -> int {
+            StageTimer tp(GVQA_STAGE_PROJ, stream);
+            int64_t K_ = K1_;
+            if (A2_) {
+                ep_.a2 = reinterpret_cast<const uint16_t*>(A2_);
+                ep_.a2_inv = reinterpret_cast<const float*>(A2_ + inv_off);
+                ep_.a2_kb0 = (int)(K1_ / 16); ep_.a2_KB = KBO;
+                K_ = K1_ + O;
+            }
+            ep_.pk_out = reinterpret_cast<uint16_t*>(pk_);
+            return launch_linear_split(2, N, N_, K_, A_, W2(widx), ep_, C_, ldc_, stream);
+        };
+#define CH(call_) do { rc = (call_); if (rc) return rc; } while (0)
+        CH(PACK(x, Cin, Cin, base + L.apk));                                                                    // x_loc = init(x)            :305
+        CH(PROD(O, Cin, base + L.apk, nullptr, 7, LinearEpilogue{p->init_bias, nullptr, 0, nullptr, 0, 0}, nullptr, O, xloc_pk));
+        {   // the per-question command chain (all T iterations): "graph_term"                                   :307,292-300,148-149
+            StageTimer tq(GVQA_STAGE_GRAPH_TERM, stream);
+            LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);
+            LIN(B, T * O, O, P(L.q_emb), O, PB(PL.Wq), O, PB(PL.bq), 0, P(L.q_cmd), (int64_t)T * O);
+            hipLaunchKernelGGL(k_lcgn_command, dim3((unsigned)B, (unsigned)T), dim3(256), (size_t)Lq * sizeof(float), stream, Lq, (int)B,
+                               O, P(L.q_cmd), lstm_outputs, p->cmd_logit_weight, p->cmd_logit_bias, P(L.cmd));
+            GVQA_LAUNCH_CHECK();
+            LIN((int64_t)T * B, 2 * O, O, P(L.cmd), O, PB(PL.Wpc), O, nullptr, 0, P(L.pc), 2 * O);
+        }
+        CH(PROD(O, O, xloc_pk, nullptr, 0, LinearEpilogue{p->proj_x_loc_bias, nullptr, 0, nullptr, 0, 0}, P(L.proj_x_loc), O, nullptr));      // :308
+        CH(PROD(3 * O, O, xloc_pk, nullptr, 1, LinearEpilogue{nullptr, nullptr, 0, nullptr, 0, 0}, P(L.XL), 3 * O, nullptr));                  // x_loc segment of lin_l / lin_r / cal_x
+        CH(PACK(x_ctx_init, O, O, xc_pk[0]));                                                                                                // :306
+        float* msg = P(L.XC0);                                                   // [N, O] dense (the [prod | x_ctx | msg] rows of the unchained form are not needed)
+        for (int t = 0; t < T; ++t) {
+            const int cur = t & 1;
+            const float* pc = P(L.pc) + (size_t)t * B * 2 * O;                  // [proj_cmd(cmd_t) | cal_cmd(cmd_t)] per graph
+            // prod = proj_x_ctx(x_ctx) * proj_x_loc: packed only                                                 :312-313
+            CH(PROD(O, O, xc_pk[cur], nullptr, 3, LinearEpilogue{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0}, nullptr, O, prod_pk));
+            // J = XL + [prod | x_ctx] . Wj^T: two K segments                                                     :144-145,230
+            CH(PROD(3 * O, O, prod_pk, xc_pk[cur], 2, LinearEpilogue{nullptr, P(L.XL), 3 * O, nullptr, 0, 0}, P(L.J), 3 * O, nullptr));
+            {
+                StageTimer tl(GVQA_STAGE_EDGE_LOGIT, stream);
+                const dim3 ngrid((unsigned)cdiv(N, 4));
+#define EDGE_LOGIT(KERNEL_)                                                                                              \
+                hipLaunchKernelGGL(KERNEL_, ngrid, dim3(256), 0, stream, (int)N, O, P(L.J), (int64_t)3 * O, P(L.J) + O, (int64_t)3 * O, pc,   \
+                                   (int64_t)2 * O, g->rowptr, g->csr_src, g->csr_eid, g->node_graph, P(L.logit))
+                EDGE_LOGIT((k_lcgn_edge_logit_v<false, 1>));                      // (O % 32 == 0, O <= 512)
+#undef EDGE_LOGIT
+                GVQA_LAUNCH_CHECK();
+            }
+            gvqa_gat_mp_desc m;
+            memset(&m, 0, sizeof(m));
+            m.C = O; m.H = 1; m.negative_slope = d->negative_slope; m.bn_eps = 1e-5f;
+            m.xp = P(L.J) + 2 * O; m.xp_ld = 3 * O;
+            m.a_edge = P(L.logit); m.a_edge_stride = 1;
+            m.graph_scale = pc + O; m.graph_scale_ld = 2 * O;
+            m.bias = p->bias; m.out = msg; m.out_ld = O;
+            CH(launch_gat_mp_public(g, &m, P(L.alpha), (size_t)E * sizeof(float), stream));                                                  // :209-238,166-168
+            CH(PACK(msg, O, O, msg_pk));
+            // x_ctx = output_layer([x_ctx | msg]): two K segments, packed only                                   :316-319
+            CH(PROD(O, O, xc_pk[cur], msg_pk, 4, LinearEpilogue{p->output_bias, nullptr, 0, nullptr, 0, 0}, nullptr, O, xc_pk[cur ^ 1]));
+        }
+        // out = fin_layer([x_loc | x_ctx])                                                                        :321-322
+        CH(PROD(O, O, xloc_pk, nullptr, 5, LinearEpilogue{p->fin_bias, nullptr, 0, nullptr, 0, 0}, out, O, nullptr));
+        CH(PROD(O, O, xc_pk[T & 1], nullptr, 6, LinearEpilogue{nullptr, out, O, nullptr, 0, 0}, out, O, nullptr));
+#undef CH
+        return GVQA_OK;
+    }
     {   // x_loc = init(x)                                                                       lcgn.py:305
         LinearEpilogue e{p->init_bias, nullptr, 0, nullptr, 0, 0};
         if (mf16) {     // x is a node tensor too: bf16 copy with K zero-padded to a multiple of 8

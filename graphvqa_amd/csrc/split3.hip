@@ -212,16 +212,39 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     // packed operand (edge blocks) re-read the last valid tile: their products are never stored.
     const uint16_t* src[TPW];
     unsigned dst[TPW];
+    // (two K segments of A, ep.a2: the first image holds a2_kb0 k blocks per row tile; at k block a2_kb0 the A tiles' sources move to the second image)
+    const bool seg2 = EPI != 2 && NP == 2 && ep.a2 != nullptr;
+    const int kb_sw = seg2 ? ep.a2_kb0 : 0x7fffffff;
+    const uint16_t* src2[TPW];
+    int kbi[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
         const bool isA = t < FA;
         const int tile = isA ? min(rtf + t, rtA - 1) : min(bn * FB + (t - FA), rtB - 1);
-        src[q] = (isA ? Apk : Bpk) + (int64_t)tile * KB * (NP * 512) + lane * 8;
+        src[q] = (isA ? Apk : Bpk) + (int64_t)tile * ((isA && seg2) ? ep.a2_kb0 : KB) * (NP * 512) + lane * 8;
+        src2[q] = (isA && seg2) ? ep.a2 + (int64_t)tile * ep.a2_KB * (NP * 512) + lane * 8 : nullptr;
+        kbi[q] = 0;
         dst[q] = lds_base + t * FRAG;
     }
+    // accumulators from the first segment's row scale to the second's (lane (m, .) holds rows m of its tiles)
+    auto rescale_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int gr = min((bm * FA + wr * TM + i) * 32 + (lane & 31), M - 1);
+            const float ratio = a_inv[gr] / ep.a2_inv[gr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= ratio;
+        }
+    };
     // one (tile, k step) = NP 1 KiB fragments contiguous in global memory and in the LDS stage: ONE M0 set-up, NP DMAs
     auto issue_triple = [&](int buf, int q) {
+        if constexpr (NP == 2 && EPI != 2) {
+            if (kbi[q] == kb_sw && src2[q]) src[q] = src2[q];       // (wave-uniform)
+            kbi[q] += 1;
+        }
         if constexpr (NP == 3) lds_dma16_x3(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
         else lds_dma16_x2(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
         src[q] += NP * 512;
@@ -365,6 +388,10 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
 #pragma unroll
         for (int q = 0; q < TPW; ++q) dst2[q] = lds_base + (wave + q * NW) * FRAG2;
         auto issue_quad = [&](int b, int q) {
+            if constexpr (EPI != 2) {
+                if (kbi[q] == kb_sw && src2[q]) src[q] = src2[q];   // (wave-uniform; the launcher keeps a2_kb0 even for this loop)
+                kbi[q] += 2;
+            }
             lds_dma16_x4(src[q], __builtin_amdgcn_readfirstlane(dst2[q] + b * STAGE2));
             src[q] += 2 * NP * 512;
         };
@@ -379,6 +406,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const bool more = s2 + 1 < KB2;
+            if constexpr (EPI != 2) { if (2 * s2 == kb_sw) rescale_acc(); }
             const unsigned char* sb = smem + b * STAGE2;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -499,6 +527,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             __builtin_amdgcn_s_barrier();
         }
         const bool more = s + NBUF - 1 < KB && !(dbg & 32);
+        if constexpr (NP == 2 && EPI != 2) { if (s == kb_sw) rescale_acc(); }
         if (!ILV && more) issue(pf);                   // refills the slot read in iteration s-1
         const unsigned char* sb = smem + buf * STAGE;
         if (mm_on && (s == 0 || !(dbg & 16))) {
@@ -534,6 +563,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     }
     }
 
+    if (seg2) a_inv = ep.a2_inv;                       // (the accumulators are in the second segment's units now)
     if (NOSTORE) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1052,6 +1082,10 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                         if (ep.addend) {
                             const float4 a4 = *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
                             v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                        }
+                        if (ep.mul) {
+                            const float4 m4 = *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc);
+                            v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
                         }
                         if (ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                         if (C) *reinterpret_cast<float4*>(C + (int64_t)gr * ldc + gc) = v;
@@ -1633,7 +1667,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     if (M == 0 || N == 0) return GVQA_OK;
     GVQA_REQUIRE(Apk && Bpk && (C || ep.rowdot_w || ep.pk_out), GVQA_E_INVALID, "linear_split3: null operand");
     if (ep.pk_out) {      // the result as the next product's packed operand: whole rows per workgroup (128 x 512 tile)
-        GVQA_REQUIRE(np == 2 && batch == 1 && !ep.mul && !ep.rowdot_w && ep.relu != 2 && M <= 65535ll * 128, GVQA_E_INVALID,
+        GVQA_REQUIRE(np == 2 && batch == 1 && !ep.rowdot_w && ep.relu != 2 && M <= 65535ll * 128, GVQA_E_INVALID,
                      "linear_split: packed output takes two-piece operands, one batch, bias / addend / ReLU epilogues");
         if (N > 512) return GVQA_E_UNSUPPORTED;
         GVQA_REQUIRE((reinterpret_cast<uintptr_t>(ep.pk_out) & 15) == 0 && (!ep.pk_mul || (ep.pk_mul_idx && ep.pk_mul_ld % 4 == 0 &&
@@ -1655,10 +1689,17 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     // 128-column tiles instead (3 x 128): a quarter less matrix-core work at a lower arithmetic intensity per tile
     if (np == 2 && get_option(GVQA_OPT_SPLIT3_VARIANT) < 10 && N % 256 != 0 && N % 256 <= 128 && N <= 1024) variant = 124;
     if (forced_variant) variant = forced_variant;
+    const int KBA = ep.a2 ? ep.a2_kb0 : KB;            // k blocks of the (first) A image
+    if (ep.a2) {
+        // two K segments of A: the plain and the two-steps-per-barrier loops know the switch (not the read-ahead loop)
+        GVQA_REQUIRE(np == 2 && batch == 1 && ep.a2_inv && ep.a2_kb0 > 0 && ep.a2_KB > 0 && ep.a2_kb0 + ep.a2_KB == KB && M <= 65535ll * 128 &&
+                     (reinterpret_cast<uintptr_t>(ep.a2) & 15) == 0, GVQA_E_INVALID, "linear_split: bad second K segment of A");
+        if (!ep.pk_out) variant = ((KB & 1) == 0 && (ep.a2_kb0 & 1) == 0) ? 112 : 114;
+    }
     GVQA_REQUIRE((variant >= 100) == (np == 2), GVQA_E_INVALID, "linear_split: variant %d does not take %d-piece operands", variant, np);
     const int64_t bm = variant % 100 < 20 ? 256 : 128;     // (rows per tile: 1x = 256, 2x / 3x / 4x = 128)
     GVQA_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || M <= 65535 * bm), GVQA_E_INVALID, "linear_split: bad batch count");
-    const float* a_inv = np == 2 ? (a_inv_batched ? a_inv_batched : split2h_inv_scales(Apk, cdiv(M, 32), KB)) : nullptr;
+    const float* a_inv = np == 2 ? (a_inv_batched ? a_inv_batched : split2h_inv_scales(Apk, cdiv(M, 32), KBA)) : nullptr;
     const float* b_inv = np == 2 ? (b_inv_batched ? b_inv_batched : split2h_inv_scales(Bpk, rtB, KB)) : nullptr;
 #ifdef GVQA_PROBES
     const char* ssv = getenv("GVQA_SPLIT3_STAGGER");      // quarter units of the default start offset (tuning aid)
@@ -1680,7 +1721,7 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
             e2.pk_RT = (int)cdiv(M, 32);
             e2.pk_inv = const_cast<float*>(split2h_inv_scales(ep.pk_out, e2.pk_RT, e2.pk_KB));
         }
-        const uint16_t* a2 = a + (m0 / 32) * (int64_t)KB * (np * 512);
+        const uint16_t* a2 = a + (m0 / 32) * (int64_t)KBA * (np * 512);
         const float* a_inv2 = a_inv ? a_inv + m0 : nullptr;
         const int rt2 = (int)cdiv(m, 32);
 #define GVQA_S3_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_) GVQA_SP_LAUNCH(WM_, WN_, TM_, TN_, NBUF_, ILV_, PRIO_, NOST_, STAG_, EPI_, 3, 0)
@@ -2120,6 +2161,23 @@ extern "C" int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* 
                                    int64_t ldc, void* stream) {
     gvqa::LinearEpilogue ep{bias, addend, ld_add, mul, ld_mul, relu};
     return gvqa::launch_linear_split(2, M, N, K, Apk, Bpk, ep, C, ldc, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gvqa_linear_split2h_chain(int64_t M, int64_t N, int64_t K1, const void* Apk, int64_t K2, const void* A2pk, const void* Bpk,
+                                         const float* bias, const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu,
+                                         float* C, int64_t ldc, void* pk_out, void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(M >= 0 && N > 0 && K1 > 0 && K2 >= 0 && (A2pk != nullptr) == (K2 > 0) && (!A2pk || K1 % 16 == 0), GVQA_E_INVALID,
+                 "linear_split2h_chain: bad segment sizes (K1 must be a multiple of 16 when a second segment follows)");
+    LinearEpilogue ep{bias, addend, ld_add, mul, ld_mul, relu};
+    if (A2pk) {
+        ep.a2 = static_cast<const uint16_t*>(A2pk);
+        ep.a2_kb0 = (int)(K1 / 16);
+        ep.a2_KB = (int)cdiv(K2, 16);
+        ep.a2_inv = reinterpret_cast<const float*>(static_cast<const char*>(A2pk) + (size_t)cdiv(M, 32) * ep.a2_KB * 2048);
+    }
+    ep.pk_out = static_cast<uint16_t*>(pk_out);
+    return launch_linear_split(2, M, N, K1 + (A2pk ? (int64_t)ep.a2_KB * 16 : 0), Apk, Bpk, ep, C, ldc, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,

@@ -315,6 +315,15 @@ GVQA_API int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Ap
                         const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                         int64_t ldc, void* stream);
 
+/* The same product as a link of a CHAIN of products (round 5; LCGN's node products, lcgn.py:312-319): the A operand may come as TWO K
+ * segments packed by different producers -- Apk [M, K1] and A2pk [M, K2] (NULL: one segment), each with its own row scales, against ONE
+ * packed weight image [N, K1 + K2] (K1 a multiple of 16) -- and the finished rows may leave as the NEXT product's packed A operand
+ * (pk_out: a buffer of gvqa_split2h_packed_bytes(M, N) bytes, N <= 512, laid out and scaled exactly as gvqa_split2h_pack would; C may
+ * then be NULL).  Epilogue order: bias, addend, mul (elementwise), ReLU.  No pack pass over [u | v] or over the result. */
+GVQA_API int gvqa_linear_split2h_chain(int64_t M, int64_t N, int64_t K1, const void* Apk, int64_t K2, const void* A2pk, const void* Bpk,
+                              const float* bias, const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu,
+                              float* C, int64_t ldc, void* pk_out, void* stream);
+
 /* Tall-skinny products of the differentiable path (training; csrc/train.hip): the attention logits
  * (x_i * att).sum(-1) of gat_skip.py:134-135,151 with the attention vectors folded through the projection weights, a = X V,
  * V [D, J] row-major with J <= 32 (2H node columns, or the H edge columns of all K hops side by side), and the two products

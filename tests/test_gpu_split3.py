@@ -209,3 +209,45 @@ def test_linear_split2h_two_k_steps_per_barrier(env, M, N, K):
     C0 = _run(env, A, W, 114, scheme="split2h")
     ref = A.double() @ W.double().t()
     assert float((C.double() - ref).abs().max()) < max(2e-6, 2 * float((C0.double() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("M,K1,K2,N,packed_out,mul", [(300, 64, 48, 96, False, False), (1000, 512, 512, 512, True, False), (777, 512, 0, 512, True, True),
+                                                       (2049, 32, 512, 260, False, True), (4100, 512, 512, 1536, False, False), (129, 16, 16, 64, True, True)])
+def test_chained_products_two_a_segments_and_packed_output(env, M, K1, K2, N, packed_out, mul):
+    """gvqa_linear_split2h_chain (round 5; LCGN's node products, /root/reference baseline_and_test_models/lcgn.py:312-319): the A operand as
+    TWO separately packed K segments with their own row scales -- deliberately 2^9 apart here, so that the exact power-of-two rescale of
+    the accumulators at the switch is exercised in both directions --, bias / addend / elementwise mul / ReLU, and the finished rows
+    leaving as the next product's packed operand.  Against fp64: the fp32 result within the two-piece bound of a single-segment product,
+    the packed result piece-for-piece what gvqa_split2h_pack makes of the fp32 result."""
+    _lib, lib, dev = env
+    g = torch.Generator(device="cpu").manual_seed(M + K1 + N)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    U = (rn(M, K1) * torch.exp(2 * rn(M, 1))).to(dev)
+    V = (rn(M, K2) * torch.exp(2 * rn(M, 1)) * (2.0 ** 9 if M % 2 else 2.0 ** -9)).to(dev) if K2 else None
+    K2p = -(-K2 // 16) * 16
+    W = (rn(N, K1 + K2p) / (K1 + K2) ** 0.5).to(dev)
+    if K2 and K2p != K2:
+        W[:, K1 + K2:] = 0
+    bias = rn(N).to(dev)
+    add = rn(M, N).to(dev)
+    mulv = (rn(M, N).to(dev) if mul else None)
+    upk = _pack(env, U, "split2h")
+    vpk = _pack(env, V, "split2h") if K2 else None
+    wpk = _pack(env, W, "split2h")
+    C = torch.empty(M, N, device=dev)
+    pk = torch.empty(lib.gvqa_split2h_packed_bytes(M, N), dtype=torch.uint8, device=dev) if packed_out else None
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gvqa_linear_split2h_chain(M, N, K1, upk.data_ptr(), K2, vpk.data_ptr() if K2 else None, wpk.data_ptr(), bias.data_ptr(),
+                                             add.data_ptr(), N, mulv.data_ptr() if mul else None, N if mul else 0, 1, C.data_ptr(), N,
+                                             pk.data_ptr() if packed_out else None, st))
+    A = torch.cat([U, V], 1) if K2 else U
+    ref = A.double() @ W[:, :A.shape[1]].double().t() + bias.double() + add.double()
+    if mul:
+        ref = ref * mulv.double()
+    ref = torch.relu(ref)
+    scale = float((A.double().abs() @ W[:, :A.shape[1]].double().abs().t()).max())      # the products' own magnitude (before cancellation)
+    err = float((C.double() - ref).abs().max())
+    assert err < 2e-6 * scale + 1e-6, (err, scale)
+    if packed_out:
+        again = _pack(env, C, "split2h")                   # what the pack pass would have made of the fp32 rows
+        assert torch.equal(pk, again)
