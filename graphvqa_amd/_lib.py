@@ -18,7 +18,7 @@ STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp
 OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS, OPT_HOP_COEFFS, OPT_HOP_HALF_TILES = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PROJECTION_SPLIT3, PROJECTION_F32, PROJECTION_SPLIT2H = 0, 1, 2
 NUM_STAGES = len(STAGES)
-HOP_KERNELS = ("unfused", "fused8", "persistent", "fused8_chained", "persistent_chained", "aggregate_first", "aggregate_first_seq")      # GVQA_HOP_*
+HOP_KERNELS = ("unfused", "fused8", "persistent", "fused8_chained", "persistent_chained", "aggregate_first", "aggregate_first_seq", "aggregate_first_parts")      # GVQA_HOP_*
 
 
 class GvqaLibraryError(RuntimeError):

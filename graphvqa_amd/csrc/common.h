@@ -260,6 +260,11 @@ struct HopAggArgs {
     const int32_t* csr_eid;     // [E] CSR slot -> COO edge id
     float* alpha_out;           // NULL or [E, H]: the attention weights, COO order
     float slope;
+    // column parts (k_hopagg4<..., CP > 1>: a row group's output columns split over CP workgroups, per-hop launches only -- small batches /
+    // strong-scaling shards, where one workgroup per row group leaves most CUs idle): the next hop's node logits and the per-graph maxima
+    // leave as one set per part (a_node_out / gmax_out + part x stride) and are combined by the reader (sum / max over the parts_in sets)
+    int parts_in;               // sets of a_node_in / gmax_in to combine (1: the layout pass or a CP = 1 launch produced them)
+    int64_t an_part_stride, gm_part_stride;      // floats between two sets (N x 2 H, B)
     int dbg;                    // measurement build only (GVQA_HOPAGG_DEBUG): 1 no producer in the loop, 2 no weight DMA, 4 no MFMAs, 8 no fragment reads after step 0, 16 no waits / barriers, 32 no epilogue
 };
 // The K hops of gat_seq as ONE launch of the aggregate-first kernel (k_hopagg4<..., SEQ>): per-hop operands.  The HopAggArgs beside it
@@ -291,7 +296,7 @@ size_t hopagg_packed_w_bytes(int C, int Dn, int H);
 int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream,
                       const float* Vn = nullptr, float* a_node = nullptr);      // Vn: [8][D] folded vectors of hop 0 -> a_node [N, 8]
-int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream);
+int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream, int col_parts = 1);
 
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);
 int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream);

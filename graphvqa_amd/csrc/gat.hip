@@ -1043,8 +1043,24 @@ static bool hop_fusion_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // H = 4, C == Dn <= 512, the two-piece projection, a row-group plan with <= 1024 edges per group.  Rows travel chunk-major
 // between hops; per-hop fp32 outputs and the attention weights are served, batch-statistics BatchNorm is not.
 constexpr bool kAggFirstByDefault = true;            // (since the epilogue's loads run a batch ahead: 386-400 vs 389-428 us per hop for the chained 8-wave kernel, same boxes)
+// ... with a row group's output columns split over four workgroups (k_hopagg4<4, 2, 1, 2, ..., CP = 4>; GVQA_OPT_HOP_FUSION = 6: built for
+// strong-scaling shards, where one workgroup per row group leaves most CUs idle).  Per-hop launches; attention weights and per-hop rows served.
+constexpr int kHopaggParts = 4;
+static bool hopagg_parts_shape(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    const int H = d->heads, C = d->out_channels;
+    return H == 4 && C == d->node_dim && C > 384 && C <= 512 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
+           proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && hopagg_supported(H, C, d->node_dim, g->max_row_group_edges);
+}
+static bool hopagg_parts_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
+    const int mode = opt_hop_fusion(d);
+    // (explicit only.  Measured on 256- / 128- / 64-graph shards of config 3, round 5: 89 / 82 / 81 us per hop against 54 / 35 / 31 for the
+    //  8-wave kernel + its two small launches (0.54 vs 0.43 ms per step at 256 graphs) -- a 128 x 128 part is 6 MFMAs in two dependent
+    //  chains per wave and step beside the full producer, and 64 us of the hop are outside the loop; profiles/r05_hop_coeffs_ab.txt)
+    return mode == 6 && hopagg_parts_shape(g, d);
+}
 static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int mode = opt_hop_fusion(d);
+    if (hopagg_parts_applies(g, d)) return true;
     if (mode != 4 && mode != 5 && mode != 3) return false;
     const int H = d->heads, C = d->out_channels;
     if (!(proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
@@ -1073,7 +1089,7 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // overflow edges sit in registers the workgroups' hops are even, and the one launch is the faster form: 2.29 vs 2.35 ms per step, same box).
 static bool hopagg_seq_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int mode = opt_hop_fusion(d);
-    return (mode == 5 || mode == 3) && d->num_hops >= 2 && d->num_hops <= HA_MAXHOPS && hopagg_applies(g, d);
+    return (mode == 5 || mode == 3) && d->num_hops >= 2 && d->num_hops <= HA_MAXHOPS && hopagg_applies(g, d) && !hopagg_parts_applies(g, d);
 }
 
 // Chained hops on the 8-WAVE kernel (launch_hop_fused_split with a chain descriptor): a hop writes the next hop's packed operand
@@ -1191,7 +1207,8 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     L.Ve = L.Gw = L.Vn;
     L.T = take(K * B * align_up(C + H, 4));
     L.a_edge = take((size_t)E * K * H);
-    L.a_node = take((size_t)N * 2 * H);
+    const bool agg_parts = g && hopagg_parts_applies(g, d);
+    L.a_node = take((size_t)N * 2 * H * (agg_parts ? 2 * kHopaggParts : 1));      // (column parts: two buffers of one set per part)
     L.xp = take(fused ? 0 : (size_t)N * H * C);                // the fused hop never materialises xp
     L.h0 = take((size_t)N * C);
     L.h1 = take((size_t)N * C);
@@ -1209,7 +1226,7 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
     {   // aggregate-first hops: the rows chunk-major (two buffers: a hop reads one, writes the other), per-graph maxima likewise
         const size_t x4 = aggf ? (size_t)g->num_row_groups * (size_t)cdiv((int64_t)d->node_dim, 4) * 128 * 4 : 0;
         L.x4a = take(x4); L.x4b = take(x4);
-        L.gma = take(aggf ? (size_t)B : 0); L.gmb = take(aggf ? (size_t)B : 0);
+        L.gma = take(aggf ? (size_t)B * (agg_parts ? kHopaggParts : 1) : 0); L.gmb = take(aggf ? (size_t)B * (agg_parts ? kHopaggParts : 1) : 0);
     }
     // in-kernel coefficients: the next hop's partial node logits by column block, two buffers (a hop reads one, writes the other)
     const bool ic_lp = chain && chain8 && chain8_in_kernel_coeffs(g, d);
@@ -1556,6 +1573,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         }
         if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
         const bool aggseq = hopagg_seq_applies(g, d) && !alpha_out && !hop_out;
+        const int cp = hopagg_parts_applies(g, d) ? kHopaggParts : 1;         // column parts: node logits / maxima as one set per part, two buffers
         for (int i = 0; i < K; ++i) {
             const float* gterm = Di > 0 ? P(L.T) + (int64_t)i * B * Tld : nullptr;
             if (aggseq && i > 0) break;               // (one launch: hops 1 .. K - 1 compute their coefficients inside it)
@@ -1581,13 +1599,20 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 ha.out = hop_out ? hop_out + (int64_t)i * N * C : (last ? out : nullptr);
                 ha.out_ld = C;
                 ha.relu = hops[i].bn_weight != nullptr;
+                // (column parts: hop i reads buffer i & 1 -- hop 0: the layout pass's single set --, writes buffer (i + 1) & 1: the workgroups
+                //  of a row group read each other's sets, so the in-place hand-over of the one-workgroup form does not apply)
+                const int64_t an_set = (int64_t)N * 2 * H;
+                float* an_in = cp > 1 ? P(L.a_node) + (int64_t)(i & 1) * cp * an_set : P(L.a_node);
+                float* an_out = cp > 1 ? P(L.a_node) + (int64_t)((i + 1) & 1) * cp * an_set : P(L.a_node);
+                ha.parts_in = (cp > 1 && i > 0) ? cp : 1;
+                ha.an_part_stride = an_set; ha.gm_part_stride = B;
                 if (!last && !aggseq) {               // the next hop's node logits leave with the rows
                     ha.Vn_next = Vn_all + (int64_t)(i + 1) * 2 * H * Dn;
-                    ha.a_node_out = P(L.a_node);
+                    ha.a_node_out = an_out;
                 }
                 if (in_prologue) {                    // (in place: a workgroup reads its rows' logits before it writes the next hop's)
                     ha.alpha_csr = nullptr;
-                    ha.a_node_in = P(L.a_node);
+                    ha.a_node_in = an_in;
                     ha.a_edge = P(L.a_edge) + (int64_t)i * H; ha.a_edge_stride = (int64_t)K * H; ha.csr_eid = g->csr_eid;
                     ha.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
                     ha.slope = d->negative_slope;
@@ -1617,7 +1642,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                     if (rc) return rc;
                     continue;
                 }
-                rc = launch_hopagg(H, ha, g->num_row_groups, stream);
+                rc = launch_hopagg(H, ha, g->num_row_groups, stream, cp);
                 if (rc) return rc;
             }
         }
@@ -1815,6 +1840,7 @@ int gvqa_gat_seq_hop_kernel(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (!g || !d || check_dims(d, true) || !g->finalized) return GVQA_E_INVALID;
     if (!g->intra_graph) return GVQA_E_UNSUPPORTED;
     if (hopagg_seq_applies(g, d)) return GVQA_HOP_AGGREGATE_FIRST_SEQ;
+    if (hopagg_parts_applies(g, d)) return GVQA_HOP_AGGREGATE_FIRST_PARTS;
     if (hopagg_applies(g, d)) return GVQA_HOP_AGGREGATE_FIRST;
     if (!hop_fusion_applies(g, d)) return GVQA_HOP_UNFUSED;
     const bool logits = split_pack_groups_logits_supported(2, 2 * d->heads, d->node_dim);

@@ -332,11 +332,30 @@ static_assert(HA_LDS_SEQ <= 160 * 1024 && HA_ST0 + HA_ECAP * 16 <= HA_A0, "hopag
 // ALP (per-hop launches): the hop's attention coefficients are computed in this launch's PROLOGUE -- node logits left by the previous
 // launch (a_node_in), edge halves gathered through the slice's COO edge ids, leaky-relu + segment softmax by the lane that owns the
 // producer item (node, head) -- under the latency of the priming DMAs: no coefficient kernel, no alpha_csr round trip.
-template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false, bool ALP = !SEQ>
+// CP > 1 (per-hop launches only): the output columns of a row group split over CP workgroups (blockIdx.y), WC x TN column tiles each -- a
+// 256-graph shard of config 3 is 64 row groups for 256 CUs; as 64 x 4 workgroups of 128 x 128 every CU has one.  Each part forms the full
+// A' (the producer's work is duplicated: ~46 VALU per lane and step beside 6 MFMAs per wave instead of 24) but streams only its own
+// quarter of the weights; the next hop's node logits and the per-graph maxima leave as one set per part and are combined by the reader.
+template <int WR, int WC, int RT, int TN, bool SEQ, bool LGT = false, bool ALP = !SEQ, int CP = 1>
 __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) {
     static_assert(SEQ || ALP, "hopagg: the per-hop form computes its coefficients in its prologue (the form fed by a coefficient kernel was removed with that kernel)");
     static_assert(!(SEQ && (LGT || ALP)), "hopagg: the one-launch form computes its logits and coefficients itself (hop 0's in its first prologue, as ALP does)");
     static_assert(WR * WC == 8 && WR * RT == 4 && WC * TN <= 16, "hopagg: eight waves over 128 rows and at most 16 column tiles");
+    static_assert(CP == 1 || (!SEQ && WC * TN <= 8), "hopagg: column parts are a per-hop form of at most 8 column tiles per part");
+    constexpr int NTP = WC * TN;                      // column tiles of this workgroup
+    constexpr int NBU = CP > 1 ? 1 : 2;               // weight DMA units per wave and step (a unit = one column tile, both pieces)
+    const int cpart = CP > 1 ? (int)blockIdx.y : 0, ct0 = cpart * NTP, cbase = ct0 * 32;
+    // Rings.  One workgroup per row group: weight stages of 16 tiles (32 KiB), three of them, DMAs two steps ahead; x chunks three ahead in
+    // four slots.  Column parts: a step is 6 MFMAs per wave (~0.25 us), shorter than an L2 -> LDS DMA's trip (~0.5 us: with the rings above
+    // the part measured 0.6 us per step, latency-bound) -- so weight stages of NTP tiles (8 KiB), SIX of them, DMAs FOUR steps ahead (only the
+    // waves that own a tile issue them), x chunks five ahead in eight slots, both inside the first 64 KiB of the (otherwise idle) weight area.
+    constexpr int PD = CP > 1 ? 4 : 2;                // weight DMAs run PD steps ahead
+    constexpr int NBST = CP > 1 ? 6 : 3;              // weight ring stages
+    constexpr unsigned BST = CP > 1 ? (unsigned)NTP * 2048u : HA_BSTAGE;      // bytes per weight stage
+    constexpr int NXS = CP > 1 ? 8 : 4;               // x ring slots (x DMAs run PD + 1 steps ahead)
+    constexpr unsigned XR0 = CP > 1 ? 48u * 1024u : HA_X0;
+    static_assert(CP == 1 || (NBST * BST <= 48 * 1024 && XR0 + NXS * 2048 <= HA_VN0), "hopagg: the column part's rings sit below the coefficient phase's scratch");
+    const bool b_owner = CP == 1 || __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < NTP;       // this wave issues weight DMAs
     constexpr int H = 4;
     constexpr int NM = RT * TN;                       // MFMAs of one piece product per wave
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SEQ ? HA_LDS_SEQ : HA_LDS1];
@@ -362,14 +381,15 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     int relu_h = a.relu;
     const uint16_t *wbase0 = nullptr, *wbase1 = nullptr;
     const float* xbase = nullptr;
-    auto issue_b_unit = [&](int st, int u) {           // weight unit u of step st (clamped) -> ring slot st % 3
+    auto issue_b_unit = [&](int st, int u) {           // weight unit u of step st (clamped) -> ring slot st % NBST
+        if (CP > 1 && !b_owner) return;                // (wave-uniform)
         ha_dma16_x2(ha_uniform((u ? wbase1 : wbase0) + (int64_t)min(st, NQ - 1) * 1024), lane16,
-                    __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + (unsigned)(st % 3) * HA_BSTAGE + (unsigned)(wave + 8 * u) * 2048u));
+                    __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + (unsigned)(st % NBST) * BST + (unsigned)(wave + 8 * u) * 2048u));
     };
-    auto issue_b = [&](int st) { issue_b_unit(st, 0); issue_b_unit(st, 1); };
+    auto issue_b = [&](int st) { issue_b_unit(st, 0); if (NBU > 1) issue_b_unit(st, 1); };
     auto issue_x = [&](int q) {                        // this wave's 256 bytes of x chunk q (clamped) -> ring slot q & 3
         ha_dma4(ha_uniform(xbase + (int64_t)min(q, NQ - 1) * (HA_ROWS * 4)), lane4,
-                __builtin_amdgcn_readfirstlane(lds_base + HA_X0 + (unsigned)(q & 3) * 2048u + (unsigned)wave * 256u));
+                __builtin_amdgcn_readfirstlane(lds_base + XR0 + (unsigned)(q & (NXS - 1)) * 2048u + (unsigned)wave * 256u));
     };
     // ---- this lane's producer item: node i = 16 wave + a, head h = 2 hhi + hlo; its first 8 in-edges in registers
     // (the four heads of a node are the four lanes of a quad: every lane fetches ONE of the node's source rows per batch of four
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     // A'(q) from x chunk q -> A' slot q & 1 (the first chunk, ahead of the loop; inside the loop the same operations are spread
     // between the MFMAs of a step)
     auto produce = [&](int q) {
-        const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + (q & 3) * 2048);
+        const float4* xs = reinterpret_cast<const float4*>(smem + XR0 + (q & (NXS - 1)) * 2048);
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
         const float4 xr0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep & 0xFFFFu));
         const float4 xr1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));
@@ -552,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #define GVQA_HA_STEP(s_, BO_, BN_, OV_)                                                                                     \
     {                                                                                                                       \
         const int s = (s_);                                                                                                 \
-        const float4* xs = reinterpret_cast<const float4*>(smem + HA_X0 + ((s + 1) & 3) * 2048);                            \
+        const float4* xs = reinterpret_cast<const float4*>(smem + XR0 + ((s + 1) & (NXS - 1)) * 2048);                      \
         float4 v0;                                                                                                          \
         if ((OV_) == 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
         /* a node's 9th and 10th in-edge (most overflow is one or two edges): their rows are only FETCHED here -- the FMAs sit  \
@@ -587,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }                                                                                                                   \
         /* ---- from here to the barrier ONE basic block ---- */                                                            \
         const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;                                                    \
-        const unsigned char* sb = smem + HA_B0 + (s % 3) * HA_BSTAGE + b_off;                                               \
+        const unsigned char* sb = smem + HA_B0 + (s % NBST) * BST + b_off;                                                  \
         float4 xr;                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < RT; ++i) afl[i] = rd(sa + i * 2048 + 1024);                                   \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) BN_[j] = rd(sb + j * 2048);                                          \
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_group_barrier(0x100, RT + TN, 0);                                                            \
         __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (!GVQA_HA_DBG(2)) issue_b_unit(s + 2, 0);                                                                        \
+        if (!GVQA_HA_DBG(2)) issue_b_unit(s + PD, 0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a lo, b hi); a hi, b lo and the first four x rows travel under it */                                            \
         GVQA_HA_MFR(0, NM, afl, BN_);                                                                                       \
@@ -606,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         _Pragma("unroll") for (int z = 0; z < (RT + TN + 2) / 2; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } \
         __builtin_amdgcn_sched_group_barrier(0x008, NM - (RT + TN + 2) / 2, 0);                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (!GVQA_HA_DBG(2)) issue_b_unit(s + 2, 1);                                                                        \
+        if (NBU > 1 && !GVQA_HA_DBG(2)) issue_b_unit(s + PD, 1);                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a hi, b lo) with the producer: 8 x (4 FMAs), the second four x rows re-using xa */                              \
         GVQA_HA_MFR(0, NH, afh, bl);                                                                                        \
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         else if ((OV_) != 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
         _Pragma("unroll") for (int z = 0; z < NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (40 + NH - 1) / NH, 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        issue_x(s + 3);                                                                                                     \
+        issue_x(s + PD + 1);                                                                                                \
         xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         GVQA_HA_MFR(NH, NM, afh, bl);                                                                                       \
@@ -634,7 +654,9 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
         /* this wave's DMAs of step s + 1 (issued one step ago) have landed, its A' writes are out; then everybody's */     \
         if (!GVQA_HA_DBG(16)) {                                                                                             \
-            asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
+            if (CP == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
+            else if (b_owner) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");   /* (column parts: the last PD - 1 = 3 steps' DMAs -- 3 per step, */ \
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                /*  or the x DMA alone for a wave without a weight tile) */   \
             __builtin_amdgcn_s_barrier();                                                                                   \
         }                                                                                                                   \
     }
@@ -664,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         X4out_h = more ? ((hop & 1) ? hs.X4a : hs.X4b) : nullptr;
         out_h = more ? nullptr : a.out;
     }
-    wbase0 = Wk_h + (int64_t)min(wave, NCT - 1) * NQ * 1024;            // (wave-uniform: SGPRs)
+    wbase0 = Wk_h + (int64_t)min(CP > 1 ? ct0 + wave % NTP : wave, NCT - 1) * NQ * 1024;            // (wave-uniform: SGPRs)
     wbase1 = Wk_h + (int64_t)min(wave + 8, NCT - 1) * NQ * 1024;
     xbase = X4in_h + (int64_t)t * NQ * (HA_ROWS * 4) + wave * 64;
     {   // the epilogue's per-column constants -> LDS [4][512] (one 1 KiB unit per wave; lanes past C re-read the row's last 16 bytes into the padding)
@@ -676,10 +698,10 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }
     }
     if (!SEQ || hop == 0) {            // (SEQ, later hops: the previous hop's coefficient phase primed the weight ring and wrote x chunks 0 .. 2 into the x ring)
-        issue_b(0);
-        issue_b(1);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) issue_x(q);
+        for (int q = 0; q < PD; ++q) issue_b(q);
+#pragma unroll
+        for (int q = 0; q < PD + 1; ++q) issue_x(q);
     }
     [[maybe_unused]] float tlog0 = 0.f;
     // (the one-launch form computes hop 0's coefficients the same way, in the prologue of its first hop: its operands ride in `hs`)
@@ -693,8 +715,11 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         for (int u = wbase; u < ne; u += 512)
             lds_dma4_b(a.csr_src + e0 + min(u + lane, ne - 1), __builtin_amdgcn_readfirstlane(lds_base + HA_SRC0 + (unsigned)u * 4u));
         const int nan = cnt * 8;
-        for (int u = wave * 256; u < nan; u += 2048)
-            lds_dma16_b(a.a_node_in + (int64_t)ns * 8 + min(u + lane * 4, nan - 4), __builtin_amdgcn_readfirstlane(lds_base + HA_VN0 + (unsigned)u * 4u));
+        const int nparts = SEQ ? 1 : max(a.parts_in, 1);              // (sets of node logits / maxima left by a column-split launch)
+        for (int pp = 0; pp < nparts; ++pp)
+            for (int u = wave * 256; u < nan; u += 2048)
+                lds_dma16_b(a.a_node_in + (int64_t)pp * a.an_part_stride + (int64_t)ns * 8 + min(u + lane * 4, nan - 4),
+                            __builtin_amdgcn_readfirstlane(lds_base + HA_VN0 + (unsigned)(pp * 1024 + u) * 4u));
         for (int u = wbase; u < ne; u += 512) {
             const int eid = eid0_[e0 + min(u + lane, ne - 1)];
             const float* src = ae0_ + (int64_t)eid * aes0_;
@@ -709,7 +734,9 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         ovtrips = max(ha_wave_max(pdeg) - HA_DMAX - HA_NOV, 0);
         pg = a.node_graph[ns + min(pi, cnt - 1)];
         if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pg * a.t_ld + a.C + ph];
-        set_row_scale(a.gmax_in[pg], true);
+        float gmx = a.gmax_in[pg];
+        for (int pp = 1; pp < nparts; ++pp) gmx = fmaxf(gmx, a.gmax_in[(int64_t)pp * a.gm_part_stride + pg]);
+        set_row_scale(gmx, true);
         if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
         if constexpr (SEQ) { if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM1)[tid] = 0u; }
     }
@@ -722,13 +749,24 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // rings' first stages, CSR slice and per-row arrays are in place
+    if constexpr (!SEQ) {
+        if (a.parts_in > 1) {                         // (block-uniform) the parts' node-logit sets summed in place, in a fixed order
+            float* an = reinterpret_cast<float*>(smem + HA_VN0);
+            for (int it = tid; it < cnt * 8; it += 512) {
+                float sv = an[it];
+                for (int pp = 1; pp < a.parts_in; ++pp) sv += an[pp * 1024 + it];
+                an[it] = sv;
+            }
+            __syncthreads();
+        }
+    }
     if ((ALP && !SEQ) || (SEQ && hop == 0)) {
         coeffs_from_lds(reinterpret_cast<const float*>(smem + HA_VN0), reinterpret_cast<float*>(smem + HA_ST0) + ph * HA_ECAP + plo, tlog0, SEQ ? hs.slope : a.slope);
         const int i0 = max(min(plo + ph, ne - 1), 0), i1 = max(min(plo + 4 + ph, ne - 1), 0);
         const unsigned s0 = ne > 0 ? (unsigned)min(max(src_l[i0] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         const unsigned s1 = ne > 0 ? (unsigned)min(max(src_l[i1] - ns, 0), HA_ROWS - 1) * 16u : 0u;
         sep = s0 | (s1 << 16);
-        if (!SEQ && a.alpha_out) {                    // (block-uniform) the attention weights are asked for: COO order, [E, H]
+        if (!SEQ && a.alpha_out && cpart == 0) {      // (block-uniform) the attention weights are asked for: COO order, [E, H]
             const float* al_w = reinterpret_cast<const float*>(smem + HA_AL0);
 #pragma unroll
             for (int e = 0; e < HA_DMAX; ++e)
@@ -859,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
+                    const int c0 = cbase + (wc * TN + j) * 32 + 8 * q + 4 * hh;
                     if (c0 >= C) continue;
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
@@ -932,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int cc = min((wc * TN + j) * 32 + 8 * (2 * qp + u) + 4 * hb, C - 4);       // (columns past C: clamped re-reads, never used)
+                const int cc = min(cbase + (wc * TN + j) * 32 + 8 * (2 * qp + u) + 4 * hb, C - 4);       // (columns past C: clamped re-reads, never used)
                 sk[u] = ha_row_load(X4in_h + (((int64_t)t * NQ + (cc >> 2)) * HA_ROWS + r) * 4);
                 tg[u] = *reinterpret_cast<const float4*>(gt_ + (int64_t)g_[i] * gt_ld + cc);
             }
@@ -950,7 +988,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                 const int q = 2 * qp + u;
                 const float4 (&sk)[2] = sk_;
                 const float4 (&tg)[2] = tg_;
-                const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
+                const int c0 = cbase + (wc * TN + j) * 32 + 8 * q + 4 * hh;
                 if (c0 >= C) continue;
                 const float4 bv = *reinterpret_cast<const float4*>(cc_l + c0);
                 const float4 bi = *reinterpret_cast<const float4*>(cc_l + 512 + c0);
@@ -1032,12 +1070,12 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                 const float2 pw = *reinterpret_cast<const float2*>(part + w * HA_ROWS * 8 + tid * 2);
                 sacc.x += pw.x; sacc.y += pw.y;
             }
-            if ((tid >> 2) < cnt) *reinterpret_cast<float2*>(a.a_node_out + (int64_t)(ns + (tid >> 2)) * 8 + (tid & 3) * 2) = sacc;
+            if ((tid >> 2) < cnt) *reinterpret_cast<float2*>(a.a_node_out + (int64_t)cpart * a.an_part_stride + (int64_t)(ns + (tid >> 2)) * 8 + (tid & 3) * 2) = sacc;
         }
         if (a.gmax_out) {
             __syncthreads();
             const int ngl = a.node_graph[ns + cnt - 1] - gf + 1;
-            if (tid < ngl) a.gmax_out[gf + tid] = __uint_as_float(gm_l[tid]);
+            if (tid < ngl) a.gmax_out[(int64_t)cpart * a.gm_part_stride + gf + tid] = __uint_as_float(gm_l[tid]);
         }
     } else if (more) {
         // ---- coefficient phase of hop + 1, inside the workgroup ---------------------------------------------------------------
@@ -1059,7 +1097,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c0 = (wc * TN + j) * 32 + 8 * q + 4 * hh;
+                    const int c0 = cbase + (wc * TN + j) * 32 + 8 * q + 4 * hh;
                     if (c0 >= C) continue;
                     const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                     ha_row_store(X4out_h + (((int64_t)t * CQ + (c0 >> 2)) * HA_ROWS + r) * 4, v);
@@ -1104,7 +1142,7 @@ bool hopagg_supported(int H, int C, int Dn, int max_row_group_edges) {
     return H == 4 && C == Dn && C % 4 == 0 && C >= 32 && C <= 512 && max_row_group_edges <= HA_ECAP;
 }
 
-int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream) {
+int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream, int col_parts) {
     GVQA_REQUIRE(H == 4 && a.group_ptr && a.rowptr && a.csr_src && a.a_node_in && a.a_edge && a.csr_eid && a.node_graph && a.X4in && a.Wk && a.binv && a.epc &&
                  a.gmax_in && (a.X4out || a.out), GVQA_E_INVALID, "hopagg: null operand");
     GVQA_REQUIRE(a.C % 4 == 0 && a.NCT <= 16 && a.NQ >= 1, GVQA_E_UNSUPPORTED, "hopagg: needs C %% 4 == 0 and C <= 512");
@@ -1119,9 +1157,11 @@ int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream
     GVQA_REQUIRE(!a.a_node_out || a.Vn_next, GVQA_E_INVALID, "hopagg: node logits out need the next hop's folded attention vectors");
     const dim3 grid((unsigned)num_groups), block(512);
     const bool lg = a.a_node_out != nullptr, narrow = a.NCT <= 10;
+    if (col_parts > 1) GVQA_REQUIRE(col_parts == 4 && a.NCT > 12 && a.NCT <= 16 && a.an_part_stride > 0 && a.gm_part_stride > 0, GVQA_E_INVALID, "hopagg: column parts are 4 x 128 columns of a 512-wide hop");
 #define GVQA_HA_LAUNCH(LG_)                                                                                                  \
     do {                                                                                                                     \
-        if (narrow) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, LG_, true>), grid, block, 0, stream, b, none);            \
+        if (col_parts > 1) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 2, false, LG_, true, 4>), dim3((unsigned)num_groups, 4), block, 0, stream, b, none); \
+        else if (narrow) hipLaunchKernelGGL((k_hopagg4<4, 2, 1, 5, false, LG_, true>), grid, block, 0, stream, b, none);       \
         else hipLaunchKernelGGL((k_hopagg4<2, 4, 2, 4, false, LG_, true>), grid, block, 0, stream, b, none);                   \
     } while (0)
     if (lg) GVQA_HA_LAUNCH(true);

@@ -208,6 +208,8 @@ GVQA_API int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims
 #define GVQA_HOP_PERSISTENT_CHAINED 4 /* the persistent kernel, hops chained                                              */
 #define GVQA_HOP_AGGREGATE_FIRST 5    /* hopagg.hip: heads concatenated along K (GVQA_OPT_HOP_FUSION = 4)                  */
 #define GVQA_HOP_AGGREGATE_FIRST_SEQ 6 /* the same, the K hops as ONE launch (GVQA_OPT_HOP_FUSION = 5)                     */
+#define GVQA_HOP_AGGREGATE_FIRST_PARTS 7 /* the same, one launch per hop, a row group's 512 output columns split over four workgroups
+                                            (GVQA_OPT_HOP_FUSION = 6, explicit only: measured slower than the 8-wave kernel on the shards it was built for) */
 GVQA_API int gvqa_gat_seq_hop_kernel(const gvqa_graph* g, const gvqa_gat_dims* d);
 GVQA_API int gvqa_gat_seq_prepare_weights(const gvqa_gat_dims* d, const gvqa_gat_conv_params* hops, int32_t layout, void* cache,
                                  size_t cache_bytes, void* stream);
@@ -396,7 +398,11 @@ enum gvqa_option {
                                       5: mode 4 with the K hops as ONE launch: a workgroup owns all output columns of its row group (whole
                                          graphs), so hop i + 1 of its rows needs nothing from another workgroup -- it runs the coefficient
                                          phase (node logits, leaky-relu, segment softmax) itself between two hops; rows travel chunk-major
-                                         through L2 / HBM.  Plain outputs only (attention weights / per-hop rows: mode 4's launches). */
+                                         through L2 / HBM.  Plain outputs only (attention weights / per-hop rows: mode 4's launches);
+                                      6: the aggregate-first kernel with a row group's output columns split over four workgroups (128 x 128 tiles,
+                                         per-hop launches; 384 < C <= 512): built for small batches / strong-scaling shards, where one workgroup per
+                                         row group leaves most CUs idle; parity-green, measured SLOWER than mode 1 there (0.54 vs 0.43 ms on a 256-graph
+                                         shard of config 3), so the default rule does not take it. */
     GVQA_OPT_COEFF_KERNEL = 5,     /* attention coefficients: 0 (default) the row-group kernel when a row-group plan exists, 1 always the
                                       per-(node, head) kernel (same operations in the same order: bit-identical; tests) */
     GVQA_OPT_MP_PARTS = 6,         /* stand-alone message-passing kernel: 0 (default) blocks per graph chosen by batch size, n > 0 exactly n */

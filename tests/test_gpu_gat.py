@@ -906,6 +906,63 @@ def test_chained_hops_with_in_kernel_coefficients(dev, shape):
     assert maxabs(res[1][0], res[0][0]) < 2e-5 and torch.equal(res[1][0], res[1][1])      # the two forms agree; asking for alpha changes nothing
 
 
+@pytest.mark.parametrize("stratum", ["tiny_groups", "sparse_e_over_n_1", "hubs", "many_small", "big_graphs", "shard256"])
+def test_aggregate_first_column_parts_parity(dev, stratum):
+    """GVQA_OPT_HOP_FUSION = 6 (round 5): the aggregate-first hop with a row group's 512 output columns split over four workgroups
+    (k_hopagg4<4, 2, 1, 2, ..., CP = 4>, per-hop launches; built for strong-scaling shards, explicit only since it measured slower
+    than the 8-wave kernel there).  The next hop's node logits and the per-graph maxima travel as one set per part and are combined by the
+    reader.  Widths 512 / 448 / 400 (partial last part), K = 1..5, every batch regime, plain / attention-weight / per-hop outputs,
+    against the oracle at 1e-4 (alpha 5e-5), and on a 256-graph shard of the config-3 batch against the oracle and the 8-wave kernel."""
+    from tests.fuzz import stratified_case, run, STRATA
+    from graphvqa_amd import _lib
+    if stratum == "shard256":
+        from oracle import ref_torch as R
+        from graphvqa_amd.gat_skip import gat_seq
+        from graphvqa_amd.graph import SceneGraphBatch
+        gb = synth.config3_batch(256)
+        N, E, B, d = gb.num_nodes, gb.num_edges, gb.num_graphs, 512
+        p = synth.gat_seq_params(d, d, d, d, 5, 4, seed=777)
+        x, ea, ins = synth.normal((N, d), 1), synth.normal((E, d), 2), synth.normal((5, B, d), 3)
+        m = _load_module(gat_seq(d, d, d, d, 5, dropout=0.1, gat_heads=4), p, dev)
+        args = [t(a, device=dev) for a in (x, gb.edge_index, ea, ins, gb.batch)]
+        g = SceneGraphBatch(args[1], args[4], N, B)
+        assert m.hop_kernel(g) != "aggregate_first_parts"          # (explicit only: measured slower than the 8-wave kernel on this very shard)
+        out8 = m(*args, graph=g)
+        old = _lib.set_option(_lib.OPT_HOP_FUSION, 6)
+        try:
+            assert m.hop_kernel(g) == "aggregate_first_parts"
+            _lib.prof_enable(True); _lib.prof_collect()
+            out = m(*args, graph=g)
+            pr = _lib.prof_collect(); _lib.prof_enable(False)
+        finally:
+            _lib.set_option(_lib.OPT_HOP_FUSION, old)
+            _lib.prof_enable(False)
+        assert pr["proj"][1] == 5 and pr["alpha"][1] == 0 and pr["mp"][1] == 0, pr
+        threads = torch.get_num_threads(); torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        try:
+            ref = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), heads=4)
+        finally:
+            torch.set_num_threads(threads)
+        assert maxabs(out, ref) < TOL and maxabs(out, out8) < 2e-5     # (the 8-wave kernel on the same shard: same rows within the kernels' tolerance)
+        return
+    rng = np.random.default_rng(6000 + STRATA.index(stratum))
+    bad, ran = [], 0
+    for K in range(1, 6):
+        for rep in range(2):
+            c = stratified_case(rng, 6, stratum, K)
+            c["H"] = 4
+            c["C"] = [512, 448, 400, 512, 480][K - 1] if rep == 0 else int(rng.choice([512, 416, 388 + 4 * int(rng.integers(0, 8))]))
+            c["di"] = int(rng.choice([0, 8, 512]))
+            _lib.prof_enable(True); _lib.prof_collect()
+            ok, errs, sz = run(c, dev)
+            pr = _lib.prof_collect(); _lib.prof_enable(False)
+            assert pr["mp"][1] == 0 and pr["proj"][1] == 2 * K and pr["alpha"][1] == 0 and pr["node_logit"][1] == 0, (c, pr)      # 2 forwards x K hop launches, nothing else
+            ran += 1
+            if not ok:
+                bad.append((c, errs, sz))
+    assert ran == 10 and not bad, (ran, len(bad), bad[:3])
+
+
 def test_parity_sweep_bound_census(dev):
     """tests/fuzz.run asserts north_star's 1e-4 MAX-ABS whenever the oracle's outputs stay within 32 in magnitude and a bound scaled
     by peak / 32 only above that (VERDICT r04 #3a).  This test reports how many of the sweeps' cases (run earlier in this file, same
