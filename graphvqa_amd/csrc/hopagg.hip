@@ -241,6 +241,7 @@ int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, fl
 
 // LDS-DMA with the global address as SGPR base + 32-bit VGPR offset (no 64-bit address registers per lane): 2 x 16 bytes per lane,
 // 1 KiB apart on both sides / 4 bytes per lane
+#ifdef GVQA_HA_M0_SAVE       /* (A/B build switch: round 4's form, M0 saved and restored around every DMA set-up) */
 __device__ __forceinline__ void ha_dma16_x2(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -250,6 +251,18 @@ __device__ __forceinline__ void ha_dma16_x2(const void* sbase, unsigned voff, un
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
+#else
+__device__ __forceinline__ void ha_dma16_x2(const void* sbase, unsigned voff, unsigned lds_dst) {
+    // (M0 is declared clobbered instead of saved and restored around the pair: two SALU instructions less per DMA set-up -- nothing else
+    //  in this kernel lives in M0, and the compiler re-materialises it where it needs it)
+    asm volatile(
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:1024"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory", "m0");
+}
+#endif
 // GVQA_HA_NT (A/B build switch; bits: 1 x-chunk DMAs, 2 skip-row loads, 4 row stores): the ROW traffic of the hop kernel -- x chunks in, skip rows in, result rows out: 16 + 8 MiB per XCD and
 // hop, each line touched once or re-used only ~100 us later -- carries the non-temporal hint, so that it does not push the hop's 4 MiB of
 // weight tiles (re-used by all 32 workgroups of an XCD) out of the XCD's 4 MiB L2.
@@ -261,6 +274,7 @@ __device__ __forceinline__ void ha_dma16_x2(const void* sbase, unsigned voff, un
 #else
 #define GVQA_HA_NT_STR ""
 #endif
+#ifdef GVQA_HA_M0_SAVE
 __device__ __forceinline__ void ha_dma4(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" GVQA_HA_NT_STR "\n\ts_mov_b32 m0, %0"
@@ -268,6 +282,14 @@ __device__ __forceinline__ void ha_dma4(const void* sbase, unsigned voff, unsign
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
+#else
+__device__ __forceinline__ void ha_dma4(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" GVQA_HA_NT_STR
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory", "m0");
+}
+#endif
 typedef float ha_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ha_row_load(const float* p) {
 #if GVQA_HA_NT & 2
