@@ -1133,7 +1133,10 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         }
         return;
     }
-    auto finish = [&](float4 v, int gr, int gc) -> float4 {      // bias / addend / mul / activation on 4 consecutive columns, then the store (C NULL: no store)
+    // (pa / pm: the addend / mul values of this quad when the caller fetched them ahead -- the EPI 1 loop issues a tile's four passes'
+    //  worth of them before it turns the tile through LDS: written with the loads inside, every quad's 16-byte read was issued, waited
+    //  for and consumed alone -- J = XL + [prod | x_ctx] Wj^T of lcgn_seq took 369 us with its addend against 266 without: 183 MB at 1.8 TB/s)
+    auto finish = [&](float4 v, int gr, int gc, const float4* pa = nullptr, const float4* pm = nullptr) -> float4 {      // bias / addend / mul / activation on 4 consecutive columns, then the store (C NULL: no store)
         if constexpr (NP == 2) {                       // undo the operands' power-of-two scales (exact)
             const float sa = a_inv[gr];
             const float4 sb = *reinterpret_cast<const float4*>(b_inv + gc);
@@ -1144,11 +1147,11 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
         }
         if (ep.addend) {
-            const float4 a4 = *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
+            const float4 a4 = pa ? *pa : *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc);
             v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
         }
         if (ep.mul) {
-            const float4 m4 = *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc);
+            const float4 m4 = pm ? *pm : *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc);
             v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
         }
         if (ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -1208,13 +1211,24 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 const int gc = (bn * FB + wc * TN + j) * 32 + cc * 4;
                 float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ep.rowdot_w && gc < N) w4 = *reinterpret_cast<const float4*>(ep.rowdot_w + gc);
+                // the tile's addend / mul quads, all four passes in flight together (they travel under the LDS turn below)
+                float4 pa4[4], pm4[4];
+                if (ep.addend || ep.mul) {
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int gr = (bm * FA + wr * TM + i) * 32 + ps * 8 + rr;
+                        const bool ok = gr < M && gc < N;
+                        pa4[ps] = (ep.addend && ok) ? *reinterpret_cast<const float4*>(ep.addend + (int64_t)gr * ep.ld_add + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        pm4[ps] = (ep.mul && ok) ? *reinterpret_cast<const float4*>(ep.mul + (int64_t)gr * ep.ld_mul + gc) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    }
+                }
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     const int r = ps * 8 + rr;
                     const float4 v = *reinterpret_cast<const float4*>(t + r * 128 + ((cc ^ (r & 7)) << 4));
                     const int gr = (bm * FA + wr * TM + i) * 32 + r;
                     if (gr < M && gc < N) {
-                        const float4 o = finish(v, gr, gc);
+                        const float4 o = finish(v, gr, gc, ep.addend ? &pa4[ps] : nullptr, ep.mul ? &pm4[ps] : nullptr);
                         rd[i][ps] += (o.x * w4.x + o.y * w4.y) + (o.z * w4.z + o.w * w4.w);
                     }
                 }

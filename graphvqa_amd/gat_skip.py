@@ -68,8 +68,10 @@ def _lib_abt(a: Tensor, b: Tensor, bias: Optional[Tensor] = None, out: Optional[
     lib = _lib.load()
     M, K = a.shape
     N = b.shape[0]
-    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
-        raise RuntimeError("graphvqa_amd runs on an MI355X only (no CPU fallback): got %s / %s tensors" % (a.device, a.dtype))
+    if not a.is_cuda:
+        raise RuntimeError("graphvqa_amd runs on an MI355X only (no CPU fallback): got a tensor on %s" % (a.device,))
+    if a.dtype != torch.float32 or b.dtype != torch.float32:       # (fp64 gradcheck, autocast halves: name the dtype -- ADVICE r04)
+        raise TypeError("graphvqa_amd's products take float32 operands (got %s x %s): cast the module and its inputs to float32" % (a.dtype, b.dtype))
     if a.stride(1) != 1 or (M > 1 and a.stride(0) < K):
         a = a.contiguous()
     if b.stride(1) != 1 or (N > 1 and b.stride(0) < K):
