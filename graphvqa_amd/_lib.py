@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GVQA_LIB", os.path.join(HERE, "lib", "libgvqa_hip.so"
 GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack", "alpha")
 # gvqa_set_option keys / values (include/gvqa.h)
-OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS, OPT_HOP_COEFFS, OPT_HOP_HALF_TILES = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS, OPT_HOP_COEFFS, OPT_HOP_HALF_TILES, OPT_TN_DIRECT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 PROJECTION_SPLIT3, PROJECTION_F32, PROJECTION_SPLIT2H = 0, 1, 2
 NUM_STAGES = len(STAGES)
 HOP_KERNELS = ("unfused", "fused8", "persistent", "fused8_chained", "persistent_chained", "aggregate_first", "aggregate_first_seq", "aggregate_first_parts")      # GVQA_HOP_*

@@ -305,6 +305,9 @@ int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t 
                                const int64_t* tok = nullptr, int V = 0, const uint8_t* neg = nullptr);   // tok: Y rows are +-Y[tok[r]] (a table)
 int launch_split2h_pack_rowmul(int64_t rows, int64_t K, const float* X, int64_t ld, const float* R, const int32_t* idx, int64_t ldr, void* packed,
                                hipStream_t stream);
+// C = X^T Y from row-major fp32 operands, split-K chunks of KC rows into S partial results (tn_direct.hip)
+int launch_linear_tn_direct(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy, const float* xmax, int nxmax,
+                            const float* ymax, int nymax, int KC, int S, float* C, int64_t ldc, int64_t zs_c, hipStream_t stream);
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
                         int64_t ldc, hipStream_t stream, int batch = 1,

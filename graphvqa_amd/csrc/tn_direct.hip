@@ -1,0 +1,239 @@
+// C = X^T Y straight from the row-major fp32 operands (gfx950): the weight gradient dW = dy^T x of a projection (the reference gets it from
+// autograd through torch.nn.Linear, /root/reference gat_skip.py:133), a reduction over ALL rows of the batch.
+//
+// train.hip's first form packs both operands TRANSPOSED (k_split2h_pack_t: 1.6 GB of traffic per hop for dy alone) so that the split GEMM of
+// split3.hip can contract over a contiguous dimension.  Here the transposition happens on the way from global memory to the MFMA fragment
+// image in LDS and nothing is packed in HBM:
+//
+//   * workgroup = a 256 x 256 tile of C over one chunk of KC rows (split-K: partial results added in a fixed order by k_splitk_reduce);
+//     8 waves as 2 (128 columns of X) x 4 (64 columns of Y), 4 x 2 accumulators of 32 x 32 per wave;
+//   * K step = 16 rows.  Thread (column c, row half g) of the 512 loads X[r0 + 8 g + j, c], j = 0..7 -- a wave's load instruction is 64
+//     consecutive floats of ONE row, 256 contiguous bytes -- and the same for Y; these eight values ARE the 8 consecutive k of lane
+//     (c mod 32, g) of an MFMA operand fragment: scaled by the operand's power of two, split into two fp16 pieces (v_fma_mix, as the
+//     aggregate-first hop kernel does), written as 2 x 16 bytes into the fragment image of the NEXT step (double-buffered, 64 KiB);
+//   * the loads of step s + 2 are issued when step s + 1's registers have been converted: a full step (~1.4 us) to land;
+//   * one power-of-two scale per operand (train.hip's argument: a piece pair carries 22 bits below each element's own exponent while
+//     the element is within 2^18 of the operand's largest), from the producer's slice maxima or k_absmax.
+//
+// Same arithmetic as the packed form: same scales, same pieces, the same three piece products, fp32 accumulation, the same split-K chunks.
+#include "common.h"
+#include "gemm_tile.h"
+
+namespace gvqa {
+
+typedef _Float16 tnd_f16x8 __attribute__((ext_vector_type(8)));
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GVQA_TND_SPLIT2(hi_, lo_, p_, a_, b_)                                                                                         \
+    asm("v_fma_mixlo_f16 %0, %2, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %4, 0\n\t"                                                          \
+        "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %2, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"       \
+        : "=&v"(hi_), "=&v"(lo_) : "v"(p_), "v"(a_), "v"(b_))
+#else
+#define GVQA_TND_SPLIT2(hi_, lo_, p_, a_, b_) do { (hi_) = 0u; (lo_) = 0u; } while (0)
+#endif
+
+constexpr int TND_TILE = 256, TND_STEP = 16, TND_IMG = 16 * 1024;      // one operand's fragment image of a step: 8 tiles x 2 pieces x 1 KiB
+
+struct TndArgs {
+    int64_t R;
+    int M, N;
+    const float* X; int64_t ldx;
+    const float* Y; int64_t ldy;
+    const float* xmax; int nxmax;
+    const float* ymax; int nymax;
+    int KC, S, tiles_n, ntiles;
+    float* C; int64_t ldc, zs_c;
+};
+
+__global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TND_IMG];
+    __shared__ float mx_s[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // chunk / tile of this workgroup.  The tiles of one chunk read the same rows: consecutive workgroup ids go round the 8 XCDs, so a chunk's
+    // tiles take ids that are 8 apart (one XCD, one L2) when the chunk count allows it
+    int z, tile;
+    {
+        const int L = blockIdx.x;
+        if (a.S % 8 == 0) { const int q = L >> 3; z = (L & 7) + 8 * (q / a.ntiles); tile = q % a.ntiles; }
+        else { z = L / a.ntiles; tile = L % a.ntiles; }
+    }
+    const int m0 = (tile / a.tiles_n) * TND_TILE, n0 = (tile % a.tiles_n) * TND_TILE;
+    const int64_t rbeg = (int64_t)z * a.KC, rend = rbeg + a.KC < a.R ? rbeg + a.KC : a.R;
+    const int rows = (int)(rend - rbeg);
+    const int ns = (rows + TND_STEP - 1) / TND_STEP, nfull = rows / TND_STEP;
+
+    // the operands' scales
+    {
+        float mx = tid < a.nxmax ? a.xmax[tid] : 0.f, my = tid < a.nymax ? a.ymax[tid] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); my = fmaxf(my, __shfl_xor(my, o, 64)); }
+        if (lane == 0) { mx_s[0][wave] = mx; mx_s[1][wave] = my; }
+    }
+    __syncthreads();
+    float vx = 0.f, vy = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { vx = fmaxf(vx, mx_s[0][w]); vy = fmaxf(vy, mx_s[1][w]); }
+    const int ex = split2h_exponent(vx), ey = split2h_exponent(vy);
+
+    // loader role: column c of the tile, row half g.  Buffer loads: a wave-uniform descriptor (base = the step's first row, size = what is left of
+    // the chunk: rows past its end read as zero, no guards anywhere) + eight 32-bit per-lane byte offsets (row j of the half, column c)
+    const int c = tid & 255, g = tid >> 8;
+    const bool okx = m0 + c < a.M, oky = n0 + c < a.N;
+    const float sx = okx ? pow2i(ex) : 0.f, sy = oky ? pow2i(ey) : 0.f;
+    const float* bx = a.X + rbeg * a.ldx;
+    const float* by = a.Y + rbeg * a.ldy;
+    const int64_t bytes_x = ((int64_t)(rows - 1) * a.ldx + a.M) * 4, bytes_y = ((int64_t)(rows - 1) * a.ldy + a.N) * 4;
+    const int64_t step_x = (int64_t)TND_STEP * a.ldx * 4, step_y = (int64_t)TND_STEP * a.ldy * 4;
+    unsigned ox[8], oy[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ox[j] = 4u * (unsigned)((8 * g + j) * a.ldx + (okx ? m0 + c : 0));
+        oy[j] = 4u * (unsigned)((8 * g + j) * a.ldy + (oky ? n0 + c : 0));
+    }
+    auto rsrc_of = [](const float* base, int64_t first, int64_t total) {
+        // (wave-uniform by construction -- kernel arguments and blockIdx -- and made PROVABLY so for the compiler: a descriptor it takes for
+        //  divergent turns every load into a waterfall loop)
+        const int64_t left = total - first;
+        const uint64_t addr = reinterpret_cast<uint64_t>(base) + (uint64_t)(left > 0 ? first : 0);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+        const int n = __builtin_amdgcn_readfirstlane((int)(left > 0 ? left : 0));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), (short)0, n, 0x00020000);
+    };
+#ifndef GVQA_TND_DBG        /* A/B build switch (scripts/ab_tn.sh): bit 1 no loads inside the loop, 2 no split / image writes, 4 no MFMAs */
+#define GVQA_TND_DBG 0
+#endif
+#define GVQA_TND_LD(rs_, off_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (int)(off_), 0, 0))
+#define GVQA_TND_LDL(dst_, rs_, off_) do { if (!(GVQA_TND_DBG & 1)) (dst_) = GVQA_TND_LD(rs_, off_); } while (0)
+#define GVQA_TND_SPL(h_, l_, p_, a_, b_) do { if (!(GVQA_TND_DBG & 2)) GVQA_TND_SPLIT2(h_, l_, p_, a_, b_); } while (0)
+    const unsigned wr_off = (unsigned)((c >> 5) * 2048 + ((c & 31) + 32 * g) * 16);
+    float fa[16], fb[16];                        // two register sets of loaded rows (x: 0..7, y: 8..15): one being converted, one in flight
+    uint4 hx, lx, hy, ly;
+
+    // consumer role: wave (wr, wc) = rows [128 wr, +128) of the tile (4 fragments of X) x columns [64 wc, +64) (2 fragments of Y)
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned a_off = (unsigned)(wr * 4 * 2048 + lane * 16), b_off = (unsigned)(TND_IMG + wc * 2 * 2048 + lane * 16);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto rd = [&](const unsigned char* p) { return __builtin_bit_cast(tnd_f16x8, *reinterpret_cast<const uint4*>(p)); };
+    tnd_f16x8 ah[4], al[4], bh[2], bl[2];
+    // product n of a step: piece pair n / 8 -- (lo, hi), (hi, hi), (hi, lo) -- of accumulator n % 8: the three products of one accumulator are 8 apart
+#define GVQA_TND_MF(n_) do { constexpr int q_ = (n_) / 8, t_ = (n_) % 8, i_ = t_ >> 1, j_ = t_ & 1;                                       \
+        if (!(GVQA_TND_DBG & 4)) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q_ == 0 ? al[i_] : ah[i_], q_ == 2 ? bl[j_] : bh[j_], acc[i_][j_], 0, 0, 0); } while (0)
+#define GVQA_TND_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    {   // step 0's rows -> image 0; step 1's rows in flight in set A
+        const auto r0x = rsrc_of(bx, 0, bytes_x), r0y = rsrc_of(by, 0, bytes_y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fb[j] = GVQA_TND_LD(r0x, ox[j]); fb[8 + j] = GVQA_TND_LD(r0y, oy[j]); }
+        const auto r1x = rsrc_of(bx, step_x, bytes_x), r1y = rsrc_of(by, step_y, bytes_y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = GVQA_TND_LD(r1x, ox[j]); fa[8 + j] = GVQA_TND_LD(r1y, oy[j]); }
+        GVQA_TND_SPLIT2(hx.x, lx.x, sx, fb[0], fb[1]); GVQA_TND_SPLIT2(hx.y, lx.y, sx, fb[2], fb[3]);
+        GVQA_TND_SPLIT2(hx.z, lx.z, sx, fb[4], fb[5]); GVQA_TND_SPLIT2(hx.w, lx.w, sx, fb[6], fb[7]);
+        GVQA_TND_SPLIT2(hy.x, ly.x, sy, fb[8], fb[9]); GVQA_TND_SPLIT2(hy.y, ly.y, sy, fb[10], fb[11]);
+        GVQA_TND_SPLIT2(hy.z, ly.z, sy, fb[12], fb[13]); GVQA_TND_SPLIT2(hy.w, ly.w, sy, fb[14], fb[15]);
+        unsigned char* d = smem + wr_off;
+        *reinterpret_cast<uint4*>(d) = hx; *reinterpret_cast<uint4*>(d + 1024) = lx;
+        *reinterpret_cast<uint4*>(d + TND_IMG) = hy; *reinterpret_cast<uint4*>(d + TND_IMG + 1024) = ly;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) al[i] = rd(smem + a_off + i * 2048 + 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bh[j] = rd(smem + b_off + j * 2048);
+    // One step, laid out by hand: an MFMA holds the SIMD's matrix pipe for 32 cycles and the wave issues in order, so the step's other work --
+    // 16 loads (rows of step s + 2 into set LD_), 32 VALU of the split (rows of step s + 1 out of set CV_), 4 LDS writes -- sits in the shadow of
+    // the first ten MFMAs, a few instructions behind each; the first product's fragments (a lo, b hi) were read under the PREVIOUS step's last MFMAs.  The step's barrier comes right after the image writes (MFMAs queued in front of it
+    // and behind it), not at the end of the step: what it orders is the image of step s + 1 (written above it by everybody, read at the top of the
+    // next step) and the image of step s (read at the top of this step by everybody, overwritten below the NEXT barrier).  Loads have a whole
+    // step to land.  Steps past the chunk's end: the descriptor is empty, the rows read as zero, the products add zeros.
+#define GVQA_TND_STEP(s_, CV_, LD_)                                                                                                           \
+    {                                                                                                                                         \
+        const int st_ = (s_);                                                                                                                 \
+        const unsigned char* img = smem + (st_ & 1) * (2 * TND_IMG);                                                                          \
+        unsigned char* d = smem + ((st_ + 1) & 1) * (2 * TND_IMG) + wr_off;                                                                   \
+        const auto rx_ = rsrc_of(bx, (int64_t)(st_ + 2) * step_x, bytes_x), ry_ = rsrc_of(by, (int64_t)(st_ + 2) * step_y, bytes_y);          \
+        const unsigned char* imn = smem + ((st_ + 1) & 1) * (2 * TND_IMG);                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) ah[i] = rd(img + a_off + i * 2048);                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bl[j] = rd(img + b_off + j * 2048 + 1024);                                              \
+        GVQA_TND_FENCE();                                                                                                                     \
+        GVQA_TND_MF(0); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.x, lx.x, sx, CV_[0], CV_[1]); GVQA_TND_LDL(LD_[0], rx_, ox[0]); GVQA_TND_LDL(LD_[1], rx_, ox[1]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(1); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.y, lx.y, sx, CV_[2], CV_[3]); GVQA_TND_LDL(LD_[2], rx_, ox[2]); GVQA_TND_LDL(LD_[3], rx_, ox[3]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(2); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.z, lx.z, sx, CV_[4], CV_[5]); GVQA_TND_LDL(LD_[4], rx_, ox[4]); GVQA_TND_LDL(LD_[5], rx_, ox[5]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(3); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.w, lx.w, sx, CV_[6], CV_[7]); GVQA_TND_LDL(LD_[6], rx_, ox[6]); GVQA_TND_LDL(LD_[7], rx_, ox[7]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(4); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.x, ly.x, sy, CV_[8], CV_[9]); GVQA_TND_LDL(LD_[8], ry_, oy[0]); GVQA_TND_LDL(LD_[9], ry_, oy[1]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(5); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.y, ly.y, sy, CV_[10], CV_[11]); GVQA_TND_LDL(LD_[10], ry_, oy[2]); GVQA_TND_LDL(LD_[11], ry_, oy[3]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(6); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.z, ly.z, sy, CV_[12], CV_[13]); GVQA_TND_LDL(LD_[12], ry_, oy[4]); GVQA_TND_LDL(LD_[13], ry_, oy[5]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(7); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.w, ly.w, sy, CV_[14], CV_[15]); GVQA_TND_LDL(LD_[14], ry_, oy[6]); GVQA_TND_LDL(LD_[15], ry_, oy[7]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(8); GVQA_TND_FENCE();                                                                                                     \
+        if (!(GVQA_TND_DBG & 2)) { *reinterpret_cast<uint4*>(d) = hx; *reinterpret_cast<uint4*>(d + 1024) = lx; }                            \
+        GVQA_TND_FENCE();                                                                                                                     \
+        GVQA_TND_MF(9); GVQA_TND_FENCE();                                                                                                     \
+        if (!(GVQA_TND_DBG & 2)) { *reinterpret_cast<uint4*>(d + TND_IMG) = hy; *reinterpret_cast<uint4*>(d + TND_IMG + 1024) = ly; }        \
+        GVQA_TND_FENCE();                                                                                                                     \
+        GVQA_TND_MF(10); GVQA_TND_MF(11); GVQA_TND_FENCE();                                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                                         \
+        GVQA_TND_FENCE();                                                                                                                     \
+        GVQA_TND_MF(12); GVQA_TND_MF(13); GVQA_TND_MF(14); GVQA_TND_MF(15);                                                                   \
+        GVQA_TND_FENCE();                                                                                                                     \
+        /* a lo and b hi are dead (products 0 .. 15): the NEXT step's come in under this step's last eight MFMAs, so that step starts on registers */ \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) al[i] = rd(imn + a_off + i * 2048 + 1024);                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bh[j] = rd(imn + b_off + j * 2048);                                                     \
+        GVQA_TND_FENCE();                                                                                                                     \
+        GVQA_TND_MF(16); GVQA_TND_MF(17); GVQA_TND_MF(18); GVQA_TND_MF(19); GVQA_TND_MF(20); GVQA_TND_MF(21); GVQA_TND_MF(22); GVQA_TND_MF(23); \
+        GVQA_TND_FENCE();                                                                                                                     \
+    }
+    for (int s = 0; s < ns; s += 2) {          // (an odd count runs one more step on zero rows)
+        GVQA_TND_STEP(s, fa, fb)
+        GVQA_TND_STEP(s + 1, fb, fa)
+    }
+#undef GVQA_TND_STEP
+#undef GVQA_TND_MF
+#undef GVQA_TND_FENCE
+#undef GVQA_TND_LD
+#undef GVQA_TND_LDL
+#undef GVQA_TND_SPL
+
+    // partial result (or C itself when there is one chunk): C/D map of the 32 x 32 MFMA -- column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const float inv = pow2i(-ex) * pow2i(-ey);
+    float* dst = a.C + (int64_t)z * a.zs_c;
+    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gc = n0 + wc * 64 + j * 32 + ccol;
+        if (gc >= a.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr0 = m0 + wr * 128 + i * 32 + crow0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = gr0 + (r & 3) + 8 * (r >> 2);
+                if (gr < a.M) dst[(int64_t)gr * a.ldc + gc] = acc[i][j][r] * inv;
+            }
+        }
+    }
+}
+
+// X [R, M] (ldx), Y [R, N] (ldy), chunks of KC rows (multiple of 16) -> S partial results C + z zs_c (ldc); maxima as in train.hip
+int launch_linear_tn_direct(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy, const float* xmax, int nxmax,
+                            const float* ymax, int nymax, int KC, int S, float* C, int64_t ldc, int64_t zs_c, hipStream_t stream) {
+    GVQA_REQUIRE(R > 0 && M > 0 && N > 0 && X && Y && C && xmax && ymax && KC > 0 && KC % TND_STEP == 0 && S >= 1 && (int64_t)S * KC >= R && (int64_t)(KC + 16) * ldx < (1ll << 29) &&
+                     (int64_t)(KC + 16) * ldy < (1ll << 29) &&
+                     nxmax >= 1 && nxmax <= 512 && nymax >= 1 && nymax <= 512,
+                 GVQA_E_INVALID, "linear_tn_direct: bad argument");
+    TndArgs a;
+    a.R = R; a.M = (int)M; a.N = (int)N; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.xmax = xmax; a.nxmax = nxmax; a.ymax = ymax; a.nymax = nymax;
+    a.KC = KC; a.S = S; a.tiles_n = (int)cdiv(N, TND_TILE); a.ntiles = (int)cdiv(M, TND_TILE) * a.tiles_n;
+    a.C = C; a.ldc = ldc; a.zs_c = zs_c;
+    hipLaunchKernelGGL(k_linear_tn_direct, dim3((unsigned)((int64_t)a.ntiles * S)), dim3(512), 0, stream, a);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+}  // namespace gvqa

@@ -888,17 +888,22 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
         }
         GVQA_LAUNCH_CHECK();
     }
-    const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
-    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(M, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax,
-                       x_absmax_n, p.KC, p.TA, PA, IA, PackNt{});
-    hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(N, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax,
-                       y_absmax_n, p.KC, p.TB, PB, IB, PackNt{});
-    GVQA_LAUNCH_CHECK();
-    LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
-    ep.zs_a = (int64_t)p.TA * p.KBc * 1024; ep.zs_b = (int64_t)p.TB * p.KBc * 1024; ep.zs_c = M * N;
-    ep.zs_ia = (int64_t)p.TA * 32; ep.zs_ib = (int64_t)p.TB * 32;
     float* dst = p.S == 1 ? C : part;
-    const int rc = launch_linear_split(2, M, N, p.KC, PA, PB, ep, dst, p.S == 1 ? ldc : N, st, p.S, IA, IB);
+    int rc;
+    if (get_option(GVQA_OPT_TN_DIRECT)) {
+        rc = launch_linear_tn_direct(R, M, N, X, ldx, Y, ldy, x_absmax, x_absmax_n, y_absmax, y_absmax_n, p.KC, p.S, dst, p.S == 1 ? ldc : N, M * N, st);
+    } else {
+        const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
+        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(M, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)M, X, ldx, x_absmax,
+                           x_absmax_n, p.KC, p.TA, PA, IA, PackNt{});
+        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(N, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)N, Y, ldy, y_absmax,
+                           y_absmax_n, p.KC, p.TB, PB, IB, PackNt{});
+        GVQA_LAUNCH_CHECK();
+        LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
+        ep.zs_a = (int64_t)p.TA * p.KBc * 1024; ep.zs_b = (int64_t)p.TB * p.KBc * 1024; ep.zs_c = M * N;
+        ep.zs_ia = (int64_t)p.TA * 32; ep.zs_ib = (int64_t)p.TB * 32;
+        rc = launch_linear_split(2, M, N, p.KC, PA, PB, ep, dst, p.S == 1 ? ldc : N, st, p.S, IA, IB);
+    }
     if (rc != GVQA_OK) return rc;
     if (p.S > 1) {
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<int64_t>(cdiv(M * (N / 4), 256), 4096)), dim3(256), 0, st, p.S, (int)M, (int)N,
@@ -978,10 +983,11 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
     if (dx) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(M, 1024)), dim3(256), 0, st, M, (int)K, W, ldw, mx + 2);
     const unsigned slabs = (unsigned)((int64_t)p.tn.S * p.tn.KC / TN_SLAB_ROWS);
     const dim3 gdy(slabs, (unsigned)cdiv(M, TN_SLAB_COLS));
+    const bool direct = get_option(GVQA_OPT_TN_DIRECT) != 0;           // dW reads dy and x as they are: only dx's row-form pack of dy is left
     if (dx) hipLaunchKernelGGL(k_split2h_pack_t<true>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA,
-                               dW ? PA : nullptr, IA, PackNt{PN, IN, p.RT, p.KBw});
-    else hipLaunchKernelGGL(k_split2h_pack_t<false>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA, PA, IA,
-                            PackNt{});
+                               (dW && !direct) ? PA : nullptr, IA, PackNt{PN, IN, p.RT, p.KBw});
+    else if (!direct) hipLaunchKernelGGL(k_split2h_pack_t<false>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA, PA, IA,
+                                         PackNt{});
     GVQA_LAUNCH_CHECK();
     if (dx) {
         // B operand: W^T [K x M] = the transposed pack of W as ONE chunk of KCw rows
@@ -994,14 +1000,20 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
         if (rc != GVQA_OK) return rc;
     }
     if (dW) {
-        hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(K, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)K, x, ldx,
-                           reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.TB, PB, IB, PackNt{});
-        GVQA_LAUNCH_CHECK();
-        LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
-        ep.zs_a = (int64_t)p.tn.TA * p.tn.KBc * 1024; ep.zs_b = (int64_t)p.tn.TB * p.tn.KBc * 1024; ep.zs_c = M * K;
-        ep.zs_ia = (int64_t)p.tn.TA * 32; ep.zs_ib = (int64_t)p.tn.TB * 32;
         float* dst = p.tn.S == 1 ? dW : part;
-        const int rc = launch_linear_split(2, M, K, p.tn.KC, PA, PB, ep, dst, p.tn.S == 1 ? ld_dw : K, st, p.tn.S, IA, IB);
+        int rc;
+        if (direct) {
+            rc = launch_linear_tn_direct(R, M, K, dy, ld_dy, x, ldx, dy_absmax, dy_absmax_n, reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.S, dst,
+                                         p.tn.S == 1 ? ld_dw : K, M * K, st);
+        } else {
+            hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(K, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)K, x, ldx,
+                               reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.TB, PB, IB, PackNt{});
+            GVQA_LAUNCH_CHECK();
+            LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
+            ep.zs_a = (int64_t)p.tn.TA * p.tn.KBc * 1024; ep.zs_b = (int64_t)p.tn.TB * p.tn.KBc * 1024; ep.zs_c = M * K;
+            ep.zs_ia = (int64_t)p.tn.TA * 32; ep.zs_ib = (int64_t)p.tn.TB * 32;
+            rc = launch_linear_split(2, M, K, p.tn.KC, PA, PB, ep, dst, p.tn.S == 1 ? ld_dw : K, st, p.tn.S, IA, IB);
+        }
         if (rc != GVQA_OK) return rc;
         if (p.tn.S > 1) {
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<int64_t>(cdiv(M * (K / 4), 256), 4096)), dim3(256), 0, st, p.tn.S, (int)M,

@@ -415,7 +415,10 @@ enum gvqa_option {
     GVQA_OPT_HOP_HALF_TILES = 8,   /* 8-wave fused hop: 1 (default) the row blocks of a launch's last PARTIAL round of workgroups take one row group each (128-row
                                       half tiles, the empty half's waves skip their products) when that shortens the launch -- config 2: 585 workgroups
                                       = three rounds on 256 CUs for 2.29 rounds of work -> 510 + 145 half tiles; 0 = every block two row groups */
-    GVQA_NUM_OPTIONS = 9
+    GVQA_OPT_TN_DIRECT = 9,        /* weight gradient dW = dy^T x (gvqa_linear_tn_split2h, gvqa_linear_backward_split2h): 1 (default) the product reads the
+                                      row-major fp32 operands itself and transposes them on the way into the MFMA fragment image (tn_direct.hip); 0 = both
+                                      operands packed transposed in HBM first (round 3's form; same scales, pieces and chunks) */
+    GVQA_NUM_OPTIONS = 10
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */

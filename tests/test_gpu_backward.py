@@ -697,11 +697,14 @@ def test_message_passing_with_per_graph_rows_kept_out_of_xp(dev, C, H, with_mask
 
 @pytest.mark.parametrize("R,M,N,ldx", [(5000, 256, 128, 256), (65536, 2048, 512, 2048), (1000, 36, 300, 40), (63, 512, 512, 512),
                                        (70001, 1200, 300, 1200), (0, 64, 32, 64)])
-def test_transposed_split_product_vs_fp64(dev, R, M, N, ldx):
+@pytest.mark.parametrize("direct", [1, 0])
+def test_transposed_split_product_vs_fp64(dev, R, M, N, ldx, direct):
     """gvqa_linear_tn_split2h: C = X^T Y (the weight gradient of the hop projection) against an fp64 product, next to torch's own
-    fp32 matmul on the same operands; ragged R / M / N, a strided X, columns of very different magnitude, the empty case."""
+    fp32 matmul on the same operands; ragged R / M / N, a strided X, columns of very different magnitude, the empty case.
+    direct = 1: the product transposes the row-major operands itself (tn_direct.hip, the default); 0: transposed packs in HBM first."""
     from graphvqa_amd import _lib
     lib = _lib.load()
+    old_direct = _lib.set_option(_lib.OPT_TN_DIRECT, direct)
     g = torch.Generator().manual_seed(R + M + N)
     X = torch.randn((max(R, 1), ldx), generator=g).to(dev)[:R]
     Y = torch.randn((max(R, 1), N), generator=g).to(dev)[:R]
@@ -710,8 +713,11 @@ def test_transposed_split_product_vs_fp64(dev, R, M, N, ldx):
         Y[:, ::3] *= 50.0
     C_ = torch.full((M, N), 3.0, device=dev)
     ws = torch.empty(max(lib.gvqa_linear_tn_workspace_bytes(R, M, N), 256), dtype=torch.uint8, device=dev)
-    _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), ldx, Y.data_ptr(), N, None, 0, None, 0, C_.data_ptr(), N, ws.data_ptr(), ws.numel(),
-                                          torch.cuda.current_stream().cuda_stream))
+    try:
+        _lib.check(lib.gvqa_linear_tn_split2h(R, M, N, X.data_ptr(), ldx, Y.data_ptr(), N, None, 0, None, 0, C_.data_ptr(), N, ws.data_ptr(), ws.numel(),
+                                              torch.cuda.current_stream().cuda_stream))
+    finally:
+        _lib.set_option(_lib.OPT_TN_DIRECT, old_direct)
     ref = X[:, :M].double().t() @ Y.double()
     if R == 0:
         assert bool((C_ == 0).all())
@@ -793,7 +799,8 @@ def test_fold_attention_vs_fp64_einsum(dev, H, C, Kin, two):
 
 @pytest.mark.parametrize("R,M,K,ldw,which", [(5000, 256, 128, 128, "both"), (65536, 2048, 512, 1024, "both"), (1000, 36, 300, 300, "both"),
                                              (63, 512, 512, 512, "dx"), (70001, 1200, 300, 812, "dw"), (4097, 100, 64, 64, "both")])
-def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which):
+@pytest.mark.parametrize("direct", [1, 0])
+def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which, direct):
     """gvqa_linear_backward_split2h: dx = dy W and dW = dy^T x from ONE pass over dy, against fp64 products and next to torch's fp32
     matmuls; W as a column slice of a wider weight (row stride), ragged sizes, rows of dy of very different magnitude (the packed
     rows share the operand's one scale), either gradient alone."""
@@ -809,8 +816,12 @@ def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which):
     dW = torch.full((M, K), 5.0, device=dev) if which in ("both", "dw") else None
     ws = torch.empty(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dtype=torch.uint8, device=dev)
     p = lambda a: None if a is None else a.data_ptr()
-    _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, p(dx), K, 0, p(dW), K,
-                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    old_direct = _lib.set_option(_lib.OPT_TN_DIRECT, direct)        # (1: dW reads dy and x as they are -- tn_direct.hip; 0: transposed packs first)
+    try:
+        _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, dy.data_ptr(), M, W.data_ptr(), ldw, x.data_ptr(), K, None, 0, p(dx), K, 0, p(dW), K,
+                                                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    finally:
+        _lib.set_option(_lib.OPT_TN_DIRECT, old_direct)
     if dx is not None:
         ref = dy.double() @ W.double()
         bound = dy.double().abs() @ W.double().abs()
