@@ -220,6 +220,183 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// C = A B^T with A taken as it is -- row-major fp32 rows, e.g. dy of dx = dy W (the input gradient of the projection) -- and B packed (the small,
+// weight-sized operand: two-piece fragments [tile][k block][piece][lane][8] + per-row inverse scales, what k_split2h_pack_t / gvqa_split2h_pack
+// write).  The row-form pack of dy (537 MB read, 537 MB written per hop at config 3, 263 us) goes away: thread (row, k half) of the 512 loads its
+// 8 consecutive floats of the step (2 x 16 bytes), scales by the operand's ONE power of two (as the pack it replaces does for gradients:
+// train.hip), splits, and writes the two 16-byte fragment units; B's 16 KiB of the step are copied global -> registers -> image.  Step layout,
+// barrier placement and fragment rotation as in k_linear_tn_direct.  K % 16 == 0.
+struct NndArgs {
+    int64_t R;
+    int N, K;
+    const float* A; int64_t lda;
+    const float* amax; int namax;
+    const uint16_t* Bpk; int KBb, TB;         // k blocks per tile in the pack, tiles
+    const float* b_inv;
+    float* C; int64_t ldc;
+    int accumulate, tiles_n, row_tiles;
+};
+
+__global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TND_IMG];
+    __shared__ float mx_s[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the column tiles of one row tile read the same rows of A: they take workgroup ids 8 apart (one XCD, one L2)
+    const int q = blockIdx.x >> 3, rt = (q / a.tiles_n) * 8 + (blockIdx.x & 7), ct = q % a.tiles_n;
+    if (rt >= a.row_tiles) return;
+    const int m0 = rt * TND_TILE, n0 = ct * TND_TILE;
+    const int ns = a.K / TND_STEP;
+    {
+        float m = tid < a.namax ? a.amax[tid] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) mx_s[wave] = m;
+    }
+    __syncthreads();
+    float vm = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) vm = fmaxf(vm, mx_s[w]);
+    const int ea = split2h_exponent(vm);
+    const float sa = pow2i(ea);
+
+    auto rsrc_of = [](const void* base, int64_t first, int64_t total) {
+        const int64_t left = total - first;
+        const uint64_t addr = reinterpret_cast<uint64_t>(base) + (uint64_t)(left > 0 ? first : 0);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+        const int n = __builtin_amdgcn_readfirstlane((int)(left > 0 ? left : 0));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), (short)0, n, 0x00020000);
+    };
+    // loader roles.  A: row tid / 2 of the tile, k half tid & 1 (rows past R: beyond the descriptor, read as zero).  B: tile tid / 64, lane tid & 63
+    const int arow = tid >> 1, ag = tid & 1;
+    const int64_t bytes_a = ((a.R - 1) * a.lda + a.K) * 4, bytes_b = (int64_t)a.TB * a.KBb * 2048;
+    const unsigned oa = (unsigned)(((int64_t)(m0 + arow) * a.lda + 8 * ag) * 4);
+    const unsigned ob = (unsigned)((int64_t)(ct * 8 + (tid >> 6)) * a.KBb * 2048 + lane * 16);
+    const unsigned wa_off = (unsigned)((arow >> 5) * 2048 + ((arow & 31) + 32 * ag) * 16);
+    const unsigned wb_off = (unsigned)(TND_IMG + (tid >> 6) * 2048 + lane * 16);
+    typedef float nnd_f32x4 __attribute__((ext_vector_type(4)));
+    nnd_f32x4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;       // two register sets (A: 8 floats, B: hi / lo fragment units), one converted, one in flight
+#define GVQA_NND_LD4(rs_, off_) __builtin_bit_cast(nnd_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(off_), 0, 0))
+    uint4 hx, lx;
+
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned a_off = (unsigned)(wr * 4 * 2048 + lane * 16), b_off = (unsigned)(TND_IMG + wc * 2 * 2048 + lane * 16);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto rd = [&](const unsigned char* p) { return __builtin_bit_cast(tnd_f16x8, *reinterpret_cast<const uint4*>(p)); };
+    tnd_f16x8 ah[4], al[4], bh[2], bl[2];
+#define GVQA_NND_MF(n_) do { constexpr int q_ = (n_) / 8, t_ = (n_) % 8, i_ = t_ >> 1, j_ = t_ & 1;                                       \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q_ == 0 ? al[i_] : ah[i_], q_ == 2 ? bl[j_] : bh[j_], acc[i_][j_], 0, 0, 0); } while (0)
+#define GVQA_NND_FENCE() __builtin_amdgcn_sched_barrier(0)
+    {
+        const auto r0a = rsrc_of(a.A, 0, bytes_a), r0b = rsrc_of(a.Bpk, 0, bytes_b);
+        qa0 = GVQA_NND_LD4(r0a, oa); qa1 = GVQA_NND_LD4(r0a, oa + 16); qb0 = GVQA_NND_LD4(r0b, ob); qb1 = GVQA_NND_LD4(r0b, ob + 1024);
+        const auto r1a = rsrc_of(a.A, ns > 1 ? 64 : bytes_a, bytes_a), r1b = rsrc_of(a.Bpk, 2048, bytes_b);      // (steps past the last: an empty descriptor, zeros)
+        pa0 = GVQA_NND_LD4(r1a, oa); pa1 = GVQA_NND_LD4(r1a, oa + 16); pb0 = GVQA_NND_LD4(r1b, ob); pb1 = GVQA_NND_LD4(r1b, ob + 1024);
+        GVQA_TND_SPLIT2(hx.x, lx.x, sa, qa0.x, qa0.y); GVQA_TND_SPLIT2(hx.y, lx.y, sa, qa0.z, qa0.w);
+        GVQA_TND_SPLIT2(hx.z, lx.z, sa, qa1.x, qa1.y); GVQA_TND_SPLIT2(hx.w, lx.w, sa, qa1.z, qa1.w);
+        *reinterpret_cast<uint4*>(smem + wa_off) = hx; *reinterpret_cast<uint4*>(smem + wa_off + 1024) = lx;
+        *reinterpret_cast<nnd_f32x4*>(smem + wb_off) = qb0; *reinterpret_cast<nnd_f32x4*>(smem + wb_off + 1024) = qb1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) al[i] = rd(smem + a_off + i * 2048 + 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bh[j] = rd(smem + b_off + j * 2048);
+    // step s_: rows of step s + 1 (set CA_/CB_) -> image, rows of step s + 2 -> set LA_/LB_
+#define GVQA_NND_STEP(s_, CA0_, CA1_, CB0_, CB1_, LA0_, LA1_, LB0_, LB1_)                                                                     \
+    {                                                                                                                                         \
+        const int st_ = (s_);                                                                                                                 \
+        const unsigned char* img = smem + (st_ & 1) * (2 * TND_IMG);                                                                          \
+        const unsigned char* imn = smem + ((st_ + 1) & 1) * (2 * TND_IMG);                                                                    \
+        unsigned char* dn = smem + ((st_ + 1) & 1) * (2 * TND_IMG);                                                                           \
+        const auto ra_ = rsrc_of(a.A, st_ + 2 < ns ? (int64_t)(st_ + 2) * 64 : bytes_a, bytes_a), rb_ = rsrc_of(a.Bpk, (int64_t)(st_ + 2) * 2048, bytes_b); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) ah[i] = rd(img + a_off + i * 2048);                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bl[j] = rd(img + b_off + j * 2048 + 1024);                                              \
+        GVQA_NND_FENCE();                                                                                                                     \
+        GVQA_NND_MF(0); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.x, lx.x, sa, CA0_.x, CA0_.y); LA0_ = GVQA_NND_LD4(ra_, oa); GVQA_NND_FENCE();      \
+        GVQA_NND_MF(1); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.y, lx.y, sa, CA0_.z, CA0_.w); LA1_ = GVQA_NND_LD4(ra_, oa + 16); GVQA_NND_FENCE(); \
+        GVQA_NND_MF(2); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.z, lx.z, sa, CA1_.x, CA1_.y); GVQA_NND_FENCE();                                   \
+        GVQA_NND_MF(3); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.w, lx.w, sa, CA1_.z, CA1_.w); GVQA_NND_FENCE();                                   \
+        GVQA_NND_MF(4); GVQA_NND_FENCE();                                                                                                     \
+        *reinterpret_cast<uint4*>(dn + wa_off) = hx; *reinterpret_cast<uint4*>(dn + wa_off + 1024) = lx;                                      \
+        GVQA_NND_FENCE();                                                                                                                     \
+        GVQA_NND_MF(5); GVQA_NND_FENCE();                                                                                                     \
+        *reinterpret_cast<nnd_f32x4*>(dn + wb_off) = CB0_; *reinterpret_cast<nnd_f32x4*>(dn + wb_off + 1024) = CB1_;                            \
+        GVQA_NND_FENCE();                                                                                                                     \
+        GVQA_NND_MF(6); GVQA_NND_FENCE(); LB0_ = GVQA_NND_LD4(rb_, ob); LB1_ = GVQA_NND_LD4(rb_, ob + 1024); GVQA_NND_FENCE();                 \
+        GVQA_NND_MF(7); GVQA_NND_FENCE();                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                                         \
+        GVQA_NND_FENCE();                                                                                                                     \
+        GVQA_NND_MF(8); GVQA_NND_MF(9); GVQA_NND_MF(10); GVQA_NND_MF(11); GVQA_NND_MF(12); GVQA_NND_MF(13); GVQA_NND_MF(14); GVQA_NND_MF(15);  \
+        GVQA_NND_FENCE();                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) al[i] = rd(imn + a_off + i * 2048 + 1024);                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bh[j] = rd(imn + b_off + j * 2048);                                                     \
+        GVQA_NND_FENCE();                                                                                                                     \
+        GVQA_NND_MF(16); GVQA_NND_MF(17); GVQA_NND_MF(18); GVQA_NND_MF(19); GVQA_NND_MF(20); GVQA_NND_MF(21); GVQA_NND_MF(22); GVQA_NND_MF(23); \
+        GVQA_NND_FENCE();                                                                                                                     \
+    }
+    for (int s = 0; s < ns; s += 2) {          // (an odd count runs one more step on zero operands)
+        GVQA_NND_STEP(s, pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1)
+        GVQA_NND_STEP(s + 1, qa0, qa1, qb0, qb1, pa0, pa1, pb0, pb1)
+    }
+#undef GVQA_NND_STEP
+#undef GVQA_NND_MF
+#undef GVQA_NND_FENCE
+#undef GVQA_NND_LD4
+
+    const float ainv = pow2i(-ea);
+    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gc = n0 + wc * 64 + j * 32 + ccol;
+        if (gc >= a.N) continue;
+        const float inv = ainv * a.b_inv[gc];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr0 = m0 + wr * 128 + i * 32 + crow0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = gr0 + (r & 3) + 8 * (r >> 2);
+                if (gr < a.R) {
+                    float v = acc[i][j][r] * inv;
+                    if (a.accumulate) v += a.C[gr * a.ldc + gc];
+                    a.C[gr * a.ldc + gc] = v;
+                }
+            }
+        }
+    }
+}
+
+bool linear_nn_direct_applies(int64_t R, int64_t N, int64_t K, int64_t lda) {
+    return R > 0 && N > 0 && K > 0 && K % TND_STEP == 0 && lda % 4 == 0 && (R + TND_TILE) * lda < (1ll << 29);
+}
+
+// C [R, N] (+)= A [R, K] (fp32 rows, lda, one scale from amax) x packed B [N rows, K] (TB tiles of KBb k blocks, b_inv [N])
+int launch_linear_nn_direct(int64_t R, int64_t N, int64_t K, const float* A, int64_t lda, const float* amax, int namax, const void* Bpk, int KBb, int TB,
+                            const float* b_inv, float* C, int64_t ldc, int accumulate, hipStream_t stream) {
+    GVQA_REQUIRE(linear_nn_direct_applies(R, N, K, lda) && A && amax && Bpk && b_inv && C && namax >= 1 && namax <= 512 && KBb * TND_STEP >= K &&
+                     (int64_t)TB * 32 >= N && (reinterpret_cast<uintptr_t>(A) & 15) == 0,
+                 GVQA_E_INVALID, "linear_nn_direct: bad argument");
+    NndArgs a;
+    a.R = R; a.N = (int)N; a.K = (int)K; a.A = A; a.lda = lda; a.amax = amax; a.namax = namax; a.Bpk = static_cast<const uint16_t*>(Bpk); a.KBb = KBb; a.TB = TB;
+    a.b_inv = b_inv; a.C = C; a.ldc = ldc; a.accumulate = accumulate; a.tiles_n = (int)cdiv(N, TND_TILE); a.row_tiles = (int)cdiv(R, TND_TILE);
+    const int64_t groups = cdiv(a.row_tiles, 8) * a.tiles_n;
+    hipLaunchKernelGGL(k_linear_nn_direct, dim3((unsigned)(groups * 8)), dim3(512), 0, stream, a);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+bool linear_tn_direct_applies(int KC, int64_t ldx, int64_t ldy) {
+    return KC > 0 && KC % TND_STEP == 0 && (int64_t)(KC + 16) * ldx < (1ll << 29) && (int64_t)(KC + 16) * ldy < (1ll << 29);
+}
+
 // X [R, M] (ldx), Y [R, N] (ldy), chunks of KC rows (multiple of 16) -> S partial results C + z zs_c (ldc); maxima as in train.hip
 int launch_linear_tn_direct(int64_t R, int64_t M, int64_t N, const float* X, int64_t ldx, const float* Y, int64_t ldy, const float* xmax, int nxmax,
                             const float* ymax, int nymax, int KC, int S, float* C, int64_t ldc, int64_t zs_c, hipStream_t stream) {

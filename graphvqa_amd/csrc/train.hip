@@ -890,7 +890,7 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
     }
     float* dst = p.S == 1 ? C : part;
     int rc;
-    if (get_option(GVQA_OPT_TN_DIRECT)) {
+    if (get_option(GVQA_OPT_TN_DIRECT) && linear_tn_direct_applies(p.KC, ldx, ldy)) {
         rc = launch_linear_tn_direct(R, M, N, X, ldx, Y, ldy, x_absmax, x_absmax_n, y_absmax, y_absmax_n, p.KC, p.S, dst, p.S == 1 ? ldc : N, M * N, st);
     } else {
         const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
@@ -983,8 +983,13 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
     if (dx) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(M, 1024)), dim3(256), 0, st, M, (int)K, W, ldw, mx + 2);
     const unsigned slabs = (unsigned)((int64_t)p.tn.S * p.tn.KC / TN_SLAB_ROWS);
     const dim3 gdy(slabs, (unsigned)cdiv(M, TN_SLAB_COLS));
-    const bool direct = get_option(GVQA_OPT_TN_DIRECT) != 0;           // dW reads dy and x as they are: only dx's row-form pack of dy is left
-    if (dx) hipLaunchKernelGGL(k_split2h_pack_t<true>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA,
+    // GVQA_OPT_TN_DIRECT: both products read dy (and x) as they are -- dW transposes on the way into its fragment image, dx converts its rows
+    // of dy in the kernel (tn_direct.hip) -- and dy is not packed at all
+    const bool direct = get_option(GVQA_OPT_TN_DIRECT) != 0 && linear_tn_direct_applies(p.tn.KC, ld_dy, dW ? ldx : 4);
+    const bool direct_dx = dx && get_option(GVQA_OPT_TN_DIRECT) != 0 && M % 16 == 0 && linear_nn_direct_applies(R, K, M, ld_dy) &&
+                           (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    if (dx && direct_dx && (!dW || direct)) { /* no pack of dy */ }
+    else if (dx) hipLaunchKernelGGL(k_split2h_pack_t<true>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA,
                                (dW && !direct) ? PA : nullptr, IA, PackNt{PN, IN, p.RT, p.KBw});
     else if (!direct) hipLaunchKernelGGL(k_split2h_pack_t<false>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA, PA, IA,
                                          PackNt{});
@@ -996,7 +1001,9 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
         GVQA_LAUNCH_CHECK();
         LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
         if (dx_accumulate) { ep.addend = dx; ep.ld_add = ld_dx; }      // dx += dy W (the GEMM's epilogue reads the element it writes)
-        const int rc = launch_linear_split(2, R, K, p.KCw, PN, PW, ep, dx, ld_dx, st, 1, IN, IW);
+        const int rc = (direct_dx && (!dW || direct))
+                           ? launch_linear_nn_direct(R, K, M, dy, ld_dy, dy_absmax, dy_absmax_n, PW, p.KBw, p.TBw, IW, dx, ld_dx, dx_accumulate, st)
+                           : launch_linear_split(2, R, K, p.KCw, PN, PW, ep, dx, ld_dx, st, 1, IN, IW);
         if (rc != GVQA_OK) return rc;
     }
     if (dW) {
