@@ -61,7 +61,8 @@ class GatMpDesc(C.Structure):
                 ("graph_scale", C.c_void_p), ("graph_scale_ld", C.c_int64), ("skip", C.c_void_p),
                 ("skip_ld", C.c_int64), ("bias", C.c_void_p), ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p),
                 ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int64),
-                ("alpha_out", C.c_void_p), ("alpha_mask", C.c_void_p), ("force", C.c_int32)]
+                ("alpha_out", C.c_void_p), ("alpha_mask", C.c_void_p), ("force", C.c_int32),
+                ("head_rows", C.c_void_p), ("head_rows_ld", C.c_int64), ("head_weight_out", C.c_void_p)]
 
 
 ABSMAX_SLOTS = 256        # GVQA_ABSMAX_SLOTS

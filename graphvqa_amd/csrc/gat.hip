@@ -137,6 +137,9 @@ struct MpArgs {
     float* alpha_out;         // NULL or [E, H] COO order (the softmax output, before the mask)
     const float* alpha_mask;  // NULL or [E, H] COO order: multiplies alpha after the softmax (attention dropout)
     float* alpha_csr;         // general kernel only: [E, H] in CSR slot order
+    const float* head_rows;   // tiled kernel: NULL or [B, hr_ld] per-graph rows added per HEAD, weighted by the node's coefficient sums (below)
+    int64_t hr_ld;
+    float* head_weight_out;   // NULL or [N, H]: s[i, h] = sum over the in-edges of alpha * mask (written with head_rows; the backward's operand)
     int N, C, cw;             // cw: channel chunk width handled by one block (tiled kernel)
     int e_cap, n_cap;         // LDS capacity in edges / nodes per graph (tiled kernel)
     int nbuf;                 // stage buffers in LDS (prefetch depth = nbuf - 1)
@@ -233,7 +236,7 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-template <int H, int ITEMS>
+template <int H, int ITEMS, bool HR = false>
 __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const size_t off_src = (size_t)a.e_cap * H * 4;
@@ -248,7 +251,8 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     const size_t off_ap = (off_ps + (size_t)(a.n_cap + 1) * 4 + 15) & ~(size_t)15;
     const size_t off_sq = off_ap + (size_t)H * EPQ * 16;
     const size_t off_cst = off_sq + (size_t)EPQ * 16;
-    const size_t off_buf = off_cst + (size_t)5 * a.C * 4;
+    const size_t off_hr = off_cst + (size_t)5 * a.C * 4;                       // [H][C] per-graph head rows (head_rows only)
+    const size_t off_buf = off_hr + (a.head_rows ? (size_t)H * a.C * 4 : 0);
     float* alpha_s = reinterpret_cast<float*>(smem);
     int* src_l = reinterpret_cast<int*>(smem + off_src);
     int* rowp_l = reinterpret_cast<int*>(smem + off_row);
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
     float* alpha_p = reinterpret_cast<float*>(smem + off_ap);   // [H][4 EPQ]
     int* srcq = reinterpret_cast<int*>(smem + off_sq);          // [4 EPQ] local source row of every padded slot
     float* cst = reinterpret_cast<float*>(smem + off_cst);      // [pbar | bias | scale | shift | gscale][C]
+    float* hrow = reinterpret_cast<float*>(smem + off_hr);
     // stage buffers hold whole DMA rounds of MP_THREADS units
     const size_t buf_bytes = (((size_t)a.n_cap * (a.cw >> 2) + MP_THREADS - 1) / MP_THREADS) * MP_THREADS * 16;
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
@@ -340,6 +345,8 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
         cst[3 * C + c] = sh;
         cst[4 * C + c] = a.graph_scale ? a.graph_scale[(int64_t)g * a.gs_ld + c] : 1.f;
     }
+    if (a.head_rows)
+        for (int c = tid; c < H * C; c += MP_THREADS) hrow[c] = a.head_rows[(int64_t)g * a.hr_ld + c];
     for (int u = tid; u < (H + 1) * EPQ; u += MP_THREADS)      // padded table: all slots zero weight / row 0 first (alpha_p | srcq are contiguous)
         reinterpret_cast<float4*>(alpha_p)[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -469,15 +476,27 @@ __global__ __launch_bounds__(MP_THREADS, 6) void k_gat_mp_tiled(MpArgs a) {
             for (int k = 0; k < ITEMS; ++k) {
                 const int q0 = it_q0[k], own = it_own[k], trips = it_trips[k];
                 float4 s4 = acc[k];
+                float wsum = 0.f;                               // (head_rows: the node's coefficient sum of this head)
                 for (int tr = 0; tr < trips; ++tr) {
                     const int pq = tr < own ? q0 + tr : zq;     // (past this node's list: the all-zero quad)
                     const int4 sl = sq4[pq];
                     const float4 al = ap4[pq];
+                    if (HR) wsum += (al.x + al.y) + (al.z + al.w);
                     const float4 v0 = buf4[sl.x * q4c + qq], v1 = buf4[sl.y * q4c + qq], v2 = buf4[sl.z * q4c + qq], v3 = buf4[sl.w * q4c + qq];
                     s4.x += al.x * v0.x; s4.y += al.x * v0.y; s4.z += al.x * v0.z; s4.w += al.x * v0.w;
                     s4.x += al.y * v1.x; s4.y += al.y * v1.y; s4.z += al.y * v1.z; s4.w += al.y * v1.w;
                     s4.x += al.z * v2.x; s4.y += al.z * v2.y; s4.z += al.z * v2.z; s4.w += al.z * v2.w;
                     s4.x += al.w * v3.x; s4.y += al.w * v3.y; s4.z += al.w * v3.z; s4.w += al.w * v3.w;
+                }
+                if (HR) {
+                    // the per-graph row of this head rides on the node's coefficient sum: MP(xp + rows[graph]) without forming the sum
+                    // (gat_skip.py:133,263-264: the instruction half of lin_l).  No mask: the sum is 1 (0 without in-edges), exactly
+                    if (!a.alpha_mask) wsum = own > 0 ? 1.f : 0.f;
+                    const float4 hr = *reinterpret_cast<const float4*>(hrow + j * C + c0 + qq * 4);
+                    s4.x += wsum * hr.x; s4.y += wsum * hr.y; s4.z += wsum * hr.z; s4.w += wsum * hr.w;
+                    const int i = i_base + k * i_step;
+                    if (a.head_weight_out && q == 0 && i < tn && part == 0 && c0 == 0)
+                        a.head_weight_out[(int64_t)(n0 + i) * H + j] = wsum;
                 }
                 acc[k] = s4;
             }
@@ -829,13 +848,13 @@ static size_t env_size(const char* name, size_t dflt) {
 #endif
 }
 
-static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, int nbuf) {
+static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, int nbuf, bool head_rows = false) {
     size_t off = e_cap * H * 4;
     off = align_up(off + e_cap * 4, 16);
     off = align_up(off + (n_cap + 1) * 4, 16);
     off = align_up(off + (n_cap + 1) * 4, 16);                                      // quad starts
     off += (size_t)(H + 1) * (size_t)mp_padded_quads((int)e_cap, (int)n_cap) * 16;  // padded coefficients (head-major) + source rows
-    off += (size_t)5 * C * 4;
+    off += (size_t)5 * C * 4 + (head_rows ? (size_t)H * C * 4 : 0);
     return off + (size_t)nbuf * align_up(n_cap * (size_t)(cw / 4), MP_THREADS) * 16;
 }
 
@@ -845,7 +864,7 @@ static size_t tiled_lds_bytes(size_t e_cap, size_t n_cap, int C, int H, int cw, 
 // fits (row segments of >= 256 B preferred, >= 128 B required unless C is smaller), subject to the
 // per-thread accumulator budget.  If nothing fits the 3-per-CU target, 2 then 1 per CU.
 // Tunables for experiments: GVQA_MP_CW, GVQA_MP_NBUF, GVQA_MP_LDS (bytes per block).
-static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
+static TilePlan plan_tiled(const gvqa_graph* g, int C, int H, bool head_rows = false) {
     TilePlan p{false, 0, 0, 0, 0, 0, 0};
     if (!g->finalized || !g->intra_graph || (C & 3) || !(H == 1 || H == 2 || H == 4 || H == 8)) return p;
     if (g->num_graphs <= 0 || g->num_graphs > 0x7fffffff) return p;
@@ -869,7 +888,7 @@ static TilePlan plan_tiled(const gvqa_graph* g, int C, int H) {
                 while ((1 << lpn_log) < cw / 4) ++lpn_log;
                 if (cw > C || (1 << lpn_log) > MP_THREADS ||
                     n_cap > (size_t)MP_ITEMS * (MP_THREADS >> lpn_log)) { if (forced_cw) break; continue; }
-                const size_t bytes = tiled_lds_bytes(e_cap, n_cap, C, H, cw, nbuf);
+                const size_t bytes = tiled_lds_bytes(e_cap, n_cap, C, H, cw, nbuf, head_rows);
                 if (bytes > target) { if (forced_cw) break; continue; }
                 if (cw < 32 && cw < C && ti < 2 && !forced_cw) break;        // segments < 128 B: next target
                 size_t score = (size_t)(nbuf - 1) * n_cap * cw * 4;           // bytes in flight per block
@@ -898,7 +917,7 @@ static int plan_parts(int64_t B, int C, const TilePlan& p) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(nch, cdiv(2 * 256, std::max<int64_t>(B, 1))));
 }
 
-template <int H, int ITEMS>
+template <int H, int ITEMS, bool HR = false>
 static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
     // the 160 KiB dynamic-LDS opt-in is a per-device function attribute: set once per (instantiation, device)
     static std::mutex mu;
@@ -908,12 +927,12 @@ static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStre
     {
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H, ITEMS>),
+            GVQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_mp_tiled<H, ITEMS, HR>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL((k_gat_mp_tiled<H, ITEMS>), dim3((unsigned)B, (unsigned)a.nparts), dim3(MP_THREADS), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_gat_mp_tiled<H, ITEMS, HR>), dim3((unsigned)B, (unsigned)a.nparts), dim3(MP_THREADS), p.lds_bytes, stream, a);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -921,6 +940,10 @@ static int launch_tiled_i(const MpArgs& a, const TilePlan& p, int64_t B, hipStre
 template <int H>
 static int launch_tiled(const MpArgs& a, const TilePlan& p, int64_t B, hipStream_t stream) {
     // fewer accumulators (registers) when the largest graph needs only two node passes per thread
+    if (a.head_rows) {
+        if ((size_t)p.n_cap <= (size_t)2 * (MP_THREADS >> p.lpn_log)) return launch_tiled_i<H, 2, true>(a, p, B, stream);
+        return launch_tiled_i<H, MP_ITEMS, true>(a, p, B, stream);
+    }
     if ((size_t)p.n_cap <= (size_t)2 * (MP_THREADS >> p.lpn_log)) return launch_tiled_i<H, 2>(a, p, B, stream);
     return launch_tiled_i<H, MP_ITEMS>(a, p, B, stream);
 }
@@ -948,6 +971,9 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
     a.bias = d->bias;
     a.bn_w = d->bn_weight; a.bn_b = d->bn_bias; a.bn_m = d->bn_mean; a.bn_v = d->bn_var;
     a.out = d->out; a.out_ld = d->out_ld ? d->out_ld : C; a.alpha_out = d->alpha_out; a.alpha_mask = d->alpha_mask; a.alpha_csr = nullptr;
+    a.head_rows = d->head_rows; a.hr_ld = d->head_rows_ld ? d->head_rows_ld : (int64_t)H * C; a.head_weight_out = d->head_rows ? d->head_weight_out : nullptr;
+    GVQA_REQUIRE(!d->head_rows || (a.hr_ld >= (int64_t)H * C && !d->graph_term && !d->graph_scale), GVQA_E_INVALID,
+                 "gat_mp: head_rows needs head_rows_ld >= H*C and excludes graph_term / graph_scale");
     a.N = (int)g->num_nodes; a.C = C; a.cw = 0; a.e_cap = 0; a.n_cap = 0; a.nbuf = 2; a.nparts = 1; a.lpn_log = 0;
 #ifdef GVQA_PROBES
     { const char* dv = getenv("GVQA_MP_DEBUG"); a.debug = dv ? atoi(dv) : 0; }
@@ -960,8 +986,9 @@ static int launch_gat_mp(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* w
                              reinterpret_cast<uintptr_t>(a.skip)) & 15) == 0;
 
     StageTimer timer(GVQA_STAGE_MP, stream);
-    TilePlan plan = plan_tiled(g, C, H);
+    TilePlan plan = plan_tiled(g, C, H, d->head_rows != nullptr);
     if (!ld_vec_ok) plan.ok = false;
+    GVQA_REQUIRE(!d->head_rows || (plan.ok && force != 2), GVQA_E_UNSUPPORTED, "gat_mp: head_rows needs the LDS-tiled kernel (gvqa_graph_head_rows_add is the general form)");
     GVQA_REQUIRE(force != 1 || plan.ok, GVQA_E_UNSUPPORTED,
                  "gat_mp: tiled kernel not applicable (needs finalized intra-graph batch, C %% 4 == 0, "
                  "H in {1,2,4,8}, largest graph fitting 160 KiB of LDS)");

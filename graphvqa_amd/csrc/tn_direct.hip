@@ -290,8 +290,11 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto rd = [&](const unsigned char* p) { return __builtin_bit_cast(tnd_f16x8, *reinterpret_cast<const uint4*>(p)); };
     tnd_f16x8 ah[4], al[4], bh[2], bl[2];
+#ifndef GVQA_NND_DBG        /* A/B build switch: bit 1 no A loads in the loop, 2 no split / A image writes, 4 no MFMAs, 8 no B loads / writes */
+#define GVQA_NND_DBG 0
+#endif
 #define GVQA_NND_MF(n_) do { constexpr int q_ = (n_) / 8, t_ = (n_) % 8, i_ = t_ >> 1, j_ = t_ & 1;                                       \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q_ == 0 ? al[i_] : ah[i_], q_ == 2 ? bl[j_] : bh[j_], acc[i_][j_], 0, 0, 0); } while (0)
+        if (!(GVQA_NND_DBG & 4)) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q_ == 0 ? al[i_] : ah[i_], q_ == 2 ? bl[j_] : bh[j_], acc[i_][j_], 0, 0, 0); } while (0)
 #define GVQA_NND_FENCE() __builtin_amdgcn_sched_barrier(0)
     {
         const auto r0a = rsrc_of(a.A, 0, bytes_a), r0b = rsrc_of(a.Bpk, 0, bytes_b);
@@ -319,17 +322,17 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i) ah[i] = rd(img + a_off + i * 2048);                                                     \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) bl[j] = rd(img + b_off + j * 2048 + 1024);                                              \
         GVQA_NND_FENCE();                                                                                                                     \
-        GVQA_NND_MF(0); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.x, lx.x, sa, CA0_.x, CA0_.y); LA0_ = GVQA_NND_LD4(ra_, oa); GVQA_NND_FENCE();      \
-        GVQA_NND_MF(1); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.y, lx.y, sa, CA0_.z, CA0_.w); LA1_ = GVQA_NND_LD4(ra_, oa + 16); GVQA_NND_FENCE(); \
-        GVQA_NND_MF(2); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.z, lx.z, sa, CA1_.x, CA1_.y); GVQA_NND_FENCE();                                   \
-        GVQA_NND_MF(3); GVQA_NND_FENCE(); GVQA_TND_SPLIT2(hx.w, lx.w, sa, CA1_.z, CA1_.w); GVQA_NND_FENCE();                                   \
+        GVQA_NND_MF(0); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 2)) GVQA_TND_SPLIT2(hx.x, lx.x, sa, CA0_.x, CA0_.y); if (!(GVQA_NND_DBG & 1)) LA0_ = GVQA_NND_LD4(ra_, oa); GVQA_NND_FENCE();      \
+        GVQA_NND_MF(1); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 2)) GVQA_TND_SPLIT2(hx.y, lx.y, sa, CA0_.z, CA0_.w); if (!(GVQA_NND_DBG & 1)) LA1_ = GVQA_NND_LD4(ra_, oa + 16); GVQA_NND_FENCE(); \
+        GVQA_NND_MF(2); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 2)) GVQA_TND_SPLIT2(hx.z, lx.z, sa, CA1_.x, CA1_.y); GVQA_NND_FENCE();                                   \
+        GVQA_NND_MF(3); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 2)) GVQA_TND_SPLIT2(hx.w, lx.w, sa, CA1_.z, CA1_.w); GVQA_NND_FENCE();                                   \
         GVQA_NND_MF(4); GVQA_NND_FENCE();                                                                                                     \
-        *reinterpret_cast<uint4*>(dn + wa_off) = hx; *reinterpret_cast<uint4*>(dn + wa_off + 1024) = lx;                                      \
+        if (!(GVQA_NND_DBG & 2)) { *reinterpret_cast<uint4*>(dn + wa_off) = hx; *reinterpret_cast<uint4*>(dn + wa_off + 1024) = lx; }        \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(5); GVQA_NND_FENCE();                                                                                                     \
-        *reinterpret_cast<nnd_f32x4*>(dn + wb_off) = CB0_; *reinterpret_cast<nnd_f32x4*>(dn + wb_off + 1024) = CB1_;                            \
+        if (!(GVQA_NND_DBG & 8)) { *reinterpret_cast<nnd_f32x4*>(dn + wb_off) = CB0_; *reinterpret_cast<nnd_f32x4*>(dn + wb_off + 1024) = CB1_; } \
         GVQA_NND_FENCE();                                                                                                                     \
-        GVQA_NND_MF(6); GVQA_NND_FENCE(); LB0_ = GVQA_NND_LD4(rb_, ob); LB1_ = GVQA_NND_LD4(rb_, ob + 1024); GVQA_NND_FENCE();                 \
+        GVQA_NND_MF(6); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 8)) { LB0_ = GVQA_NND_LD4(rb_, ob); LB1_ = GVQA_NND_LD4(rb_, ob + 1024); } GVQA_NND_FENCE();                 \
         GVQA_NND_MF(7); GVQA_NND_FENCE();                                                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                    \
         __builtin_amdgcn_s_barrier();                                                                                                         \

@@ -208,6 +208,12 @@ def _absmax_hint(gy: Tensor):
     return am if (gy.data_ptr() == ptr and gy._version == version) else None
 
 
+class _NoCtx:
+    """Stand-in for an autograd context when a Function's forward is used as a plain kernel call inside another node."""
+    def save_for_backward(self, *a):
+        pass
+
+
 class _SkinnyLinear(torch.autograd.Function):
     """y = x V for a tall x [R, D] and a narrow V [D, J] (J <= 32): the attention logits of the differentiable path,
     (x_i * att).sum(-1) of gat_skip.py:134-135,151 with att folded through the projection weights.  Forward, dV = x^T dy and
@@ -332,7 +338,11 @@ class _HopProducts(torch.autograd.Function):
     full-size dF -- no column slices of W or F in the autograd graph, hence no zero-padded slice gradients to fill and add."""
 
     @staticmethod
-    def forward(ctx, h, ins, W, F_, U_e, Dn):
+    def forward(ctx, h, ins, W, F_, U_e, Dn, skip_grad=None):
+        # skip_grad: a list shared with the hop's message-passing node (gat_seq._forward_autograd): that node's backward leaves the gradient
+        # of its `skip` operand -- the same h -- there instead of returning it, and the backward below adds it inside the kernel that
+        # writes dh (no [N, D] add by autograd between the two nodes)
+        ctx.skip_grad = skip_grad
         heads2 = F_.shape[1]
         H = heads2 // 2
         with torch.no_grad():
@@ -341,7 +351,9 @@ class _HopProducts(torch.autograd.Function):
             xp_rows = _lib_abt(ins, W[:, Dn:])
             U_n = F_[Dn:].clone()
             U_n[:, :H] += U_e
-            a_rows = _lib_abt(ins, U_n.t().contiguous())
+            # [B, Di] x [Di, 2H]: the tall-skinny kernel (a K = Di loop on 16 workgroups of the tiled f32 kernel is latency, 38 us)
+            a_rows = (_SkinnyLinear.forward(_NoCtx(), ins, U_n) if _SkinnyLinear.supported(ins, U_n) and ins.is_contiguous()
+                      else _lib_abt(ins, U_n.t().contiguous()))
         ctx.save_for_backward(h, ins, W, F_, U_n)
         ctx.Dn = Dn
         return xp, a_part, xp_rows, a_rows
@@ -369,17 +381,27 @@ class _HopProducts(torch.autograd.Function):
                                                                ws.numel(), _stream(dev)))
             else:
                 _lib_abt(h.t().contiguous(), ga.t().contiguous(), out=gF[:Dn])
-            ins_t = ins.t().contiguous()                      # [Di, B]: the contraction over graphs as the unit-stride dimension
-            _lib_abt(ins_t, g_arows.t().contiguous(), out=gF[Dn:])           # d a_rows / d U_n = ins^T g_arows: rows [Dn:] of dF ...
+            g_arows = g_arows.contiguous()
+            if _SkinnyLinear.supported(ins, U_n) and ins.is_contiguous() and H2 in (2, 4, 8, 16):
+                with torch.cuda.device(dev):                  # d a_rows / d U_n = ins^T g_arows: rows [Dn:] of dF ... (tall-skinny dV kernel)
+                    ws = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(ins.shape[0], ins.shape[1], H2), dev)
+                    _lib.check(lib.gvqa_skinny_backward_weight(ins.shape[0], ins.shape[1], H2, ins.data_ptr(), ins.stride(0), g_arows.data_ptr(),
+                                                               gF[Dn:].data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)))
+            else:
+                ins_t = ins.t().contiguous()                  # [Di, B]: the contraction over graphs as the unit-stride dimension
+                _lib_abt(ins_t, g_arows.t().contiguous(), out=gF[Dn:])
             if want_ue:
                 gUe = gF[Dn:, :H].clone()                     # ... whose source half is dU_e as well
+        extra = ctx.skip_grad.pop() if ctx.skip_grad else None          # d loss / d (the hop's skip operand), left by the message-passing node
         if want_h:
-            if ok:
+            if ok and (extra is None or (extra.is_contiguous() and extra.shape == (R, D) and extra.dtype == torch.float32)):
                 gh = torch.empty((R, D), dtype=torch.float32, device=dev)
                 with torch.cuda.device(dev):
-                    _lib.check(lib.gvqa_skinny_backward_input(R, D, H2, ga.data_ptr(), V.data_ptr(), None, 0, gh.data_ptr(), D, _stream(dev)))
+                    _lib.check(lib.gvqa_skinny_backward_input(R, D, H2, ga.data_ptr(), V.data_ptr(), _ptr(extra), D, gh.data_ptr(), D, _stream(dev)))
             else:
                 gh = _lib_abt(ga, V)
+                if extra is not None:
+                    gh = gh + extra
         if want_w:
             gW = torch.empty_like(W)
             _lib_abt(g_rows.t().contiguous(), ins.t().contiguous(), out=gW[:, Dn:])      # instruction half: dW_i = d xp_rows^T ins
@@ -394,7 +416,7 @@ class _HopProducts(torch.autograd.Function):
                 gW[:, :Dn] = _ProjectionLinear._weight_grad(gxp, h)
         if want_ins:
             gins = _lib_abt(g_rows, W[:, Dn:].t().contiguous()) + _lib_abt(g_arows, U_n)
-        return gh, gins, gW, (gF if want_f else None), gUe, None
+        return gh, gins, gW, (gF if want_f else None), gUe, None, None
 
 
 class _GatMessagePassing(torch.autograd.Function):
@@ -407,8 +429,9 @@ class _GatMessagePassing(torch.autograd.Function):
     `bias` [C] and `skip` [N, C] (optional) are added in the same pass (gat_skip.py:167-168, :270)."""
 
     @staticmethod
-    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope, graph_rows=None, bias=None, skip=None):
+    def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope, graph_rows=None, bias=None, skip=None, skip_grad=None):
         lib = _lib.load()
+        ctx.skip_grad = skip_grad          # (a list: the gradient of `skip` is left there for _HopProducts.backward instead of being returned)
         xp, a_node, a_edge = _f32c(xp, "xp"), _f32c(a_node, "a_node"), _f32c(a_edge, "a_edge")
         if mask is not None:
             mask = _f32c(mask, "alpha_mask")
@@ -428,21 +451,39 @@ class _GatMessagePassing(torch.autograd.Function):
         m.C, m.H, m.negative_slope, m.bn_eps = channels, heads, slope, 1e-5
         m.xp, m.a_node, m.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
         m.out, m.alpha_out, m.alpha_mask = out.data_ptr(), alpha.data_ptr(), _ptr(mask)
+        s = None
+        if bias is not None:
+            bias = _f32c(bias, "bias")
+        if skip is not None:
+            skip = _f32c(skip, "skip")
+            if skip.shape != (N, channels):
+                raise ValueError("gat_message_passing: skip must be [N, channels]")
         with torch.cuda.device(dev):
             ws = _workspace(4 * E * heads, dev)
-            _lib.check(lib.gvqa_gat_message_passing(C.byref(graph.c), C.byref(m), ws.data_ptr(), ws.numel(), _stream(dev)))
-            s = None
-            if bias is not None:
-                bias = _f32c(bias, "bias")
-            if skip is not None:
-                skip = _f32c(skip, "skip")
-                if skip.shape != (N, channels):
-                    raise ValueError("gat_message_passing: skip must be [N, channels]")
+            fused = False
             if graph_rows is not None or bias is not None or skip is not None:
-                if graph_rows is not None and mask is not None:   # s[i,h] = sum over the in-edges of alpha * mask (1 when nothing is dropped)
-                    s = _edge_rows_sum_raw(alpha * mask, graph)
-                _lib.check(lib.gvqa_graph_head_rows_add(C.byref(graph.c), channels, heads, _ptr(graph_rows), _ptr(s), _ptr(bias), _ptr(skip),
-                                                        channels, out.data_ptr(), channels, _stream(dev)))
+                # one pass: the per-graph rows (weighted by the nodes' coefficient sums, which the kernel has in hand), bias and skip in the
+                # message-passing kernel's own epilogue -- the LDS-tiled kernel's form; other batches take the two-pass form below
+                m.bias, m.skip = _ptr(bias), _ptr(skip)
+                if graph_rows is not None:
+                    m.head_rows = graph_rows.data_ptr()
+                    if mask is not None:
+                        s = torch.empty((N, heads), dtype=torch.float32, device=dev)
+                        m.head_weight_out = s.data_ptr()
+                rc = lib.gvqa_gat_message_passing(C.byref(graph.c), C.byref(m), ws.data_ptr(), ws.numel(), _stream(dev))
+                if rc == _lib.E_UNSUPPORTED:
+                    m.bias = m.skip = m.head_rows = m.head_weight_out = None
+                    s = None
+                else:
+                    _lib.check(rc)
+                    fused = True
+            if not fused:
+                _lib.check(lib.gvqa_gat_message_passing(C.byref(graph.c), C.byref(m), ws.data_ptr(), ws.numel(), _stream(dev)))
+                if graph_rows is not None or bias is not None or skip is not None:
+                    if graph_rows is not None and mask is not None:   # s[i,h] = sum over the in-edges of alpha * mask (1 when nothing is dropped)
+                        s = _edge_rows_sum_raw(alpha * mask, graph)
+                    _lib.check(lib.gvqa_graph_head_rows_add(C.byref(graph.c), channels, heads, _ptr(graph_rows), _ptr(s), _ptr(bias), _ptr(skip),
+                                                            channels, out.data_ptr(), channels, _stream(dev)))
         ctx.save_for_backward(xp, a_node, a_edge, alpha, mask, graph_rows, s)
         ctx.graph, ctx.dims = graph, (heads, channels, slope)
         ctx.has_bias, ctx.has_skip = bias is not None, skip is not None
@@ -483,7 +524,10 @@ class _GatMessagePassing(torch.autograd.Function):
         # place, a hook may rescale it -- either bumps the version counter and the consumer then measures the maxima itself
         dxp._gvqa_absmax = (am, dxp.data_ptr(), dxp._version)
         d_bias = dcol.sum(0) if dcol is not None else None
-        return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, (dout if ctx.has_skip else None)
+        if ctx.skip_grad is not None and ctx.has_skip:
+            ctx.skip_grad.append(dout)
+            return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, None, None
+        return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, (dout if ctx.has_skip else None), None
 
 
 class _BatchNormReluTrain(torch.autograd.Function):
@@ -705,7 +749,7 @@ def graph_softmax(score: Tensor, graph: SceneGraphBatch) -> Tensor:
 
 def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: SceneGraphBatch, heads: int, channels: int,
                         negative_slope: float = 0.2, alpha_mask: Optional[Tensor] = None, graph_rows: Optional[Tensor] = None,
-                        bias: Optional[Tensor] = None, skip: Optional[Tensor] = None):
+                        bias: Optional[Tensor] = None, skip: Optional[Tensor] = None, _skip_grad: Optional[list] = None):
     """Differentiable GAT message passing on the HIP kernels: (out [N, C], alpha [E, H]).
     xp [N, H*C] projected features, a_node [N, 2H] = (a_l | a_r), a_edge [E, H]; alpha_mask [E, H] multiplies alpha
     after the softmax (attention dropout: mask / (1 - p)); graph_rows [B, H*C]: rows added to xp per graph (kept out of xp);
@@ -721,7 +765,7 @@ def gat_message_passing(xp: Tensor, a_node: Tensor, a_edge: Tensor, graph: Scene
         if skip is not None:
             out = out + skip
         return out, alpha
-    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, graph_rows, bias, skip)
+    return _GatMessagePassing.apply(xp, a_node, a_edge, alpha_mask, graph, heads, channels, negative_slope, graph_rows, bias, skip, _skip_grad)
 
 
 class gat(torch.nn.Module):
@@ -1092,7 +1136,11 @@ class gat_seq(torch.nn.Module):
             # attention logits through the attention vectors folded into the weights ([D, H] matrices): a_l | a_r per
             # node; the edge's instruction term ins[batch[src]] . U_e (:257-260) rides on the source half a_l
             fold_n = fold_attention(W, conv.att_l, conv.att_r, H)              # [Dn + Di, 2H]: att_l | att_r through lin_l
-            xp, a_part, xp_rows, a_rows = _HopProducts.apply(h, ins, W, fold_n, folds_e[i][De:], Dn)
+            # h feeds two nodes of the hop, the products and the message passing's skip: the skip's gradient travels between their backwards in
+            # `sg` and is added inside the kernel that writes dh, not by autograd (one [N, D] pass per hop less).  Only where the one-pass
+            # message-passing op applies (otherwise the skip is a torch add that needs its own gradient)
+            sg = [] if (h.requires_grad and torch.is_grad_enabled() and Cc % 4 == 0 and H <= 8) else None
+            xp, a_part, xp_rows, a_rows = _HopProducts.apply(h, ins, W, fold_n, folds_e[i][De:], Dn, sg)
             a_node = add_graph_rows(a_part, a_rows, graph)
             a_edge = a_edge_all[:, i * H:(i + 1) * H]
             mask = None
@@ -1106,7 +1154,7 @@ class gat_seq(torch.nn.Module):
             if not graph.intra_graph:
                 xp, xp_rows = add_graph_rows(xp, xp_rows, graph), None
             h, alpha = gat_message_passing(xp, a_node, a_edge, graph, H, Cc, self.negative_slope, mask, graph_rows=xp_rows,
-                                           bias=conv.bias, skip=h)
+                                           bias=conv.bias, skip=h.detach() if sg is not None else h, _skip_grad=sg)
             if i != K - 1:
                 if feature_masks is not None:                  # (tests: given masks)
                     h = (_bn_relu_train(self.bns[i], h) if self.training else torch.relu(self.bns[i](h))) * feature_masks[i]

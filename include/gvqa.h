@@ -492,6 +492,14 @@ typedef struct gvqa_gat_mp_desc {
     const float* alpha_mask;    /* NULL or [E, H] in COO edge order: multiplies alpha after the softmax
                                    (attention dropout, gat_skip.py:205: mask / (1 - p))              */
     int32_t force;              /* 0 = auto, 1 = LDS-tiled kernel, 2 = general CSR kernel            */
+    const float* head_rows;     /* NULL or [B, head_rows_ld]: rows added to xp per GRAPH and head (the instruction half of lin_l on
+                                   [h | ins[batch]], gat_skip.py:133,263-264) without forming the [N, H*C] sum:
+                                   out[i] += (1/H) sum_h s[i,h] head_rows[graph(i), h*C .. h*C+C), s[i,h] = sum over the in-edges
+                                   of alpha * alpha_mask (1 without a mask, 0 for a node without in-edges).  LDS-tiled kernel only
+                                   (GVQA_E_UNSUPPORTED otherwise: gvqa_graph_head_rows_add is the general form); excludes
+                                   graph_term / graph_scale */
+    int64_t head_rows_ld;       /* 0 -> H*C                                                          */
+    float* head_weight_out;     /* NULL or [N, H]: s (what gvqa_graph_head_rows_backward needs)      */
 } gvqa_gat_mp_desc;
 /* ws: >= 4*E*H bytes, used by the general kernel only. */
 GVQA_API int gvqa_gat_message_passing(const gvqa_graph* g, const gvqa_gat_mp_desc* d, void* ws, size_t ws_bytes, void* stream);
