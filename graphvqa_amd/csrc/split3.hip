@@ -1297,6 +1297,9 @@ struct PackRows {
     // GATHER, optional: gop = 1 -- the packed value is X[r, k] * ga[gi32[r], k] (rows scaled by a per-graph row: the pooling head's
     // ques_nn(u)[batch] * x', pipeline_model_gat.py:165, formed on the way into gate_nn's operand); gia NULL, gi32 the int32 index
     const int32_t* gi32; int gop;
+    // optional: the rows' largest magnitudes leave as GVQA_ABSMAX_SLOTS slice maxima (slot = row tile mod slots; the caller zeroes them): a later
+    // consumer that wants ONE scale for the whole operand -- the weight-gradient product of the backward -- then needs no pass of its own
+    float* absmax;
 };                                // HEADS2 (hop2.hip): packed row 256 cb + 64 w + 32 j + t = W row h C + cb cw + j hw + cc, (h, cc) = divmod(32 w + t, hw), hw = cw / 2
 // head and channel of row `within` (0..255) of column block cb
 template <int MAP>
@@ -1477,6 +1480,12 @@ __global__ __launch_bounds__(64 * NWV) void k_split2h_pack(PackRows pr, int K, i
 #pragma unroll
         for (int w = 0; w < NWV; ++w) rowmax = fmaxf(rowmax, mx_s[w]);
     }
+    if (pr.absmax && wave == 0) {                                     // one atomic per workgroup, GVQA_ABSMAX_SLOTS addresses
+        float t = rowmax;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(pr.absmax) + (rt & (GVQA_ABSMAX_SLOTS - 1)), __float_as_uint(t));
+    }
     const int ex = split2h_exponent(rowmax);
     const float scale = pow2i(ex);
     if (tid < 32) inv_scale[rt * 32 + tid] = pow2i(-ex);
@@ -1631,7 +1640,7 @@ int launch_split2h_pack_rowmul(int64_t rows, int64_t K, const float* X, int64_t 
     return launch_split2h_pack_tiles<PACK_GATHER>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
 }
 
-int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream) {
+int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream, float* absmax) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack: 2 or 3 pieces");
     GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split_pack: bad size");
     if (rows == 0 || K == 0) return GVQA_OK;
@@ -1643,8 +1652,10 @@ int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t l
     if (np == 2) {
         GVQA_REQUIRE(RT < (1ll << 31), GVQA_E_INVALID, "split_pack: too many rows");
         PackRows pr{X, ld, rows, nullptr, 0, 0, 0};
+        pr.absmax = absmax;
         return launch_split2h_pack_tiles<PACK_PLAIN>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
     }
+    GVQA_REQUIRE(!absmax, GVQA_E_UNSUPPORTED, "split_pack: slice maxima are a two-piece pack's by-product");
     for (int64_t r0 = 0; r0 < RT; r0 += 65535) {       // grid.y holds 65535 row tiles
         const int64_t n = std::min<int64_t>(65535, RT - r0);
         hipLaunchKernelGGL(k_split3_pack, dim3((unsigned)cdiv(KB, 4), (unsigned)n), dim3(256), 0, stream, rows - r0 * 32, (int)K, KB,
@@ -2166,6 +2177,11 @@ extern "C" size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K) {
     return gvqa::split_packed_bytes(2, rows, K);
 }
 
+extern "C" int gvqa_split2h_pack_absmax(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, float* absmax, void* stream) {
+    GVQA_REQUIRE(absmax, GVQA_E_INVALID, "split2h_pack_absmax: null maxima");
+    GVQA_HIP_CHECK(hipMemsetAsync(absmax, 0, GVQA_ABSMAX_SLOTS * sizeof(float), static_cast<hipStream_t>(stream)));
+    return gvqa::launch_split_pack(2, rows, K, X, ld, packed, static_cast<hipStream_t>(stream), absmax);
+}
 extern "C" int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream) {
     return gvqa::launch_split_pack(2, rows, K, X, ld, packed, static_cast<hipStream_t>(stream));
 }

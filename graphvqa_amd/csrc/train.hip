@@ -949,6 +949,14 @@ size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64_t K) {
 int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
                                  const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
                                  int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream) {
+    return gvqa_linear_backward_split2h_hint(R, M, K, dy, ld_dy, W, ldw, x, ldx, dy_absmax, dy_absmax_n, nullptr, 0, dx, ld_dx, dx_accumulate, dW, ld_dw,
+                                             ws, ws_bytes, stream);
+}
+
+int gvqa_linear_backward_split2h_hint(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
+                                      const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, const float* x_absmax, int x_absmax_n,
+                                      float* dx, int64_t ld_dx, int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream) {
+    GVQA_REQUIRE(!x_absmax || (x_absmax_n >= 1 && x_absmax_n <= GVQA_ABSMAX_SLOTS), GVQA_E_INVALID, "linear_backward: 1 <= absmax count <= %d", GVQA_ABSMAX_SLOTS);
     GVQA_REQUIRE(R >= 0 && M > 0 && K > 0 && M < (1ll << 30) && K < (1ll << 30) && R < (1ll << 31), GVQA_E_INVALID, "linear_backward: bad size");
     GVQA_REQUIRE(M % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= M, GVQA_E_INVALID, "linear_backward: M, K, ld_dy multiples of 4");
     GVQA_REQUIRE((!dx || (W && ldw % 4 == 0 && ldw >= K && ld_dx % 4 == 0 && ld_dx >= K)) && (!dW || (x && ldx % 4 == 0 && ldx >= K && ld_dw % 4 == 0 && ld_dw >= K)),
@@ -979,7 +987,10 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
         hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)M, dy, ld_dy, mx);
         dy_absmax = reinterpret_cast<const float*>(mx); dy_absmax_n = 1;
     }
-    if (dW) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)K, x, ldx, mx + 1);
+    if (dW && !x_absmax) {
+        hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(R, 1024)), dim3(256), 0, st, R, (int)K, x, ldx, mx + 1);
+        x_absmax = reinterpret_cast<const float*>(mx + 1); x_absmax_n = 1;
+    }
     if (dx) hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(M, 1024)), dim3(256), 0, st, M, (int)K, W, ldw, mx + 2);
     const unsigned slabs = (unsigned)((int64_t)p.tn.S * p.tn.KC / TN_SLAB_ROWS);
     const dim3 gdy(slabs, (unsigned)cdiv(M, TN_SLAB_COLS));
@@ -1010,11 +1021,11 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
         float* dst = p.tn.S == 1 ? dW : part;
         int rc;
         if (direct) {
-            rc = launch_linear_tn_direct(R, M, K, dy, ld_dy, x, ldx, dy_absmax, dy_absmax_n, reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.S, dst,
+            rc = launch_linear_tn_direct(R, M, K, dy, ld_dy, x, ldx, dy_absmax, dy_absmax_n, x_absmax, x_absmax_n, p.tn.KC, p.tn.S, dst,
                                          p.tn.S == 1 ? ld_dw : K, M * K, st);
         } else {
             hipLaunchKernelGGL(k_split2h_pack_t<false>, dim3(slabs, (unsigned)cdiv(K, TN_SLAB_COLS)), dim3(256), 0, st, R, (int)K, x, ldx,
-                               reinterpret_cast<const float*>(mx + 1), 1, p.tn.KC, p.tn.TB, PB, IB, PackNt{});
+                               x_absmax, x_absmax_n, p.tn.KC, p.tn.TB, PB, IB, PackNt{});
             GVQA_LAUNCH_CHECK();
             LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
             ep.zs_a = (int64_t)p.tn.TA * p.tn.KBc * 1024; ep.zs_b = (int64_t)p.tn.TB * p.tn.KBc * 1024; ep.zs_c = M * K;

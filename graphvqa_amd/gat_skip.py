@@ -31,6 +31,11 @@ from . import _lib
 from .graph import SceneGraphBatch, _stream, _ptr
 
 
+# A/B switch of the training path's round-5 fusions (scripts/ab_train_parts.sh; measurement only, 0 = everything on): bit 1 no |h| maxima from
+# the operand pack, 2 the skip's gradient through autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel
+_TRAIN_AB = int(os.environ.get("GVQA_TRAIN_AB", "0") or 0)
+
+
 def _glorot(t: Tensor):
     """PyG inits.glorot (call sites gat_skip.py:101-107)."""
     a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
@@ -106,7 +111,9 @@ class _ProjectionLinear(torch.autograd.Function):
         return _ProjectionLinear._product(x, w, bias)
 
     @staticmethod
-    def _product(x, w, bias=None):
+    def _product(x, w, bias=None, absmax_out=None):
+        """absmax_out ([_lib.ABSMAX_SLOTS] fp32, optional): filled with slice maxima of |x| when the two-piece path packs x (a by-product of
+        its row scales) and then tagged `_gvqa_filled`; the backward's weight-gradient product takes it instead of a pass over x."""
         lib = _lib.load()
         M, K = x.shape
         N = w.shape[0]
@@ -127,7 +134,11 @@ class _ProjectionLinear(torch.autograd.Function):
                                     if mode == _lib.PROJECTION_SPLIT2H else
                                     (lib.gvqa_split3_packed_bytes, lib.gvqa_split3_pack, lib.gvqa_linear_split3))
             apk, wpk = _workspace(nbytes(M, K), dev), _workspace(nbytes(N, K), dev)
-            _lib.check(pack(M, K, x.data_ptr(), K, apk.data_ptr(), st))
+            if absmax_out is not None and mode == _lib.PROJECTION_SPLIT2H:
+                _lib.check(lib.gvqa_split2h_pack_absmax(M, K, x.data_ptr(), K, apk.data_ptr(), absmax_out.data_ptr(), st))
+                absmax_out._gvqa_filled = True
+            else:
+                _lib.check(pack(M, K, x.data_ptr(), K, apk.data_ptr(), st))
             _lib.check(pack(N, K, w.data_ptr(), w.stride(0), wpk.data_ptr(), st))
             _lib.check(linear(M, N, K, apk.data_ptr(), wpk.data_ptr(), _ptr(bias), None, 0, None, 0, 0, out.data_ptr(), N, st))
         return out
@@ -147,7 +158,7 @@ class _ProjectionLinear(torch.autograd.Function):
         return gx, gw, gb
 
     @staticmethod
-    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None, gw_out=None):
+    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None, gw_out=None, x_absmax=None):
         """dx = dy W and dW = dy^T x in one library call under the two-piece arithmetic (gvqa_linear_backward_split2h: dy is read and
         packed once for both products); None when the shapes / settings are not the ones it takes."""
         lib = _lib.load()
@@ -166,10 +177,11 @@ class _ProjectionLinear(torch.autograd.Function):
         gw = (gw_out if gw_out is not None else torch.empty((M, K), dtype=torch.float32, device=dev)) if want_w else None      # (gw_out: a column block of a wider gradient, row stride = its width)
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dev)
-            _lib.check(lib.gvqa_linear_backward_split2h(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
-                                                        _ptr(am), 0 if am is None else am.numel(), _ptr(gx), K,
-                                                        int(gx_init is not None and want_x), _ptr(gw), K if gw is None else gw.stride(0),
-                                                        ws.data_ptr(), ws.numel(), _stream(dev)))
+            _lib.check(lib.gvqa_linear_backward_split2h_hint(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
+                                                             _ptr(am), 0 if am is None else am.numel(), _ptr(x_absmax),
+                                                             0 if x_absmax is None else x_absmax.numel(), _ptr(gx), K,
+                                                             int(gx_init is not None and want_x), _ptr(gw), K if gw is None else gw.stride(0),
+                                                             ws.data_ptr(), ws.numel(), _stream(dev)))
         return gx, gw
 
     @staticmethod
@@ -346,13 +358,16 @@ class _HopProducts(torch.autograd.Function):
         heads2 = F_.shape[1]
         H = heads2 // 2
         with torch.no_grad():
-            xp = _ProjectionLinear._product(h, W[:, :Dn])
+            # (the largest magnitudes of h leave the operand pack as a by-product: the backward's dW = dxp^T h needs h's ONE scale)
+            am_h = torch.zeros(_lib.ABSMAX_SLOTS, dtype=torch.float32, device=h.device) if (h.is_cuda and W.requires_grad and not (_TRAIN_AB & 1)) else None
+            xp = _ProjectionLinear._product(h, W[:, :Dn], absmax_out=am_h)
+            ctx.h_absmax = (am_h, h._version) if (am_h is not None and getattr(am_h, "_gvqa_filled", False)) else None
             a_part = skinny_linear(h, F_[:Dn])
             xp_rows = _lib_abt(ins, W[:, Dn:])
             U_n = F_[Dn:].clone()
             U_n[:, :H] += U_e
             # [B, Di] x [Di, 2H]: the tall-skinny kernel (a K = Di loop on 16 workgroups of the tiled f32 kernel is latency, 38 us)
-            a_rows = (_SkinnyLinear.forward(_NoCtx(), ins, U_n) if _SkinnyLinear.supported(ins, U_n) and ins.is_contiguous()
+            a_rows = (_SkinnyLinear.forward(_NoCtx(), ins, U_n) if _SkinnyLinear.supported(ins, U_n) and ins.is_contiguous() and not (_TRAIN_AB & 8)
                       else _lib_abt(ins, U_n.t().contiguous()))
         ctx.save_for_backward(h, ins, W, F_, U_n)
         ctx.Dn = Dn
@@ -382,7 +397,7 @@ class _HopProducts(torch.autograd.Function):
             else:
                 _lib_abt(h.t().contiguous(), ga.t().contiguous(), out=gF[:Dn])
             g_arows = g_arows.contiguous()
-            if _SkinnyLinear.supported(ins, U_n) and ins.is_contiguous() and H2 in (2, 4, 8, 16):
+            if _SkinnyLinear.supported(ins, U_n) and ins.is_contiguous() and H2 in (2, 4, 8, 16) and not (_TRAIN_AB & 8):
                 with torch.cuda.device(dev):                  # d a_rows / d U_n = ins^T g_arows: rows [Dn:] of dF ... (tall-skinny dV kernel)
                     ws = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(ins.shape[0], ins.shape[1], H2), dev)
                     _lib.check(lib.gvqa_skinny_backward_weight(ins.shape[0], ins.shape[1], H2, ins.data_ptr(), ins.stride(0), g_arows.data_ptr(),
@@ -406,7 +421,9 @@ class _HopProducts(torch.autograd.Function):
             gW = torch.empty_like(W)
             _lib_abt(g_rows.t().contiguous(), ins.t().contiguous(), out=gW[:, Dn:])      # instruction half: dW_i = d xp_rows^T ins
         Wh = W[:, :Dn]
-        fused = _ProjectionLinear._backward_fused(gxp, h, Wh, want_h, want_w, gx_init=gh, gw_out=None if gW is None else gW[:, :Dn])
+        # (the hint holds while h is what the forward packed: an in-place change since then bumps its version counter)
+        hint = ctx.h_absmax[0] if (ctx.h_absmax is not None and ctx.h_absmax[1] == h._version) else None
+        fused = _ProjectionLinear._backward_fused(gxp, h, Wh, want_h, want_w, gx_init=gh, gw_out=None if gW is None else gW[:, :Dn], x_absmax=hint)
         if fused is not None:
             gh = fused[0] if want_h else None
         else:
@@ -461,7 +478,7 @@ class _GatMessagePassing(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = _workspace(4 * E * heads, dev)
             fused = False
-            if graph_rows is not None or bias is not None or skip is not None:
+            if (graph_rows is not None or bias is not None or skip is not None) and not (_TRAIN_AB & 4):
                 # one pass: the per-graph rows (weighted by the nodes' coefficient sums, which the kernel has in hand), bias and skip in the
                 # message-passing kernel's own epilogue -- the LDS-tiled kernel's form; other batches take the two-pass form below
                 m.bias, m.skip = _ptr(bias), _ptr(skip)
@@ -1139,7 +1156,7 @@ class gat_seq(torch.nn.Module):
             # h feeds two nodes of the hop, the products and the message passing's skip: the skip's gradient travels between their backwards in
             # `sg` and is added inside the kernel that writes dh, not by autograd (one [N, D] pass per hop less).  Only where the one-pass
             # message-passing op applies (otherwise the skip is a torch add that needs its own gradient)
-            sg = [] if (h.requires_grad and torch.is_grad_enabled() and Cc % 4 == 0 and H <= 8) else None
+            sg = [] if (h.requires_grad and torch.is_grad_enabled() and Cc % 4 == 0 and H <= 8 and not (_TRAIN_AB & 2)) else None
             xp, a_part, xp_rows, a_rows = _HopProducts.apply(h, ins, W, fold_n, folds_e[i][De:], Dn, sg)
             a_node = add_graph_rows(a_part, a_rows, graph)
             a_edge = a_edge_all[:, i * H:(i + 1) * H]

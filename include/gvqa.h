@@ -313,6 +313,9 @@ GVQA_API int gvqa_linear_split3(int64_t M, int64_t N, int64_t K, const void* Apk
  * P[ceil(rows/32)][ceil(K/16)][2][64 lanes][8 fp16] | inv_scale[32 ceil(rows/32)]. */
 GVQA_API size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K);
 GVQA_API int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, void* stream);
+/* gvqa_split2h_pack that also leaves the operand's largest magnitudes as GVQA_ABSMAX_SLOTS slice maxima in `absmax` (zeroed here): the hint the
+ * backward's one-scale products take (gvqa_linear_backward_split2h_hint, gvqa_linear_tn_split2h). */
+GVQA_API int gvqa_split2h_pack_absmax(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, float* absmax, void* stream);
 GVQA_API int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
                         const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                         int64_t ldc, void* stream);
@@ -371,6 +374,12 @@ GVQA_API size_t gvqa_linear_backward_workspace_bytes(int64_t R, int64_t M, int64
 GVQA_API int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
                                  const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
                                  int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream);
+/* The same with the largest magnitudes of x known too (x_absmax: 1 .. GVQA_ABSMAX_SLOTS slice maxima, e.g. the by-product of the forward's
+ * operand pack, gvqa_split2h_pack_absmax; NULL = measured here): no pass over x before dW. */
+GVQA_API int gvqa_linear_backward_split2h_hint(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
+                                               const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, const float* x_absmax,
+                                               int x_absmax_n, float* dx, int64_t ld_dx, int dx_accumulate, float* dW, int64_t ld_dw, void* ws,
+                                               size_t ws_bytes, void* stream);
 
 /* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls

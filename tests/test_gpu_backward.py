@@ -842,6 +842,38 @@ def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which, direc
         assert float((acc - (add + dx)).abs().max()) <= 1e-6 * max(float(dx.abs().max()), 1.0)
 
 
+def test_operand_pack_leaves_slice_maxima_and_the_backward_takes_them(dev):
+    """gvqa_split2h_pack_absmax: the packed operand is the one gvqa_split2h_pack writes and the slice maxima's maximum is max|x| exactly;
+    gvqa_linear_backward_split2h_hint fed with them returns the same dW, bit for bit, as the call that measures x itself."""
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    R, M, K = 5000, 256, 132
+    x = torch.randn((R, K), generator=g).to(dev)
+    x[::13] *= 40.0
+    dy = torch.randn((R, M), generator=g).to(dev)
+    W = torch.randn((M, K), generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.gvqa_split2h_packed_bytes(R, K)
+    p0, p1 = torch.zeros(nb, dtype=torch.uint8, device=dev), torch.zeros(nb, dtype=torch.uint8, device=dev)
+    am = torch.full((_lib.ABSMAX_SLOTS,), 7.0, device=dev)
+    _lib.check(lib.gvqa_split2h_pack(R, K, x.data_ptr(), K, p0.data_ptr(), st))
+    _lib.check(lib.gvqa_split2h_pack_absmax(R, K, x.data_ptr(), K, p1.data_ptr(), am.data_ptr(), st))
+    assert torch.equal(p0, p1)
+    assert float(am.max()) == float(x.abs().max())
+    ws = torch.empty(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dtype=torch.uint8, device=dev)
+    outs = []
+    for hint in (None, am):
+        dW, dx = torch.empty((M, K), device=dev), torch.empty((R, K), device=dev)
+        _lib.check(lib.gvqa_linear_backward_split2h_hint(R, M, K, dy.data_ptr(), M, W.data_ptr(), K, x.data_ptr(), K, None, 0,
+                                                         None if hint is None else hint.data_ptr(), 0 if hint is None else hint.numel(),
+                                                         dx.data_ptr(), K, 0, dW.data_ptr(), K, ws.data_ptr(), ws.numel(), st))
+        outs.append((dW, dx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = dy.double().t() @ x.double()
+    assert float((outs[1][0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_gat_seq_gradients_on_the_library_products(dev, train):
     """The gradient checks above run below the size at which the projection leaves torch (GVQA_OPT_SPLIT3_MIN_MFLOP); here the
