@@ -68,6 +68,12 @@ class GatMpDesc(C.Structure):
 ABSMAX_SLOTS = 256        # GVQA_ABSMAX_SLOTS
 
 
+class LinearBackwardExtras(C.Structure):
+    """Mirror of `struct gvqa_linear_backward_extras`."""
+    _fields_ = [("x_absmax", C.c_void_p), ("x_absmax_n", C.c_int32), ("J", C.c_int32), ("lowrank_g", C.c_void_p), ("lowrank_v", C.c_void_p),
+                ("addend", C.c_void_p), ("ld_addend", C.c_int64)]
+
+
 class GatMpBwdDesc(C.Structure):
     """Mirror of `struct gvqa_gat_mp_bwd_desc`."""
     _fields_ = [("C", C.c_int32), ("H", C.c_int32), ("negative_slope", C.c_float), ("xp", C.c_void_p), ("xp_ld", C.c_int64),
@@ -250,6 +256,9 @@ PROTOTYPES = {
     "gvqa_linear_backward_split2h_hint": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                                     C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                                     C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_linear_backward_split2h_ex": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                  C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                                  C.POINTER(LinearBackwardExtras), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gvqa_gather_add_relu": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "gvqa_embed_sum": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

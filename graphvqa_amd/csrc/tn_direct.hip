@@ -236,6 +236,8 @@ struct NndArgs {
     const float* b_inv;
     float* C; int64_t ldc;
     int accumulate, tiles_n, row_tiles;
+    const float* lr_g; const float* lr_v; int J;      // optional rank-J term of the epilogue: C[r, n] += sum_j lr_g[r, j] lr_v[n, j]  (fp32 FMAs; J % 4 == 0, <= 16)
+    const float* addend; int64_t ld_add;               // optional [R, N] added to the result
 };
 
 __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
@@ -354,42 +356,91 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
 #undef GVQA_NND_FENCE
 #undef GVQA_NND_LD4
 
+    // Epilogue through LDS, 32 rows of the tile at a time (the waves that hold them -- one row half, accumulator row i -- write their scaled
+    // accumulators as a [32][256] fp32 image; then thread (row, 4 consecutive columns) adds the optional terms and moves 16 bytes): the result,
+    // the addend and an accumulated-into dx all travel as 1 KiB row segments per wave instead of 4 bytes per lane, and a row of lr_g is
+    // read once per four output columns.
+    constexpr int EP_LD = 260;
+    float* stage = reinterpret_cast<float*>(smem);
     const float ainv = pow2i(-ea);
     const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+    float binv[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int gc = n0 + wc * 64 + j * 32 + ccol;
-        if (gc >= a.N) continue;
-        const float inv = ainv * a.b_inv[gc];
+    for (int j = 0; j < 2; ++j) { const int gc = n0 + wc * 64 + j * 32 + ccol; binv[j] = gc < a.N ? ainv * a.b_inv[gc] : 0.f; }
+    const int ecol = (tid & 63) * 4, erow0 = tid >> 6;             // this thread's 4 columns of the tile, rows erow0 + 8 k
+    const int gcol = n0 + ecol;
+    const bool col_on = gcol < a.N;                                // (N % 4 == 0: a column quad is inside or outside)
+    float4 vrow[4][4];                                             // lr_v rows of the 4 columns (J <= 16)
+    if (a.lr_g && col_on) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr0 = m0 + wr * 128 + i * 32 + crow0;
+        for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t gr = gr0 + (r & 3) + 8 * (r >> 2);
-                if (gr < a.R) {
-                    float v = acc[i][j][r] * inv;
-                    if (a.accumulate) v += a.C[gr * a.ldc + gc];
-                    a.C[gr * a.ldc + gc] = v;
+            for (int u = 0; u < 4; ++u)
+                vrow[q4][u] = 4 * u < a.J ? *reinterpret_cast<const float4*>(a.lr_v + (int64_t)(gcol + q4) * a.J + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();                                               // every wave is done with the operand images
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const int cwr = ch >> 2, ci = ch & 3;
+        if (wr == cwr) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(crow0 + (r & 3) + 8 * (r >> 2)) * EP_LD + wc * 64 + jj * 32 + ccol] = acc[ci][jj][r] * binv[jj];
+        }
+        __syncthreads();
+        if (col_on) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lr = erow0 + 8 * k;
+                const int64_t gr = m0 + cwr * 128 + ci * 32 + lr;
+                if (gr >= a.R) continue;
+                float4 v = *reinterpret_cast<const float4*>(&stage[lr * EP_LD + ecol]);
+                if (a.lr_g) {
+                    const float* gp = a.lr_g + gr * a.J;
+                    for (int u = 0; 4 * u < a.J; ++u) {
+                        const float4 gq = *reinterpret_cast<const float4*>(gp + 4 * u);
+                        v.x += gq.x * vrow[0][u].x + gq.y * vrow[0][u].y + gq.z * vrow[0][u].z + gq.w * vrow[0][u].w;
+                        v.y += gq.x * vrow[1][u].x + gq.y * vrow[1][u].y + gq.z * vrow[1][u].z + gq.w * vrow[1][u].w;
+                        v.z += gq.x * vrow[2][u].x + gq.y * vrow[2][u].y + gq.z * vrow[2][u].z + gq.w * vrow[2][u].w;
+                        v.w += gq.x * vrow[3][u].x + gq.y * vrow[3][u].y + gq.z * vrow[3][u].z + gq.w * vrow[3][u].w;
+                    }
                 }
+                if (a.addend) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.addend + gr * a.ld_add + gcol);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                float* cp = a.C + gr * a.ldc + gcol;
+                if (a.accumulate) {
+                    const float4 t = *reinterpret_cast<const float4*>(cp);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                *reinterpret_cast<float4*>(cp) = v;
             }
         }
+        __syncthreads();
     }
 }
 
 bool linear_nn_direct_applies(int64_t R, int64_t N, int64_t K, int64_t lda) {
-    return R > 0 && N > 0 && K > 0 && K % TND_STEP == 0 && lda % 4 == 0 && (R + TND_TILE) * lda < (1ll << 29);
+    return R > 0 && N > 0 && N % 4 == 0 && K > 0 && K % TND_STEP == 0 && lda % 4 == 0 && (R + TND_TILE) * lda < (1ll << 29);
 }
 
 // C [R, N] (+)= A [R, K] (fp32 rows, lda, one scale from amax) x packed B [N rows, K] (TB tiles of KBb k blocks, b_inv [N])
 int launch_linear_nn_direct(int64_t R, int64_t N, int64_t K, const float* A, int64_t lda, const float* amax, int namax, const void* Bpk, int KBb, int TB,
-                            const float* b_inv, float* C, int64_t ldc, int accumulate, hipStream_t stream) {
+                            const float* b_inv, float* C, int64_t ldc, int accumulate, hipStream_t stream, const float* lr_g, const float* lr_v, int J,
+                            const float* addend, int64_t ld_add) {
+    GVQA_REQUIRE(!lr_g || (lr_v && J > 0 && J <= 16 && J % 4 == 0 && ((reinterpret_cast<uintptr_t>(lr_g) | reinterpret_cast<uintptr_t>(lr_v)) & 15) == 0),
+                 GVQA_E_INVALID, "linear_nn_direct: rank-J term needs J in {4, 8, 12, 16} and 16-byte aligned operands");
     GVQA_REQUIRE(linear_nn_direct_applies(R, N, K, lda) && A && amax && Bpk && b_inv && C && namax >= 1 && namax <= 512 && KBb * TND_STEP >= K &&
-                     (int64_t)TB * 32 >= N && (reinterpret_cast<uintptr_t>(A) & 15) == 0,
-                 GVQA_E_INVALID, "linear_nn_direct: bad argument");
+                     (int64_t)TB * 32 >= N && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 &&
+                     (!addend || ((reinterpret_cast<uintptr_t>(addend) & 15) == 0 && ld_add % 4 == 0)),
+                 GVQA_E_INVALID, "linear_nn_direct: bad argument (16-byte aligned rows)");
     NndArgs a;
     a.R = R; a.N = (int)N; a.K = (int)K; a.A = A; a.lda = lda; a.amax = amax; a.namax = namax; a.Bpk = static_cast<const uint16_t*>(Bpk); a.KBb = KBb; a.TB = TB;
     a.b_inv = b_inv; a.C = C; a.ldc = ldc; a.accumulate = accumulate; a.tiles_n = (int)cdiv(N, TND_TILE); a.row_tiles = (int)cdiv(R, TND_TILE);
+    a.lr_g = lr_g; a.lr_v = lr_v; a.J = lr_g ? J : 0; a.addend = addend; a.ld_add = ld_add;
     const int64_t groups = cdiv(a.row_tiles, 8) * a.tiles_n;
     hipLaunchKernelGGL(k_linear_nn_direct, dim3((unsigned)(groups * 8)), dim3(512), 0, stream, a);
     GVQA_LAUNCH_CHECK();

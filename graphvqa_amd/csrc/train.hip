@@ -956,7 +956,25 @@ int gvqa_linear_backward_split2h(int64_t R, int64_t M, int64_t K, const float* d
 int gvqa_linear_backward_split2h_hint(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
                                       const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, const float* x_absmax, int x_absmax_n,
                                       float* dx, int64_t ld_dx, int dx_accumulate, float* dW, int64_t ld_dw, void* ws, size_t ws_bytes, void* stream) {
+    gvqa_linear_backward_extras ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.x_absmax = x_absmax; ex.x_absmax_n = x_absmax_n;
+    return gvqa_linear_backward_split2h_ex(R, M, K, dy, ld_dy, W, ldw, x, ldx, dy_absmax, dy_absmax_n, dx, ld_dx, dx_accumulate, dW, ld_dw, &ex, ws, ws_bytes,
+                                           stream);
+}
+
+int gvqa_linear_backward_split2h_ex(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw, const float* x,
+                                    int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx, int dx_accumulate, float* dW,
+                                    int64_t ld_dw, const gvqa_linear_backward_extras* ex, void* ws, size_t ws_bytes, void* stream) {
+    const float* x_absmax = ex ? ex->x_absmax : nullptr;
+    int x_absmax_n = ex ? ex->x_absmax_n : 0;
+    const float* lr_g = ex ? ex->lowrank_g : nullptr;
+    const float* lr_v = ex ? ex->lowrank_v : nullptr;
+    const int lr_J = ex ? ex->J : 0;
+    const float* dx_addend = ex ? ex->addend : nullptr;
+    const int64_t ld_addend = ex ? (ex->ld_addend ? ex->ld_addend : K) : 0;
     GVQA_REQUIRE(!x_absmax || (x_absmax_n >= 1 && x_absmax_n <= GVQA_ABSMAX_SLOTS), GVQA_E_INVALID, "linear_backward: 1 <= absmax count <= %d", GVQA_ABSMAX_SLOTS);
+    GVQA_REQUIRE((!lr_g && !dx_addend) || dx, GVQA_E_INVALID, "linear_backward: the rank-J term and the addend belong to dx");
     GVQA_REQUIRE(R >= 0 && M > 0 && K > 0 && M < (1ll << 30) && K < (1ll << 30) && R < (1ll << 31), GVQA_E_INVALID, "linear_backward: bad size");
     GVQA_REQUIRE(M % 4 == 0 && K % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= M, GVQA_E_INVALID, "linear_backward: M, K, ld_dy multiples of 4");
     GVQA_REQUIRE((!dx || (W && ldw % 4 == 0 && ldw >= K && ld_dx % 4 == 0 && ld_dx >= K)) && (!dW || (x && ldx % 4 == 0 && ldx >= K && ld_dw % 4 == 0 && ld_dw >= K)),
@@ -998,7 +1016,10 @@ int gvqa_linear_backward_split2h_hint(int64_t R, int64_t M, int64_t K, const flo
     // of dy in the kernel (tn_direct.hip) -- and dy is not packed at all
     const bool direct = get_option(GVQA_OPT_TN_DIRECT) != 0 && linear_tn_direct_applies(p.tn.KC, ld_dy, dW ? ldx : 4);
     const bool direct_dx = dx && get_option(GVQA_OPT_TN_DIRECT) != 0 && M % 16 == 0 && linear_nn_direct_applies(R, K, M, ld_dy) &&
-                           (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+                           ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dx_addend)) & 15) == 0 &&
+                           ld_dx % 4 == 0 && ld_addend % 4 == 0;
+    GVQA_REQUIRE((!lr_g && !dx_addend) || (direct_dx && (!dW || direct)), GVQA_E_UNSUPPORTED,
+                 "linear_backward: the rank-J term / addend of dx ride in the direct product's epilogue (GVQA_OPT_TN_DIRECT, M %% 16 == 0, 16-byte aligned dy)");
     if (dx && direct_dx && (!dW || direct)) { /* no pack of dy */ }
     else if (dx) hipLaunchKernelGGL(k_split2h_pack_t<true>, gdy, dim3(256), 0, st, R, (int)M, dy, ld_dy, dy_absmax, dy_absmax_n, p.tn.KC, p.tn.TA,
                                (dW && !direct) ? PA : nullptr, IA, PackNt{PN, IN, p.RT, p.KBw});
@@ -1013,7 +1034,8 @@ int gvqa_linear_backward_split2h_hint(int64_t R, int64_t M, int64_t K, const flo
         LinearEpilogue ep{nullptr, nullptr, 0, nullptr, 0, 0};
         if (dx_accumulate) { ep.addend = dx; ep.ld_add = ld_dx; }      // dx += dy W (the GEMM's epilogue reads the element it writes)
         const int rc = (direct_dx && (!dW || direct))
-                           ? launch_linear_nn_direct(R, K, M, dy, ld_dy, dy_absmax, dy_absmax_n, PW, p.KBw, p.TBw, IW, dx, ld_dx, dx_accumulate, st)
+                           ? launch_linear_nn_direct(R, K, M, dy, ld_dy, dy_absmax, dy_absmax_n, PW, p.KBw, p.TBw, IW, dx, ld_dx, dx_accumulate, st, lr_g, lr_v,
+                                                     lr_J, dx_addend, ld_addend)
                            : launch_linear_split(2, R, K, p.KCw, PN, PW, ep, dx, ld_dx, st, 1, IN, IW);
         if (rc != GVQA_OK) return rc;
     }

@@ -32,7 +32,8 @@ from .graph import SceneGraphBatch, _stream, _ptr
 
 
 # A/B switch of the training path's round-5 fusions (scripts/ab_train_parts.sh; measurement only, 0 = everything on): bit 1 no |h| maxima from
-# the operand pack, 2 the skip's gradient through autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel
+# the operand pack, 2 the skip's gradient through autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel;
+# bit 16 switches ON the (slower, kept for the record) form that adds the logit products' input gradient in the dx product's epilogue
 _TRAIN_AB = int(os.environ.get("GVQA_TRAIN_AB", "0") or 0)
 
 
@@ -158,7 +159,7 @@ class _ProjectionLinear(torch.autograd.Function):
         return gx, gw, gb
 
     @staticmethod
-    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None, gw_out=None, x_absmax=None):
+    def _backward_fused(gy, x, w, want_x, want_w, gx_init=None, gw_out=None, x_absmax=None, lowrank=None, addend=None):
         """dx = dy W and dW = dy^T x in one library call under the two-piece arithmetic (gvqa_linear_backward_split2h: dy is read and
         packed once for both products); None when the shapes / settings are not the ones it takes."""
         lib = _lib.load()
@@ -177,11 +178,19 @@ class _ProjectionLinear(torch.autograd.Function):
         gw = (gw_out if gw_out is not None else torch.empty((M, K), dtype=torch.float32, device=dev)) if want_w else None      # (gw_out: a column block of a wider gradient, row stride = its width)
         with torch.cuda.device(dev):
             ws = _workspace(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dev)
-            _lib.check(lib.gvqa_linear_backward_split2h_hint(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
-                                                             _ptr(am), 0 if am is None else am.numel(), _ptr(x_absmax),
-                                                             0 if x_absmax is None else x_absmax.numel(), _ptr(gx), K,
-                                                             int(gx_init is not None and want_x), _ptr(gw), K if gw is None else gw.stride(0),
-                                                             ws.data_ptr(), ws.numel(), _stream(dev)))
+            ex = _lib.LinearBackwardExtras()
+            ex.x_absmax, ex.x_absmax_n = _ptr(x_absmax), 0 if x_absmax is None else x_absmax.numel()
+            if want_x and lowrank is not None:        # dx += g v^T in the product's epilogue (`lowrank` = (g [R, J], v [K, J]))
+                ex.lowrank_g, ex.lowrank_v, ex.J = lowrank[0].data_ptr(), lowrank[1].data_ptr(), lowrank[0].shape[1]
+            if want_x and addend is not None:
+                ex.addend, ex.ld_addend = addend.data_ptr(), addend.stride(0)
+            rc = lib.gvqa_linear_backward_split2h_ex(R, M, K, gy.data_ptr(), M, w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0),
+                                                     _ptr(am), 0 if am is None else am.numel(), _ptr(gx), K,
+                                                     int(gx_init is not None and want_x), _ptr(gw), K if gw is None else gw.stride(0),
+                                                     C.byref(ex), ws.data_ptr(), ws.numel(), _stream(dev))
+            if rc == _lib.E_UNSUPPORTED and (lowrank is not None or addend is not None):
+                return None                            # (the epilogue terms need the direct product: the caller takes the separate passes)
+            _lib.check(rc)
         return gx, gw
 
     @staticmethod
@@ -218,6 +227,41 @@ def _absmax_hint(gy: Tensor):
         return None
     am, ptr, version = hint
     return am if (gy.data_ptr() == ptr and gy._version == version) else None
+
+
+class _ColumnBlocks(torch.autograd.Function):
+    """[R, K*W] -> K column blocks [R, W] as views (no copies); the backward writes the K gradients into ONE [R, K*W] tensor -- K strided copies
+    instead of autograd's K zero-filled full-size tensors, K slice copies and K - 1 full-size adds."""
+
+    @staticmethod
+    def forward(ctx, a, K, W):
+        ctx.dims = (a.shape, K, W)
+        return tuple(a[:, i * W:(i + 1) * W] for i in range(K))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, K, W = ctx.dims
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(shape, dtype=ref.dtype, device=ref.device)
+        for i, g in enumerate(grads):
+            if g is None:
+                out[:, i * W:(i + 1) * W].zero_()
+            else:
+                out[:, i * W:(i + 1) * W].copy_(g)
+        return out, None, None
+
+
+_ONES = {}
+
+
+def _ones_column(n: int, device) -> Tensor:
+    key = (n, str(device))
+    t = _ONES.get(key)
+    if t is None:
+        if len(_ONES) > 16:
+            _ONES.clear()
+        t = _ONES[key] = torch.ones((n, 1), dtype=torch.float32, device=device)
+    return t
 
 
 class _NoCtx:
@@ -359,7 +403,7 @@ class _HopProducts(torch.autograd.Function):
         H = heads2 // 2
         with torch.no_grad():
             # (the largest magnitudes of h leave the operand pack as a by-product: the backward's dW = dxp^T h needs h's ONE scale)
-            am_h = torch.zeros(_lib.ABSMAX_SLOTS, dtype=torch.float32, device=h.device) if (h.is_cuda and W.requires_grad and not (_TRAIN_AB & 1)) else None
+            am_h = torch.empty(_lib.ABSMAX_SLOTS, dtype=torch.float32, device=h.device) if (h.is_cuda and W.requires_grad and not (_TRAIN_AB & 1)) else None
             xp = _ProjectionLinear._product(h, W[:, :Dn], absmax_out=am_h)
             ctx.h_absmax = (am_h, h._version) if (am_h is not None and getattr(am_h, "_gvqa_filled", False)) else None
             a_part = skinny_linear(h, F_[:Dn])
@@ -408,29 +452,41 @@ class _HopProducts(torch.autograd.Function):
             if want_ue:
                 gUe = gF[Dn:, :H].clone()                     # ... whose source half is dU_e as well
         extra = ctx.skip_grad.pop() if ctx.skip_grad else None          # d loss / d (the hop's skip operand), left by the message-passing node
-        if want_h:
-            if ok and (extra is None or (extra.is_contiguous() and extra.shape == (R, D) and extra.dtype == torch.float32)):
-                gh = torch.empty((R, D), dtype=torch.float32, device=dev)
-                with torch.cuda.device(dev):
-                    _lib.check(lib.gvqa_skinny_backward_input(R, D, H2, ga.data_ptr(), V.data_ptr(), _ptr(extra), D, gh.data_ptr(), D, _stream(dev)))
-            else:
-                gh = _lib_abt(ga, V)
-                if extra is not None:
-                    gh = gh + extra
         if want_w:
             gW = torch.empty_like(W)
             _lib_abt(g_rows.t().contiguous(), ins.t().contiguous(), out=gW[:, Dn:])      # instruction half: dW_i = d xp_rows^T ins
         Wh = W[:, :Dn]
         # (the hint holds while h is what the forward packed: an in-place change since then bumps its version counter)
         hint = ctx.h_absmax[0] if (ctx.h_absmax is not None and ctx.h_absmax[1] == h._version) else None
-        fused = _ProjectionLinear._backward_fused(gxp, h, Wh, want_h, want_w, gx_init=gh, gw_out=None if gW is None else gW[:, :Dn], x_absmax=hint)
-        if fused is not None:
-            gh = fused[0] if want_h else None
-        else:
+        extra_ok = extra is None or (extra.is_contiguous() and extra.shape == (R, D) and extra.dtype == torch.float32)
+        fused = None
+        if want_h and ok and extra_ok and H2 % 4 == 0 and H2 <= 16 and (_TRAIN_AB & 16):
+            # dh = d xp W_h + d a V^T + d skip, written ONCE: the logit products' input gradient (a rank-2H term) and the skip's gradient ride in
+            # the epilogue of the product that reads d xp directly (gvqa_linear_backward_split2h_ex).  OFF by default: measured 0.27 ms per
+            # config-3 step SLOWER than the separate tall-skinny pass (13.16 vs 12.89 ms, same box) -- the epilogue's 8 FMAs per element run with
+            # the matrix cores idle, the separate pass streams at the copy rate
+            fused = _ProjectionLinear._backward_fused(gxp, h, Wh, True, want_w, gw_out=None if gW is None else gW[:, :Dn], x_absmax=hint,
+                                                      lowrank=(ga, V), addend=extra)
+            if fused is not None:
+                gh = fused[0]
+        if fused is None:
             if want_h:
-                gh = _ProjectionLinear._product(gxp.contiguous(), Wh.t().contiguous()) + gh
-            if want_w:
-                gW[:, :Dn] = _ProjectionLinear._weight_grad(gxp, h)
+                if ok and extra_ok:
+                    gh = torch.empty((R, D), dtype=torch.float32, device=dev)
+                    with torch.cuda.device(dev):
+                        _lib.check(lib.gvqa_skinny_backward_input(R, D, H2, ga.data_ptr(), V.data_ptr(), _ptr(extra), D, gh.data_ptr(), D, _stream(dev)))
+                else:
+                    gh = _lib_abt(ga, V)
+                    if extra is not None:
+                        gh = gh + extra
+            fused = _ProjectionLinear._backward_fused(gxp, h, Wh, want_h, want_w, gx_init=gh, gw_out=None if gW is None else gW[:, :Dn], x_absmax=hint)
+            if fused is not None:
+                gh = fused[0] if want_h else None
+            else:
+                if want_h:
+                    gh = _ProjectionLinear._product(gxp.contiguous(), Wh.t().contiguous()) + gh
+                if want_w:
+                    gW[:, :Dn] = _ProjectionLinear._weight_grad(gxp, h)
         if want_ins:
             gins = _lib_abt(g_rows, W[:, Dn:].t().contiguous()) + _lib_abt(g_arows, U_n)
         return gh, gins, gW, (gF if want_f else None), gUe, None, None
@@ -449,7 +505,10 @@ class _GatMessagePassing(torch.autograd.Function):
     def forward(ctx, xp, a_node, a_edge, mask, graph, heads, channels, slope, graph_rows=None, bias=None, skip=None, skip_grad=None):
         lib = _lib.load()
         ctx.skip_grad = skip_grad          # (a list: the gradient of `skip` is left there for _HopProducts.backward instead of being returned)
-        xp, a_node, a_edge = _f32c(xp, "xp"), _f32c(a_node, "a_node"), _f32c(a_edge, "a_edge")
+        xp, a_node = _f32c(xp, "xp"), _f32c(a_node, "a_node")
+        # a_edge may be a column block of a wider [E, K*H] tensor (the K hops' edge logits side by side): the kernels take its row stride
+        if not (a_edge.is_cuda and a_edge.dtype == torch.float32 and a_edge.dim() == 2 and a_edge.stride(1) == 1 and a_edge.stride(0) >= a_edge.shape[1]):
+            a_edge = _f32c(a_edge, "a_edge")
         if mask is not None:
             mask = _f32c(mask, "alpha_mask")
         if graph_rows is not None:
@@ -467,6 +526,7 @@ class _GatMessagePassing(torch.autograd.Function):
         m = _lib.GatMpDesc()
         m.C, m.H, m.negative_slope, m.bn_eps = channels, heads, slope, 1e-5
         m.xp, m.a_node, m.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
+        m.a_edge_stride = a_edge.stride(0)
         m.out, m.alpha_out, m.alpha_mask = out.data_ptr(), alpha.data_ptr(), _ptr(mask)
         s = None
         if bias is not None:
@@ -514,7 +574,8 @@ class _GatMessagePassing(torch.autograd.Function):
         heads, channels, slope = ctx.dims
         graph, dev = ctx.graph, xp.device
         dout = dout.contiguous()
-        dxp, da_node, da_edge = torch.empty_like(xp), torch.empty_like(a_node), torch.empty_like(a_edge)
+        dxp, da_node = torch.empty_like(xp), torch.empty_like(a_node)
+        da_edge = torch.empty(a_edge.shape, dtype=torch.float32, device=dev)
         d_rows = ds = dcol = None
         if graph_rows is not None or ctx.has_bias:
             if graph_rows is not None:
@@ -529,6 +590,7 @@ class _GatMessagePassing(torch.autograd.Function):
         d = _lib.GatMpBwdDesc()
         d.C, d.H, d.negative_slope = channels, heads, slope
         d.xp, d.a_node, d.a_edge = xp.data_ptr(), a_node.data_ptr(), a_edge.data_ptr()
+        d.a_edge_stride = a_edge.stride(0)
         d.alpha, d.alpha_mask, d.dout = alpha.data_ptr(), _ptr(mask), dout.data_ptr()
         d.dxp, d.da_node, d.da_edge = dxp.data_ptr(), da_node.data_ptr(), da_edge.data_ptr()
         d.dalpha_node = _ptr(ds)
@@ -540,7 +602,19 @@ class _GatMessagePassing(torch.autograd.Function):
         # the hint is valid for THIS tensor in THIS state only: autograd may accumulate a second consumer's gradient into dxp in
         # place, a hook may rescale it -- either bumps the version counter and the consumer then measures the maxima itself
         dxp._gvqa_absmax = (am, dxp.data_ptr(), dxp._version)
-        d_bias = dcol.sum(0) if dcol is not None else None
+        d_bias = None
+        if dcol is not None:                 # bias gradient = the sum of the per-graph column sums: a tall-skinny product with a column of ones
+            Bg = dcol.shape[0]
+            if channels % 4 == 0 and channels <= 1024:
+                ones = _ones_column(Bg, dev)
+                d_bias = torch.empty((channels, 1), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    wsb = _workspace(lib.gvqa_skinny_backward_weight_workspace_bytes(Bg, channels, 1), dev)
+                    _lib.check(lib.gvqa_skinny_backward_weight(Bg, channels, 1, dcol.data_ptr(), channels, ones.data_ptr(), d_bias.data_ptr(),
+                                                               wsb.data_ptr(), wsb.numel(), _stream(dev)))
+                d_bias = d_bias.view(channels)
+            else:
+                d_bias = dcol.sum(0)
         if ctx.skip_grad is not None and ctx.has_skip:
             ctx.skip_grad.append(dout)
             return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, None, None
@@ -600,8 +674,9 @@ def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor, p: float = 0.0) -> Tenso
             bn.num_batches_tracked += 1
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             n = x.shape[0]
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var * (n / (n - 1)), alpha=mom)
+            stats = [bn.running_mean, bn.running_var]             # (same arithmetic as mul_().add_() per tensor, two launches instead of four)
+            torch._foreach_mul_(stats, 1 - mom)
+            torch._foreach_add_(stats, [mean, var * (n / (n - 1))], alpha=mom)
     return y
 
 
@@ -1145,6 +1220,7 @@ class gat_seq(torch.nn.Module):
         # (att_e through lin_e, one launch per hop: rows [:De] act on edge_attr, rows [De:] on the instruction half, :257-260)
         folds_e = [fold_attention(c.lin_e.weight, c.att_e, None, H) for c in self.convs]
         a_edge_all = skinny_linear(edge_attr, torch.cat([f[:De] for f in folds_e], dim=1))
+        a_edge_cols = _ColumnBlocks.apply(a_edge_all, K, H) if a_edge_all.shape[1] == K * H else [a_edge_all[:, i * H:(i + 1) * H] for i in range(K)]
         for i, conv in enumerate(self.convs):
             ins = instr[i]
             W, We = conv.lin_l.weight, conv.lin_e.weight
@@ -1159,7 +1235,7 @@ class gat_seq(torch.nn.Module):
             sg = [] if (h.requires_grad and torch.is_grad_enabled() and Cc % 4 == 0 and H <= 8 and not (_TRAIN_AB & 2)) else None
             xp, a_part, xp_rows, a_rows = _HopProducts.apply(h, ins, W, fold_n, folds_e[i][De:], Dn, sg)
             a_node = add_graph_rows(a_part, a_rows, graph)
-            a_edge = a_edge_all[:, i * H:(i + 1) * H]
+            a_edge = a_edge_cols[i]
             mask = None
             if alpha_masks is not None:
                 mask = alpha_masks[i]

@@ -380,6 +380,24 @@ GVQA_API int gvqa_linear_backward_split2h_hint(int64_t R, int64_t M, int64_t K, 
                                                const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, const float* x_absmax,
                                                int x_absmax_n, float* dx, int64_t ld_dx, int dx_accumulate, float* dW, int64_t ld_dw, void* ws,
                                                size_t ws_bytes, void* stream);
+/* The general form.  `ex` (may be NULL) carries the optional operands: x_absmax as above, and two terms that ride in the EPILOGUE of the dx product
+ * when it reads dy directly (GVQA_OPT_TN_DIRECT, M % 16 == 0, dy 16-byte aligned; GVQA_E_UNSUPPORTED before anything is launched otherwise):
+ *     dx = [dx +] dy W + lowrank_g lowrank_v^T + addend
+ * -- in the hop, the logit products' input gradient (g = d a_node [R, J], v = the folded attention vectors [K, J]; gvqa_skinny_backward_input's
+ * product) and the gradient of the skip connection, so that dh is written once. */
+typedef struct gvqa_linear_backward_extras {
+    const float* x_absmax;      /* NULL or slice maxima of |x|                                       */
+    int32_t x_absmax_n;
+    int32_t J;                  /* columns of lowrank_g / lowrank_v: 4, 8, 12 or 16                  */
+    const float* lowrank_g;     /* NULL or [R, J], 16-byte aligned                                   */
+    const float* lowrank_v;     /* [K, J], 16-byte aligned                                           */
+    const float* addend;        /* NULL or [R, ld_addend]                                            */
+    int64_t ld_addend;          /* 0 -> K                                                            */
+} gvqa_linear_backward_extras;
+GVQA_API int gvqa_linear_backward_split2h_ex(int64_t R, int64_t M, int64_t K, const float* dy, int64_t ld_dy, const float* W, int64_t ldw,
+                                             const float* x, int64_t ldx, const float* dy_absmax, int dy_absmax_n, float* dx, int64_t ld_dx,
+                                             int dx_accumulate, float* dW, int64_t ld_dw, const gvqa_linear_backward_extras* ex, void* ws,
+                                             size_t ws_bytes, void* stream);
 
 /* Process-wide run-time options.  Initial values come from the environment (GVQA_PROJ=split2h|split3|f32,
  * GVQA_GEMM_BACKEND=rocblas, GVQA_SPLIT3_MIN_MFLOP, GVQA_SPLIT3_VARIANT); gvqa_set_option overrides them for calls

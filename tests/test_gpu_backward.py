@@ -1,6 +1,7 @@
 """GPU tests of the differentiable path: HIP message-passing backward against torch autograd through
 the oracle's restatement of PyG's gather / segment softmax / scatter-add, and gat_seq parameter / input gradients
 against autograd through the oracle's gat_seq.  Tolerances are relative to the gradient's scale."""
+import ctypes as C
 import numpy as np
 import pytest
 import torch
@@ -872,6 +873,24 @@ def test_operand_pack_leaves_slice_maxima_and_the_backward_takes_them(dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     ref = dy.double().t() @ x.double()
     assert float((outs[1][0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # gvqa_linear_backward_split2h_ex: dx = dy W + g v^T + addend in the product's epilogue (M % 16 == 0: the direct product applies), against the
+    # separate passes; the packed form refuses the epilogue terms before launching anything
+    J = 8
+    gl, vl, add = torch.randn((R, J), generator=g).to(dev), torch.randn((K, J), generator=g).to(dev), torch.randn((R, K), generator=g).to(dev)
+    ex = _lib.LinearBackwardExtras()
+    ex.lowrank_g, ex.lowrank_v, ex.J, ex.addend, ex.ld_addend = gl.data_ptr(), vl.data_ptr(), J, add.data_ptr(), K
+    dx2 = torch.empty((R, K), device=dev)
+    _lib.check(lib.gvqa_linear_backward_split2h_ex(R, M, K, dy.data_ptr(), M, W.data_ptr(), K, x.data_ptr(), K, None, 0, dx2.data_ptr(), K, 0, None, K,
+                                                   C.byref(ex), ws.data_ptr(), ws.numel(), st))
+    want = outs[0][1].double() + gl.double() @ vl.double().t() + add.double()
+    assert float((dx2.double() - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1.0)
+    old = _lib.set_option(_lib.OPT_TN_DIRECT, 0)
+    try:
+        rc = lib.gvqa_linear_backward_split2h_ex(R, M, K, dy.data_ptr(), M, W.data_ptr(), K, x.data_ptr(), K, None, 0, dx2.data_ptr(), K, 0, None, K,
+                                                 C.byref(ex), ws.data_ptr(), ws.numel(), st)
+    finally:
+        _lib.set_option(_lib.OPT_TN_DIRECT, old)
+    assert rc == _lib.E_UNSUPPORTED
 
 
 @pytest.mark.parametrize("train", [False, True])
