@@ -54,7 +54,8 @@ _HEADER_STRUCTS = {"Graph": "gvqa_graph", "GatConvParams": "gvqa_gat_conv_params
                    "GatMpDesc": "gvqa_gat_mp_desc", "GatMpBwdDesc": "gvqa_gat_mp_bwd_desc", "MpPlan": "gvqa_mp_plan",
                    "BnParams": "gvqa_bn_params", "GineParams": "gvqa_gine_params", "GcnParams": "gvqa_gcn_params",
                    "LcgnDims": "gvqa_lcgn_dims", "LcgnParams": "gvqa_lcgn_params", "PoolParams": "gvqa_pool_params",
-                   "ClassifierParams": "gvqa_classifier_params", "EncoderParams": "gvqa_encoder_params"}
+                   "ClassifierParams": "gvqa_classifier_params", "EncoderParams": "gvqa_encoder_params",
+                   "LinearBackwardExtras": "gvqa_linear_backward_extras"}
 
 
 def test_every_ctypes_structure_matches_the_header_member_for_member():
