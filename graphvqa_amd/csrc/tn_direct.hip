@@ -15,7 +15,8 @@
 //   * one power-of-two scale per operand (train.hip's argument: a piece pair carries 22 bits below each element's own exponent while
 //     the element is within 2^18 of the operand's largest), from the producer's slice maxima or k_absmax.
 //
-// Same arithmetic as the packed form: same scales, same pieces, the same three piece products, fp32 accumulation, the same split-K chunks.
+// Same arithmetic as the packed form: same scales, same pieces, the same three piece products (in another order), fp32 accumulation, the same
+// split-K chunks.
 #include "common.h"
 #include "gemm_tile.h"
 
