@@ -241,8 +241,20 @@ struct NndArgs {
     const float* addend; int64_t ld_add;               // optional [R, N] added to the result
 };
 
+// LDS-DMA of a packed operand's fragment pair (hi at +0, lo at +1024 on both sides): global = scalar base + 32-bit lane offset, LDS = M0 base +
+// lane * 16.  Inline asm: invisible to the compiler's wait-count bookkeeping, ordered by the counted s_waitcnt in front of the step's barrier.
+typedef __attribute__((address_space(3))) unsigned char* tnd_lds_ptr;
+__device__ __forceinline__ void tnd_dma16_x2(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                 :
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory", "m0");
+}
+
+constexpr int NND_A0 = 0, NND_B0 = 2 * TND_IMG, NND_LDS = 5 * TND_IMG;     // A images x 2 | B ring x 3
+
 __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TND_IMG];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NND_LDS];
     __shared__ float mx_s[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the column tiles of one row tile read the same rows of A: they take workgroup ids 8 apart (one XCD, one L2)
@@ -272,18 +284,25 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
     };
     // loader roles.  A: row tid / 2 of the tile, k half tid & 1 (rows past R: beyond the descriptor, read as zero).  B: tile tid / 64, lane tid & 63
     const int arow = tid >> 1, ag = tid & 1;
-    const int64_t bytes_a = ((a.R - 1) * a.lda + a.K) * 4, bytes_b = (int64_t)a.TB * a.KBb * 2048;
+    const int64_t bytes_a = ((a.R - 1) * a.lda + a.K) * 4;
     const unsigned oa = (unsigned)(((int64_t)(m0 + arow) * a.lda + 8 * ag) * 4);
-    const unsigned ob = (unsigned)((int64_t)(ct * 8 + (tid >> 6)) * a.KBb * 2048 + lane * 16);
+    // B: wave w copies tile w of the column block (tiles past the operand's last: the last one again -- columns that are never stored), by
+    // LDS-DMA, no register round trip (through registers the copy cost 40 us of a 409 us launch: profiles/r05_tn_direct_ab.txt)
+    const int btile = min(ct * 8 + wave, a.TB - 1);
+    const unsigned ob = (unsigned)((int64_t)btile * a.KBb * 2048 + lane * 16);
+    const unsigned lds_base = (unsigned)(size_t)(tnd_lds_ptr)smem;
     const unsigned wa_off = (unsigned)((arow >> 5) * 2048 + ((arow & 31) + 32 * ag) * 16);
-    const unsigned wb_off = (unsigned)(TND_IMG + (tid >> 6) * 2048 + lane * 16);
+    auto dma_b = [&](int step, int slot) {                  // the step's 2 KiB of this wave's tile -> ring slot (steps past the pack's last block: the last)
+        const int kb = min(step, a.KBb - 1);
+        tnd_dma16_x2(a.Bpk, ob + (unsigned)kb * 2048u, __builtin_amdgcn_readfirstlane(lds_base + NND_B0 + (unsigned)slot * TND_IMG + (unsigned)wave * 2048u));
+    };
     typedef float nnd_f32x4 __attribute__((ext_vector_type(4)));
-    nnd_f32x4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;       // two register sets (A: 8 floats, B: hi / lo fragment units), one converted, one in flight
+    nnd_f32x4 pa0, pa1, qa0, qa1;                           // two register sets of A rows (8 floats), one converted, one in flight
 #define GVQA_NND_LD4(rs_, off_) __builtin_bit_cast(nnd_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(off_), 0, 0))
     uint4 hx, lx;
 
     const int wr = wave >> 2, wc = wave & 3;
-    const unsigned a_off = (unsigned)(wr * 4 * 2048 + lane * 16), b_off = (unsigned)(TND_IMG + wc * 2 * 2048 + lane * 16);
+    const unsigned a_off = (unsigned)(NND_A0 + wr * 4 * 2048 + lane * 16), b_off = (unsigned)(NND_B0 + wc * 2 * 2048 + lane * 16);
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -293,37 +312,43 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto rd = [&](const unsigned char* p) { return __builtin_bit_cast(tnd_f16x8, *reinterpret_cast<const uint4*>(p)); };
     tnd_f16x8 ah[4], al[4], bh[2], bl[2];
-#ifndef GVQA_NND_DBG        /* A/B build switch: bit 1 no A loads in the loop, 2 no split / A image writes, 4 no MFMAs, 8 no B loads / writes */
+#ifndef GVQA_NND_DBG        /* A/B build switch: bit 1 no A loads in the loop, 2 no split / A image writes, 4 no MFMAs (timing only: results wrong) */
 #define GVQA_NND_DBG 0
 #endif
 #define GVQA_NND_MF(n_) do { constexpr int q_ = (n_) / 8, t_ = (n_) % 8, i_ = t_ >> 1, j_ = t_ & 1;                                       \
         if (!(GVQA_NND_DBG & 4)) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q_ == 0 ? al[i_] : ah[i_], q_ == 2 ? bl[j_] : bh[j_], acc[i_][j_], 0, 0, 0); } while (0)
 #define GVQA_NND_FENCE() __builtin_amdgcn_sched_barrier(0)
     {
-        const auto r0a = rsrc_of(a.A, 0, bytes_a), r0b = rsrc_of(a.Bpk, 0, bytes_b);
-        qa0 = GVQA_NND_LD4(r0a, oa); qa1 = GVQA_NND_LD4(r0a, oa + 16); qb0 = GVQA_NND_LD4(r0b, ob); qb1 = GVQA_NND_LD4(r0b, ob + 1024);
-        const auto r1a = rsrc_of(a.A, ns > 1 ? 64 : bytes_a, bytes_a), r1b = rsrc_of(a.Bpk, 2048, bytes_b);      // (steps past the last: an empty descriptor, zeros)
-        pa0 = GVQA_NND_LD4(r1a, oa); pa1 = GVQA_NND_LD4(r1a, oa + 16); pb0 = GVQA_NND_LD4(r1b, ob); pb1 = GVQA_NND_LD4(r1b, ob + 1024);
+        dma_b(0, 0);
+        dma_b(1, 1);
+        const auto r0a = rsrc_of(a.A, 0, bytes_a);
+        qa0 = GVQA_NND_LD4(r0a, oa); qa1 = GVQA_NND_LD4(r0a, oa + 16);
+        const auto r1a = rsrc_of(a.A, ns > 1 ? 64 : bytes_a, bytes_a);      // (steps past the last: an empty descriptor, zeros)
+        pa0 = GVQA_NND_LD4(r1a, oa); pa1 = GVQA_NND_LD4(r1a, oa + 16);
         GVQA_TND_SPLIT2(hx.x, lx.x, sa, qa0.x, qa0.y); GVQA_TND_SPLIT2(hx.y, lx.y, sa, qa0.z, qa0.w);
         GVQA_TND_SPLIT2(hx.z, lx.z, sa, qa1.x, qa1.y); GVQA_TND_SPLIT2(hx.w, lx.w, sa, qa1.z, qa1.w);
-        *reinterpret_cast<uint4*>(smem + wa_off) = hx; *reinterpret_cast<uint4*>(smem + wa_off + 1024) = lx;
-        *reinterpret_cast<nnd_f32x4*>(smem + wb_off) = qb0; *reinterpret_cast<nnd_f32x4*>(smem + wb_off + 1024) = qb1;
+        *reinterpret_cast<uint4*>(smem + NND_A0 + wa_off) = hx; *reinterpret_cast<uint4*>(smem + NND_A0 + wa_off + 1024) = lx;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) al[i] = rd(smem + a_off + i * 2048 + 1024);
 #pragma unroll
     for (int j = 0; j < 2; ++j) bh[j] = rd(smem + b_off + j * 2048);
-    // step s_: rows of step s + 1 (set CA_/CB_) -> image, rows of step s + 2 -> set LA_/LB_
-#define GVQA_NND_STEP(s_, CA0_, CA1_, CB0_, CB1_, LA0_, LA1_, LB0_, LB1_)                                                                     \
+    int bcur = 0;                                           // ring slot of the current step's B tiles
+    // step s_: A rows of step s + 1 (set CA_) -> image, A rows of step s + 2 -> set LA_; B tiles of step s + 2 -> ring by DMA.  At the barrier the
+    // DMAs of step s + 1 (issued one step ago) must have landed: the four younger memory operations -- this step's two A loads and two DMAs -- may
+    // stay in flight (loads retire in order)
+#define GVQA_NND_STEP(s_, CA0_, CA1_, LA0_, LA1_)                                                                                             \
     {                                                                                                                                         \
         const int st_ = (s_);                                                                                                                 \
-        const unsigned char* img = smem + (st_ & 1) * (2 * TND_IMG);                                                                          \
-        const unsigned char* imn = smem + ((st_ + 1) & 1) * (2 * TND_IMG);                                                                    \
-        unsigned char* dn = smem + ((st_ + 1) & 1) * (2 * TND_IMG);                                                                           \
-        const auto ra_ = rsrc_of(a.A, st_ + 2 < ns ? (int64_t)(st_ + 2) * 64 : bytes_a, bytes_a), rb_ = rsrc_of(a.Bpk, (int64_t)(st_ + 2) * 2048, bytes_b); \
+        const int bnext = bcur == 2 ? 0 : bcur + 1, bload = bnext == 2 ? 0 : bnext + 1;                                                       \
+        const unsigned char* img = smem + (st_ & 1) * TND_IMG;                                                                                \
+        const unsigned char* imn = smem + ((st_ + 1) & 1) * TND_IMG;                                                                          \
+        unsigned char* dn = smem + NND_A0 + ((st_ + 1) & 1) * TND_IMG;                                                                        \
+        const auto ra_ = rsrc_of(a.A, st_ + 2 < ns ? (int64_t)(st_ + 2) * 64 : bytes_a, bytes_a);                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) ah[i] = rd(img + a_off + i * 2048);                                                     \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) bl[j] = rd(img + b_off + j * 2048 + 1024);                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bl[j] = rd(smem + bcur * TND_IMG + b_off + j * 2048 + 1024);                            \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(0); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 2)) GVQA_TND_SPLIT2(hx.x, lx.x, sa, CA0_.x, CA0_.y); if (!(GVQA_NND_DBG & 1)) LA0_ = GVQA_NND_LD4(ra_, oa); GVQA_NND_FENCE();      \
         GVQA_NND_MF(1); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 2)) GVQA_TND_SPLIT2(hx.y, lx.y, sa, CA0_.z, CA0_.w); if (!(GVQA_NND_DBG & 1)) LA1_ = GVQA_NND_LD4(ra_, oa + 16); GVQA_NND_FENCE(); \
@@ -333,24 +358,24 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
         if (!(GVQA_NND_DBG & 2)) { *reinterpret_cast<uint4*>(dn + wa_off) = hx; *reinterpret_cast<uint4*>(dn + wa_off + 1024) = lx; }        \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(5); GVQA_NND_FENCE();                                                                                                     \
-        if (!(GVQA_NND_DBG & 8)) { *reinterpret_cast<nnd_f32x4*>(dn + wb_off) = CB0_; *reinterpret_cast<nnd_f32x4*>(dn + wb_off + 1024) = CB1_; } \
+        dma_b(st_ + 2, bload);                                                                                                                \
         GVQA_NND_FENCE();                                                                                                                     \
-        GVQA_NND_MF(6); GVQA_NND_FENCE(); if (!(GVQA_NND_DBG & 8)) { LB0_ = GVQA_NND_LD4(rb_, ob); LB1_ = GVQA_NND_LD4(rb_, ob + 1024); } GVQA_NND_FENCE();                 \
-        GVQA_NND_MF(7); GVQA_NND_FENCE();                                                                                                     \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                    \
+        GVQA_NND_MF(6); GVQA_NND_MF(7); GVQA_NND_FENCE();                                                                                     \
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                                         \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(8); GVQA_NND_MF(9); GVQA_NND_MF(10); GVQA_NND_MF(11); GVQA_NND_MF(12); GVQA_NND_MF(13); GVQA_NND_MF(14); GVQA_NND_MF(15);  \
         GVQA_NND_FENCE();                                                                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) al[i] = rd(imn + a_off + i * 2048 + 1024);                                              \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) bh[j] = rd(imn + b_off + j * 2048);                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bh[j] = rd(smem + bnext * TND_IMG + b_off + j * 2048);                                  \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(16); GVQA_NND_MF(17); GVQA_NND_MF(18); GVQA_NND_MF(19); GVQA_NND_MF(20); GVQA_NND_MF(21); GVQA_NND_MF(22); GVQA_NND_MF(23); \
         GVQA_NND_FENCE();                                                                                                                     \
+        bcur = bnext;                                                                                                                         \
     }
-    for (int s = 0; s < ns; s += 2) {          // (an odd count runs one more step on zero operands)
-        GVQA_NND_STEP(s, pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1)
-        GVQA_NND_STEP(s + 1, qa0, qa1, qb0, qb1, pa0, pa1, pb0, pb1)
+    for (int s = 0; s < ns; s += 2) {          // (an odd count runs one more step: A zeros -- an empty descriptor -- against B's last block again)
+        GVQA_NND_STEP(s, pa0, pa1, qa0, qa1)
+        GVQA_NND_STEP(s + 1, qa0, qa1, pa0, pa1)
     }
 #undef GVQA_NND_STEP
 #undef GVQA_NND_MF
@@ -379,6 +404,7 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
             for (int u = 0; u < 4; ++u)
                 vrow[q4][u] = 4 * u < a.J ? *reinterpret_cast<const float4*>(a.lr_v + (int64_t)(gcol + q4) * a.J + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the last steps' DMAs -- invisible to the compiler -- have landed: the stage below overlaps the ring)
     __syncthreads();                                               // every wave is done with the operand images
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
