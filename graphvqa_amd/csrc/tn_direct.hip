@@ -7,9 +7,9 @@
 //
 //   * workgroup = a 256 x 256 tile of C over one chunk of KC rows (split-K: partial results added in a fixed order by k_splitk_reduce);
 //     8 waves as 2 (128 columns of X) x 4 (64 columns of Y), 4 x 2 accumulators of 32 x 32 per wave;
-//   * K step = 16 rows.  Thread (column c, row half g) of the 512 loads X[r0 + 8 g + j, c], j = 0..7 -- a wave's load instruction is 64
-//     consecutive floats of ONE row, 256 contiguous bytes -- and the same for Y; these eight values ARE the 8 consecutive k of lane
-//     (c mod 32, g) of an MFMA operand fragment: scaled by the operand's power of two, split into two fp16 pieces (v_fma_mix, as the
+//   * K step = 16 rows.  Thread (column pair cp, row half g) of an operand's 256 loaders reads X[r0 + 8 g + j, 2 cp .. 2 cp + 1], j = 0..7 -- a
+//     wave's load instruction is 128 consecutive floats of ONE row, 512 contiguous bytes; waves 0..3 serve X, 4..7 serve Y.  The eight values
+//     of a column ARE the 8 consecutive k of lane (c mod 32, g) of an MFMA operand fragment: scaled by the operand's power of two, split into two fp16 pieces (v_fma_mix, as the
 //     aggregate-first hop kernel does), written as 2 x 16 bytes into the fragment image of the NEXT step (double-buffered, 64 KiB);
 //   * the loads of step s + 2 are issued when step s + 1's registers have been converted: a full step (~1.4 us) to land;
 //   * one power-of-two scale per operand (train.hip's argument: a piece pair carries 22 bits below each element's own exponent while
@@ -76,24 +76,25 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
     for (int w = 0; w < 8; ++w) { vx = fmaxf(vx, mx_s[0][w]); vy = fmaxf(vy, mx_s[1][w]); }
     const int ex = split2h_exponent(vx), ey = split2h_exponent(vy);
 
-    // loader role: column c of the tile, row half g.  Buffer loads: a wave-uniform descriptor (base = the step's first row, size = what is left of
-    // the chunk: rows past its end read as zero, no guards anywhere) + eight 32-bit per-lane byte offsets (row j of the half, column c)
-    const int c = tid & 255, g = tid >> 8;
-    const bool okx = m0 + c < a.M, oky = n0 + c < a.N;
-    const float sx = okx ? pow2i(ex) : 0.f, sy = oky ? pow2i(ey) : 0.f;
-    const float* bx = a.X + rbeg * a.ldx;
-    const float* by = a.Y + rbeg * a.ldy;
-    const int64_t bytes_x = ((int64_t)(rows - 1) * a.ldx + a.M) * 4, bytes_y = ((int64_t)(rows - 1) * a.ldy + a.N) * 4;
-    const int64_t step_x = (int64_t)TND_STEP * a.ldx * 4, step_y = (int64_t)TND_STEP * a.ldy * 4;
-    unsigned ox[8], oy[8];
+    // loader role: waves 0..3 load X, waves 4..7 load Y; thread = (column PAIR cp, row half g) of its operand's tile: 8 rows x 2 adjacent columns
+    // per step as eight 8-byte buffer loads (a wave instruction = 512 contiguous bytes of one row; half the load instructions of one column
+    // per thread), i.e. two fragment units.  Buffer loads: a wave-uniform descriptor (base = the step's first row, size = what is left of the
+    // chunk: rows past its end read as zero, no guards anywhere) + eight 32-bit per-lane byte offsets (row j of the half, column 2 cp)
+    const int op = __builtin_amdgcn_readfirstlane(tid >> 8);           // 0: X, 1: Y
+    const int cp = tid & 127, g = (tid >> 7) & 1, c = 2 * cp;
+    const int col0 = op ? n0 : m0, ncols = op ? a.N : a.M;
+    const int64_t ld = op ? a.ldy : a.ldx;
+    const bool okc = col0 + c < ncols;                                  // (M, N multiples of 4: a pair is inside or outside)
+    const float sc = okc ? pow2i(op ? ey : ex) : 0.f;
+    const float* bo = (op ? a.Y : a.X) + rbeg * ld;
+    const int64_t bytes_o = ((int64_t)(rows - 1) * ld + ncols) * 4;
+    const int64_t step_o = (int64_t)TND_STEP * ld * 4;
+    unsigned oo[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        ox[j] = 4u * (unsigned)((8 * g + j) * a.ldx + (okx ? m0 + c : 0));
-        oy[j] = 4u * (unsigned)((8 * g + j) * a.ldy + (oky ? n0 + c : 0));
-    }
+    for (int j = 0; j < 8; ++j) oo[j] = 4u * (unsigned)((8 * g + j) * ld + (okc ? col0 + c : 0));
     auto rsrc_of = [](const float* base, int64_t first, int64_t total) {
-        // (wave-uniform by construction -- kernel arguments and blockIdx -- and made PROVABLY so for the compiler: a descriptor it takes for
-        //  divergent turns every load into a waterfall loop)
+        // (wave-uniform by construction -- kernel arguments, blockIdx, the wave's operand -- and made PROVABLY so for the compiler: a
+        //  descriptor it takes for divergent turns every load into a waterfall loop)
         const int64_t left = total - first;
         const uint64_t addr = reinterpret_cast<uint64_t>(base) + (uint64_t)(left > 0 ? first : 0);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
@@ -103,12 +104,13 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
 #ifndef GVQA_TND_DBG        /* A/B build switch (scripts/ab_tn.sh): bit 1 no loads inside the loop, 2 no split / image writes, 4 no MFMAs */
 #define GVQA_TND_DBG 0
 #endif
-#define GVQA_TND_LD(rs_, off_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (int)(off_), 0, 0))
+    typedef float tnd_f32x2 __attribute__((ext_vector_type(2)));
+#define GVQA_TND_LD(rs_, off_) __builtin_bit_cast(tnd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)(off_), 0, 0))
 #define GVQA_TND_LDL(dst_, rs_, off_) do { if (!(GVQA_TND_DBG & 1)) (dst_) = GVQA_TND_LD(rs_, off_); } while (0)
 #define GVQA_TND_SPL(h_, l_, p_, a_, b_) do { if (!(GVQA_TND_DBG & 2)) GVQA_TND_SPLIT2(h_, l_, p_, a_, b_); } while (0)
-    const unsigned wr_off = (unsigned)((c >> 5) * 2048 + ((c & 31) + 32 * g) * 16);
-    float fa[16], fb[16];                        // two register sets of loaded rows (x: 0..7, y: 8..15): one being converted, one in flight
-    uint4 hx, lx, hy, ly;
+    const unsigned wr_off = (unsigned)(op * TND_IMG + (c >> 5) * 2048 + ((c & 31) + 32 * g) * 16);      // unit of column c; column c + 1: + 16
+    tnd_f32x2 fa[8], fb[8];                      // two register sets of loaded rows (row j: columns c, c + 1): one being converted, one in flight
+    uint4 h0, l0, h1, l1;                        // hi / lo fragment units of columns c and c + 1
 
     // consumer role: wave (wr, wc) = rows [128 wr, +128) of the tile (4 fragments of X) x columns [64 wc, +64) (2 fragments of Y)
     const int wr = wave >> 2, wc = wave & 3;
@@ -128,19 +130,19 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
 #define GVQA_TND_FENCE() __builtin_amdgcn_sched_barrier(0)
 
     {   // step 0's rows -> image 0; step 1's rows in flight in set A
-        const auto r0x = rsrc_of(bx, 0, bytes_x), r0y = rsrc_of(by, 0, bytes_y);
+        const auto r0 = rsrc_of(bo, 0, bytes_o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { fb[j] = GVQA_TND_LD(r0x, ox[j]); fb[8 + j] = GVQA_TND_LD(r0y, oy[j]); }
-        const auto r1x = rsrc_of(bx, step_x, bytes_x), r1y = rsrc_of(by, step_y, bytes_y);
+        for (int j = 0; j < 8; ++j) fb[j] = GVQA_TND_LD(r0, oo[j]);
+        const auto r1 = rsrc_of(bo, step_o, bytes_o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { fa[j] = GVQA_TND_LD(r1x, ox[j]); fa[8 + j] = GVQA_TND_LD(r1y, oy[j]); }
-        GVQA_TND_SPLIT2(hx.x, lx.x, sx, fb[0], fb[1]); GVQA_TND_SPLIT2(hx.y, lx.y, sx, fb[2], fb[3]);
-        GVQA_TND_SPLIT2(hx.z, lx.z, sx, fb[4], fb[5]); GVQA_TND_SPLIT2(hx.w, lx.w, sx, fb[6], fb[7]);
-        GVQA_TND_SPLIT2(hy.x, ly.x, sy, fb[8], fb[9]); GVQA_TND_SPLIT2(hy.y, ly.y, sy, fb[10], fb[11]);
-        GVQA_TND_SPLIT2(hy.z, ly.z, sy, fb[12], fb[13]); GVQA_TND_SPLIT2(hy.w, ly.w, sy, fb[14], fb[15]);
+        for (int j = 0; j < 8; ++j) fa[j] = GVQA_TND_LD(r1, oo[j]);
+        GVQA_TND_SPLIT2(h0.x, l0.x, sc, fb[0].x, fb[1].x); GVQA_TND_SPLIT2(h0.y, l0.y, sc, fb[2].x, fb[3].x);
+        GVQA_TND_SPLIT2(h0.z, l0.z, sc, fb[4].x, fb[5].x); GVQA_TND_SPLIT2(h0.w, l0.w, sc, fb[6].x, fb[7].x);
+        GVQA_TND_SPLIT2(h1.x, l1.x, sc, fb[0].y, fb[1].y); GVQA_TND_SPLIT2(h1.y, l1.y, sc, fb[2].y, fb[3].y);
+        GVQA_TND_SPLIT2(h1.z, l1.z, sc, fb[4].y, fb[5].y); GVQA_TND_SPLIT2(h1.w, l1.w, sc, fb[6].y, fb[7].y);
         unsigned char* d = smem + wr_off;
-        *reinterpret_cast<uint4*>(d) = hx; *reinterpret_cast<uint4*>(d + 1024) = lx;
-        *reinterpret_cast<uint4*>(d + TND_IMG) = hy; *reinterpret_cast<uint4*>(d + TND_IMG + 1024) = ly;
+        *reinterpret_cast<uint4*>(d) = h0; *reinterpret_cast<uint4*>(d + 1024) = l0;
+        *reinterpret_cast<uint4*>(d + 16) = h1; *reinterpret_cast<uint4*>(d + 16 + 1024) = l1;
     }
     __syncthreads();
 #pragma unroll
@@ -148,8 +150,9 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) bh[j] = rd(smem + b_off + j * 2048);
     // One step, laid out by hand: an MFMA holds the SIMD's matrix pipe for 32 cycles and the wave issues in order, so the step's other work --
-    // 16 loads (rows of step s + 2 into set LD_), 32 VALU of the split (rows of step s + 1 out of set CV_), 4 LDS writes -- sits in the shadow of
-    // the first ten MFMAs, a few instructions behind each; the first product's fragments (a lo, b hi) were read under the PREVIOUS step's last MFMAs.  The step's barrier comes right after the image writes (MFMAs queued in front of it
+    // 8 loads (rows of step s + 2 into set LD_), 32 VALU of the split (rows of step s + 1 out of set CV_), 4 LDS writes -- sits in the shadow of
+    // the first ten MFMAs, a few instructions behind each; the first product's fragments (a lo, b hi) were read under the PREVIOUS step's last MFMAs.
+    // The step's barrier comes right after the image writes (MFMAs queued in front of it
     // and behind it), not at the end of the step: what it orders is the image of step s + 1 (written above it by everybody, read at the top of the
     // next step) and the image of step s (read at the top of this step by everybody, overwritten below the NEXT barrier).  Loads have a whole
     // step to land.  Steps past the chunk's end: the descriptor is empty, the rows read as zero, the products add zeros.
@@ -158,24 +161,24 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
         const int st_ = (s_);                                                                                                                 \
         const unsigned char* img = smem + (st_ & 1) * (2 * TND_IMG);                                                                          \
         unsigned char* d = smem + ((st_ + 1) & 1) * (2 * TND_IMG) + wr_off;                                                                   \
-        const auto rx_ = rsrc_of(bx, (int64_t)(st_ + 2) * step_x, bytes_x), ry_ = rsrc_of(by, (int64_t)(st_ + 2) * step_y, bytes_y);          \
+        const auto rs_ = rsrc_of(bo, (int64_t)(st_ + 2) * step_o, bytes_o);                                                                   \
         const unsigned char* imn = smem + ((st_ + 1) & 1) * (2 * TND_IMG);                                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) ah[i] = rd(img + a_off + i * 2048);                                                     \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) bl[j] = rd(img + b_off + j * 2048 + 1024);                                              \
         GVQA_TND_FENCE();                                                                                                                     \
-        GVQA_TND_MF(0); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.x, lx.x, sx, CV_[0], CV_[1]); GVQA_TND_LDL(LD_[0], rx_, ox[0]); GVQA_TND_LDL(LD_[1], rx_, ox[1]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(1); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.y, lx.y, sx, CV_[2], CV_[3]); GVQA_TND_LDL(LD_[2], rx_, ox[2]); GVQA_TND_LDL(LD_[3], rx_, ox[3]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(2); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.z, lx.z, sx, CV_[4], CV_[5]); GVQA_TND_LDL(LD_[4], rx_, ox[4]); GVQA_TND_LDL(LD_[5], rx_, ox[5]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(3); GVQA_TND_FENCE(); GVQA_TND_SPL(hx.w, lx.w, sx, CV_[6], CV_[7]); GVQA_TND_LDL(LD_[6], rx_, ox[6]); GVQA_TND_LDL(LD_[7], rx_, ox[7]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(4); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.x, ly.x, sy, CV_[8], CV_[9]); GVQA_TND_LDL(LD_[8], ry_, oy[0]); GVQA_TND_LDL(LD_[9], ry_, oy[1]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(5); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.y, ly.y, sy, CV_[10], CV_[11]); GVQA_TND_LDL(LD_[10], ry_, oy[2]); GVQA_TND_LDL(LD_[11], ry_, oy[3]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(6); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.z, ly.z, sy, CV_[12], CV_[13]); GVQA_TND_LDL(LD_[12], ry_, oy[4]); GVQA_TND_LDL(LD_[13], ry_, oy[5]); GVQA_TND_FENCE(); \
-        GVQA_TND_MF(7); GVQA_TND_FENCE(); GVQA_TND_SPL(hy.w, ly.w, sy, CV_[14], CV_[15]); GVQA_TND_LDL(LD_[14], ry_, oy[6]); GVQA_TND_LDL(LD_[15], ry_, oy[7]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(0); GVQA_TND_FENCE(); GVQA_TND_SPL(h0.x, l0.x, sc, CV_[0].x, CV_[1].x); GVQA_TND_FENCE();                                  \
+        GVQA_TND_MF(1); GVQA_TND_FENCE(); GVQA_TND_SPL(h1.x, l1.x, sc, CV_[0].y, CV_[1].y); GVQA_TND_LDL(LD_[0], rs_, oo[0]); GVQA_TND_LDL(LD_[1], rs_, oo[1]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(2); GVQA_TND_FENCE(); GVQA_TND_SPL(h0.y, l0.y, sc, CV_[2].x, CV_[3].x); GVQA_TND_FENCE();                                  \
+        GVQA_TND_MF(3); GVQA_TND_FENCE(); GVQA_TND_SPL(h1.y, l1.y, sc, CV_[2].y, CV_[3].y); GVQA_TND_LDL(LD_[2], rs_, oo[2]); GVQA_TND_LDL(LD_[3], rs_, oo[3]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(4); GVQA_TND_FENCE(); GVQA_TND_SPL(h0.z, l0.z, sc, CV_[4].x, CV_[5].x); GVQA_TND_FENCE();                                  \
+        GVQA_TND_MF(5); GVQA_TND_FENCE(); GVQA_TND_SPL(h1.z, l1.z, sc, CV_[4].y, CV_[5].y); GVQA_TND_LDL(LD_[4], rs_, oo[4]); GVQA_TND_LDL(LD_[5], rs_, oo[5]); GVQA_TND_FENCE(); \
+        GVQA_TND_MF(6); GVQA_TND_FENCE(); GVQA_TND_SPL(h0.w, l0.w, sc, CV_[6].x, CV_[7].x); GVQA_TND_FENCE();                                  \
+        GVQA_TND_MF(7); GVQA_TND_FENCE(); GVQA_TND_SPL(h1.w, l1.w, sc, CV_[6].y, CV_[7].y); GVQA_TND_LDL(LD_[6], rs_, oo[6]); GVQA_TND_LDL(LD_[7], rs_, oo[7]); GVQA_TND_FENCE(); \
         GVQA_TND_MF(8); GVQA_TND_FENCE();                                                                                                     \
-        if (!(GVQA_TND_DBG & 2)) { *reinterpret_cast<uint4*>(d) = hx; *reinterpret_cast<uint4*>(d + 1024) = lx; }                            \
+        if (!(GVQA_TND_DBG & 2)) { *reinterpret_cast<uint4*>(d) = h0; *reinterpret_cast<uint4*>(d + 1024) = l0; }                            \
         GVQA_TND_FENCE();                                                                                                                     \
         GVQA_TND_MF(9); GVQA_TND_FENCE();                                                                                                     \
-        if (!(GVQA_TND_DBG & 2)) { *reinterpret_cast<uint4*>(d + TND_IMG) = hy; *reinterpret_cast<uint4*>(d + TND_IMG + 1024) = ly; }        \
+        if (!(GVQA_TND_DBG & 2)) { *reinterpret_cast<uint4*>(d + 16) = h1; *reinterpret_cast<uint4*>(d + 16 + 1024) = l1; }                  \
         GVQA_TND_FENCE();                                                                                                                     \
         GVQA_TND_MF(10); GVQA_TND_MF(11); GVQA_TND_FENCE();                                                                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                                    \
@@ -474,8 +477,8 @@ int launch_linear_nn_direct(int64_t R, int64_t N, int64_t K, const float* A, int
     return GVQA_OK;
 }
 
-bool linear_tn_direct_applies(int KC, int64_t ldx, int64_t ldy) {
-    return KC > 0 && KC % TND_STEP == 0 && (int64_t)(KC + 16) * ldx < (1ll << 29) && (int64_t)(KC + 16) * ldy < (1ll << 29);
+bool linear_tn_direct_applies(int KC, int64_t ldx, int64_t ldy) {      // (+ 8-byte aligned operands with even leading dimensions: the launcher)
+    return KC > 0 && KC % TND_STEP == 0 && ldx % 2 == 0 && ldy % 2 == 0 && (int64_t)(KC + 16) * ldx < (1ll << 29) && (int64_t)(KC + 16) * ldy < (1ll << 29);
 }
 
 // X [R, M] (ldx), Y [R, N] (ldy), chunks of KC rows (multiple of 16) -> S partial results C + z zs_c (ldc); maxima as in train.hip

@@ -890,7 +890,7 @@ int gvqa_linear_tn_split2h(int64_t R, int64_t M, int64_t N, const float* X, int6
     }
     float* dst = p.S == 1 ? C : part;
     int rc;
-    if (get_option(GVQA_OPT_TN_DIRECT) && linear_tn_direct_applies(p.KC, ldx, ldy)) {
+    if (get_option(GVQA_OPT_TN_DIRECT) && linear_tn_direct_applies(p.KC, ldx, ldy) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 7) == 0) {
         rc = launch_linear_tn_direct(R, M, N, X, ldx, Y, ldy, x_absmax, x_absmax_n, y_absmax, y_absmax_n, p.KC, p.S, dst, p.S == 1 ? ldc : N, M * N, st);
     } else {
         const unsigned slabs = (unsigned)((int64_t)p.S * p.KC / TN_SLAB_ROWS);
@@ -1014,7 +1014,8 @@ int gvqa_linear_backward_split2h_ex(int64_t R, int64_t M, int64_t K, const float
     const dim3 gdy(slabs, (unsigned)cdiv(M, TN_SLAB_COLS));
     // GVQA_OPT_TN_DIRECT: both products read dy (and x) as they are -- dW transposes on the way into its fragment image, dx converts its rows
     // of dy in the kernel (tn_direct.hip) -- and dy is not packed at all
-    const bool direct = get_option(GVQA_OPT_TN_DIRECT) != 0 && linear_tn_direct_applies(p.tn.KC, ld_dy, dW ? ldx : 4);
+    const bool direct = get_option(GVQA_OPT_TN_DIRECT) != 0 && linear_tn_direct_applies(p.tn.KC, ld_dy, dW ? ldx : 4) &&
+                        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dW ? x : nullptr)) & 7) == 0;
     const bool direct_dx = dx && get_option(GVQA_OPT_TN_DIRECT) != 0 && M % 16 == 0 && linear_nn_direct_applies(R, K, M, ld_dy) &&
                            ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dx_addend)) & 15) == 0 &&
                            ld_dx % 4 == 0 && ld_addend % 4 == 0;
