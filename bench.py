@@ -275,6 +275,40 @@ def extra_configs(torch, np, synth, _lib, lib, dev, with_cpu=True):
                                   "max_abs_dev_vs_oracle_bf16_node_features": float((outs["bf16_node_features"].cpu() - r[1]).abs().max()),
                                   "oracle_output_max_abs": float(r[1].abs().max())}
         res["config5_lcgn"] = c5
+        del g, x, ea, ins, ei, batch
+        torch.cuda.empty_cache()
+
+        # ---- one training step of gat_seq (forward + backward + SGD, dropout 0.1, loss = mean square of the output) at config 3
+        #      and config 2 sizes, wall clock; the reference's loop: mainExplain_gat.py:538-552
+        tr = {"workload": "gat_seq training step: forward + loss.backward() + SGD step, dropout 0.1, synthetic batch", "unit": "ms per step"}
+        for name, gbt, dd in (("config3", synth.config3_batch(), 512), ("config2", gb, 300)):
+            Nt, Et, Bt = gbt.num_nodes, gbt.num_edges, gbt.num_graphs
+            mt = gat_seq(dd, dd, dd, 512, 5, dropout=0.1, gat_heads=4)
+            mt.load_state_dict({k: tt(v) for k, v in synth.gat_seq_params(dd, dd, dd, 512, 5, 4, seed=777).items()})
+            mt = mt.to(dev).train()
+            xt, et, it = tt(synth.normal((Nt, dd), 1)).to(dev), tt(synth.normal((Et, dd), 2)).to(dev), tt(synth.normal((5, Bt, 512), 3)).to(dev)
+            eit, bt = tt(gbt.edge_index).to(dev), tt(gbt.batch).to(dev)
+            gt = SceneGraphBatch(eit, bt, Nt, Bt); gt.transposed()
+            opt = torch.optim.SGD(mt.parameters(), lr=1e-3)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                mt(xt, eit, et, it, bt, graph=gt).square().mean().backward()
+                opt.step()
+            with torch.enable_grad():
+                for _ in range(3):
+                    step()
+                best = None
+                for _ in range(2):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(5):
+                        step()
+                    torch.cuda.synchronize(); t1 = (time.perf_counter() - t0) / 5
+                    best = t1 if best is None else min(best, t1)
+            tr[name] = {"ms": best * 1e3, "edges_per_s": Et / best, "nodes": Nt, "edges": Et, "graphs": Bt}
+            del mt, opt, xt, et, it, eit, bt, gt
+            torch.cuda.empty_cache()
+        res["training_step"] = tr
     except Exception as e:             # the headline line must still come out
         res["error"] = repr(e)[:300]
     res["seconds"] = round(time.perf_counter() - t_begin, 1)
