@@ -22,6 +22,10 @@ for h in 1 4; do HOP=$h python scripts/probe_hop2.py 2>/dev/null | head -2; done
 python scripts/probe_hop2_loop.py 2>/dev/null | grep workgroups_per_cu > $O/hop2_loop_parts.jsonl
 python scripts/bench_train.py 2>/dev/null | tail -1 > $O/train_cfg3.json
 python scripts/bench_skinny.py 2>/dev/null | grep "^{" > $O/train_products.jsonl
+CONFIG=2 TRAIN_ONLY=1 python scripts/bench_train.py 2>/dev/null | tail -1 > $O/train_cfg2.json
+python scripts/bench_tn.py 2>/dev/null | grep "^{" > $O/train_tn_direct.jsonl            # the projection's gradient products, direct vs packed operands
+bash scripts/ab_train_parts.sh 2>/dev/null > $O/train_parts_ab.txt                         # the training step with each round-5 change switched off
+python scripts/prof_train_ops.py 2>/dev/null | grep -v Warning | tail -34 > $O/train_aten_ops.txt   # what torch still runs inside the step
 ( cd /tmp && TRAIN_ONLY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/tprof -o ks -- python $GRAFT_REPO_ROOT/scripts/bench_train.py > /dev/null 2>&1 )
 cp $(find $O/tprof -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv 2>/dev/null
 # SQ counters of the hop kernels (separate --pmc passes, kernel trace only)
