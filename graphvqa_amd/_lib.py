@@ -234,6 +234,12 @@ PROTOTYPES = {
                                               C.c_void_p]),
     "gvqa_bn_relu_dropout_train_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_bn_relu_dropout_train_forward_rng": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint64, C.c_uint64,
+                                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gvqa_bn_relu_dropout_train_backward_rng": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                                          C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                          C.c_size_t, C.c_void_p]),
+    "gvqa_dropout_keep_mask": (C.c_int, [C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
     "gvqa_bn_relu_dropout_train_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -60,6 +60,30 @@ __global__ __launch_bounds__(1024) void k_bn_col_finish(int nblocks, int C, cons
     }
 }
 
+// Feature-dropout decisions made in the kernels (Philox4x32-10, the counter-based generator torch's own CUDA dropout uses): the quad of 4
+// consecutive channels at element index 4 q gets counter (q, offset), key = seed; an element is kept when its 32-bit draw is below
+// `thresh` = (1 - p) 2^32.  Forward and both backward passes regenerate the same decisions: no [N, C] mask exists in HBM.
+struct KeepRng { unsigned long long seed, offset; unsigned thresh; int on; };
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ uchar4 rng_keep4(const KeepRng& g, int64_t quad) {
+    const uint4 d = philox4x32_10(make_uint4((unsigned)quad, (unsigned)((unsigned long long)quad >> 32), (unsigned)g.offset, (unsigned)(g.offset >> 32)),
+                                  make_uint2((unsigned)g.seed, (unsigned)(g.seed >> 32)));
+    return make_uchar4(d.x < g.thresh, d.y < g.thresh, d.z < g.thresh, d.w < g.thresh);
+}
+__global__ __launch_bounds__(256) void k_rng_keep_mask(int64_t quads, KeepRng g, uint8_t* __restrict__ out) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256)
+        *reinterpret_cast<uchar4*>(out + 4 * q) = rng_keep4(g, q);
+}
+
 __global__ __launch_bounds__(256) void k_bn_relu_apply(int64_t total, int C, const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const float* __restrict__ w,
                                                        const float* __restrict__ b, float eps, float* __restrict__ y,
@@ -77,7 +101,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply(int64_t total, int C, con
 __global__ __launch_bounds__(256) void k_bn_relu_apply_v4(int64_t N, int C, int TPR, const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ var, const float* __restrict__ w,
                                                           const float* __restrict__ b, float eps, float* __restrict__ y,
-                                                          const uint8_t* __restrict__ keep, float kscale) {
+                                                          const uint8_t* __restrict__ keep, float kscale, KeepRng rng) {
     const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
     for (int c4 = tcol; c4 < (C >> 2); c4 += TPR) {
         const int c = c4 * 4;
@@ -89,8 +113,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_apply_v4(int64_t N, int C, int 
             // (x - mean) * invstd * w + b, in the scalar kernel's operation order
             float4 o = make_float4(fmaxf((xv.x - m.x) * is.x * wc.x + bc.x, 0.f), fmaxf((xv.y - m.y) * is.y * wc.y + bc.y, 0.f),
                                    fmaxf((xv.z - m.z) * is.z * wc.z + bc.z, 0.f), fmaxf((xv.w - m.w) * is.w * wc.w + bc.w, 0.f));
-            if (keep) {
-                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + r * C + c);
+            if (keep || rng.on) {
+                const uchar4 k4 = rng.on ? rng_keep4(rng, (r * C + c) >> 2) : *reinterpret_cast<const uchar4*>(keep + r * C + c);
                 o.x = k4.x ? o.x * kscale : 0.f; o.y = k4.y ? o.y * kscale : 0.f; o.z = k4.z ? o.z * kscale : 0.f; o.w = k4.w ? o.w * kscale : 0.f;
             }
             *reinterpret_cast<float4*>(y + r * C + c) = o;
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply(int64_t total, int C,
 __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce_v4(int64_t N, int C, int TPR, const float* __restrict__ x, const float* __restrict__ dy,
                                                                const float* __restrict__ mean, const float* __restrict__ var,
                                                                const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                               float* __restrict__ partial, const uint8_t* __restrict__ keep, float kscale) {
+                                                               float* __restrict__ partial, const uint8_t* __restrict__ keep, float kscale, KeepRng rng) {
     __shared__ float4 red[2][256];
     const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
     const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
@@ -154,8 +178,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_reduce_v4(int64_t N, int C,
         for (int64_t r = r0 + trow; on && r < r1; r += RPB) {
             const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
             float4 gv = *reinterpret_cast<const float4*>(dy + r * C + c);
-            if (keep) {
-                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + r * C + c);
+            if (keep || rng.on) {
+                const uchar4 k4 = rng.on ? rng_keep4(rng, (r * C + c) >> 2) : *reinterpret_cast<const uchar4*>(keep + r * C + c);
                 gv.x = k4.x ? gv.x * kscale : 0.f; gv.y = k4.y ? gv.y * kscale : 0.f; gv.z = k4.z ? gv.z * kscale : 0.f; gv.w = k4.w ? gv.w * kscale : 0.f;
             }
             const float4 xh = make_float4((xv.x - m.x) * is.x, (xv.y - m.y) * is.y, (xv.z - m.z) * is.z, (xv.w - m.w) * is.w);
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply_v4(int64_t N, int C, 
                                                               const float* __restrict__ var, const float* __restrict__ w,
                                                               const float* __restrict__ b, float eps, const float* __restrict__ dbias,
                                                               const float* __restrict__ dweight, float* __restrict__ dx,
-                                                              const uint8_t* __restrict__ keep, float kscale) {
+                                                              const uint8_t* __restrict__ keep, float kscale, KeepRng rng) {
     const int tcol = threadIdx.x & (TPR - 1), trow = threadIdx.x / TPR, RPB = 256 / TPR;
     for (int c4 = tcol; c4 < (C >> 2); c4 += TPR) {
         const int c = c4 * 4;
@@ -201,8 +225,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_apply_v4(int64_t N, int C, 
         for (int64_t r = (int64_t)blockIdx.x * RPB + trow; r < N; r += (int64_t)gridDim.x * RPB) {
             const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
             float4 gv = *reinterpret_cast<const float4*>(dy + r * C + c);
-            if (keep) {
-                const uchar4 k4 = *reinterpret_cast<const uchar4*>(keep + r * C + c);
+            if (keep || rng.on) {
+                const uchar4 k4 = rng.on ? rng_keep4(rng, (r * C + c) >> 2) : *reinterpret_cast<const uchar4*>(keep + r * C + c);
                 gv.x = k4.x ? gv.x * kscale : 0.f; gv.y = k4.y ? gv.y * kscale : 0.f; gv.z = k4.z ? gv.z * kscale : 0.f; gv.w = k4.w ? gv.w * kscale : 0.f;
             }
             *reinterpret_cast<float4*>(dx + r * C + c) =
@@ -225,9 +249,70 @@ extern "C" int gvqa_bn_relu_train_forward(int64_t N, int32_t C, const float* x, 
     return gvqa_bn_relu_dropout_train_forward(N, C, x, weight, bias, eps, nullptr, 1.0f, y, save_mean, save_var, ws, ws_bytes, stream_);
 }
 
+namespace gvqa {
+namespace {
+KeepRng keep_rng_of(uint64_t seed, uint64_t offset, float p) {
+    KeepRng g;
+    g.seed = seed; g.offset = offset; g.on = 1;
+    const double keep = 1.0 - (double)p;
+    g.thresh = keep >= 1.0 ? 0xFFFFFFFFu : (unsigned)(keep * 4294967296.0);
+    return g;
+}
+const KeepRng kNoRng{0, 0, 0, 0};
+}  // namespace
+}  // namespace gvqa
+
+static int bn_relu_dropout_train_forward_impl(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                              const uint8_t* keep, float keep_scale, gvqa::KeepRng rng, float* y, float* save_mean, float* save_var,
+                                              void* ws, size_t ws_bytes, void* stream_);
+static int bn_relu_dropout_train_backward_impl(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, const float* save_mean,
+                                               const float* save_var, float eps, const uint8_t* keep, float keep_scale, gvqa::KeepRng rng, const float* dy,
+                                               float* dx, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream_);
+
 extern "C" int gvqa_bn_relu_dropout_train_forward(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
                                                   const uint8_t* keep, float keep_scale, float* y, float* save_mean, float* save_var,
                                                   void* ws, size_t ws_bytes, void* stream_) {
+    return bn_relu_dropout_train_forward_impl(N, C, x, weight, bias, eps, keep, keep_scale, gvqa::kNoRng, y, save_mean, save_var, ws, ws_bytes, stream_);
+}
+
+// the same with the keep decisions drawn in the kernels (p in [0, 1): y = relu(bn(x)) * (kept ? 1 / (1 - p) : 0)); C % 4 == 0, 16-byte aligned rows
+extern "C" int gvqa_bn_relu_dropout_train_forward_rng(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                                      uint64_t seed, uint64_t offset, float p, float* y, float* save_mean, float* save_var, void* ws,
+                                                      size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(p >= 0.f && p < 1.f, GVQA_E_INVALID, "bn_relu_dropout_train_forward_rng: p in [0, 1)");
+    GVQA_REQUIRE(C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, GVQA_E_UNSUPPORTED,
+                 "bn_relu_dropout_train_forward_rng: C %% 4 == 0 and 16-byte aligned rows (explicit masks otherwise)");
+    return bn_relu_dropout_train_forward_impl(N, C, x, weight, bias, eps, nullptr, 1.0f / (1.0f - p), gvqa::keep_rng_of(seed, offset, p), y, save_mean,
+                                              save_var, ws, ws_bytes, stream_);
+}
+
+extern "C" int gvqa_bn_relu_dropout_train_backward_rng(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+                                                       const float* save_mean, const float* save_var, float eps, uint64_t seed, uint64_t offset, float p,
+                                                       const float* dy, float* dx, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream_) {
+    GVQA_REQUIRE(p >= 0.f && p < 1.f, GVQA_E_INVALID, "bn_relu_dropout_train_backward_rng: p in [0, 1)");
+    GVQA_REQUIRE(C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+                 GVQA_E_UNSUPPORTED, "bn_relu_dropout_train_backward_rng: C %% 4 == 0 and 16-byte aligned rows (explicit masks otherwise)");
+    return bn_relu_dropout_train_backward_impl(N, C, x, weight, bias, save_mean, save_var, eps, nullptr, 1.0f / (1.0f - p),
+                                               gvqa::keep_rng_of(seed, offset, p), dy, dx, dweight, dbias, ws, ws_bytes, stream_);
+}
+
+// the keep decisions of the two _rng entry points as a byte mask [N, C] (tests / reproducing a run's masks); C % 4 == 0
+extern "C" int gvqa_dropout_keep_mask(int64_t N, int32_t C, uint64_t seed, uint64_t offset, float p, uint8_t* keep, void* stream_) {
+    using namespace gvqa;
+    GVQA_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && p >= 0.f && p < 1.f && (reinterpret_cast<uintptr_t>(keep) & 3) == 0, GVQA_E_INVALID,
+                 "dropout_keep_mask: C %% 4 == 0, p in [0, 1), 4-byte aligned mask");
+    if (N == 0) return GVQA_OK;
+    GVQA_REQUIRE(keep, GVQA_E_INVALID, "dropout_keep_mask: null mask");
+    const int64_t quads = N * C / 4;
+    hipLaunchKernelGGL(k_rng_keep_mask, dim3((unsigned)std::min<int64_t>(cdiv(quads, 256), 8192)), dim3(256), 0, static_cast<hipStream_t>(stream_), quads,
+                       keep_rng_of(seed, offset, p), keep);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+static int bn_relu_dropout_train_forward_impl(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                              const uint8_t* keep, float keep_scale, gvqa::KeepRng rng, float* y, float* save_mean, float* save_var,
+                                              void* ws, size_t ws_bytes, void* stream_) {
     using namespace gvqa;
     GVQA_REQUIRE(N >= 0 && C > 0, GVQA_E_INVALID, "bn_relu_train_forward: bad sizes");
     if (N == 0) return GVQA_OK;
@@ -246,8 +331,9 @@ extern "C" int gvqa_bn_relu_dropout_train_forward(int64_t N, int32_t C, const fl
     const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     int TPR = 1;
     while (TPR < 256 && TPR < C / 4) TPR <<= 1;
+    GVQA_REQUIRE(!rng.on || v4, GVQA_E_UNSUPPORTED, "bn_relu_dropout_train: in-kernel masks need the 16-byte form");
     if (v4) hipLaunchKernelGGL(k_bn_relu_apply_v4, dim3((unsigned)std::min<int64_t>(cdiv(N, 256 / TPR), 4096)), dim3(256), 0, stream, N, (int)C, TPR, x,
-                               save_mean, save_var, weight, bias, eps, y, keep, keep_scale);
+                               save_mean, save_var, weight, bias, eps, y, keep, keep_scale, rng);
     else hipLaunchKernelGGL(k_bn_relu_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, x, save_mean, save_var, weight, bias,
                             eps, y, keep, keep_scale);
     GVQA_LAUNCH_CHECK();
@@ -265,6 +351,13 @@ extern "C" int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const f
                                                    const float* save_mean, const float* save_var, float eps, const uint8_t* keep,
                                                    float keep_scale, const float* dy, float* dx, float* dweight, float* dbias, void* ws,
                                                    size_t ws_bytes, void* stream_) {
+    return bn_relu_dropout_train_backward_impl(N, C, x, weight, bias, save_mean, save_var, eps, keep, keep_scale, gvqa::kNoRng, dy, dx, dweight, dbias, ws,
+                                               ws_bytes, stream_);
+}
+
+static int bn_relu_dropout_train_backward_impl(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, const float* save_mean,
+                                               const float* save_var, float eps, const uint8_t* keep, float keep_scale, gvqa::KeepRng rng, const float* dy,
+                                               float* dx, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream_) {
     using namespace gvqa;
     GVQA_REQUIRE(N >= 0 && C > 0, GVQA_E_INVALID, "bn_relu_train_backward: bad sizes");
     if (N == 0) return GVQA_OK;
@@ -281,15 +374,16 @@ extern "C" int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const f
                     (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     int TPR = 1;
     while (TPR < 256 && TPR < C / 4) TPR <<= 1;
+    GVQA_REQUIRE(!rng.on || v4, GVQA_E_UNSUPPORTED, "bn_relu_dropout_train: in-kernel masks need the 16-byte form");
     if (v4) hipLaunchKernelGGL(k_bn_relu_bwd_reduce_v4, dim3((unsigned)nb), dim3(256), 0, stream, N, (int)C, TPR, x, dy, save_mean, save_var, weight,
-                               bias, eps, partial, keep, keep_scale);
+                               bias, eps, partial, keep, keep_scale, rng);
     else hipLaunchKernelGGL(k_bn_relu_bwd_reduce, grid, dim3(256), 0, stream, N, (int)C, x, dy, save_mean, save_var, weight, bias, eps, partial, keep,
                             keep_scale);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f, dbias);
     hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial + C, (int64_t)2 * C, 1.0f, dweight);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
     if (v4) hipLaunchKernelGGL(k_bn_relu_bwd_apply_v4, dim3((unsigned)std::min<int64_t>(cdiv(N, 256 / TPR), 4096)), dim3(256), 0, stream, N, (int)C,
-                               TPR, 1.0f / (float)N, x, dy, save_mean, save_var, weight, bias, eps, dbias, dweight, dx, keep, keep_scale);
+                               TPR, 1.0f / (float)N, x, dy, save_mean, save_var, weight, bias, eps, dbias, dweight, dx, keep, keep_scale, rng);
     else hipLaunchKernelGGL(k_bn_relu_bwd_apply, dim3((unsigned)blocks), dim3(256), 0, stream, N * C, (int)C, 1.0f / (float)N, x, dy, save_mean,
                             save_var, weight, bias, eps, dbias, dweight, dx, keep, keep_scale);
     GVQA_LAUNCH_CHECK();

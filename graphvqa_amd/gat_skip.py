@@ -33,6 +33,7 @@ from .graph import SceneGraphBatch, _stream, _ptr
 
 # A/B switch of the training path's round-5 fusions (scripts/ab_train_parts.sh; measurement only, 0 = everything on): bit 1 no |h| maxima from
 # the operand pack, 2 the skip's gradient through autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel;
+# bit 32: feature-dropout masks as torch bernoulli_ tensors instead of in-kernel Philox draws;
 # bit 16 switches ON the (slower, kept for the record) form that adds the logit products' input gradient in the dx product's epilogue
 _TRAIN_AB = int(os.environ.get("GVQA_TRAIN_AB", "0") or 0)
 
@@ -628,10 +629,23 @@ class _BatchNormReluTrain(torch.autograd.Function):
     y = relu(bn(x)) * (keep ? keep_scale : 0) -- the mask is drawn by the caller with torch's generator."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, keep=None, keep_scale=1.0):
+    def forward(ctx, x, weight, bias, eps, keep=None, keep_scale=1.0, rng=None):
+        """rng = (seed, offset, p): the keep decisions are drawn inside the kernels (gvqa_bn_relu_dropout_train_*_rng) -- no mask tensor."""
         lib = _lib.load()
         x, weight, bias = _f32c(x, "x"), _f32c(weight, "bn.weight"), _f32c(bias, "bn.bias")
         N, Cc = x.shape
+        ctx.rng = rng
+        if rng is not None:
+            y, mean, var = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
+            with torch.cuda.device(x.device):
+                ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
+                _lib.check(lib.gvqa_bn_relu_dropout_train_forward_rng(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps, rng[0], rng[1],
+                                                                      float(rng[2]), y.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(),
+                                                                      ws.numel(), _stream(x.device)))
+            ctx.save_for_backward(x, weight, bias, mean, var, None)
+            ctx.eps, ctx.keep_scale = eps, 1.0
+            ctx.mark_non_differentiable(mean, var)
+            return y, mean, var
         if keep is not None and (keep.dtype != torch.uint8 or keep.shape != x.shape or not keep.is_contiguous() or keep.device != x.device):
             raise ValueError("bn_relu_train: keep must be a contiguous uint8 [N, C] tensor on x's device")
         y, mean, var = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(weight)
@@ -652,12 +666,20 @@ class _BatchNormReluTrain(torch.autograd.Function):
         N, Cc = x.shape
         dy = dy.contiguous()
         dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(bias)
+        if ctx.rng is not None:
+            with torch.cuda.device(x.device):
+                ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
+                _lib.check(lib.gvqa_bn_relu_dropout_train_backward_rng(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
+                                                                       var.data_ptr(), ctx.eps, ctx.rng[0], ctx.rng[1], float(ctx.rng[2]), dy.data_ptr(),
+                                                                       dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                                       _stream(x.device)))
+            return dx, dw, db, None, None, None, None
         with torch.cuda.device(x.device):
             ws = _workspace(lib.gvqa_bn_train_workspace_bytes(N, Cc), x.device)
             _lib.check(lib.gvqa_bn_relu_dropout_train_backward(N, Cc, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), mean.data_ptr(),
                                                                var.data_ptr(), ctx.eps, _ptr(keep), ctx.keep_scale, dy.data_ptr(), dx.data_ptr(),
                                                                dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x.device)))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor, p: float = 0.0) -> Tensor:
@@ -667,8 +689,18 @@ def _bn_relu_train(bn: torch.nn.BatchNorm1d, x: Tensor, p: float = 0.0) -> Tenso
     if bn.weight is None or bn.bias is None or x.shape[0] < 2 or p >= 1.0:
         # (p = 1: F.dropout returns zeros -- gat_skip.py:276 -- and BatchNorm still updates its running statistics)
         return torch.nn.functional.dropout(torch.relu(bn(x)), p=p, training=p > 0)
-    keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p) if p > 0 else None
-    y, mean, var = _BatchNormReluTrain.apply(x, bn.weight, bn.bias, bn.eps, keep, 1.0 / (1.0 - p) if p > 0 else 1.0)
+    rng = keep = None
+    if p > 0 and x.is_cuda and x.shape[1] % 4 == 0 and x.data_ptr() % 16 == 0 and x.is_contiguous() and not (_TRAIN_AB & 32):
+        # the decisions are drawn in the kernels (Philox, keyed on torch's CUDA generator: reproducible from torch.manual_seed) -- the counters this
+        # call uses are reserved on the generator, as torch's own dropout does
+        gen = torch.cuda.default_generators[x.device.index if x.device.index is not None else torch.cuda.current_device()]
+        if hasattr(gen, "get_offset") and hasattr(gen, "set_offset"):
+            off = gen.get_offset()
+            gen.set_offset(off + 4 * ((x.numel() // 4 + 3) // 4))
+            rng = (gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off, p)
+    if p > 0 and rng is None:
+        keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p)
+    y, mean, var = _BatchNormReluTrain.apply(x, bn.weight, bn.bias, bn.eps, keep, 1.0 / (1.0 - p) if p > 0 else 1.0, rng)
     if bn.track_running_stats and bn.running_mean is not None:
         with torch.no_grad():
             bn.num_batches_tracked += 1

@@ -248,6 +248,19 @@ GVQA_API int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const flo
                                         const float* save_mean, const float* save_var, float eps, const uint8_t* keep,
                                         float keep_scale, const float* dy, float* dx, float* dweight, float* dbias, void* ws,
                                         size_t ws_bytes, void* stream);
+/* The same with the keep decisions DRAWN IN THE KERNELS (F.dropout of gat_skip.py:276 without a mask tensor): Philox4x32-10, counter = (index of
+ * the quad of 4 consecutive channels, offset), key = seed -- the caller takes (seed, offset) from its generator (torch: initial_seed() /
+ * get_offset(), then set_offset() past the N*C/4 counters used) so that runs are reproducible from torch.manual_seed; an element is kept when its
+ * 32-bit draw is below (1 - p) 2^32 and scaled by 1 / (1 - p).  The backward regenerates the forward's decisions from the same (seed, offset, p).
+ * C % 4 == 0 and 16-byte aligned rows (GVQA_E_UNSUPPORTED otherwise: use the explicit-mask forms).  gvqa_dropout_keep_mask writes the decisions
+ * as a byte mask [N, C] (tests; reproducing a run's masks). */
+GVQA_API int gvqa_bn_relu_dropout_train_forward_rng(int64_t N, int32_t C, const float* x, const float* weight, const float* bias, float eps,
+                                                    uint64_t seed, uint64_t offset, float p, float* y, float* save_mean, float* save_var, void* ws,
+                                                    size_t ws_bytes, void* stream);
+GVQA_API int gvqa_bn_relu_dropout_train_backward_rng(int64_t N, int32_t C, const float* x, const float* weight, const float* bias,
+                                                     const float* save_mean, const float* save_var, float eps, uint64_t seed, uint64_t offset, float p,
+                                                     const float* dy, float* dx, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
+GVQA_API int gvqa_dropout_keep_mask(int64_t N, int32_t C, uint64_t seed, uint64_t offset, float p, uint8_t* keep, void* stream);
 
 /* Per-graph rows <-> node rows (glue of the differentiable path: the per-graph instruction terms).
  * rows_to_nodes: out[i, :F] (= or +=) rows[graph(i), :F];  segment_sum (its adjoint): out[b, :F] = sum of x[i, :F]

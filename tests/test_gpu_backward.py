@@ -843,6 +843,60 @@ def test_projection_backward_in_one_call_vs_fp64(dev, R, M, K, ldw, which, direc
         assert float((acc - (add + dx)).abs().max()) <= 1e-6 * max(float(dx.abs().max()), 1.0)
 
 
+def test_in_kernel_dropout_draws_equal_their_explicit_mask(dev):
+    """gvqa_bn_relu_dropout_train_*_rng (feature dropout of gat_skip.py:276 drawn inside the BatchNorm passes, Philox keyed on (seed, offset)):
+    forward and backward equal, bit for bit, the explicit-mask entry points fed with gvqa_dropout_keep_mask's bytes; the kept fraction is 1 - p;
+    the same (seed, offset) reproduces, another offset does not; and the module path reserves its counters on torch's generator, so
+    torch.manual_seed reproduces a training forward."""
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    N, Cc, p, seed, off = 3001, 300, 0.1, 0x1234567890ABCDEF, 4096
+    x, dy = torch.randn((N, Cc), generator=g).to(dev), torch.randn((N, Cc), generator=g).to(dev)
+    w, b = (torch.rand(Cc, generator=g) + 0.5).to(dev), torch.randn(Cc, generator=g).to(dev)
+    keep = torch.empty((N, Cc), dtype=torch.uint8, device=dev)
+    _lib.check(lib.gvqa_dropout_keep_mask(N, Cc, seed, off, p, keep.data_ptr(), st))
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 4e-3 and set(keep.unique().tolist()) <= {0, 1}
+    keep2 = torch.empty_like(keep)
+    _lib.check(lib.gvqa_dropout_keep_mask(N, Cc, seed, off, p, keep2.data_ptr(), st))
+    assert torch.equal(keep, keep2)
+    _lib.check(lib.gvqa_dropout_keep_mask(N, Cc, seed, off + 4, p, keep2.data_ptr(), st))
+    assert not torch.equal(keep, keep2)
+    ws = torch.empty(lib.gvqa_bn_train_workspace_bytes(N, Cc), dtype=torch.uint8, device=dev)
+    outs = []
+    for rng in (True, False):
+        y, mean, var = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        if rng:
+            _lib.check(lib.gvqa_bn_relu_dropout_train_forward_rng(N, Cc, x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, seed, off, p, y.data_ptr(),
+                                                                  mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            _lib.check(lib.gvqa_bn_relu_dropout_train_backward_rng(N, Cc, x.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(), 1e-5,
+                                                                   seed, off, p, dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                                   ws.data_ptr(), ws.numel(), st))
+        else:
+            ks = 1.0 / (1.0 - p)
+            _lib.check(lib.gvqa_bn_relu_dropout_train_forward(N, Cc, x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, keep.data_ptr(), ks, y.data_ptr(),
+                                                              mean.data_ptr(), var.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            _lib.check(lib.gvqa_bn_relu_dropout_train_backward(N, Cc, x.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(), 1e-5,
+                                                               keep.data_ptr(), ks, dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                               ws.data_ptr(), ws.numel(), st))
+        outs.append((y, dx, dw, db))
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a, c)
+    assert float((outs[0][0] == 0).float().mean()) > p * 0.9          # (dropped or clipped by the ReLU)
+    # module path: the generator's counters are reserved, the seed reproduces
+    from graphvqa_amd.gat_skip import _bn_relu_train
+    bn = torch.nn.BatchNorm1d(Cc).to(dev).train()
+    xm = x[:3000].contiguous()
+    torch.manual_seed(77); o0 = torch.cuda.default_generators[dev.index or 0].get_offset(); y1 = _bn_relu_train(bn, xm, p)
+    assert torch.cuda.default_generators[dev.index or 0].get_offset() > o0
+    y2 = _bn_relu_train(bn, xm, p)
+    torch.manual_seed(77); y3 = _bn_relu_train(bn, xm, p)
+    assert torch.equal(y1, y3) and not torch.equal(y1, y2)
+
+
 def test_operand_pack_leaves_slice_maxima_and_the_backward_takes_them(dev):
     """gvqa_split2h_pack_absmax: the packed operand is the one gvqa_split2h_pack writes and the slice maxima's maximum is max|x| exactly;
     gvqa_linear_backward_split2h_hint fed with them returns the same dW, bit for bit, as the call that measures x itself."""
