@@ -240,6 +240,7 @@ PROTOTYPES = {
                                                           C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                           C.c_size_t, C.c_void_p]),
     "gvqa_dropout_keep_mask": (C.c_int, [C.c_int64, C.c_int32, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
+    "gvqa_dropout_scale_mask": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
     "gvqa_bn_relu_dropout_train_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_size_t, C.c_void_p]),

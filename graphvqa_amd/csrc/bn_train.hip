@@ -79,6 +79,12 @@ __device__ __forceinline__ uchar4 rng_keep4(const KeepRng& g, int64_t quad) {
                                   make_uint2((unsigned)g.seed, (unsigned)(g.seed >> 32)));
     return make_uchar4(d.x < g.thresh, d.y < g.thresh, d.z < g.thresh, d.w < g.thresh);
 }
+__global__ __launch_bounds__(256) void k_rng_scale_mask(int64_t quads, KeepRng g, float kscale, float* __restrict__ out) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const uchar4 k = rng_keep4(g, q);
+        *reinterpret_cast<float4*>(out + 4 * q) = make_float4(k.x ? kscale : 0.f, k.y ? kscale : 0.f, k.z ? kscale : 0.f, k.w ? kscale : 0.f);
+    }
+}
 __global__ __launch_bounds__(256) void k_rng_keep_mask(int64_t quads, KeepRng g, uint8_t* __restrict__ out) {
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256)
         *reinterpret_cast<uchar4*>(out + 4 * q) = rng_keep4(g, q);
@@ -306,6 +312,20 @@ extern "C" int gvqa_dropout_keep_mask(int64_t N, int32_t C, uint64_t seed, uint6
     const int64_t quads = N * C / 4;
     hipLaunchKernelGGL(k_rng_keep_mask, dim3((unsigned)std::min<int64_t>(cdiv(quads, 256), 8192)), dim3(256), 0, static_cast<hipStream_t>(stream_), quads,
                        keep_rng_of(seed, offset, p), keep);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
+// mask[i] = kept ? 1 / (1 - p) : 0 for n floats (n % 4 == 0): the multiplicative mask of F.dropout on the attention coefficients
+// (gat_skip.py:205; gvqa_gat_mp_desc.alpha_mask), one launch instead of torch's fill + bernoulli + div
+extern "C" int gvqa_dropout_scale_mask(int64_t n, uint64_t seed, uint64_t offset, float p, float* mask, void* stream_) {
+    using namespace gvqa;
+    GVQA_REQUIRE(n >= 0 && n % 4 == 0 && p >= 0.f && p < 1.f && (reinterpret_cast<uintptr_t>(mask) & 15) == 0, GVQA_E_INVALID,
+                 "dropout_scale_mask: n %% 4 == 0, p in [0, 1), 16-byte aligned mask");
+    if (n == 0) return GVQA_OK;
+    GVQA_REQUIRE(mask, GVQA_E_INVALID, "dropout_scale_mask: null mask");
+    hipLaunchKernelGGL(k_rng_scale_mask, dim3((unsigned)std::min<int64_t>(cdiv(n / 4, 256), 8192)), dim3(256), 0, static_cast<hipStream_t>(stream_), n / 4,
+                       keep_rng_of(seed, offset, p), 1.0f / (1.0f - p), mask);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }

@@ -230,6 +230,21 @@ def _absmax_hint(gy: Tensor):
     return am if (gy.data_ptr() == ptr and gy._version == version) else None
 
 
+def _attention_dropout_mask(E: int, H: int, p: float, device) -> Tensor:
+    """mask / (1 - p) of F.dropout(alpha) (gat_skip.py:205) as one library launch keyed on torch's CUDA generator (counters reserved there), or
+    torch's own three kernels where that does not apply."""
+    n = E * H
+    gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()] if device.type == "cuda" else None
+    if gen is None or n % 4 != 0 or n == 0 or not hasattr(gen, "get_offset") or (_TRAIN_AB & 32):
+        return torch.bernoulli(torch.full((E, H), 1.0 - p, device=device)) / (1.0 - p)
+    off = gen.get_offset()
+    gen.set_offset(off + 4 * ((n // 4 + 3) // 4))
+    mask = torch.empty((E, H), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().gvqa_dropout_scale_mask(n, gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off, float(p), mask.data_ptr(), _stream(device)))
+    return mask
+
+
 class _ColumnBlocks(torch.autograd.Function):
     """[R, K*W] -> K column blocks [R, W] as views (no copies); the backward writes the K gradients into ONE [R, K*W] tensor -- K strided copies
     instead of autograd's K zero-filled full-size tensors, K slice copies and K - 1 full-size adds."""
@@ -1272,7 +1287,7 @@ class gat_seq(torch.nn.Module):
             if alpha_masks is not None:
                 mask = alpha_masks[i]
             elif p > 0:
-                mask = torch.bernoulli(torch.full((E, H), 1.0 - p, device=x.device)) / (1.0 - p)
+                mask = _attention_dropout_mask(E, H, p, x.device)
             # aggregation + head mean (:155-165) + bias (:167-168) + skip (:270) in one op
             # (per-graph rows stay out of xp when every edge stays inside its graph -- any batch the reference's collate makes;
             # with cross-graph edges a message carries the SOURCE graph's row and the sum is formed)

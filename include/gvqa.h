@@ -261,6 +261,9 @@ GVQA_API int gvqa_bn_relu_dropout_train_backward_rng(int64_t N, int32_t C, const
                                                      const float* save_mean, const float* save_var, float eps, uint64_t seed, uint64_t offset, float p,
                                                      const float* dy, float* dx, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
 GVQA_API int gvqa_dropout_keep_mask(int64_t N, int32_t C, uint64_t seed, uint64_t offset, float p, uint8_t* keep, void* stream);
+/* mask[i] = kept ? 1 / (1 - p) : 0 for n floats (n % 4 == 0), the same generator: the multiplicative mask of F.dropout on the attention
+ * coefficients (gat_skip.py:205) that gvqa_gat_mp_desc.alpha_mask takes. */
+GVQA_API int gvqa_dropout_scale_mask(int64_t n, uint64_t seed, uint64_t offset, float p, float* mask, void* stream);
 
 /* Per-graph rows <-> node rows (glue of the differentiable path: the per-graph instruction terms).
  * rows_to_nodes: out[i, :F] (= or +=) rows[graph(i), :F];  segment_sum (its adjoint): out[b, :F] = sum of x[i, :F]

@@ -886,6 +886,10 @@ def test_in_kernel_dropout_draws_equal_their_explicit_mask(dev):
     for a, c in zip(outs[0], outs[1]):
         assert torch.equal(a, c)
     assert float((outs[0][0] == 0).float().mean()) > p * 0.9          # (dropped or clipped by the ReLU)
+    # the attention-dropout mask (gvqa_dropout_scale_mask): the same decisions as floats 0 | 1 / (1 - p)
+    fm = torch.empty(N * Cc, device=dev)
+    _lib.check(lib.gvqa_dropout_scale_mask(N * Cc, seed, off, p, fm.data_ptr(), st))
+    assert torch.equal(fm.view(N, Cc) > 0, keep > 0) and float((fm[fm > 0] - 1.0 / (1.0 - p)).abs().max()) < 1e-6
     # module path: the generator's counters are reserved, the seed reproduces
     from graphvqa_amd.gat_skip import _bn_relu_train
     bn = torch.nn.BatchNorm1d(Cc).to(dev).train()
