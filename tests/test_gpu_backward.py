@@ -976,6 +976,22 @@ def test_gat_seq_gradients_with_dropout_masks_on_the_library_products(dev):
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
 
 
+@pytest.mark.parametrize("ab", [1, 2, 4, 8, 16, 47])
+def test_gat_seq_gradients_with_each_training_fusion_switched(dev, ab, monkeypatch):
+    """Every alternative form of the differentiable path (gat_skip._TRAIN_AB: 1 |h| maxima measured by the backward, 2 the skip's gradient through
+    autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel, 16 dh written by ONE epilogue
+    (gvqa_linear_backward_split2h_ex's rank-J + addend terms), 47 = round 4's path) against the oracle's fp64 autograd, with and without dropout
+    masks, at the reference's widths -- the default forms are the tests above."""
+    from graphvqa_amd import _lib, gat_skip
+    monkeypatch.setattr(gat_skip, "_TRAIN_AB", ab)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        test_gat_seq_gradients_with_dropout_masks(dev)
+        _grads_vs_oracle(dev, train=True, dims=(300, 300, 512, 2, 4), seed=9, graphs=60)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+
+
 def test_lcgn_seq_gradients_on_the_library_products(dev):
     """lcgn_seq's node-sized layers (init / proj_x_loc / proj_x_ctx / the stacked lin_l|lin_r|cal_x with its iteration-invariant
     x_loc block / output_layer / fin_layer, lcgn.py:305-322) forced onto the library's products and one-call backward."""
