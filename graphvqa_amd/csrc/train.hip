@@ -642,7 +642,8 @@ struct TnPlan {
 static TnPlan tn_plan(int64_t R, int64_t M, int64_t N) {
     TnPlan p;
     const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
-    int64_t S = std::max<int64_t>(1, std::min<int64_t>((256 + tiles - 1) / tiles, cdiv(R, 1024)));
+    // (chunks of >= 256 rows: a reduction over a few thousand rows -- the per-graph products of the hop, R = graphs -- still spreads over the chip)
+    int64_t S = std::max<int64_t>(1, std::min<int64_t>((256 + tiles - 1) / tiles, cdiv(R, R >= 16384 ? 1024 : 256)));
     S = std::min<int64_t>(S, 1024);
     const int64_t KC = cdiv(cdiv(std::max<int64_t>(R, 1), S), 64) * 64;
     p.S = (int)cdiv(std::max<int64_t>(R, 1), KC);

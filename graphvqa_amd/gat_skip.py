@@ -470,7 +470,19 @@ class _HopProducts(torch.autograd.Function):
         extra = ctx.skip_grad.pop() if ctx.skip_grad else None          # d loss / d (the hop's skip operand), left by the message-passing node
         if want_w:
             gW = torch.empty_like(W)
-            _lib_abt(g_rows.t().contiguous(), ins.t().contiguous(), out=gW[:, Dn:])      # instruction half: dW_i = d xp_rows^T ins
+            # instruction half: dW_i = d xp_rows^T ins, a reduction over the graphs: the direct transposing product (no [B, H*C] / [B, Di]
+            # transposes through torch), or the tiled f32 kernel on transposed copies where that does not apply
+            g_rows = g_rows.contiguous()
+            gWi = gW[:, Dn:]
+            Bg, HC, Di_ = g_rows.shape[0], g_rows.shape[1], ins.shape[1]
+            if (lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H and lib.gvqa_get_option(_lib.OPT_TN_DIRECT) and ins.is_contiguous()
+                    and HC % 4 == 0 and Di_ % 4 == 0 and gWi.stride(0) % 4 == 0 and gWi.data_ptr() % 16 == 0 and Bg >= 256 and not (_TRAIN_AB & 8)):
+                with torch.cuda.device(dev):
+                    wst = _workspace(lib.gvqa_linear_tn_workspace_bytes(Bg, HC, Di_), dev)
+                    _lib.check(lib.gvqa_linear_tn_split2h(Bg, HC, Di_, g_rows.data_ptr(), HC, ins.data_ptr(), Di_, None, 0, None, 0, gWi.data_ptr(),
+                                                          gWi.stride(0), wst.data_ptr(), wst.numel(), _stream(dev)))
+            else:
+                _lib_abt(g_rows.t().contiguous(), ins.t().contiguous(), out=gWi)
         Wh = W[:, :Dn]
         # (the hint holds while h is what the forward packed: an in-place change since then bumps its version counter)
         hint = ctx.h_absmax[0] if (ctx.h_absmax is not None and ctx.h_absmax[1] == h._version) else None
