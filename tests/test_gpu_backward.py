@@ -931,6 +931,13 @@ def test_operand_pack_leaves_slice_maxima_and_the_backward_takes_them(dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     ref = dy.double().t() @ x.double()
     assert float((outs[1][0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # dy as a column block of a wider buffer (row stride > M): the direct products' descriptors cover exactly the rows' extents
+    wide = torch.full((R, M + 48), float("nan"), device=dev)
+    wide[:, :M] = dy
+    dW3, dx3 = torch.empty((M, K), device=dev), torch.empty((R, K), device=dev)
+    _lib.check(lib.gvqa_linear_backward_split2h_hint(R, M, K, wide.data_ptr(), M + 48, W.data_ptr(), K, x.data_ptr(), K, None, 0, am.data_ptr(), am.numel(),
+                                                     dx3.data_ptr(), K, 0, dW3.data_ptr(), K, ws.data_ptr(), ws.numel(), st))
+    assert torch.equal(dW3, outs[1][0]) and torch.equal(dx3, outs[1][1])
     # gvqa_linear_backward_split2h_ex: dx = dy W + g v^T + addend in the product's epilogue (M % 16 == 0: the direct product applies), against the
     # separate passes; the packed form refuses the epilogue terms before launching anything
     J = 8
