@@ -30,7 +30,7 @@ typedef _Float16 tnd_f16x8 __attribute__((ext_vector_type(8)));
         "v_fma_mixlo_f16 %1, %2, %3, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %2, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"       \
         : "=&v"(hi_), "=&v"(lo_) : "v"(p_), "v"(a_), "v"(b_))
 #else
-#define GVQA_TND_SPLIT2(hi_, lo_, p_, a_, b_) do { (hi_) = 0u; (lo_) = 0u; } while (0)
+#define GVQA_TND_SPLIT2(hi_, lo_, p_, a_, b_) do { (void)(p_); (void)(a_); (void)(b_); (hi_) = 0u; (lo_) = 0u; } while (0)     /* (host pass) */
 #endif
 
 constexpr int TND_TILE = 256, TND_STEP = 16, TND_IMG = 16 * 1024;      // one operand's fragment image of a step: 8 tiles x 2 pieces x 1 KiB
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void k_linear_tn_direct(TndArgs a) {
     const int m0 = (tile / a.tiles_n) * TND_TILE, n0 = (tile % a.tiles_n) * TND_TILE;
     const int64_t rbeg = (int64_t)z * a.KC, rend = rbeg + a.KC < a.R ? rbeg + a.KC : a.R;
     const int rows = (int)(rend - rbeg);
-    const int ns = (rows + TND_STEP - 1) / TND_STEP, nfull = rows / TND_STEP;
+    const int ns = (rows + TND_STEP - 1) / TND_STEP;
 
     // the operands' scales
     {
