@@ -314,6 +314,9 @@ bool linear_nn_direct_applies(int64_t R, int64_t N, int64_t K, int64_t lda);
 int launch_linear_nn_direct(int64_t R, int64_t N, int64_t K, const float* A, int64_t lda, const float* amax, int namax, const void* Bpk, int KBb, int TB,
                             const float* b_inv, float* C, int64_t ldc, int accumulate, hipStream_t stream, const float* lr_g = nullptr,
                             const float* lr_v = nullptr, int J = 0, const float* addend = nullptr, int64_t ld_add = 0);
+// plain two-piece product from packed operands in the direct kernels' step layout (tn_direct.hip); measurement switch GVQA_PK_DIRECT
+int launch_linear_pk_direct(int64_t M, int64_t N, int KB, const void* Apk, const float* a_inv, const void* Bpk, const float* b_inv, const LinearEpilogue& ep,
+                            float* C, int64_t ldc, hipStream_t stream);
 bool linear_split3_supported(int64_t N, const LinearEpilogue& ep, const float* C, int64_t ldc);
 int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, LinearEpilogue ep, float* C,
                         int64_t ldc, hipStream_t stream, int batch = 1,

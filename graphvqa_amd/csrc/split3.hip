@@ -1726,6 +1726,16 @@ int launch_linear_split(int np, int64_t M, int64_t N, int64_t K, const void* Apk
     GVQA_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || M <= 65535 * bm), GVQA_E_INVALID, "linear_split: bad batch count");
     const float* a_inv = np == 2 ? (a_inv_batched ? a_inv_batched : split2h_inv_scales(Apk, cdiv(M, 32), KBA)) : nullptr;
     const float* b_inv = np == 2 ? (b_inv_batched ? b_inv_batched : split2h_inv_scales(Bpk, rtB, KB)) : nullptr;
+    {   // measurement switch GVQA_PK_DIRECT (default 0; 1 = widths whose 256-column tiles are more than half full, 2 = every width): the plain
+        // product in the direct kernels' step layout (tn_direct.hip: three-slot ring of DMA'd fragment pairs, barrier mid-step, epilogue through
+        // LDS).  Stand-alone it is 2-10 % faster than k_linear_split3 on this path's shapes (scripts/bench_pk_direct.py), inside the training step
+        // and the LCGN forward it is not (12.77 vs 12.63 ms, 2.97 vs 2.97 ms: profiles/r05_pk_direct_ab.txt) -- off; GPU tier green with it on
+        static const int pk_direct = [] { const char* v = getenv("GVQA_PK_DIRECT"); return v ? atoi(v) : 0; }();
+        if (pk_direct && np == 2 && batch == 1 && !ep.pk_out && !ep.rowdot_w && !ep.a2 && C && M >= 1024 && N >= 128 &&
+            (pk_direct == 2 || N % 256 == 0 || N % 256 > 128) && get_option(GVQA_OPT_SPLIT3_VARIANT) == 0 &&
+            cdiv(M, 32) * (int64_t)KB * 2048 < (1ll << 32))
+            return launch_linear_pk_direct(M, N, KB, Apk, a_inv, Bpk, b_inv, ep, C, ldc, stream);
+    }
 #ifdef GVQA_PROBES
     const char* ssv = getenv("GVQA_SPLIT3_STAGGER");      // quarter units of the default start offset (tuning aid)
     const int stag_scale = ssv ? atoi(ssv) : 0;

@@ -477,6 +477,158 @@ int launch_linear_nn_direct(int64_t R, int64_t N, int64_t K, const float* A, int
     return GVQA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// C = A B^T from two PACKED two-piece operands (what gvqa_split2h_pack writes), in the step layout of the two kernels above: both operands'
+// fragment pairs reach a three-slot ring by LDS-DMA (wave w: row tile w of A and column tile w of B, 4 DMA instructions per step, no VALU),
+// the step's barrier sits behind the DMA issue with MFMAs queued on both sides, the first product's fragments are read under the previous
+// step's last MFMAs; the epilogue goes through LDS in 32-row slabs (16-byte row segments; bias, addend, elementwise multiplier, ReLU / ELU).
+struct PkdArgs {
+    int M, N, KB;
+    const uint16_t* Apk; const uint16_t* Bpk;
+    const float* a_inv; const float* b_inv;
+    int RTa, RTb;                                   // 32-row tiles in the packs
+    LinearEpilogue ep;
+    float* C; int64_t ldc;
+    int tiles_n, row_tiles;
+};
+
+__global__ __launch_bounds__(512) void k_linear_pk_direct(PkdArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[6 * TND_IMG];          // ring of 3 x (A image | B image)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x >> 3, rt = (q / a.tiles_n) * 8 + (blockIdx.x & 7), ct = q % a.tiles_n;    // column tiles of a row tile: one XCD
+    if (rt >= a.row_tiles) return;
+    const int m0 = rt * TND_TILE, n0 = ct * TND_TILE;
+    const int ns = a.KB;
+    const unsigned lds_base = (unsigned)(size_t)(tnd_lds_ptr)smem;
+    const int atile = min(rt * 8 + wave, a.RTa - 1), btile = min(ct * 8 + wave, a.RTb - 1);      // (tiles past the packs' last: re-read it; never stored)
+    const unsigned oa = (unsigned)((int64_t)atile * a.KB * 2048 + lane * 16), ob = (unsigned)((int64_t)btile * a.KB * 2048 + lane * 16);
+    auto dma = [&](int step, int slot) {
+        const unsigned kb = (unsigned)min(step, a.KB - 1) * 2048u;
+        const unsigned dst = lds_base + (unsigned)slot * (2 * TND_IMG) + (unsigned)wave * 2048u;
+        tnd_dma16_x2(a.Apk, oa + kb, __builtin_amdgcn_readfirstlane(dst));
+        tnd_dma16_x2(a.Bpk, ob + kb, __builtin_amdgcn_readfirstlane(dst + TND_IMG));
+    };
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned a_off = (unsigned)(wr * 4 * 2048 + lane * 16), b_off = (unsigned)(TND_IMG + wc * 2 * 2048 + lane * 16);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto rd = [&](const unsigned char* p) { return __builtin_bit_cast(tnd_f16x8, *reinterpret_cast<const uint4*>(p)); };
+    tnd_f16x8 ah[4], al[4], bh[2], bl[2];
+#define GVQA_PKD_MF(n_) do { constexpr int q_ = (n_) / 8, t_ = (n_) % 8, i_ = t_ >> 1, j_ = t_ & 1;                                       \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q_ == 0 ? al[i_] : ah[i_], q_ == 2 ? bl[j_] : bh[j_], acc[i_][j_], 0, 0, 0); } while (0)
+#define GVQA_PKD_FENCE() __builtin_amdgcn_sched_barrier(0)
+    dma(0, 0);
+    dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) al[i] = rd(smem + a_off + i * 2048 + 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bh[j] = rd(smem + b_off + j * 2048);
+    int cur = 0;
+    for (int s = 0; s < ns; ++s) {
+        const int nxt = cur == 2 ? 0 : cur + 1, ld = nxt == 2 ? 0 : nxt + 1;
+        const unsigned char* img = smem + cur * (2 * TND_IMG);
+        const unsigned char* imn = smem + nxt * (2 * TND_IMG);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ah[i] = rd(img + a_off + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bl[j] = rd(img + b_off + j * 2048 + 1024);
+        GVQA_PKD_FENCE();
+        GVQA_PKD_MF(0); GVQA_PKD_MF(1); GVQA_PKD_FENCE();
+        dma(s + 2, ld);                                   // (slot of step s - 1: every wave read it before the previous barrier)
+        GVQA_PKD_FENCE();
+        GVQA_PKD_MF(2); GVQA_PKD_MF(3); GVQA_PKD_MF(4); GVQA_PKD_MF(5); GVQA_PKD_MF(6); GVQA_PKD_MF(7); GVQA_PKD_FENCE();
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");          // step s + 1's DMAs (issued one step ago) have landed; this step's four stay in flight
+        __builtin_amdgcn_s_barrier();
+        GVQA_PKD_FENCE();
+        GVQA_PKD_MF(8); GVQA_PKD_MF(9); GVQA_PKD_MF(10); GVQA_PKD_MF(11); GVQA_PKD_MF(12); GVQA_PKD_MF(13); GVQA_PKD_MF(14); GVQA_PKD_MF(15);
+        GVQA_PKD_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) al[i] = rd(imn + a_off + i * 2048 + 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bh[j] = rd(imn + b_off + j * 2048);
+        GVQA_PKD_FENCE();
+        GVQA_PKD_MF(16); GVQA_PKD_MF(17); GVQA_PKD_MF(18); GVQA_PKD_MF(19); GVQA_PKD_MF(20); GVQA_PKD_MF(21); GVQA_PKD_MF(22); GVQA_PKD_MF(23);
+        GVQA_PKD_FENCE();
+        cur = nxt;
+    }
+#undef GVQA_PKD_MF
+#undef GVQA_PKD_FENCE
+    // epilogue through LDS, 32 rows at a time
+    constexpr int EP_LD = 260;
+    float* stage = reinterpret_cast<float*>(smem);
+    const int ccol = lane & 31, crow0 = 4 * (lane >> 5);
+    float binv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int gc = n0 + wc * 64 + j * 32 + ccol; binv[j] = gc < a.N ? a.b_inv[gc] : 0.f; }
+    const int ecol = (tid & 63) * 4, erow0 = tid >> 6;
+    const int gcol = n0 + ecol;
+    const bool col_on = gcol < a.N;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.ep.bias && col_on) bias4 = *reinterpret_cast<const float4*>(a.ep.bias + gcol);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+        const int cwr = ch >> 2, ci = ch & 3;
+        if (wr == cwr) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(crow0 + (r & 3) + 8 * (r >> 2)) * EP_LD + wc * 64 + jj * 32 + ccol] = acc[ci][jj][r] * binv[jj];
+        }
+        __syncthreads();
+        if (col_on) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lr = erow0 + 8 * k;
+                const int64_t gr = m0 + cwr * 128 + ci * 32 + lr;
+                if (gr >= a.M) continue;
+                float4 v = *reinterpret_cast<const float4*>(&stage[lr * EP_LD + ecol]);
+                const float ai = a.a_inv[gr];
+                v.x = v.x * ai + bias4.x; v.y = v.y * ai + bias4.y; v.z = v.z * ai + bias4.z; v.w = v.w * ai + bias4.w;
+                if (a.ep.addend) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.ep.addend + gr * a.ep.ld_add + gcol);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (a.ep.mul) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.ep.mul + gr * a.ep.ld_mul + gcol);
+                    v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w;
+                }
+                if (a.ep.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.ep.relu == 2) {
+                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : expf(v.y) - 1.f;
+                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : expf(v.w) - 1.f;
+                }
+                *reinterpret_cast<float4*>(a.C + gr * a.ldc + gcol) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// plain two-piece product (no batch, chain, packed output or row-dot epilogue); KB = cdiv(K, 16) k blocks per tile in both packs
+int launch_linear_pk_direct(int64_t M, int64_t N, int KB, const void* Apk, const float* a_inv, const void* Bpk, const float* b_inv, const LinearEpilogue& ep,
+                            float* C, int64_t ldc, hipStream_t stream) {
+    GVQA_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && KB > 0 && Apk && Bpk && a_inv && b_inv && C && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 &&
+                     cdiv(M, 32) * (int64_t)KB * 2048 < (1ll << 32) && cdiv(N, 32) * (int64_t)KB * 2048 < (1ll << 32),
+                 GVQA_E_INVALID, "linear_pk_direct: bad argument");
+    PkdArgs a;
+    a.M = (int)M; a.N = (int)N; a.KB = KB; a.Apk = static_cast<const uint16_t*>(Apk); a.Bpk = static_cast<const uint16_t*>(Bpk); a.a_inv = a_inv; a.b_inv = b_inv;
+    a.RTa = (int)cdiv(M, 32); a.RTb = (int)cdiv(N, 32); a.ep = ep; a.C = C; a.ldc = ldc;
+    a.tiles_n = (int)cdiv(N, TND_TILE); a.row_tiles = (int)cdiv(M, TND_TILE);
+    hipLaunchKernelGGL(k_linear_pk_direct, dim3((unsigned)(cdiv(a.row_tiles, 8) * a.tiles_n * 8)), dim3(512), 0, stream, a);
+    GVQA_LAUNCH_CHECK();
+    return GVQA_OK;
+}
+
 bool linear_tn_direct_applies(int KC, int64_t ldx, int64_t ldy) {      // (+ 8-byte aligned operands with even leading dimensions: the launcher)
     return KC > 0 && KC % TND_STEP == 0 && ldx % 2 == 0 && ldy % 2 == 0 && (int64_t)(KC + 16) * ldx < (1ll << 29) && (int64_t)(KC + 16) * ldy < (1ll << 29);
 }
