@@ -14,24 +14,55 @@ namespace {
 
 constexpr int BN_ROWS = 64;           // rows per block of the column reductions (N / 64 row blocks x C / 256 column blocks)
 
-// mode 0: sum x;  mode 1: sum (x - mean)^2
-__global__ __launch_bounds__(256) void k_bn_col_stats(int64_t N, int C, const float* __restrict__ x, const float* __restrict__ mean,
-                                                      float* __restrict__ partial) {
-    const int c = blockIdx.y * 256 + threadIdx.x;           // row blocks on grid.x (no 65535 limit), column blocks on grid.y
+// Both statistics from ONE pass over x: a thread keeps its column's (<= 64) rows of the block in registers, forms the block's sum, then the block's
+// sum of squared deviations from the BLOCK mean out of the registers; k_bn_col_finish_m2 combines the blocks exactly (Chan et al.:
+// M2 = sum_b [M2_b + n_b (mean_b - mean)^2]) -- the accuracy of the two-pass form (deviations from a mean, never x^2), one read of x instead of two.
+// partial[b, 0, c] = sum_b, partial[b, 1, c] = M2_b
+__global__ __launch_bounds__(256) void k_bn_col_stats_fused(int64_t N, int C, const float* __restrict__ x, float* __restrict__ partial) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS, r1 = min(N, r0 + BN_ROWS);
-    const float m = mean ? mean[c] : 0.f;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four independent chains: loads in flight, fixed summation order
-    int64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        const float v0 = x[r * C + c] - m, v1 = x[(r + 1) * C + c] - m, v2 = x[(r + 2) * C + c] - m, v3 = x[(r + 3) * C + c] - m;
-        a0 += mean ? v0 * v0 : v0; a1 += mean ? v1 * v1 : v1; a2 += mean ? v2 * v2 : v2; a3 += mean ? v3 * v3 : v3;
+    const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
+    const int n = (int)min<int64_t>(BN_ROWS, N - r0);
+    float v[BN_ROWS];
+#pragma unroll
+    for (int r = 0; r < BN_ROWS; ++r) v[r] = r < n ? x[(r0 + r) * C + c] : 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < BN_ROWS; r += 4) { a0 += v[r]; a1 += v[r + 1]; a2 += v[r + 2]; a3 += v[r + 3]; }
+    const float sum = (a0 + a1) + (a2 + a3), mb = sum / (float)n;
+    a0 = a1 = a2 = a3 = 0.f;
+#pragma unroll
+    for (int r = 0; r < BN_ROWS; r += 4) {
+        const float d0 = v[r] - mb, d1 = v[r + 1] - mb, d2 = v[r + 2] - mb, d3 = v[r + 3] - mb;
+        a0 += r < n ? d0 * d0 : 0.f; a1 += r + 1 < n ? d1 * d1 : 0.f; a2 += r + 2 < n ? d2 * d2 : 0.f; a3 += r + 3 < n ? d3 * d3 : 0.f;
     }
-    for (; r < r1; ++r) {
-        const float v = x[r * C + c] - m;
-        a0 += mean ? v * v : v;
+    partial[((int64_t)blockIdx.x * 2 + 0) * C + c] = sum;
+    partial[((int64_t)blockIdx.x * 2 + 1) * C + c] = (a0 + a1) + (a2 + a3);
+}
+
+// var[c] = (1 / N) sum_b [ M2_b + n_b (sum_b / n_b - mean[c])^2 ]   (same thread geometry and summation order as k_bn_col_finish)
+__global__ __launch_bounds__(1024) void k_bn_col_finish_m2(int nblocks, int C, int64_t N, const float* __restrict__ partial, const float* __restrict__ mean,
+                                                           float* __restrict__ var) {
+    __shared__ float red[64][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    float a0 = 0.f;
+    if (c < C) {
+        const float m = mean[c];
+        for (int b = ry; b < nblocks; b += 64) {
+            const float nb = (float)min<int64_t>(BN_ROWS, N - (int64_t)b * BN_ROWS);
+            const float d = partial[((int64_t)b * 2 + 0) * C + c] / nb - m;
+            a0 += partial[((int64_t)b * 2 + 1) * C + c] + nb * d * d;
+        }
     }
-    partial[(int64_t)blockIdx.x * C + c] = (a0 + a1) + (a2 + a3);
+    red[ry][cx] = a0;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) t += red[k][cx];
+        var[c] = t / (float)N;
+    }
 }
 
 // out[c] = scale * sum_b partial[b * blk_stride + c]: a block owns 16 columns, its 64 thread rows sum interleaved
@@ -343,10 +374,10 @@ static int bn_relu_dropout_train_forward_impl(int64_t N, int32_t C, const float*
     const int nb = (int)cdiv(N, BN_ROWS);
     GVQA_REQUIRE(cdiv(N, BN_ROWS) < (1ll << 31) && C <= 65535 * 256, GVQA_E_UNSUPPORTED, "bn_relu_train: sizes out of range");
     const dim3 grid((unsigned)nb, (unsigned)cdiv(C, 256)), cgrid((unsigned)cdiv(C, 16));
-    hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, nullptr, partial);
-    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_mean);
-    hipLaunchKernelGGL(k_bn_col_stats, grid, dim3(256), 0, stream, N, (int)C, x, save_mean, partial);
-    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)C, 1.0f / (float)N, save_var);
+    // batch mean and biased variance from one pass over x (block sums + block M2, combined exactly)
+    hipLaunchKernelGGL(k_bn_col_stats_fused, grid, dim3(256), 0, stream, N, (int)C, x, partial);
+    hipLaunchKernelGGL(k_bn_col_finish, cgrid, dim3(1024), 0, stream, nb, (int)C, partial, (int64_t)2 * C, 1.0f / (float)N, save_mean);
+    hipLaunchKernelGGL(k_bn_col_finish_m2, cgrid, dim3(1024), 0, stream, nb, (int)C, N, partial, save_mean, save_var);
     const int64_t blocks = std::min<int64_t>(cdiv(N * C, 256), 4096);
     const bool v4 = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (reinterpret_cast<uintptr_t>(keep) & 3) == 0;
     int TPR = 1;
