@@ -189,6 +189,8 @@ PROTOTYPES = {
     "gvqa_split2h_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gvqa_split2h_pack": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "gvqa_split2h_pack_absmax": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gvqa_split2h_pack_logits": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_void_p]),
     "gvqa_linear_split2h": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "gvqa_linear_split2h_chain": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

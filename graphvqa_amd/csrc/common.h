@@ -299,7 +299,8 @@ int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, fl
 int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream, int col_parts = 1);
 
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);
-int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream, float* absmax = nullptr);
+int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream, float* absmax = nullptr,
+                      const float* Vn = nullptr, int J = 0, float* a_node = nullptr);
 int launch_split2h_pack_gather(int64_t rows, int64_t K, const float* Y, int64_t ld, const float* a, const int64_t* ia, int64_t lda,
                                const float* b, const int64_t* ib, int64_t ldb, const float* bias, void* packed, hipStream_t stream,
                                const int64_t* tok = nullptr, int V = 0, const uint8_t* neg = nullptr);   // tok: Y rows are +-Y[tok[r]] (a table)

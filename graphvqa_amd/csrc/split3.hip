@@ -1599,6 +1599,9 @@ static int launch_split2h_pack_tiles(const PackRows& pr, int64_t RT, int64_t K, 
             case 16: if (regs) GVQA_P2(16, 8); else GVQA_P2(16, 0); break;
             default: return GVQA_E_UNSUPPORTED;
         }
+    } else if constexpr (MAP == PACK_PLAIN) {            // (plain rows + their J = 8 logits: the training forward's operand pack, gvqa_split2h_pack_logits)
+        if (J != 8 || w8 || lm) return GVQA_E_UNSUPPORTED;
+        if (KB <= 32) GVQA_P2L(8, 8, 0); else GVQA_P2L(8, 0, 0);
     } else {
         return GVQA_E_UNSUPPORTED;
     }
@@ -1640,7 +1643,8 @@ int launch_split2h_pack_rowmul(int64_t rows, int64_t K, const float* X, int64_t 
     return launch_split2h_pack_tiles<PACK_GATHER>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
 }
 
-int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream, float* absmax) {
+int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, hipStream_t stream, float* absmax, const float* Vn, int J,
+                      float* a_node) {
     GVQA_REQUIRE(np == 2 || np == 3, GVQA_E_INVALID, "split_pack: 2 or 3 pieces");
     GVQA_REQUIRE(rows >= 0 && K >= 0 && K < (1ll << 30) && ld >= K, GVQA_E_INVALID, "split_pack: bad size");
     if (rows == 0 || K == 0) return GVQA_OK;
@@ -1653,9 +1657,9 @@ int launch_split_pack(int np, int64_t rows, int64_t K, const float* X, int64_t l
         GVQA_REQUIRE(RT < (1ll << 31), GVQA_E_INVALID, "split_pack: too many rows");
         PackRows pr{X, ld, rows, nullptr, 0, 0, 0};
         pr.absmax = absmax;
-        return launch_split2h_pack_tiles<PACK_PLAIN>(pr, RT, K, packed, nullptr, 0, nullptr, stream);
+        return launch_split2h_pack_tiles<PACK_PLAIN>(pr, RT, K, packed, Vn, Vn ? J : 0, a_node, stream);
     }
-    GVQA_REQUIRE(!absmax, GVQA_E_UNSUPPORTED, "split_pack: slice maxima are a two-piece pack's by-product");
+    GVQA_REQUIRE(!absmax && !Vn, GVQA_E_UNSUPPORTED, "split_pack: slice maxima / logits are a two-piece pack's by-products");
     for (int64_t r0 = 0; r0 < RT; r0 += 65535) {       // grid.y holds 65535 row tiles
         const int64_t n = std::min<int64_t>(65535, RT - r0);
         hipLaunchKernelGGL(k_split3_pack, dim3((unsigned)cdiv(KB, 4), (unsigned)n), dim3(256), 0, stream, rows - r0 * 32, (int)K, KB,
@@ -2187,6 +2191,12 @@ extern "C" size_t gvqa_split2h_packed_bytes(int64_t rows, int64_t K) {
     return gvqa::split_packed_bytes(2, rows, K);
 }
 
+extern "C" int gvqa_split2h_pack_logits(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, float* absmax, const float* Vn, int32_t J,
+                                        float* a_node, void* stream) {
+    GVQA_REQUIRE(Vn && a_node && J == 8 && K % 4 == 0 && K <= 1024, GVQA_E_UNSUPPORTED, "split2h_pack_logits: J = 8 vectors, K %% 4 == 0, K <= 1024");
+    if (absmax) GVQA_HIP_CHECK(hipMemsetAsync(absmax, 0, GVQA_ABSMAX_SLOTS * sizeof(float), static_cast<hipStream_t>(stream)));
+    return gvqa::launch_split_pack(2, rows, K, X, ld, packed, static_cast<hipStream_t>(stream), absmax, Vn, J, a_node);
+}
 extern "C" int gvqa_split2h_pack_absmax(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, float* absmax, void* stream) {
     GVQA_REQUIRE(absmax, GVQA_E_INVALID, "split2h_pack_absmax: null maxima");
     GVQA_HIP_CHECK(hipMemsetAsync(absmax, 0, GVQA_ABSMAX_SLOTS * sizeof(float), static_cast<hipStream_t>(stream)));

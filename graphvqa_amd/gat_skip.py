@@ -33,7 +33,7 @@ from .graph import SceneGraphBatch, _stream, _ptr
 
 # A/B switch of the training path's round-5 fusions (scripts/ab_train_parts.sh; measurement only, 0 = everything on): bit 1 no |h| maxima from
 # the operand pack, 2 the skip's gradient through autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel;
-# bit 32: feature-dropout masks as torch bernoulli_ tensors instead of in-kernel Philox draws;
+# bit 64: the node logits as a pass of their own instead of a by-product of the operand pack; bit 32: feature-dropout masks as torch bernoulli_ tensors instead of in-kernel Philox draws;
 # bit 16 switches ON the (slower, kept for the record) form that adds the logit products' input gradient in the dx product's epilogue
 _TRAIN_AB = int(os.environ.get("GVQA_TRAIN_AB", "0") or 0)
 
@@ -113,7 +113,7 @@ class _ProjectionLinear(torch.autograd.Function):
         return _ProjectionLinear._product(x, w, bias)
 
     @staticmethod
-    def _product(x, w, bias=None, absmax_out=None):
+    def _product(x, w, bias=None, absmax_out=None, logits=None):
         """absmax_out ([_lib.ABSMAX_SLOTS] fp32, optional): filled with slice maxima of |x| when the two-piece path packs x (a by-product of
         its row scales) and then tagged `_gvqa_filled`; the backward's weight-gradient product takes it instead of a pass over x."""
         lib = _lib.load()
@@ -136,7 +136,14 @@ class _ProjectionLinear(torch.autograd.Function):
                                     if mode == _lib.PROJECTION_SPLIT2H else
                                     (lib.gvqa_split3_packed_bytes, lib.gvqa_split3_pack, lib.gvqa_linear_split3))
             apk, wpk = _workspace(nbytes(M, K), dev), _workspace(nbytes(N, K), dev)
-            if absmax_out is not None and mode == _lib.PROJECTION_SPLIT2H:
+            if logits is not None and mode == _lib.PROJECTION_SPLIT2H and logits[0].shape == (8, K) and K % 4 == 0 and K <= 1024:
+                # `logits` = (Vn [8, K], out [M, 8]): x Vn^T leaves the pack pass as well (tagged `_gvqa_filled` on the output)
+                _lib.check(lib.gvqa_split2h_pack_logits(M, K, x.data_ptr(), K, apk.data_ptr(), _ptr(absmax_out), logits[0].data_ptr(), 8,
+                                                        logits[1].data_ptr(), st))
+                logits[1]._gvqa_filled = True
+                if absmax_out is not None:
+                    absmax_out._gvqa_filled = True
+            elif absmax_out is not None and mode == _lib.PROJECTION_SPLIT2H:
                 _lib.check(lib.gvqa_split2h_pack_absmax(M, K, x.data_ptr(), K, apk.data_ptr(), absmax_out.data_ptr(), st))
                 absmax_out._gvqa_filled = True
             else:
@@ -420,9 +427,13 @@ class _HopProducts(torch.autograd.Function):
         with torch.no_grad():
             # (the largest magnitudes of h leave the operand pack as a by-product: the backward's dW = dxp^T h needs h's ONE scale)
             am_h = torch.empty(_lib.ABSMAX_SLOTS, dtype=torch.float32, device=h.device) if (h.is_cuda and W.requires_grad and not (_TRAIN_AB & 1)) else None
-            xp = _ProjectionLinear._product(h, W[:, :Dn], absmax_out=am_h)
+            # ... and the node halves of the folded logits, a_part = h F[:Dn], come out of the same pass over h (2H = 8)
+            lg = None
+            if heads2 == 8 and h.is_cuda and h.is_contiguous() and not (_TRAIN_AB & 64):
+                lg = (F_[:Dn].t().contiguous(), torch.empty((h.shape[0], 8), dtype=torch.float32, device=h.device))
+            xp = _ProjectionLinear._product(h, W[:, :Dn], absmax_out=am_h, logits=lg)
             ctx.h_absmax = (am_h, h._version) if (am_h is not None and getattr(am_h, "_gvqa_filled", False)) else None
-            a_part = skinny_linear(h, F_[:Dn])
+            a_part = lg[1] if (lg is not None and getattr(lg[1], "_gvqa_filled", False)) else skinny_linear(h, F_[:Dn])
             xp_rows = _lib_abt(ins, W[:, Dn:])
             U_n = F_[Dn:].clone()
             U_n[:, :H] += U_e

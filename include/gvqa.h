@@ -332,6 +332,11 @@ GVQA_API int gvqa_split2h_pack(int64_t rows, int64_t K, const float* X, int64_t 
 /* gvqa_split2h_pack that also leaves the operand's largest magnitudes as GVQA_ABSMAX_SLOTS slice maxima in `absmax` (zeroed here): the hint the
  * backward's one-scale products take (gvqa_linear_backward_split2h_hint, gvqa_linear_tn_split2h). */
 GVQA_API int gvqa_split2h_pack_absmax(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, float* absmax, void* stream);
+/* ... and J = 8 dot products per row on the way, a_node[r, j] = sum_k X[r, k] Vn[j, k] (Vn [J, K] row-major): the node halves of the attention
+ * logits with the attention vectors folded through the weights (gat_skip.py:134-135) from the SAME pass over h that packs it for the projection
+ * (absmax may be NULL).  K % 4 == 0, K <= 1024 (GVQA_E_UNSUPPORTED otherwise: gvqa_skinny_forward is the general form). */
+GVQA_API int gvqa_split2h_pack_logits(int64_t rows, int64_t K, const float* X, int64_t ld, void* packed, float* absmax, const float* Vn, int32_t J,
+                                      float* a_node, void* stream);
 GVQA_API int gvqa_linear_split2h(int64_t M, int64_t N, int64_t K, const void* Apk, const void* Bpk, const float* bias,
                         const float* addend, int64_t ld_add, const float* mul, int64_t ld_mul, int relu, float* C,
                         int64_t ldc, void* stream);

@@ -920,6 +920,13 @@ def test_operand_pack_leaves_slice_maxima_and_the_backward_takes_them(dev):
     _lib.check(lib.gvqa_split2h_pack_absmax(R, K, x.data_ptr(), K, p1.data_ptr(), am.data_ptr(), st))
     assert torch.equal(p0, p1)
     assert float(am.max()) == float(x.abs().max())
+    # gvqa_split2h_pack_logits: the same packed operand and maxima, plus x Vn^T (J = 8) from the same pass
+    Vn = torch.randn((8, K), generator=g).to(dev)
+    p2, am2, lg = torch.zeros(nb, dtype=torch.uint8, device=dev), torch.full((_lib.ABSMAX_SLOTS,), 7.0, device=dev), torch.empty((R, 8), device=dev)
+    _lib.check(lib.gvqa_split2h_pack_logits(R, K, x.data_ptr(), K, p2.data_ptr(), am2.data_ptr(), Vn.data_ptr(), 8, lg.data_ptr(), st))
+    assert torch.equal(p0, p2) and torch.equal(am, am2)
+    refl = x.double() @ Vn.double().t()
+    assert float((lg.double() - refl).abs().max()) <= 2e-6 * float(refl.abs().max()) * K ** 0.5
     ws = torch.empty(lib.gvqa_linear_backward_workspace_bytes(R, M, K), dtype=torch.uint8, device=dev)
     outs = []
     for hint in (None, am):
@@ -983,11 +990,11 @@ def test_gat_seq_gradients_with_dropout_masks_on_the_library_products(dev):
         _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
 
 
-@pytest.mark.parametrize("ab", [1, 2, 4, 8, 16, 47])
+@pytest.mark.parametrize("ab", [1, 2, 4, 8, 16, 64, 111])
 def test_gat_seq_gradients_with_each_training_fusion_switched(dev, ab, monkeypatch):
     """Every alternative form of the differentiable path (gat_skip._TRAIN_AB: 1 |h| maxima measured by the backward, 2 the skip's gradient through
     autograd, 4 head rows / bias / skip as a second pass, 8 tiny per-graph products on the tiled kernel, 16 dh written by ONE epilogue
-    (gvqa_linear_backward_split2h_ex's rank-J + addend terms), 47 = round 4's path) against the oracle's fp64 autograd, with and without dropout
+    (gvqa_linear_backward_split2h_ex's rank-J + addend terms), 64 node logits as a pass of their own, 111 = round 4's path) against the oracle's fp64 autograd, with and without dropout
     masks, at the reference's widths -- the default forms are the tests above."""
     from graphvqa_amd import _lib, gat_skip
     monkeypatch.setattr(gat_skip, "_TRAIN_AB", ab)
