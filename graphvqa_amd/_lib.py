@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GVQA_LIB", os.path.join(HERE, "lib", "libgvqa_hip.so"
 GVQA_OK, E_INVALID, E_WORKSPACE, E_HIP, E_GRAPH, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 STAGES = ("graph", "fold", "edge_logit", "graph_term", "proj", "node_logit", "mp", "other", "pack", "alpha")
 # gvqa_set_option keys / values (include/gvqa.h)
-OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS, OPT_HOP_COEFFS, OPT_HOP_HALF_TILES, OPT_TN_DIRECT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_PROJECTION, OPT_VENDOR_GEMM, OPT_SPLIT3_MIN_MFLOP, OPT_SPLIT3_VARIANT, OPT_HOP_FUSION, OPT_COEFF_KERNEL, OPT_MP_PARTS, OPT_HOP_COEFFS, OPT_HOP_HALF_TILES, OPT_TN_DIRECT, OPT_PACKED_GROUPS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 PROJECTION_SPLIT3, PROJECTION_F32, PROJECTION_SPLIT2H = 0, 1, 2
 NUM_STAGES = len(STAGES)
 HOP_KERNELS = ("unfused", "fused8", "persistent", "fused8_chained", "persistent_chained", "aggregate_first", "aggregate_first_seq", "aggregate_first_parts")      # GVQA_HOP_*
@@ -43,7 +43,10 @@ class Graph(C.Structure):
                 ("max_graph_nodes", C.c_int32), ("max_graph_edges", C.c_int32),
                 ("max_in_degree", C.c_int32), ("intra_graph", C.c_int32), ("valid", C.c_int32),
                 ("finalized", C.c_int32), ("row_group_ptr", C.c_void_p), ("num_row_groups", C.c_int32),
-                ("max_row_group_edges", C.c_int32), ("row_group_order", C.c_void_p)]
+                ("max_row_group_edges", C.c_int32), ("row_group_order", C.c_void_p),
+                ("pk_num_row_groups", C.c_int32), ("pk_max_row_group_edges", C.c_int32), ("pk_row_group_ptr", C.c_void_p),
+                ("pk_rowptr", C.c_void_p), ("pk_csr_src", C.c_void_p), ("pk_csr_eid", C.c_void_p), ("pk_node_graph", C.c_void_p),
+                ("pk_node_old", C.c_void_p), ("pk_graph_old", C.c_void_p)]
 
 
 class GatConvParams(C.Structure):

@@ -266,6 +266,9 @@ struct HopAggArgs {
     int parts_in;               // sets of a_node_in / gmax_in to combine (1: the layout pass or a CP = 1 launch produced them)
     int64_t an_part_stride, gm_part_stride;      // floats between two sets (N x 2 H, B)
     int dbg;                    // measurement build only (GVQA_HOPAGG_DEBUG): 1 no producer in the loop, 2 no weight DMA, 4 no MFMAs, 8 no fragment reads after step 0, 16 no waits / barriers, 32 no epilogue
+    // packed row groups (gvqa_graph::pk_*): group_ptr / rowptr / csr_src / csr_eid / node_graph above are then the PACKED arrays, and
+    const int32_t* row_map;     // NULL or [N]: row of `out` (and of the caller's x) of packed node n
+    const int32_t* graph_old;   // NULL or [B]: row of graph_term of packed graph index j
 };
 // The K hops of gat_seq as ONE launch of the aggregate-first kernel (k_hopagg4<..., SEQ>): per-hop operands.  The HopAggArgs beside it
 // carry the batch (CSR, row groups), hop 0's node logits (a_node_in, from the layout pass), the per-graph maxima of the input rows
@@ -295,7 +298,7 @@ int launch_hopagg_seq(int H, const HopAggArgs& a, const HopAggSeq& hs, int num_g
 size_t hopagg_packed_w_bytes(int C, int Dn, int H);
 int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void* packed, hipStream_t stream);
 int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream,
-                      const float* Vn = nullptr, float* a_node = nullptr);      // Vn: [8][D] folded vectors of hop 0 -> a_node [N, 8]
+                      const float* Vn = nullptr, float* a_node = nullptr, bool packed = false);      // Vn: [8][D] folded vectors of hop 0 -> a_node [N, 8]; packed: the handle's packed row groups
 int launch_hopagg(int H, const HopAggArgs& a, int num_groups, hipStream_t stream, int col_parts = 1);
 
 size_t split_packed_bytes(int np, int64_t rows, int64_t K);

@@ -1073,10 +1073,15 @@ constexpr bool kAggFirstByDefault = true;            // (since the epilogue's lo
 // ... with a row group's output columns split over four workgroups (k_hopagg4<4, 2, 1, 2, ..., CP = 4>; GVQA_OPT_HOP_FUSION = 6: built for
 // strong-scaling shards, where one workgroup per row group leaves most CUs idle).  Per-hop launches; attention weights and per-hop rows served.
 constexpr int kHopaggParts = 4;
+// Packed row groups (gvqa_graph::pk_*, graph.hip): when the handle carries them, the aggregate-first hops run on the packed numbering --
+// fewer, fuller groups = fewer workgroups of the one-per-CU launch
+static bool agg_packed(const gvqa_graph* g) { return g->pk_num_row_groups > 0 && g->pk_row_group_ptr && get_option(GVQA_OPT_PACKED_GROUPS) != 0; }
+static int agg_groups(const gvqa_graph* g) { return agg_packed(g) ? g->pk_num_row_groups : g->num_row_groups; }
+static int agg_max_group_edges(const gvqa_graph* g) { return agg_packed(g) ? g->pk_max_row_group_edges : g->max_row_group_edges; }
 static bool hopagg_parts_shape(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int H = d->heads, C = d->out_channels;
     return H == 4 && C == d->node_dim && C > 384 && C <= 512 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
-           proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && hopagg_supported(H, C, d->node_dim, g->max_row_group_edges);
+           proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && hopagg_supported(H, C, d->node_dim, agg_max_group_edges(g));
 }
 static bool hopagg_parts_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     const int mode = opt_hop_fusion(d);
@@ -1091,7 +1096,7 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
     if (mode != 4 && mode != 5 && mode != 3) return false;
     const int H = d->heads, C = d->out_channels;
     if (!(proj_pieces(d, g->num_nodes, (int64_t)H * C, d->node_dim) == 2 && g->num_row_groups > 0 && g->row_group_ptr && g->intra_graph &&
-          hopagg_supported(H, C, d->node_dim, g->max_row_group_edges)))
+          hopagg_supported(H, C, d->node_dim, agg_max_group_edges(g))))
         return false;
     if (mode == 3 && !kAggFirstByDefault) return false;
     if (mode == 3) {
@@ -1102,10 +1107,14 @@ static bool hopagg_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
         // a workgroup's hops run faster when the last round is thin (fewer CUs draw power), so two rounds pay from ~0.72 on, three
         // from ~0.80; one round and four or more keep the earlier 0.85.
         const int64_t cus = device_cu_count();         // (per device: the thresholds below were tuned on the 256-CU part)
-        const int64_t G = g->num_row_groups, rounds = cdiv(G, cus);
+        const int64_t G = agg_groups(g), rounds = cdiv(G, cus);
         const int64_t fill_pct = rounds == 2 ? 76 : rounds == 3 ? 82 : 85;
         if (G * 100 < rounds * cus * fill_pct) return false;
-        if (C <= 320) return false;                    // (the 4 x 2-wave layout of narrow rows is issue-bound: d = 300, 149 vs 110 us per hop)
+        // (round 5 excluded C <= 320 here: "d = 300, 149 vs 110 us per hop".  That comparison was config 2's 262 in-order row groups = TWO
+        //  rounds on 256 CUs; inside a workgroup a d = 300 hop is 88 us against 113 + 17 + 4 for the 8-wave kernel and its two small launches
+        //  (profiles/r06a_cfg2_seq_stamps.json), and with the packed row groups (246 groups: one round) the forward is 0.56 vs 0.72 ms
+        //  (profiles/r06b_cfg2_packed_ab.jsonl).  Narrower rows are unmeasured: they keep the 8-wave kernels)
+        if (C <= 256) return false;
     }
     return true;
 }
@@ -1591,11 +1600,13 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
         // coefficient kernel (node logits from the chunks + segment softmax) and the hop kernel -- rows staying chunk-major.
         float* X4[2] = {P(L.x4a), P(L.x4b)};
         float* GM[2] = {P(L.gma), P(L.gmb)};
+        const bool pk = agg_packed(g);            // packed row groups: every array of the batch below in the packed numbering, rows in / out through the map
+        const int ngroups = agg_groups(g);
         const int NQ = (int)cdiv(Dn, 4);
         {
             StageTimer tp(GVQA_STAGE_PACK, stream);
             // (+ hop 0's node logits, out of the slab it moves the rows through)
-            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream, Vn_all, P(L.a_node));
+            rc = launch_rows_to_x4(g, Dn, x, Dn, X4[0], GM[0], stream, Vn_all, P(L.a_node), pk);
             if (rc) return rc;
         }
         if (ss) { rc = side_join(ss, stream); if (rc) return rc; }
@@ -1611,7 +1622,10 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 StageTimer t(GVQA_STAGE_PROJ, stream);
                 HopAggArgs ha;
                 memset(&ha, 0, sizeof(ha));
-                ha.group_ptr = g->row_group_ptr; ha.rowptr = g->rowptr; ha.csr_src = g->csr_src; ha.node_graph = g->node_graph;
+                ha.group_ptr = pk ? g->pk_row_group_ptr : g->row_group_ptr; ha.rowptr = pk ? g->pk_rowptr : g->rowptr;
+                ha.csr_src = pk ? g->pk_csr_src : g->csr_src; ha.node_graph = pk ? g->pk_node_graph : g->node_graph;
+                ha.row_map = pk ? g->pk_node_old : nullptr; ha.graph_old = pk ? g->pk_graph_old : nullptr;
+                const int32_t* agg_csr_eid = pk ? g->pk_csr_eid : g->csr_eid;
                 ha.alpha_csr = P(L.alpha_csr); ha.X4in = X4[i & 1];
                 const char* wk = w6 + (size_t)i * w6_hop;
                 ha.NCT = (int)cdiv(C, 32); ha.NQ = NQ; ha.C = C;
@@ -1640,7 +1654,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                 if (in_prologue) {                    // (in place: a workgroup reads its rows' logits before it writes the next hop's)
                     ha.alpha_csr = nullptr;
                     ha.a_node_in = an_in;
-                    ha.a_edge = P(L.a_edge) + (int64_t)i * H; ha.a_edge_stride = (int64_t)K * H; ha.csr_eid = g->csr_eid;
+                    ha.a_edge = P(L.a_edge) + (int64_t)i * H; ha.a_edge_stride = (int64_t)K * H; ha.csr_eid = agg_csr_eid;
                     ha.alpha_out = alpha_out ? alpha_out + (int64_t)i * E * H : nullptr;
                     ha.slope = d->negative_slope;
                 }
@@ -1655,7 +1669,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                     hs.epc = reinterpret_cast<const float*>(wbase + WL.epc); hs.epc_hop = (int64_t)(WL.epc_hop / sizeof(float));
                     hs.graph_term = Di > 0 ? P(L.T) : nullptr; hs.t_hop = (int64_t)B * Tld;
                     hs.Vn = Vn_all;
-                    hs.csr_eid = g->csr_eid; hs.a_edge = P(L.a_edge); hs.a_edge_stride = (int64_t)K * H;
+                    hs.csr_eid = agg_csr_eid; hs.a_edge = P(L.a_edge); hs.a_edge_stride = (int64_t)K * H;
                     hs.X4a = X4[0]; hs.X4b = X4[1];
                     hs.slope = d->negative_slope; hs.K = K;
                     for (int j = 0; j < K; ++j) {
@@ -1665,11 +1679,11 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
                     }
                     ha.out = out; ha.X4out = nullptr; ha.gmax_out = nullptr;
                     ha.alpha_csr = nullptr; ha.a_node_in = P(L.a_node); ha.a_node_out = nullptr; ha.Vn_next = nullptr;
-                    rc = launch_hopagg_seq(H, ha, hs, g->num_row_groups, stream);
+                    rc = launch_hopagg_seq(H, ha, hs, ngroups, stream);
                     if (rc) return rc;
                     continue;
                 }
-                rc = launch_hopagg(H, ha, g->num_row_groups, stream, cp);
+                rc = launch_hopagg(H, ha, ngroups, stream, cp);
                 if (rc) return rc;
             }
         }

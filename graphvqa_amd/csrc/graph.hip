@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256) void k_stats(int64_t N, int64_t B, const int32
 
 struct GraphLayout {
     size_t rowptr, csr_src, csr_eid, node_graph, graph_ptr, stats, row_group, row_group_e, deg, rank, slot_eid, tile_sum, graph_eptr, row_order, total;
+    size_t clear_bytes;         // what gvqa_graph_build zeroes: everything in front of the packed plan's arrays (they are written in full when used)
+    size_t pk_plan, pk_rowptr, pk_csr_src, pk_csr_eid, pk_node_graph, pk_node_old;      // packed row groups (plan_packed)
 };
 
 constexpr int ROW_GROUP = 128;      // rows of one group of the fused hop kernel (half a 256-row block tile)
@@ -317,8 +319,180 @@ static GraphLayout graph_layout(int64_t N, int64_t E, int64_t B) {
     L.tile_sum = take(cdiv(N + 1, SCAN_TILE) + 1);
     L.graph_eptr = take(B + 1);
     L.row_order = take(N);
+    L.clear_bytes = off;
+    // packed row groups: [group_ptr (B + 2) | group_eptr (B + 2) | group_gptr (B + 2) | graph_old (B)] uploaded as one image, then the packed CSR
+    L.pk_plan = take(3 * (B + 2) + B);
+    L.pk_rowptr = take(N + 1);
+    L.pk_csr_src = take(E);
+    L.pk_csr_eid = take(E);
+    L.pk_node_graph = take(N);
+    L.pk_node_old = take(N);
     L.total = off;
     return L;
+}
+
+// ---- packed row groups (gvqa_graph::pk_*) ---------------------------------------------------------------------------------
+// The in-order groups below leave a ragged batch's groups partly empty; the aggregate-first hop (hopagg.hip) runs one workgroup
+// per group and CU, so what counts is the NUMBER of groups against the CU count.  plan_packed re-orders the graphs (best fit
+// decreasing: <= 128 nodes and <= PK_EDGE_CAP in-edges per group) and k_build_packed copies the CSR into that numbering: one
+// block per packed group, rows copied slot for slot (same in-row COO order: every per-node sum is unchanged, bit for bit).
+constexpr int PK_EDGE_CAP = 1024;       // = HA_ECAP of hopagg.hip: the CSR slice of a row group it keeps in LDS
+__global__ __launch_bounds__(256) void k_build_packed(int64_t N, int64_t E, const int32_t* __restrict__ group_ptr, const int32_t* __restrict__ group_eptr,
+                                                      const int32_t* __restrict__ group_gptr, const int32_t* __restrict__ graph_old,
+                                                      const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ csr_src, const int32_t* __restrict__ csr_eid,
+                                                      int32_t* __restrict__ pk_rowptr, int32_t* __restrict__ pk_csr_src, int32_t* __restrict__ pk_csr_eid,
+                                                      int32_t* __restrict__ pk_node_graph, int32_t* __restrict__ pk_node_old) {
+    __shared__ int gstart_s[ROW_GROUP + 1], gold0_s[ROW_GROUP], scan_s[8];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int ns = group_ptr[t], cnt = group_ptr[t + 1] - ns;
+    const int j0 = group_gptr[t], nj = min(group_gptr[t + 1] - j0, ROW_GROUP);
+    const int e0 = group_eptr[t];
+    if (tid < nj) {
+        const int q = graph_old[j0 + tid];
+        const int p0 = graph_ptr[q];
+        gold0_s[tid] = p0;
+        gstart_s[tid + 1] = graph_ptr[q + 1] - p0;          // (node count; prefix-summed below)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int j = 0; j < nj; ++j) { const int c = gstart_s[j + 1]; gstart_s[j] = acc; acc += c; }
+        gstart_s[nj] = acc;
+    }
+    __syncthreads();
+    int j = 0, o = 0, lo = 0, deg = 0;
+    if (tid < cnt) {
+        while (j + 1 < nj && gstart_s[j + 1] <= tid) ++j;
+        o = gold0_s[j] + (tid - gstart_s[j]);
+        lo = rowptr[o];
+        deg = rowptr[o + 1] - lo;
+    }
+    int total = 0;
+    const int ex = block_exclusive_scan(deg, &total, scan_s);
+    if (tid < cnt) {
+        pk_rowptr[ns + tid] = e0 + ex;
+        pk_node_old[ns + tid] = o;
+        pk_node_graph[ns + tid] = j0 + j;
+        const int shift = ns + gstart_s[j] - gold0_s[j];     // old node id -> packed node id inside this graph
+        for (int k = 0; k < deg; ++k) {
+            pk_csr_src[e0 + ex + k] = csr_src[lo + k] + shift;
+            pk_csr_eid[e0 + ex + k] = csr_eid[lo + k];
+        }
+    }
+    if (tid == 0 && t == (int)gridDim.x - 1) pk_rowptr[N] = (int32_t)E;
+}
+
+// Host side: best fit decreasing over the non-empty graphs (sizes are small integers: counting sort by node count, open groups
+// bucketed by their free rows -- O(B x 128) worst case, O(B) in practice), then one upload and one launch.  `hp` / `he`: host copies
+// of graph_ptr [B + 1] and of the graphs' first in-edge slots [B + 1] (edges counted by destination graph).
+static int plan_packed(gvqa_graph* g, const int32_t* hp, const int32_t* he, hipStream_t stream) {
+    g->pk_num_row_groups = 0;
+    g->pk_max_row_group_edges = 0;
+    g->pk_row_group_ptr = g->pk_rowptr = g->pk_csr_src = g->pk_csr_eid = g->pk_node_graph = g->pk_node_old = g->pk_graph_old = nullptr;
+    const int mode = get_option(GVQA_OPT_PACKED_GROUPS);
+    const int64_t B = g->num_graphs, N = g->num_nodes, E = g->num_edges;
+    const int G0 = g->num_row_groups;
+    if (mode == 0 || G0 <= 1 || !g->intra_graph || N <= 0 || B <= 0) return GVQA_OK;
+    const int64_t cus = device_cu_count();
+    const int64_t gmin = cdiv(N, ROW_GROUP);
+    if (mode == 1 ? cdiv(gmin, cus) >= cdiv((int64_t)G0, cus) : gmin >= G0) return GVQA_OK;      // no order of the graphs can pay
+    static thread_local std::vector<int32_t> order, bin_rows, bin_edges, bin_of, byrem_head, byrem_next;
+    // graphs by node count, largest first (ties in batch order); empty graphs take no rows
+    int32_t cnt_by_size[ROW_GROUP + 2] = {0};
+    for (int64_t q = 0; q < B; ++q) {
+        const int32_t n = hp[q + 1] - hp[q];
+        if (n > ROW_GROUP || he[q + 1] - he[q] > PK_EDGE_CAP) return GVQA_OK;              // (a graph the aggregate-first hop cannot take anyway)
+        ++cnt_by_size[n];
+    }
+    int32_t first_of_size[ROW_GROUP + 2];
+    { int32_t acc = 0; for (int n = ROW_GROUP; n >= 0; --n) { first_of_size[n] = acc; acc += cnt_by_size[n]; } }
+    order.resize(B);
+    for (int64_t q = 0; q < B; ++q) order[first_of_size[hp[q + 1] - hp[q]]++] = (int32_t)q;
+    const int64_t nonempty = B - cnt_by_size[0];
+    bin_rows.clear(); bin_edges.clear();
+    bin_of.assign(B, -1);
+    byrem_head.assign(ROW_GROUP + 1, -1);       // open groups by free rows: singly linked stacks (head per free-row count, next per group)
+    byrem_next.clear();
+    for (int64_t k = 0; k < nonempty; ++k) {
+        const int32_t q = order[k], n = hp[q + 1] - hp[q], e = he[q + 1] - he[q];
+        int32_t take = -1, take_rem = 0, take_prev = -1;
+        for (int rem = n; rem <= ROW_GROUP && take < 0; ++rem) {                           // best fit: the fullest group that still takes it
+            int32_t prev = -1;
+            for (int32_t b = byrem_head[rem]; b >= 0; prev = b, b = byrem_next[b])
+                if (bin_edges[b] + e <= PK_EDGE_CAP) { take = b; take_rem = rem; take_prev = prev; break; }
+        }
+        if (take < 0) {
+            take = (int32_t)bin_rows.size();
+            bin_rows.push_back(0); bin_edges.push_back(0); byrem_next.push_back(-1);
+        } else {                                                                           // unlink from its free-row list
+            if (take_prev < 0) byrem_head[take_rem] = byrem_next[take];
+            else byrem_next[take_prev] = byrem_next[take];
+        }
+        bin_rows[take] += n; bin_edges[take] += e;
+        bin_of[q] = take;
+        const int rem = ROW_GROUP - bin_rows[take];
+        byrem_next[take] = byrem_head[rem];
+        byrem_head[rem] = take;
+    }
+    const int64_t G1 = (int64_t)bin_rows.size();
+    if (mode == 1 ? cdiv(G1, cus) >= cdiv((int64_t)G0, cus) : G1 >= G0) return GVQA_OK;
+    // the upload image: [group_ptr | group_eptr | group_gptr | graph_old]; graphs of a group in placement order (largest first),
+    // the empty graphs behind the last group
+    GraphLayout L = graph_layout(N, E, B);
+    char* base = const_cast<char*>(reinterpret_cast<const char*>(g->rowptr)) - L.rowptr;
+    const size_t words = (size_t)(3 * (B + 2) + B);
+    struct Slot { int32_t* v = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; int device = -1; };
+    static thread_local Slot ring[4];
+    static thread_local int next = 0;
+    Slot& sl = ring[next];
+    next = (next + 1) & 3;
+    int dev = -1;
+    GVQA_HIP_CHECK(hipGetDevice(&dev));
+    if (sl.used) GVQA_HIP_CHECK(hipEventSynchronize(sl.done));
+    if (sl.done && sl.device != dev) { GVQA_HIP_CHECK(hipEventDestroy(sl.done)); sl.done = nullptr; }
+    if (!sl.done) { GVQA_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)); sl.device = dev; }
+    if (sl.cap < words) {
+        if (sl.v) GVQA_HIP_CHECK(hipHostFree(sl.v));
+        sl.v = nullptr; sl.cap = 0;
+        const size_t want = std::max<size_t>(words, 4096) * 2;
+        GVQA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sl.v), want * sizeof(int32_t), hipHostMallocDefault));
+        sl.cap = want;
+    }
+    int32_t *s_grp = sl.v, *s_gre = sl.v + (B + 2), *s_gg = sl.v + 2 * (B + 2), *s_old = sl.v + 3 * (B + 2);
+    // group_gptr from the groups' graph counts, then the graphs dealt into their group's range in placement order
+    for (int64_t b = 0; b <= G1; ++b) s_gg[b] = 0;
+    for (int64_t k = 0; k < nonempty; ++k) ++s_gg[bin_of[order[k]] + 1];
+    for (int64_t b = 0; b < G1; ++b) s_gg[b + 1] += s_gg[b];
+    {
+        static thread_local std::vector<int32_t> cursor;
+        cursor.assign(s_gg, s_gg + G1);
+        for (int64_t k = 0; k < nonempty; ++k) s_old[cursor[bin_of[order[k]]]++] = order[k];
+        for (int64_t k = nonempty; k < B; ++k) s_old[k] = order[k];
+    }
+    int32_t max_e = 0;
+    s_grp[0] = 0; s_gre[0] = 0;
+    for (int64_t b = 0; b < G1; ++b) {
+        s_grp[b + 1] = s_grp[b] + bin_rows[b];
+        s_gre[b + 1] = s_gre[b] + bin_edges[b];
+        max_e = std::max(max_e, bin_edges[b]);
+    }
+    int32_t* plan_dev = reinterpret_cast<int32_t*>(base + L.pk_plan);
+    GVQA_HIP_CHECK(hipMemcpyAsync(plan_dev, sl.v, words * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    GVQA_HIP_CHECK(hipEventRecord(sl.done, stream));
+    sl.used = true;
+    auto P = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
+    hipLaunchKernelGGL(k_build_packed, dim3((unsigned)G1), dim3(256), 0, stream, N, E, plan_dev, plan_dev + (B + 2), plan_dev + 2 * (B + 2),
+                       plan_dev + 3 * (B + 2), g->graph_ptr, g->rowptr, g->csr_src, g->csr_eid, P(L.pk_rowptr), P(L.pk_csr_src), P(L.pk_csr_eid),
+                       P(L.pk_node_graph), P(L.pk_node_old));
+    GVQA_LAUNCH_CHECK();
+    g->pk_num_row_groups = (int32_t)G1;
+    g->pk_max_row_group_edges = max_e;
+    g->pk_row_group_ptr = plan_dev;
+    g->pk_graph_old = plan_dev + 3 * (B + 2);
+    g->pk_rowptr = P(L.pk_rowptr); g->pk_csr_src = P(L.pk_csr_src); g->pk_csr_eid = P(L.pk_csr_eid);
+    g->pk_node_graph = P(L.pk_node_graph); g->pk_node_old = P(L.pk_node_old);
+    return GVQA_OK;
 }
 
 // Row groups for the fused hop kernel: greedy in order, a group closes when the next graph would not fit.  `hp` / `he`:
@@ -388,7 +562,7 @@ static int plan_row_groups(gvqa_graph* g, const int32_t* hp, const int32_t* he, 
     hipLaunchKernelGGL(k_row_group_order, dim3((unsigned)g->num_row_groups), dim3(ROW_GROUP), 0, stream, grp_dev, g->rowptr, order);
     GVQA_LAUNCH_CHECK();
     g->row_group_order = order;
-    return GVQA_OK;
+    return plan_packed(g, hp, he, stream);
 }
 
 }  // namespace gvqa
@@ -420,7 +594,7 @@ int gvqa_graph_build(int64_t N, int64_t E, int64_t B, const int64_t* edge_index,
     char* base = static_cast<char*>(ws);
     auto P = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
 
-    GVQA_HIP_CHECK(hipMemsetAsync(ws, 0, L.total, stream));
+    GVQA_HIP_CHECK(hipMemsetAsync(ws, 0, L.clear_bytes, stream));
     int64_t m = N > E ? N : E;
     if (m > 0) {
         hipLaunchKernelGGL(k_count, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, stream, N, E, B, edge_index,
@@ -613,7 +787,7 @@ int gvqa_graph_build_grouped(int64_t N, int64_t E, int64_t B, const int64_t* edg
     out->intra_graph = 1; out->valid = 1; out->finalized = 1;
     out->row_group_ptr = P(L.row_group); out->num_row_groups = G; out->max_row_group_edges = max_e;
     out->row_group_order = P(L.row_order);
-    return GVQA_OK;
+    return plan_packed(out, hp, he, stream);
 }
 
 // The deferred check behind gvqa_graph_finalize_host: that call reads nothing back, so a wrong loader-side layout (counts by

@@ -114,7 +114,7 @@ int launch_hopagg_pack_w(int H, int C, int Dn, const float* W, int64_t ldw, void
 // leave with the rows (out of the slab in LDS: thread (row, quarter) takes every fourth chunk) -- hop 0 needs no pass of its own over x.
 __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ group_ptr, const int32_t* __restrict__ node_graph, int D, int NQ,
                                                     const float* __restrict__ X, int64_t ld, float* __restrict__ X4, float* __restrict__ gmax,
-                                                    const float* __restrict__ Vn, float* __restrict__ a_node) {
+                                                    const float* __restrict__ Vn, float* __restrict__ a_node, const int32_t* __restrict__ row_map) {
     __shared__ float4 slab[HA_ROWS][33];         // 32 chunks (+1: the column walk of the write phase is conflict-free)
     __shared__ unsigned gm_s[HA_ROWS];
     __shared__ float4 vn_s[8][32];               // Vn columns of the current 128-column block
@@ -135,13 +135,20 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
     // as block q0 sits in the slab -- they travel under its node-logit FMAs, its chunk writes and both barriers (issued at the top of the
     // iteration, every block's read latency was exposed: 82 us for 268 MB)
     float4 pre[8], prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (packed row groups: row r of the group is row row_map[ns + r] of X -- whole rows still move as 512-byte segments)
+    int xrow[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int r = (u * 512 + tid) >> 5;
+        xrow[u] = r < cnt ? (row_map ? row_map[ns + r] : ns + r) : 0;
+    }
     auto load_block = [&](int q0) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = u * 512 + tid, r = idx >> 5, p = idx & 31, q = q0 + p;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < cnt && q < NQ) {
-                const float* src = X + (int64_t)(ns + r) * ld + q * 4;
+                const float* src = X + (int64_t)xrow[u] * ld + q * 4;
                 if (q * 4 + 4 <= D) v = *reinterpret_cast<const float4*>(src);
                 else { v.x = src[0]; if (q * 4 + 1 < D) v.y = src[1]; if (q * 4 + 2 < D) v.z = src[2]; }
             }
@@ -222,12 +229,15 @@ __global__ __launch_bounds__(512) void k_rows_to_x4(const int32_t* __restrict__ 
     }
 }
 
-int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream, const float* Vn, float* a_node) {
+int launch_rows_to_x4(const gvqa_graph* g, int D, const float* X, int64_t ld, float* X4, float* gmax, hipStream_t stream, const float* Vn, float* a_node,
+                      bool packed) {
     GVQA_REQUIRE(g && g->num_row_groups > 0 && X && X4 && gmax && D > 0 && ld >= D && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
                  GVQA_E_INVALID, "rows_to_x4: bad argument");
     GVQA_REQUIRE(!Vn == !a_node, GVQA_E_INVALID, "rows_to_x4: node logits need both the folded vectors and their destination");
-    hipLaunchKernelGGL(k_rows_to_x4, dim3((unsigned)g->num_row_groups), dim3(512), 0, stream, g->row_group_ptr, g->node_graph, D, (int)cdiv(D, 4), X, ld,
-                       X4, gmax, Vn, a_node);
+    GVQA_REQUIRE(!packed || g->pk_num_row_groups > 0, GVQA_E_INVALID, "rows_to_x4: the handle has no packed row groups");
+    hipLaunchKernelGGL(k_rows_to_x4, dim3((unsigned)(packed ? g->pk_num_row_groups : g->num_row_groups)), dim3(512), 0, stream,
+                       packed ? g->pk_row_group_ptr : g->row_group_ptr, packed ? g->pk_node_graph : g->node_graph, D, (int)cdiv(D, 4), X, ld,
+                       X4, gmax, Vn, a_node, packed ? g->pk_node_old : nullptr);
     GVQA_LAUNCH_CHECK();
     return GVQA_OK;
 }
@@ -326,9 +336,9 @@ __device__ __forceinline__ int ha_wave_max(int v) {
 }
 
 // LDS map (bytes): weight ring 3 x 32 KiB | A' ring 2 x 8 KiB | x ring 4 x 2 KiB | CSR slice: src [ECAP] ints, alpha [ECAP][4] floats |
-// per-row: 1 / (scale H), graph id, in-degree | per-graph output maxima
+// per-row: 1 / (scale H), graph id, in-degree, row of graph_term, row of `out` | per-graph output maxima
 constexpr unsigned HA_BSTAGE = 16 * 2048, HA_B0 = 0, HA_A0 = 3 * HA_BSTAGE, HA_X0 = HA_A0 + 2 * 8192, HA_SRC0 = HA_X0 + 4 * 2048,
-                   HA_AL0 = HA_SRC0 + HA_ECAP * 4, HA_ROW0 = HA_AL0 + HA_ECAP * 16, HA_GM0 = HA_ROW0 + 3 * HA_ROWS * 4, HA_LDS = HA_GM0 + HA_ROWS * 4;
+                   HA_AL0 = HA_SRC0 + HA_ECAP * 4, HA_ROW0 = HA_AL0 + HA_ECAP * 16, HA_GM0 = HA_ROW0 + 5 * HA_ROWS * 4, HA_LDS = HA_GM0 + HA_ROWS * 4;
 static_assert(HA_LDS <= 160 * 1024, "hopagg: LDS");
 // One-launch form (SEQ): + the second set of per-graph maxima | the slice's COO edge ids.  BETWEEN two hops of a tile the idle rings
 // hold the next hop's coefficient phase: weight-ring stage 2 = the next hop's folded attention vectors Vn [8][C] | edge halves of the
@@ -403,8 +413,13 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     int relu_h = a.relu;
     const uint16_t *wbase0 = nullptr, *wbase1 = nullptr;
     const float* xbase = nullptr;
+    // (narrow layout, NTP = 10 column tiles: only waves 0 and 1 own a second tile -- the other six used to re-load tile 9 into unused ring
+    //  slots to keep the counted waits uniform: 12 of 34 KiB per K step and CU of L2 -> LDS traffic for nothing.  Now a wave without a
+    //  second tile issues three DMA instructions per step and waits on its own count)
+    const bool b_second = NBU > 1 && (NTP >= 16 || __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + 8 < NTP);
     auto issue_b_unit = [&](int st, int u) {           // weight unit u of step st (clamped) -> ring slot st % NBST
         if (CP > 1 && !b_owner) return;                // (wave-uniform)
+        if (u && !b_second) return;                    // (wave-uniform)
         ha_dma16_x2(ha_uniform((u ? wbase1 : wbase0) + (int64_t)min(st, NQ - 1) * 1024), lane16,
                     __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + (unsigned)(st % NBST) * BST + (unsigned)(wave + 8 * u) * 2048u));
     };
@@ -451,8 +466,9 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     unsigned so2[HA_NOV / 2];                         // their rows' byte offsets in a chunk (slot x 16), two per register
     float pscale = 1.f;
     int pg = 0;                                       // graph of this lane's node
+
     // the rows' power-of-two scale from their graph's largest input magnitude; per-row arrays of the epilogue
-    auto set_row_scale = [&](float gmax_of_graph, bool first) {
+    auto set_row_scale = [&](float gmax_of_graph, bool first, int pgt_ = 0) {      // pgt_ (first call): the graph's row of graph_term (packed row groups: its id in the batch; otherwise pg)
         const int ex = split2h_exponent(gmax_of_graph);
         pscale = pow2i(ex);
         float* row_l = reinterpret_cast<float*>(smem + HA_ROW0);
@@ -461,6 +477,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
             if (first) {
                 reinterpret_cast<int*>(row_l)[HA_ROWS + pi] = pg;
                 reinterpret_cast<int*>(row_l)[2 * HA_ROWS + pi] = pdeg;
+                reinterpret_cast<int*>(row_l)[3 * HA_ROWS + pi] = pgt_;
+                reinterpret_cast<int*>(row_l)[4 * HA_ROWS + pi] = p_on ? (a.row_map ? a.row_map[ns + pi] : ns + pi) : 0;
             }
         }
     };
@@ -676,7 +694,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
         /* this wave's DMAs of step s + 1 (issued one step ago) have landed, its A' writes are out; then everybody's */     \
         if (!GVQA_HA_DBG(16)) {                                                                                             \
-            if (CP == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
+            if (CP == 1 && (NTP >= 16 || b_second)) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
+            else if (CP == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");   /* (a wave with one weight tile: three) */ \
             else if (b_owner) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");   /* (column parts: the last PD - 1 = 3 steps' DMAs -- 3 per step, */ \
             else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                /*  or the x DMA alone for a wave without a weight tile) */   \
             __builtin_amdgcn_s_barrier();                                                                                   \
@@ -755,10 +774,11 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         ovn = min(max(ha_wave_max(pdeg) - HA_DMAX, 0), HA_NOV);
         ovtrips = max(ha_wave_max(pdeg) - HA_DMAX - HA_NOV, 0);
         pg = a.node_graph[ns + min(pi, cnt - 1)];
-        if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pg * a.t_ld + a.C + ph];
+        const int pgt = a.graph_old ? a.graph_old[pg] : pg;
+        if (gterm_h && p_on) tlog0 = gterm_h[(int64_t)pgt * a.t_ld + a.C + ph];
         float gmx = a.gmax_in[pg];
         for (int pp = 1; pp < nparts; ++pp) gmx = fmaxf(gmx, a.gmax_in[(int64_t)pp * a.gm_part_stride + pg]);
-        set_row_scale(gmx, true);
+        set_row_scale(gmx, true, pgt);
         if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM0)[tid] = 0u;
         if constexpr (SEQ) { if (tid < HA_ROWS) reinterpret_cast<unsigned*>(smem + HA_GM1)[tid] = 0u; }
     }
@@ -896,7 +916,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                 for (int h = 0; h < H; ++h)
                     lds_dma4_b(src + h, __builtin_amdgcn_readfirstlane(lds_base + HA_ST0 + (unsigned)(h * HA_ECAP + u) * 4u));
             }
-            if (gterm_next && p_on) tlog = gterm_next[(int64_t)pg * a.t_ld + C + ph];
+            if (gterm_next && p_on) tlog = gterm_next[(int64_t)reinterpret_cast<const int*>(smem + HA_ROW0)[3 * HA_ROWS + pi] * a.t_ld + C + ph];     // (the graph's row of graph_term: out of LDS, not carried across the hop)
             const uint16_t* wkn = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(hs.Wk) + (hop + 1) * hs.w_hop_bytes);
             wbase0 = wkn + (int64_t)min(wave, NCT - 1) * NQ * 1024;
             wbase1 = wkn + (int64_t)min(wave + 8, NCT - 1) * NQ * 1024;
@@ -990,11 +1010,12 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(r), "+v"(hb));             // (addresses formed here, per batch: carried from batch to batch -- row parts, column parts -- they spill)
 #endif
+            const int gt_row = reinterpret_cast<const int*>(row_l)[3 * HA_ROWS + r];      // (row of graph_term: out of LDS per batch, not carried in registers)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int cc = min(cbase + (wc * TN + j) * 32 + 8 * (2 * qp + u) + 4 * hb, C - 4);       // (columns past C: clamped re-reads, never used)
                 sk[u] = ha_row_load(X4in_h + (((int64_t)t * NQ + (cc >> 2)) * HA_ROWS + r) * 4);
-                tg[u] = *reinterpret_cast<const float4*>(gt_ + (int64_t)g_[i] * gt_ld + cc);
+                tg[u] = *reinterpret_cast<const float4*>(gt_ + (int64_t)gt_row * gt_ld + cc);
             }
         };
         auto consume_batch = [&](int b, const float4 (&sk_)[2], const float4 (&tg_)[2]) {
@@ -1003,7 +1024,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(r));
 #endif
-            const int64_t node = ns + r;
+            const int64_t node = out_h ? reinterpret_cast<const int*>(row_l)[4 * HA_ROWS + r] : 0;      // (row of `out`: ns + r, or through the packed plan's row map)
             const float rf = rf_[i], tm = tmask_[i];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

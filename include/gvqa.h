@@ -90,6 +90,23 @@ typedef struct gvqa_graph {
     int32_t max_row_group_edges;    /* most in-edges of any row group                              */
     const int32_t* row_group_order; /* [N], device: the rows of every group by in-degree, largest first (slot s of group r =
                                        local row row_group_order[row_group_ptr[r] + s]); the fused hop aggregates in this order */
+    /* PACKED row groups (round 6; valid after finalize, pk_num_row_groups == 0: none).  The groups above cut the node range IN
+     * ORDER, so a ragged batch leaves every group partly empty (graphs of 20..40 nodes: 114 of 128 rows on average) -- and the
+     * aggregate-first hop runs ONE workgroup per group and CU: config 2's 262 groups are two rounds on 256 CUs where 235 full
+     * groups would be one.  When re-ordering the GRAPHS lets the groups fill up and that saves a round (GVQA_OPT_PACKED_GROUPS),
+     * finalize also leaves the batch in a packed numbering: graphs placed best-fit-decreasing into groups of <= 128 nodes and
+     * <= 1024 in-edges, nodes of a graph consecutive and in their order, CSR rows copied slot for slot (the per-node COO order --
+     * and with it every sum -- is unchanged).  Only the aggregate-first hop kernels read these; they gather the input rows and
+     * scatter the output rows through pk_node_old, so callers never see the numbering. */
+    int32_t pk_num_row_groups;
+    int32_t pk_max_row_group_edges;
+    const int32_t* pk_row_group_ptr; /* [pk_num_row_groups + 1] first packed node of group r                                  */
+    const int32_t* pk_rowptr;        /* [N+1] CSR row pointer by packed destination node                                       */
+    const int32_t* pk_csr_src;       /* [E]   packed source node of packed CSR slot s                                          */
+    const int32_t* pk_csr_eid;       /* [E]   COO edge id of packed CSR slot s                                                 */
+    const int32_t* pk_node_graph;    /* [N]   packed graph index (position in the packed graph order) of packed node n         */
+    const int32_t* pk_node_old;      /* [N]   node id (row of x / out) of packed node n                                        */
+    const int32_t* pk_graph_old;     /* [B]   graph id (row of instr_vectors[i]) of packed graph index j                       */
 } gvqa_graph;
 
 GVQA_API size_t gvqa_graph_workspace_bytes(int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
@@ -436,8 +453,9 @@ enum gvqa_option {
                                       2: the same as the persistent kernel of csrc/hop2.hip (two 4-wave workgroups per CU, one's aggregation
                                          under the other's matrix-core loop; two-piece operands), hops CHAINED: a hop leaves the next hop's
                                          packed operand, so only the first hop has a pack pass;
-                                      3 (default): mode 5's form (plain outputs; mode 4's otherwise) when H = 4, C == node_dim, 320 < C <= 512 and the
-                                         batch's row groups fill the CUs' last round (two rounds from 0.76 full, three from 0.82, else 0.85); else with H = 4 and >= 128 row groups, 1 with the hops chained (the 8-wave kernel writes the next
+                                      3 (default): mode 5's form (plain outputs; mode 4's otherwise) when H = 4, C == node_dim, 256 < C <= 512 and the
+                                         batch's row groups -- the PACKED ones when the handle has them, GVQA_OPT_PACKED_GROUPS -- fill the CUs' last round
+                                         (two rounds from 0.76 full, three from 0.82, else 0.85); else with H = 4 and >= 128 row groups, 1 with the hops chained (the 8-wave kernel writes the next
                                          hop's packed operand too: the faster of the two chained forms, round 4); otherwise 2 when the batch has
                                          >= 6 (row group, column block) items per workgroup slot, else 1;
                                       4: the aggregate-first kernel of csrc/hopagg.hip (H = 4, C == node_dim <= 512: heads concatenated along K,
@@ -466,7 +484,10 @@ enum gvqa_option {
     GVQA_OPT_TN_DIRECT = 9,        /* weight gradient dW = dy^T x (gvqa_linear_tn_split2h, gvqa_linear_backward_split2h): 1 (default) the product reads the
                                       row-major fp32 operands itself and transposes them on the way into the MFMA fragment image (tn_direct.hip); 0 = both
                                       operands packed transposed in HBM first (round 3's form; same scales, pieces and chunks) */
-    GVQA_NUM_OPTIONS = 10
+    GVQA_OPT_PACKED_GROUPS = 10,   /* packed row groups for the aggregate-first hops (gvqa_graph::pk_*): 1 (default) built at finalize when re-ordering the
+                                      graphs saves a round of workgroups on this device, and then used by those hops; 0 never; 2 built whenever it saves a
+                                      row group at all (tests).  Read at gvqa_graph_finalize* / gvqa_graph_build_grouped time. */
+    GVQA_NUM_OPTIONS = 11
 };
 #define GVQA_PROJECTION_SPLIT3 0   /* three exact bf16 pieces per fp32 value, six bf16-MFMA products, fp32 accumulate */
 #define GVQA_PROJECTION_F32 1      /* f32-input MFMA (k_linear_f32*) */

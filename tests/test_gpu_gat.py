@@ -851,6 +851,167 @@ def test_aggregate_first_one_launch_parity_sweep(dev, stratum):
     assert ran >= 8 and not bad, (ran, len(bad), bad[:3])
 
 
+def _ragged_batch(rng, B, lo, hi, dens):
+    sizes = rng.integers(lo, hi + 1, size=B)
+    if sizes.sum() == 0:
+        sizes[0] = 1
+    batch = np.repeat(np.arange(B), sizes).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    src, dst = [np.zeros(0, np.int64)], [np.zeros(0, np.int64)]
+    for g in range(B):
+        n = int(sizes[g])
+        if n == 0:
+            continue
+        e = int(rng.integers(0, int(dens * n) + 1))
+        src.append(np.concatenate([np.arange(n), rng.integers(0, n, size=e)]) + offs[g])      # one self loop per node first, then random intra-graph edges
+        dst.append(np.concatenate([np.arange(n), rng.integers(0, n, size=e)]) + offs[g])
+    return np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64), batch, sizes
+
+
+def test_default_rule_takes_the_packed_one_launch_form_at_config2(dev):
+    """BASELINE config 2 under DEFAULT options (round 6): 1000 graphs of 20..40 nodes cut in order are 262 row groups -- two rounds of
+    one-workgroup-per-CU launches on 256 CUs -- so finalize leaves the packed numbering (<= 256 fuller groups: one round) and the
+    default rule runs the d = 300 forward as the layout pass + ONE aggregate-first launch on it.  Against the oracle at 1e-4 (plain
+    output, attention weights, per-hop rows), and bit for bit against the in-order groups."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    gb = synth.config2_batch()
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    p = synth.gat_seq_params(300, 300, 300, 512, 5, 4, seed=303)
+    x, ea, ins = synth.normal((N, 300), 1), synth.normal((E, 300), 2), synth.normal((5, B, 512), 3)
+    ref, hs, alphas = R.gat_seq(t(x), t(gb.edge_index), t(ea), t(ins), t(gb.batch), tparams(p), return_all=True)
+    m = _load_module(gat_seq(300, 300, 300, 512, 5, dropout=0.1, gat_heads=4), p, dev)
+    args = [t(a, device=dev) for a in (x, gb.edge_index, ea, ins, gb.batch)]
+    lib = _lib.load()
+    assert lib.gvqa_get_option(_lib.OPT_HOP_FUSION) == 3 and lib.gvqa_get_option(_lib.OPT_PACKED_GROUPS) == 1
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    for g in (SceneGraphBatch(args[1], args[4], N, B, host_layout=HostLayout.from_numpy(gb.edge_index, gb.batch, B)), SceneGraphBatch(args[1], args[4], N, B)):
+        if -(-g.c.num_row_groups // cus) > -(-N // 128 // cus) and cus == 256:
+            assert 0 < g.c.pk_num_row_groups <= cus < g.c.num_row_groups, (g.c.pk_num_row_groups, g.c.num_row_groups)
+            assert m.hop_kernel(g) == "aggregate_first_seq"
+        m(*args, graph=g)
+        _lib.prof_enable(True); _lib.prof_collect()
+        try:
+            out = m(*args, graph=g)
+            prof = _lib.prof_collect()
+        finally:
+            _lib.prof_enable(False)
+        if g.c.pk_num_row_groups:
+            assert prof["mp"][1] == 0 and prof["alpha"][1] == 0 and prof["proj"][1] == 1 and prof["pack"][1] == 1, prof
+        out_a, alpha, hops = m(*args, graph=g, return_attention_weights=True, return_hops=True)
+        assert maxabs(out, ref) < TOL and maxabs(out_a, ref) < TOL and maxabs(hops, torch.stack(hs)) < TOL
+        assert maxabs(alpha, torch.stack(alphas)) < 2e-5
+        if g.c.pk_num_row_groups:
+            old = _lib.set_option(_lib.OPT_PACKED_GROUPS, 0)
+            try:
+                m.hop_fusion = 5
+                assert torch.equal(m(*args, graph=g), out)
+            finally:
+                _lib.set_option(_lib.OPT_PACKED_GROUPS, old)
+                m.hop_fusion = None
+
+
+def test_packed_row_groups_plan_is_a_row_permuted_copy_of_the_csr(dev):
+    """gvqa_graph::pk_* (round 6, graph.hip plan_packed / k_build_packed): with GVQA_OPT_PACKED_GROUPS = 2 every ragged batch whose graphs
+    pack into fewer row groups gets the packed numbering.  Checked against numpy, exactly: pk_node_old is a permutation that keeps
+    every graph's nodes consecutive and in order; groups hold whole graphs, <= 128 nodes and <= 1024 in-edges; every packed CSR row is
+    the original row slot for slot (same COO edge ids in the same order, sources renumbered); pk_node_graph / pk_graph_old name the
+    graph.  Both build paths (one-launch grouped build, general build + host finalize, general build + device finalize)."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    rng = np.random.default_rng(606)
+    old = _lib.set_option(_lib.OPT_PACKED_GROUPS, 2)
+    packed_cases = 0
+    try:
+        for case in range(36):
+            B = int(rng.choice([3, 40, 300, 1000]))
+            lo, hi = [(20, 40), (1, 128), (0, 9), (60, 70), (100, 128)][case % 5]
+            ei, batch, sizes = _ragged_batch(rng, B, lo, hi, float(rng.choice([0.0, 1.0, 3.0, 7.0])))
+            N, E = int(batch.shape[0]), int(ei.shape[1])
+            hl = HostLayout.from_numpy(ei, batch, B)
+            eit, bt = t(ei, device=dev), t(batch, device=dev)
+            gs = [SceneGraphBatch(eit, bt, N, B, host_layout=hl),
+                  SceneGraphBatch(eit, bt, N, B, host_layout=HostLayout(hl.graph_ptr, hl.edge_ptr, hl.max_in_degree)),
+                  SceneGraphBatch(eit, bt, N, B)]
+            torch.cuda.synchronize()
+            G1s = {g.c.pk_num_row_groups for g in gs}
+            assert len(G1s) == 1, (case, G1s)
+            for g in gs:
+                G0, G1 = g.c.num_row_groups, g.c.pk_num_row_groups
+                if G1 == 0:
+                    continue
+                assert 0 < G1 < G0 and G1 >= -(-N // 128), (case, G0, G1)
+                packed_cases += 1
+                v = lambda p, n: g._view(p, n).cpu().numpy().astype(np.int64)
+                gp, rp, cs, ce = v(g.c.pk_row_group_ptr, G1 + 1), v(g.c.pk_rowptr, N + 1), v(g.c.pk_csr_src, E), v(g.c.pk_csr_eid, E)
+                ng, no, go = v(g.c.pk_node_graph, N), v(g.c.pk_node_old, N), v(g.c.pk_graph_old, B)
+                rp0, cs0, ce0 = (a.cpu().numpy().astype(np.int64) for a in (g.rowptr, g.csr_src, g.csr_eid))
+                assert np.array_equal(np.sort(no), np.arange(N)) and np.array_equal(np.sort(go), np.arange(B)), case
+                assert gp[0] == 0 and gp[-1] == N and np.all(np.diff(gp) > 0) and np.all(np.diff(gp) <= 128), case
+                assert np.array_equal(batch[no], go[ng]), case                       # the packed graph index names the node's graph
+                assert np.all(np.diff(ng) >= 0), case                                 # graphs consecutive in the packed order ...
+                same = ng[1:] == ng[:-1]
+                assert np.all(no[1:][same] == no[:-1][same] + 1), case                # ... their nodes in order
+                # a group holds whole graphs: no graph index on both sides of a cut
+                cuts = gp[1:-1]
+                assert np.all(ng[cuts] != ng[cuts - 1]), case
+                assert rp[0] == 0 and rp[-1] == E and np.array_equal(np.diff(rp), np.diff(rp0)[no]), case
+                assert g.c.pk_max_row_group_edges == int(np.max(rp[gp[1:]] - rp[gp[:-1]])) <= 1024, case
+                old2new = np.empty(N, np.int64); old2new[no] = np.arange(N)
+                # slot for slot: packed row n = original row no[n]
+                idx0 = np.concatenate([np.arange(rp0[o], rp0[o + 1]) for o in no]) if E else np.zeros(0, np.int64)
+                assert np.array_equal(ce, ce0[idx0]) and np.array_equal(cs, old2new[cs0[idx0]]), case
+    finally:
+        _lib.set_option(_lib.OPT_PACKED_GROUPS, old)
+    assert packed_cases >= 20, packed_cases
+
+
+@pytest.mark.parametrize("C,de,di", [(64, 16, 12), (300, 40, 512), (512, 24, 32)])
+def test_packed_row_groups_forward_equals_the_in_order_groups_bit_for_bit(dev, C, de, di):
+    """The aggregate-first hops (GVQA_OPT_HOP_FUSION = 4 per-hop launches with attention weights and per-hop rows, 5 one launch) on the
+    packed row groups: same graphs, same per-node edge order, same per-graph scales -- so the output must EQUAL the in-order groups'
+    (GVQA_OPT_PACKED_GROUPS = 0 at forward time) bit for bit, and both sit within 1e-4 of the oracle (gat_skip.py:249-279)."""
+    from oracle import ref_torch as R
+    from graphvqa_amd import _lib
+    from graphvqa_amd.gat_skip import gat_seq
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    H, K = 4, 3
+    rng = np.random.default_rng(77 + C)
+    ei, batch, sizes = _ragged_batch(rng, 90, 20, 40, 1.5)
+    N, E, B = int(batch.shape[0]), int(ei.shape[1]), int(sizes.shape[0])
+    p = synth.gat_seq_params(C, C, de, di, K, H, seed=78)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    ref, hops_ref, alphas = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(batch), tparams(p), heads=H, return_all=True)
+    m = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)
+    args = [t(a, device=dev) for a in (x, ei, ea, ins, batch)]
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    old_p = _lib.set_option(_lib.OPT_PACKED_GROUPS, 2)
+    try:
+        g = SceneGraphBatch(args[1], args[4], N, B, host_layout=HostLayout.from_numpy(ei, batch, B))
+        assert 0 < g.c.pk_num_row_groups < g.c.num_row_groups
+        res = {}
+        for packed in (2, 0):
+            _lib.set_option(_lib.OPT_PACKED_GROUPS, packed)
+            for fusion in (5, 4):
+                m.hop_fusion = fusion
+                _lib.prof_enable(True); _lib.prof_collect()
+                out = m(*args, graph=g)
+                pr = _lib.prof_collect(); _lib.prof_enable(False)
+                assert pr["mp"][1] == 0 and pr["alpha"][1] == 0 and pr["proj"][1] == (1 if fusion == 5 else K), (packed, fusion, pr)
+                out_a, alpha, hops = m(*args, graph=g, return_attention_weights=True, return_hops=True)
+                res[(packed, fusion)] = (out, out_a, alpha, hops)
+                assert maxabs(out, ref) < TOL and maxabs(out_a, ref) < TOL, (packed, fusion)
+                assert maxabs(alpha, torch.stack(alphas)) < 5e-5 and maxabs(hops, torch.stack(hops_ref)) < TOL, (packed, fusion)
+        for fusion in (5, 4):
+            for a, b_ in zip(res[(2, fusion)], res[(0, fusion)]):
+                assert torch.equal(a, b_), fusion
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+        _lib.set_option(_lib.OPT_PACKED_GROUPS, old_p)
+
+
 @pytest.mark.parametrize("shape", ["shard256_d512", "config2_like_d300", "ragged_d64", "tiny", "isolated_nodes", "dense_row_groups", "one_hop", "no_instructions"])
 def test_chained_hops_with_in_kernel_coefficients(dev, shape):
     """GVQA_OPT_HOP_COEFFS = 1 (default): the chained 8-wave hop kernel computes its attention coefficients itself (csrc/split3.hip,
