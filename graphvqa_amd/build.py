@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgvqa_hip.so")
-SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "hopagg.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "lcgn.hip", "head.hip", "encoder.hip", "collate.hip", "train.hip", "tn_direct.hip"]
+SOURCES = ["capi.hip", "graph.hip", "gemm.hip", "gemm_bf16.hip", "split3.hip", "hop2.hip", "hopagg.hip", "gat.hip", "gat_bwd.hip", "bn_train.hip", "variants.hip", "gine_mlp.hip", "lcgn.hip", "head.hip", "encoder.hip", "collate.hip", "train.hip", "tn_direct.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file additions.  hopagg.hip: no SLP vectorisation -- its K step interleaves scalar fp32 FMAs with MFMAs, and packed fp32 math
 # (v_pk_fma_f32, what the SLP pass makes of adjacent FMAs) costs the matrix-core stream more than two plain FMAs (MI355X_MICROARCH.md)

@@ -330,5 +330,11 @@ size_t linear_auto_scratch_bytes(int64_t M, int64_t N, int64_t K);
 int launch_linear_auto(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, LinearEpilogue ep,
                        float* C, int64_t ldc, void* scratch, size_t scratch_bytes, hipStream_t stream);
 const char* gemm_backend_name();
+// gine_mlp.hip: GINEConv's Lin -> ReLU -> Lin as one kernel (C <= 320; the hidden rows stay in registers)
+size_t gine_mlp_packed_bytes(int C, int Dn);
+bool gine_mlp_supported(int64_t N, int C, int Dn, const float* z, int64_t ldz, const float* out, int64_t ldo, int64_t ldp);
+int launch_gine_mlp(int64_t N, int C, int Dn, const float* z, int64_t ldz, const float* zmax, const float* W1, int64_t ld1, const float* b1,
+                    const float* W2, int64_t ld2, const float* b2, const float* P1, const float* P2, int64_t ldp, const int32_t* node_graph,
+                    const int32_t* rowptr, float eps, float* out, int64_t ldo, void* packed, hipStream_t stream);
 
 }  // namespace gvqa

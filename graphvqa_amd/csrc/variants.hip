@@ -56,12 +56,13 @@ __global__ __launch_bounds__(256) void k_gine_aggregate(int N, int D, const floa
                                                         const float* __restrict__ ea, const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ csr_src,
                                                         const int32_t* __restrict__ csr_eid, float eps,
-                                                        float* __restrict__ z) {
+                                                        float* __restrict__ z, float* __restrict__ zmax) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;
     const int lo = rowptr[i], hi = rowptr[i + 1];
     const float one_eps = 1.0f + eps;
+    float vmax = 0.f;                                 // largest |z| of the row: the fused MLP's row scale (gine_mlp.hip) comes for free here
     if (VEC) {
         for (int c = lane * 4; c < D; c += 256) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -85,20 +86,33 @@ __global__ __launch_bounds__(256) void k_gine_aggregate(int N, int D, const floa
             const float4 xi = *reinterpret_cast<const float4*>(h + (int64_t)i * D + c);
             acc.x += one_eps * xi.x; acc.y += one_eps * xi.y; acc.z += one_eps * xi.z; acc.w += one_eps * xi.w;
             *reinterpret_cast<float4*>(z + (int64_t)i * D + c) = acc;
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
         }
     } else {
         for (int c = lane; c < D; c += 64) {
             float acc = 0.f;
             for (int s = lo; s < hi; ++s)
                 acc += fmaxf(h[(int64_t)csr_src[s] * D + c] + ea[(int64_t)csr_eid[s] * D + c], 0.f);
-            z[(int64_t)i * D + c] = acc + one_eps * h[(int64_t)i * D + c];
+            const float v = acc + one_eps * h[(int64_t)i * D + c];
+            z[(int64_t)i * D + c] = v;
+            vmax = fmaxf(vmax, fabsf(v));
         }
+    }
+    if (zmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if (lane == 0) zmax[i] = vmax;
     }
 }
 
 __global__ __launch_bounds__(256) void k_relu2(int64_t n, const float* __restrict__ in, float* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = fmaxf(in[i] + in[i], 0.f);      // relu(x_j + e) with both halves = ins[g]
+}
+// ... and [ins ; relu(2 ins)] as one [2 B, Di] operand: both per-graph products of the instruction half as ONE launch
+__global__ __launch_bounds__(256) void k_ins_cat(int64_t n, const float* __restrict__ in, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float v = in[i]; out[i] = v; out[n + i] = fmaxf(v + v, 0.f); }
 }
 
 // y = relu(y + b1 + (1+eps) P1[g] + deg * P2[g])      (first MLP layer, instruction share)
@@ -216,12 +230,14 @@ __global__ __launch_bounds__(256) void k_gcn_aggregate_v4(int N, int C4, const f
     }
 }
 
-struct GineLayout { size_t z, y, tmp, P1, P2, scr, scr_bytes, total; };
+struct GineLayout { size_t z, y, tmp, P1, P2, scr, scr_bytes, zmax, mlp, total; };
 static GineLayout gine_layout(int64_t N, int64_t B, int Dn, int Di, int C) {
     GineLayout L; size_t off = 0;
     auto take = [&](size_t n) { size_t r = off; off += align_up(n * sizeof(float), 256); return r; };
-    L.z = take((size_t)N * Dn); L.y = take((size_t)N * C); L.tmp = take((size_t)B * Di);
-    L.P1 = take((size_t)B * C); L.P2 = take((size_t)B * C);
+    L.z = take((size_t)N * Dn + 64); L.y = take((size_t)N * C); L.tmp = take((size_t)2 * B * Di);      // (tmp: [ins ; relu(2 ins)] of the fused form)
+    L.P1 = take((size_t)B * C); L.P2 = take((size_t)B * C);                                             // (contiguous: the fused form's [2 B, C] product)
+    L.zmax = take((size_t)N);
+    L.mlp = take(gine_mlp_packed_bytes(C, Dn) / sizeof(float) + 64);
     // scratch of the two node-sized Linears on the two-piece products (operands packed per call; round 5: 54 -> ~36 us each at config 4)
     L.scr_bytes = std::max(linear_auto_scratch_bytes(N, C, Dn), linear_auto_scratch_bytes(N, C, C));
     L.scr = take(L.scr_bytes / sizeof(float) + 64);
@@ -294,14 +310,30 @@ int gvqa_gine_conv_forward(const gvqa_graph* g, int32_t Dn, int32_t Di, int32_t 
         const bool vec = (Dn % 4 == 0) && ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(edge_attr)) & 15) == 0;
         if (vec)
             hipLaunchKernelGGL(k_gine_aggregate<true>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, Dn, h,
-                               edge_attr, g->rowptr, g->csr_src, g->csr_eid, p->eps, P(L.z));
+                               edge_attr, g->rowptr, g->csr_src, g->csr_eid, p->eps, P(L.z), P(L.zmax));
         else
             hipLaunchKernelGGL(k_gine_aggregate<false>, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, stream, (int)N, Dn, h,
-                               edge_attr, g->rowptr, g->csr_src, g->csr_eid, p->eps, P(L.z));
+                               edge_attr, g->rowptr, g->csr_src, g->csr_eid, p->eps, P(L.z), P(L.zmax));
         GVQA_LAUNCH_CHECK();
     }
     StageTimer t(GVQA_STAGE_PROJ, stream);
     int rc;
+    // nn = Lin -> ReLU -> Lin as ONE kernel, the hidden rows in registers (gine_mlp.hip): C <= 320, the two-piece arithmetic of the products below
+    static const bool fused_off = []() { const char* v = getenv("GVQA_GINE_FUSED"); return v && v[0] == '0'; }();      // (A/B switch)
+    if (!fused_off && get_option(GVQA_OPT_PROJECTION) == GVQA_PROJECTION_SPLIT2H && N >= 1024 &&
+        gine_mlp_supported(N, C, Dn, P(L.z), Dn, out, C, C) && ld1 % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(p->nn0_weight) | reinterpret_cast<uintptr_t>(p->nn2_weight)) & 15) == 0) {
+        const float *P1 = nullptr, *P2 = nullptr;
+        if (Di > 0) {       // both per-graph products of the instruction half in one launch: [ins ; relu(2 ins)] x W1[:, Dn:]^T -> [P1 ; P2]
+            hipLaunchKernelGGL(k_ins_cat, dim3((unsigned)cdiv(B * Di, 256)), dim3(256), 0, stream, B * Di, ins, P(L.tmp));
+            GVQA_LAUNCH_CHECK();
+            rc = launch_linear(2 * B, C, Di, P(L.tmp), Di, p->nn0_weight + Dn, ld1, nullptr, 0, P(L.P1), C, 1, 0, 0, 0, stream);
+            if (rc) return rc;
+            P1 = P(L.P1); P2 = P(L.P1) + (size_t)B * C;
+        }
+        return launch_gine_mlp(N, C, Dn, P(L.z), Dn, P(L.zmax), p->nn0_weight, ld1, p->nn0_bias, p->nn2_weight, C, p->nn2_bias, P1, P2, C,
+                               g->node_graph, g->rowptr, p->eps, out, C, base + L.mlp, stream);
+    }
     if (Di == 0) {
         rc = launch_linear_auto(N, C, Dn, P(L.z), Dn, p->nn0_weight, ld1, LinearEpilogue{p->nn0_bias, nullptr, 0, nullptr, 0, 1}, P(L.y), C,
                                 base + L.scr, L.scr_bytes, stream);

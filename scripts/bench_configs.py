@@ -19,7 +19,7 @@ tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 dev = torch.device("cuda:0")
 
 
-def timed(fn, warmup=3, steps=20):
+def timed(fn, warmup=12, steps=20):
     """Wall time per call WITHOUT the in-library stage timers (their HIP events cost a launch-bound forward 5-10 %), then the stage
     breakdown from a second pass with them on."""
     for _ in range(warmup):

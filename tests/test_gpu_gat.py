@@ -1635,6 +1635,46 @@ def test_gine_gcn_config2_shape_vs_oracle(dev):
     assert maxabs(torch.stack(convs), torch.stack(ref_convs)) < TOL
 
 
+@pytest.mark.parametrize("dn,C,di,graphs", [(300, 300, 512, 120), (64, 320, 16, 200), (812, 300, 0, 90), (40, 8, 8, 400), (128, 132, 24, 64), (300, 300, 512, 37)])
+def test_gine_conv_fused_mlp_vs_oracle(dev, dn, C, di, graphs):
+    """GINEConv with nn = Lin -> ReLU -> Lin as ONE kernel (csrc/gine_mlp.hip, round 6: layer 1's A operand converted from the fp32 rows
+    in registers, the hidden rows handed from layer 1's accumulators to layer 2's A fragments in registers, both weights through one
+    LDS ring) against the oracle's GINEConv (pipeline_model_gine.py:628,651-665) at 1e-4: the reference's dims, the widest tile count
+    (C = 320), a 812-wide layer 1 without instruction halves (K tail 812 = 50 x 16 + 12), a one-quad output, widths with partial tiles,
+    row counts that are no multiple of 128; against the unfused path (GVQA_GINE_FUSED is read once: compared through the oracle); large
+    magnitudes in single rows (per-row scales)."""
+    from oracle import ref_torch as R
+    from graphvqa_amd.baseline_models import GINEConv
+    from graphvqa_amd.graph import SceneGraphBatch
+    from graphvqa_amd import _lib
+    from torch.nn import Linear, ReLU, Sequential
+    gb = synth.make_graph_batch(graphs, seed=0x61 + C + dn, nodes_lo=5, nodes_hi=40, rel_per_node=1.5)
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    rng = np.random.default_rng(dn * 7 + C)
+    x, ea = synth.normal((N, dn), 1), synth.normal((E, dn), 2)
+    x[rng.integers(0, N, size=5)] *= 300.0                                    # a few rows far above the rest: the row scales are per row
+    x[rng.integers(0, N, size=5)] *= 1e-3
+    ins = synth.normal((B, max(di, 1)), 3)[:, :di]
+    w = lambda *shape: (rng.standard_normal(shape) / np.sqrt(shape[-1])).astype(np.float32)
+    p = {"nn.0.weight": w(C, dn + di), "nn.0.bias": w(C), "nn.2.weight": w(C, C), "nn.2.bias": w(C)}
+    p["nn.2.weight"][C // 2] *= 1e-4                                           # an output channel far below its neighbours: per-column weight scales
+    conv = GINEConv(Sequential(Linear(dn + di, C), ReLU(), Linear(C, C)), eps=0.25).to(dev).eval()
+    conv.load_state_dict({**{k: t(v) for k, v in p.items()}, "eps": torch.tensor([0.25])})
+    g = SceneGraphBatch(t(gb.edge_index, device=dev), t(gb.batch, device=dev), N, B)
+    old = _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, 0)
+    try:
+        _lib.prof_enable(True); _lib.prof_collect()
+        out = conv(t(x, device=dev), t(gb.edge_index, device=dev), t(ea, device=dev), graph=g, ins=t(ins, device=dev) if di else None)
+        pr = _lib.prof_collect(); _lib.prof_enable(False)
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT3_MIN_MFLOP, old)
+    xc = np.concatenate([x, ins[gb.batch]], 1) if di else x
+    ec = np.concatenate([ea, ins[gb.batch[gb.edge_index[0]]]], 1) if di else ea
+    ref = R.gine_conv(t(xc).double(), t(gb.edge_index), t(ec).double(), {k: t(v).double() for k, v in p.items()}, eps=0.25)
+    scale = max(1.0, float(ref.abs().max()) / 32.0)                            # (the sweeps' bound: absolute 1e-4 up to |ref| = 32, relative to the peak above)
+    assert maxabs(out, ref.float()) < TOL * scale, (maxabs(out, ref.float()), scale)
+
+
 def test_gine_unaligned_width_and_cross_graph_edges(dev):
     """C % 4 != 0 takes the scalar kernels; cross-graph edges take the concatenated formulation."""
     from oracle import ref_torch as R
