@@ -425,12 +425,34 @@ def live_pmc_traffic():
 
 
 def main():
+    """N = 1: setup -> primary (the timed region) -> headline -> n_eq_1 (roofline legs, configs, cpu_baseline) -> one JSON line.
+    N > 1: setup -> primary -> n_gt_1 (the other scaling form, the other gather form, the exchange A/B: under one deadline, in a worker
+    thread) -> headline -> the line -> bounded communicator clean-up.  (Round 6: one 480-line function before; VERDICT r05 weak #7.)"""
     a = parse_args()
     if a.floor_child:
         return floor_child()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(a)
+    cx = setup(a)
+    if a.pmc_child:
+        return pmc_child(cx)
+    if a.emulate_world > 1 and cx.world == 1:
+        return emulated_shard(cx)
+    prim = primary(cx)
+    sec = n_gt_1(cx, prim) if cx.dist is not None else {"other": None, "other_gather": None, "gather_ab": None, "errors": {}, "hung": False}
+    line = None
+    if cx.rank == 0:
+        res = headline(cx, prim, sec)
+        if cx.world == 1:
+            n_eq_1(cx, prim, res)
+        line = json.dumps(res)
+    emit_and_leave(cx, line, sec)
 
+
+def setup(a):
+    """Process group (RCCL; gloo only behind the one-GPU test hook), module, THE batch, and the step machinery every leg shares:
+    make_shard / runner / fence / timed."""
+    import types
     import numpy as np
     import torch
     from graphvqa_amd import synth, _lib
@@ -544,30 +566,51 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt
-
-    if a.pmc_child:                      # counter pass: a few plain steps fused, a few unfused, nothing else
-        step = runner(make_shard(0, 1))
-        for fusion in (lib.gvqa_get_option(_lib.OPT_HOP_FUSION), 0):
-            _lib.set_option(_lib.OPT_HOP_FUSION, fusion)
-            for _ in range(2):
-                step()
-        torch.cuda.synchronize()
-        return
-
     strong = a.scaling == "strong"
-    if a.emulate_world > 1 and world == 1:       # one rank's share of an N-way strong-scaling run, on this one GPU
-        sh = make_shard(0, a.emulate_world)
-        run = runner(sh)
-        t = timed(run, a.steps, a.warmup) / a.steps
-        _lib.prof_enable(True); _lib.prof_collect()
-        timed(run, a.steps, 0)
-        pr = _lib.prof_collect(); _lib.prof_enable(False)
-        print(json.dumps({"emulated_world": a.emulate_world, "graphs": sh.num_graphs, "edges": sh.num_edges, "ms_per_step": t * 1e3,
-                          "gpu_stage_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in pr.items() if v[1]},
-                          "gpu_stage_sum_ms": round(sum(v[0] for v in pr.values()) / a.steps, 4),
-                          "note": "rank 0's shard only, no all-gather; whole-job edges/s would be <= "
-                                  f"{Eall / t:.4g} if every rank matched it"}))
-        return
+    return types.SimpleNamespace(a=a, np=np, torch=torch, synth=synth, _lib=_lib, lib=lib, dev=dev, dist=dist, world=world, rank=rank, m=m, params=params,
+                                 tt=tt, make_shard=make_shard, runner=runner, fence=fence, timed=timed, SceneGraphBatch=SceneGraphBatch, Nall=Nall, Eall=Eall,
+                                 Ball=Ball, strong=strong, force_dist=force_dist, head=head, rccl_ranks_seen=rccl_ranks_seen)
+
+
+def pmc_child(cx):
+    """Counter pass (live_pmc_traffic's child): a few plain steps fused, a few unfused, nothing else."""
+    a, np, torch, synth, _lib, lib, dev, dist, world, rank, m, params = cx.a, cx.np, cx.torch, cx.synth, cx._lib, cx.lib, cx.dev, cx.dist, cx.world, cx.rank, cx.m, cx.params
+    tt, make_shard, runner, fence, timed, SceneGraphBatch = cx.tt, cx.make_shard, cx.runner, cx.fence, cx.timed, cx.SceneGraphBatch
+    Nall, Eall, Ball, strong, force_dist, head, rccl_ranks_seen = cx.Nall, cx.Eall, cx.Ball, cx.strong, cx.force_dist, cx.head, cx.rccl_ranks_seen
+    step = runner(make_shard(0, 1))
+    for fusion in (lib.gvqa_get_option(_lib.OPT_HOP_FUSION), 0):
+        _lib.set_option(_lib.OPT_HOP_FUSION, fusion)
+        for _ in range(2):
+            step()
+    torch.cuda.synchronize()
+    return
+
+
+def emulated_shard(cx):
+    """`--emulate-world N`: one rank's share of an N-way strong-scaling run, on this one GPU (no collective)."""
+    a, np, torch, synth, _lib, lib, dev, dist, world, rank, m, params = cx.a, cx.np, cx.torch, cx.synth, cx._lib, cx.lib, cx.dev, cx.dist, cx.world, cx.rank, cx.m, cx.params
+    tt, make_shard, runner, fence, timed, SceneGraphBatch = cx.tt, cx.make_shard, cx.runner, cx.fence, cx.timed, cx.SceneGraphBatch
+    Nall, Eall, Ball, strong, force_dist, head, rccl_ranks_seen = cx.Nall, cx.Eall, cx.Ball, cx.strong, cx.force_dist, cx.head, cx.rccl_ranks_seen
+    sh = make_shard(0, a.emulate_world)
+    run = runner(sh)
+    t = timed(run, a.steps, a.warmup) / a.steps
+    _lib.prof_enable(True); _lib.prof_collect()
+    timed(run, a.steps, 0)
+    pr = _lib.prof_collect(); _lib.prof_enable(False)
+    print(json.dumps({"emulated_world": a.emulate_world, "graphs": sh.num_graphs, "edges": sh.num_edges, "ms_per_step": t * 1e3,
+                      "gpu_stage_ms_per_step": {k: round(v[0] / a.steps, 4) for k, v in pr.items() if v[1]},
+                      "gpu_stage_sum_ms": round(sum(v[0] for v in pr.values()) / a.steps, 4),
+                      "note": "rank 0's shard only, no all-gather; whole-job edges/s would be <= "
+                              f"{Eall / t:.4g} if every rank matched it"}))
+    return
+
+
+def primary(cx):
+    """The timed region: W warm-up steps, K timed steps between fences (barrier + synchronize on both sides, max over ranks), with the
+    in-library HIP events of the dominant kernel's stage only; then an untimed pass with every stage's events."""
+    a, np, torch, synth, _lib, lib, dev, dist, world, rank, m, params = cx.a, cx.np, cx.torch, cx.synth, cx._lib, cx.lib, cx.dev, cx.dist, cx.world, cx.rank, cx.m, cx.params
+    tt, make_shard, runner, fence, timed, SceneGraphBatch = cx.tt, cx.make_shard, cx.runner, cx.fence, cx.timed, cx.SceneGraphBatch
+    Nall, Eall, Ball, strong, force_dist, head, rccl_ranks_seen = cx.Nall, cx.Eall, cx.Ball, cx.strong, cx.force_dist, cx.head, cx.rccl_ranks_seen
     shard = make_shard(rank, world) if strong else make_shard(0, 1)
     if not strong and rank:             # weak scaling: every rank its own batch of the full size (different values)
         shard.x = tt(synth.normal((Nall, D), 1 + 10 * rank)).to(dev)
@@ -588,7 +631,35 @@ def main():
     prof = _lib.prof_collect()
     _lib.prof_enable(False)
     edges_per_step = Eall if strong else world * Eall
+    return types_ns(shard=shard, step=step, dt=dt, prof_timed=prof_timed, prof=prof, n_prof=n_prof, edges_per_step=edges_per_step)
 
+
+def types_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
+
+
+def _test_fault(leg_name, rank):
+    """GVQA_BENCH_TEST_FAULT=<rank>:<exit|hang>[:<leg>] (tests/test_gpu_bench_faults.py): that rank leaves (exit code 3) or stops responding inside
+    the named secondary leg (default: the first one) -- the other ranks must still print the line, with an error field, inside the deadline."""
+    spec = os.environ.get("GVQA_BENCH_TEST_FAULT")
+    if not spec:
+        return
+    parts = spec.split(":")
+    if int(parts[0]) != rank or (len(parts) > 2 and parts[2] != leg_name) or (len(parts) <= 2 and leg_name != "other_scaling_form"):
+        return
+    if parts[1] == "exit":
+        os._exit(3)
+    time.sleep(float(os.environ.get("GVQA_BENCH_SECONDARY_DEADLINE_S", "150")) + 20.0)
+    os._exit(0)
+
+
+def n_gt_1(cx, prim):
+    """The secondary legs at N > 1.  They must not cost the line its primary figure and must not be able to hang it."""
+    a, np, torch, synth, _lib, lib, dev, dist, world, rank, m, params = cx.a, cx.np, cx.torch, cx.synth, cx._lib, cx.lib, cx.dev, cx.dist, cx.world, cx.rank, cx.m, cx.params
+    tt, make_shard, runner, fence, timed, SceneGraphBatch = cx.tt, cx.make_shard, cx.runner, cx.fence, cx.timed, cx.SceneGraphBatch
+    Nall, Eall, Ball, strong, force_dist, head, rccl_ranks_seen = cx.Nall, cx.Eall, cx.Ball, cx.strong, cx.force_dist, cx.head, cx.rccl_ranks_seen
+    shard, edges_per_step = prim.shard, prim.edges_per_step
     # ---- secondary legs at N > 1 (the other scaling form, the other gather form, the exchange A/B).  They must not cost the line its
     # primary figure, and they must not be able to hang it (ADVICE r04): every leg is SET UP first (allocation is where one rank
     # fails alone), then all ranks agree -- an all-reduce of an ok flag -- whether to run it; the whole sequence runs in a worker
@@ -615,6 +686,7 @@ def main():
                 secondary_errors[name] = err or "skipped: another rank failed to set this leg up"
                 return None
             try:
+                _test_fault(name, rank)                  # (test hook: GVQA_BENCH_TEST_FAULT -- a rank dies or hangs inside this leg)
                 res_ = run(obj)
                 err = None
             except Exception as e:
@@ -625,6 +697,12 @@ def main():
             return res_
 
         def secondary():
+            try:
+                secondary_legs()
+            except Exception as e:           # (a peer that died takes the communicator with it: agree() itself raises -- keep what the legs have, name the cause)
+                secondary_errors["exception"] = repr(e)[:300]
+
+        def secondary_legs():
             torch.cuda.set_device(dev)
             if world > 1:
                 osteps = max(3, a.steps // 2)
@@ -654,224 +732,263 @@ def main():
         if secondary_hung:
             secondary_errors["deadline"] = "secondary legs did not finish in time: line printed without them, process leaves without communicator clean-up"
         other, other_gather, gather_ab_res = box.get("other"), box.get("other_gather"), box.get("gather_ab")
+    return {"other": other, "other_gather": other_gather, "gather_ab": gather_ab_res, "errors": secondary_errors, "hung": secondary_hung}
 
-    line = None
-    if rank == 0:
-        N, E, B = shard.num_nodes, shard.num_edges, shard.num_graphs
-        ms_step = dt / a.steps * 1e3
-        g0 = SceneGraphBatch(shard.edge_index, shard.batch, N, B)
-        hops = a.steps * K
-        fused = prof["mp"][1] == 0 and prof["proj"][1] > 0        # the default path: projection + aggregation in one kernel
-        flops32 = 2 * N * D * H * D                                # folded projection flops per hop (fp32 equivalent)
-        split = prof["pack"][1] > 0                                # a split projection ran (operand packing happened)
-        pieces = 2 if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H else 3
-        products = pieces * (pieces + 1) // 2                      # piece products kept: 3 of 4 (fp16 x 2) or 6 of 9 (bf16 x 3)
-        arith = {2: "fp32 operand rows scaled by a power of two and split into two fp16 pieces (22-23 significant bits), three fp16-MFMA "
-                    "piece products, fp32 accumulate; error vs fp64 not above the f32-input MFMA's (tests/test_gpu_split3.py), end to "
-                    "end <= 1e-4 vs the oracle",
-                 3: "fp32 operands split into three exact bf16 pieces, six bf16-MFMA piece products, fp32 accumulate (fp32 error class: "
-                    "tests/test_gpu_split3.py; end to end <= 1e-4 vs the oracle)"}[pieces]
 
-        def mp_roofline(pr, graph):
-            """HBM roofline of the message-passing kernel from a stage profile (unfused runs)."""
-            mp_ms, mp_n = pr["mp"]
-            if not mp_n:
-                return None
-            mp_avg_s = mp_ms / mp_n * 1e-3
-            plan = _lib.MpPlan()
-            _lib.check(lib.gvqa_gat_mp_plan(graph.c, D, H, plan))
-            kernel = (f"gvqa::k_gat_mp_tiled<{H},{plan.accumulators}> (channel range {plan.channel_range}, {plan.stage_buffers} stage "
-                      f"buffers, {plan.lds_bytes} B LDS, {plan.blocks_per_graph} block(s) per graph)") if plan.tiled else "gvqa::k_gat_*_general"
-            alg = mp_algorithmic_bytes(graph.num_nodes, graph.num_edges, D, H)
-            alg_base = mp_algorithmic_bytes(graph.num_nodes, graph.num_edges, D, H, fused_skip=False)
-            ach = alg / mp_avg_s / 1e9
-            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": alg,
-                    "frac_without_fused_skip_bytes": alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS,
-                    "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n}
+def _mp_roofline(cx, pr, graph):
+    """HBM roofline of the message-passing kernel from a stage profile (unfused runs)."""
+    _lib, lib = cx._lib, cx.lib
+    mp_ms, mp_n = pr["mp"]
+    if not mp_n:
+        return None
+    mp_avg_s = mp_ms / mp_n * 1e-3
+    plan = _lib.MpPlan()
+    _lib.check(lib.gvqa_gat_mp_plan(graph.c, D, H, plan))
+    kernel = (f"gvqa::k_gat_mp_tiled<{H},{plan.accumulators}> (channel range {plan.channel_range}, {plan.stage_buffers} stage "
+              f"buffers, {plan.lds_bytes} B LDS, {plan.blocks_per_graph} block(s) per graph)") if plan.tiled else "gvqa::k_gat_*_general"
+    alg = mp_algorithmic_bytes(graph.num_nodes, graph.num_edges, D, H)
+    alg_base = mp_algorithmic_bytes(graph.num_nodes, graph.num_edges, D, H, fused_skip=False)
+    ach = alg / mp_avg_s / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "frac_without_fused_skip_bytes": alg_base / mp_avg_s / 1e9 / HBM_PEAK_GBS,
+            "avg_launch_us": mp_avg_s * 1e6, "launches": mp_n}
 
-        proj_ms, proj_n = prof_timed["proj"]        # the dominant kernel's launches INSIDE the timed region
-        if fused:
-            # dominant kernel: the fused hop (split projection + aggregation + epilogue), MFMA-bound.  Algorithmic work per
-            # launch = the kept piece products of the folded projection (8(d)'s 2 N Dn H C, x 3 or x 6) -- the aggregation's
-            # 2 E H C flops (0.4 %) are not counted.
-            hk0 = m.hop_kernel(g0)
-            if hk0 == "aggregate_first_seq":
-                proj_n *= K                                              # one launch = K hops: per-hop figures below (traffic likewise)
-            avg_s = proj_ms / max(proj_n, 1) * 1e-3
-            ach = flops32 / avg_s / 1e12                                 # SURVEY 8(d): the folded projection's 2 N Dn H C flops per launch
-            issued = products * flops32 / avg_s / 1e12                   # what the matrix cores execute: 3 (6) piece products of them
-            hk = m.hop_kernel(g0)                                         # what the library says it runs for this batch (gvqa_gat_seq_hop_kernel)
-            ks2 = pieces == 2 and (-(-D // 16)) % 2 == 0                 # two K steps per stage when the k-block count is even
-            kname = {
-                "fused8_chained": f"gvqa::k_linear_split3<2,4,4,2,NBUF={2 if ks2 else 4},ILV,EPI=2,H={H},NP=2,KS={2 if ks2 else 1},CHN=1> (fused hop, 8 waves, 256 x 256 "
-                                  "tile: two-piece split projection, GAT aggregation + skip/BN/ReLU epilogue out of LDS, skip rows out of the packed input, "
-                                  "output written as the next hop's packed operand; xp never reaches HBM)",
-                "persistent_chained": f"gvqa::k_hop2<H={H},NBUF=3,CHAIN,NW=4> (persistent hop kernel, two 4-wave workgroups per CU, 128 x 256 items; output "
-                                      "written as the next hop's packed operand; xp never reaches HBM)",
-                "aggregate_first": "gvqa::k_hopagg4<2,4,2,4,SEQ=0> (aggregate-first hop: heads concatenated along K, the attention-weighted neighbour sum formed "
-                                   "inside the matrix-core loop, register -> global epilogue with its loads a batch ahead; rows chunk-major between hops)",
-                "aggregate_first_seq": "gvqa::k_hopagg4<2,4,2,4,SEQ=1> (aggregate-first hops, the K hops as ONE launch: a workgroup walks all hops of its "
-                                       "row group, coefficient phase inside the workgroup; avg_launch_us is per hop = launch / K)",
-                "persistent": f"gvqa::k_hop2<H={H},NBUF=3,NW=4> (persistent hop kernel, a pack pass per hop)",
-            }.get(hk, f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
-                      f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
-                      "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)")
-            roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
-                    "algorithmic_flops_per_launch": flops32,
-                    "issued_flops_per_launch": products * flops32, "issued_tflops": issued,
-                    "mfma_utilisation": issued / 2500.0,     # matrix-core utilisation: two thirds of the issued flops are the price of fp32 accuracy on 16-bit cores
-                    "frac_of_f32_mfma_peak": ach / 157.3,    # the same algorithmic flops against the pipe the reference's dtype would use
-                    # rows in once + rows out once (+ the hop's weights, CSR, coefficients): the 8-wave / persistent kernels read their
-                    # input as two-piece packed rows (2 x 2 B per value) and the skip rows out of the same operand, the aggregate-first
-                    # kernel reads fp32 chunk-major rows
-                    "algorithmic_bytes_per_launch": ((4 * N * D + 4 * N * D + 2 * 2 * H * D * D) if hk.startswith("aggregate_first") else
-                                                     (2 * pieces * N * D + 2 * 4 * N * D)) + 4 * (E * H + E + N + 1),
-                    "avg_launch_us": avg_s * 1e6, "launches": proj_n,
-                    "dtype_note": "peak = dense 16-bit MFMA (bf16 = fp16 rate, MI355X_MICROARCH.md); operands are 16-bit pieces of fp32 "
-                                  "values, fp32 accumulate"}
-        else:
-            roof = mp_roofline(prof_timed, g0)
-        gather_note = ("" if dist is None else " (each step waits for its own)" if not a.pipelined_gather else
-                       " (enqueued on RCCL's stream: it overlaps the next step's hops; all gathered before the closing synchronize)")
-        hk_name = m.hop_kernel(g0) if fused else "unfused"
-        res = {
-            "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
-            "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": ("f32 in/out; 2xfp16-split MFMA, fp32 accumulate" if split and pieces == 2 else
-                      "f32 in/out; 3xbf16-split MFMA (exact split), fp32 accumulate" if split else "f32"),
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: " + ("ONE batch" if strong or world == 1 else f"{world} batches (one per GPU)") +
-                                   " of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
-                                   "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, device CSR build from COO inside the step "
-                                   "(per-graph node / edge counts supplied by the host loader, no device read-back; weight-only products cached)"
-                                   + ("; + attention pooling + 1842-way classifier, true logits gathered" if head else ""),
-                       "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
-                       "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
-                                       "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
-                       else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
-                       "hop_kernel": hk_name,
-                       "projection_arithmetic": arith if split else "f32-input MFMA"},
-            "roofline": roof,
-            "stage_ms_per_step": {k: round(v[0] / n_prof, 5) for k, v in prof.items() if v[1]},
-        }
-        if rccl_ranks_seen is not None:
-            res["rccl_ranks_seen"] = rccl_ranks_seen
-        if gather_ab_res is not None:
-            res["allgather_ab"] = gather_ab_res
-        if secondary_errors:
-            res["secondary_leg_errors"] = secondary_errors
-        if other_gather is not None:
-            o = "blocking_gather" if a.pipelined_gather else "pipelined_gather"
-            res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other_gather["value"], other_gather["ms_per_step"], other_gather["steps"]
-        if world > 1:
-            res["scaling_note"] = ("`value` = STRONG scaling: the ONE config-3 batch sharded by graphs, whole-batch edges / max-over-ranks step time "
-                                   "(the form the >= 6x target refers to); `weak_value` = every rank its own full batch" if strong else
-                                   "`value` = WEAK scaling (every rank its own full batch); `strong_value` = the ONE batch sharded by graphs")
-        if other is not None:
-            o = "weak" if strong else "strong"
-            res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other["value"], other["ms_per_step"], other["steps"]
-            res[o + "_graphs_on_rank0"] = other["graphs_per_gpu"]
-        if world == 1:
-            full_shard = make_shard(0, 1)
-            full = runner(full_shard)
-            gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
-            n_x = max(5, a.steps // 4)
-            per = lambda pr, k="proj": pr[k][0] / max(pr[k][1], 1) * 1e3
-            if not a.no_extras:
-                # (a) the same step UNFUSED -- split projection + the stand-alone message-passing kernel, whose HBM roofline the north star
-                # names -- and (b) on the f32-input MFMA kernels (strict fp32 products): few steps each
-                _lib.prof_enable(True)
-                old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 0)
-                t_u = timed(full, n_x, 2, _lib.prof_collect) / n_x
-                pu = _lib.prof_collect()
-                old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
-                t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
-                p32 = _lib.prof_collect()
-                _lib.prof_enable(False)
-                _lib.set_option(_lib.OPT_PROJECTION, old_p)
-                _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
-                if gfull is not None:
-                    res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
-                    sa = mp_standalone(torch, _lib, lib, dev, gfull, reps=max(20, a.steps))
-                    mpr_ = res["mp_kernel_roofline"]
-                    if mpr_ is not None and sa.get("avg_launch_us"):
-                        # `frac` = the kernel launched back to back on the batch's own operands (its roofline proper: SURVEY 8(d) prices the kernel's
-                        # average launch); the same kernel inside the unfused step -- between split GEMMs that have pulled the clock down -- beside it
-                        mpr_["in_unfused_step"] = {"avg_launch_us": mpr_["avg_launch_us"], "achieved": mpr_["achieved"], "frac": mpr_["frac"], "launches": mpr_["launches"]}
-                        alg_ = mpr_["algorithmic_bytes_per_launch"]
-                        mpr_.update(avg_launch_us=sa["avg_launch_us"], launches=sa["launches"], achieved=alg_ / (sa["avg_launch_us"] * 1e-6) / 1e9,
-                                    frac=alg_ / (sa["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                    frac_without_fused_skip_bytes=mp_algorithmic_bytes(N, E, D, H, fused_skip=False) / (sa["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                    condition=sa["condition"])
-                    elif mpr_ is not None:
-                        mpr_["standalone_error"] = sa.get("error")
-                res["strict_fp32"] = {"kernel": "gvqa::k_linear_f32_dma (f32-input MFMA, bit-for-bit fp32 products) + gvqa::k_gat_mp_tiled, unfused",
-                                      "ms_per_step": t_f32 * 1e3, "value": Eall / t_f32, "projection_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
-                gemm_u = per(pu) - pu["pack"][0] / max(pu["proj"][1], 1) * 1e3
-                res["unfused_split"] = {"ms_per_step": t_u * 1e3, "value": Eall / t_u, "gemm_only_us": gemm_u,
-                                        "gemm_issued_mfma_tflops": products * flops32 / (gemm_u * 1e-6) / 1e12}
-                if fused and pieces == 2 and (N, E) == (Nall, Eall):
-                    fl = mfma_floor(lib, torch, dev, N, H * D, D)
-                    res["roofline"]["matrix_core_floor"] = fl
-                    if fl.get("mfma_only_us"):
-                        res["roofline"]["frac_of_matrix_core_floor"] = fl["mfma_only_us"] / res["roofline"]["avg_launch_us"]
-            if a.extras:
-                # comparison legs of earlier rounds: the other split arithmetic (fused), the vendor library, products' error vs fp64, clock probe
-                _lib.prof_enable(True)
-                old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1)
-                otherp = _lib.PROJECTION_SPLIT3 if pieces == 2 else _lib.PROJECTION_SPLIT2H
-                old_p = _lib.set_option(_lib.OPT_PROJECTION, otherp)
-                t_o = timed(full, n_x, 2, _lib.prof_collect) / n_x
-                po = _lib.prof_collect()
-                _lib.set_option(_lib.OPT_HOP_FUSION, 0)
-                _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
-                _lib.set_option(_lib.OPT_VENDOR_GEMM, 1)
-                t_v = timed(full, n_x, 2, _lib.prof_collect) / n_x
-                pv = _lib.prof_collect()
-                _lib.prof_enable(False)
-                _lib.set_option(_lib.OPT_VENDOR_GEMM, 0)
-                _lib.set_option(_lib.OPT_PROJECTION, old_p)
-                _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
-                opieces = 5 - pieces
-                res["fused_other_split"] = {"projection": "three exact bf16 pieces, six products" if opieces == 3 else "two scaled fp16 pieces, three products",
-                                            "ms_per_step": t_o * 1e3, "value": Eall / t_o, "avg_launch_us": per(po),
-                                            "issued_mfma_tflops": opieces * (opieces + 1) // 2 * flops32 / (per(po) * 1e-6) / 1e12}
-                res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
-                                            "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
-                res["projection_error_vs_fp64"] = projection_accuracy(lib, params, shard, torch, np, dev)
-                if fused and (N, E) == (Nall, Eall):
-                    res["roofline"]["dvfs_probe"] = dvfs_probe(m, full_shard, full, torch, _lib, n_x)
-            if not a.no_pmc:
-                pm = live_pmc_traffic()
-                if "fused" in pm and fused:
-                    per_hop = K if m.hop_kernel(g0) == "aggregate_first_seq" else 1       # (one launch = K hops: bytes per hop, like avg_launch_us)
-                    res["roofline"]["traffic"] = pm["fused"]["bytes"] / per_hop
-                    res["roofline"]["traffic_detail"] = dict(pm["fused"], hops_per_launch=per_hop)
-                if "mp" in pm:
-                    tgt = res.get("mp_kernel_roofline") if fused else res["roofline"]
-                    if tgt is not None:
-                        tgt["traffic"] = pm["mp"]["bytes"]
-                        tgt["traffic_detail"] = pm["mp"]
-                if "error" in pm:
-                    res["roofline"]["traffic_error"] = pm["error"]
-            mpr = res.get("mp_kernel_roofline") if fused else res["roofline"]
-            if mpr is not None and mpr.get("traffic") is None:
-                mpr["traffic_from_profile"] = profile_traffic()
-            cp = measured_copy_bandwidth(torch, dev, lib)
-            res["hbm_copy_measured"] = cp
-            if mpr is not None:
-                mpr["frac_of_guide_achievable"] = mpr["achieved"] / GUIDE_ACHIEVABLE_GBS
-                if cp.get("GBps"):
-                    mpr["frac_of_measured_copy"] = mpr["achieved"] / cp["GBps"]
-            if not a.no_extras and not a.no_configs:
-                res["configs"] = extra_configs(torch, np, synth, _lib, lib, dev, with_cpu=not a.no_cpu_baseline)
-            if not a.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(params, synth, np, torch, m, dev)
-        line = json.dumps(res)
+
+def headline(cx, prim, sec):
+    """Rank 0: the contract keys, `roofline` of the dominant kernel, and -- N > 1 -- what the scaling record needs FIRST (the ranks RCCL
+    connected, the strong and weak values, the exchange A/B); the secondary legs' other figures last."""
+    a, np, torch, synth, _lib, lib, dev, dist, world, rank, m, params = cx.a, cx.np, cx.torch, cx.synth, cx._lib, cx.lib, cx.dev, cx.dist, cx.world, cx.rank, cx.m, cx.params
+    tt, make_shard, runner, fence, timed, SceneGraphBatch = cx.tt, cx.make_shard, cx.runner, cx.fence, cx.timed, cx.SceneGraphBatch
+    Nall, Eall, Ball, strong, force_dist, head, rccl_ranks_seen = cx.Nall, cx.Eall, cx.Ball, cx.strong, cx.force_dist, cx.head, cx.rccl_ranks_seen
+    shard, dt, prof_timed, prof, n_prof, edges_per_step = prim.shard, prim.dt, prim.prof_timed, prim.prof, prim.n_prof, prim.edges_per_step
+    other, other_gather, gather_ab_res, secondary_errors = sec["other"], sec["other_gather"], sec["gather_ab"], sec["errors"]
+    N, E, B = shard.num_nodes, shard.num_edges, shard.num_graphs
+    ms_step = dt / a.steps * 1e3
+    g0 = SceneGraphBatch(shard.edge_index, shard.batch, N, B)
+    hops = a.steps * K
+    fused = prof["mp"][1] == 0 and prof["proj"][1] > 0        # the default path: projection + aggregation in one kernel
+    flops32 = 2 * N * D * H * D                                # SURVEY 8(d): folded projection flops per hop (fp32 equivalent)
+    split = prof["pack"][1] > 0                                # a split projection ran (operand packing happened)
+    pieces = 2 if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H else 3
+    products = pieces * (pieces + 1) // 2                      # piece products kept: 3 of 4 (fp16 x 2) or 6 of 9 (bf16 x 3)
+    arith = {2: "fp32 operand rows scaled by a power of two and split into two fp16 pieces (22-23 significant bits), three fp16-MFMA "
+                "piece products, fp32 accumulate; error vs fp64 not above the f32-input MFMA's (tests/test_gpu_split3.py), end to "
+                "end <= 1e-4 vs the oracle",
+             3: "fp32 operands split into three exact bf16 pieces, six bf16-MFMA piece products, fp32 accumulate (fp32 error class: "
+                "tests/test_gpu_split3.py; end to end <= 1e-4 vs the oracle)"}[pieces]
+
+    mp_roofline = lambda pr, graph: _mp_roofline(cx, pr, graph)
+
+    proj_ms, proj_n = prof_timed["proj"]        # the dominant kernel's launches INSIDE the timed region
+    if fused:
+        # dominant kernel: the fused hop (split projection + aggregation + epilogue), MFMA-bound.  Algorithmic work per
+        # launch = the kept piece products of the folded projection (8(d)'s 2 N Dn H C, x 3 or x 6) -- the aggregation's
+        # 2 E H C flops (0.4 %) are not counted.
+        hk0 = m.hop_kernel(g0)
+        if hk0 == "aggregate_first_seq":
+            proj_n *= K                                              # one launch = K hops: per-hop figures below (traffic likewise)
+        avg_s = proj_ms / max(proj_n, 1) * 1e-3
+        ach = flops32 / avg_s / 1e12                                 # SURVEY 8(d): the folded projection's 2 N Dn H C flops per launch
+        issued = products * flops32 / avg_s / 1e12                   # what the matrix cores execute: 3 (6) piece products of them
+        hk = m.hop_kernel(g0)                                         # what the library says it runs for this batch (gvqa_gat_seq_hop_kernel)
+        ks2 = pieces == 2 and (-(-D // 16)) % 2 == 0                 # two K steps per stage when the k-block count is even
+        kname = {
+            "fused8_chained": f"gvqa::k_linear_split3<2,4,4,2,NBUF={2 if ks2 else 4},ILV,EPI=2,H={H},NP=2,KS={2 if ks2 else 1},CHN=1> (fused hop, 8 waves, 256 x 256 "
+                              "tile: two-piece split projection, GAT aggregation + skip/BN/ReLU epilogue out of LDS, skip rows out of the packed input, "
+                              "output written as the next hop's packed operand; xp never reaches HBM)",
+            "persistent_chained": f"gvqa::k_hop2<H={H},NBUF=3,CHAIN,NW=4> (persistent hop kernel, two 4-wave workgroups per CU, 128 x 256 items; output "
+                                  "written as the next hop's packed operand; xp never reaches HBM)",
+            "aggregate_first": "gvqa::k_hopagg4<2,4,2,4,SEQ=0> (aggregate-first hop: heads concatenated along K, the attention-weighted neighbour sum formed "
+                               "inside the matrix-core loop, register -> global epilogue with its loads a batch ahead; rows chunk-major between hops)",
+            "aggregate_first_seq": "gvqa::k_hopagg4<2,4,2,4,SEQ=1> (aggregate-first hops, the K hops as ONE launch: a workgroup walks all hops of its "
+                                   "row group, coefficient phase inside the workgroup; avg_launch_us is per hop = launch / K)",
+            "persistent": f"gvqa::k_hop2<H={H},NBUF=3,NW=4> (persistent hop kernel, a pack pass per hop)",
+        }.get(hk, f"gvqa::k_linear_split3<2,4,4,2,NBUF={(2 if ks2 else 4) if pieces == 2 else 3},ILV,EPI=2,H={H},NP={pieces},"
+                  f"KS={2 if ks2 else 1}> (fused hop: {pieces}-piece split projection, 256 x 256 tile, GAT aggregation + "
+                  "skip/BN/ReLU epilogue out of LDS; xp never reaches HBM)")
+        roof = {"bound": "mfma", "kernel": kname,
+                "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                "algorithmic_flops_per_launch": flops32,
+                "issued_flops_per_launch": products * flops32, "issued_tflops": issued,
+                "mfma_utilisation": issued / 2500.0,     # matrix-core utilisation: two thirds of the issued flops are the price of fp32 accuracy on 16-bit cores
+                "frac_of_f32_mfma_peak": ach / 157.3,    # the same algorithmic flops against the pipe the reference's dtype would use
+                # rows in once + rows out once (+ the hop's weights, CSR, coefficients): the 8-wave / persistent kernels read their
+                # input as two-piece packed rows (2 x 2 B per value) and the skip rows out of the same operand, the aggregate-first
+                # kernel reads fp32 chunk-major rows
+                "algorithmic_bytes_per_launch": ((4 * N * D + 4 * N * D + 2 * 2 * H * D * D) if hk.startswith("aggregate_first") else
+                                                 (2 * pieces * N * D + 2 * 4 * N * D)) + 4 * (E * H + E + N + 1),
+                "avg_launch_us": avg_s * 1e6, "launches": proj_n,
+                "dtype_note": "peak = dense 16-bit MFMA (bf16 = fp16 rate, MI355X_MICROARCH.md); operands are 16-bit pieces of fp32 "
+                              "values, fp32 accumulate"}
+    else:
+        roof = mp_roofline(prof_timed, g0)
+    gather_note = ("" if dist is None else " (each step waits for its own)" if not a.pipelined_gather else
+                   " (enqueued on RCCL's stream: it overlaps the next step's hops; all gathered before the closing synchronize)")
+    hk_name = m.hop_kernel(g0) if fused else "unfused"
+    res = {
+        "metric": "scene-graph edges/sec (K=5 GAT hops, d=512)",
+        "value": edges_per_step / (dt / a.steps), "unit": "edges/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+        "dtype": ("f32 in/out; 2xfp16-split MFMA, fp32 accumulate" if split and pieces == 2 else
+                  "f32 in/out; 3xbf16-split MFMA (exact split), fp32 accumulate" if split else "f32"),
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: " + ("ONE batch" if strong or world == 1 else f"{world} batches (one per GPU)") +
+                               " of 2048 graphs x 32 nodes x 128 edges (64k nodes / 256k edges), "
+                               "Dn=De=Di=C=512, H=4, K=5 gat_seq eval forward, fp32 in / fp32 out, device CSR build from COO inside the step "
+                               "(per-graph node / edge counts supplied by the host loader, no device read-back; weight-only products cached)"
+                               + ("; + attention pooling + 1842-way classifier, true logits gathered" if head else ""),
+                   "nodes_per_gpu": N, "edges_per_gpu": E, "graphs_per_gpu": B,
+                   "parallelism": (f"one batch sharded by graphs over {world} GPU(s) (edge-balanced contiguous ranges), "
+                                   "no communication inside the hops, one RCCL all-gather of per-graph rows per step" + gather_note) if strong
+                   else f"every one of {world} GPU(s) its own full batch, one RCCL all-gather of per-graph rows per step" + gather_note,
+                   "hop_kernel": hk_name,
+                   "projection_arithmetic": arith if split else "f32-input MFMA"},
+        "roofline": roof,
+        "stage_ms_per_step": {k: round(v[0] / n_prof, 5) for k, v in prof.items() if v[1]},
+    }
+    if rccl_ranks_seen is not None:
+        res["rccl_ranks_seen"] = rccl_ranks_seen
+    if gather_ab_res is not None:
+        res["allgather_ab"] = gather_ab_res
+    if secondary_errors:
+        res["secondary_leg_errors"] = secondary_errors
+    if other_gather is not None:
+        o = "blocking_gather" if a.pipelined_gather else "pipelined_gather"
+        res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other_gather["value"], other_gather["ms_per_step"], other_gather["steps"]
+    if world > 1:
+        res["scaling_note"] = ("`value` = STRONG scaling: the ONE config-3 batch sharded by graphs, whole-batch edges / max-over-ranks step time "
+                               "(the form the >= 6x target refers to); `weak_value` = every rank its own full batch" if strong else
+                               "`value` = WEAK scaling (every rank its own full batch); `strong_value` = the ONE batch sharded by graphs")
+    if other is not None:
+        o = "weak" if strong else "strong"
+        res[o + "_value"], res[o + "_ms_per_step"], res[o + "_steps"] = other["value"], other["ms_per_step"], other["steps"]
+        res[o + "_graphs_on_rank0"] = other["graphs_per_gpu"]
+    if world > 1 or rccl_ranks_seen is not None:
+        # key order of the N > 1 line: the contract keys, then what the scaling record is read for -- the ranks RCCL connected, the strong and weak
+        # values, the exchange A/B -- then the roofline and the rest; the secondary legs' remaining figures last
+        first = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                 "rccl_ranks_seen", "weak_value", "strong_value", "weak_ms_per_step", "strong_ms_per_step", "allgather_ab", "scaling_note", "config", "roofline",
+                 "stage_ms_per_step"]
+        res = {**{k: res[k] for k in first if k in res}, **{k: v for k, v in res.items() if k not in first}}
+    return res
+
+
+def n_eq_1(cx, prim, res):
+    """N = 1 only: the unfused / strict-fp32 legs, the stand-alone message-passing kernel's HBM roofline, the matrix-core floor, live PMC
+    traffic, the measured copy bandwidth, BASELINE configs 2 / 4 / 5, the CPU baseline."""
+    a, np, torch, synth, _lib, lib, dev, dist, world, rank, m, params = cx.a, cx.np, cx.torch, cx.synth, cx._lib, cx.lib, cx.dev, cx.dist, cx.world, cx.rank, cx.m, cx.params
+    tt, make_shard, runner, fence, timed, SceneGraphBatch = cx.tt, cx.make_shard, cx.runner, cx.fence, cx.timed, cx.SceneGraphBatch
+    Nall, Eall, Ball, strong, force_dist, head, rccl_ranks_seen = cx.Nall, cx.Eall, cx.Ball, cx.strong, cx.force_dist, cx.head, cx.rccl_ranks_seen
+    shard = prim.shard
+    N, E, B = shard.num_nodes, shard.num_edges, shard.num_graphs
+    g0 = SceneGraphBatch(shard.edge_index, shard.batch, N, B)
+    fused = prim.prof["mp"][1] == 0 and prim.prof["proj"][1] > 0
+    flops32 = 2 * N * D * H * D
+    pieces = 2 if lib.gvqa_get_option(_lib.OPT_PROJECTION) == _lib.PROJECTION_SPLIT2H else 3
+    products = pieces * (pieces + 1) // 2
+    mp_roofline = lambda pr, graph: _mp_roofline(cx, pr, graph)
+    full_shard = make_shard(0, 1)
+    full = runner(full_shard)
+    gfull = SceneGraphBatch(shard.edge_index, shard.batch, N, B) if (N, E) == (Nall, Eall) else None
+    n_x = max(5, a.steps // 4)
+    per = lambda pr, k="proj": pr[k][0] / max(pr[k][1], 1) * 1e3
+    if not a.no_extras:
+        # (a) the same step UNFUSED -- split projection + the stand-alone message-passing kernel, whose HBM roofline the north star
+        # names -- and (b) on the f32-input MFMA kernels (strict fp32 products): few steps each
+        _lib.prof_enable(True)
+        old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 0)
+        t_u = timed(full, n_x, 2, _lib.prof_collect) / n_x
+        pu = _lib.prof_collect()
+        old_p = _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
+        t_f32 = timed(full, n_x, 2, _lib.prof_collect) / n_x
+        p32 = _lib.prof_collect()
+        _lib.prof_enable(False)
+        _lib.set_option(_lib.OPT_PROJECTION, old_p)
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+        if gfull is not None:
+            res["mp_kernel_roofline"] = mp_roofline(pu, gfull)
+            sa = mp_standalone(torch, _lib, lib, dev, gfull, reps=max(20, a.steps))
+            mpr_ = res["mp_kernel_roofline"]
+            if mpr_ is not None and sa.get("avg_launch_us"):
+                # `frac` = the kernel launched back to back on the batch's own operands (its roofline proper: SURVEY 8(d) prices the kernel's
+                # average launch); the same kernel inside the unfused step -- between split GEMMs that have pulled the clock down -- beside it
+                mpr_["in_unfused_step"] = {"avg_launch_us": mpr_["avg_launch_us"], "achieved": mpr_["achieved"], "frac": mpr_["frac"], "launches": mpr_["launches"]}
+                alg_ = mpr_["algorithmic_bytes_per_launch"]
+                mpr_.update(avg_launch_us=sa["avg_launch_us"], launches=sa["launches"], achieved=alg_ / (sa["avg_launch_us"] * 1e-6) / 1e9,
+                            frac=alg_ / (sa["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            frac_without_fused_skip_bytes=mp_algorithmic_bytes(N, E, D, H, fused_skip=False) / (sa["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            condition=sa["condition"])
+            elif mpr_ is not None:
+                mpr_["standalone_error"] = sa.get("error")
+        res["strict_fp32"] = {"kernel": "gvqa::k_linear_f32_dma (f32-input MFMA, bit-for-bit fp32 products) + gvqa::k_gat_mp_tiled, unfused",
+                              "ms_per_step": t_f32 * 1e3, "value": Eall / t_f32, "projection_us": per(p32), "tflops": flops32 / (per(p32) * 1e-6) / 1e12}
+        gemm_u = per(pu) - pu["pack"][0] / max(pu["proj"][1], 1) * 1e3
+        res["unfused_split"] = {"ms_per_step": t_u * 1e3, "value": Eall / t_u, "gemm_only_us": gemm_u,
+                                "gemm_issued_mfma_tflops": products * flops32 / (gemm_u * 1e-6) / 1e12}
+        if fused and pieces == 2 and (N, E) == (Nall, Eall):
+            fl = mfma_floor(lib, torch, dev, N, H * D, D)
+            res["roofline"]["matrix_core_floor"] = fl
+            if fl.get("mfma_only_us"):
+                res["roofline"]["frac_of_matrix_core_floor"] = fl["mfma_only_us"] / res["roofline"]["avg_launch_us"]
+    if a.extras:
+        # comparison legs of earlier rounds: the other split arithmetic (fused), the vendor library, products' error vs fp64, clock probe
+        _lib.prof_enable(True)
+        old_f = _lib.set_option(_lib.OPT_HOP_FUSION, 1)
+        otherp = _lib.PROJECTION_SPLIT3 if pieces == 2 else _lib.PROJECTION_SPLIT2H
+        old_p = _lib.set_option(_lib.OPT_PROJECTION, otherp)
+        t_o = timed(full, n_x, 2, _lib.prof_collect) / n_x
+        po = _lib.prof_collect()
+        _lib.set_option(_lib.OPT_HOP_FUSION, 0)
+        _lib.set_option(_lib.OPT_PROJECTION, _lib.PROJECTION_F32)
+        _lib.set_option(_lib.OPT_VENDOR_GEMM, 1)
+        t_v = timed(full, n_x, 2, _lib.prof_collect) / n_x
+        pv = _lib.prof_collect()
+        _lib.prof_enable(False)
+        _lib.set_option(_lib.OPT_VENDOR_GEMM, 0)
+        _lib.set_option(_lib.OPT_PROJECTION, old_p)
+        _lib.set_option(_lib.OPT_HOP_FUSION, old_f)
+        opieces = 5 - pieces
+        res["fused_other_split"] = {"projection": "three exact bf16 pieces, six products" if opieces == 3 else "two scaled fp16 pieces, three products",
+                                    "ms_per_step": t_o * 1e3, "value": Eall / t_o, "avg_launch_us": per(po),
+                                    "issued_mfma_tflops": opieces * (opieces + 1) // 2 * flops32 / (per(po) * 1e-6) / 1e12}
+        res["projection_vendor"] = {"library": "rocBLAS sgemm (opt-in, comparison only; + gvqa::k_gat_mp_tiled)", "ms_per_step": t_v * 1e3,
+                                    "value": Eall / t_v, "avg_launch_us": per(pv), "tflops": flops32 / (per(pv) * 1e-6) / 1e12}
+        res["projection_error_vs_fp64"] = projection_accuracy(lib, params, shard, torch, np, dev)
+        if fused and (N, E) == (Nall, Eall):
+            res["roofline"]["dvfs_probe"] = dvfs_probe(m, full_shard, full, torch, _lib, n_x)
+    if not a.no_pmc:
+        pm = live_pmc_traffic()
+        if "fused" in pm and fused:
+            per_hop = K if m.hop_kernel(g0) == "aggregate_first_seq" else 1       # (one launch = K hops: bytes per hop, like avg_launch_us)
+            res["roofline"]["traffic"] = pm["fused"]["bytes"] / per_hop
+            res["roofline"]["traffic_detail"] = dict(pm["fused"], hops_per_launch=per_hop)
+        if "mp" in pm:
+            tgt = res.get("mp_kernel_roofline") if fused else res["roofline"]
+            if tgt is not None:
+                tgt["traffic"] = pm["mp"]["bytes"]
+                tgt["traffic_detail"] = pm["mp"]
+        if "error" in pm:
+            res["roofline"]["traffic_error"] = pm["error"]
+    mpr = res.get("mp_kernel_roofline") if fused else res["roofline"]
+    if mpr is not None and mpr.get("traffic") is None:
+        mpr["traffic_from_profile"] = profile_traffic()
+    cp = measured_copy_bandwidth(torch, dev, lib)
+    res["hbm_copy_measured"] = cp
+    if mpr is not None:
+        mpr["frac_of_guide_achievable"] = mpr["achieved"] / GUIDE_ACHIEVABLE_GBS
+        if cp.get("GBps"):
+            mpr["frac_of_measured_copy"] = mpr["achieved"] / cp["GBps"]
+    if not a.no_extras and not a.no_configs:
+        res["configs"] = extra_configs(torch, np, synth, _lib, lib, dev, with_cpu=not a.no_cpu_baseline)
+    if not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(params, synth, np, torch, m, dev)
+
+
+def emit_and_leave(cx, line, sec):
+    dist = cx.dist
+    secondary_hung = sec["hung"] or "exception" in sec["errors"]        # (a dead peer: the communicator is gone, do not wait on it again)
     if line is not None:
         # RCCL prints a version banner through C stdio, which is block-buffered on a pipe and would
         # otherwise be flushed at exit, AFTER our line: flush the C streams first so that the JSON

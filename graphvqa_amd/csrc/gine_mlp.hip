@@ -32,7 +32,11 @@ typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int GM_ROWS = 128;          // rows of a workgroup
 constexpr int GM_TN = 10;             // 32-column tiles: C <= 320
 constexpr int GM_CMAX = GM_TN * 32;
-constexpr int GM_NST = 4, GM_PD = 3;  // weight ring stages; DMAs run GM_PD steps ahead
+#ifndef GVQA_GM_DEEP
+#define GVQA_GM_DEEP 1
+#endif
+constexpr int GM_NST = GVQA_GM_DEEP ? 6 : 4, GM_PD = GVQA_GM_DEEP ? 5 : 3;  // weight ring stages; weight DMAs run GM_PD steps ahead (layer 1's rows: 3)
+constexpr int GM_ZD = 3;
 constexpr unsigned GM_BST = GM_TN * 2048u;                        // bytes per stage: 10 tiles x two pieces x 1 KiB
 constexpr unsigned GM_CC0 = GM_NST * GM_BST, GM_Z0 = GM_CC0 + 4 * GM_CMAX * 4, GM_LDS = GM_Z0 + 4 * 8192;     // + per-column constants [4][320]: 1/scale 1 | b1 | 1/scale 2 | b2; + layer 1's rows in flight (4 slots x 2 KiB per wave)
 constexpr int GM_MAXQ2 = GM_CMAX / 16;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
 #pragma unroll
     for (int g = 0; g < GM_PD; ++g) issue_b(g);
 #pragma unroll
-    for (int g = 0; g < GM_PD; ++g) zload(g);
+    for (int g = 0; g < GM_ZD; ++g) zload(g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
     for (int s = 0; s < NQ1; ++s) {
         const gm_f32x4 zc0 = *reinterpret_cast<const gm_f32x4*>(smem + zl0 + (s & 3) * 2048 + lane * 16);
         const gm_f32x4 zc1 = *reinterpret_cast<const gm_f32x4*>(smem + zl0 + (s & 3) * 2048 + 1024 + lane * 16);
-        zload(s + GM_PD);
+        zload(s + GM_ZD);
         const int k0 = 16 * s + 8 * hh;
         const gm_f32x4 zero4 = gm_f32x4{0.f, 0.f, 0.f, 0.f};
         const gm_f32x4 v0 = k0 + 4 <= Dn ? zc0 : zero4, v1 = k0 + 8 <= Dn ? zc1 : zero4;      // (k >= Dn contributes nothing -- and must not meet the fp16 range with another row's values)
@@ -233,7 +237,9 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
         // rows and weights of step s + 1 (issued two steps ago) have landed; what this step and the previous one issued -- 2 x (2 row DMAs
         // + 2 per weight tile) -- may stay in flight: two full steps of lead (one step of lead measured 114 us per launch: every step
         // waited out an L2 round trip)
-        if (nd == 3) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        // (deep ring, GM_PD = 5: + the weight DMAs of step s - 2, issued behind the rows this wait is for: 2 x (2 + 2 nd) + 2 nd)
+        if (GM_PD == 5) { if (nd == 3) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); }
+        else if (nd == 3) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -317,7 +323,8 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
             const uint4 al = make_uint4(a2l[j][o], a2l[j][o + 1], a2l[j][o + 2], a2l[j][o + 3]);
             issue_b(NQ1 + s + GM_PD);
             mma_step(NQ1 + s, __builtin_bit_cast(gm_f16x8, ah), __builtin_bit_cast(gm_f16x8, al));
-            if (nd == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");       // (the weight DMAs of this step and the previous one may stay in flight)
+            if (GM_PD == 5) { if (nd == 3) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); }     // (deep ring: three steps' weight DMAs)
+            else if (nd == 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");       // (the weight DMAs of this step and the previous one may stay in flight)
             else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }

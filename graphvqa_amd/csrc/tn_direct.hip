@@ -340,8 +340,12 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
     for (int j = 0; j < 2; ++j) bh[j] = rd(smem + b_off + j * 2048);
     int bcur = 0;                                           // ring slot of the current step's B tiles
     // step s_: A rows of step s + 1 (set CA_) -> image, A rows of step s + 2 -> set LA_; B tiles of step s + 2 -> ring by DMA.  At the barrier the
-    // DMAs of step s + 1 (issued one step ago) must have landed: the four younger memory operations -- this step's two A loads and two DMAs -- may
-    // stay in flight (loads retire in order)
+    // DMAs of step s + 1 (issued one step ago) must have landed.  Round 5 let "the four younger memory operations -- this step's two A loads and two
+    // DMAs --" stay in flight, on the assumption that memory reads retire in issue order.  They do among LDS-DMAs and among register loads, NOT across
+    // the two kinds (gine_mlp.hip, round 6: a register load counted together with younger DMAs came back after the count said "landed" -- whole rows
+    // wrong in one launch of three): with four allowed, two early A loads could stand in for the two DMAs the barrier is for.  Now only this step's two
+    // DMAs (the youngest operations, in order among themselves) may stay in flight; the A loads have landed -- they are converted at the top of the
+    // next step anyway, so the stricter wait costs nothing measurable
 #define GVQA_NND_STEP(s_, CA0_, CA1_, LA0_, LA1_)                                                                                             \
     {                                                                                                                                         \
         const int st_ = (s_);                                                                                                                 \
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
         dma_b(st_ + 2, bload);                                                                                                                \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(6); GVQA_NND_MF(7); GVQA_NND_FENCE();                                                                                     \
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                                                           \
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      /* (round 6: was vmcnt(4), see the note above the step) */         \
         __builtin_amdgcn_s_barrier();                                                                                                         \
         GVQA_NND_FENCE();                                                                                                                     \
         GVQA_NND_MF(8); GVQA_NND_MF(9); GVQA_NND_MF(10); GVQA_NND_MF(11); GVQA_NND_MF(12); GVQA_NND_MF(13); GVQA_NND_MF(14); GVQA_NND_MF(15);  \
