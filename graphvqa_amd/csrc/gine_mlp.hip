@@ -33,7 +33,7 @@ constexpr int GM_ROWS = 128;          // rows of a workgroup
 constexpr int GM_TN = 10;             // 32-column tiles: C <= 320
 constexpr int GM_CMAX = GM_TN * 32;
 #ifndef GVQA_GM_DEEP
-#define GVQA_GM_DEEP 1
+#define GVQA_GM_DEEP 0      /* (measured: 0.656 vs 0.664 ms per five layers -- the DMA lead is not what a step waits for; the shallow ring leaves 40 KiB of LDS free) */
 #endif
 constexpr int GM_NST = GVQA_GM_DEEP ? 6 : 4, GM_PD = GVQA_GM_DEEP ? 5 : 3;  // weight ring stages; weight DMAs run GM_PD steps ahead (layer 1's rows: 3)
 constexpr int GM_ZD = 3;
@@ -184,6 +184,13 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
                      : "v"(p_), "s"(d_), "s"(d_ + 1024u - 16u)
                      : "memory", "m0");
     };
+#ifdef GVQA_GM_STAMPS          /* measurement variant: phase stamps (100 MHz) of wave 0 overwrite the first 12 floats of the workgroup's first output row */
+    unsigned long long st_[6];
+#define GVQA_GM_STAMP(k_) st_[k_] = __builtin_amdgcn_s_memrealtime()
+#else
+#define GVQA_GM_STAMP(k_) do { } while (0)
+#endif
+    GVQA_GM_STAMP(0);
     const int ex1 = split2h_exponent(a.zmax[rowc]);
     const float ps1 = pow2i(ex1);
     f32x16 acc[GM_TN];
@@ -219,6 +226,7 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
             for (int j = 0; j < 5; ++j) acc[grp * 5 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], afh, acc[grp * 5 + j], 0, 0, 0);
         }
     };
+    GVQA_GM_STAMP(1);
     // ---- layer 1 ----
     // step s: rows of step s + 1 requested; rows of step s -> two pieces; DMAs of step s + GM_PD; products.  End of the step: only the DMAs
     // just issued may stay in flight (loads retire in order: the rows of step s + 1 and the DMAs of step s + 2, issued a step ago, have landed)
@@ -243,25 +251,21 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
         else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    GVQA_GM_STAMP(2);
     // ---- between the layers: y = relu(acc / (row scale x column scale) + b1 + (1 + eps) P1[g] + deg P2[g])  (k_gine_mid's arithmetic,
     // pipeline_model_gine.py:628's ReLU), its row maximum, two fp16 pieces per value -> layer 2's A fragments, all in registers
     const float rinv1 = pow2i(-ex1);
     const int gidx = a.P1 ? a.node_graph[rowc] : 0;
     const float deg = a.P1 ? (float)(a.rowptr[rowc + 1] - a.rowptr[rowc]) : 0.f;
     const float e1 = 1.0f + a.eps;
-    // (two passes that only READ the accumulators: the row maximum first, then the same values again, split straight into layer 2's A
-    //  registers.  Writing y back into the accumulator array between the passes cost 270 spilled registers per lane -- and a kernel with a
-    //  kilobyte of scratch per lane pays for it at every dispatch: 2.2 ms of wall time for 1.1 ms of kernels)
     const float* p1row = a.P1 ? a.P1 + (int64_t)gidx * a.ldp : cc_l;      // (no instruction shares: a mapped address, the factors below are 0)
     const float* p2row = a.P1 ? a.P2 + (int64_t)gidx * a.ldp : cc_l;
     const float e1p = a.P1 ? e1 : 0.f, degp = a.P1 ? deg : 0.f;
-    auto yquad = [&](int j, int q, float (&y)[4], const float* cc_, const float* p1_, const float* p2_) {
+    auto yquad = [&](int j, int q, float (&y)[4], const float* cc_, const float4& p1, const float4& p2) {
         const int c0 = 32 * j + 8 * q + 4 * hh;
         const bool live = c0 < C;
-        const int cl = live ? c0 : 0;
         const float4 bv = *reinterpret_cast<const float4*>(cc_ + c0);
         const float4 bb = *reinterpret_cast<const float4*>(cc_ + GM_CMAX + c0);
-        const float4 p1 = *reinterpret_cast<const float4*>(p1_ + cl), p2 = *reinterpret_cast<const float4*>(p2_ + cl);
         // (each accumulator element is read by an explicit, volatile v_accvgpr_read: the tile stays in its accumulator registers --
         //  hipcc otherwise copies whole 16-register tiles to VGPRs, keeps the first pass's copies for the second, and spills 270 .. 600 registers)
         float a0, a1, a2, a3;
@@ -280,33 +284,58 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[i] = live ? fmaxf(y[i], 0.f) : 0.f;
     };
+    // pass 1: y of every column, the row maximum, y back into the accumulator registers it came from (explicit v_accvgpr_write, element
+    // by element) -- the second pass needs no loads.  The per-graph rows are fetched for FIVE tiles at a time (40 x 16 bytes per lane in
+    // flight: one tile at a time was ten exposed L2 round trips, 12 of the kernel's 56 us)
     float ymax = 0.f;
 #pragma unroll
-    for (int j = 0; j < GM_TN; ++j) {
+    for (int half = 0; half < 2; ++half) {
+        float4 p1v[5][4], p2v[5][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float y[4];
-            yquad(j, q, y, cc_l, p1row, p2row);
-            ymax = fmaxf(ymax, fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])));
+        for (int jj = 0; jj < 5; ++jj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * (5 * half + jj) + 8 * q + 4 * hh, cl = c0 < C ? c0 : 0;
+                p1v[jj][q] = *reinterpret_cast<const float4*>(p1row + cl);
+                p2v[jj][q] = *reinterpret_cast<const float4*>(p2row + cl);
+            }
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int j = 5 * half + jj;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y[4];
+                yquad(j, q, y, cc_l, p1v[jj][q], p2v[jj][q]);
+                ymax = fmaxf(ymax, fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])));
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[j][4 * q]) : "v"(y[0]));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[j][4 * q + 1]) : "v"(y[1]));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[j][4 * q + 2]) : "v"(y[2]));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(acc[j][4 * q + 3]) : "v"(y[3]));
+#else
+                acc[j][4 * q] = y[0]; acc[j][4 * q + 1] = y[1]; acc[j][4 * q + 2] = y[2]; acc[j][4 * q + 3] = y[3];
+#endif
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);             // (a tile's eight row loads in flight, not all eighty)
+        __builtin_amdgcn_sched_barrier(0);
     }
     ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
     const int ex2 = split2h_exponent(ymax);
     const float ps2 = pow2i(ex2), rinv2 = pow2i(-ex2);
-    // (the second pass reads through pointers the compiler cannot identify with the first pass's: otherwise all 480 loaded values of the
-    //  first pass are kept -- spilled -- for the second)
-    const float *cc2 = cc_l, *p1row2 = p1row, *p2row2 = p2row;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(cc2), "+v"(p1row2), "+v"(p2row2));
-#endif
     unsigned a2h[GM_TN][8], a2l[GM_TN][8];             // [tile][2 q + pair]: K step s of layer 2 = tile s / 2, registers 4 (s & 1) .. + 3
 #pragma unroll
     for (int j = 0; j < GM_TN; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float y[4];
-            yquad(j, q, y, cc2, p1row2, p2row2);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y[0]) : "a"(acc[j][4 * q]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y[1]) : "a"(acc[j][4 * q + 1]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y[2]) : "a"(acc[j][4 * q + 2]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(y[3]) : "a"(acc[j][4 * q + 3]));
+#else
+            y[0] = acc[j][4 * q]; y[1] = acc[j][4 * q + 1]; y[2] = acc[j][4 * q + 2]; y[3] = acc[j][4 * q + 3];
+#endif
             GVQA_GM_SPLIT2(a2h[j][2 * q], a2l[j][2 * q], ps2, y[0], y[1]);
             GVQA_GM_SPLIT2(a2h[j][2 * q + 1], a2l[j][2 * q + 1], ps2, y[2], y[3]);
         }
@@ -314,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         __builtin_amdgcn_sched_barrier(0);
     }
+    GVQA_GM_STAMP(3);
     // ---- layer 2: A from registers ----
 #pragma unroll
     for (int s = 0; s < GM_MAXQ2; ++s) {
@@ -329,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
             __builtin_amdgcn_s_barrier();
         }
     }
+    GVQA_GM_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the clamped re-loads of the last steps: nothing may land in LDS after the workgroup has gone)
     // ---- out = acc / (row scale x column scale) + b2 ----
     if (on) {
@@ -349,6 +380,15 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
                 *reinterpret_cast<float4*>(orow + c0) = v;
             }
     }
+#ifdef GVQA_GM_STAMPS
+    GVQA_GM_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out + (int64_t)(blockIdx.x * GM_ROWS) * a.ldo);
+        for (int k = 0; k < 6; ++k) dst[k] = st_[k];
+    }
+#endif
+#undef GVQA_GM_STAMP
 }
 
 size_t gine_mlp_packed_bytes(int C, int Dn) {
