@@ -384,7 +384,12 @@ __global__ __launch_bounds__(512) void k_linear_bf16_wide(int M, int N, int K, c
                 if (more) {                                       // the next step's DMAs, spread evenly over this step's 4 P MFMA groups
 #pragma unroll
                     for (int d = 0; d < NDMA; ++d)
-                        if (d * (4 * P) / NDMA == kg * P + (P - 1 - p)) issue_one(cur ^ 1, d);
+#ifndef GVQA_BF16_DMA_SPREAD
+#define GVQA_BF16_DMA_SPREAD 4            /* MFMA groups of the step (of 4 P) that the next step's DMAs are issued between.  Round 5 spread them over all 4 P: the last ones
+                                             then have a fraction of a step to land before the vmcnt(0) at the next barrier.  Within the first half: LCGN bf16 forward
+                                             2.355 -> 2.25 ms (same box, alternating; 2: 2.30) */
+#endif
+                        if (d * (GVQA_BF16_DMA_SPREAD) / NDMA == kg * P + (P - 1 - p)) issue_one(cur ^ 1, d);
                 }
             }
         }

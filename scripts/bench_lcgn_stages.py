@@ -19,7 +19,7 @@ for key, kw in (("fp32", {}), ("bf16", {"node_feature_dtype": torch.bfloat16})):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.lcgn_seq_params(300, O, seed=808).items()})
     m = m.to(dev).eval()
     run = lambda: m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc)
-    for _ in range(3): run()
+    for _ in range(12): run()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): run()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
