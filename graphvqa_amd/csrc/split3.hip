@@ -2066,6 +2066,10 @@ int launch_hop_fused_split(int np, int64_t K, const void* Apk, const void* Bpk, 
             pair_blocks -= rem_blocks;
             single_blocks = f.num_groups - 2 * pair_blocks;
         }
+        if ((int64_t)pair_blocks + single_blocks > 65535) {               // (grid.y: the split adds up to rem_blocks rows to cdiv(groups, 2) -- near the limit keep pairs only)
+            pair_blocks = (int)cdiv(f.num_groups, 2);
+            single_blocks = 0;
+        }
     }
     dim3 grid((unsigned)ncb, (unsigned)(pair_blocks + single_blocks));
     FusedHopArgs f2 = f;

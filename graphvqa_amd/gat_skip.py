@@ -25,6 +25,7 @@ from typing import Optional
 
 import torch
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 from torch.nn import Parameter, Linear
 
 from . import _lib
@@ -445,6 +446,7 @@ class _HopProducts(torch.autograd.Function):
         return xp, a_part, xp_rows, a_rows
 
     @staticmethod
+    @once_differentiable        # (the skip gradient travels in `skip_grad`, outside autograd: a double backward would silently lose it -- ADVICE r05)
     def backward(ctx, gxp, ga, g_rows, g_arows):
         h, ins, W, F_, U_n = ctx.saved_tensors
         Dn = ctx.Dn
@@ -607,6 +609,7 @@ class _GatMessagePassing(torch.autograd.Function):
         return out, alpha
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout, _dalpha):
         lib = _lib.load()
         xp, a_node, a_edge, alpha, mask, graph_rows, s = ctx.saved_tensors
@@ -655,6 +658,9 @@ class _GatMessagePassing(torch.autograd.Function):
             else:
                 d_bias = dcol.sum(0)
         if ctx.skip_grad is not None and ctx.has_skip:
+            # internal hand-over to the same hop's _HopProducts.backward, which runs next and pops it.  A backward that stops short of that
+            # node (torch.autograd.grad on a subset of inputs, retain_graph re-runs) must not pile tensors up here: at most ONE entry
+            del ctx.skip_grad[:]
             ctx.skip_grad.append(dout)
             return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, None, None
         return dxp, da_node, da_edge, None, None, None, None, None, d_rows, d_bias, (dout if ctx.has_skip else None), None
@@ -1101,7 +1107,7 @@ class gat_seq(torch.nn.Module):
         self.last_stats = None
         # Per-module overrides of the library's process-wide options (None = follow gvqa_set_option / the environment), carried in the
         # dims struct of every call -- two models with different settings can live in one process:
-        #   projection: "split2h" | "split3" | "f32"      hop_fusion: 0 .. 5 (include/gvqa.h, GVQA_OPT_HOP_FUSION)
+        #   projection: "split2h" | "split3" | "f32"      hop_fusion: 0 .. 6 (include/gvqa.h, GVQA_OPT_HOP_FUSION: 3 = the default rule, 4 / 5 aggregate-first per hop / one launch, 6 column parts)
         self.projection = None
         self.hop_fusion = None
 

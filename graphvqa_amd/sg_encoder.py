@@ -279,6 +279,10 @@ class GroundTruth_SceneGraph_Encoder(torch.nn.Module):
                 self._packed_stream = st
             elif getattr(self, "_packed_stream", st) != st and getattr(self, "_packed_event", None) is not None:
                 torch.cuda.current_stream(dev).wait_event(self._packed_event)
+                if self._packed is not None:
+                    # used on a stream other than the one it was allocated on: the caching allocator must not hand the block back to the packing
+                    # stream while this stream's forward still reads it (a dropped / rebuilt cache would free it) -- ADVICE r05
+                    self._packed.record_stream(torch.cuda.current_stream(dev))
             if self._packed is not None:
                 p.packed, p.packed_bytes = self._packed.data_ptr(), self._packed.numel()
             ws = _workspace(lib.gvqa_sg_encoder_workspace_bytes(C.byref(graph.c), D), dev)
