@@ -47,6 +47,30 @@ int get_option(int option) {
     return (option >= 0 && option < GVQA_NUM_OPTIONS) ? g_opt[option].load(std::memory_order_relaxed) : 0;
 }
 
+// ---- side stream (see common.h) ------------------------------------------------------------
+SideStream* side_stream_get() {
+    static thread_local SideStream ss;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (!ss.ok || ss.device != dev) {
+        ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.fork_ev, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.join_ev, hipEventDisableTiming) == hipSuccess;
+        ss.device = dev;
+    }
+    return ss.ok ? &ss : nullptr;
+}
+int side_fork(SideStream* ss, hipStream_t main) {
+    GVQA_HIP_CHECK(hipEventRecord(ss->fork_ev, main));
+    GVQA_HIP_CHECK(hipStreamWaitEvent(ss->stream, ss->fork_ev, 0));
+    return GVQA_OK;
+}
+int side_join(SideStream* ss, hipStream_t main) {
+    GVQA_HIP_CHECK(hipEventRecord(ss->join_ev, ss->stream));
+    GVQA_HIP_CHECK(hipStreamWaitEvent(main, ss->join_ev, 0));
+    return GVQA_OK;
+}
+
 // ---- stage timing -------------------------------------------------------------------------
 struct ProfSlot {
     int stage;

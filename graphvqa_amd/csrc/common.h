@@ -65,6 +65,20 @@ struct Carver {
     bool ok() const { return off <= cap; }
 };
 
+// Side stream (capi.hip): one non-blocking stream and a pair of events per host thread and device.  fork = the side stream waits for
+// everything already enqueued on the caller's stream, join = the caller's stream waits for the side stream.  For work that is
+// LATENCY-bound and independent of what the caller's stream runs meanwhile (LCGN's per-question command chain beside the node products);
+// HBM-bound kernels beside each other gained nothing (gat.hip, rounds 1 / 4 / 6: GVQA_OVERLAP stays off there).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int device = -1;
+    bool ok = false;
+};
+SideStream* side_stream_get();
+int side_fork(SideStream* ss, hipStream_t main);
+int side_join(SideStream* ss, hipStream_t main);
+
 // Stage timing (gvqa_prof_*): RAII bracket recording two events on the stream when enabled.
 struct StageTimer {
     int stage;

@@ -1287,35 +1287,9 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
 // terms and the chained hops' term maxima beside hop 0's pack pass, ONE fork and ONE join per forward -- and measured it again,
 // alternating on one box: 2.76 / 2.81 ms with, 2.63 / 2.63 ms without.  The kernels that would overlap are HBM-bound alike (they
 // share the bandwidth) and the two cross-stream dependencies cost this runtime more than the small GEMM hides.  It stays off.
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    int device = -1;
-    bool ok = false;
-};
 static SideStream* side_stream() {
     static const bool enabled = []() { const char* v = getenv("GVQA_OVERLAP"); return v && v[0] == '1'; }();
-    if (!enabled) return nullptr;
-    static thread_local SideStream ss;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (!ss.ok || ss.device != dev) {
-        ss.ok = hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&ss.fork_ev, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&ss.join_ev, hipEventDisableTiming) == hipSuccess;
-        ss.device = dev;
-    }
-    return ss.ok ? &ss : nullptr;
-}
-static int side_fork(SideStream* ss, hipStream_t main) {
-    GVQA_HIP_CHECK(hipEventRecord(ss->fork_ev, main));
-    GVQA_HIP_CHECK(hipStreamWaitEvent(ss->stream, ss->fork_ev, 0));
-    return GVQA_OK;
-}
-static int side_join(SideStream* ss, hipStream_t main) {
-    GVQA_HIP_CHECK(hipEventRecord(ss->join_ev, ss->stream));
-    GVQA_HIP_CHECK(hipStreamWaitEvent(main, ss->join_ev, 0));
-    return GVQA_OK;
+    return enabled ? side_stream_get() : nullptr;
 }
 
 static gvqa_gat_mp_desc mp_desc_from(const gvqa_gat_dims* d, const gvqa_gat_conv_params* p) {

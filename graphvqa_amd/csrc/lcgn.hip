@@ -494,6 +494,8 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
     // msg once per iteration (2 + T) instead of 5 + 3 T; no fp32 x_loc / x_ctx / prod rows at all.
     const bool chained = split_nodes && O % 32 == 0 && O <= 512 && Cin % 4 == 0 && N <= 65535ll * 128 &&
                          2.0 * (double)N * (double)O * (double)O >= 1e6 * (double)get_option(GVQA_OPT_SPLIT3_MIN_MFLOP);
+    static const bool overlap_off = []() { const char* v = getenv("GVQA_LCGN_OVERLAP"); return v && v[0] == '0'; }();      // (A/B switch)
+    SideStream* ss = (overlap_off || T < 1) ? nullptr : side_stream_get();
     if (chained) {
         char* pkb = base + L.pk5;
         char *xloc_pk = pkb, *xc_pk[2] = {pkb + L.pk_one, pkb + 2 * L.pk_one}, *prod_pk = pkb + 3 * L.pk_one, *msg_pk = pkb + 4 * L.pk_one;
@@ -521,6 +523,12 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         CH(PACK(x, Cin, Cin, base + L.apk));                                                                    // x_loc = init(x)            :305
         CH(PROD(O, Cin, base + L.apk, nullptr, 7, LinearEpilogue{p->init_bias, nullptr, 0, nullptr, 0, 0}, nullptr, O, xloc_pk));
         {   // the per-question command chain (all T iterations): "graph_term"                                   :307,292-300,148-149
+            // (four small dependent launches on [B, O]-sized operands -- 0.14 ms of pure latency at config 5 -- that nothing needs before the
+            //  first iteration's edge logits: on the side stream, beside the node products below; joined in front of those logits)
+            if (ss) CH(side_fork(ss, stream));
+            hipStream_t stream_main = stream;
+            (void)stream_main;
+            hipStream_t stream = ss ? ss->stream : stream_main;           // (the LIN macro launches on `stream`)
             StageTimer tq(GVQA_STAGE_GRAPH_TERM, stream);
             LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);
             LIN(B, T * O, O, P(L.q_emb), O, PB(PL.Wq), O, PB(PL.bq), 0, P(L.q_cmd), (int64_t)T * O);
@@ -540,6 +548,7 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             CH(PROD(O, O, xc_pk[cur], nullptr, 3, LinearEpilogue{p->proj_x_ctx_bias, nullptr, 0, P(L.proj_x_loc), O, 0}, nullptr, O, prod_pk));
             // J = XL + [prod | x_ctx] . Wj^T: two K segments                                                     :144-145,230
             CH(PROD(3 * O, O, prod_pk, xc_pk[cur], 2, LinearEpilogue{nullptr, P(L.XL), 3 * O, nullptr, 0, 0}, P(L.J), 3 * O, nullptr));
+            if (ss && t == 0) CH(side_join(ss, stream));                          // the command chain's [proj_cmd | cal_cmd] rows
             {
                 StageTimer tl(GVQA_STAGE_EDGE_LOGIT, stream);
                 const dim3 ngrid((unsigned)cdiv(N, 4));
@@ -583,7 +592,11 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
             else LINT(N, O, Cin, x, Cin, p->init_weight, Cin, e, P(L.x_loc), O, FC);      // (x itself is fp32 in every mode)
         }
     }
-    {   // the per-question command chain (all T iterations): "graph_term"
+    {   // the per-question command chain (all T iterations): "graph_term" -- on the side stream, as in the chained form above
+    if (ss) { rc = side_fork(ss, stream); if (rc) return rc; }
+    hipStream_t stream_main = stream;
+    (void)stream_main;
+    hipStream_t stream = ss ? ss->stream : stream_main;
     StageTimer tq(GVQA_STAGE_GRAPH_TERM, stream);
     LIN(B, O, Q, q_encoding, Q, p->qinput1_weight, Q, p->qinput1_bias, 1, P(L.q_emb), O);           // :307
     // textual commands (:292-300) and their projections (:148-149) for all T iterations: per-graph, fp32,
@@ -626,6 +639,7 @@ int gvqa_lcgn_seq_forward(const gvqa_graph* g, const gvqa_lcgn_dims* d, const gv
         NODE_LIN(N, 3 * O, 2 * O, prod, ldx, PB(PL.Wj), 2 * O, pkw.Wj, ep_add, P(L.J), 3 * O, true, 2);
         // dot-product attention logits per edge                                                     // :154,207
         const dim3 ngrid((unsigned)cdiv(N, 4));
+        if (ss && t == 0) { rc = side_join(ss, stream); if (rc) return rc; }      // the command chain's [proj_cmd | cal_cmd] rows
         {
         StageTimer tl(GVQA_STAGE_EDGE_LOGIT, stream);
 #define EDGE_LOGIT(KERNEL_, XL_, XR_)                                                                                    \
