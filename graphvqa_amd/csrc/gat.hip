@@ -1287,10 +1287,15 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
 // terms and the chained hops' term maxima beside hop 0's pack pass, ONE fork and ONE join per forward -- and measured it again,
 // alternating on one box: 2.76 / 2.81 ms with, 2.63 / 2.63 ms without.  The kernels that would overlap are HBM-bound alike (they
 // share the bandwidth) and the two cross-stream dependencies cost this runtime more than the small GEMM hides.  It stays off.
-static SideStream* side_stream() {
-    static const bool enabled = []() { const char* v = getenv("GVQA_OVERLAP"); return v && v[0] == '1'; }();
-    return enabled ? side_stream_get() : nullptr;
+// Round 6: mode 2 -- ONLY the latency-bound per-graph instruction terms (a 50 us chain of two small launches) on the side stream, the HBM-bound
+// edge-logit pass stays in front of the layout pass on the caller's stream -- is the default (-1) for batches of >= 128k edges: config 3
+// 2.122 / 2.136 -> 2.107 / 2.110 ms same box (mode 1: 2.133 / 2.129); config 2 0.552 -> 0.550 (noise); a 256-graph shard LOSES 3 % (the two
+// cross-stream dependencies cost more than its 20 us chain): `profiles/r06_overlap_modes_ab.jsonl`.  GVQA_OVERLAP = 0 / 1 / 2 forces a mode.
+static int side_stream_mode(int64_t edges = 0) {
+    static const int mode = []() { const char* v = getenv("GVQA_OVERLAP"); return v ? atoi(v) : -1; }();
+    return mode >= 0 ? mode : (edges >= 131072 ? 2 : 0);
 }
+static SideStream* side_stream(int64_t edges) { return side_stream_mode(edges) > 0 ? side_stream_get() : nullptr; }
 
 static gvqa_gat_mp_desc mp_desc_from(const gvqa_gat_dims* d, const gvqa_gat_conv_params* p) {
     gvqa_gat_mp_desc m;
@@ -1498,7 +1503,7 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     // Everything that does not depend on the current hop's projection runs on a side stream, under
     // the MFMA-bound projection GEMM on the caller's stream: weight folding, the all-hops edge-logit
     // pass and the graph terms (hop 0), and each hop's node-logit product.
-    SideStream* ss = side_stream();
+    SideStream* ss = side_stream(g->num_edges);
     hipStream_t aux = ss ? ss->stream : stream;
     if (ss) { rc = side_fork(ss, stream); if (rc) return rc; }
     const int np = proj_pieces(d, N, (int64_t)H * C, Dn);
@@ -1532,9 +1537,12 @@ static int gat_seq_forward_impl(const gvqa_graph* g, const gvqa_gat_dims* d, con
     const char* w6 = wbase + WL.w6;
     const size_t w6_hop = WL.w6_hop;
     {   // edge logit terms of ALL hops in one pass over edge_attr: [E, De] x [De, K*H]
-        StageTimer t(GVQA_STAGE_EDGE_LOGIT, aux);
+        // (GVQA_OVERLAP = 2: this HBM-bound pass stays on the caller's stream, in front of the equally HBM-bound layout pass; only the
+        //  latency-bound per-graph terms go to the side stream)
+        hipStream_t es = (side_stream_mode(g->num_edges) == 2 && cached) ? stream : aux;
+        StageTimer t(GVQA_STAGE_EDGE_LOGIT, es);
         rc = launch_linear(E, (int64_t)K * H, De, edge_attr, De, Ve_all, De, nullptr, 0, P(L.a_edge), (int64_t)K * H, 1, 0,
-                           0, 0, aux);
+                           0, 0, es);
         if (rc) return rc;
     }
     if (Di > 0) {   // per-graph instruction terms of all hops: [K] x ([B, Di] x [Di, C+H])

@@ -424,6 +424,37 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
                     __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + (unsigned)(st % NBST) * BST + (unsigned)(wave + 8 * u) * 2048u));
     };
     auto issue_b = [&](int st) { issue_b_unit(st, 0); if (NBU > 1) issue_b_unit(st, 1); };
+    // ... and their forms for the K loop (round 6).  The general forms above cost every step ~25 scalar instructions of pure bookkeeping -- three 64-bit
+    // pointer products with their clamps, two `st % 3` by multiply-high, three pairs of v_readfirstlane -- in a loop that PMC counters and the ISA put at
+    // ~145 issued instructions per wave and step for 24 (wide) or 15 (narrow layout) MFMAs: the narrow layout's step IS its issue time.  In the loop the
+    // bases stay put (SGPR pairs, set per hop), the step is a 32-bit byte offset per lane that advances by 2 KiB and saturates at the last step (two VALU),
+    // and the ring slots are byte offsets that rotate by compare-and-select.
+    unsigned vb_off = 0, vx_off = 0;                  // byte offsets (lane part included) of the NEXT weight step / x chunk to request
+    unsigned bld_off = 0, bcur_off = 0;               // ring stage (byte offset) the next weight DMAs go to / the current step reads
+    const uint16_t *wb0u = nullptr, *wb1u = nullptr;  // wbase0 / wbase1 / xbase as scalar-register pairs
+    const float* xbu = nullptr;
+    auto loop_state_init = [&]() {                     // after the priming DMAs of a hop: the loop's step 0 requests weight step PD and x chunk PD + 1
+        wb0u = ha_uniform(wbase0); wb1u = ha_uniform(wbase1); xbu = ha_uniform(xbase);
+        vb_off = lane16 + (unsigned)min(PD, NQ - 1) * 2048u;
+        vx_off = lane4 + (unsigned)min(PD + 1, NQ - 1) * 2048u;
+        bld_off = (unsigned)(PD % NBST) * BST;
+        bcur_off = 0u;
+    };
+    const unsigned vb_last = lane16 + (unsigned)(NQ - 1) * 2048u, vx_last = lane4 + (unsigned)(NQ - 1) * 2048u;
+    auto loop_issue_b = [&](int u) {
+        if (CP > 1 && !b_owner) return;
+        if (u && !b_second) return;
+        ha_dma16_x2(u ? wb1u : wb0u, vb_off, __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + bld_off + (unsigned)(wave + 8 * u) * 2048u));
+    };
+    auto loop_issue_x = [&](int q) {
+        ha_dma4(xbu, vx_off, __builtin_amdgcn_readfirstlane(lds_base + XR0 + (unsigned)(q & (NXS - 1)) * 2048u + (unsigned)wave * 256u));
+    };
+    auto loop_advance = [&]() {                        // end of a step
+        vb_off = min(vb_off + 2048u, vb_last);
+        vx_off = min(vx_off + 2048u, vx_last);
+        bld_off = bld_off == (unsigned)(NBST - 1) * BST ? 0u : bld_off + BST;
+        bcur_off = bcur_off == (unsigned)(NBST - 1) * BST ? 0u : bcur_off + BST;
+    };
     auto issue_x = [&](int q) {                        // this wave's 256 bytes of x chunk q (clamped) -> ring slot q & 3
         ha_dma4(ha_uniform(xbase + (int64_t)min(q, NQ - 1) * (HA_ROWS * 4)), lane4,
                 __builtin_amdgcn_readfirstlane(lds_base + XR0 + (unsigned)(q & (NXS - 1)) * 2048u + (unsigned)wave * 256u));
@@ -647,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }                                                                                                                   \
         /* ---- from here to the barrier ONE basic block ---- */                                                            \
         const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;                                                    \
-        const unsigned char* sb = smem + HA_B0 + (s % NBST) * BST + b_off;                                                  \
+        const unsigned char* sb = smem + HA_B0 + bcur_off + b_off;                                                          \
         float4 xr;                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < RT; ++i) afl[i] = rd(sa + i * 2048 + 1024);                                   \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) BN_[j] = rd(sb + j * 2048);                                          \
@@ -656,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_group_barrier(0x100, RT + TN, 0);                                                            \
         __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (!GVQA_HA_DBG(2)) issue_b_unit(s + PD, 0);                                                                       \
+        if (!GVQA_HA_DBG(2)) loop_issue_b(0);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a lo, b hi); a hi, b lo and the first four x rows travel under it */                                            \
         GVQA_HA_MFR(0, NM, afl, BN_);                                                                                       \
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         _Pragma("unroll") for (int z = 0; z < (RT + TN + 2) / 2; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); } \
         __builtin_amdgcn_sched_group_barrier(0x008, NM - (RT + TN + 2) / 2, 0);                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        if (NBU > 1 && !GVQA_HA_DBG(2)) issue_b_unit(s + PD, 1);                                                            \
+        if (NBU > 1 && !GVQA_HA_DBG(2)) loop_issue_b(1);                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         /* (a hi, b lo) with the producer: 8 x (4 FMAs), the second four x rows re-using xa */                              \
         GVQA_HA_MFR(0, NH, afh, bl);                                                                                        \
@@ -676,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         else if ((OV_) != 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
         _Pragma("unroll") for (int z = 0; z < NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (40 + NH - 1) / NH, 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        issue_x(s + PD + 1);                                                                                                \
+        loop_issue_x(s + PD + 1);                                                                                           \
         xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                  \
         GVQA_HA_MFR(NH, NM, afh, bl);                                                                                       \
@@ -692,6 +723,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }                                                                                                                   \
         _Pragma("unroll") for (int z = 0; z < NM - NH; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (52 + NM - NH - 1) / (NM - NH), 0); } \
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
+        loop_advance();                                                                                                     \
         /* this wave's DMAs of step s + 1 (issued one step ago) have landed, its A' writes are out; then everybody's */     \
         if (!GVQA_HA_DBG(16)) {                                                                                             \
             if (CP == 1 && (NTP >= 16 || b_second)) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
@@ -834,6 +866,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         for (int e = 0; e < HA_NOV / 2; ++e) so2[e] = 0u;
     }
     produce(0);
+    loop_state_init();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     GVQA_HA_STAMP(hop, 1);                            // rings primed, first A' chunk produced
