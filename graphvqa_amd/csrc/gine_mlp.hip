@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
 
     auto rd = [&](const unsigned char* p_) { return __builtin_bit_cast(gm_f16x8, *reinterpret_cast<const uint4*>(p_)); };
     // one K step of either layer: 10 column tiles x three piece products, B fragments from ring stage g % GM_NST in two groups of five
-    // tiles (product-major inside a group: five independent MFMAs between two on the same accumulator)
+    // tiles (product-major inside a group: five independent MFMAs between two on the same accumulator).
+    // (Tried, round 6: the step ROTATED around its barrier -- the second group's fragments read before the barrier, multiplied behind it
+    //  under the next step's first reads, so that no step opens with an exposed LDS round trip: layer 1 19.1 -> 20.3 us, layer 2 14.7 ->
+    //  16.1 us.  The read latency is not what a step waits for.  What the ISA and the guide's price list point at instead: the step's
+    //  6-8 LDS-DMA instructions per wave -- 60-185 cycles of issue each beside MFMAs -- are ~500 cycles per SIMD and step, the size of
+    //  the gap between the step's 0.46 us of MFMAs and its 0.75-1.0 us.  A K step moves 28 KiB per CU whichever wave asks for it.)
     auto mma_step = [&](int g, const gm_f16x8& afh, const gm_f16x8& afl) {
         const unsigned char* sb = smem + (g % GM_NST) * GM_BST + lane * 16;
 #pragma unroll
