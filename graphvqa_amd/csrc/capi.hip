@@ -37,7 +37,7 @@ static void options_init() {
     g_opt[GVQA_OPT_HOP_FUSION] = env_int("GVQA_HOP_FUSION", 3);
     g_opt[GVQA_OPT_COEFF_KERNEL] = 0;
     g_opt[GVQA_OPT_MP_PARTS] = 0;
-    g_opt[GVQA_OPT_HOP_COEFFS] = env_int("GVQA_HOP_COEFFS", 0);
+    g_opt[GVQA_OPT_HOP_COEFFS] = env_int("GVQA_HOP_COEFFS", 2);
     g_opt[GVQA_OPT_HOP_HALF_TILES] = env_int("GVQA_HOP_HALF_TILES", 1);
     g_opt[GVQA_OPT_TN_DIRECT] = env_int("GVQA_TN_DIRECT", 1);
     g_opt[GVQA_OPT_PACKED_GROUPS] = env_int("GVQA_PACKED_GROUPS", 1);

@@ -1136,7 +1136,12 @@ static bool hopagg_seq_applies(const gvqa_graph* g, const gvqa_gat_dims* d) {
 // In-kernel attention coefficients for the chained 8-wave hops (k_linear_split3<..., CHN = 2>, GVQA_OPT_HOP_COEFFS): both row groups'
 // CSR slices resident in LDS at once
 static bool chain8_in_kernel_coeffs(const gvqa_graph* g, const gvqa_gat_dims* d) {
-    return get_option(GVQA_OPT_HOP_COEFFS) != 0 && d->heads == 4 && (size_t)g->max_row_group_edges <= hop_fused_ic_lds_edge_capacity(4);
+    // GVQA_OPT_HOP_COEFFS: 1 always, 0 never, 2 (default, round 6) by size -- below 128 row groups a hop's launches are latency-bound and
+    // the in-kernel phase replaces two of them per hop (256-graph shard, same box: 0.413 -> 0.394 ms, 16 launches -> 7); above that the
+    // coefficient kernels win (config 2 on the 8-wave kernel, round 5: 0.705 vs 0.725)
+    const int opt = get_option(GVQA_OPT_HOP_COEFFS);
+    const bool want = opt == 1 || (opt == 2 && g->num_row_groups < 128);
+    return want && d->heads == 4 && (size_t)g->max_row_group_edges <= hop_fused_ic_lds_edge_capacity(4);
 }
 static bool chain8_shape_ok(const gvqa_graph* g, const gvqa_gat_dims* d) {
     // (below ~128 row groups every launch of a hop is latency-bound and the chained coefficient kernel -- it reads the packed rows

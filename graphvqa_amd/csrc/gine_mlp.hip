@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
     const int nd = wave < 2 ? 3 : 2;                   // (wave-uniform)
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_b = [&](int g) {
+#ifdef GVQA_GM_NODMA            /* (timing variant, results wrong: no weight DMAs after the priming ones -- what their issue costs a step) */
+        if (g >= GM_PD) return;
+#endif
         const int gs = min(g, NS - 1);
         const bool l2 = gs >= NQ1;
         const uint16_t* img = l2 ? a.W2pk : a.W1pk;
@@ -176,6 +179,9 @@ __global__ __launch_bounds__(256, 1) void k_gine_mlp(GineMlpArgs a) {
     const float* zrow = a.z + (int64_t)rowc * a.ldz + 8 * hh;
     const unsigned zl0 = GM_Z0 + (unsigned)wave * 8192u;        // this wave's [4 slots][2 quads][64 lanes][16 bytes]
     auto zload = [&](int s) {                          // (steps past the last: the last step's rows again, into a free slot)
+#ifdef GVQA_GM_NODMA
+        if (s >= GM_ZD) return;
+#endif
         const float* p_ = zrow + 16 * min(s, NQ1 - 1);
         const unsigned d_ = __builtin_amdgcn_readfirstlane(lds_base + zl0 + (unsigned)(s & 3) * 2048u);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"

@@ -475,7 +475,8 @@ enum gvqa_option {
     GVQA_OPT_HOP_COEFFS = 7,       /* chained hops on the 8-wave kernel: 1 = attention coefficients computed INSIDE the hop kernel -- partial node logits
                                       left by the previous hop's column blocks, edge halves gathered through the CSR edge ids, leaky-relu + segment
                                       softmax in LDS: one launch per hop, no coefficient kernel, no pack pass after hop 0 (row groups within 522 edges
-                                      at H = 4).  0 (default) = the coefficient kernels of rounds 3 / 4.  Built and parity-green in round 5, and
+                                      at H = 4).  0 = the coefficient kernels of rounds 3 / 4.  2 (default since round 6) = 1 for batches of fewer than 128 row
+                                      groups (where a hop's launches are latency-bound: 256-graph shard 0.413 -> 0.394 ms), 0 above.  Built and parity-green in round 5, and
                                       measured a wash: the phase costs the hop kernel what the two small launches it replaces cost (256-graph shard
                                       0.409 vs 0.414 ms, config 2 0.723 vs 0.705 ms per forward; profiles/r05_hop_coeffs_ab.txt) */
     GVQA_OPT_HOP_HALF_TILES = 8,   /* 8-wave fused hop: 1 (default) the row blocks of a launch's last PARTIAL round of workgroups take one row group each (128-row
