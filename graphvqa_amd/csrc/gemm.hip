@@ -389,13 +389,17 @@ __global__ __launch_bounds__(256) void k_linear_f32_skinny_dma(int M, int N, int
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         pb = B + (int64_t)min(row, N - 1) * ldb + chunk * 4;
     }
-    const int nt = K / BK;
+    // (round 6: K % 4 == 0 instead of K % 32 == 0 -- the reference's real edge width is 300.  The last step's chunks past K are fetched from the
+    //  row's first chunk instead -- a mapped address -- and the A fragment is zeroed at use)
+    const int nt = (K + BK - 1) / BK;
+    const int my_chunk4 = ((lane & 7) ^ ((((wave * 8 + (lane >> 3))) >> 1) & 7)) * 4;       // k offset of this lane's chunk inside a step (the row groups wave + 4 j share wave's swizzle)
     auto issue = [&](int t) {                    // K step t (clamped: steps past the last re-load it into a free slot, so that the counted waits stay uniform)
         const int tt = min(t, nt - 1);
+        const int64_t off = (tt * BK + my_chunk4 < K) ? (int64_t)tt * BK : -(int64_t)my_chunk4;
         const unsigned dst = lds_base + (unsigned)(t % NS) * STAGE + (unsigned)wave * 1024u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16_b(pa[j] + (int64_t)tt * BK, __builtin_amdgcn_readfirstlane(dst + j * 4096));
-        lds_dma16_b(pb + (int64_t)tt * BK, __builtin_amdgcn_readfirstlane(dst + A_BYTES));
+        for (int j = 0; j < 4; ++j) lds_dma16_b(pa[j] + off, __builtin_amdgcn_readfirstlane(dst + j * 4096));
+        lds_dma16_b(pb + off, __builtin_amdgcn_readfirstlane(dst + A_BYTES));
     };
     const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
     unsigned xo[4];
@@ -411,8 +415,9 @@ __global__ __launch_bounds__(256) void k_linear_f32_skinny_dma(int M, int N, int
         const unsigned char* bt = at + A_BYTES;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
-            const float4 af = *reinterpret_cast<const float4*>(at + a_row + xo[kg]);
+            float4 af = *reinterpret_cast<const float4*>(at + a_row + xo[kg]);
             const float4 bf = *reinterpret_cast<const float4*>(bt + b_row + xo[kg]);
+            if (t * BK + (kg * 2 + fh) * 4 >= K) af = make_float4(0.f, 0.f, 0.f, 0.f);      // (the last step's chunks past K)
             // (operands swapped, B first: a lane owns 4 consecutive columns of one C row per register quad)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.x, af.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf.y, af.y, acc, 0, 0, 0);
@@ -643,7 +648,7 @@ int launch_linear_t(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     auto al16 = [&](const void* q, int64_t ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); };
     const bool ep4_ok = N % 4 == 0 && al16(C, ldc) && al16(ep.addend, ep.ld_add) && al16(ep.mul, ep.ld_mul) && al16(ep.bias, 4);
     // tall skinny streams (the all-hops edge logits): the four-stage LDS-DMA ring keeps three A tiles per workgroup in flight
-    if (N <= 32 && N % 4 == 0 && K % 32 == 0 && K >= 96 && vec && batch == 1 && M >= 16384 && !ep.bias && !ep.addend && !ep.mul && !ep.relu &&
+    if (N <= 32 && N % 4 == 0 && K % 4 == 0 && K >= 96 && vec && batch == 1 && M >= 16384 && !ep.bias && !ep.addend && !ep.mul && !ep.relu &&
         ep4_ok && tile_sel == 0) {
         hipLaunchKernelGGL(k_linear_f32_skinny_dma, dim3((unsigned)cdiv(M, 128)), dim3(256), 0, stream, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc);
     }

@@ -103,7 +103,7 @@ def test_linear_f32(dev, M, N, K):
         assert maxabs(out2, ref2) < 2e-6 * (float(ref2.abs().max()) + 1) * np.sqrt(K)
 
 
-@pytest.mark.parametrize("M,N,K,ldc", [(20000, 20, 512, 20), (16385, 4, 96, 8), (65536 + 77, 32, 128, 32), (40000, 8, 300 // 32 * 32, 12)])
+@pytest.mark.parametrize("M,N,K,ldc", [(20000, 20, 512, 20), (16385, 4, 96, 8), (65536 + 77, 32, 128, 32), (40000, 8, 300 // 32 * 32, 12), (59570, 20, 300, 20), (16400, 32, 100, 32), (20000, 12, 132, 12)])
 def test_linear_tall_skinny_stream(dev, M, N, K, ldc):
     """The LDS-DMA streaming kernel for tall skinny plain products (k_linear_f32_skinny_dma: M >= 16384, N <= 32, N % 4 == 0, K % 32 == 0 --
     the all-hops edge logits [E, De] x [De, K H]): ragged last row tile, N from 4 to 32, result rows wider than N (the columns beyond stay
