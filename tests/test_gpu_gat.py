@@ -968,8 +968,39 @@ def test_packed_row_groups_plan_is_a_row_permuted_copy_of_the_csr(dev):
     assert packed_cases >= 20, packed_cases
 
 
-@pytest.mark.parametrize("C,de,di", [(64, 16, 12), (300, 40, 512), (512, 24, 32)])
-def test_packed_row_groups_forward_equals_the_in_order_groups_bit_for_bit(dev, C, de, di):
+def test_packed_row_groups_are_not_built_where_they_cannot_serve(dev):
+    """No packed numbering when GVQA_OPT_PACKED_GROUPS = 0, when a graph alone exceeds the aggregate-first kernel's CSR slice (1024
+    in-edges), or when no order of the graphs saves a row group; mode 1 (default) builds it only when it saves a ROUND of workgroups."""
+    from graphvqa_amd import _lib
+    from graphvqa_amd.graph import SceneGraphBatch, HostLayout
+    rng = np.random.default_rng(9)
+    ei, batch, sizes = _ragged_batch(rng, 300, 20, 40, 1.0)
+    N, B = int(batch.shape[0]), int(sizes.shape[0])
+    mk = lambda e_, b_, n_, B_: SceneGraphBatch(t(e_, device=dev), t(b_, device=dev), n_, B_, host_layout=HostLayout.from_numpy(e_, b_, B_))
+    old = _lib.set_option(_lib.OPT_PACKED_GROUPS, 0)
+    try:
+        assert mk(ei, batch, N, B).c.pk_num_row_groups == 0
+        _lib.set_option(_lib.OPT_PACKED_GROUPS, 2)
+        g = mk(ei, batch, N, B)
+        assert 0 < g.c.pk_num_row_groups < g.c.num_row_groups
+        _lib.set_option(_lib.OPT_PACKED_GROUPS, 1)        # ~80 in-order groups -> ~70 packed: one round of 256 CUs either way
+        assert mk(ei, batch, N, B).c.pk_num_row_groups == 0
+        _lib.set_option(_lib.OPT_PACKED_GROUPS, 2)
+        # one graph with 1100 in-edges among small ones
+        n0 = 40
+        big = np.stack([rng.integers(0, n0, size=1100), rng.integers(0, n0, size=1100)]).astype(np.int64)
+        ei2 = np.concatenate([big, ei + n0], axis=1)
+        batch2 = np.concatenate([np.zeros(n0, np.int64), batch + 1])
+        assert mk(ei2, batch2, N + n0, B + 1).c.pk_num_row_groups == 0
+        # full groups already: 64 graphs of 32 nodes
+        gb = synth.config3_batch(64)
+        assert mk(gb.edge_index, gb.batch, gb.num_nodes, gb.num_graphs).c.pk_num_row_groups == 0
+    finally:
+        _lib.set_option(_lib.OPT_PACKED_GROUPS, old)
+
+
+@pytest.mark.parametrize("C,de,di,lo,hi,dens", [(64, 16, 12, 20, 40, 1.5), (300, 40, 512, 20, 40, 1.5), (512, 24, 32, 20, 40, 1.5), (128, 8, 8, 0, 50, 0.5), (64, 8, 0, 1, 128, 3.0)])
+def test_packed_row_groups_forward_equals_the_in_order_groups_bit_for_bit(dev, C, de, di, lo, hi, dens):
     """The aggregate-first hops (GVQA_OPT_HOP_FUSION = 4 per-hop launches with attention weights and per-hop rows, 5 one launch) on the
     packed row groups: same graphs, same per-node edge order, same per-graph scales -- so the output must EQUAL the in-order groups'
     (GVQA_OPT_PACKED_GROUPS = 0 at forward time) bit for bit, and both sit within 1e-4 of the oracle (gat_skip.py:249-279)."""
@@ -979,10 +1010,10 @@ def test_packed_row_groups_forward_equals_the_in_order_groups_bit_for_bit(dev, C
     from graphvqa_amd.graph import SceneGraphBatch, HostLayout
     H, K = 4, 3
     rng = np.random.default_rng(77 + C)
-    ei, batch, sizes = _ragged_batch(rng, 90, 20, 40, 1.5)
+    ei, batch, sizes = _ragged_batch(rng, 90 if hi <= 50 else 160, lo, hi, dens)      # (lo = 0: empty graphs take ids without rows; hi = 128: graphs that fill a group alone)
     N, E, B = int(batch.shape[0]), int(ei.shape[1]), int(sizes.shape[0])
     p = synth.gat_seq_params(C, C, de, di, K, H, seed=78)
-    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, di), 3)
+    x, ea, ins = synth.normal((N, C), 1), synth.normal((E, de), 2), synth.normal((K, B, max(di, 1)), 3)[:, :, :di]
     ref, hops_ref, alphas = R.gat_seq(t(x), t(ei), t(ea), t(ins), t(batch), tparams(p), heads=H, return_all=True)
     m = _load_module(gat_seq(C, C, de, di, K, dropout=0.1, gat_heads=H), p, dev)
     args = [t(a, device=dev) for a in (x, ei, ea, ins, batch)]
