@@ -660,7 +660,9 @@ typedef struct gvqa_gine_params {   /* GINEConv(Seq(Lin, ReLU, Lin)): convs.i.nn
 /* PyG GINEConv on x = [h || ins[batch]], e = [edge_attr || ins[batch[src]]] (both node_dim+ins_dim
  * wide, pipeline_model_gine.py:651-665): out = nn((1+eps) x_i + sum_{j->i} relu(x_j + e_ji)).
  * h [N, node_dim], edge_attr [E, node_dim] (COO order), ins [B, ins_dim] (NULL when ins_dim == 0:
- * h / edge_attr are then the full inputs), out [N, C].  ins_dim > 0 needs an intra-graph batch. */
+ * h / edge_attr are then the full inputs), out [N, C].  ins_dim > 0 needs an intra-graph batch.
+ * C <= 320 (the reference: 300) with 16-byte aligned rows and >= 1024 nodes: nn runs as ONE kernel (csrc/gine_mlp.hip -- the hidden
+ * rows stay in registers between the two Linears); other shapes: two products with the ReLU pass between them. */
 GVQA_API size_t gvqa_gine_conv_workspace_bytes(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C);
 GVQA_API int gvqa_gine_conv_forward(const gvqa_graph* g, int32_t node_dim, int32_t ins_dim, int32_t C,
                            const gvqa_gine_params* p, const float* h, const float* edge_attr, const float* ins,
