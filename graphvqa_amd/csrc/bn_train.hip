@@ -92,7 +92,7 @@ __global__ __launch_bounds__(1024) void k_bn_col_finish(int nblocks, int C, cons
 }
 
 // Feature-dropout decisions made in the kernels (Philox4x32-10, the counter-based generator torch's own CUDA dropout uses): the quad of 4
-// consecutive channels at element index 4 q gets counter (q, offset), key = seed; an element is kept when its 32-bit draw is below
+// consecutive channels at element index 4 q gets counter (q, offset), key = seed ^ a library constant; an element is kept when its 32-bit draw is below
 // `thresh` = (1 - p) 2^32.  Forward and both backward passes regenerate the same decisions: no [N, C] mask exists in HBM.
 struct KeepRng { unsigned long long seed, offset; unsigned thresh; int on; };
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
@@ -107,7 +107,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 __device__ __forceinline__ uchar4 rng_keep4(const KeepRng& g, int64_t quad) {
     const uint4 d = philox4x32_10(make_uint4((unsigned)quad, (unsigned)((unsigned long long)quad >> 32), (unsigned)g.offset, (unsigned)(g.offset >> 32)),
-                                  make_uint2((unsigned)g.seed, (unsigned)(g.seed >> 32)));
+                                  make_uint2((unsigned)g.seed ^ 0x48495031u, (unsigned)(g.seed >> 32) ^ 0x67767161u));
+    // (the key is the caller's seed XOR a library constant: with the seed itself -- torch's own key -- and counters laid out (quad, offset) against torch's
+    //  (offset / 4, thread), a draw here could coincide with one of torch's dropout / randn kernels under the same torch.manual_seed; a different key is a
+    //  different, independent stream whatever the counters are -- ADVICE r05)
     return make_uchar4(d.x < g.thresh, d.y < g.thresh, d.z < g.thresh, d.w < g.thresh);
 }
 __global__ __launch_bounds__(256) void k_rng_scale_mask(int64_t quads, KeepRng g, float kscale, float* __restrict__ out) {

@@ -709,6 +709,8 @@ class _BatchNormReluTrain(torch.autograd.Function):
         x, weight, bias, mean, var, keep = ctx.saved_tensors
         N, Cc = x.shape
         dy = dy.contiguous()
+        if ctx.rng is not None and dy.data_ptr() % 16:
+            dy = dy.clone(memory_format=torch.contiguous_format)      # (a view at an unaligned offset: the rng kernels read 16-byte quads; a fresh allocation is aligned -- ADVICE r05: never raise from backward for this)
         dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(bias)
         if ctx.rng is not None:
             with torch.cuda.device(x.device):

@@ -266,7 +266,7 @@ GVQA_API int gvqa_bn_relu_dropout_train_backward(int64_t N, int32_t C, const flo
                                         float keep_scale, const float* dy, float* dx, float* dweight, float* dbias, void* ws,
                                         size_t ws_bytes, void* stream);
 /* The same with the keep decisions DRAWN IN THE KERNELS (F.dropout of gat_skip.py:276 without a mask tensor): Philox4x32-10, counter = (index of
- * the quad of 4 consecutive channels, offset), key = seed -- the caller takes (seed, offset) from its generator (torch: initial_seed() /
+ * the quad of 4 consecutive channels, offset), key = seed XOR a library constant (a stream of its own: never one of torch's under the same seed) -- the caller takes (seed, offset) from its generator (torch: initial_seed() /
  * get_offset(), then set_offset() past the N*C/4 counters used) so that runs are reproducible from torch.manual_seed; an element is kept when its
  * 32-bit draw is below (1 - p) 2^32 and scaled by 1 / (1 - p).  The backward regenerates the forward's decisions from the same (seed, offset, p).
  * C % 4 == 0 and 16-byte aligned rows (GVQA_E_UNSUPPORTED otherwise: use the explicit-mask forms).  gvqa_dropout_keep_mask writes the decisions
