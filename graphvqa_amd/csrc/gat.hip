@@ -1293,12 +1293,15 @@ static SeqLayout seq_layout(int64_t N, int64_t E, int64_t B, const gvqa_gat_dims
 // alternating on one box: 2.76 / 2.81 ms with, 2.63 / 2.63 ms without.  The kernels that would overlap are HBM-bound alike (they
 // share the bandwidth) and the two cross-stream dependencies cost this runtime more than the small GEMM hides.  It stays off.
 // Round 6: mode 2 -- ONLY the latency-bound per-graph instruction terms (a 50 us chain of two small launches) on the side stream, the HBM-bound
-// edge-logit pass stays in front of the layout pass on the caller's stream -- is the default (-1) for batches of >= 128k edges: config 3
-// 2.122 / 2.136 -> 2.107 / 2.110 ms same box (mode 1: 2.133 / 2.129); config 2 0.552 -> 0.550 (noise); a 256-graph shard LOSES 3 % (the two
-// cross-stream dependencies cost more than its 20 us chain): `profiles/r06_overlap_modes_ab.jsonl`.  GVQA_OVERLAP = 0 / 1 / 2 forces a mode.
+// edge-logit pass stays in front of the layout pass on the caller's stream.  On a forward with a PREBUILT graph handle it gained 0.9 % at config 3
+// (2.122 / 2.136 -> 2.107 / 2.110 ms same box, scripts/bench_hopagg.py; mode 1: 2.133 / 2.129), nothing at config 2, and lost 3 % on a 256-graph
+// shard -- and inside bench.py's step, where the CSR build (pinned upload + launch) precedes every forward, it LOST 5-10 % (2.12 / 2.25 -> 2.36 /
+// 2.32 ms, alternating on one box; the side stream's two launches then run 2.5x longer and the join stalls the hop launch):
+// `profiles/r06_overlap_modes_ab.jsonl`.  Off by default, as after rounds 1 and 4; GVQA_OVERLAP = 1 / 2 asks for a mode.
 static int side_stream_mode(int64_t edges = 0) {
-    static const int mode = []() { const char* v = getenv("GVQA_OVERLAP"); return v ? atoi(v) : -1; }();
-    return mode >= 0 ? mode : (edges >= 131072 ? 2 : 0);
+    static const int mode = []() { const char* v = getenv("GVQA_OVERLAP"); return v ? atoi(v) : 0; }();
+    (void)edges;
+    return mode;
 }
 static SideStream* side_stream(int64_t edges) { return side_stream_mode(edges) > 0 ? side_stream_get() : nullptr; }
 
