@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_linear_bf16(int M, int N, int 
 // Epilogue from TRANSPOSED accumulators (MFMA operands swapped: a lane owns 4 consecutive columns of one C row per
 // register quad): 16 stores per lane of 8 bytes (bf16 C) / 16 bytes (fp32 C), addend / mul read the same way; no LDS
 // round trip, no barrier.  Needs N % 4 == 0 and 8- / 16-byte aligned rows.
-template <bool C16, typename TC>
-__device__ __forceinline__ void store_tile_transposed_b(f32x16 (&acc)[2][2], int M, int N, int m0, int n0, int wr, int wc, int lane,
+template <bool C16, typename TC, int MT = 2, int NT = 2>
+__device__ __forceinline__ void store_tile_transposed_b(f32x16 (&acc)[MT][NT], int M, int N, int m0, int n0, int wr, int wc, int lane,
                                                         const LinearEpilogue& ep, TC* C, int64_t ldc) {
     const int mrow = lane & 31, ncol0 = 4 * (lane >> 5);
     auto load4 = [&](const float* base, int64_t elem, float (&o)[4]) {
@@ -155,14 +155,14 @@ __device__ __forceinline__ void store_tile_transposed_b(f32x16 (&acc)[2][2], int
         }
     };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gr = m0 + wr * 64 + i * 32 + mrow;
+    for (int i = 0; i < MT; ++i) {
+        const int gr = m0 + wr * (MT * 32) + i * 32 + mrow;
         if (gr >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int gc = n0 + wc * 64 + j * 32 + 8 * q + ncol0;
+                const int gc = n0 + wc * (NT * 32) + j * 32 + 8 * q + ncol0;
                 if (gc >= N) continue;                 // N % 4 == 0: a quad is entirely inside or outside
                 float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 if (ep.bias) {
@@ -399,6 +399,113 @@ __global__ __launch_bounds__(512) void k_linear_bf16_wide(int M, int N, int K, c
     store_tile_transposed_b<C16>(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
 }
 
+// ---- 256 x 256 tile, two-piece weights, three-stage ring (round 6) ----------------------------------------------------
+// Why another tile: in the 256 x 128 kernel above a wave (64 x 64 of C, two weight pieces) reads 2 A + 4 B fragments from LDS for 8
+// MFMAs -- per K step the CU's LDS moves 48 KiB of fragment reads + 16 KiB of DMA writes per 512 matrix-core clocks and SIMD: at
+// 128 B/clk that IS 512 clocks, the LDS pipe saturates exactly where the matrix pipe does, and every bank conflict or issue bubble
+// is lost MFMA time (0.66-0.71 PF/s issued on the LCGN shapes).  Here a wave owns 128 x 64 of C (4 x 2 tiles, 128 accumulator
+// registers): 4 A + 4 B fragments for 16 MFMAs, LDS traffic 0.69 of the matrix-core time; and a [29785, 512] product is 234
+// workgroups -- ONE round of the 256 CUs instead of two rounds of 468 half-size ones.  K step 32 (64-byte rows: a DMA instruction
+// deposits 16 rows; slot (row r, position q) holds k-chunk q ^ ((r >> 2) & 3), so that the 16 rows of a fragment-read phase fall
+// on 64 distinct banks), stage = 16 KiB of A + 2 x 16 KiB of weights, three stages (144 KiB), DMAs two steps ahead behind a
+// counted wait, one barrier per step.
+template <bool C16>
+__global__ __launch_bounds__(512) void k_linear_bf16_big(int M, int N, int K, const uint16_t* __restrict__ A, int64_t lda,
+                                                         const uint16_t* __restrict__ B, int64_t ldb, LinearEpilogue ep,
+                                                         void* C_, int64_t ldc) {
+    constexpr int BM = 256, BN = 256, BK = 32, P = 2, NST = 3;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;              // 16 KiB each
+    constexpr int STAGE = A_BYTES + P * B_BYTES;                             // 48 KiB
+    constexpr int NDMA = STAGE / 1024 / 8;                                   // 6 DMA instructions per wave per K step
+    typedef typename std::conditional<C16, uint16_t, float>::type TC;
+    TC* C = static_cast<TC*>(C_);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // DMA d of wave w covers stage unit u = d * 8 + w (16 rows of 64 bytes): units [0, 16) are A rows, then 16 units per weight piece
+    const uint16_t* src[NDMA];
+    unsigned dst[NDMA];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) {
+        const int u = d * 8 + wave;
+        const bool isA = u < BM / 16;
+        const int ub = isA ? u : (u - BM / 16) % (BN / 16), piece = isA ? 0 : (u - BM / 16) / (BN / 16);
+        const int row = ub * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        src[d] = isA ? A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8
+                     : B + (int64_t)min(n0 + row, N - 1) * ldb + (int64_t)piece * K + chunk * 8;
+        dst[d] = lds_base + (unsigned)u * 1024u;
+    }
+    auto issue_one = [&](unsigned stage_off, int d) {
+        lds_dma16_b(src[d], __builtin_amdgcn_readfirstlane(dst[d] + stage_off));
+        src[d] += BK;
+    };
+
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 2) & 3;
+    unsigned xo[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
+    const unsigned a_row = (unsigned)((wr * 128 + frow) * 64), b_row = (unsigned)(A_BYTES + (wc * 64 + frow) * 64);
+
+    const int nt = K / BK;
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) issue_one(0u, d);
+    if (nt > 1) {
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) issue_one((unsigned)STAGE, d);
+    }
+    unsigned cur_off = 0u, ld_off = 2u * STAGE;                // stage of the current step / of the step two ahead
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 2 < nt;
+        // step t's six DMAs are older than step t + 1's (the only ones that may still fly): counted wait, then the barrier that also
+        // says every wave is done reading stage (t - 1) % 3 -- the one refilled below
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* st = smem + cur_off;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            bf16x8 af[4], bf[P][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 64 + xo[kg]));
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bf[p][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + b_row + p * B_BYTES + j * 32 * 64 + xo[kg]));
+            // operands swapped (B fragment first): transposed accumulators, see store_tile_transposed_b
+#pragma unroll
+            for (int p = P - 1; p >= 0; --p) {                    // low-order piece first
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[p][j], af[i], acc[i][j], 0, 0, 0);
+                if (more) {                                       // the DMAs of the step two ahead, spread over this step's four MFMA groups
+#pragma unroll
+                    for (int d = 0; d < NDMA; ++d)
+                        if (d * 4 / NDMA == kg * P + (P - 1 - p)) issue_one(ld_off, d);
+                }
+            }
+        }
+        cur_off = cur_off == (unsigned)(NST - 1) * STAGE ? 0u : cur_off + STAGE;
+        ld_off = ld_off == (unsigned)(NST - 1) * STAGE ? 0u : ld_off + STAGE;
+    }
+    store_tile_transposed_b<C16, TC, 4, 2>(acc, M, N, m0, n0, wr, wc, lane, ep, C, ldc);
+}
+
 // Wpk[n, p*Kp + k] = p-th bf16 piece of W[n, k] (piece 0 = round-to-nearest bf16 of w, piece 1 = bf16 of the
 // remainder), zero for K <= k < Kp (K padded up to the GEMM's multiple of 8)
 __global__ __launch_bounds__(256) void k_pack_weight_bf16(int64_t rows, int K, int Kp, int P, const float* __restrict__ W,
@@ -469,6 +576,19 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     // wide tile: whole K steps, a grid that fills the chip (>= 256 tiles of 256 x 128)
     // (measured, MFMA rate at the LCGN shapes: two-piece weights 808-852 TF wide vs 715 narrow; single piece 506-557 wide vs
     //  578-600 narrow -- without a second piece to share the A fragments the wide tile's longer block lifetime costs more)
+    // 256 x 256 tile (two-piece weights, whole K steps of 32): from three quarters of a round of the CUs up to four rounds
+    // (measured stand-alone, issued PF/s, 256 x 256 vs 256 x 128 -- `profiles/r06_bf16_gemm_ab.jsonl`: [29785, 512] x K 512 0.78 vs 0.72, x K 1024
+    //  0.95 vs 0.90; [29785, 1536] x K 512 0.82 vs 0.78, x K 1024 0.89 vs 0.86; but [65536, 2048] x K 512 -- eight rounds -- 0.79 vs 0.85; the LCGN
+    //  bf16 forward 2.207 -> 2.150 ms)
+    static const bool no_big = []() { const char* v = getenv("GVQA_BF16_GEMM"); return v && (!strcmp(v, "wide") || !strcmp(v, "narrow")); }();
+    const int64_t big_tiles = cdiv(M, 256) * cdiv(N, 256);
+    if (P == 2 && K % 32 == 0 && !no_dma && !no_big && quad_ok && big_tiles >= 192 && big_tiles <= 4 * (int64_t)device_cu_count() && cdiv(M, 256) <= 65535) {
+        dim3 gridb((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256));
+        if (c16) hipLaunchKernelGGL(k_linear_bf16_big<true>, gridb, dim3(512), 0, stream, (int)M, (int)N, (int)K, a, lda, b, (int64_t)P * K, ep, C, ldc);
+        else hipLaunchKernelGGL(k_linear_bf16_big<false>, gridb, dim3(512), 0, stream, (int)M, (int)N, (int)K, a, lda, b, (int64_t)P * K, ep, C, ldc);
+        GVQA_LAUNCH_CHECK();
+        return GVQA_OK;
+    }
     if (P == 2 && K % 64 == 0 && !no_dma && !no_wide && quad_ok && cdiv(M, 256) * cdiv(N, 128) >= 256) {
         dim3 gridw((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 256));
 #define GVQA_WIDE(C16_, P_) hipLaunchKernelGGL((k_linear_bf16_wide<C16_, P_>), gridw, dim3(512), 0, stream, (int)M, (int)N, (int)K, a, lda, b, \
