@@ -409,23 +409,93 @@ __global__ __launch_bounds__(512) void k_linear_bf16_wide(int M, int N, int K, c
 // deposits 16 rows; slot (row r, position q) holds k-chunk q ^ ((r >> 2) & 3), so that the 16 rows of a fragment-read phase fall
 // on 64 distinct banks), stage = 16 KiB of A + 2 x 16 KiB of weights, three stages (144 KiB), DMAs two steps ahead behind a
 // counted wait, one barrier per step.
+#ifndef GVQA_BIG_LOADERS
+#define GVQA_BIG_LOADERS 0  /* 4: the DMAs are issued by four extra waves (one per SIMD) that do nothing else; the eight MFMA waves issue none */
+#endif
+#ifndef GVQA_BIG_ABL
+#define GVQA_BIG_ABL 0      /* measurement builds (scripts/r06_big_ablation.sh): 1 no DMAs in the loop, 2 fragments read once, 4 no barrier, 8 no counted wait */
+#endif
+// (Measured and dropped: per-lane 64-bit source pointers advanced every step instead of a scalar base + constant lane offset -- 0.966 vs 1.006 PF/s
+//  issued on [29785, 1536] x K 1024; the two waves of a SIMD issuing their DMAs in different halves of the step -- no change.  What the step spends
+//  outside its MFMAs, same product, `profiles/r06_bf16_big_ablation.jsonl`: MFMAs only 1.244 PF/s (the chip's power-limited rate on random operands:
+//  1.47 on zeros), without the DMAs 1.107, as shipped 1.006.  GVQA_BIG_LOADERS = 4 -- the DMAs issued by four extra waves, one per SIMD, that do
+//  nothing else (162 registers, twelve waves per CU) -- 1.066-1.070 against 1.055 on the same box, nothing on the smaller products, the LCGN
+//  forward 2.131 -> 2.118 ms (`r06_bf16_big_loaders_ab.jsonl`): what the DMAs cost is not issue slots of the MFMA waves but the data movement
+//  itself.  Left as a build switch, off.)
 template <bool C16>
-__global__ __launch_bounds__(512) void k_linear_bf16_big(int M, int N, int K, const uint16_t* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(512 + 64 * GVQA_BIG_LOADERS) void k_linear_bf16_big(int M, int N, int K, const uint16_t* __restrict__ A, int64_t lda,
                                                          const uint16_t* __restrict__ B, int64_t ldb, LinearEpilogue ep,
                                                          void* C_, int64_t ldc) {
     constexpr int BM = 256, BN = 256, BK = 32, P = 2, NST = 3;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;              // 16 KiB each
     constexpr int STAGE = A_BYTES + P * B_BYTES;                             // 48 KiB
-    constexpr int NDMA = STAGE / 1024 / 8;                                   // 6 DMA instructions per wave per K step
+    constexpr int LDW = GVQA_BIG_LOADERS;                                    // loader waves (0: every MFMA wave issues its share)
+    constexpr int NIW = LDW > 0 ? LDW : 8;                                   // waves that issue DMAs
+    constexpr int NDMA = STAGE / 1024 / NIW;                                 // DMA instructions per issuing wave per K step (6, or 12 per loader)
     typedef typename std::conditional<C16, uint16_t, float>::type TC;
     TC* C = static_cast<TC*>(C_);
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = (wave >> 2) & 1, wc = wave & 3;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const unsigned lds_base = (unsigned)(size_t)(lds_bytes_t)smem;
+    const bool loader = LDW > 0 && wave >= 8;
+    const int iw = LDW > 0 ? (wave & (NIW - 1)) : wave;                      // index among the issuing waves
+
+    // DMA d of issuing wave w covers stage unit u = d * NIW + w (16 rows of 64 bytes): units [0, 16) are A rows, then 16 units per weight
+    // piece.  Scalar base (the workgroup's first row at the step's K offset) + a 32-bit lane offset that never changes: no per-lane
+    // pointer arithmetic in the loop.
+    constexpr int DA = (BM / 16) / NIW;                                      // this wave's first DA units are A rows
+    unsigned voff[NDMA];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) {
+        const int u = d * NIW + iw;
+        const bool isA = d < DA;
+        const int ub = isA ? u : (u - BM / 16) % (BN / 16), piece = isA ? 0 : (u - BM / 16) / (BN / 16);
+        const int row = ub * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        voff[d] = isA ? (unsigned)(min(m0 + row, M - 1) - m0) * (unsigned)lda * 2u + (unsigned)chunk * 16u
+                      : (unsigned)(min(n0 + row, N - 1) - n0) * (unsigned)ldb * 2u + (unsigned)piece * (unsigned)K * 2u + (unsigned)chunk * 16u;
+    }
+    const char* const a_u = reinterpret_cast<const char*>(A) + (int64_t)m0 * lda * 2;
+    const char* const b_u = reinterpret_cast<const char*>(B) + (int64_t)n0 * ldb * 2;
+    const unsigned sdst0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)iw * 1024u);
+    auto issue_one = [&](unsigned stage_off, int d, int step) {
+        const char* sb = (d < DA ? a_u : b_u) + (int64_t)step * (BK * 2);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(voff[d]), "s"(sb), "s"(sdst0 + (unsigned)d * (unsigned)(NIW * 1024) + stage_off)
+                     : "memory", "m0");
+    };
+    const int nt = K / BK;
+    if (LDW == 0 || loader) {
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) issue_one(0u, d, 0);
+        if (nt > 1) {
+#pragma unroll
+            for (int d = 0; d < NDMA; ++d) issue_one((unsigned)STAGE, d, 1);
+        }
+    }
+    unsigned cur_off = 0u, ld_off = 2u * STAGE;                // stage of the current step / of the step two ahead
+    if constexpr (LDW > 0) {
+        if (loader) {
+            // loader wave: wait for step t (its DMAs are older than step t + 1's), meet the MFMA waves at the barrier -- which also says they are
+            // done with stage (t - 1) % 3 --, refill that stage with step t + 2
+            for (int t = 0; t < nt; ++t) {
+                if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 2 < nt) {
+#pragma unroll
+                    for (int d = 0; d < NDMA; ++d) issue_one(ld_off, d, t + 2);
+                }
+                ld_off = ld_off == (unsigned)(NST - 1) * STAGE ? 0u : ld_off + STAGE;
+            }
+            return;
+        }
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -435,50 +505,34 @@ __global__ __launch_bounds__(512) void k_linear_bf16_big(int M, int N, int K, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // DMA d of wave w covers stage unit u = d * 8 + w (16 rows of 64 bytes): units [0, 16) are A rows, then 16 units per weight piece
-    const uint16_t* src[NDMA];
-    unsigned dst[NDMA];
-#pragma unroll
-    for (int d = 0; d < NDMA; ++d) {
-        const int u = d * 8 + wave;
-        const bool isA = u < BM / 16;
-        const int ub = isA ? u : (u - BM / 16) % (BN / 16), piece = isA ? 0 : (u - BM / 16) / (BN / 16);
-        const int row = ub * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        src[d] = isA ? A + (int64_t)min(m0 + row, M - 1) * lda + chunk * 8
-                     : B + (int64_t)min(n0 + row, N - 1) * ldb + (int64_t)piece * K + chunk * 8;
-        dst[d] = lds_base + (unsigned)u * 1024u;
-    }
-    auto issue_one = [&](unsigned stage_off, int d) {
-        lds_dma16_b(src[d], __builtin_amdgcn_readfirstlane(dst[d] + stage_off));
-        src[d] += BK;
-    };
-
     const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 2) & 3;
     unsigned xo[2];
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) xo[kg] = (unsigned)(((kg * 2 + fh) ^ swz) * 16);
     const unsigned a_row = (unsigned)((wr * 128 + frow) * 64), b_row = (unsigned)(A_BYTES + (wc * 64 + frow) * 64);
 
-    const int nt = K / BK;
-#pragma unroll
-    for (int d = 0; d < NDMA; ++d) issue_one(0u, d);
-    if (nt > 1) {
-#pragma unroll
-        for (int d = 0; d < NDMA; ++d) issue_one((unsigned)STAGE, d);
-    }
-    unsigned cur_off = 0u, ld_off = 2u * STAGE;                // stage of the current step / of the step two ahead
+    [[maybe_unused]] bf16x8 abl_af[2][4], abl_bf[2][P][2];     // (measurement builds)
     for (int t = 0; t < nt; ++t) {
         const bool more = t + 2 < nt;
-        // step t's six DMAs are older than step t + 1's (the only ones that may still fly): counted wait, then the barrier that also
+        // step t's DMAs are older than step t + 1's (the only ones that may still fly): counted wait, then the barrier that also
         // says every wave is done reading stage (t - 1) % 3 -- the one refilled below
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(GVQA_BIG_ABL & 8) && LDW == 0) {
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (!(GVQA_BIG_ABL & 4)) __builtin_amdgcn_s_barrier();
         const unsigned char* st = smem + cur_off;
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
             bf16x8 af[4], bf[P][2];
+            if ((GVQA_BIG_ABL & 2) && t > 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = abl_af[kg][i];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[p][j] = abl_bf[kg][p][j];
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + a_row + i * 32 * 64 + xo[kg]));
 #pragma unroll
@@ -486,6 +540,15 @@ __global__ __launch_bounds__(512) void k_linear_bf16_big(int M, int N, int K, co
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     bf[p][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(st + b_row + p * B_BYTES + j * 32 * 64 + xo[kg]));
+            if constexpr ((GVQA_BIG_ABL & 2) != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) abl_af[kg][i] = af[i];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) abl_bf[kg][p][j] = bf[p][j];
+            }
+            }
             // operands swapped (B fragment first): transposed accumulators, see store_tile_transposed_b
 #pragma unroll
             for (int p = P - 1; p >= 0; --p) {                    // low-order piece first
@@ -493,10 +556,10 @@ __global__ __launch_bounds__(512) void k_linear_bf16_big(int M, int N, int K, co
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[p][j], af[i], acc[i][j], 0, 0, 0);
-                if (more) {                                       // the DMAs of the step two ahead, spread over this step's four MFMA groups
+                if (LDW == 0 && more && !(GVQA_BIG_ABL & 1)) {    // the DMAs of the step two ahead, spread over this step's four MFMA groups
 #pragma unroll
                     for (int d = 0; d < NDMA; ++d)
-                        if (d * 4 / NDMA == kg * P + (P - 1 - p)) issue_one(ld_off, d);
+                        if (d * 4 / NDMA == kg * P + (P - 1 - p)) issue_one(ld_off, d, t + 2);
                 }
             }
         }
@@ -584,8 +647,8 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     const int64_t big_tiles = cdiv(M, 256) * cdiv(N, 256);
     if (P == 2 && K % 32 == 0 && !no_dma && !no_big && quad_ok && big_tiles >= 192 && big_tiles <= 4 * (int64_t)device_cu_count() && cdiv(M, 256) <= 65535) {
         dim3 gridb((unsigned)cdiv(N, 256), (unsigned)cdiv(M, 256));
-        if (c16) hipLaunchKernelGGL(k_linear_bf16_big<true>, gridb, dim3(512), 0, stream, (int)M, (int)N, (int)K, a, lda, b, (int64_t)P * K, ep, C, ldc);
-        else hipLaunchKernelGGL(k_linear_bf16_big<false>, gridb, dim3(512), 0, stream, (int)M, (int)N, (int)K, a, lda, b, (int64_t)P * K, ep, C, ldc);
+        if (c16) hipLaunchKernelGGL(k_linear_bf16_big<true>, gridb, dim3(512 + 64 * GVQA_BIG_LOADERS), 0, stream, (int)M, (int)N, (int)K, a, lda, b, (int64_t)P * K, ep, C, ldc);
+        else hipLaunchKernelGGL(k_linear_bf16_big<false>, gridb, dim3(512 + 64 * GVQA_BIG_LOADERS), 0, stream, (int)M, (int)N, (int)K, a, lda, b, (int64_t)P * K, ep, C, ldc);
         GVQA_LAUNCH_CHECK();
         return GVQA_OK;
     }
