@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 D, H, K = 512, 4, 5
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0  # dense 16-bit MFMA peak (same guide)
 BATCH_SEED = 0x5EED0003
 
 
@@ -118,6 +119,41 @@ def measured_copy_bandwidth(torch, dev, lib, mib=1024, reps=10):
                 "guide_achievable_GBps": GUIDE_ACHIEVABLE_GBS, "copies_verified": ok, "buffer_MiB": mib, "reps": reps,
                 "method": "1 GiB fp32 buffer device-to-device, read + written bytes / HIP-event time; best of torch's copy kernel and "
                           "gvqa_stream_copy variants 0 / 1 / 2"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
+def measured_matrix_rate(torch, dev, lib, iters=4000):
+    """The matrix pipes' own rate on THIS box, measured now (the MFMA counterpart of `hbm_copy_measured`): gvqa_mfma_stream -- a loop of nothing but
+    v_mfma_f32_32x32x16_f16, eight waves per CU, the occupancy of the hop kernels -- on random fp16 operands (what a kernel's products look like to
+    the power budget) and on zeros (what the clock allows).  `roofline.peak` stays the data sheet's dense 2.5 PF/s; this says how much of it random
+    operands can draw at all, so that an MFMA-bound kernel's issued rate can be read against it."""
+    try:
+        import ctypes
+        from graphvqa_amd import _lib
+        st = torch.cuda.current_stream().cuda_stream
+        sink = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+        out = {}
+        for name, ops in (("random_operands", torch.empty(1 << 19, dtype=torch.float16, device=dev).normal_()),
+                          ("zero_operands", torch.zeros(1 << 19, dtype=torch.float16, device=dev))):
+            fl = ctypes.c_int64(0)
+            fn = lambda: _lib.check(lib.gvqa_mfma_stream(ops.data_ptr(), ops.numel() * 2, sink.data_ptr(), sink.numel(), iters, 0, ctypes.byref(fl), st))
+            for _ in range(2):
+                fn()
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                fn()
+                e1.record(); torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                best = ms if best is None else min(best, ms)
+            out[name + "_tflops"] = fl.value / (best * 1e-3) / 1e12
+            out[name + "_launch_ms"] = best
+        out["frac_of_spec_random"] = out["random_operands_tflops"] / MFMA_PEAK_TFLOPS
+        out["method"] = ("gvqa_mfma_stream: v_mfma_f32_32x32x16_f16 only, one workgroup of 8 waves per CU, 64 MFMAs per wave and iteration, %d iterations, "
+                         "HIP-event time of one launch (best of 3); operands decide the power draw and with it the clock" % iters)
+        return out
     except Exception as e:
         return {"error": repr(e)[:200]}
 
@@ -976,6 +1012,10 @@ def n_eq_1(cx, prim, res):
         mpr["traffic_from_profile"] = profile_traffic()
     cp = measured_copy_bandwidth(torch, dev, lib)
     res["hbm_copy_measured"] = cp
+    mr = measured_matrix_rate(torch, dev, lib)
+    res["matrix_rate_measured"] = mr
+    if mr.get("random_operands_tflops") and res["roofline"].get("issued_tflops"):
+        res["roofline"]["issued_frac_of_measured_matrix_rate"] = res["roofline"]["issued_tflops"] / mr["random_operands_tflops"]
     if mpr is not None:
         mpr["frac_of_guide_achievable"] = mpr["achieved"] / GUIDE_ACHIEVABLE_GBS
         if cp.get("GBps"):

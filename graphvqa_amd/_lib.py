@@ -152,6 +152,7 @@ PROTOTYPES = {
     "gvqa_version": (C.c_char_p, []),
     "gvqa_gemm_backend": (C.c_char_p, []),
     "gvqa_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "gvqa_mfma_stream": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
     "gvqa_graph_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "gvqa_graph_build": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.POINTER(Graph)]),

@@ -417,8 +417,8 @@ __global__ __launch_bounds__(512) void k_linear_bf16_wide(int M, int N, int K, c
 #endif
 // (Measured and dropped: per-lane 64-bit source pointers advanced every step instead of a scalar base + constant lane offset -- 0.966 vs 1.006 PF/s
 //  issued on [29785, 1536] x K 1024; the two waves of a SIMD issuing their DMAs in different halves of the step -- no change.  What the step spends
-//  outside its MFMAs, same product, `profiles/r06_bf16_big_ablation.jsonl`: MFMAs only 1.244 PF/s (the chip's power-limited rate on random operands:
-//  1.47 on zeros), without the DMAs 1.107, as shipped 1.006.  GVQA_BIG_LOADERS = 4 -- the DMAs issued by four extra waves, one per SIMD, that do
+//  outside its MFMAs, same product, `profiles/r06_bf16_big_ablation.jsonl`: this kernel with MFMAs only 1.244 PF/s (tile rounds, prologue and epilogue included; the bare
+//  MFMA stream of gvqa_mfma_stream below: 1.84 on random bf16 operands, 2.47 on zeros), without the DMAs 1.107, as shipped 1.006.  GVQA_BIG_LOADERS = 4 -- the DMAs issued by four extra waves, one per SIMD, that do
 //  nothing else (162 registers, twelve waves per CU) -- 1.066-1.070 against 1.055 on the same box, nothing on the smaller products, the LCGN
 //  forward 2.131 -> 2.118 ms (`r06_bf16_big_loaders_ab.jsonl`): what the DMAs cost is not issue slots of the MFMA waves but the data movement
 //  itself.  Left as a build switch, off.)
@@ -678,6 +678,53 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
     return GVQA_OK;
 }
 
+// ---- the matrix pipes' own rate on given operands (measurement entry point, bench.py's `matrix_rate_measured`) ---------------------
+// What `v_mfma_f32_32x32x16_{f16,bf16}` sustains on this chip at this moment with NOTHING else in the loop: eight waves per CU (two per SIMD, the
+// occupancy of the hop kernels), eight accumulator tiles per wave, fragments loaded once from `operands` and rotated through the products.  The
+// chip clocks to its power budget, and the budget depends on the operand bits (`profiles/r06_matrix_rate_probe.jsonl`): normally distributed fp16
+// operands sustain 1.68 PF/s, bf16 1.84, small integers 2.1, zeros or ones 2.47-2.48 -- the data sheet's rate.
+// The dense peak of the data sheet (2.5 PF/s) is the denominator of `roofline.frac`; this is the rate an MFMA-bound kernel can be compared with.
+typedef _Float16 f16x8_probe __attribute__((ext_vector_type(8)));
+template <bool BF>
+__global__ __launch_bounds__(512) void k_mfma_stream(const uint4* __restrict__ operands, int nvec, float* __restrict__ sink, int iters) {
+    const int g = blockIdx.x * 512 + threadIdx.x;
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        a[f] = operands[(unsigned)(g * 8 + f) % (unsigned)nvec];
+        b[f] = operands[(unsigned)(g * 8 + 4 + f) % (unsigned)nvec];
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)            // four K steps' worth of products: 16 MFMAs each, operands rotated
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint4 bb = b[(2 * p + j + u) & 3], aa = a[(i + u) & 3];
+                        if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bb), __builtin_bit_cast(bf16x8, aa), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_probe, bb), __builtin_bit_cast(f16x8_probe, aa), acc[i][j], 0, 0, 0);
+                    }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    sink[g] = t;
+}
+
 }  // namespace gvqa
 
 extern "C" int gvqa_pack_weight_bf16(int64_t rows, int64_t K, int pieces, const float* W, int64_t ldw, void* Wpk, void* stream) {
@@ -694,4 +741,19 @@ extern "C" int gvqa_linear_bf16(int64_t M, int64_t N, int64_t K, int pieces, con
     GVQA_REQUIRE((!addend || ld_add >= N) && (!mul || ld_mul >= N), GVQA_E_INVALID, "linear_bf16: epilogue leading dimension too small");
     LinearEpilogue ep{bias, static_cast<const float*>(addend), ld_add, static_cast<const float*>(mul), ld_mul, relu};
     return launch_linear_bf16(M, N, K, pieces, A, lda, Wpk, ep, C, ldc, c_bf16 != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gvqa_mfma_stream(const void* operands, size_t operand_bytes, float* sink, size_t sink_elems, int iters, int bf16, int64_t* flops_out,
+                                void* stream) {
+    using namespace gvqa;
+    GVQA_REQUIRE(operands && sink && iters >= 1 && operand_bytes >= 1024 && (reinterpret_cast<uintptr_t>(operands) & 15) == 0, GVQA_E_INVALID,
+                 "mfma_stream: needs a 16-byte aligned operand buffer of >= 1 KiB, a sink and iters >= 1");
+    const int cus = device_cu_count();
+    GVQA_REQUIRE(sink_elems >= (size_t)cus * 512, GVQA_E_WORKSPACE, "mfma_stream: sink holds %zu floats, %zu needed", sink_elems, (size_t)cus * 512);
+    const int nvec = (int)std::min<size_t>(operand_bytes / 16, (size_t)1 << 24);
+    if (bf16) hipLaunchKernelGGL(k_mfma_stream<true>, dim3((unsigned)cus), dim3(512), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(operands), nvec, sink, iters);
+    else hipLaunchKernelGGL(k_mfma_stream<false>, dim3((unsigned)cus), dim3(512), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(operands), nvec, sink, iters);
+    GVQA_LAUNCH_CHECK();
+    if (flops_out) *flops_out = (int64_t)cus * 8 * iters * 64 * 32768;      // workgroups x waves x iterations x 64 MFMAs x 2 x 32 x 32 x 16
+    return GVQA_OK;
 }

@@ -206,6 +206,29 @@ def test_linear_bf16(dev, M, N, K, pieces):
     assert float((out16.float().cpu() == ref3.float().bfloat16().float().cpu()).float().mean()) > 0.99
 
 
+def test_mfma_stream_probe_runs_and_reports_its_flops(dev):
+    """gvqa_mfma_stream (bench.py's `matrix_rate_measured`): the launch succeeds on random and on zero operands, reports cus x 8 x iters x 64 MFMAs
+    of 2 x 32 x 32 x 16 flops, leaves finite sums in the sink (zeros for zero operands) and rejects a sink that is too small."""
+    import ctypes
+    from graphvqa_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    sink = torch.full((cus * 512,), float("nan"), device=dev)
+    for bf in (0, 1):
+        ops = torch.empty(1 << 16, dtype=torch.bfloat16 if bf else torch.float16, device=dev).normal_()
+        fl = ctypes.c_int64(0)
+        _lib.check(lib.gvqa_mfma_stream(ops.data_ptr(), ops.numel() * 2, sink.data_ptr(), sink.numel(), 3, bf, ctypes.byref(fl), st))
+        torch.cuda.synchronize()
+        assert fl.value == cus * 8 * 3 * 64 * 2 * 32 * 32 * 16
+        assert bool(torch.isfinite(sink).all()) and float(sink.abs().max()) > 0
+    zeros = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
+    _lib.check(lib.gvqa_mfma_stream(zeros.data_ptr(), zeros.numel() * 2, sink.data_ptr(), sink.numel(), 2, 0, None, st))
+    torch.cuda.synchronize()
+    assert float(sink.abs().max()) == 0.0
+    assert lib.gvqa_mfma_stream(zeros.data_ptr(), zeros.numel() * 2, sink.data_ptr(), 16, 2, 0, None, st) != 0
+
+
 def _load_module(m, params, dev):
     sd = {k: t(v) for k, v in params.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
