@@ -685,7 +685,7 @@ int launch_linear_bf16(int64_t M, int64_t N, int64_t K, int P, const void* A, in
 // operands sustain 1.68 PF/s, bf16 1.84, small integers 2.1, zeros or ones 2.47-2.48 -- the data sheet's rate.
 // The dense peak of the data sheet (2.5 PF/s) is the denominator of `roofline.frac`; this is the rate an MFMA-bound kernel can be compared with.
 typedef _Float16 f16x8_probe __attribute__((ext_vector_type(8)));
-template <bool BF>
+template <bool BF, int ORDER>
 __global__ __launch_bounds__(512) void k_mfma_stream(const uint4* __restrict__ operands, int nvec, float* __restrict__ sink, int iters) {
     const int g = blockIdx.x * 512 + threadIdx.x;
     uint4 a[4], b[4];
@@ -709,8 +709,11 @@ __global__ __launch_bounds__(512) void k_mfma_stream(const uint4* __restrict__ o
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint4 bb = b[(2 * p + j + u) & 3], aa = a[(i + u) & 3];
+                    for (int jj = 0; jj < 2; ++jj) {
+                        // ORDER 0: i-major (consecutive products share the A fragment, the B fragment alternates: the GEMM kernels' order);
+                        // 1: snake (every consecutive pair shares one operand); 2: the same two fragments for 8 products in a row
+                        const int j = ORDER == 1 ? ((i & 1) ? 1 - jj : jj) : jj;
+                        const uint4 bb = ORDER == 2 ? b[(2 * p + u) & 3] : b[(2 * p + j + u) & 3], aa = ORDER == 2 ? a[(p + u) & 3] : a[(i + u) & 3];
                         if constexpr (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bb), __builtin_bit_cast(bf16x8, aa), acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_probe, bb), __builtin_bit_cast(f16x8_probe, aa), acc[i][j], 0, 0, 0);
                     }
@@ -751,8 +754,12 @@ extern "C" int gvqa_mfma_stream(const void* operands, size_t operand_bytes, floa
     const int cus = device_cu_count();
     GVQA_REQUIRE(sink_elems >= (size_t)cus * 512, GVQA_E_WORKSPACE, "mfma_stream: sink holds %zu floats, %zu needed", sink_elems, (size_t)cus * 512);
     const int nvec = (int)std::min<size_t>(operand_bytes / 16, (size_t)1 << 24);
-    if (bf16) hipLaunchKernelGGL(k_mfma_stream<true>, dim3((unsigned)cus), dim3(512), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(operands), nvec, sink, iters);
-    else hipLaunchKernelGGL(k_mfma_stream<false>, dim3((unsigned)cus), dim3(512), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(operands), nvec, sink, iters);
+    // (bf16: bit 0 = bf16 products; bits 1-2 = the order of a step's products, see the kernel: 0 as the GEMM kernels issue them)
+    const int order = (bf16 >> 1) & 3;
+#define GVQA_MS(BF_, O_) hipLaunchKernelGGL((k_mfma_stream<BF_, O_>), dim3((unsigned)cus), dim3(512), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(operands), nvec, sink, iters)
+    if (bf16 & 1) { if (order == 1) GVQA_MS(true, 1); else if (order == 2) GVQA_MS(true, 2); else GVQA_MS(true, 0); }
+    else { if (order == 1) GVQA_MS(false, 1); else if (order == 2) GVQA_MS(false, 2); else GVQA_MS(false, 0); }
+#undef GVQA_MS
     GVQA_LAUNCH_CHECK();
     if (flops_out) *flops_out = (int64_t)cus * 8 * iters * 64 * 32768;      // workgroups x waves x iterations x 64 MFMAs x 2 x 32 x 32 x 16
     return GVQA_OK;

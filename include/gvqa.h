@@ -530,7 +530,8 @@ GVQA_API int gvqa_stream_copy(void* dst, const void* src, size_t bytes, int vari
 /* Measurement entry point: a loop of nothing but v_mfma_f32_32x32x16_f16 (bf16 != 0: _bf16) on fragments taken from `operands` (any bit
  * patterns: what they hold decides the power the matrix pipes draw, hence the clock), one workgroup of eight waves per CU, 64 MFMAs per wave and
  * iteration.  sink: >= CUs x 512 floats (keeps the accumulators live).  *flops_out (host, may be NULL) = the launch's flop count.  bench.py times
- * it on random and on zero operands and reports the rates as `matrix_rate_measured` beside the data sheet's dense peak.
+ * it on random and on zero operands and reports the rates as `matrix_rate_measured` beside the data sheet's dense peak.  Bits 1-2 of `bf16`
+ * pick the order in which a step's 16 products are issued (0: as the GEMM kernels do; 1, 2: operand-reuse experiments, see the kernel).
  * No counterpart in the reference. */
 GVQA_API int gvqa_mfma_stream(const void* operands, size_t operand_bytes, float* sink, size_t sink_elems, int iters, int bf16, int64_t* flops_out,
                               void* stream);
