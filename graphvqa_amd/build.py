@@ -7,6 +7,7 @@ travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ign
 """
 from __future__ import annotations
 
+import json
 import os
 import subprocess
 import sys
@@ -22,6 +23,24 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (v_pk_fma_f32, what the SLP pass makes of adjacent FMAs) costs the matrix-core stream more than two plain FMAs (MI355X_MICROARCH.md)
 EXTRA_FLAGS = {"hopagg.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _resource_usage(stderr: str) -> dict:
+    """hipcc -Rpass-analysis=kernel-resource-usage -> {mangled kernel name: {"VGPRs": .., "AGPRs": .., "ScratchSize": .., "Occupancy": ..,
+    "SGPRs Spill": .., "VGPRs Spill": .., "LDS Size": ..}} (device pass only)."""
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        if "kernel-resource-usage" not in line or "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].rsplit("[-Rpass", 1)[0].strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            k = k.split("[")[0].strip()
+            v = v.strip()
+            cur[k] = int(v) if v.lstrip("-").isdigit() else v
+    return out
 
 
 def _stale(target: str, deps) -> bool:
@@ -55,8 +74,8 @@ def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
+        if force or _stale(obj, [src] + headers) or not os.path.exists(obj.replace(".o", ".res.json")):
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -64,11 +83,22 @@ def _build(LIBDIR: str, FLAGS, force: bool, verbose: bool) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        if "-c" in cmd:         # the compiler's per-kernel resource remarks -> <object>.res.json (registers, scratch, LDS: tests/test_host.py checks them)
+            with open(cmd[cmd.index("-o") + 1].replace(".o", ".res.json"), "w") as f:
+                json.dump(_resource_usage(r.stderr), f, indent=0, sort_keys=True)
+        if verbose:
+            rest = "\n".join(l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l)
+            if rest.strip():
+                print(rest, file=sys.stderr)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    merged = {}
+    for o in objs:
+        with open(o.replace(".o", ".res.json")) as f:
+            merged.update(json.load(f))
+    with open(os.path.join(LIBDIR, "kernel_resources.json"), "w") as f:
+        json.dump(merged, f, indent=0, sort_keys=True)
     relink = bool(jobs) or force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")])
     if relink:
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl",

@@ -429,29 +429,33 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     // ~145 issued instructions per wave and step for 24 (wide) or 15 (narrow layout) MFMAs: the narrow layout's step IS its issue time.  In the loop the
     // bases stay put (SGPR pairs, set per hop), the step is a 32-bit byte offset per lane that advances by 2 KiB and saturates at the last step (two VALU),
     // and the ring slots are byte offsets that rotate by compare-and-select.
-    unsigned vb_off = 0, vx_off = 0;                  // byte offsets (lane part included) of the NEXT weight step / x chunk to request
+    // (round 6, late: the step's byte offset was first kept per lane -- lane part included -- in two VGPRs; with the register file full hipcc spilled exactly
+    //  those two, re-loaded each in front of its DMA with `scratch_load_dword` + `s_waitcnt vmcnt(0)` -- its own counter knows nothing of the asm DMAs, so the
+    //  wait drained every DMA in flight, twice per K step, the second time a few dozen instructions behind the step's weight DMAs.  Now the step offset is a
+    //  scalar added to the base; the lane part is the constant lane16 / lane4)
+    unsigned sb_off = 0, sx_off = 0;                  // scalar byte offsets of the NEXT weight step / x chunk to request
     unsigned bld_off = 0, bcur_off = 0;               // ring stage (byte offset) the next weight DMAs go to / the current step reads
     const uint16_t *wb0u = nullptr, *wb1u = nullptr;  // wbase0 / wbase1 / xbase as scalar-register pairs
     const float* xbu = nullptr;
     auto loop_state_init = [&]() {                     // after the priming DMAs of a hop: the loop's step 0 requests weight step PD and x chunk PD + 1
         wb0u = ha_uniform(wbase0); wb1u = ha_uniform(wbase1); xbu = ha_uniform(xbase);
-        vb_off = lane16 + (unsigned)min(PD, NQ - 1) * 2048u;
-        vx_off = lane4 + (unsigned)min(PD + 1, NQ - 1) * 2048u;
+        sb_off = (unsigned)min(PD, NQ - 1) * 2048u;
+        sx_off = (unsigned)min(PD + 1, NQ - 1) * 2048u;
         bld_off = (unsigned)(PD % NBST) * BST;
         bcur_off = 0u;
     };
-    const unsigned vb_last = lane16 + (unsigned)(NQ - 1) * 2048u, vx_last = lane4 + (unsigned)(NQ - 1) * 2048u;
+    const unsigned s_last = (unsigned)(NQ - 1) * 2048u;
     auto loop_issue_b = [&](int u) {
         if (CP > 1 && !b_owner) return;
         if (u && !b_second) return;
-        ha_dma16_x2(u ? wb1u : wb0u, vb_off, __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + bld_off + (unsigned)(wave + 8 * u) * 2048u));
+        ha_dma16_x2(reinterpret_cast<const char*>(u ? wb1u : wb0u) + sb_off, lane16, __builtin_amdgcn_readfirstlane(lds_base + HA_B0 + bld_off + (unsigned)(wave + 8 * u) * 2048u));
     };
     auto loop_issue_x = [&](int q) {
-        ha_dma4(xbu, vx_off, __builtin_amdgcn_readfirstlane(lds_base + XR0 + (unsigned)(q & (NXS - 1)) * 2048u + (unsigned)wave * 256u));
+        ha_dma4(reinterpret_cast<const char*>(xbu) + sx_off, lane4, __builtin_amdgcn_readfirstlane(lds_base + XR0 + (unsigned)(q & (NXS - 1)) * 2048u + (unsigned)wave * 256u));
     };
     auto loop_advance = [&]() {                        // end of a step
-        vb_off = min(vb_off + 2048u, vb_last);
-        vx_off = min(vx_off + 2048u, vx_last);
+        sb_off = min(sb_off + 2048u, s_last);
+        sx_off = min(sx_off + 2048u, s_last);
         bld_off = bld_off == (unsigned)(NBST - 1) * BST ? 0u : bld_off + BST;
         bcur_off = bcur_off == (unsigned)(NBST - 1) * BST ? 0u : bcur_off + BST;
     };

@@ -403,14 +403,9 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
     const int ecol = (tid & 63) * 4, erow0 = tid >> 6;             // this thread's 4 columns of the tile, rows erow0 + 8 k
     const int gcol = n0 + ecol;
     const bool col_on = gcol < a.N;                                // (N % 4 == 0: a column quad is inside or outside)
-    float4 vrow[4][4];                                             // lr_v rows of the 4 columns (J <= 16)
-    if (a.lr_g && col_on) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                vrow[q4][u] = 4 * u < a.J ? *reinterpret_cast<const float4*>(a.lr_v + (int64_t)(gcol + q4) * a.J + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // (the lr_v rows of this thread's 4 columns -- J <= 16 floats each -- are re-read from L1 per output row: kept in a register array indexed by the
+    //  runtime J they were 272 bytes of scratch per lane, i.e. memory loads all the same, plus the stores and the dispatch's scratch set-up)
+    const float* const vbase = a.lr_v + (int64_t)gcol * a.J;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the last steps' DMAs -- invisible to the compiler -- have landed: the stage below overlaps the ring)
     __syncthreads();                                               // every wave is done with the operand images
 #pragma unroll
@@ -435,10 +430,12 @@ __global__ __launch_bounds__(512) void k_linear_nn_direct(NndArgs a) {
                     const float* gp = a.lr_g + gr * a.J;
                     for (int u = 0; 4 * u < a.J; ++u) {
                         const float4 gq = *reinterpret_cast<const float4*>(gp + 4 * u);
-                        v.x += gq.x * vrow[0][u].x + gq.y * vrow[0][u].y + gq.z * vrow[0][u].z + gq.w * vrow[0][u].w;
-                        v.y += gq.x * vrow[1][u].x + gq.y * vrow[1][u].y + gq.z * vrow[1][u].z + gq.w * vrow[1][u].w;
-                        v.z += gq.x * vrow[2][u].x + gq.y * vrow[2][u].y + gq.z * vrow[2][u].z + gq.w * vrow[2][u].w;
-                        v.w += gq.x * vrow[3][u].x + gq.y * vrow[3][u].y + gq.z * vrow[3][u].z + gq.w * vrow[3][u].w;
+                        const float4 v0 = *reinterpret_cast<const float4*>(vbase + 4 * u), v1 = *reinterpret_cast<const float4*>(vbase + a.J + 4 * u);
+                        const float4 v2 = *reinterpret_cast<const float4*>(vbase + 2 * a.J + 4 * u), v3 = *reinterpret_cast<const float4*>(vbase + 3 * a.J + 4 * u);
+                        v.x += gq.x * v0.x + gq.y * v0.y + gq.z * v0.z + gq.w * v0.w;
+                        v.y += gq.x * v1.x + gq.y * v1.y + gq.z * v1.z + gq.w * v1.w;
+                        v.z += gq.x * v2.x + gq.y * v2.y + gq.z * v2.z + gq.w * v2.w;
+                        v.w += gq.x * v3.x + gq.y * v3.y + gq.z * v3.z + gq.w * v3.w;
                     }
                 }
                 if (a.addend) {

@@ -99,6 +99,32 @@ def test_dynamic_symbols_are_the_c_abi_only():
     assert set(syms) == set(_lib.PROTOTYPES), set(syms) ^ set(_lib.PROTOTYPES)
 
 
+def test_kernels_with_counted_dma_waits_keep_their_register_budget():
+    """The LDS-DMA kernels order their asm-issued DMAs with hand-counted `s_waitcnt vmcnt(N)`; the compiler's own counter knows nothing of those DMAs, so a
+    spill it re-loads inside a K loop comes with a `vmcnt(0)` that drains every DMA in flight (round 6 found two per step in the one-launch hop kernel), and
+    a large scratch frame doubles a short kernel's dispatch time (round 6: the GINE MLP).  build.py keeps the compiler's per-kernel resource remarks
+    (lib/kernel_resources.json); this pins what the shipped kernels were measured with: no scratch at all in the GEMM-class kernels, a bounded frame --
+    outside the K loop, checked in the ISA when it was set -- in the hop kernels, and the occupancy each was designed for."""
+    from graphvqa_amd import build
+    lib = build.build()
+    res = json.load(open(os.path.join(os.path.dirname(lib), "kernel_resources.json")))
+    def of(sub):
+        hits = {k: v for k, v in res.items() if sub in k}
+        assert hits, sub
+        return hits
+    for sub in ("k_linear_bf16_big", "k_linear_bf16_wide", "k_linear_bf16_dma", "k_gine_mlp", "k_linear_nn_direct", "k_linear_tn_direct", "k_linear_f32_dma"):
+        for k, v in of(sub).items():
+            assert v["ScratchSize"] == 0 and v["VGPRs Spill"] == 0, (k, v)          # (SGPR spills go to VGPR lanes: no memory traffic)
+    for k, v in of("k_linear_split3").items():          # (the six-product bf16 x 3 epilogue variants keep a 12-byte frame)
+        assert v["ScratchSize"] <= 16, (k, v)
+    for k, v in of("k_hopagg4").items():                # 8 waves x 256 registers; the one-launch forms spill a few hop-invariant values outside the K loop
+        assert v["Occupancy"] == 2 and v["ScratchSize"] <= 160 and v["LDS Size"] <= 160 * 1024, (k, v)
+    for k, v in of("k_gine_mlp").items():               # 4 waves x 512 registers (accumulators in AGPRs)
+        assert v["Occupancy"] == 1 and v["AGPRs"] >= 160, (k, v)
+    for k, v in of("k_linear_bf16_big").items():
+        assert v["Occupancy"] == 2 and v["LDS Size"] == 3 * 48 * 1024, (k, v)
+
+
 def test_argument_validation_without_gpu():
     import ctypes as C
     from graphvqa_amd import _lib
