@@ -166,6 +166,27 @@ __device__ __forceinline__ void lds_dma16_x4(const void* gsrc, unsigned lds_dst)
         : "memory");
 }
 
+// The same groups with the source as SCALAR base + 32-bit lane offset (`global_load_lds_dwordx4 voff, s[base:base+1]`) and M0 declared clobbered instead
+// of saved and restored: a packed operand's fragment is contiguous, so the lane part is the constant lane * 16 and the base advances in SGPRs -- no
+// per-lane 64-bit pointer arithmetic and two SALU instructions less per group (round 6: +4 % on the 256 x 256 bf16 kernel, `profiles/r06_bf16_big_ablation.jsonl`)
+template <int NX>
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    static_assert(NX >= 1 && NX <= 4, "one to four 16-byte DMAs 1 KiB apart");
+    if constexpr (NX == 1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    else if constexpr (NX == 2)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                     : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    else if constexpr (NX == 3)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048"
+                     : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
 // 4 bytes per lane: LDS byte address `lds_dst` + lane * 4 (no alignment requirement beyond 4 bytes on either side)
 __device__ __forceinline__ void lds_dma4_b(const void* gsrc, unsigned lds_dst) {
     unsigned keep;

@@ -212,6 +212,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
     // packed operand (edge blocks) re-read the last valid tile: their products are never stored.
     const uint16_t* src[TPW];
     unsigned dst[TPW];
+    const unsigned lane16 = (unsigned)lane * 16u;
     // (two K segments of A, ep.a2: the first image holds a2_kb0 k blocks per row tile; at k block a2_kb0 the A tiles' sources move to the second image)
     const bool seg2 = EPI != 2 && NP == 2 && ep.a2 != nullptr;
     const int kb_sw = seg2 ? ep.a2_kb0 : 0x7fffffff;
@@ -222,8 +223,9 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
         const int t = wave + q * NW;
         const bool isA = t < FA;
         const int tile = isA ? min(rtf + t, rtA - 1) : min(bn * FB + (t - FA), rtB - 1);
-        src[q] = (isA ? Apk : Bpk) + (int64_t)tile * ((isA && seg2) ? ep.a2_kb0 : KB) * (NP * 512) + lane * 8;
-        src2[q] = (isA && seg2) ? ep.a2 + (int64_t)tile * ep.a2_KB * (NP * 512) + lane * 8 : nullptr;
+        // (wave-uniform: the ring's DMAs take them as scalar bases, the lane part is the constant lane16 below)
+        src[q] = (isA ? Apk : Bpk) + (int64_t)tile * ((isA && seg2) ? ep.a2_kb0 : KB) * (NP * 512);
+        src2[q] = (isA && seg2) ? ep.a2 + (int64_t)tile * ep.a2_KB * (NP * 512) : nullptr;
         kbi[q] = 0;
         dst[q] = lds_base + t * FRAG;
     }
@@ -245,8 +247,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
             if (kbi[q] == kb_sw && src2[q]) src[q] = src2[q];       // (wave-uniform)
             kbi[q] += 1;
         }
-        if constexpr (NP == 3) lds_dma16_x3(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
-        else lds_dma16_x2(src[q], __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
+        lds_dma16_s<NP>(src[q], lane16, __builtin_amdgcn_readfirstlane(dst[q] + buf * STAGE));
         src[q] += NP * 512;
     };
     auto issue = [&](int buf) {
@@ -392,7 +393,7 @@ void k_linear_split3(int M, int N, int KB, const uint16_t* __restrict__ Apk, int
                 if (kbi[q] == kb_sw && src2[q]) src[q] = src2[q];   // (wave-uniform; the launcher keeps a2_kb0 even for this loop)
                 kbi[q] += 2;
             }
-            lds_dma16_x4(src[q], __builtin_amdgcn_readfirstlane(dst2[q] + b * STAGE2));
+            lds_dma16_s<4>(src[q], lane16, __builtin_amdgcn_readfirstlane(dst2[q] + b * STAGE2));
             src[q] += 2 * NP * 512;
         };
         const unsigned a_off2 = (unsigned)(wr * TM * FRAG2 + lane * 16);

@@ -13,7 +13,7 @@ x = tt(synth.normal((N, 300), 1)).to(dev)
 m = lcgn_seq(300, 512, 300, 5); m.load_state_dict({k: tt(v) for k, v in synth.lcgn_seq_params(300, 512, seed=808).items()}); m = m.to(dev).eval()
 q, lstm, xc = tt(synth.normal((B, 512), 5)).to(dev), tt(synth.normal((10, B, 512), 6)).to(dev), tt(synth.normal((N, 512), 7)).to(dev)
 g = SceneGraphBatch(ei, batch, N, B)
-for _ in range(3): m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc)
+for _ in range(12): m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): m(x, ei, batch, q, lstm, graph=g, x_ctx_init=xc)
 torch.cuda.synchronize()
