@@ -123,7 +123,7 @@ def measured_copy_bandwidth(torch, dev, lib, mib=1024, reps=10):
         return {"error": repr(e)[:200]}
 
 
-def measured_matrix_rate(torch, dev, lib, iters=4000):
+def measured_matrix_rate(torch, dev, lib, iters=1500):
     """The matrix pipes' own rate on THIS box, measured now (the MFMA counterpart of `hbm_copy_measured`): gvqa_mfma_stream -- a loop of nothing but
     v_mfma_f32_32x32x16_f16, eight waves per CU, the occupancy of the hop kernels -- on random fp16 operands (what a kernel's products look like to
     the power budget) and on zeros (what the clock allows).  `roofline.peak` stays the data sheet's dense 2.5 PF/s; this says how much of it random

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Evidence run on the GPU box (everything lands under gpurun_out/r06e/; copy what is to be judged into profiles/): scripts/collect_profiles.sh
+# Evidence run on the GPU box (everything lands under gpurun_out/r06f/; copy what is to be judged into profiles/): scripts/collect_profiles.sh
 # bench line (live PMC traffic, matrix-core floor, CPU baseline, configs), rocprofv3 kernel stats of the default path, of BASELINE configs 2 / 4 / 5,
 # of the stand-alone message-passing kernel and of the 8-way shard, emulated strong-scaling shards, the distributed step with one rank,
 # SQ counters of the hop kernels, training step.
-O=gpurun_out/r06e; mkdir -p $O; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+O=gpurun_out/r06f; mkdir -p $O; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 python -m graphvqa_amd.build > $O/build.txt 2>&1                     # (the product library and the measurement build the floor leg loads: never a stale one --
 python -m graphvqa_amd.build --probes >> $O/build.txt 2>&1           #  VERDICT r05 weak #6)
 python bench.py > $O/bench_cfg3_n1.json 2> $O/bench.err
