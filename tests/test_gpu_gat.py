@@ -165,7 +165,8 @@ def _bf16_pieces(W, pieces):
 @pytest.mark.parametrize("M,N,K", [(300, 200, 64), (129, 100, 72), (1, 8, 8), (1000, 512, 512), (4100, 1536, 1024),
                                    (5637, 1536, 576),                            # two pieces: the wide 256 x 128 kernel
                                    (8197, 1536, 1024), (33001, 516, 512),        # two pieces: the 256 x 256 kernel (edge tiles in M and N)
-                                   (29785, 520, 544)])                           # ... an odd number of its 32-deep K steps
+                                   (29785, 520, 544),                            # ... an odd number of its 32-deep K steps
+                                   (29785, 512, 32), (29785, 512, 64)])          # ... one and two steps (shorter than its ring)
 @pytest.mark.parametrize("pieces", [1, 2])
 def test_linear_bf16(dev, M, N, K, pieces):
     """k_linear_bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate) against fp64 on the SAME bf16 operands:
