@@ -217,7 +217,8 @@ GVQA_API size_t gvqa_gat_seq_weight_cache_bytes(const gvqa_gat_dims* d, int32_t 
 GVQA_API int gvqa_gat_seq_weight_layout(const gvqa_graph* g, const gvqa_gat_dims* d);
 /* Which hop kernel an eval forward of this batch runs under the current options (introspection: bench.py labels its line with it,
  * tests assert it): GVQA_HOP_* below, or a negative status.  Plain outputs assumed (per-hop fp32 outputs / batch statistics take
- * the unchained form of the same kernel). */
+ * the unchained form of the same kernel), and node rows `x` that are 16-byte aligned: the query does not see `x`, and a forward whose
+ * rows are not takes the 8-wave kernels where this reports an aggregate-first form (results are the same to the stated tolerance). */
 #define GVQA_HOP_UNFUSED 0            /* projection GEMM + gvqa::k_gat_mp_tiled                                          */
 #define GVQA_HOP_FUSED8 1             /* the 8-wave fused kernel, a pack pass per hop                                     */
 #define GVQA_HOP_PERSISTENT 2         /* the persistent kernel (hop2.hip), a pack pass per hop                            */
