@@ -1012,7 +1012,8 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     // The loads of a batch -- row i, half of column tile j: two skip-row chunks and two per-graph term chunks per lane -- are issued one
     // batch AHEAD of the arithmetic and stores that consume them (two register sets; whole column tiles per batch spill).  Written as a plain loop the epilogue came out
     // as 32 x (loads, wait for all of them, arithmetic, store): one 16-byte skip read in flight per lane, 29 us per tile of pure
-    // latency.  The per-column constants come from LDS.
+    // latency.  The per-column constants come from LDS.  (Round 6: two and three batches ahead -- three and four register sets -- measured SLOWER, same box: 374.7-377.6 us per
+    // hop with one batch ahead, 376.7-378.1 with two, 382.3-384.7 with three: the extra sets spill, and the loads are no longer what the epilogue waits for.)
     {
         const float* cc_l = reinterpret_cast<const float*>(smem + HA_CC0);
         constexpr int NB = RT * TN * 2;
