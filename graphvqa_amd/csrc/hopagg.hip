@@ -622,8 +622,13 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
     // loop body is written for two steps with the sets swapped).
     ha_f16x8 afh[RT], afl[RT], bh0[TN], bh1[TN], bl[TN];      // a hi / a lo fragments, b hi (two sets), b lo
     // products n = lo .. hi - 1 of a piece product (n -> row tile n / TN, column tile n % TN)
+#ifndef GVQA_HA_SNAKE
+#define GVQA_HA_SNAKE 0       /* 1: odd row tiles walk their column tiles backwards, so that every two consecutive products share an operand: + 4 % for a bare MFMA
+                                 stream (gvqa_mfma_stream), 0.2-0.5 % here -- inside the noise (`profiles/r06_snake_order_ab.jsonl`, same box, bit-identical results); off */
+#endif
+#define GVQA_HA_COL(n_) ((GVQA_HA_SNAKE && (((n_) / TN) & 1)) ? TN - 1 - (n_) % TN : (n_) % TN)
 #define GVQA_HA_MFR(lo_, hi_, a_, b_) do { if (!GVQA_HA_DBG(4)) { _Pragma("unroll") for (int n_ = (lo_); n_ < (hi_); ++n_)                  \
-        acc[n_ / TN][n_ % TN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[n_ % TN], a_[n_ / TN], acc[n_ / TN][n_ % TN], 0, 0, 0); } } while (0)
+        acc[n_ / TN][GVQA_HA_COL(n_)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[GVQA_HA_COL(n_)], a_[n_ / TN], acc[n_ / TN][GVQA_HA_COL(n_)], 0, 0, 0); } } while (0)
     constexpr int NH = NM / 2;                        // the (a hi, b lo) product is issued in two parts around the x DMA
     // two values scaled by a power of two and split into fp16 pieces, packed two to a register: hi = f16(p v), lo = f16(p v - hi), each ONE
     // v_fma_mix instruction (the multiply by the scale rides in the FMA; hipcc's own lowering of the same expressions: v_mul + v_cvt_pk for
