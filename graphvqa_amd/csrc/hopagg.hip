@@ -734,13 +734,104 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                                                  \
         loop_advance();                                                                                                     \
         /* this wave's DMAs of step s + 1 (issued one step ago) have landed, its A' writes are out; then everybody's */     \
-        if (!GVQA_HA_DBG(16)) {                                                                                             \
+        if (GVQA_HA_DBG(64)) {            /* (measurement: the barrier without the counted DMA wait / 128: the waits without the barrier) */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+            __builtin_amdgcn_s_barrier();                                                                                   \
+        } else if (!GVQA_HA_DBG(16)) {                                                                                      \
             if (CP == 1 && (NTP >= 16 || b_second)) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   /* (this step's five DMA instructions may stay in flight) */ \
             else if (CP == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");   /* (a wave with one weight tile: three) */ \
             else if (b_owner) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");   /* (column parts: the last PD - 1 = 3 steps' DMAs -- 3 per step, */ \
             else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                /*  or the x DMA alone for a wave without a weight tile) */   \
-            __builtin_amdgcn_s_barrier();                                                                                   \
+            if (!GVQA_HA_DBG(128)) __builtin_amdgcn_s_barrier();                                                            \
         }                                                                                                                   \
+    }
+    // ---- ping-pong form of the step (GVQA_HA_PP; round 6, late) ------------------------------------------------------------------------
+    // The step above costs 1.43 us at config 3 for 0.64-0.81 us of MFMA time per SIMD, and `r06_cfg3_sync_parts_stamps.jsonl` says where the rest
+    // goes: without the barrier that closes it the main loop runs 27 % shorter (without the counted DMA wait: 1-4 %).  Eight waves that leave a
+    // barrier together run the same phase at the same time -- everybody reads LDS, then everybody multiplies -- so the LDS pipe and the matrix pipe
+    // take turns idling.  Here the two waves of a SIMD (w and w + 4: row halves 0 and 1, each of which produces exactly the A' rows it consumes)
+    // run HALF A STEP APART: while one is in its X phase (all 12 fragment reads of its step into registers, the producer's gather / FMAs / split /
+    // A' writes for the next step, the five DMAs), the other is in its Y phase (the step's 24 MFMAs back to back, raised priority); two barriers
+    // per step keep them there.  Row half 1 enters the loop one barrier late and row half 0 leaves it one barrier late.  Hazards: a weight stage
+    // and an A' image are only read in X (into registers), the stage refilled in X(s) -- step s + 2's, slot (s - 1) % 3 -- was last read in
+    // X(s - 1) by the lagging half, one barrier earlier; a wave's own DMAs of step s + 1 (issued in X(s - 1)) are waited for at the end of X(s),
+    // two barriers before the leading half reads them.
+    // MEASURED (`profiles/r06_pingpong_step_ab.jsonl`, same box, results bit-identical to the shipped step's): 384-390 us per hop against 371-377 -- 2-4 % SLOWER,
+    // whatever the Y phase's priority.  What the barrier costs is not that the waves run the same phase together but that a step then takes as long as its
+    // slowest wave, 128 times per hop (a sum of maxima, not a maximum of sums); two barriers per step pay that twice.  Kept as a build switch, off.
+#ifndef GVQA_HA_PP_PRIO
+#define GVQA_HA_PP_PRIO 3
+#endif
+#define GVQA_HA_STEP_PP(s_, OV_)                                                                                            \
+    {                                                                                                                       \
+        const int s = (s_);                                                                                                 \
+        const float4* xs = reinterpret_cast<const float4*>(smem + XR0 + ((s + 1) & (NXS - 1)) * 2048);                      \
+        float4 v0;                                                                                                          \
+        if ((OV_) == 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                               \
+        float4 xo0, xo1;                                                                                                    \
+        if ((OV_) == 1) {                                                                                                   \
+            xo0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] & 0xFFFFu));        \
+            xo1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] >> 16));            \
+        }                                                                                                                   \
+        if ((OV_) == 2) {                                                                                                   \
+            xo0 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] & 0xFFFFu));        \
+            xo1 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (so2[0] >> 16));            \
+            if (ovn > 2) {                                                                                                  \
+                _Pragma("unroll") for (int e = 2; e < HA_NOV; ++e)                                                          \
+                    if (e < ovn) {                                                                                          \
+                        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + ((so2[e >> 1] >> (16 * (e & 1))) & 0xFFFFu)); \
+                        GVQA_HA_FMA4(v0, al_o[e], x);                                                                       \
+                    }                                                                                                       \
+            }                                                                                                               \
+        }                                                                                                                   \
+        if ((OV_) == 2 && ovtrips > 0) {                                                                                    \
+            for (int e = 0; e < ovtrips; ++e) {                                                                             \
+                const int k = HA_DMAX + HA_NOV + e;                                                                         \
+                const int idx = max(min(plo + k, plo + pdeg - 1), 0);                                                       \
+                const int sr = min(max(src_l[idx] - ns, 0), HA_ROWS - 1);                                                   \
+                const float w = al_l[idx * H + ph];                                                                         \
+                const float av = k < pdeg ? w : 0.f;                                                                        \
+                const float4 x = xs[sr];                                                                                    \
+                GVQA_HA_FMA4(v0, av, x);                                                                                    \
+            }                                                                                                               \
+        }                                                                                                                   \
+        /* ---- X: the step's fragments, the next step's A', the DMAs ---- */                                               \
+        const unsigned char* sa = smem + HA_A0 + (s & 1) * 8192 + a_off;                                                    \
+        const unsigned char* sb = smem + HA_B0 + bcur_off + b_off;                                                          \
+        float4 xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep & 0xFFFFu));         \
+        _Pragma("unroll") for (int i = 0; i < RT; ++i) { afl[i] = rd(sa + i * 2048 + 1024); afh[i] = rd(sa + i * 2048); }   \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) { bh0[j] = rd(sb + j * 2048); bl[j] = rd(sb + j * 2048 + 1024); }     \
+        if (!GVQA_HA_DBG(2)) { loop_issue_b(0); if (NBU > 1) loop_issue_b(1); }                                             \
+        if (!GVQA_HA_DBG(1)) { if ((OV_) == 2) GVQA_HA_QFMA(v0, al[0], xr, 0); else GVQA_HA_QMUL(v0, al[0], xr, 0);           \
+                               GVQA_HA_QFMA(v0, al[1], xr, 1); GVQA_HA_QFMA(v0, al[2], xr, 2); GVQA_HA_QFMA(v0, al[3], xr, 3); \
+                               if (OV_) { GVQA_HA_FMA4(v0, al_o[0], xo0); GVQA_HA_FMA4(v0, al_o[1], xo1); } }                 \
+        else if ((OV_) != 2) v0 = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+        loop_issue_x(s + PD + 1);                                                                                           \
+        xr = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(xs) + (sep >> 16));                    \
+        if (!GVQA_HA_DBG(1)) {                                                                                              \
+            GVQA_HA_QFMA(v0, al[4], xr, 0); GVQA_HA_QFMA(v0, al[5], xr, 1); GVQA_HA_QFMA(v0, al[6], xr, 2); GVQA_HA_QFMA(v0, al[7], xr, 3); \
+            const float psc = s + 1 < NQ ? pscale : 0.f;                                                                    \
+            uint2 hi, lo;                                                                                                   \
+            GVQA_HA_SPLIT2(hi.x, lo.x, psc, v0.x, v0.y); GVQA_HA_SPLIT2(hi.y, lo.y, psc, v0.z, v0.w);                       \
+            unsigned char* dst = smem + HA_A0 + ((s + 1) & 1) * 8192 + a_wr_off;                                            \
+            *reinterpret_cast<uint2*>(dst) = hi;                                                                            \
+            *reinterpret_cast<uint2*>(dst + 1024) = lo;                                                                     \
+        }                                                                                                                   \
+        loop_advance();                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);            /* (the MFMAs below only read registers: nothing else keeps them behind the barrier) */ \
+        if (NTP >= 16 || b_second) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        /* ---- Y: the step's products, nothing else ---- */                                                                \
+        if (GVQA_HA_PP_PRIO) __builtin_amdgcn_s_setprio(GVQA_HA_PP_PRIO);                                                   \
+        GVQA_HA_MFR(0, NM, afl, bh0);                                                                                       \
+        GVQA_HA_MFR(0, NM, afh, bl);                                                                                        \
+        GVQA_HA_MFR(0, NM, afh, bh0);                                                                                       \
+        if (GVQA_HA_PP_PRIO) __builtin_amdgcn_s_setprio(0);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
     }
     // (an odd number of steps runs one more with an all-zero A operand -- the producer's scale is 0 past the last chunk, the weight
     //  DMA re-loads the last step's tiles -- so that the two-step body needs no tail variant)
@@ -883,6 +974,22 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
 #ifndef GVQA_HA_OV_ALWAYS
 #define GVQA_HA_OV_ALWAYS 0                           // (A/B build switch: 1 = every wave takes the overflow-capable body, as in round 4)
 #endif
+#ifndef GVQA_HA_PP
+#define GVQA_HA_PP 0                                  // 1: the ping-pong form of the step (one workgroup per row group only)
+#endif
+    constexpr bool PP = GVQA_HA_PP != 0 && CP == 1;
+    if constexpr (PP) {
+        const int NQe = (NQ + 1) & ~1;
+        if (wave >= 4) __builtin_amdgcn_s_barrier();                      // row half 1 runs half a step behind row half 0
+        if (GVQA_HA_OV_ALWAYS || ovn > 2 || ovtrips > 0) {
+            for (int sq = 0; sq < NQe; ++sq) GVQA_HA_STEP_PP(sq, 2)
+        } else if (ovn > 0) {
+            for (int sq = 0; sq < NQe; ++sq) GVQA_HA_STEP_PP(sq, 1)
+        } else {
+            for (int sq = 0; sq < NQe; ++sq) GVQA_HA_STEP_PP(sq, 0)
+        }
+        if (wave < 4) __builtin_amdgcn_s_barrier();
+    } else {
     if (GVQA_HA_OV_ALWAYS || ovn > 2 || ovtrips > 0) {                    // (wave-uniform; all three bodies meet the same barriers)
         for (int sq = 0; sq < NQ; sq += 2) {
             GVQA_HA_STEP(sq, bh1, bh0, 2)
@@ -900,6 +1007,7 @@ __global__ __launch_bounds__(512, 2) void k_hopagg4(HopAggArgs a, HopAggSeq hs) 
         }
     }
     GVQA_HA_MFR(0, NM, afh, bh1);                    // the last step's (a hi, b hi)
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (the clamped re-loads of the last steps)
     GVQA_HA_STAMP(hop, 2);                            // main loop done
 #ifdef GVQA_PROBES
